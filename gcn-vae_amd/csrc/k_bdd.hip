@@ -1,0 +1,540 @@
+// K1: R-GCN block-diagonal relational aggregation for gfx950 (forward, backward-x, backward-W).
+//
+// One 64-lane wavefront per work item (= one destination row, or one <=chunk-edge slice of a hub
+// row).  Lanes split the feature row: lane l owns BPL consecutive diagonal blocks, i.e. BPL*P
+// gathered floats (one or two 16-B loads: a 64-lane row read is a coalesced 1 KiB burst), the
+// matching BPL*P*Q block weights of the edge's relation and BPL*Q accumulators kept in registers
+// across the whole row -> exactly one store per output row, no atomics.  Edge metadata (neighbour,
+// relation, coefficient) is read 64 edges at a time, one edge per lane, and broadcast with
+// v_readlane so every gather address is scalar-base + lane-offset.  U edges are kept in flight
+// per wave to cover L2 / Infinity-Cache latency (the feature table and the relation weights of
+// FB15k-237 are cache resident; the kernel is bound by cache bandwidth, not FLOPs: ~1 flop/byte).
+#include "common.h"
+
+namespace gv {
+
+struct AggParams {
+    const int4* items;
+    int n_items;
+    const int* nbr;
+    const int* etype;
+    const float* coef;
+    const int* coef_idx;
+    const float* feat;
+    int ld_feat;
+    const float* w;
+    int w_row;  // floats per relation row = nb * P * Q
+    const float* addend;
+    int ld_add;
+    int act;
+    const uint8_t* keep;
+    float keep_scale;
+    float* out;
+    int ld_out;
+    float* partial;
+    int out_dim;
+    int nb;
+    int p, q;  // runtime block sizes (generic kernel)
+};
+
+__device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float rl_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+template <int P, int Q, bool TRANS, int BPL>
+__device__ __forceinline__ void block_fma(const float (&x)[BPL * P], const float (&w)[BPL * P * Q], float c,
+                                          float (&acc)[BPL * Q]) {
+#pragma unroll
+    for (int b = 0; b < BPL; ++b) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            float t = 0.f;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const float wv = TRANS ? w[b * P * Q + q * P + p] : w[b * P * Q + p * Q + q];
+                t = fmaf(x[b * P + p], wv, t);
+            }
+            acc[b * Q + q] = fmaf(t, c, acc[b * Q + q]);
+        }
+    }
+}
+
+template <int P, int Q, bool TRANS, int BPL, int U>
+__global__ __launch_bounds__(256) void k_agg_fast(const AggParams a) {
+    constexpr int GV = BPL * P, PV = BPL * Q, WV = BPL * P * Q;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (wave >= a.n_items) return;
+    const int4 it = a.items[wave];
+    const bool active = lane * BPL < a.nb;
+    const float* __restrict__ fbase = a.feat + lane * GV;
+    const float* __restrict__ wbase = a.w + lane * WV;
+
+    float acc[PV];
+#pragma unroll
+    for (int i = 0; i < PV; ++i) acc[i] = 0.f;
+
+    for (int e0 = it.y; e0 < it.z; e0 += 64) {
+        const int cnt = min(64, it.z - e0);
+        int my_n = 0, my_t = 0;
+        float my_c = 1.f;
+        if (lane < cnt) {
+            my_n = a.nbr[e0 + lane];
+            my_t = a.etype[e0 + lane];
+            if (a.coef) my_c = a.coef_idx ? a.coef[a.coef_idx[e0 + lane]] : a.coef[e0 + lane];
+        }
+        int j = 0;
+        for (; j + U <= cnt; j += U) {
+            float xv[U][GV], wv[U][WV], cc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s = rl_i(my_n, j + u);
+                const int r = rl_i(my_t, j + u);
+                cc[u] = rl_f(my_c, j + u);
+                if (active) {
+                    load_vec<GV>(fbase + (size_t)s * a.ld_feat, xv[u]);
+                    load_vec<WV>(wbase + (size_t)r * a.w_row, wv[u]);
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) block_fma<P, Q, TRANS, BPL>(xv[u], wv[u], cc[u], acc);
+            }
+        }
+        for (; j < cnt; ++j) {
+            float xv[GV], wv[WV];
+            const int s = rl_i(my_n, j);
+            const int r = rl_i(my_t, j);
+            const float c = rl_f(my_c, j);
+            if (active) {
+                load_vec<GV>(fbase + (size_t)s * a.ld_feat, xv);
+                load_vec<WV>(wbase + (size_t)r * a.w_row, wv);
+                block_fma<P, Q, TRANS, BPL>(xv, wv, c, acc);
+            }
+        }
+    }
+    if (!active) return;
+    if (it.w >= 0) {
+        store_vec<PV>(a.partial + (size_t)it.w * a.out_dim + lane * PV, acc);
+        return;
+    }
+    if (a.addend) {
+        float ad[PV];
+        load_vec<PV>(a.addend + (size_t)it.x * a.ld_add + lane * PV, ad);
+#pragma unroll
+        for (int i = 0; i < PV; ++i) acc[i] += ad[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PV; ++i) acc[i] = apply_act(acc[i], a.act);
+    if (a.keep) {
+        const uint8_t* kp = a.keep + (size_t)it.x * a.out_dim + lane * PV;
+#pragma unroll
+        for (int i = 0; i < PV; ++i) acc[i] = kp[i] ? acc[i] * a.keep_scale : 0.f;
+    }
+    store_vec<PV>(a.out + (size_t)it.x * a.ld_out + lane * PV, acc);
+}
+
+// Any (P, Q): lane <-> output column, 64 columns per sweep over the item's edges.
+template <bool TRANS>
+__global__ __launch_bounds__(256) void k_agg_generic(const AggParams a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (wave >= a.n_items) return;
+    const int4 it = a.items[wave];
+    const int P = a.p, Q = a.q;
+    for (int c0 = 0; c0 < a.out_dim; c0 += 64) {
+        const int c = c0 + lane;
+        const bool active = c < a.out_dim;
+        const int b = active ? c / Q : 0;
+        const int q = active ? c - b * Q : 0;
+        float acc = 0.f;
+        for (int e0 = it.y; e0 < it.z; e0 += 64) {
+            const int cnt = min(64, it.z - e0);
+            int my_n = 0, my_t = 0;
+            float my_c = 1.f;
+            if (lane < cnt) {
+                my_n = a.nbr[e0 + lane];
+                my_t = a.etype[e0 + lane];
+                if (a.coef) my_c = a.coef_idx ? a.coef[a.coef_idx[e0 + lane]] : a.coef[e0 + lane];
+            }
+            for (int j = 0; j < cnt; ++j) {
+                const int s = rl_i(my_n, j);
+                const int r = rl_i(my_t, j);
+                const float cf = rl_f(my_c, j);
+                if (active) {
+                    const float* xr = a.feat + (size_t)s * a.ld_feat + b * P;
+                    const float* wr = a.w + (size_t)r * a.w_row + b * P * Q;
+                    float t = 0.f;
+                    for (int p = 0; p < P; ++p) t = fmaf(xr[p], TRANS ? wr[q * P + p] : wr[p * Q + q], t);
+                    acc = fmaf(t, cf, acc);
+                }
+            }
+        }
+        if (!active) continue;
+        if (it.w >= 0) {
+            a.partial[(size_t)it.w * a.out_dim + c] = acc;
+        } else {
+            if (a.addend) acc += a.addend[(size_t)it.x * a.ld_add + c];
+            acc = apply_act(acc, a.act);
+            if (a.keep) acc = a.keep[(size_t)it.x * a.out_dim + c] ? acc * a.keep_scale : 0.f;
+            a.out[(size_t)it.x * a.ld_out + c] = acc;
+        }
+    }
+}
+
+// Sum the partial rows of split segments in slot order and apply the epilogue.
+__global__ __launch_bounds__(256) void k_agg_fixup(const int4* fix, int n_fix, const float* partial, int out_dim,
+                                                   const float* addend, int ld_add, int act, const uint8_t* keep,
+                                                   float keep_scale, float* out, int ld_out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (wave >= n_fix) return;
+    const int4 f = fix[wave];
+    for (int c = lane; c < out_dim; c += 64) {
+        float acc = 0.f;
+        for (int k = 0; k < f.z; ++k) acc += partial[(size_t)(f.y + k) * out_dim + c];
+        if (addend) acc += addend[(size_t)f.x * ld_add + c];
+        acc = apply_act(acc, act);
+        if (keep) acc = keep[(size_t)f.x * out_dim + c] ? acc * keep_scale : 0.f;
+        out[(size_t)f.x * ld_out + c] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// grad_W: one wave per (relation, <=chunk-edge slice); lane keeps its BPL blocks' PxQ outer-product
+// sums in registers over the slice.
+struct GradWParams {
+    const int4* items;
+    int n_items;
+    const int* src;
+    const int* dst;
+    const float* coef;
+    const int* coef_idx;
+    const float* x;
+    int ld_x;
+    const float* g;
+    int ld_g;
+    float* grad_w;
+    int w_row;
+    float* partial;
+    int accumulate;
+    int nb;
+    int p, q;
+};
+
+template <int P, int Q, int BPL, int U>
+__global__ __launch_bounds__(256) void k_gradw_fast(const GradWParams a) {
+    constexpr int GV = BPL * P, PV = BPL * Q, WV = BPL * P * Q;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (wave >= a.n_items) return;
+    const int4 it = a.items[wave];
+    const bool active = lane * BPL < a.nb;
+    const float* __restrict__ xbase = a.x + lane * GV;
+    const float* __restrict__ gbase = a.g + lane * PV;
+    float acc[WV];
+#pragma unroll
+    for (int i = 0; i < WV; ++i) acc[i] = 0.f;
+    for (int e0 = it.y; e0 < it.z; e0 += 64) {
+        const int cnt = min(64, it.z - e0);
+        int my_s = 0, my_d = 0;
+        float my_c = 1.f;
+        if (lane < cnt) {
+            my_s = a.src[e0 + lane];
+            my_d = a.dst[e0 + lane];
+            if (a.coef) my_c = a.coef_idx ? a.coef[a.coef_idx[e0 + lane]] : a.coef[e0 + lane];
+        }
+        int j = 0;
+        for (; j + U <= cnt; j += U) {
+            float xv[U][GV], gvv[U][PV], cc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s = rl_i(my_s, j + u);
+                const int d = rl_i(my_d, j + u);
+                cc[u] = rl_f(my_c, j + u);
+                if (active) {
+                    load_vec<GV>(xbase + (size_t)s * a.ld_x, xv[u]);
+                    load_vec<PV>(gbase + (size_t)d * a.ld_g, gvv[u]);
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int b = 0; b < BPL; ++b)
+#pragma unroll
+                        for (int p = 0; p < P; ++p) {
+                            const float xc = xv[u][b * P + p] * cc[u];
+#pragma unroll
+                            for (int q = 0; q < Q; ++q)
+                                acc[b * P * Q + p * Q + q] = fmaf(xc, gvv[u][b * Q + q], acc[b * P * Q + p * Q + q]);
+                        }
+            }
+        }
+        for (; j < cnt; ++j) {
+            float xv[GV], gvv[PV];
+            const int s = rl_i(my_s, j);
+            const int d = rl_i(my_d, j);
+            const float c = rl_f(my_c, j);
+            if (active) {
+                load_vec<GV>(xbase + (size_t)s * a.ld_x, xv);
+                load_vec<PV>(gbase + (size_t)d * a.ld_g, gvv);
+#pragma unroll
+                for (int b = 0; b < BPL; ++b)
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const float xc = xv[b * P + p] * c;
+#pragma unroll
+                        for (int q = 0; q < Q; ++q)
+                            acc[b * P * Q + p * Q + q] = fmaf(xc, gvv[b * Q + q], acc[b * P * Q + p * Q + q]);
+                    }
+            }
+        }
+    }
+    if (!active) return;
+    if (it.w >= 0) {
+        store_vec<WV>(a.partial + (size_t)it.w * a.w_row + lane * WV, acc);
+    } else {
+        float* o = a.grad_w + (size_t)it.x * a.w_row + lane * WV;
+        if (a.accumulate) {
+            float old[WV];
+            load_vec<WV>(o, old);
+#pragma unroll
+            for (int i = 0; i < WV; ++i) acc[i] += old[i];
+        }
+        store_vec<WV>(o, acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gradw_generic(const GradWParams a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (wave >= a.n_items) return;
+    const int4 it = a.items[wave];
+    const int P = a.p, Q = a.q;
+    for (int c0 = 0; c0 < a.w_row; c0 += 64) {
+        const int c = c0 + lane;
+        const bool active = c < a.w_row;
+        const int b = active ? c / (P * Q) : 0;
+        const int rem = c - b * P * Q;
+        const int p = rem / Q, q = rem - p * Q;
+        float acc = 0.f;
+        for (int e0 = it.y; e0 < it.z; e0 += 64) {
+            const int cnt = min(64, it.z - e0);
+            int my_s = 0, my_d = 0;
+            float my_c = 1.f;
+            if (lane < cnt) {
+                my_s = a.src[e0 + lane];
+                my_d = a.dst[e0 + lane];
+                if (a.coef) my_c = a.coef_idx ? a.coef[a.coef_idx[e0 + lane]] : a.coef[e0 + lane];
+            }
+            for (int j = 0; j < cnt; ++j) {
+                const int s = rl_i(my_s, j);
+                const int d = rl_i(my_d, j);
+                const float cf = rl_f(my_c, j);
+                if (active)
+                    acc = fmaf(a.x[(size_t)s * a.ld_x + b * P + p] * cf, a.g[(size_t)d * a.ld_g + b * Q + q], acc);
+            }
+        }
+        if (!active) continue;
+        if (it.w >= 0) {
+            a.partial[(size_t)it.w * a.w_row + c] = acc;
+        } else {
+            float* o = a.grad_w + (size_t)it.x * a.w_row + c;
+            *o = a.accumulate ? *o + acc : acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gradw_fixup(const int4* fix, int n_fix, const float* partial, int w_row,
+                                                     float* grad_w, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (wave >= n_fix) return;
+    const int4 f = fix[wave];
+    for (int c = lane; c < w_row; c += 64) {
+        float acc = 0.f;
+        for (int k = 0; k < f.z; ++k) acc += partial[(size_t)(f.y + k) * w_row + c];
+        float* o = grad_w + (size_t)f.x * w_row + c;
+        *o = accumulate ? *o + acc : acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void k_items_count(const int* rowptr, int n_seg, int chunk, int* n_chunks, int* n_slots, int* is_split) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    const int deg = rowptr[s + 1] - rowptr[s];
+    const int nch = max(1, (deg + chunk - 1) / chunk);
+    n_chunks[s] = nch;
+    n_slots[s] = nch > 1 ? nch : 0;
+    is_split[s] = nch > 1 ? 1 : 0;
+}
+
+__global__ void k_items_fill(const int* rowptr, int n_seg, int chunk, const int* item_off, const int* slot_off,
+                             const int* fix_off, int4* items, int4* fix) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    const int beg = rowptr[s], end = rowptr[s + 1];
+    const int nch = max(1, (end - beg + chunk - 1) / chunk);
+    const int ib = item_off[s];
+    for (int k = 0; k < nch; ++k) {
+        const int b = beg + k * chunk;
+        items[ib + k] = make_int4(s, b, min(end, b + chunk), nch > 1 ? slot_off[s] + k : -1);
+    }
+    if (nch > 1) fix[fix_off[s]] = make_int4(s, slot_off[s], nch, 0);
+}
+
+template <typename K, typename Pm>
+static int launch_items(K kern, const Pm& p, int n_items, hipStream_t st, const char* what) {
+    if (n_items <= 0) return GV_OK;
+    const int waves_per_block = 4;
+    dim3 grid((n_items + waves_per_block - 1) / waves_per_block), block(64 * waves_per_block);
+    hipLaunchKernelGGL(kern, grid, block, 0, st, p);
+    return launch_status(what);
+}
+
+}  // namespace gv
+
+using namespace gv;
+
+extern "C" int gv_segment_items_count(const int32_t* rowptr, int n_seg, int chunk, int32_t* n_chunks,
+                                      int32_t* n_slots, int32_t* is_split, void* stream) {
+    GV_REQUIRE(rowptr && n_chunks && n_slots && is_split, GV_ERR_NULL, "gv_segment_items_count: NULL pointer");
+    GV_REQUIRE(n_seg >= 0 && chunk > 0, GV_ERR_SHAPE, "gv_segment_items_count: n_seg=%d chunk=%d", n_seg, chunk);
+    if (n_seg == 0) return GV_OK;
+    hipLaunchKernelGGL(k_items_count, dim3((n_seg + 255) / 256), dim3(256), 0, (hipStream_t)stream, rowptr, n_seg,
+                       chunk, n_chunks, n_slots, is_split);
+    return launch_status("gv_segment_items_count");
+}
+
+extern "C" int gv_segment_items_fill(const int32_t* rowptr, int n_seg, int chunk, const int32_t* item_off,
+                                     const int32_t* slot_off, const int32_t* fix_off, int32_t* items, int32_t* fix,
+                                     void* stream) {
+    GV_REQUIRE(rowptr && item_off && slot_off && fix_off && items, GV_ERR_NULL, "gv_segment_items_fill: NULL pointer");
+    GV_REQUIRE(n_seg >= 0 && chunk > 0, GV_ERR_SHAPE, "gv_segment_items_fill: n_seg=%d chunk=%d", n_seg, chunk);
+    if (n_seg == 0) return GV_OK;
+    hipLaunchKernelGGL(k_items_fill, dim3((n_seg + 255) / 256), dim3(256), 0, (hipStream_t)stream, rowptr, n_seg,
+                       chunk, item_off, slot_off, fix_off, (int4*)items, (int4*)fix);
+    return launch_status("gv_segment_items_fill");
+}
+
+namespace {
+// Blocks per lane: aim for a 16-B gather per lane (BPL*P == 4), then 32 B, then narrower, under the
+// constraints that lanes own whole blocks and one 64-lane wave covers the row.  0 => generic kernel.
+int pick_bpl(int nb, int p) {
+    for (int target : {4, 8, 2, 1}) {
+        if (target % p != 0) continue;
+        const int bpl = target / p;
+        if ((bpl == 1 || bpl == 2 || bpl == 4) && nb % bpl == 0 && nb / bpl <= 64) return bpl;
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const int32_t* fix, int n_fix,
+                                     const int32_t* nbr, const int32_t* etype, const float* coef,
+                                     const int32_t* coef_idx, const float* feat, int ld_feat, const float* weight,
+                                     int num_rels, int num_bases, int blk_in, int blk_out, int transpose_w,
+                                     const float* addend, int ld_addend, int act, const uint8_t* keep,
+                                     float keep_scale, float* out, int ld_out, float* partial, void* stream) {
+    GV_REQUIRE(n_items >= 0 && n_fix >= 0, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate: negative item count");
+    if (n_items == 0) return GV_OK;
+    GV_REQUIRE(items && nbr && etype && feat && weight && out, GV_ERR_NULL, "gv_rgcn_bdd_aggregate: NULL pointer");
+    GV_REQUIRE(num_bases > 0 && blk_in > 0 && blk_out > 0 && num_rels > 0, GV_ERR_SHAPE,
+               "gv_rgcn_bdd_aggregate: num_bases=%d blk_in=%d blk_out=%d num_rels=%d", num_bases, blk_in, blk_out,
+               num_rels);
+    GV_REQUIRE(n_fix == 0 || (fix && partial), GV_ERR_NULL, "gv_rgcn_bdd_aggregate: split segments need fix+partial");
+    GV_REQUIRE(ld_feat >= num_bases * blk_in && ld_out >= num_bases * blk_out, GV_ERR_SHAPE,
+               "gv_rgcn_bdd_aggregate: leading dimension smaller than the row");
+    GV_REQUIRE(act == GV_ACT_NONE || act == GV_ACT_RELU, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate: unknown act %d", act);
+    AggParams a;
+    a.items = (const int4*)items; a.n_items = n_items; a.nbr = nbr; a.etype = etype; a.coef = coef;
+    a.coef_idx = coef_idx; a.feat = feat; a.ld_feat = ld_feat; a.w = weight;
+    a.w_row = num_bases * blk_in * blk_out; a.addend = addend; a.ld_add = ld_addend; a.act = act; a.keep = keep;
+    a.keep_scale = keep_scale; a.out = out; a.ld_out = ld_out; a.partial = partial;
+    a.out_dim = num_bases * blk_out; a.nb = num_bases; a.p = blk_in; a.q = blk_out;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec_ok = aligned16(feat) && aligned16(weight) && aligned16(out) && (ld_feat % 4 == 0) &&
+                        (ld_out % 4 == 0) && (!addend || (aligned16(addend) && ld_addend % 4 == 0)) &&
+                        (!partial || aligned16(partial)) && (a.out_dim % 4 == 0) && (a.w_row % 4 == 0);
+    const int bpl = pick_bpl(num_bases, blk_in);
+    int rc = -1000;
+#define GV_AGG_CASE(P_, Q_, T_, B_, U_)                                                               \
+    if (rc == -1000 && vec_ok && blk_in == P_ && blk_out == Q_ && (transpose_w != 0) == T_ && bpl == B_) \
+        rc = launch_items(k_agg_fast<P_, Q_, T_, B_, U_>, a, n_items, st, "gv_rgcn_bdd_aggregate");
+    GV_AGG_CASE(1, 1, false, 4, 8)
+    GV_AGG_CASE(1, 2, false, 4, 4)
+    GV_AGG_CASE(2, 2, false, 2, 8)
+    GV_AGG_CASE(2, 4, false, 2, 4)
+    GV_AGG_CASE(4, 4, false, 1, 4)
+    GV_AGG_CASE(4, 4, false, 2, 2)
+    GV_AGG_CASE(4, 8, false, 1, 2)
+    GV_AGG_CASE(4, 8, false, 2, 2)
+    GV_AGG_CASE(1, 1, true, 4, 8)
+    GV_AGG_CASE(2, 1, true, 2, 8)
+    GV_AGG_CASE(2, 2, true, 2, 8)
+    GV_AGG_CASE(4, 2, true, 1, 8)
+    GV_AGG_CASE(4, 2, true, 2, 4)
+    GV_AGG_CASE(4, 4, true, 1, 4)
+    GV_AGG_CASE(4, 4, true, 2, 2)
+    GV_AGG_CASE(8, 4, true, 1, 2)
+#undef GV_AGG_CASE
+    if (rc == -1000) {
+        if (transpose_w)
+            rc = launch_items(k_agg_generic<true>, a, n_items, st, "gv_rgcn_bdd_aggregate(generic)");
+        else
+            rc = launch_items(k_agg_generic<false>, a, n_items, st, "gv_rgcn_bdd_aggregate(generic)");
+    }
+    if (rc != GV_OK) return rc;
+    if (n_fix > 0) {
+        hipLaunchKernelGGL(k_agg_fixup, dim3((n_fix + 3) / 4), dim3(256), 0, st, (const int4*)fix, n_fix, partial,
+                           a.out_dim, addend, ld_addend, act, keep, keep_scale, out, ld_out);
+        return launch_status("gv_rgcn_bdd_aggregate(fixup)");
+    }
+    return GV_OK;
+}
+
+extern "C" int gv_rgcn_bdd_grad_weight(const int32_t* items, int n_items, const int32_t* fix, int n_fix,
+                                       const int32_t* src, const int32_t* dst, const float* coef,
+                                       const int32_t* coef_idx, const float* x, int ld_x, const float* g, int ld_g,
+                                       int num_bases, int blk_in, int blk_out, float* grad_w, float* partial,
+                                       int accumulate, void* stream) {
+    GV_REQUIRE(n_items >= 0 && n_fix >= 0, GV_ERR_SHAPE, "gv_rgcn_bdd_grad_weight: negative item count");
+    if (n_items == 0) return GV_OK;
+    GV_REQUIRE(items && src && dst && x && g && grad_w, GV_ERR_NULL, "gv_rgcn_bdd_grad_weight: NULL pointer");
+    GV_REQUIRE(num_bases > 0 && blk_in > 0 && blk_out > 0, GV_ERR_SHAPE, "gv_rgcn_bdd_grad_weight: bad block sizes");
+    GV_REQUIRE(n_fix == 0 || (fix && partial), GV_ERR_NULL, "gv_rgcn_bdd_grad_weight: split segments need fix+partial");
+    GV_REQUIRE(ld_x >= num_bases * blk_in && ld_g >= num_bases * blk_out, GV_ERR_SHAPE,
+               "gv_rgcn_bdd_grad_weight: leading dimension smaller than the row");
+    GradWParams a;
+    a.items = (const int4*)items; a.n_items = n_items; a.src = src; a.dst = dst; a.coef = coef; a.coef_idx = coef_idx;
+    a.x = x; a.ld_x = ld_x; a.g = g; a.ld_g = ld_g; a.grad_w = grad_w; a.w_row = num_bases * blk_in * blk_out;
+    a.partial = partial; a.accumulate = accumulate; a.nb = num_bases; a.p = blk_in; a.q = blk_out;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec_ok = aligned16(x) && aligned16(g) && aligned16(grad_w) && (ld_x % 4 == 0) && (ld_g % 4 == 0) &&
+                        (!partial || aligned16(partial)) && (a.w_row % 4 == 0);
+    const int bpl = pick_bpl(num_bases, blk_in);
+    int rc = -1000;
+#define GV_GW_CASE(P_, Q_, B_, U_)                                                  \
+    if (rc == -1000 && vec_ok && blk_in == P_ && blk_out == Q_ && bpl == B_)        \
+        rc = launch_items(k_gradw_fast<P_, Q_, B_, U_>, a, n_items, st, "gv_rgcn_bdd_grad_weight");
+    GV_GW_CASE(1, 1, 4, 8)
+    GV_GW_CASE(1, 2, 4, 4)
+    GV_GW_CASE(2, 2, 2, 8)
+    GV_GW_CASE(2, 4, 2, 4)
+    GV_GW_CASE(4, 4, 1, 4)
+    GV_GW_CASE(4, 4, 2, 2)
+    GV_GW_CASE(4, 8, 1, 2)
+    GV_GW_CASE(4, 8, 2, 2)
+#undef GV_GW_CASE
+    if (rc == -1000) rc = launch_items(k_gradw_generic, a, n_items, st, "gv_rgcn_bdd_grad_weight(generic)");
+    if (rc != GV_OK) return rc;
+    if (n_fix > 0) {
+        hipLaunchKernelGGL(k_gradw_fixup, dim3((n_fix + 3) / 4), dim3(256), 0, st, (const int4*)fix, n_fix, partial,
+                           a.w_row, grad_w, accumulate);
+        return launch_status("gv_rgcn_bdd_grad_weight(fixup)");
+    }
+    return GV_OK;
+}

@@ -1,0 +1,280 @@
+// K2/K4: dense fp32 GEMM on the gfx950 f32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+//   C[M,N] = act( op(A)[M,K] @ op(B)[K,N] + bias[N] ) (+ C)
+//
+// The MFMA result is bit-for-bit a k-ordered fp32 fma chain (no reduced-precision path exists on
+// gfx950), so parity with the CPU reference is at fp32 rounding.  Block tile 128x64x16, four waves
+// in a 2x2 grid, each wave owns a 64x32 patch = two 32x32 accumulators.  Operands are staged
+// through LDS k-major (As[k][m], Bs[k][n], +1 padding) so that the MFMA operand read -- lane l
+// needs A[m = l&31][k = l>>5] and B[k = l>>5][n = l&31] -- is a conflict-free ds_read_b32 for both
+// 32-lane halves.  Global loads of tile t+1 are issued before the MFMAs of tile t (register
+// staging); the shapes on this path are skinny (K = N = 200..400, M = nodes), so the kernel is
+// sized for many small blocks rather than for a 256^2 pipeline.
+// split-K (grid.z) writes raw partial tiles to a workspace that a second kernel sums in order.
+#include "common.h"
+
+namespace gv {
+
+constexpr int BM = 128, BN = 64, BK = 16;
+constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmParams {
+    const float* a;
+    const float* b;
+    float* c;
+    const float* bias;
+    float* ws;
+    int m, n, k, lda, ldb, ldc;
+    int act, accumulate, split_k, k_chunk;
+    int vec_a, vec_b;
+};
+
+// ---- global -> registers (8 floats of A, 4 floats of B per thread), zero-filled outside the matrix
+template <bool TA>
+__device__ __forceinline__ void load_a(const GemmParams& p, int m0, int k0, int kend, float (&r)[8]) {
+    const int t = threadIdx.x;
+    if constexpr (!TA) {  // A is [M, K], K contiguous: thread -> row t/2, 8 consecutive k
+        const int m = m0 + (t >> 1), kk = k0 + (t & 1) * 8;
+        const float* src = p.a + (size_t)m * p.lda + kk;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kq = kk + 4 * h;
+            if (m < p.m && p.vec_a && kq + 3 < kend) {
+                const float4 v = *reinterpret_cast<const float4*>(src + 4 * h);
+                r[4 * h] = v.x; r[4 * h + 1] = v.y; r[4 * h + 2] = v.z; r[4 * h + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[4 * h + i] = (m < p.m && kq + i < kend) ? src[4 * h + i] : 0.f;
+            }
+        }
+    } else {  // A is stored [K, M], M contiguous: thread -> k t/16, 8 consecutive m
+        const int kq = k0 + (t >> 4), m = m0 + (t & 15) * 8;
+        const float* src = p.a + (size_t)kq * p.lda + m;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int mq = m + 4 * h;
+            if (kq < kend && p.vec_a && mq + 3 < p.m) {
+                const float4 v = *reinterpret_cast<const float4*>(src + 4 * h);
+                r[4 * h] = v.x; r[4 * h + 1] = v.y; r[4 * h + 2] = v.z; r[4 * h + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[4 * h + i] = (kq < kend && mq + i < p.m) ? src[4 * h + i] : 0.f;
+            }
+        }
+    }
+}
+
+template <bool TB>
+__device__ __forceinline__ void load_b(const GemmParams& p, int n0, int k0, int kend, float (&r)[4]) {
+    const int t = threadIdx.x;
+    if constexpr (!TB) {  // B is [K, N], N contiguous: thread -> k t/16, 4 consecutive n
+        const int kq = k0 + (t >> 4), n = n0 + (t & 15) * 4;
+        const float* src = p.b + (size_t)kq * p.ldb + n;
+        if (kq < kend && p.vec_b && n + 3 < p.n) {
+            const float4 v = *reinterpret_cast<const float4*>(src);
+            r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = (kq < kend && n + i < p.n) ? src[i] : 0.f;
+        }
+    } else {  // B is stored [N, K], K contiguous: thread -> n t/4, 4 consecutive k
+        const int n = n0 + (t >> 2), kq = k0 + (t & 3) * 4;
+        const float* src = p.b + (size_t)n * p.ldb + kq;
+        if (n < p.n && p.vec_b && kq + 3 < kend) {
+            const float4 v = *reinterpret_cast<const float4*>(src);
+            r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = (n < p.n && kq + i < kend) ? src[i] : 0.f;
+        }
+    }
+}
+
+template <bool TA>
+__device__ __forceinline__ void stage_a(float* As, const float (&r)[8]) {
+    const int t = threadIdx.x;
+    if constexpr (!TA) {
+        const int m = t >> 1, kk = (t & 1) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) As[(kk + i) * LDA_S + m] = r[i];
+    } else {
+        const int kq = t >> 4, m = (t & 15) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) As[kq * LDA_S + m + i] = r[i];
+    }
+}
+
+template <bool TB>
+__device__ __forceinline__ void stage_b(float* Bs, const float (&r)[4]) {
+    const int t = threadIdx.x;
+    if constexpr (!TB) {
+        const int kq = t >> 4, n = (t & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Bs[kq * LDB_S + n + i] = r[i];
+    } else {
+        const int n = t >> 2, kq = (t & 3) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Bs[(kq + i) * LDB_S + n] = r[i];
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_gemm_f32(const GemmParams p) {
+    __shared__ float As[BK * LDA_S];
+    __shared__ float Bs[BK * LDB_S];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * p.k_chunk;
+    const int kend = min(p.k, kbeg + p.k_chunk);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm = (wid >> 1) * 64, wn = (wid & 1) * 32;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    float ra[8], rb[4];
+    load_a<TA>(p, m0, kbeg, kend, ra);
+    load_b<TB>(p, n0, kbeg, kend, rb);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        stage_a<TA>(As, ra);
+        stage_b<TB>(Bs, rb);
+        __syncthreads();
+        if (k0 + BK < kend) {  // next tile's loads fly under this tile's MFMAs
+            load_a<TA>(p, m0, k0 + BK, kend, ra);
+            load_b<TB>(p, n0, k0 + BK, kend, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float b = Bs[(kk + lhi) * LDB_S + wn + l31];
+            const float a0 = As[(kk + lhi) * LDA_S + wm + l31];
+            const float a1 = As[(kk + lhi) * LDA_S + wm + 32 + l31];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int col = n0 + wn + l31;
+    if (col >= p.n) return;
+    const float bv = (p.bias && p.split_k == 1) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm + half * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (row >= p.m) continue;
+            float v = half ? acc1[r] : acc0[r];
+            if (p.split_k > 1) {
+                p.ws[((size_t)blockIdx.z * p.m + row) * p.n + col] = v;
+            } else {
+                v = apply_act(v + bv, p.act);
+                float* dst = p.c + (size_t)row * p.ldc + col;
+                *dst = p.accumulate ? *dst + v : v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_splitk_reduce(const GemmParams p) {
+    const size_t total = (size_t)p.m * p.n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int z = 0; z < p.split_k; ++z) v += p.ws[(size_t)z * total + i];
+        const int row = (int)(i / p.n), col = (int)(i - (size_t)row * p.n);
+        if (p.bias) v += p.bias[col];
+        v = apply_act(v, p.act);
+        float* dst = p.c + (size_t)row * p.ldc + col;
+        *dst = p.accumulate ? *dst + v : v;
+    }
+}
+
+// column sums: 64 row-slices, then an ordered 64-way sum
+__global__ __launch_bounds__(256) void k_colsum_part(const float* x, int64_t m, int n, int ld, float* part) {
+    const int slice = blockIdx.y, nsl = gridDim.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const int64_t per = (m + nsl - 1) / nsl;
+    const int64_t r0 = slice * per, r1 = min(m, r0 + per);
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; ++r) acc += x[r * ld + c];
+    part[(size_t)slice * n + c] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_colsum_final(const float* part, int n, int nsl, float* out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float acc = 0.f;
+    for (int s = 0; s < nsl; ++s) acc += part[(size_t)s * n + c];
+    out[c] = accumulate ? out[c] + acc : acc;
+}
+
+}  // namespace gv
+
+using namespace gv;
+
+static int k_chunk_for(int k, int split_k) {
+    int per = (k + split_k - 1) / split_k;
+    return ((per + BK - 1) / BK) * BK;
+}
+
+extern "C" int64_t gv_gemm_workspace_bytes(int m, int n, int k, int split_k) {
+    (void)k;
+    return split_k > 1 ? (int64_t)split_k * m * n * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b,
+                           int ldb, float* c, int ldc, const float* bias, int act, int accumulate, int split_k,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
+    GV_REQUIRE(m >= 0 && n >= 0 && k >= 0, GV_ERR_SHAPE, "gv_gemm_f32: negative size");
+    if (m == 0 || n == 0) return GV_OK;
+    GV_REQUIRE(a && b && c, GV_ERR_NULL, "gv_gemm_f32: NULL matrix");
+    GV_REQUIRE(lda >= (trans_a ? m : k) && ldb >= (trans_b ? k : n) && ldc >= n, GV_ERR_SHAPE,
+               "gv_gemm_f32: leading dimension too small (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
+    GV_REQUIRE(act == GV_ACT_NONE || act == GV_ACT_RELU, GV_ERR_SHAPE, "gv_gemm_f32: unknown act %d", act);
+    if (split_k < 1) split_k = 1;
+    if (k == 0) split_k = 1;
+    GemmParams p;
+    p.a = a; p.b = b; p.c = c; p.bias = bias; p.ws = (float*)workspace;
+    p.m = m; p.n = n; p.k = k; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.act = act; p.accumulate = accumulate;
+    p.k_chunk = k_chunk_for(k > 0 ? k : 1, split_k);
+    split_k = k > 0 ? (k + p.k_chunk - 1) / p.k_chunk : 1;
+    p.split_k = split_k;
+    p.vec_a = aligned16(a) && (lda % 4 == 0);
+    p.vec_b = aligned16(b) && (ldb % 4 == 0);
+    if (split_k > 1) {
+        GV_REQUIRE(workspace, GV_ERR_NULL, "gv_gemm_f32: split_k needs a workspace");
+        GV_REQUIRE(workspace_bytes >= gv_gemm_workspace_bytes(m, n, k, split_k), GV_ERR_WORKSPACE,
+                   "gv_gemm_f32: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                   (long long)gv_gemm_workspace_bytes(m, n, k, split_k));
+    }
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM, split_k), block(256);
+    if (!trans_a && !trans_b) hipLaunchKernelGGL((k_gemm_f32<false, false>), grid, block, 0, st, p);
+    else if (!trans_a && trans_b) hipLaunchKernelGGL((k_gemm_f32<false, true>), grid, block, 0, st, p);
+    else if (trans_a && !trans_b) hipLaunchKernelGGL((k_gemm_f32<true, false>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_f32<true, true>), grid, block, 0, st, p);
+    int rc = launch_status("gv_gemm_f32");
+    if (rc != GV_OK) return rc;
+    if (split_k > 1) {
+        const size_t total = (size_t)m * n;
+        const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+        hipLaunchKernelGGL(k_gemm_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);
+        return launch_status("gv_gemm_f32(split-k reduce)");
+    }
+    return GV_OK;
+}
+
+extern "C" int gv_colsum(const float* x, int64_t m, int n, int ld, float* out, float* workspace, int accumulate,
+                         void* stream) {
+    GV_REQUIRE(x && out && workspace, GV_ERR_NULL, "gv_colsum: NULL pointer");
+    GV_REQUIRE(m >= 0 && n > 0 && ld >= n, GV_ERR_SHAPE, "gv_colsum: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const int nsl = 64;
+    hipLaunchKernelGGL(k_colsum_part, dim3((n + 255) / 256, nsl), dim3(256), 0, st, x, m, n, ld, workspace);
+    hipLaunchKernelGGL(k_colsum_final, dim3((n + 255) / 256), dim3(256), 0, st, workspace, n, nsl, out, accumulate);
+    return launch_status("gv_colsum");
+}

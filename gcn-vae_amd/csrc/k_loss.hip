@@ -1,0 +1,318 @@
+// K5 DistMult + BCE-with-logits, K6 fused reductions (regulariser, KL to the mixture prior).
+// All scalar results are produced by an ordered two-pass reduction (per-block partials, then one
+// block sums them in index order) -> bitwise reproducible, no float atomics.
+#include "common.h"
+
+namespace gv {
+
+constexpr int RED_BLOCKS = 1024;  // partial slots of the two-pass scalar reductions
+
+__device__ __forceinline__ float block_sum_256(float v, float* sm /*[4]*/) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// out (+)= scale * sum(part[0..n))
+__global__ __launch_bounds__(256) void k_final_sum(const float* part, int n, float scale, float* out, int accumulate) {
+    __shared__ float sm[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+    const float tot = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) *out = accumulate ? *out + scale * tot : scale * tot;
+}
+
+// ---- DistMult: 16 lanes per triplet (4 triplets per wave); three 800-B row gathers per triplet
+__global__ __launch_bounds__(256) void k_distmult_bce(const float* e, int ld_e, const float* w, int ld_w,
+                                                      const int* trip, const float* labels, const float* bias,
+                                                      float* score, float* part, int64_t T, int h) {
+    __shared__ float sm[4];
+    const int sub = threadIdx.x & 15;
+    const float bv = bias ? *bias : 0.f;
+    const bool vec = (h % 4 == 0) && (ld_e % 4 == 0) && (ld_w % 4 == 0);
+    float lsum = 0.f;
+    // 16 triplets per block iteration; every lane runs the same trip count (shuffles below)
+    for (int64_t t0 = (int64_t)blockIdx.x * 16; t0 < T; t0 += (int64_t)gridDim.x * 16) {
+        const int64_t t = t0 + (threadIdx.x >> 4);
+        float acc = 0.f;
+        if (t < T) {
+            const int s = trip[3 * t], r = trip[3 * t + 1], o = trip[3 * t + 2];
+            const float* es = e + (size_t)s * ld_e;
+            const float* eo = e + (size_t)o * ld_e;
+            const float* wr = w + (size_t)r * ld_w;
+            if (vec) {
+                for (int c = sub * 4; c < h; c += 64) {
+                    const float4 a = *reinterpret_cast<const float4*>(es + c);
+                    const float4 b = *reinterpret_cast<const float4*>(wr + c);
+                    const float4 d = *reinterpret_cast<const float4*>(eo + c);
+                    acc = fmaf(a.x * b.x, d.x, acc);
+                    acc = fmaf(a.y * b.y, d.y, acc);
+                    acc = fmaf(a.z * b.z, d.z, acc);
+                    acc = fmaf(a.w * b.w, d.w, acc);
+                }
+            } else {
+                for (int c = sub; c < h; c += 16) acc = fmaf(es[c] * wr[c], eo[c], acc);
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (t < T && sub == 0) {
+            const float x = acc + bv;
+            score[t] = x;
+            const float y = labels[t];
+            lsum += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+        }
+    }
+    const float tot = block_sum_256(lsum, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_bce_grad(const float* score, const float* labels, const float* gloss,
+                                                  float* dscore, float* part, int64_t T) {
+    __shared__ float sm[4];
+    const float g = (gloss ? *gloss : 1.f) / (float)T;
+    float acc = 0.f;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < T; t += (int64_t)gridDim.x * 256) {
+        const float d = g * (1.f / (1.f + expf(-score[t])) - labels[t]);
+        dscore[t] = d;
+        acc += d;
+    }
+    const float tot = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_sumsq_part(const float* x, int64_t n, float* part) {
+    __shared__ float sm[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc = fmaf(x[i], x[i], acc);
+    const float tot = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// ---- KL -----------------------------------------------------------------------------------------
+// workspace layout (floats): mix[3][k*h] (mu_j, 1/(2 v_j), log sqrt v_j + log sqrt 2pi) | terms[n] | part[...]
+constexpr float LOG_SQRT_2PI = 0.9189385332046727f;
+
+__device__ __forceinline__ float softplus_t(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+__global__ __launch_bounds__(256) void k_kl_mix(const float* z_pre, int k, int h, float* mix) {
+    const int total = k * h;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const float v = softplus_t(z_pre[total + i]) + 1e-8f;
+        mix[i] = z_pre[i];
+        mix[total + i] = 1.f / (2.f * v);
+        mix[2 * total + i] = logf(sqrtf(v)) + LOG_SQRT_2PI;
+    }
+}
+
+constexpr int KL_KMAX = 32;
+
+// one wave per node; mixture table staged in LDS once per block
+__global__ __launch_bounds__(256) void k_kl_fwd(const float* z, const float* m, int ld_m, const float* v,
+                                                const float* mix, const float* flp, float* resp, float* terms,
+                                                int64_t n, int h, int k) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int kh = k * h;
+    for (int i = threadIdx.x; i < 3 * kh; i += 256) sm[i] = mix[i];
+    __syncthreads();
+    const float* mu = sm;
+    const float* i2v = sm + kh;
+    const float* lsv = sm + 2 * kh;
+    const int lane = threadIdx.x & 63;
+    const float fl = flp ? *flp : 0.f;
+    const float logk = logf((float)k);
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {
+        float a = 0.f;
+        float L[KL_KMAX];
+#pragma unroll
+        for (int j = 0; j < KL_KMAX; ++j) L[j] = 0.f;
+        for (int c = lane; c < h; c += 64) {
+            const float zz = z[r * h + c], mm = m[r * ld_m + c], vv = v[r * h + c];
+            const float d = zz - mm;
+            a += -(d * d) / (2.f * vv) - logf(sqrtf(vv)) - LOG_SQRT_2PI;
+#pragma unroll
+            for (int j = 0; j < KL_KMAX; ++j)
+                if (j < k) {
+                    const float dj = zz - mu[j * h + c];
+                    L[j] += -(dj * dj) * i2v[j * h + c] - lsv[j * h + c];
+                }
+        }
+        a = wave_sum(a);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < KL_KMAX; ++j)
+            if (j < k) {
+                L[j] = wave_sum(L[j]);
+                mx = fmaxf(mx, L[j]);
+            }
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < KL_KMAX; ++j)
+            if (j < k) {
+                L[j] = expf(L[j] - mx);
+                se += L[j];
+            }
+        if (lane == 0) {
+            terms[r] = a + fl - (mx + logf(se) - logk);
+#pragma unroll
+            for (int j = 0; j < KL_KMAX; ++j)
+                if (j < k) resp[r * k + j] = L[j] / se;
+        }
+    }
+}
+
+// per-node gradients gz, gm, gv (scaled by *gkl / n)
+__global__ __launch_bounds__(256) void k_kl_bwd_nodes(const float* z, const float* m, int ld_m, const float* v,
+                                                      const float* mix, const float* resp, const float* gkl, float* gz,
+                                                      float* gm, float* gv, int64_t n, int h, int k) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int kh = k * h;
+    for (int i = threadIdx.x; i < 2 * kh; i += 256) sm[i] = mix[i];
+    __syncthreads();
+    const float* mu = sm;
+    const float* i2v = sm + kh;
+    const int lane = threadIdx.x & 63;
+    const float cg = (gkl ? *gkl : 1.f) / (float)n;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {
+        const float* rp = resp + r * k;
+        for (int c = lane; c < h; c += 64) {
+            const float zz = z[r * h + c], mm = m[r * ld_m + c], vv = v[r * h + c];
+            const float d = zz - mm;
+            float mixg = 0.f;
+            for (int j = 0; j < k; ++j) mixg += rp[j] * (zz - mu[j * h + c]) * 2.f * i2v[j * h + c];
+            gz[r * h + c] = cg * (-d / vv + mixg);
+            gm[r * h + c] = cg * (d / vv);
+            gv[r * h + c] = cg * (d * d / (2.f * vv * vv) - 0.5f / vv);
+        }
+    }
+}
+
+// mixture-parameter gradients: block (j, slice) sums over its node slice; threads own columns
+__global__ __launch_bounds__(256) void k_kl_bwd_mix_part(const float* z, const float* mix, const float* resp,
+                                                         float* part, int64_t n, int h, int k) {
+    const int j = blockIdx.x, slice = blockIdx.y, nsl = gridDim.y;
+    const int64_t per = (n + nsl - 1) / nsl;
+    const int64_t r0 = slice * per, r1 = min(n, r0 + per);
+    const int kh = k * h;
+    for (int c = threadIdx.x; c < h; c += 256) {
+        const float muj = mix[j * h + c], i2 = mix[kh + j * h + c];  // i2 = 1/(2 v_j)
+        float gmu = 0.f, gvv = 0.f;
+        for (int64_t r = r0; r < r1; ++r) {
+            const float rj = resp[r * k + j];
+            const float d = z[r * h + c] - muj;
+            gmu += rj * d;
+            gvv += rj * (d * d * 2.f * i2 * i2 - i2);     // (d^2/(2 v^2) - 1/(2v)) with i2 = 1/(2v)
+        }
+        // d(-lme)/dmu = -resp * d / v ; d(-lme)/dv = -resp * (...)
+        part[((size_t)slice * 2 * k + j) * h + c] = -gmu * 2.f * i2;
+        part[((size_t)slice * 2 * k + k + j) * h + c] = -gvv;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_kl_bwd_mix_final(const float* part, const float* z_pre, const float* gkl,
+                                                          float* g_zpre, int64_t n, int h, int k, int nsl) {
+    const int total = 2 * k * h, kh = k * h;
+    const float cg = (gkl ? *gkl : 1.f) / (float)n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        float acc = 0.f;
+        for (int s = 0; s < nsl; ++s) acc += part[(size_t)s * total + i];
+        if (i >= kh) {  // chain through v_j = softplus(raw) + 1e-8
+            const float raw = z_pre[i];
+            acc *= raw > 20.f ? 1.f : 1.f / (1.f + expf(-raw));
+        }
+        g_zpre[i] = cg * acc;
+    }
+}
+
+constexpr int KL_SLICES = 32;
+
+}  // namespace gv
+
+using namespace gv;
+
+#define GV_ST ((hipStream_t)stream)
+
+static int red_blocks(int64_t n, int per_block) {
+    int64_t b = (n + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > RED_BLOCKS ? RED_BLOCKS : b));
+}
+
+extern "C" int gv_distmult_bce_fwd(const float* embed, int ld_e, const float* w_rel, int ld_w,
+                                   const int32_t* triplets, const float* labels, const float* bias, float* score,
+                                   float* loss, float* workspace, int64_t t, int h, void* stream) {
+    GV_REQUIRE(embed && w_rel && triplets && labels && score && loss && workspace, GV_ERR_NULL,
+               "gv_distmult_bce_fwd: NULL pointer");
+    GV_REQUIRE(t > 0 && h > 0 && ld_e >= h && ld_w >= h, GV_ERR_SHAPE, "gv_distmult_bce_fwd: bad shape");
+    const int nb = red_blocks(t, 16);
+    hipLaunchKernelGGL(k_distmult_bce, dim3(nb), dim3(256), 0, GV_ST, embed, ld_e, w_rel, ld_w, triplets, labels, bias,
+                       score, workspace, t, h);
+    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, nb, 1.f / (float)t, loss, 0);
+    return launch_status("gv_distmult_bce_fwd");
+}
+
+extern "C" int gv_bce_grad(const float* score, const float* labels, const float* gloss, float* dscore, float* dbias,
+                           float* workspace, int64_t t, void* stream) {
+    GV_REQUIRE(score && labels && dscore && workspace, GV_ERR_NULL, "gv_bce_grad: NULL pointer");
+    GV_REQUIRE(t > 0, GV_ERR_SHAPE, "gv_bce_grad: t=%lld", (long long)t);
+    const int nb = red_blocks(t, 256);
+    hipLaunchKernelGGL(k_bce_grad, dim3(nb), dim3(256), 0, GV_ST, score, labels, gloss, dscore, workspace, t);
+    if (dbias) hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, nb, 1.f, dbias, 0);
+    return launch_status("gv_bce_grad");
+}
+
+extern "C" int gv_mean_sq(const float* x, int64_t n, float scale, float* out, float* workspace, int accumulate,
+                          void* stream) {
+    GV_REQUIRE(x && out && workspace, GV_ERR_NULL, "gv_mean_sq: NULL pointer");
+    GV_REQUIRE(n > 0, GV_ERR_SHAPE, "gv_mean_sq: n=%lld", (long long)n);
+    const int nb = red_blocks(n, 4096);
+    hipLaunchKernelGGL(k_sumsq_part, dim3(nb), dim3(256), 0, GV_ST, x, n, workspace);
+    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, nb, scale, out, accumulate);
+    return launch_status("gv_mean_sq");
+}
+
+extern "C" int64_t gv_kl_workspace_bytes(int64_t n, int h, int k) {
+    return (int64_t)sizeof(float) * (3 * (int64_t)k * h + n + RED_BLOCKS + (int64_t)KL_SLICES * 2 * k * h);
+}
+
+extern "C" int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre,
+                         const float* flp, float* resp, float* kl, float* workspace, int64_t n, int h, int k,
+                         void* stream) {
+    GV_REQUIRE(z && m && v && z_pre && resp && kl && workspace, GV_ERR_NULL, "gv_kl_fwd: NULL pointer");
+    GV_REQUIRE(n > 0 && h > 0 && k > 0 && k <= KL_KMAX && ld_m >= h, GV_ERR_SHAPE, "gv_kl_fwd: n=%lld h=%d k=%d",
+               (long long)n, h, k);
+    const size_t lds = (size_t)3 * k * h * sizeof(float);
+    GV_REQUIRE(lds <= 64 * 1024, GV_ERR_SHAPE, "gv_kl_fwd: mixture table %zu B exceeds the 64 KiB LDS budget", lds);
+    float* mix = workspace;
+    float* terms = workspace + 3 * (size_t)k * h;
+    float* part = terms + n;
+    hipLaunchKernelGGL(k_kl_mix, dim3((k * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, k, h, mix);
+    const int nb = (int)((n + 3) / 4 > 1024 ? 1024 : (n + 3) / 4);
+    hipLaunchKernelGGL(k_kl_fwd, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, flp, resp, terms, n, h, k);
+    // mean over nodes: ordered two-pass sum of terms (reuse the sum kernel: part = terms chunks)
+    (void)part;
+    // mean over nodes: one block sums terms[] in a fixed order
+    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, terms, (int)n, 1.f / (float)n, kl, 0);
+    return launch_status("gv_kl_fwd");
+}
+
+extern "C" int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre,
+                         const float* resp, const float* gkl, float* gz, float* gm, float* gv, float* g_zpre,
+                         float* workspace, int64_t n, int h, int k, void* stream) {
+    GV_REQUIRE(z && m && v && z_pre && resp && gz && gm && gv && g_zpre && workspace, GV_ERR_NULL,
+               "gv_kl_bwd: NULL pointer");
+    GV_REQUIRE(n > 0 && h > 0 && k > 0 && k <= KL_KMAX && ld_m >= h, GV_ERR_SHAPE, "gv_kl_bwd: bad shape");
+    float* mix = workspace;  // filled by gv_kl_fwd of the same step; recomputed here to stay self-contained
+    hipLaunchKernelGGL(k_kl_mix, dim3((k * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, k, h, mix);
+    const size_t lds = (size_t)2 * k * h * sizeof(float);
+    const int nb = (int)((n + 3) / 4 > 1024 ? 1024 : (n + 3) / 4);
+    hipLaunchKernelGGL(k_kl_bwd_nodes, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, resp, gkl, gz, gm, gv, n,
+                       h, k);
+    float* part = workspace + 3 * (size_t)k * h + n + RED_BLOCKS;
+    hipLaunchKernelGGL(k_kl_bwd_mix_part, dim3(k, KL_SLICES), dim3(256), 0, GV_ST, z, mix, resp, part, n, h, k);
+    hipLaunchKernelGGL(k_kl_bwd_mix_final, dim3((2 * k * h + 255) / 256), dim3(256), 0, GV_ST, part, z_pre, gkl,
+                       g_zpre, n, h, k, KL_SLICES);
+    return launch_status("gv_kl_bwd");
+}

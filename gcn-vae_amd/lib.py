@@ -1,0 +1,83 @@
+"""ctypes binding of libgcnvae_hip.so (the C ABI declared in include/gcnvae.h).
+
+There is NO fallback: if the shared library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgcnvae_hip.so')
+
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/gcnvae.h one to one (checked by tests/test_abi.py)
+SIGNATURES = {
+    'gv_version': (_I, []),
+    'gv_last_error_string': (ctypes.c_char_p, []),
+    'gv_segment_items_count': (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    'gv_segment_items_fill': (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    'gv_rgcn_bdd_aggregate': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I,
+                                   _P, _I, _I, _P, _F, _P, _I, _P, _P]),
+    'gv_rgcn_bdd_grad_weight': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
+    'gv_rgcn_epilogue_fwd': (_I, [_P, _P, _I, _P, _F, _P, _L, _I, _P]),
+    'gv_rgcn_epilogue_bwd': (_I, [_P, _P, _I, _P, _F, _P, _L, _I, _P]),
+    'gv_gemm_workspace_bytes': (_L, [_I, _I, _I, _I]),
+    'gv_gemm_f32': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _L, _P]),
+    'gv_colsum': (_I, [_P, _L, _I, _I, _P, _P, _I, _P]),
+    'gv_gather_rows': (_I, [_P, _P, _P, _L, _I, _P]),
+    'gv_scatter_add_rows': (_I, [_P, _P, _P, _L, _I, _P]),
+    'gv_reparam_fwd': (_I, [_P, _P, _P, _P, _L, _I, _P]),
+    'gv_reparam_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    'gv_distmult_bce_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    'gv_bce_grad': (_I, [_P, _P, _P, _P, _P, _P, _L, _P]),
+    'gv_mean_sq': (_I, [_P, _L, _F, _P, _P, _I, _P]),
+    'gv_axpby': (_I, [_L, _P, _F, _P, _F, _P, _P]),
+    'gv_mul': (_I, [_L, _P, _P, _P, _P]),
+    'gv_kl_workspace_bytes': (_L, [_L, _I, _I]),
+    'gv_kl_fwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    'gv_kl_bwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    'gv_iaf_update_fwd': (_I, [_P, _P, _P, _P, _P, _L, _I, _P]),
+    'gv_iaf_update_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    'gv_rowsum': (_I, [_P, _I, _I, _I, _P, _L, _P]),
+    'gv_reverse_cols': (_I, [_P, _P, _L, _I, _P]),
+    'gv_adam_step': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} not found: the HIP extension is not built. Run `python gcn-vae_amd/_build.py` '
+                '(or __graft_entry__.build()). There is no CPU fallback for this path.')
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().gv_last_error_string().decode('utf-8', 'replace')
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; non-zero status raises with the library's message."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f'{name} failed with status {rc}: {last_error()}')
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,691 @@
+"""Tensor-level wrappers over the C ABI: index builders, raw ops, and torch.autograd Functions.
+
+Every function here requires CUDA (ROCm) float32 tensors and the built HIP library; nothing
+falls back to torch CPU math.  torch is used for device memory, the current stream and autograd
+bookkeeping only (plus sort/cumsum when an index is built, outside the hot step).
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import lib
+from .lib import ptr
+
+ACT_NONE, ACT_RELU = 0, 1
+DEFAULT_CHUNK = 256        # max edges per work item of the dst/src-sorted aggregations
+DEFAULT_CHUNK_REL = 128    # max edges per work item of the by-relation weight gradient
+
+
+def _chk(t, dtype=torch.float32, name='tensor'):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f'{name}: the gfx950 path needs a CUDA/ROCm tensor (got '
+                           f'{type(t).__name__} on {getattr(t, "device", "?")}); there is no CPU fallback')
+    if t.dtype != dtype:
+        raise TypeError(f'{name}: expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name}: must be contiguous')
+    return t
+
+
+def _row_major(t, name='matrix'):
+    """2-D fp32 CUDA tensor with unit inner stride; returns (tensor, leading dimension)."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f'{name}: the gfx950 path needs a CUDA/ROCm tensor; there is no CPU fallback')
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise TypeError(f'{name}: expected 2-D float32, got {t.dtype} {tuple(t.shape)}')
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t, (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+
+
+# ------------------------------------------------------------------------------------------------
+# segment work items
+@dataclass
+class SegmentItems:
+    items: torch.Tensor      # int32 [n_items, 4]
+    fix: torch.Tensor        # int32 [n_fix, 4]
+    n_items: int
+    n_fix: int
+    n_slots: int
+    rowptr: torch.Tensor     # int32 [n_seg + 1]
+    chunk: int
+
+
+def build_segment_items(rowptr: torch.Tensor, chunk: int) -> SegmentItems:
+    """Cut a CSR segment list into <=chunk-edge work items (device kernels + two scans).
+    Synchronises once (item counts come back to the host); call outside the hot step."""
+    _chk(rowptr, torch.int32, 'rowptr')
+    n_seg = rowptr.numel() - 1
+    dev = rowptr.device
+    n_chunks = torch.empty(n_seg, dtype=torch.int32, device=dev)
+    n_slots = torch.empty(n_seg, dtype=torch.int32, device=dev)
+    is_split = torch.empty(n_seg, dtype=torch.int32, device=dev)
+    lib.call('gv_segment_items_count', ptr(rowptr), n_seg, chunk, ptr(n_chunks), ptr(n_slots), ptr(is_split),
+             lib.stream())
+
+    def excl(t):
+        out = torch.zeros(n_seg + 1, dtype=torch.int32, device=dev)
+        out[1:] = torch.cumsum(t, 0)
+        return out
+
+    item_off, slot_off, fix_off = excl(n_chunks), excl(n_slots), excl(is_split)
+    totals = torch.stack([item_off[-1], slot_off[-1], fix_off[-1]]).tolist()
+    n_items, n_slot_total, n_fix = (int(v) for v in totals)
+    items = torch.empty(max(n_items, 1), 4, dtype=torch.int32, device=dev)
+    fix = torch.empty(max(n_fix, 1), 4, dtype=torch.int32, device=dev)
+    lib.call('gv_segment_items_fill', ptr(rowptr), n_seg, chunk, ptr(item_off), ptr(slot_off), ptr(fix_off),
+             ptr(items), ptr(fix), lib.stream())
+    return SegmentItems(items, fix, n_items, n_fix, n_slot_total, rowptr, chunk)
+
+
+def _rowptr_from_sorted(keys_sorted: torch.Tensor, n_seg: int) -> torch.Tensor:
+    counts = torch.bincount(keys_sorted, minlength=n_seg)
+    rp = torch.zeros(n_seg + 1, dtype=torch.int32, device=keys_sorted.device)
+    rp[1:] = torch.cumsum(counts, 0)
+    return rp
+
+
+@dataclass
+class EdgeOrder:
+    """One ordering of the edge list: the segment key (dst, src or relation) is sorted."""
+    perm: Optional[torch.Tensor]   # int32 [E] original edge id of each position; None = identity
+    seg: SegmentItems
+
+
+class GraphIndex:
+    """Device-side index of a relational graph for the K1 kernels.
+
+    by_dst : CSR over destinations  (forward aggregation; the reference's edge order is already
+             dst-sorted, kgvae/utils.py:146-147, so ``perm`` is usually None)
+    by_src : CSC over sources       (backward w.r.t. x)
+    Relation-dependent arrays live in ``RelationIndex`` (etypes arrive per forward call).
+    """
+
+    def __init__(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: int, chunk: int = DEFAULT_CHUNK):
+        if not src.is_cuda:
+            raise RuntimeError('GraphIndex needs CUDA index tensors; there is no CPU fallback')
+        self.num_nodes, self.num_edges = int(num_nodes), int(src.numel())
+        self.device = src.device
+        src = src.to(torch.int64)
+        dst = dst.to(torch.int64)
+        self.src32, self.dst32 = src.to(torch.int32), dst.to(torch.int32)
+        if self.num_edges and bool((dst[1:] >= dst[:-1]).all()):
+            perm_d = None
+            dst_sorted = dst
+        else:
+            perm_d = torch.sort(dst, stable=True)[1]
+            dst_sorted = dst[perm_d]
+        self.nbr_by_dst = (src if perm_d is None else src[perm_d]).to(torch.int32).contiguous()
+        self.by_dst = EdgeOrder(None if perm_d is None else perm_d.to(torch.int32),
+                                build_segment_items(_rowptr_from_sorted(dst_sorted, self.num_nodes), chunk))
+        perm_s = torch.sort(src, stable=True)[1]
+        self.nbr_by_src = dst[perm_s].to(torch.int32).contiguous()
+        self.by_src = EdgeOrder(perm_s.to(torch.int32),
+                                build_segment_items(_rowptr_from_sorted(src[perm_s], self.num_nodes), chunk))
+        self._rel_cache = {}
+
+    def relation_index(self, etypes: torch.Tensor, num_rels: int) -> 'RelationIndex':
+        key = (etypes.data_ptr(), etypes._version, int(num_rels))
+        hit = self._rel_cache.get(key)
+        if hit is None:
+            if len(self._rel_cache) > 8:
+                self._rel_cache.clear()
+            hit = self._rel_cache[key] = RelationIndex(self, etypes, num_rels)
+        return hit
+
+
+class RelationIndex:
+    def __init__(self, g: GraphIndex, etypes: torch.Tensor, num_rels: int, chunk: int = DEFAULT_CHUNK_REL):
+        if etypes.numel() != g.num_edges:
+            raise ValueError(f'etypes has {etypes.numel()} entries for {g.num_edges} edges')
+        et = etypes.reshape(-1).to(torch.int64)
+        if g.num_edges and (int(et.min()) < 0 or int(et.max()) >= num_rels):
+            raise ValueError(f'edge types must lie in [0, {num_rels})')
+        self.num_rels = int(num_rels)
+        self.keepalive = etypes
+        self.et_by_dst = (et if g.by_dst.perm is None else et[g.by_dst.perm.long()]).to(torch.int32).contiguous()
+        self.et_by_src = et[g.by_src.perm.long()].to(torch.int32).contiguous()
+        perm_r = torch.sort(et, stable=True)[1]
+        self.src_by_rel = g.src32[perm_r].contiguous()
+        self.dst_by_rel = g.dst32[perm_r].contiguous()
+        self.by_rel = EdgeOrder(perm_r.to(torch.int32),
+                                build_segment_items(_rowptr_from_sorted(et[perm_r], self.num_rels), chunk))
+
+
+class TripletIndex:
+    """Index of a (T,3) triplet batch for the DistMult backward (K1 with 1x1 blocks).
+
+    incidence list: 2T entries (entity, other entity, relation, triplet id), sorted by entity
+    relation list : T entries sorted by relation
+    """
+
+    def __init__(self, triplets: torch.Tensor, num_entities: int, num_rels: int, chunk: int = DEFAULT_CHUNK,
+                 chunk_rel: int = DEFAULT_CHUNK_REL):
+        if not triplets.is_cuda:
+            raise RuntimeError('TripletIndex needs a CUDA tensor; there is no CPU fallback')
+        t = triplets.to(torch.int64)
+        self.T = int(t.shape[0])
+        self.num_entities, self.num_rels = int(num_entities), int(num_rels)
+        self.trip32 = t.to(torch.int32).contiguous()
+        s, r, o = t[:, 0], t[:, 1], t[:, 2]
+        ent = torch.cat([s, o])
+        other = torch.cat([o, s])
+        rel2 = torch.cat([r, r])
+        tid = torch.arange(self.T, device=t.device).repeat(2)
+        perm = torch.sort(ent, stable=True)[1]
+        self.inc_other = other[perm].to(torch.int32).contiguous()
+        self.inc_rel = rel2[perm].to(torch.int32).contiguous()
+        self.inc_tid = tid[perm].to(torch.int32).contiguous()
+        self.inc = build_segment_items(_rowptr_from_sorted(ent[perm], self.num_entities), chunk)
+        perm_r = torch.sort(r, stable=True)[1]
+        self.rel_s = s[perm_r].to(torch.int32).contiguous()
+        self.rel_o = o[perm_r].to(torch.int32).contiguous()
+        self.rel_tid = perm_r.to(torch.int32).contiguous()
+        self.rel = build_segment_items(_rowptr_from_sorted(r[perm_r], self.num_rels), chunk_rel)
+
+
+# ------------------------------------------------------------------------------------------------
+# raw ops
+def bdd_aggregate(seg: SegmentItems, nbr, etype, coef, coef_idx, feat, weight, num_bases, blk_in, blk_out,
+                  transpose_w=False, addend=None, act=ACT_NONE, keep=None, keep_scale=1.0, out=None):
+    feat, ld_feat = _row_major(feat, 'feat')
+    weight = _chk(weight, name='weight')
+    n_seg = seg.rowptr.numel() - 1
+    out_dim = num_bases * blk_out
+    if feat.shape[1] != num_bases * blk_in:
+        raise ValueError(f'feat has {feat.shape[1]} columns, expected num_bases*blk_in = {num_bases * blk_in}')
+    num_rels = weight.shape[0]
+    if weight.numel() != num_rels * num_bases * blk_in * blk_out:
+        raise ValueError('weight shape does not match (R, num_bases*blk_in*blk_out)')
+    if out is None:
+        out = torch.empty(n_seg, out_dim, dtype=torch.float32, device=feat.device)
+    ld_add = 0
+    if addend is not None:
+        addend, ld_add = _row_major(addend, 'addend')
+        if tuple(addend.shape) != (n_seg, out_dim):
+            raise ValueError('addend shape mismatch')
+    if keep is not None:
+        _chk(keep, torch.uint8, 'keep')
+        if tuple(keep.shape) != (n_seg, out_dim):
+            raise ValueError('keep shape mismatch')
+    if coef is not None:
+        coef = _chk(coef.reshape(-1), name='coef')
+    partial = None
+    if seg.n_fix > 0:
+        partial = torch.empty(seg.n_slots, out_dim, dtype=torch.float32, device=feat.device)
+    lib.call('gv_rgcn_bdd_aggregate', ptr(seg.items), seg.n_items, ptr(seg.fix), seg.n_fix, ptr(nbr), ptr(etype),
+             ptr(coef), ptr(coef_idx), ptr(feat), ld_feat, ptr(weight), num_rels, num_bases, blk_in, blk_out,
+             1 if transpose_w else 0, ptr(addend), ld_add, act, ptr(keep), float(keep_scale), ptr(out),
+             out.stride(0) if n_seg > 1 else out_dim, ptr(partial), lib.stream())
+    return out
+
+
+def bdd_grad_weight(seg: SegmentItems, src, dst, coef, coef_idx, x, g, num_bases, blk_in, blk_out, out=None,
+                    accumulate=False):
+    x, ld_x = _row_major(x, 'x')
+    g, ld_g = _row_major(g, 'g')
+    n_seg = seg.rowptr.numel() - 1
+    w_row = num_bases * blk_in * blk_out
+    if out is None:
+        out = torch.empty(n_seg, w_row, dtype=torch.float32, device=x.device)
+        accumulate = False
+    if coef is not None:
+        coef = _chk(coef.reshape(-1), name='coef')
+    partial = None
+    if seg.n_fix > 0:
+        partial = torch.empty(seg.n_slots, w_row, dtype=torch.float32, device=x.device)
+    lib.call('gv_rgcn_bdd_grad_weight', ptr(seg.items), seg.n_items, ptr(seg.fix), seg.n_fix, ptr(src), ptr(dst),
+             ptr(coef), ptr(coef_idx), ptr(x), ld_x, ptr(g), ld_g, num_bases, blk_in, blk_out, ptr(out), ptr(partial),
+             1 if accumulate else 0, lib.stream())
+    return out
+
+
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, accumulate=False, split_k=1):
+    """out = act(op(a) @ op(b) + bias) (+ out)."""
+    a, lda = _row_major(a, 'a')
+    b, ldb = _row_major(b, 'b')
+    m, k = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    kb, n = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    if k != kb:
+        raise ValueError(f'gemm inner dimensions differ: {k} vs {kb}')
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+        accumulate = False
+    if bias is not None:
+        _chk(bias, name='bias')
+    ws, ws_bytes = None, 0
+    if split_k > 1:
+        ws_bytes = int(lib.load().gv_gemm_workspace_bytes(m, n, k, split_k))
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=a.device)
+    lib.call('gv_gemm_f32', 1 if trans_a else 0, 1 if trans_b else 0, m, n, k, ptr(a), lda, ptr(b), ldb, ptr(out),
+             out.stride(0) if m > 1 else n, ptr(bias), act, 1 if accumulate else 0, split_k, ptr(ws), ws_bytes,
+             lib.stream())
+    return out
+
+
+def pick_split_k(m_out, n_out, k):
+    """Reduction-heavy shapes (weight gradients: small output, K = nodes) need split-K to fill 256 CUs."""
+    tiles = ((m_out + 127) // 128) * ((n_out + 63) // 64)
+    if tiles >= 256 or k < 2048:
+        return 1
+    return max(1, min(64, 512 // tiles, k // 256))
+
+
+def colsum(x, out=None, accumulate=False):
+    x, ld = _row_major(x, 'x')
+    m, n = x.shape
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=x.device)
+        accumulate = False
+    ws = torch.empty(64 * n, dtype=torch.float32, device=x.device)
+    lib.call('gv_colsum', ptr(x), m, n, ld, ptr(out), ptr(ws), 1 if accumulate else 0, lib.stream())
+    return out
+
+
+def epilogue_fwd(agg, addend, act, keep, keep_scale):
+    agg = _chk(agg, name='agg')
+    out = torch.empty_like(agg)
+    if addend is not None:
+        addend = _chk(addend, name='addend')
+    lib.call('gv_rgcn_epilogue_fwd', ptr(agg), ptr(addend), act, ptr(keep), float(keep_scale), ptr(out),
+             agg.shape[0], agg.shape[1], lib.stream())
+    return out
+
+
+def epilogue_bwd(out, grad_out, act, keep, keep_scale):
+    grad_out = _chk(grad_out.contiguous(), name='grad_out')
+    g = torch.empty_like(grad_out)
+    lib.call('gv_rgcn_epilogue_bwd', ptr(out), ptr(grad_out), act, ptr(keep), float(keep_scale), ptr(g),
+             grad_out.shape[0], grad_out.shape[1], lib.stream())
+    return g
+
+
+def axpby(alpha, x, beta=0.0, y=None, a=None):
+    x = _chk(x.contiguous(), name='x')
+    if y is None:
+        y = torch.empty_like(x)
+        beta = 0.0
+    lib.call('gv_axpby', x.numel(), ptr(a), float(alpha), ptr(x), float(beta), ptr(y), lib.stream())
+    return y
+
+
+def mul(a, b):
+    a, b = _chk(a.contiguous(), name='a'), _chk(b.contiguous(), name='b')
+    out = torch.empty_like(a)
+    lib.call('gv_mul', a.numel(), ptr(a), ptr(b), ptr(out), lib.stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd Functions
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, ids):
+        table = _chk(table, name='embedding table')
+        ids = _chk(ids.reshape(-1), torch.int64, 'node ids')
+        out = torch.empty(ids.numel(), table.shape[1], dtype=torch.float32, device=table.device)
+        lib.call('gv_gather_rows', ptr(table), ptr(ids), ptr(out), ids.numel(), table.shape[1], lib.stream())
+        ctx.save_for_backward(ids)
+        ctx.shape = tuple(table.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        g = _chk(g.contiguous(), name='grad')
+        gt = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        lib.call('gv_scatter_add_rows', ptr(g), ptr(ids), ptr(gt), ids.numel(), ctx.shape[1], lib.stream())
+        return gt, None
+
+
+def embedding(table, ids):
+    return _Embedding.apply(table, ids)
+
+
+class _RelGraphConvBdd(torch.autograd.Function):
+    """out = keep*scale*act( sum_e norm_e * blockdiag(W_{r_e}) x[src_e]  + x@loop_weight + h_bias ).
+
+    ``reduce_hook`` (multi-GPU edge sharding): a callable that sums a tensor over the ranks in place
+    and returns it.  With a hook the raw aggregate is kept separate from the epilogue so that it can
+    be all-reduced in between; backward all-reduces the gradient of the aggregate the same way.
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, h_bias, loop_weight, norm, gidx, ridx, num_bases, act, keep, keep_scale,
+                reduce_hook):
+        x, _ = _row_major(x, 'x')
+        n, in_feat = x.shape
+        si = in_feat // num_bases
+        so = weight.shape[1] // (num_bases * si)
+        out_feat = num_bases * so
+        addend = None
+        if loop_weight is not None:
+            addend = gemm(x, loop_weight, bias=h_bias)
+        elif h_bias is not None:
+            addend = h_bias.unsqueeze(0).expand(n, out_feat).contiguous()
+        coef = None if norm is None else norm.reshape(-1)
+        if reduce_hook is None:
+            out = bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x, weight,
+                                num_bases, si, so, False, addend, act, keep, keep_scale)
+        else:
+            agg = bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x, weight,
+                                num_bases, si, so)
+            agg = reduce_hook(agg)
+            out = epilogue_fwd(agg, addend, act, keep, keep_scale)
+        ctx.save_for_backward(x, weight, loop_weight, coef, out if act == ACT_RELU else None, keep)
+        ctx.meta = (gidx, ridx, num_bases, si, so, act, keep_scale, h_bias is not None, reduce_hook)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight, loop_weight, coef, out, keep = ctx.saved_tensors
+        gidx, ridx, nb, si, so, act, keep_scale, has_bias, reduce_hook = ctx.meta
+        g = epilogue_bwd(out, grad_out, act, keep, keep_scale)
+        g_agg = g if reduce_hook is None else reduce_hook(g.clone())
+        grad_bias = colsum(g) if (has_bias and ctx.needs_input_grad[2]) else None
+        grad_loop = gx_loop = None
+        if loop_weight is not None:
+            if ctx.needs_input_grad[3]:
+                grad_loop = gemm(x, g, trans_a=True, split_k=pick_split_k(x.shape[1], g.shape[1], x.shape[0]))
+            if ctx.needs_input_grad[0]:
+                gx_loop = gemm(g, loop_weight, trans_b=True)
+        grad_x = None
+        if ctx.needs_input_grad[0]:
+            grad_x = bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, coef, gidx.by_src.perm, g_agg,
+                                   weight, nb, so, si, True, gx_loop)
+        grad_w = None
+        if ctx.needs_input_grad[1]:
+            grad_w = bdd_grad_weight(ridx.by_rel.seg, ridx.src_by_rel, ridx.dst_by_rel, coef, ridx.by_rel.perm, x,
+                                     g_agg, nb, si, so)
+        return grad_x, grad_w, grad_bias, grad_loop, None, None, None, None, None, None, None, None
+
+
+def rel_graph_conv_bdd(x, weight, h_bias, loop_weight, norm, gidx, ridx, num_bases, act=ACT_NONE, keep=None,
+                       keep_scale=1.0, reduce_hook=None):
+    return _RelGraphConvBdd.apply(x, weight, h_bias, loop_weight, norm, gidx, ridx, num_bases, act, keep,
+                                  float(keep_scale), reduce_hook)
+
+
+class _Linear(torch.autograd.Function):
+    """y = act(x @ W^T + b) with W (out, in) -- torch's F.linear layout (MaskedLinear, flow_network.py:14-15)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        x, _ = _row_major(x, 'x')
+        y = gemm(x, w, trans_b=True, bias=b, act=act)
+        ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
+        ctx.act, ctx.has_bias = act, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        g = epilogue_bwd(y, gy, ctx.act, None, 1.0) if ctx.act == ACT_RELU else _chk(gy.contiguous(), name='gy')
+        gx = gemm(g, w) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = gemm(g, x, trans_a=True, split_k=pick_split_k(g.shape[1], x.shape[1], x.shape[0]))
+        gb = colsum(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None
+
+
+def linear(x, w, b=None, act=ACT_NONE):
+    return _Linear.apply(x, w, b, act)
+
+
+class _Mul(torch.autograd.Function):
+    """mask * weight (MaskedLinear); the mask is a constant buffer."""
+
+    @staticmethod
+    def forward(ctx, mask, w):
+        ctx.save_for_backward(mask)
+        return mul(mask, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return None, mul(mask, g)
+
+
+def masked_weight(mask, w):
+    return _Mul.apply(mask, w)
+
+
+class _Reparam(torch.autograd.Function):
+    """(z, m, v) = reparameterise(h2, eps): m = h2[:, :h], v = softplus(h2[:, h:]) + 1e-8, z = m + eps*sqrt(v)."""
+
+    @staticmethod
+    def forward(ctx, h2, eps):
+        h2 = _chk(h2.contiguous(), name='h2')
+        n, h = h2.shape[0], h2.shape[1] // 2
+        eps = _chk(eps.contiguous(), name='eps')
+        z = torch.empty(n, h, dtype=torch.float32, device=h2.device)
+        v = torch.empty_like(z)
+        lib.call('gv_reparam_fwd', ptr(h2), ptr(eps), ptr(z), ptr(v), n, h, lib.stream())
+        m = h2[:, :h].contiguous()
+        ctx.save_for_backward(h2, eps, v)
+        return z, m, v
+
+    @staticmethod
+    def backward(ctx, gz, gm, gv):
+        h2, eps, v = ctx.saved_tensors
+        n, h = v.shape
+        gz = None if gz is None else _chk(gz.contiguous(), name='gz')
+        gm = None if gm is None else _chk(gm.contiguous(), name='gm')
+        gv = None if gv is None else _chk(gv.contiguous(), name='gv')
+        gh2 = torch.empty_like(h2)
+        lib.call('gv_reparam_bwd', ptr(h2), ptr(eps), ptr(v), ptr(gz), ptr(gm), ptr(gv), ptr(gh2), n, h, lib.stream())
+        return gh2, None
+
+
+def reparam(h2, eps):
+    return _Reparam.apply(h2, eps)
+
+
+class _DistMultBCE(torch.autograd.Function):
+    """(loss, score) of the DistMult scorer with BCE-with-logits (mean); ``bias`` = flow_log_prob or None.
+    ``gscore`` handed to backward (from users of ``score``) is added to the BCE gradient."""
+
+    @staticmethod
+    def forward(ctx, embed, w_rel, bias, labels, tidx):
+        embed, ld_e = _row_major(embed, 'embed')
+        w_rel, ld_w = _row_major(w_rel, 'w_relation')
+        labels = _chk(labels.reshape(-1), name='labels')
+        T, h = tidx.T, embed.shape[1]
+        if labels.numel() != T:
+            raise ValueError('labels / triplets length mismatch')
+        score = torch.empty(T, dtype=torch.float32, device=embed.device)
+        loss = torch.empty((), dtype=torch.float32, device=embed.device)
+        ws = torch.empty(1024, dtype=torch.float32, device=embed.device)
+        lib.call('gv_distmult_bce_fwd', ptr(embed), ld_e, ptr(w_rel), ld_w, ptr(tidx.trip32), ptr(labels), ptr(bias),
+                 ptr(score), ptr(loss), ptr(ws), T, h, lib.stream())
+        ctx.save_for_backward(embed, w_rel, labels, score)
+        ctx.tidx, ctx.has_bias = tidx, bias is not None
+        ctx.mark_non_differentiable(score)
+        return loss, score
+
+    @staticmethod
+    def backward(ctx, gloss, _gscore):
+        embed, w_rel, labels, score = ctx.saved_tensors
+        tidx = ctx.tidx
+        T, h = tidx.T, embed.shape[1]
+        dev = embed.device
+        gloss = _chk(gloss.reshape(1).contiguous(), name='gloss')
+        dscore = torch.empty(T, dtype=torch.float32, device=dev)
+        dbias = torch.empty((), dtype=torch.float32, device=dev) if ctx.has_bias else None
+        ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        lib.call('gv_bce_grad', ptr(score), ptr(labels), ptr(gloss), ptr(dscore), ptr(dbias), ptr(ws), T, lib.stream())
+        g_embed = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_embed = bdd_aggregate(tidx.inc, tidx.inc_other, tidx.inc_rel, dscore, tidx.inc_tid, embed, w_rel,
+                                    h, 1, 1)
+        if ctx.needs_input_grad[1]:
+            g_w = bdd_grad_weight(tidx.rel, tidx.rel_s, tidx.rel_o, dscore, tidx.rel_tid, embed, embed, h, 1, 1)
+        return g_embed, g_w, dbias, None, None
+
+
+def distmult_bce(embed, w_rel, bias, labels, tidx):
+    return _DistMultBCE.apply(embed, w_rel, bias, labels, tidx)
+
+
+class _DistMultScore(torch.autograd.Function):
+    """score_t = sum_d e[s,d] w[r,d] e[o,d]  (LinkPredict.calc_score) with a general backward."""
+
+    @staticmethod
+    def forward(ctx, embed, w_rel, tidx):
+        embed, ld_e = _row_major(embed, 'embed')
+        w_rel, ld_w = _row_major(w_rel, 'w_relation')
+        T, h = tidx.T, embed.shape[1]
+        score = torch.empty(T, dtype=torch.float32, device=embed.device)
+        loss = torch.empty((), dtype=torch.float32, device=embed.device)
+        ws = torch.empty(1024, dtype=torch.float32, device=embed.device)
+        zeros = torch.zeros(T, dtype=torch.float32, device=embed.device)
+        lib.call('gv_distmult_bce_fwd', ptr(embed), ld_e, ptr(w_rel), ld_w, ptr(tidx.trip32), ptr(zeros), None,
+                 ptr(score), ptr(loss), ptr(ws), T, h, lib.stream())
+        ctx.save_for_backward(embed, w_rel)
+        ctx.tidx = tidx
+        return score
+
+    @staticmethod
+    def backward(ctx, gscore):
+        embed, w_rel = ctx.saved_tensors
+        tidx, h = ctx.tidx, embed.shape[1]
+        gscore = _chk(gscore.contiguous(), name='gscore')
+        g_embed = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_embed = bdd_aggregate(tidx.inc, tidx.inc_other, tidx.inc_rel, gscore, tidx.inc_tid, embed, w_rel,
+                                    h, 1, 1)
+        if ctx.needs_input_grad[1]:
+            g_w = bdd_grad_weight(tidx.rel, tidx.rel_s, tidx.rel_o, gscore, tidx.rel_tid, embed, embed, h, 1, 1)
+        return g_embed, g_w, None
+
+
+def distmult_score(embed, w_rel, tidx):
+    return _DistMultScore.apply(embed, w_rel, tidx)
+
+
+class _MeanSq(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x.contiguous(), name='x')
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        ws = torch.empty(1024, dtype=torch.float32, device=x.device)
+        lib.call('gv_mean_sq', ptr(x), x.numel(), 1.0 / x.numel(), ptr(out), ptr(ws), 0, lib.stream())
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return axpby(2.0 / x.numel(), x, a=_chk(g.reshape(1).contiguous(), name='g'))
+
+
+def mean_sq(x):
+    return _MeanSq.apply(x)
+
+
+class _KL(torch.autograd.Function):
+    """KGVAE.get_kl: mean_n[ logN(z; m, v) + flp - log mean_j N(z; m_j, v_j) ]; z_pre is (2k, h)."""
+
+    @staticmethod
+    def forward(ctx, z, m, v, z_pre, flp):
+        z, m, v = (_chk(t.contiguous(), name=nm) for t, nm in ((z, 'z'), (m, 'z_mean'), (v, 'z_sigma')))
+        z_pre = _chk(z_pre.contiguous(), name='z_pre')
+        n, h = z.shape
+        k = z_pre.shape[0] // 2
+        ws = torch.empty(int(lib.load().gv_kl_workspace_bytes(n, h, k)) // 4, dtype=torch.float32, device=z.device)
+        resp = torch.empty(n, k, dtype=torch.float32, device=z.device)
+        kl = torch.empty((), dtype=torch.float32, device=z.device)
+        lib.call('gv_kl_fwd', ptr(z), ptr(m), h, ptr(v), ptr(z_pre), ptr(flp), ptr(resp), ptr(kl), ptr(ws), n, h, k,
+                 lib.stream())
+        ctx.save_for_backward(z, m, v, z_pre, resp)
+        ctx.has_flp = flp is not None
+        return kl
+
+    @staticmethod
+    def backward(ctx, gkl):
+        z, m, v, z_pre, resp = ctx.saved_tensors
+        n, h = z.shape
+        k = z_pre.shape[0] // 2
+        gkl = _chk(gkl.reshape(1).contiguous(), name='gkl')
+        ws = torch.empty(int(lib.load().gv_kl_workspace_bytes(n, h, k)) // 4, dtype=torch.float32, device=z.device)
+        gz, gm, gv = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+        gzp = torch.empty_like(z_pre)
+        lib.call('gv_kl_bwd', ptr(z), ptr(m), h, ptr(v), ptr(z_pre), ptr(resp), ptr(gkl), ptr(gz), ptr(gm), ptr(gv),
+                 ptr(gzp), ptr(ws), n, h, k, lib.stream())
+        return gz, gm, gv, gzp, (gkl.reshape(()).clone() if ctx.has_flp else None)
+
+
+def kl_to_mixture(z, m, v, z_pre, flp=None):
+    return _KL.apply(z, m, v, z_pre, flp)
+
+
+class _IAFUpdate(torch.autograd.Function):
+    """x_new[:, c] = z*exp(alpha+mu) where colcount[c] > 0 else x_old; net = [mu | alpha]."""
+
+    @staticmethod
+    def forward(ctx, z, net, x_old, colcount):
+        z, net, x_old = (_chk(t.contiguous(), name=nm) for t, nm in ((z, 'z'), (net, 'net'), (x_old, 'x_old')))
+        n, d = z.shape
+        x_new = torch.empty_like(z)
+        lib.call('gv_iaf_update_fwd', ptr(z), ptr(net), ptr(x_old), ptr(colcount), ptr(x_new), n, d, lib.stream())
+        ctx.save_for_backward(z, net, colcount)
+        return x_new
+
+    @staticmethod
+    def backward(ctx, gx):
+        z, net, colcount = ctx.saved_tensors
+        n, d = z.shape
+        gx = _chk(gx.contiguous(), name='gx')
+        gz, gnet, gold = torch.empty_like(z), torch.empty_like(net), torch.empty_like(z)
+        lib.call('gv_iaf_update_bwd', ptr(z), ptr(net), ptr(colcount), ptr(gx), None, ptr(gz), ptr(gnet), ptr(gold),
+                 n, d, lib.stream())
+        return gz, gnet, gold, None
+
+
+def iaf_update(z, net, x_old, colcount):
+    return _IAFUpdate.apply(z, net, x_old, colcount)
+
+
+class _RowSumCols(torch.autograd.Function):
+    """sum over columns [col0, col0+ncols) of each row (log_det = sum_d alpha)."""
+
+    @staticmethod
+    def forward(ctx, x, col0, ncols):
+        x = _chk(x.contiguous(), name='x')
+        out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        lib.call('gv_rowsum', ptr(x), x.shape[1], col0, ncols, ptr(out), x.shape[0], lib.stream())
+        ctx.meta = (tuple(x.shape), col0, ncols)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, col0, ncols = ctx.meta
+        gx = torch.zeros(shape, dtype=torch.float32, device=g.device)
+        gx[:, col0:col0 + ncols] = g.unsqueeze(1)
+        return gx, None, None
+
+
+def rowsum_cols(x, col0, ncols):
+    return _RowSumCols.apply(x, col0, ncols)
+
+
+class _ReverseCols(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x.contiguous(), name='x')
+        out = torch.empty_like(x)
+        lib.call('gv_reverse_cols', ptr(x), ptr(out), x.shape[0], x.shape[1], lib.stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _chk(g.contiguous(), name='g')
+        out = torch.empty_like(g)
+        lib.call('gv_reverse_cols', ptr(g), ptr(out), g.shape[0], g.shape[1], lib.stream())
+        return out
+
+
+def reverse_cols(x):
+    return _ReverseCols.apply(x)

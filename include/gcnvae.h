@@ -1,0 +1,178 @@
+/* gcnvae.h -- C ABI of libgcnvae_hip.so: the R-GCN-VAE link-prediction hot path of
+ * karenyang/GCN-VAE as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference has no FFI for this path: it is Python calling torch / DGL ops.  Each entry
+ * point below therefore cites the reference op sequence it replaces (paths relative to
+ * /root/reference/).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a NEGATIVE gv_status for an argument error, or a
+ *     POSITIVE hipError_t; nothing throws across the ABI; gv_last_error_string() explains.
+ *   - all pointers are DEVICE pointers unless a name ends in _host; no function allocates,
+ *     synchronises or copies to the host; everything is enqueued on the caller's stream
+ *     (hipStream_t passed as void*), so calls are graph-capturable.
+ *   - matrices are dense row-major fp32 with an explicit leading dimension (in floats);
+ *     indices are int32.
+ *   - "segment work items": a destination-sorted edge list is cut into chunks of at most
+ *     `chunk` edges.  items[i] = {segment, edge_begin, edge_end, slot}: slot < 0 means the
+ *     segment fits one item and the wave stores the final row itself; slot >= 0 means the wave
+ *     stores a raw partial row into partial[slot] and a fix-up pass sums the segment's slots
+ *     IN ORDER (fix[j] = {segment, first_slot, n_slots, 0}) -- no atomics, bitwise reproducible.
+ *     gv_segment_items_* build these lists on the device from a CSR row pointer.
+ */
+#ifndef GCNVAE_H
+#define GCNVAE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    GV_OK = 0,
+    GV_ERR_NULL = -1,      /* required pointer is NULL */
+    GV_ERR_SHAPE = -2,     /* inconsistent / unsupported sizes */
+    GV_ERR_ALIGN = -3,     /* pointer or leading dimension breaks an alignment the call needs */
+    GV_ERR_WORKSPACE = -4  /* workspace too small */
+} gv_status;
+
+enum { GV_ACT_NONE = 0, GV_ACT_RELU = 1 };
+
+int gv_version(void);
+const char* gv_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Segment work items (device-side builder; replaces nothing in the reference -- DGL hides it).
+ * rowptr[n_seg+1] int32 CSR pointer.  Pass 1 counts, pass 2 fills (the caller scans in between).
+ *   gv_segment_items_count: n_chunks[s] = max(1, ceil(deg/chunk)); n_slots[s] = n_chunks>1 ? n_chunks : 0
+ *   gv_segment_items_fill : item_off / slot_off / fix_off are EXCLUSIVE scans of n_chunks / n_slots /
+ *                           (n_chunks>1), each with n_seg+1 entries.
+ */
+int gv_segment_items_count(const int32_t* rowptr, int n_seg, int chunk, int32_t* n_chunks, int32_t* n_slots,
+                           int32_t* is_split, void* stream);
+int gv_segment_items_fill(const int32_t* rowptr, int n_seg, int chunk, const int32_t* item_off,
+                          const int32_t* slot_off, const int32_t* fix_off, int32_t* items /*[n_items][4]*/,
+                          int32_t* fix /*[n_fix][4]*/, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  R-GCN block-diagonal ("bdd") relational aggregation.
+ * Replaces DGL RelGraphConv.bdd_message_func + update_all(fn.sum) + bias/self-loop/activation/dropout
+ * (call sites kgvae/model.py:54-59, :110-111, :209-211; semantics oracle/rgcn.py):
+ *   agg[v, b*so+j] = sum_{e: dst_e = v} norm_e * sum_i x[src_e, b*si+i] * W[etype_e, b, i, j]
+ *   out[v]         = keep[v] * keep_scale * act(agg[v] + addend[v])       (each part optional)
+ * addend is the self-loop term x@loop_weight + h_bias (gv_gemm_f32); with addend == NULL, act = NONE,
+ * keep == NULL the call returns the raw aggregate (multi-GPU partial).
+ * transpose_w = 1 contracts over the SECOND block index instead (backward w.r.t. x:
+ *   grad_x[s, b*si+i] = sum_{e: src_e = s} norm_e * sum_j g[dst_e, b*so+j] * W[etype_e, b, i, j]
+ * with blk_in = so, blk_out = si, nbr = dst ordered by src).
+ * coef_idx (optional) reads the edge coefficient as coef[coef_idx[e]] (DistMult backward reuses K1
+ * with si = so = 1, W = w_relation, coef = dL/dscore per triplet: kgvae/link_predict.py:57-63).
+ * partial: [n_slots, nb*blk_out] workspace (may be NULL when n_fix == 0).
+ */
+int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const int32_t* fix, int n_fix,
+                          const int32_t* nbr, const int32_t* etype, const float* coef, const int32_t* coef_idx,
+                          const float* feat, int ld_feat, const float* weight, int num_rels, int num_bases,
+                          int blk_in, int blk_out, int transpose_w,
+                          const float* addend, int ld_addend, int act, const uint8_t* keep, float keep_scale,
+                          float* out, int ld_out, float* partial, void* stream);
+
+/* K1 backward w.r.t. the block weights (edges ordered by relation; segments = relations):
+ *   grad_W[r, b, i, j] = sum_{e: etype_e = r} norm_e * x[src_e, b*si+i] * g[dst_e, b*so+j]
+ * partial: [n_slots, nb*si*so] workspace. accumulate != 0 adds into grad_w instead of overwriting. */
+int gv_rgcn_bdd_grad_weight(const int32_t* items, int n_items, const int32_t* fix, int n_fix,
+                            const int32_t* src, const int32_t* dst, const float* coef, const int32_t* coef_idx,
+                            const float* x, int ld_x, const float* g, int ld_g, int num_bases, int blk_in,
+                            int blk_out, float* grad_w, float* partial, int accumulate, void* stream);
+
+/* Epilogue alone (multi-GPU: after the all-reduce of partial aggregates) and its backward
+ *   fwd: out = keep*keep_scale*act(agg + addend)        bwd: g = grad_out*keep*keep_scale*act'(out) */
+int gv_rgcn_epilogue_fwd(const float* agg, const float* addend, int act, const uint8_t* keep, float keep_scale,
+                         float* out, int64_t n_rows, int n_cols, void* stream);
+int gv_rgcn_epilogue_bwd(const float* out, const float* grad_out, int act, const uint8_t* keep, float keep_scale,
+                         float* g, int64_t n_rows, int n_cols, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2/K4  dense fp32 GEMM on the f32 MFMA (v_mfma_f32_32x32x2_f32; exact fp32 fma chain):
+ *   C = act(op(A) @ op(B) + bias) (+ C if accumulate)      op(X) = X or X^T; bias (length N) optional.
+ * Replaces x@loop_weight (DGL RelGraphConv self loop), MaskedLinear (kgvae/flow_network.py:14-15)
+ * and their autograd backward.  split_k > 1 needs workspace of gv_gemm_workspace_bytes().
+ */
+int64_t gv_gemm_workspace_bytes(int m, int n, int k, int split_k);
+int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b, int ldb,
+                float* c, int ldc, const float* bias, int act, int accumulate, int split_k, void* workspace,
+                int64_t workspace_bytes, void* stream);
+
+/* column sums of an [m, n] matrix (bias gradients); workspace: 64*n floats. */
+int gv_colsum(const float* x, int64_t m, int n, int ld, float* out, float* workspace, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Embedding gather / gradient scatter (kgvae/model.py:185-191, nn.Embedding dense backward). */
+int gv_gather_rows(const float* table, const int64_t* ids, float* out, int64_t n, int h, void* stream);
+int gv_scatter_add_rows(const float* grad_out, const int64_t* ids, float* grad_table, int64_t n, int h, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  Gaussian parameters + reparameterisation (kgvae/utils.py:323-361, kgvae/model.py:112-113)
+ *   m = h2[:, :h]; v = softplus(h2[:, h:]) + 1e-8; z = m + eps*sqrt(v)
+ * bwd: grad_h2[:, :h] = gz + gm ; grad_h2[:, h:] = (gz*eps/(2 sqrt v) + gv) * sigmoid(raw)   (gm, gv optional) */
+int gv_reparam_fwd(const float* h2, const float* eps, float* z, float* v, int64_t n, int h, void* stream);
+int gv_reparam_bwd(const float* h2, const float* eps, const float* v, const float* gz, const float* gm,
+                   const float* gv, float* grad_h2, int64_t n, int h, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5  DistMult scorer + BCE-with-logits (kgvae/link_predict.py:57-63, :74-77)
+ *   score_t = sum_d e[s_t,d] w[r_t,d] e[o_t,d] (+ *bias);  loss = mean_t bce(score_t, label_t)
+ * triplets int32 [T,3] = (s, r, o).  workspace: 1024 floats.  bias: optional device scalar
+ * (flow_log_prob).  The backward w.r.t. e and w is K1 with 1x1 blocks over the triplet incidence
+ * index (see gv_rgcn_bdd_aggregate / gv_rgcn_bdd_grad_weight).
+ *   gv_bce_grad: dscore_t = (*gloss) * (sigmoid(score_t) - label_t) / T ;  *dbias (+)= sum_t dscore_t */
+int gv_distmult_bce_fwd(const float* embed, int ld_e, const float* w_rel, int ld_w, const int32_t* triplets,
+                        const float* labels, const float* bias, float* score, float* loss, float* workspace,
+                        int64_t t, int h, void* stream);
+int gv_bce_grad(const float* score, const float* labels, const float* gloss, float* dscore, float* dbias,
+                float* workspace, int64_t t, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K6  fused reductions
+ *   gv_mean_sq : *out (+)= scale * sum(x^2)            (regularization_loss, kgvae/link_predict.py:68-69)
+ *   gv_axpby   : y = alpha * (*a) * x + beta * y        (a: optional device scalar, e.g. an upstream grad)
+ *   gv_kl_*    : KGVAE.get_kl (kgvae/model.py:82-87; kgvae/utils.py:364-428)
+ *       kl = mean_n [ logN(z; m, v) + flp - log(1/k sum_j N(z; m_j, v_j)) ],  (m_j, v_j) from z_pre (2k, h)
+ *     fwd writes resp[n, k] (mixture responsibilities) for the backward.
+ *     bwd: gz, gm, gv [n,h] (overwritten), g_zpre [2k,h] (overwritten, deterministic 2-pass), scaled by *gkl.
+ */
+int gv_mean_sq(const float* x, int64_t n, float scale, float* out, float* workspace, int accumulate, void* stream);
+int gv_axpby(int64_t n, const float* a, float alpha, const float* x, float beta, float* y, void* stream);
+int gv_mul(int64_t n, const float* a, const float* b, float* out, void* stream);
+int64_t gv_kl_workspace_bytes(int64_t n, int h, int k);
+int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre, const float* flp,
+              float* resp, float* kl, float* workspace, int64_t n, int h, int k, void* stream);
+int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre, const float* resp,
+              const float* gkl, float* gz, float* gm, float* gv, float* g_zpre, float* workspace, int64_t n, int h,
+              int k, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4  IAF / MADE update step (kgvae/flow_network.py:93-96); the masked linears are gv_gemm_f32.
+ *   net = [mu | alpha] (n, 2d);  x_new[:, c] = colcount[c] > 0 ? z*exp(alpha+mu) : x_old
+ *   bwd multiplies the column's gradient by colcount[c] (autograd's duplicate-index behaviour,
+ *   pinned by tests/golden/made.npz).  gv_rowsum: log_det = sum_d alpha.  gv_reverse_cols: PermuteLayer. */
+int gv_iaf_update_fwd(const float* z, const float* net, const float* x_old, const int32_t* colcount, float* x_new,
+                      int64_t n, int d, void* stream);
+int gv_iaf_update_bwd(const float* z, const float* net, const int32_t* colcount, const float* g_xnew,
+                      const float* g_logdet /*[n] or NULL*/, float* g_z, float* g_net, float* g_xold, int64_t n, int d,
+                      void* stream);
+int gv_rowsum(const float* x, int ld, int col0, int ncols, float* out, int64_t n, void* stream);
+int gv_reverse_cols(const float* x, float* out, int64_t n, int d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a-11  gradient clipping + Adam (kgvae/link_predict.py:227-228) over a flat parameter arena:
+ *   gv_sumsq_accum : *out += sum(g^2)   (call per tensor or once on the flat grad arena)
+ *   gv_adam_step   : clip coefficient min(1, max_norm/(sqrt(*sumsq)+1e-6)) applied to g on the fly,
+ *                    then torch.optim.Adam's update (bias correction from *step, eps outside the sqrt). */
+int gv_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, const float* sumsq,
+                 float max_norm, float lr, float beta1, float beta2, float eps, const float* step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCNVAE_H */

@@ -1,0 +1,274 @@
+"""HIP kernels (through the C ABI) against the CPU oracle, op by op.   pytest -m gpu
+
+Tolerance: north_star asks for 1e-4 (fp32) against the reference's CPU path; every comparison
+below uses rtol=1e-4 with an absolute floor of 1e-5 x the output scale."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kgvae as okg
+from oracle import prob as oprob
+from oracle import rgcn as orgcn
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol=1e-4, atol_scale=1e-5, msg=''):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    atol = atol_scale * max(1.0, float(b.abs().max()) if b.numel() else 1.0)
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol, msg=lambda m: f'{msg}: {m}')
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from gcn_vae_amd import ops as _ops
+    return _ops
+
+
+def zipf_graph(n, e, r, seed, skew=1.1):
+    rs = np.random.RandomState(seed)
+    p = (np.arange(n) + 1.0) ** (-skew)
+    p /= p.sum()
+    src = rs.choice(n, size=e, p=p)
+    dst = rs.choice(n, size=e, p=p)
+    et = rs.randint(0, r, size=e)
+    order = np.lexsort((et, src, dst))
+    src, dst, et = src[order], dst[order], et[order]
+    deg = np.bincount(dst, minlength=n).astype(np.float32)
+    norm = (1.0 / np.maximum(deg, 1))[dst].astype(np.float32)
+    return (torch.from_numpy(src), torch.from_numpy(dst), torch.from_numpy(et), torch.from_numpy(norm).view(-1, 1))
+
+
+def test_segment_items(ops):
+    rs = np.random.RandomState(0)
+    deg = rs.randint(0, 40, size=200)
+    deg[7], deg[50], deg[199] = 1000, 0, 257
+    rowptr = np.zeros(201, dtype=np.int32)
+    rowptr[1:] = np.cumsum(deg)
+    for chunk in (16, 64, 256):
+        seg = ops.build_segment_items(torch.from_numpy(rowptr).cuda(), chunk)
+        items = seg.items[:seg.n_items].cpu().numpy()
+        fix = seg.fix[:seg.n_fix].cpu().numpy()
+        exp_items, exp_fix, slot = [], [], 0
+        for s in range(200):
+            nch = max(1, -(-deg[s] // chunk))
+            if nch > 1:
+                exp_fix.append((s, slot, nch, 0))
+            for k in range(nch):
+                b = rowptr[s] + k * chunk
+                exp_items.append((s, b, min(rowptr[s + 1], b + chunk), slot + k if nch > 1 else -1))
+            if nch > 1:
+                slot += nch
+        assert np.array_equal(items, np.array(exp_items, dtype=np.int32))
+        assert np.array_equal(fix, np.array(exp_fix, dtype=np.int32).reshape(-1, 4))
+        assert seg.n_slots == slot
+
+
+CASES = [  # (in, out, num_bases)  -> block sizes; covers the fast instantiations and the generic kernel
+    (200, 200, 100), (200, 400, 100),   # C2 layer 1 / 2   (2x2, 2x4)
+    (16, 16, 4), (16, 32, 4),           # C1               (4x4, 4x8)
+    (40, 40, 40), (40, 80, 40),         # 1x1, 1x2
+    (30, 30, 6), (30, 60, 6),           # 5x5, 5x10 -> generic
+    (200, 200, 20),                     # C3 10x10 -> generic
+    (24, 12, 3),                        # 8x4 -> generic (non-transposed), bwd-x 4x8
+]
+
+
+@pytest.mark.parametrize('fin,fout,nb', CASES)
+@pytest.mark.parametrize('chunk', [8, 256])
+def test_rel_graph_conv_fwd_bwd(ops, fin, fout, nb, chunk):
+    n, e, r = 300, 4000, 120
+    src, dst, et, norm = zipf_graph(n, e, r, seed=fin + fout + nb)
+    gen = torch.Generator().manual_seed(fin * 7 + nb)
+    x = torch.randn(n, fin, generator=gen)
+    p = orgcn.init_params(fin, fout, r, 'bdd', nb, True, True, gen)
+    p['h_bias'] = torch.randn(fout, generator=gen) * 0.1
+    keep = (torch.rand(n, fout, generator=gen) > 0.2).to(torch.uint8)
+    gout = torch.randn(n, fout, generator=gen)
+    for act_id, act in ((1, torch.relu), (0, None)):
+        # oracle
+        xo = x.clone().requires_grad_(True)
+        po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        ho = orgcn.rel_graph_conv(xo, src, dst, et, norm, po, 'bdd', nb, act, dropout_keep=keep, dropout_p=0.2)
+        ho.backward(gout)
+        # HIP
+        gidx = ops.GraphIndex(src.cuda(), dst.cuda(), n, chunk=chunk)
+        etc = et.cuda()
+        ridx = ops.RelationIndex(gidx, etc, r, chunk=max(4, chunk // 2))
+        xg = x.cuda().requires_grad_(True)
+        pg = {k: v.cuda().requires_grad_(True) for k, v in p.items()}
+        hg = ops.rel_graph_conv_bdd(xg, pg['weight'], pg['h_bias'], pg['loop_weight'], norm.cuda(), gidx, ridx, nb,
+                                    act_id, keep.cuda(), 1.0 / 0.8)
+        hg.backward(gout.cuda())
+        close(hg, ho, msg='forward')
+        close(xg.grad, xo.grad, msg='grad_x')
+        close(pg['weight'].grad, po['weight'].grad, msg='grad_weight')
+        close(pg['h_bias'].grad, po['h_bias'].grad, msg='grad_bias')
+        close(pg['loop_weight'].grad, po['loop_weight'].grad, msg='grad_loop')
+
+
+def test_rel_graph_conv_unsorted_edges_and_empty_rows(ops):
+    n, e, r, fin, fout, nb = 120, 900, 5, 8, 16, 4
+    src, dst, et, norm = zipf_graph(n, e, r, seed=3)
+    perm = torch.randperm(e, generator=torch.Generator().manual_seed(1))
+    src, dst, et, norm = src[perm], dst[perm], et[perm], norm[perm]
+    dst = torch.where(dst >= n - 5, torch.zeros_like(dst), dst)      # last 5 nodes: in-degree 0
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(n, fin, generator=gen)
+    p = orgcn.init_params(fin, fout, r, 'bdd', nb, True, True, gen)
+    ho = orgcn.rel_graph_conv(x, src, dst, et, norm, p, 'bdd', nb, torch.relu)
+    gidx = ops.GraphIndex(src.cuda(), dst.cuda(), n)
+    assert gidx.by_dst.perm is not None
+    ridx = gidx.relation_index(et.cuda(), r)
+    hg = ops.rel_graph_conv_bdd(x.cuda(), p['weight'].cuda(), p['h_bias'].cuda(), p['loop_weight'].cuda(),
+                                norm.cuda(), gidx, ridx, nb, 1)
+    close(hg, ho)
+    # no self loop, no bias, no norm
+    ho2 = orgcn.rel_graph_conv(x, src, dst, et, None, {'weight': p['weight']}, 'bdd', nb, None)
+    hg2 = ops.rel_graph_conv_bdd(x.cuda(), p['weight'].cuda(), None, None, None, gidx, ridx, nb, 0)
+    close(hg2, ho2)
+    assert float(hg2[n - 5:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('m,n,k', [(300, 200, 200), (1000, 400, 200), (37, 19, 53), (128, 64, 16), (5, 3, 2),
+                                   (200, 400, 3000)])
+def test_gemm_all_layouts(ops, m, n, k):
+    gen = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=gen)
+    b = torch.randn(k, n, generator=gen)
+    bias = torch.randn(n, generator=gen)
+    ref = a.double() @ b.double()
+    close(ops.gemm(a.cuda(), b.cuda()), ref)
+    close(ops.gemm(a.t().contiguous().cuda(), b.cuda(), trans_a=True), ref)
+    close(ops.gemm(a.cuda(), b.t().contiguous().cuda(), trans_b=True), ref)
+    close(ops.gemm(a.t().contiguous().cuda(), b.t().contiguous().cuda(), trans_a=True, trans_b=True), ref)
+    close(ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), act=1), torch.relu(ref + bias.double()))
+    c0 = torch.randn(m, n, generator=gen)
+    close(ops.gemm(a.cuda(), b.cuda(), out=c0.clone().cuda(), accumulate=True), ref + c0.double())
+    for sk in (2, 7):
+        close(ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), split_k=sk), ref + bias.double())
+        close(ops.gemm(a.t().contiguous().cuda(), b.cuda(), trans_a=True, split_k=sk), ref)
+    close(ops.colsum(a.cuda()), a.double().sum(0))
+
+
+def test_linear_fn(ops):
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(257, 200, generator=gen)
+    w = torch.randn(400, 200, generator=gen) * 0.1
+    b = torch.randn(400, generator=gen) * 0.1
+    go = torch.randn(257, 400, generator=gen)
+    for act_id, f in ((1, torch.relu), (0, lambda t: t)):
+        xo, wo, bo = (t.clone().requires_grad_(True) for t in (x, w, b))
+        yo = f(torch.nn.functional.linear(xo, wo, bo))
+        yo.backward(go)
+        xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+        yg = ops.linear(xg, wg, bg, act_id)
+        yg.backward(go.cuda())
+        close(yg, yo)
+        close(xg.grad, xo.grad)
+        close(wg.grad, wo.grad)
+        close(bg.grad, bo.grad)
+
+
+def test_embedding(ops):
+    gen = torch.Generator().manual_seed(0)
+    table = torch.randn(50, 24, generator=gen)
+    ids = torch.tensor([3, 7, 7, 0, 49, 3, 3]).view(-1, 1)
+    go = torch.randn(7, 24, generator=gen)
+    to = table.clone().requires_grad_(True)
+    torch.nn.functional.embedding(ids.squeeze(), to).backward(go)
+    tg = table.cuda().requires_grad_(True)
+    out = ops.embedding(tg, ids.cuda())
+    out.backward(go.cuda())
+    close(out, table[ids.squeeze()])
+    close(tg.grad, to.grad)
+
+
+def test_reparam(ops):
+    gen = torch.Generator().manual_seed(1)
+    h2 = torch.randn(301, 80, generator=gen) * 3
+    h2[0, 40:48] = torch.tensor([-30.0, -5.0, 0.0, 5.0, 19.9, 20.1, 50.0, 1e-3])
+    eps = torch.randn(301, 40, generator=gen)
+    gz, gm, gv = (torch.randn(301, 40, generator=gen) for _ in range(3))
+    ho = h2.clone().requires_grad_(True)
+    m, v = oprob.gaussian_parameters(ho)
+    z = oprob.sample_gaussian(m, v, eps)
+    (z * gz + m * gm + v * gv).sum().backward()
+    hg = h2.cuda().requires_grad_(True)
+    zg, mg, vg = ops.reparam(hg, eps.cuda())
+    (zg * gz.cuda() + mg * gm.cuda() + vg * gv.cuda()).sum().backward()
+    close(zg, z)
+    close(mg, m)
+    close(vg, v)
+    close(hg.grad, ho.grad)
+
+
+def test_distmult_bce_and_score(ops):
+    gen = torch.Generator().manual_seed(2)
+    n, r, h, T = 400, 9, 200, 5000
+    emb = torch.randn(n, h, generator=gen) * 0.3
+    w = torch.randn(r, h, generator=gen) * 0.3
+    rs = np.random.RandomState(0)
+    p = (np.arange(n) + 1.0) ** -1.0
+    p /= p.sum()
+    trip = torch.from_numpy(np.stack([rs.choice(n, T, p=p), rs.randint(0, r, T), rs.choice(n, T, p=p)], 1))
+    labels = (torch.rand(T, generator=gen) > 0.7).float()
+    flp = torch.tensor(-0.37)
+    eo, wo, fo = emb.clone().requires_grad_(True), w.clone().requires_grad_(True), flp.clone().requires_grad_(True)
+    so = okg.distmult_score(eo, wo, trip) + fo
+    lo = torch.nn.functional.binary_cross_entropy_with_logits(so, labels)
+    (lo * 1.7).backward()
+    tidx = ops.TripletIndex(trip.cuda(), n, r, chunk=64, chunk_rel=32)
+    eg, wg, fg = emb.cuda().requires_grad_(True), w.cuda().requires_grad_(True), flp.cuda().requires_grad_(True)
+    lg, sg = ops.distmult_bce(eg, wg, fg, labels.cuda(), tidx)
+    (lg * 1.7).backward()
+    close(sg, so)
+    close(lg, lo)
+    close(eg.grad, eo.grad)
+    close(wg.grad, wo.grad)
+    close(fg.grad, fo.grad)
+    # calc_score path with an arbitrary upstream gradient
+    gs = torch.randn(T, generator=gen)
+    eo2, wo2 = emb.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    okg.distmult_score(eo2, wo2, trip).backward(gs)
+    eg2, wg2 = emb.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    s2 = ops.distmult_score(eg2, wg2, tidx)
+    s2.backward(gs.cuda())
+    close(s2, so - flp)
+    close(eg2.grad, eo2.grad)
+    close(wg2.grad, wo2.grad)
+
+
+def test_mean_sq_and_kl(ops):
+    gen = torch.Generator().manual_seed(3)
+    n, h, k = 333, 200, 10
+    z = torch.randn(n, h, generator=gen)
+    m = torch.randn(n, h, generator=gen) * 0.5
+    v = torch.rand(n, h, generator=gen) + 0.2
+    z_pre = torch.randn(1, 2 * k, h, generator=gen) / np.sqrt(k * h) * 30
+    flp = torch.tensor(0.83)
+    xo = z.clone().requires_grad_(True)
+    (xo.pow(2).mean() * 3).backward()
+    xg = z.cuda().requires_grad_(True)
+    ms = ops.mean_sq(xg)
+    (ms * 3).backward()
+    close(ms, z.pow(2).mean())
+    close(xg.grad, xo.grad)
+    to = [t.clone().requires_grad_(True) for t in (z, m, v, z_pre, flp)]
+    klo = okg.kl_term(to[0], to[1], to[2], to[3], to[4])
+    (klo * 2.5).backward()
+    tg = [t.cuda().requires_grad_(True) for t in (z, m, v, z_pre, flp)]
+    klg = ops.kl_to_mixture(tg[0], tg[1], tg[2], tg[3].squeeze(0), tg[4])
+    (klg * 2.5).backward()
+    close(klg, klo)
+    for a, b, nm in zip(tg, to, ('z', 'm', 'v', 'z_pre', 'flp')):
+        close(a.grad, b.grad, msg=nm)
+    # flp = None reads as 0 (documented fix of the reference's None + tensor crash)
+    close(ops.kl_to_mixture(tg[0].detach(), tg[1].detach(), tg[2].detach(), tg[3].detach().squeeze(0), None),
+          okg.kl_term(z, m, v, z_pre, None))
+
+
+def test_product_rejects_cpu_tensors(ops):
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.gemm(torch.randn(4, 4), torch.randn(4, 4))
