@@ -1,0 +1,182 @@
+"""Encoders with the reference's class names and signatures (kgvae/model.py:13-211):
+``KGVAE`` (embedding -> 2 x RelGraphConv(bdd) -> Gaussian parameters -> reparameterise -> IAF),
+``BaseRGCN`` / ``RGCN`` and the small wrapper layers.  state_dict keys are the reference's."""
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops, prob
+from .flows import MADE, PermuteLayer
+from .layers import RelGraphConv
+
+
+class EmbeddingLayer(nn.Module):
+    def __init__(self, num_nodes, h_dim):
+        super().__init__()
+        self.embedding = nn.Embedding(num_nodes, h_dim)
+
+    def forward(self, g, h, r, norm):
+        return ops.embedding(self.embedding.weight, h.squeeze())
+
+
+class DistLayer(nn.Module):
+    """Present in the reference (kgvae/model.py:194-200) but never instantiated."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.linear = nn.Linear(in_dim, out_dim)
+
+    def forward(self, g, h, r, norm):
+        return ops.linear(h.squeeze(), self.linear.weight, self.linear.bias)
+
+
+class KGVAE(nn.Module):
+    def __init__(self, num_nodes, h_dim, out_dim, num_rels, num_bases, num_hidden_layers=1, dropout=0,
+                 use_self_loop=False, use_cuda=True, k=10, n_flows=0, verbose=False):
+        super().__init__()
+        self.num_nodes, self.h_dim, self.out_dim, self.num_rels = num_nodes, h_dim, out_dim, num_rels
+        self.num_bases = None if num_bases < 0 else num_bases
+        self.num_hidden_layers, self.dropout = num_hidden_layers, dropout
+        self.use_self_loop, self.use_cuda = use_self_loop, use_cuda
+        self.k = k
+        if verbose:
+            print("use cuda", self.use_cuda)
+            print(f"Mixture of {self.k} Gaussians.")
+        self.flow_log_prob = None
+        self.build_encoder()
+        self.z_pre = nn.Parameter(torch.randn(1, 2 * self.k, self.h_dim) / np.sqrt(self.k * self.h_dim))
+        self.pi = nn.Parameter(torch.ones(k) / k, requires_grad=False)
+        self.n_flows = n_flows
+        if self.n_flows > 0:
+            if verbose:
+                print(f"Sequence of {self.n_flows} Flow transforms.")
+            self.build_iaf()
+        # parity / graph-capture hooks (None = draw on the device / host as the reference does)
+        self.eps_override = None          # (N, h) standard-normal draw for the reparameterisation
+        self.mmd_eps_override = None      # (num_sample, h) draw for the prior samples of get_mmd
+        self.mmd_index_override = None    # int64 (num_sample,) posterior row pick of get_mmd
+
+    def build_iaf(self):
+        blocks = []
+        for _ in range(self.n_flows):
+            blocks.append(MADE(self.h_dim, self.h_dim, self.n_flows))
+            blocks.append(PermuteLayer(self.h_dim))
+        self.nf = nn.Sequential(*blocks)
+
+    def build_encoder(self):
+        self.input_layer = EmbeddingLayer(self.num_nodes, self.h_dim)
+        self.rconv_layer_1 = RelGraphConv(self.h_dim, self.h_dim, self.num_rels, "bdd", self.num_bases,
+                                          activation=nn.ReLU(), self_loop=True, dropout=self.dropout)
+        self.rconv_layer_2 = RelGraphConv(self.h_dim, self.h_dim * 2, self.num_rels, "bdd", self.num_bases,
+                                          activation=None, self_loop=True, dropout=self.dropout)
+
+    def sample_z(self, batch):
+        m, v = prob.gaussian_parameters(self.z_pre.squeeze(0), dim=0)
+        idx = torch.distributions.categorical.Categorical(self.pi).sample((batch,))
+        x = prob.sample_gaussian(m[idx], v[idx])
+        if self.n_flows > 0:
+            for flow in self.nf[::-1]:
+                x, _ = flow.inverse(x)
+        return x
+
+    def compute_kernel(self, x, y):
+        dim = x.size(1)
+        d2 = (x.unsqueeze(1) - y.unsqueeze(0)).pow(2).mean(2) / float(dim)
+        return torch.exp(-d2)
+
+    def get_kl(self, z):
+        # the reference adds ``self.flow_log_prob`` unconditionally and crashes when n_flows == 0
+        # (None + tensor, kgvae/model.py:86); None is read as "no flow term".
+        return ops.kl_to_mixture(z, self.z_mean, self.z_sigma, self.z_pre.squeeze(0), self.flow_log_prob)
+
+    def get_mmd(self, z):
+        m_mix, s_mix = prob.gaussian_parameters(self.z_pre, dim=1)
+        num_sample = 200
+        z_pri = prob.sample_gaussian(m_mix, s_mix, repeat=num_sample // self.k, eps=self.mmd_eps_override)
+        if self.n_flows > 0:
+            for flow in self.nf:
+                z_pri, _ = flow.forward(z_pri)
+        if self.mmd_index_override is not None:
+            pick = self.mmd_index_override
+        else:
+            pick = torch.tensor(random.sample(range(z.shape[0]), num_sample), device=z.device)
+        z_post = z[pick]
+        return (self.compute_kernel(z_pri, z_pri).mean() + self.compute_kernel(z_post, z_post).mean()
+                - 2 * self.compute_kernel(z_pri, z_post).mean())
+
+    def get_flow_log_prob(self):
+        return self.flow_log_prob
+
+    def forward(self, g, h, r, norm):
+        self.node_id = h.squeeze()
+        h = self.input_layer(g, h, r, norm)
+        h = self.rconv_layer_1(g, h, r, norm)
+        h = self.rconv_layer_2(g, h, r, norm)
+        eps = self.eps_override if self.eps_override is not None else \
+            torch.randn(h.shape[0], h.shape[1] // 2, device=h.device, dtype=h.dtype)
+        z, self.z_mean, self.z_sigma = ops.reparam(h, eps)
+        if self.n_flows > 0:
+            log_det_sum = None
+            for flow in self.nf:
+                z, log_det = flow.forward(z)
+                if isinstance(flow, MADE):            # PermuteLayer contributes zeros
+                    log_det_sum = log_det if log_det_sum is None else log_det_sum + log_det
+            self.flow_log_prob = torch.mean(log_det_sum.view(-1, 1))
+        return z
+
+
+class BaseRGCN(nn.Module):
+    def __init__(self, num_nodes, h_dim, out_dim, num_rels, num_bases, num_hidden_layers=1, dropout=0,
+                 use_self_loop=False, use_cuda=False, **unused):
+        # **unused: LinkPredict passes k= / n_flows= to every encoder class; the reference's BaseRGCN
+        # does not accept them and ``--model-class RGCN`` dies with a TypeError (kgvae/link_predict.py:35-46).
+        super().__init__()
+        self.num_nodes, self.h_dim, self.out_dim, self.num_rels = num_nodes, h_dim, out_dim, num_rels
+        self.num_bases = None if num_bases < 0 else num_bases
+        self.num_hidden_layers, self.dropout = num_hidden_layers, dropout
+        self.use_self_loop, self.use_cuda = use_self_loop, use_cuda
+        self.build_model()
+
+    def build_model(self):
+        self.layers = nn.ModuleList()
+        i2h = self.build_input_layer()
+        if i2h is not None:
+            self.layers.append(i2h)
+        for idx in range(self.num_hidden_layers):
+            self.layers.append(self.build_hidden_layer(idx))
+        h2o = self.build_output_layer()
+        if h2o is not None:
+            self.layers.append(h2o)
+
+    def build_input_layer(self):
+        return None
+
+    def build_hidden_layer(self, idx):
+        raise NotImplementedError
+
+    def build_output_layer(self):
+        return None
+
+    def forward(self, g, h, r, norm):
+        for layer in self.layers:
+            h = layer(g, h, r, norm)
+        return h
+
+    def get_kl(self, z):
+        return torch.zeros(1, device=z.device)
+
+    def get_flow_log_prob(self):
+        return None
+
+
+class RGCN(BaseRGCN):
+    def build_input_layer(self):
+        return EmbeddingLayer(self.num_nodes, self.h_dim)
+
+    def build_hidden_layer(self, idx):
+        act = F.relu if idx < self.num_hidden_layers - 1 else None
+        return RelGraphConv(self.h_dim, self.h_dim, self.num_rels, "bdd", self.num_bases, activation=act,
+                            self_loop=True, dropout=self.dropout)

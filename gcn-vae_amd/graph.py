@@ -1,0 +1,96 @@
+"""Graph handle with the DGL-0.4 ``DGLGraph`` surface the reference touches
+(kgvae/utils.py:127-150, kgvae/link_predict.py:95-100, :216) plus the device index cache the
+HIP kernels need.  Edge arrays stay on the host until a layer asks for ``device_index``."""
+import numpy as np
+import torch
+
+from . import ops
+
+
+class _EdgeView:
+    def __init__(self, g):
+        self.src = {k: v[g._src.to(v.device)] for k, v in g.ndata.items()}
+        self.dst = {k: v[g._dst.to(v.device)] for k, v in g.ndata.items()}
+        self.data = g.edata
+
+
+class KGraph:
+    def __init__(self):
+        self._n = 0
+        self._src = torch.zeros(0, dtype=torch.int64)
+        self._dst = torch.zeros(0, dtype=torch.int64)
+        self.ndata, self.edata = {}, {}
+        self._index = {}
+
+    # -- construction ---------------------------------------------------------------------------
+    def add_nodes(self, n):
+        self._n += int(n)
+        self._index.clear()
+
+    def add_edges(self, src, dst):
+        s = torch.as_tensor(np.asarray(src) if not isinstance(src, torch.Tensor) else src, dtype=torch.int64).cpu()
+        d = torch.as_tensor(np.asarray(dst) if not isinstance(dst, torch.Tensor) else dst, dtype=torch.int64).cpu()
+        if s.shape != d.shape:
+            raise ValueError('src and dst must have the same length')
+        if s.numel() and (int(torch.max(torch.max(s), torch.max(d))) >= self._n or int(torch.min(torch.min(s), torch.min(d))) < 0):
+            raise ValueError('edge endpoint out of range; call add_nodes first')
+        self._src = torch.cat([self._src, s.reshape(-1)])
+        self._dst = torch.cat([self._dst, d.reshape(-1)])
+        self._index.clear()
+
+    # -- queries --------------------------------------------------------------------------------
+    def number_of_nodes(self):
+        return self._n
+
+    def number_of_edges(self):
+        return int(self._src.numel())
+
+    def __len__(self):
+        return self._n
+
+    def edges(self):
+        return self._src, self._dst
+
+    def in_degrees(self, nodes=None):
+        deg = torch.bincount(self._dst, minlength=self._n)
+        if nodes is None:
+            return deg
+        return deg[torch.as_tensor(list(nodes) if not isinstance(nodes, torch.Tensor) else nodes, dtype=torch.int64)]
+
+    def local_var(self):
+        g = KGraph()
+        g._n, g._src, g._dst = self._n, self._src, self._dst
+        g.ndata, g.edata = dict(self.ndata), dict(self.edata)
+        g._index = self._index          # the device index depends on (src, dst) only
+        return g
+
+    def apply_edges(self, fn):
+        self.edata.update(fn(_EdgeView(self)))
+
+    # -- device side ----------------------------------------------------------------------------
+    def device_index(self, device) -> 'ops.GraphIndex':
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise RuntimeError('the R-GCN kernels run on a ROCm device only; there is no CPU fallback '
+                               f'(asked for an index on {device})')
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        idx = self._index.get(key)
+        if idx is None:
+            idx = self._index[key] = ops.GraphIndex(self._src.to(device), self._dst.to(device), self._n)
+        return idx
+
+
+DGLGraph = KGraph
+
+
+def graph_index_of(g, device):
+    """``device_index`` of our handle, or an index built from any object exposing edges()/number_of_nodes()."""
+    if hasattr(g, 'device_index'):
+        return g.device_index(device)
+    cache = g.__dict__.setdefault('_gv_index', {})
+    key = str(device)
+    if key not in cache:
+        src, dst = g.edges()
+        cache[key] = ops.GraphIndex(torch.as_tensor(src).to(device), torch.as_tensor(dst).to(device),
+                                    g.number_of_nodes())
+    return cache[key]

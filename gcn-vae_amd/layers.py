@@ -1,0 +1,104 @@
+"""``RelGraphConv`` -- the R-GCN layer of DGL 0.4.x, re-implemented on the gfx950 K1/K2 kernels.
+
+Interface and state_dict keys follow the DGL layer as the reference uses it
+(kgvae/model.py:54-59, :110-111, :209-211; kgvae/entity_classify.py:31-43):
+
+    RelGraphConv(in_feat, out_feat, num_rels, regularizer="basis", num_bases=None, bias=True,
+                 activation=None, self_loop=False, dropout=0.0).forward(g, x, etypes, norm=None)
+
+parameters ``weight`` [(R, B*si*so) for "bdd", (nb, in, out) for "basis"], ``w_comp`` (basis, nb < R),
+``h_bias`` (zeros), ``loop_weight``; xavier_uniform with relu gain, created in DGL's order so that a
+seeded construction reproduces the reference's initial weights.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .graph import graph_index_of
+
+
+def _activation_id(activation):
+    """Map the reference's activations onto the fused epilogue; anything else runs after the kernel."""
+    if activation is None:
+        return ops.ACT_NONE, None
+    if activation is F.relu or activation is torch.relu or isinstance(activation, nn.ReLU):
+        return ops.ACT_RELU, None
+    return ops.ACT_NONE, activation
+
+
+class RelGraphConv(nn.Module):
+    def __init__(self, in_feat, out_feat, num_rels, regularizer="basis", num_bases=None, bias=True,
+                 activation=None, self_loop=False, dropout=0.0):
+        super().__init__()
+        self.in_feat, self.out_feat, self.num_rels = in_feat, out_feat, num_rels
+        self.regularizer = regularizer
+        self.num_bases = num_bases
+        if self.num_bases is None or self.num_bases > self.num_rels or self.num_bases < 0:
+            self.num_bases = self.num_rels
+        self.bias, self.activation, self.self_loop = bias, activation, self_loop
+        gain = nn.init.calculate_gain('relu')
+        if regularizer == "basis":
+            self.weight = nn.Parameter(torch.Tensor(self.num_bases, in_feat, out_feat))
+            if self.num_bases < self.num_rels:
+                self.w_comp = nn.Parameter(torch.Tensor(self.num_rels, self.num_bases))
+            nn.init.xavier_uniform_(self.weight, gain=gain)
+            if self.num_bases < self.num_rels:
+                nn.init.xavier_uniform_(self.w_comp, gain=gain)
+        elif regularizer == "bdd":
+            if in_feat % self.num_bases != 0 or out_feat % self.num_bases != 0:
+                raise ValueError('Feature size must be a multiplier of num_bases.')
+            self.submat_in = in_feat // self.num_bases
+            self.submat_out = out_feat // self.num_bases
+            self.weight = nn.Parameter(torch.Tensor(self.num_rels, self.num_bases * self.submat_in * self.submat_out))
+            nn.init.xavier_uniform_(self.weight, gain=gain)
+        else:
+            raise ValueError("Regularizer must be either 'basis' or 'bdd'")
+        if self.bias:
+            self.h_bias = nn.Parameter(torch.Tensor(out_feat))
+            nn.init.zeros_(self.h_bias)
+        if self.self_loop:
+            self.loop_weight = nn.Parameter(torch.Tensor(in_feat, out_feat))
+            nn.init.xavier_uniform_(self.loop_weight, gain=gain)
+        self.dropout = nn.Dropout(dropout)
+        self.keep_mask_override = None   # parity mode: a uint8 (N, out) keep mask instead of the device RNG
+        self.reduce_hook = None          # multi-GPU: sums the partial aggregate over the edge shards
+
+    def _keep_mask(self, n, device):
+        p = self.dropout.p
+        if self.keep_mask_override is not None:
+            return self.keep_mask_override.to(device=device, dtype=torch.uint8).contiguous(), 1.0 / (1.0 - p)
+        if not self.training or p <= 0.0:
+            return None, 1.0
+        keep = torch.empty(n, self.out_feat, dtype=torch.uint8, device=device).bernoulli_(1.0 - p)
+        return keep, 1.0 / (1.0 - p)
+
+    def forward(self, g, x, etypes, norm=None):
+        if x.dtype == torch.int64 and x.dim() == 1:
+            if self.regularizer == 'bdd':
+                raise TypeError('Block decomposition does not allow integer ID feature.')
+            raise NotImplementedError('integer-id node features (entity_classify input layer) are out of scope')
+        gidx = graph_index_of(g, x.device)
+        ridx = gidx.relation_index(etypes, self.num_rels)
+        act_id, post_act = _activation_id(self.activation if self.activation else None)
+        keep, scale = self._keep_mask(x.shape[0], x.device)
+        h_bias = self.h_bias if self.bias else None
+        loop_w = self.loop_weight if self.self_loop else None
+        if post_act is not None and keep is not None:      # unknown activation: dropout must follow it
+            late_keep, keep = keep, None
+        else:
+            late_keep = None
+        if self.regularizer == 'bdd':
+            weight, nb = self.weight, self.num_bases
+        else:
+            # basis: W_r = sum_b w_comp[r, b] V_b, then one dense (in x out) "block" per relation
+            flat = self.weight.view(self.num_bases, self.in_feat * self.out_feat)
+            weight = ops.matmul(self.w_comp, flat) if self.num_bases < self.num_rels else flat
+            nb = 1
+        h = ops.rel_graph_conv_bdd(x, weight, h_bias, loop_w, norm, gidx, ridx, nb, act_id, keep,
+                                   scale if keep is not None else 1.0, self.reduce_hook)
+        if post_act is not None:
+            h = post_act(h)
+            if late_keep is not None:
+                h = h * (late_keep.to(h.dtype) * scale)
+        return h

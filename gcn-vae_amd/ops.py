@@ -689,3 +689,25 @@ class _ReverseCols(torch.autograd.Function):
 
 def reverse_cols(x):
     return _ReverseCols.apply(x)
+
+
+class _MatMul(torch.autograd.Function):
+    """Plain differentiable a @ b on the f32 MFMA GEMM (basis combination W = w_comp @ V)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return gemm(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _chk(g.contiguous(), name='g')
+        ga = gemm(g, b, trans_b=True) if ctx.needs_input_grad[0] else None
+        gb = gemm(a, g, trans_a=True, split_k=pick_split_k(a.shape[1], g.shape[1], a.shape[0])) \
+            if ctx.needs_input_grad[1] else None
+        return ga, gb
+
+
+def matmul(a, b):
+    return _MatMul.apply(a, b)

@@ -1,0 +1,56 @@
+"""Raw-MRR evaluation with the reference's function names (kgvae/utils.py:180-221, :293-314).
+
+The reference scores a batch against every entity by materialising a (h, Eb, V) outer-product
+tensor and summing over h; here that is ONE f32 MFMA GEMM (Eb, h) @ (h, V) (``ops.gemm``), followed
+by the reference's own ``+ flow_log_prob``, sigmoid and rank extraction.  Ranks come from a count of
+strictly larger scores (ties broken towards the better rank), which equals the reference's
+sort-and-find whenever scores are tie free; sigmoid saturation makes the reference's own ranks
+depend on ``torch.sort``'s unspecified tie order, so no implementation can match it there.
+"""
+import torch
+
+from . import ops
+
+
+def sort_and_rank(score, target):
+    tgt = score.gather(1, target.view(-1, 1))
+    return (score > tgt).sum(dim=1)
+
+
+def perturb_and_get_rank(embedding, w, a, r, b, test_size, batch_size=100, all_batches=True, flow_log_prob=None,
+                         verbose=False):
+    n_batch = (test_size + batch_size - 1) // batch_size
+    if all_batches is False:
+        n_batch = 1
+    ranks = []
+    emb = embedding.detach().contiguous()
+    for idx in range(n_batch):
+        lo, hi = idx * batch_size, min(test_size, (idx + 1) * batch_size)
+        emb_ar = ops.mul(emb[a[lo:hi]].contiguous(), w.detach()[r[lo:hi]].contiguous())
+        score = ops.gemm(emb_ar, emb, trans_b=True)                       # (Eb, V)
+        if flow_log_prob is not None:
+            score = score + flow_log_prob
+        score = torch.sigmoid(score)
+        ranks.append(sort_and_rank(score, b[lo:hi]))
+        if verbose:
+            rr = 1.0 + torch.cat(ranks).float()
+            print("batch {} / {}: MR : {:.6f} |  MRR : {:.6f}".format(idx, n_batch, rr.mean().item(),
+                                                                      (1.0 / rr).mean().item()))
+    return torch.cat(ranks)
+
+
+def calc_mrr(embedding, w, test_triplets, hits=[], eval_bz=100, all_batches=True, flow_log_prob=None,
+             verbose=True):
+    with torch.no_grad():
+        test_triplets = test_triplets.to(embedding.device)
+        s, r, o = test_triplets[:, 0], test_triplets[:, 1], test_triplets[:, 2]
+        n = test_triplets.shape[0]
+        ranks_s = perturb_and_get_rank(embedding, w, o, r, s, n, eval_bz, all_batches, flow_log_prob)
+        ranks_o = perturb_and_get_rank(embedding, w, s, r, o, n, eval_bz, all_batches, flow_log_prob)
+        ranks = torch.cat([ranks_s, ranks_o]) + 1
+        mrr = torch.mean(1.0 / ranks.float())
+        if verbose:
+            print("MRR (raw): {:.6f}".format(mrr.item()))
+            for hit in hits:
+                print("Hits (raw) @ {}: {:.6f}".format(hit, torch.mean((ranks <= hit).float()).item()))
+    return mrr.item()

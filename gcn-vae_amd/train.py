@@ -1,0 +1,214 @@
+"""Link-prediction task head and driver with the reference's names, flags and control flow
+(kgvae/link_predict.py:30-326), running on the gfx950 kernels.
+
+    python -m gcn_vae_amd.train -d FB15k-237-synthetic --n-hidden 200 --n-bases 100 --n-flows 3 \
+        --mmd-param 1 --mog-k 10 --gpu 0
+
+Differences from the reference, all forced by its own crashes or by the device:
+  * defaults that crash there (``--n-flows 0`` with ``--kl-param > 0``; ``--model-class RGCN``;
+    the periodic validation with ``flow_log_prob=None``) run here;
+  * validation stays on the GPU (the reference flips the model to the CPU because its scorer
+    materialises a (h, Eb, V) tensor; ours is one GEMM);
+  * the wall-clock spans synchronise the device before reading the clock;
+  * ``--gpu`` must name a ROCm device: there is no CPU path.
+"""
+import argparse
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops, ranking, sampling
+from .data import load_data
+from .encoders import KGVAE, RGCN
+from .sampling import node_norm_to_edge_norm
+
+
+class LinkPredict(nn.Module):
+    def __init__(self, model_class, in_dim, h_dim, num_rels, num_bases=-1, num_hidden_layers=1, dropout=0,
+                 use_cuda=True, reg_param=0, kl_param=0, mmd_param=0, k=1, n_flows=0):
+        super().__init__()
+        self.encoder = model_class(num_nodes=in_dim, h_dim=h_dim, out_dim=h_dim, num_rels=num_rels * 2,
+                                   num_bases=num_bases, num_hidden_layers=num_hidden_layers, dropout=dropout,
+                                   use_self_loop=use_cuda, use_cuda=use_cuda, k=k, n_flows=n_flows)
+        self.reg_param, self.kl_param, self.mmd_param = reg_param, kl_param, mmd_param
+        self.w_relation = nn.Parameter(torch.Tensor(num_rels, h_dim))
+        self.use_cuda, self.k, self.n_flows = use_cuda, k, n_flows
+        nn.init.xavier_uniform_(self.w_relation, gain=nn.init.calculate_gain('relu'))
+        self._tidx_key, self._tidx = None, None
+
+    def triplet_index(self, embedding, triplets):
+        """Index of a triplet batch for the DistMult backward; cached per (storage, version)."""
+        key = (triplets.data_ptr(), triplets._version, tuple(triplets.shape), embedding.shape[0])
+        if key != self._tidx_key:
+            self._tidx = ops.TripletIndex(triplets.to(embedding.device), embedding.shape[0], self.w_relation.shape[0])
+            self._tidx_key = key
+            self._tidx_keepalive = triplets
+        return self._tidx
+
+    def calc_score(self, embedding, triplets):
+        return ops.distmult_score(embedding, self.w_relation, self.triplet_index(embedding, triplets))
+
+    def forward(self, g, h, r, norm):
+        return self.encoder.forward(g, h, r, norm)
+
+    def regularization_loss(self, embedding):
+        return ops.mean_sq(embedding) + ops.mean_sq(self.w_relation)
+
+    def get_loss(self, g, embed, triplets, labels):
+        flp = self.encoder.get_flow_log_prob() if self.n_flows > 0 else None
+        predict_loss, _ = ops.distmult_bce(embed, self.w_relation, flp, labels,
+                                           self.triplet_index(embed, triplets))
+        reg_loss = self.regularization_loss(embed)
+        if self.kl_param > 0:
+            kl = self.encoder.get_kl(embed)
+        else:
+            kl = torch.zeros(1, device=embed.device)
+        if self.mmd_param > 0:
+            mmd = self.encoder.get_mmd(embed)
+        else:
+            mmd = torch.zeros(1, device=embed.device)
+        loss = predict_loss + self.reg_param * reg_loss + self.kl_param * kl + self.mmd_param * mmd
+        return loss, predict_loss, kl, mmd
+
+
+def _sync():
+    torch.cuda.synchronize()
+
+
+def main(args):
+    data = load_data(args.dataset)
+    num_nodes, num_rels = data.num_nodes, data.num_rels
+    train_data, valid_data, test_data = data.train, data.valid, data.test
+
+    if args.gpu < 0 or not torch.cuda.is_available():
+        raise RuntimeError('gcn_vae_amd runs on a ROCm device only (pass --gpu N on an MI355X box); '
+                           'there is no CPU path')
+    torch.cuda.set_device(args.gpu)
+    dev = torch.device('cuda', args.gpu)
+
+    model_class = KGVAE if args.model_class == "KGVAE" else RGCN
+    model = LinkPredict(model_class=model_class, in_dim=num_nodes, h_dim=args.n_hidden, num_rels=num_rels,
+                        num_bases=args.n_bases, num_hidden_layers=args.n_layers, dropout=args.dropout, use_cuda=True,
+                        reg_param=args.regularization, kl_param=args.kl_param, mmd_param=args.mmd_param,
+                        k=args.mog_k, n_flows=args.n_flows)
+    model.to(dev)
+
+    def graph_inputs(triplets):
+        g, rel, norm = sampling.build_test_graph(num_nodes, num_rels, triplets)
+        node_id = torch.arange(0, num_nodes, dtype=torch.long, device=dev).view(-1, 1)
+        enorm = node_norm_to_edge_norm(g, torch.from_numpy(norm).view(-1, 1)).to(dev)
+        return g, node_id, torch.from_numpy(rel).to(dev), enorm
+
+    valid_t = torch.as_tensor(valid_data, dtype=torch.long, device=dev)
+    val_graph, val_node_id, val_rel, val_norm = graph_inputs(valid_data)     # eval graph from VALID triplets (:141-147)
+    adj_list, degrees = sampling.get_adj_and_degrees(num_nodes, train_data)
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
+    forward_time, backward_time = [], []
+
+    if args.test_mode is True:
+        print("\nstart testing:")
+        checkpoint = torch.load(args.model_state_file, map_location=dev)
+        test_t = torch.as_tensor(test_data, dtype=torch.long, device=dev)
+        test_graph, test_node_id, test_rel, test_norm = graph_inputs(test_data)
+        model.eval()
+        model.load_state_dict(checkpoint['state_dict'])
+        print("Using best epoch: {}".format(checkpoint['epoch']))
+        with torch.no_grad():
+            embed = model(test_graph, test_node_id, test_rel, test_norm)
+        return ranking.calc_mrr(embed, model.w_relation, test_t, hits=[1, 3, 10], eval_bz=args.eval_batch_size,
+                                all_batches=True, flow_log_prob=model.encoder.get_flow_log_prob())
+
+    print("start training...")
+    epoch, best_mrr = 0, 0
+    if args.load is True:
+        print(f"Loading checkpoint file {args.model_state_file} for training")
+        checkpoint = torch.load(args.model_state_file, map_location=dev)
+        model.load_state_dict(checkpoint['state_dict'])
+        epoch = checkpoint['epoch']
+
+    while True:
+        model.train()
+        epoch += 1
+        g, node_id, edge_type, node_norm, batch, labels = sampling.generate_sampled_graph_and_labels(
+            train_data, args.graph_batch_size, args.graph_split_size, num_rels, adj_list, degrees,
+            args.negative_sample, args.edge_sampler)
+        node_id = torch.from_numpy(node_id).view(-1, 1).long().to(dev)
+        edge_type = torch.from_numpy(edge_type).to(dev)
+        edge_norm = node_norm_to_edge_norm(g, torch.from_numpy(node_norm).view(-1, 1)).to(dev)
+        batch, labels = torch.from_numpy(batch).to(dev), torch.from_numpy(labels).to(dev)
+
+        _sync()
+        t0 = time.time()
+        embed = model(g, node_id, edge_type, edge_norm)
+        loss, pred_loss, kl, mmd = model.get_loss(g, embed, batch, labels)
+        _sync()
+        t1 = time.time()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), args.grad_norm)
+        optimizer.step()
+        _sync()
+        t2 = time.time()
+        forward_time.append(t1 - t0)
+        backward_time.append(t2 - t1)
+        print("Epoch {:04d} | Loss {:.4f} | Best MRR {:.4f} | pred_loss {:.4f} | kl {:.4f} | mmd {:.4f}".format(
+            epoch, loss.item(), best_mrr, pred_loss.item(), kl.item(), mmd.item()))
+        optimizer.zero_grad()
+
+        if epoch % args.evaluate_every == 0:
+            model.eval()
+            print("start eval")
+            torch.save({'state_dict': model.state_dict(), 'epoch': epoch}, args.model_state_file)
+            with torch.no_grad():
+                embed = model(val_graph, val_node_id, val_rel, val_norm)
+            mrr = ranking.calc_mrr(embed, model.w_relation, valid_t, hits=[1, 3, 10], eval_bz=args.eval_batch_size,
+                                   all_batches=False, flow_log_prob=model.encoder.get_flow_log_prob())
+            if mrr < best_mrr:
+                torch.save({'state_dict': model.state_dict(), 'epoch': epoch}, args.model_state_file + "_latest")
+            else:
+                best_mrr = mrr
+                torch.save({'state_dict': model.state_dict(), 'epoch': epoch}, args.model_state_file)
+        if epoch >= args.n_epochs:
+            break
+
+    print("training done")
+    print("Mean forward time: {:4f}s".format(np.mean(forward_time)))
+    print("Mean Backward time: {:4f}s".format(np.mean(backward_time)))
+    return best_mrr
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description='Link Prediction')
+    p.add_argument("--dropout", type=float, default=0.2, help="dropout probability")
+    p.add_argument("--n-hidden", type=int, default=500, help="number of hidden units")
+    p.add_argument("--gpu", type=int, default=-1, help="gpu")
+    p.add_argument("--lr", type=float, default=1e-3, help="learning rate")
+    p.add_argument("--n-bases", type=int, default=100, help="number of weight blocks for each relation")
+    p.add_argument("--n-layers", type=int, default=2, help="number of propagation rounds")
+    p.add_argument("--n-epochs", type=int, default=1e5, help="number of minimum training epochs")
+    p.add_argument("-d", "--dataset", type=str, required=True, help="dataset to use")
+    p.add_argument("--eval-batch-size", type=int, default=400, help="batch size when evaluating")
+    p.add_argument("--regularization", type=float, default=0.01, help="regularization weight")
+    p.add_argument("--kl-param", type=float, default=1e-5, help="kl regularization weight")
+    p.add_argument("--mmd-param", type=float, default=0, help="mmd regularization weight")
+    p.add_argument("--mog-k", type=int, default=10, help="number of mixture of gaussian")
+    p.add_argument("--n-flows", type=int, default=0, help="number of flow transform layers")
+    p.add_argument("--grad-norm", type=float, default=1.0, help="norm to clip gradient to")
+    p.add_argument("--graph-batch-size", type=int, default=20000, help="number of edges to sample in each iteration")
+    p.add_argument("--graph-split-size", type=float, default=0.5, help="portion of edges used as positive sample")
+    p.add_argument("--negative-sample", type=int, default=10, help="number of negative samples per positive sample")
+    p.add_argument("--evaluate-every", type=int, default=200, help="perform evaluation every n epochs")
+    p.add_argument("--edge-sampler", type=str, default="uniform", help="type of edge sampler: 'uniform' or 'neighbor'")
+    p.add_argument("--test-mode", type=bool, default=False, help="only evaluate on test dataset")
+    p.add_argument("--model-state-file", type=str, default='model_state.pth', help="model state file to load or save")
+    p.add_argument("--model-class", type=str, default='KGVAE', help="model class")
+    p.add_argument("--load", type=bool, default=False, help="whether to load a model state file for training")
+    p.add_argument("--generate", type=bool, default=False, help="(reference demo; not supported here)")
+    return p
+
+
+if __name__ == '__main__':
+    cli = build_parser().parse_args()
+    print(cli)
+    main(cli)

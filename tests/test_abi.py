@@ -1,0 +1,44 @@
+"""The C-ABI library loads and exports every symbol include/gcnvae.h declares; the product never
+imports the oracle.  No compute calls (CPU box)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'gcnvae.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(gv_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gcn_vae_amd import lib
+    names = declared_symbols()
+    assert len(names) >= 28
+    handle = ctypes.CDLL(lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), f'{n} declared in include/gcnvae.h but not exported'
+    assert sorted(lib.SIGNATURES) == names, 'ctypes signature table out of sync with the header'
+    assert lib.load().gv_version() >= 100
+    assert lib.last_error() == '' or isinstance(lib.last_error(), str)
+
+
+def test_argument_errors_are_reported_not_thrown():
+    from gcn_vae_amd import lib
+    l = lib.load()
+    rc = l.gv_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, 1, None, 0, None)
+    assert rc == -1 and 'NULL' in lib.last_error()
+    rc = l.gv_segment_items_count(None, 3, 0, None, None, None, None)
+    assert rc < 0
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'gcn-vae_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+                assert 'oracle/' not in src or f.endswith('.md'), f

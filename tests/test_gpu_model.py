@@ -1,0 +1,185 @@
+"""Whole-path parity on the GPU: modules with the reference's signatures, loaded with the reference's
+state_dict, against (a) the golden vectors captured from the reference at C1 size and (b) the CPU
+oracle at the C2 mini-batch shape.   pytest -m gpu.   Tolerance 1e-4 (north_star)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import kgvae as okg
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol=1e-4, atol_scale=1e-5, msg=''):
+    a, b = a.detach().cpu().double().reshape(-1), b.detach().cpu().double().reshape(-1)
+    atol = atol_scale * max(1.0, float(b.abs().max()) if b.numel() else 1.0)
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol, msg=lambda m: f'{msg}: {m}')
+
+
+def build_model(g, n_flows, kl, mmd, h=16, nb=4, num_nodes=1000, num_rels=20, dropout=0.0):
+    from gcn_vae_amd.encoders import KGVAE
+    from gcn_vae_amd.train import LinkPredict
+    net = LinkPredict(KGVAE, num_nodes, h, num_rels, num_bases=nb, num_hidden_layers=2, dropout=dropout,
+                      use_cuda=True, reg_param=0.01, kl_param=kl, mmd_param=mmd, k=10, n_flows=n_flows)
+    state = {k[6:]: v for k, v in g.items() if k.startswith('state.')}
+    net.load_state_dict(state)           # strict: proves key/shape parity with the reference
+    return net.cuda()
+
+
+def run_golden(tag, n_flows, kl, mmd):
+    from gcn_vae_amd.graph import KGraph
+    g = load_golden(f'model_c1_{tag}.npz')
+    net = build_model(g, n_flows, kl, mmd)
+    net.train()
+    graph = KGraph()
+    graph.add_nodes(len(g['node_id']))
+    graph.add_edges(g['src'], g['dst'])
+    enc = net.encoder
+    enc.eps_override = g['eps'].cuda()
+    enc.mmd_eps_override = g['eps_prior'].cuda()
+    enc.mmd_index_override = g['post_idx'].cuda()
+    embed = net(graph, g['node_id'].view(-1, 1).cuda(), g['etype'].cuda(), g['edge_norm'].cuda())
+    loss, pred, klv, mmdv = net.get_loss(graph, embed, g['samples'].cuda(), g['labels'].cuda())
+    loss.backward()
+    return g, net, embed, (loss, pred, klv, mmdv)
+
+
+def test_golden_c1_with_flows():
+    g, net, embed, (loss, pred, kl, mmd) = run_golden('flows3', 3, 1e-5, 1.0)
+    close(embed, g['z'], msg='z')
+    close(net.encoder.z_mean, g['z_mean'], msg='z_mean')
+    close(net.encoder.z_sigma, g['z_sigma'], msg='z_sigma')
+    close(net.encoder.get_flow_log_prob(), g['flow_log_prob'], msg='flow_log_prob')
+    for a, b in ((loss, 'loss'), (pred, 'pred'), (kl, 'kl'), (mmd, 'mmd')):
+        close(a, g[b], msg=b)
+    close(net.calc_score(embed, g['samples'].cuda()), g['score'], msg='score')
+    close(net.regularization_loss(embed), g['reg'], msg='reg')
+    n = 0
+    for name, p in net.named_parameters():
+        if 'grad.' + name in g:
+            close(p.grad, g['grad.' + name], rtol=2e-4, atol_scale=2e-5, msg='grad ' + name)
+            n += 1
+    assert n >= 36
+
+
+def test_golden_c1_without_flows():
+    g, net, embed, (loss, pred, kl, mmd) = run_golden('flows0', 0, 0.0, 1.0)
+    close(embed, g['z'], msg='z')
+    for a, b in ((loss, 'loss'), (pred, 'pred'), (mmd, 'mmd')):
+        close(a, g[b], msg=b)
+    for name, p in net.named_parameters():
+        if 'grad.' + name in g:
+            close(p.grad, g['grad.' + name], rtol=2e-4, atol_scale=2e-5, msg='grad ' + name)
+        elif p.requires_grad:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+
+
+def test_made_module_against_golden():
+    import seeded
+    from gcn_vae_amd.flows import MADE, PermuteLayer
+    g = load_golden('made.npz')
+    for tag, (d, h, nh, seed) in {'d16': (16, 16, 3, 100), 'd200': (200, 200, 3, 200), 'd8h12': (8, 12, 2, 300)}.items():
+        m = MADE(d, h, nh)
+        with torch.no_grad():
+            for i, (w, b) in enumerate(seeded.made_layers(seed, d, h, nh)):
+                m.net[2 * i].weight.copy_(w)
+                m.net[2 * i].bias.copy_(b)
+        m = m.cuda()
+        z = g[f'{tag}_z'].cuda().requires_grad_(True)
+        x, ld = m.forward(z)
+        close(x, g[f'{tag}_x'], msg=tag + ' x')
+        close(ld, g[f'{tag}_logdet'], msg=tag + ' logdet')
+        (x.pow(2).sum() + ld.sum()).backward()
+        close(z.grad, g[f'{tag}_grad_z'], rtol=2e-4, atol_scale=2e-5, msg=tag + ' grad_z')
+        close(m.net[0].weight.grad, g[f'{tag}_grad_w0'], rtol=2e-4, atol_scale=2e-5, msg=tag + ' grad_w0')
+        close(m.net[2 * (nh + 1)].weight.grad, g[f'{tag}_grad_wlast'], rtol=2e-4, atol_scale=2e-5, msg=tag + ' grad_wlast')
+        zi, ldi = m.inverse(g[f'{tag}_z'].cuda())
+        close(zi, g[f'{tag}_inv'], msg=tag + ' inverse')
+        close(ldi, g[f'{tag}_inv_logdet'], msg=tag + ' inverse logdet')
+    px, pld = PermuteLayer(7)(g['perm_in'].cuda())
+    close(px, g['perm_out'])
+    assert pld.shape == (3, 1) and float(pld.abs().max()) == 0
+
+
+@pytest.mark.parametrize('n_flows', [0, 3])
+def test_c2_minibatch_against_oracle(n_flows):
+    """FB15k-237-shaped mini-batch (h=200, B=100, 474 directed relations, E=20k, T=44k) incl. dropout masks."""
+    from gcn_vae_amd import sampling
+    from gcn_vae_amd.data import synthetic_kg
+    from gcn_vae_amd.encoders import KGVAE
+    from gcn_vae_amd.train import LinkPredict
+    data = synthetic_kg(14541, 237, 60000, seed=1)
+    adj, deg = sampling.get_adj_and_degrees(data.num_nodes, data.train)
+    np.random.seed(0)
+    graph, node_id, etype, node_norm, samples, labels = sampling.generate_sampled_graph_and_labels(
+        data.train, 20000, 0.5, data.num_rels, adj, deg, 1 if n_flows else 3, 'uniform')
+    n = len(node_id)
+    torch.manual_seed(0)
+    kl_param = 1e-2
+    net = LinkPredict(KGVAE, data.num_nodes, 200, data.num_rels, num_bases=100, num_hidden_layers=2, dropout=0.2,
+                      use_cuda=True, reg_param=0.01, kl_param=kl_param, mmd_param=1.0, k=10, n_flows=n_flows)
+    with torch.no_grad():
+        net.encoder.rconv_layer_1.h_bias.normal_(0, 0.1)
+        net.encoder.rconv_layer_2.h_bias.normal_(0, 0.1)
+    state = {k: v.detach().clone().requires_grad_(v.is_floating_point() and 'mask' not in k and not k.endswith('.pi'))
+             for k, v in net.state_dict().items()}
+    gen = torch.Generator().manual_seed(5)
+    eps, eps_prior = torch.randn(n, 200, generator=gen), torch.randn(200, 200, generator=gen)
+    keep1 = (torch.rand(n, 200, generator=gen) > 0.2).to(torch.uint8)
+    keep2 = (torch.rand(n, 400, generator=gen) > 0.2).to(torch.uint8)
+    random.seed(3)
+    post_idx = torch.tensor(random.sample(range(n), 200))
+    src, dst = graph.edges()
+    node_id_t = torch.from_numpy(node_id).view(-1, 1)
+    etype_t = torch.from_numpy(etype)
+    enorm = sampling.node_norm_to_edge_norm(graph, torch.from_numpy(node_norm).view(-1, 1))
+    samples_t, labels_t = torch.from_numpy(samples), torch.from_numpy(labels)
+    enc = okg.kgvae_encode(state, src, dst, node_id_t, etype_t, enorm, eps, 100, n_flows, 0.2, keep1, keep2)
+    lo = okg.link_predict_loss(state, enc, samples_t, labels_t, 0.01, kl_param, 1.0, 10, n_flows, eps_prior, post_idx)
+    lo[0].backward()
+
+    net = net.cuda().train()
+    e = net.encoder
+    e.eps_override, e.mmd_eps_override, e.mmd_index_override = eps.cuda(), eps_prior.cuda(), post_idx.cuda()
+    e.rconv_layer_1.keep_mask_override, e.rconv_layer_2.keep_mask_override = keep1.cuda(), keep2.cuda()
+    embed = net(graph, node_id_t.cuda(), etype_t.cuda(), enorm.cuda())
+    lg = net.get_loss(graph, embed, samples_t.cuda(), labels_t.cuda())
+    lg[0].backward()
+    close(embed, enc['z'], msg='z')
+    for a, b, nm in zip(lg, lo, ('loss', 'pred', 'kl', 'mmd')):
+        close(a, b, msg=nm)
+    for name, p in net.named_parameters():
+        ref = state[name].grad
+        if ref is None:
+            continue
+        close(p.grad, ref, rtol=5e-4, atol_scale=5e-5, msg='grad ' + name)
+
+
+def test_rgcn_encoder_and_eval_ranking():
+    """--model-class RGCN (crashes in the reference, SURVEY 0 bug 2) + the GEMM-based ranker vs the oracle's."""
+    from gcn_vae_amd import ranking, sampling
+    from gcn_vae_amd.data import synthetic_kg
+    from gcn_vae_amd.encoders import RGCN
+    from gcn_vae_amd.train import LinkPredict
+    from oracle import ranking as orank
+    data = synthetic_kg(300, 7, 1500, 120, seed=2)
+    torch.manual_seed(1)
+    net = LinkPredict(RGCN, data.num_nodes, 16, data.num_rels, num_bases=4, num_hidden_layers=2, dropout=0.0,
+                      use_cuda=True, reg_param=0.01)
+    state = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    graph, rel, norm = sampling.build_test_graph(data.num_nodes, data.num_rels, data.train)
+    src, dst = graph.edges()
+    node_id = torch.arange(data.num_nodes).view(-1, 1)
+    enorm = sampling.node_norm_to_edge_norm(graph, torch.from_numpy(norm).view(-1, 1))
+    ho = okg.rgcn_encode(state, src, dst, node_id, torch.from_numpy(rel), enorm, 4, 2)
+    net = net.cuda().eval()
+    hg = net(graph, node_id.cuda(), torch.from_numpy(rel).cuda(), enorm.cuda())
+    close(hg, ho, msg='rgcn embed')
+    valid = torch.from_numpy(data.valid)
+    mrr_o, _, ranks_o = orank.calc_mrr(ho, state['w_relation'], valid, hits=[1, 3, 10], eval_bz=50,
+                                       flow_log_prob=torch.tensor(0.0))
+    mrr_g = ranking.calc_mrr(hg, net.w_relation, valid.cuda(), hits=[1, 3, 10], eval_bz=50, verbose=False)
+    assert abs(mrr_o - mrr_g) < 2e-3, (mrr_o, mrr_g)

@@ -1,0 +1,105 @@
+"""Host logic of the product (no GPU): graph construction and sampling reproduce the reference's
+numpy RNG stream (golden vectors), the graph handle behaves like the DGL surface, the data reader
+parses the DGL-0.4 on-disk layout."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def test_sampling_matches_reference_vectors():
+    from gcn_vae_amd import sampling
+    g = load_golden('pipeline.npz')
+    train = g['train'].numpy()
+    adj, deg = sampling.get_adj_and_degrees(300, train)
+    assert np.array_equal(deg, g['degrees'].numpy())
+    assert np.array_equal(np.concatenate([a.reshape(-1, 2) for a in adj if a.size]), g['adj_flat'].numpy())
+    np.random.seed(0)
+    ns, nl = sampling.negative_sampling(g['neg_pos'].numpy().copy(), 300, 3)
+    assert np.array_equal(ns, g['neg_samples'].numpy()) and np.array_equal(nl, g['neg_labels'].numpy())
+    np.random.seed(1)
+    assert np.array_equal(sampling.sample_edge_uniform(adj, deg, len(train), 100), g['uniform_edges'].numpy())
+    np.random.seed(2)
+    assert np.array_equal(sampling.sample_edge_neighborhood(adj, deg, len(train), 60), g['neighbor_edges'].numpy())
+    for tag, sampler, seed in (('u', 'uniform', 3), ('n', 'neighbor', 4)):
+        np.random.seed(seed)
+        gr, uniq_v, rel, norm, samples, labels = sampling.generate_sampled_graph_and_labels(
+            train, 200, 0.5, 12, adj, deg, 4, sampler)
+        src, dst = gr.edges()
+        assert torch.equal(src, g[f'{tag}_src']) and torch.equal(dst, g[f'{tag}_dst'])
+        assert np.array_equal(uniq_v, g[f'{tag}_uniq_v'].numpy()) and np.array_equal(rel, g[f'{tag}_rel'].numpy())
+        assert np.array_equal(norm, g[f'{tag}_norm'].numpy())
+        assert np.array_equal(samples, g[f'{tag}_samples'].numpy()) and np.array_equal(labels, g[f'{tag}_labels'].numpy())
+        en = sampling.node_norm_to_edge_norm(gr, torch.from_numpy(norm).view(-1, 1))
+        assert torch.equal(en, g[f'{tag}_edge_norm'])
+    tg, trel, tnorm = sampling.build_test_graph(300, 12, g['valid'].numpy())
+    ts, td = tg.edges()
+    assert torch.equal(ts, g['test_src']) and torch.equal(td, g['test_dst'])
+    assert np.array_equal(trel, g['test_rel'].numpy()) and np.array_equal(tnorm, g['test_norm'].numpy())
+    with pytest.raises(ValueError, match="'uniform' or 'neighbor'"):
+        sampling.generate_sampled_graph_and_labels(train, 10, 0.5, 12, adj, deg, 1, 'nope')
+
+
+def test_graph_handle_surface():
+    from gcn_vae_amd.graph import KGraph
+    g = KGraph()
+    g.add_nodes(5)
+    g.add_edges([0, 1, 1, 4], [1, 2, 2, 0])
+    assert len(g) == 5 and g.number_of_nodes() == 5 and g.number_of_edges() == 4
+    assert g.in_degrees(range(5)).tolist() == [1, 1, 2, 0, 0]
+    loc = g.local_var()
+    loc.ndata['norm'] = torch.arange(5.0).view(-1, 1)
+    loc.apply_edges(lambda edges: {'norm': edges.dst['norm']})
+    assert loc.edata['norm'].view(-1).tolist() == [1.0, 2.0, 2.0, 0.0]
+    assert 'norm' not in g.ndata and 'norm' not in g.edata
+    with pytest.raises(ValueError):
+        g.add_edges([0], [7])
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        g.device_index('cpu')
+
+
+def test_data_reader_dgl_layout(tmp_path, monkeypatch):
+    from gcn_vae_amd import data
+    d = tmp_path / 'toy'
+    d.mkdir()
+    (d / 'entities.dict').write_text('0\t/m/a\n1\t/m/b\n2\t/m/c\n')
+    (d / 'relations.dict').write_text('0\tlikes\n1\tknows\n')
+    (d / 'train.txt').write_text('/m/a\tlikes\t/m/b\n/m/b\tknows\t/m/c\n')
+    (d / 'valid.txt').write_text('/m/c\tlikes\t/m/a\n')
+    (d / 'test.txt').write_text('')
+    monkeypatch.setenv('GCNVAE_DATA', str(tmp_path))
+    ds = data.load_data('toy')
+    assert (ds.num_nodes, ds.num_rels) == (3, 2)
+    assert ds.train.tolist() == [[0, 0, 1], [1, 1, 2]] and ds.valid.tolist() == [[2, 0, 0]] and ds.test.shape == (0, 3)
+    syn = data.load_data('synthetic:50:4:300:20:10:7')
+    assert syn.train.shape == (300, 3) and syn.train[:, 1].max() < 4 and syn.train[:, [0, 2]].max() < 50
+    with pytest.raises(FileNotFoundError):
+        data.load_data('FB15k-237')
+
+
+def test_modules_construct_and_reject_cpu():
+    from gcn_vae_amd.encoders import KGVAE
+    from gcn_vae_amd.graph import KGraph
+    from gcn_vae_amd.layers import RelGraphConv
+    from gcn_vae_amd.train import LinkPredict, build_parser
+    with pytest.raises(ValueError, match='multiplier of num_bases'):
+        RelGraphConv(200, 200, 22, 'bdd', 100)        # C3: --n-bases 100 is clamped to 22 relations
+    with pytest.raises(ValueError, match="'basis' or 'bdd'"):
+        RelGraphConv(8, 8, 4, 'nope', 2)
+    net = LinkPredict(KGVAE, 30, 8, 3, num_bases=2, num_hidden_layers=2, k=2, n_flows=1)
+    g = KGraph()
+    g.add_nodes(30)
+    g.add_edges([0, 1], [1, 2])
+    with pytest.raises(RuntimeError, match='no CPU'):
+        net(g, torch.arange(30).view(-1, 1), torch.tensor([0, 1]), torch.ones(2, 1))
+    args = build_parser().parse_args(['-d', 'x'])
+    ref_defaults = dict(dropout=0.2, n_hidden=500, gpu=-1, lr=1e-3, n_bases=100, n_layers=2, n_epochs=1e5,
+                        eval_batch_size=400, regularization=0.01, kl_param=1e-5, mmd_param=0, mog_k=10, n_flows=0,
+                        grad_norm=1.0, graph_batch_size=20000, graph_split_size=0.5, negative_sample=10,
+                        evaluate_every=200, edge_sampler='uniform', test_mode=False,
+                        model_state_file='model_state.pth', model_class='KGVAE', load=False, generate=False)
+    for k, v in ref_defaults.items():
+        assert getattr(args, k) == v, k
