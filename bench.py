@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""bench.py -- edges/sec of the R-GCN-VAE forward+backward hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): FB15k-237-shaped synthetic knowledge graph (14 541 entities,
+237 relations = 474 directed edge types, 272 115 triplets with Zipf(0.8) endpoints => 544 230 directed
+edges), 2-layer R-GCN-VAE encoder (bdd, num_bases=100, emb_dim=200, fp32, dropout 0.2) on the FULL
+graph + DistMult decoder on 220 000 triplets (20 000 positives x (1 + 10 negatives)).
+One step = forward + loss (BCE + 0.01 reg + 1e-5 KL + 1.0 MMD) + backward + grad-clip + Adam,
+i.e. the reference's t0..t2 span (kgvae/link_predict.py:222-229) with device synchronisation.
+At N GPUs every rank holds one such edge block and triplet slice (weak scaling); node embeddings are
+all-reduced over RCCL once per layer per direction, parameter gradients once per step.
+
+Rank 0 prints ONE JSON line: value = all ranks' directed edges x steps / max-over-ranks seconds.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=30)
+    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--hidden', type=int, default=200)
+    p.add_argument('--n-bases', type=int, default=100)
+    p.add_argument('--n-flows', type=int, default=0)
+    p.add_argument('--positives', type=int, default=20000)
+    p.add_argument('--negative-sample', type=int, default=10)
+    p.add_argument('--dropout', type=float, default=0.2)
+    p.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU-oracle baseline leg')
+    p.add_argument('--profile-steps', type=int, default=3, help='instrumented eager steps for the roofline figure')
+    return p.parse_args()
+
+
+def make_workload(rank, world, args, dev):
+    from gcn_vae_amd import distributed as gdist
+    from gcn_vae_amd import sampling
+    from gcn_vae_amd.data import FB15K237, synthetic_kg
+    cfg = FB15K237
+    data = synthetic_kg(cfg['num_nodes'], cfg['num_rels'], cfg['n_train'], seed=rank)
+    g, rel, node_norm = sampling.build_test_graph(data.num_nodes, data.num_rels, data.train)
+    src, dst = g.edges()
+    if world > 1:      # 1/in-degree over the union of all ranks' edge blocks
+        norm = gdist.global_in_degree_norm(dst, data.num_nodes, device=dev)
+    else:
+        norm = torch.from_numpy(node_norm).to(dev)
+    enorm = norm[dst.to(dev)].view(-1, 1).contiguous()
+    rs = np.random.RandomState(1000 + rank)
+    pos = data.train[rs.permutation(len(data.train))[:args.positives]]
+    np.random.seed(7 + rank)
+    samples, labels = sampling.negative_sampling(pos, data.num_nodes, args.negative_sample)
+    return dict(data=data, g=g, src=src, dst=dst, rel=torch.from_numpy(rel), enorm=enorm,
+                node_id=torch.arange(data.num_nodes, dtype=torch.long).view(-1, 1),
+                samples=torch.from_numpy(samples), labels=torch.from_numpy(labels))
+
+
+def build_model(w, args):
+    from gcn_vae_amd.encoders import KGVAE
+    from gcn_vae_amd.train import LinkPredict
+    d = w['data']
+    torch.manual_seed(0)
+    return LinkPredict(KGVAE, d.num_nodes, args.hidden, d.num_rels, num_bases=args.n_bases, num_hidden_layers=2,
+                       dropout=args.dropout, use_cuda=True, reg_param=0.01, kl_param=1e-5, mmd_param=1.0, k=10,
+                       n_flows=args.n_flows)
+
+
+def algorithmic_bytes(tag, E, N, R, T):
+    """bytes one launch must move (fp32, int32 indices), by kernel tag."""
+    kind, rest = tag.split('_', 1)
+    if kind == 'agg':
+        tr, blk, nb = rest.split('_')
+        p, q = (int(x) for x in blk.split('x'))
+        nb = int(nb[2:])
+        fin, fout = nb * p, nb * q
+        if p == 1 and q == 1:           # DistMult backward over 2T incidences, N entity rows, T/11.. relations
+            return 2 * T * (fin * 4 + 16) + N * (fout * 4 + 4) + R // 2 * fin * 4
+        return E * (fin * 4 + 12) + N * (fout * 4 + 4) + R * fin * fout // nb * 4
+    if kind == 'gradw':
+        blk, nb = rest.split('_')
+        p, q = (int(x) for x in blk.split('x'))
+        nb = int(nb[2:])
+        fin, fout = nb * p, nb * q
+        if p == 1 and q == 1:
+            return T * (2 * fin * 4 + 16) + R // 2 * fin * 4
+        return E * (fin * 4 + fout * 4 + 12) + R * fin * fout // nb * 4
+    return 0
+
+
+def cpu_baseline(w, model, args, budget_s):
+    """The CPU oracle (oracle/, a torch-CPU port of the reference's op sequence) on the same inputs."""
+    from oracle import kgvae as okg
+    torch.set_num_threads(os.cpu_count() or 1)
+    state = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and 'mask' not in k and not k.endswith('.pi'))
+             for k, v in model.state_dict().items()}
+    n, h = w['data'].num_nodes, args.hidden
+    gen = torch.Generator().manual_seed(0)
+    eps, eps_prior = torch.randn(n, h, generator=gen), torch.randn(200, h, generator=gen)
+    keep1 = (torch.rand(n, h, generator=gen) > args.dropout).to(torch.uint8)
+    keep2 = (torch.rand(n, 2 * h, generator=gen) > args.dropout).to(torch.uint8)
+    post_idx = torch.tensor(random.Random(0).sample(range(n), 200))
+    enorm = w['enorm'].cpu()
+    times = []
+    t_start = time.time()
+    for it in range(4):
+        for v in state.values():
+            v.grad = None
+        t0 = time.time()
+        enc = okg.kgvae_encode(state, w['src'], w['dst'], w['node_id'], w['rel'], enorm, eps, args.n_bases,
+                               args.n_flows, args.dropout, keep1, keep2)
+        loss = okg.link_predict_loss(state, enc, w['samples'], w['labels'], 0.01, 1e-5, 1.0, 10, args.n_flows,
+                                     eps_prior, post_idx)[0]
+        loss.backward()
+        dt = time.time() - t0
+        if it > 0:
+            times.append(dt)
+        if time.time() - t_start + dt > budget_s and times:
+            break
+    E = int(w['src'].numel())
+    med = float(np.median(times))
+    return {'value': E / med, 'unit': 'edges/s', 'cores': os.cpu_count() or 1, 'kind': 'port',
+            'sample': f'{len(times)} timed full steps (fwd+loss+bwd, no optimizer) of the same workload after 1 warm-up; '
+                      f'median {med:.3f} s/step; torch {torch.__version__} CPU, anomaly mode off'}
+
+
+def main():
+    args = parse()
+    from gcn_vae_amd import distributed as gdist
+    from gcn_vae_amd import lib
+    rank, local_rank, world = gdist.env_world()
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run', file=sys.stderr)
+        world = max(world, 1)
+    if not torch.cuda.is_available():
+        raise RuntimeError('bench.py needs an MI355X (no CPU path); the cpu_baseline leg alone is not a benchmark')
+    gdist.init_process_group('nccl' if world > 1 else None)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    lib.load()
+    import torch.distributed as dist
+
+    w = make_workload(rank, world, args, dev)
+    model = build_model(w, args).to(dev).train()
+    g = w['g']
+    node_id, etype = w['node_id'].to(dev), w['rel'].to(dev)
+    enorm, samples, labels = w['enorm'], w['samples'].to(dev), w['labels'].to(dev)
+    n_nodes, E, T = w['data'].num_nodes, int(w['src'].numel()), int(samples.shape[0])
+    params = [p for p in model.parameters() if p.requires_grad]
+    use_graph = not args.no_graph
+    from gcn_vae_amd.optim import FlatAdam
+    opt = FlatAdam(params, lr=1e-3, max_grad_norm=1.0)      # clip_grad_norm_(1.0) + Adam over one flat arena
+    if world > 1:
+        hook = gdist.make_reduce_hook()
+        model.encoder.rconv_layer_1.reduce_hook = hook
+        model.encoder.rconv_layer_2.reduce_hook = hook
+    pick_rng = random.Random(rank)
+    post_idx = torch.zeros(200, dtype=torch.long, device=dev)
+    model.encoder.mmd_index_override = post_idx          # static buffer: contents refreshed per step on the host
+    pinned = torch.zeros(200, dtype=torch.long).pin_memory()
+
+    def refresh_host_inputs():
+        pinned.copy_(torch.tensor(pick_rng.sample(range(n_nodes), 200)))
+        post_idx.copy_(pinned, non_blocking=True)
+
+    def step_body():
+        opt.zero_grad()
+        embed = model(g, node_id, etype, enorm)
+        loss, pred, kl, mmd = model.get_loss(g, embed, samples, labels)
+        loss.backward()
+        if world > 1:
+            gdist.average_flat(opt.flat_g)
+        opt.step()
+        return loss
+
+    # ---- build indices + warm up eagerly (side stream, as graph capture wants) -------------------
+    launch = 'eager'
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            refresh_host_inputs()
+            loss = step_body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = None
+    if use_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = step_body()
+            launch = 'hipgraph'
+        except Exception as exc:      # capture refused (e.g. a collective that cannot be captured): run eagerly
+            print(f'[bench] graph capture failed on rank {rank}: {type(exc).__name__}: {exc}; running eagerly',
+                  file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def run_step():
+        refresh_host_inputs()
+        if graph is not None:
+            graph.replay()
+            return static_loss
+        return step_body()
+
+    for _ in range(args.warmup):
+        loss = run_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = run_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    final_loss = float(loss.item())
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- roofline leg: the same step, eager, with HIP events around the K1 launches --------------
+    roofline, detail = None, {}
+    if rank == 0 and args.profile_steps > 0:
+        lib.TIMER = lib.KernelTimer()
+        if world == 1:
+            for _ in range(args.profile_steps):
+                refresh_host_inputs()
+                step_body()
+        ms = lib.TIMER.results_ms()
+        lib.TIMER = None
+        R = 2 * w['data'].num_rels
+        for tag, vals in sorted(ms.items()):
+            vals = vals[len(vals) // 3:] if len(vals) >= 3 else vals     # drop the first (cold) third
+            avg_ms = float(np.mean(vals))
+            nbytes = algorithmic_bytes(tag, E, n_nodes, R, T)
+            detail[tag] = {'avg_us': round(avg_ms * 1e3, 2), 'launches': len(vals),
+                           'algorithmic_MB': round(nbytes / 1e6, 2),
+                           'achieved_GBs': round(nbytes / 1e9 / (avg_ms * 1e-3), 1) if avg_ms > 0 else None}
+        rg = {k: v for k, v in detail.items() if k.startswith('agg_') and not k.startswith('agg_N_1x1')}
+        if rg:
+            dom = max(rg, key=lambda k: rg[k]['avg_us'])
+            ach = rg[dom]['achieved_GBs']
+            roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                        'avg_us': rg[dom]['avg_us'], 'algorithmic_MB': rg[dom]['algorithmic_MB']}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        out = {
+            'metric': 'edges/sec R-GCN forward+backward, FB15k-237 emb=200',
+            'value': world * E * args.steps / elapsed, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'FB15k-237-shaped synthetic full graph (BASELINE configs[1]): 14541 entities, '
+                                   '474 directed relation types, E=%d directed edges per GPU, 2-layer R-GCN-VAE bdd '
+                                   'num_bases=%d emb_dim=%d fp32 dropout %.1f, DistMult decoder on T=%d triplets, '
+                                   'step = fwd + loss(BCE+reg+KL+MMD) + bwd + clip + Adam' %
+                                   (E, args.n_bases, args.hidden, args.dropout, T),
+                       'edges_per_gpu': E, 'nodes': n_nodes, 'triplets_per_gpu': T, 'n_flows': args.n_flows,
+                       'launch': launch, 'parallelism': 'edge-block sharding x%d, RCCL all-reduce of node embeddings' % world
+                       if world > 1 else 'single GPU'},
+            'final_loss': final_loss,
+            'roofline': roofline, 'roofline_detail': detail,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(w, model, args, args.cpu_seconds)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -183,22 +183,39 @@ __global__ __launch_bounds__(256) void k_agg_generic(const AggParams a) {
     }
 }
 
-// Sum the partial rows of split segments in slot order and apply the epilogue.
+// Sum the partial rows of split segments and apply the epilogue.  One wave per (split segment,
+// 64-column tile); the slot sum runs in a fixed order (4 interleaved chains, then a fixed combine)
+// so the result is bitwise reproducible, with 8 loads in flight per lane.
+__device__ __forceinline__ float ordered_slot_sum(const float* __restrict__ p, int n, size_t stride) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int k = 0;
+    for (; k + 8 <= n; k += 8) {
+        const float v0 = p[(size_t)(k + 0) * stride], v1 = p[(size_t)(k + 1) * stride];
+        const float v2 = p[(size_t)(k + 2) * stride], v3 = p[(size_t)(k + 3) * stride];
+        const float v4 = p[(size_t)(k + 4) * stride], v5 = p[(size_t)(k + 5) * stride];
+        const float v6 = p[(size_t)(k + 6) * stride], v7 = p[(size_t)(k + 7) * stride];
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        a0 += v4; a1 += v5; a2 += v6; a3 += v7;
+    }
+    for (; k < n; ++k) a0 += p[(size_t)k * stride];
+    return (a0 + a1) + (a2 + a3);
+}
+
 __global__ __launch_bounds__(256) void k_agg_fixup(const int4* fix, int n_fix, const float* partial, int out_dim,
                                                    const float* addend, int ld_add, int act, const uint8_t* keep,
                                                    float keep_scale, float* out, int ld_out) {
     const int lane = threadIdx.x & 63;
+    const int tiles = (out_dim + 63) >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    if (wave >= n_fix) return;
-    const int4 f = fix[wave];
-    for (int c = lane; c < out_dim; c += 64) {
-        float acc = 0.f;
-        for (int k = 0; k < f.z; ++k) acc += partial[(size_t)(f.y + k) * out_dim + c];
-        if (addend) acc += addend[(size_t)f.x * ld_add + c];
-        acc = apply_act(acc, act);
-        if (keep) acc = keep[(size_t)f.x * out_dim + c] ? acc * keep_scale : 0.f;
-        out[(size_t)f.x * ld_out + c] = acc;
-    }
+    if (wave >= n_fix * tiles) return;
+    const int4 f = fix[wave / tiles];
+    const int c = (wave % tiles) * 64 + lane;
+    if (c >= out_dim) return;
+    float acc = ordered_slot_sum(partial + (size_t)f.y * out_dim + c, f.z, out_dim);
+    if (addend) acc += addend[(size_t)f.x * ld_add + c];
+    acc = apply_act(acc, act);
+    if (keep) acc = keep[(size_t)f.x * out_dim + c] ? acc * keep_scale : 0.f;
+    out[(size_t)f.x * ld_out + c] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -350,15 +367,15 @@ __global__ __launch_bounds__(256) void k_gradw_generic(const GradWParams a) {
 __global__ __launch_bounds__(256) void k_gradw_fixup(const int4* fix, int n_fix, const float* partial, int w_row,
                                                      float* grad_w, int accumulate) {
     const int lane = threadIdx.x & 63;
+    const int tiles = (w_row + 63) >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    if (wave >= n_fix) return;
-    const int4 f = fix[wave];
-    for (int c = lane; c < w_row; c += 64) {
-        float acc = 0.f;
-        for (int k = 0; k < f.z; ++k) acc += partial[(size_t)(f.y + k) * w_row + c];
-        float* o = grad_w + (size_t)f.x * w_row + c;
-        *o = accumulate ? *o + acc : acc;
-    }
+    if (wave >= n_fix * tiles) return;
+    const int4 f = fix[wave / tiles];
+    const int c = (wave % tiles) * 64 + lane;
+    if (c >= w_row) return;
+    const float acc = ordered_slot_sum(partial + (size_t)f.y * w_row + c, f.z, w_row);
+    float* o = grad_w + (size_t)f.x * w_row + c;
+    *o = accumulate ? *o + acc : acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -489,11 +506,24 @@ extern "C" int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const in
     }
     if (rc != GV_OK) return rc;
     if (n_fix > 0) {
-        hipLaunchKernelGGL(k_agg_fixup, dim3((n_fix + 3) / 4), dim3(256), 0, st, (const int4*)fix, n_fix, partial,
+        const int waves = n_fix * ((a.out_dim + 63) / 64);
+        hipLaunchKernelGGL(k_agg_fixup, dim3((waves + 3) / 4), dim3(256), 0, st, (const int4*)fix, n_fix, partial,
                            a.out_dim, addend, ld_addend, act, keep, keep_scale, out, ld_out);
         return launch_status("gv_rgcn_bdd_aggregate(fixup)");
     }
     return GV_OK;
+}
+
+extern "C" int gv_rgcn_bdd_fixup(const int32_t* fix, int n_fix, const float* partial, int out_dim, const float* addend,
+                                 int ld_addend, int act, const uint8_t* keep, float keep_scale, float* out, int ld_out,
+                                 void* stream) {
+    GV_REQUIRE(n_fix >= 0, GV_ERR_SHAPE, "gv_rgcn_bdd_fixup: negative count");
+    if (n_fix == 0) return GV_OK;
+    GV_REQUIRE(fix && partial && out, GV_ERR_NULL, "gv_rgcn_bdd_fixup: NULL pointer");
+    const int waves = n_fix * ((out_dim + 63) / 64);
+    hipLaunchKernelGGL(k_agg_fixup, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const int4*)fix, n_fix,
+                       partial, out_dim, addend, ld_addend, act, keep, keep_scale, out, ld_out);
+    return launch_status("gv_rgcn_bdd_fixup");
 }
 
 extern "C" int gv_rgcn_bdd_grad_weight(const int32_t* items, int n_items, const int32_t* fix, int n_fix,
@@ -532,7 +562,8 @@ extern "C" int gv_rgcn_bdd_grad_weight(const int32_t* items, int n_items, const 
     if (rc == -1000) rc = launch_items(k_gradw_generic, a, n_items, st, "gv_rgcn_bdd_grad_weight(generic)");
     if (rc != GV_OK) return rc;
     if (n_fix > 0) {
-        hipLaunchKernelGGL(k_gradw_fixup, dim3((n_fix + 3) / 4), dim3(256), 0, st, (const int4*)fix, n_fix, partial,
+        const int waves = n_fix * ((a.w_row + 63) / 64);
+        hipLaunchKernelGGL(k_gradw_fixup, dim3((waves + 3) / 4), dim3(256), 0, st, (const int4*)fix, n_fix, partial,
                            a.w_row, grad_w, accumulate);
         return launch_status("gv_rgcn_bdd_grad_weight(fixup)");
     }

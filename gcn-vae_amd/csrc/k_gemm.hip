@@ -191,23 +191,42 @@ __global__ __launch_bounds__(256) void k_gemm_splitk_reduce(const GemmParams p) 
     }
 }
 
-// column sums: 64 row-slices, then an ordered 64-way sum
+// column sums: grid (column tiles of 64, row slices); the 4 waves of a block interleave the slice's rows
+// (4 loads in flight per lane), combine through LDS in wave order; a second kernel sums the slices in order.
+constexpr int COLSUM_SLICES = 64;
+
 __global__ __launch_bounds__(256) void k_colsum_part(const float* x, int64_t m, int n, int ld, float* part) {
-    const int slice = blockIdx.y, nsl = gridDim.y;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    const int64_t per = (m + nsl - 1) / nsl;
-    const int64_t r0 = slice * per, r1 = min(m, r0 + per);
-    float acc = 0.f;
-    for (int64_t r = r0; r < r1; ++r) acc += x[r * ld + c];
-    part[(size_t)slice * n + c] = acc;
+    __shared__ float sm[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int64_t per = (m + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = blockIdx.y * per, r1 = min(m, r0 + per);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < n) {
+        int64_t r = r0 + w;
+        for (; r + 12 < r1; r += 16) {
+            const float v0 = x[r * ld + c], v1 = x[(r + 4) * ld + c], v2 = x[(r + 8) * ld + c], v3 = x[(r + 12) * ld + c];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; r < r1; r += 4) a0 += x[r * ld + c];
+    }
+    sm[w][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (w == 0 && c < n) part[(size_t)blockIdx.y * n + c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
 __global__ __launch_bounds__(256) void k_colsum_final(const float* part, int n, int nsl, float* out, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
-    float acc = 0.f;
-    for (int s = 0; s < nsl; ++s) acc += part[(size_t)s * n + c];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 4 <= nsl; s += 4) {
+        const float v0 = part[(size_t)s * n + c], v1 = part[(size_t)(s + 1) * n + c];
+        const float v2 = part[(size_t)(s + 2) * n + c], v3 = part[(size_t)(s + 3) * n + c];
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; s < nsl; ++s) a0 += part[(size_t)s * n + c];
+    const float acc = (a0 + a1) + (a2 + a3);
     out[c] = accumulate ? out[c] + acc : acc;
 }
 
@@ -273,8 +292,8 @@ extern "C" int gv_colsum(const float* x, int64_t m, int n, int ld, float* out, f
     GV_REQUIRE(x && out && workspace, GV_ERR_NULL, "gv_colsum: NULL pointer");
     GV_REQUIRE(m >= 0 && n > 0 && ld >= n, GV_ERR_SHAPE, "gv_colsum: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    const int nsl = 64;
-    hipLaunchKernelGGL(k_colsum_part, dim3((n + 255) / 256, nsl), dim3(256), 0, st, x, m, n, ld, workspace);
-    hipLaunchKernelGGL(k_colsum_final, dim3((n + 255) / 256), dim3(256), 0, st, workspace, n, nsl, out, accumulate);
+    const int nsl = COLSUM_SLICES;
+    hipLaunchKernelGGL(k_colsum_part, dim3((n + 63) / 64, nsl), dim3(256), 0, st, x, m, n, ld, workspace);
+    hipLaunchKernelGGL(k_colsum_final, dim3((n + 63) / 64), dim3(64), 0, st, workspace, n, nsl, out, accumulate);
     return launch_status("gv_colsum");
 }

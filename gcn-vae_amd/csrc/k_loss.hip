@@ -108,9 +108,10 @@ __global__ __launch_bounds__(256) void k_kl_mix(const float* z_pre, int k, int h
     }
 }
 
-constexpr int KL_KMAX = 32;
+constexpr int KL_KMAX = 64;   // mixture components (lane j keeps component j's log-density)
 
-// one wave per node; mixture table staged in LDS once per block
+// one wave per node; mixture table staged in LDS once per block; CPL = columns per lane (h <= 64*CPL)
+template <int CPL>
 __global__ __launch_bounds__(256) void k_kl_fwd(const float* z, const float* m, int ld_m, const float* v,
                                                 const float* mix, const float* flp, float* resp, float* terms,
                                                 int64_t n, int h, int k) {
@@ -125,42 +126,38 @@ __global__ __launch_bounds__(256) void k_kl_fwd(const float* z, const float* m, 
     const float fl = flp ? *flp : 0.f;
     const float logk = logf((float)k);
     for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {
+        float zz[CPL];
         float a = 0.f;
-        float L[KL_KMAX];
 #pragma unroll
-        for (int j = 0; j < KL_KMAX; ++j) L[j] = 0.f;
-        for (int c = lane; c < h; c += 64) {
-            const float zz = z[r * h + c], mm = m[r * ld_m + c], vv = v[r * h + c];
-            const float d = zz - mm;
-            a += -(d * d) / (2.f * vv) - logf(sqrtf(vv)) - LOG_SQRT_2PI;
-#pragma unroll
-            for (int j = 0; j < KL_KMAX; ++j)
-                if (j < k) {
-                    const float dj = zz - mu[j * h + c];
-                    L[j] += -(dj * dj) * i2v[j * h + c] - lsv[j * h + c];
-                }
+        for (int i = 0; i < CPL; ++i) {
+            const int c = lane + 64 * i;
+            zz[i] = 0.f;
+            if (c < h) {
+                zz[i] = z[r * h + c];
+                const float d = zz[i] - m[r * ld_m + c], vv = v[r * h + c];
+                a += -(d * d) / (2.f * vv) - logf(sqrtf(vv)) - LOG_SQRT_2PI;
+            }
         }
         a = wave_sum(a);
-        float mx = -INFINITY;
+        float my_l = -INFINITY;
+        for (int j = 0; j < k; ++j) {
+            float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < KL_KMAX; ++j)
-            if (j < k) {
-                L[j] = wave_sum(L[j]);
-                mx = fmaxf(mx, L[j]);
+            for (int i = 0; i < CPL; ++i) {
+                const int c = lane + 64 * i;
+                if (c < h) {
+                    const float dj = zz[i] - mu[j * h + c];
+                    acc += -(dj * dj) * i2v[j * h + c] - lsv[j * h + c];
+                }
             }
-        float se = 0.f;
-#pragma unroll
-        for (int j = 0; j < KL_KMAX; ++j)
-            if (j < k) {
-                L[j] = expf(L[j] - mx);
-                se += L[j];
-            }
-        if (lane == 0) {
-            terms[r] = a + fl - (mx + logf(se) - logk);
-#pragma unroll
-            for (int j = 0; j < KL_KMAX; ++j)
-                if (j < k) resp[r * k + j] = L[j] / se;
+            acc = wave_sum(acc);
+            if (lane == j) my_l = acc;
         }
+        const float mx = wave_max(my_l);
+        const float e = lane < k ? expf(my_l - mx) : 0.f;
+        const float se = wave_sum(e);
+        if (lane < k) resp[r * k + lane] = e / se;
+        if (lane == 0) terms[r] = a + fl - (mx + logf(se) - logk);
     }
 }
 
@@ -190,22 +187,43 @@ __global__ __launch_bounds__(256) void k_kl_bwd_nodes(const float* z, const floa
     }
 }
 
-// mixture-parameter gradients: block (j, slice) sums over its node slice; threads own columns
+// mixture-parameter gradients: grid (component j, 64-column tile, node slice); the block's 4 waves
+// interleave the slice's nodes (2 rows in flight per lane) and combine through LDS in wave order.
 __global__ __launch_bounds__(256) void k_kl_bwd_mix_part(const float* z, const float* mix, const float* resp,
                                                          float* part, int64_t n, int h, int k) {
-    const int j = blockIdx.x, slice = blockIdx.y, nsl = gridDim.y;
+    __shared__ float sm[2][4][64];
+    const int j = blockIdx.x, slice = blockIdx.z, nsl = gridDim.z;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
     const int64_t per = (n + nsl - 1) / nsl;
     const int64_t r0 = slice * per, r1 = min(n, r0 + per);
     const int kh = k * h;
-    for (int c = threadIdx.x; c < h; c += 256) {
-        const float muj = mix[j * h + c], i2 = mix[kh + j * h + c];  // i2 = 1/(2 v_j)
-        float gmu = 0.f, gvv = 0.f;
-        for (int64_t r = r0; r < r1; ++r) {
-            const float rj = resp[r * k + j];
-            const float d = z[r * h + c] - muj;
-            gmu += rj * d;
-            gvv += rj * (d * d * 2.f * i2 * i2 - i2);     // (d^2/(2 v^2) - 1/(2v)) with i2 = 1/(2v)
+    float gmu0 = 0.f, gmu1 = 0.f, gv0 = 0.f, gv1 = 0.f;
+    const bool ok = c < h;
+    const float muj = ok ? mix[j * h + c] : 0.f, i2 = ok ? mix[kh + j * h + c] : 0.f;   // i2 = 1/(2 v_j)
+    if (ok) {
+        int64_t r = r0 + w;
+        for (; r + 4 < r1; r += 8) {
+            const float ra = resp[r * k + j], rb = resp[(r + 4) * k + j];
+            const float da = z[r * h + c] - muj, db = z[(r + 4) * h + c] - muj;
+            gmu0 += ra * da;
+            gmu1 += rb * db;
+            gv0 += ra * (da * da * 2.f * i2 * i2 - i2);      // d^2/(2 v^2) - 1/(2 v)
+            gv1 += rb * (db * db * 2.f * i2 * i2 - i2);
         }
+        for (; r < r1; r += 4) {
+            const float ra = resp[r * k + j];
+            const float da = z[r * h + c] - muj;
+            gmu0 += ra * da;
+            gv0 += ra * (da * da * 2.f * i2 * i2 - i2);
+        }
+    }
+    sm[0][w][lane] = gmu0 + gmu1;
+    sm[1][w][lane] = gv0 + gv1;
+    __syncthreads();
+    if (w == 0 && ok) {
+        const float gmu = (sm[0][0][lane] + sm[0][1][lane]) + (sm[0][2][lane] + sm[0][3][lane]);
+        const float gvv = (sm[1][0][lane] + sm[1][1][lane]) + (sm[1][2][lane] + sm[1][3][lane]);
         // d(-lme)/dmu = -resp * d / v ; d(-lme)/dv = -resp * (...)
         part[((size_t)slice * 2 * k + j) * h + c] = -gmu * 2.f * i2;
         part[((size_t)slice * 2 * k + k + j) * h + c] = -gvv;
@@ -217,8 +235,15 @@ __global__ __launch_bounds__(256) void k_kl_bwd_mix_final(const float* part, con
     const int total = 2 * k * h, kh = k * h;
     const float cg = (gkl ? *gkl : 1.f) / (float)n;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        float acc = 0.f;
-        for (int s = 0; s < nsl; ++s) acc += part[(size_t)s * total + i];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int s = 0;
+        for (; s + 4 <= nsl; s += 4) {
+            const float v0 = part[(size_t)s * total + i], v1 = part[(size_t)(s + 1) * total + i];
+            const float v2 = part[(size_t)(s + 2) * total + i], v3 = part[(size_t)(s + 3) * total + i];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; s < nsl; ++s) a0 += part[(size_t)s * total + i];
+        float acc = (a0 + a1) + (a2 + a3);
         if (i >= kh) {  // chain through v_j = softplus(raw) + 1e-8
             const float raw = z_pre[i];
             acc *= raw > 20.f ? 1.f : 1.f / (1.f + expf(-raw));
@@ -227,7 +252,122 @@ __global__ __launch_bounds__(256) void k_kl_bwd_mix_final(const float* part, con
     }
 }
 
-constexpr int KL_SLICES = 32;
+// ---- MMD (KGVAE.get_mmd / compute_kernel, kgvae/model.py:71-80, :89-102) -------------------------------
+//   K(a, b) = exp(-mean_d (a_d - b_d)^2 / h) ;  mmd = mean Kxx + mean Kyy - 2 mean Kxy
+// grid: one block per row of x (first sx blocks) or of y; the block's 4 waves walk the partner rows.
+constexpr int MMD_CPL = 16;   // columns per lane: h <= 1024
+
+__global__ __launch_bounds__(256) void k_mmd_fwd(const float* x, const float* y, int sx, int sy, int h, float* part) {
+    __shared__ float sm[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool is_x = (int)blockIdx.x < sx;
+    const float* a = is_x ? x + (size_t)blockIdx.x * h : y + (size_t)(blockIdx.x - sx) * h;
+    float av[MMD_CPL];
+#pragma unroll
+    for (int i = 0; i < MMD_CPL; ++i) av[i] = (lane + 64 * i < h) ? a[lane + 64 * i] : 0.f;
+    const float inv = 1.f / ((float)h * (float)h);
+    float tot = 0.f;
+    // x rows: + Kxx/sx^2 - 2 Kxy/(sx sy);   y rows: + Kyy/sy^2
+    const int n_same = is_x ? sx : sy;
+    const float* same = is_x ? x : y;
+    const float w_same = 1.f / ((float)n_same * (float)n_same);
+    for (int j = w; j < n_same; j += 4) {
+        float d2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MMD_CPL; ++i)
+            if (lane + 64 * i < h) { const float d = av[i] - same[(size_t)j * h + lane + 64 * i]; d2 = fmaf(d, d, d2); }
+        d2 = wave_sum(d2);
+        tot += w_same * expf(-d2 * inv);
+    }
+    if (is_x) {
+        const float w_x = -2.f / ((float)sx * (float)sy);
+        for (int j = w; j < sy; j += 4) {
+            float d2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MMD_CPL; ++i)
+                if (lane + 64 * i < h) { const float d = av[i] - y[(size_t)j * h + lane + 64 * i]; d2 = fmaf(d, d, d2); }
+            d2 = wave_sum(d2);
+            tot += w_x * expf(-d2 * inv);
+        }
+    }
+    __syncthreads();
+    if (lane == 0) sm[w] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+__global__ __launch_bounds__(256) void k_mmd_bwd(const float* x, const float* y, int sx, int sy, int h, const float* gmmd,
+                                                 float* gx, float* gy) {
+    __shared__ float sm[4][64 * MMD_CPL];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool is_x = (int)blockIdx.x < sx;
+    const int row = is_x ? blockIdx.x : blockIdx.x - sx;
+    const float* a = (is_x ? x : y) + (size_t)row * h;
+    float av[MMD_CPL], acc[MMD_CPL];
+#pragma unroll
+    for (int i = 0; i < MMD_CPL; ++i) { av[i] = (lane + 64 * i < h) ? a[lane + 64 * i] : 0.f; acc[i] = 0.f; }
+    const float inv = 1.f / ((float)h * (float)h);
+    const float g = gmmd ? *gmmd : 1.f;
+    const int n_same = is_x ? sx : sy, n_other = is_x ? sy : sx;
+    const float* same = is_x ? x : y;
+    const float* other = is_x ? y : x;
+    // d mmd / d a = (-2/h^2) [ (2/n_same^2) sum_j K(a,same_j)(a - same_j) - (2/(sx sy)) sum_j K(a,other_j)(a - other_j) ]
+    const float c_same = g * (-2.f * inv) * 2.f / ((float)n_same * (float)n_same);
+    const float c_other = g * (-2.f * inv) * (-2.f) / ((float)sx * (float)sy);
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* b = pass == 0 ? same : other;
+        const int nb = pass == 0 ? n_same : n_other;
+        const float cf = pass == 0 ? c_same : c_other;
+        for (int j = w; j < nb; j += 4) {
+            float bv[MMD_CPL];
+            float d2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MMD_CPL; ++i) {
+                bv[i] = (lane + 64 * i < h) ? b[(size_t)j * h + lane + 64 * i] : 0.f;
+                const float d = av[i] - bv[i];
+                d2 = fmaf(d, d, d2);
+            }
+            d2 = wave_sum(d2);
+            const float kv = cf * expf(-d2 * inv);
+#pragma unroll
+            for (int i = 0; i < MMD_CPL; ++i) acc[i] = fmaf(kv, av[i] - bv[i], acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MMD_CPL; ++i) sm[w][lane + 64 * i] = acc[i];
+    __syncthreads();
+    float* o = (is_x ? gx : gy) + (size_t)row * h;
+    for (int c = threadIdx.x; c < h; c += 256) o[c] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+}
+
+// prior samples of get_mmd: z_pri[i] = mu[i % k] + eps[i] * sqrt(softplus(raw[i % k]) + 1e-8)   (z_pre = [mu; raw], (2k, h))
+__global__ __launch_bounds__(256) void k_prior_sample_fwd(const float* z_pre, const float* eps, float* out, int s, int k, int h) {
+    const int total = s * h;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int r = i / h, c = i - r * h, j = r % k;
+        const float v = softplus_t(z_pre[(size_t)(k + j) * h + c]) + 1e-8f;
+        out[i] = z_pre[(size_t)j * h + c] + eps[i] * sqrtf(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_prior_sample_bwd(const float* z_pre, const float* eps, const float* g, float* gz_pre,
+                                                          int s, int k, int h) {
+    const int total = k * h;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int j = i / h, c = i - j * h;
+        const float raw = z_pre[(size_t)(k + j) * h + c];
+        const float v = softplus_t(raw) + 1e-8f;
+        float gm = 0.f, gs = 0.f;
+        for (int r = j; r < s; r += k) {
+            gm += g[(size_t)r * h + c];
+            gs += g[(size_t)r * h + c] * eps[(size_t)r * h + c];
+        }
+        gz_pre[i] = gm;
+        gz_pre[total + i] = gs * 0.5f / sqrtf(v) * (raw > 20.f ? 1.f : 1.f / (1.f + expf(-raw)));
+    }
+}
+
+constexpr int KL_SLICES = 64;
 
 }  // namespace gv
 
@@ -290,7 +430,14 @@ extern "C" int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* 
     float* part = terms + n;
     hipLaunchKernelGGL(k_kl_mix, dim3((k * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, k, h, mix);
     const int nb = (int)((n + 3) / 4 > 1024 ? 1024 : (n + 3) / 4);
-    hipLaunchKernelGGL(k_kl_fwd, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, flp, resp, terms, n, h, k);
+    GV_REQUIRE(h <= 1024, GV_ERR_SHAPE, "gv_kl_fwd: h=%d > 1024 unsupported", h);
+#define GV_KL_FWD(CPL_) hipLaunchKernelGGL(k_kl_fwd<CPL_>, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, flp, resp, terms, n, h, k)
+    if (h <= 64) GV_KL_FWD(1);
+    else if (h <= 128) GV_KL_FWD(2);
+    else if (h <= 256) GV_KL_FWD(4);
+    else if (h <= 512) GV_KL_FWD(8);
+    else GV_KL_FWD(16);
+#undef GV_KL_FWD
     // mean over nodes: ordered two-pass sum of terms (reuse the sum kernel: part = terms chunks)
     (void)part;
     // mean over nodes: one block sums terms[] in a fixed order
@@ -311,8 +458,42 @@ extern "C" int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* 
     hipLaunchKernelGGL(k_kl_bwd_nodes, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, resp, gkl, gz, gm, gv, n,
                        h, k);
     float* part = workspace + 3 * (size_t)k * h + n + RED_BLOCKS;
-    hipLaunchKernelGGL(k_kl_bwd_mix_part, dim3(k, KL_SLICES), dim3(256), 0, GV_ST, z, mix, resp, part, n, h, k);
+    hipLaunchKernelGGL(k_kl_bwd_mix_part, dim3(k, (h + 63) / 64, KL_SLICES), dim3(256), 0, GV_ST, z, mix, resp, part, n,
+                       h, k);
     hipLaunchKernelGGL(k_kl_bwd_mix_final, dim3((2 * k * h + 255) / 256), dim3(256), 0, GV_ST, part, z_pre, gkl,
                        g_zpre, n, h, k, KL_SLICES);
     return launch_status("gv_kl_bwd");
+}
+
+extern "C" int gv_mmd_fwd(const float* x, const float* y, int sx, int sy, int h, float* mmd, float* workspace,
+                          void* stream) {
+    GV_REQUIRE(x && y && mmd && workspace, GV_ERR_NULL, "gv_mmd_fwd: NULL pointer");
+    GV_REQUIRE(sx > 0 && sy > 0 && h > 0 && h <= 64 * MMD_CPL && sx + sy <= RED_BLOCKS, GV_ERR_SHAPE,
+               "gv_mmd_fwd: sx=%d sy=%d h=%d (need h <= %d, sx+sy <= %d)", sx, sy, h, 64 * MMD_CPL, RED_BLOCKS);
+    hipLaunchKernelGGL(k_mmd_fwd, dim3(sx + sy), dim3(256), 0, GV_ST, x, y, sx, sy, h, workspace);
+    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, sx + sy, 1.f, mmd, 0);
+    return launch_status("gv_mmd_fwd");
+}
+
+extern "C" int gv_mmd_bwd(const float* x, const float* y, int sx, int sy, int h, const float* gmmd, float* gx,
+                          float* gy, void* stream) {
+    GV_REQUIRE(x && y && gx && gy, GV_ERR_NULL, "gv_mmd_bwd: NULL pointer");
+    GV_REQUIRE(sx > 0 && sy > 0 && h > 0 && h <= 64 * MMD_CPL, GV_ERR_SHAPE, "gv_mmd_bwd: bad shape");
+    hipLaunchKernelGGL(k_mmd_bwd, dim3(sx + sy), dim3(256), 0, GV_ST, x, y, sx, sy, h, gmmd, gx, gy);
+    return launch_status("gv_mmd_bwd");
+}
+
+extern "C" int gv_prior_sample_fwd(const float* z_pre, const float* eps, float* out, int s, int k, int h, void* stream) {
+    GV_REQUIRE(z_pre && eps && out, GV_ERR_NULL, "gv_prior_sample_fwd: NULL pointer");
+    GV_REQUIRE(s > 0 && k > 0 && h > 0, GV_ERR_SHAPE, "gv_prior_sample_fwd: bad shape");
+    hipLaunchKernelGGL(k_prior_sample_fwd, dim3((s * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, eps, out, s, k, h);
+    return launch_status("gv_prior_sample_fwd");
+}
+
+extern "C" int gv_prior_sample_bwd(const float* z_pre, const float* eps, const float* g, float* gz_pre, int s, int k,
+                                   int h, void* stream) {
+    GV_REQUIRE(z_pre && eps && g && gz_pre, GV_ERR_NULL, "gv_prior_sample_bwd: NULL pointer");
+    GV_REQUIRE(s > 0 && k > 0 && h > 0, GV_ERR_SHAPE, "gv_prior_sample_bwd: bad shape");
+    hipLaunchKernelGGL(k_prior_sample_bwd, dim3((k * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, eps, g, gz_pre, s, k, h);
+    return launch_status("gv_prior_sample_bwd");
 }

@@ -93,19 +93,20 @@ class KGVAE(nn.Module):
         return ops.kl_to_mixture(z, self.z_mean, self.z_sigma, self.z_pre.squeeze(0), self.flow_log_prob)
 
     def get_mmd(self, z):
-        m_mix, s_mix = prob.gaussian_parameters(self.z_pre, dim=1)
         num_sample = 200
-        z_pri = prob.sample_gaussian(m_mix, s_mix, repeat=num_sample // self.k, eps=self.mmd_eps_override)
+        rows = (num_sample // self.k) * self.k if num_sample // self.k > 1 else self.k
+        eps = self.mmd_eps_override if self.mmd_eps_override is not None else \
+            torch.randn(rows, self.h_dim, device=z.device, dtype=z.dtype)
+        z_pri = ops.prior_sample(self.z_pre.squeeze(0), eps)      # sample_gaussian(m_mix, s_mix, repeat)
         if self.n_flows > 0:
             for flow in self.nf:
                 z_pri, _ = flow.forward(z_pri)
         if self.mmd_index_override is not None:
             pick = self.mmd_index_override
-        else:
+        else:   # (Monte Carlo) posterior rows, python RNG as in the reference
             pick = torch.tensor(random.sample(range(z.shape[0]), num_sample), device=z.device)
-        z_post = z[pick]
-        return (self.compute_kernel(z_pri, z_pri).mean() + self.compute_kernel(z_post, z_post).mean()
-                - 2 * self.compute_kernel(z_pri, z_post).mean())
+        z_post = ops.embedding(z, pick)
+        return ops.mmd(z_pri, z_post)
 
     def get_flow_log_prob(self):
         return self.flow_log_prob

@@ -20,6 +20,7 @@ SIGNATURES = {
     'gv_segment_items_fill': (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P]),
     'gv_rgcn_bdd_aggregate': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I,
                                    _P, _I, _I, _P, _F, _P, _I, _P, _P]),
+    'gv_rgcn_bdd_fixup': (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _F, _P, _I, _P]),
     'gv_rgcn_bdd_grad_weight': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
     'gv_rgcn_epilogue_fwd': (_I, [_P, _P, _I, _P, _F, _P, _L, _I, _P]),
     'gv_rgcn_epilogue_bwd': (_I, [_P, _P, _I, _P, _F, _P, _L, _I, _P]),
@@ -38,6 +39,10 @@ SIGNATURES = {
     'gv_kl_workspace_bytes': (_L, [_L, _I, _I]),
     'gv_kl_fwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'gv_kl_bwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    'gv_mmd_fwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    'gv_mmd_bwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    'gv_prior_sample_fwd': (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    'gv_prior_sample_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     'gv_iaf_update_fwd': (_I, [_P, _P, _P, _P, _P, _L, _I, _P]),
     'gv_iaf_update_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     'gv_rowsum': (_I, [_P, _I, _I, _I, _P, _L, _P]),
@@ -68,9 +73,37 @@ def last_error():
     return load().gv_last_error_string().decode('utf-8', 'replace')
 
 
-def call(name, *args):
+class KernelTimer:
+    """Brackets selected C-ABI launches with HIP events on torch's current stream (the stream the
+    kernels are enqueued on).  Used by bench.py for the roofline figure; never active otherwise."""
+
+    def __init__(self):
+        self.events = {}
+
+    def bracket(self, key, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.events.setdefault(key, []).append((s, e))
+
+    def results_ms(self):
+        torch.cuda.synchronize()
+        return {k: [s.elapsed_time(e) for s, e in v] for k, v in self.events.items()}
+
+
+TIMER = None      # set to a KernelTimer to time tagged launches
+
+
+def call(name, *args, tag=None):
     """Invoke an int-returning entry point; non-zero status raises with the library's message."""
-    rc = getattr(load(), name)(*args)
+    fn = getattr(load(), name)
+    if TIMER is not None and tag is not None:
+        box = []
+        TIMER.bracket(tag, lambda: box.append(fn(*args)))
+        rc = box[0]
+    else:
+        rc = fn(*args)
     if rc != 0:
         raise RuntimeError(f'{name} failed with status {rc}: {last_error()}')
 

@@ -214,10 +214,16 @@ def bdd_aggregate(seg: SegmentItems, nbr, etype, coef, coef_idx, feat, weight, n
     partial = None
     if seg.n_fix > 0:
         partial = torch.empty(seg.n_slots, out_dim, dtype=torch.float32, device=feat.device)
-    lib.call('gv_rgcn_bdd_aggregate', ptr(seg.items), seg.n_items, ptr(seg.fix), seg.n_fix, ptr(nbr), ptr(etype),
-             ptr(coef), ptr(coef_idx), ptr(feat), ld_feat, ptr(weight), num_rels, num_bases, blk_in, blk_out,
-             1 if transpose_w else 0, ptr(addend), ld_add, act, ptr(keep), float(keep_scale), ptr(out),
-             out.stride(0) if n_seg > 1 else out_dim, ptr(partial), lib.stream())
+    ld_out = out.stride(0) if n_seg > 1 else out_dim
+    tag = f'agg_{"T" if transpose_w else "N"}_{blk_in}x{blk_out}_nb{num_bases}'
+    timed = lib.TIMER is not None
+    lib.call('gv_rgcn_bdd_aggregate', ptr(seg.items), seg.n_items, ptr(seg.fix), 0 if timed else seg.n_fix, ptr(nbr),
+             ptr(etype), ptr(coef), ptr(coef_idx), ptr(feat), ld_feat, ptr(weight), num_rels, num_bases, blk_in,
+             blk_out, 1 if transpose_w else 0, ptr(addend), ld_add, act, ptr(keep), float(keep_scale), ptr(out),
+             ld_out, ptr(partial), lib.stream(), tag=tag)
+    if timed and seg.n_fix > 0:      # the aggregation kernel was timed alone; finish the split rows
+        lib.call('gv_rgcn_bdd_fixup', ptr(seg.fix), seg.n_fix, ptr(partial), out_dim, ptr(addend), ld_add, act,
+                 ptr(keep), float(keep_scale), ptr(out), ld_out, lib.stream())
     return out
 
 
@@ -237,7 +243,7 @@ def bdd_grad_weight(seg: SegmentItems, src, dst, coef, coef_idx, x, g, num_bases
         partial = torch.empty(seg.n_slots, w_row, dtype=torch.float32, device=x.device)
     lib.call('gv_rgcn_bdd_grad_weight', ptr(seg.items), seg.n_items, ptr(seg.fix), seg.n_fix, ptr(src), ptr(dst),
              ptr(coef), ptr(coef_idx), ptr(x), ld_x, ptr(g), ld_g, num_bases, blk_in, blk_out, ptr(out), ptr(partial),
-             1 if accumulate else 0, lib.stream())
+             1 if accumulate else 0, lib.stream(), tag=f'gradw_{blk_in}x{blk_out}_nb{num_bases}')
     return out
 
 
@@ -711,3 +717,55 @@ class _MatMul(torch.autograd.Function):
 
 def matmul(a, b):
     return _MatMul.apply(a, b)
+
+
+class _MMD(torch.autograd.Function):
+    """KGVAE.get_mmd's three RBF-kernel means on x (sx, h) and y (sy, h), fused forward / backward."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = _chk(x.contiguous(), name='z_pri'), _chk(y.contiguous(), name='z_post')
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        ws = torch.empty(x.shape[0] + y.shape[0], dtype=torch.float32, device=x.device)
+        lib.call('gv_mmd_fwd', ptr(x), ptr(y), x.shape[0], y.shape[0], x.shape[1], ptr(out), ptr(ws), lib.stream())
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        g = _chk(g.reshape(1).contiguous(), name='g')
+        gx, gy = torch.empty_like(x), torch.empty_like(y)
+        lib.call('gv_mmd_bwd', ptr(x), ptr(y), x.shape[0], y.shape[0], x.shape[1], ptr(g), ptr(gx), ptr(gy),
+                 lib.stream())
+        return gx, gy
+
+
+def mmd(x, y):
+    return _MMD.apply(x, y)
+
+
+class _PriorSample(torch.autograd.Function):
+    """z_pri = cat([m]*repeat) + eps * cat([sqrt(softplus(raw)+1e-8)]*repeat) for z_pre = [m; raw] (2k, h)."""
+
+    @staticmethod
+    def forward(ctx, z_pre, eps):
+        z_pre, eps = _chk(z_pre.contiguous(), name='z_pre'), _chk(eps.contiguous(), name='eps')
+        k, h = z_pre.shape[0] // 2, z_pre.shape[1]
+        out = torch.empty_like(eps)
+        lib.call('gv_prior_sample_fwd', ptr(z_pre), ptr(eps), ptr(out), eps.shape[0], k, h, lib.stream())
+        ctx.save_for_backward(z_pre, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z_pre, eps = ctx.saved_tensors
+        g = _chk(g.contiguous(), name='g')
+        gz = torch.empty_like(z_pre)
+        lib.call('gv_prior_sample_bwd', ptr(z_pre), ptr(eps), ptr(g), ptr(gz), eps.shape[0], z_pre.shape[0] // 2,
+                 z_pre.shape[1], lib.stream())
+        return gz, None
+
+
+def prior_sample(z_pre, eps):
+    return _PriorSample.apply(z_pre, eps)

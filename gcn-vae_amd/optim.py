@@ -1,0 +1,60 @@
+"""Gradient clipping + Adam over ONE flat parameter arena (kgvae/link_predict.py:227-228:
+``clip_grad_norm_(model.parameters(), grad_norm); optimizer.step()``).
+
+Parameters and their gradients are re-pointed at slices of two persistent device buffers, so the
+whole optimiser step is three launches (sum of squares, ordered final sum, fused clip+Adam) instead of
+torch's per-tensor / foreach kernel sets, and every address is static -- the step is hipGraph-capturable.
+Numerics follow ``torch.nn.utils.clip_grad_norm_`` (coefficient min(1, max_norm / (norm + 1e-6))) and
+``torch.optim.Adam`` (bias correction, eps added outside the square root).
+"""
+import torch
+
+from . import lib
+from .lib import ptr
+
+
+class FlatAdam:
+    ALIGN = 64   # floats: keeps every parameter 256-B aligned for the 16-B vector paths of the kernels
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError('FlatAdam: no trainable parameters')
+        dev = self.params[0].device
+        if dev.type != 'cuda':
+            raise RuntimeError('FlatAdam runs on a ROCm device only; move the model first (no CPU fallback)')
+        self.lr, self.betas, self.eps, self.max_grad_norm = lr, betas, eps, max_grad_norm
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.total = total
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.step_t = torch.zeros((), dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros((), dtype=torch.float32, device=dev)
+        self._ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, offs):
+            n = p.numel()
+            self.flat_p[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[o:o + n].view(p.shape)
+            p.grad = self.flat_g[o:o + n].view(p.shape)
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def grad_norm(self):
+        """Total gradient norm of the last ``step`` (device scalar)."""
+        return self.sumsq.sqrt()
+
+    def step(self):
+        self.step_t += 1
+        sumsq = None
+        if self.max_grad_norm is not None:
+            lib.call('gv_mean_sq', ptr(self.flat_g), self.total, 1.0, ptr(self.sumsq), ptr(self._ws), 0, lib.stream())
+            sumsq = self.sumsq
+        lib.call('gv_adam_step', ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                 self.total, ptr(sumsq), float(self.max_grad_norm or 0.0), float(self.lr), float(self.betas[0]),
+                 float(self.betas[1]), float(self.eps), ptr(self.step_t), lib.stream())

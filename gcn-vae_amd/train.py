@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops, ranking, sampling
+from .optim import FlatAdam
 from .data import load_data
 from .encoders import KGVAE, RGCN
 from .sampling import node_norm_to_edge_norm
@@ -104,7 +105,7 @@ def main(args):
     valid_t = torch.as_tensor(valid_data, dtype=torch.long, device=dev)
     val_graph, val_node_id, val_rel, val_norm = graph_inputs(valid_data)     # eval graph from VALID triplets (:141-147)
     adj_list, degrees = sampling.get_adj_and_degrees(num_nodes, train_data)
-    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
+    optimizer = FlatAdam(model.parameters(), lr=args.lr, max_grad_norm=args.grad_norm)   # clip + Adam, one arena
     forward_time, backward_time = [], []
 
     if args.test_mode is True:
@@ -146,8 +147,7 @@ def main(args):
         _sync()
         t1 = time.time()
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), args.grad_norm)
-        optimizer.step()
+        optimizer.step()              # clip_grad_norm_(grad_norm) + Adam, fused
         _sync()
         t2 = time.time()
         forward_time.append(t1 - t0)

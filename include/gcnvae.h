@@ -77,6 +77,12 @@ int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const int32_t* fix,
                           const float* addend, int ld_addend, int act, const uint8_t* keep, float keep_scale,
                           float* out, int ld_out, float* partial, void* stream);
 
+/* The fix-up pass of gv_rgcn_bdd_aggregate on its own (a caller that passed n_fix = 0 there, e.g. to
+ * time the aggregation kernel alone, finishes the split rows with this). */
+int gv_rgcn_bdd_fixup(const int32_t* fix, int n_fix, const float* partial, int out_dim, const float* addend,
+                      int ld_addend, int act, const uint8_t* keep, float keep_scale, float* out, int ld_out,
+                      void* stream);
+
 /* K1 backward w.r.t. the block weights (edges ordered by relation; segments = relations):
  *   grad_W[r, b, i, j] = sum_{e: etype_e = r} norm_e * x[src_e, b*si+i] * g[dst_e, b*so+j]
  * partial: [n_slots, nb*si*so] workspace. accumulate != 0 adds into grad_w instead of overwriting. */
@@ -150,6 +156,18 @@ int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* v, const fl
 int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre, const float* resp,
               const float* gkl, float* gz, float* gm, float* gv, float* g_zpre, float* workspace, int64_t n, int h,
               int k, void* stream);
+
+/*   gv_mmd_*  : KGVAE.get_mmd / compute_kernel (kgvae/model.py:71-80, :89-102) on x = prior samples (sx, h),
+ *       y = posterior rows (sy, h):  K(a,b) = exp(-mean_d (a_d-b_d)^2 / h);  mmd = mean Kxx + mean Kyy - 2 mean Kxy.
+ *       workspace: sx + sy floats (sx + sy <= 1024).  bwd overwrites gx (sx, h), gy (sy, h), scaled by *gmmd.
+ *   gv_prior_sample_* : the prior draw of get_mmd (sample_gaussian(..., repeat), kgvae/utils.py:355-361):
+ *       out[i] = mu[i % k] + eps[i] * sqrt(softplus(raw[i % k]) + 1e-8), z_pre = [mu; raw] (2k, h); bwd -> gz_pre (2k, h). */
+int gv_mmd_fwd(const float* x, const float* y, int sx, int sy, int h, float* mmd, float* workspace, void* stream);
+int gv_mmd_bwd(const float* x, const float* y, int sx, int sy, int h, const float* gmmd, float* gx, float* gy,
+               void* stream);
+int gv_prior_sample_fwd(const float* z_pre, const float* eps, float* out, int s, int k, int h, void* stream);
+int gv_prior_sample_bwd(const float* z_pre, const float* eps, const float* g, float* gz_pre, int s, int k, int h,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4  IAF / MADE update step (kgvae/flow_network.py:93-96); the masked linears are gv_gemm_f32.

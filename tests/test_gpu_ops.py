@@ -272,3 +272,47 @@ def test_mean_sq_and_kl(ops):
 def test_product_rejects_cpu_tensors(ops):
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         ops.gemm(torch.randn(4, 4), torch.randn(4, 4))
+
+
+def test_mmd_and_prior_sample(ops):
+    from oracle import prob as op_
+    gen = torch.Generator().manual_seed(4)
+    k, h = 10, 200
+    z_pre = torch.randn(1, 2 * k, h, generator=gen) * 0.3
+    eps = torch.randn(200, h, generator=gen)
+    y = torch.randn(150, h, generator=gen) * 0.8
+    zo, yo = z_pre.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    m_mix, v_mix = op_.gaussian_parameters(zo, dim=1)
+    xo = op_.sample_gaussian(m_mix, v_mix, eps, repeat=20)
+    mo = okg.rbf_kernel(xo, xo).mean() + okg.rbf_kernel(yo, yo).mean() - 2 * okg.rbf_kernel(xo, yo).mean()
+    (mo * 1.3).backward()
+    zg, yg = z_pre.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    xg = ops.prior_sample(zg.squeeze(0), eps.cuda())
+    mg = ops.mmd(xg, yg)
+    (mg * 1.3).backward()
+    close(xg, xo)
+    close(mg, mo, atol_scale=1e-6)
+    close(zg.grad, zo.grad, rtol=2e-4, atol_scale=2e-5)
+    close(yg.grad, yo.grad, rtol=2e-4, atol_scale=2e-5)
+
+
+def test_flat_adam_matches_torch_clip_and_adam(ops):
+    from gcn_vae_amd.optim import FlatAdam
+    gen = torch.Generator().manual_seed(6)
+    shapes = [(37, 5), (200,), (3, 4, 5), (1,)]
+    ref = [torch.nn.Parameter(torch.randn(*s, generator=gen)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref]
+    opt_r = torch.optim.Adam(ref, lr=1e-2)
+    opt_m = FlatAdam(mine, lr=1e-2, max_grad_norm=0.7)
+    for it in range(5):
+        grads = [torch.randn(*s, generator=gen) * (3.0 if it % 2 else 0.05) for s in shapes]
+        for p, gr in zip(ref, grads):
+            p.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 0.7)
+        opt_r.step()
+        opt_m.zero_grad()
+        for p, gr in zip(mine, grads):
+            p.grad += gr.cuda()
+        opt_m.step()
+        for a, b in zip(mine, ref):
+            close(a, b, rtol=2e-5, atol_scale=1e-6)
