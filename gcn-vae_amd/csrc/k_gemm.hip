@@ -15,8 +15,8 @@
 
 namespace gv {
 
-constexpr int BM = 128, BN = 64, BK = 16;
-constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
+constexpr int BN = 64, BK = 16;
+constexpr int LDB_S = BN + 1;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -31,15 +31,17 @@ struct GemmParams {
     int vec_a, vec_b;
 };
 
-// ---- global -> registers (8 floats of A, 4 floats of B per thread), zero-filled outside the matrix
-template <bool TA>
-__device__ __forceinline__ void load_a(const GemmParams& p, int m0, int k0, int kend, float (&r)[8]) {
+// ---- global -> registers (BM/16 floats of A, 4 floats of B per thread), zero-filled outside the matrix
+template <bool TA, int BM>
+__device__ __forceinline__ void load_a(const GemmParams& p, int m0, int k0, int kend, float (&r)[BM / 16]) {
+    constexpr int APT = BM / 16;       // floats per thread: 8 (BM=128) or 4 (BM=64)
     const int t = threadIdx.x;
-    if constexpr (!TA) {  // A is [M, K], K contiguous: thread -> row t/2, 8 consecutive k
-        const int m = m0 + (t >> 1), kk = k0 + (t & 1) * 8;
+    if constexpr (!TA) {               // A is [M, K], K contiguous: 16/APT threads per row, APT consecutive k each
+        constexpr int TPR = 16 / APT;
+        const int m = m0 + t / TPR, kk = k0 + (t % TPR) * APT;
         const float* src = p.a + (size_t)m * p.lda + kk;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < APT / 4; ++h) {
             const int kq = kk + 4 * h;
             if (m < p.m && p.vec_a && kq + 3 < kend) {
                 const float4 v = *reinterpret_cast<const float4*>(src + 4 * h);
@@ -49,11 +51,11 @@ __device__ __forceinline__ void load_a(const GemmParams& p, int m0, int k0, int 
                 for (int i = 0; i < 4; ++i) r[4 * h + i] = (m < p.m && kq + i < kend) ? src[4 * h + i] : 0.f;
             }
         }
-    } else {  // A is stored [K, M], M contiguous: thread -> k t/16, 8 consecutive m
-        const int kq = k0 + (t >> 4), m = m0 + (t & 15) * 8;
+    } else {                           // A is stored [K, M], M contiguous: thread -> k t/16, APT consecutive m
+        const int kq = k0 + (t >> 4), m = m0 + (t & 15) * APT;
         const float* src = p.a + (size_t)kq * p.lda + m;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < APT / 4; ++h) {
             const int mq = m + 4 * h;
             if (kq < kend && p.vec_a && mq + 3 < p.m) {
                 const float4 v = *reinterpret_cast<const float4*>(src + 4 * h);
@@ -92,17 +94,19 @@ __device__ __forceinline__ void load_b(const GemmParams& p, int n0, int k0, int 
     }
 }
 
-template <bool TA>
-__device__ __forceinline__ void stage_a(float* As, const float (&r)[8]) {
+template <bool TA, int BM>
+__device__ __forceinline__ void stage_a(float* As, const float (&r)[BM / 16]) {
+    constexpr int APT = BM / 16, LDA_S = BM + 1;
     const int t = threadIdx.x;
     if constexpr (!TA) {
-        const int m = t >> 1, kk = (t & 1) * 8;
+        constexpr int TPR = 16 / APT;
+        const int m = t / TPR, kk = (t % TPR) * APT;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) As[(kk + i) * LDA_S + m] = r[i];
+        for (int i = 0; i < APT; ++i) As[(kk + i) * LDA_S + m] = r[i];
     } else {
-        const int kq = t >> 4, m = (t & 15) * 8;
+        const int kq = t >> 4, m = (t & 15) * APT;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) As[kq * LDA_S + m + i] = r[i];
+        for (int i = 0; i < APT; ++i) As[kq * LDA_S + m + i] = r[i];
     }
 }
 
@@ -120,39 +124,44 @@ __device__ __forceinline__ void stage_b(float* Bs, const float (&r)[4]) {
     }
 }
 
-template <bool TA, bool TB>
+// MT = 32-row MFMA tiles per wave: block tile (64*MT) x 64, four waves as 2 (M) x 2 (N).
+template <bool TA, bool TB, int MT>
 __global__ __launch_bounds__(256) void k_gemm_f32(const GemmParams p) {
+    constexpr int BM = 64 * MT, LDA_S = BM + 1;
     __shared__ float As[BK * LDA_S];
     __shared__ float Bs[BK * LDB_S];
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * p.k_chunk;
     const int kend = min(p.k, kbeg + p.k_chunk);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int wm = (wid >> 1) * 64, wn = (wid & 1) * 32;
+    const int wm = (wid >> 1) * 32 * MT, wn = (wid & 1) * 32;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    f32x16 acc0, acc1;
+    f32x16 acc[MT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    float ra[8], rb[4];
-    load_a<TA>(p, m0, kbeg, kend, ra);
+    float ra[BM / 16], rb[4];
+    load_a<TA, BM>(p, m0, kbeg, kend, ra);
     load_b<TB>(p, n0, kbeg, kend, rb);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        stage_a<TA>(As, ra);
+        stage_a<TA, BM>(As, ra);
         stage_b<TB>(Bs, rb);
         __syncthreads();
         if (k0 + BK < kend) {  // next tile's loads fly under this tile's MFMAs
-            load_a<TA>(p, m0, k0 + BK, kend, ra);
+            load_a<TA, BM>(p, m0, k0 + BK, kend, ra);
             load_b<TB>(p, n0, k0 + BK, kend, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const float b = Bs[(kk + lhi) * LDB_S + wn + l31];
-            const float a0 = As[(kk + lhi) * LDA_S + wm + l31];
-            const float a1 = As[(kk + lhi) * LDA_S + wm + 32 + l31];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const float a = As[(kk + lhi) * LDA_S + wm + 32 * t + l31];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -161,12 +170,12 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmParams p) {
     if (col >= p.n) return;
     const float bv = (p.bias && p.split_k == 1) ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int t = 0; t < MT; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm + half * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const int row = m0 + wm + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
             if (row >= p.m) continue;
-            float v = half ? acc1[r] : acc0[r];
+            float v = acc[t][r];
             if (p.split_k > 1) {
                 p.ws[((size_t)blockIdx.z * p.m + row) * p.n + col] = v;
             } else {
@@ -271,11 +280,21 @@ extern "C" int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const 
                    (long long)gv_gemm_workspace_bytes(m, n, k, split_k));
     }
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM, split_k), block(256);
-    if (!trans_a && !trans_b) hipLaunchKernelGGL((k_gemm_f32<false, false>), grid, block, 0, st, p);
-    else if (!trans_a && trans_b) hipLaunchKernelGGL((k_gemm_f32<false, true>), grid, block, 0, st, p);
-    else if (trans_a && !trans_b) hipLaunchKernelGGL((k_gemm_f32<true, false>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((k_gemm_f32<true, true>), grid, block, 0, st, p);
+    // 128-row tiles only when they still give every CU >= 4 blocks; otherwise 64-row tiles (more, smaller
+    // blocks hide the global-load latency of these short-K shapes better than one long MFMA chain)
+    const long blocks128 = (long)((n + BN - 1) / BN) * ((m + 127) / 128) * split_k;
+    const int mt = blocks128 >= 1024 ? 2 : 1;
+    dim3 grid((n + BN - 1) / BN, (m + 64 * mt - 1) / (64 * mt), split_k), block(256);
+#define GV_GEMM_LAUNCH(TA_, TB_)                                                          \
+    do {                                                                                  \
+        if (mt == 2) hipLaunchKernelGGL((k_gemm_f32<TA_, TB_, 2>), grid, block, 0, st, p); \
+        else hipLaunchKernelGGL((k_gemm_f32<TA_, TB_, 1>), grid, block, 0, st, p);         \
+    } while (0)
+    if (!trans_a && !trans_b) GV_GEMM_LAUNCH(false, false);
+    else if (!trans_a && trans_b) GV_GEMM_LAUNCH(false, true);
+    else if (trans_a && !trans_b) GV_GEMM_LAUNCH(true, false);
+    else GV_GEMM_LAUNCH(true, true);
+#undef GV_GEMM_LAUNCH
     int rc = launch_status("gv_gemm_f32");
     if (rc != GV_OK) return rc;
     if (split_k > 1) {

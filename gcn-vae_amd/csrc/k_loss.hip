@@ -255,89 +255,106 @@ __global__ __launch_bounds__(256) void k_kl_bwd_mix_final(const float* part, con
 // ---- MMD (KGVAE.get_mmd / compute_kernel, kgvae/model.py:71-80, :89-102) -------------------------------
 //   K(a, b) = exp(-mean_d (a_d - b_d)^2 / h) ;  mmd = mean Kxx + mean Kyy - 2 mean Kxy
 // grid: one block per row of x (first sx blocks) or of y; the block's 4 waves walk the partner rows.
-constexpr int MMD_CPL = 16;   // columns per lane: h <= 1024
+// 16 waves per block, each wave takes partner rows j = w, w+16, ... four at a time (independent loads and
+// wave reductions in flight: the loop is latency-bound, the whole problem is ~100 MFLOP).
+constexpr int MMD_WAVES = 16;
 
-__global__ __launch_bounds__(256) void k_mmd_fwd(const float* x, const float* y, int sx, int sy, int h, float* part) {
-    __shared__ float sm[4];
+template <int CPL>
+__device__ __forceinline__ void mmd_load_row(const float* p, int h, int lane, float (&v)[CPL]) {
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) v[i] = (lane + 64 * i < h) ? p[lane + 64 * i] : 0.f;
+}
+
+template <int CPL>
+__device__ __forceinline__ float mmd_d2(const float (&a)[CPL], const float (&b)[CPL]) {
+    float d2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) { const float d = a[i] - b[i]; d2 = fmaf(d, d, d2); }
+    return d2;
+}
+
+template <int CPL>
+__global__ __launch_bounds__(64 * MMD_WAVES) void k_mmd_fwd(const float* x, const float* y, int sx, int sy, int h,
+                                                             float* part) {
+    __shared__ float sm[MMD_WAVES];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool is_x = (int)blockIdx.x < sx;
-    const float* a = is_x ? x + (size_t)blockIdx.x * h : y + (size_t)(blockIdx.x - sx) * h;
-    float av[MMD_CPL];
-#pragma unroll
-    for (int i = 0; i < MMD_CPL; ++i) av[i] = (lane + 64 * i < h) ? a[lane + 64 * i] : 0.f;
+    float av[CPL];
+    mmd_load_row<CPL>(is_x ? x + (size_t)blockIdx.x * h : y + (size_t)(blockIdx.x - sx) * h, h, lane, av);
     const float inv = 1.f / ((float)h * (float)h);
     float tot = 0.f;
     // x rows: + Kxx/sx^2 - 2 Kxy/(sx sy);   y rows: + Kyy/sy^2
-    const int n_same = is_x ? sx : sy;
-    const float* same = is_x ? x : y;
-    const float w_same = 1.f / ((float)n_same * (float)n_same);
-    for (int j = w; j < n_same; j += 4) {
-        float d2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < MMD_CPL; ++i)
-            if (lane + 64 * i < h) { const float d = av[i] - same[(size_t)j * h + lane + 64 * i]; d2 = fmaf(d, d, d2); }
-        d2 = wave_sum(d2);
-        tot += w_same * expf(-d2 * inv);
-    }
-    if (is_x) {
-        const float w_x = -2.f / ((float)sx * (float)sy);
-        for (int j = w; j < sy; j += 4) {
-            float d2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < MMD_CPL; ++i)
-                if (lane + 64 * i < h) { const float d = av[i] - y[(size_t)j * h + lane + 64 * i]; d2 = fmaf(d, d, d2); }
-            d2 = wave_sum(d2);
-            tot += w_x * expf(-d2 * inv);
+    for (int pass = 0; pass < (is_x ? 2 : 1); ++pass) {
+        const float* b = pass == 0 ? (is_x ? x : y) : y;
+        const int nb = pass == 0 ? (is_x ? sx : sy) : sy;
+        const float wt = pass == 0 ? 1.f / ((float)nb * (float)nb) : -2.f / ((float)sx * (float)sy);
+        for (int j = w; j < nb; j += 4 * MMD_WAVES) {
+            float b0[CPL], b1[CPL], b2[CPL], b3[CPL];
+            const int j1 = j + MMD_WAVES, j2 = j + 2 * MMD_WAVES, j3 = j + 3 * MMD_WAVES;
+            mmd_load_row<CPL>(b + (size_t)j * h, h, lane, b0);
+            mmd_load_row<CPL>(b + (size_t)min(j1, nb - 1) * h, h, lane, b1);
+            mmd_load_row<CPL>(b + (size_t)min(j2, nb - 1) * h, h, lane, b2);
+            mmd_load_row<CPL>(b + (size_t)min(j3, nb - 1) * h, h, lane, b3);
+            const float d0 = wave_sum(mmd_d2<CPL>(av, b0)), d1 = wave_sum(mmd_d2<CPL>(av, b1));
+            const float d2 = wave_sum(mmd_d2<CPL>(av, b2)), d3 = wave_sum(mmd_d2<CPL>(av, b3));
+            tot += wt * expf(-d0 * inv);
+            if (j1 < nb) tot += wt * expf(-d1 * inv);
+            if (j2 < nb) tot += wt * expf(-d2 * inv);
+            if (j3 < nb) tot += wt * expf(-d3 * inv);
         }
     }
-    __syncthreads();
     if (lane == 0) sm[w] = tot;
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MMD_WAVES; ++i) s += sm[i];
+        part[blockIdx.x] = s;
+    }
 }
 
-__global__ __launch_bounds__(256) void k_mmd_bwd(const float* x, const float* y, int sx, int sy, int h, const float* gmmd,
-                                                 float* gx, float* gy) {
-    __shared__ float sm[4][64 * MMD_CPL];
+template <int CPL>
+__global__ __launch_bounds__(64 * MMD_WAVES) void k_mmd_bwd(const float* x, const float* y, int sx, int sy, int h,
+                                                             const float* gmmd, float* gx, float* gy) {
+    __shared__ float sm[MMD_WAVES][64 * CPL];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool is_x = (int)blockIdx.x < sx;
     const int row = is_x ? blockIdx.x : blockIdx.x - sx;
-    const float* a = (is_x ? x : y) + (size_t)row * h;
-    float av[MMD_CPL], acc[MMD_CPL];
+    float av[CPL], acc[CPL];
+    mmd_load_row<CPL>((is_x ? x : y) + (size_t)row * h, h, lane, av);
 #pragma unroll
-    for (int i = 0; i < MMD_CPL; ++i) { av[i] = (lane + 64 * i < h) ? a[lane + 64 * i] : 0.f; acc[i] = 0.f; }
+    for (int i = 0; i < CPL; ++i) acc[i] = 0.f;
     const float inv = 1.f / ((float)h * (float)h);
     const float g = gmmd ? *gmmd : 1.f;
     const int n_same = is_x ? sx : sy, n_other = is_x ? sy : sx;
-    const float* same = is_x ? x : y;
-    const float* other = is_x ? y : x;
     // d mmd / d a = (-2/h^2) [ (2/n_same^2) sum_j K(a,same_j)(a - same_j) - (2/(sx sy)) sum_j K(a,other_j)(a - other_j) ]
     const float c_same = g * (-2.f * inv) * 2.f / ((float)n_same * (float)n_same);
     const float c_other = g * (-2.f * inv) * (-2.f) / ((float)sx * (float)sy);
     for (int pass = 0; pass < 2; ++pass) {
-        const float* b = pass == 0 ? same : other;
+        const float* b = pass == 0 ? (is_x ? x : y) : (is_x ? y : x);
         const int nb = pass == 0 ? n_same : n_other;
         const float cf = pass == 0 ? c_same : c_other;
-        for (int j = w; j < nb; j += 4) {
-            float bv[MMD_CPL];
-            float d2 = 0.f;
+        for (int j = w; j < nb; j += 2 * MMD_WAVES) {
+            float b0[CPL], b1[CPL];
+            const int j1 = j + MMD_WAVES;
+            mmd_load_row<CPL>(b + (size_t)j * h, h, lane, b0);
+            mmd_load_row<CPL>(b + (size_t)min(j1, nb - 1) * h, h, lane, b1);
+            const float d0 = wave_sum(mmd_d2<CPL>(av, b0)), d1 = wave_sum(mmd_d2<CPL>(av, b1));
+            const float k0 = cf * expf(-d0 * inv), k1 = j1 < nb ? cf * expf(-d1 * inv) : 0.f;
 #pragma unroll
-            for (int i = 0; i < MMD_CPL; ++i) {
-                bv[i] = (lane + 64 * i < h) ? b[(size_t)j * h + lane + 64 * i] : 0.f;
-                const float d = av[i] - bv[i];
-                d2 = fmaf(d, d, d2);
-            }
-            d2 = wave_sum(d2);
-            const float kv = cf * expf(-d2 * inv);
-#pragma unroll
-            for (int i = 0; i < MMD_CPL; ++i) acc[i] = fmaf(kv, av[i] - bv[i], acc[i]);
+            for (int i = 0; i < CPL; ++i) acc[i] = fmaf(k0, av[i] - b0[i], fmaf(k1, av[i] - b1[i], acc[i]));
         }
     }
 #pragma unroll
-    for (int i = 0; i < MMD_CPL; ++i) sm[w][lane + 64 * i] = acc[i];
+    for (int i = 0; i < CPL; ++i) sm[w][lane + 64 * i] = acc[i];
     __syncthreads();
     float* o = (is_x ? gx : gy) + (size_t)row * h;
-    for (int c = threadIdx.x; c < h; c += 256) o[c] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+    for (int c = threadIdx.x; c < h; c += 64 * MMD_WAVES) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MMD_WAVES; ++i) s += sm[i][c];
+        o[c] = s;
+    }
 }
 
 // prior samples of get_mmd: z_pri[i] = mu[i % k] + eps[i] * sqrt(softplus(raw[i % k]) + 1e-8)   (z_pre = [mu; raw], (2k, h))
@@ -468,9 +485,10 @@ extern "C" int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* 
 extern "C" int gv_mmd_fwd(const float* x, const float* y, int sx, int sy, int h, float* mmd, float* workspace,
                           void* stream) {
     GV_REQUIRE(x && y && mmd && workspace, GV_ERR_NULL, "gv_mmd_fwd: NULL pointer");
-    GV_REQUIRE(sx > 0 && sy > 0 && h > 0 && h <= 64 * MMD_CPL && sx + sy <= RED_BLOCKS, GV_ERR_SHAPE,
-               "gv_mmd_fwd: sx=%d sy=%d h=%d (need h <= %d, sx+sy <= %d)", sx, sy, h, 64 * MMD_CPL, RED_BLOCKS);
-    hipLaunchKernelGGL(k_mmd_fwd, dim3(sx + sy), dim3(256), 0, GV_ST, x, y, sx, sy, h, workspace);
+    GV_REQUIRE(sx > 0 && sy > 0 && h > 0 && h <= 1024 && sx + sy <= RED_BLOCKS, GV_ERR_SHAPE,
+               "gv_mmd_fwd: sx=%d sy=%d h=%d (need h <= 1024, sx+sy <= %d)", sx, sy, h, RED_BLOCKS);
+    if (h <= 256) hipLaunchKernelGGL(k_mmd_fwd<4>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, sx, sy, h, workspace);
+    else hipLaunchKernelGGL(k_mmd_fwd<16>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, sx, sy, h, workspace);
     hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, sx + sy, 1.f, mmd, 0);
     return launch_status("gv_mmd_fwd");
 }
@@ -478,8 +496,9 @@ extern "C" int gv_mmd_fwd(const float* x, const float* y, int sx, int sy, int h,
 extern "C" int gv_mmd_bwd(const float* x, const float* y, int sx, int sy, int h, const float* gmmd, float* gx,
                           float* gy, void* stream) {
     GV_REQUIRE(x && y && gx && gy, GV_ERR_NULL, "gv_mmd_bwd: NULL pointer");
-    GV_REQUIRE(sx > 0 && sy > 0 && h > 0 && h <= 64 * MMD_CPL, GV_ERR_SHAPE, "gv_mmd_bwd: bad shape");
-    hipLaunchKernelGGL(k_mmd_bwd, dim3(sx + sy), dim3(256), 0, GV_ST, x, y, sx, sy, h, gmmd, gx, gy);
+    GV_REQUIRE(sx > 0 && sy > 0 && h > 0 && h <= 1024, GV_ERR_SHAPE, "gv_mmd_bwd: bad shape");
+    if (h <= 256) hipLaunchKernelGGL(k_mmd_bwd<4>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, sx, sy, h, gmmd, gx, gy);
+    else hipLaunchKernelGGL(k_mmd_bwd<16>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, sx, sy, h, gmmd, gx, gy);
     return launch_status("gv_mmd_bwd");
 }
 
