@@ -47,6 +47,7 @@ def parse():
     p.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU-oracle baseline leg')
+    p.add_argument('--force-dist', action='store_true', help='run the RCCL code path even at world size 1 (testing)')
     p.add_argument('--profile-steps', type=int, default=3, help='instrumented eager steps for the roofline figure')
     return p.parse_args()
 
@@ -152,6 +153,13 @@ def main():
         world = max(world, 1)
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs an MI355X (no CPU path); the cpu_baseline leg alone is not a benchmark')
+    dist_on = world > 1 or args.force_dist
+    if args.force_dist and world == 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        import torch.distributed as _d
+        torch.cuda.set_device(local_rank)
+        _d.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', local_rank))
     gdist.init_process_group('nccl' if world > 1 else None)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -168,7 +176,7 @@ def main():
     use_graph = not args.no_graph
     from gcn_vae_amd.optim import FlatAdam
     opt = FlatAdam(params, lr=1e-3, max_grad_norm=1.0)      # clip_grad_norm_(1.0) + Adam over one flat arena
-    if world > 1:
+    if dist_on:
         hook = gdist.make_reduce_hook()
         model.encoder.rconv_layer_1.reduce_hook = hook
         model.encoder.rconv_layer_2.reduce_hook = hook
@@ -186,7 +194,7 @@ def main():
         embed = model(g, node_id, etype, enorm)
         loss, pred, kl, mmd = model.get_loss(g, embed, samples, labels)
         loss.backward()
-        if world > 1:
+        if dist_on:
             gdist.average_flat(opt.flat_g)
         opt.step()
         return loss
@@ -293,6 +301,7 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
+    if dist_on:
         dist.destroy_process_group()
 
 
