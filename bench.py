@@ -109,7 +109,25 @@ def algorithmic_bytes(tag, E, N, R, T):
 def cpu_baseline(w, model, args, budget_s):
     """The CPU oracle (oracle/, a torch-CPU port of the reference's op sequence) on the same inputs."""
     from oracle import kgvae as okg
-    torch.set_num_threads(os.cpu_count() or 1)
+    from oracle import rgcn as orgcn
+    ncpu = os.cpu_count() or 1
+    # torch's CPU ops do not scale to hundreds of threads on this op mix: pick the fastest of a few thread
+    # counts on the dominant op (one layer-1 message pass) and report the count actually used.
+    xs = model.state_dict()
+    probe = {'weight': xs['encoder.rconv_layer_1.weight'].detach().cpu(), 'h_bias': xs['encoder.rconv_layer_1.h_bias'].detach().cpu(),
+             'loop_weight': xs['encoder.rconv_layer_1.loop_weight'].detach().cpu()}
+    xprobe = xs['encoder.input_layer.embedding.weight'].detach().cpu()
+    best_t, threads = None, 1
+    for cand in [c for c in (8, 16, 32, 64, 128) if c <= ncpu] or [ncpu]:
+        torch.set_num_threads(cand)
+        with torch.no_grad():
+            orgcn.rel_graph_conv(xprobe, w['src'], w['dst'], w['rel'], w['enorm'].cpu(), probe, 'bdd', args.n_bases, torch.relu)
+            t0 = time.time()
+            orgcn.rel_graph_conv(xprobe, w['src'], w['dst'], w['rel'], w['enorm'].cpu(), probe, 'bdd', args.n_bases, torch.relu)
+            dt = time.time() - t0
+        if best_t is None or dt < best_t:
+            best_t, threads = dt, cand
+    torch.set_num_threads(threads)
     state = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and 'mask' not in k and not k.endswith('.pi'))
              for k, v in model.state_dict().items()}
     n, h = w['data'].num_nodes, args.hidden
@@ -137,9 +155,9 @@ def cpu_baseline(w, model, args, budget_s):
             break
     E = int(w['src'].numel())
     med = float(np.median(times))
-    return {'value': E / med, 'unit': 'edges/s', 'cores': os.cpu_count() or 1, 'kind': 'port',
+    return {'value': E / med, 'unit': 'edges/s', 'cores': threads, 'kind': 'port',
             'sample': f'{len(times)} timed full steps (fwd+loss+bwd, no optimizer) of the same workload after 1 warm-up; '
-                      f'median {med:.3f} s/step; torch {torch.__version__} CPU, anomaly mode off'}
+                      f'median {med:.3f} s/step; torch {torch.__version__} CPU with {threads} of {ncpu} host threads (fastest of 8..128 on a probe), anomaly mode off'}
 
 
 def main():

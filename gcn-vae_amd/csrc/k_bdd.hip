@@ -9,6 +9,8 @@
 // v_readlane so every gather address is scalar-base + lane-offset.  U edges are kept in flight
 // per wave to cover L2 / Infinity-Cache latency (the feature table and the relation weights of
 // FB15k-237 are cache resident; the kernel is bound by cache bandwidth, not FLOPs: ~1 flop/byte).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gv {
@@ -133,6 +135,133 @@ __global__ __launch_bounds__(256) void k_agg_fast(const AggParams a) {
         for (int i = 0; i < PV; ++i) acc[i] = kp[i] ? acc[i] * a.keep_scale : 0.f;
     }
     store_vec<PV>(a.out + (size_t)it.x * a.ld_out + lane * PV, acc);
+}
+
+// ---- lane-packed weight variant -------------------------------------------------------------------
+// The per-edge relation-weight read dominates K1's cache traffic.  With the row layout a lane's weights
+// are BPL*P*Q contiguous floats, so one 16-B load instruction touches ~25 cache lines at 25-50 % use.
+// Here the weights come in the LANE-PACKED layout written by k_pack_weight,
+//     packed[r][jq*L + l][0..3] = quad jq of lane l's weight list        (L = nb/BPL active lanes)
+// so every weight instruction reads one contiguous L*16-B burst.  Block ownership is chosen so that the
+// FEATURE gather is a contiguous burst too: ADJ (lane owns blocks BPL*l .. BPL*l+BPL-1, one BPL*P-float
+// vector load) when P < 4, strided (lane owns blocks l + s*L, one P-float load each) when P >= 4.
+// Same arithmetic and per-output operation order as k_agg_fast: results are bit-identical.
+template <int BPL, bool ADJ>
+__device__ __forceinline__ int owned_block(int lane, int sb, int L) { return ADJ ? lane * BPL + sb : lane + sb * L; }
+
+template <int P, int Q, bool TRANS, int BPL, bool ADJ, int U>
+__global__ __launch_bounds__(256) void k_agg_packed(const AggParams a) {
+    constexpr int PQ = P * Q, NQ = BPL * PQ / 4;      // weight quads per lane
+    static_assert((BPL * PQ) % 4 == 0, "lane-packed layout needs whole float4s per lane");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (wave >= a.n_items) return;
+    const int4 it = a.items[wave];
+    const int L = a.nb / BPL;
+    const bool active = lane < L;
+    const float4* __restrict__ wbase = reinterpret_cast<const float4*>(a.w) + lane;
+
+    float acc[BPL * Q];
+#pragma unroll
+    for (int i = 0; i < BPL * Q; ++i) acc[i] = 0.f;
+
+    auto load_edge = [&](int sidx, int r, float (&xv)[BPL * P], float (&wv)[BPL * PQ]) {
+        const float* xr = a.feat + (size_t)sidx * a.ld_feat;
+        if constexpr (ADJ) {
+            load_vec<BPL * P>(xr + lane * BPL * P, xv);
+        } else {
+#pragma unroll
+            for (int sb = 0; sb < BPL; ++sb) {
+                float t[P];
+                load_vec<P>(xr + (lane + sb * L) * P, t);
+#pragma unroll
+                for (int i = 0; i < P; ++i) xv[sb * P + i] = t[i];
+            }
+        }
+        const float4* wr = wbase + (size_t)r * (a.w_row / 4);
+#pragma unroll
+        for (int jq = 0; jq < NQ; ++jq) {
+            const float4 q4 = wr[jq * L];
+            wv[4 * jq] = q4.x; wv[4 * jq + 1] = q4.y; wv[4 * jq + 2] = q4.z; wv[4 * jq + 3] = q4.w;
+        }
+    };
+
+    for (int e0 = it.y; e0 < it.z; e0 += 64) {
+        const int cnt = min(64, it.z - e0);
+        int my_n = 0, my_t = 0;
+        float my_c = 1.f;
+        if (lane < cnt) {
+            my_n = a.nbr[e0 + lane];
+            my_t = a.etype[e0 + lane];
+            if (a.coef) my_c = a.coef_idx ? a.coef[a.coef_idx[e0 + lane]] : a.coef[e0 + lane];
+        }
+        int j0 = 0;
+        for (; j0 + U <= cnt; j0 += U) {
+            float xv[U][BPL * P], wv[U][BPL * PQ], cc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int sidx = rl_i(my_n, j0 + u);
+                const int r = rl_i(my_t, j0 + u);
+                cc[u] = rl_f(my_c, j0 + u);
+                if (active) load_edge(sidx, r, xv[u], wv[u]);
+            }
+            if (active) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) block_fma<P, Q, TRANS, BPL>(xv[u], wv[u], cc[u], acc);
+            }
+        }
+        for (; j0 < cnt; ++j0) {
+            float xv[BPL * P], wv[BPL * PQ];
+            const int sidx = rl_i(my_n, j0);
+            const int r = rl_i(my_t, j0);
+            const float c = rl_f(my_c, j0);
+            if (active) {
+                load_edge(sidx, r, xv, wv);
+                block_fma<P, Q, TRANS, BPL>(xv, wv, c, acc);
+            }
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int sb = 0; sb < BPL; ++sb) {
+        const int col = owned_block<BPL, ADJ>(lane, sb, L) * Q;
+        float o[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) o[i] = acc[sb * Q + i];
+        if (it.w >= 0) {
+            store_vec<Q>(a.partial + (size_t)it.w * a.out_dim + col, o);
+            continue;
+        }
+        if (a.addend) {
+            float ad[Q];
+            load_vec<Q>(a.addend + (size_t)it.x * a.ld_add + col, ad);
+#pragma unroll
+            for (int i = 0; i < Q; ++i) o[i] += ad[i];
+        }
+#pragma unroll
+        for (int i = 0; i < Q; ++i) o[i] = apply_act(o[i], a.act);
+        if (a.keep) {
+            const uint8_t* kp = a.keep + (size_t)it.x * a.out_dim + col;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) o[i] = kp[i] ? o[i] * a.keep_scale : 0.f;
+        }
+        store_vec<Q>(a.out + (size_t)it.x * a.ld_out + col, o);
+    }
+}
+
+// row layout [R][nb*P*Q] -> lane-packed layout for (BPL, ownership); one thread per float4
+__global__ __launch_bounds__(256) void k_pack_weight(const float* w, float* packed, int num_rels, int nb, int pq, int bpl,
+                                                     int adj) {
+    const int L = nb / bpl, nq = bpl * pq / 4, quads = L * nq;     // float4 per relation row
+    const int total = num_rels * quads;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int r = i / quads, rem = i - r * quads;
+        const int l = rem % L, jq = rem / L;               // quad jq of lane l's weight list
+        const int f = 4 * jq, sb = f / pq, within = f - sb * pq;
+        const int block = adj ? l * bpl + sb : l + sb * L;
+        reinterpret_cast<float4*>(packed)[i] =
+            *reinterpret_cast<const float4*>(w + (size_t)r * nb * pq + (size_t)block * pq + within);
+    }
 }
 
 // Any (P, Q): lane <-> output column, 64 columns per sweep over the item's edges.
@@ -450,12 +579,57 @@ int pick_bpl(int nb, int p) {
 }
 }  // namespace
 
+namespace {
+// lane-packed kernels: BPL = fewest blocks per lane that fit the row into one wave; ownership by the
+// gathered block size (adjacent for P < 4 so that the feature gather stays one 16-B vector per lane)
+struct PackPlan { int bpl; int adj; };
+bool pack_plan(int nb, int p_gather, int q_out, bool trans, PackPlan* plan) {
+    int bpl = 0;
+    if (p_gather < 4) {                       // adjacent blocks must make up >= 4 gathered floats per lane
+        bpl = 4 / p_gather;
+        if (nb % bpl != 0 || nb / bpl > 64) return false;
+    } else {
+        for (int b : {1, 2})
+            if (!bpl && nb % b == 0 && nb / b <= 64) bpl = b;
+        if (!bpl) return false;
+    }
+    if ((bpl * p_gather * q_out) % 4 != 0) return false;
+    const bool ok = !trans ? ((p_gather == 2 && (q_out == 2 || q_out == 4)) || (p_gather == 4 && (q_out == 4 || q_out == 8)))
+                           : ((p_gather == 2 && q_out == 2) || (p_gather == 4 && (q_out == 2 || q_out == 4)) ||
+                              (p_gather == 8 && q_out == 4));
+    if (!ok) return false;
+    plan->bpl = bpl;
+    plan->adj = p_gather < 4 ? 1 : 0;
+    return true;
+}
+}  // namespace
+
+extern "C" int gv_rgcn_bdd_pack_supported(int num_bases, int blk_in, int blk_out, int transpose_w) {
+    PackPlan pl;
+    return pack_plan(num_bases, blk_in, blk_out, transpose_w != 0, &pl) ? 1 : 0;
+}
+
+extern "C" int gv_rgcn_bdd_pack_weight(const float* weight, int num_rels, int num_bases, int blk_in, int blk_out,
+                                       int transpose_w, float* packed, void* stream) {
+    GV_REQUIRE(weight && packed, GV_ERR_NULL, "gv_rgcn_bdd_pack_weight: NULL pointer");
+    PackPlan pl;
+    GV_REQUIRE(pack_plan(num_bases, blk_in, blk_out, transpose_w != 0, &pl), GV_ERR_SHAPE,
+               "gv_rgcn_bdd_pack_weight: no lane-packed kernel for num_bases=%d blocks %dx%d trans=%d", num_bases, blk_in,
+               blk_out, transpose_w);
+    GV_REQUIRE(aligned16(weight) && aligned16(packed), GV_ERR_ALIGN, "gv_rgcn_bdd_pack_weight: 16-B alignment required");
+    const int total = num_rels * num_bases * blk_in * blk_out / 4;
+    hipLaunchKernelGGL(k_pack_weight, dim3(min(2048, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight,
+                       packed, num_rels, num_bases, blk_in * blk_out, pl.bpl, pl.adj);
+    return launch_status("gv_rgcn_bdd_pack_weight");
+}
+
 extern "C" int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const int32_t* fix, int n_fix,
                                      const int32_t* nbr, const int32_t* etype, const float* coef,
                                      const int32_t* coef_idx, const float* feat, int ld_feat, const float* weight,
                                      int num_rels, int num_bases, int blk_in, int blk_out, int transpose_w,
-                                     const float* addend, int ld_addend, int act, const uint8_t* keep,
-                                     float keep_scale, float* out, int ld_out, float* partial, void* stream) {
+                                     int weight_packed, const float* addend, int ld_addend, int act,
+                                     const uint8_t* keep, float keep_scale, float* out, int ld_out, float* partial,
+                                     void* stream) {
     GV_REQUIRE(n_items >= 0 && n_fix >= 0, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate: negative item count");
     if (n_items == 0) return GV_OK;
     GV_REQUIRE(items && nbr && etype && feat && weight && out, GV_ERR_NULL, "gv_rgcn_bdd_aggregate: NULL pointer");
@@ -476,11 +650,46 @@ extern "C" int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const in
     const bool vec_ok = aligned16(feat) && aligned16(weight) && aligned16(out) && (ld_feat % 4 == 0) &&
                         (ld_out % 4 == 0) && (!addend || (aligned16(addend) && ld_addend % 4 == 0)) &&
                         (!partial || aligned16(partial)) && (a.out_dim % 4 == 0) && (a.w_row % 4 == 0);
-    const int bpl = pick_bpl(num_bases, blk_in);
     int rc = -1000;
+    static const int u_env = getenv("GV_K1_U") ? atoi(getenv("GV_K1_U")) : 0;     // tuning knob (tools/microbench.py)
+    if (weight_packed) {
+        PackPlan pl;
+        GV_REQUIRE(vec_ok && pack_plan(num_bases, blk_in, blk_out, transpose_w != 0, &pl), GV_ERR_SHAPE,
+                   "gv_rgcn_bdd_aggregate: lane-packed weights unsupported for num_bases=%d blocks %dx%d (or unaligned)",
+                   num_bases, blk_in, blk_out);
+#define GV_PK_CASE(P_, Q_, T_, B_, A_, U_)                                                                   \
+    if (rc == -1000 && blk_in == P_ && blk_out == Q_ && (transpose_w != 0) == T_ && pl.bpl == B_ && pl.adj == A_) \
+        rc = launch_items(k_agg_packed<P_, Q_, T_, B_, (A_ != 0), U_>, a, n_items, st, "gv_rgcn_bdd_aggregate(packed)");
+#define GV_PK_U(P_, Q_, T_, B_, A_)                                                                            \
+    if (rc == -1000 && u_env && blk_in == P_ && blk_out == Q_ && (transpose_w != 0) == T_ && pl.bpl == B_ && pl.adj == A_) { \
+        if (u_env == 2) rc = launch_items(k_agg_packed<P_, Q_, T_, B_, (A_ != 0), 2>, a, n_items, st, "agg(packed,U2)");    \
+        if (u_env == 4) rc = launch_items(k_agg_packed<P_, Q_, T_, B_, (A_ != 0), 4>, a, n_items, st, "agg(packed,U4)");    \
+        if (u_env == 8) rc = launch_items(k_agg_packed<P_, Q_, T_, B_, (A_ != 0), 8>, a, n_items, st, "agg(packed,U8)");    \
+    }
+        GV_PK_U(2, 2, false, 2, 1) GV_PK_U(2, 4, false, 2, 1) GV_PK_U(2, 2, true, 2, 1) GV_PK_U(4, 2, true, 2, 0)
+#undef GV_PK_U
+        GV_PK_CASE(2, 2, false, 2, 1, 4)
+        GV_PK_CASE(2, 4, false, 2, 1, 4)
+        GV_PK_CASE(4, 4, false, 1, 0, 4) GV_PK_CASE(4, 4, false, 2, 0, 2)
+        GV_PK_CASE(4, 8, false, 1, 0, 2) GV_PK_CASE(4, 8, false, 2, 0, 2)
+        GV_PK_CASE(2, 2, true, 2, 1, 2)
+        GV_PK_CASE(4, 2, true, 1, 0, 8) GV_PK_CASE(4, 2, true, 2, 0, 2)
+        GV_PK_CASE(4, 4, true, 1, 0, 4) GV_PK_CASE(4, 4, true, 2, 0, 2)
+        GV_PK_CASE(8, 4, true, 1, 0, 2) GV_PK_CASE(8, 4, true, 2, 0, 2)
+#undef GV_PK_CASE
+    }
+    const int bpl = pick_bpl(num_bases, blk_in);
 #define GV_AGG_CASE(P_, Q_, T_, B_, U_)                                                               \
     if (rc == -1000 && vec_ok && blk_in == P_ && blk_out == Q_ && (transpose_w != 0) == T_ && bpl == B_) \
         rc = launch_items(k_agg_fast<P_, Q_, T_, B_, U_>, a, n_items, st, "gv_rgcn_bdd_aggregate");
+#define GV_AGG_U(P_, Q_, T_, B_)                                                                              \
+    if (rc == -1000 && u_env && vec_ok && blk_in == P_ && blk_out == Q_ && (transpose_w != 0) == T_ && bpl == B_) { \
+        if (u_env == 2) rc = launch_items(k_agg_fast<P_, Q_, T_, B_, 2>, a, n_items, st, "agg(U2)");                    \
+        if (u_env == 4) rc = launch_items(k_agg_fast<P_, Q_, T_, B_, 4>, a, n_items, st, "agg(U4)");                    \
+        if (u_env == 8) rc = launch_items(k_agg_fast<P_, Q_, T_, B_, 8>, a, n_items, st, "agg(U8)");                    \
+    }
+    GV_AGG_U(2, 2, false, 2) GV_AGG_U(2, 4, false, 2) GV_AGG_U(2, 2, true, 2) GV_AGG_U(4, 2, true, 2)
+#undef GV_AGG_U
     GV_AGG_CASE(1, 1, false, 4, 8)
     GV_AGG_CASE(1, 2, false, 4, 4)
     GV_AGG_CASE(2, 2, false, 2, 8)
@@ -545,8 +754,8 @@ extern "C" int gv_rgcn_bdd_grad_weight(const int32_t* items, int n_items, const 
     hipStream_t st = (hipStream_t)stream;
     const bool vec_ok = aligned16(x) && aligned16(g) && aligned16(grad_w) && (ld_x % 4 == 0) && (ld_g % 4 == 0) &&
                         (!partial || aligned16(partial)) && (a.w_row % 4 == 0);
-    const int bpl = pick_bpl(num_bases, blk_in);
     int rc = -1000;
+    const int bpl = pick_bpl(num_bases, blk_in);
 #define GV_GW_CASE(P_, Q_, B_, U_)                                                  \
     if (rc == -1000 && vec_ok && blk_in == P_ && blk_out == Q_ && bpl == B_)        \
         rc = launch_items(k_gradw_fast<P_, Q_, B_, U_>, a, n_items, st, "gv_rgcn_bdd_grad_weight");

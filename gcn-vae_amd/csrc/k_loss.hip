@@ -482,6 +482,25 @@ extern "C" int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* 
     return launch_status("gv_kl_bwd");
 }
 
+__global__ void k_lincomb(const float* a0, float c0, const float* a1, float c1, const float* a2, float c2, const float* a3,
+                          float c3, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float v = 0.f;
+        if (a0) v += c0 * *a0;
+        if (a1) v += c1 * *a1;
+        if (a2) v += c2 * *a2;
+        if (a3) v += c3 * *a3;
+        *out = v;
+    }
+}
+
+extern "C" int gv_lincomb4(const float* a0, float c0, const float* a1, float c1, const float* a2, float c2,
+                           const float* a3, float c3, float* out, void* stream) {
+    GV_REQUIRE(out, GV_ERR_NULL, "gv_lincomb4: NULL output");
+    hipLaunchKernelGGL(k_lincomb, dim3(1), dim3(64), 0, GV_ST, a0, c0, a1, c1, a2, c2, a3, c3, out);
+    return launch_status("gv_lincomb4");
+}
+
 extern "C" int gv_mmd_fwd(const float* x, const float* y, int sx, int sy, int h, float* mmd, float* workspace,
                           void* stream) {
     GV_REQUIRE(x && y && mmd && workspace, GV_ERR_NULL, "gv_mmd_fwd: NULL pointer");

@@ -92,7 +92,8 @@ class KGVAE(nn.Module):
         # (None + tensor, kgvae/model.py:86); None is read as "no flow term".
         return ops.kl_to_mixture(z, self.z_mean, self.z_sigma, self.z_pre.squeeze(0), self.flow_log_prob)
 
-    def get_mmd(self, z):
+    def mmd_inputs(self, z):
+        """The two sample sets of get_mmd: prior draws (through the flows) and the posterior row pick."""
         num_sample = 200
         rows = (num_sample // self.k) * self.k if num_sample // self.k > 1 else self.k
         eps = self.mmd_eps_override if self.mmd_eps_override is not None else \
@@ -105,8 +106,11 @@ class KGVAE(nn.Module):
             pick = self.mmd_index_override
         else:   # (Monte Carlo) posterior rows, python RNG as in the reference
             pick = torch.tensor(random.sample(range(z.shape[0]), num_sample), device=z.device)
-        z_post = ops.embedding(z, pick)
-        return ops.mmd(z_pri, z_post)
+        return z_pri, pick
+
+    def get_mmd(self, z):
+        z_pri, pick = self.mmd_inputs(z)
+        return ops.mmd(z_pri, ops.embedding(z, pick))
 
     def get_flow_log_prob(self):
         return self.flow_log_prob

@@ -18,8 +18,10 @@ SIGNATURES = {
     'gv_last_error_string': (ctypes.c_char_p, []),
     'gv_segment_items_count': (_I, [_P, _I, _I, _P, _P, _P, _P]),
     'gv_segment_items_fill': (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P]),
-    'gv_rgcn_bdd_aggregate': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I,
+    'gv_rgcn_bdd_aggregate': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I,
                                    _P, _I, _I, _P, _F, _P, _I, _P, _P]),
+    'gv_rgcn_bdd_pack_supported': (_I, [_I, _I, _I, _I]),
+    'gv_rgcn_bdd_pack_weight': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'gv_rgcn_bdd_fixup': (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _F, _P, _I, _P]),
     'gv_rgcn_bdd_grad_weight': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
     'gv_rgcn_epilogue_fwd': (_I, [_P, _P, _I, _P, _F, _P, _L, _I, _P]),
@@ -39,6 +41,7 @@ SIGNATURES = {
     'gv_kl_workspace_bytes': (_L, [_L, _I, _I]),
     'gv_kl_fwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'gv_kl_bwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    'gv_lincomb4': (_I, [_P, _F, _P, _F, _P, _F, _P, _F, _P, _P]),
     'gv_mmd_fwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     'gv_mmd_bwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     'gv_prior_sample_fwd': (_I, [_P, _P, _P, _I, _I, _I, _P]),

@@ -187,8 +187,21 @@ class TripletIndex:
 
 # ------------------------------------------------------------------------------------------------
 # raw ops
+def pack_supported(num_bases, blk_in, blk_out, transpose_w=False):
+    return bool(lib.load().gv_rgcn_bdd_pack_supported(num_bases, blk_in, blk_out, 1 if transpose_w else 0))
+
+
+def pack_weight(weight, num_bases, blk_in, blk_out, transpose_w=False):
+    """Lane-packed copy of a bdd relation-weight matrix for one K1 launch kind (see include/gcnvae.h)."""
+    weight = _chk(weight, name='weight')
+    packed = torch.empty_like(weight)
+    lib.call('gv_rgcn_bdd_pack_weight', ptr(weight), weight.shape[0], num_bases, blk_in, blk_out,
+             1 if transpose_w else 0, ptr(packed), lib.stream())
+    return packed
+
+
 def bdd_aggregate(seg: SegmentItems, nbr, etype, coef, coef_idx, feat, weight, num_bases, blk_in, blk_out,
-                  transpose_w=False, addend=None, act=ACT_NONE, keep=None, keep_scale=1.0, out=None):
+                  transpose_w=False, addend=None, act=ACT_NONE, keep=None, keep_scale=1.0, out=None, packed=False):
     feat, ld_feat = _row_major(feat, 'feat')
     weight = _chk(weight, name='weight')
     n_seg = seg.rowptr.numel() - 1
@@ -219,8 +232,8 @@ def bdd_aggregate(seg: SegmentItems, nbr, etype, coef, coef_idx, feat, weight, n
     timed = lib.TIMER is not None
     lib.call('gv_rgcn_bdd_aggregate', ptr(seg.items), seg.n_items, ptr(seg.fix), 0 if timed else seg.n_fix, ptr(nbr),
              ptr(etype), ptr(coef), ptr(coef_idx), ptr(feat), ld_feat, ptr(weight), num_rels, num_bases, blk_in,
-             blk_out, 1 if transpose_w else 0, ptr(addend), ld_add, act, ptr(keep), float(keep_scale), ptr(out),
-             ld_out, ptr(partial), lib.stream(), tag=tag)
+             blk_out, 1 if transpose_w else 0, 1 if packed else 0, ptr(addend), ld_add, act, ptr(keep),
+             float(keep_scale), ptr(out), ld_out, ptr(partial), lib.stream(), tag=tag)
     if timed and seg.n_fix > 0:      # the aggregation kernel was timed alone; finish the split rows
         lib.call('gv_rgcn_bdd_fixup', ptr(seg.fix), seg.n_fix, ptr(partial), out_dim, ptr(addend), ld_add, act,
                  ptr(keep), float(keep_scale), ptr(out), ld_out, lib.stream())
@@ -371,12 +384,16 @@ class _RelGraphConvBdd(torch.autograd.Function):
         elif h_bias is not None:
             addend = h_bias.unsqueeze(0).expand(n, out_feat).contiguous()
         coef = None if norm is None else norm.reshape(-1)
+        # lane-packed weights pay off once a block's weights span >= 32 B (measured: 2x4 / 4x2 blocks -24 % / -19 %,
+        # 2x2 blocks +-0): pack per launch kind, a ~1.5 MB pass per layer
+        pk = si * so >= 8 and pack_supported(num_bases, si, so, False)
+        w_fwd = pack_weight(weight, num_bases, si, so, False) if pk else weight
         if reduce_hook is None:
-            out = bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x, weight,
-                                num_bases, si, so, False, addend, act, keep, keep_scale)
+            out = bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x, w_fwd,
+                                num_bases, si, so, False, addend, act, keep, keep_scale, packed=pk)
         else:
-            agg = bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x, weight,
-                                num_bases, si, so)
+            agg = bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x, w_fwd,
+                                num_bases, si, so, packed=pk)
             agg = reduce_hook(agg)
             out = epilogue_fwd(agg, addend, act, keep, keep_scale)
         ctx.save_for_backward(x, weight, loop_weight, coef, out if act == ACT_RELU else None, keep)
@@ -398,8 +415,10 @@ class _RelGraphConvBdd(torch.autograd.Function):
                 gx_loop = gemm(g, loop_weight, trans_b=True)
         grad_x = None
         if ctx.needs_input_grad[0]:
+            pk = si * so >= 8 and pack_supported(nb, so, si, True)
+            w_bwd = pack_weight(weight, nb, so, si, True) if pk else weight
             grad_x = bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, coef, gidx.by_src.perm, g_agg,
-                                   weight, nb, so, si, True, gx_loop)
+                                   w_bwd, nb, so, si, True, gx_loop, packed=pk)
         grad_w = None
         if ctx.needs_input_grad[1]:
             grad_w = bdd_grad_weight(ridx.by_rel.seg, ridx.src_by_rel, ridx.dst_by_rel, coef, ridx.by_rel.perm, x,
@@ -769,3 +788,117 @@ class _PriorSample(torch.autograd.Function):
 
 def prior_sample(z_pre, eps):
     return _PriorSample.apply(z_pre, eps)
+
+
+class _LossHead(torch.autograd.Function):
+    """LinkPredict.get_loss as ONE autograd node (kgvae/link_predict.py:71-92):
+
+        loss = BCE(DistMult(z, w_rel, triplets) + flp) + reg*(mean z^2 + mean w_rel^2) + kl_w*KL + mmd_w*MMD
+
+    with KL = KGVAE.get_kl(z) and MMD = KGVAE.get_mmd's kernel means on (z_pri, z[pick]).  Forward is the
+    K5/K6 kernels plus one scalar combine; backward produces a single gradient for z: KL's gz, the regulariser
+    and the MMD rows are accumulated into one buffer that the DistMult gather-aggregate (K1, 1x1 blocks)
+    takes as its fused addend -- no multi-use gradient adds, no scalar glue kernels.
+    Returns (loss, predict_loss, kl, mmd); only ``loss`` is differentiable.
+    """
+
+    @staticmethod
+    def forward(ctx, z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, reg_w, kl_w, mmd_w, score_bias):
+        z, ld_z = _row_major(z, 'embed')
+        w_rel, ld_w = _row_major(w_rel, 'w_relation')
+        labels = _chk(labels.reshape(-1), name='labels')
+        dev, (n, h), T = z.device, z.shape, tidx.T
+        if labels.numel() != T:
+            raise ValueError('labels / triplets length mismatch')
+        st = lib.stream()
+        f32 = dict(dtype=torch.float32, device=dev)
+        scal = torch.zeros(4, **f32)                 # pred, reg, kl, mmd
+        pred, reg, kl, mmd = scal[0:1], scal[1:2], scal[2:3], scal[3:4]
+        ws = torch.empty(1024, **f32)
+        score = torch.empty(T, **f32)
+        bias = flp if (score_bias and flp is not None) else None
+        lib.call('gv_distmult_bce_fwd', ptr(z), ld_z, ptr(w_rel), ld_w, ptr(tidx.trip32), ptr(labels), ptr(bias),
+                 ptr(score), ptr(pred), ptr(ws), T, h, st)
+        ws2 = torch.empty(1024, **f32)
+        lib.call('gv_mean_sq', ptr(z), z.numel(), 1.0 / z.numel(), ptr(reg), ptr(ws2), 0, st)
+        lib.call('gv_mean_sq', ptr(w_rel), w_rel.numel(), 1.0 / w_rel.numel(), ptr(reg), ptr(ws2), 1, st)
+        resp = None
+        if kl_w > 0:
+            z_mean, z_sigma = _chk(z_mean.contiguous(), name='z_mean'), _chk(z_sigma.contiguous(), name='z_sigma')
+            z_pre = _chk(z_pre.contiguous(), name='z_pre')
+            k = z_pre.shape[0] // 2
+            wsk = torch.empty(int(lib.load().gv_kl_workspace_bytes(n, h, k)) // 4, **f32)
+            resp = torch.empty(n, k, **f32)
+            lib.call('gv_kl_fwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(flp), ptr(resp), ptr(kl),
+                     ptr(wsk), n, h, k, st)
+        z_post = None
+        if mmd_w > 0:
+            z_pri = _chk(z_pri.contiguous(), name='z_pri')
+            pick = _chk(pick.reshape(-1), torch.int64, 'pick')
+            z_post = torch.empty(pick.numel(), h, **f32)
+            lib.call('gv_gather_rows', ptr(z), ptr(pick), ptr(z_post), pick.numel(), h, st)
+            wsm = torch.empty(z_pri.shape[0] + z_post.shape[0], **f32)
+            lib.call('gv_mmd_fwd', ptr(z_pri), ptr(z_post), z_pri.shape[0], z_post.shape[0], h, ptr(mmd), ptr(wsm), st)
+        loss = torch.empty((), **f32)
+        lib.call('gv_lincomb4', ptr(pred), 1.0, ptr(reg), float(reg_w), ptr(kl) if kl_w > 0 else None, float(kl_w),
+                 ptr(mmd) if mmd_w > 0 else None, float(mmd_w), ptr(loss), st)
+        ctx.save_for_backward(z, z_mean if kl_w > 0 else None, z_sigma if kl_w > 0 else None, w_rel,
+                              z_pre if kl_w > 0 else None, resp, z_pri if mmd_w > 0 else None, z_post,
+                              pick if mmd_w > 0 else None, labels, score)
+        ctx.meta = (tidx, float(reg_w), float(kl_w), float(mmd_w), bias is not None, flp is not None and kl_w > 0)
+        out_pred, out_kl, out_mmd = pred.reshape(()), kl.reshape(1), mmd.reshape(())
+        ctx.mark_non_differentiable(out_pred, out_kl, out_mmd)
+        return loss, out_pred, out_kl, out_mmd
+
+    @staticmethod
+    def backward(ctx, g, _gp, _gk, _gm):
+        z, z_mean, z_sigma, w_rel, z_pre, resp, z_pri, z_post, pick, labels, score = ctx.saved_tensors
+        tidx, reg_w, kl_w, mmd_w, has_bias, flp_in_kl = ctx.meta
+        dev, (n, h), T = z.device, z.shape, tidx.T
+        st = lib.stream()
+        f32 = dict(dtype=torch.float32, device=dev)
+        g = _chk(g.reshape(1).contiguous(), name='gloss')
+        dscore = torch.empty(T, **f32)
+        dbias = torch.zeros((), **f32) if has_bias else None
+        ws = torch.empty(1024, **f32)
+        lib.call('gv_bce_grad', ptr(score), ptr(labels), ptr(g), ptr(dscore), ptr(dbias), ptr(ws), T, st)
+        gm = gv = gzp = gz = None
+        gsc = None
+        if kl_w > 0 or mmd_w > 0:
+            gsc = torch.empty(2, **f32)               # g*kl_w, g*mmd_w as device scalars
+            lib.call('gv_lincomb4', ptr(g), kl_w, None, 0.0, None, 0.0, None, 0.0, ptr(gsc[0:1]), st)
+            lib.call('gv_lincomb4', ptr(g), mmd_w, None, 0.0, None, 0.0, None, 0.0, ptr(gsc[1:2]), st)
+        if kl_w > 0:
+            k = z_pre.shape[0] // 2
+            wsk = torch.empty(int(lib.load().gv_kl_workspace_bytes(n, h, k)) // 4, **f32)
+            gz, gm, gv = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+            gzp = torch.empty_like(z_pre)
+            lib.call('gv_kl_bwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(resp), ptr(gsc[0:1]), ptr(gz),
+                     ptr(gm), ptr(gv), ptr(gzp), ptr(wsk), n, h, k, st)
+        # regulariser on z: gz (+)= g * reg_w * 2/(n h) * z
+        if gz is None:
+            gz = torch.empty_like(z)
+            lib.call('gv_axpby', z.numel(), ptr(g), 2.0 * reg_w / z.numel(), ptr(z), 0.0, ptr(gz), st)
+        else:
+            lib.call('gv_axpby', z.numel(), ptr(g), 2.0 * reg_w / z.numel(), ptr(z), 1.0, ptr(gz), st)
+        g_pri = None
+        if mmd_w > 0:
+            g_pri, g_post = torch.empty_like(z_pri), torch.empty_like(z_post)
+            lib.call('gv_mmd_bwd', ptr(z_pri), ptr(z_post), z_pri.shape[0], z_post.shape[0], h, ptr(gsc[1:2]), ptr(g_pri),
+                     ptr(g_post), st)
+            lib.call('gv_scatter_add_rows', ptr(g_post), ptr(pick), ptr(gz), pick.numel(), h, st)
+        g_z = bdd_aggregate(tidx.inc, tidx.inc_other, tidx.inc_rel, dscore, tidx.inc_tid, z, w_rel, h, 1, 1,
+                            addend=gz)
+        g_w = bdd_grad_weight(tidx.rel, tidx.rel_s, tidx.rel_o, dscore, tidx.rel_tid, z, z, h, 1, 1)
+        lib.call('gv_axpby', w_rel.numel(), ptr(g), 2.0 * reg_w / w_rel.numel(), ptr(w_rel), 1.0, ptr(g_w), st)
+        g_flp = None
+        if has_bias or flp_in_kl:
+            g_flp = torch.empty((), **f32)
+            lib.call('gv_lincomb4', ptr(dbias) if has_bias else None, 1.0, ptr(g) if flp_in_kl else None, kl_w, None, 0.0,
+                     None, 0.0, ptr(g_flp), st)
+        return (g_z, gm, gv, g_w, gzp, g_flp, g_pri, None, None, None, None, None, None, None)
+
+
+def loss_head(z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, reg_w, kl_w, mmd_w, score_bias):
+    return _LossHead.apply(z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, float(reg_w), float(kl_w),
+                           float(mmd_w), bool(score_bias))

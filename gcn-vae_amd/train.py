@@ -58,19 +58,20 @@ class LinkPredict(nn.Module):
         return ops.mean_sq(embedding) + ops.mean_sq(self.w_relation)
 
     def get_loss(self, g, embed, triplets, labels):
-        flp = self.encoder.get_flow_log_prob() if self.n_flows > 0 else None
-        predict_loss, _ = ops.distmult_bce(embed, self.w_relation, flp, labels,
-                                           self.triplet_index(embed, triplets))
-        reg_loss = self.regularization_loss(embed)
-        if self.kl_param > 0:
-            kl = self.encoder.get_kl(embed)
-        else:
-            kl = torch.zeros(1, device=embed.device)
-        if self.mmd_param > 0:
-            mmd = self.encoder.get_mmd(embed)
-        else:
-            mmd = torch.zeros(1, device=embed.device)
-        loss = predict_loss + self.reg_param * reg_loss + self.kl_param * kl + self.mmd_param * mmd
+        """(loss, predict_loss, kl, mmd) -- the four terms of kgvae/link_predict.py:71-92 from one fused
+        autograd node (ops.loss_head); calc_score / regularization_loss / get_kl / get_mmd stay available
+        as separate differentiable ops with the reference's signatures."""
+        enc = self.encoder
+        tidx = self.triplet_index(embed, triplets)
+        vae = isinstance(enc, KGVAE)
+        flp = enc.get_flow_log_prob() if vae else None
+        kl_w = self.kl_param if vae else 0.0
+        mmd_w = self.mmd_param if vae else 0.0
+        z_pri, pick = enc.mmd_inputs(embed) if mmd_w > 0 else (None, None)
+        loss, predict_loss, kl, mmd = ops.loss_head(
+            embed, enc.z_mean if kl_w > 0 else None, enc.z_sigma if kl_w > 0 else None, self.w_relation,
+            enc.z_pre.squeeze(0) if kl_w > 0 else None, flp, z_pri, pick, labels, tidx, self.reg_param, kl_w, mmd_w,
+            score_bias=self.n_flows > 0)
         return loss, predict_loss, kl, mmd
 
 

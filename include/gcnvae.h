@@ -73,9 +73,17 @@ int gv_segment_items_fill(const int32_t* rowptr, int n_seg, int chunk, const int
 int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const int32_t* fix, int n_fix,
                           const int32_t* nbr, const int32_t* etype, const float* coef, const int32_t* coef_idx,
                           const float* feat, int ld_feat, const float* weight, int num_rels, int num_bases,
-                          int blk_in, int blk_out, int transpose_w,
+                          int blk_in, int blk_out, int transpose_w, int weight_packed,
                           const float* addend, int ld_addend, int act, const uint8_t* keep, float keep_scale,
                           float* out, int ld_out, float* partial, void* stream);
+
+/* Lane-packed relation weights for K1 (weight_packed = 1 above): the per-edge weight read becomes one
+ * contiguous burst per load instruction (it dominates K1's cache traffic).  The layout depends on the launch
+ * kind, so pack once per (layer, transpose_w) per step; packed has the size of weight.
+ * gv_rgcn_bdd_pack_supported returns 1 when a packed kernel exists for that launch. */
+int gv_rgcn_bdd_pack_supported(int num_bases, int blk_in, int blk_out, int transpose_w);
+int gv_rgcn_bdd_pack_weight(const float* weight, int num_rels, int num_bases, int blk_in, int blk_out, int transpose_w,
+                            float* packed, void* stream);
 
 /* The fix-up pass of gv_rgcn_bdd_aggregate on its own (a caller that passed n_fix = 0 there, e.g. to
  * time the aggregation kernel alone, finishes the split rows with this). */
@@ -162,6 +170,10 @@ int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* v, const fl
  *       workspace: sx + sy floats (sx + sy <= 1024).  bwd overwrites gx (sx, h), gy (sy, h), scaled by *gmmd.
  *   gv_prior_sample_* : the prior draw of get_mmd (sample_gaussian(..., repeat), kgvae/utils.py:355-361):
  *       out[i] = mu[i % k] + eps[i] * sqrt(softplus(raw[i % k]) + 1e-8), z_pre = [mu; raw] (2k, h); bwd -> gz_pre (2k, h). */
+/* *out = c0*(*a0) + c1*(*a1) + c2*(*a2) + c3*(*a3) on device scalars (NULL terms skipped): the loss assembly of
+ * LinkPredict.get_loss (kgvae/link_predict.py:91) and its scalar gradients, without host round trips. */
+int gv_lincomb4(const float* a0, float c0, const float* a1, float c1, const float* a2, float c2, const float* a3,
+                float c3, float* out, void* stream);
 int gv_mmd_fwd(const float* x, const float* y, int sx, int sy, int h, float* mmd, float* workspace, void* stream);
 int gv_mmd_bwd(const float* x, const float* y, int sx, int sy, int h, const float* gmmd, float* gx, float* gy,
                void* stream);

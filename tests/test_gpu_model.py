@@ -183,3 +183,16 @@ def test_rgcn_encoder_and_eval_ranking():
                                        flow_log_prob=torch.tensor(0.0))
     mrr_g = ranking.calc_mrr(hg, net.w_relation, valid.cuda(), hits=[1, 3, 10], eval_bz=50, verbose=False)
     assert abs(mrr_o - mrr_g) < 2e-3, (mrr_o, mrr_g)
+
+
+def test_separate_loss_ops_match_fused_head():
+    """calc_score / regularization_loss / get_kl / get_mmd (reference signatures) agree with get_loss's fused node."""
+    g, net, embed, (loss, pred, kl, mmd) = run_golden('flows3', 3, 1e-5, 1.0)
+    enc = net.encoder
+    embed2 = embed.detach()
+    score = net.calc_score(embed2, g['samples'].cuda()) + enc.get_flow_log_prob().detach()
+    pred2 = torch.nn.functional.binary_cross_entropy_with_logits(score, g['labels'].cuda())
+    close(pred2, pred, msg='pred')
+    close(net.regularization_loss(embed2), g['reg'], msg='reg')
+    close(enc.get_kl(embed2), kl, msg='kl')
+    close(enc.get_mmd(embed2), mmd, atol_scale=1e-6, msg='mmd')

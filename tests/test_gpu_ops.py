@@ -316,3 +316,25 @@ def test_flat_adam_matches_torch_clip_and_adam(ops):
         opt_m.step()
         for a, b in zip(mine, ref):
             close(a, b, rtol=2e-5, atol_scale=1e-6)
+
+
+@pytest.mark.parametrize('fin,fout,nb', [(200, 200, 100), (200, 400, 100), (16, 16, 4), (16, 32, 4), (64, 64, 16)])
+def test_lane_packed_weights_are_bit_identical(ops, fin, fout, nb):
+    n, e, r = 300, 5000, 120
+    src, dst, et, norm = zipf_graph(n, e, r, seed=fin + nb)
+    gen = torch.Generator().manual_seed(3)
+    si, so = fin // nb, fout // nb
+    x = torch.randn(n, fin, generator=gen).cuda()
+    g = torch.randn(n, fout, generator=gen).cuda()
+    w = torch.randn(r, nb * si * so, generator=gen).cuda()
+    gidx = ops.GraphIndex(src.cuda(), dst.cuda(), n, chunk=32)
+    ridx = gidx.relation_index(et.cuda(), r)
+    nrm = norm.cuda().reshape(-1)
+    for (seg, nbr, ety, perm, feat, p, q, tr) in (
+            (gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, gidx.by_dst.perm, x, si, so, False),
+            (gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, gidx.by_src.perm, g, so, si, True)):
+        assert ops.pack_supported(nb, p, q, tr)
+        ref = ops.bdd_aggregate(seg, nbr, ety, nrm, perm, feat, w, nb, p, q, tr)
+        got = ops.bdd_aggregate(seg, nbr, ety, nrm, perm, feat, ops.pack_weight(w, nb, p, q, tr), nb, p, q, tr, packed=True)
+        assert torch.equal(ref, got)
+    assert not ops.pack_supported(200, 1, 1, False) and not ops.pack_supported(20, 10, 10, False)

@@ -66,10 +66,24 @@ def bench_k1(chunk=256, chunk_rel=128):
                                              w, nb, si, so, False, pre, 1))
         by = E * (fin * 4 + 12) + N * (fout * 4 + 4) + R * fin * fout // nb * 4
         print(f'agg fwd   {si}x{so}: {t:7.1f} us  {by / t / 1e3:7.1f} GB/s algorithmic')
+        wp = ops.pack_weight(w, nb, si, so)
+        wpt = ops.pack_weight(w, nb, so, si, True)
+        ref = ops.bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, norm, gidx.by_dst.perm, x, w, nb, si, so, False, pre, 1)
+        got = ops.bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, norm, gidx.by_dst.perm, x, wp, nb, si, so, False, pre, 1, packed=True)
+        t = timeit(lambda: ops.bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, norm, gidx.by_dst.perm, x,
+                                             wp, nb, si, so, False, pre, 1, packed=True))
+        print(f'agg fwd   {si}x{so}: {t:7.1f} us  {by / t / 1e3:7.1f} GB/s algorithmic   [lane-packed W]  maxdiff {float((ref - got).abs().max()):.2e}')
+        tp = timeit(lambda: ops.pack_weight(w, nb, si, so))
+        print(f'pack W    {si}x{so}: {tp:7.1f} us')
         t = timeit(lambda: ops.bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, norm, gidx.by_src.perm, gg,
                                              w, nb, so, si, True))
         by = E * (fout * 4 + 12) + N * (fin * 4 + 4) + R * fin * fout // nb * 4
         print(f'agg bwd-x {so}x{si}: {t:7.1f} us  {by / t / 1e3:7.1f} GB/s algorithmic')
+        ref = ops.bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, norm, gidx.by_src.perm, gg, w, nb, so, si, True)
+        got = ops.bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, norm, gidx.by_src.perm, gg, wpt, nb, so, si, True, packed=True)
+        t = timeit(lambda: ops.bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, norm, gidx.by_src.perm, gg,
+                                             wpt, nb, so, si, True, packed=True))
+        print(f'agg bwd-x {so}x{si}: {t:7.1f} us  {by / t / 1e3:7.1f} GB/s algorithmic   [lane-packed W]  maxdiff {float((ref - got).abs().max()):.2e}')
         t = timeit(lambda: ops.bdd_grad_weight(ridx.by_rel.seg, ridx.src_by_rel, ridx.dst_by_rel, norm, ridx.by_rel.perm,
                                                x, gg, nb, si, so))
         by = E * (fin * 4 + fout * 4 + 12) + R * fin * fout // nb * 4
