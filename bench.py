@@ -106,6 +106,30 @@ def algorithmic_bytes(tag, E, N, R, T):
     return 0
 
 
+def pmc_traffic_for(tag):
+    """HBM-side bytes per launch of the kernel behind a K1 tag, from the committed rocprofv3 PMC passes of this same
+    command (profiles/<round>/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc runs, gfx950 correction
+    per MI355X_MICROARCH.md).  None when no profile of that kernel is committed."""
+    import glob
+    import re
+    kind, rest = tag.split('_', 1)
+    if kind != 'agg':
+        return None
+    tr, blk, _ = rest.split('_')
+    p, q = blk.split('x')
+    pat = re.compile(r'k_agg_(fast|packed)<%s,%s,%s,' % (p, q, 'true' if tr == 'T' else 'false'))
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*', 'pmc_traffic.json'))):
+        try:
+            data = json.load(open(path))
+        except Exception:
+            continue
+        for k, v in data.items():
+            if pat.match(k):
+                best = v['traffic_bytes']
+    return best
+
+
 def cpu_baseline(w, model, args, budget_s):
     """The CPU oracle (oracle/, a torch-CPU port of the reference's op sequence) on the same inputs."""
     from oracle import kgvae as okg
@@ -290,7 +314,7 @@ def main():
             dom = max(rg, key=lambda k: rg[k]['avg_us'])
             ach = rg[dom]['achieved_GBs']
             roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                        'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic_for(dom),
                         'avg_us': rg[dom]['avg_us'], 'algorithmic_MB': rg[dom]['algorithmic_MB']}
     if world > 1:
         dist.barrier()

@@ -11,11 +11,13 @@
 // staging); the shapes on this path are skinny (K = N = 200..400, M = nodes), so the kernel is
 // sized for many small blocks rather than for a 256^2 pipeline.
 // split-K (grid.z) writes raw partial tiles to a workspace that a second kernel sums in order.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gv {
 
-constexpr int BN = 64, BK = 16;
+constexpr int BN = 64;
 constexpr int LDB_S = BN + 1;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -31,101 +33,90 @@ struct GemmParams {
     int vec_a, vec_b;
 };
 
-// ---- global -> registers (BM/16 floats of A, 4 floats of B per thread), zero-filled outside the matrix
-template <bool TA, int BM>
-__device__ __forceinline__ void load_a(const GemmParams& p, int m0, int k0, int kend, float (&r)[BM / 16]) {
-    constexpr int APT = BM / 16;       // floats per thread: 8 (BM=128) or 4 (BM=64)
+// guarded load of VPT consecutive floats (VPT % 4 == 0) along the contiguous dimension; `lim` bounds that
+// dimension, `ok` says the other coordinate is inside the matrix
+template <int VPT>
+__device__ __forceinline__ void load_run(const float* src, int pos, int lim, bool ok, bool vec, float (&r)[VPT], int off) {
+#pragma unroll
+    for (int h = 0; h < VPT / 4; ++h) {
+        const int q = pos + 4 * h;
+        if (ok && vec && q + 3 < lim) {
+            const float4 v = *reinterpret_cast<const float4*>(src + 4 * h);
+            r[off + 4 * h] = v.x; r[off + 4 * h + 1] = v.y; r[off + 4 * h + 2] = v.z; r[off + 4 * h + 3] = v.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[off + 4 * h + i] = (ok && q + i < lim) ? src[4 * h + i] : 0.f;
+        }
+    }
+}
+
+// ---- global -> registers: BM*BK/256 floats of A and BN*BK/256 floats of B per thread, zero outside the matrix
+template <bool TA, int BM, int BK>
+__device__ __forceinline__ void load_a(const GemmParams& p, int m0, int k0, int kend, float (&r)[BM * BK / 256]) {
+    constexpr int APT = BM * BK / 256;
     const int t = threadIdx.x;
-    if constexpr (!TA) {               // A is [M, K], K contiguous: 16/APT threads per row, APT consecutive k each
-        constexpr int TPR = 16 / APT;
+    if constexpr (!TA) {               // A is [M, K], K contiguous: BK/APT threads per row
+        constexpr int TPR = BK / APT;
         const int m = m0 + t / TPR, kk = k0 + (t % TPR) * APT;
-        const float* src = p.a + (size_t)m * p.lda + kk;
-#pragma unroll
-        for (int h = 0; h < APT / 4; ++h) {
-            const int kq = kk + 4 * h;
-            if (m < p.m && p.vec_a && kq + 3 < kend) {
-                const float4 v = *reinterpret_cast<const float4*>(src + 4 * h);
-                r[4 * h] = v.x; r[4 * h + 1] = v.y; r[4 * h + 2] = v.z; r[4 * h + 3] = v.w;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) r[4 * h + i] = (m < p.m && kq + i < kend) ? src[4 * h + i] : 0.f;
-            }
-        }
-    } else {                           // A is stored [K, M], M contiguous: thread -> k t/16, APT consecutive m
-        const int kq = k0 + (t >> 4), m = m0 + (t & 15) * APT;
-        const float* src = p.a + (size_t)kq * p.lda + m;
-#pragma unroll
-        for (int h = 0; h < APT / 4; ++h) {
-            const int mq = m + 4 * h;
-            if (kq < kend && p.vec_a && mq + 3 < p.m) {
-                const float4 v = *reinterpret_cast<const float4*>(src + 4 * h);
-                r[4 * h] = v.x; r[4 * h + 1] = v.y; r[4 * h + 2] = v.z; r[4 * h + 3] = v.w;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) r[4 * h + i] = (kq < kend && mq + i < p.m) ? src[4 * h + i] : 0.f;
-            }
-        }
+        load_run<APT>(p.a + (size_t)m * p.lda + kk, kk, kend, m < p.m, p.vec_a, r, 0);
+    } else {                           // A is stored [K, M], M contiguous: BM/APT threads per k
+        constexpr int TPK = BM / APT;
+        const int kq = k0 + t / TPK, m = m0 + (t % TPK) * APT;
+        load_run<APT>(p.a + (size_t)kq * p.lda + m, m, p.m, kq < kend, p.vec_a, r, 0);
     }
 }
 
-template <bool TB>
-__device__ __forceinline__ void load_b(const GemmParams& p, int n0, int k0, int kend, float (&r)[4]) {
+template <bool TB, int BK>
+__device__ __forceinline__ void load_b(const GemmParams& p, int n0, int k0, int kend, float (&r)[BN * BK / 256]) {
+    constexpr int BPT = BN * BK / 256;
     const int t = threadIdx.x;
-    if constexpr (!TB) {  // B is [K, N], N contiguous: thread -> k t/16, 4 consecutive n
-        const int kq = k0 + (t >> 4), n = n0 + (t & 15) * 4;
-        const float* src = p.b + (size_t)kq * p.ldb + n;
-        if (kq < kend && p.vec_b && n + 3 < p.n) {
-            const float4 v = *reinterpret_cast<const float4*>(src);
-            r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) r[i] = (kq < kend && n + i < p.n) ? src[i] : 0.f;
-        }
-    } else {  // B is stored [N, K], K contiguous: thread -> n t/4, 4 consecutive k
-        const int n = n0 + (t >> 2), kq = k0 + (t & 3) * 4;
-        const float* src = p.b + (size_t)n * p.ldb + kq;
-        if (n < p.n && p.vec_b && kq + 3 < kend) {
-            const float4 v = *reinterpret_cast<const float4*>(src);
-            r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) r[i] = (n < p.n && kq + i < kend) ? src[i] : 0.f;
-        }
+    if constexpr (!TB) {               // B is [K, N], N contiguous: BN/BPT threads per k
+        constexpr int TPK = BN / BPT;
+        const int kq = k0 + t / TPK, n = n0 + (t % TPK) * BPT;
+        load_run<BPT>(p.b + (size_t)kq * p.ldb + n, n, p.n, kq < kend, p.vec_b, r, 0);
+    } else {                           // B is stored [N, K], K contiguous: BK/BPT threads per n
+        constexpr int TPN = BK / BPT;
+        const int n = n0 + t / TPN, kq = k0 + (t % TPN) * BPT;
+        load_run<BPT>(p.b + (size_t)n * p.ldb + kq, kq, kend, n < p.n, p.vec_b, r, 0);
     }
 }
 
-template <bool TA, int BM>
-__device__ __forceinline__ void stage_a(float* As, const float (&r)[BM / 16]) {
-    constexpr int APT = BM / 16, LDA_S = BM + 1;
+template <bool TA, int BM, int BK>
+__device__ __forceinline__ void stage_a(float* As, const float (&r)[BM * BK / 256]) {
+    constexpr int APT = BM * BK / 256, LDA_S = BM + 1;
     const int t = threadIdx.x;
     if constexpr (!TA) {
-        constexpr int TPR = 16 / APT;
+        constexpr int TPR = BK / APT;
         const int m = t / TPR, kk = (t % TPR) * APT;
 #pragma unroll
         for (int i = 0; i < APT; ++i) As[(kk + i) * LDA_S + m] = r[i];
     } else {
-        const int kq = t >> 4, m = (t & 15) * APT;
+        constexpr int TPK = BM / APT;
+        const int kq = t / TPK, m = (t % TPK) * APT;
 #pragma unroll
         for (int i = 0; i < APT; ++i) As[kq * LDA_S + m + i] = r[i];
     }
 }
 
-template <bool TB>
-__device__ __forceinline__ void stage_b(float* Bs, const float (&r)[4]) {
+template <bool TB, int BK>
+__device__ __forceinline__ void stage_b(float* Bs, const float (&r)[BN * BK / 256]) {
+    constexpr int BPT = BN * BK / 256;
     const int t = threadIdx.x;
     if constexpr (!TB) {
-        const int kq = t >> 4, n = (t & 15) * 4;
+        constexpr int TPK = BN / BPT;
+        const int kq = t / TPK, n = (t % TPK) * BPT;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Bs[kq * LDB_S + n + i] = r[i];
+        for (int i = 0; i < BPT; ++i) Bs[kq * LDB_S + n + i] = r[i];
     } else {
-        const int n = t >> 2, kq = (t & 3) * 4;
+        constexpr int TPN = BK / BPT;
+        const int n = t / TPN, kq = (t % TPN) * BPT;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Bs[(kq + i) * LDB_S + n] = r[i];
+        for (int i = 0; i < BPT; ++i) Bs[(kq + i) * LDB_S + n] = r[i];
     }
 }
 
-// MT = 32-row MFMA tiles per wave: block tile (64*MT) x 64, four waves as 2 (M) x 2 (N).
-template <bool TA, bool TB, int MT>
+// MT = 32-row MFMA tiles per wave: block tile (64*MT) x 64 x BK, four waves as 2 (M) x 2 (N).
+template <bool TA, bool TB, int MT, int BK>
 __global__ __launch_bounds__(256) void k_gemm_f32(const GemmParams p) {
     constexpr int BM = 64 * MT, LDA_S = BM + 1;
     __shared__ float As[BK * LDA_S];
@@ -143,16 +134,16 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    float ra[BM / 16], rb[4];
-    load_a<TA, BM>(p, m0, kbeg, kend, ra);
-    load_b<TB>(p, n0, kbeg, kend, rb);
+    float ra[BM * BK / 256], rb[BN * BK / 256];
+    load_a<TA, BM, BK>(p, m0, kbeg, kend, ra);
+    load_b<TB, BK>(p, n0, kbeg, kend, rb);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        stage_a<TA, BM>(As, ra);
-        stage_b<TB>(Bs, rb);
+        stage_a<TA, BM, BK>(As, ra);
+        stage_b<TB, BK>(Bs, rb);
         __syncthreads();
         if (k0 + BK < kend) {  // next tile's loads fly under this tile's MFMAs
-            load_a<TA, BM>(p, m0, k0 + BK, kend, ra);
-            load_b<TB>(p, n0, k0 + BK, kend, rb);
+            load_a<TA, BM, BK>(p, m0, k0 + BK, kend, ra);
+            load_b<TB, BK>(p, n0, k0 + BK, kend, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
@@ -245,7 +236,7 @@ using namespace gv;
 
 static int k_chunk_for(int k, int split_k) {
     int per = (k + split_k - 1) / split_k;
-    return ((per + BK - 1) / BK) * BK;
+    return ((per + 31) / 32) * 32;
 }
 
 extern "C" int64_t gv_gemm_workspace_bytes(int m, int n, int k, int split_k) {
@@ -283,12 +274,17 @@ extern "C" int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const 
     // 128-row tiles only when they still give every CU >= 4 blocks; otherwise 64-row tiles (more, smaller
     // blocks hide the global-load latency of these short-K shapes better than one long MFMA chain)
     const long blocks128 = (long)((n + BN - 1) / BN) * ((m + 127) / 128) * split_k;
-    const int mt = blocks128 >= 1024 ? 2 : 1;
+    static const int mt_env = getenv("GV_GEMM_MT") ? atoi(getenv("GV_GEMM_MT")) : 0;   // tuning knob
+    const int mt = mt_env ? mt_env : (blocks128 >= 1024 ? 2 : 1);
     dim3 grid((n + BN - 1) / BN, (m + 64 * mt - 1) / (64 * mt), split_k), block(256);
-#define GV_GEMM_LAUNCH(TA_, TB_)                                                          \
-    do {                                                                                  \
-        if (mt == 2) hipLaunchKernelGGL((k_gemm_f32<TA_, TB_, 2>), grid, block, 0, st, p); \
-        else hipLaunchKernelGGL((k_gemm_f32<TA_, TB_, 1>), grid, block, 0, st, p);         \
+    static const int bk_env = getenv("GV_GEMM_BK") ? atoi(getenv("GV_GEMM_BK")) : 32;   // tuning knob
+    const int bk = bk_env == 16 ? 16 : 32;
+#define GV_GEMM_LAUNCH(TA_, TB_)                                                                   \
+    do {                                                                                           \
+        if (mt == 2 && bk == 32) hipLaunchKernelGGL((k_gemm_f32<TA_, TB_, 2, 32>), grid, block, 0, st, p);   \
+        else if (mt == 2) hipLaunchKernelGGL((k_gemm_f32<TA_, TB_, 2, 16>), grid, block, 0, st, p);          \
+        else if (bk == 32) hipLaunchKernelGGL((k_gemm_f32<TA_, TB_, 1, 32>), grid, block, 0, st, p);         \
+        else hipLaunchKernelGGL((k_gemm_f32<TA_, TB_, 1, 16>), grid, block, 0, st, p);                       \
     } while (0)
     if (!trans_a && !trans_b) GV_GEMM_LAUNCH(false, false);
     else if (!trans_a && trans_b) GV_GEMM_LAUNCH(false, true);

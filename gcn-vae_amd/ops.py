@@ -13,6 +13,17 @@ from . import lib
 from .lib import ptr
 
 ACT_NONE, ACT_RELU = 0, 1
+
+# Direct gradient targets: parameter storage address -> the gradient buffer its gradient should be ADDED
+# into (registered by optim.FlatAdam, whose arena is zeroed once per step).  A backward that finds its
+# parameter here accumulates in place and returns None for it, so autograd launches no zero-fill and no
+# AccumulateGrad add for that parameter.  Empty registry = ordinary autograd behaviour.
+DIRECT_GRAD = {}
+
+
+def _direct(t):
+    tgt = DIRECT_GRAD.get(t.data_ptr()) if t is not None else None
+    return tgt if (tgt is not None and tgt.shape == t.shape) else None
 DEFAULT_CHUNK = 256        # max edges per work item of the dst/src-sorted aggregations
 DEFAULT_CHUNK_REL = 128    # max edges per work item of the by-relation weight gradient
 
@@ -347,15 +358,17 @@ class _Embedding(torch.autograd.Function):
         lib.call('gv_gather_rows', ptr(table), ptr(ids), ptr(out), ids.numel(), table.shape[1], lib.stream())
         ctx.save_for_backward(ids)
         ctx.shape = tuple(table.shape)
+        ctx.direct = _direct(table)
         return out
 
     @staticmethod
     def backward(ctx, g):
         (ids,) = ctx.saved_tensors
         g = _chk(g.contiguous(), name='grad')
-        gt = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        tgt = ctx.direct
+        gt = tgt if tgt is not None else torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
         lib.call('gv_scatter_add_rows', ptr(g), ptr(ids), ptr(gt), ids.numel(), ctx.shape[1], lib.stream())
-        return gt, None
+        return (None if tgt is not None else gt), None
 
 
 def embedding(table, ids):
@@ -398,6 +411,7 @@ class _RelGraphConvBdd(torch.autograd.Function):
             out = epilogue_fwd(agg, addend, act, keep, keep_scale)
         ctx.save_for_backward(x, weight, loop_weight, coef, out if act == ACT_RELU else None, keep)
         ctx.meta = (gidx, ridx, num_bases, si, so, act, keep_scale, h_bias is not None, reduce_hook)
+        ctx.direct = (_direct(weight), _direct(h_bias), _direct(loop_weight))
         return out
 
     @staticmethod
@@ -406,11 +420,19 @@ class _RelGraphConvBdd(torch.autograd.Function):
         gidx, ridx, nb, si, so, act, keep_scale, has_bias, reduce_hook = ctx.meta
         g = epilogue_bwd(out, grad_out, act, keep, keep_scale)
         g_agg = g if reduce_hook is None else reduce_hook(g.clone())
-        grad_bias = colsum(g) if (has_bias and ctx.needs_input_grad[2]) else None
+        d_w, d_b, d_l = ctx.direct
+        grad_bias = None
+        if has_bias and ctx.needs_input_grad[2]:
+            grad_bias = colsum(g, out=d_b, accumulate=d_b is not None)
+            if d_b is not None:
+                grad_bias = None
         grad_loop = gx_loop = None
         if loop_weight is not None:
             if ctx.needs_input_grad[3]:
-                grad_loop = gemm(x, g, trans_a=True, split_k=pick_split_k(x.shape[1], g.shape[1], x.shape[0]))
+                grad_loop = gemm(x, g, trans_a=True, split_k=pick_split_k(x.shape[1], g.shape[1], x.shape[0]),
+                                 out=d_l, accumulate=d_l is not None)
+                if d_l is not None:
+                    grad_loop = None
             if ctx.needs_input_grad[0]:
                 gx_loop = gemm(g, loop_weight, trans_b=True)
         grad_x = None
@@ -422,7 +444,9 @@ class _RelGraphConvBdd(torch.autograd.Function):
         grad_w = None
         if ctx.needs_input_grad[1]:
             grad_w = bdd_grad_weight(ridx.by_rel.seg, ridx.src_by_rel, ridx.dst_by_rel, coef, ridx.by_rel.perm, x,
-                                     g_agg, nb, si, so)
+                                     g_agg, nb, si, so, out=d_w, accumulate=d_w is not None)
+            if d_w is not None:
+                grad_w = None
         return grad_x, grad_w, grad_bias, grad_loop, None, None, None, None, None, None, None, None
 
 
@@ -846,6 +870,7 @@ class _LossHead(torch.autograd.Function):
                               z_pre if kl_w > 0 else None, resp, z_pri if mmd_w > 0 else None, z_post,
                               pick if mmd_w > 0 else None, labels, score)
         ctx.meta = (tidx, float(reg_w), float(kl_w), float(mmd_w), bias is not None, flp is not None and kl_w > 0)
+        ctx.direct_w = _direct(w_rel) if ld_w == h else None
         out_pred, out_kl, out_mmd = pred.reshape(()), kl.reshape(1), mmd.reshape(())
         ctx.mark_non_differentiable(out_pred, out_kl, out_mmd)
         return loss, out_pred, out_kl, out_mmd
@@ -889,8 +914,12 @@ class _LossHead(torch.autograd.Function):
             lib.call('gv_scatter_add_rows', ptr(g_post), ptr(pick), ptr(gz), pick.numel(), h, st)
         g_z = bdd_aggregate(tidx.inc, tidx.inc_other, tidx.inc_rel, dscore, tidx.inc_tid, z, w_rel, h, 1, 1,
                             addend=gz)
-        g_w = bdd_grad_weight(tidx.rel, tidx.rel_s, tidx.rel_o, dscore, tidx.rel_tid, z, z, h, 1, 1)
+        d_w = ctx.direct_w
+        g_w = bdd_grad_weight(tidx.rel, tidx.rel_s, tidx.rel_o, dscore, tidx.rel_tid, z, z, h, 1, 1, out=d_w,
+                              accumulate=d_w is not None)
         lib.call('gv_axpby', w_rel.numel(), ptr(g), 2.0 * reg_w / w_rel.numel(), ptr(w_rel), 1.0, ptr(g_w), st)
+        if d_w is not None:
+            g_w = None
         g_flp = None
         if has_bias or flp_in_kl:
             g_flp = torch.empty((), **f32)

@@ -9,7 +9,7 @@ Numerics follow ``torch.nn.utils.clip_grad_norm_`` (coefficient min(1, max_norm 
 """
 import torch
 
-from . import lib
+from . import lib, ops
 from .lib import ptr
 
 
@@ -36,11 +36,21 @@ class FlatAdam:
         self.step_t = torch.zeros((), dtype=torch.float32, device=dev)
         self.sumsq = torch.zeros((), dtype=torch.float32, device=dev)
         self._ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        self._direct_keys = []
         for p, o in zip(self.params, offs):
             n = p.numel()
             self.flat_p[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat_p[o:o + n].view(p.shape)
             p.grad = self.flat_g[o:o + n].view(p.shape)
+            ops.DIRECT_GRAD[p.data.data_ptr()] = p.grad      # backward kernels add straight into the arena
+            self._direct_keys.append(p.data.data_ptr())
+
+    def __del__(self):
+        try:
+            for k in getattr(self, '_direct_keys', ()):
+                ops.DIRECT_GRAD.pop(k, None)
+        except Exception:
+            pass
 
     def zero_grad(self):
         self.flat_g.zero_()

@@ -196,3 +196,75 @@ def test_separate_loss_ops_match_fused_head():
     close(net.regularization_loss(embed2), g['reg'], msg='reg')
     close(enc.get_kl(embed2), kl, msg='kl')
     close(enc.get_mmd(embed2), mmd, atol_scale=1e-6, msg='mmd')
+
+
+def test_c2_full_graph_layer_against_oracle():
+    """BASELINE configs[1] at FULL size: one R-GCN layer (h=200 -> 400, B=100, 474 relation types) over the
+    544 230-edge FB15k-237-shaped graph, forward and all gradients, against the CPU oracle."""
+    from gcn_vae_amd import ops, sampling
+    from gcn_vae_amd.data import FB15K237, synthetic_kg
+    from oracle import rgcn as orgcn
+    data = synthetic_kg(FB15K237['num_nodes'], FB15K237['num_rels'], FB15K237['n_train'], seed=0)
+    graph, rel, node_norm = sampling.build_test_graph(data.num_nodes, data.num_rels, data.train)
+    src, dst = graph.edges()
+    n, r = data.num_nodes, 2 * data.num_rels
+    assert src.numel() == 544230
+    norm = torch.from_numpy(node_norm)[dst].view(-1, 1)
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(n, 200, generator=gen)
+    p = orgcn.init_params(200, 400, r, 'bdd', 100, True, True, gen)
+    p['h_bias'] = torch.randn(400, generator=gen) * 0.1
+    gout = torch.randn(n, 400, generator=gen)
+    et = torch.from_numpy(rel)
+    xo = x.clone().requires_grad_(True)
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    orgcn.rel_graph_conv(xo, src, dst, et, norm, po, 'bdd', 100, torch.relu).backward(gout)
+    ho = orgcn.rel_graph_conv(x, src, dst, et, norm, p, 'bdd', 100, torch.relu)
+    gidx = graph.device_index('cuda')
+    ridx = gidx.relation_index(et.cuda(), r)
+    xg = x.cuda().requires_grad_(True)
+    pg = {k: v.cuda().requires_grad_(True) for k, v in p.items()}
+    hg = ops.rel_graph_conv_bdd(xg, pg['weight'], pg['h_bias'], pg['loop_weight'], norm.cuda(), gidx, ridx, 100, 1)
+    hg.backward(gout.cuda())
+    close(hg, ho, msg='forward')
+    close(xg.grad, xo.grad, msg='grad_x')
+    close(pg['weight'].grad, po['weight'].grad, msg='grad_weight')
+    close(pg['loop_weight'].grad, po['loop_weight'].grad, rtol=3e-4, atol_scale=3e-5, msg='grad_loop')
+    close(pg['h_bias'].grad, po['h_bias'].grad, rtol=3e-4, atol_scale=3e-5, msg='grad_bias')
+
+
+def test_large_graph_properties():
+    """4 M directed edges over 200 k entities (beyond what the oracle materialises in seconds): size-independent
+    properties of the aggregation -- linearity in x, invariance to the edge order handed in, and total mass."""
+    from gcn_vae_amd import ops
+    n, e, r, nb, si, so = 200_000, 4_000_000, 400, 100, 2, 4
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    src = torch.randint(0, n, (e,), device='cuda', generator=gen)
+    dst = (torch.rand(e, device='cuda', generator=gen) ** 3 * n).long().clamp_(max=n - 1)     # skewed in-degrees
+    et = torch.randint(0, r, (e,), device='cuda', generator=gen)
+    deg = torch.bincount(dst, minlength=n).float()
+    norm = (1.0 / deg.clamp(min=1))[dst]
+    w = torch.randn(r, nb * si * so, device='cuda', generator=gen)
+    x1 = torch.randn(n, nb * si, device='cuda', generator=gen)
+    x2 = torch.randn(n, nb * si, device='cuda', generator=gen)
+    gidx = ops.GraphIndex(src, dst, n)
+    assert gidx.by_dst.perm is not None and gidx.by_dst.seg.n_fix > 0          # unsorted input, hub rows split
+    ridx = gidx.relation_index(et, r)
+
+    def agg(xx, gi=gidx, ri=ridx, nm=norm):
+        return ops.bdd_aggregate(gi.by_dst.seg, gi.nbr_by_dst, ri.et_by_dst, nm, gi.by_dst.perm, xx, w, nb, si, so)
+    a1, a2, a12 = agg(x1), agg(x2), agg(2.0 * x1 - 0.5 * x2)
+    close(a12, 2.0 * a1 - 0.5 * a2, rtol=1e-4, atol_scale=2e-5, msg='linearity')
+    perm = torch.randperm(e, device='cuda', generator=gen)
+    g2 = ops.GraphIndex(src[perm], dst[perm], n)
+    r2 = g2.relation_index(et[perm], r)
+    close(agg(x1, g2, r2, norm[perm]), a1, rtol=1e-4, atol_scale=2e-5, msg='edge-order invariance')
+    # total mass: sum_v out[v] = sum_e norm_e * blockdiag(W_e) x[src_e], evaluated edge-wise in fp64 on a sample of columns
+    cols = torch.tensor([0, 1, 7, 202, 399], device='cuda')
+    b, j = cols // so, cols % so
+    wsel = w.view(r, nb, si, so).double()
+    msg = torch.zeros(e, len(cols), dtype=torch.float64, device='cuda')
+    for i in range(si):
+        msg += x1[src][:, b * si + i].double() * wsel[et][:, b, i, j]
+    tot = (msg * norm.double().unsqueeze(1)).sum(0)
+    close(a1[:, cols].double().sum(0), tot, rtol=1e-4, atol_scale=1e-5, msg='total mass')
