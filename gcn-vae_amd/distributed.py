@@ -4,10 +4,11 @@ The path shards by EDGE BLOCK (north_star): every rank holds the replicated para
 block of the edge list (CSR built locally) and its own slice of the decoder's triplets.
 
   forward   partial aggregate  agg_p = sum over the rank's edges     (K1, local)
-            all-reduce(sum) of (N, out) node embeddings               <- the one exchange per layer
+            all-reduce(sum) of (N, out) node embeddings  || self-loop GEMM   <- the one exchange per layer
             epilogue (self loop + bias + activation + dropout), decoder on the rank's triplets
   backward  the gradient of the aggregate is all-reduced(sum) the same way (every rank's loss sees
-            every rank's edges through the reduced embeddings), then K1^T / grad-W run locally
+            every rank's edges through the reduced embeddings) || bias / loop-weight gradients and the
+            loop GEMM of the layer, then K1^T / grad-W run locally
   step      parameter gradients are averaged over ranks (one flat all-reduce), so the update equals
             the single-process gradient of  (1/P) sum_p loss_p  on the union graph.
 
@@ -41,11 +42,21 @@ def init_process_group(backend=None):
     return rank, local_rank, world
 
 
-def make_reduce_hook(group=None):
-    """Callable for ``RelGraphConv.reduce_hook``: in-place sum over the edge shards."""
+class _Done:
+    def wait(self):
+        return None
+
+
+def make_reduce_hook(group=None, async_op=True):
+    """Callable for ``RelGraphConv.reduce_hook``: starts an in-place sum of ``t`` over the edge shards and
+    returns a handle whose ``wait()`` orders the current stream behind it.  With ``async_op`` the collective
+    runs on RCCL's own stream, so whatever the caller enqueues between the call and ``wait()`` (the layer's
+    self-loop GEMM in forward; bias / loop-weight gradients and the loop GEMM in backward) overlaps with it."""
     def hook(t):
+        if async_op:
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        return t
+        return _Done()
     return hook
 
 

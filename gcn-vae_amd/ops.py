@@ -378,9 +378,11 @@ def embedding(table, ids):
 class _RelGraphConvBdd(torch.autograd.Function):
     """out = keep*scale*act( sum_e norm_e * blockdiag(W_{r_e}) x[src_e]  + x@loop_weight + h_bias ).
 
-    ``reduce_hook`` (multi-GPU edge sharding): a callable that sums a tensor over the ranks in place
-    and returns it.  With a hook the raw aggregate is kept separate from the epilogue so that it can
-    be all-reduced in between; backward all-reduces the gradient of the aggregate the same way.
+    ``reduce_hook`` (multi-GPU edge sharding): a callable that STARTS an in-place sum of a tensor over the
+    ranks and returns a handle with ``wait()`` (distributed.make_reduce_hook).  With a hook the raw aggregate
+    is kept separate from the epilogue so that it can be all-reduced in between, overlapped with the layer's
+    self-loop GEMM; backward all-reduces the gradient of the aggregate the same way, overlapped with the bias /
+    loop-weight gradients and the loop GEMM.
     """
 
     @staticmethod
@@ -391,23 +393,28 @@ class _RelGraphConvBdd(torch.autograd.Function):
         si = in_feat // num_bases
         so = weight.shape[1] // (num_bases * si)
         out_feat = num_bases * so
-        addend = None
-        if loop_weight is not None:
-            addend = gemm(x, loop_weight, bias=h_bias)
-        elif h_bias is not None:
-            addend = h_bias.unsqueeze(0).expand(n, out_feat).contiguous()
         coef = None if norm is None else norm.reshape(-1)
         # lane-packed weights pay off once a block's weights span >= 32 B (measured: 2x4 / 4x2 blocks -24 % / -19 %,
         # 2x2 blocks +-0): pack per launch kind, a ~1.5 MB pass per layer
         pk = si * so >= 8 and pack_supported(num_bases, si, so, False)
         w_fwd = pack_weight(weight, num_bases, si, so, False) if pk else weight
+
+        def self_loop_term():
+            if loop_weight is not None:
+                return gemm(x, loop_weight, bias=h_bias)
+            if h_bias is not None:
+                return h_bias.unsqueeze(0).expand(n, out_feat).contiguous()
+            return None
+
         if reduce_hook is None:
             out = bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x, w_fwd,
-                                num_bases, si, so, False, addend, act, keep, keep_scale, packed=pk)
+                                num_bases, si, so, False, self_loop_term(), act, keep, keep_scale, packed=pk)
         else:
             agg = bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x, w_fwd,
                                 num_bases, si, so, packed=pk)
-            agg = reduce_hook(agg)
+            pending = reduce_hook(agg)          # all-reduce of the partial node aggregate ...
+            addend = self_loop_term()           # ... overlapped with the self-loop GEMM
+            pending.wait()
             out = epilogue_fwd(agg, addend, act, keep, keep_scale)
         ctx.save_for_backward(x, weight, loop_weight, coef, out if act == ACT_RELU else None, keep)
         ctx.meta = (gidx, ridx, num_bases, si, so, act, keep_scale, h_bias is not None, reduce_hook)
@@ -419,7 +426,11 @@ class _RelGraphConvBdd(torch.autograd.Function):
         x, weight, loop_weight, coef, out, keep = ctx.saved_tensors
         gidx, ridx, nb, si, so, act, keep_scale, has_bias, reduce_hook = ctx.meta
         g = epilogue_bwd(out, grad_out, act, keep, keep_scale)
-        g_agg = g if reduce_hook is None else reduce_hook(g.clone())
+        pending = None
+        g_agg = g
+        if reduce_hook is not None:      # gradient of this rank's partial aggregate = sum over ranks; overlapped below
+            g_agg = g.clone()
+            pending = reduce_hook(g_agg)
         d_w, d_b, d_l = ctx.direct
         grad_bias = None
         if has_bias and ctx.needs_input_grad[2]:
@@ -435,6 +446,8 @@ class _RelGraphConvBdd(torch.autograd.Function):
                     grad_loop = None
             if ctx.needs_input_grad[0]:
                 gx_loop = gemm(g, loop_weight, trans_b=True)
+        if pending is not None:
+            pending.wait()
         grad_x = None
         if ctx.needs_input_grad[0]:
             pk = si * so >= 8 and pack_supported(nb, so, si, True)

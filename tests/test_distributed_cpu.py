@@ -104,8 +104,10 @@ def worker(rank, world, port, out_q):
         assert torch.allclose(arena, torch.full((7,), 1.5))
         hook = gdist.make_reduce_hook()
         t = torch.full((3,), float(rank))
-        out = hook(t)
-        assert out.data_ptr() == t.data_ptr() and torch.equal(out, torch.full((3,), 1.0))      # in place, summed
+        for h in (gdist.make_reduce_hook(), gdist.make_reduce_hook(async_op=False)):
+            t = torch.full((3,), float(rank))
+            h(t).wait()
+            assert torch.equal(t, torch.full((3,), 1.0))                           # in place, summed over ranks
         mean_loss = torch.tensor([float(loss)])
         dist.all_reduce(mean_loss)
         out_q.put((rank, {k: v.grad.clone().numpy() for k, v in p.items()}, float(mean_loss) / world, flat.numpy()))
