@@ -277,8 +277,10 @@ extern "C" int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const 
     static const int mt_env = getenv("GV_GEMM_MT") ? atoi(getenv("GV_GEMM_MT")) : 0;   // tuning knob
     const int mt = mt_env ? mt_env : (blocks128 >= 1024 ? 2 : 1);
     dim3 grid((n + BN - 1) / BN, (m + 64 * mt - 1) / (64 * mt), split_k), block(256);
-    static const int bk_env = getenv("GV_GEMM_BK") ? atoi(getenv("GV_GEMM_BK")) : 32;   // tuning knob
-    const int bk = bk_env == 16 ? 16 : 32;
+    // measured on the C2 shapes: BK=16 is best for the row-major-A products (K = 200..400), BK=32 for the
+    // split-K weight-gradient products (A stored [K, M], K = nodes)
+    static const int bk_env = getenv("GV_GEMM_BK") ? atoi(getenv("GV_GEMM_BK")) : 0;   // tuning knob
+    const int bk = bk_env ? (bk_env == 16 ? 16 : 32) : (trans_a ? 32 : 16);
 #define GV_GEMM_LAUNCH(TA_, TB_)                                                                   \
     do {                                                                                           \
         if (mt == 2 && bk == 32) hipLaunchKernelGGL((k_gemm_f32<TA_, TB_, 2, 32>), grid, block, 0, st, p);   \

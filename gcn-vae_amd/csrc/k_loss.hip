@@ -456,7 +456,7 @@ extern "C" int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* 
     float* terms = workspace + 3 * (size_t)k * h;
     float* part = terms + n;
     hipLaunchKernelGGL(k_kl_mix, dim3((k * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, k, h, mix);
-    const int nb = (int)((n + 3) / 4 > 512 ? 512 : (n + 3) / 4);
+    const int nb = (int)((n + 3) / 4 > 1024 ? 1024 : (n + 3) / 4);
     GV_REQUIRE(h <= 1024, GV_ERR_SHAPE, "gv_kl_fwd: h=%d > 1024 unsupported", h);
 #define GV_KL_FWD(CPL_) hipLaunchKernelGGL(k_kl_fwd<CPL_>, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, flp, resp, terms, n, h, k)
     if (h <= 64) GV_KL_FWD(1);
@@ -481,7 +481,7 @@ extern "C" int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* 
     float* mix = workspace;  // filled by gv_kl_fwd of the same step; recomputed here to stay self-contained
     hipLaunchKernelGGL(k_kl_mix, dim3((k * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, k, h, mix);
     const size_t lds = (size_t)2 * k * h * sizeof(float);
-    const int nb = (int)((n + 3) / 4 > 512 ? 512 : (n + 3) / 4);
+    const int nb = (int)((n + 3) / 4 > 1024 ? 1024 : (n + 3) / 4);
     hipLaunchKernelGGL(k_kl_bwd_nodes, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, resp, gkl, gz, gm, gv, n,
                        h, k);
     float* part = workspace + 3 * (size_t)k * h + n + RED_BLOCKS;

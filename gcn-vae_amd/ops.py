@@ -28,6 +28,45 @@ DEFAULT_CHUNK = 256        # max edges per work item of the dst/src-sorted aggre
 DEFAULT_CHUNK_REL = 128    # max edges per work item of the by-relation weight gradient
 
 
+# ------------------------------------------------------------------------------------------------
+# fork / join on side streams: independent groups of small, latency-bound launches (KL, MMD, scalar
+# reductions, weight-gradient GEMMs) run beside the bandwidth-bound kernels instead of behind them.
+# Under hipGraph capture the event edges become parallel graph branches.  Buffers a branch writes are
+# allocated by the caller BEFORE the fork (torch's allocator is per stream).  Opt in with GV_CONCURRENCY=1.
+import contextlib
+import os as _os
+
+CONCURRENCY = _os.environ.get('GV_CONCURRENCY', '0') == '1'   # measured null on MI355X (1.49 vs 1.49 ms/step): off by default
+_side_streams = {}
+
+
+def _side(i):
+    key = (torch.cuda.current_device(), i)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream()
+    return _side_streams[key]
+
+
+@contextlib.contextmanager
+def fork(i):
+    """Run the enclosed launches on side stream ``i`` (after everything already enqueued on the current
+    stream); pair with ``join(i)`` before their results are consumed."""
+    if not CONCURRENCY:
+        yield
+        return
+    s = _side(i)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        yield
+
+
+def join(*ids):
+    if CONCURRENCY:
+        cur = torch.cuda.current_stream()
+        for i in ids:
+            cur.wait_stream(_side(i))
+
+
 def _chk(t, dtype=torch.float32, name='tensor'):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError(f'{name}: the gfx950 path needs a CUDA/ROCm tensor (got '
@@ -835,7 +874,8 @@ class _LossHead(torch.autograd.Function):
     with KL = KGVAE.get_kl(z) and MMD = KGVAE.get_mmd's kernel means on (z_pri, z[pick]).  Forward is the
     K5/K6 kernels plus one scalar combine; backward produces a single gradient for z: KL's gz, the regulariser
     and the MMD rows are accumulated into one buffer that the DistMult gather-aggregate (K1, 1x1 blocks)
-    takes as its fused addend -- no multi-use gradient adds, no scalar glue kernels.
+    takes as its fused addend -- no multi-use gradient adds, no scalar glue kernels.  The KL and MMD kernel
+    groups (small, latency-bound) run on side streams beside the bandwidth-bound DistMult kernels.
     Returns (loss, predict_loss, kl, mmd); only ``loss`` is differentiable.
     """
 
@@ -847,36 +887,43 @@ class _LossHead(torch.autograd.Function):
         dev, (n, h), T = z.device, z.shape, tidx.T
         if labels.numel() != T:
             raise ValueError('labels / triplets length mismatch')
-        st = lib.stream()
         f32 = dict(dtype=torch.float32, device=dev)
         scal = torch.zeros(4, **f32)                 # pred, reg, kl, mmd
         pred, reg, kl, mmd = scal[0:1], scal[1:2], scal[2:3], scal[3:4]
-        ws = torch.empty(1024, **f32)
+        ws, ws2 = torch.empty(1024, **f32), torch.empty(1024, **f32)
         score = torch.empty(T, **f32)
+        loss = torch.empty((), **f32)
         bias = flp if (score_bias and flp is not None) else None
-        lib.call('gv_distmult_bce_fwd', ptr(z), ld_z, ptr(w_rel), ld_w, ptr(tidx.trip32), ptr(labels), ptr(bias),
-                 ptr(score), ptr(pred), ptr(ws), T, h, st)
-        ws2 = torch.empty(1024, **f32)
-        lib.call('gv_mean_sq', ptr(z), z.numel(), 1.0 / z.numel(), ptr(reg), ptr(ws2), 0, st)
-        lib.call('gv_mean_sq', ptr(w_rel), w_rel.numel(), 1.0 / w_rel.numel(), ptr(reg), ptr(ws2), 1, st)
-        resp = None
+        resp = wsk = z_post = wsm = None
         if kl_w > 0:
             z_mean, z_sigma = _chk(z_mean.contiguous(), name='z_mean'), _chk(z_sigma.contiguous(), name='z_sigma')
             z_pre = _chk(z_pre.contiguous(), name='z_pre')
             k = z_pre.shape[0] // 2
             wsk = torch.empty(int(lib.load().gv_kl_workspace_bytes(n, h, k)) // 4, **f32)
             resp = torch.empty(n, k, **f32)
-            lib.call('gv_kl_fwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(flp), ptr(resp), ptr(kl),
-                     ptr(wsk), n, h, k, st)
-        z_post = None
         if mmd_w > 0:
             z_pri = _chk(z_pri.contiguous(), name='z_pri')
             pick = _chk(pick.reshape(-1), torch.int64, 'pick')
             z_post = torch.empty(pick.numel(), h, **f32)
-            lib.call('gv_gather_rows', ptr(z), ptr(pick), ptr(z_post), pick.numel(), h, st)
             wsm = torch.empty(z_pri.shape[0] + z_post.shape[0], **f32)
-            lib.call('gv_mmd_fwd', ptr(z_pri), ptr(z_post), z_pri.shape[0], z_post.shape[0], h, ptr(mmd), ptr(wsm), st)
-        loss = torch.empty((), **f32)
+        # branch 1: KL to the mixture prior
+        if kl_w > 0:
+            with fork(1):
+                lib.call('gv_kl_fwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(flp), ptr(resp), ptr(kl),
+                         ptr(wsk), n, h, k, lib.stream())
+        # branch 2: MMD + the regulariser sums
+        with fork(2):
+            st2 = lib.stream()
+            if mmd_w > 0:
+                lib.call('gv_gather_rows', ptr(z), ptr(pick), ptr(z_post), pick.numel(), h, st2)
+                lib.call('gv_mmd_fwd', ptr(z_pri), ptr(z_post), z_pri.shape[0], z_post.shape[0], h, ptr(mmd), ptr(wsm), st2)
+            lib.call('gv_mean_sq', ptr(z), z.numel(), 1.0 / z.numel(), ptr(reg), ptr(ws2), 0, st2)
+            lib.call('gv_mean_sq', ptr(w_rel), w_rel.numel(), 1.0 / w_rel.numel(), ptr(reg), ptr(ws2), 1, st2)
+        # main: DistMult scorer + BCE (three 800-B row gathers per triplet: the bandwidth-bound part)
+        st = lib.stream()
+        lib.call('gv_distmult_bce_fwd', ptr(z), ld_z, ptr(w_rel), ld_w, ptr(tidx.trip32), ptr(labels), ptr(bias),
+                 ptr(score), ptr(pred), ptr(ws), T, h, st)
+        join(1, 2)
         lib.call('gv_lincomb4', ptr(pred), 1.0, ptr(reg), float(reg_w), ptr(kl) if kl_w > 0 else None, float(kl_w),
                  ptr(mmd) if mmd_w > 0 else None, float(mmd_w), ptr(loss), st)
         ctx.save_for_backward(z, z_mean if kl_w > 0 else None, z_sigma if kl_w > 0 else None, w_rel,
@@ -893,52 +940,57 @@ class _LossHead(torch.autograd.Function):
         z, z_mean, z_sigma, w_rel, z_pre, resp, z_pri, z_post, pick, labels, score = ctx.saved_tensors
         tidx, reg_w, kl_w, mmd_w, has_bias, flp_in_kl = ctx.meta
         dev, (n, h), T = z.device, z.shape, tidx.T
-        st = lib.stream()
         f32 = dict(dtype=torch.float32, device=dev)
         g = _chk(g.reshape(1).contiguous(), name='gloss')
+        # every buffer a side branch writes is allocated here, before the forks
         dscore = torch.empty(T, **f32)
         dbias = torch.zeros((), **f32) if has_bias else None
         ws = torch.empty(1024, **f32)
-        lib.call('gv_bce_grad', ptr(score), ptr(labels), ptr(g), ptr(dscore), ptr(dbias), ptr(ws), T, st)
-        gm = gv = gzp = gz = None
-        gsc = None
-        if kl_w > 0 or mmd_w > 0:
-            gsc = torch.empty(2, **f32)               # g*kl_w, g*mmd_w as device scalars
-            lib.call('gv_lincomb4', ptr(g), kl_w, None, 0.0, None, 0.0, None, 0.0, ptr(gsc[0:1]), st)
-            lib.call('gv_lincomb4', ptr(g), mmd_w, None, 0.0, None, 0.0, None, 0.0, ptr(gsc[1:2]), st)
+        gsc = torch.empty(2, **f32) if (kl_w > 0 or mmd_w > 0) else None     # g*kl_w, g*mmd_w as device scalars
+        gz = torch.empty_like(z)
+        gm = gv = gzp = wsk = g_pri = g_post = None
         if kl_w > 0:
             k = z_pre.shape[0] // 2
             wsk = torch.empty(int(lib.load().gv_kl_workspace_bytes(n, h, k)) // 4, **f32)
-            gz, gm, gv = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
-            gzp = torch.empty_like(z_pre)
-            lib.call('gv_kl_bwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(resp), ptr(gsc[0:1]), ptr(gz),
-                     ptr(gm), ptr(gv), ptr(gzp), ptr(wsk), n, h, k, st)
-        # regulariser on z: gz (+)= g * reg_w * 2/(n h) * z
-        if gz is None:
-            gz = torch.empty_like(z)
-            lib.call('gv_axpby', z.numel(), ptr(g), 2.0 * reg_w / z.numel(), ptr(z), 0.0, ptr(gz), st)
-        else:
-            lib.call('gv_axpby', z.numel(), ptr(g), 2.0 * reg_w / z.numel(), ptr(z), 1.0, ptr(gz), st)
-        g_pri = None
+            gm, gv, gzp = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z_pre)
         if mmd_w > 0:
             g_pri, g_post = torch.empty_like(z_pri), torch.empty_like(z_post)
-            lib.call('gv_mmd_bwd', ptr(z_pri), ptr(z_post), z_pri.shape[0], z_post.shape[0], h, ptr(gsc[1:2]), ptr(g_pri),
-                     ptr(g_post), st)
+        d_w = ctx.direct_w
+        g_w = d_w if d_w is not None else torch.empty_like(w_rel)
+        g_flp = torch.empty((), **f32) if (has_bias or flp_in_kl) else None
+        st = lib.stream()
+        if gsc is not None:
+            lib.call('gv_lincomb4', ptr(g), kl_w, None, 0.0, None, 0.0, None, 0.0, ptr(gsc[0:1]), st)
+            lib.call('gv_lincomb4', ptr(g), mmd_w, None, 0.0, None, 0.0, None, 0.0, ptr(gsc[1:2]), st)
+        # branch 1: KL backward (writes gz, gm, gv, gzp), then the regulariser folded into gz
+        with fork(1):
+            s1 = lib.stream()
+            if kl_w > 0:
+                lib.call('gv_kl_bwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(resp), ptr(gsc[0:1]), ptr(gz),
+                         ptr(gm), ptr(gv), ptr(gzp), ptr(wsk), n, h, k, s1)
+                lib.call('gv_axpby', z.numel(), ptr(g), 2.0 * reg_w / z.numel(), ptr(z), 1.0, ptr(gz), s1)
+            else:
+                lib.call('gv_axpby', z.numel(), ptr(g), 2.0 * reg_w / z.numel(), ptr(z), 0.0, ptr(gz), s1)
+        # branch 2: MMD backward
+        if mmd_w > 0:
+            with fork(2):
+                lib.call('gv_mmd_bwd', ptr(z_pri), ptr(z_post), z_pri.shape[0], z_post.shape[0], h, ptr(gsc[1:2]),
+                         ptr(g_pri), ptr(g_post), lib.stream())
+        # main: dL/dscore, then the relation-side gradient (does not need gz)
+        lib.call('gv_bce_grad', ptr(score), ptr(labels), ptr(g), ptr(dscore), ptr(dbias), ptr(ws), T, st)
+        bdd_grad_weight(tidx.rel, tidx.rel_s, tidx.rel_o, dscore, tidx.rel_tid, z, z, h, 1, 1, out=g_w,
+                        accumulate=d_w is not None)
+        lib.call('gv_axpby', w_rel.numel(), ptr(g), 2.0 * reg_w / w_rel.numel(), ptr(w_rel), 1.0, ptr(g_w), st)
+        join(1, 2)
+        if mmd_w > 0:
             lib.call('gv_scatter_add_rows', ptr(g_post), ptr(pick), ptr(gz), pick.numel(), h, st)
         g_z = bdd_aggregate(tidx.inc, tidx.inc_other, tidx.inc_rel, dscore, tidx.inc_tid, z, w_rel, h, 1, 1,
                             addend=gz)
-        d_w = ctx.direct_w
-        g_w = bdd_grad_weight(tidx.rel, tidx.rel_s, tidx.rel_o, dscore, tidx.rel_tid, z, z, h, 1, 1, out=d_w,
-                              accumulate=d_w is not None)
-        lib.call('gv_axpby', w_rel.numel(), ptr(g), 2.0 * reg_w / w_rel.numel(), ptr(w_rel), 1.0, ptr(g_w), st)
-        if d_w is not None:
-            g_w = None
-        g_flp = None
-        if has_bias or flp_in_kl:
-            g_flp = torch.empty((), **f32)
+        if g_flp is not None:
             lib.call('gv_lincomb4', ptr(dbias) if has_bias else None, 1.0, ptr(g) if flp_in_kl else None, kl_w, None, 0.0,
                      None, 0.0, ptr(g_flp), st)
-        return (g_z, gm, gv, g_w, gzp, g_flp, g_pri, None, None, None, None, None, None, None)
+        return (g_z, gm, gv, (None if d_w is not None else g_w), gzp, g_flp, g_pri, None, None, None, None, None, None,
+                None)
 
 
 def loss_head(z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, reg_w, kl_w, mmd_w, score_bias):
