@@ -37,6 +37,7 @@ struct AggParams {
     int out_dim;
     int nb;
     int p, q;  // runtime block sizes (generic kernel)
+    int nbp;   // blocks per column part (fast kernels: grid.y parts of nbp blocks each, nbp/BPL <= 64 lanes)
 };
 
 __device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -69,9 +70,10 @@ __global__ __launch_bounds__(256) void k_agg_fast(const AggParams a) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (wave >= a.n_items) return;
     const int4 it = a.items[wave];
-    const bool active = lane * BPL < a.nb;
-    const float* __restrict__ fbase = a.feat + lane * GV;
-    const float* __restrict__ wbase = a.w + lane * WV;
+    const bool active = lane * BPL < a.nbp;
+    const int blk0 = blockIdx.y * a.nbp + lane * BPL;       // first diagonal block this lane owns
+    const float* __restrict__ fbase = a.feat + blk0 * P;
+    const float* __restrict__ wbase = a.w + blk0 * (P * Q);
 
     float acc[PV];
 #pragma unroll
@@ -117,24 +119,25 @@ __global__ __launch_bounds__(256) void k_agg_fast(const AggParams a) {
         }
     }
     if (!active) return;
+    const int col0 = blk0 * Q;
     if (it.w >= 0) {
-        store_vec<PV>(a.partial + (size_t)it.w * a.out_dim + lane * PV, acc);
+        store_vec<PV>(a.partial + (size_t)it.w * a.out_dim + col0, acc);
         return;
     }
     if (a.addend) {
         float ad[PV];
-        load_vec<PV>(a.addend + (size_t)it.x * a.ld_add + lane * PV, ad);
+        load_vec<PV>(a.addend + (size_t)it.x * a.ld_add + col0, ad);
 #pragma unroll
         for (int i = 0; i < PV; ++i) acc[i] += ad[i];
     }
 #pragma unroll
     for (int i = 0; i < PV; ++i) acc[i] = apply_act(acc[i], a.act);
     if (a.keep) {
-        const uint8_t* kp = a.keep + (size_t)it.x * a.out_dim + lane * PV;
+        const uint8_t* kp = a.keep + (size_t)it.x * a.out_dim + col0;
 #pragma unroll
         for (int i = 0; i < PV; ++i) acc[i] = kp[i] ? acc[i] * a.keep_scale : 0.f;
     }
-    store_vec<PV>(a.out + (size_t)it.x * a.ld_out + lane * PV, acc);
+    store_vec<PV>(a.out + (size_t)it.x * a.ld_out + col0, acc);
 }
 
 // ---- lane-packed weight variant -------------------------------------------------------------------
@@ -367,6 +370,7 @@ struct GradWParams {
     int accumulate;
     int nb;
     int p, q;
+    int nbp;
 };
 
 template <int P, int Q, int BPL, int U>
@@ -376,9 +380,10 @@ __global__ __launch_bounds__(256) void k_gradw_fast(const GradWParams a) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (wave >= a.n_items) return;
     const int4 it = a.items[wave];
-    const bool active = lane * BPL < a.nb;
-    const float* __restrict__ xbase = a.x + lane * GV;
-    const float* __restrict__ gbase = a.g + lane * PV;
+    const bool active = lane * BPL < a.nbp;
+    const int blk0 = blockIdx.y * a.nbp + lane * BPL;
+    const float* __restrict__ xbase = a.x + blk0 * P;
+    const float* __restrict__ gbase = a.g + blk0 * Q;
     float acc[WV];
 #pragma unroll
     for (int i = 0; i < WV; ++i) acc[i] = 0.f;
@@ -440,9 +445,9 @@ __global__ __launch_bounds__(256) void k_gradw_fast(const GradWParams a) {
     }
     if (!active) return;
     if (it.w >= 0) {
-        store_vec<WV>(a.partial + (size_t)it.w * a.w_row + lane * WV, acc);
+        store_vec<WV>(a.partial + (size_t)it.w * a.w_row + blk0 * (P * Q), acc);
     } else {
-        float* o = a.grad_w + (size_t)it.x * a.w_row + lane * WV;
+        float* o = a.grad_w + (size_t)it.x * a.w_row + blk0 * (P * Q);
         if (a.accumulate) {
             float old[WV];
             load_vec<WV>(o, old);
@@ -533,10 +538,10 @@ __global__ void k_items_fill(const int* rowptr, int n_seg, int chunk, const int*
 }
 
 template <typename K, typename Pm>
-static int launch_items(K kern, const Pm& p, int n_items, hipStream_t st, const char* what) {
+static int launch_items(K kern, const Pm& p, int n_items, hipStream_t st, const char* what, int parts = 1) {
     if (n_items <= 0) return GV_OK;
     const int waves_per_block = 4;
-    dim3 grid((n_items + waves_per_block - 1) / waves_per_block), block(64 * waves_per_block);
+    dim3 grid((n_items + waves_per_block - 1) / waves_per_block, parts), block(64 * waves_per_block);
     hipLaunchKernelGGL(kern, grid, block, 0, st, p);
     return launch_status(what);
 }
@@ -567,15 +572,33 @@ extern "C" int gv_segment_items_fill(const int32_t* rowptr, int n_seg, int chunk
 }
 
 namespace {
-// Blocks per lane: aim for a 16-B gather per lane (BPL*P == 4), then 32 B, then narrower, under the
-// constraints that lanes own whole blocks and one 64-lane wave covers the row.  0 => generic kernel.
-int pick_bpl(int nb, int p) {
-    for (int target : {4, 8, 2, 1}) {
-        if (target % p != 0) continue;
-        const int bpl = target / p;
-        if ((bpl == 1 || bpl == 2 || bpl == 4) && nb % bpl == 0 && nb / bpl <= 64) return bpl;
+// Lane mapping of the register kernels: BPL adjacent blocks per lane (so that a lane gathers 16 B where the block
+// size allows: P=1 -> 4 blocks, P=2 -> 2, P=4 -> 1..2; odd sizes P=5 -> 2 blocks = 40 B as five 8-B loads,
+// P=10 -> 1 block = 40 B) and `parts` column parts (grid.y) when the row needs more than 64 lanes.
+// Returns false when no such mapping exists -> generic kernel.
+struct LanePlan { int bpl; int parts; };
+bool lane_plan(int nb, int p, LanePlan* out) {
+    int cands[3] = {0, 0, 0};
+    switch (p) {
+        case 1: cands[0] = 4; cands[1] = 2; break;
+        case 2: cands[0] = 2; cands[1] = 4; cands[2] = 1; break;
+        case 4: cands[0] = 1; cands[1] = 2; break;
+        case 8: cands[0] = 1; break;
+        case 5: cands[0] = 2; break;
+        case 10: cands[0] = 1; break;
+        default: return false;
     }
-    return 0;
+    for (int c = 0; c < 3 && cands[c]; ++c) {
+        const int bpl = cands[c];
+        if (nb % bpl) continue;
+        const int lanes = nb / bpl;
+        for (int parts = 1; parts <= 16; ++parts) {
+            if (lanes % parts) continue;
+            const int per = lanes / parts;
+            if (per <= 64 && (per >= 16 || parts == 1)) { out->bpl = bpl; out->parts = parts; return true; }
+        }
+    }
+    return false;
 }
 }  // namespace
 
@@ -647,6 +670,8 @@ extern "C" int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const in
     a.keep_scale = keep_scale; a.out = out; a.ld_out = ld_out; a.partial = partial;
     a.out_dim = num_bases * blk_out; a.nb = num_bases; a.p = blk_in; a.q = blk_out;
     hipStream_t st = (hipStream_t)stream;
+    // vector paths: 16-B accesses need every row base 16-B aligned (ld % 4); the odd block sizes (5, 10) only
+    // issue 8-B accesses, for which ld % 2 suffices -- h = 500, 1000 satisfy both
     const bool vec_ok = aligned16(feat) && aligned16(weight) && aligned16(out) && (ld_feat % 4 == 0) &&
                         (ld_out % 4 == 0) && (!addend || (aligned16(addend) && ld_addend % 4 == 0)) &&
                         (!partial || aligned16(partial)) && (a.out_dim % 4 == 0) && (a.w_row % 4 == 0);
@@ -678,15 +703,18 @@ extern "C" int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const in
         GV_PK_CASE(8, 4, true, 1, 0, 2) GV_PK_CASE(8, 4, true, 2, 0, 2)
 #undef GV_PK_CASE
     }
-    const int bpl = pick_bpl(num_bases, blk_in);
+    LanePlan lp{0, 1};
+    const bool has_plan = lane_plan(num_bases, blk_in, &lp);
+    const int bpl = has_plan ? lp.bpl : 0;
+    a.nbp = has_plan ? num_bases / lp.parts : num_bases;
 #define GV_AGG_CASE(P_, Q_, T_, B_, U_)                                                               \
     if (rc == -1000 && vec_ok && blk_in == P_ && blk_out == Q_ && (transpose_w != 0) == T_ && bpl == B_) \
-        rc = launch_items(k_agg_fast<P_, Q_, T_, B_, U_>, a, n_items, st, "gv_rgcn_bdd_aggregate");
+        rc = launch_items(k_agg_fast<P_, Q_, T_, B_, U_>, a, n_items, st, "gv_rgcn_bdd_aggregate", lp.parts);
 #define GV_AGG_U(P_, Q_, T_, B_)                                                                              \
     if (rc == -1000 && u_env && vec_ok && blk_in == P_ && blk_out == Q_ && (transpose_w != 0) == T_ && bpl == B_) { \
-        if (u_env == 2) rc = launch_items(k_agg_fast<P_, Q_, T_, B_, 2>, a, n_items, st, "agg(U2)");                    \
-        if (u_env == 4) rc = launch_items(k_agg_fast<P_, Q_, T_, B_, 4>, a, n_items, st, "agg(U4)");                    \
-        if (u_env == 8) rc = launch_items(k_agg_fast<P_, Q_, T_, B_, 8>, a, n_items, st, "agg(U8)");                    \
+        if (u_env == 2) rc = launch_items(k_agg_fast<P_, Q_, T_, B_, 2>, a, n_items, st, "agg(U2)", lp.parts);          \
+        if (u_env == 4) rc = launch_items(k_agg_fast<P_, Q_, T_, B_, 4>, a, n_items, st, "agg(U4)", lp.parts);          \
+        if (u_env == 8) rc = launch_items(k_agg_fast<P_, Q_, T_, B_, 8>, a, n_items, st, "agg(U8)", lp.parts);          \
     }
     GV_AGG_U(2, 2, false, 2) GV_AGG_U(2, 4, false, 2) GV_AGG_U(2, 2, true, 2) GV_AGG_U(4, 2, true, 2)
 #undef GV_AGG_U
@@ -706,6 +734,12 @@ extern "C" int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const in
     GV_AGG_CASE(4, 4, true, 1, 4)
     GV_AGG_CASE(4, 4, true, 2, 2)
     GV_AGG_CASE(8, 4, true, 1, 2)
+    GV_AGG_CASE(5, 5, false, 2, 2)
+    GV_AGG_CASE(5, 10, false, 2, 1)
+    GV_AGG_CASE(5, 5, true, 2, 2)
+    GV_AGG_CASE(10, 5, true, 1, 2)
+    GV_AGG_CASE(10, 10, false, 1, 1)
+    GV_AGG_CASE(10, 10, true, 1, 1)
 #undef GV_AGG_CASE
     if (rc == -1000) {
         if (transpose_w)
@@ -755,10 +789,13 @@ extern "C" int gv_rgcn_bdd_grad_weight(const int32_t* items, int n_items, const 
     const bool vec_ok = aligned16(x) && aligned16(g) && aligned16(grad_w) && (ld_x % 4 == 0) && (ld_g % 4 == 0) &&
                         (!partial || aligned16(partial)) && (a.w_row % 4 == 0);
     int rc = -1000;
-    const int bpl = pick_bpl(num_bases, blk_in);
+    LanePlan lp{0, 1};
+    const bool has_plan = lane_plan(num_bases, blk_in, &lp);
+    const int bpl = has_plan ? lp.bpl : 0;
+    a.nbp = has_plan ? num_bases / lp.parts : num_bases;
 #define GV_GW_CASE(P_, Q_, B_, U_)                                                  \
     if (rc == -1000 && vec_ok && blk_in == P_ && blk_out == Q_ && bpl == B_)        \
-        rc = launch_items(k_gradw_fast<P_, Q_, B_, U_>, a, n_items, st, "gv_rgcn_bdd_grad_weight");
+        rc = launch_items(k_gradw_fast<P_, Q_, B_, U_>, a, n_items, st, "gv_rgcn_bdd_grad_weight", lp.parts);
     GV_GW_CASE(1, 1, 4, 8)
     GV_GW_CASE(1, 2, 4, 4)
     GV_GW_CASE(2, 2, 2, 8)
@@ -767,6 +804,9 @@ extern "C" int gv_rgcn_bdd_grad_weight(const int32_t* items, int n_items, const 
     GV_GW_CASE(4, 4, 2, 2)
     GV_GW_CASE(4, 8, 1, 2)
     GV_GW_CASE(4, 8, 2, 2)
+    GV_GW_CASE(5, 5, 2, 2)
+    GV_GW_CASE(5, 10, 2, 1)
+    GV_GW_CASE(10, 10, 1, 1)
 #undef GV_GW_CASE
     if (rc == -1000) rc = launch_items(k_gradw_generic, a, n_items, st, "gv_rgcn_bdd_grad_weight(generic)");
     if (rc != GV_OK) return rc;

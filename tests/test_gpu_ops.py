@@ -72,6 +72,7 @@ CASES = [  # (in, out, num_bases)  -> block sizes; covers the fast instantiation
     (30, 30, 6), (30, 60, 6),           # 5x5, 5x10 -> generic
     (200, 200, 20),                     # C3 10x10 -> generic
     (24, 12, 3),                        # 8x4 -> generic (non-transposed), bwd-x 4x8
+    (500, 500, 100), (500, 1000, 100),  # C4 / the reference's default --n-hidden 500: 5x5, 5x10, two column parts
 ]
 
 
@@ -204,9 +205,10 @@ def test_reparam(ops):
     close(hg.grad, ho.grad)
 
 
-def test_distmult_bce_and_score(ops):
+@pytest.mark.parametrize('h', [200, 500, 36])      # 500: 1x1 blocks over several column parts; 36: generic sizes
+def test_distmult_bce_and_score(ops, h):
     gen = torch.Generator().manual_seed(2)
-    n, r, h, T = 400, 9, 200, 5000
+    n, r, T = 400, 9, 5000
     emb = torch.randn(n, h, generator=gen) * 0.3
     w = torch.randn(r, h, generator=gen) * 0.3
     rs = np.random.RandomState(0)

@@ -13,9 +13,30 @@ from gcn_vae_amd import ops  # noqa: E402
 
 
 def timeit(fn, iters=50, warm=5):
+    """GPU time per launch: the launches are captured into one hipGraph and replayed, so host-side launch
+    cost (python + ctypes, ~10-15 us per call) cannot floor the figure."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    if os.environ.get('MB_GRAPH', '1') == '1':
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(3):
+            g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / (3 * iters) * 1e3
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters):
