@@ -27,6 +27,7 @@ struct GemmParams {
     const float* b;
     float* c;
     const float* bias;
+    const float* a_mask;   // optional, same layout as A: A is read as (a_mask > 0 ? A : 0)  (ReLU backward folded in)
     float* ws;
     int m, n, k, lda, ldb, ldc;
     int act, accumulate, split_k, k_chunk;
@@ -50,6 +51,15 @@ __device__ __forceinline__ void load_run(const float* src, int pos, int lim, boo
     }
 }
 
+// the same run of the mask matrix zeroes the entries whose mask value is not positive
+template <int VPT>
+__device__ __forceinline__ void mask_run(const float* msk, int pos, int lim, bool ok, bool vec, float (&r)[VPT]) {
+    float mv[VPT];
+    load_run<VPT>(msk, pos, lim, ok, vec, mv, 0);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) r[i] = mv[i] > 0.f ? r[i] : 0.f;
+}
+
 // ---- global -> registers: BM*BK/256 floats of A and BN*BK/256 floats of B per thread, zero outside the matrix
 template <bool TA, int BM, int BK>
 __device__ __forceinline__ void load_a(const GemmParams& p, int m0, int k0, int kend, float (&r)[BM * BK / 256]) {
@@ -59,10 +69,12 @@ __device__ __forceinline__ void load_a(const GemmParams& p, int m0, int k0, int 
         constexpr int TPR = BK / APT;
         const int m = m0 + t / TPR, kk = k0 + (t % TPR) * APT;
         load_run<APT>(p.a + (size_t)m * p.lda + kk, kk, kend, m < p.m, p.vec_a, r, 0);
+        if (p.a_mask) mask_run<APT>(p.a_mask + (size_t)m * p.lda + kk, kk, kend, m < p.m, p.vec_a, r);
     } else {                           // A is stored [K, M], M contiguous: BM/APT threads per k
         constexpr int TPK = BM / APT;
         const int kq = k0 + t / TPK, m = m0 + (t % TPK) * APT;
         load_run<APT>(p.a + (size_t)kq * p.lda + m, m, p.m, kq < kend, p.vec_a, r, 0);
+        if (p.a_mask) mask_run<APT>(p.a_mask + (size_t)kq * p.lda + m, m, p.m, kq < kend, p.vec_a, r);
     }
 }
 
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(256) void k_gemm_splitk_reduce(const GemmParams p) 
 // (4 loads in flight per lane), combine through LDS in wave order; a second kernel sums the slices in order.
 constexpr int COLSUM_SLICES = 64;
 
-__global__ __launch_bounds__(256) void k_colsum_part(const float* x, int64_t m, int n, int ld, float* part) {
+__global__ __launch_bounds__(256) void k_colsum_part(const float* x, const float* msk, int64_t m, int n, int ld, float* part) {
     __shared__ float sm[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -204,11 +216,20 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* x, int64_t m, 
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (c < n) {
         int64_t r = r0 + w;
-        for (; r + 12 < r1; r += 16) {
-            const float v0 = x[r * ld + c], v1 = x[(r + 4) * ld + c], v2 = x[(r + 8) * ld + c], v3 = x[(r + 12) * ld + c];
-            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        if (msk) {
+            for (; r + 12 < r1; r += 16) {
+                const float v0 = x[r * ld + c], v1 = x[(r + 4) * ld + c], v2 = x[(r + 8) * ld + c], v3 = x[(r + 12) * ld + c];
+                const float m0 = msk[r * ld + c], m1 = msk[(r + 4) * ld + c], m2 = msk[(r + 8) * ld + c], m3 = msk[(r + 12) * ld + c];
+                a0 += m0 > 0.f ? v0 : 0.f; a1 += m1 > 0.f ? v1 : 0.f; a2 += m2 > 0.f ? v2 : 0.f; a3 += m3 > 0.f ? v3 : 0.f;
+            }
+            for (; r < r1; r += 4) a0 += msk[r * ld + c] > 0.f ? x[r * ld + c] : 0.f;
+        } else {
+            for (; r + 12 < r1; r += 16) {
+                const float v0 = x[r * ld + c], v1 = x[(r + 4) * ld + c], v2 = x[(r + 8) * ld + c], v3 = x[(r + 12) * ld + c];
+                a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+            }
+            for (; r < r1; r += 4) a0 += x[r * ld + c];
         }
-        for (; r < r1; r += 4) a0 += x[r * ld + c];
     }
     sm[w][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
@@ -246,7 +267,7 @@ extern "C" int64_t gv_gemm_workspace_bytes(int m, int n, int k, int split_k) {
 
 extern "C" int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b,
                            int ldb, float* c, int ldc, const float* bias, int act, int accumulate, int split_k,
-                           void* workspace, int64_t workspace_bytes, void* stream) {
+                           const float* a_relu_mask, void* workspace, int64_t workspace_bytes, void* stream) {
     GV_REQUIRE(m >= 0 && n >= 0 && k >= 0, GV_ERR_SHAPE, "gv_gemm_f32: negative size");
     if (m == 0 || n == 0) return GV_OK;
     GV_REQUIRE(a && b && c, GV_ERR_NULL, "gv_gemm_f32: NULL matrix");
@@ -256,13 +277,13 @@ extern "C" int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const 
     if (split_k < 1) split_k = 1;
     if (k == 0) split_k = 1;
     GemmParams p;
-    p.a = a; p.b = b; p.c = c; p.bias = bias; p.ws = (float*)workspace;
+    p.a = a; p.b = b; p.c = c; p.bias = bias; p.a_mask = a_relu_mask; p.ws = (float*)workspace;
     p.m = m; p.n = n; p.k = k; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.act = act; p.accumulate = accumulate;
     p.k_chunk = k_chunk_for(k > 0 ? k : 1, split_k);
     split_k = k > 0 ? (k + p.k_chunk - 1) / p.k_chunk : 1;
     p.split_k = split_k;
-    p.vec_a = aligned16(a) && (lda % 4 == 0);
+    p.vec_a = aligned16(a) && (lda % 4 == 0) && (!a_relu_mask || aligned16(a_relu_mask));
     p.vec_b = aligned16(b) && (ldb % 4 == 0);
     if (split_k > 1) {
         GV_REQUIRE(workspace, GV_ERR_NULL, "gv_gemm_f32: split_k needs a workspace");
@@ -304,13 +325,13 @@ extern "C" int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const 
     return GV_OK;
 }
 
-extern "C" int gv_colsum(const float* x, int64_t m, int n, int ld, float* out, float* workspace, int accumulate,
-                         void* stream) {
+extern "C" int gv_colsum(const float* x, const float* relu_mask, int64_t m, int n, int ld, float* out, float* workspace,
+                         int accumulate, void* stream) {
     GV_REQUIRE(x && out && workspace, GV_ERR_NULL, "gv_colsum: NULL pointer");
     GV_REQUIRE(m >= 0 && n > 0 && ld >= n, GV_ERR_SHAPE, "gv_colsum: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    const int nsl = COLSUM_SLICES;
-    hipLaunchKernelGGL(k_colsum_part, dim3((n + 63) / 64, nsl), dim3(256), 0, st, x, m, n, ld, workspace);
+    const int nsl = COLSUM_SLICES;     // workspace is sized for 64 slices
+    hipLaunchKernelGGL(k_colsum_part, dim3((n + 63) / 64, nsl), dim3(256), 0, st, x, relu_mask, m, n, ld, workspace);
     hipLaunchKernelGGL(k_colsum_final, dim3((n + 63) / 64), dim3(64), 0, st, workspace, n, nsl, out, accumulate);
     return launch_status("gv_colsum");
 }

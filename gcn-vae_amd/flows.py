@@ -65,8 +65,14 @@ class MADE(nn.Module):
         return x
 
     def forward(self, z):
+        lin = self._linears()
+        weights = [l.masked_weight() for l in lin]                 # mask folded once per call, not per pass
+        return ops.made_forward(z, self._colcount, weights, [l.bias for l in lin])
+
+    def forward_unfused(self, z):
+        """The same computation as a chain of per-op autograd nodes (kept for cross-checking the fused node)."""
         d = self.input_size
-        weights = [l.masked_weight() for l in self._linears()]     # mask folded once per call, not per pass
+        weights = [l.masked_weight() for l in self._linears()]
         x = torch.zeros_like(z)
         net_out = None
         for p in range(len(self.m)):

@@ -27,8 +27,8 @@ SIGNATURES = {
     'gv_rgcn_epilogue_fwd': (_I, [_P, _P, _I, _P, _F, _P, _L, _I, _P]),
     'gv_rgcn_epilogue_bwd': (_I, [_P, _P, _I, _P, _F, _P, _L, _I, _P]),
     'gv_gemm_workspace_bytes': (_L, [_I, _I, _I, _I]),
-    'gv_gemm_f32': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _L, _P]),
-    'gv_colsum': (_I, [_P, _L, _I, _I, _P, _P, _I, _P]),
+    'gv_gemm_f32': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P]),
+    'gv_colsum': (_I, [_P, _P, _L, _I, _I, _P, _P, _I, _P]),
     'gv_gather_rows': (_I, [_P, _P, _P, _L, _I, _P]),
     'gv_scatter_add_rows': (_I, [_P, _P, _P, _L, _I, _P]),
     'gv_reparam_fwd': (_I, [_P, _P, _P, _P, _L, _I, _P]),

@@ -310,8 +310,9 @@ def bdd_grad_weight(seg: SegmentItems, src, dst, coef, coef_idx, x, g, num_bases
     return out
 
 
-def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, accumulate=False, split_k=1):
-    """out = act(op(a) @ op(b) + bias) (+ out)."""
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, accumulate=False, split_k=1,
+         a_relu_mask=None):
+    """out = act(op(a') @ op(b) + bias) (+ out);  a' = a * [a_relu_mask > 0] when a mask (same layout as a) is given."""
     a, lda = _row_major(a, 'a')
     b, ldb = _row_major(b, 'b')
     m, k = (a.shape[1], a.shape[0]) if trans_a else a.shape
@@ -327,9 +328,13 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, 
     if split_k > 1:
         ws_bytes = int(lib.load().gv_gemm_workspace_bytes(m, n, k, split_k))
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=a.device)
+    if a_relu_mask is not None:
+        a_relu_mask, ld_mask = _row_major(a_relu_mask, 'a_relu_mask')
+        if tuple(a_relu_mask.shape) != tuple(a.shape) or ld_mask != lda:
+            raise ValueError('a_relu_mask must have the shape and leading dimension of a')
     lib.call('gv_gemm_f32', 1 if trans_a else 0, 1 if trans_b else 0, m, n, k, ptr(a), lda, ptr(b), ldb, ptr(out),
-             out.stride(0) if m > 1 else n, ptr(bias), act, 1 if accumulate else 0, split_k, ptr(ws), ws_bytes,
-             lib.stream())
+             out.stride(0) if m > 1 else n, ptr(bias), act, 1 if accumulate else 0, split_k, ptr(a_relu_mask), ptr(ws),
+             ws_bytes, lib.stream())
     return out
 
 
@@ -341,14 +346,18 @@ def pick_split_k(m_out, n_out, k):
     return max(1, min(64, 512 // tiles, k // 256))
 
 
-def colsum(x, out=None, accumulate=False):
+def colsum(x, out=None, accumulate=False, relu_mask=None):
     x, ld = _row_major(x, 'x')
+    if relu_mask is not None:
+        relu_mask, ldm = _row_major(relu_mask, 'relu_mask')
+        if tuple(relu_mask.shape) != tuple(x.shape) or ldm != ld:
+            raise ValueError('relu_mask must have the shape and leading dimension of x')
     m, n = x.shape
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=x.device)
         accumulate = False
     ws = torch.empty(64 * n, dtype=torch.float32, device=x.device)
-    lib.call('gv_colsum', ptr(x), m, n, ld, ptr(out), ptr(ws), 1 if accumulate else 0, lib.stream())
+    lib.call('gv_colsum', ptr(x), ptr(relu_mask), m, n, ld, ptr(out), ptr(ws), 1 if accumulate else 0, lib.stream())
     return out
 
 
@@ -996,3 +1005,97 @@ class _LossHead(torch.autograd.Function):
 def loss_head(z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, reg_w, kl_w, mmd_w, score_bias):
     return _LossHead.apply(z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, float(reg_w), float(kl_w),
                            float(mmd_w), bool(score_bias))
+
+
+class _MADEForward(torch.autograd.Function):
+    """MADE.forward (kgvae/flow_network.py:85-98) as ONE autograd node.
+
+    The reference runs ``len(self.m)`` (= n_hidden + 3) sequential passes of the masked MLP, each followed by
+    ``x[:, i] = z[:, i] * exp(alpha[:, i] + mu[:, i])``.  Here every pass writes its layer activations into row
+    slices of per-layer buffers stacked over the passes, so the backward
+      * walks the passes in reverse with one NN GEMM per layer whose A operand is read through the ReLU mask of the
+        stored activation (no separate masking kernels, no materialised masked gradient), and
+      * forms each layer's weight gradient ONCE, as a single split-K product over all passes' rows (K = passes x N)
+        -- the reference's autograd does it per pass and sums.
+    Inputs: z (N, D); masked weights W_l (out_l, in_l) and biases, l = 0..L-1 (last layer: 2D outputs [mu | alpha]);
+    colcount int32 (passes, D).  Outputs: x (N, D), log_det (N,) = sum_d alpha of the last pass.
+    """
+
+    @staticmethod
+    def forward(ctx, z, colcount, *wb):
+        L = len(wb) // 2
+        ws, bs = wb[:L], wb[L:]
+        z = _chk(z.contiguous(), name='z')
+        n, d = z.shape
+        P = colcount.shape[0]
+        dev = z.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        st = lib.stream()
+        xin = torch.empty(P * n, d, **f32)                       # input of every pass (pass 0: zeros)
+        xin[:n].zero_()
+        acts = [torch.empty(P * n, ws[l].shape[0], **f32) for l in range(L)]   # acts[L-1] = net outputs [mu | alpha]
+        x_out = torch.empty(n, d, **f32)
+        for p in range(P):
+            inp = xin[p * n:(p + 1) * n]
+            for l in range(L):
+                out = acts[l][p * n:(p + 1) * n]
+                gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE, out=out)
+                inp = out
+            nxt = xin[(p + 1) * n:(p + 2) * n] if p + 1 < P else x_out
+            lib.call('gv_iaf_update_fwd', ptr(z), ptr(inp), ptr(xin[p * n:(p + 1) * n]), ptr(colcount[p]), ptr(nxt), n, d, st)
+        log_det = torch.empty(n, **f32)
+        last = acts[L - 1][(P - 1) * n:]
+        lib.call('gv_rowsum', ptr(last), 2 * d, d, d, ptr(log_det), n, st)
+        ctx.save_for_backward(z, colcount, xin, *acts, *ws)
+        ctx.L = L
+        ctx.has_bias = [b is not None for b in bs]
+        return x_out, log_det
+
+    @staticmethod
+    def backward(ctx, gx, gld):
+        L = ctx.L
+        saved = ctx.saved_tensors
+        z, colcount, xin = saved[0], saved[1], saved[2]
+        acts, ws = saved[3:3 + L], saved[3 + L:3 + 2 * L]
+        n, d = z.shape
+        P = colcount.shape[0]
+        dev = z.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        st = lib.stream()
+        gx = torch.zeros(n, d, **f32) if gx is None else _chk(gx.contiguous(), name='gx')
+        gld = None if gld is None else _chk(gld.contiguous(), name='gld')
+        grads = [torch.empty(P * n, ws[l].shape[0], **f32) for l in range(L)]   # grad w.r.t. each layer's OUTPUT
+        g_z = torch.zeros(n, d, **f32)
+        gz_p = torch.empty(n, d, **f32)
+        g_cur = gx
+        for p in reversed(range(P)):
+            sl = slice(p * n, (p + 1) * n)
+            g_old = torch.empty(n, d, **f32)
+            lib.call('gv_iaf_update_bwd', ptr(z), ptr(acts[L - 1][sl]), ptr(colcount[p]), ptr(g_cur),
+                     ptr(gld) if p == P - 1 else None, ptr(gz_p), ptr(grads[L - 1][sl]), ptr(g_old), n, d, st)
+            lib.call('gv_axpby', n * d, None, 1.0, ptr(gz_p), 1.0, ptr(g_z), st)
+            for l in reversed(range(L)):
+                mask = acts[l][sl] if l < L - 1 else None
+                if l > 0:
+                    gemm(grads[l][sl], ws[l], out=grads[l - 1][sl], a_relu_mask=mask)
+                else:       # gradient w.r.t. the pass's input x_p joins the update's pass-through gradient
+                    gemm(grads[0][sl], ws[0], out=g_old, accumulate=True, a_relu_mask=mask)
+            g_cur = g_old
+        g_ws, g_bs = [], []
+        for l in range(L):
+            inp = xin if l == 0 else acts[l - 1]
+            mask = acts[l] if l < L - 1 else None
+            if ctx.needs_input_grad[2 + l]:
+                g_ws.append(gemm(grads[l], inp, trans_a=True, a_relu_mask=mask,
+                                 split_k=pick_split_k(ws[l].shape[0], ws[l].shape[1], P * n)))
+            else:
+                g_ws.append(None)
+            if ctx.has_bias[l] and ctx.needs_input_grad[2 + L + l]:
+                g_bs.append(colsum(grads[l], relu_mask=mask))
+            else:
+                g_bs.append(None)
+        return (g_z, None, *g_ws, *g_bs)
+
+
+def made_forward(z, colcount, weights, biases):
+    return _MADEForward.apply(z, colcount, *weights, *biases)

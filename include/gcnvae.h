@@ -114,11 +114,14 @@ int gv_rgcn_epilogue_bwd(const float* out, const float* grad_out, int act, const
  */
 int64_t gv_gemm_workspace_bytes(int m, int n, int k, int split_k);
 int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b, int ldb,
-                float* c, int ldc, const float* bias, int act, int accumulate, int split_k, void* workspace,
-                int64_t workspace_bytes, void* stream);
+                float* c, int ldc, const float* bias, int act, int accumulate, int split_k, const float* a_relu_mask,
+                void* workspace, int64_t workspace_bytes, void* stream);
+/* a_relu_mask (optional, same storage layout and lda as A): A is read as (mask > 0 ? A : 0), i.e. the ReLU backward
+ * g * [h > 0] is folded into the operand load of the two gradient products of a MaskedLinear layer. */
 
-/* column sums of an [m, n] matrix (bias gradients); workspace: 64*n floats. */
-int gv_colsum(const float* x, int64_t m, int n, int ld, float* out, float* workspace, int accumulate, void* stream);
+/* column sums of an [m, n] matrix (bias gradients), optionally of x * [relu_mask > 0]; workspace: 64*n floats. */
+int gv_colsum(const float* x, const float* relu_mask, int64_t m, int n, int ld, float* out, float* workspace,
+              int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Embedding gather / gradient scatter (kgvae/model.py:185-191, nn.Embedding dense backward). */

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_argument_errors_are_reported_not_thrown():
     from gcn_vae_amd import lib
     l = lib.load()
-    rc = l.gv_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, 1, None, 0, None)
+    rc = l.gv_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, 1, None, None, 0, None)
     assert rc == -1 and 'NULL' in lib.last_error()
     rc = l.gv_segment_items_count(None, 3, 0, None, None, None, None)
     assert rc < 0

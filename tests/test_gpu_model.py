@@ -268,3 +268,22 @@ def test_large_graph_properties():
         msg += x1[src][:, b * si + i].double() * wsel[et][:, b, i, j]
     tot = (msg * norm.double().unsqueeze(1)).sum(0)
     close(a1[:, cols].double().sum(0), tot, rtol=1e-4, atol_scale=1e-5, msg='total mass')
+
+
+def test_made_fused_node_equals_op_chain():
+    from gcn_vae_amd.flows import MADE
+    torch.manual_seed(3)
+    m = MADE(40, 56, 2).cuda()
+    z = torch.randn(300, 40, device='cuda')
+    outs = []
+    for fn in (m.forward, m.forward_unfused):
+        m.zero_grad()
+        zz = z.clone().requires_grad_(True)
+        x, ld = fn(zz)
+        (x.sin().sum() + (ld * ld).sum()).backward()
+        outs.append((x, ld, zz.grad, [p.grad.clone() for p in m.parameters()]))
+    close(outs[0][0], outs[1][0], msg='x')
+    close(outs[0][1], outs[1][1], msg='logdet')
+    close(outs[0][2], outs[1][2], rtol=2e-4, atol_scale=2e-5, msg='grad z')
+    for a, b in zip(outs[0][3], outs[1][3]):
+        close(a, b, rtol=2e-4, atol_scale=2e-5, msg='grad param')
