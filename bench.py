@@ -215,7 +215,7 @@ def main():
     enorm, samples, labels = w['enorm'], w['samples'].to(dev), w['labels'].to(dev)
     n_nodes, E, T = w['data'].num_nodes, int(w['src'].numel()), int(samples.shape[0])
     params = [p for p in model.parameters() if p.requires_grad]
-    use_graph = not args.no_graph
+    use_graph = not args.no_graph      # RCCL collectives are captured too (checked with a 1-rank group); on failure: eager
     from gcn_vae_amd.optim import FlatAdam
     opt = FlatAdam(params, lr=1e-3, max_grad_norm=1.0)      # clip_grad_norm_(1.0) + Adam over one flat arena
     if dist_on:

@@ -26,6 +26,7 @@ def _direct(t):
     return tgt if (tgt is not None and tgt.shape == t.shape) else None
 DEFAULT_CHUNK = 256        # max edges per work item of the dst/src-sorted aggregations
 DEFAULT_CHUNK_REL = 128    # max edges per work item of the by-relation weight gradient
+DIST_FWD_CHUNKS = 2        # destination-row blocks whose all-reduce overlaps the next block's aggregation
 
 
 # ------------------------------------------------------------------------------------------------
@@ -174,6 +175,33 @@ class GraphIndex:
         self.by_src = EdgeOrder(perm_s.to(torch.int32),
                                 build_segment_items(_rowptr_from_sorted(src[perm_s], self.num_nodes), chunk))
         self._rel_cache = {}
+        self._chunk_cache = {}
+
+    def dst_chunks(self, n_chunks: int):
+        """Cut the destination rows into ``n_chunks`` contiguous blocks of ~equal edge count and return, per block,
+        (row0, row1, SegmentItems restricted to those rows).  Used by the multi-GPU forward to start the all-reduce
+        of one row block while the next one is still being aggregated.  Cached; synchronises once when built."""
+        hit = self._chunk_cache.get(n_chunks)
+        if hit is not None:
+            return hit
+        seg = self.by_dst.seg
+        rp = seg.rowptr.to(torch.int64)
+        targets = torch.arange(1, n_chunks, device=rp.device, dtype=torch.int64) * (self.num_edges // max(n_chunks, 1))
+        cuts = torch.searchsorted(rp, targets).clamp_(0, self.num_nodes).tolist() if n_chunks > 1 else []
+        rows = [0] + [int(c) for c in cuts] + [self.num_nodes]
+        rows = sorted(set(rows))
+        item_seg = seg.items[:seg.n_items, 0].contiguous().to(torch.int64)
+        fix_seg = seg.fix[:seg.n_fix, 0].contiguous().to(torch.int64)
+        bounds = torch.tensor(rows, device=rp.device, dtype=torch.int64)
+        ib = torch.searchsorted(item_seg, bounds).tolist()
+        fb = torch.searchsorted(fix_seg, bounds).tolist() if seg.n_fix > 0 else [0] * len(rows)
+        out = []
+        for c in range(len(rows) - 1):
+            sub = SegmentItems(seg.items[ib[c]:ib[c + 1]], seg.fix[fb[c]:fb[c + 1]] if seg.n_fix > 0 else seg.fix,
+                               ib[c + 1] - ib[c], fb[c + 1] - fb[c], seg.n_slots, seg.rowptr, seg.chunk)
+            out.append((rows[c], rows[c + 1], sub))
+        self._chunk_cache[n_chunks] = out
+        return out
 
     def relation_index(self, etypes: torch.Tensor, num_rels: int) -> 'RelationIndex':
         key = (etypes.data_ptr(), etypes._version, int(num_rels))
@@ -458,11 +486,17 @@ class _RelGraphConvBdd(torch.autograd.Function):
             out = bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x, w_fwd,
                                 num_bases, si, so, False, self_loop_term(), act, keep, keep_scale, packed=pk)
         else:
-            agg = bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x, w_fwd,
-                                num_bases, si, so, packed=pk)
-            pending = reduce_hook(agg)          # all-reduce of the partial node aggregate ...
-            addend = self_loop_term()           # ... overlapped with the self-loop GEMM
-            pending.wait()
+            # edge-sharded: aggregate the destination rows in DIST_FWD_CHUNKS blocks; the all-reduce of block c runs
+            # on RCCL's stream while block c+1 is aggregated and, at the end, under the self-loop GEMM
+            agg = torch.empty(n, out_feat, dtype=torch.float32, device=x.device)
+            pending = []
+            for r0, r1, sub in gidx.dst_chunks(DIST_FWD_CHUNKS):
+                bdd_aggregate(sub, gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x, w_fwd, num_bases, si, so,
+                              packed=pk, out=agg)
+                pending.append(reduce_hook(agg[r0:r1]))
+            addend = self_loop_term()
+            for h in pending:
+                h.wait()
             out = epilogue_fwd(agg, addend, act, keep, keep_scale)
         ctx.save_for_backward(x, weight, loop_weight, coef, out if act == ACT_RELU else None, keep)
         ctx.meta = (gidx, ridx, num_bases, si, so, act, keep_scale, h_bias is not None, reduce_hook)

@@ -340,3 +340,39 @@ def test_lane_packed_weights_are_bit_identical(ops, fin, fout, nb):
         got = ops.bdd_aggregate(seg, nbr, ety, nrm, perm, feat, ops.pack_weight(w, nb, p, q, tr), nb, p, q, tr, packed=True)
         assert torch.equal(ref, got)
     assert not ops.pack_supported(200, 1, 1, False) and not ops.pack_supported(20, 10, 10, False)
+
+
+def test_edge_shard_code_path_equals_fused_path(ops):
+    """The multi-GPU branch of the layer (chunked raw aggregate -> reduce hook -> separate epilogue; reduce hook on the
+    backward gradient) with a no-op hook must reproduce the single-GPU fused path."""
+    class Done:
+        def wait(self):
+            return None
+    calls = []
+
+    def hook(t):
+        calls.append(tuple(t.shape))
+        return Done()
+    n, e, r, fin, fout, nb = 500, 9000, 120, 200, 400, 100
+    src, dst, et, norm = zipf_graph(n, e, r, seed=11)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(n, fin, generator=gen)
+    p = orgcn.init_params(fin, fout, r, 'bdd', nb, True, True, gen)
+    p['h_bias'] = torch.randn(fout, generator=gen) * 0.1
+    keep = (torch.rand(n, fout, generator=gen) > 0.2).to(torch.uint8).cuda()
+    gout = torch.randn(n, fout, generator=gen).cuda()
+    gidx = ops.GraphIndex(src.cuda(), dst.cuda(), n, chunk=64)
+    ridx = gidx.relation_index(et.cuda(), r)
+    res = []
+    for hk in (None, hook):
+        xg = x.cuda().requires_grad_(True)
+        pg = {k: v.cuda().requires_grad_(True) for k, v in p.items()}
+        h = ops.rel_graph_conv_bdd(xg, pg['weight'], pg['h_bias'], pg['loop_weight'], norm.cuda(), gidx, ridx, nb, 1, keep,
+                                   1.25, hk)
+        h.backward(gout)
+        res.append((h, xg.grad, pg['weight'].grad, pg['h_bias'].grad, pg['loop_weight'].grad))
+    for a, b in zip(*res):
+        close(a, b, rtol=1e-5, atol_scale=1e-6)
+    chunks = gidx.dst_chunks(ops.DIST_FWD_CHUNKS)
+    assert chunks[0][0] == 0 and chunks[-1][1] == n and sum(c[2].n_items for c in chunks) == gidx.by_dst.seg.n_items
+    assert len(calls) == len(chunks) + 1 and calls[-1] == (n, fout)          # forward row blocks + one backward gradient
