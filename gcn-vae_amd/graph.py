@@ -9,25 +9,44 @@ from . import ops
 
 class _EdgeView:
     def __init__(self, g):
-        self.src = {k: v[g._src.to(v.device)] for k, v in g.ndata.items()}
-        self.dst = {k: v[g._dst.to(v.device)] for k, v in g.ndata.items()}
+        src, dst = g.edges()
+        self.src = {k: v[src.to(v.device)] for k, v in g.ndata.items()}
+        self.dst = {k: v[dst.to(v.device)] for k, v in g.ndata.items()}
         self.data = g.edata
 
 
 class KGraph:
     def __init__(self):
         self._n = 0
+        self._dev_edges = None
         self._src = torch.zeros(0, dtype=torch.int64)
         self._dst = torch.zeros(0, dtype=torch.int64)
         self.ndata, self.edata = {}, {}
         self._index = {}
 
     # -- construction ---------------------------------------------------------------------------
+    @classmethod
+    def from_device_edges(cls, num_nodes, src, dst):
+        """Handle over edge lists that already live on a ROCm device (device_sampling.DeviceSampler): the
+        kernels' index is built from them directly; a host copy is made only if ``edges()`` is asked for."""
+        g = cls()
+        g._n = int(num_nodes)
+        g._dev_edges = (src.to(torch.int64), dst.to(torch.int64))
+        g._src = g._dst = None
+        return g
+
+    def _host_edges(self):
+        if self._src is None:
+            self._src, self._dst = (t.cpu() for t in self._dev_edges)
+        return self._src, self._dst
+
     def add_nodes(self, n):
         self._n += int(n)
         self._index.clear()
 
     def add_edges(self, src, dst):
+        self._host_edges() if getattr(self, '_dev_edges', None) is not None else None
+        self._dev_edges = None
         s = torch.as_tensor(np.asarray(src) if not isinstance(src, torch.Tensor) else src, dtype=torch.int64).cpu()
         d = torch.as_tensor(np.asarray(dst) if not isinstance(dst, torch.Tensor) else dst, dtype=torch.int64).cpu()
         if s.shape != d.shape:
@@ -43,16 +62,20 @@ class KGraph:
         return self._n
 
     def number_of_edges(self):
+        if getattr(self, '_dev_edges', None) is not None:
+            return int(self._dev_edges[0].numel())
         return int(self._src.numel())
 
     def __len__(self):
         return self._n
 
     def edges(self):
+        if getattr(self, '_dev_edges', None) is not None:
+            return self._host_edges()
         return self._src, self._dst
 
     def in_degrees(self, nodes=None):
-        deg = torch.bincount(self._dst, minlength=self._n)
+        deg = torch.bincount(self.edges()[1], minlength=self._n)
         if nodes is None:
             return deg
         return deg[torch.as_tensor(list(nodes) if not isinstance(nodes, torch.Tensor) else nodes, dtype=torch.int64)]
@@ -60,6 +83,7 @@ class KGraph:
     def local_var(self):
         g = KGraph()
         g._n, g._src, g._dst = self._n, self._src, self._dst
+        g._dev_edges = getattr(self, '_dev_edges', None)
         g.ndata, g.edata = dict(self.ndata), dict(self.edata)
         g._index = self._index          # the device index depends on (src, dst) only
         return g
@@ -76,7 +100,11 @@ class KGraph:
         key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
         idx = self._index.get(key)
         if idx is None:
-            idx = self._index[key] = ops.GraphIndex(self._src.to(device), self._dst.to(device), self._n)
+            if getattr(self, '_dev_edges', None) is not None:
+                src, dst = (t.to(device) for t in self._dev_edges)
+            else:
+                src, dst = self._src.to(device), self._dst.to(device)
+            idx = self._index[key] = ops.GraphIndex(src, dst, self._n)
         return idx
 
 

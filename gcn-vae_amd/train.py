@@ -130,16 +130,27 @@ def main(args):
         model.load_state_dict(checkpoint['state_dict'])
         epoch = checkpoint['epoch']
 
+    dev_sampler = None
+    if getattr(args, 'device_sampler', False):
+        if args.edge_sampler != 'uniform':
+            raise ValueError("--device-sampler supports --edge-sampler uniform only")
+        from .device_sampling import DeviceSampler
+        dev_sampler = DeviceSampler(train_data, num_nodes, num_rels, dev)
+
     while True:
         model.train()
         epoch += 1
-        g, node_id, edge_type, node_norm, batch, labels = sampling.generate_sampled_graph_and_labels(
-            train_data, args.graph_batch_size, args.graph_split_size, num_rels, adj_list, degrees,
-            args.negative_sample, args.edge_sampler)
-        node_id = torch.from_numpy(node_id).view(-1, 1).long().to(dev)
-        edge_type = torch.from_numpy(edge_type).to(dev)
-        edge_norm = node_norm_to_edge_norm(g, torch.from_numpy(node_norm).view(-1, 1)).to(dev)
-        batch, labels = torch.from_numpy(batch).to(dev), torch.from_numpy(labels).to(dev)
+        if dev_sampler is not None:
+            b = dev_sampler.sample(args.graph_batch_size, args.graph_split_size, args.negative_sample)
+            g, node_id, edge_type, edge_norm, batch, labels = b.g, b.node_id, b.edge_type, b.edge_norm, b.samples, b.labels
+        else:
+            g, node_id, edge_type, node_norm, batch, labels = sampling.generate_sampled_graph_and_labels(
+                train_data, args.graph_batch_size, args.graph_split_size, num_rels, adj_list, degrees,
+                args.negative_sample, args.edge_sampler)
+            node_id = torch.from_numpy(node_id).view(-1, 1).long().to(dev)
+            edge_type = torch.from_numpy(edge_type).to(dev)
+            edge_norm = node_norm_to_edge_norm(g, torch.from_numpy(node_norm).view(-1, 1)).to(dev)
+            batch, labels = torch.from_numpy(batch).to(dev), torch.from_numpy(labels).to(dev)
 
         _sync()
         t0 = time.time()
@@ -206,6 +217,9 @@ def build_parser():
     p.add_argument("--model-class", type=str, default='KGVAE', help="model class")
     p.add_argument("--load", type=bool, default=False, help="whether to load a model state file for training")
     p.add_argument("--generate", type=bool, default=False, help="(reference demo; not supported here)")
+    p.add_argument("--device-sampler", action="store_true",
+                   help="prepare batches on the GPU (uniform sampler, torch's device RNG instead of numpy's: not the "
+                        "reference's random stream, ~10x less host time per step)")
     return p
 
 

@@ -287,3 +287,57 @@ def test_made_fused_node_equals_op_chain():
     close(outs[0][2], outs[1][2], rtol=2e-4, atol_scale=2e-5, msg='grad z')
     for a, b in zip(outs[0][3], outs[1][3]):
         close(a, b, rtol=2e-4, atol_scale=2e-5, msg='grad param')
+
+
+def test_device_sampler_batches_are_well_formed_and_train():
+    """device-side batch preparation.  Not the reference's RNG stream, so the checks are structural:
+    the batch is what generate_sampled_graph_and_labels would build from the same picks."""
+    from gcn_vae_amd.data import synthetic_kg
+    from gcn_vae_amd.device_sampling import DeviceSampler
+    from gcn_vae_amd.encoders import KGVAE
+    from gcn_vae_amd.optim import FlatAdam
+    from gcn_vae_amd.train import LinkPredict
+    data = synthetic_kg(2000, 15, 30000, seed=4)
+    sm = DeviceSampler(data.train, data.num_nodes, data.num_rels, 'cuda', seed=1)
+    b = sm.sample(4000, 0.5, 3)
+    n = len(b.g)
+    src, dst = (t.cuda() for t in b.g.edges())
+    assert b.node_id.shape == (n, 1) and bool((b.node_id[1:] > b.node_id[:-1]).all())           # unique, sorted global ids
+    assert src.numel() == 4000 and b.edge_type.numel() == 4000 and b.edge_norm.shape == (4000, 1)     # 2 x split edges
+    key = (dst * n + src) * 30 + b.edge_type
+    assert bool((key[1:] >= key[:-1]).all())                                                      # (dst, src, rel) order
+    deg = torch.bincount(dst, minlength=n).float()
+    assert torch.equal(b.edge_norm.view(-1), (1.0 / deg)[dst])
+    # forward edges (rel < R) have a mirrored reverse edge with rel + R
+    fwd = b.edge_type < 15
+    a = torch.stack([src[fwd], dst[fwd], b.edge_type[fwd]], 1)
+    r = torch.stack([dst[~fwd], src[~fwd], b.edge_type[~fwd] - 15], 1)
+    assert torch.equal(torch.unique(a, dim=0), torch.unique(r, dim=0))
+    # samples: positives are real triplets (after mapping back), negatives differ from their positive in exactly one end
+    pos, neg = b.samples[:4000], b.samples[4000:]
+    glob = torch.stack([b.node_id.view(-1)[pos[:, 0]], pos[:, 1], b.node_id.view(-1)[pos[:, 2]]], 1)
+    train = torch.from_numpy(data.train).cuda()
+    keyf = lambda t: (t[:, 0] * 2000 + t[:, 2]) * 15 + t[:, 1]
+    assert bool(torch.isin(keyf(glob), keyf(train)).all())
+    rep = pos.repeat(3, 1)
+    same_s, same_o = neg[:, 0] == rep[:, 0], neg[:, 2] == rep[:, 2]
+    assert bool((same_s | same_o).all()) and bool((neg[:, 1] == rep[:, 1]).all())
+    assert 0.35 < float((~same_s).float().mean()) < 0.65
+    assert b.labels.sum().item() == 4000 and b.labels.numel() == 16000
+    # and a few optimisation steps run and reduce the loss
+    torch.manual_seed(0)
+    net = LinkPredict(KGVAE, data.num_nodes, 16, data.num_rels, num_bases=4, num_hidden_layers=2, dropout=0.1, use_cuda=True,
+                      reg_param=0.01, kl_param=1e-5, mmd_param=1.0, k=4, n_flows=1).cuda().train()
+    opt = FlatAdam(net.parameters(), lr=1e-2, max_grad_norm=1.0)
+    losses = []
+    for _ in range(12):
+        bb = sm.sample(4000, 0.5, 3)
+        opt.zero_grad()
+        emb = net(bb.g, bb.node_id, bb.edge_type, bb.edge_norm)
+        loss = net.get_loss(bb.g, emb, bb.samples, bb.labels)[0]
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
+    g, node_id, et, en = sm.full_graph()
+    assert len(g) == 2000 and g.number_of_edges() == 60000 and node_id.shape == (2000, 1)
