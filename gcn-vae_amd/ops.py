@@ -601,6 +601,7 @@ class _Reparam(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h2, eps):
+        ctx.set_materialize_grads(False)
         h2 = _chk(h2.contiguous(), name='h2')
         n, h = h2.shape[0], h2.shape[1] // 2
         eps = _chk(eps.contiguous(), name='eps')
@@ -633,6 +634,7 @@ class _DistMultBCE(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, embed, w_rel, bias, labels, tidx):
+        ctx.set_materialize_grads(False)
         embed, ld_e = _row_major(embed, 'embed')
         w_rel, ld_w = _row_major(w_rel, 'w_relation')
         labels = _chk(labels.reshape(-1), name='labels')
@@ -651,6 +653,8 @@ class _DistMultBCE(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gloss, _gscore):
+        if gloss is None:
+            return None, None, None, None, None
         embed, w_rel, labels, score = ctx.saved_tensors
         tidx = ctx.tidx
         T, h = tidx.T, embed.shape[1]
@@ -931,7 +935,8 @@ class _LossHead(torch.autograd.Function):
         if labels.numel() != T:
             raise ValueError('labels / triplets length mismatch')
         f32 = dict(dtype=torch.float32, device=dev)
-        scal = torch.zeros(4, **f32)                 # pred, reg, kl, mmd
+        ctx.set_materialize_grads(False)
+        scal = torch.empty(4, **f32)                 # pred, reg, kl, mmd (each written before it is read)
         pred, reg, kl, mmd = scal[0:1], scal[1:2], scal[2:3], scal[3:4]
         ws, ws2 = torch.empty(1024, **f32), torch.empty(1024, **f32)
         score = torch.empty(T, **f32)
@@ -980,6 +985,8 @@ class _LossHead(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _gp, _gk, _gm):
+        if g is None:
+            return (None,) * 14
         z, z_mean, z_sigma, w_rel, z_pre, resp, z_pri, z_post, pick, labels, score = ctx.saved_tensors
         tidx, reg_w, kl_w, mmd_w, has_bias, flp_in_kl = ctx.meta
         dev, (n, h), T = z.device, z.shape, tidx.T
@@ -1057,6 +1064,7 @@ class _MADEForward(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, colcount, *wb):
+        ctx.set_materialize_grads(False)
         L = len(wb) // 2
         ws, bs = wb[:L], wb[L:]
         z = _chk(z.contiguous(), name='z')
