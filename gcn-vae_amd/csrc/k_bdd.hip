@@ -655,7 +655,8 @@ extern "C" int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const in
                                      void* stream) {
     GV_REQUIRE(n_items >= 0 && n_fix >= 0, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate: negative item count");
     if (n_items == 0) return GV_OK;
-    GV_REQUIRE(items && nbr && etype && feat && weight && out, GV_ERR_NULL, "gv_rgcn_bdd_aggregate: NULL pointer");
+    // nbr / etype may be NULL for an edge-less graph (every item then has begin == end and never reads them)
+    GV_REQUIRE(items && feat && weight && out, GV_ERR_NULL, "gv_rgcn_bdd_aggregate: NULL pointer");
     GV_REQUIRE(num_bases > 0 && blk_in > 0 && blk_out > 0 && num_rels > 0, GV_ERR_SHAPE,
                "gv_rgcn_bdd_aggregate: num_bases=%d blk_in=%d blk_out=%d num_rels=%d", num_bases, blk_in, blk_out,
                num_rels);
@@ -776,7 +777,7 @@ extern "C" int gv_rgcn_bdd_grad_weight(const int32_t* items, int n_items, const 
                                        int accumulate, void* stream) {
     GV_REQUIRE(n_items >= 0 && n_fix >= 0, GV_ERR_SHAPE, "gv_rgcn_bdd_grad_weight: negative item count");
     if (n_items == 0) return GV_OK;
-    GV_REQUIRE(items && src && dst && x && g && grad_w, GV_ERR_NULL, "gv_rgcn_bdd_grad_weight: NULL pointer");
+    GV_REQUIRE(items && x && g && grad_w, GV_ERR_NULL, "gv_rgcn_bdd_grad_weight: NULL pointer");   // src/dst: see above
     GV_REQUIRE(num_bases > 0 && blk_in > 0 && blk_out > 0, GV_ERR_SHAPE, "gv_rgcn_bdd_grad_weight: bad block sizes");
     GV_REQUIRE(n_fix == 0 || (fix && partial), GV_ERR_NULL, "gv_rgcn_bdd_grad_weight: split segments need fix+partial");
     GV_REQUIRE(ld_x >= num_bases * blk_in && ld_g >= num_bases * blk_out, GV_ERR_SHAPE,

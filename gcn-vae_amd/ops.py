@@ -4,6 +4,8 @@ Every function here requires CUDA (ROCm) float32 tensors and the built HIP libra
 falls back to torch CPU math.  torch is used for device memory, the current stream and autograd
 bookkeeping only (plus sort/cumsum when an index is built, outside the hot step).
 """
+import contextlib
+import os as _os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -34,9 +36,6 @@ DIST_FWD_CHUNKS = 2        # destination-row blocks whose all-reduce overlaps th
 # reductions, weight-gradient GEMMs) run beside the bandwidth-bound kernels instead of behind them.
 # Under hipGraph capture the event edges become parallel graph branches.  Buffers a branch writes are
 # allocated by the caller BEFORE the fork (torch's allocator is per stream).  Opt in with GV_CONCURRENCY=1.
-import contextlib
-import os as _os
-
 CONCURRENCY = _os.environ.get('GV_CONCURRENCY', '0') == '1'   # measured null on MI355X (1.49 vs 1.49 ms/step): off by default
 _side_streams = {}
 

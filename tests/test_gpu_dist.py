@@ -1,0 +1,32 @@
+"""The RCCL code path of bench.py as a 1-rank torch.distributed.run job (one GPU): process-group init over 127.0.0.1,
+edge-shard layer branch with async all-reduces, flat-gradient averaging, hipGraph capture with collectives."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize('extra', [[], ['--no-graph']])
+def test_bench_single_rank_rccl(extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-dist', '--steps', '3',
+           '--warmup', '1', '--no-cpu-baseline', '--profile-steps', '0', '--positives', '2000'] + extra
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 1 and d['value'] > 1e6 and d['config']['launch'] == ('eager' if extra else 'hipgraph')
+    assert d['final_loss'] == d['final_loss']          # not NaN

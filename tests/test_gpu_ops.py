@@ -376,3 +376,80 @@ def test_edge_shard_code_path_equals_fused_path(ops):
     chunks = gidx.dst_chunks(ops.DIST_FWD_CHUNKS)
     assert chunks[0][0] == 0 and chunks[-1][1] == n and sum(c[2].n_items for c in chunks) == gidx.by_dst.seg.n_items
     assert len(calls) == len(chunks) + 1 and calls[-1] == (n, fout)          # forward row blocks + one backward gradient
+
+
+def test_basis_regularizer_layer(ops):
+    """RelGraphConv(regularizer='basis') -- W_r = sum_b w_comp[r,b] V_b through the f32 GEMM, then the
+    generic aggregation kernels with one dense (in x out) block per relation; forward + all gradients vs the oracle."""
+    from gcn_vae_amd.graph import KGraph
+    from gcn_vae_amd.layers import RelGraphConv
+    n, e, r, fin, fout, nbases = 90, 700, 12, 10, 14, 5
+    src, dst, et, norm = zipf_graph(n, e, r, seed=8)
+    torch.manual_seed(0)
+    for nb in (nbases, r):          # nb < R: w_comp present; nb == R: plain per-relation matrices
+        layer = RelGraphConv(fin, fout, r, 'basis', nb, activation=torch.tanh, self_loop=True, dropout=0.0)
+        with torch.no_grad():
+            layer.h_bias.normal_(0, 0.1)
+        assert ('w_comp' in dict(layer.named_parameters())) == (nb < r)
+        x = torch.randn(n, fin)
+        gout = torch.randn(n, fout)
+        po = {k: v.detach().clone().requires_grad_(True) for k, v in layer.named_parameters()}
+        xo = x.clone().requires_grad_(True)
+        ho = orgcn.rel_graph_conv(xo, src, dst, et, norm, po, 'basis', nb, torch.tanh)
+        ho.backward(gout)
+        g = KGraph()
+        g.add_nodes(n)
+        g.add_edges(src, dst)
+        layer = layer.cuda()
+        xg = x.cuda().requires_grad_(True)
+        hg = layer(g, xg, et.cuda(), norm.cuda())
+        hg.backward(gout.cuda())
+        close(hg, ho, msg='basis forward')
+        close(xg.grad, xo.grad, msg='basis grad_x')
+        for k, v in layer.named_parameters():
+            close(v.grad, po[k].grad, rtol=2e-4, atol_scale=2e-5, msg='basis grad ' + k)
+
+
+def test_odd_widths_and_degenerate_graphs(ops):
+    # feature widths that are not multiples of 4 take the generic kernels and the scalar GEMM loads
+    n, e, r, fin, fout, nb = 70, 400, 5, 9, 15, 3
+    src, dst, et, norm = zipf_graph(n, e, r, seed=1)
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(n, fin, generator=gen)
+    p = orgcn.init_params(fin, fout, r, 'bdd', nb, True, True, gen)
+    gout = torch.randn(n, fout, generator=gen)
+    xo = x.clone().requires_grad_(True)
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ho = orgcn.rel_graph_conv(xo, src, dst, et, norm, po, 'bdd', nb, torch.relu)
+    ho.backward(gout)
+    gidx = ops.GraphIndex(src.cuda(), dst.cuda(), n)
+    ridx = gidx.relation_index(et.cuda(), r)
+    xg = x.cuda().requires_grad_(True)
+    pg = {k: v.cuda().requires_grad_(True) for k, v in p.items()}
+    hg = ops.rel_graph_conv_bdd(xg, pg['weight'], pg['h_bias'], pg['loop_weight'], norm.cuda(), gidx, ridx, nb, 1)
+    hg.backward(gout.cuda())
+    close(hg, ho)
+    close(xg.grad, xo.grad)
+    for k in p:
+        close(pg[k].grad, po[k].grad, msg=k)
+    # a graph without edges: every row is act(bias + x @ loop_weight); gradients of the relation weights are zero
+    empty = torch.zeros(0, dtype=torch.int64)
+    g0 = ops.GraphIndex(empty.cuda(), empty.cuda(), n)
+    r0 = g0.relation_index(empty.cuda(), r)
+    pg = {k: v.cuda().requires_grad_(True) for k, v in p.items()}
+    h0 = ops.rel_graph_conv_bdd(x.cuda(), pg['weight'], pg['h_bias'], pg['loop_weight'], None, g0, r0, nb, 1)
+    close(h0, torch.relu(x @ p['loop_weight'] + p['h_bias']))
+    h0.sum().backward()
+    assert float(pg['weight'].grad.abs().max()) == 0.0
+    # one node, self loops only
+    one = torch.zeros(3, dtype=torch.int64)
+    g1 = ops.GraphIndex(one.cuda(), one.cuda(), 1)
+    r1 = g1.relation_index(torch.tensor([0, 1, 1]).cuda(), r)
+    x1 = torch.randn(1, fin, generator=gen)
+    h1 = ops.rel_graph_conv_bdd(x1.cuda(), p['weight'].cuda(), None, None, None, g1, r1, nb, 0)
+    close(h1, orgcn.rel_graph_conv(x1, one, one, torch.tensor([0, 1, 1]), None, {'weight': p['weight']}, 'bdd', nb))
+    # non-contiguous inputs are accepted (made contiguous), wrong dtypes are refused
+    xt = torch.randn(fin, n, generator=gen).t()
+    close(ops.gemm(xt.cuda(), p['loop_weight'].cuda()), xt.double() @ p['loop_weight'].double())
+    with pytest.raises(TypeError):
+        ops.gemm(x.cuda().double(), p['loop_weight'].cuda())
