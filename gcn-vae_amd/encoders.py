@@ -58,6 +58,11 @@ class KGVAE(nn.Module):
         self.eps_override = None          # (N, h) standard-normal draw for the reparameterisation
         self.mmd_eps_override = None      # (num_sample, h) draw for the prior samples of get_mmd
         self.mmd_index_override = None    # int64 (num_sample,) posterior row pick of get_mmd
+        # get_mmd pushes 200 prior samples through the same flow stack as the N node rows.  The flows act row-wise,
+        # so when the task head announces that MMD will be evaluated (LinkPredict sets this for mmd_param > 0) the
+        # prior rows ride along in forward() as extra rows of the same GEMMs instead of ~150 tiny launches of their own.
+        self.batch_mmd_prior_with_forward = False
+        self._z_pri_flowed = None
 
     def build_iaf(self):
         blocks = []
@@ -92,16 +97,23 @@ class KGVAE(nn.Module):
         # (None + tensor, kgvae/model.py:86); None is read as "no flow term".
         return ops.kl_to_mixture(z, self.z_mean, self.z_sigma, self.z_pre.squeeze(0), self.flow_log_prob)
 
-    def mmd_inputs(self, z):
-        """The two sample sets of get_mmd: prior draws (through the flows) and the posterior row pick."""
+    def _prior_draw(self, device, dtype):
         num_sample = 200
         rows = (num_sample // self.k) * self.k if num_sample // self.k > 1 else self.k
         eps = self.mmd_eps_override if self.mmd_eps_override is not None else \
-            torch.randn(rows, self.h_dim, device=z.device, dtype=z.dtype)
-        z_pri = ops.prior_sample(self.z_pre.squeeze(0), eps)      # sample_gaussian(m_mix, s_mix, repeat)
-        if self.n_flows > 0:
-            for flow in self.nf:
-                z_pri, _ = flow.forward(z_pri)
+            torch.randn(rows, self.h_dim, device=device, dtype=dtype)
+        return ops.prior_sample(self.z_pre.squeeze(0), eps)       # sample_gaussian(m_mix, s_mix, repeat)
+
+    def mmd_inputs(self, z):
+        """The two sample sets of get_mmd: prior draws (through the flows) and the posterior row pick."""
+        num_sample = 200
+        if self._z_pri_flowed is not None:        # already carried through the flows by forward()
+            z_pri, self._z_pri_flowed = self._z_pri_flowed, None
+        else:
+            z_pri = self._prior_draw(z.device, z.dtype)
+            if self.n_flows > 0:
+                for flow in self.nf:
+                    z_pri, _ = flow.forward(z_pri)
         if self.mmd_index_override is not None:
             pick = self.mmd_index_override
         else:   # (Monte Carlo) posterior rows, python RNG as in the reference
@@ -123,12 +135,20 @@ class KGVAE(nn.Module):
         eps = self.eps_override if self.eps_override is not None else \
             torch.randn(h.shape[0], h.shape[1] // 2, device=h.device, dtype=h.dtype)
         z, self.z_mean, self.z_sigma = ops.reparam(h, eps)
+        self._z_pri_flowed = None
         if self.n_flows > 0:
+            n = z.shape[0]
+            ride_along = self.batch_mmd_prior_with_forward and self.training
+            if ride_along:
+                z = torch.cat([z, self._prior_draw(z.device, z.dtype)], dim=0)
             log_det_sum = None
             for flow in self.nf:
                 z, log_det = flow.forward(z)
                 if isinstance(flow, MADE):            # PermuteLayer contributes zeros
                     log_det_sum = log_det if log_det_sum is None else log_det_sum + log_det
+            if ride_along:
+                self._z_pri_flowed = z[n:]
+                z, log_det_sum = z[:n], log_det_sum[:n]
             self.flow_log_prob = torch.mean(log_det_sum.view(-1, 1))
         return z
 
