@@ -98,14 +98,14 @@ __global__ __launch_bounds__(256) void k_mul(int64_t n, const float* a, const fl
     GV_GRID_STRIDE(i, n) out[i] = a[i] * b[i];
 }
 
-__global__ __launch_bounds__(256) void k_iaf_fwd(const float* z, const float* net, const float* xold,
+__global__ __launch_bounds__(256) void k_iaf_fwd(const float* z, const float* net, int ld_net, const float* xold,
                                                  const int* colcount, float* xnew, int64_t n, int d) {
     const int64_t total = n * d;
     GV_GRID_STRIDE(i, total) {
         const int64_t r = i / d;
         const int c = (int)(i - r * d);
         if (colcount[c] > 0) {
-            const float mu = net[r * 2 * d + c], al = net[r * 2 * d + d + c];
+            const float mu = net[r * ld_net + c], al = net[r * ld_net + d + c];
             xnew[i] = z[i] * expf(al + mu);
         } else {
             xnew[i] = xold[i];
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_iaf_fwd(const float* z, const float* ne
     }
 }
 
-__global__ __launch_bounds__(256) void k_iaf_bwd(const float* z, const float* net, const int* colcount,
+__global__ __launch_bounds__(256) void k_iaf_bwd(const float* z, const float* net, int ld_net, const int* colcount,
                                                  const float* gx, const float* gld, float* gz, float* gnet,
                                                  float* gxold, int64_t n, int d) {
     const int64_t total = n * d;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_iaf_bwd(const float* z, const float* ne
         const float g = gx[i];
         float g_mu = 0.f, g_al = gld ? gld[r] : 0.f, g_z = 0.f, g_old = g;
         if (cnt > 0) {
-            const float e = expf(net[r * 2 * d + d + c] + net[r * 2 * d + c]);
+            const float e = expf(net[r * ld_net + d + c] + net[r * ld_net + c]);
             const float gc = g * (float)cnt;  // autograd gives the column's gradient to every duplicate index
             g_z = gc * e;
             g_mu = gc * z[i] * e;
@@ -247,21 +247,23 @@ extern "C" int gv_mul(int64_t n, const float* a, const float* b, float* out, voi
     return launch_status("gv_mul");
 }
 
-extern "C" int gv_iaf_update_fwd(const float* z, const float* net, const float* x_old, const int32_t* colcount,
-                                 float* x_new, int64_t n, int d, void* stream) {
+extern "C" int gv_iaf_update_fwd(const float* z, const float* net, int ld_net, const float* x_old,
+                                 const int32_t* colcount, float* x_new, int64_t n, int d, void* stream) {
     GV_REQUIRE(z && net && x_old && colcount && x_new, GV_ERR_NULL, "gv_iaf_update_fwd: NULL pointer");
+    GV_REQUIRE(ld_net == 0 || ld_net >= 2 * d, GV_ERR_SHAPE, "gv_iaf_update_fwd: ld_net=%d (0 = broadcast one row, else >= 2d)", ld_net);
     if (n * d <= 0) return GV_OK;
-    hipLaunchKernelGGL(k_iaf_fwd, dim3(grid_for(n * d, 1024)), dim3(256), 0, GV_ST, z, net, x_old, colcount, x_new, n, d);
+    hipLaunchKernelGGL(k_iaf_fwd, dim3(grid_for(n * d, 1024)), dim3(256), 0, GV_ST, z, net, ld_net, x_old, colcount, x_new, n, d);
     return launch_status("gv_iaf_update_fwd");
 }
 
-extern "C" int gv_iaf_update_bwd(const float* z, const float* net, const int32_t* colcount, const float* g_xnew,
-                                 const float* g_logdet, float* g_z, float* g_net, float* g_xold, int64_t n, int d,
-                                 void* stream) {
+extern "C" int gv_iaf_update_bwd(const float* z, const float* net, int ld_net, const int32_t* colcount,
+                                 const float* g_xnew, const float* g_logdet, float* g_z, float* g_net, float* g_xold,
+                                 int64_t n, int d, void* stream) {
     GV_REQUIRE(z && net && colcount && g_xnew && g_z && g_net && g_xold, GV_ERR_NULL, "gv_iaf_update_bwd: NULL pointer");
+    GV_REQUIRE(ld_net == 0 || ld_net >= 2 * d, GV_ERR_SHAPE, "gv_iaf_update_bwd: ld_net=%d", ld_net);
     if (n * d <= 0) return GV_OK;
-    hipLaunchKernelGGL(k_iaf_bwd, dim3(grid_for(n * d, 1024)), dim3(256), 0, GV_ST, z, net, colcount, g_xnew, g_logdet,
-                       g_z, g_net, g_xold, n, d);
+    hipLaunchKernelGGL(k_iaf_bwd, dim3(grid_for(n * d, 1024)), dim3(256), 0, GV_ST, z, net, ld_net, colcount, g_xnew,
+                       g_logdet, g_z, g_net, g_xold, n, d);
     return launch_status("gv_iaf_update_bwd");
 }
 

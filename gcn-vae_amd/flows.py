@@ -46,6 +46,8 @@ class MADE(nn.Module):
         self.net = nn.Sequential(*layers)
         # per pass: how often each column occurs in the index set (0 = column untouched)
         counts = torch.stack([torch.bincount(idx % input_size, minlength=input_size) for idx in self.m])
+        if bool((counts[0] == 0).any()):     # the fused node evaluates pass 0 on one broadcast row and relies on this
+            raise ValueError('MADE: the first index set must cover every column (arange(D) in the reference)')
         self.register_buffer('_colcount', counts.to(torch.int32), persistent=False)
 
     def create_masks(self):

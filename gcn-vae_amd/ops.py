@@ -776,7 +776,7 @@ class _IAFUpdate(torch.autograd.Function):
         z, net, x_old = (_chk(t.contiguous(), name=nm) for t, nm in ((z, 'z'), (net, 'net'), (x_old, 'x_old')))
         n, d = z.shape
         x_new = torch.empty_like(z)
-        lib.call('gv_iaf_update_fwd', ptr(z), ptr(net), ptr(x_old), ptr(colcount), ptr(x_new), n, d, lib.stream())
+        lib.call('gv_iaf_update_fwd', ptr(z), ptr(net), 2 * d, ptr(x_old), ptr(colcount), ptr(x_new), n, d, lib.stream())
         ctx.save_for_backward(z, net, colcount)
         return x_new
 
@@ -786,7 +786,7 @@ class _IAFUpdate(torch.autograd.Function):
         n, d = z.shape
         gx = _chk(gx.contiguous(), name='gx')
         gz, gnet, gold = torch.empty_like(z), torch.empty_like(net), torch.empty_like(z)
-        lib.call('gv_iaf_update_bwd', ptr(z), ptr(net), ptr(colcount), ptr(gx), None, ptr(gz), ptr(gnet), ptr(gold),
+        lib.call('gv_iaf_update_bwd', ptr(z), ptr(net), 2 * d, ptr(colcount), ptr(gx), None, ptr(gz), ptr(gnet), ptr(gold),
                  n, d, lib.stream())
         return gz, gnet, gold, None
 
@@ -1051,12 +1051,15 @@ class _MADEForward(torch.autograd.Function):
     """MADE.forward (kgvae/flow_network.py:85-98) as ONE autograd node.
 
     The reference runs ``len(self.m)`` (= n_hidden + 3) sequential passes of the masked MLP, each followed by
-    ``x[:, i] = z[:, i] * exp(alpha[:, i] + mu[:, i])``.  Here every pass writes its layer activations into row
-    slices of per-layer buffers stacked over the passes, so the backward
-      * walks the passes in reverse with one NN GEMM per layer whose A operand is read through the ReLU mask of the
-        stored activation (no separate masking kernels, no materialised masked gradient), and
-      * forms each layer's weight gradient ONCE, as a single split-K product over all passes' rows (K = passes x N)
-        -- the reference's autograd does it per pass and sums.
+    ``x[:, i] = z[:, i] * exp(alpha[:, i] + mu[:, i])``.  Here
+      * pass 0 -- whose input is the all-zero matrix, i.e. N identical rows -- evaluates the MLP on ONE row and
+        broadcasts it into the update (its backward sums the update's gradient over the rows and back-propagates
+        that single row);
+      * every later pass writes its layer activations into row slices of per-layer buffers stacked over the passes,
+        so the backward walks the passes in reverse with one NN GEMM per layer whose A operand is read through the
+        ReLU mask of the stored activation (no masking kernels, no materialised masked gradient), and forms each
+        layer's weight gradient ONCE as a single split-K product over all stacked rows (K = (passes-1) x N); the
+        reference's autograd does it per pass and sums.
     Inputs: z (N, D); masked weights W_l (out_l, in_l) and biases, l = 0..L-1 (last layer: 2D outputs [mu | alpha]);
     colcount int32 (passes, D).  Outputs: x (N, D), log_det (N,) = sum_d alpha of the last pass.
     """
@@ -1069,25 +1072,36 @@ class _MADEForward(torch.autograd.Function):
         z = _chk(z.contiguous(), name='z')
         n, d = z.shape
         P = colcount.shape[0]
-        dev = z.device
-        f32 = dict(dtype=torch.float32, device=dev)
+        f32 = dict(dtype=torch.float32, device=z.device)
         st = lib.stream()
-        xin = torch.empty(P * n, d, **f32)                       # input of every pass (pass 0: zeros)
-        xin[:n].zero_()
-        acts = [torch.empty(P * n, ws[l].shape[0], **f32) for l in range(L)]   # acts[L-1] = net outputs [mu | alpha]
+        S = P - 1                                                 # passes 1..P-1 are stacked; pass 0 is one row
+        xin = torch.empty(max(S, 1) * n, d, **f32)               # xin[s] = input of pass s+1 = output of pass s
+        acts = [torch.empty(max(S, 1) * n, ws[l].shape[0], **f32) for l in range(L)]   # acts[L-1] = [mu | alpha]
         x_out = torch.empty(n, d, **f32)
-        for p in range(P):
-            inp = xin[p * n:(p + 1) * n]
+        # pass 0 on a single zero row
+        zero_row = torch.zeros(1, d, **f32)
+        acts0, inp = [], zero_row
+        for l in range(L):
+            inp = gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE)
+            acts0.append(inp)
+        first_out = xin[0:n] if P > 1 else x_out
+        # (columns outside the first index set would keep x_old = 0: flows.MADE checks at construction that there are none)
+        lib.call('gv_iaf_update_fwd', ptr(z), ptr(acts0[L - 1]), 0, ptr(z), ptr(colcount[0]), ptr(first_out), n, d, st)
+        for p in range(1, P):
+            sl = slice((p - 1) * n, p * n)
+            inp = xin[sl]
             for l in range(L):
-                out = acts[l][p * n:(p + 1) * n]
+                out = acts[l][sl]
                 gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE, out=out)
                 inp = out
-            nxt = xin[(p + 1) * n:(p + 2) * n] if p + 1 < P else x_out
-            lib.call('gv_iaf_update_fwd', ptr(z), ptr(inp), ptr(xin[p * n:(p + 1) * n]), ptr(colcount[p]), ptr(nxt), n, d, st)
+            nxt = xin[p * n:(p + 1) * n] if p + 1 < P else x_out
+            lib.call('gv_iaf_update_fwd', ptr(z), ptr(inp), 2 * d, ptr(xin[sl]), ptr(colcount[p]), ptr(nxt), n, d, st)
         log_det = torch.empty(n, **f32)
-        last = acts[L - 1][(P - 1) * n:]
-        lib.call('gv_rowsum', ptr(last), 2 * d, d, d, ptr(log_det), n, st)
-        ctx.save_for_backward(z, colcount, xin, *acts, *ws)
+        if P > 1:
+            lib.call('gv_rowsum', ptr(acts[L - 1][(S - 1) * n:]), 2 * d, d, d, ptr(log_det), n, st)
+        else:
+            log_det = acts0[L - 1][:, d:].sum(dim=1).expand(n).contiguous()
+        ctx.save_for_backward(z, colcount, xin, zero_row, *acts, *acts0, *ws)
         ctx.L = L
         ctx.has_bias = [b is not None for b in bs]
         return x_out, log_det
@@ -1096,23 +1110,23 @@ class _MADEForward(torch.autograd.Function):
     def backward(ctx, gx, gld):
         L = ctx.L
         saved = ctx.saved_tensors
-        z, colcount, xin = saved[0], saved[1], saved[2]
-        acts, ws = saved[3:3 + L], saved[3 + L:3 + 2 * L]
+        z, colcount, xin, zero_row = saved[:4]
+        acts, acts0, ws = saved[4:4 + L], saved[4 + L:4 + 2 * L], saved[4 + 2 * L:4 + 3 * L]
         n, d = z.shape
         P = colcount.shape[0]
-        dev = z.device
-        f32 = dict(dtype=torch.float32, device=dev)
+        S = P - 1
+        f32 = dict(dtype=torch.float32, device=z.device)
         st = lib.stream()
         gx = torch.zeros(n, d, **f32) if gx is None else _chk(gx.contiguous(), name='gx')
         gld = None if gld is None else _chk(gld.contiguous(), name='gld')
-        grads = [torch.empty(P * n, ws[l].shape[0], **f32) for l in range(L)]   # grad w.r.t. each layer's OUTPUT
+        grads = [torch.empty(max(S, 1) * n, ws[l].shape[0], **f32) for l in range(L)]   # grad w.r.t. each layer's OUTPUT
         g_z = torch.zeros(n, d, **f32)
         gz_p = torch.empty(n, d, **f32)
         g_cur = gx
-        for p in reversed(range(P)):
-            sl = slice(p * n, (p + 1) * n)
+        for p in reversed(range(1, P)):
+            sl = slice((p - 1) * n, p * n)
             g_old = torch.empty(n, d, **f32)
-            lib.call('gv_iaf_update_bwd', ptr(z), ptr(acts[L - 1][sl]), ptr(colcount[p]), ptr(g_cur),
+            lib.call('gv_iaf_update_bwd', ptr(z), ptr(acts[L - 1][sl]), 2 * d, ptr(colcount[p]), ptr(g_cur),
                      ptr(gld) if p == P - 1 else None, ptr(gz_p), ptr(grads[L - 1][sl]), ptr(g_old), n, d, st)
             lib.call('gv_axpby', n * d, None, 1.0, ptr(gz_p), 1.0, ptr(g_z), st)
             for l in reversed(range(L)):
@@ -1122,19 +1136,38 @@ class _MADEForward(torch.autograd.Function):
                 else:       # gradient w.r.t. the pass's input x_p joins the update's pass-through gradient
                     gemm(grads[0][sl], ws[0], out=g_old, accumulate=True, a_relu_mask=mask)
             g_cur = g_old
+        # pass 0: the update's gradient w.r.t. the broadcast net row is its column sum; x_old was the zero matrix
+        g_net0 = torch.empty(n, 2 * d, **f32)
+        g_dump = torch.empty(n, d, **f32)
+        lib.call('gv_iaf_update_bwd', ptr(z), ptr(acts0[L - 1]), 0, ptr(colcount[0]), ptr(g_cur),
+                 ptr(gld) if P == 1 else None, ptr(gz_p), ptr(g_net0), ptr(g_dump), n, d, st)
+        lib.call('gv_axpby', n * d, None, 1.0, ptr(gz_p), 1.0, ptr(g_z), st)
+        g_row = colsum(g_net0).view(1, -1)                      # (1, 2D)
+        rows0 = [None] * L                                        # masked single-row gradients per layer output
+        for l in reversed(range(L)):
+            rows0[l] = g_row
+            if l > 0:
+                mask = acts0[l] if l < L - 1 else None
+                g_row = gemm(g_row, ws[l], a_relu_mask=mask)
         g_ws, g_bs = [], []
         for l in range(L):
-            inp = xin if l == 0 else acts[l - 1]
             mask = acts[l] if l < L - 1 else None
+            mask0 = acts0[l] if l < L - 1 else None
+            inp0 = zero_row if l == 0 else acts0[l - 1]
+            gw = gb = None
             if ctx.needs_input_grad[2 + l]:
-                g_ws.append(gemm(grads[l], inp, trans_a=True, a_relu_mask=mask,
-                                 split_k=pick_split_k(ws[l].shape[0], ws[l].shape[1], P * n)))
-            else:
-                g_ws.append(None)
+                gw = gemm(rows0[l], inp0, trans_a=True, a_relu_mask=mask0)           # pass 0: outer product of two rows
+                if S > 0:
+                    inp = xin if l == 0 else acts[l - 1]
+                    part = gemm(grads[l], inp, trans_a=True, a_relu_mask=mask,
+                                split_k=pick_split_k(ws[l].shape[0], ws[l].shape[1], S * n))
+                    lib.call('gv_axpby', gw.numel(), None, 1.0, ptr(part), 1.0, ptr(gw), st)
             if ctx.has_bias[l] and ctx.needs_input_grad[2 + L + l]:
-                g_bs.append(colsum(grads[l], relu_mask=mask))
-            else:
-                g_bs.append(None)
+                gb = colsum(rows0[l], relu_mask=mask0)
+                if S > 0:
+                    colsum(grads[l], relu_mask=mask, out=gb, accumulate=True)
+            g_ws.append(gw)
+            g_bs.append(gb)
         return (g_z, None, *g_ws, *g_bs)
 
 

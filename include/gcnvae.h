@@ -189,9 +189,11 @@ int gv_prior_sample_bwd(const float* z_pre, const float* eps, const float* g, fl
  *   net = [mu | alpha] (n, 2d);  x_new[:, c] = colcount[c] > 0 ? z*exp(alpha+mu) : x_old
  *   bwd multiplies the column's gradient by colcount[c] (autograd's duplicate-index behaviour,
  *   pinned by tests/golden/made.npz).  gv_rowsum: log_det = sum_d alpha.  gv_reverse_cols: PermuteLayer. */
-int gv_iaf_update_fwd(const float* z, const float* net, const float* x_old, const int32_t* colcount, float* x_new,
-                      int64_t n, int d, void* stream);
-int gv_iaf_update_bwd(const float* z, const float* net, const int32_t* colcount, const float* g_xnew,
+/* ld_net: row stride of net in floats (>= 2d), or 0 to broadcast ONE net row to all n rows -- the first pass of
+ * MADE.forward evaluates the MLP on an all-zero input, i.e. n identical rows.  g_net is always (n, 2d). */
+int gv_iaf_update_fwd(const float* z, const float* net, int ld_net, const float* x_old, const int32_t* colcount,
+                      float* x_new, int64_t n, int d, void* stream);
+int gv_iaf_update_bwd(const float* z, const float* net, int ld_net, const int32_t* colcount, const float* g_xnew,
                       const float* g_logdet /*[n] or NULL*/, float* g_z, float* g_net, float* g_xold, int64_t n, int d,
                       void* stream);
 int gv_rowsum(const float* x, int ld, int col0, int ncols, float* out, int64_t n, void* stream);
