@@ -17,8 +17,6 @@
 
 namespace gv {
 
-constexpr int BN = 64;
-constexpr int LDB_S = BN + 1;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -78,7 +76,7 @@ __device__ __forceinline__ void load_a(const GemmParams& p, int m0, int k0, int 
     }
 }
 
-template <bool TB, int BK>
+template <bool TB, int BN, int BK>
 __device__ __forceinline__ void load_b(const GemmParams& p, int n0, int k0, int kend, float (&r)[BN * BK / 256]) {
     constexpr int BPT = BN * BK / 256;
     const int t = threadIdx.x;
@@ -110,9 +108,9 @@ __device__ __forceinline__ void stage_a(float* As, const float (&r)[BM * BK / 25
     }
 }
 
-template <bool TB, int BK>
+template <bool TB, int BN, int BK>
 __device__ __forceinline__ void stage_b(float* Bs, const float (&r)[BN * BK / 256]) {
-    constexpr int BPT = BN * BK / 256;
+    constexpr int BPT = BN * BK / 256, LDB_S = BN + 1;
     const int t = threadIdx.x;
     if constexpr (!TB) {
         constexpr int TPK = BN / BPT;
@@ -127,64 +125,73 @@ __device__ __forceinline__ void stage_b(float* Bs, const float (&r)[BN * BK / 25
     }
 }
 
-// MT = 32-row MFMA tiles per wave: block tile (64*MT) x 64 x BK, four waves as 2 (M) x 2 (N).
-template <bool TA, bool TB, int MT, int BK>
+// MT / NT = 32-row / 32-column MFMA tiles per wave: block tile (64*MT) x (64*NT) x BK, four waves as 2 (M) x 2 (N).
+template <bool TA, bool TB, int MT, int NT, int BK>
 __global__ __launch_bounds__(256) void k_gemm_f32(const GemmParams p) {
-    constexpr int BM = 64 * MT, LDA_S = BM + 1;
+    constexpr int BM = 64 * MT, BN = 64 * NT, LDA_S = BM + 1, LDB_S = BN + 1;
     __shared__ float As[BK * LDA_S];
     __shared__ float Bs[BK * LDB_S];
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * p.k_chunk;
     const int kend = min(p.k, kbeg + p.k_chunk);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int wm = (wid >> 1) * 32 * MT, wn = (wid & 1) * 32;
+    const int wm = (wid >> 1) * 32 * MT, wn = (wid & 1) * 32 * NT;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    f32x16 acc[MT];
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
 
     float ra[BM * BK / 256], rb[BN * BK / 256];
     load_a<TA, BM, BK>(p, m0, kbeg, kend, ra);
-    load_b<TB, BK>(p, n0, kbeg, kend, rb);
+    load_b<TB, BN, BK>(p, n0, kbeg, kend, rb);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         stage_a<TA, BM, BK>(As, ra);
-        stage_b<TB, BK>(Bs, rb);
+        stage_b<TB, BN, BK>(Bs, rb);
         __syncthreads();
         if (k0 + BK < kend) {  // next tile's loads fly under this tile's MFMAs
             load_a<TA, BM, BK>(p, m0, k0 + BK, kend, ra);
-            load_b<TB, BK>(p, n0, k0 + BK, kend, rb);
+            load_b<TB, BN, BK>(p, n0, k0 + BK, kend, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float b = Bs[(kk + lhi) * LDB_S + wn + l31];
+            float bf[NT], af[MT];
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const float a = As[(kk + lhi) * LDA_S + wm + 32 * t + l31];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-            }
+            for (int u = 0; u < NT; ++u) bf[u] = Bs[(kk + lhi) * LDB_S + wn + 32 * u + l31];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) af[t] = As[(kk + lhi) * LDA_S + wm + 32 * t + l31];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], bf[u], acc[t][u], 0, 0, 0);
         }
         __syncthreads();
     }
     // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const int col = n0 + wn + l31;
-    if (col >= p.n) return;
-    const float bv = (p.bias && p.split_k == 1) ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
+    for (int u = 0; u < NT; ++u) {
+        const int col = n0 + wn + 32 * u + l31;
+        if (col >= p.n) continue;
+        const float bv = (p.bias && p.split_k == 1) ? p.bias[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (row >= p.m) continue;
-            float v = acc[t][r];
-            if (p.split_k > 1) {
-                p.ws[((size_t)blockIdx.z * p.m + row) * p.n + col] = v;
-            } else {
-                v = apply_act(v + bv, p.act);
-                float* dst = p.c + (size_t)row * p.ldc + col;
-                *dst = p.accumulate ? *dst + v : v;
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (row >= p.m) continue;
+                float v = acc[t][u][r];
+                if (p.split_k > 1) {
+                    p.ws[((size_t)blockIdx.z * p.m + row) * p.n + col] = v;
+                } else {
+                    v = apply_act(v + bv, p.act);
+                    float* dst = p.c + (size_t)row * p.ldc + col;
+                    *dst = p.accumulate ? *dst + v : v;
+                }
             }
         }
     }
@@ -292,28 +299,32 @@ extern "C" int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const 
                    (long long)gv_gemm_workspace_bytes(m, n, k, split_k));
     }
     hipStream_t st = (hipStream_t)stream;
-    // 128-row tiles only when they still give every CU >= 4 blocks; otherwise 64-row tiles (more, smaller
-    // blocks hide the global-load latency of these short-K shapes better than one long MFMA chain)
-    const long blocks128 = (long)((n + BN - 1) / BN) * ((m + 127) / 128) * split_k;
-    static const int mt_env = getenv("GV_GEMM_MT") ? atoi(getenv("GV_GEMM_MT")) : 0;   // tuning knob
+    // Tile choice (measured on the C2 shapes, tools/microbench.py): 64-row tiles unless 128-row tiles still give every
+    // CU >= 4 blocks; 64-column tiles; BK = 16 for the row-major-A
+    // products (K = 200..400), 32 for the split-K weight-gradient products (A stored [K, M], K = nodes).
+    static const int mt_env = getenv("GV_GEMM_MT") ? atoi(getenv("GV_GEMM_MT")) : 0;   // tuning knobs
+    static const int nt_env = getenv("GV_GEMM_NT") ? atoi(getenv("GV_GEMM_NT")) : 0;
+    static const int bk_env = getenv("GV_GEMM_BK") ? atoi(getenv("GV_GEMM_BK")) : 0;
+    const int nt = nt_env == 2 ? 2 : 1;        // 128-column tiles measured 8-12 % slower on every C2 shape: opt-in only
+    const int bn = 64 * nt;
+    const long blocks128 = (long)((n + bn - 1) / bn) * ((m + 127) / 128) * split_k;
     const int mt = mt_env ? mt_env : (blocks128 >= 1024 ? 2 : 1);
-    dim3 grid((n + BN - 1) / BN, (m + 64 * mt - 1) / (64 * mt), split_k), block(256);
-    // measured on the C2 shapes: BK=16 is best for the row-major-A products (K = 200..400), BK=32 for the
-    // split-K weight-gradient products (A stored [K, M], K = nodes)
-    static const int bk_env = getenv("GV_GEMM_BK") ? atoi(getenv("GV_GEMM_BK")) : 0;   // tuning knob
     const int bk = bk_env ? (bk_env == 16 ? 16 : 32) : (trans_a ? 32 : 16);
-#define GV_GEMM_LAUNCH(TA_, TB_)                                                                   \
-    do {                                                                                           \
-        if (mt == 2 && bk == 32) hipLaunchKernelGGL((k_gemm_f32<TA_, TB_, 2, 32>), grid, block, 0, st, p);   \
-        else if (mt == 2) hipLaunchKernelGGL((k_gemm_f32<TA_, TB_, 2, 16>), grid, block, 0, st, p);          \
-        else if (bk == 32) hipLaunchKernelGGL((k_gemm_f32<TA_, TB_, 1, 32>), grid, block, 0, st, p);         \
-        else hipLaunchKernelGGL((k_gemm_f32<TA_, TB_, 1, 16>), grid, block, 0, st, p);                       \
+    dim3 grid((n + bn - 1) / bn, (m + 64 * mt - 1) / (64 * mt), split_k), block(256);
+#define GV_GEMM_CFG(TA_, TB_, MT_, NT_, BK_) \
+    if (mt == MT_ && nt == NT_ && bk == BK_) hipLaunchKernelGGL((k_gemm_f32<TA_, TB_, MT_, NT_, BK_>), grid, block, 0, st, p);
+#define GV_GEMM_LAUNCH(TA_, TB_)                                                                       \
+    do {                                                                                               \
+        GV_GEMM_CFG(TA_, TB_, 1, 1, 16) GV_GEMM_CFG(TA_, TB_, 1, 1, 32) GV_GEMM_CFG(TA_, TB_, 1, 2, 16) \
+        GV_GEMM_CFG(TA_, TB_, 1, 2, 32) GV_GEMM_CFG(TA_, TB_, 2, 1, 16) GV_GEMM_CFG(TA_, TB_, 2, 1, 32) \
+        GV_GEMM_CFG(TA_, TB_, 2, 2, 16) GV_GEMM_CFG(TA_, TB_, 2, 2, 32)                                 \
     } while (0)
     if (!trans_a && !trans_b) GV_GEMM_LAUNCH(false, false);
     else if (!trans_a && trans_b) GV_GEMM_LAUNCH(false, true);
     else if (trans_a && !trans_b) GV_GEMM_LAUNCH(true, false);
     else GV_GEMM_LAUNCH(true, true);
 #undef GV_GEMM_LAUNCH
+#undef GV_GEMM_CFG
     int rc = launch_status("gv_gemm_f32");
     if (rc != GV_OK) return rc;
     if (split_k > 1) {

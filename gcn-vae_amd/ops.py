@@ -367,10 +367,10 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, 
 
 def pick_split_k(m_out, n_out, k):
     """Reduction-heavy shapes (weight gradients: small output, K = nodes) need split-K to fill 256 CUs."""
-    tiles = ((m_out + 127) // 128) * ((n_out + 63) // 64)
+    tiles = ((m_out + 63) // 64) * ((n_out + 63) // 64)
     if tiles >= 256 or k < 2048:
         return 1
-    return max(1, min(64, 512 // tiles, k // 256))
+    return max(1, min(64, 1024 // tiles, k // 256))
 
 
 def colsum(x, out=None, accumulate=False, relu_mask=None):
