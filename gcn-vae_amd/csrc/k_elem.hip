@@ -34,6 +34,31 @@ __global__ __launch_bounds__(256) void k_epilogue_bwd(const float* out, const fl
     }
 }
 
+// epilogue backward that also emits the column sums of g (the bias gradient): grid (64-column tiles, row slices);
+// the block's 4 waves interleave the slice's rows, combine in LDS in wave order; gv_colsum's final kernel sums slices
+__global__ __launch_bounds__(256) void k_epilogue_bwd_colsum(const float* out, const float* gout, int act, const uint8_t* keep,
+                                                             float scale, float* g, int64_t m, int n, float* part) {
+    __shared__ float sm[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int64_t per = (m + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = blockIdx.y * per, r1 = min(m, r0 + per);
+    float acc = 0.f;
+    if (c < n) {
+        for (int64_t r = r0 + w; r < r1; r += 4) {
+            const int64_t i = r * n + c;
+            float v = gout[i];
+            if (keep) v = keep[i] ? v * scale : 0.f;
+            if (act == GV_ACT_RELU && !(out[i] > 0.f)) v = 0.f;
+            g[i] = v;
+            acc += v;
+        }
+    }
+    sm[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && c < n) part[(size_t)blockIdx.y * n + c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+}
+
 // one wave per row; int64 ids as torch's embedding takes them
 __global__ __launch_bounds__(256) void k_gather_rows(const float* table, const int64_t* ids, float* out, int64_t n,
                                                      int h) {
@@ -60,8 +85,8 @@ __device__ __forceinline__ float softplus_t(float x) {  // torch: beta=1, thresh
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ __launch_bounds__(256) void k_reparam_fwd(const float* h2, const float* eps, float* z, float* v, int64_t n,
-                                                     int h) {
+__global__ __launch_bounds__(256) void k_reparam_fwd(const float* h2, const float* eps, float* z, float* v, float* mout,
+                                                     int64_t n, int h) {
     const int64_t total = n * h;
     GV_GRID_STRIDE(i, total) {
         const int64_t r = i / h;
@@ -69,6 +94,7 @@ __global__ __launch_bounds__(256) void k_reparam_fwd(const float* h2, const floa
         const float m = h2[r * 2 * h + c];
         const float var = softplus_t(h2[r * 2 * h + h + c]) + 1e-8f;
         v[i] = var;
+        if (mout) mout[i] = m;
         z[i] = m + eps[i] * sqrtf(var);
     }
 }
@@ -193,10 +219,16 @@ extern "C" int gv_rgcn_epilogue_fwd(const float* agg, const float* addend, int a
 }
 
 extern "C" int gv_rgcn_epilogue_bwd(const float* out, const float* grad_out, int act, const uint8_t* keep,
-                                    float keep_scale, float* g, int64_t n_rows, int n_cols, void* stream) {
+                                    float keep_scale, float* g, int64_t n_rows, int n_cols, float* colsum_part,
+                                    void* stream) {
     GV_REQUIRE(grad_out && g && (act == GV_ACT_NONE || out), GV_ERR_NULL, "gv_rgcn_epilogue_bwd: NULL pointer");
     const int64_t n = n_rows * n_cols;
     if (n <= 0) return GV_OK;
+    if (colsum_part) {      // also write the 64 row-slice partials of the column sums (finish with gv_colsum_finish)
+        hipLaunchKernelGGL(k_epilogue_bwd_colsum, dim3((n_cols + 63) / 64, 64), dim3(256), 0, GV_ST, out, grad_out, act, keep,
+                           keep_scale, g, n_rows, n_cols, colsum_part);
+        return launch_status("gv_rgcn_epilogue_bwd(colsum)");
+    }
     hipLaunchKernelGGL(k_epilogue_bwd, dim3(grid_for(n, 1024)), dim3(256), 0, GV_ST, out, grad_out, act, keep,
                        keep_scale, g, n);
     return launch_status("gv_rgcn_epilogue_bwd");
@@ -217,10 +249,11 @@ extern "C" int gv_scatter_add_rows(const float* grad_out, const int64_t* ids, fl
     return launch_status("gv_scatter_add_rows");
 }
 
-extern "C" int gv_reparam_fwd(const float* h2, const float* eps, float* z, float* v, int64_t n, int h, void* stream) {
+extern "C" int gv_reparam_fwd(const float* h2, const float* eps, float* z, float* v, float* m_out, int64_t n, int h,
+                              void* stream) {
     GV_REQUIRE(h2 && eps && z && v, GV_ERR_NULL, "gv_reparam_fwd: NULL pointer");
     if (n * h <= 0) return GV_OK;
-    hipLaunchKernelGGL(k_reparam_fwd, dim3(grid_for(n * h, 1024)), dim3(256), 0, GV_ST, h2, eps, z, v, n, h);
+    hipLaunchKernelGGL(k_reparam_fwd, dim3(grid_for(n * h, 1024)), dim3(256), 0, GV_ST, h2, eps, z, v, m_out, n, h);
     return launch_status("gv_reparam_fwd");
 }
 

@@ -336,6 +336,14 @@ extern "C" int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const 
     return GV_OK;
 }
 
+extern "C" int gv_colsum_finish(const float* part, int n, float* out, int accumulate, void* stream) {
+    GV_REQUIRE(part && out, GV_ERR_NULL, "gv_colsum_finish: NULL pointer");
+    GV_REQUIRE(n > 0, GV_ERR_SHAPE, "gv_colsum_finish: n=%d", n);
+    hipLaunchKernelGGL(k_colsum_final, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, n, COLSUM_SLICES, out,
+                       accumulate);
+    return launch_status("gv_colsum_finish");
+}
+
 extern "C" int gv_colsum(const float* x, const float* relu_mask, int64_t m, int n, int ld, float* out, float* workspace,
                          int accumulate, void* stream) {
     GV_REQUIRE(x && out && workspace, GV_ERR_NULL, "gv_colsum: NULL pointer");

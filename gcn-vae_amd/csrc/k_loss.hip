@@ -113,9 +113,10 @@ constexpr int KL_KMAX = 64;   // mixture components (lane j keeps component j's 
 // one wave per node; mixture table staged in LDS once per block; CPL = columns per lane (h <= 64*CPL)
 template <int CPL>
 __global__ __launch_bounds__(256) void k_kl_fwd(const float* z, const float* m, int ld_m, const float* v,
-                                                const float* mix, const float* flp, float* resp, float* terms,
+                                                const float* mix, const float* flp, float* resp, float* part,
                                                 int64_t n, int h, int k) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float wsum[4];
     const int kh = k * h;
     if ((kh & 3) == 0) {
         for (int i = threadIdx.x; i < 3 * kh / 4; i += 256)
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void k_kl_fwd(const float* z, const float* m, 
     const int lane = threadIdx.x & 63;
     const float fl = flp ? *flp : 0.f;
     const float logk = logf((float)k);
+    float my_terms = 0.f;                       // lane 0 of each wave: sum of its nodes' terms, in node order
     for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {
         float zz[CPL];
         float a = 0.f;
@@ -162,14 +164,17 @@ __global__ __launch_bounds__(256) void k_kl_fwd(const float* z, const float* m, 
         const float e = lane < k ? expf(my_l - mx) : 0.f;
         const float se = wave_sum(e);
         if (lane < k) resp[r * k + lane] = e / se;
-        if (lane == 0) terms[r] = a + fl - (mx + logf(se) - logk);
+        my_terms += a + fl - (mx + logf(se) - logk);
     }
+    if (lane == 0) wsum[threadIdx.x >> 6] = my_terms;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
 // per-node gradients gz, gm, gv (scaled by *gkl / n)
 __global__ __launch_bounds__(256) void k_kl_bwd_nodes(const float* z, const float* m, int ld_m, const float* v,
-                                                      const float* mix, const float* resp, const float* gkl, float* gz,
-                                                      float* gm, float* gv, int64_t n, int h, int k) {
+                                                      const float* mix, const float* resp, const float* gkl, float gscale,
+                                                      float* gz, float* gm, float* gv, int64_t n, int h, int k) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int kh = k * h;
     if ((kh & 3) == 0) {
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256) void k_kl_bwd_nodes(const float* z, const floa
     const float* mu = sm;
     const float* i2v = sm + kh;
     const int lane = threadIdx.x & 63;
-    const float cg = (gkl ? *gkl : 1.f) / (float)n;
+    const float cg = gscale * (gkl ? *gkl : 1.f) / (float)n;
     for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {
         const float* rp = resp + r * k;
         for (int c = lane; c < h; c += 64) {
@@ -241,9 +246,10 @@ __global__ __launch_bounds__(256) void k_kl_bwd_mix_part(const float* z, const f
 }
 
 __global__ __launch_bounds__(256) void k_kl_bwd_mix_final(const float* part, const float* z_pre, const float* gkl,
-                                                          float* g_zpre, int64_t n, int h, int k, int nsl) {
+                                                          float gscale, float* g_zpre, int accumulate, int64_t n, int h,
+                                                          int k, int nsl) {
     const int total = 2 * k * h, kh = k * h;
-    const float cg = (gkl ? *gkl : 1.f) / (float)n;
+    const float cg = gscale * (gkl ? *gkl : 1.f) / (float)n;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int s = 0;
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(256) void k_kl_bwd_mix_final(const float* part, con
             const float raw = z_pre[i];
             acc *= raw > 20.f ? 1.f : 1.f / (1.f + expf(-raw));
         }
-        g_zpre[i] = cg * acc;
+        g_zpre[i] = accumulate ? g_zpre[i] + cg * acc : cg * acc;
     }
 }
 
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(64 * MMD_WAVES) void k_mmd_fwd(const float* x, cons
 
 template <int CPL>
 __global__ __launch_bounds__(64 * MMD_WAVES) void k_mmd_bwd(const float* x, const float* y, int sx, int sy, int h,
-                                                             const float* gmmd, float* gx, float* gy) {
+                                                             const float* gmmd, float gscale, float* gx, float* gy) {
     __shared__ float sm[MMD_WAVES][64 * CPL];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool is_x = (int)blockIdx.x < sx;
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(64 * MMD_WAVES) void k_mmd_bwd(const float* x, cons
 #pragma unroll
     for (int i = 0; i < CPL; ++i) acc[i] = 0.f;
     const float inv = 1.f / ((float)h * (float)h);
-    const float g = gmmd ? *gmmd : 1.f;
+    const float g = gscale * (gmmd ? *gmmd : 1.f);
     const int n_same = is_x ? sx : sy, n_other = is_x ? sy : sx;
     // d mmd / d a = (-2/h^2) [ (2/n_same^2) sum_j K(a,same_j)(a - same_j) - (2/(sx sy)) sum_j K(a,other_j)(a - other_j) ]
     const float c_same = g * (-2.f * inv) * 2.f / ((float)n_same * (float)n_same);
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(256) void k_prior_sample_fwd(const float* z_pre, co
 }
 
 __global__ __launch_bounds__(256) void k_prior_sample_bwd(const float* z_pre, const float* eps, const float* g, float* gz_pre,
-                                                          int s, int k, int h) {
+                                                          int accumulate, int s, int k, int h) {
     const int total = k * h;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int j = i / h, c = i - j * h;
@@ -389,8 +395,9 @@ __global__ __launch_bounds__(256) void k_prior_sample_bwd(const float* z_pre, co
             gm += g[(size_t)r * h + c];
             gs += g[(size_t)r * h + c] * eps[(size_t)r * h + c];
         }
-        gz_pre[i] = gm;
-        gz_pre[total + i] = gs * 0.5f / sqrtf(v) * (raw > 20.f ? 1.f : 1.f / (1.f + expf(-raw)));
+        const float gr = gs * 0.5f / sqrtf(v) * (raw > 20.f ? 1.f : 1.f / (1.f + expf(-raw)));
+        gz_pre[i] = accumulate ? gz_pre[i] + gm : gm;
+        gz_pre[total + i] = accumulate ? gz_pre[total + i] + gr : gr;
     }
 }
 
@@ -440,8 +447,33 @@ extern "C" int gv_mean_sq(const float* x, int64_t n, float scale, float* out, fl
     return launch_status("gv_mean_sq");
 }
 
+__global__ __launch_bounds__(256) void k_sumsq2_part(const float* x1, int64_t n1, float s1, int nb1, const float* x2,
+                                                     int64_t n2, float s2, float* part) {
+    __shared__ float sm[4];
+    const bool first = (int)blockIdx.x < nb1;
+    const float* x = first ? x1 : x2;
+    const int64_t n = first ? n1 : n2;
+    const int b = first ? blockIdx.x : blockIdx.x - nb1, nb = first ? nb1 : gridDim.x - nb1;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) acc = fmaf(x[i], x[i], acc);
+    const float tot = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot * (first ? s1 : s2);
+}
+
+extern "C" int gv_mean_sq2(const float* x1, int64_t n1, float scale1, const float* x2, int64_t n2, float scale2, float* out,
+                           float* workspace, void* stream) {
+    GV_REQUIRE(x1 && x2 && out && workspace, GV_ERR_NULL, "gv_mean_sq2: NULL pointer");
+    GV_REQUIRE(n1 > 0 && n2 > 0, GV_ERR_SHAPE, "gv_mean_sq2: empty input");
+    const int nb1 = red_blocks(n1, 4096) > 768 ? 768 : red_blocks(n1, 4096);
+    const int nb2 = red_blocks(n2, 4096) > 255 ? 255 : red_blocks(n2, 4096);
+    hipLaunchKernelGGL(k_sumsq2_part, dim3(nb1 + nb2), dim3(256), 0, GV_ST, x1, n1, scale1, nb1, x2, n2, scale2, workspace);
+    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, nb1 + nb2, 1.f, out, 0);
+    return launch_status("gv_mean_sq2");
+}
+
 extern "C" int64_t gv_kl_workspace_bytes(int64_t n, int h, int k) {
-    return (int64_t)sizeof(float) * (3 * (int64_t)k * h + n + RED_BLOCKS + (int64_t)KL_SLICES * 2 * k * h);
+    (void)n;
+    return (int64_t)sizeof(float) * (3 * (int64_t)k * h + RED_BLOCKS + (int64_t)KL_SLICES * 2 * k * h);
 }
 
 extern "C" int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre,
@@ -453,12 +485,11 @@ extern "C" int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* 
     const size_t lds = (size_t)3 * k * h * sizeof(float);
     GV_REQUIRE(lds <= 64 * 1024, GV_ERR_SHAPE, "gv_kl_fwd: mixture table %zu B exceeds the 64 KiB LDS budget", lds);
     float* mix = workspace;
-    float* terms = workspace + 3 * (size_t)k * h;
-    float* part = terms + n;
+    float* part = workspace + 3 * (size_t)k * h;
     hipLaunchKernelGGL(k_kl_mix, dim3((k * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, k, h, mix);
     const int nb = (int)((n + 3) / 4 > 1024 ? 1024 : (n + 3) / 4);
     GV_REQUIRE(h <= 1024, GV_ERR_SHAPE, "gv_kl_fwd: h=%d > 1024 unsupported", h);
-#define GV_KL_FWD(CPL_) hipLaunchKernelGGL(k_kl_fwd<CPL_>, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, flp, resp, terms, n, h, k)
+#define GV_KL_FWD(CPL_) hipLaunchKernelGGL(k_kl_fwd<CPL_>, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, flp, resp, part, n, h, k)
     if (h <= 64) GV_KL_FWD(1);
     else if (h <= 128) GV_KL_FWD(2);
     else if (h <= 256) GV_KL_FWD(4);
@@ -466,29 +497,29 @@ extern "C" int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* 
     else GV_KL_FWD(16);
 #undef GV_KL_FWD
     // mean over nodes: ordered two-pass sum of terms (reuse the sum kernel: part = terms chunks)
-    (void)part;
-    // mean over nodes: one block sums terms[] in a fixed order
-    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, terms, (int)n, 1.f / (float)n, kl, 0);
+    // mean over nodes: the per-block partials (fixed node->wave->block assignment) summed in block order
+    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, part, nb, 1.f / (float)n, kl, 0);
     return launch_status("gv_kl_fwd");
 }
 
 extern "C" int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre,
-                         const float* resp, const float* gkl, float* gz, float* gm, float* gv, float* g_zpre,
-                         float* workspace, int64_t n, int h, int k, void* stream) {
+                         const float* resp, const float* gkl, float gscale, float* gz, float* gm, float* gv,
+                         float* g_zpre, int accumulate_zpre, float* workspace, int mix_ready, int64_t n, int h, int k,
+                         void* stream) {
     GV_REQUIRE(z && m && v && z_pre && resp && gz && gm && gv && g_zpre && workspace, GV_ERR_NULL,
                "gv_kl_bwd: NULL pointer");
     GV_REQUIRE(n > 0 && h > 0 && k > 0 && k <= KL_KMAX && ld_m >= h, GV_ERR_SHAPE, "gv_kl_bwd: bad shape");
-    float* mix = workspace;  // filled by gv_kl_fwd of the same step; recomputed here to stay self-contained
-    hipLaunchKernelGGL(k_kl_mix, dim3((k * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, k, h, mix);
+    float* mix = workspace;  // mix_ready: the caller hands back the workspace gv_kl_fwd filled for the same z_pre
+    if (!mix_ready) hipLaunchKernelGGL(k_kl_mix, dim3((k * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, k, h, mix);
     const size_t lds = (size_t)2 * k * h * sizeof(float);
     const int nb = (int)((n + 3) / 4 > 1024 ? 1024 : (n + 3) / 4);
-    hipLaunchKernelGGL(k_kl_bwd_nodes, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, resp, gkl, gz, gm, gv, n,
-                       h, k);
-    float* part = workspace + 3 * (size_t)k * h + n + RED_BLOCKS;
+    hipLaunchKernelGGL(k_kl_bwd_nodes, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, resp, gkl, gscale, gz, gm,
+                       gv, n, h, k);
+    float* part = workspace + 3 * (size_t)k * h + RED_BLOCKS;
     hipLaunchKernelGGL(k_kl_bwd_mix_part, dim3(k, (h + 63) / 64, KL_SLICES), dim3(256), 0, GV_ST, z, mix, resp, part, n,
                        h, k);
     hipLaunchKernelGGL(k_kl_bwd_mix_final, dim3((2 * k * h + 255) / 256), dim3(256), 0, GV_ST, part, z_pre, gkl,
-                       g_zpre, n, h, k, KL_SLICES);
+                       gscale, g_zpre, accumulate_zpre, n, h, k, KL_SLICES);
     return launch_status("gv_kl_bwd");
 }
 
@@ -522,12 +553,12 @@ extern "C" int gv_mmd_fwd(const float* x, const float* y, int sx, int sy, int h,
     return launch_status("gv_mmd_fwd");
 }
 
-extern "C" int gv_mmd_bwd(const float* x, const float* y, int sx, int sy, int h, const float* gmmd, float* gx,
-                          float* gy, void* stream) {
+extern "C" int gv_mmd_bwd(const float* x, const float* y, int sx, int sy, int h, const float* gmmd, float gscale,
+                          float* gx, float* gy, void* stream) {
     GV_REQUIRE(x && y && gx && gy, GV_ERR_NULL, "gv_mmd_bwd: NULL pointer");
     GV_REQUIRE(sx > 0 && sy > 0 && h > 0 && h <= 1024, GV_ERR_SHAPE, "gv_mmd_bwd: bad shape");
-    if (h <= 256) hipLaunchKernelGGL(k_mmd_bwd<4>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, sx, sy, h, gmmd, gx, gy);
-    else hipLaunchKernelGGL(k_mmd_bwd<16>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, sx, sy, h, gmmd, gx, gy);
+    if (h <= 256) hipLaunchKernelGGL(k_mmd_bwd<4>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, sx, sy, h, gmmd, gscale, gx, gy);
+    else hipLaunchKernelGGL(k_mmd_bwd<16>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, sx, sy, h, gmmd, gscale, gx, gy);
     return launch_status("gv_mmd_bwd");
 }
 
@@ -538,10 +569,10 @@ extern "C" int gv_prior_sample_fwd(const float* z_pre, const float* eps, float* 
     return launch_status("gv_prior_sample_fwd");
 }
 
-extern "C" int gv_prior_sample_bwd(const float* z_pre, const float* eps, const float* g, float* gz_pre, int s, int k,
-                                   int h, void* stream) {
+extern "C" int gv_prior_sample_bwd(const float* z_pre, const float* eps, const float* g, float* gz_pre, int accumulate,
+                                   int s, int k, int h, void* stream) {
     GV_REQUIRE(z_pre && eps && g && gz_pre, GV_ERR_NULL, "gv_prior_sample_bwd: NULL pointer");
     GV_REQUIRE(s > 0 && k > 0 && h > 0, GV_ERR_SHAPE, "gv_prior_sample_bwd: bad shape");
-    hipLaunchKernelGGL(k_prior_sample_bwd, dim3((k * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, eps, g, gz_pre, s, k, h);
+    hipLaunchKernelGGL(k_prior_sample_bwd, dim3((k * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, eps, g, gz_pre, accumulate, s, k, h);
     return launch_status("gv_prior_sample_bwd");
 }

@@ -25,27 +25,29 @@ SIGNATURES = {
     'gv_rgcn_bdd_fixup': (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _F, _P, _I, _P]),
     'gv_rgcn_bdd_grad_weight': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
     'gv_rgcn_epilogue_fwd': (_I, [_P, _P, _I, _P, _F, _P, _L, _I, _P]),
-    'gv_rgcn_epilogue_bwd': (_I, [_P, _P, _I, _P, _F, _P, _L, _I, _P]),
+    'gv_rgcn_epilogue_bwd': (_I, [_P, _P, _I, _P, _F, _P, _L, _I, _P, _P]),
+    'gv_colsum_finish': (_I, [_P, _I, _P, _I, _P]),
     'gv_gemm_workspace_bytes': (_L, [_I, _I, _I, _I]),
     'gv_gemm_f32': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P]),
     'gv_colsum': (_I, [_P, _P, _L, _I, _I, _P, _P, _I, _P]),
     'gv_gather_rows': (_I, [_P, _P, _P, _L, _I, _P]),
     'gv_scatter_add_rows': (_I, [_P, _P, _P, _L, _I, _P]),
-    'gv_reparam_fwd': (_I, [_P, _P, _P, _P, _L, _I, _P]),
+    'gv_reparam_fwd': (_I, [_P, _P, _P, _P, _P, _L, _I, _P]),
     'gv_reparam_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     'gv_distmult_bce_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     'gv_bce_grad': (_I, [_P, _P, _P, _P, _P, _P, _L, _P]),
     'gv_mean_sq': (_I, [_P, _L, _F, _P, _P, _I, _P]),
+    'gv_mean_sq2': (_I, [_P, _L, _F, _P, _L, _F, _P, _P, _P]),
     'gv_axpby': (_I, [_L, _P, _F, _P, _F, _P, _P]),
     'gv_mul': (_I, [_L, _P, _P, _P, _P]),
     'gv_kl_workspace_bytes': (_L, [_L, _I, _I]),
     'gv_kl_fwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
-    'gv_kl_bwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    'gv_kl_bwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _P, _I, _L, _I, _I, _P]),
     'gv_lincomb4': (_I, [_P, _F, _P, _F, _P, _F, _P, _F, _P, _P]),
     'gv_mmd_fwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
-    'gv_mmd_bwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    'gv_mmd_bwd': (_I, [_P, _P, _I, _I, _I, _P, _F, _P, _P, _P]),
     'gv_prior_sample_fwd': (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    'gv_prior_sample_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    'gv_prior_sample_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'gv_iaf_update_fwd': (_I, [_P, _P, _I, _P, _P, _P, _L, _I, _P]),
     'gv_iaf_update_bwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     'gv_rowsum': (_I, [_P, _I, _I, _I, _P, _L, _P]),

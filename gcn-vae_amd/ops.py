@@ -26,6 +26,12 @@ DIRECT_GRAD = {}
 def _direct(t):
     tgt = DIRECT_GRAD.get(t.data_ptr()) if t is not None else None
     return tgt if (tgt is not None and tgt.shape == t.shape) else None
+
+
+def _direct_flat(t):
+    """Direct target of a contiguous VIEW of a parameter that starts at its storage (e.g. z_pre.squeeze(0))."""
+    tgt = DIRECT_GRAD.get(t.data_ptr()) if t is not None else None
+    return tgt.view(t.shape) if (tgt is not None and tgt.numel() == t.numel() and tgt.is_contiguous()) else None
 DEFAULT_CHUNK = 256        # max edges per work item of the dst/src-sorted aggregations
 DEFAULT_CHUNK_REL = 128    # max edges per work item of the by-relation weight gradient
 DIST_FWD_CHUNKS = 2        # destination-row blocks whose all-reduce overlaps the next block's aggregation
@@ -398,11 +404,16 @@ def epilogue_fwd(agg, addend, act, keep, keep_scale):
     return out
 
 
-def epilogue_bwd(out, grad_out, act, keep, keep_scale):
+def epilogue_bwd(out, grad_out, act, keep, keep_scale, colsum_out=None, colsum_accumulate=False):
+    """g = d(act/dropout epilogue); with ``colsum_out`` the same pass also yields the column sums of g (bias grad)."""
     grad_out = _chk(grad_out.contiguous(), name='grad_out')
     g = torch.empty_like(grad_out)
-    lib.call('gv_rgcn_epilogue_bwd', ptr(out), ptr(grad_out), act, ptr(keep), float(keep_scale), ptr(g),
-             grad_out.shape[0], grad_out.shape[1], lib.stream())
+    m, n = grad_out.shape
+    part = torch.empty(64 * n, dtype=torch.float32, device=g.device) if colsum_out is not None else None
+    lib.call('gv_rgcn_epilogue_bwd', ptr(out), ptr(grad_out), act, ptr(keep), float(keep_scale), ptr(g), m, n, ptr(part),
+             lib.stream())
+    if colsum_out is not None:
+        lib.call('gv_colsum_finish', ptr(part), n, ptr(colsum_out), 1 if colsum_accumulate else 0, lib.stream())
     return g
 
 
@@ -506,18 +517,20 @@ class _RelGraphConvBdd(torch.autograd.Function):
     def backward(ctx, grad_out):
         x, weight, loop_weight, coef, out, keep = ctx.saved_tensors
         gidx, ridx, nb, si, so, act, keep_scale, has_bias, reduce_hook = ctx.meta
-        g = epilogue_bwd(out, grad_out, act, keep, keep_scale)
+        d_w, d_b, d_l = ctx.direct
+        grad_bias = None
+        if has_bias and ctx.needs_input_grad[2]:         # bias gradient = column sums of g, from the same pass
+            grad_bias = d_b if d_b is not None else torch.empty(grad_out.shape[1], dtype=torch.float32, device=x.device)
+            g = epilogue_bwd(out, grad_out, act, keep, keep_scale, colsum_out=grad_bias, colsum_accumulate=d_b is not None)
+            if d_b is not None:
+                grad_bias = None
+        else:
+            g = epilogue_bwd(out, grad_out, act, keep, keep_scale)
         pending = None
         g_agg = g
         if reduce_hook is not None:      # gradient of this rank's partial aggregate = sum over ranks; overlapped below
             g_agg = g.clone()
             pending = reduce_hook(g_agg)
-        d_w, d_b, d_l = ctx.direct
-        grad_bias = None
-        if has_bias and ctx.needs_input_grad[2]:
-            grad_bias = colsum(g, out=d_b, accumulate=d_b is not None)
-            if d_b is not None:
-                grad_bias = None
         grad_loop = gx_loop = None
         if loop_weight is not None:
             if ctx.needs_input_grad[3]:
@@ -606,8 +619,8 @@ class _Reparam(torch.autograd.Function):
         eps = _chk(eps.contiguous(), name='eps')
         z = torch.empty(n, h, dtype=torch.float32, device=h2.device)
         v = torch.empty_like(z)
-        lib.call('gv_reparam_fwd', ptr(h2), ptr(eps), ptr(z), ptr(v), n, h, lib.stream())
-        m = h2[:, :h].contiguous()
+        m = torch.empty_like(z)
+        lib.call('gv_reparam_fwd', ptr(h2), ptr(eps), ptr(z), ptr(v), ptr(m), n, h, lib.stream())
         ctx.save_for_backward(h2, eps, v)
         return z, m, v
 
@@ -746,22 +759,23 @@ class _KL(torch.autograd.Function):
         kl = torch.empty((), dtype=torch.float32, device=z.device)
         lib.call('gv_kl_fwd', ptr(z), ptr(m), h, ptr(v), ptr(z_pre), ptr(flp), ptr(resp), ptr(kl), ptr(ws), n, h, k,
                  lib.stream())
-        ctx.save_for_backward(z, m, v, z_pre, resp)
+        ctx.save_for_backward(z, m, v, z_pre, resp, ws)
         ctx.has_flp = flp is not None
+        ctx.zp_version = z_pre._version
         return kl
 
     @staticmethod
     def backward(ctx, gkl):
-        z, m, v, z_pre, resp = ctx.saved_tensors
+        z, m, v, z_pre, resp, ws = ctx.saved_tensors       # ws still holds the forward's mixture table
         n, h = z.shape
         k = z_pre.shape[0] // 2
         gkl = _chk(gkl.reshape(1).contiguous(), name='gkl')
-        ws = torch.empty(int(lib.load().gv_kl_workspace_bytes(n, h, k)) // 4, dtype=torch.float32, device=z.device)
         gz, gm, gv = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
-        gzp = torch.empty_like(z_pre)
-        lib.call('gv_kl_bwd', ptr(z), ptr(m), h, ptr(v), ptr(z_pre), ptr(resp), ptr(gkl), ptr(gz), ptr(gm), ptr(gv),
-                 ptr(gzp), ptr(ws), n, h, k, lib.stream())
-        return gz, gm, gv, gzp, (gkl.reshape(()).clone() if ctx.has_flp else None)
+        d_zp = _direct_flat(z_pre)
+        gzp = d_zp if d_zp is not None else torch.empty_like(z_pre)
+        lib.call('gv_kl_bwd', ptr(z), ptr(m), h, ptr(v), ptr(z_pre), ptr(resp), ptr(gkl), 1.0, ptr(gz), ptr(gm), ptr(gv),
+                 ptr(gzp), 1 if d_zp is not None else 0, ptr(ws), 1, n, h, k, lib.stream())
+        return gz, gm, gv, (None if d_zp is not None else gzp), (gkl.reshape(()).clone() if ctx.has_flp else None)
 
 
 def kl_to_mixture(z, m, v, z_pre, flp=None):
@@ -877,7 +891,7 @@ class _MMD(torch.autograd.Function):
         x, y = ctx.saved_tensors
         g = _chk(g.reshape(1).contiguous(), name='g')
         gx, gy = torch.empty_like(x), torch.empty_like(y)
-        lib.call('gv_mmd_bwd', ptr(x), ptr(y), x.shape[0], y.shape[0], x.shape[1], ptr(g), ptr(gx), ptr(gy),
+        lib.call('gv_mmd_bwd', ptr(x), ptr(y), x.shape[0], y.shape[0], x.shape[1], ptr(g), 1.0, ptr(gx), ptr(gy),
                  lib.stream())
         return gx, gy
 
@@ -894,6 +908,7 @@ class _PriorSample(torch.autograd.Function):
         z_pre, eps = _chk(z_pre.contiguous(), name='z_pre'), _chk(eps.contiguous(), name='eps')
         k, h = z_pre.shape[0] // 2, z_pre.shape[1]
         out = torch.empty_like(eps)
+        ctx.set_materialize_grads(False)
         lib.call('gv_prior_sample_fwd', ptr(z_pre), ptr(eps), ptr(out), eps.shape[0], k, h, lib.stream())
         ctx.save_for_backward(z_pre, eps)
         return out
@@ -901,11 +916,14 @@ class _PriorSample(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         z_pre, eps = ctx.saved_tensors
+        if g is None:
+            return None, None
         g = _chk(g.contiguous(), name='g')
-        gz = torch.empty_like(z_pre)
-        lib.call('gv_prior_sample_bwd', ptr(z_pre), ptr(eps), ptr(g), ptr(gz), eps.shape[0], z_pre.shape[0] // 2,
-                 z_pre.shape[1], lib.stream())
-        return gz, None
+        d_zp = _direct_flat(z_pre)
+        gz = d_zp if d_zp is not None else torch.empty_like(z_pre)
+        lib.call('gv_prior_sample_bwd', ptr(z_pre), ptr(eps), ptr(g), ptr(gz), 1 if d_zp is not None else 0, eps.shape[0],
+                 z_pre.shape[0] // 2, z_pre.shape[1], lib.stream())
+        return (None if d_zp is not None else gz), None
 
 
 def prior_sample(z_pre, eps):
@@ -964,8 +982,11 @@ class _LossHead(torch.autograd.Function):
             if mmd_w > 0:
                 lib.call('gv_gather_rows', ptr(z), ptr(pick), ptr(z_post), pick.numel(), h, st2)
                 lib.call('gv_mmd_fwd', ptr(z_pri), ptr(z_post), z_pri.shape[0], z_post.shape[0], h, ptr(mmd), ptr(wsm), st2)
-            lib.call('gv_mean_sq', ptr(z), z.numel(), 1.0 / z.numel(), ptr(reg), ptr(ws2), 0, st2)
-            lib.call('gv_mean_sq', ptr(w_rel), w_rel.numel(), 1.0 / w_rel.numel(), ptr(reg), ptr(ws2), 1, st2)
+            if ld_z == h and ld_w == h:
+                lib.call('gv_mean_sq2', ptr(z), z.numel(), 1.0 / z.numel(), ptr(w_rel), w_rel.numel(), 1.0 / w_rel.numel(),
+                         ptr(reg), ptr(ws2), st2)
+            else:
+                raise ValueError('loss_head needs contiguous embeddings and relation table')
         # main: DistMult scorer + BCE (three 800-B row gathers per triplet: the bandwidth-bound part)
         st = lib.stream()
         lib.call('gv_distmult_bce_fwd', ptr(z), ld_z, ptr(w_rel), ld_w, ptr(tidx.trip32), ptr(labels), ptr(bias),
@@ -975,7 +996,7 @@ class _LossHead(torch.autograd.Function):
                  ptr(mmd) if mmd_w > 0 else None, float(mmd_w), ptr(loss), st)
         ctx.save_for_backward(z, z_mean if kl_w > 0 else None, z_sigma if kl_w > 0 else None, w_rel,
                               z_pre if kl_w > 0 else None, resp, z_pri if mmd_w > 0 else None, z_post,
-                              pick if mmd_w > 0 else None, labels, score)
+                              pick if mmd_w > 0 else None, labels, score, wsk)
         ctx.meta = (tidx, float(reg_w), float(kl_w), float(mmd_w), bias is not None, flp is not None and kl_w > 0)
         ctx.direct_w = _direct(w_rel) if ld_w == h else None
         out_pred, out_kl, out_mmd = pred.reshape(()), kl.reshape(1), mmd.reshape(())
@@ -986,7 +1007,7 @@ class _LossHead(torch.autograd.Function):
     def backward(ctx, g, _gp, _gk, _gm):
         if g is None:
             return (None,) * 14
-        z, z_mean, z_sigma, w_rel, z_pre, resp, z_pri, z_post, pick, labels, score = ctx.saved_tensors
+        z, z_mean, z_sigma, w_rel, z_pre, resp, z_pri, z_post, pick, labels, score, wsk = ctx.saved_tensors
         tidx, reg_w, kl_w, mmd_w, has_bias, flp_in_kl = ctx.meta
         dev, (n, h), T = z.device, z.shape, tidx.T
         f32 = dict(dtype=torch.float32, device=dev)
@@ -995,35 +1016,32 @@ class _LossHead(torch.autograd.Function):
         dscore = torch.empty(T, **f32)
         dbias = torch.zeros((), **f32) if has_bias else None
         ws = torch.empty(1024, **f32)
-        gsc = torch.empty(2, **f32) if (kl_w > 0 or mmd_w > 0) else None     # g*kl_w, g*mmd_w as device scalars
         gz = torch.empty_like(z)
-        gm = gv = gzp = wsk = g_pri = g_post = None
+        gm = gv = gzp = d_zp = g_pri = g_post = None
         if kl_w > 0:
-            k = z_pre.shape[0] // 2
-            wsk = torch.empty(int(lib.load().gv_kl_workspace_bytes(n, h, k)) // 4, **f32)
-            gm, gv, gzp = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z_pre)
+            k = z_pre.shape[0] // 2                       # wsk: the forward's workspace, mixture table still valid
+            d_zp = _direct_flat(z_pre)
+            gm, gv = torch.empty_like(z), torch.empty_like(z)
+            gzp = d_zp if d_zp is not None else torch.empty_like(z_pre)
         if mmd_w > 0:
             g_pri, g_post = torch.empty_like(z_pri), torch.empty_like(z_post)
         d_w = ctx.direct_w
         g_w = d_w if d_w is not None else torch.empty_like(w_rel)
         g_flp = torch.empty((), **f32) if (has_bias or flp_in_kl) else None
         st = lib.stream()
-        if gsc is not None:
-            lib.call('gv_lincomb4', ptr(g), kl_w, None, 0.0, None, 0.0, None, 0.0, ptr(gsc[0:1]), st)
-            lib.call('gv_lincomb4', ptr(g), mmd_w, None, 0.0, None, 0.0, None, 0.0, ptr(gsc[1:2]), st)
         # branch 1: KL backward (writes gz, gm, gv, gzp), then the regulariser folded into gz
         with fork(1):
             s1 = lib.stream()
             if kl_w > 0:
-                lib.call('gv_kl_bwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(resp), ptr(gsc[0:1]), ptr(gz),
-                         ptr(gm), ptr(gv), ptr(gzp), ptr(wsk), n, h, k, s1)
+                lib.call('gv_kl_bwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(resp), ptr(g), kl_w, ptr(gz),
+                         ptr(gm), ptr(gv), ptr(gzp), 1 if d_zp is not None else 0, ptr(wsk), 1, n, h, k, s1)
                 lib.call('gv_axpby', z.numel(), ptr(g), 2.0 * reg_w / z.numel(), ptr(z), 1.0, ptr(gz), s1)
             else:
                 lib.call('gv_axpby', z.numel(), ptr(g), 2.0 * reg_w / z.numel(), ptr(z), 0.0, ptr(gz), s1)
         # branch 2: MMD backward
         if mmd_w > 0:
             with fork(2):
-                lib.call('gv_mmd_bwd', ptr(z_pri), ptr(z_post), z_pri.shape[0], z_post.shape[0], h, ptr(gsc[1:2]),
+                lib.call('gv_mmd_bwd', ptr(z_pri), ptr(z_post), z_pri.shape[0], z_post.shape[0], h, ptr(g), mmd_w,
                          ptr(g_pri), ptr(g_post), lib.stream())
         # main: dL/dscore, then the relation-side gradient (does not need gz)
         lib.call('gv_bce_grad', ptr(score), ptr(labels), ptr(g), ptr(dscore), ptr(dbias), ptr(ws), T, st)
@@ -1038,8 +1056,8 @@ class _LossHead(torch.autograd.Function):
         if g_flp is not None:
             lib.call('gv_lincomb4', ptr(dbias) if has_bias else None, 1.0, ptr(g) if flp_in_kl else None, kl_w, None, 0.0,
                      None, 0.0, ptr(g_flp), st)
-        return (g_z, gm, gv, (None if d_w is not None else g_w), gzp, g_flp, g_pri, None, None, None, None, None, None,
-                None)
+        return (g_z, gm, gv, (None if d_w is not None else g_w), (None if d_zp is not None else gzp), g_flp, g_pri, None,
+                None, None, None, None, None, None)
 
 
 def loss_head(z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, reg_w, kl_w, mmd_w, score_bias):

@@ -104,7 +104,11 @@ int gv_rgcn_bdd_grad_weight(const int32_t* items, int n_items, const int32_t* fi
 int gv_rgcn_epilogue_fwd(const float* agg, const float* addend, int act, const uint8_t* keep, float keep_scale,
                          float* out, int64_t n_rows, int n_cols, void* stream);
 int gv_rgcn_epilogue_bwd(const float* out, const float* grad_out, int act, const uint8_t* keep, float keep_scale,
-                         float* g, int64_t n_rows, int n_cols, void* stream);
+                         float* g, int64_t n_rows, int n_cols, float* colsum_part /* optional: 64*n_cols floats */,
+                         void* stream);
+/* colsum_part != NULL: the same pass also writes 64 row-slice partials of the column sums of g (the bias gradient);
+ * gv_colsum_finish(part, n_cols, out, accumulate) sums them in slice order. */
+int gv_colsum_finish(const float* part, int n, float* out, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K2/K4  dense fp32 GEMM on the f32 MFMA (v_mfma_f32_32x32x2_f32; exact fp32 fma chain):
@@ -132,7 +136,8 @@ int gv_scatter_add_rows(const float* grad_out, const int64_t* ids, float* grad_t
  * K3  Gaussian parameters + reparameterisation (kgvae/utils.py:323-361, kgvae/model.py:112-113)
  *   m = h2[:, :h]; v = softplus(h2[:, h:]) + 1e-8; z = m + eps*sqrt(v)
  * bwd: grad_h2[:, :h] = gz + gm ; grad_h2[:, h:] = (gz*eps/(2 sqrt v) + gv) * sigmoid(raw)   (gm, gv optional) */
-int gv_reparam_fwd(const float* h2, const float* eps, float* z, float* v, int64_t n, int h, void* stream);
+int gv_reparam_fwd(const float* h2, const float* eps, float* z, float* v, float* m_out /* optional contiguous copy of m */,
+                   int64_t n, int h, void* stream);
 int gv_reparam_bwd(const float* h2, const float* eps, const float* v, const float* gz, const float* gm,
                    const float* gv, float* grad_h2, int64_t n, int h, void* stream);
 
@@ -159,14 +164,19 @@ int gv_bce_grad(const float* score, const float* labels, const float* gloss, flo
  *     bwd: gz, gm, gv [n,h] (overwritten), g_zpre [2k,h] (overwritten, deterministic 2-pass), scaled by *gkl.
  */
 int gv_mean_sq(const float* x, int64_t n, float scale, float* out, float* workspace, int accumulate, void* stream);
+/* *out = scale1*sum(x1^2) + scale2*sum(x2^2) in one pass pair (the two regulariser terms); workspace: 1024 floats */
+int gv_mean_sq2(const float* x1, int64_t n1, float scale1, const float* x2, int64_t n2, float scale2, float* out,
+                float* workspace, void* stream);
 int gv_axpby(int64_t n, const float* a, float alpha, const float* x, float beta, float* y, void* stream);
 int gv_mul(int64_t n, const float* a, const float* b, float* out, void* stream);
 int64_t gv_kl_workspace_bytes(int64_t n, int h, int k);
 int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre, const float* flp,
               float* resp, float* kl, float* workspace, int64_t n, int h, int k, void* stream);
 int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre, const float* resp,
-              const float* gkl, float* gz, float* gm, float* gv, float* g_zpre, float* workspace, int64_t n, int h,
-              int k, void* stream);
+              const float* gkl, float gscale, float* gz, float* gm, float* gv, float* g_zpre, int accumulate_zpre,
+              float* workspace, int mix_ready, int64_t n, int h, int k, void* stream);
+/* upstream gradient = gscale * (*gkl); accumulate_zpre adds into g_zpre; mix_ready = 1 when `workspace` is the one
+ * gv_kl_fwd filled for the same z_pre (skips recomputing the mixture table). */
 
 /*   gv_mmd_*  : KGVAE.get_mmd / compute_kernel (kgvae/model.py:71-80, :89-102) on x = prior samples (sx, h),
  *       y = posterior rows (sy, h):  K(a,b) = exp(-mean_d (a_d-b_d)^2 / h);  mmd = mean Kxx + mean Kyy - 2 mean Kxy.
@@ -178,11 +188,11 @@ int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* v, const fl
 int gv_lincomb4(const float* a0, float c0, const float* a1, float c1, const float* a2, float c2, const float* a3,
                 float c3, float* out, void* stream);
 int gv_mmd_fwd(const float* x, const float* y, int sx, int sy, int h, float* mmd, float* workspace, void* stream);
-int gv_mmd_bwd(const float* x, const float* y, int sx, int sy, int h, const float* gmmd, float* gx, float* gy,
-               void* stream);
+int gv_mmd_bwd(const float* x, const float* y, int sx, int sy, int h, const float* gmmd, float gscale, float* gx,
+               float* gy, void* stream);
 int gv_prior_sample_fwd(const float* z_pre, const float* eps, float* out, int s, int k, int h, void* stream);
-int gv_prior_sample_bwd(const float* z_pre, const float* eps, const float* g, float* gz_pre, int s, int k, int h,
-                        void* stream);
+int gv_prior_sample_bwd(const float* z_pre, const float* eps, const float* g, float* gz_pre, int accumulate, int s, int k,
+                        int h, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4  IAF / MADE update step (kgvae/flow_network.py:93-96); the masked linears are gv_gemm_f32.
