@@ -111,7 +111,48 @@ def bench_k1(chunk=256, chunk_rel=128):
         print(f'grad-W    {si}x{so}: {t:7.1f} us  {by / t / 1e3:7.1f} GB/s algorithmic')
 
 
+def probe_k1():
+    """Where does K1's time go?  Re-times the forward/backward-x aggregations with (a) every edge on relation 0
+    (weights then hit the per-CU cache), (b) every edge reading node 0 (features cached), (c) both."""
+    from gcn_vae_amd import sampling
+    from gcn_vae_amd.data import FB15K237, synthetic_kg
+    cfg = FB15K237
+    data = synthetic_kg(cfg['num_nodes'], cfg['num_rels'], cfg['n_train'], seed=0)
+    g, rel, node_norm = sampling.build_test_graph(data.num_nodes, data.num_rels, data.train)
+    src, dst = g.edges()
+    N, R = data.num_nodes, 2 * data.num_rels
+    gidx = ops.GraphIndex(src.cuda(), dst.cuda(), N)
+    ridx = ops.RelationIndex(gidx, torch.from_numpy(rel).cuda(), R)
+    norm = torch.from_numpy(node_norm).cuda()[dst.cuda()].contiguous()
+    for (fin, fout) in ((200, 200), (200, 400)):
+        nb = 100
+        si, so = fin // nb, fout // nb
+        pad = int(os.environ.get('MB_PAD', '0'))
+        x = torch.randn(N, fin, device='cuda')
+        gg = torch.randn(N, fout, device='cuda')
+        if pad:                                  # rows start on `pad`-float boundaries (ld > row length)
+            x = torch.randn(N, -(-fin // pad) * pad, device='cuda')[:, :fin]
+            gg = torch.randn(N, -(-fout // pad) * pad, device='cuda')[:, :fout]
+        w = torch.randn(R, nb * si * so, device='cuda')
+        wp = ops.pack_weight(w, nb, si, so) if (ops.pack_supported(nb, si, so, False) and si * so >= 8) else None
+        wpt = ops.pack_weight(w, nb, so, si, True) if (ops.pack_supported(nb, so, si, True) and si * so >= 8) else None
+        for tag, et_d, nb_d, et_s, nb_s in (
+                ('as is        ', ridx.et_by_dst, gidx.nbr_by_dst, ridx.et_by_src, gidx.nbr_by_src),
+                ('one relation ', torch.zeros_like(ridx.et_by_dst), gidx.nbr_by_dst, torch.zeros_like(ridx.et_by_src), gidx.nbr_by_src),
+                ('one neighbour', ridx.et_by_dst, torch.zeros_like(gidx.nbr_by_dst), ridx.et_by_src, torch.zeros_like(gidx.nbr_by_src)),
+                ('both         ', torch.zeros_like(ridx.et_by_dst), torch.zeros_like(gidx.nbr_by_dst), torch.zeros_like(ridx.et_by_src),
+                 torch.zeros_like(gidx.nbr_by_src))):
+            tf = timeit(lambda: ops.bdd_aggregate(gidx.by_dst.seg, nb_d, et_d, norm, gidx.by_dst.perm, x,
+                                                  wp if wp is not None else w, nb, si, so, False, None, 0, packed=wp is not None))
+            tb = timeit(lambda: ops.bdd_aggregate(gidx.by_src.seg, nb_s, et_s, norm, gidx.by_src.perm, gg,
+                                                  wpt if wpt is not None else w, nb, so, si, True, packed=wpt is not None))
+            print(f'{si}x{so} {tag}: fwd {tf:6.1f} us   bwd-x {tb:6.1f} us')
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'probe':
+        probe_k1()
+        sys.exit(0)
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     if what in ('gemm', 'all'):
         bench_gemm()
