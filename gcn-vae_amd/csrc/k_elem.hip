@@ -34,29 +34,50 @@ __global__ __launch_bounds__(256) void k_epilogue_bwd(const float* out, const fl
     }
 }
 
-// epilogue backward that also emits the column sums of g (the bias gradient): grid (64-column tiles, row slices);
-// the block's 4 waves interleave the slice's rows, combine in LDS in wave order; gv_colsum's final kernel sums slices
-__global__ __launch_bounds__(256) void k_epilogue_bwd_colsum(const float* out, const float* gout, int act, const uint8_t* keep,
-                                                             float scale, float* g, int64_t m, int n, float* part) {
-    __shared__ float sm[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    const int64_t per = (m + gridDim.y - 1) / gridDim.y;
-    const int64_t r0 = blockIdx.y * per, r1 = min(m, r0 + per);
-    float acc = 0.f;
-    if (c < n) {
-        for (int64_t r = r0 + w; r < r1; r += 4) {
-            const int64_t i = r * n + c;
-            float v = gout[i];
-            if (keep) v = keep[i] ? v * scale : 0.f;
-            if (act == GV_ACT_RELU && !(out[i] > 0.f)) v = 0.f;
-            g[i] = v;
-            acc += v;
+// epilogue backward that also emits the column sums of g (the bias gradient).  Block b owns a contiguous row range;
+// a thread owns one float4 column group and every (256 / groups)-th row of the range, so each pass of the block is a
+// coalesced sweep of whole rows; the row lanes' sums are combined through LDS in lane order and written as slice b
+// of `part` (EPI_SLICES x n); gv_colsum_finish adds the slices in order.
+constexpr int EPI_SLICES = 256;
+__global__ __launch_bounds__(256) void k_epilogue_bwd_colsum(const float* __restrict__ out, const float* __restrict__ gout,
+                                                             int act, const uint8_t* __restrict__ keep, float scale,
+                                                             float* __restrict__ g, int64_t m, int n, float* part) {
+    __shared__ float4 sm[256];
+    const int groups = n >> 2;                                  // float4 column groups per row (n % 4 == 0, <= 256)
+    const int rows_par = 256 / groups;
+    const int rl = threadIdx.x / groups, cg = threadIdx.x - rl * groups;
+    const int64_t per = (m + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = blockIdx.x * per, r1 = min(m, r0 + per);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rl < rows_par) {
+        for (int64_t r = r0 + rl; r < r1; r += rows_par) {
+            const int64_t i = r * n + 4 * cg;
+            float4 v = *reinterpret_cast<const float4*>(gout + i);
+            if (keep) {
+                const uchar4 k4 = *reinterpret_cast<const uchar4*>(keep + i);
+                v.x = k4.x ? v.x * scale : 0.f; v.y = k4.y ? v.y * scale : 0.f;
+                v.z = k4.z ? v.z * scale : 0.f; v.w = k4.w ? v.w * scale : 0.f;
+            }
+            if (act == GV_ACT_RELU) {
+                const float4 o = *reinterpret_cast<const float4*>(out + i);
+                if (!(o.x > 0.f)) v.x = 0.f;
+                if (!(o.y > 0.f)) v.y = 0.f;
+                if (!(o.z > 0.f)) v.z = 0.f;
+                if (!(o.w > 0.f)) v.w = 0.f;
+            }
+            *reinterpret_cast<float4*>(g + i) = v;
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
+        sm[threadIdx.x] = acc;
     }
-    sm[w][lane] = acc;
     __syncthreads();
-    if (w == 0 && c < n) part[(size_t)blockIdx.y * n + c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+    if (rl == 0) {
+        for (int k = 1; k < rows_par; ++k) {
+            const float4 t = sm[k * groups + cg];
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * n + 4 * cg) = acc;
+    }
 }
 
 // one wave per row; int64 ids as torch's embedding takes them
@@ -184,11 +205,41 @@ __global__ __launch_bounds__(256) void k_reverse_cols(const float* x, float* out
     }
 }
 
-__global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m, float* v, int64_t n,
-                                              const float* sumsq, float max_norm, float lr, float b1, float b2,
-                                              float eps, const float* step) {
+// first pass of the gradient norm: per-block sums of g^2 into part[]; thread 0 of block 0 also advances the
+// optimiser's step counter (nothing else reads it during this launch)
+__global__ __launch_bounds__(256) void k_gradsq_part(const float* g, int64_t n, float* part, float* step) {
+    __shared__ float sm[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc = fmaf(g[i], g[i], acc);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+        if (step && blockIdx.x == 0) *step += 1.f;
+    }
+}
+
+// Adam over the flat arena.  n_part > 0: every block first adds the n_part partial sums of g^2 in index order (the
+// second pass of the norm, no separate launch) and block 0 publishes the total; zero_g: the gradient is cleared as it
+// is consumed (the next step's zero_grad).
+__global__ __launch_bounds__(256) void k_adam(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq,
+                                              const float* part, int n_part, float* sumsq_out, float max_norm, float lr,
+                                              float b1, float b2, float eps, const float* step, int zero_g) {
+    __shared__ float sm[4];
     float clip = 1.f;
-    if (sumsq && max_norm > 0.f) clip = fminf(1.f, max_norm / (sqrtf(*sumsq) + 1e-6f));
+    if (part && n_part > 0) {
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < n_part; i += 256) acc += part[i];
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        const float tot = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+        if (sumsq_out && blockIdx.x == 0 && threadIdx.x == 0) *sumsq_out = tot;
+        if (max_norm > 0.f) clip = fminf(1.f, max_norm / (sqrtf(tot) + 1e-6f));
+    } else if (sumsq && max_norm > 0.f) {
+        clip = fminf(1.f, max_norm / (sqrtf(*sumsq) + 1e-6f));
+    }
     const float t = *step;
     const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
     const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
@@ -199,6 +250,7 @@ __global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m
         m[i] = mi;
         v[i] = vi;
         p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        if (zero_g) g[i] = 0.f;
     }
 }
 
@@ -224,9 +276,13 @@ extern "C" int gv_rgcn_epilogue_bwd(const float* out, const float* grad_out, int
     GV_REQUIRE(grad_out && g && (act == GV_ACT_NONE || out), GV_ERR_NULL, "gv_rgcn_epilogue_bwd: NULL pointer");
     const int64_t n = n_rows * n_cols;
     if (n <= 0) return GV_OK;
-    if (colsum_part) {      // also write the 64 row-slice partials of the column sums (finish with gv_colsum_finish)
-        hipLaunchKernelGGL(k_epilogue_bwd_colsum, dim3((n_cols + 63) / 64, 64), dim3(256), 0, GV_ST, out, grad_out, act, keep,
-                           keep_scale, g, n_rows, n_cols, colsum_part);
+    if (colsum_part) {      // also write GV_EPILOGUE_COLSUM_SLICES row-slice partials of the column sums
+        GV_REQUIRE(n_cols % 4 == 0 && n_cols <= 1024 && aligned16(grad_out) && aligned16(g) && (!out || aligned16(out)) &&
+                       aligned16(colsum_part) && (!keep || (reinterpret_cast<uintptr_t>(keep) & 3u) == 0),
+                   GV_ERR_ALIGN, "gv_rgcn_epilogue_bwd(colsum): needs n_cols %% 4 == 0, n_cols <= 1024 and aligned buffers");
+        static_assert(EPI_SLICES == GV_EPILOGUE_COLSUM_SLICES, "header constant");
+        hipLaunchKernelGGL(k_epilogue_bwd_colsum, dim3(EPI_SLICES), dim3(256), 0, GV_ST, out, grad_out, act, keep, keep_scale,
+                           g, n_rows, n_cols, colsum_part);
         return launch_status("gv_rgcn_epilogue_bwd(colsum)");
     }
     hipLaunchKernelGGL(k_epilogue_bwd, dim3(grid_for(n, 1024)), dim3(256), 0, GV_ST, out, grad_out, act, keep,
@@ -319,7 +375,20 @@ extern "C" int gv_adam_step(float* p, const float* g, float* exp_avg, float* exp
                             const float* step, void* stream) {
     GV_REQUIRE(p && g && exp_avg && exp_avg_sq && step, GV_ERR_NULL, "gv_adam_step: NULL pointer");
     if (n <= 0) return GV_OK;
-    hipLaunchKernelGGL(k_adam, dim3(grid_for(n, 1024)), dim3(256), 0, GV_ST, p, g, exp_avg, exp_avg_sq, n, sumsq,
-                       max_norm, lr, beta1, beta2, eps, step);
+    hipLaunchKernelGGL(k_adam, dim3(grid_for(n, 1024)), dim3(256), 0, GV_ST, p, const_cast<float*>(g), exp_avg, exp_avg_sq,
+                       n, sumsq, (const float*)nullptr, 0, (float*)nullptr, max_norm, lr, beta1, beta2, eps, step, 0);
     return launch_status("gv_adam_step");
+}
+
+extern "C" int gv_clip_adam_step(float* p, float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float* workspace,
+                                 float* sumsq_out, float max_norm, float lr, float beta1, float beta2, float eps,
+                                 float* step, int zero_grad, void* stream) {
+    GV_REQUIRE(p && g && exp_avg && exp_avg_sq && step && workspace, GV_ERR_NULL, "gv_clip_adam_step: NULL pointer");
+    if (n <= 0) return GV_OK;
+    int64_t nb64 = (n + 4095) / 4096;
+    const int nb = (int)(nb64 < 1 ? 1 : (nb64 > 1024 ? 1024 : nb64));
+    hipLaunchKernelGGL(k_gradsq_part, dim3(nb), dim3(256), 0, GV_ST, g, n, workspace, step);
+    hipLaunchKernelGGL(k_adam, dim3(grid_for(n, 1024)), dim3(256), 0, GV_ST, p, g, exp_avg, exp_avg_sq, n,
+                       (const float*)nullptr, workspace, nb, sumsq_out, max_norm, lr, beta1, beta2, eps, step, zero_grad);
+    return launch_status("gv_clip_adam_step");
 }

@@ -25,6 +25,33 @@ __global__ __launch_bounds__(256) void k_final_sum(const float* part, int n, flo
     if (threadIdx.x == 0) *out = accumulate ? *out + scale * tot : scale * tot;
 }
 
+// the four loss terms' final sums and their weighted combination in one block:
+//   scal = {s0*sum(p0), s1*sum(p1), s2*sum(p2), s3*sum(p3)},  loss = scal[0] + w1*scal[1] + w2*scal[2] + w3*scal[3]
+__global__ __launch_bounds__(256) void k_loss_combine(const float* p0, int n0, float s0, const float* p1, int n1, float s1,
+                                                      const float* p2, int n2, float s2, const float* p3, int n3, float s3,
+                                                      float w1, float w2, float w3, float* scal, float* loss) {
+    __shared__ float sm[4];
+    const float* ps[4] = {p0, p1, p2, p3};
+    const int ns[4] = {n0, n1, n2, n3};
+    const float ss[4] = {s0, s1, s2, s3};
+    float term[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float acc = 0.f;
+        if (ps[j])
+            for (int i = threadIdx.x; i < ns[j]; i += 256) acc += ps[j][i];
+        term[j] = ss[j] * block_sum_256(acc, sm);
+    }
+    if (threadIdx.x == 0) {
+        if (scal) { scal[0] = term[0]; scal[1] = term[1]; scal[2] = term[2]; scal[3] = term[3]; }
+        float v = term[0];
+        if (p1) v += w1 * term[1];
+        if (p2) v += w2 * term[2];
+        if (p3) v += w3 * term[3];
+        *loss = v;
+    }
+}
+
 // ---- DistMult: 16 lanes per triplet (4 triplets per wave); three 800-B row gathers per triplet
 __global__ __launch_bounds__(256) void k_distmult_bce(const float* e, int ld_e, const float* w, int ld_w,
                                                       const int* trip, const float* labels, const float* bias,
@@ -414,16 +441,23 @@ static int red_blocks(int64_t n, int per_block) {
     return (int)(b < 1 ? 1 : (b > RED_BLOCKS ? RED_BLOCKS : b));
 }
 
+static int sq2_blocks(int64_t n, int cap) {
+    const int b = red_blocks(n, 4096);
+    return b > cap ? cap : b;
+}
+
+static int kl_blocks(int64_t n) { return (int)((n + 3) / 4 > RED_BLOCKS ? RED_BLOCKS : (n + 3) / 4); }
+
 extern "C" int gv_distmult_bce_fwd(const float* embed, int ld_e, const float* w_rel, int ld_w,
                                    const int32_t* triplets, const float* labels, const float* bias, float* score,
                                    float* loss, float* workspace, int64_t t, int h, void* stream) {
-    GV_REQUIRE(embed && w_rel && triplets && labels && score && loss && workspace, GV_ERR_NULL,
+    GV_REQUIRE(embed && w_rel && triplets && labels && score && workspace, GV_ERR_NULL,
                "gv_distmult_bce_fwd: NULL pointer");
     GV_REQUIRE(t > 0 && h > 0 && ld_e >= h && ld_w >= h, GV_ERR_SHAPE, "gv_distmult_bce_fwd: bad shape");
     const int nb = red_blocks(t, 16);
     hipLaunchKernelGGL(k_distmult_bce, dim3(nb), dim3(256), 0, GV_ST, embed, ld_e, w_rel, ld_w, triplets, labels, bias,
                        score, workspace, t, h);
-    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, nb, 1.f / (float)t, loss, 0);
+    if (loss) hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, nb, 1.f / (float)t, loss, 0);
     return launch_status("gv_distmult_bce_fwd");
 }
 
@@ -462,12 +496,11 @@ __global__ __launch_bounds__(256) void k_sumsq2_part(const float* x1, int64_t n1
 
 extern "C" int gv_mean_sq2(const float* x1, int64_t n1, float scale1, const float* x2, int64_t n2, float scale2, float* out,
                            float* workspace, void* stream) {
-    GV_REQUIRE(x1 && x2 && out && workspace, GV_ERR_NULL, "gv_mean_sq2: NULL pointer");
+    GV_REQUIRE(x1 && x2 && workspace, GV_ERR_NULL, "gv_mean_sq2: NULL pointer");
     GV_REQUIRE(n1 > 0 && n2 > 0, GV_ERR_SHAPE, "gv_mean_sq2: empty input");
-    const int nb1 = red_blocks(n1, 4096) > 768 ? 768 : red_blocks(n1, 4096);
-    const int nb2 = red_blocks(n2, 4096) > 255 ? 255 : red_blocks(n2, 4096);
+    const int nb1 = sq2_blocks(n1, 768), nb2 = sq2_blocks(n2, 255);
     hipLaunchKernelGGL(k_sumsq2_part, dim3(nb1 + nb2), dim3(256), 0, GV_ST, x1, n1, scale1, nb1, x2, n2, scale2, workspace);
-    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, nb1 + nb2, 1.f, out, 0);
+    if (out) hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, nb1 + nb2, 1.f, out, 0);
     return launch_status("gv_mean_sq2");
 }
 
@@ -479,7 +512,7 @@ extern "C" int64_t gv_kl_workspace_bytes(int64_t n, int h, int k) {
 extern "C" int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre,
                          const float* flp, float* resp, float* kl, float* workspace, int64_t n, int h, int k,
                          void* stream) {
-    GV_REQUIRE(z && m && v && z_pre && resp && kl && workspace, GV_ERR_NULL, "gv_kl_fwd: NULL pointer");
+    GV_REQUIRE(z && m && v && z_pre && resp && workspace, GV_ERR_NULL, "gv_kl_fwd: NULL pointer");
     GV_REQUIRE(n > 0 && h > 0 && k > 0 && k <= KL_KMAX && ld_m >= h, GV_ERR_SHAPE, "gv_kl_fwd: n=%lld h=%d k=%d",
                (long long)n, h, k);
     const size_t lds = (size_t)3 * k * h * sizeof(float);
@@ -487,7 +520,7 @@ extern "C" int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* 
     float* mix = workspace;
     float* part = workspace + 3 * (size_t)k * h;
     hipLaunchKernelGGL(k_kl_mix, dim3((k * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, k, h, mix);
-    const int nb = (int)((n + 3) / 4 > 1024 ? 1024 : (n + 3) / 4);
+    const int nb = kl_blocks(n);
     GV_REQUIRE(h <= 1024, GV_ERR_SHAPE, "gv_kl_fwd: h=%d > 1024 unsupported", h);
 #define GV_KL_FWD(CPL_) hipLaunchKernelGGL(k_kl_fwd<CPL_>, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, flp, resp, part, n, h, k)
     if (h <= 64) GV_KL_FWD(1);
@@ -496,9 +529,8 @@ extern "C" int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* 
     else if (h <= 512) GV_KL_FWD(8);
     else GV_KL_FWD(16);
 #undef GV_KL_FWD
-    // mean over nodes: ordered two-pass sum of terms (reuse the sum kernel: part = terms chunks)
     // mean over nodes: the per-block partials (fixed node->wave->block assignment) summed in block order
-    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, part, nb, 1.f / (float)n, kl, 0);
+    if (kl) hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, part, nb, 1.f / (float)n, kl, 0);
     return launch_status("gv_kl_fwd");
 }
 
@@ -544,13 +576,28 @@ extern "C" int gv_lincomb4(const float* a0, float c0, const float* a1, float c1,
 
 extern "C" int gv_mmd_fwd(const float* x, const float* y, int sx, int sy, int h, float* mmd, float* workspace,
                           void* stream) {
-    GV_REQUIRE(x && y && mmd && workspace, GV_ERR_NULL, "gv_mmd_fwd: NULL pointer");
+    GV_REQUIRE(x && y && workspace, GV_ERR_NULL, "gv_mmd_fwd: NULL pointer");
     GV_REQUIRE(sx > 0 && sy > 0 && h > 0 && h <= 1024 && sx + sy <= RED_BLOCKS, GV_ERR_SHAPE,
                "gv_mmd_fwd: sx=%d sy=%d h=%d (need h <= 1024, sx+sy <= %d)", sx, sy, h, RED_BLOCKS);
     if (h <= 256) hipLaunchKernelGGL(k_mmd_fwd<4>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, sx, sy, h, workspace);
     else hipLaunchKernelGGL(k_mmd_fwd<16>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, sx, sy, h, workspace);
-    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, sx + sy, 1.f, mmd, 0);
+    if (mmd) hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, sx + sy, 1.f, mmd, 0);
     return launch_status("gv_mmd_fwd");
+}
+
+extern "C" int gv_loss_combine(const float* ws_pred, int64_t t, const float* ws_reg, int64_t n_embed, int64_t n_wrel,
+                               const float* ws_kl, int64_t n_nodes, int h, int k, const float* ws_mmd, int sx, int sy,
+                               float reg_w, float kl_w, float mmd_w, float* scal, float* loss, void* stream) {
+    GV_REQUIRE(ws_pred && loss, GV_ERR_NULL, "gv_loss_combine: NULL pointer");
+    GV_REQUIRE(t > 0, GV_ERR_SHAPE, "gv_loss_combine: t=%lld", (long long)t);
+    const int n0 = red_blocks(t, 16);
+    const int n1 = ws_reg ? sq2_blocks(n_embed, 768) + sq2_blocks(n_wrel, 255) : 0;
+    const int n2 = ws_kl ? kl_blocks(n_nodes) : 0;
+    const int n3 = ws_mmd ? sx + sy : 0;
+    const float* kl_part = ws_kl ? ws_kl + 3 * (size_t)k * h : nullptr;     // partials follow the mixture table
+    hipLaunchKernelGGL(k_loss_combine, dim3(1), dim3(256), 0, GV_ST, ws_pred, n0, 1.f / (float)t, ws_reg, n1, 1.f, kl_part,
+                       n2, ws_kl ? 1.f / (float)n_nodes : 0.f, ws_mmd, n3, 1.f, reg_w, kl_w, mmd_w, scal, loss);
+    return launch_status("gv_loss_combine");
 }
 
 extern "C" int gv_mmd_bwd(const float* x, const float* y, int sx, int sy, int h, const float* gmmd, float gscale,

@@ -26,7 +26,7 @@ SIGNATURES = {
     'gv_rgcn_bdd_grad_weight': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
     'gv_rgcn_epilogue_fwd': (_I, [_P, _P, _I, _P, _F, _P, _L, _I, _P]),
     'gv_rgcn_epilogue_bwd': (_I, [_P, _P, _I, _P, _F, _P, _L, _I, _P, _P]),
-    'gv_colsum_finish': (_I, [_P, _I, _P, _I, _P]),
+    'gv_colsum_finish': (_I, [_P, _I, _I, _P, _I, _P]),
     'gv_gemm_workspace_bytes': (_L, [_I, _I, _I, _I]),
     'gv_gemm_f32': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P]),
     'gv_colsum': (_I, [_P, _P, _L, _I, _I, _P, _P, _I, _P]),
@@ -43,6 +43,7 @@ SIGNATURES = {
     'gv_kl_workspace_bytes': (_L, [_L, _I, _I]),
     'gv_kl_fwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'gv_kl_bwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _P, _I, _L, _I, _I, _P]),
+    'gv_loss_combine': (_I, [_P, _L, _P, _L, _L, _P, _L, _I, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P]),
     'gv_lincomb4': (_I, [_P, _F, _P, _F, _P, _F, _P, _F, _P, _P]),
     'gv_mmd_fwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     'gv_mmd_bwd': (_I, [_P, _P, _I, _I, _I, _P, _F, _P, _P, _P]),
@@ -53,6 +54,7 @@ SIGNATURES = {
     'gv_rowsum': (_I, [_P, _I, _I, _I, _P, _L, _P]),
     'gv_reverse_cols': (_I, [_P, _P, _L, _I, _P]),
     'gv_adam_step': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P, _P]),
+    'gv_clip_adam_step': (_I, [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _P, _I, _P]),
 }
 
 _lib = None

@@ -32,6 +32,7 @@ def _direct_flat(t):
     """Direct target of a contiguous VIEW of a parameter that starts at its storage (e.g. z_pre.squeeze(0))."""
     tgt = DIRECT_GRAD.get(t.data_ptr()) if t is not None else None
     return tgt.view(t.shape) if (tgt is not None and tgt.numel() == t.numel() and tgt.is_contiguous()) else None
+EPILOGUE_COLSUM_SLICES = 256   # = GV_EPILOGUE_COLSUM_SLICES (include/gcnvae.h)
 DEFAULT_CHUNK = 256        # max edges per work item of the dst/src-sorted aggregations
 DEFAULT_CHUNK_REL = 128    # max edges per work item of the by-relation weight gradient
 DIST_FWD_CHUNKS = 2        # destination-row blocks whose all-reduce overlaps the next block's aggregation
@@ -409,11 +410,15 @@ def epilogue_bwd(out, grad_out, act, keep, keep_scale, colsum_out=None, colsum_a
     grad_out = _chk(grad_out.contiguous(), name='grad_out')
     g = torch.empty_like(grad_out)
     m, n = grad_out.shape
-    part = torch.empty(64 * n, dtype=torch.float32, device=g.device) if colsum_out is not None else None
+    fused = colsum_out is not None and n % 4 == 0 and n <= 1024
+    part = torch.empty(EPILOGUE_COLSUM_SLICES * n, dtype=torch.float32, device=g.device) if fused else None
     lib.call('gv_rgcn_epilogue_bwd', ptr(out), ptr(grad_out), act, ptr(keep), float(keep_scale), ptr(g), m, n, ptr(part),
              lib.stream())
-    if colsum_out is not None:
-        lib.call('gv_colsum_finish', ptr(part), n, ptr(colsum_out), 1 if colsum_accumulate else 0, lib.stream())
+    if fused:
+        lib.call('gv_colsum_finish', ptr(part), n, EPILOGUE_COLSUM_SLICES, ptr(colsum_out), 1 if colsum_accumulate else 0,
+                 lib.stream())
+    elif colsum_out is not None:
+        colsum(g, out=colsum_out, accumulate=colsum_accumulate)
     return g
 
 
@@ -971,29 +976,25 @@ class _LossHead(torch.autograd.Function):
             pick = _chk(pick.reshape(-1), torch.int64, 'pick')
             z_post = torch.empty(pick.numel(), h, **f32)
             wsm = torch.empty(z_pri.shape[0] + z_post.shape[0], **f32)
-        # branch 1: KL to the mixture prior
-        if kl_w > 0:
-            with fork(1):
-                lib.call('gv_kl_fwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(flp), ptr(resp), ptr(kl),
-                         ptr(wsk), n, h, k, lib.stream())
-        # branch 2: MMD + the regulariser sums
-        with fork(2):
-            st2 = lib.stream()
-            if mmd_w > 0:
-                lib.call('gv_gather_rows', ptr(z), ptr(pick), ptr(z_post), pick.numel(), h, st2)
-                lib.call('gv_mmd_fwd', ptr(z_pri), ptr(z_post), z_pri.shape[0], z_post.shape[0], h, ptr(mmd), ptr(wsm), st2)
-            if ld_z == h and ld_w == h:
-                lib.call('gv_mean_sq2', ptr(z), z.numel(), 1.0 / z.numel(), ptr(w_rel), w_rel.numel(), 1.0 / w_rel.numel(),
-                         ptr(reg), ptr(ws2), st2)
-            else:
-                raise ValueError('loss_head needs contiguous embeddings and relation table')
-        # main: DistMult scorer + BCE (three 800-B row gathers per triplet: the bandwidth-bound part)
+        if ld_z != h or ld_w != h:
+            raise ValueError('loss_head needs contiguous embeddings and relation table')
         st = lib.stream()
+        # every term leaves its per-block partial sums in its workspace; ONE combine launch finishes the four sums
+        if kl_w > 0:
+            lib.call('gv_kl_fwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(flp), ptr(resp), None, ptr(wsk),
+                     n, h, k, st)
+        if mmd_w > 0:
+            lib.call('gv_gather_rows', ptr(z), ptr(pick), ptr(z_post), pick.numel(), h, st)
+            lib.call('gv_mmd_fwd', ptr(z_pri), ptr(z_post), z_pri.shape[0], z_post.shape[0], h, None, ptr(wsm), st)
+        lib.call('gv_mean_sq2', ptr(z), z.numel(), 1.0 / z.numel(), ptr(w_rel), w_rel.numel(), 1.0 / w_rel.numel(), None,
+                 ptr(ws2), st)
+        # DistMult scorer + BCE (three 800-B row gathers per triplet: the bandwidth-bound part)
         lib.call('gv_distmult_bce_fwd', ptr(z), ld_z, ptr(w_rel), ld_w, ptr(tidx.trip32), ptr(labels), ptr(bias),
-                 ptr(score), ptr(pred), ptr(ws), T, h, st)
-        join(1, 2)
-        lib.call('gv_lincomb4', ptr(pred), 1.0, ptr(reg), float(reg_w), ptr(kl) if kl_w > 0 else None, float(kl_w),
-                 ptr(mmd) if mmd_w > 0 else None, float(mmd_w), ptr(loss), st)
+                 ptr(score), None, ptr(ws), T, h, st)
+        lib.call('gv_loss_combine', ptr(ws), T, ptr(ws2), z.numel(), w_rel.numel(), ptr(wsk) if kl_w > 0 else None, n, h,
+                 (z_pre.shape[0] // 2) if kl_w > 0 else 0, ptr(wsm) if mmd_w > 0 else None,
+                 z_pri.shape[0] if mmd_w > 0 else 0, z_post.shape[0] if mmd_w > 0 else 0, float(reg_w), float(kl_w),
+                 float(mmd_w), ptr(scal), ptr(loss), st)
         ctx.save_for_backward(z, z_mean if kl_w > 0 else None, z_sigma if kl_w > 0 else None, w_rel,
                               z_pre if kl_w > 0 else None, resp, z_pri if mmd_w > 0 else None, z_post,
                               pick if mmd_w > 0 else None, labels, score, wsk)

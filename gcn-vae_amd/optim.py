@@ -2,8 +2,9 @@
 ``clip_grad_norm_(model.parameters(), grad_norm); optimizer.step()``).
 
 Parameters and their gradients are re-pointed at slices of two persistent device buffers, so the
-whole optimiser step is three launches (sum of squares, ordered final sum, fused clip+Adam) instead of
-torch's per-tensor / foreach kernel sets, and every address is static -- the step is hipGraph-capturable.
+whole optimiser step is two launches (per-block sums of squares + step counter; clip+Adam, each block finishing
+the norm from the partials in a fixed order and clearing the gradient it has consumed) instead of torch's
+per-tensor / foreach kernel sets, and every address is static -- the step is hipGraph-capturable.
 Numerics follow ``torch.nn.utils.clip_grad_norm_`` (coefficient min(1, max_norm / (norm + 1e-6))) and
 ``torch.optim.Adam`` (bias correction, eps added outside the square root).
 """
@@ -37,6 +38,7 @@ class FlatAdam:
         self.sumsq = torch.zeros((), dtype=torch.float32, device=dev)
         self._ws = torch.empty(1024, dtype=torch.float32, device=dev)
         self._direct_keys = []
+        self._clean = False
         for p, o in zip(self.params, offs):
             n = p.numel()
             self.flat_p[o:o + n].copy_(p.data.reshape(-1))
@@ -53,6 +55,10 @@ class FlatAdam:
             pass
 
     def zero_grad(self):
+        # the clip+Adam kernel clears the arena as it consumes it: right after step() there is nothing to do
+        if self._clean:
+            self._clean = False
+            return
         self.flat_g.zero_()
 
     def grad_norm(self):
@@ -60,11 +66,14 @@ class FlatAdam:
         return self.sumsq.sqrt()
 
     def step(self):
+        if self.max_grad_norm is not None:
+            lib.call('gv_clip_adam_step', ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                     self.total, ptr(self._ws), ptr(self.sumsq), float(self.max_grad_norm), float(self.lr),
+                     float(self.betas[0]), float(self.betas[1]), float(self.eps), ptr(self.step_t), 1, lib.stream())
+            self._clean = True
+            return
         self.step_t += 1
         sumsq = None
-        if self.max_grad_norm is not None:
-            lib.call('gv_mean_sq', ptr(self.flat_g), self.total, 1.0, ptr(self.sumsq), ptr(self._ws), 0, lib.stream())
-            sumsq = self.sumsq
         lib.call('gv_adam_step', ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
                  self.total, ptr(sumsq), float(self.max_grad_norm or 0.0), float(self.lr), float(self.betas[0]),
                  float(self.betas[1]), float(self.eps), ptr(self.step_t), lib.stream())

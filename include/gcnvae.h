@@ -104,11 +104,13 @@ int gv_rgcn_bdd_grad_weight(const int32_t* items, int n_items, const int32_t* fi
 int gv_rgcn_epilogue_fwd(const float* agg, const float* addend, int act, const uint8_t* keep, float keep_scale,
                          float* out, int64_t n_rows, int n_cols, void* stream);
 int gv_rgcn_epilogue_bwd(const float* out, const float* grad_out, int act, const uint8_t* keep, float keep_scale,
-                         float* g, int64_t n_rows, int n_cols, float* colsum_part /* optional: 64*n_cols floats */,
-                         void* stream);
-/* colsum_part != NULL: the same pass also writes 64 row-slice partials of the column sums of g (the bias gradient);
- * gv_colsum_finish(part, n_cols, out, accumulate) sums them in slice order. */
-int gv_colsum_finish(const float* part, int n, float* out, int accumulate, void* stream);
+                         float* g, int64_t n_rows, int n_cols,
+                         float* colsum_part /* optional: GV_EPILOGUE_COLSUM_SLICES*n_cols floats */, void* stream);
+/* colsum_part != NULL (needs n_cols % 4 == 0): the same pass also writes GV_EPILOGUE_COLSUM_SLICES row-slice partials
+ * of the column sums of g (the bias gradient); gv_colsum_finish(part, n_cols, n_slices, out, accumulate) adds the
+ * slices in a fixed order. */
+#define GV_EPILOGUE_COLSUM_SLICES 256
+int gv_colsum_finish(const float* part, int n, int n_slices, float* out, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K2/K4  dense fp32 GEMM on the f32 MFMA (v_mfma_f32_32x32x2_f32; exact fp32 fma chain):
@@ -185,6 +187,13 @@ int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* v, const fl
  *       out[i] = mu[i % k] + eps[i] * sqrt(softplus(raw[i % k]) + 1e-8), z_pre = [mu; raw] (2k, h); bwd -> gz_pre (2k, h). */
 /* *out = c0*(*a0) + c1*(*a1) + c2*(*a2) + c3*(*a3) on device scalars (NULL terms skipped): the loss assembly of
  * LinkPredict.get_loss (kgvae/link_predict.py:91) and its scalar gradients, without host round trips. */
+/* Deferred final sums: gv_distmult_bce_fwd (loss), gv_mean_sq2 (out), gv_kl_fwd (kl) and gv_mmd_fwd (mmd) accept NULL
+ * for their scalar output and then leave their per-block partial sums in `workspace`.  gv_loss_combine finishes all
+ * four in ONE launch from those workspaces (same shapes as the producing calls; ws_reg / ws_kl / ws_mmd may be NULL):
+ *   scal = {pred, reg, kl, mmd},  *loss = pred + reg_w*reg + kl_w*kl + mmd_w*mmd   (kgvae/link_predict.py:86-91) */
+int gv_loss_combine(const float* ws_pred, int64_t t, const float* ws_reg, int64_t n_embed, int64_t n_wrel,
+                    const float* ws_kl, int64_t n_nodes, int h, int k, const float* ws_mmd, int sx, int sy, float reg_w,
+                    float kl_w, float mmd_w, float* scal /* 4 floats, optional */, float* loss, void* stream);
 int gv_lincomb4(const float* a0, float c0, const float* a1, float c1, const float* a2, float c2, const float* a3,
                 float c3, float* out, void* stream);
 int gv_mmd_fwd(const float* x, const float* y, int sx, int sy, int h, float* mmd, float* workspace, void* stream);
@@ -216,6 +225,12 @@ int gv_reverse_cols(const float* x, float* out, int64_t n, int d, void* stream);
  *                    then torch.optim.Adam's update (bias correction from *step, eps outside the sqrt). */
 int gv_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, const float* sumsq,
                  float max_norm, float lr, float beta1, float beta2, float eps, const float* step, void* stream);
+/* clip_grad_norm_ + Adam.step in two launches: (1) per-block sums of g^2 into workspace (1024 floats) and *step += 1,
+ * (2) the update, each block finishing the norm from the partials; *sumsq_out (optional) receives sum(g^2);
+ * zero_grad != 0 clears g as it is consumed (the next iteration's optimizer.zero_grad()). */
+int gv_clip_adam_step(float* p, float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float* workspace,
+                      float* sumsq_out, float max_norm, float lr, float beta1, float beta2, float eps, float* step,
+                      int zero_grad, void* stream);
 
 #ifdef __cplusplus
 }
