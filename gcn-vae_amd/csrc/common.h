@@ -32,16 +32,39 @@ inline int launch_status(const char* what) {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- device helpers -------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions on the VALU's DPP path (no LDS-crossbar ds_bpermute round trips): two quad permutes, then
+// row_half_mirror and row_mirror leave every lane with the sum of its row of 16; the four row sums are read with
+// v_readlane and added in row order.  Fixed order -> bitwise reproducible.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+
+__device__ __forceinline__ float rl_bcast_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// sum over each row of 16 lanes, result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<DPP_QUAD_1032>(v);
+    v += dpp_f<DPP_QUAD_2301>(v);
+    v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f<DPP_ROW_MIRROR>(v);
     return v;
 }
 
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return (rl_bcast_f(v, 0) + rl_bcast_f(v, 16)) + (rl_bcast_f(v, 32) + rl_bcast_f(v, 48));
+}
+
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f<DPP_QUAD_1032>(v));
+    v = fmaxf(v, dpp_f<DPP_QUAD_2301>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+    return fmaxf(fmaxf(rl_bcast_f(v, 0), rl_bcast_f(v, 16)), fmaxf(rl_bcast_f(v, 32), rl_bcast_f(v, 48)));
 }
 
 // contiguous load/store of N floats; the widest access the element count permits (callers

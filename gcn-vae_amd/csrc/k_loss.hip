@@ -84,8 +84,7 @@ __global__ __launch_bounds__(256) void k_distmult_bce(const float* e, int ld_e, 
                 for (int c = sub; c < h; c += 16) acc = fmaf(es[c] * wr[c], eo[c], acc);
             }
         }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        acc = row16_sum(acc);          // the triplet's 16 lanes are one DPP row
         if (t < T && sub == 0) {
             const float x = acc + bv;
             score[t] = x;
@@ -144,17 +143,23 @@ __global__ __launch_bounds__(256) void k_kl_fwd(const float* z, const float* m, 
                                                 int64_t n, int h, int k) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float wsum[4];
+    __shared__ float lconst[KL_KMAX];          // sum_c (log sqrt v_jc + log sqrt 2 pi): independent of the node
     const int kh = k * h;
     if ((kh & 3) == 0) {
-        for (int i = threadIdx.x; i < 3 * kh / 4; i += 256)
+        for (int i = threadIdx.x; i < 2 * kh / 4; i += 256)
             reinterpret_cast<float4*>(sm)[i] = reinterpret_cast<const float4*>(mix)[i];
     } else {
-        for (int i = threadIdx.x; i < 3 * kh; i += 256) sm[i] = mix[i];
+        for (int i = threadIdx.x; i < 2 * kh; i += 256) sm[i] = mix[i];
+    }
+    for (int j = threadIdx.x >> 6; j < k; j += 4) {
+        float t = 0.f;
+        for (int c = threadIdx.x & 63; c < h; c += 64) t += mix[2 * kh + j * h + c];
+        t = wave_sum(t);
+        if ((threadIdx.x & 63) == 0) lconst[j] = t;
     }
     __syncthreads();
     const float* mu = sm;
     const float* i2v = sm + kh;
-    const float* lsv = sm + 2 * kh;
     const int lane = threadIdx.x & 63;
     const float fl = flp ? *flp : 0.f;
     const float logk = logf((float)k);
@@ -181,10 +186,10 @@ __global__ __launch_bounds__(256) void k_kl_fwd(const float* z, const float* m, 
                 const int c = lane + 64 * i;
                 if (c < h) {
                     const float dj = zz[i] - mu[j * h + c];
-                    acc += -(dj * dj) * i2v[j * h + c] - lsv[j * h + c];
+                    acc = fmaf(-(dj * dj), i2v[j * h + c], acc);
                 }
             }
-            acc = wave_sum(acc);
+            acc = wave_sum(acc) - lconst[j];
             if (lane == j) my_l = acc;
         }
         const float mx = wave_max(my_l);
@@ -515,7 +520,7 @@ extern "C" int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* 
     GV_REQUIRE(z && m && v && z_pre && resp && workspace, GV_ERR_NULL, "gv_kl_fwd: NULL pointer");
     GV_REQUIRE(n > 0 && h > 0 && k > 0 && k <= KL_KMAX && ld_m >= h, GV_ERR_SHAPE, "gv_kl_fwd: n=%lld h=%d k=%d",
                (long long)n, h, k);
-    const size_t lds = (size_t)3 * k * h * sizeof(float);
+    const size_t lds = (size_t)2 * k * h * sizeof(float);
     GV_REQUIRE(lds <= 64 * 1024, GV_ERR_SHAPE, "gv_kl_fwd: mixture table %zu B exceeds the 64 KiB LDS budget", lds);
     float* mix = workspace;
     float* part = workspace + 3 * (size_t)k * h;
