@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void k_epilogue_bwd_colsum(const float* __rest
 
 // one wave per row; int64 ids as torch's embedding takes them
 __global__ __launch_bounds__(256) void k_gather_rows(const float* table, const int64_t* ids, float* out, int64_t n,
-                                                     int h) {
+                                                     int h, uint64_t* rng_state) {
+    if (rng_state && blockIdx.x == 0 && threadIdx.x == 0) rng_state[1] += 1;   // start-of-forward RNG tick (nobody reads it here)
     const int lane = threadIdx.x & 63;
     for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {
         const float* src = table + ids[r] * (int64_t)h;
@@ -205,6 +206,83 @@ __global__ __launch_bounds__(256) void k_reverse_cols(const float* x, float* out
     }
 }
 
+// ---- counter-based RNG: every random draw of one forward pass in ONE launch ---------------------------------
+// Philox4x32-10 (Salmon et al., SC'11): key = the 64-bit seed, counter = (group, stream, tick_lo, tick_hi); one call
+// yields the 4 outputs of elements 4*group .. 4*group+3 of a job.  `tick` is a device-side step counter (state[1]),
+// so a captured hipGraph draws fresh numbers on every replay; `stream` separates the jobs of one tick.
+//   kind 0: keep mask, byte = (u32 >= floor(p_drop * 2^32))            (nn.Dropout's Bernoulli(1-p) decision)
+//   kind 1: standard normals by Box-Muller, (u1, u2) = ((x0 + 1) * 2^-32, x1 * 2^-32)  (torch.randn_like)
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+struct RngJobs {
+    void* ptr[GV_RNG_MAX_JOBS];
+    long long n[GV_RNG_MAX_JOBS];
+    long long group0[GV_RNG_MAX_JOBS + 1];     // prefix of ceil(n/4): job j owns global groups [group0[j], group0[j+1])
+    int kind[GV_RNG_MAX_JOBS];
+    uint32_t thresh[GV_RNG_MAX_JOBS];
+    uint32_t stream[GV_RNG_MAX_JOBS];
+    int n_jobs;
+};
+
+__global__ __launch_bounds__(256) void k_rng_fill(const uint64_t* state, const RngJobs jobs) {
+    const uint64_t seed = state[0], tick = state[1];
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), t0 = (uint32_t)tick, t1 = (uint32_t)(tick >> 32);
+    const long long total = jobs.group0[jobs.n_jobs];
+    for (long long gg = (long long)blockIdx.x * 256 + threadIdx.x; gg < total; gg += (long long)gridDim.x * 256) {
+        int j = 0;
+#pragma unroll
+        for (int q = 1; q < GV_RNG_MAX_JOBS; ++q)
+            if (q < jobs.n_jobs && gg >= jobs.group0[q]) j = q;
+        const long long grp = gg - jobs.group0[j];
+        const uint4 x = philox4x32_10(k0, k1, (uint32_t)grp, jobs.stream[j], t0, t1);
+        const long long e0 = grp * 4, left = jobs.n[j] - e0;
+        if (jobs.kind[j] == 0) {
+            const uint32_t th = jobs.thresh[j];
+            uint8_t* o = (uint8_t*)jobs.ptr[j] + e0;
+            const uchar4 b = make_uchar4(x.x >= th, x.y >= th, x.z >= th, x.w >= th);
+            if (left >= 4) {
+                *reinterpret_cast<uchar4*>(o) = b;
+            } else {
+                o[0] = b.x;
+                if (left > 1) o[1] = b.y;
+                if (left > 2) o[2] = b.z;
+            }
+        } else {
+            // hardware transcendentals: v_log_f32 (base 2), v_sin/v_cos_f32 (argument in revolutions) -- ~1e-6 absolute
+            // on the result, far inside what noise needs; the precise libm sincosf tripled this kernel's time
+            const float s = 2.3283064365386963e-10f;       // 2^-32
+            const float r0 = sqrtf(-1.3862943611198906f * __log2f(((float)x.x + 1.f) * s));    // -2 ln u = -2 ln2 log2 u
+            const float r1 = sqrtf(-1.3862943611198906f * __log2f(((float)x.z + 1.f) * s));
+            const float a0 = (float)x.y * s, a1 = (float)x.w * s;                                 // revolutions in [0, 1]
+            const float s0 = __builtin_amdgcn_sinf(a0), c0 = __builtin_amdgcn_cosf(a0);
+            const float s1 = __builtin_amdgcn_sinf(a1), c1 = __builtin_amdgcn_cosf(a1);
+            const float4 nrm = make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
+            float* o = (float*)jobs.ptr[j] + e0;
+            if (left >= 4) {
+                *reinterpret_cast<float4*>(o) = nrm;
+            } else {
+                o[0] = nrm.x;
+                if (left > 1) o[1] = nrm.y;
+                if (left > 2) o[2] = nrm.z;
+            }
+        }
+    }
+}
+
+__global__ void k_rng_tick(uint64_t* state) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) state[1] += 1;
+}
+
 // first pass of the gradient norm: per-block sums of g^2 into part[]; thread 0 of block 0 also advances the
 // optimiser's step counter (nothing else reads it during this launch)
 __global__ __launch_bounds__(256) void k_gradsq_part(const float* g, int64_t n, float* part, float* step) {
@@ -293,8 +371,51 @@ extern "C" int gv_rgcn_epilogue_bwd(const float* out, const float* grad_out, int
 extern "C" int gv_gather_rows(const float* table, const int64_t* ids, float* out, int64_t n, int h, void* stream) {
     GV_REQUIRE(table && ids && out, GV_ERR_NULL, "gv_gather_rows: NULL pointer");
     if (n <= 0) return GV_OK;
-    hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(n, 4)), dim3(256), 0, GV_ST, table, ids, out, n, h);
+    hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(n, 4)), dim3(256), 0, GV_ST, table, ids, out, n, h, (uint64_t*)nullptr);
     return launch_status("gv_gather_rows");
+}
+
+extern "C" int gv_gather_rows_rng_tick(const float* table, const int64_t* ids, float* out, int64_t n, int h,
+                                       uint64_t* rng_state, void* stream) {
+    GV_REQUIRE(table && ids && out && rng_state, GV_ERR_NULL, "gv_gather_rows_rng_tick: NULL pointer");
+    GV_REQUIRE(n > 0, GV_ERR_SHAPE, "gv_gather_rows_rng_tick: n=%lld (the tick rides on a non-empty gather)", (long long)n);
+    hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(n, 4)), dim3(256), 0, GV_ST, table, ids, out, n, h, rng_state);
+    return launch_status("gv_gather_rows_rng_tick");
+}
+
+extern "C" int gv_rng_tick(uint64_t* rng_state, void* stream) {
+    GV_REQUIRE(rng_state, GV_ERR_NULL, "gv_rng_tick: NULL pointer");
+    hipLaunchKernelGGL(k_rng_tick, dim3(1), dim3(64), 0, GV_ST, rng_state);
+    return launch_status("gv_rng_tick");
+}
+
+extern "C" int gv_rng_fill(const uint64_t* rng_state, int n_jobs, void* const* ptrs, const int64_t* counts, const int32_t* kinds,
+                           const float* drop_p, const uint32_t* streams, void* stream) {
+    GV_REQUIRE(rng_state && ptrs && counts && kinds && drop_p && streams, GV_ERR_NULL, "gv_rng_fill: NULL pointer");
+    GV_REQUIRE(n_jobs > 0 && n_jobs <= GV_RNG_MAX_JOBS, GV_ERR_SHAPE, "gv_rng_fill: n_jobs=%d (1..%d)", n_jobs, GV_RNG_MAX_JOBS);
+    RngJobs jb;
+    long long g = 0;
+    for (int j = 0; j < GV_RNG_MAX_JOBS; ++j) {
+        jb.group0[j] = g;
+        if (j < n_jobs) {
+            GV_REQUIRE(ptrs[j] && counts[j] > 0 && counts[j] < (1ll << 34), GV_ERR_SHAPE, "gv_rng_fill: job %d: bad buffer/count", j);
+            GV_REQUIRE(kinds[j] == GV_RNG_KEEP_MASK || kinds[j] == GV_RNG_NORMAL, GV_ERR_SHAPE, "gv_rng_fill: job %d: kind %d", j, kinds[j]);
+            GV_REQUIRE((reinterpret_cast<uintptr_t>(ptrs[j]) & (kinds[j] == GV_RNG_NORMAL ? 15u : 3u)) == 0, GV_ERR_ALIGN,
+                       "gv_rng_fill: job %d: buffer alignment", j);
+            GV_REQUIRE(kinds[j] == GV_RNG_NORMAL || (drop_p[j] >= 0.f && drop_p[j] < 1.f), GV_ERR_SHAPE, "gv_rng_fill: job %d: p=%f", j, drop_p[j]);
+            jb.ptr[j] = ptrs[j]; jb.n[j] = counts[j]; jb.kind[j] = kinds[j]; jb.stream[j] = streams[j];
+            const double th = (double)drop_p[j] * 4294967296.0;
+            jb.thresh[j] = th >= 4294967295.0 ? 4294967295u : (uint32_t)th;
+            g += (counts[j] + 3) / 4;
+        } else {
+            jb.ptr[j] = nullptr; jb.n[j] = 0; jb.kind[j] = 0; jb.stream[j] = 0; jb.thresh[j] = 0;
+        }
+    }
+    jb.group0[GV_RNG_MAX_JOBS] = g;
+    for (int j = n_jobs; j <= GV_RNG_MAX_JOBS; ++j) jb.group0[j] = g;
+    jb.n_jobs = n_jobs;
+    hipLaunchKernelGGL(k_rng_fill, dim3(grid_for(g, 1024)), dim3(256), 0, GV_ST, rng_state, jb);
+    return launch_status("gv_rng_fill");
 }
 
 extern "C" int gv_scatter_add_rows(const float* grad_out, const int64_t* ids, float* grad_table, int64_t n, int h,

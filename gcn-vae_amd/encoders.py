@@ -19,7 +19,8 @@ class EmbeddingLayer(nn.Module):
         self.embedding = nn.Embedding(num_nodes, h_dim)
 
     def forward(self, g, h, r, norm):
-        return ops.embedding(self.embedding.weight, h.squeeze())
+        # the lookup opens every forward pass: the device RNG's tick advances on this launch
+        return ops.embedding(self.embedding.weight, h.squeeze(), ops.device_rng(self.embedding.weight.device))
 
 
 class DistLayer(nn.Module):
@@ -58,6 +59,8 @@ class KGVAE(nn.Module):
         self.eps_override = None          # (N, h) standard-normal draw for the reparameterisation
         self.mmd_eps_override = None      # (num_sample, h) draw for the prior samples of get_mmd
         self.mmd_index_override = None    # int64 (num_sample,) posterior row pick of get_mmd
+        self.rng_stream_eps, self.rng_stream_prior = ops.new_rng_stream(), ops.new_rng_stream()
+        self._prior_eps_next = None       # prior noise drawn by forward()'s fused RNG launch
         # get_mmd pushes 200 prior samples through the same flow stack as the N node rows.  The flows act row-wise,
         # so when the task head announces that MMD will be evaluated (LinkPredict sets this for mmd_param > 0) the
         # prior rows ride along in forward() as extra rows of the same GEMMs instead of ~150 tiny launches of their own.
@@ -100,9 +103,36 @@ class KGVAE(nn.Module):
     def _prior_draw(self, device, dtype):
         num_sample = 200
         rows = (num_sample // self.k) * self.k if num_sample // self.k > 1 else self.k
-        eps = self.mmd_eps_override if self.mmd_eps_override is not None else \
-            torch.randn(rows, self.h_dim, device=device, dtype=dtype)
+        if self.mmd_eps_override is not None:
+            eps = self.mmd_eps_override
+        elif self._prior_eps_next is not None:
+            eps, self._prior_eps_next = self._prior_eps_next, None
+        else:
+            eps = torch.empty(rows, self.h_dim, device=device, dtype=dtype)
+            ops.device_rng(device).fill([(eps, ops.RNG_NORMAL, 0.0, self.rng_stream_prior)])
         return ops.prior_sample(self.z_pre.squeeze(0), eps)       # sample_gaussian(m_mix, s_mix, repeat)
+
+    def _prior_rows(self):
+        num_sample = 200
+        return (num_sample // self.k) * self.k if num_sample // self.k > 1 else self.k
+
+    def _draw_noise(self, n, device):
+        """All random draws of one forward pass in ONE launch: both layers' dropout masks, the reparameterisation
+        noise and (when the head announced get_mmd) the prior noise.  Overrides (parity mode) are left alone."""
+        jobs, eps = [], self.eps_override
+        for layer in (self.rconv_layer_1, self.rconv_layer_2):
+            if layer.wants_keep_mask():
+                layer._keep_next = torch.empty(n, layer.out_feat, dtype=torch.uint8, device=device)
+                jobs.append(layer.keep_job(layer._keep_next))
+        if eps is None:
+            eps = torch.empty(n, self.h_dim, dtype=torch.float32, device=device)
+            jobs.append((eps, ops.RNG_NORMAL, 0.0, self.rng_stream_eps))
+        if self.batch_mmd_prior_with_forward and self.training and self.mmd_eps_override is None:
+            self._prior_eps_next = torch.empty(self._prior_rows(), self.h_dim, dtype=torch.float32, device=device)
+            jobs.append((self._prior_eps_next, ops.RNG_NORMAL, 0.0, self.rng_stream_prior))
+        if jobs:
+            ops.device_rng(device).fill(jobs)
+        return eps
 
     def mmd_inputs(self, z):
         """The two sample sets of get_mmd: prior draws (through the flows) and the posterior row pick."""
@@ -130,10 +160,9 @@ class KGVAE(nn.Module):
     def forward(self, g, h, r, norm):
         self.node_id = h.squeeze()
         h = self.input_layer(g, h, r, norm)
+        eps = self._draw_noise(h.shape[0], h.device)
         h = self.rconv_layer_1(g, h, r, norm)
         h = self.rconv_layer_2(g, h, r, norm)
-        eps = self.eps_override if self.eps_override is not None else \
-            torch.randn(h.shape[0], h.shape[1] // 2, device=h.device, dtype=h.dtype)
         z, self.z_mean, self.z_sigma = ops.reparam(h, eps)
         self._z_pri_flowed = None
         if self.n_flows > 0:

@@ -62,6 +62,8 @@ class RelGraphConv(nn.Module):
             nn.init.xavier_uniform_(self.loop_weight, gain=gain)
         self.dropout = nn.Dropout(dropout)
         self.keep_mask_override = None   # parity mode: a uint8 (N, out) keep mask instead of the device RNG
+        self.rng_stream = ops.new_rng_stream()
+        self._keep_next = None           # a mask the enclosing encoder drew for this call (one fused RNG launch)
         self.reduce_hook = None          # multi-GPU: sums the partial aggregate over the edge shards
 
     def _keep_mask(self, n, device):
@@ -70,8 +72,19 @@ class RelGraphConv(nn.Module):
             return self.keep_mask_override.to(device=device, dtype=torch.uint8).contiguous(), 1.0 / (1.0 - p)
         if not self.training or p <= 0.0:
             return None, 1.0
-        keep = torch.empty(n, self.out_feat, dtype=torch.uint8, device=device).bernoulli_(1.0 - p)
+        if self._keep_next is not None:
+            keep, self._keep_next = self._keep_next, None
+            return keep, 1.0 / (1.0 - p)
+        keep = torch.empty(n, self.out_feat, dtype=torch.uint8, device=device)
+        ops.device_rng(device).fill([self.keep_job(keep)])
         return keep, 1.0 / (1.0 - p)
+
+    def wants_keep_mask(self):
+        return self.training and self.dropout.p > 0.0 and self.keep_mask_override is None
+
+    def keep_job(self, keep):
+        """The RNG job that fills ``keep`` (uint8, (N, out_feat)) with this layer's Bernoulli(1 - p) decisions."""
+        return (keep, ops.RNG_KEEP_MASK, float(self.dropout.p), self.rng_stream)
 
     def forward(self, g, x, etypes, norm=None):
         if x.dtype == torch.int64 and x.dim() == 1:

@@ -31,6 +31,9 @@ SIGNATURES = {
     'gv_gemm_f32': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P]),
     'gv_colsum': (_I, [_P, _P, _L, _I, _I, _P, _P, _I, _P]),
     'gv_gather_rows': (_I, [_P, _P, _P, _L, _I, _P]),
+    'gv_gather_rows_rng_tick': (_I, [_P, _P, _P, _L, _I, _P, _P]),
+    'gv_rng_fill': (_I, [_P, _I, _P, _P, _P, _P, _P, _P]),
+    'gv_rng_tick': (_I, [_P, _P]),
     'gv_scatter_add_rows': (_I, [_P, _P, _P, _L, _I, _P]),
     'gv_reparam_fwd': (_I, [_P, _P, _P, _P, _P, _L, _I, _P]),
     'gv_reparam_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),

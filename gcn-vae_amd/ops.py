@@ -5,6 +5,8 @@ falls back to torch CPU math.  torch is used for device memory, the current stre
 bookkeeping only (plus sort/cumsum when an index is built, outside the hot step).
 """
 import contextlib
+import ctypes as _ct
+import itertools as _it
 import os as _os
 from dataclasses import dataclass
 from typing import Optional
@@ -440,13 +442,91 @@ def mul(a, b):
 
 # ------------------------------------------------------------------------------------------------
 # autograd Functions
+# ------------------------------------------------------------------------------------------------
+# Device RNG: every random draw of a forward pass (dropout keep masks, reparameterisation noise, prior
+# noise) comes from ONE launch of a counter-based generator (Philox4x32-10, gv_rng_fill) keyed by
+# {seed, tick} held on the device.  The tick advances on the device (folded into the embedding lookup, or
+# gv_rng_tick), so a captured hipGraph draws fresh numbers at every replay -- and none of torch's graph-safe
+# RNG bookkeeping kernels (seed/offset fills, one generator launch per tensor) are on the path.
+RNG_KEEP_MASK, RNG_NORMAL = 0, 1
+_rng_streams = _it.count(1)
+_rngs = {}
+
+
+def new_rng_stream():
+    """A process-unique stream id; modules take one per random draw site at construction."""
+    return next(_rng_streams) & 0xFFFFFFFF
+
+
+class DeviceRNG:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._seed = None
+        self.state = torch.zeros(2, dtype=torch.int64, device=self.device)     # {seed, tick}
+        self._used = set()          # streams drawn since the last tick
+        self._sync_seed()
+
+    def _sync_seed(self):
+        seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF     # follows torch.manual_seed
+        if seed != self._seed:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('torch.manual_seed changed during hipGraph capture')
+            self._seed = seed
+            self.state.copy_(torch.tensor([seed, 0], dtype=torch.int64))
+            self._used.clear()
+
+    def tick(self):
+        lib.call('gv_rng_tick', ptr(self.state), lib.stream())
+        self._used.clear()
+
+    def folded_tick(self):
+        """The state pointer for a kernel that advances the tick as a side effect (gv_gather_rows_rng_tick)."""
+        self._sync_seed()
+        self._used.clear()
+        return self.state
+
+    def fill(self, jobs):
+        """jobs: [(tensor, kind, drop_p, stream)] -- uint8 tensors for RNG_KEEP_MASK, float32 for RNG_NORMAL."""
+        self._sync_seed()
+        if any(j[3] in self._used for j in jobs):     # same stream twice within one tick would repeat its numbers
+            self.tick()
+        for i in range(0, len(jobs), 8):
+            part = jobs[i:i + 8]
+            n = len(part)
+            for t, kind, _, _ in part:
+                want = torch.uint8 if kind == RNG_KEEP_MASK else torch.float32
+                if t.dtype != want or not t.is_contiguous() or t.device != self.device:
+                    raise TypeError('rng fill: buffers must be contiguous uint8 (mask) / float32 (normal) on the RNG device')
+            ptrs = (_ct.c_void_p * n)(*[t.data_ptr() for t, _, _, _ in part])
+            counts = (_ct.c_int64 * n)(*[t.numel() for t, _, _, _ in part])
+            kinds = (_ct.c_int32 * n)(*[k for _, k, _, _ in part])
+            ps = (_ct.c_float * n)(*[float(p) for _, _, p, _ in part])
+            streams = (_ct.c_uint32 * n)(*[s for _, _, _, s in part])
+            lib.call('gv_rng_fill', ptr(self.state), n, ptrs, counts, kinds, ps, streams, lib.stream())
+        self._used.update(j[3] for j in jobs)
+
+
+def device_rng(device):
+    dev = torch.device(device)
+    if dev.type != 'cuda':
+        raise RuntimeError('the device RNG lives on a ROCm device (no CPU fallback)')
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _rngs:
+        _rngs[key] = DeviceRNG(torch.device('cuda', key))
+    return _rngs[key]
+
+
 class _Embedding(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, table, ids):
+    def forward(ctx, table, ids, tick_rng=None):
         table = _chk(table, name='embedding table')
         ids = _chk(ids.reshape(-1), torch.int64, 'node ids')
         out = torch.empty(ids.numel(), table.shape[1], dtype=torch.float32, device=table.device)
-        lib.call('gv_gather_rows', ptr(table), ptr(ids), ptr(out), ids.numel(), table.shape[1], lib.stream())
+        if tick_rng is not None and ids.numel() > 0:      # the start-of-forward RNG tick rides on this launch
+            lib.call('gv_gather_rows_rng_tick', ptr(table), ptr(ids), ptr(out), ids.numel(), table.shape[1],
+                     ptr(tick_rng.folded_tick()), lib.stream())
+        else:
+            lib.call('gv_gather_rows', ptr(table), ptr(ids), ptr(out), ids.numel(), table.shape[1], lib.stream())
         ctx.save_for_backward(ids)
         ctx.shape = tuple(table.shape)
         ctx.direct = _direct(table)
@@ -459,11 +539,11 @@ class _Embedding(torch.autograd.Function):
         tgt = ctx.direct
         gt = tgt if tgt is not None else torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
         lib.call('gv_scatter_add_rows', ptr(g), ptr(ids), ptr(gt), ids.numel(), ctx.shape[1], lib.stream())
-        return (None if tgt is not None else gt), None
+        return (None if tgt is not None else gt), None, None
 
 
-def embedding(table, ids):
-    return _Embedding.apply(table, ids)
+def embedding(table, ids, tick_rng=None):
+    return _Embedding.apply(table, ids, tick_rng)
 
 
 class _RelGraphConvBdd(torch.autograd.Function):

@@ -132,7 +132,28 @@ int gv_colsum(const float* x, const float* relu_mask, int64_t m, int n, int ld, 
 /* ---------------------------------------------------------------------------------------------
  * Embedding gather / gradient scatter (kgvae/model.py:185-191, nn.Embedding dense backward). */
 int gv_gather_rows(const float* table, const int64_t* ids, float* out, int64_t n, int h, void* stream);
+/* The same gather, additionally advancing the device RNG's tick (rng_state[1] += 1): the start-of-forward tick rides on
+ * the embedding lookup instead of a launch of its own (gv_rng_tick). */
+int gv_gather_rows_rng_tick(const float* table, const int64_t* ids, float* out, int64_t n, int h, uint64_t* rng_state,
+                            void* stream);
 int gv_scatter_add_rows(const float* grad_out, const int64_t* ids, float* grad_table, int64_t n, int h, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Random draws of the path -- nn.Dropout's keep masks inside RelGraphConv, randn_like in
+ * utils.sample_gaussian (kgvae/utils.py:342-361) -- as ONE launch per forward pass.
+ * rng_state = {seed, tick} (two uint64 on the device).  Element e of job j takes output e%4 of
+ * Philox4x32-10(key = seed, counter = (e/4, streams[j], tick_lo, tick_hi)):
+ *   GV_RNG_KEEP_MASK: uint8 byte = (u32 >= floor(drop_p * 2^32))      -- keep with probability 1 - drop_p
+ *   GV_RNG_NORMAL   : float, Box-Muller on (u1, u2) = ((x0 + 1) * 2^-32, x1 * 2^-32) -> (r cos, r sin) for outputs
+ *                     (0, 1) and likewise (x2, x3) for outputs (2, 3)
+ * The tick is read, never written, by gv_rng_fill: advance it between forwards with gv_rng_tick or
+ * gv_gather_rows_rng_tick, so a captured hipGraph draws new numbers at every replay.  ptrs/counts/... are HOST arrays. */
+#define GV_RNG_MAX_JOBS 8
+#define GV_RNG_KEEP_MASK 0
+#define GV_RNG_NORMAL 1
+int gv_rng_fill(const uint64_t* rng_state, int n_jobs, void* const* ptrs, const int64_t* counts, const int32_t* kinds,
+                const float* drop_p, const uint32_t* streams, void* stream);
+int gv_rng_tick(uint64_t* rng_state, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  Gaussian parameters + reparameterisation (kgvae/utils.py:323-361, kgvae/model.py:112-113)

@@ -1,0 +1,55 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy restatement of the device RNG contract of include/gcnvae.h (gv_rng_fill).
+
+Philox4x32-10 as published (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11;
+multipliers 0xD2511F53 / 0xCD9E8D57, Weyl key increments 0x9E3779B9 / 0xBB67AE85), pinned against the paper's
+known-answer vectors in tests/test_oracle_golden.py.  The reference draws its randomness from torch's CPU generator
+(nn.Dropout, randn_like: kgvae/utils.py:342-361); that stream cannot be reproduced on a device, so the product defines
+its own counter-based stream and this file is its checker: masks must match bit for bit, normals to float rounding.
+"""
+import numpy as np
+
+M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+W0, W1 = 0x9E3779B9, 0xBB67AE85
+MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(key, ctr):
+    """key: (k0, k1) python ints; ctr: uint32 array (..., 4).  Returns uint32 array (..., 4)."""
+    c = [ctr[..., i].astype(np.uint64) for i in range(4)]
+    k0, k1 = key[0] & 0xFFFFFFFF, key[1] & 0xFFFFFFFF
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        hi0, lo0 = p0 >> np.uint64(32), p0 & MASK
+        hi1, lo1 = p1 >> np.uint64(32), p1 & MASK
+        c = [hi1 ^ c[1] ^ np.uint64(k0), lo1, hi0 ^ c[3] ^ np.uint64(k1), lo0]
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def _raw(seed, tick, stream, n):
+    groups = (n + 3) // 4
+    ctr = np.zeros((groups, 4), dtype=np.uint32)
+    ctr[:, 0] = np.arange(groups, dtype=np.uint64).astype(np.uint32)
+    ctr[:, 1] = stream & 0xFFFFFFFF
+    ctr[:, 2] = tick & 0xFFFFFFFF
+    ctr[:, 3] = (tick >> 32) & 0xFFFFFFFF
+    return philox4x32_10((seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF), ctr)
+
+
+def keep_mask(seed, tick, stream, n, drop_p):
+    """uint8 (n,): byte = (u32 >= floor(float32(drop_p) * 2^32))."""
+    th = min(int(float(np.float32(drop_p)) * 4294967296.0), 4294967295)
+    return (_raw(seed, tick, stream, n).reshape(-1)[:n] >= np.uint32(th)).astype(np.uint8)
+
+
+def normals(seed, tick, stream, n):
+    """float32 (n,): Box-Muller on (x0, x1) -> outputs 0, 1 and (x2, x3) -> outputs 2, 3 of each group."""
+    x = _raw(seed, tick, stream, n).astype(np.float32)          # the kernel converts u32 -> f32 (round to nearest)
+    s = np.float32(2.3283064365386963e-10)
+    out = np.empty((x.shape[0], 4), dtype=np.float32)
+    for a, b, o in ((0, 1, 0), (2, 3, 2)):
+        u1 = (x[:, a] + np.float32(1.0)) * s
+        r = np.sqrt(np.float32(-2.0) * np.log(u1))
+        th = np.float32(6.283185307179586) * (x[:, b] * s)
+        out[:, o], out[:, o + 1] = r * np.cos(th), r * np.sin(th)
+    return out.reshape(-1)[:n]

@@ -453,3 +453,68 @@ def test_odd_widths_and_degenerate_graphs(ops):
     close(ops.gemm(xt.cuda(), p['loop_weight'].cuda()), xt.double() @ p['loop_weight'].double())
     with pytest.raises(TypeError):
         ops.gemm(x.cuda().double(), p['loop_weight'].cuda())
+
+
+# ------------------------------------------------------------------------------------------------
+# device RNG (gv_rng_fill): bit-exact against the numpy Philox restatement, fresh draws per tick
+@pytest.mark.gpu
+def test_device_rng_matches_philox_oracle_and_ticks(ops):
+    from oracle import philox
+    torch.manual_seed(1234)
+    rng = ops.device_rng('cuda')
+    rng.tick()                                           # also syncs the seed
+    seed, tick = (int(v) for v in rng.state.cpu())
+    assert seed == 1234
+    n_mask, n_norm = 14541 * 200 + 3, 40 * 200 + 1      # lengths that are not multiples of 4
+    keep = torch.empty(n_mask, dtype=torch.uint8, device='cuda')
+    keep2 = torch.empty(1000, dtype=torch.uint8, device='cuda')
+    eps = torch.empty(n_norm, dtype=torch.float32, device='cuda')
+    rng.fill([(keep, ops.RNG_KEEP_MASK, 0.2, 11), (eps, ops.RNG_NORMAL, 0.0, 12), (keep2, ops.RNG_KEEP_MASK, 0.5, 13)])
+    assert np.array_equal(keep.cpu().numpy(), philox.keep_mask(seed, tick, 11, n_mask, 0.2))        # bit-exact
+    assert np.array_equal(keep2.cpu().numpy(), philox.keep_mask(seed, tick, 13, 1000, 0.5))
+    want = philox.normals(seed, tick, 12, n_norm)
+    np.testing.assert_allclose(eps.cpu().numpy(), want, rtol=0, atol=2e-5)    # libm vs device log/sincos
+    assert abs(float(keep.float().mean()) - 0.8) < 2e-3
+    assert abs(float(eps.mean())) < 0.05 and abs(float(eps.std()) - 1.0) < 0.05
+    # drawing the same stream again within a tick forces a tick: new numbers, and the state moved by one
+    first = keep.clone()
+    rng.fill([(keep, ops.RNG_KEEP_MASK, 0.2, 11)])
+    assert int(rng.state[1]) == tick + 1
+    assert not torch.equal(first, keep)
+    assert np.array_equal(keep.cpu().numpy(), philox.keep_mask(seed, tick + 1, 11, n_mask, 0.2))
+    # a new torch.manual_seed value restarts the stream at tick 0
+    torch.manual_seed(4321)
+    rng.fill([(keep2, ops.RNG_KEEP_MASK, 0.5, 13)])
+    assert [int(v) for v in rng.state.cpu()] == [4321, 0]
+    assert np.array_equal(keep2.cpu().numpy(), philox.keep_mask(4321, 0, 13, 1000, 0.5))
+
+
+@pytest.mark.gpu
+def test_device_rng_draws_fresh_numbers_on_graph_replay(ops):
+    """The embedding lookup carries the tick, so a captured forward draws new dropout masks at every replay."""
+    torch.manual_seed(7)
+    table = torch.randn(50, 8, device='cuda')
+    ids = torch.arange(50, device='cuda')
+    rng = ops.device_rng('cuda')
+    keep = torch.empty(4096, dtype=torch.uint8, device='cuda')
+
+    def step():
+        ops.embedding(table, ids, rng)
+        rng.fill([(keep, ops.RNG_KEEP_MASK, 0.5, 99)])
+
+    step()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    seen = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        seen.append(keep.clone())
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])

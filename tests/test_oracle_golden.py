@@ -158,3 +158,17 @@ def test_whole_model_c1_without_flows():
     for k, v in g.items():
         if k.startswith('grad.'):
             torch.testing.assert_close(state[k[5:]].grad, v, rtol=1e-5, atol=1e-6, msg=k)
+
+
+def test_philox_known_answers():
+    """Random123's published known-answer vectors for philox4x32_10 (kat_vectors: zeros, ones, digits of pi)."""
+    import numpy as np
+    from oracle import philox
+
+    def run(ctr, key):
+        return [int(v) for v in philox.philox4x32_10(key, np.array([ctr], dtype=np.uint32))[0]]
+
+    assert run([0, 0, 0, 0], (0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert run([0xffffffff] * 4, (0xffffffff, 0xffffffff)) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert run([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], (0xa4093822, 0x299f31d0)) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
