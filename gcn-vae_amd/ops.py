@@ -476,6 +476,7 @@ class DeviceRNG:
             self._used.clear()
 
     def tick(self):
+        self._sync_seed()
         lib.call('gv_rng_tick', ptr(self.state), lib.stream())
         self._used.clear()
 
