@@ -41,6 +41,8 @@ def parse():
     p.add_argument('--hidden', type=int, default=200)
     p.add_argument('--n-bases', type=int, default=100)
     p.add_argument('--n-flows', type=int, default=0)
+    p.add_argument('--gemm-precision', choices=['f32', 'bf16'], default='f32',
+                   help="bf16: dense products with bf16 operands / fp32 accumulation (configs[2]'s precision); default fp32")
     p.add_argument('--positives', type=int, default=20000)
     p.add_argument('--negative-sample', type=int, default=10)
     p.add_argument('--dropout', type=float, default=0.2)
@@ -195,6 +197,8 @@ def main():
         world = max(world, 1)
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs an MI355X (no CPU path); the cpu_baseline leg alone is not a benchmark')
+    from gcn_vae_amd import ops as _ops
+    _ops.set_gemm_precision(args.gemm_precision)
     dist_on = world > 1 or args.force_dist
     if args.force_dist and world == 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -326,14 +330,16 @@ def main():
             'metric': 'edges/sec R-GCN forward+backward, FB15k-237 emb=200',
             'value': world * E * args.steps / elapsed, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.gemm_precision == 'f32' else 'f32 (dense products: bf16 operands, f32 accumulate)',
+            'data': 'synthetic',
             'config': {'workload': 'FB15k-237-shaped synthetic full graph (BASELINE configs[1]): 14541 entities, '
                                    '474 directed relation types, E=%d directed edges per GPU, 2-layer R-GCN-VAE bdd '
                                    'num_bases=%d emb_dim=%d fp32 dropout %.1f, DistMult decoder on T=%d triplets, '
                                    'step = fwd + loss(BCE+reg+KL+MMD) + bwd + clip + Adam' %
                                    (E, args.n_bases, args.hidden, args.dropout, T),
                        'edges_per_gpu': E, 'nodes': n_nodes, 'triplets_per_gpu': T, 'n_flows': args.n_flows,
-                       'launch': launch, 'parallelism': 'edge-block sharding x%d, RCCL all-reduce of node embeddings' % world
+                       'gemm_precision': args.gemm_precision, 'launch': launch, 'parallelism': 'edge-block sharding x%d, RCCL all-reduce of node embeddings' % world
                        if world > 1 else 'single GPU'},
             'final_loss': final_loss,
             'roofline': roofline, 'roofline_detail': detail,

@@ -197,6 +197,108 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmParams p) {
     }
 }
 
+// ---- bf16-operand variant (BASELINE configs[2]: bf16 with fp32 accumulation) --------------------------------------
+// Same contract and epilogue as k_gemm_f32; A and B are read as fp32 from memory, rounded to bf16 (RNE,
+// v_cvt_pk_bf16_f32) on their way into LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulators:
+// a bf16 x bf16 product is exact in fp32, so the result equals an fp32 GEMM of the rounded operands up to summation
+// order.  Block tile 64 x 64 x 32, four waves 2 x 2, one 32x32 accumulator per wave, two MFMAs per tile.
+// LDS holds both tiles k-contiguous, [row][32 k + 8 pad] bf16: the operand fragment of lane l (row l&31, k = 8*(l>>5)
+// .. +7) is ONE 16-byte ds_read_b128, conflict-free at the 80-byte row pitch.  Staging: an operand whose k runs
+// along memory (A [M,K]; B stored [N,K]) is read as 2 x 16 B per thread; one whose k is the row index (A stored [K,M];
+// B [K,N]) as 8 coalesced 4-B loads (64 consecutive rows per wave instruction) -- either way 8 k-values of one row per
+// thread, packed into one 16-byte LDS store.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int HB_BK = 32, HB_LD = 40;      // bf16 elements per LDS row (80 B)
+
+// KC: element (row, k) at base[row * ld + k]
+__device__ __forceinline__ void hb_load_kc(const float* base, const float* mask, int ld, int row0, int rows, int k0, int kend,
+                                           bool vec, float (&r)[8]) {
+    const int t = threadIdx.x;
+    const int row = row0 + (t >> 2), kk = k0 + (t & 3) * 8;
+    const bool ok = row < rows;
+    const float* src = base + (size_t)row * ld + kk;
+    load_run<8>(src, kk, kend, ok, vec, r, 0);
+    if (mask) mask_run<8>(mask + (size_t)row * ld + kk, kk, kend, ok, vec, r);
+}
+
+// KS: element (row, k) at base[k * ld + row]
+__device__ __forceinline__ void hb_load_ks(const float* base, const float* mask, int ld, int row0, int rows, int k0, int kend,
+                                           float (&r)[8]) {
+    const int t = threadIdx.x;
+    const int row = row0 + (t & 63), kk = k0 + (t >> 6) * 8;
+    const bool ok = row < rows;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool in = ok && kk + j < kend;
+        float v = in ? base[(size_t)(kk + j) * ld + row] : 0.f;
+        if (mask && in) v = mask[(size_t)(kk + j) * ld + row] > 0.f ? v : 0.f;
+        r[j] = v;
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void hb_stage(__bf16* S, const float (&r)[8]) {
+    const int t = threadIdx.x;
+    const int row = KC ? (t >> 2) : (t & 63), kk = KC ? (t & 3) * 8 : (t >> 6) * 8;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)r[j];
+    *reinterpret_cast<bf16x8*>(S + row * HB_LD + kk) = v;
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_gemm_bf16(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[64 * HB_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[64 * HB_LD];
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int kbeg = blockIdx.z * p.k_chunk;
+    const int kend = min(p.k, kbeg + p.k_chunk);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm = (wid >> 1) * 32, wn = (wid & 1) * 32;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    float ra[8], rb[8];
+    auto load_tiles = [&](int k0) {
+        if constexpr (!TA) hb_load_kc(p.a, p.a_mask, p.lda, m0, p.m, k0, kend, p.vec_a, ra);
+        else hb_load_ks(p.a, p.a_mask, p.lda, m0, p.m, k0, kend, ra);
+        if constexpr (TB) hb_load_kc(p.b, nullptr, p.ldb, n0, p.n, k0, kend, p.vec_b, rb);
+        else hb_load_ks(p.b, nullptr, p.ldb, n0, p.n, k0, kend, rb);
+    };
+    load_tiles(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += HB_BK) {
+        hb_stage<!TA>(As, ra);
+        hb_stage<TB>(Bs, rb);
+        __syncthreads();
+        if (k0 + HB_BK < kend) load_tiles(k0 + HB_BK);     // next tile's loads fly under this tile's MFMAs
+#pragma unroll
+        for (int kk = 0; kk < HB_BK; kk += 16) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(As + (wm + l31) * HB_LD + kk + 8 * lhi);
+            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(Bs + (wn + l31) * HB_LD + kk + 8 * lhi);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wn + l31;
+    if (col >= p.n) return;
+    const float bv = (p.bias && p.split_k == 1) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row >= p.m) continue;
+        float v = acc[r];
+        if (p.split_k > 1) {
+            p.ws[((size_t)blockIdx.z * p.m + row) * p.n + col] = v;
+        } else {
+            v = apply_act(v + bv, p.act);
+            float* dst = p.c + (size_t)row * p.ldc + col;
+            *dst = p.accumulate ? *dst + v : v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gemm_splitk_reduce(const GemmParams p) {
     const size_t total = (size_t)p.m * p.n;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -300,9 +402,9 @@ extern "C" int64_t gv_gemm_workspace_bytes(int m, int n, int k, int split_k) {
     return split_k > 1 ? (int64_t)split_k * m * n * (int64_t)sizeof(float) : 0;
 }
 
-extern "C" int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b,
-                           int ldb, float* c, int ldc, const float* bias, int act, int accumulate, int split_k,
-                           const float* a_relu_mask, void* workspace, int64_t workspace_bytes, void* stream) {
+static int gemm_any(bool bf16, int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b,
+                    int ldb, float* c, int ldc, const float* bias, int act, int accumulate, int split_k,
+                    const float* a_relu_mask, void* workspace, int64_t workspace_bytes, void* stream) {
     GV_REQUIRE(m >= 0 && n >= 0 && k >= 0, GV_ERR_SHAPE, "gv_gemm_f32: negative size");
     if (m == 0 || n == 0) return GV_OK;
     GV_REQUIRE(a && b && c, GV_ERR_NULL, "gv_gemm_f32: NULL matrix");
@@ -327,6 +429,22 @@ extern "C" int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const 
                    (long long)gv_gemm_workspace_bytes(m, n, k, split_k));
     }
     hipStream_t st = (hipStream_t)stream;
+    if (bf16) {
+        dim3 grid((n + 63) / 64, (m + 63) / 64, split_k), block(256);
+        if (!trans_a && !trans_b) hipLaunchKernelGGL((k_gemm_bf16<false, false>), grid, block, 0, st, p);
+        else if (!trans_a && trans_b) hipLaunchKernelGGL((k_gemm_bf16<false, true>), grid, block, 0, st, p);
+        else if (trans_a && !trans_b) hipLaunchKernelGGL((k_gemm_bf16<true, false>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((k_gemm_bf16<true, true>), grid, block, 0, st, p);
+        int rcb = launch_status("gv_gemm_bf16");
+        if (rcb != GV_OK) return rcb;
+        if (split_k > 1) {
+            const size_t total = (size_t)m * n;
+            const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+            hipLaunchKernelGGL(k_gemm_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);
+            return launch_status("gv_gemm_bf16(split-k reduce)");
+        }
+        return GV_OK;
+    }
     // Tile choice (measured on the C2 shapes, tools/microbench.py): 64-row tiles unless 128-row tiles still give every
     // CU >= 4 blocks; 64-column tiles; BK = 16 for the row-major-A
     // products (K = 200..400), 32 for the split-K weight-gradient products (A stored [K, M], K = nodes).
@@ -362,6 +480,20 @@ extern "C" int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const 
         return launch_status("gv_gemm_f32(split-k reduce)");
     }
     return GV_OK;
+}
+
+extern "C" int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b,
+                           int ldb, float* c, int ldc, const float* bias, int act, int accumulate, int split_k,
+                           const float* a_relu_mask, void* workspace, int64_t workspace_bytes, void* stream) {
+    return gemm_any(false, trans_a, trans_b, m, n, k, a, lda, b, ldb, c, ldc, bias, act, accumulate, split_k, a_relu_mask,
+                    workspace, workspace_bytes, stream);
+}
+
+extern "C" int gv_gemm_bf16(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b,
+                            int ldb, float* c, int ldc, const float* bias, int act, int accumulate, int split_k,
+                            const float* a_relu_mask, void* workspace, int64_t workspace_bytes, void* stream) {
+    return gemm_any(true, trans_a, trans_b, m, n, k, a, lda, b, ldb, c, ldc, bias, act, accumulate, split_k, a_relu_mask,
+                    workspace, workspace_bytes, stream);
 }
 
 extern "C" int gv_colsum_finish(const float* part, int n, int n_slices, float* out, int accumulate, void* stream) {

@@ -346,9 +346,31 @@ def bdd_grad_weight(seg: SegmentItems, src, dst, coef, coef_idx, x, g, num_bases
     return out
 
 
+GEMM_PRECISION = 'f32'      # 'f32': exact fp32 MFMA; 'bf16': bf16 operands, fp32 accumulation (BASELINE configs[2])
+
+
+def set_gemm_precision(precision):
+    """Precision of every dense product on the path (MaskedLinear, self-loop term, evaluation scorer)."""
+    global GEMM_PRECISION
+    if precision not in ('f32', 'bf16'):
+        raise ValueError("precision must be 'f32' or 'bf16'")
+    GEMM_PRECISION = precision
+
+
+@contextlib.contextmanager
+def gemm_precision(precision):
+    old = GEMM_PRECISION
+    set_gemm_precision(precision)
+    try:
+        yield
+    finally:
+        set_gemm_precision(old)
+
+
 def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, accumulate=False, split_k=1,
-         a_relu_mask=None):
-    """out = act(op(a') @ op(b) + bias) (+ out);  a' = a * [a_relu_mask > 0] when a mask (same layout as a) is given."""
+         a_relu_mask=None, precision=None):
+    """out = act(op(a') @ op(b) + bias) (+ out);  a' = a * [a_relu_mask > 0] when a mask (same layout as a) is given.
+    precision None = the global GEMM_PRECISION."""
     a, lda = _row_major(a, 'a')
     b, ldb = _row_major(b, 'b')
     m, k = (a.shape[1], a.shape[0]) if trans_a else a.shape
@@ -368,7 +390,8 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, 
         a_relu_mask, ld_mask = _row_major(a_relu_mask, 'a_relu_mask')
         if tuple(a_relu_mask.shape) != tuple(a.shape) or ld_mask != lda:
             raise ValueError('a_relu_mask must have the shape and leading dimension of a')
-    lib.call('gv_gemm_f32', 1 if trans_a else 0, 1 if trans_b else 0, m, n, k, ptr(a), lda, ptr(b), ldb, ptr(out),
+    entry = 'gv_gemm_bf16' if (precision or GEMM_PRECISION) == 'bf16' else 'gv_gemm_f32'
+    lib.call(entry, 1 if trans_a else 0, 1 if trans_b else 0, m, n, k, ptr(a), lda, ptr(b), ldb, ptr(out),
              out.stride(0) if m > 1 else n, ptr(bias), act, 1 if accumulate else 0, split_k, ptr(a_relu_mask), ptr(ws),
              ws_bytes, lib.stream())
     return out

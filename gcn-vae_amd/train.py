@@ -91,6 +91,7 @@ def main(args):
                            'there is no CPU path')
     torch.cuda.set_device(args.gpu)
     dev = torch.device('cuda', args.gpu)
+    ops.set_gemm_precision('bf16' if getattr(args, 'bf16', False) else 'f32')
 
     model_class = KGVAE if args.model_class == "KGVAE" else RGCN
     model = LinkPredict(model_class=model_class, in_dim=num_nodes, h_dim=args.n_hidden, num_rels=num_rels,
@@ -219,6 +220,9 @@ def build_parser():
     p.add_argument("--model-class", type=str, default='KGVAE', help="model class")
     p.add_argument("--load", type=bool, default=False, help="whether to load a model state file for training")
     p.add_argument("--generate", type=bool, default=False, help="(reference demo; not supported here)")
+    p.add_argument("--bf16", action="store_true",
+                   help="dense products (MaskedLinear, self-loop term, evaluation scorer) with bf16 operands and fp32 "
+                        "accumulation (BASELINE configs[2]); not a reference flag, default fp32")
     p.add_argument("--device-sampler", action="store_true",
                    help="prepare batches on the GPU (uniform sampler, torch's device RNG instead of numpy's: not the "
                         "reference's random stream, ~10x less host time per step)")

@@ -122,6 +122,12 @@ int64_t gv_gemm_workspace_bytes(int m, int n, int k, int split_k);
 int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b, int ldb,
                 float* c, int ldc, const float* bias, int act, int accumulate, int split_k, const float* a_relu_mask,
                 void* workspace, int64_t workspace_bytes, void* stream);
+/* The same product with bf16 OPERANDS and fp32 accumulation (BASELINE configs[2]: "bf16"): A and B are fp32 in memory,
+ * rounded to bf16 (round-to-nearest-even) as they are staged, multiplied on v_mfma_f32_32x32x16_bf16; bias, act,
+ * accumulate, split-K and the result stay fp32.  Equals an fp32 GEMM of the rounded operands up to summation order. */
+int gv_gemm_bf16(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b, int ldb,
+                float* c, int ldc, const float* bias, int act, int accumulate, int split_k, const float* a_relu_mask,
+                void* workspace, int64_t workspace_bytes, void* stream);
 /* a_relu_mask (optional, same storage layout and lda as A): A is read as (mask > 0 ? A : 0), i.e. the ReLU backward
  * g * [h > 0] is folded into the operand load of the two gradient products of a MaskedLinear layer. */
 

@@ -14,6 +14,8 @@ A MADE block is described here by ``(input_size, hidden_size, n_hidden)`` plus a
 import torch
 import torch.nn.functional as F
 
+from . import bf16
+
 
 def made_degrees(input_size, hidden_size, n_hidden):
     """flow_network.py:69-77 -- list of n_hidden+3 int64 degree vectors (``MADE.m``)."""
@@ -42,7 +44,7 @@ def made_net(x, layers, masks):
     h = x
     last = len(layers) - 1
     for li, ((w, b), m) in enumerate(zip(layers, masks)):
-        h = F.linear(h, m * w, b)
+        h = bf16.linear(h, m * w, b)
         if li != last:
             h = torch.relu(h)
     return h

@@ -23,6 +23,8 @@ Three implementations live here so they can be checked against each other:
 """
 import torch
 
+from . import bf16
+
 
 def clamp_num_bases(num_bases, num_rels):
     """DGL 0.4.x: ``None``, negative or > num_rels  ==>  num_rels."""
@@ -99,7 +101,7 @@ def rel_graph_conv(x, src, dst, etypes, norm, params, regularizer='bdd', num_bas
     if 'h_bias' in params:
         h = h + params['h_bias']
     if 'loop_weight' in params:
-        h = h + x @ params['loop_weight']
+        h = h + bf16.mm(x, params['loop_weight'])      # fp32 unless oracle.bf16.enabled()
     if activation is not None:
         h = activation(h)
     if dropout_keep is not None:

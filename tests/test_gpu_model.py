@@ -341,3 +341,88 @@ def test_device_sampler_batches_are_well_formed_and_train():
     assert losses[-1] < losses[0]
     g, node_id, et, en = sm.full_graph()
     assert len(g) == 2000 and g.number_of_edges() == 60000 and node_id.shape == (2000, 1)
+
+
+def _wn18rr_shaped_case(n_nodes=4000, n_rel=11, n_trip=9000, h=200, nb=20, n_flows=3):
+    """BASELINE configs[2] in shape (WN18RR: 11 relations -> 22 directed types, so num_bases = 20 and 10x10 / 10x20
+    blocks; 3 IAF blocks), scaled down in node count so that the CPU oracle finishes in seconds."""
+    from gcn_vae_amd import sampling
+    from gcn_vae_amd.data import synthetic_kg
+    from gcn_vae_amd.encoders import KGVAE
+    from gcn_vae_amd.train import LinkPredict
+    data = synthetic_kg(n_nodes, n_rel, n_trip, seed=3)
+    graph, rel, node_norm = sampling.build_test_graph(data.num_nodes, data.num_rels, data.train)
+    torch.manual_seed(0)
+    net = LinkPredict(KGVAE, data.num_nodes, h, data.num_rels, num_bases=nb, num_hidden_layers=2, dropout=0.0,
+                      use_cuda=True, reg_param=0.01, kl_param=1e-3, mmd_param=1.0, k=10, n_flows=n_flows)
+    state = {k: v.detach().clone().requires_grad_(v.is_floating_point() and 'mask' not in k and not k.endswith('.pi'))
+             for k, v in net.state_dict().items()}
+    gen = torch.Generator().manual_seed(9)
+    eps, eps_prior = torch.randn(n_nodes, h, generator=gen), torch.randn(200, h, generator=gen)
+    random.seed(4)
+    post_idx = torch.tensor(random.sample(range(n_nodes), 200))
+    src, dst = graph.edges()
+    node_id = torch.arange(n_nodes).view(-1, 1)
+    etype = torch.from_numpy(rel)
+    enorm = sampling.node_norm_to_edge_norm(graph, torch.from_numpy(node_norm).view(-1, 1))
+    np.random.seed(1)
+    pos = data.train[np.random.choice(len(data.train), 3000, replace=False)]
+    samples, labels = sampling.negative_sampling(pos, n_nodes, 2)
+    return dict(net=net, state=state, graph=graph, src=src, dst=dst, node_id=node_id, etype=etype, enorm=enorm, eps=eps,
+                eps_prior=eps_prior, post_idx=post_idx, samples=torch.from_numpy(samples), labels=torch.from_numpy(labels),
+                nb=nb, n_flows=n_flows)
+
+
+def _oracle_step(c):
+    state = {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in c['state'].items()}
+    enc = okg.kgvae_encode(state, c['src'], c['dst'], c['node_id'], c['etype'], c['enorm'], c['eps'], c['nb'],
+                           c['n_flows'], 0.0, None, None)
+    lo = okg.link_predict_loss(state, enc, c['samples'], c['labels'], 0.01, 1e-3, 1.0, 10, c['n_flows'], c['eps_prior'],
+                               c['post_idx'])
+    lo[0].backward()
+    return state, enc, lo
+
+
+def test_c3_wn18rr_shape_bf16_operand_gemms():
+    """configs[2]: every dense product (MaskedLinear, self-loop term) with bf16 operands and fp32 accumulation.
+    Checked against the oracle's emulation of exactly that (oracle/bf16.py; tolerance 5e-3: a last-bit difference in an
+    fp32 activation can flip its bf16 rounding, 2^-9 relative on that operand) and, loosely, against the fp32 oracle."""
+    from gcn_vae_amd import ops
+    from oracle import bf16
+    c = _wn18rr_shaped_case()
+    with bf16.enabled():
+        st_b, enc_b, lo_b = _oracle_step(c)
+    st_f, enc_f, lo_f = _oracle_step(c)
+    net = c['net'].cuda().train()
+    e = net.encoder
+    e.eps_override, e.mmd_eps_override, e.mmd_index_override = c['eps'].cuda(), c['eps_prior'].cuda(), c['post_idx'].cuda()
+
+    def run():
+        net.zero_grad()
+        embed = net(c['graph'], c['node_id'].cuda(), c['etype'].cuda(), c['enorm'].cuda())
+        lg = net.get_loss(c['graph'], embed, c['samples'].cuda(), c['labels'].cuda())
+        lg[0].backward()
+        return embed, lg
+
+    with ops.gemm_precision('bf16'):
+        embed, lg = run()
+        grads = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+    close(embed, enc_b['z'], rtol=5e-3, atol_scale=5e-3, msg='z (bf16 operands)')
+    for a, b, nm in zip(lg, lo_b, ('loss', 'pred', 'kl', 'mmd')):
+        close(a, b, rtol=5e-3, atol_scale=5e-3, msg=nm + ' (bf16 operands)')
+    for name, g in grads.items():
+        if st_b[name].grad is not None:
+            close(g, st_b[name].grad, rtol=2e-2, atol_scale=2e-2, msg='grad ' + name + ' (bf16 operands)')
+    # the mode is really on (differs from fp32) and stays near the fp32 result
+    zf = enc_f['z'].detach()
+    dz = float((embed.detach().cpu() - zf).abs().max()) / float(zf.abs().max())
+    assert 1e-5 < dz < 5e-2, dz
+    assert abs(float(lg[0]) - float(lo_f[0])) < 5e-2 * max(1.0, abs(float(lo_f[0])))
+    # and the same modules in fp32 meet the 1e-4 bar on this shape (10x10 / 10x20 blocks, R = 22)
+    embed32, lg32 = run()
+    close(embed32, enc_f['z'], msg='z fp32')
+    for a, b, nm in zip(lg32, lo_f, ('loss', 'pred', 'kl', 'mmd')):
+        close(a, b, msg=nm + ' fp32')
+    for name, p in net.named_parameters():
+        if st_f[name].grad is not None:
+            close(p.grad, st_f[name].grad, rtol=5e-4, atol_scale=5e-5, msg='grad ' + name + ' fp32')

@@ -56,11 +56,12 @@ def bench_gemm():
         b = torch.randn((n, k) if tb else (k, n), device='cuda')
         sk = ops.pick_split_k(m, n, k) if ta else 1
         t_mine = timeit(lambda: ops.gemm(a, b, trans_a=ta, trans_b=tb, split_k=sk))
+        t_bf16 = timeit(lambda: ops.gemm(a, b, trans_a=ta, trans_b=tb, split_k=sk, precision='bf16'))
         aa, bb = (a.t() if ta else a), (b.t() if tb else b)
         t_torch = timeit(lambda: torch.mm(aa, bb))
         fl = 2.0 * m * n * k
         print(f'{name}  m={m:6d} n={n:4d} k={k:6d} split_k={sk:2d}: mine {t_mine:7.1f} us ({fl / t_mine / 1e6:6.1f} TF)   '
-              f'torch.mm {t_torch:7.1f} us')
+              f'bf16 operands {t_bf16:7.1f} us   torch.mm {t_torch:7.1f} us')
 
 
 def bench_k1(chunk=256, chunk_rel=128):
