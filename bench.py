@@ -47,6 +47,8 @@ def parse():
     p.add_argument('--negative-sample', type=int, default=10)
     p.add_argument('--dropout', type=float, default=0.2)
     p.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
+    p.add_argument('--graph-collectives', action='store_true',
+                   help='world size > 1: capture the RCCL all-reduces in the hipGraph too (default there: eager launches)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU-oracle baseline leg')
     p.add_argument('--force-dist', action='store_true', help='run the RCCL code path even at world size 1 (testing)')
@@ -219,7 +221,10 @@ def main():
     enorm, samples, labels = w['enorm'], w['samples'].to(dev), w['labels'].to(dev)
     n_nodes, E, T = w['data'].num_nodes, int(w['src'].numel()), int(samples.shape[0])
     params = [p for p in model.parameters() if p.requires_grad]
-    use_graph = not args.no_graph      # RCCL collectives are captured too (checked with a 1-rank group); on failure: eager
+    # One GPU: the step is replayed as a hipGraph.  With RCCL collectives in the step (world > 1) the default is eager
+    # launching -- measured equal to graph replay on one GPU (the step is GPU-bound: ~55 launches of 5-130 us against
+    # ~15 us of host work each), and it keeps RCCL out of stream capture, which only a 1-rank group could verify here.
+    use_graph = not args.no_graph and (world == 1 or args.graph_collectives)
     from gcn_vae_amd.optim import FlatAdam
     opt = FlatAdam(params, lr=1e-3, max_grad_norm=1.0)      # clip_grad_norm_(1.0) + Adam over one flat arena
     if dist_on:

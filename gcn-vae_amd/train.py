@@ -74,6 +74,11 @@ class LinkPredict(nn.Module):
             embed, enc.z_mean if kl_w > 0 else None, enc.z_sigma if kl_w > 0 else None, self.w_relation,
             enc.z_pre.squeeze(0) if kl_w > 0 else None, flp, z_pri, pick, labels, tidx, self.reg_param, kl_w, mmd_w,
             score_bias=self.n_flows > 0)
+        # shapes as the reference returns them: a disabled term is ``zeros(1)`` there and broadcasts the loss to (1,)
+        kl = kl.reshape(()) if kl_w > 0 else kl.reshape(1)
+        mmd = mmd.reshape(()) if mmd_w > 0 else mmd.reshape(1)
+        if kl_w <= 0 or mmd_w <= 0:
+            loss = loss.reshape(1)
         return loss, predict_loss, kl, mmd
 
 
