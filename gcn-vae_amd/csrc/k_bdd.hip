@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void k_agg_fast(const AggParams a) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (wave >= a.n_items) return;
     const int4 it = a.items[wave];
+    if (it.x < 0) return;                 // unused tail entry of an upper-bound-sized item list
     const bool active = lane * BPL < a.nbp;
     const int blk0 = blockIdx.y * a.nbp + lane * BPL;       // first diagonal block this lane owns
     const float* __restrict__ fbase = a.feat + blk0 * P;
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(256) void k_agg_packed(const AggParams a) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (wave >= a.n_items) return;
     const int4 it = a.items[wave];
+    if (it.x < 0) return;                 // unused tail entry of an upper-bound-sized item list
     const int L = a.nb / BPL;
     const bool active = lane < L;
     const float4* __restrict__ wbase = reinterpret_cast<const float4*>(a.w) + lane;
@@ -274,6 +276,7 @@ __global__ __launch_bounds__(256) void k_agg_generic(const AggParams a) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (wave >= a.n_items) return;
     const int4 it = a.items[wave];
+    if (it.x < 0) return;                 // unused tail entry of an upper-bound-sized item list
     const int P = a.p, Q = a.q;
     for (int c0 = 0; c0 < a.out_dim; c0 += 64) {
         const int c = c0 + lane;
@@ -341,6 +344,7 @@ __global__ __launch_bounds__(256) void k_agg_fixup(const int4* fix, int n_fix, c
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (wave >= n_fix * tiles) return;
     const int4 f = fix[wave / tiles];
+    if (f.x < 0) return;                  // unused tail entry of an upper-bound-sized fix list
     const int c = (wave % tiles) * 64 + lane;
     if (c >= out_dim) return;
     float acc = ordered_slot_sum(partial + (size_t)f.y * out_dim + c, f.z, out_dim);
@@ -380,6 +384,7 @@ __global__ __launch_bounds__(256) void k_gradw_fast(const GradWParams a) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (wave >= a.n_items) return;
     const int4 it = a.items[wave];
+    if (it.x < 0) return;                 // unused tail entry of an upper-bound-sized item list
     const bool active = lane * BPL < a.nbp;
     const int blk0 = blockIdx.y * a.nbp + lane * BPL;
     const float* __restrict__ xbase = a.x + blk0 * P;
@@ -463,6 +468,7 @@ __global__ __launch_bounds__(256) void k_gradw_generic(const GradWParams a) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (wave >= a.n_items) return;
     const int4 it = a.items[wave];
+    if (it.x < 0) return;                 // unused tail entry of an upper-bound-sized item list
     const int P = a.p, Q = a.q;
     for (int c0 = 0; c0 < a.w_row; c0 += 64) {
         const int c = c0 + lane;
@@ -505,6 +511,7 @@ __global__ __launch_bounds__(256) void k_gradw_fixup(const int4* fix, int n_fix,
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (wave >= n_fix * tiles) return;
     const int4 f = fix[wave / tiles];
+    if (f.x < 0) return;                  // unused tail entry of an upper-bound-sized fix list
     const int c = (wave % tiles) * 64 + lane;
     if (c >= w_row) return;
     const float acc = ordered_slot_sum(partial + (size_t)f.y * w_row + c, f.z, w_row);

@@ -47,9 +47,11 @@ class DeviceSampler:
         key = (d * n + s) * (2 * self.num_rels) + r            # < n^2 * 2R: fits int64 for any realistic n
         order = torch.argsort(key)
         s, d, r = s[order], d[order], r[order]
-        deg = torch.bincount(d, minlength=n).to(torch.float32)
+        # in-degrees from the sorted destination column (torch.bincount would synchronise to size its output)
+        bounds = torch.searchsorted(d, torch.arange(n + 1, device=d.device, dtype=d.dtype))
+        deg = (bounds[1:] - bounds[:-1]).to(torch.float32)
         norm = torch.where(deg > 0, 1.0 / deg.clamp(min=1.0), torch.zeros_like(deg))
-        g = KGraph.from_device_edges(n, s, d)
+        g = KGraph.from_device_edges(n, s, d, dst_sorted=True)
         return g, r, norm[d].view(-1, 1)
 
     def sample(self, sample_size, split_size=0.5, negative_rate=10):

@@ -26,10 +26,12 @@ class KGraph:
 
     # -- construction ---------------------------------------------------------------------------
     @classmethod
-    def from_device_edges(cls, num_nodes, src, dst):
+    def from_device_edges(cls, num_nodes, src, dst, dst_sorted=None):
         """Handle over edge lists that already live on a ROCm device (device_sampling.DeviceSampler): the
-        kernels' index is built from them directly; a host copy is made only if ``edges()`` is asked for."""
+        kernels' index is built from them directly; a host copy is made only if ``edges()`` is asked for.
+        ``dst_sorted=True``: the caller guarantees the reference's (dst, src, rel) edge order, which saves the check."""
         g = cls()
+        g._dst_sorted = dst_sorted
         g._n = int(num_nodes)
         g._dev_edges = (src.to(torch.int64), dst.to(torch.int64))
         g._src = g._dst = None
@@ -104,9 +106,14 @@ class KGraph:
                 src, dst = (t.to(device) for t in self._dev_edges)
             else:
                 src, dst = self._src.to(device), self._dst.to(device)
-            idx = self._index[key] = ops.GraphIndex(src, dst, self._n)
+            # graphs of mini-batch size are rebuilt every step: build their index without host synchronisation
+            small = src.numel() <= SYNC_FREE_MAX_EDGES
+            idx = self._index[key] = ops.GraphIndex(src, dst, self._n, dst_sorted=getattr(self, '_dst_sorted', None),
+                                                    sync_free=small)
         return idx
 
+
+SYNC_FREE_MAX_EDGES = 200_000     # above this a graph is assumed to be built once: exact work-item lists
 
 DGLGraph = KGraph
 

@@ -111,38 +111,39 @@ class SegmentItems:
     chunk: int
 
 
-def build_segment_items(rowptr: torch.Tensor, chunk: int) -> SegmentItems:
-    """Cut a CSR segment list into <=chunk-edge work items (device kernels + two scans).
-    Synchronises once (item counts come back to the host); call outside the hot step."""
+def build_segment_items(rowptr: torch.Tensor, chunk: int, n_edges: Optional[int] = None) -> SegmentItems:
+    """Cut a CSR segment list into <=chunk-edge work items (two device kernels around one scan).
+
+    ``n_edges`` None: exact lists; the three totals come back to the host (ONE synchronisation) -- right for an index
+    that is built once per graph.  ``n_edges`` given (= rowptr[-1], known to the caller): no synchronisation at all --
+    the lists are sized by their upper bounds (items <= n_seg + E/chunk, fix-ups <= min(n_seg, E/chunk), slots <=
+    2 E/chunk) and pre-filled with -1, which the kernels skip -- right for per-mini-batch indices."""
     _chk(rowptr, torch.int32, 'rowptr')
     n_seg = rowptr.numel() - 1
     dev = rowptr.device
-    n_chunks = torch.empty(n_seg, dtype=torch.int32, device=dev)
-    n_slots = torch.empty(n_seg, dtype=torch.int32, device=dev)
-    is_split = torch.empty(n_seg, dtype=torch.int32, device=dev)
-    lib.call('gv_segment_items_count', ptr(rowptr), n_seg, chunk, ptr(n_chunks), ptr(n_slots), ptr(is_split),
+    counts = torch.empty(3, n_seg, dtype=torch.int32, device=dev)        # n_chunks, n_slots, is_split
+    lib.call('gv_segment_items_count', ptr(rowptr), n_seg, chunk, ptr(counts[0]), ptr(counts[1]), ptr(counts[2]),
              lib.stream())
-
-    def excl(t):
-        out = torch.zeros(n_seg + 1, dtype=torch.int32, device=dev)
-        out[1:] = torch.cumsum(t, 0)
-        return out
-
-    item_off, slot_off, fix_off = excl(n_chunks), excl(n_slots), excl(is_split)
-    totals = torch.stack([item_off[-1], slot_off[-1], fix_off[-1]]).tolist()
-    n_items, n_slot_total, n_fix = (int(v) for v in totals)
-    items = torch.empty(max(n_items, 1), 4, dtype=torch.int32, device=dev)
-    fix = torch.empty(max(n_fix, 1), 4, dtype=torch.int32, device=dev)
-    lib.call('gv_segment_items_fill', ptr(rowptr), n_seg, chunk, ptr(item_off), ptr(slot_off), ptr(fix_off),
+    offs = torch.zeros(3, n_seg + 1, dtype=torch.int32, device=dev)      # exclusive scans
+    offs[:, 1:] = torch.cumsum(counts, 1, dtype=torch.int32)
+    if n_edges is None:
+        n_items, n_slot_total, n_fix = (int(v) for v in offs[:, -1].tolist())
+        items = torch.empty(max(n_items, 1), 4, dtype=torch.int32, device=dev)
+        fix = torch.empty(max(n_fix, 1), 4, dtype=torch.int32, device=dev)
+    else:
+        extra = int(n_edges) // chunk + 1
+        n_items, n_fix, n_slot_total = n_seg + extra, min(n_seg, extra), 2 * extra
+        items = torch.full((max(n_items, 1), 4), -1, dtype=torch.int32, device=dev)
+        fix = torch.full((max(n_fix, 1), 4), -1, dtype=torch.int32, device=dev)
+    lib.call('gv_segment_items_fill', ptr(rowptr), n_seg, chunk, ptr(offs[0]), ptr(offs[1]), ptr(offs[2]),
              ptr(items), ptr(fix), lib.stream())
     return SegmentItems(items, fix, n_items, n_fix, n_slot_total, rowptr, chunk)
 
 
 def _rowptr_from_sorted(keys_sorted: torch.Tensor, n_seg: int) -> torch.Tensor:
-    counts = torch.bincount(keys_sorted, minlength=n_seg)
-    rp = torch.zeros(n_seg + 1, dtype=torch.int32, device=keys_sorted.device)
-    rp[1:] = torch.cumsum(counts, 0)
-    return rp
+    """CSR pointer of a sorted key list (no host synchronisation: torch.bincount would size its output on the host)."""
+    bounds = torch.arange(n_seg + 1, device=keys_sorted.device, dtype=keys_sorted.dtype)
+    return torch.searchsorted(keys_sorted.contiguous(), bounds).to(torch.int32)
 
 
 @dataclass
@@ -161,27 +162,34 @@ class GraphIndex:
     Relation-dependent arrays live in ``RelationIndex`` (etypes arrive per forward call).
     """
 
-    def __init__(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: int, chunk: int = DEFAULT_CHUNK):
+    def __init__(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: int, chunk: int = DEFAULT_CHUNK,
+                 dst_sorted: Optional[bool] = None, sync_free: bool = False):
+        """``dst_sorted``: None = check (one host synchronisation), True = the caller guarantees dst is non-decreasing.
+        ``sync_free``: size the work-item lists by upper bounds instead of reading their totals back (per-batch graphs)."""
         if not src.is_cuda:
             raise RuntimeError('GraphIndex needs CUDA index tensors; there is no CPU fallback')
         self.num_nodes, self.num_edges = int(num_nodes), int(src.numel())
         self.device = src.device
+        self.sync_free = bool(sync_free)
+        ne = self.num_edges if sync_free else None
         src = src.to(torch.int64)
         dst = dst.to(torch.int64)
         self.src32, self.dst32 = src.to(torch.int32), dst.to(torch.int32)
-        if self.num_edges and bool((dst[1:] >= dst[:-1]).all()):
+        if dst_sorted is None:
+            dst_sorted = bool(self.num_edges) and bool((dst[1:] >= dst[:-1]).all())
+        if dst_sorted:
             perm_d = None
-            dst_sorted = dst
+            dst_keys = dst
         else:
             perm_d = torch.sort(dst, stable=True)[1]
-            dst_sorted = dst[perm_d]
+            dst_keys = dst[perm_d]
         self.nbr_by_dst = (src if perm_d is None else src[perm_d]).to(torch.int32).contiguous()
         self.by_dst = EdgeOrder(None if perm_d is None else perm_d.to(torch.int32),
-                                build_segment_items(_rowptr_from_sorted(dst_sorted, self.num_nodes), chunk))
+                                build_segment_items(_rowptr_from_sorted(dst_keys, self.num_nodes), chunk, ne))
         perm_s = torch.sort(src, stable=True)[1]
         self.nbr_by_src = dst[perm_s].to(torch.int32).contiguous()
         self.by_src = EdgeOrder(perm_s.to(torch.int32),
-                                build_segment_items(_rowptr_from_sorted(src[perm_s], self.num_nodes), chunk))
+                                build_segment_items(_rowptr_from_sorted(src[perm_s], self.num_nodes), chunk, ne))
         self._rel_cache = {}
         self._chunk_cache = {}
 
@@ -236,7 +244,8 @@ class RelationIndex:
         self.src_by_rel = g.src32[perm_r].contiguous()
         self.dst_by_rel = g.dst32[perm_r].contiguous()
         self.by_rel = EdgeOrder(perm_r.to(torch.int32),
-                                build_segment_items(_rowptr_from_sorted(et[perm_r], self.num_rels), chunk))
+                                build_segment_items(_rowptr_from_sorted(et[perm_r], self.num_rels), chunk,
+                                                    g.num_edges if g.sync_free else None))
 
 
 class TripletIndex:
@@ -247,7 +256,7 @@ class TripletIndex:
     """
 
     def __init__(self, triplets: torch.Tensor, num_entities: int, num_rels: int, chunk: int = DEFAULT_CHUNK,
-                 chunk_rel: int = DEFAULT_CHUNK_REL):
+                 chunk_rel: int = DEFAULT_CHUNK_REL, sync_free: bool = False):
         if not triplets.is_cuda:
             raise RuntimeError('TripletIndex needs a CUDA tensor; there is no CPU fallback')
         t = triplets.to(torch.int64)
@@ -263,12 +272,14 @@ class TripletIndex:
         self.inc_other = other[perm].to(torch.int32).contiguous()
         self.inc_rel = rel2[perm].to(torch.int32).contiguous()
         self.inc_tid = tid[perm].to(torch.int32).contiguous()
-        self.inc = build_segment_items(_rowptr_from_sorted(ent[perm], self.num_entities), chunk)
+        self.inc = build_segment_items(_rowptr_from_sorted(ent[perm], self.num_entities), chunk,
+                                       2 * self.T if sync_free else None)
         perm_r = torch.sort(r, stable=True)[1]
         self.rel_s = s[perm_r].to(torch.int32).contiguous()
         self.rel_o = o[perm_r].to(torch.int32).contiguous()
         self.rel_tid = perm_r.to(torch.int32).contiguous()
-        self.rel = build_segment_items(_rowptr_from_sorted(r[perm_r], self.num_rels), chunk_rel)
+        self.rel = build_segment_items(_rowptr_from_sorted(r[perm_r], self.num_rels), chunk_rel,
+                                       self.T if sync_free else None)
 
 
 # ------------------------------------------------------------------------------------------------

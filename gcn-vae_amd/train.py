@@ -45,7 +45,8 @@ class LinkPredict(nn.Module):
         """Index of a triplet batch for the DistMult backward; cached per (storage, version)."""
         key = (triplets.data_ptr(), triplets._version, tuple(triplets.shape), embedding.shape[0])
         if key != self._tidx_key:
-            self._tidx = ops.TripletIndex(triplets.to(embedding.device), embedding.shape[0], self.w_relation.shape[0])
+            self._tidx = ops.TripletIndex(triplets.to(embedding.device), embedding.shape[0], self.w_relation.shape[0],
+                                          sync_free=True)
             self._tidx_key = key
             self._tidx_keepalive = triplets
         return self._tidx

@@ -48,6 +48,10 @@ const char* gv_last_error_string(void);
  *   gv_segment_items_count: n_chunks[s] = max(1, ceil(deg/chunk)); n_slots[s] = n_chunks>1 ? n_chunks : 0
  *   gv_segment_items_fill : item_off / slot_off / fix_off are EXCLUSIVE scans of n_chunks / n_slots /
  *                           (n_chunks>1), each with n_seg+1 entries.
+ * The K1 entry points ignore list entries whose first field is negative, so a caller that does not want to read the
+ * totals back (no host synchronisation per mini-batch) may size both lists by their upper bounds
+ * (items <= n_seg + E/chunk, fix <= min(n_seg, E/chunk), slots <= 2*E/chunk), pre-fill them with -1 and pass the
+ * bounds as n_items / n_fix.
  */
 int gv_segment_items_count(const int32_t* rowptr, int n_seg, int chunk, int32_t* n_chunks, int32_t* n_slots,
                            int32_t* is_split, void* stream);

@@ -63,6 +63,36 @@ def test_segment_items(ops):
         assert np.array_equal(items, np.array(exp_items, dtype=np.int32))
         assert np.array_equal(fix, np.array(exp_fix, dtype=np.int32).reshape(-1, 4))
         assert seg.n_slots == slot
+        # sync-free form: the same entries followed by -1 padding, sized by the upper bounds
+        ub = ops.build_segment_items(torch.from_numpy(rowptr).cuda(), chunk, n_edges=int(rowptr[-1]))
+        ui, uf = ub.items[:ub.n_items].cpu().numpy(), ub.fix[:ub.n_fix].cpu().numpy()
+        assert ub.n_items >= seg.n_items and ub.n_fix >= seg.n_fix and ub.n_slots >= seg.n_slots
+        assert np.array_equal(ui[:seg.n_items], items) and (ui[seg.n_items:] == -1).all()
+        assert np.array_equal(uf[:seg.n_fix], fix) and (uf[seg.n_fix:] == -1).all()
+
+
+def test_sync_free_index_gives_identical_results(ops):
+    """Upper-bound-sized work-item lists (no host synchronisation per batch) vs exact lists: same bits, incl. hub rows."""
+    rs = np.random.RandomState(1)
+    n, e, r, nb = 300, 9000, 12, 10
+    dst = np.sort(np.minimum((rs.pareto(1.2, e) * 3).astype(np.int64), n - 1))      # a few hub rows > chunk
+    src = rs.randint(0, n, e)
+    et = torch.from_numpy(rs.randint(0, r, e)).cuda()
+    x = torch.randn(n, 40, device='cuda')
+    w = torch.randn(r, nb * 4 * 4, device='cuda')
+    g = torch.randn(n, 40, device='cuda')
+    coef = torch.rand(e, device='cuda')
+    outs = []
+    for sf in (False, True):
+        gi = ops.GraphIndex(torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda(), n, chunk=64, dst_sorted=True if sf else None,
+                            sync_free=sf)
+        ri = ops.RelationIndex(gi, et, r, chunk=32)
+        fwd = ops.bdd_aggregate(gi.by_dst.seg, gi.nbr_by_dst, ri.et_by_dst, coef, gi.by_dst.perm, x, w, nb, 4, 4)
+        bwd = ops.bdd_aggregate(gi.by_src.seg, gi.nbr_by_src, ri.et_by_src, coef, gi.by_src.perm, g, w, nb, 4, 4, True)
+        gw = ops.bdd_grad_weight(ri.by_rel.seg, ri.src_by_rel, ri.dst_by_rel, coef, ri.by_rel.perm, x, g, nb, 4, 4)
+        outs.append((fwd, bwd, gw))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
 
 
 CASES = [  # (in, out, num_bases)  -> block sizes; covers the fast instantiations and the generic kernel
