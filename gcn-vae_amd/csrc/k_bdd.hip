@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void k_agg_fast(const AggParams a) {
     if (wave >= a.n_items) return;
     const int4 it = a.items[wave];
     if (it.x < 0) return;                 // unused tail entry of an upper-bound-sized item list
+    if (it.w >= 0 && !a.partial) return;   // split item without a partial buffer: inconsistent handle, never dereference NULL
     const bool active = lane * BPL < a.nbp;
     const int blk0 = blockIdx.y * a.nbp + lane * BPL;       // first diagonal block this lane owns
     const float* __restrict__ fbase = a.feat + blk0 * P;
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256) void k_agg_packed(const AggParams a) {
     if (wave >= a.n_items) return;
     const int4 it = a.items[wave];
     if (it.x < 0) return;                 // unused tail entry of an upper-bound-sized item list
+    if (it.w >= 0 && !a.partial) return;   // split item without a partial buffer: inconsistent handle, never dereference NULL
     const int L = a.nb / BPL;
     const bool active = lane < L;
     const float4* __restrict__ wbase = reinterpret_cast<const float4*>(a.w) + lane;
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(256) void k_agg_generic(const AggParams a) {
     if (wave >= a.n_items) return;
     const int4 it = a.items[wave];
     if (it.x < 0) return;                 // unused tail entry of an upper-bound-sized item list
+    if (it.w >= 0 && !a.partial) return;   // split item without a partial buffer: inconsistent handle, never dereference NULL
     const int P = a.p, Q = a.q;
     for (int c0 = 0; c0 < a.out_dim; c0 += 64) {
         const int c = c0 + lane;
@@ -385,6 +388,7 @@ __global__ __launch_bounds__(256) void k_gradw_fast(const GradWParams a) {
     if (wave >= a.n_items) return;
     const int4 it = a.items[wave];
     if (it.x < 0) return;                 // unused tail entry of an upper-bound-sized item list
+    if (it.w >= 0 && !a.partial) return;   // split item without a partial buffer: inconsistent handle, never dereference NULL
     const bool active = lane * BPL < a.nbp;
     const int blk0 = blockIdx.y * a.nbp + lane * BPL;
     const float* __restrict__ xbase = a.x + blk0 * P;
@@ -469,6 +473,7 @@ __global__ __launch_bounds__(256) void k_gradw_generic(const GradWParams a) {
     if (wave >= a.n_items) return;
     const int4 it = a.items[wave];
     if (it.x < 0) return;                 // unused tail entry of an upper-bound-sized item list
+    if (it.w >= 0 && !a.partial) return;   // split item without a partial buffer: inconsistent handle, never dereference NULL
     const int P = a.p, Q = a.q;
     for (int c0 = 0; c0 < a.w_row; c0 += 64) {
         const int c = c0 + lane;

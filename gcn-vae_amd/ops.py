@@ -194,26 +194,28 @@ class GraphIndex:
         self._chunk_cache = {}
 
     def dst_chunks(self, n_chunks: int):
-        """Cut the destination rows into ``n_chunks`` contiguous blocks of ~equal edge count and return, per block,
+        """Cut the destination rows into ``n_chunks`` contiguous blocks of EQUAL ROW COUNT and return, per block,
         (row0, row1, SegmentItems restricted to those rows).  Used by the multi-GPU forward to start the all-reduce
-        of one row block while the next one is still being aggregated.  Cached; synchronises once when built."""
+        of one row block while the next one is still being aggregated.  The cut points depend on the node count only:
+        every rank must slice the aggregate identically (its own edge block would give every rank different cuts and
+        mismatched collectives).  Cached; synchronises once when built."""
         hit = self._chunk_cache.get(n_chunks)
         if hit is not None:
             return hit
         seg = self.by_dst.seg
-        rp = seg.rowptr.to(torch.int64)
-        targets = torch.arange(1, n_chunks, device=rp.device, dtype=torch.int64) * (self.num_edges // max(n_chunks, 1))
-        cuts = torch.searchsorted(rp, targets).clamp_(0, self.num_nodes).tolist() if n_chunks > 1 else []
-        rows = [0] + [int(c) for c in cuts] + [self.num_nodes]
-        rows = sorted(set(rows))
-        item_seg = seg.items[:seg.n_items, 0].contiguous().to(torch.int64)
-        fix_seg = seg.fix[:seg.n_fix, 0].contiguous().to(torch.int64)
-        bounds = torch.tensor(rows, device=rp.device, dtype=torch.int64)
+        n_chunks = max(1, min(int(n_chunks), self.num_nodes))
+        rows = sorted(set([0] + [(self.num_nodes * c) // n_chunks for c in range(1, n_chunks)] + [self.num_nodes]))
+        # upper-bound-sized lists (sync-free build) end in -1 entries: cut them off first (this method synchronises anyway)
+        n_items = int((seg.items[:seg.n_items, 0] >= 0).sum())
+        n_fix = int((seg.fix[:seg.n_fix, 0] >= 0).sum()) if seg.n_fix > 0 else 0
+        item_seg = seg.items[:n_items, 0].contiguous().to(torch.int64)
+        fix_seg = seg.fix[:n_fix, 0].contiguous().to(torch.int64)
+        bounds = torch.tensor(rows, device=seg.items.device, dtype=torch.int64)
         ib = torch.searchsorted(item_seg, bounds).tolist()
-        fb = torch.searchsorted(fix_seg, bounds).tolist() if seg.n_fix > 0 else [0] * len(rows)
+        fb = torch.searchsorted(fix_seg, bounds).tolist() if n_fix > 0 else [0] * len(rows)
         out = []
         for c in range(len(rows) - 1):
-            sub = SegmentItems(seg.items[ib[c]:ib[c + 1]], seg.fix[fb[c]:fb[c + 1]] if seg.n_fix > 0 else seg.fix,
+            sub = SegmentItems(seg.items[ib[c]:ib[c + 1]], seg.fix[fb[c]:fb[c + 1]] if n_fix > 0 else seg.fix,
                                ib[c + 1] - ib[c], fb[c + 1] - fb[c], seg.n_slots, seg.rowptr, seg.chunk)
             out.append((rows[c], rows[c + 1], sub))
         self._chunk_cache[n_chunks] = out
@@ -297,6 +299,15 @@ def pack_weight(weight, num_bases, blk_in, blk_out, transpose_w=False):
     return packed
 
 
+def _check_items(seg: SegmentItems):
+    """The kernels index these lists by launch geometry: refuse a handle whose counts exceed its buffers."""
+    if seg.n_items < 0 or seg.n_fix < 0 or seg.items.numel() < 4 * seg.n_items or seg.fix.numel() < 4 * seg.n_fix:
+        raise ValueError(f'inconsistent work-item lists: n_items={seg.n_items} (buffer {seg.items.numel() // 4}), '
+                         f'n_fix={seg.n_fix} (buffer {seg.fix.numel() // 4})')
+    if seg.n_items > 0 and seg.items.data_ptr() == 0:
+        raise ValueError('work-item list has no storage')
+
+
 def bdd_aggregate(seg: SegmentItems, nbr, etype, coef, coef_idx, feat, weight, num_bases, blk_in, blk_out,
                   transpose_w=False, addend=None, act=ACT_NONE, keep=None, keep_scale=1.0, out=None, packed=False):
     feat, ld_feat = _row_major(feat, 'feat')
@@ -321,6 +332,7 @@ def bdd_aggregate(seg: SegmentItems, nbr, etype, coef, coef_idx, feat, weight, n
             raise ValueError('keep shape mismatch')
     if coef is not None:
         coef = _chk(coef.reshape(-1), name='coef')
+    _check_items(seg)
     partial = None
     if seg.n_fix > 0:
         partial = torch.empty(seg.n_slots, out_dim, dtype=torch.float32, device=feat.device)

@@ -30,3 +30,14 @@ def test_bench_single_rank_rccl(extra):
     d = json.loads(line)
     assert d['n_gpus'] == 1 and d['value'] > 1e6 and d['config']['launch'] == ('eager' if extra else 'hipgraph')
     assert d['final_loss'] == d['final_loss']          # not NaN
+
+
+def test_two_ranks_edge_sharded_equals_single_process():
+    """world_size 2 on ONE GPU (gloo, both ranks on cuda:0): the edge-sharded HIP path -- reduce hooks in both layers'
+    forward and backward, averaged gradients -- equals the single-process HIP run on the union graph."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'tests', 'workers', 'dist_gpu_worker.py')]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:] + '\n' + out.stderr[-2500:])
+    assert out.stdout.count('worst rel err') == 2, out.stdout[-1500:]
