@@ -208,9 +208,22 @@ def main():
         import torch.distributed as _d
         torch.cuda.set_device(local_rank)
         _d.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', local_rank))
-    gdist.init_process_group('nccl' if world > 1 else None)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # GV_DIST_BACKEND=gloo: functional check of the multi-rank path on a box with fewer GPUs than ranks (ranks then share
+    # devices; gloo moves CUDA tensors through the host).  Never a performance configuration.
+    backend = os.environ.get('GV_DIST_BACKEND', 'nccl')
+    n_dev = torch.cuda.device_count()
+    if world > 1 and backend == 'nccl' and n_dev < world:
+        raise RuntimeError(f'{world} ranks need {world} GPUs for RCCL (found {n_dev}); GV_DIST_BACKEND=gloo shares devices')
+    dev_index = local_rank % max(n_dev, 1)
+    if world > 1 and backend != 'nccl':
+        torch.cuda.set_device(dev_index)
+        import torch.distributed as _dg
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        _dg.init_process_group(backend)
+    else:
+        gdist.init_process_group('nccl' if world > 1 else None)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     lib.load()
     import torch.distributed as dist
 

@@ -41,3 +41,18 @@ def test_two_ranks_edge_sharded_equals_single_process():
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:] + '\n' + out.stderr[-2500:])
     assert out.stdout.count('worst rel err') == 2, out.stdout[-1500:]
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """bench.py's world_size-2 flow end to end (sharded workload, eager launches with collectives, barrier-bracketed
+    timing, max over ranks, one JSON line from rank 0) on ONE GPU: GV_DIST_BACKEND=gloo lets the ranks share it."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GV_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--no-cpu-baseline', '--profile-steps', '0', '--positives', '2000']
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:] + '\n' + out.stderr[-2500:])
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['launch'] == 'eager'
+    assert d['value'] > 0 and d['final_loss'] == d['final_loss']
