@@ -62,6 +62,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_fns = {}        # name -> bound foreign function (a dict lookup per launch instead of CDLL.__getattr__)
 
 
 def load():
@@ -76,6 +77,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+            _fns[name] = fn
         _lib = lib
     return _lib
 
@@ -108,7 +110,9 @@ TIMER = None      # set to a KernelTimer to time tagged launches
 
 def call(name, *args, tag=None):
     """Invoke an int-returning entry point; non-zero status raises with the library's message."""
-    fn = getattr(load(), name)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = getattr(load(), name)
     if TIMER is not None and tag is not None:
         box = []
         TIMER.bracket(tag, lambda: box.append(fn(*args)))
@@ -120,8 +124,10 @@ def call(name, *args, tag=None):
 
 
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The caller's current stream as a raw handle (an int: ctypes converts it for the void* parameter)."""
+    return torch.cuda.current_stream().cuda_stream or None
 
 
 def ptr(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    """Raw device address of a tensor (int), None -> NULL."""
+    return None if t is None else (t.data_ptr() or None)

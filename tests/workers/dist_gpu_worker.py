@@ -1,4 +1,4 @@
-"""Launched by tests/test_gpu_dist.py under torch.distributed.run with TWO ranks that share cuda:0 (backend gloo, which
+"""Launched by tests/test_gpu_zz_dist.py under torch.distributed.run with TWO ranks that share cuda:0 (backend gloo, which
 moves CUDA tensors through the host -- RCCL refuses two ranks on one device).  Runs the edge-sharded HIP path
 (reduce hooks on both R-GCN layers, averaged flat gradients) and checks it against a single-process HIP run on the
 union graph:  mean over ranks of the rank losses == the full loss,  averaged gradients == the full gradients."""
