@@ -104,6 +104,34 @@ __device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&s
     }
 }
 
+// Ordered sum over `nsl` row slices of a [nsl][ncols] partial matrix for a 1024-thread block laid out as 16 columns x 64
+// slice groups: group g adds its contiguous range of slices in order (4 independent chains, fixed combine), then the 64
+// group sums of a column are added in group order.  Returns the column total to the threads of group 0 (others: 0);
+// `sm` is a 64 x 16 float scratch.  Many small blocks instead of one wide one: the sum is latency-bound.
+__device__ __forceinline__ float sum_slices_16x64(const float* __restrict__ part, int ncols, int nsl, int col, float (*sm)[16]) {
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int per = (nsl + 63) / 64;
+    const int s0 = grp * per, s1 = min(nsl, s0 + per);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (col < ncols) {
+        int s = s0;
+        for (; s + 4 <= s1; s += 4) {
+            const float v0 = part[(size_t)s * ncols + col], v1 = part[(size_t)(s + 1) * ncols + col];
+            const float v2 = part[(size_t)(s + 2) * ncols + col], v3 = part[(size_t)(s + 3) * ncols + col];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; s < s1; ++s) a0 += part[(size_t)s * ncols + col];
+    }
+    sm[grp][cl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    float tot = 0.f;
+    if (grp == 0) {
+#pragma unroll 8
+        for (int g = 0; g < 64; ++g) tot += sm[g][cl];
+    }
+    return tot;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) { return act == GV_ACT_RELU ? fmaxf(v, 0.f) : v; }
 
 }  // namespace gv

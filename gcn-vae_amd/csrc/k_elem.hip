@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_epilogue_bwd(const float* out, const fl
 // a thread owns one float4 column group and every (256 / groups)-th row of the range, so each pass of the block is a
 // coalesced sweep of whole rows; the row lanes' sums are combined through LDS in lane order and written as slice b
 // of `part` (EPI_SLICES x n); gv_colsum_finish adds the slices in order.
-constexpr int EPI_SLICES = 256;
+constexpr int EPI_SLICES = 1024;
 __global__ __launch_bounds__(256) void k_epilogue_bwd_colsum(const float* __restrict__ out, const float* __restrict__ gout,
                                                              int act, const uint8_t* __restrict__ keep, float scale,
                                                              float* __restrict__ g, int64_t m, int n, float* part) {

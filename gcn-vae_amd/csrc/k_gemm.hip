@@ -360,32 +360,12 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float* part, int n, 
     out[c] = accumulate ? out[c] + acc : acc;
 }
 
-// final pass over many slices: block = 64 columns x 16 slice groups; each group adds its slices in order, the groups
-// are combined in group order through LDS
+// final pass over many slices: 16 columns per 1024-thread block (common.h: sum_slices_16x64)
 __global__ __launch_bounds__(1024) void k_colsum_final_wide(const float* part, int n, int nsl, float* out, int accumulate) {
-    __shared__ float sm[16][64];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    const int per = (nsl + 15) / 16;
-    const int s0 = grp * per, s1 = min(nsl, s0 + per);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (c < n) {
-        int s = s0;
-        for (; s + 4 <= s1; s += 4) {
-            const float v0 = part[(size_t)s * n + c], v1 = part[(size_t)(s + 1) * n + c];
-            const float v2 = part[(size_t)(s + 2) * n + c], v3 = part[(size_t)(s + 3) * n + c];
-            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
-        }
-        for (; s < s1; ++s) a0 += part[(size_t)s * n + c];
-    }
-    sm[grp][lane] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (grp == 0 && c < n) {
-        float acc = sm[0][lane];
-#pragma unroll
-        for (int k = 1; k < 16; ++k) acc += sm[k][lane];
-        out[c] = accumulate ? out[c] + acc : acc;
-    }
+    __shared__ float sm[64][16];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const float acc = sum_slices_16x64(part, n, nsl, c, sm);
+    if ((threadIdx.x >> 4) == 0 && c < n) out[c] = accumulate ? out[c] + acc : acc;
 }
 
 }  // namespace gv
@@ -499,7 +479,7 @@ extern "C" int gv_gemm_bf16(int trans_a, int trans_b, int m, int n, int k, const
 extern "C" int gv_colsum_finish(const float* part, int n, int n_slices, float* out, int accumulate, void* stream) {
     GV_REQUIRE(part && out, GV_ERR_NULL, "gv_colsum_finish: NULL pointer");
     GV_REQUIRE(n > 0 && n_slices > 0, GV_ERR_SHAPE, "gv_colsum_finish: n=%d n_slices=%d", n, n_slices);
-    hipLaunchKernelGGL(k_colsum_final_wide, dim3((n + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, n, n_slices, out,
+    hipLaunchKernelGGL(k_colsum_final_wide, dim3((n + 15) / 16), dim3(1024), 0, (hipStream_t)stream, part, n, n_slices, out,
                        accumulate);
     return launch_status("gv_colsum_finish");
 }

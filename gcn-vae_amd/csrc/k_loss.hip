@@ -234,6 +234,93 @@ __global__ __launch_bounds__(256) void k_kl_bwd_nodes(const float* z, const floa
     }
 }
 
+// Fused KL backward for k <= KT components: ONE pass over z / m / v / resp produces the per-node gradients AND the
+// row-slice partial sums of the mixture-parameter gradients (the two-kernel form reads z ten more times, once per
+// component).  Grid (64-column tile, row slice); lane <-> column, the block's 4 waves interleave the slice's rows; a
+// lane keeps its column's k (mu_j, 1/(2 v_j)) pairs and 2k accumulators in registers; the row's k responsibilities are a
+// wave-uniform read.  The 4 waves' accumulators are combined through LDS in wave order and written as slice `blockIdx.y`
+// of `part`, which k_kl_bwd_mix_final then sums in slice order (deterministic).
+template <int KT>
+__global__ __launch_bounds__(256) void k_kl_bwd_fused(const float* z, const float* m, int ld_m, const float* v, const float* mix,
+                                                      const float* resp, const float* gkl, float gscale, float* gz, float* gm,
+                                                      float* gv, float* part, int64_t n, int h, int k) {
+    __shared__ float sm[2 * KT][4][64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // uniform: resp rows become scalar loads
+    const int c = blockIdx.x * 64 + lane;
+    const bool ok = c < h;
+    const int kh = k * h;
+    const int nsl = gridDim.y;
+    const int64_t per = (n + nsl - 1) / nsl;
+    const int64_t r0 = blockIdx.y * per, r1 = min(n, r0 + per);
+    const float cg = gscale * (gkl ? *gkl : 1.f) / (float)n;
+    float mu[KT], i2[KT], amu[KT], av[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        mu[j] = (ok && j < k) ? mix[j * h + c] : 0.f;
+        i2[j] = (ok && j < k) ? mix[kh + j * h + c] : 0.f;
+        amu[j] = 0.f;
+        av[j] = 0.f;
+    }
+    // four rows in flight per wave (independent loads issued together: the loop is latency-bound)
+    constexpr int RU = 4;
+    for (int64_t rb = r0 + w; rb < r1; rb += 4 * RU) {
+        float zz[RU], mm[RU], vv[RU];
+        // the 4 rows' responsibilities: lanes 16u .. 16u+k-1 load row u's k values (one 64-lane load), read back by v_readlane
+        float rv = 0.f;
+        {
+            const int64_t rr = rb + 4 * (lane >> 4);
+            if ((lane & 15) < k && rr < r1) rv = resp[rr * k + (lane & 15)];
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int64_t r = rb + 4 * u;
+            zz[u] = 0.f; mm[u] = 0.f; vv[u] = 1.f;
+            if (ok && r < r1) {
+                zz[u] = z[r * h + c];
+                mm[u] = m[r * ld_m + c];
+                vv[u] = v[r * h + c];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int64_t r = rb + 4 * u;
+            if (r >= r1) break;                            // wave-uniform
+            const float d = zz[u] - mm[u];
+            float mixg = 0.f;
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                if (j < k) {
+                    const float ra = rl_bcast_f(rv, 16 * u + j);
+                    const float dj = zz[u] - mu[j];
+                    mixg = fmaf(ra * dj, 2.f * i2[j], mixg);
+                    amu[j] = fmaf(ra, dj, amu[j]);
+                    av[j] = fmaf(ra, dj * dj * 2.f * i2[j] * i2[j] - i2[j], av[j]);
+                }
+            }
+            if (ok) {
+                gz[r * h + c] = cg * (-d / vv[u] + mixg);
+                gm[r * h + c] = cg * (d / vv[u]);
+                gv[r * h + c] = cg * (d * d / (2.f * vv[u] * vv[u]) - 0.5f / vv[u]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        sm[j][w][lane] = amu[j];
+        sm[KT + j][w][lane] = av[j];
+    }
+    __syncthreads();
+    if (w == 0 && ok) {
+        for (int j = 0; j < k; ++j) {
+            const float gmu = (sm[j][0][lane] + sm[j][1][lane]) + (sm[j][2][lane] + sm[j][3][lane]);
+            const float gvv = (sm[KT + j][0][lane] + sm[KT + j][1][lane]) + (sm[KT + j][2][lane] + sm[KT + j][3][lane]);
+            part[((size_t)blockIdx.y * 2 * k + j) * h + c] = -gmu * 2.f * i2[j];       // same terms as k_kl_bwd_mix_part
+            part[((size_t)blockIdx.y * 2 * k + k + j) * h + c] = -gvv;
+        }
+    }
+}
+
 // mixture-parameter gradients: grid (component j, 64-column tile, node slice); the block's 4 waves
 // interleave the slice's nodes (2 rows in flight per lane) and combine through LDS in wave order.
 __global__ __launch_bounds__(256) void k_kl_bwd_mix_part(const float* z, const float* mix, const float* resp,
@@ -277,27 +364,20 @@ __global__ __launch_bounds__(256) void k_kl_bwd_mix_part(const float* z, const f
     }
 }
 
-__global__ __launch_bounds__(256) void k_kl_bwd_mix_final(const float* part, const float* z_pre, const float* gkl,
-                                                          float gscale, float* g_zpre, int accumulate, int64_t n, int h,
-                                                          int k, int nsl) {
+__global__ __launch_bounds__(1024) void k_kl_bwd_mix_final(const float* part, const float* z_pre, const float* gkl,
+                                                           float gscale, float* g_zpre, int accumulate, int64_t n, int h,
+                                                           int k, int nsl) {
+    __shared__ float sm[64][16];
     const int total = 2 * k * h, kh = k * h;
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15);
+    float acc = sum_slices_16x64(part, total, nsl, i, sm);     // slices added in a fixed order
+    if ((threadIdx.x >> 4) != 0 || i >= total) return;
     const float cg = gscale * (gkl ? *gkl : 1.f) / (float)n;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int s = 0;
-        for (; s + 4 <= nsl; s += 4) {
-            const float v0 = part[(size_t)s * total + i], v1 = part[(size_t)(s + 1) * total + i];
-            const float v2 = part[(size_t)(s + 2) * total + i], v3 = part[(size_t)(s + 3) * total + i];
-            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
-        }
-        for (; s < nsl; ++s) a0 += part[(size_t)s * total + i];
-        float acc = (a0 + a1) + (a2 + a3);
-        if (i >= kh) {  // chain through v_j = softplus(raw) + 1e-8
-            const float raw = z_pre[i];
-            acc *= raw > 20.f ? 1.f : 1.f / (1.f + expf(-raw));
-        }
-        g_zpre[i] = accumulate ? g_zpre[i] + cg * acc : cg * acc;
+    if (i >= kh) {  // chain through v_j = softplus(raw) + 1e-8
+        const float raw = z_pre[i];
+        acc *= raw > 20.f ? 1.f : 1.f / (1.f + expf(-raw));
     }
+    g_zpre[i] = accumulate ? g_zpre[i] + cg * acc : cg * acc;
 }
 
 // ---- MMD (KGVAE.get_mmd / compute_kernel, kgvae/model.py:71-80, :89-102) -------------------------------
@@ -433,7 +513,8 @@ __global__ __launch_bounds__(256) void k_prior_sample_bwd(const float* z_pre, co
     }
 }
 
-constexpr int KL_SLICES = 64;
+constexpr int KL_SLICES = 256;      // row slices of the mixture-gradient partial sums
+constexpr int KL_FUSED_KT = 16;     // (also the 16-lane group that carries one row's responsibilities)     // the fused backward keeps 4*KT floats per lane: k <= 16 (the reference's mog_k is 10)
 
 }  // namespace gv
 
@@ -548,14 +629,19 @@ extern "C" int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* 
     GV_REQUIRE(n > 0 && h > 0 && k > 0 && k <= KL_KMAX && ld_m >= h, GV_ERR_SHAPE, "gv_kl_bwd: bad shape");
     float* mix = workspace;  // mix_ready: the caller hands back the workspace gv_kl_fwd filled for the same z_pre
     if (!mix_ready) hipLaunchKernelGGL(k_kl_mix, dim3((k * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, k, h, mix);
-    const size_t lds = (size_t)2 * k * h * sizeof(float);
-    const int nb = (int)((n + 3) / 4 > 1024 ? 1024 : (n + 3) / 4);
-    hipLaunchKernelGGL(k_kl_bwd_nodes, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, resp, gkl, gscale, gz, gm,
-                       gv, n, h, k);
     float* part = workspace + 3 * (size_t)k * h + RED_BLOCKS;
-    hipLaunchKernelGGL(k_kl_bwd_mix_part, dim3(k, (h + 63) / 64, KL_SLICES), dim3(256), 0, GV_ST, z, mix, resp, part, n,
-                       h, k);
-    hipLaunchKernelGGL(k_kl_bwd_mix_final, dim3((2 * k * h + 255) / 256), dim3(256), 0, GV_ST, part, z_pre, gkl,
+    if (k <= KL_FUSED_KT) {
+        hipLaunchKernelGGL(k_kl_bwd_fused<KL_FUSED_KT>, dim3((h + 63) / 64, KL_SLICES), dim3(256), 0, GV_ST, z, m, ld_m, v, mix,
+                           resp, gkl, gscale, gz, gm, gv, part, n, h, k);
+    } else {
+        const size_t lds = (size_t)2 * k * h * sizeof(float);
+        const int nb = (int)((n + 3) / 4 > 1024 ? 1024 : (n + 3) / 4);
+        hipLaunchKernelGGL(k_kl_bwd_nodes, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, resp, gkl, gscale, gz, gm,
+                           gv, n, h, k);
+        hipLaunchKernelGGL(k_kl_bwd_mix_part, dim3(k, (h + 63) / 64, KL_SLICES), dim3(256), 0, GV_ST, z, mix, resp, part, n,
+                           h, k);
+    }
+    hipLaunchKernelGGL(k_kl_bwd_mix_final, dim3((2 * k * h + 15) / 16), dim3(1024), 0, GV_ST, part, z_pre, gkl,
                        gscale, g_zpre, accumulate_zpre, n, h, k, KL_SLICES);
     return launch_status("gv_kl_bwd");
 }

@@ -34,7 +34,7 @@ def _direct_flat(t):
     """Direct target of a contiguous VIEW of a parameter that starts at its storage (e.g. z_pre.squeeze(0))."""
     tgt = DIRECT_GRAD.get(t.data_ptr()) if t is not None else None
     return tgt.view(t.shape) if (tgt is not None and tgt.numel() == t.numel() and tgt.is_contiguous()) else None
-EPILOGUE_COLSUM_SLICES = 256   # = GV_EPILOGUE_COLSUM_SLICES (include/gcnvae.h)
+EPILOGUE_COLSUM_SLICES = 1024  # = GV_EPILOGUE_COLSUM_SLICES (include/gcnvae.h)
 DEFAULT_CHUNK = 256        # max edges per work item of the dst/src-sorted aggregations
 DEFAULT_CHUNK_REL = 128    # max edges per work item of the by-relation weight gradient
 DIST_FWD_CHUNKS = 2        # destination-row blocks whose all-reduce overlaps the next block's aggregation

@@ -113,7 +113,7 @@ int gv_rgcn_epilogue_bwd(const float* out, const float* grad_out, int act, const
 /* colsum_part != NULL (needs n_cols % 4 == 0): the same pass also writes GV_EPILOGUE_COLSUM_SLICES row-slice partials
  * of the column sums of g (the bias gradient); gv_colsum_finish(part, n_cols, n_slices, out, accumulate) adds the
  * slices in a fixed order. */
-#define GV_EPILOGUE_COLSUM_SLICES 256
+#define GV_EPILOGUE_COLSUM_SLICES 1024
 int gv_colsum_finish(const float* part, int n, int n_slices, float* out, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
