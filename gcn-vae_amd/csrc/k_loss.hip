@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_kl_fwd(const float* z, const float* m, 
 // per-node gradients gz, gm, gv (scaled by *gkl / n)
 __global__ __launch_bounds__(256) void k_kl_bwd_nodes(const float* z, const float* m, int ld_m, const float* v,
                                                       const float* mix, const float* resp, const float* gkl, float gscale,
-                                                      float* gz, float* gm, float* gv, int64_t n, int h, int k) {
+                                                      float z_extra, float* gz, float* gm, float* gv, int64_t n, int h, int k) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int kh = k * h;
     if ((kh & 3) == 0) {
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void k_kl_bwd_nodes(const float* z, const floa
     const float* i2v = sm + kh;
     const int lane = threadIdx.x & 63;
     const float cg = gscale * (gkl ? *gkl : 1.f) / (float)n;
+    const float cz = z_extra * (gkl ? *gkl : 1.f);
     for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {
         const float* rp = resp + r * k;
         for (int c = lane; c < h; c += 64) {
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void k_kl_bwd_nodes(const float* z, const floa
             const float d = zz - mm;
             float mixg = 0.f;
             for (int j = 0; j < k; ++j) mixg += rp[j] * (zz - mu[j * h + c]) * 2.f * i2v[j * h + c];
-            gz[r * h + c] = cg * (-d / vv + mixg);
+            gz[r * h + c] = fmaf(cz, zz, cg * (-d / vv + mixg));
             gm[r * h + c] = cg * (d / vv);
             gv[r * h + c] = cg * (d * d / (2.f * vv * vv) - 0.5f / vv);
         }
@@ -242,8 +243,8 @@ __global__ __launch_bounds__(256) void k_kl_bwd_nodes(const float* z, const floa
 // of `part`, which k_kl_bwd_mix_final then sums in slice order (deterministic).
 template <int KT>
 __global__ __launch_bounds__(256) void k_kl_bwd_fused(const float* z, const float* m, int ld_m, const float* v, const float* mix,
-                                                      const float* resp, const float* gkl, float gscale, float* gz, float* gm,
-                                                      float* gv, float* part, int64_t n, int h, int k) {
+                                                      const float* resp, const float* gkl, float gscale, float z_extra,
+                                                      float* gz, float* gm, float* gv, float* part, int64_t n, int h, int k) {
     __shared__ float sm[2 * KT][4][64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // uniform: resp rows become scalar loads
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(256) void k_kl_bwd_fused(const float* z, const floa
     const int64_t per = (n + nsl - 1) / nsl;
     const int64_t r0 = blockIdx.y * per, r1 = min(n, r0 + per);
     const float cg = gscale * (gkl ? *gkl : 1.f) / (float)n;
+    const float cz = z_extra * (gkl ? *gkl : 1.f);           // an extra upstream * z_extra * z term on gz (the regulariser)
     float mu[KT], i2[KT], amu[KT], av[KT];
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(256) void k_kl_bwd_fused(const float* z, const floa
                 }
             }
             if (ok) {
-                gz[r * h + c] = cg * (-d / vv[u] + mixg);
+                gz[r * h + c] = fmaf(cz, zz[u], cg * (-d / vv[u] + mixg));
                 gm[r * h + c] = cg * (d / vv[u]);
                 gv[r * h + c] = cg * (d * d / (2.f * vv[u] * vv[u]) - 0.5f / vv[u]);
             }
@@ -402,27 +404,31 @@ __device__ __forceinline__ float mmd_d2(const float (&a)[CPL], const float (&b)[
 }
 
 template <int CPL>
-__global__ __launch_bounds__(64 * MMD_WAVES) void k_mmd_fwd(const float* x, const float* y, int sx, int sy, int h,
-                                                             float* part) {
+__global__ __launch_bounds__(64 * MMD_WAVES) void k_mmd_fwd(const float* x, const float* y, const int64_t* yidx, int sx, int sy,
+                                                             int h, float* part) {
     __shared__ float sm[MMD_WAVES];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool is_x = (int)blockIdx.x < sx;
+    // sample row j of a set: x is dense; y is dense or, with yidx, row yidx[j] of a larger matrix (no gathered copy)
+    auto row_of = [&](bool from_y, int j) -> const float* {
+        return from_y ? y + (size_t)(yidx ? yidx[j] : j) * h : x + (size_t)j * h;
+    };
     float av[CPL];
-    mmd_load_row<CPL>(is_x ? x + (size_t)blockIdx.x * h : y + (size_t)(blockIdx.x - sx) * h, h, lane, av);
+    mmd_load_row<CPL>(row_of(!is_x, is_x ? (int)blockIdx.x : (int)blockIdx.x - sx), h, lane, av);
     const float inv = 1.f / ((float)h * (float)h);
     float tot = 0.f;
     // x rows: + Kxx/sx^2 - 2 Kxy/(sx sy);   y rows: + Kyy/sy^2
     for (int pass = 0; pass < (is_x ? 2 : 1); ++pass) {
-        const float* b = pass == 0 ? (is_x ? x : y) : y;
+        const bool b_is_y = pass == 0 ? !is_x : true;
         const int nb = pass == 0 ? (is_x ? sx : sy) : sy;
         const float wt = pass == 0 ? 1.f / ((float)nb * (float)nb) : -2.f / ((float)sx * (float)sy);
         for (int j = w; j < nb; j += 4 * MMD_WAVES) {
             float b0[CPL], b1[CPL], b2[CPL], b3[CPL];
             const int j1 = j + MMD_WAVES, j2 = j + 2 * MMD_WAVES, j3 = j + 3 * MMD_WAVES;
-            mmd_load_row<CPL>(b + (size_t)j * h, h, lane, b0);
-            mmd_load_row<CPL>(b + (size_t)min(j1, nb - 1) * h, h, lane, b1);
-            mmd_load_row<CPL>(b + (size_t)min(j2, nb - 1) * h, h, lane, b2);
-            mmd_load_row<CPL>(b + (size_t)min(j3, nb - 1) * h, h, lane, b3);
+            mmd_load_row<CPL>(row_of(b_is_y, j), h, lane, b0);
+            mmd_load_row<CPL>(row_of(b_is_y, min(j1, nb - 1)), h, lane, b1);
+            mmd_load_row<CPL>(row_of(b_is_y, min(j2, nb - 1)), h, lane, b2);
+            mmd_load_row<CPL>(row_of(b_is_y, min(j3, nb - 1)), h, lane, b3);
             const float d0 = wave_sum(mmd_d2<CPL>(av, b0)), d1 = wave_sum(mmd_d2<CPL>(av, b1));
             const float d2 = wave_sum(mmd_d2<CPL>(av, b2)), d3 = wave_sum(mmd_d2<CPL>(av, b3));
             tot += wt * expf(-d0 * inv);
@@ -442,14 +448,17 @@ __global__ __launch_bounds__(64 * MMD_WAVES) void k_mmd_fwd(const float* x, cons
 }
 
 template <int CPL>
-__global__ __launch_bounds__(64 * MMD_WAVES) void k_mmd_bwd(const float* x, const float* y, int sx, int sy, int h,
-                                                             const float* gmmd, float gscale, float* gx, float* gy) {
+__global__ __launch_bounds__(64 * MMD_WAVES) void k_mmd_bwd(const float* x, const float* y, const int64_t* yidx, int sx, int sy,
+                                                             int h, const float* gmmd, float gscale, float* gx, float* gy) {
     __shared__ float sm[MMD_WAVES][64 * CPL];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool is_x = (int)blockIdx.x < sx;
     const int row = is_x ? blockIdx.x : blockIdx.x - sx;
+    auto row_of = [&](bool from_y, int j) -> const float* {
+        return from_y ? y + (size_t)(yidx ? yidx[j] : j) * h : x + (size_t)j * h;
+    };
     float av[CPL], acc[CPL];
-    mmd_load_row<CPL>((is_x ? x : y) + (size_t)row * h, h, lane, av);
+    mmd_load_row<CPL>(row_of(!is_x, row), h, lane, av);
 #pragma unroll
     for (int i = 0; i < CPL; ++i) acc[i] = 0.f;
     const float inv = 1.f / ((float)h * (float)h);
@@ -459,14 +468,14 @@ __global__ __launch_bounds__(64 * MMD_WAVES) void k_mmd_bwd(const float* x, cons
     const float c_same = g * (-2.f * inv) * 2.f / ((float)n_same * (float)n_same);
     const float c_other = g * (-2.f * inv) * (-2.f) / ((float)sx * (float)sy);
     for (int pass = 0; pass < 2; ++pass) {
-        const float* b = pass == 0 ? (is_x ? x : y) : (is_x ? y : x);
+        const bool b_is_y = pass == 0 ? !is_x : is_x;
         const int nb = pass == 0 ? n_same : n_other;
         const float cf = pass == 0 ? c_same : c_other;
         for (int j = w; j < nb; j += 2 * MMD_WAVES) {
             float b0[CPL], b1[CPL];
             const int j1 = j + MMD_WAVES;
-            mmd_load_row<CPL>(b + (size_t)j * h, h, lane, b0);
-            mmd_load_row<CPL>(b + (size_t)min(j1, nb - 1) * h, h, lane, b1);
+            mmd_load_row<CPL>(row_of(b_is_y, j), h, lane, b0);
+            mmd_load_row<CPL>(row_of(b_is_y, min(j1, nb - 1)), h, lane, b1);
             const float d0 = wave_sum(mmd_d2<CPL>(av, b0)), d1 = wave_sum(mmd_d2<CPL>(av, b1));
             const float k0 = cf * expf(-d0 * inv), k1 = j1 < nb ? cf * expf(-d1 * inv) : 0.f;
 #pragma unroll
@@ -476,12 +485,16 @@ __global__ __launch_bounds__(64 * MMD_WAVES) void k_mmd_bwd(const float* x, cons
 #pragma unroll
     for (int i = 0; i < CPL; ++i) sm[w][lane + 64 * i] = acc[i];
     __syncthreads();
-    float* o = (is_x ? gx : gy) + (size_t)row * h;
+    // x rows and dense y rows are stored; indexed y rows ADD into row yidx[row] of gy (a gradient that already holds
+    // other terms; float atomics, since an index may repeat)
+    const bool indexed = !is_x && yidx;
+    float* o = is_x ? gx + (size_t)row * h : gy + (size_t)(yidx ? yidx[row] : row) * h;
     for (int c = threadIdx.x; c < h; c += 64 * MMD_WAVES) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < MMD_WAVES; ++i) s += sm[i][c];
-        o[c] = s;
+        if (indexed) atomicAdd(o + c, s);
+        else o[c] = s;
     }
 }
 
@@ -621,9 +634,9 @@ extern "C" int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* 
 }
 
 extern "C" int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre,
-                         const float* resp, const float* gkl, float gscale, float* gz, float* gm, float* gv,
-                         float* g_zpre, int accumulate_zpre, float* workspace, int mix_ready, int64_t n, int h, int k,
-                         void* stream) {
+                         const float* resp, const float* gkl, float gscale, float z_extra, float* gz, float* gm,
+                         float* gv, float* g_zpre, int accumulate_zpre, float* workspace, int mix_ready, int64_t n, int h,
+                         int k, void* stream) {
     GV_REQUIRE(z && m && v && z_pre && resp && gz && gm && gv && g_zpre && workspace, GV_ERR_NULL,
                "gv_kl_bwd: NULL pointer");
     GV_REQUIRE(n > 0 && h > 0 && k > 0 && k <= KL_KMAX && ld_m >= h, GV_ERR_SHAPE, "gv_kl_bwd: bad shape");
@@ -632,12 +645,12 @@ extern "C" int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* 
     float* part = workspace + 3 * (size_t)k * h + RED_BLOCKS;
     if (k <= KL_FUSED_KT) {
         hipLaunchKernelGGL(k_kl_bwd_fused<KL_FUSED_KT>, dim3((h + 63) / 64, KL_SLICES), dim3(256), 0, GV_ST, z, m, ld_m, v, mix,
-                           resp, gkl, gscale, gz, gm, gv, part, n, h, k);
+                           resp, gkl, gscale, z_extra, gz, gm, gv, part, n, h, k);
     } else {
         const size_t lds = (size_t)2 * k * h * sizeof(float);
         const int nb = (int)((n + 3) / 4 > 1024 ? 1024 : (n + 3) / 4);
-        hipLaunchKernelGGL(k_kl_bwd_nodes, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, resp, gkl, gscale, gz, gm,
-                           gv, n, h, k);
+        hipLaunchKernelGGL(k_kl_bwd_nodes, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, resp, gkl, gscale, z_extra,
+                           gz, gm, gv, n, h, k);
         hipLaunchKernelGGL(k_kl_bwd_mix_part, dim3(k, (h + 63) / 64, KL_SLICES), dim3(256), 0, GV_ST, z, mix, resp, part, n,
                            h, k);
     }
@@ -665,13 +678,13 @@ extern "C" int gv_lincomb4(const float* a0, float c0, const float* a1, float c1,
     return launch_status("gv_lincomb4");
 }
 
-extern "C" int gv_mmd_fwd(const float* x, const float* y, int sx, int sy, int h, float* mmd, float* workspace,
-                          void* stream) {
+extern "C" int gv_mmd_fwd(const float* x, const float* y, const int64_t* y_index, int sx, int sy, int h, float* mmd,
+                          float* workspace, void* stream) {
     GV_REQUIRE(x && y && workspace, GV_ERR_NULL, "gv_mmd_fwd: NULL pointer");
     GV_REQUIRE(sx > 0 && sy > 0 && h > 0 && h <= 1024 && sx + sy <= RED_BLOCKS, GV_ERR_SHAPE,
                "gv_mmd_fwd: sx=%d sy=%d h=%d (need h <= 1024, sx+sy <= %d)", sx, sy, h, RED_BLOCKS);
-    if (h <= 256) hipLaunchKernelGGL(k_mmd_fwd<4>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, sx, sy, h, workspace);
-    else hipLaunchKernelGGL(k_mmd_fwd<16>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, sx, sy, h, workspace);
+    if (h <= 256) hipLaunchKernelGGL(k_mmd_fwd<4>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, y_index, sx, sy, h, workspace);
+    else hipLaunchKernelGGL(k_mmd_fwd<16>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, y_index, sx, sy, h, workspace);
     if (mmd) hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, sx + sy, 1.f, mmd, 0);
     return launch_status("gv_mmd_fwd");
 }
@@ -691,12 +704,12 @@ extern "C" int gv_loss_combine(const float* ws_pred, int64_t t, const float* ws_
     return launch_status("gv_loss_combine");
 }
 
-extern "C" int gv_mmd_bwd(const float* x, const float* y, int sx, int sy, int h, const float* gmmd, float gscale,
-                          float* gx, float* gy, void* stream) {
+extern "C" int gv_mmd_bwd(const float* x, const float* y, const int64_t* y_index, int sx, int sy, int h, const float* gmmd,
+                          float gscale, float* gx, float* gy, void* stream) {
     GV_REQUIRE(x && y && gx && gy, GV_ERR_NULL, "gv_mmd_bwd: NULL pointer");
     GV_REQUIRE(sx > 0 && sy > 0 && h > 0 && h <= 1024, GV_ERR_SHAPE, "gv_mmd_bwd: bad shape");
-    if (h <= 256) hipLaunchKernelGGL(k_mmd_bwd<4>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, sx, sy, h, gmmd, gscale, gx, gy);
-    else hipLaunchKernelGGL(k_mmd_bwd<16>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, sx, sy, h, gmmd, gscale, gx, gy);
+    if (h <= 256) hipLaunchKernelGGL(k_mmd_bwd<4>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, y_index, sx, sy, h, gmmd, gscale, gx, gy);
+    else hipLaunchKernelGGL(k_mmd_bwd<16>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, y_index, sx, sy, h, gmmd, gscale, gx, gy);
     return launch_status("gv_mmd_bwd");
 }
 

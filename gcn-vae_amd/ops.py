@@ -905,7 +905,7 @@ class _KL(torch.autograd.Function):
         gz, gm, gv = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
         d_zp = _direct_flat(z_pre)
         gzp = d_zp if d_zp is not None else torch.empty_like(z_pre)
-        lib.call('gv_kl_bwd', ptr(z), ptr(m), h, ptr(v), ptr(z_pre), ptr(resp), ptr(gkl), 1.0, ptr(gz), ptr(gm), ptr(gv),
+        lib.call('gv_kl_bwd', ptr(z), ptr(m), h, ptr(v), ptr(z_pre), ptr(resp), ptr(gkl), 1.0, 0.0, ptr(gz), ptr(gm), ptr(gv),
                  ptr(gzp), 1 if d_zp is not None else 0, ptr(ws), 1, n, h, k, lib.stream())
         return gz, gm, gv, (None if d_zp is not None else gzp), (gkl.reshape(()).clone() if ctx.has_flp else None)
 
@@ -1014,7 +1014,7 @@ class _MMD(torch.autograd.Function):
         x, y = _chk(x.contiguous(), name='z_pri'), _chk(y.contiguous(), name='z_post')
         out = torch.empty((), dtype=torch.float32, device=x.device)
         ws = torch.empty(x.shape[0] + y.shape[0], dtype=torch.float32, device=x.device)
-        lib.call('gv_mmd_fwd', ptr(x), ptr(y), x.shape[0], y.shape[0], x.shape[1], ptr(out), ptr(ws), lib.stream())
+        lib.call('gv_mmd_fwd', ptr(x), ptr(y), None, x.shape[0], y.shape[0], x.shape[1], ptr(out), ptr(ws), lib.stream())
         ctx.save_for_backward(x, y)
         return out
 
@@ -1023,7 +1023,7 @@ class _MMD(torch.autograd.Function):
         x, y = ctx.saved_tensors
         g = _chk(g.reshape(1).contiguous(), name='g')
         gx, gy = torch.empty_like(x), torch.empty_like(y)
-        lib.call('gv_mmd_bwd', ptr(x), ptr(y), x.shape[0], y.shape[0], x.shape[1], ptr(g), 1.0, ptr(gx), ptr(gy),
+        lib.call('gv_mmd_bwd', ptr(x), ptr(y), None, x.shape[0], y.shape[0], x.shape[1], ptr(g), 1.0, ptr(gx), ptr(gy),
                  lib.stream())
         return gx, gy
 
@@ -1101,8 +1101,7 @@ class _LossHead(torch.autograd.Function):
         if mmd_w > 0:
             z_pri = _chk(z_pri.contiguous(), name='z_pri')
             pick = _chk(pick.reshape(-1), torch.int64, 'pick')
-            z_post = torch.empty(pick.numel(), h, **f32)
-            wsm = torch.empty(z_pri.shape[0] + z_post.shape[0], **f32)
+            wsm = torch.empty(z_pri.shape[0] + pick.numel(), **f32)
         if ld_z != h or ld_w != h:
             raise ValueError('loss_head needs contiguous embeddings and relation table')
         st = lib.stream()
@@ -1110,9 +1109,8 @@ class _LossHead(torch.autograd.Function):
         if kl_w > 0:
             lib.call('gv_kl_fwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(flp), ptr(resp), None, ptr(wsk),
                      n, h, k, st)
-        if mmd_w > 0:
-            lib.call('gv_gather_rows', ptr(z), ptr(pick), ptr(z_post), pick.numel(), h, st)
-            lib.call('gv_mmd_fwd', ptr(z_pri), ptr(z_post), z_pri.shape[0], z_post.shape[0], h, None, ptr(wsm), st)
+        if mmd_w > 0:      # the posterior sample set is rows `pick` of z, read in place
+            lib.call('gv_mmd_fwd', ptr(z_pri), ptr(z), ptr(pick), z_pri.shape[0], pick.numel(), h, None, ptr(wsm), st)
         lib.call('gv_mean_sq2', ptr(z), z.numel(), 1.0 / z.numel(), ptr(w_rel), w_rel.numel(), 1.0 / w_rel.numel(), None,
                  ptr(ws2), st)
         # DistMult scorer + BCE (three 800-B row gathers per triplet: the bandwidth-bound part)
@@ -1120,7 +1118,7 @@ class _LossHead(torch.autograd.Function):
                  ptr(score), None, ptr(ws), T, h, st)
         lib.call('gv_loss_combine', ptr(ws), T, ptr(ws2), z.numel(), w_rel.numel(), ptr(wsk) if kl_w > 0 else None, n, h,
                  (z_pre.shape[0] // 2) if kl_w > 0 else 0, ptr(wsm) if mmd_w > 0 else None,
-                 z_pri.shape[0] if mmd_w > 0 else 0, z_post.shape[0] if mmd_w > 0 else 0, float(reg_w), float(kl_w),
+                 z_pri.shape[0] if mmd_w > 0 else 0, pick.numel() if mmd_w > 0 else 0, float(reg_w), float(kl_w),
                  float(mmd_w), ptr(scal), ptr(loss), st)
         ctx.save_for_backward(z, z_mean if kl_w > 0 else None, z_sigma if kl_w > 0 else None, w_rel,
                               z_pre if kl_w > 0 else None, resp, z_pri if mmd_w > 0 else None, z_post,
@@ -1152,7 +1150,7 @@ class _LossHead(torch.autograd.Function):
             gm, gv = torch.empty_like(z), torch.empty_like(z)
             gzp = d_zp if d_zp is not None else torch.empty_like(z_pre)
         if mmd_w > 0:
-            g_pri, g_post = torch.empty_like(z_pri), torch.empty_like(z_post)
+            g_pri = torch.empty_like(z_pri)
         d_w = ctx.direct_w
         g_w = d_w if d_w is not None else torch.empty_like(w_rel)
         g_flp = torch.empty((), **f32) if (has_bias or flp_in_kl) else None
@@ -1161,24 +1159,21 @@ class _LossHead(torch.autograd.Function):
         with fork(1):
             s1 = lib.stream()
             if kl_w > 0:
-                lib.call('gv_kl_bwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(resp), ptr(g), kl_w, ptr(gz),
-                         ptr(gm), ptr(gv), ptr(gzp), 1 if d_zp is not None else 0, ptr(wsk), 1, n, h, k, s1)
-                lib.call('gv_axpby', z.numel(), ptr(g), 2.0 * reg_w / z.numel(), ptr(z), 1.0, ptr(gz), s1)
+                # the embedding regulariser's gradient g * (2 reg_w / numel) * z rides on the same pass over z
+                lib.call('gv_kl_bwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(resp), ptr(g), kl_w,
+                         2.0 * reg_w / z.numel(), ptr(gz), ptr(gm), ptr(gv), ptr(gzp), 1 if d_zp is not None else 0, ptr(wsk),
+                         1, n, h, k, s1)
             else:
                 lib.call('gv_axpby', z.numel(), ptr(g), 2.0 * reg_w / z.numel(), ptr(z), 0.0, ptr(gz), s1)
-        # branch 2: MMD backward
-        if mmd_w > 0:
-            with fork(2):
-                lib.call('gv_mmd_bwd', ptr(z_pri), ptr(z_post), z_pri.shape[0], z_post.shape[0], h, ptr(g), mmd_w,
-                         ptr(g_pri), ptr(g_post), lib.stream())
+            if mmd_w > 0:      # MMD backward: prior rows -> g_pri, posterior rows ADDED into rows `pick` of gz (now complete)
+                lib.call('gv_mmd_bwd', ptr(z_pri), ptr(z), ptr(pick), z_pri.shape[0], pick.numel(), h, ptr(g), mmd_w,
+                         ptr(g_pri), ptr(gz), s1)
         # main: dL/dscore, then the relation-side gradient (does not need gz)
         lib.call('gv_bce_grad', ptr(score), ptr(labels), ptr(g), ptr(dscore), ptr(dbias), ptr(ws), T, st)
         bdd_grad_weight(tidx.rel, tidx.rel_s, tidx.rel_o, dscore, tidx.rel_tid, z, z, h, 1, 1, out=g_w,
                         accumulate=d_w is not None)
         lib.call('gv_axpby', w_rel.numel(), ptr(g), 2.0 * reg_w / w_rel.numel(), ptr(w_rel), 1.0, ptr(g_w), st)
-        join(1, 2)
-        if mmd_w > 0:
-            lib.call('gv_scatter_add_rows', ptr(g_post), ptr(pick), ptr(gz), pick.numel(), h, st)
+        join(1)
         g_z = bdd_aggregate(tidx.inc, tidx.inc_other, tidx.inc_rel, dscore, tidx.inc_tid, z, w_rel, h, 1, 1,
                             addend=gz)
         if g_flp is not None:

@@ -206,9 +206,10 @@ int64_t gv_kl_workspace_bytes(int64_t n, int h, int k);
 int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre, const float* flp,
               float* resp, float* kl, float* workspace, int64_t n, int h, int k, void* stream);
 int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre, const float* resp,
-              const float* gkl, float gscale, float* gz, float* gm, float* gv, float* g_zpre, int accumulate_zpre,
-              float* workspace, int mix_ready, int64_t n, int h, int k, void* stream);
-/* upstream gradient = gscale * (*gkl); accumulate_zpre adds into g_zpre; mix_ready = 1 when `workspace` is the one
+              const float* gkl, float gscale, float z_extra, float* gz, float* gm, float* gv, float* g_zpre,
+              int accumulate_zpre, float* workspace, int mix_ready, int64_t n, int h, int k, void* stream);
+/* upstream gradient = gscale * (*gkl); gz additionally receives (*gkl) * z_extra * z (the embedding regulariser's
+ * gradient, kgvae/link_predict.py:68-69, folded into the same pass); accumulate_zpre adds into g_zpre; mix_ready = 1 when `workspace` is the one
  * gv_kl_fwd filled for the same z_pre (skips recomputing the mixture table). */
 
 /*   gv_mmd_*  : KGVAE.get_mmd / compute_kernel (kgvae/model.py:71-80, :89-102) on x = prior samples (sx, h),
@@ -227,9 +228,14 @@ int gv_loss_combine(const float* ws_pred, int64_t t, const float* ws_reg, int64_
                     float kl_w, float mmd_w, float* scal /* 4 floats, optional */, float* loss, void* stream);
 int gv_lincomb4(const float* a0, float c0, const float* a1, float c1, const float* a2, float c2, const float* a3,
                 float c3, float* out, void* stream);
-int gv_mmd_fwd(const float* x, const float* y, int sx, int sy, int h, float* mmd, float* workspace, void* stream);
-int gv_mmd_bwd(const float* x, const float* y, int sx, int sy, int h, const float* gmmd, float gscale, float* gx,
-               float* gy, void* stream);
+/* y_index (optional, int64[sy]): sample j of the second set is row y_index[j] of y (KGVAE.get_mmd's posterior rows are a
+ * random pick of z, kgvae/model.py:96-99: no gathered copy).  With y_index the backward ADDS each row's gradient into row
+ * y_index[j] of gy (float atomics; gy is then a gradient of the whole matrix that already holds other terms); without it
+ * gy[j] is overwritten. */
+int gv_mmd_fwd(const float* x, const float* y, const int64_t* y_index, int sx, int sy, int h, float* mmd, float* workspace,
+               void* stream);
+int gv_mmd_bwd(const float* x, const float* y, const int64_t* y_index, int sx, int sy, int h, const float* gmmd, float gscale,
+               float* gx, float* gy, void* stream);
 int gv_prior_sample_fwd(const float* z_pre, const float* eps, float* out, int s, int k, int h, void* stream);
 int gv_prior_sample_bwd(const float* z_pre, const float* eps, const float* g, float* gz_pre, int accumulate, int s, int k,
                         int h, void* stream);
