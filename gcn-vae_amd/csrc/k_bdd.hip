@@ -258,7 +258,9 @@ __global__ __launch_bounds__(256) void k_agg_packed(const AggParams a) {
 
 // row layout [R][nb*P*Q] -> lane-packed layout for (BPL, ownership); one thread per float4
 __global__ __launch_bounds__(256) void k_pack_weight(const float* w, float* packed, int num_rels, int nb, int pq, int bpl,
-                                                     int adj) {
+                                                     int adj, float* packed2, int bpl2, int adj2) {
+    // blockIdx.y = 1: the second layout of the same weights (a layer's forward and backward-x launches pack differently)
+    if (blockIdx.y == 1) { packed = packed2; bpl = bpl2; adj = adj2; }
     const int L = nb / bpl, nq = bpl * pq / 4, quads = L * nq;     // float4 per relation row
     const int total = num_rels * quads;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
@@ -654,8 +656,23 @@ extern "C" int gv_rgcn_bdd_pack_weight(const float* weight, int num_rels, int nu
     GV_REQUIRE(aligned16(weight) && aligned16(packed), GV_ERR_ALIGN, "gv_rgcn_bdd_pack_weight: 16-B alignment required");
     const int total = num_rels * num_bases * blk_in * blk_out / 4;
     hipLaunchKernelGGL(k_pack_weight, dim3(min(2048, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight,
-                       packed, num_rels, num_bases, blk_in * blk_out, pl.bpl, pl.adj);
+                       packed, num_rels, num_bases, blk_in * blk_out, pl.bpl, pl.adj, (float*)nullptr, 0, 0);
     return launch_status("gv_rgcn_bdd_pack_weight");
+}
+
+extern "C" int gv_rgcn_bdd_pack_weight_pair(const float* weight, int num_rels, int num_bases, int blk_in, int blk_out,
+                                            float* packed_fwd, float* packed_bwd, void* stream) {
+    GV_REQUIRE(weight && packed_fwd && packed_bwd, GV_ERR_NULL, "gv_rgcn_bdd_pack_weight_pair: NULL pointer");
+    PackPlan pf, pb;
+    GV_REQUIRE(pack_plan(num_bases, blk_in, blk_out, false, &pf) && pack_plan(num_bases, blk_out, blk_in, true, &pb),
+               GV_ERR_SHAPE, "gv_rgcn_bdd_pack_weight_pair: no lane-packed kernels for num_bases=%d blocks %dx%d", num_bases,
+               blk_in, blk_out);
+    GV_REQUIRE(aligned16(weight) && aligned16(packed_fwd) && aligned16(packed_bwd), GV_ERR_ALIGN,
+               "gv_rgcn_bdd_pack_weight_pair: 16-B alignment required");
+    const int total = num_rels * num_bases * blk_in * blk_out / 4;
+    hipLaunchKernelGGL(k_pack_weight, dim3(min(2048, (total + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream, weight,
+                       packed_fwd, num_rels, num_bases, blk_in * blk_out, pf.bpl, pf.adj, packed_bwd, pb.bpl, pb.adj);
+    return launch_status("gv_rgcn_bdd_pack_weight_pair");
 }
 
 extern "C" int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const int32_t* fix, int n_fix,

@@ -302,8 +302,18 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmParams p) {
 __global__ __launch_bounds__(256) void k_gemm_splitk_reduce(const GemmParams p) {
     const size_t total = (size_t)p.m * p.n;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        float v = 0.f;
-        for (int z = 0; z < p.split_k; ++z) v += p.ws[(size_t)z * total + i];
+        // 8 partial tiles in flight (4 chains, fixed combine: the order does not depend on the launch geometry)
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int z = 0;
+        for (; z + 8 <= p.split_k; z += 8) {
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = p.ws[(size_t)(z + q) * total + i];
+            a0 += t[0]; a1 += t[1]; a2 += t[2]; a3 += t[3];
+            a0 += t[4]; a1 += t[5]; a2 += t[6]; a3 += t[7];
+        }
+        for (; z < p.split_k; ++z) a0 += p.ws[(size_t)z * total + i];
+        float v = (a0 + a1) + (a2 + a3);
         const int row = (int)(i / p.n), col = (int)(i - (size_t)row * p.n);
         if (p.bias) v += p.bias[col];
         v = apply_act(v, p.act);

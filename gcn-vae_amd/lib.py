@@ -22,6 +22,7 @@ SIGNATURES = {
                                    _P, _I, _I, _P, _F, _P, _I, _P, _P]),
     'gv_rgcn_bdd_pack_supported': (_I, [_I, _I, _I, _I]),
     'gv_rgcn_bdd_pack_weight': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    'gv_rgcn_bdd_pack_weight_pair': (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     'gv_rgcn_bdd_fixup': (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _F, _P, _I, _P]),
     'gv_rgcn_bdd_grad_weight': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
     'gv_rgcn_epilogue_fwd': (_I, [_P, _P, _I, _P, _F, _P, _L, _I, _P]),

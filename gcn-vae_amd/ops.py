@@ -615,7 +615,14 @@ class _RelGraphConvBdd(torch.autograd.Function):
         # lane-packed weights pay off once a block's weights span >= 32 B (measured: 2x4 / 4x2 blocks -24 % / -19 %,
         # 2x2 blocks +-0): pack per launch kind, a ~1.5 MB pass per layer
         pk = si * so >= 8 and pack_supported(num_bases, si, so, False)
-        w_fwd = pack_weight(weight, num_bases, si, so, False) if pk else weight
+        pk_bwd = si * so >= 8 and pack_supported(num_bases, so, si, True)
+        ctx.w_bwd_packed = None
+        if pk and pk_bwd and ctx.needs_input_grad[0]:      # one launch writes both layouts; backward-x reuses its copy
+            w_fwd, ctx.w_bwd_packed = torch.empty_like(weight), torch.empty_like(weight)
+            lib.call('gv_rgcn_bdd_pack_weight_pair', ptr(weight), weight.shape[0], num_bases, si, so, ptr(w_fwd),
+                     ptr(ctx.w_bwd_packed), lib.stream())
+        else:
+            w_fwd = pack_weight(weight, num_bases, si, so, False) if pk else weight
 
         def self_loop_term():
             if loop_weight is not None:
@@ -642,6 +649,7 @@ class _RelGraphConvBdd(torch.autograd.Function):
             out = epilogue_fwd(agg, addend, act, keep, keep_scale)
         ctx.save_for_backward(x, weight, loop_weight, coef, out if act == ACT_RELU else None, keep)
         ctx.meta = (gidx, ridx, num_bases, si, so, act, keep_scale, h_bias is not None, reduce_hook)
+        ctx.w_version = weight._version
         ctx.direct = (_direct(weight), _direct(h_bias), _direct(loop_weight))
         return out
 
@@ -677,7 +685,10 @@ class _RelGraphConvBdd(torch.autograd.Function):
         grad_x = None
         if ctx.needs_input_grad[0]:
             pk = si * so >= 8 and pack_supported(nb, so, si, True)
-            w_bwd = pack_weight(weight, nb, so, si, True) if pk else weight
+            if ctx.w_bwd_packed is not None and weight._version == ctx.w_version:
+                w_bwd = ctx.w_bwd_packed
+            else:
+                w_bwd = pack_weight(weight, nb, so, si, True) if pk else weight
             grad_x = bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, coef, gidx.by_src.perm, g_agg,
                                    w_bwd, nb, so, si, True, gx_loop, packed=pk)
         grad_w = None

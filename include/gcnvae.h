@@ -88,6 +88,10 @@ int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const int32_t* fix,
 int gv_rgcn_bdd_pack_supported(int num_bases, int blk_in, int blk_out, int transpose_w);
 int gv_rgcn_bdd_pack_weight(const float* weight, int num_rels, int num_bases, int blk_in, int blk_out, int transpose_w,
                             float* packed, void* stream);
+/* Both layouts a layer needs in one launch: packed_fwd for (blk_in, blk_out, transpose_w = 0), packed_bwd for the
+ * backward-x launch (blk_out, blk_in, transpose_w = 1). */
+int gv_rgcn_bdd_pack_weight_pair(const float* weight, int num_rels, int num_bases, int blk_in, int blk_out, float* packed_fwd,
+                                 float* packed_bwd, void* stream);
 
 /* The fix-up pass of gv_rgcn_bdd_aggregate on its own (a caller that passed n_fix = 0 there, e.g. to
  * time the aggregation kernel alone, finishes the split rows with this). */
