@@ -548,3 +548,26 @@ def test_device_rng_draws_fresh_numbers_on_graph_replay(ops):
         torch.cuda.synchronize()
         seen.append(keep.clone())
     assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+
+
+@pytest.mark.gpu
+def test_xcd_ordered_grad_w_items_give_identical_bits(ops):
+    """Reordering the grad-W work items for L2 locality (RelationIndex._xcd_order_items) changes which workgroup runs an
+    item, not what it computes: same bits, including relations split over several items."""
+    rs = np.random.RandomState(5)
+    n, e, r, nb = 400, 12000, 16, 10
+    dst = np.sort(rs.randint(0, n, e))
+    src = rs.randint(0, n, e)
+    et = torch.from_numpy(rs.randint(0, r, e)).cuda()
+    x, g = torch.randn(n, 20, device='cuda'), torch.randn(n, 40, device='cuda')
+    coef = torch.rand(e, device='cuda')
+    gi = ops.GraphIndex(torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda(), n)
+    outs = []
+    for reorder in (False, True):
+        ri = ops.RelationIndex(gi, et, r, chunk=16)
+        if reorder:
+            before = ri.by_rel.seg.n_items
+            ri._xcd_order_items()
+            assert ri.by_rel.seg.n_items >= before and int((ri.by_rel.seg.items[:, 0] >= 0).sum()) == before
+        outs.append(ops.bdd_grad_weight(ri.by_rel.seg, ri.src_by_rel, ri.dst_by_rel, coef, ri.by_rel.perm, x, g, nb, 2, 4))
+    assert torch.equal(outs[0], outs[1])
