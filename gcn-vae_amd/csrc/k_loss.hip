@@ -53,44 +53,83 @@ __global__ __launch_bounds__(256) void k_loss_combine(const float* p0, int n0, f
 }
 
 // ---- DistMult: 16 lanes per triplet (4 triplets per wave); three 800-B row gathers per triplet
+// `order` (optional): the triplets sorted by subject.  Workgroups are dealt round-robin to the 8 XCDs; workgroup b takes
+// positions of the range [T/8 * (b%8), T/8 * (b%8 + 1)) of that order, so the subject rows an XCD gathers come from one
+// window of the embedding table and stay in its L2 (consecutive triplets often share the subject outright).
 __global__ __launch_bounds__(256) void k_distmult_bce(const float* e, int ld_e, const float* w, int ld_w,
-                                                      const int* trip, const float* labels, const float* bias,
-                                                      float* score, float* part, int64_t T, int h) {
+                                                      const int* trip, const int* order, const float* labels,
+                                                      const float* bias, float* score, float* part, int64_t T, int h) {
     __shared__ float sm[4];
     const int sub = threadIdx.x & 15;
     const float bv = bias ? *bias : 0.f;
     const bool vec = (h % 4 == 0) && (ld_e % 4 == 0) && (ld_w % 4 == 0);
     float lsum = 0.f;
     // 16 triplets per block iteration; every lane runs the same trip count (shuffles below)
-    for (int64_t t0 = (int64_t)blockIdx.x * 16; t0 < T; t0 += (int64_t)gridDim.x * 16) {
-        const int64_t t = t0 + (threadIdx.x >> 4);
+    const int n_x = gridDim.x >= 8 ? 8 : 1;                       // XCD-major split of the position range
+    const int64_t per = (T + n_x - 1) / n_x;
+    const int64_t lo = (blockIdx.x % n_x) * per, hi = min(T, lo + per);
+    const int brank = blockIdx.x / n_x, bper = (gridDim.x + n_x - 1 - (blockIdx.x % n_x)) / n_x;   // blocks of this XCD
+    // one triplet per 16-lane group and iteration; its dot product over h columns
+    auto triplet_dot = [&](int64_t t) -> float {
+        const int s = trip[3 * t], r = trip[3 * t + 1], o = trip[3 * t + 2];
+        const float* es = e + (size_t)s * ld_e;
+        const float* eo = e + (size_t)o * ld_e;
+        const float* wr = w + (size_t)r * ld_w;
         float acc = 0.f;
-        if (t < T) {
-            const int s = trip[3 * t], r = trip[3 * t + 1], o = trip[3 * t + 2];
-            const float* es = e + (size_t)s * ld_e;
-            const float* eo = e + (size_t)o * ld_e;
-            const float* wr = w + (size_t)r * ld_w;
-            if (vec) {
-                for (int c = sub * 4; c < h; c += 64) {
-                    const float4 a = *reinterpret_cast<const float4*>(es + c);
-                    const float4 b = *reinterpret_cast<const float4*>(wr + c);
-                    const float4 d = *reinterpret_cast<const float4*>(eo + c);
-                    acc = fmaf(a.x * b.x, d.x, acc);
-                    acc = fmaf(a.y * b.y, d.y, acc);
-                    acc = fmaf(a.z * b.z, d.z, acc);
-                    acc = fmaf(a.w * b.w, d.w, acc);
+        if (vec && h <= 256) {
+            // all of a triplet's row pieces in flight at once (up to 4 x 3 16-B loads per lane), then the products
+            float4 a[4], b[4], d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = sub * 4 + 64 * q;
+                if (c < h) {
+                    a[q] = *reinterpret_cast<const float4*>(es + c);
+                    b[q] = *reinterpret_cast<const float4*>(wr + c);
+                    d[q] = *reinterpret_cast<const float4*>(eo + c);
                 }
-            } else {
-                for (int c = sub; c < h; c += 16) acc = fmaf(es[c] * wr[c], eo[c], acc);
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (sub * 4 + 64 * q < h) {
+                    acc = fmaf(a[q].x * b[q].x, d[q].x, acc);
+                    acc = fmaf(a[q].y * b[q].y, d[q].y, acc);
+                    acc = fmaf(a[q].z * b[q].z, d[q].z, acc);
+                    acc = fmaf(a[q].w * b[q].w, d[q].w, acc);
+                }
+            }
+        } else if (vec) {
+            for (int c = sub * 4; c < h; c += 64) {
+                const float4 a = *reinterpret_cast<const float4*>(es + c);
+                const float4 b = *reinterpret_cast<const float4*>(wr + c);
+                const float4 d = *reinterpret_cast<const float4*>(eo + c);
+                acc = fmaf(a.x * b.x, d.x, acc);
+                acc = fmaf(a.y * b.y, d.y, acc);
+                acc = fmaf(a.z * b.z, d.z, acc);
+                acc = fmaf(a.w * b.w, d.w, acc);
+            }
+        } else {
+            for (int c = sub; c < h; c += 16) acc = fmaf(es[c] * wr[c], eo[c], acc);
         }
+        return acc;
+    };
+    auto finish = [&](float acc, bool live, int64_t t) {
         acc = row16_sum(acc);          // the triplet's 16 lanes are one DPP row
-        if (t < T && sub == 0) {
+        if (live && sub == 0) {
             const float x = acc + bv;
             score[t] = x;
             const float y = labels[t];
             lsum += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
         }
+    };
+    const int64_t stride = (int64_t)bper * 16;
+    for (int64_t p0 = lo + (int64_t)brank * 16; p0 < hi; p0 += 2 * stride) {      // two triplets in flight per group
+        const int64_t pa = p0 + (threadIdx.x >> 4), pb = pa + stride;
+        const bool la = pa < hi, lb = pb < hi;
+        const int64_t ta = la ? (order ? order[pa] : pa) : 0, tb = lb ? (order ? order[pb] : pb) : 0;
+        const float xa = la ? triplet_dot(ta) : 0.f;
+        const float xb = lb ? triplet_dot(tb) : 0.f;
+        finish(xa, la, ta);
+        finish(xb, lb, tb);
     }
     const float tot = block_sum_256(lsum, sm);
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
@@ -548,14 +587,14 @@ static int sq2_blocks(int64_t n, int cap) {
 static int kl_blocks(int64_t n) { return (int)((n + 3) / 4 > RED_BLOCKS ? RED_BLOCKS : (n + 3) / 4); }
 
 extern "C" int gv_distmult_bce_fwd(const float* embed, int ld_e, const float* w_rel, int ld_w,
-                                   const int32_t* triplets, const float* labels, const float* bias, float* score,
-                                   float* loss, float* workspace, int64_t t, int h, void* stream) {
+                                   const int32_t* triplets, const int32_t* order, const float* labels, const float* bias,
+                                   float* score, float* loss, float* workspace, int64_t t, int h, void* stream) {
     GV_REQUIRE(embed && w_rel && triplets && labels && score && workspace, GV_ERR_NULL,
                "gv_distmult_bce_fwd: NULL pointer");
     GV_REQUIRE(t > 0 && h > 0 && ld_e >= h && ld_w >= h, GV_ERR_SHAPE, "gv_distmult_bce_fwd: bad shape");
     const int nb = red_blocks(t, 16);
-    hipLaunchKernelGGL(k_distmult_bce, dim3(nb), dim3(256), 0, GV_ST, embed, ld_e, w_rel, ld_w, triplets, labels, bias,
-                       score, workspace, t, h);
+    hipLaunchKernelGGL(k_distmult_bce, dim3(nb), dim3(256), 0, GV_ST, embed, ld_e, w_rel, ld_w, triplets, order, labels,
+                       bias, score, workspace, t, h);
     if (loss) hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, nb, 1.f / (float)t, loss, 0);
     return launch_status("gv_distmult_bce_fwd");
 }

@@ -231,6 +231,29 @@ class GraphIndex:
         return hit
 
 
+def xcd_order_items(seg: SegmentItems, key_by_pos: torch.Tensor, n_xcd: int = 8, group: int = 4):
+    """Reorder a work-item list in place so that the workgroups ONE XCD receives (workgroups are dealt round-robin to the
+    8 XCDs, `group` items per workgroup) are the items of one contiguous range of ``key_by_pos[item.begin]`` -- the rows
+    an XCD gathers through that key then come from one window of the table and stay in its 4 MiB L2.  Items keep their
+    contents (segment, range, slot), so results are bit-identical; -1 padding entries sort last and stay -1."""
+    n = seg.n_items
+    if n == 0 or key_by_pos.numel() == 0:
+        return
+    items = seg.items[:n]
+    valid = items[:, 0] >= 0
+    begin = items[:, 1].long().clamp(0, key_by_pos.numel() - 1)
+    key = torch.where(valid, key_by_pos[begin].long(), torch.full_like(begin, torch.iinfo(torch.int64).max))
+    order = torch.argsort(key, stable=True)
+    per = -(-n // n_xcd)
+    per = -(-per // group) * group
+    pos = torch.arange(n, device=items.device)
+    xcd, k = pos // per, pos % per
+    slot = (k // group) * (n_xcd * group) + xcd * group + (k % group)       # final index of the p-th item in key order
+    out = torch.full((per * n_xcd, 4), -1, dtype=torch.int32, device=items.device)
+    out[slot] = items[order]
+    seg.items, seg.n_items = out, per * n_xcd
+
+
 class RelationIndex:
     def __init__(self, g: GraphIndex, etypes: torch.Tensor, num_rels: int, chunk: int = DEFAULT_CHUNK_REL):
         if etypes.numel() != g.num_edges:
@@ -252,26 +275,10 @@ class RelationIndex:
         if _os.environ.get('GV_GRADW_XCD', '1') == '1' and not g.sync_free and self.by_rel.seg.n_items >= 1024:
             self._xcd_order_items()
 
-    def _xcd_order_items(self, n_xcd: int = 8, group: int = 4):
-        """Reorder the grad-W work items so that the workgroups an XCD receives (workgroups are dealt round-robin to the
-        8 XCDs, 4 items per workgroup) cover one contiguous range of destination rows: within a relation the edges are
-        in destination order, so an item gathers g[dst] rows from a narrow dst window, and items of similar windows then
-        share an XCD's L2."""
-        seg = self.by_rel.seg
-        n = seg.n_items
-        items = seg.items[:n]
-        first_dst = self.dst_by_rel[items[:, 1].long().clamp_(max=max(self.dst_by_rel.numel() - 1, 0))].long()
-        order = torch.argsort(first_dst, stable=True)
-        # position p of the sorted list -> XCD p // per; inside an XCD consecutive groups of `group` items form one workgroup
-        per = -(-n // n_xcd)
-        per = -(-per // group) * group
-        pos = torch.arange(n, device=items.device)
-        xcd, k = pos // per, pos % per
-        slot = (k // group) * (n_xcd * group) + xcd * group + (k % group)       # final index of sorted item p
-        n_pad = per * n_xcd
-        out = torch.full((n_pad, 4), -1, dtype=torch.int32, device=items.device)
-        out[slot] = items[order]
-        seg.items, seg.n_items = out, n_pad
+    def _xcd_order_items(self):
+        """Workgroups of one XCD cover one window of destination rows: within a relation the edges are in destination
+        order, so an item gathers g[dst] rows from a narrow window, and items of similar windows then share an L2."""
+        xcd_order_items(self.by_rel.seg, self.dst_by_rel)
 
 
 class TripletIndex:
@@ -282,12 +289,14 @@ class TripletIndex:
     """
 
     def __init__(self, triplets: torch.Tensor, num_entities: int, num_rels: int, chunk: int = DEFAULT_CHUNK,
-                 chunk_rel: int = DEFAULT_CHUNK_REL, sync_free: bool = False):
+                 chunk_rel: int = DEFAULT_CHUNK_REL, sync_free: bool = False, locality: Optional[bool] = None):
         if not triplets.is_cuda:
             raise RuntimeError('TripletIndex needs a CUDA tensor; there is no CPU fallback')
         t = triplets.to(torch.int64)
         self.T = int(t.shape[0])
         self.num_entities, self.num_rels = int(num_entities), int(num_rels)
+        if locality is None:       # two more sorts per index: worth it once the embedding table outgrows an XCD's L2
+            locality = self.num_entities * 800 >= (4 << 20)
         self.trip32 = t.to(torch.int32).contiguous()
         s, r, o = t[:, 0], t[:, 1], t[:, 2]
         ent = torch.cat([s, o])
@@ -300,12 +309,17 @@ class TripletIndex:
         self.inc_tid = tid[perm].to(torch.int32).contiguous()
         self.inc = build_segment_items(_rowptr_from_sorted(ent[perm], self.num_entities), chunk,
                                        2 * self.T if sync_free else None)
-        perm_r = torch.sort(r, stable=True)[1]
+        # DistMult forward walks the triplets in subject order (XCD windows of the embedding table, see k_distmult_bce);
+        # the by-relation list of its weight gradient is ordered by (relation, subject) for the same reason
+        self.fwd_order = torch.sort(s, stable=True)[1].to(torch.int32).contiguous() if locality else None
+        perm_r = torch.sort(r * self.num_entities + s if locality else r, stable=True)[1]
         self.rel_s = s[perm_r].to(torch.int32).contiguous()
         self.rel_o = o[perm_r].to(torch.int32).contiguous()
         self.rel_tid = perm_r.to(torch.int32).contiguous()
         self.rel = build_segment_items(_rowptr_from_sorted(r[perm_r], self.num_rels), chunk_rel,
                                        self.T if sync_free else None)
+        if locality and self.T >= 65536:
+            xcd_order_items(self.rel, self.rel_s)          # subject windows per XCD for the w_relation gradient
 
 
 # ------------------------------------------------------------------------------------------------
@@ -823,8 +837,8 @@ class _DistMultBCE(torch.autograd.Function):
         score = torch.empty(T, dtype=torch.float32, device=embed.device)
         loss = torch.empty((), dtype=torch.float32, device=embed.device)
         ws = torch.empty(1024, dtype=torch.float32, device=embed.device)
-        lib.call('gv_distmult_bce_fwd', ptr(embed), ld_e, ptr(w_rel), ld_w, ptr(tidx.trip32), ptr(labels), ptr(bias),
-                 ptr(score), ptr(loss), ptr(ws), T, h, lib.stream())
+        lib.call('gv_distmult_bce_fwd', ptr(embed), ld_e, ptr(w_rel), ld_w, ptr(tidx.trip32), ptr(tidx.fwd_order),
+                 ptr(labels), ptr(bias), ptr(score), ptr(loss), ptr(ws), T, h, lib.stream())
         ctx.save_for_backward(embed, w_rel, labels, score)
         ctx.tidx, ctx.has_bias = tidx, bias is not None
         ctx.mark_non_differentiable(score)
@@ -868,8 +882,8 @@ class _DistMultScore(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=embed.device)
         ws = torch.empty(1024, dtype=torch.float32, device=embed.device)
         zeros = torch.zeros(T, dtype=torch.float32, device=embed.device)
-        lib.call('gv_distmult_bce_fwd', ptr(embed), ld_e, ptr(w_rel), ld_w, ptr(tidx.trip32), ptr(zeros), None,
-                 ptr(score), ptr(loss), ptr(ws), T, h, lib.stream())
+        lib.call('gv_distmult_bce_fwd', ptr(embed), ld_e, ptr(w_rel), ld_w, ptr(tidx.trip32), ptr(tidx.fwd_order), ptr(zeros),
+                 None, ptr(score), ptr(loss), ptr(ws), T, h, lib.stream())
         ctx.save_for_backward(embed, w_rel)
         ctx.tidx = tidx
         return score
@@ -1149,8 +1163,8 @@ class _LossHead(torch.autograd.Function):
         lib.call('gv_mean_sq2', ptr(z), z.numel(), 1.0 / z.numel(), ptr(w_rel), w_rel.numel(), 1.0 / w_rel.numel(), None,
                  ptr(ws2), st)
         # DistMult scorer + BCE (three 800-B row gathers per triplet: the bandwidth-bound part)
-        lib.call('gv_distmult_bce_fwd', ptr(z), ld_z, ptr(w_rel), ld_w, ptr(tidx.trip32), ptr(labels), ptr(bias),
-                 ptr(score), None, ptr(ws), T, h, st)
+        lib.call('gv_distmult_bce_fwd', ptr(z), ld_z, ptr(w_rel), ld_w, ptr(tidx.trip32), ptr(tidx.fwd_order), ptr(labels),
+                 ptr(bias), ptr(score), None, ptr(ws), T, h, st)
         lib.call('gv_loss_combine', ptr(ws), T, ptr(ws2), z.numel(), w_rel.numel(), ptr(wsk) if kl_w > 0 else None, n, h,
                  (z_pre.shape[0] // 2) if kl_w > 0 else 0, ptr(wsm) if mmd_w > 0 else None,
                  z_pri.shape[0] if mmd_w > 0 else 0, pick.numel() if mmd_w > 0 else 0, float(reg_w), float(kl_w),

@@ -186,6 +186,7 @@ int gv_reparam_bwd(const float* h2, const float* eps, const float* v, const floa
  * index (see gv_rgcn_bdd_aggregate / gv_rgcn_bdd_grad_weight).
  *   gv_bce_grad: dscore_t = (*gloss) * (sigmoid(score_t) - label_t) / T ;  *dbias (+)= sum_t dscore_t */
 int gv_distmult_bce_fwd(const float* embed, int ld_e, const float* w_rel, int ld_w, const int32_t* triplets,
+                        const int32_t* order /* optional: triplet ids sorted by subject (L2 locality), int32[T] */,
                         const float* labels, const float* bias, float* score, float* loss, float* workspace,
                         int64_t t, int h, void* stream);
 int gv_bce_grad(const float* score, const float* labels, const float* gloss, float* dscore, float* dbias,
