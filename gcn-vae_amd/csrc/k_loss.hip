@@ -135,14 +135,23 @@ __global__ __launch_bounds__(256) void k_distmult_bce(const float* e, int ld_e, 
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
 
+// pos3 (optional, int32 [T][3]): where triplet t sits in the entity-incidence list (as subject, as object) and in the
+// by-relation list of the backward's two K1 launches; d is then also written there, so those launches read their edge
+// coefficient in their own order instead of through an index (one dependent load less per 64-edge batch).
 __global__ __launch_bounds__(256) void k_bce_grad(const float* score, const float* labels, const float* gloss,
-                                                  float* dscore, float* part, int64_t T) {
+                                                  float* dscore, const int* pos3, float* d_inc, float* d_rel, float* part,
+                                                  int64_t T) {
     __shared__ float sm[4];
     const float g = (gloss ? *gloss : 1.f) / (float)T;
     float acc = 0.f;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < T; t += (int64_t)gridDim.x * 256) {
         const float d = g * (1.f / (1.f + expf(-score[t])) - labels[t]);
         dscore[t] = d;
+        if (pos3) {
+            d_inc[pos3[3 * t]] = d;
+            d_inc[pos3[3 * t + 1]] = d;
+            d_rel[pos3[3 * t + 2]] = d;
+        }
         acc += d;
     }
     const float tot = block_sum_256(acc, sm);
@@ -599,12 +608,15 @@ extern "C" int gv_distmult_bce_fwd(const float* embed, int ld_e, const float* w_
     return launch_status("gv_distmult_bce_fwd");
 }
 
-extern "C" int gv_bce_grad(const float* score, const float* labels, const float* gloss, float* dscore, float* dbias,
-                           float* workspace, int64_t t, void* stream) {
+extern "C" int gv_bce_grad(const float* score, const float* labels, const float* gloss, float* dscore,
+                           const int32_t* pos3, float* dscore_inc, float* dscore_rel, float* dbias, float* workspace,
+                           int64_t t, void* stream) {
     GV_REQUIRE(score && labels && dscore && workspace, GV_ERR_NULL, "gv_bce_grad: NULL pointer");
+    GV_REQUIRE(!pos3 || (dscore_inc && dscore_rel), GV_ERR_NULL, "gv_bce_grad: pos3 needs dscore_inc and dscore_rel");
     GV_REQUIRE(t > 0, GV_ERR_SHAPE, "gv_bce_grad: t=%lld", (long long)t);
     const int nb = red_blocks(t, 256);
-    hipLaunchKernelGGL(k_bce_grad, dim3(nb), dim3(256), 0, GV_ST, score, labels, gloss, dscore, workspace, t);
+    hipLaunchKernelGGL(k_bce_grad, dim3(nb), dim3(256), 0, GV_ST, score, labels, gloss, dscore, pos3, dscore_inc,
+                       dscore_rel, workspace, t);
     if (dbias) hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, nb, 1.f, dbias, 0);
     return launch_status("gv_bce_grad");
 }

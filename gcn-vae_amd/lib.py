@@ -40,7 +40,7 @@ SIGNATURES = {
     'gv_reparam_fwd': (_I, [_P, _P, _P, _P, _P, _L, _I, _P]),
     'gv_reparam_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     'gv_distmult_bce_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
-    'gv_bce_grad': (_I, [_P, _P, _P, _P, _P, _P, _L, _P]),
+    'gv_bce_grad': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     'gv_mean_sq': (_I, [_P, _L, _F, _P, _P, _I, _P]),
     'gv_mean_sq2': (_I, [_P, _L, _F, _P, _L, _F, _P, _P, _P]),
     'gv_axpby': (_I, [_L, _P, _F, _P, _F, _P, _P]),

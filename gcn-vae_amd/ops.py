@@ -193,6 +193,16 @@ class GraphIndex:
         self._rel_cache = {}
         self._chunk_cache = {}
 
+    def coef_in_src_order(self, coef: torch.Tensor) -> torch.Tensor:
+        """Per-edge coefficients (given in the caller's edge order) permuted into the by-source order of the backward-x
+        aggregation, so that launch reads them directly instead of through ``coef_idx`` (a dependent load per 64-edge
+        batch).  Cached on the tensor's identity and version: the edge norm of a graph is the same every step."""
+        key = (coef.data_ptr(), coef._version, coef.numel())
+        hit = getattr(self, '_coef_src_cache', None)
+        if hit is None or hit[0] != key:
+            hit = self._coef_src_cache = (key, coef.reshape(-1)[self.by_src.perm.long()].contiguous())
+        return hit[1]
+
     def dst_chunks(self, n_chunks: int):
         """Cut the destination rows into ``n_chunks`` contiguous blocks of EQUAL ROW COUNT and return, per block,
         (row0, row1, SegmentItems restricted to those rows).  Used by the multi-GPU forward to start the all-reduce
@@ -307,6 +317,8 @@ class TripletIndex:
         self.inc_other = other[perm].to(torch.int32).contiguous()
         self.inc_rel = rel2[perm].to(torch.int32).contiguous()
         self.inc_tid = tid[perm].to(torch.int32).contiguous()
+        inv_inc = torch.empty_like(perm)
+        inv_inc[perm] = torch.arange(2 * self.T, device=t.device)
         self.inc = build_segment_items(_rowptr_from_sorted(ent[perm], self.num_entities), chunk,
                                        2 * self.T if sync_free else None)
         # DistMult forward walks the triplets in subject order (XCD windows of the embedding table, see k_distmult_bce);
@@ -316,6 +328,10 @@ class TripletIndex:
         self.rel_s = s[perm_r].to(torch.int32).contiguous()
         self.rel_o = o[perm_r].to(torch.int32).contiguous()
         self.rel_tid = perm_r.to(torch.int32).contiguous()
+        inv_rel = torch.empty_like(perm_r)
+        inv_rel[perm_r] = torch.arange(self.T, device=t.device)
+        # where triplet t sits in the two backward orders (gv_bce_grad scatters dL/dscore there: no coef_idx indirection)
+        self.pos3 = torch.stack([inv_inc[:self.T], inv_inc[self.T:], inv_rel], dim=1).to(torch.int32).contiguous()
         self.rel = build_segment_items(_rowptr_from_sorted(r[perm_r], self.num_rels), chunk_rel,
                                        self.T if sync_free else None)
         if locality and self.T >= 65536:
@@ -727,7 +743,8 @@ class _RelGraphConvBdd(torch.autograd.Function):
                 w_bwd = ctx.w_bwd_packed
             else:
                 w_bwd = pack_weight(weight, nb, so, si, True) if pk else weight
-            grad_x = bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, coef, gidx.by_src.perm, g_agg,
+            coef_s = None if coef is None else gidx.coef_in_src_order(coef)
+            grad_x = bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, coef_s, None, g_agg,
                                    w_bwd, nb, so, si, True, gx_loop, packed=pk)
         grad_w = None
         if ctx.needs_input_grad[1]:
@@ -856,7 +873,8 @@ class _DistMultBCE(torch.autograd.Function):
         dscore = torch.empty(T, dtype=torch.float32, device=dev)
         dbias = torch.empty((), dtype=torch.float32, device=dev) if ctx.has_bias else None
         ws = torch.empty(1024, dtype=torch.float32, device=dev)
-        lib.call('gv_bce_grad', ptr(score), ptr(labels), ptr(gloss), ptr(dscore), ptr(dbias), ptr(ws), T, lib.stream())
+        lib.call('gv_bce_grad', ptr(score), ptr(labels), ptr(gloss), ptr(dscore), None, None, None, ptr(dbias), ptr(ws), T,
+                 lib.stream())
         g_embed = g_w = None
         if ctx.needs_input_grad[0]:
             g_embed = bdd_aggregate(tidx.inc, tidx.inc_other, tidx.inc_rel, dscore, tidx.inc_tid, embed, w_rel,
@@ -1218,12 +1236,14 @@ class _LossHead(torch.autograd.Function):
                 lib.call('gv_mmd_bwd', ptr(z_pri), ptr(z), ptr(pick), z_pri.shape[0], pick.numel(), h, ptr(g), mmd_w,
                          ptr(g_pri), ptr(gz), s1)
         # main: dL/dscore, then the relation-side gradient (does not need gz)
-        lib.call('gv_bce_grad', ptr(score), ptr(labels), ptr(g), ptr(dscore), ptr(dbias), ptr(ws), T, st)
-        bdd_grad_weight(tidx.rel, tidx.rel_s, tidx.rel_o, dscore, tidx.rel_tid, z, z, h, 1, 1, out=g_w,
+        d_inc, d_rel = torch.empty(2 * T, **f32), torch.empty(T, **f32)       # dL/dscore in the two launches' own orders
+        lib.call('gv_bce_grad', ptr(score), ptr(labels), ptr(g), ptr(dscore), ptr(tidx.pos3), ptr(d_inc), ptr(d_rel),
+                 ptr(dbias), ptr(ws), T, st)
+        bdd_grad_weight(tidx.rel, tidx.rel_s, tidx.rel_o, d_rel, None, z, z, h, 1, 1, out=g_w,
                         accumulate=d_w is not None)
         lib.call('gv_axpby', w_rel.numel(), ptr(g), 2.0 * reg_w / w_rel.numel(), ptr(w_rel), 1.0, ptr(g_w), st)
         join(1)
-        g_z = bdd_aggregate(tidx.inc, tidx.inc_other, tidx.inc_rel, dscore, tidx.inc_tid, z, w_rel, h, 1, 1,
+        g_z = bdd_aggregate(tidx.inc, tidx.inc_other, tidx.inc_rel, d_inc, None, z, w_rel, h, 1, 1,
                             addend=gz)
         if g_flp is not None:
             lib.call('gv_lincomb4', ptr(dbias) if has_bias else None, 1.0, ptr(g) if flp_in_kl else None, kl_w, None, 0.0,

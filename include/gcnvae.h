@@ -189,8 +189,12 @@ int gv_distmult_bce_fwd(const float* embed, int ld_e, const float* w_rel, int ld
                         const int32_t* order /* optional: triplet ids sorted by subject (L2 locality), int32[T] */,
                         const float* labels, const float* bias, float* score, float* loss, float* workspace,
                         int64_t t, int h, void* stream);
-int gv_bce_grad(const float* score, const float* labels, const float* gloss, float* dscore, float* dbias,
-                float* workspace, int64_t t, void* stream);
+int gv_bce_grad(const float* score, const float* labels, const float* gloss, float* dscore,
+                const int32_t* pos3 /* optional int32[T][3] */, float* dscore_inc /* [2T] */, float* dscore_rel /* [T] */,
+                float* dbias, float* workspace, int64_t t, void* stream);
+/* pos3[t] = positions of triplet t in the entity-incidence order (as subject, as object) and in the by-relation order of
+ * the two K1 launches of the DistMult backward: dscore_t is then also written to dscore_inc / dscore_rel at those
+ * positions, and the launches take their edge coefficient without a coef_idx indirection. */
 
 /* ---------------------------------------------------------------------------------------------
  * K6  fused reductions

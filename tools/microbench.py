@@ -101,6 +101,10 @@ def bench_k1(chunk=256, chunk_rel=128):
                                              w, nb, so, si, True))
         by = E * (fout * 4 + 12) + N * (fin * 4 + 4) + R * fin * fout // nb * 4
         print(f'agg bwd-x {so}x{si}: {t:7.1f} us  {by / t / 1e3:7.1f} GB/s algorithmic')
+        norm_s = norm[gidx.by_src.perm.long()].contiguous()
+        t = timeit(lambda: ops.bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, norm_s, None, gg,
+                                             w, nb, so, si, True))
+        print(f'agg bwd-x {so}x{si}: {t:7.1f} us  {by / t / 1e3:7.1f} GB/s algorithmic   [coefficients pre-permuted]')
         ref = ops.bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, norm, gidx.by_src.perm, gg, w, nb, so, si, True)
         got = ops.bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, norm, gidx.by_src.perm, gg, wpt, nb, so, si, True, packed=True)
         t = timeit(lambda: ops.bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, norm, gidx.by_src.perm, gg,
