@@ -285,6 +285,15 @@ class RelationIndex:
         if _os.environ.get('GV_GRADW_XCD', '1') == '1' and not g.sync_free and self.by_rel.seg.n_items >= 1024:
             self._xcd_order_items()
 
+    def coef_in_rel_order(self, coef: torch.Tensor) -> torch.Tensor:
+        """Per-edge coefficients permuted into the by-relation order of the grad-W launch (cached like
+        GraphIndex.coef_in_src_order)."""
+        key = (coef.data_ptr(), coef._version, coef.numel())
+        hit = getattr(self, '_coef_rel_cache', None)
+        if hit is None or hit[0] != key:
+            hit = self._coef_rel_cache = (key, coef.reshape(-1)[self.by_rel.perm.long()].contiguous())
+        return hit[1]
+
     def _xcd_order_items(self):
         """Workgroups of one XCD cover one window of destination rows: within a relation the edges are in destination
         order, so an item gathers g[dst] rows from a narrow window, and items of similar windows then share an L2."""
@@ -748,7 +757,8 @@ class _RelGraphConvBdd(torch.autograd.Function):
                                    w_bwd, nb, so, si, True, gx_loop, packed=pk)
         grad_w = None
         if ctx.needs_input_grad[1]:
-            grad_w = bdd_grad_weight(ridx.by_rel.seg, ridx.src_by_rel, ridx.dst_by_rel, coef, ridx.by_rel.perm, x,
+            coef_r = None if coef is None else ridx.coef_in_rel_order(coef)
+            grad_w = bdd_grad_weight(ridx.by_rel.seg, ridx.src_by_rel, ridx.dst_by_rel, coef_r, None, x,
                                      g_agg, nb, si, so, out=d_w, accumulate=d_w is not None)
             if d_w is not None:
                 grad_w = None
