@@ -233,6 +233,7 @@ def main():
     node_id, etype = w['node_id'].to(dev), w['rel'].to(dev)
     enorm, samples, labels = w['enorm'], w['samples'].to(dev), w['labels'].to(dev)
     n_nodes, E, T = w['data'].num_nodes, int(w['src'].numel()), int(samples.shape[0])
+    model.static_batch = True      # the same triplets every step: build their index once, exact and locality-ordered
     params = [p for p in model.parameters() if p.requires_grad]
     # One GPU: the step is replayed as a hipGraph.  With RCCL collectives in the step (world > 1) the default is eager
     # launching -- measured equal to graph replay on one GPU (the step is GPU-bound: ~55 launches of 5-130 us against

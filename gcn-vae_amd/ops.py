@@ -314,8 +314,8 @@ class TripletIndex:
         t = triplets.to(torch.int64)
         self.T = int(t.shape[0])
         self.num_entities, self.num_rels = int(num_entities), int(num_rels)
-        if locality is None:       # two more sorts per index: worth it once the embedding table outgrows an XCD's L2
-            locality = self.num_entities * 800 >= (4 << 20)
+        if locality is None:       # extra sorts per index: for a batch that is used many times (not rebuilt every step)
+            locality = not sync_free and self.num_entities * 800 >= (4 << 20)
         self.trip32 = t.to(torch.int32).contiguous()
         s, r, o = t[:, 0], t[:, 1], t[:, 2]
         ent = torch.cat([s, o])
@@ -326,8 +326,9 @@ class TripletIndex:
         self.inc_other = other[perm].to(torch.int32).contiguous()
         self.inc_rel = rel2[perm].to(torch.int32).contiguous()
         self.inc_tid = tid[perm].to(torch.int32).contiguous()
-        inv_inc = torch.empty_like(perm)
-        inv_inc[perm] = torch.arange(2 * self.T, device=t.device)
+        if locality:
+            inv_inc = torch.empty_like(perm)
+            inv_inc[perm] = torch.arange(2 * self.T, device=t.device)
         self.inc = build_segment_items(_rowptr_from_sorted(ent[perm], self.num_entities), chunk,
                                        2 * self.T if sync_free else None)
         # DistMult forward walks the triplets in subject order (XCD windows of the embedding table, see k_distmult_bce);
@@ -337,10 +338,12 @@ class TripletIndex:
         self.rel_s = s[perm_r].to(torch.int32).contiguous()
         self.rel_o = o[perm_r].to(torch.int32).contiguous()
         self.rel_tid = perm_r.to(torch.int32).contiguous()
-        inv_rel = torch.empty_like(perm_r)
-        inv_rel[perm_r] = torch.arange(self.T, device=t.device)
-        # where triplet t sits in the two backward orders (gv_bce_grad scatters dL/dscore there: no coef_idx indirection)
-        self.pos3 = torch.stack([inv_inc[:self.T], inv_inc[self.T:], inv_rel], dim=1).to(torch.int32).contiguous()
+        self.pos3 = None
+        if locality:
+            inv_rel = torch.empty_like(perm_r)
+            inv_rel[perm_r] = torch.arange(self.T, device=t.device)
+            # where triplet t sits in the two backward orders (gv_bce_grad scatters dL/dscore there: no coef_idx indirection)
+            self.pos3 = torch.stack([inv_inc[:self.T], inv_inc[self.T:], inv_rel], dim=1).to(torch.int32).contiguous()
         self.rel = build_segment_items(_rowptr_from_sorted(r[perm_r], self.num_rels), chunk_rel,
                                        self.T if sync_free else None)
         if locality and self.T >= 65536:
@@ -752,13 +755,16 @@ class _RelGraphConvBdd(torch.autograd.Function):
                 w_bwd = ctx.w_bwd_packed
             else:
                 w_bwd = pack_weight(weight, nb, so, si, True) if pk else weight
-            coef_s = None if coef is None else gidx.coef_in_src_order(coef)
-            grad_x = bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, coef_s, None, g_agg,
+            # static graphs: the edge norm is cached in this launch's order; per-batch graphs read it through the index
+            static = not gidx.sync_free and coef is not None
+            coef_s, idx_s = (gidx.coef_in_src_order(coef), None) if static else (coef, gidx.by_src.perm)
+            grad_x = bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, coef_s, idx_s, g_agg,
                                    w_bwd, nb, so, si, True, gx_loop, packed=pk)
         grad_w = None
         if ctx.needs_input_grad[1]:
-            coef_r = None if coef is None else ridx.coef_in_rel_order(coef)
-            grad_w = bdd_grad_weight(ridx.by_rel.seg, ridx.src_by_rel, ridx.dst_by_rel, coef_r, None, x,
+            static = not gidx.sync_free and coef is not None
+            coef_r, idx_r = (ridx.coef_in_rel_order(coef), None) if static else (coef, ridx.by_rel.perm)
+            grad_w = bdd_grad_weight(ridx.by_rel.seg, ridx.src_by_rel, ridx.dst_by_rel, coef_r, idx_r, x,
                                      g_agg, nb, si, so, out=d_w, accumulate=d_w is not None)
             if d_w is not None:
                 grad_w = None
@@ -1246,14 +1252,18 @@ class _LossHead(torch.autograd.Function):
                 lib.call('gv_mmd_bwd', ptr(z_pri), ptr(z), ptr(pick), z_pri.shape[0], pick.numel(), h, ptr(g), mmd_w,
                          ptr(g_pri), ptr(gz), s1)
         # main: dL/dscore, then the relation-side gradient (does not need gz)
-        d_inc, d_rel = torch.empty(2 * T, **f32), torch.empty(T, **f32)       # dL/dscore in the two launches' own orders
-        lib.call('gv_bce_grad', ptr(score), ptr(labels), ptr(g), ptr(dscore), ptr(tidx.pos3), ptr(d_inc), ptr(d_rel),
+        if tidx.pos3 is not None:      # dL/dscore also lands in the two launches' own orders
+            d_inc, d_rel, idx_inc, idx_rel = torch.empty(2 * T, **f32), torch.empty(T, **f32), None, None
+        else:
+            d_inc, d_rel, idx_inc, idx_rel = dscore, dscore, tidx.inc_tid, tidx.rel_tid
+        lib.call('gv_bce_grad', ptr(score), ptr(labels), ptr(g), ptr(dscore), ptr(tidx.pos3),
+                 ptr(d_inc) if tidx.pos3 is not None else None, ptr(d_rel) if tidx.pos3 is not None else None,
                  ptr(dbias), ptr(ws), T, st)
-        bdd_grad_weight(tidx.rel, tidx.rel_s, tidx.rel_o, d_rel, None, z, z, h, 1, 1, out=g_w,
+        bdd_grad_weight(tidx.rel, tidx.rel_s, tidx.rel_o, d_rel, idx_rel, z, z, h, 1, 1, out=g_w,
                         accumulate=d_w is not None)
         lib.call('gv_axpby', w_rel.numel(), ptr(g), 2.0 * reg_w / w_rel.numel(), ptr(w_rel), 1.0, ptr(g_w), st)
         join(1)
-        g_z = bdd_aggregate(tidx.inc, tidx.inc_other, tidx.inc_rel, d_inc, None, z, w_rel, h, 1, 1,
+        g_z = bdd_aggregate(tidx.inc, tidx.inc_other, tidx.inc_rel, d_inc, idx_inc, z, w_rel, h, 1, 1,
                             addend=gz)
         if g_flp is not None:
             lib.call('gv_lincomb4', ptr(dbias) if has_bias else None, 1.0, ptr(g) if flp_in_kl else None, kl_w, None, 0.0,

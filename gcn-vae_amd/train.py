@@ -45,8 +45,10 @@ class LinkPredict(nn.Module):
         """Index of a triplet batch for the DistMult backward; cached per (storage, version)."""
         key = (triplets.data_ptr(), triplets._version, tuple(triplets.shape), embedding.shape[0])
         if key != self._tidx_key:
+            # a batch that is scored once (mini-batch training) gets the sync-free index; one that is reused every step
+            # (full-graph training: set ``static_batch``) gets the exact, locality-ordered one
             self._tidx = ops.TripletIndex(triplets.to(embedding.device), embedding.shape[0], self.w_relation.shape[0],
-                                          sync_free=True)
+                                          sync_free=not getattr(self, 'static_batch', False))
             self._tidx_key = key
             self._tidx_keepalive = triplets
         return self._tidx
