@@ -66,6 +66,10 @@ class KGVAE(nn.Module):
         # prior rows ride along in forward() as extra rows of the same GEMMs instead of ~150 tiny launches of their own.
         self.batch_mmd_prior_with_forward = False
         self._z_pri_flowed = None
+        # multi-GPU destination-row partition (distributed.RowPartition): this rank computes its own row block only;
+        # forward() then takes the rank's distributed.RowBlockGraph and the node ids of ALL positions, and returns the
+        # all-gathered z of all positions (padding rows zero).  None = the whole graph on this device.
+        self.row_part = None
 
     def build_iaf(self):
         blocks = []
@@ -146,6 +150,9 @@ class KGVAE(nn.Module):
                     z_pri, _ = flow.forward(z_pri)
         if self.mmd_index_override is not None:
             pick = self.mmd_index_override
+        elif self.row_part is not None and getattr(self.row_part, 'real_positions', None) is not None:
+            real = self.row_part.real_positions        # row partition: z holds all positions, some are padding
+            pick = torch.as_tensor(real[random.sample(range(len(real)), num_sample)], device=z.device)
         else:   # (Monte Carlo) posterior rows, python RNG as in the reference
             pick = torch.tensor(random.sample(range(z.shape[0]), num_sample), device=z.device)
         return z_pri, pick
@@ -157,8 +164,30 @@ class KGVAE(nn.Module):
     def get_flow_log_prob(self):
         return self.flow_log_prob
 
+    def _forward_rows(self, g, h, r, norm):
+        """forward() under the destination-row partition: embedding lookup of all positions (replicated), layer 1 on the
+        rank's rows, all-gather, layer 2 on the rank's rows, reparameterisation of the rank's rows, all-gather of z."""
+        from .distributed import AllGatherRows
+        part = self.row_part
+        if self.n_flows > 0:
+            raise NotImplementedError('the row partition runs the flow-free encoder (n_flows = 0)')
+        c = part.own_rows
+        x0 = self.input_layer(g, h, r, norm)                                   # (total_rows, h)
+        eps = self._draw_noise(c, x0.device)
+        if eps.shape[0] != c:          # parity overrides are given for all positions: take the rank's rows
+            eps = eps[part.row0:part.row0 + c].contiguous()
+        h1 = self.rconv_layer_1.forward_rows(g, x0, r, norm, part, gather_input=False, pad_output=True)
+        h2 = self.rconv_layer_2.forward_rows(g, h1, r, norm, part, gather_input=True, pad_output=False)
+        z, self.z_mean, self.z_sigma = ops.reparam(h2, eps)
+        self.z_own = z
+        self.flow_log_prob = None
+        self._z_pri_flowed = None
+        return AllGatherRows.apply(ops.pad_rows(z, part.slot_rows), part)
+
     def forward(self, g, h, r, norm):
         self.node_id = h.squeeze()
+        if self.row_part is not None:
+            return self._forward_rows(g, h, r, norm)
         h = self.input_layer(g, h, r, norm)
         eps = self._draw_noise(h.shape[0], h.device)
         h = self.rconv_layer_1(g, h, r, norm)

@@ -86,6 +86,24 @@ class RelGraphConv(nn.Module):
         """The RNG job that fills ``keep`` (uint8, (N, out_feat)) with this layer's Bernoulli(1 - p) decisions."""
         return (keep, ops.RNG_KEEP_MASK, float(self.dropout.p), self.rng_stream)
 
+    def forward_rows(self, g, x, etypes, norm, part, gather_input, pad_output):
+        """The layer on ONE rank's row block of the multi-GPU destination-row partition (ops.rel_graph_conv_rows):
+        ``g`` is the rank's distributed.RowBlockGraph, ``x`` the full table (gather_input False) or the rank's slot."""
+        if self.regularizer != 'bdd':
+            raise NotImplementedError('the row partition covers the bdd regulariser (the reference encoders use only it)')
+        gidx = graph_index_of(g, x.device)
+        ridx = gidx.relation_index(etypes, self.num_rels)
+        act_id, post_act = _activation_id(self.activation if self.activation else None)
+        if post_act is not None:
+            raise NotImplementedError('row partition: activation must be None or ReLU')
+        c = part.own_rows
+        keep, scale = self._keep_mask(c, x.device)
+        if keep is not None and keep.shape[0] != c:       # parity override given for all positions
+            keep = keep[part.row0:part.row0 + c].contiguous()
+        return ops.rel_graph_conv_rows(x, self.weight, self.h_bias if self.bias else None,
+                                       self.loop_weight if self.self_loop else None, norm, gidx, ridx, self.num_bases,
+                                       part, act_id, keep, scale if keep is not None else 1.0, gather_input, pad_output)
+
     def forward(self, g, x, etypes, norm=None):
         if x.dtype == torch.int64 and x.dim() == 1:
             if self.regularizer == 'bdd':

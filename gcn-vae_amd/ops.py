@@ -163,12 +163,15 @@ class GraphIndex:
     """
 
     def __init__(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: int, chunk: int = DEFAULT_CHUNK,
-                 dst_sorted: Optional[bool] = None, sync_free: bool = False):
+                 dst_sorted: Optional[bool] = None, sync_free: bool = False, num_src_nodes: Optional[int] = None):
         """``dst_sorted``: None = check (one host synchronisation), True = the caller guarantees dst is non-decreasing.
-        ``sync_free``: size the work-item lists by upper bounds instead of reading their totals back (per-batch graphs)."""
+        ``sync_free``: size the work-item lists by upper bounds instead of reading their totals back (per-batch graphs).
+        ``num_src_nodes``: a RECTANGULAR graph -- destinations index ``num_nodes`` rows (a rank's own row block of the
+        multi-GPU destination-row partition), sources index a table of ``num_src_nodes`` rows (all nodes)."""
         if not src.is_cuda:
             raise RuntimeError('GraphIndex needs CUDA index tensors; there is no CPU fallback')
         self.num_nodes, self.num_edges = int(num_nodes), int(src.numel())
+        self.num_src_nodes = self.num_nodes if num_src_nodes is None else int(num_src_nodes)
         self.device = src.device
         self.sync_free = bool(sync_free)
         ne = self.num_edges if sync_free else None
@@ -189,7 +192,7 @@ class GraphIndex:
         perm_s = torch.sort(src, stable=True)[1]
         self.nbr_by_src = dst[perm_s].to(torch.int32).contiguous()
         self.by_src = EdgeOrder(perm_s.to(torch.int32),
-                                build_segment_items(_rowptr_from_sorted(src[perm_s], self.num_nodes), chunk, ne))
+                                build_segment_items(_rowptr_from_sorted(src[perm_s], self.num_src_nodes), chunk, ne))
         self._rel_cache = {}
         self._chunk_cache = {}
 
@@ -777,6 +780,190 @@ def rel_graph_conv_bdd(x, weight, h_bias, loop_weight, norm, gidx, ridx, num_bas
                                   float(keep_scale), reduce_hook)
 
 
+class _RelGraphConvRows(torch.autograd.Function):
+    """The same layer for the multi-GPU DESTINATION-ROW partition ("cheaper alternative"): this rank owns
+    ``part.own_rows`` rows of the node table and every edge that ends in them, so it computes FINAL output rows -- no
+    reduction of partial aggregates.  ``gidx`` is rectangular: destinations are local row ids, sources index the whole
+    table (``part.total_rows`` rows = world x slot rows; a rank's real rows come first in its slot, the tail is zero).
+
+      gather_input   x is this rank's slot (slot_rows, in): ALL-GATHER it into the full table, under the self-loop
+                     GEMM of the rank's own rows and the weight packing; backward REDUCE-SCATTERs the partial gradient
+                     of the full table (K1^T over the rank's edges), under the loop-weight products and grad-W
+      otherwise      x already is the full table (replicated embedding lookup); backward returns this rank's partial
+                     gradient of all its rows (summed later by the parameter-gradient all-reduce)
+      pad_output     return a (slot_rows, out) tensor with a zero tail, ready to be gathered by the next layer
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, h_bias, loop_weight, norm, gidx, ridx, num_bases, act, keep, keep_scale, part,
+                gather_input, pad_output):
+        x, _ = _row_major(x, 'x')
+        c, slot, row0, total = part.own_rows, part.slot_rows, part.row0, part.total_rows
+        in_feat = x.shape[1]
+        si = in_feat // num_bases
+        so = weight.shape[1] // (num_bases * si)
+        out_feat = num_bases * so
+        if gidx.num_nodes != c or gidx.num_src_nodes != total:
+            raise ValueError(f'row-partition graph index is {gidx.num_nodes} x {gidx.num_src_nodes}, expected {c} x {total}')
+        if x.shape[0] != (slot if gather_input else total):
+            raise ValueError(f'x has {x.shape[0]} rows, expected {slot if gather_input else total}')
+        coef = None if norm is None else norm.reshape(-1)
+        pending = None
+        if gather_input:
+            x_full = torch.empty(total, in_feat, dtype=torch.float32, device=x.device)
+            pending = part.all_gather(x_full, x)
+            x_own = x[:c]
+        else:
+            x_full, x_own = x, x[row0:row0 + c]
+        pk = si * so >= 8 and pack_supported(num_bases, si, so, False)
+        pk_bwd = si * so >= 8 and pack_supported(num_bases, so, si, True)
+        ctx.w_bwd_packed = None
+        if pk and pk_bwd:
+            w_fwd, ctx.w_bwd_packed = torch.empty_like(weight), torch.empty_like(weight)
+            lib.call('gv_rgcn_bdd_pack_weight_pair', ptr(weight), weight.shape[0], num_bases, si, so, ptr(w_fwd),
+                     ptr(ctx.w_bwd_packed), lib.stream())
+        else:
+            w_fwd = pack_weight(weight, num_bases, si, so, False) if pk else weight
+        addend = None
+        if c > 0:
+            if loop_weight is not None:
+                addend = gemm(x_own, loop_weight, bias=h_bias)
+            elif h_bias is not None:
+                addend = h_bias.unsqueeze(0).expand(c, out_feat).contiguous()
+        buf = torch.empty(slot if pad_output else c, out_feat, dtype=torch.float32, device=x.device)
+        if pad_output and c < slot:
+            buf[c:].zero_()
+        if pending is not None:
+            pending.wait()
+        out = buf[:c]
+        if c > 0:
+            bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x_full, w_fwd, num_bases,
+                          si, so, False, addend, act, keep, keep_scale, out=out, packed=pk)
+        ctx.save_for_backward(x_full, weight, loop_weight, coef, out if act == ACT_RELU else None, keep)
+        ctx.meta = (gidx, ridx, num_bases, si, so, act, keep_scale, h_bias is not None, part, gather_input)
+        ctx.w_version = weight._version
+        ctx.direct = (_direct(weight), _direct(h_bias), _direct(loop_weight))
+        return buf
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x_full, weight, loop_weight, coef, out, keep = ctx.saved_tensors
+        gidx, ridx, nb, si, so, act, keep_scale, has_bias, part, gather_input = ctx.meta
+        c, slot, row0, total = part.own_rows, part.slot_rows, part.row0, part.total_rows
+        d_w, d_b, d_l = ctx.direct
+        dev, in_feat = x_full.device, x_full.shape[1]
+        grad_out = grad_out[:c]
+        x_own = x_full[row0:row0 + c]
+        grad_bias = grad_loop = grad_w = None
+        if c == 0:           # a rank without rows: contributes zeros to the exchange
+            gfull = torch.zeros(total, in_feat, dtype=torch.float32, device=dev)
+            if gather_input:
+                own = torch.empty(slot, in_feat, dtype=torch.float32, device=dev)
+                part.reduce_scatter(own, gfull).wait()
+                return (own,) + (None,) * 13
+            return (gfull,) + (None,) * 13
+        if has_bias and ctx.needs_input_grad[2]:
+            grad_bias = d_b if d_b is not None else torch.empty(grad_out.shape[1], dtype=torch.float32, device=dev)
+            g = epilogue_bwd(out, grad_out, act, keep, keep_scale, colsum_out=grad_bias, colsum_accumulate=d_b is not None)
+            if d_b is not None:
+                grad_bias = None
+        else:
+            g = epilogue_bwd(out, grad_out, act, keep, keep_scale)
+        # K1^T first: its exchange then runs under the loop-weight products and the relation-weight gradient
+        grad_x = pending = None
+        if ctx.needs_input_grad[0]:
+            pk = si * so >= 8 and pack_supported(nb, so, si, True)
+            if ctx.w_bwd_packed is not None and weight._version == ctx.w_version:
+                w_bwd = ctx.w_bwd_packed
+            else:
+                w_bwd = pack_weight(weight, nb, so, si, True) if pk else weight
+            static = not gidx.sync_free and coef is not None
+            coef_s, idx_s = (gidx.coef_in_src_order(coef), None) if static else (coef, gidx.by_src.perm)
+            gfull = bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, coef_s, idx_s, g, w_bwd, nb, so, si,
+                                  True, None, packed=pk)                      # (total, in): this rank's partial sums
+            if gather_input:
+                grad_x = torch.empty(slot, in_feat, dtype=torch.float32, device=dev)
+                pending = part.reduce_scatter(grad_x, gfull)
+            else:
+                grad_x = gfull
+        gx_loop = None
+        if loop_weight is not None:
+            if ctx.needs_input_grad[3]:
+                grad_loop = gemm(x_own, g, trans_a=True, split_k=pick_split_k(in_feat, g.shape[1], c), out=d_l,
+                                 accumulate=d_l is not None)
+                if d_l is not None:
+                    grad_loop = None
+            if ctx.needs_input_grad[0]:
+                gx_loop = gemm(g, loop_weight, trans_b=True)
+        if ctx.needs_input_grad[1]:
+            static = not gidx.sync_free and coef is not None
+            coef_r, idx_r = (ridx.coef_in_rel_order(coef), None) if static else (coef, ridx.by_rel.perm)
+            grad_w = bdd_grad_weight(ridx.by_rel.seg, ridx.src_by_rel, ridx.dst_by_rel, coef_r, idx_r, x_full, g, nb, si,
+                                     so, out=d_w, accumulate=d_w is not None)
+            if d_w is not None:
+                grad_w = None
+        if pending is not None:
+            pending.wait()
+        if gx_loop is not None:       # the self-loop term only touches the rank's own rows
+            own = grad_x[:c] if gather_input else grad_x[row0:row0 + c]
+            lib.call('gv_axpby', own.numel(), None, 1.0, ptr(gx_loop), 1.0, ptr(own), lib.stream())
+        return (grad_x, grad_w, grad_bias, grad_loop) + (None,) * 10
+
+
+def rel_graph_conv_rows(x, weight, h_bias, loop_weight, norm, gidx, ridx, num_bases, part, act=ACT_NONE, keep=None,
+                        keep_scale=1.0, gather_input=True, pad_output=False):
+    return _RelGraphConvRows.apply(x, weight, h_bias, loop_weight, norm, gidx, ridx, num_bases, act, keep,
+                                   float(keep_scale), part, bool(gather_input), bool(pad_output))
+
+
+class _PadRows(torch.autograd.Function):
+    """(c, h) -> (rows, h) with a zero tail (a rank's slot of the row partition); backward returns the first c rows."""
+
+    @staticmethod
+    def forward(ctx, x, rows):
+        ctx.c = x.shape[0]
+        out = torch.empty(rows, x.shape[1], dtype=x.dtype, device=x.device)
+        out[:ctx.c].copy_(x)
+        if rows > ctx.c:
+            out[ctx.c:].zero_()
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:ctx.c], None
+
+
+def pad_rows(x, rows):
+    return x if x.shape[0] == rows else _PadRows.apply(x, rows)
+
+
+class _LinComb2(torch.autograd.Function):
+    """wa*a + wb*b on device scalars (b may be None): the rank-local share of the loss in the row partition."""
+
+    @staticmethod
+    def forward(ctx, a, wa, b, wb):
+        ctx.w = (float(wa), float(wb), b is not None)
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        lib.call('gv_lincomb4', ptr(a), float(wa), ptr(b), float(wb), None, 0.0, None, 0.0, ptr(out), lib.stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        wa, wb, has_b = ctx.w
+        g = _chk(g.reshape(1).contiguous(), name='g')
+        ga = torch.empty((), dtype=torch.float32, device=g.device)
+        lib.call('gv_lincomb4', ptr(g), wa, None, 0.0, None, 0.0, None, 0.0, ptr(ga), lib.stream())
+        gb = None
+        if has_b:
+            gb = torch.empty((), dtype=torch.float32, device=g.device)
+            lib.call('gv_lincomb4', ptr(g), wb, None, 0.0, None, 0.0, None, 0.0, ptr(gb), lib.stream())
+        return ga, None, gb, None
+
+
+def lincomb2(a, wa, b=None, wb=0.0):
+    return _LinComb2.apply(a, wa, b, wb)
+
+
 class _Linear(torch.autograd.Function):
     """y = act(x @ W^T + b) with W (out, in) -- torch's F.linear layout (MaskedLinear, flow_network.py:14-15)."""
 
@@ -1159,7 +1346,8 @@ class _LossHead(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, reg_w, kl_w, mmd_w, score_bias):
+    def forward(ctx, z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, reg_w, kl_w, mmd_w, score_bias,
+                embed_rows=None):
         z, ld_z = _row_major(z, 'embed')
         w_rel, ld_w = _row_major(w_rel, 'w_relation')
         labels = _chk(labels.reshape(-1), name='labels')
@@ -1194,7 +1382,10 @@ class _LossHead(torch.autograd.Function):
                      n, h, k, st)
         if mmd_w > 0:      # the posterior sample set is rows `pick` of z, read in place
             lib.call('gv_mmd_fwd', ptr(z_pri), ptr(z), ptr(pick), z_pri.shape[0], pick.numel(), h, None, ptr(wsm), st)
-        lib.call('gv_mean_sq2', ptr(z), z.numel(), 1.0 / z.numel(), ptr(w_rel), w_rel.numel(), 1.0 / w_rel.numel(), None,
+        # embed_rows: the regulariser's mean runs over that many rows (the rest of z are all-zero padding rows of the
+        # multi-GPU row partition)
+        z_count = z.numel() if embed_rows is None else int(embed_rows) * h
+        lib.call('gv_mean_sq2', ptr(z), z.numel(), 1.0 / z_count, ptr(w_rel), w_rel.numel(), 1.0 / w_rel.numel(), None,
                  ptr(ws2), st)
         # DistMult scorer + BCE (three 800-B row gathers per triplet: the bandwidth-bound part)
         lib.call('gv_distmult_bce_fwd', ptr(z), ld_z, ptr(w_rel), ld_w, ptr(tidx.trip32), ptr(tidx.fwd_order), ptr(labels),
@@ -1207,6 +1398,7 @@ class _LossHead(torch.autograd.Function):
                               z_pre if kl_w > 0 else None, resp, z_pri if mmd_w > 0 else None, z_post,
                               pick if mmd_w > 0 else None, labels, score, wsk)
         ctx.meta = (tidx, float(reg_w), float(kl_w), float(mmd_w), bias is not None, flp is not None and kl_w > 0)
+        ctx.z_count = z_count
         ctx.direct_w = _direct(w_rel) if ld_w == h else None
         out_pred, out_kl, out_mmd = pred.reshape(()), kl.reshape(1), mmd.reshape(())
         ctx.mark_non_differentiable(out_pred, out_kl, out_mmd)
@@ -1215,8 +1407,9 @@ class _LossHead(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gp, _gk, _gm):
         if g is None:
-            return (None,) * 14
+            return (None,) * 15
         z, z_mean, z_sigma, w_rel, z_pre, resp, z_pri, z_post, pick, labels, score, wsk = ctx.saved_tensors
+        z_count = ctx.z_count
         tidx, reg_w, kl_w, mmd_w, has_bias, flp_in_kl = ctx.meta
         dev, (n, h), T = z.device, z.shape, tidx.T
         f32 = dict(dtype=torch.float32, device=dev)
@@ -1244,10 +1437,10 @@ class _LossHead(torch.autograd.Function):
             if kl_w > 0:
                 # the embedding regulariser's gradient g * (2 reg_w / numel) * z rides on the same pass over z
                 lib.call('gv_kl_bwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(resp), ptr(g), kl_w,
-                         2.0 * reg_w / z.numel(), ptr(gz), ptr(gm), ptr(gv), ptr(gzp), 1 if d_zp is not None else 0, ptr(wsk),
+                         2.0 * reg_w / z_count, ptr(gz), ptr(gm), ptr(gv), ptr(gzp), 1 if d_zp is not None else 0, ptr(wsk),
                          1, n, h, k, s1)
             else:
-                lib.call('gv_axpby', z.numel(), ptr(g), 2.0 * reg_w / z.numel(), ptr(z), 0.0, ptr(gz), s1)
+                lib.call('gv_axpby', z.numel(), ptr(g), 2.0 * reg_w / z_count, ptr(z), 0.0, ptr(gz), s1)
             if mmd_w > 0:      # MMD backward: prior rows -> g_pri, posterior rows ADDED into rows `pick` of gz (now complete)
                 lib.call('gv_mmd_bwd', ptr(z_pri), ptr(z), ptr(pick), z_pri.shape[0], pick.numel(), h, ptr(g), mmd_w,
                          ptr(g_pri), ptr(gz), s1)
@@ -1269,12 +1462,13 @@ class _LossHead(torch.autograd.Function):
             lib.call('gv_lincomb4', ptr(dbias) if has_bias else None, 1.0, ptr(g) if flp_in_kl else None, kl_w, None, 0.0,
                      None, 0.0, ptr(g_flp), st)
         return (g_z, gm, gv, (None if d_w is not None else g_w), (None if d_zp is not None else gzp), g_flp, g_pri, None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
-def loss_head(z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, reg_w, kl_w, mmd_w, score_bias):
+def loss_head(z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, reg_w, kl_w, mmd_w, score_bias,
+              embed_rows=None):
     return _LossHead.apply(z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, float(reg_w), float(kl_w),
-                           float(mmd_w), bool(score_bias))
+                           float(mmd_w), bool(score_bias), embed_rows)
 
 
 class _MADEForward(torch.autograd.Function):

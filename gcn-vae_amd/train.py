@@ -73,6 +73,9 @@ class LinkPredict(nn.Module):
         kl_w = self.kl_param if vae else 0.0
         mmd_w = self.mmd_param if vae else 0.0
         z_pri, pick = enc.mmd_inputs(embed) if mmd_w > 0 else (None, None)
+        part = getattr(enc, 'row_part', None) if vae else None
+        if part is not None:
+            return self._get_loss_rows(part, embed, tidx, flp, kl_w, mmd_w, z_pri, pick, labels)
         loss, predict_loss, kl, mmd = ops.loss_head(
             embed, enc.z_mean if kl_w > 0 else None, enc.z_sigma if kl_w > 0 else None, self.w_relation,
             enc.z_pre.squeeze(0) if kl_w > 0 else None, flp, z_pri, pick, labels, tidx, self.reg_param, kl_w, mmd_w,
@@ -83,6 +86,29 @@ class LinkPredict(nn.Module):
         if kl_w <= 0 or mmd_w <= 0:
             loss = loss.reshape(1)
         return loss, predict_loss, kl, mmd
+
+
+def _get_loss_rows(self, part, embed, tidx, flp, kl_w, mmd_w, z_pri, pick, labels):
+    """get_loss under the destination-row partition.  ``embed`` is z of ALL positions; the decoder, the regulariser
+    and MMD run on it (on this rank's triplets / draws), KL on the rank's own rows.  Returns the rank's SHARE of
+
+        L = mean_p(pred_p + mmd_w mmd_p) + reg_w reg + kl_w KL     (the sum of the shares over the ranks is L)
+
+    so that plain SUMS of the ranks' gradients (reduce-scatter of dL/dz, all-reduce of the parameter arena) are exact."""
+    enc = self.encoder
+    head, predict_loss, _, mmd = ops.loss_head(embed, None, None, self.w_relation, None, flp, z_pri, pick, labels, tidx,
+                                               self.reg_param, 0.0, mmd_w, score_bias=self.n_flows > 0,
+                                               embed_rows=part.real_rows)
+    kl = None
+    if kl_w > 0 and part.own_rows > 0:
+        kl = ops.kl_to_mixture(enc.z_own, enc.z_mean, enc.z_sigma, enc.z_pre.squeeze(0), flp)   # mean over own rows
+    loss = ops.lincomb2(head, 1.0 / part.world, kl, kl_w * part.own_rows / max(part.real_rows, 1))
+    kl_share = (kl.detach() * (part.own_rows / max(part.real_rows, 1))).reshape(()) if kl is not None \
+        else torch.zeros(1, device=embed.device)
+    return loss, predict_loss, kl_share, (mmd.reshape(()) if mmd_w > 0 else mmd.reshape(1))
+
+
+LinkPredict._get_loss_rows = _get_loss_rows
 
 
 def _sync():

@@ -71,3 +71,23 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     d = json.loads(line)
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['launch'] == 'eager'
     assert d['value'] > 0 and d['final_loss'] == d['final_loss']
+
+
+def test_row_partition_single_rank_equals_whole_graph_run():
+    """world 1: the destination-row path (rectangular index, ops.rel_graph_conv_rows, the loss shares) with local copies
+    in place of the collectives equals the ordinary single-GPU path."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'workers', 'dist_rows_worker.py')], cwd=ROOT,
+                         env=dict(os.environ, WORLD_SIZE='1'), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:] + '\n' + out.stderr[-2500:])
+    assert out.stdout.count('worst rel err') == 1, out.stdout[-1500:]
+
+
+def test_two_ranks_row_partition_equals_single_process():
+    """world_size 2 on ONE GPU (gloo): every rank owns a block of node rows and the edges ending in them; all-gather of
+    layer-1 rows and of z, reduce-scatter of their gradients, summed parameter gradients == the single-process run."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'tests', 'workers', 'dist_rows_worker.py')]
+    out = run_ranks(cmd, env, 600)
+    assert out.returncode == 0, (out.stdout[-1500:] + '\n' + out.stderr[-2500:])
+    assert out.stdout.count('worst rel err') == 2, out.stdout[-1500:]
