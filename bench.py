@@ -48,10 +48,18 @@ def parse():
     p.add_argument('--dropout', type=float, default=0.2)
     p.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     p.add_argument('--graph-collectives', action='store_true',
-                   help='world size > 1: capture the RCCL all-reduces in the hipGraph too (default there: eager launches)')
+                   help='world size > 1: capture the RCCL collectives inside ONE hipGraph (default there: a chain of '
+                        'hipGraph segments with the collectives launched eagerly between them)')
+    p.add_argument('--no-segments', action='store_true',
+                   help='world size > 1: launch every kernel eagerly instead of replaying hipGraph segments')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU-oracle baseline leg')
     p.add_argument('--force-dist', action='store_true', help='run the RCCL code path even at world size 1 (testing)')
+    p.add_argument('--partition', choices=['auto', 'edge', 'row'], default='auto',
+                   help='world size > 1: "edge" = edge-block sharding + all-reduce of node embeddings (north_star), "row" = '
+                        'destination-row partition + all-gather / reduce-scatter (SURVEY 8e alternative), "auto" = time '
+                        '--probe-steps steps of each during warm-up and run the faster one')
+    p.add_argument('--probe-steps', type=int, default=10)
     p.add_argument('--profile-steps', type=int, default=3, help='instrumented eager steps for the roofline figure')
     return p.parse_args()
 
@@ -76,6 +84,34 @@ def make_workload(rank, world, args, dev):
     return dict(data=data, g=g, src=src, dst=dst, rel=torch.from_numpy(rel), enorm=enorm,
                 node_id=torch.arange(data.num_nodes, dtype=torch.long).view(-1, 1),
                 samples=torch.from_numpy(samples), labels=torch.from_numpy(labels))
+
+
+def make_workload_rows(rank, world, args, dev, own):
+    """Destination-row partition of the SAME union graph: the union of all ranks' edge blocks (seed = 0..world-1) is cut
+    by destination row; this rank keeps the edges that end in its rows.  Triplets are the rank's own (as in the edge-block
+    workload ``own``), relabelled to row positions."""
+    from gcn_vae_amd import distributed as gdist
+    from gcn_vae_amd.data import FB15K237, synthetic_kg
+    cfg = FB15K237
+    n, n_rel = cfg['num_nodes'], cfg['num_rels']
+    src, dst, rel = [], [], []
+    for r in range(world):        # every rank regenerates all blocks (cheap) instead of exchanging edge lists
+        t = own['data'].train if r == rank else synthetic_kg(n, n_rel, cfg['n_train'], seed=r).train
+        s_, r_, o_ = (torch.from_numpy(np.ascontiguousarray(t[:, i])) for i in range(3))
+        src += [s_, o_]
+        dst += [o_, s_]
+        rel += [r_, r_ + n_rel]          # reverse edges carry relation id + num_rels (kgvae/utils.py:135-150)
+    src, dst, rel = (torch.cat(x).to(dev) for x in (src, dst, rel))
+    deg = torch.bincount(dst, minlength=n)
+    norm = torch.where(deg > 0, 1.0 / deg.clamp(min=1).float(), torch.zeros(n, device=dev))
+    part = gdist.make_row_partition(deg.cpu().numpy(), world, rank)
+    g, etype, enorm = gdist.build_row_block(part, part.pos_of_node, src, dst, rel, norm, dev)
+    pos = torch.from_numpy(part.pos_of_node).to(dev)
+    trip = own['samples'].to(dev)
+    samples = torch.stack([pos[trip[:, 0]], trip[:, 1], pos[trip[:, 2]]], 1).contiguous()
+    node_id = torch.from_numpy(np.maximum(part.node_of_pos, 0)).to(dev).view(-1, 1)
+    return dict(part=part, g=g, rel=etype, enorm=enorm, node_id=node_id, samples=samples, labels=own['labels'].to(dev),
+                edges=int(g.number_of_edges()), union_edges=int(src.numel()), pos_of_node=part.pos_of_node)
 
 
 def build_model(w, args):
@@ -190,6 +226,11 @@ def cpu_baseline(w, model, args, budget_s):
 
 def main():
     args = parse()
+    # stdout carries ONE JSON line: libraries that print banners to fd 1 (RCCL prints its version block there when a
+    # communicator is created) write to stderr instead until the result line is printed
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     from gcn_vae_amd import distributed as gdist
     from gcn_vae_amd import lib
     rank, local_rank, world = gdist.env_world()
@@ -229,70 +270,159 @@ def main():
 
     w = make_workload(rank, world, args, dev)
     model = build_model(w, args).to(dev).train()
-    g = w['g']
-    node_id, etype = w['node_id'].to(dev), w['rel'].to(dev)
-    enorm, samples, labels = w['enorm'], w['samples'].to(dev), w['labels'].to(dev)
-    n_nodes, E, T = w['data'].num_nodes, int(w['src'].numel()), int(samples.shape[0])
+    n_nodes, E = w['data'].num_nodes, int(w['src'].numel())
     model.static_batch = True      # the same triplets every step: build their index once, exact and locality-ordered
     params = [p for p in model.parameters() if p.requires_grad]
     # One GPU: the step is replayed as a hipGraph.  With RCCL collectives in the step (world > 1) the default is eager
     # launching -- measured equal to graph replay on one GPU (the step is GPU-bound: ~55 launches of 5-130 us against
     # ~15 us of host work each), and it keeps RCCL out of stream capture, which only a 1-rank group could verify here.
-    use_graph = not args.no_graph and (world == 1 or args.graph_collectives)
+    use_graph = not args.no_graph and ((world == 1 and not args.force_dist) or args.graph_collectives)
+    use_segments = dist_on and not use_graph and not args.no_graph and not args.no_segments
     from gcn_vae_amd.optim import FlatAdam
     opt = FlatAdam(params, lr=1e-3, max_grad_norm=1.0)      # clip_grad_norm_(1.0) + Adam over one flat arena
-    if dist_on:
-        hook = gdist.make_reduce_hook()
-        model.encoder.rconv_layer_1.reduce_hook = hook
-        model.encoder.rconv_layer_2.reduce_hook = hook
     pick_rng = random.Random(rank)
     post_idx = torch.zeros(200, dtype=torch.long, device=dev)
     model.encoder.mmd_index_override = post_idx          # static buffer: contents refreshed per step on the host
     pinned = torch.zeros(200, dtype=torch.long).pin_memory()
+    one = torch.ones((), device=dev)        # d(loss)/d(loss): handed to backward instead of a ones_like fill per step
+
+    # ---- the two multi-GPU schemes.  Each mode = inputs + how the exchange is wired into the model ----------
+    modes = {}
+    edge_in = dict(g=w['g'], node_id=w['node_id'].to(dev), etype=w['rel'].to(dev), enorm=w['enorm'],
+                   samples=w['samples'].to(dev), labels=w['labels'].to(dev), pick_map=None, seed=0)
+    want = args.partition if dist_on else 'edge'
+    if want in ('edge', 'auto') or not dist_on:
+        modes['edge'] = edge_in
+    if dist_on and want in ('row', 'auto'):
+        wr = make_workload_rows(rank, world, args, dev, w)
+        modes['row'] = dict(g=wr['g'], node_id=wr['node_id'], etype=wr['rel'], enorm=wr['enorm'], samples=wr['samples'],
+                            labels=wr['labels'], pick_map=wr['pos_of_node'], part=wr['part'], seed=1000 + rank,
+                            edges=wr['edges'])
+    hook = gdist.make_reduce_hook() if dist_on else None
+    cur = {}
+
+    def configure(name):
+        m = modes[name]
+        enc = model.encoder
+        enc.row_part = m.get('part')
+        enc.rconv_layer_1.reduce_hook = enc.rconv_layer_2.reduce_hook = hook if (dist_on and name == 'edge') else None
+        # edge-block sharding replicates the node-level work: all ranks must draw the SAME dropout masks / noise;
+        # the row partition draws per-rank noise for its own rows
+        torch.manual_seed(m['seed'])
+        cur.clear()
+        cur.update(m, name=name)
 
     def refresh_host_inputs():
-        pinned.copy_(torch.tensor(pick_rng.sample(range(n_nodes), 200)))
+        ids = pick_rng.sample(range(n_nodes), 200)
+        if cur['pick_map'] is not None:
+            ids = cur['pick_map'][ids]
+        pinned.copy_(torch.as_tensor(ids))
         post_idx.copy_(pinned, non_blocking=True)
-
-    one = torch.ones((), device=dev)        # d(loss)/d(loss): handed to backward instead of a ones_like fill per step
 
     def step_body():
         opt.zero_grad()
-        embed = model(g, node_id, etype, enorm)
-        loss, pred, kl, mmd = model.get_loss(g, embed, samples, labels)
+        embed = model(cur['g'], cur['node_id'], cur['etype'], cur['enorm'])
+        loss, pred, kl, mmd = model.get_loss(cur['g'], embed, cur['samples'], cur['labels'])
         loss.backward(gradient=one)
         if dist_on:
-            gdist.average_flat(opt.flat_g)
+            if cur['name'] == 'row':
+                gdist.sum_flat(opt.flat_g)
+            else:
+                gdist.average_flat(opt.flat_g)
         opt.step()
         return loss
 
-    # ---- build indices + warm up eagerly (side stream, as graph capture wants) -------------------
-    launch = 'eager'
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(2):
+    def warm(k):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(k):
+                refresh_host_inputs()
+                out = step_body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        return out
+
+    # ---- per scheme: build indices + warm up eagerly (side stream, as graph capture wants), capture, and -- "auto" --
+    # time a few steps of the captured program; then run the faster scheme -------------------------------------------
+    def capture_current(segments):
+        """(launch description, replay callable or None, static loss) for the configured scheme."""
+        if segments:
+            from gcn_vae_amd.segments import SegmentedGraph
+            sg, out = SegmentedGraph(), None
+            try:
+                refresh_host_inputs()
+                out = sg.capture(step_body)
+            except Exception as exc:
+                print(f'[bench] segmented capture failed on rank {rank}: {type(exc).__name__}: {exc}; running eagerly',
+                      file=sys.stderr)
+                sg = None
+                torch.cuda.synchronize()
+            if world > 1:      # all ranks must run the same program: one failed capture sends everybody to eager launches
+                ok = torch.tensor([1 if sg is not None else 0], device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    sg = None
+            if sg is not None:
+                return 'hipgraph segments (%s)' % sg.describe(), sg.replay, out
+        elif use_graph:
+            try:
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    out = step_body()
+                return 'hipgraph', gr.replay, out
+            except Exception as exc:      # capture refused (e.g. a collective that cannot be captured): run eagerly
+                print(f'[bench] graph capture failed on rank {rank}: {type(exc).__name__}: {exc}; running eagerly',
+                      file=sys.stderr)
+                torch.cuda.synchronize()
+        return 'eager', None, None
+
+    def timed_run(k, replay):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(k):
             refresh_host_inputs()
-            loss = step_body()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    graph = None
-    if use_graph:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_loss = step_body()
-            launch = 'hipgraph'
-        except Exception as exc:      # capture refused (e.g. a collective that cannot be captured): run eagerly
-            print(f'[bench] graph capture failed on rank {rank}: {type(exc).__name__}: {exc}; running eagerly',
-                  file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
+            out = replay() if replay is not None else step_body()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, out
+
+    # candidates = scheme x launch mode.  With collectives on the step the launch mode is part of the question: segments
+    # remove the per-kernel host cost but add a graph launch per segment; "auto" measures instead of guessing.
+    programs, probe = {}, {}
+    auto = dist_on and args.partition == 'auto'
+    for name in modes:
+        configure(name)
+        warm(2)
+        variants = [use_segments] if not (auto and use_segments) else [True, False]
+        for sgm in variants:
+            key = name if len(variants) == 1 else '%s/%s' % (name, 'segments' if sgm else 'eager')
+            programs[key] = (name,) + capture_current(sgm)
+            if len(modes) * len(variants) > 1:
+                k = max(1, args.probe_steps)
+                timed_run(1, programs[key][2])
+                probe[key] = timed_run(k, programs[key][2])[0] / k * 1e3
+    chosen = min(probe, key=probe.get) if probe else next(iter(programs))   # identical on all ranks (max-reduced times)
+    mode_name, launch, replay, static_loss = programs[chosen]
+    if cur.get('name') != mode_name:
+        configure(mode_name)
+    T = int(cur['samples'].shape[0])
 
     def run_step():
         refresh_host_inputs()
-        if graph is not None:
-            graph.replay()
+        if replay is not None:
+            replay()
             return static_loss
         return step_body()
 
@@ -310,11 +440,21 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    final_loss = float(loss.item())
-    if world > 1:
+    lt = loss.detach().reshape(1).clone()
+    if world > 1:      # edge-block: mean of the ranks' losses; row partition: the ranks hold SHARES of the loss
+        dist.all_reduce(lt)
+        if cur['name'] != 'row':
+            lt /= world
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    final_loss = float(lt.item())
+    edge_counts = None
+    if world > 1 and cur['name'] == 'row':
+        ec = torch.zeros(world, dtype=torch.int64, device=dev)
+        ec[rank] = cur['edges']
+        dist.all_reduce(ec)
+        edge_counts = [int(v) for v in ec.tolist()]
 
     # ---- roofline leg: the same step, eager, with HIP events around the K1 launches --------------
     roofline, detail = None, {}
@@ -358,8 +498,15 @@ def main():
                                    'step = fwd + loss(BCE+reg+KL+MMD) + bwd + clip + Adam' %
                                    (E, args.n_bases, args.hidden, args.dropout, T),
                        'edges_per_gpu': E, 'nodes': n_nodes, 'triplets_per_gpu': T, 'n_flows': args.n_flows,
-                       'gemm_precision': args.gemm_precision, 'launch': launch, 'parallelism': 'edge-block sharding x%d, RCCL all-reduce of node embeddings' % world
-                       if world > 1 else 'single GPU'},
+                       'gemm_precision': args.gemm_precision, 'launch': launch,
+                       'parallelism': ('single GPU' if not dist_on else
+                                       'edge-block sharding x%d, RCCL all-reduce of node embeddings' % world
+                                       if cur['name'] == 'edge' else
+                                       'destination-row partition x%d of the union of the ranks\' edge blocks, RCCL '
+                                       'all-gather / reduce-scatter of node rows' % world),
+                       'partition': cur['name'] if dist_on else None,
+                       'partition_probe_ms_per_step': {k: round(v, 4) for k, v in probe.items()} or None,
+                       'row_partition_edges_per_rank': edge_counts},
             'final_loss': final_loss,
             'roofline': roofline, 'roofline_detail': detail,
         }
@@ -367,7 +514,9 @@ def main():
             out['cpu_baseline'] = cpu_baseline(w, model, args, args.cpu_seconds)
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
     if dist_on:

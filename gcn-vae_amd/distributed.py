@@ -47,16 +47,27 @@ class _Done:
         return None
 
 
+# A segments.SegmentedGraph that is recording the step (None otherwise): collectives are then issued BETWEEN hipGraph
+# segments and recorded for replay.  Every collective on the step goes through start_collective.
+RECORDER = None
+
+
+def start_collective(start_fn):
+    """``start_fn()`` issues a collective and returns an object with wait() (or None when it blocks).  Returns a handle
+    with wait().  The tensors ``start_fn`` closes over must be the step's own (static under segmented capture)."""
+    if RECORDER is not None:
+        return RECORDER.collective(start_fn)
+    work = start_fn()
+    return work if work is not None else _Done()
+
+
 def make_reduce_hook(group=None, async_op=True):
     """Callable for ``RelGraphConv.reduce_hook``: starts an in-place sum of ``t`` over the edge shards and
     returns a handle whose ``wait()`` orders the current stream behind it.  With ``async_op`` the collective
     runs on RCCL's own stream, so whatever the caller enqueues between the call and ``wait()`` (the layer's
     self-loop GEMM in forward; bias / loop-weight gradients and the loop GEMM in backward) overlaps with it."""
     def hook(t):
-        if async_op:
-            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        return _Done()
+        return start_collective(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=bool(async_op)))
     return hook
 
 
@@ -96,9 +107,10 @@ def average_gradients(params, group=None):
 def average_flat(flat_grads, group=None):
     """The same for a FlatAdam gradient arena: one all-reduce, no packing."""
     world = dist.get_world_size(group)
-    if world > 1:
-        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
-        flat_grads.div_(world)
+    if dist.is_initialized():
+        start_collective(lambda: dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group, async_op=True)).wait()
+        if world > 1:
+            flat_grads.div_(world)
 
 
 def shard_edges_by_relation(etypes, num_rels, world, rank):
@@ -160,7 +172,7 @@ class RowPartition:
         self.real_rows = sum(self.counts)
         self.group = group
         if native is None:      # all_gather_into_tensor / reduce_scatter_tensor: RCCL yes, gloo no
-            native = self.world > 1 and dist.is_initialized() and dist.get_backend(group) == 'nccl'
+            native = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == 'nccl'
         self.native = bool(native)
 
     def all_gather(self, out_full, x_slot):
@@ -168,28 +180,29 @@ class RowPartition:
         if tuple(out_full.shape) != (self.total_rows, x_slot.shape[1]) or x_slot.shape[0] != self.slot_rows:
             raise ValueError(f'all_gather: shapes {tuple(out_full.shape)} / {tuple(x_slot.shape)} do not fit '
                              f'{self.world} slots of {self.slot_rows} rows')
+        if self.native:
+            x_slot = x_slot.contiguous()
+            return start_collective(lambda: dist.all_gather_into_tensor(out_full, x_slot, group=self.group, async_op=True))
         if self.world == 1:
             out_full.copy_(x_slot)
             return _Done()
-        if self.native:
-            return dist.all_gather_into_tensor(out_full, x_slot.contiguous(), group=self.group, async_op=True)
         out_full.zero_()                                     # functional fallback (gloo): a sum of disjoint slots
         out_full[self.row0:self.row0 + self.slot_rows].copy_(x_slot)
-        dist.all_reduce(out_full, op=dist.ReduceOp.SUM, group=self.group)
-        return _Done()
+        return start_collective(lambda: dist.all_reduce(out_full, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def reduce_scatter(self, out_slot, g_full):
         """out_slot (slot, h) <- this rank's slot of the sum over ranks of g_full (world*slot, h)."""
         if g_full.shape[0] != self.total_rows or tuple(out_slot.shape) != (self.slot_rows, g_full.shape[1]):
             raise ValueError('reduce_scatter: shape mismatch')
+        if self.native:
+            g_full = g_full.contiguous()
+            return start_collective(lambda: dist.reduce_scatter_tensor(out_slot, g_full, op=dist.ReduceOp.SUM,
+                                                                       group=self.group, async_op=True))
         if self.world == 1:
             out_slot.copy_(g_full)
             return _Done()
-        if self.native:
-            return dist.reduce_scatter_tensor(out_slot, g_full.contiguous(), op=dist.ReduceOp.SUM, group=self.group,
-                                              async_op=True)
-        tmp = g_full.clone()
-        dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+        tmp = g_full.clone()                                 # functional fallback (gloo)
+        start_collective(lambda: dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)).wait()
         out_slot.copy_(tmp[self.row0:self.row0 + self.slot_rows])
         return _Done()
 
@@ -293,5 +306,5 @@ def make_row_partition(in_degree, world, rank, group=None, native=None):
 def sum_flat(flat_grads, group=None):
     """Row partition: every parameter gradient is a partial sum over the ranks' rows / triplet shares -> one
     all-reduce(sum) of the FlatAdam gradient arena, no division."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+    if dist.is_initialized():
+        start_collective(lambda: dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group, async_op=True)).wait()

@@ -33,7 +33,9 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize('extra', [[], ['--no-graph']])
+@pytest.mark.parametrize('extra', [['--partition', 'edge'], ['--no-graph', '--partition', 'edge'],
+                                   ['--no-graph', '--partition', 'row'], ['--partition', 'row'], [],
+                                   ['--graph-collectives', '--partition', 'edge']])
 def test_bench_single_rank_rccl(extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
@@ -43,7 +45,15 @@ def test_bench_single_rank_rccl(extra):
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
     d = json.loads(line)
-    assert d['n_gpus'] == 1 and d['value'] > 1e6 and d['config']['launch'] == ('eager' if extra else 'hipgraph')
+    assert d['n_gpus'] == 1 and d['value'] > 1e6
+    if '--no-graph' in extra:
+        assert d['config']['launch'] == 'eager'
+    elif '--graph-collectives' in extra:
+        assert d['config']['launch'] == 'hipgraph'
+    elif extra:      # collectives on the step: a chain of hipGraph segments with RCCL launched eagerly between them
+        assert d['config']['launch'].startswith('hipgraph segments'), d['config']['launch']
+    if 'row' in extra:       # RCCL's all_gather_into_tensor / reduce_scatter_tensor on a 1-rank group
+        assert d['config']['partition'] == 'row'
     assert d['final_loss'] == d['final_loss']          # not NaN
 
 
@@ -69,8 +79,28 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert out.returncode == 0, (out.stdout[-1500:] + '\n' + out.stderr[-2500:])
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
     d = json.loads(line)
-    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['launch'] == 'eager'
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak'
+    assert d['config']['launch'] == 'eager' or d['config']['launch'].startswith('hipgraph segments')
     assert d['value'] > 0 and d['final_loss'] == d['final_loss']
+    # "auto" probes both multi-GPU schemes during warm-up and runs the faster one
+    assert set(d['config']['partition_probe_ms_per_step']) == {'edge/segments', 'edge/eager', 'row/segments', 'row/eager'}
+    assert d['config']['partition'] in ('edge', 'row')
+
+
+@pytest.mark.parametrize('partition', ['edge', 'row'])
+def test_bench_two_ranks_each_partition(partition):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GV_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--no-cpu-baseline', '--profile-steps', '0', '--positives', '2000', '--partition', partition]
+    out = run_ranks(cmd, env, 900)
+    assert out.returncode == 0, (out.stdout[-1500:] + '\n' + out.stderr[-2500:])
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['config']['partition'] == partition and d['value'] > 0
+    assert 0.3 < d['final_loss'] < 3.0, d['final_loss']         # both schemes train the same union graph from the same init
+    if partition == 'row':
+        ec = d['config']['row_partition_edges_per_rank']
+        assert sum(ec) == 2 * d['config']['edges_per_gpu'] and max(ec) < 1.2 * min(ec)
 
 
 def test_row_partition_single_rank_equals_whole_graph_run():
