@@ -156,9 +156,9 @@ def global_in_degree_norm(dst_local, num_nodes, group=None, device=None):
 #   bytes     2 all-gathers + 2 reduce-scatters of (N, h) + the flat parameter all-reduce  =  ~38 MB of all-reduce
 #             equivalents per step at FB15k-237 / h = 200, against ~85 MB for the edge-block scheme above.
 #
-# Node rows are dealt to the ranks by in-degree (snake order), so that every rank owns the same number of rows (+-1) and
-# about the same number of edges; positions are  rank * slot_rows + i,  a rank's real rows first, then <= 1 all-zero
-# padding row so that all slots have the same size (all_gather_into_tensor / reduce_scatter_tensor).
+# Node rows are dealt to the ranks by in-degree (heaviest first to the lightest rank), so that every rank owns the same number of rows (within world-1) and
+# about the same number of edges; positions are  rank * slot_rows + i,  a rank's real rows first, then a few all-zero
+# padding rows so that all slots have the same size (all_gather_into_tensor / reduce_scatter_tensor).
 class RowPartition:
     def __init__(self, world, rank, counts, group=None, native=None):
         self.world, self.rank = int(world), int(rank)
@@ -230,18 +230,38 @@ class AllGatherRows(torch.autograd.Function):
         return own, None
 
 
-def plan_row_partition(in_degree, world):
-    """Deal the nodes to ``world`` ranks in snake order of decreasing in-degree: equal row counts (+-1), near-equal
-    edge counts.  Returns (pos_of_node int64 [N], node_of_pos int64 [world*slot] (padding -> -1), counts [world])."""
+def plan_row_partition(in_degree, world, greedy_nodes=32768):
+    """Deal the nodes to ``world`` ranks: equal row counts (within a row or two) and near-equal edge counts.  The
+    heaviest ``greedy_nodes`` nodes go one by one, in order of decreasing in-degree, to the rank with the fewest edges
+    so far that still has room (longest-processing-time rule: a hub of a Zipf-like degree law is worth thousands of
+    tail nodes); the light tail is dealt in snake order.  Returns (pos_of_node int64 [N], node_of_pos int64
+    [world*slot] with padding positions -1, counts [world])."""
+    import heapq
     deg = np.asarray(in_degree).astype(np.int64).reshape(-1)
     n = deg.shape[0]
     order = np.argsort(-deg, kind='stable')
-    i = np.arange(n)
-    k, rnd = i % world, i // world
-    owner_sorted = np.where(rnd % 2 == 0, k, world - 1 - k)
     owner = np.empty(n, dtype=np.int64)
-    owner[order] = owner_sorted
-    counts = np.bincount(owner, minlength=world)
+    k_greedy = min(n, int(greedy_nodes))
+    cap = -(-k_greedy // world)
+    load, count = [0] * world, [0] * world
+    heap = [(0, p) for p in range(world)]
+    for node in order[:k_greedy]:
+        while True:
+            l, p = heapq.heappop(heap)
+            if count[p] < cap:
+                break
+        owner[node] = p
+        load[p] = l + int(deg[node])
+        count[p] += 1
+        if count[p] < cap:
+            heapq.heappush(heap, (load[p], p))
+    rest = order[k_greedy:]
+    if rest.size:
+        by_load = np.argsort(np.asarray(load), kind='stable')              # lightest rank first
+        i = np.arange(rest.size)
+        k, rnd = i % world, i // world
+        owner[rest] = by_load[np.where(rnd % 2 == 0, k, world - 1 - k)]
+    counts = np.bincount(owner, minlength=world) if n else np.zeros(world, dtype=np.int64)
     slot = max(int(counts.max()) if n else 0, 1)
     pos_of_node = np.empty(n, dtype=np.int64)
     node_of_pos = np.full(world * slot, -1, dtype=np.int64)

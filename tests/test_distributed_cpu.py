@@ -160,3 +160,127 @@ def test_shard_edges_by_relation_partitions():
     et2 = np.zeros(100, dtype=int)
     tot = sum(len(gdist.shard_edges_by_relation(et2, 1, 4, r)[0]) for r in range(4))
     assert tot == 100
+
+
+# ------------------------------------------------------------------------------------------------
+# destination-row partition (distributed.RowPartition): the same device-independent checks
+def test_plan_row_partition_balances_rows_and_edges():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from gcn_vae_amd import distributed as gdist
+    rs = np.random.RandomState(0)
+    n = 14541
+    p = (np.arange(n) + 1.0) ** -0.8
+    deg = np.bincount(rs.choice(n, size=544230, p=p / p.sum()), minlength=n)           # FB15k-237-like hub skew
+    for world in (1, 2, 3, 8):
+        pos_of_node, node_of_pos, counts = gdist.plan_row_partition(deg, world)
+        slot = max(counts)
+        assert sum(counts) == n and max(counts) - min(counts) < max(world, 2) and len(node_of_pos) == world * slot
+        real = node_of_pos >= 0
+        assert real.sum() == n and (np.sort(node_of_pos[real]) == np.arange(n)).all()      # a bijection onto positions
+        assert (node_of_pos[pos_of_node] == np.arange(n)).all()
+        owner = pos_of_node // slot
+        edges = np.bincount(owner, weights=deg, minlength=world)
+        assert edges.max() <= 1.02 * edges.mean(), (world, edges)                        # near-equal edge counts despite the hubs
+        for r in range(world):            # a rank's real rows come first in its slot, ascending node id
+            blk = node_of_pos[r * slot:(r + 1) * slot]
+            assert (blk[:counts[r]] >= 0).all() and (blk[counts[r]:] == -1).all() and (np.diff(blk[:counts[r]]) > 0).all()
+    part = gdist.RowPartition(3, 1, [5, 4, 4], native=False)
+    assert (part.slot_rows, part.own_rows, part.row0, part.total_rows, part.real_rows) == (5, 4, 5, 15, 13)
+
+
+def rows_reference():
+    """Single process, whole graph: L = mean over the two triplet halves of BCE + 0.1 mean(h2^2)."""
+    src, dst, et, trip, labels, params = make_problem()
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    src_t, dst_t, et_t = (torch.from_numpy(a) for a in (src, dst, et))
+    deg = torch.bincount(dst_t, minlength=N).float()
+    norm = torch.where(deg > 0, 1.0 / deg.clamp(min=1), torch.zeros_like(deg))[dst_t].view(-1, 1)
+    x = p['emb']
+    h1 = layer(x, src_t, dst_t, et_t, norm, p['w1'], p['b1'], p['l1'], torch.relu, lambda t: t)
+    h2 = layer(h1, src_t, dst_t, et_t, norm, p['w2'], p['b2'], p['l2'], None, lambda t: t)
+    score = okg.distmult_score(h2, p['w_rel'], torch.from_numpy(trip))
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(score, torch.from_numpy(labels)) + 0.1 * h2.pow(2).mean()
+    loss.backward()
+    return {k: v.grad.clone() for k, v in p.items()}, float(loss.detach())
+
+
+def rows_worker(rank, world, port, out_q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from gcn_vae_amd import distributed as gdist
+    torch.set_num_threads(1)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        src, dst, et, trip, labels, params = make_problem()
+        deg = np.bincount(dst, minlength=N)
+        part = gdist.make_row_partition(deg, world, rank)
+        assert not part.native and part.real_rows == N
+        c, slot, row0 = part.own_rows, part.slot_rows, part.row0
+        pos = torch.from_numpy(part.pos_of_node)
+        nop = torch.from_numpy(np.maximum(part.node_of_pos, 0))
+        # the collectives themselves (gloo fallbacks)
+        mine = torch.full((slot, 2), float(rank + 1))
+        full = torch.empty(world * slot, 2)
+        part.all_gather(full, mine).wait()
+        assert all(torch.equal(full[r * slot:(r + 1) * slot], torch.full((slot, 2), float(r + 1))) for r in range(world))
+        own = torch.empty(slot, 2)
+        part.reduce_scatter(own, full * (rank + 1)).wait()
+        assert torch.equal(own, torch.full((slot, 2), float((rank + 1) * 3)))
+        # this rank's edges: destination in its row block; sources are positions in the full table
+        ps, pd = pos[torch.from_numpy(src)], pos[torch.from_numpy(dst)]
+        sel = (pd >= row0) & (pd < row0 + slot)
+        ps, dl, et_l = ps[sel], pd[sel] - row0, torch.from_numpy(et)[sel]
+        node_norm = torch.where(torch.from_numpy(deg) > 0, 1.0 / torch.from_numpy(deg).clamp(min=1).float(), torch.zeros(N))
+        norm = node_norm[torch.from_numpy(dst)[sel]].view(-1, 1)
+        p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+
+        def layer_rows(x_full, w, b, lw, act):
+            msg = orgcn._messages(x_full, ps, et_l, norm, {'weight': w}, 'bdd', NB)
+            agg = torch.zeros(c, msg.shape[1]).index_add(0, dl, msg)
+            h = agg + b + x_full[row0:row0 + c] @ lw
+            return act(h) if act is not None else h
+
+        def pad(t):
+            return torch.cat([t, torch.zeros(slot - c, t.shape[1])]) if c < slot else t
+
+        x0 = p['emb'][nop]                                                # replicated lookup of all positions
+        h1 = gdist.AllGatherRows.apply(pad(layer_rows(x0, p['w1'], p['b1'], p['l1'], torch.relu)), part)
+        h2_own = layer_rows(h1, p['w2'], p['b2'], p['l2'], None)
+        h2 = gdist.AllGatherRows.apply(pad(h2_own), part)
+        half = T // world
+        tr = torch.from_numpy(trip[rank * half:(rank + 1) * half])
+        tr_pos = torch.stack([pos[tr[:, 0]], tr[:, 1], pos[tr[:, 2]]], 1)
+        lb = torch.from_numpy(labels[rank * half:(rank + 1) * half])
+        pred = torch.nn.functional.binary_cross_entropy_with_logits(okg.distmult_score(h2, p['w_rel'], tr_pos), lb)
+        # the rank's SHARE of the loss: replicated terms / world, row-wise terms over its own rows with the global mean's weight
+        share = pred / world + 0.1 * h2_own.pow(2).sum() / (N * h2_own.shape[1])
+        share.backward()
+        arena = torch.cat([v.grad.reshape(-1) for v in p.values()])
+        gdist.sum_flat(arena)
+        total = share.detach().reshape(1).clone()
+        dist.all_reduce(total)
+        out_q.put((rank, arena.numpy(), float(total)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_partitioned_training_step_equals_single_process():
+    ref, ref_loss = rows_reference()
+    ref_flat = torch.cat([ref[k].reshape(-1) for k in ref]).numpy()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=rows_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, arena, total in results:
+        assert abs(total - ref_loss) < 1e-5
+        np.testing.assert_allclose(arena, ref_flat, rtol=1e-4, atol=1e-6, err_msg=f'rank {rank}')
+    np.testing.assert_array_equal(results[0][1], results[1][1])
