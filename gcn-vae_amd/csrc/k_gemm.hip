@@ -197,6 +197,72 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmParams p) {
     }
 }
 
+// ---- evaluation scorer with a rank-count epilogue (perturb_and_get_rank, kgvae/utils.py:180-221) ----
+// S = Q (m x h) @ E^T (E: v x h), prob = sigmoid(S + *bias).  The reference materialises an (h, Eb, V) tensor, sorts every
+// row and looks the target up; here the probabilities never leave the registers:
+//   PASS 0  tgt[row]    = prob[row, target[row]]                      (written by the one lane that owns that element)
+//   PASS 1  count[row] += #{ col != target[row] : prob[row, col] > tgt[row] }   (wave ballots, one int atomic per 32 columns)
+// Both passes run the SAME k-ordered fp32 MFMA chain as k_gemm_f32<false, true, 1, 1, 16>, so tgt is bit-identical to the
+// element the second pass recomputes and the count equals the one taken on a materialised score matrix.
+struct RankParams {
+    GemmParams g;            // a = Q, b = E (stored [v, h]), m, n = v, k = h
+    const int* target;
+    const float* bias;
+    float* tgt;
+    int* count;
+};
+
+template <int PASS>
+__global__ __launch_bounds__(256) void k_rank_scores(const RankParams rp) {
+    constexpr int BM = 64, BN = 64, BK = 16, LDA_S = BM + 1, LDB_S = BN + 1;
+    __shared__ float As[BK * LDA_S];
+    __shared__ float Bs[BK * LDB_S];
+    const GemmParams& p = rp.g;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm = (wid >> 1) * 32, wn = (wid & 1) * 32;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float ra[BM * BK / 256], rb[BN * BK / 256];
+    load_a<false, BM, BK>(p, m0, 0, p.k, ra);
+    load_b<true, BN, BK>(p, n0, 0, p.k, rb);
+    for (int k0 = 0; k0 < p.k; k0 += BK) {
+        stage_a<false, BM, BK>(As, ra);
+        stage_b<true, BN, BK>(Bs, rb);
+        __syncthreads();
+        if (k0 + BK < p.k) {
+            load_a<false, BM, BK>(p, m0, k0 + BK, p.k, ra);
+            load_b<true, BN, BK>(p, n0, k0 + BK, p.k, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kk + lhi) * LDA_S + wm + l31], Bs[(kk + lhi) * LDB_S + wn + l31],
+                                                       acc, 0, 0, 0);
+        __syncthreads();
+    }
+    const float bv = rp.bias ? *rp.bias : 0.f;
+    const int col = n0 + wn + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const bool in = row < p.m && col < p.n;
+        const float prob = 1.f / (1.f + expf(-(acc[r] + bv)));
+        const int tcol = row < p.m ? rp.target[row] : -1;
+        if (PASS == 0) {
+            if (in && col == tcol) rp.tgt[row] = prob;
+        } else {
+            const bool above = in && col != tcol && prob > rp.tgt[row];
+            const unsigned long long mask = __ballot(above);
+            if (l31 == 0 && row < p.m) {
+                const int c = __popc((unsigned)(lhi ? (mask >> 32) : (mask & 0xffffffffull)));
+                if (c) atomicAdd(rp.count + row, c);
+            }
+        }
+    }
+}
+
 // ---- bf16-operand variant (BASELINE configs[2]: bf16 with fp32 accumulation) --------------------------------------
 // Same contract and epilogue as k_gemm_f32; A and B are read as fp32 from memory, rounded to bf16 (RNE,
 // v_cvt_pk_bf16_f32) on their way into LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulators:
@@ -484,6 +550,28 @@ extern "C" int gv_gemm_bf16(int trans_a, int trans_b, int m, int n, int k, const
                             const float* a_relu_mask, void* workspace, int64_t workspace_bytes, void* stream) {
     return gemm_any(true, trans_a, trans_b, m, n, k, a, lda, b, ldb, c, ldc, bias, act, accumulate, split_k, a_relu_mask,
                     workspace, workspace_bytes, stream);
+}
+
+extern "C" int gv_rank_scores(const float* q, int ld_q, const float* e, int ld_e, const int* target, const float* bias,
+                              float* tgt, int* count, int m, int v, int h, void* stream) {
+    GV_REQUIRE(m >= 0 && v > 0 && h > 0, GV_ERR_SHAPE, "gv_rank_scores: m=%d v=%d h=%d", m, v, h);
+    if (m == 0) return GV_OK;
+    GV_REQUIRE(q && e && target && tgt && count, GV_ERR_NULL, "gv_rank_scores: NULL pointer");
+    GV_REQUIRE(ld_q >= h && ld_e >= h, GV_ERR_SHAPE, "gv_rank_scores: leading dimension too small");
+    RankParams rp;
+    GemmParams& p = rp.g;
+    p.a = q; p.b = e; p.c = nullptr; p.bias = nullptr; p.a_mask = nullptr; p.ws = nullptr;
+    p.m = m; p.n = v; p.k = h; p.lda = ld_q; p.ldb = ld_e; p.ldc = v;
+    p.act = GV_ACT_NONE; p.accumulate = 0; p.split_k = 1; p.k_chunk = h;
+    p.vec_a = aligned16(q) && (ld_q % 4 == 0);
+    p.vec_b = aligned16(e) && (ld_e % 4 == 0);
+    rp.target = target; rp.bias = bias; rp.tgt = tgt; rp.count = count;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(count, 0, (size_t)m * sizeof(int), st) != hipSuccess) return launch_status("gv_rank_scores(memset)");
+    dim3 grid((v + 63) / 64, (m + 63) / 64), block(256);
+    hipLaunchKernelGGL(k_rank_scores<0>, grid, block, 0, st, rp);
+    hipLaunchKernelGGL(k_rank_scores<1>, grid, block, 0, st, rp);
+    return launch_status("gv_rank_scores");
 }
 
 extern "C" int gv_colsum_finish(const float* part, int n, int n_slices, float* out, int accumulate, void* stream) {

@@ -489,6 +489,30 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, 
     return out
 
 
+def rank_scores(q, entities, target, bias=None):
+    """Raw ranks (0-based, int64) of ``target[i]`` among all entities under prob = sigmoid(q @ entities^T + bias):
+    the number of OTHER entities with a strictly larger probability (gv_rank_scores: MFMA tiles with a rank-count
+    epilogue; the (m, V) score matrix is never stored)."""
+    q, ld_q = _row_major(q, 'q')
+    entities, ld_e = _row_major(entities, 'entities')
+    if q.shape[1] != entities.shape[1]:
+        raise ValueError('q / entities width mismatch')
+    m, v = q.shape[0], entities.shape[0]
+    target = target.reshape(-1)
+    if target.numel() != m:
+        raise ValueError('one target per query row')
+    if m and (int(target.min()) < 0 or int(target.max()) >= v):
+        raise ValueError(f'targets must lie in [0, {v})')
+    tgt32 = target.to(device=q.device, dtype=torch.int32).contiguous()
+    if bias is not None:
+        bias = _chk(bias.reshape(1).to(torch.float32).contiguous(), name='bias')
+    ws = torch.empty(max(m, 1), dtype=torch.float32, device=q.device)
+    count = torch.empty(max(m, 1), dtype=torch.int32, device=q.device)
+    lib.call('gv_rank_scores', ptr(q), ld_q, ptr(entities), ld_e, ptr(tgt32), ptr(bias), ptr(ws), ptr(count), m, v,
+             q.shape[1], lib.stream())
+    return count[:m].to(torch.int64)
+
+
 def pick_split_k(m_out, n_out, k):
     """Reduction-heavy shapes (weight gradients: small output, K = nodes) need split-K to fill 256 CUs."""
     tiles = ((m_out + 63) // 64) * ((n_out + 63) // 64)

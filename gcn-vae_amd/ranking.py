@@ -1,11 +1,14 @@
 """Raw-MRR evaluation with the reference's function names (kgvae/utils.py:180-221, :293-314).
 
 The reference scores a batch against every entity by materialising a (h, Eb, V) outer-product
-tensor and summing over h; here that is ONE f32 MFMA GEMM (Eb, h) @ (h, V) (``ops.gemm``), followed
-by the reference's own ``+ flow_log_prob``, sigmoid and rank extraction.  Ranks come from a count of
-strictly larger scores (ties broken towards the better rank), which equals the reference's
-sort-and-find whenever scores are tie free; sigmoid saturation makes the reference's own ranks
-depend on ``torch.sort``'s unspecified tie order, so no implementation can match it there.
+tensor and summing over h, adds ``flow_log_prob``, applies a sigmoid, sorts every row and looks the
+target up.  Here ``ops.rank_scores`` (gv_rank_scores) forms sigmoid((e_a * w_r) @ E^T + flow_log_prob)
+tile by tile on the f32 MFMA and counts, per query, the entities with a strictly larger probability than
+the target's -- the score matrix is never stored and thousands of queries go through one launch.  The
+count equals the reference's sort-and-find whenever the probabilities are tie free (ties are broken
+towards the better rank); sigmoid saturation makes the reference's own ranks depend on ``torch.sort``'s
+unspecified tie order, so no implementation can match it there.  ``perturb_and_get_rank_unfused`` keeps
+the materialised form (one GEMM + torch ops) as the in-repo cross-check of the fused kernel.
 """
 import torch
 
@@ -17,8 +20,29 @@ def sort_and_rank(score, target):
     return (score > tgt).sum(dim=1)
 
 
+MAX_QUERY_ROWS = 16384      # queries per gv_rank_scores launch (bounds the (rows, h) query matrix, nothing else)
+
+
 def perturb_and_get_rank(embedding, w, a, r, b, test_size, batch_size=100, all_batches=True, flow_log_prob=None,
                          verbose=False):
+    """Ranks of ``b`` for the queries (a, r).  ``batch_size`` only matters with ``all_batches=False`` (the reference's
+    quick validation scores the first batch only, kgvae/utils.py:183-186): the fused scorer has no (h, Eb, V) tensor to bound."""
+    n = min(test_size, batch_size) if all_batches is False else test_size
+    emb = embedding.detach().contiguous()
+    wd = w.detach()
+    ranks = []
+    for lo in range(0, n, MAX_QUERY_ROWS):
+        hi = min(n, lo + MAX_QUERY_ROWS)
+        q = ops.mul(emb[a[lo:hi]].contiguous(), wd[r[lo:hi]].contiguous())
+        ranks.append(ops.rank_scores(q, emb, b[lo:hi], flow_log_prob))
+        if verbose:
+            rr = 1.0 + torch.cat(ranks).float()
+            print("rows {} / {}: MR : {:.6f} |  MRR : {:.6f}".format(hi, n, rr.mean().item(), (1.0 / rr).mean().item()))
+    return torch.cat(ranks) if ranks else torch.zeros(0, dtype=torch.int64, device=emb.device)
+
+
+def perturb_and_get_rank_unfused(embedding, w, a, r, b, test_size, batch_size=100, all_batches=True, flow_log_prob=None,
+                                 verbose=False):
     n_batch = (test_size + batch_size - 1) // batch_size
     if all_batches is False:
         n_batch = 1

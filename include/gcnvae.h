@@ -119,6 +119,13 @@ int gv_rgcn_epilogue_bwd(const float* out, const float* grad_out, int act, const
  * slices in a fixed order. */
 #define GV_EPILOGUE_COLSUM_SLICES 1024
 int gv_colsum_finish(const float* part, int n, int n_slices, float* out, int accumulate, void* stream);
+/* Evaluation scorer with a fused rank count (replaces the (h, Eb, V) outer-product tensor + sort of
+ * utils.perturb_and_get_rank / sort_and_rank, kgvae/utils.py:180-221): prob = sigmoid(q @ e^T + *bias) is formed tile by
+ * tile on the f32 MFMA and never stored;  count[i] = #{ j != target[i] : prob[i, j] > prob[i, target[i]] }  = the raw rank
+ * (0-based) of the target with ties broken towards the better rank.  q (m, h), e (v, h) row-major fp32, target int32 [m] in
+ * [0, v), bias optional device scalar (flow_log_prob), tgt: m floats of workspace, count int32 [m] (zeroed here). */
+int gv_rank_scores(const float* q, int ld_q, const float* e, int ld_e, const int* target, const float* bias, float* tgt,
+                   int* count, int m, int v, int h, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K2/K4  dense fp32 GEMM on the f32 MFMA (v_mfma_f32_32x32x2_f32; exact fp32 fma chain):

@@ -571,3 +571,108 @@ def test_xcd_ordered_grad_w_items_give_identical_bits(ops):
             assert ri.by_rel.seg.n_items >= before and int((ri.by_rel.seg.items[:, 0] >= 0).sum()) == before
         outs.append(ops.bdd_grad_weight(ri.by_rel.seg, ri.src_by_rel, ri.dst_by_rel, coef, ri.by_rel.perm, x, g, nb, 2, 4))
     assert torch.equal(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluation scorer with the fused rank count (gv_rank_scores)
+def _ranks_by_definition(ops, emb, w, a, r, b, flp):
+    """count of OTHER entities with a strictly larger sigmoid(score); scores from the same f32 MFMA GEMM."""
+    q = ops.mul(emb[a].contiguous(), w[r].contiguous())
+    score = ops.gemm(q, emb, trans_b=True)
+    if flp is not None:
+        score = score + flp
+    prob = torch.sigmoid(score)
+    tgt = prob.gather(1, b.view(-1, 1))
+    above = prob > tgt
+    above.scatter_(1, b.view(-1, 1), False)
+    return above.sum(1)
+
+
+@pytest.mark.parametrize('m,v,h,flp', [(1, 5, 4, None), (37, 1000, 16, 0.25), (300, 14541, 200, -1.5), (129, 777, 200, None),
+                                       (64, 64, 8, 3.0)])
+def test_rank_scores_equals_materialised_count(ops, m, v, h, flp):
+    gen = torch.Generator().manual_seed(m * 7 + v)
+    emb = (torch.randn(v, h, generator=gen) * 0.7).cuda()
+    w = torch.randn(11, h, generator=gen).cuda()
+    a = torch.randint(0, v, (m,), generator=gen).cuda()
+    r = torch.randint(0, 11, (m,), generator=gen).cuda()
+    b = torch.randint(0, v, (m,), generator=gen).cuda()
+    bias = None if flp is None else torch.tensor(flp, device='cuda')
+    q = ops.mul(emb[a].contiguous(), w[r].contiguous())
+    got = ops.rank_scores(q, emb, b, bias)
+    want = _ranks_by_definition(ops, emb, w, a, r, b, bias)
+    assert got.dtype == torch.int64 and torch.equal(got, want)
+    assert int(got.min()) >= 0 and int(got.max()) < v
+
+
+def test_rank_scores_ties_and_saturation(ops):
+    """Duplicate entity rows tie with each other (neither counts as larger); saturated sigmoids (prob == 1.0f) tie too;
+    the target never counts itself."""
+    h, v = 8, 130
+    emb = torch.randn(v, h, generator=torch.Generator().manual_seed(0)).cuda()
+    emb[7] = emb[3]                       # entity 7 duplicates entity 3
+    emb[129] = emb[3]
+    q = emb[[3, 3]].clone()               # query = entity 3's own row: its self score is the squared norm
+    target = torch.tensor([3, 7], device='cuda')
+    got = ops.rank_scores(q, emb, target)
+    prob = torch.sigmoid(ops.gemm(q, emb, trans_b=True))
+    for i in range(2):
+        t = int(target[i])
+        want = int((prob[i] > prob[i, t]).sum())
+        assert int(got[i]) == want
+    assert int(got[0]) == int(got[1])     # the three copies share one rank
+    big = (emb * 50.0).contiguous()       # every positive score saturates the sigmoid: those entities all tie at 1.0
+    got_big = ops.rank_scores((q * 50.0).contiguous(), big, target)
+    prob_big = torch.sigmoid(ops.gemm((q * 50.0).contiguous(), big, trans_b=True))
+    assert float(prob_big.max()) == 1.0
+    assert int(got_big[0]) == int((prob_big[0] > prob_big[0, 3]).sum()) == 0
+    with pytest.raises(ValueError):
+        ops.rank_scores(q, emb, torch.tensor([0, v], device='cuda'))
+
+
+def test_fused_ranker_matches_golden_ranks_and_unfused_path():
+    from conftest import load_golden
+    from gcn_vae_amd import ranking
+    g = load_golden('ranking.npz')
+    emb, w, flp = g['emb'].cuda(), g['w'].cuda(), g['flp'].cuda()
+    trip = g['trip'].cuda()
+    s, r, o = trip[:, 0], trip[:, 1], trip[:, 2]
+    n = trip.shape[0]
+    rs = ranking.perturb_and_get_rank(emb, w, o, r, s, n, 10, True, flp)          # vectors captured from the reference
+    assert torch.equal(rs.cpu(), g['ranks_s'].to(torch.int64))
+    for a, b in ((o, s), (s, o)):
+        assert torch.equal(ranking.perturb_and_get_rank(emb, w, a, r, b, n, 10, True, flp),
+                           ranking.perturb_and_get_rank_unfused(emb, w, a, r, b, n, 10, True, flp))
+    first = ranking.perturb_and_get_rank(emb, w, o, r, s, n, 10, False, flp)       # quick validation: first batch only
+    assert torch.equal(first, rs[:10])
+    mrr = ranking.calc_mrr(emb, w, trip, hits=[1, 3, 10], eval_bz=10, flow_log_prob=flp, verbose=False)
+    assert abs(mrr - float(g['mrr'])) < 1e-6
+    mrr1 = ranking.calc_mrr(emb, w, trip, hits=[1], eval_bz=10, all_batches=False, flow_log_prob=flp, verbose=False)
+    assert abs(mrr1 - float(g['mrr_first_batch'])) < 1e-6
+
+
+def test_rank_scores_full_fb15k237_eval_properties(ops):
+    """The whole FB15k-237 test split in both directions (2 x 20 466 queries x 14 541 entities x h = 200): ranks are in range,
+    invariant to the launch's row chunking and to a permutation of the queries, and equal the materialised count on a sample."""
+    from gcn_vae_amd import ranking
+    gen = torch.Generator().manual_seed(5)
+    v, h, n = 14541, 200, 20466
+    emb = (torch.randn(v, h, generator=gen) * 0.3).cuda()
+    w = torch.randn(237, h, generator=gen).cuda()
+    trip = torch.stack([torch.randint(0, v, (n,), generator=gen), torch.randint(0, 237, (n,), generator=gen),
+                        torch.randint(0, v, (n,), generator=gen)], 1).cuda()
+    s, r, o = trip[:, 0], trip[:, 1], trip[:, 2]
+    full = ranking.perturb_and_get_rank(emb, w, s, r, o, n, 100, True, None)
+    assert full.shape == (n,) and int(full.min()) >= 0 and int(full.max()) < v
+    old = ranking.MAX_QUERY_ROWS
+    try:
+        ranking.MAX_QUERY_ROWS = 5000
+        again = ranking.perturb_and_get_rank(emb, w, s, r, o, n, 100, True, None)
+    finally:
+        ranking.MAX_QUERY_ROWS = old
+    assert torch.equal(full, again)
+    perm = torch.randperm(n, generator=gen).cuda()
+    shuffled = ranking.perturb_and_get_rank(emb, w, s[perm], r[perm], o[perm], n, 100, True, None)
+    assert torch.equal(shuffled, full[perm])
+    pick = torch.arange(0, n, 97, device='cuda')
+    assert torch.equal(full[pick], _ranks_by_definition(ops, emb, w, s[pick], r[pick], o[pick], None))
