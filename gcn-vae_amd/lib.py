@@ -16,6 +16,13 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 SIGNATURES = {
     'gv_version': (_I, []),
     'gv_last_error_string': (ctypes.c_char_p, []),
+    'gv_index_caps': (None, [_L, _I, _I, _P, _P, _P]),
+    'gv_index_workspace_bytes': (_L, [_L, _I]),
+    'gv_build_csr': (_I, [_P, _L, _I, _I, _P, _P, _P, _I, _P, _I, _P, _L, _P]),
+    'gv_graph_index_build': (_I, [_P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _L, _P]),
+    'gv_relation_index_build': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _L, _P]),
+    'gv_triplet_index_build': (_I, [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I,
+                                    _P, _L, _P]),
     'gv_segment_items_count': (_I, [_P, _I, _I, _P, _P, _P, _P]),
     'gv_segment_items_fill': (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P]),
     'gv_rgcn_bdd_aggregate': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I,

@@ -146,6 +146,30 @@ def _rowptr_from_sorted(keys_sorted: torch.Tensor, n_seg: int) -> torch.Tensor:
     return torch.searchsorted(keys_sorted.contiguous(), bounds).to(torch.int32)
 
 
+def _index_caps(n_entries: int, n_seg: int, chunk: int):
+    """Upper bounds of the work-item lists of one ordering (= gv_index_caps): items, fix-ups, partial-row slots."""
+    extra = int(n_entries) // chunk + 1
+    return n_seg + extra, max(1, min(n_seg, extra)), 2 * extra
+
+
+def _carve_i32(device, sizes):
+    """One int32 allocation cut into 256-B aligned pieces (a native index build writes ~10 arrays: one malloc)."""
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (int(n) + 63) // 64 * 64
+    arena = torch.empty(max(total, 64), dtype=torch.int32, device=device)
+    return [arena[o:o + int(n)] for o, n in zip(offs, sizes)]
+
+
+def _index_workspace(device, n_entries, n_seg_max):
+    nbytes = int(lib.load().gv_index_workspace_bytes(int(n_entries), int(n_seg_max)))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
+NATIVE_INDEX = _os.environ.get('GV_NATIVE_INDEX', '1') == '1'     # sync-free indices through gv_*_index_build (one C call each)
+
+
 @dataclass
 class EdgeOrder:
     """One ordering of the edge list: the segment key (dst, src or relation) is sorted."""
@@ -175,6 +199,11 @@ class GraphIndex:
         self.device = src.device
         self.sync_free = bool(sync_free)
         ne = self.num_edges if sync_free else None
+        self._rel_cache = {}
+        self._chunk_cache = {}
+        if sync_free and NATIVE_INDEX:
+            self._build_native(src, dst, chunk, bool(dst_sorted))
+            return
         src = src.to(torch.int64)
         dst = dst.to(torch.int64)
         self.src32, self.dst32 = src.to(torch.int32), dst.to(torch.int32)
@@ -193,8 +222,24 @@ class GraphIndex:
         self.nbr_by_src = dst[perm_s].to(torch.int32).contiguous()
         self.by_src = EdgeOrder(perm_s.to(torch.int32),
                                 build_segment_items(_rowptr_from_sorted(src[perm_s], self.num_src_nodes), chunk, ne))
-        self._rel_cache = {}
-        self._chunk_cache = {}
+
+    def _build_native(self, src, dst, chunk, dst_sorted):
+        """Both orderings from ONE C call (gv_graph_index_build): no torch sort / searchsorted / cumsum dispatches and no
+        host synchronisation; lists sized by their upper bounds, -1 padded.  Same arrays as the torch formulation above."""
+        E, nd, ns, dev = self.num_edges, self.num_nodes, self.num_src_nodes, self.device
+        self.src32, self.dst32 = src.to(torch.int32).contiguous(), dst.to(torch.int32).contiguous()
+        ci_d, cf_d, slots_d = _index_caps(E, nd, chunk)
+        ci_s, cf_s, slots_s = _index_caps(E, ns, chunk)
+        (perm_d, nbr_d, rp_d, it_d, fx_d, perm_s, nbr_s, rp_s, it_s, fx_s) = _carve_i32(
+            dev, [0 if dst_sorted else E, E, nd + 1, 4 * ci_d, 4 * cf_d, E, E, ns + 1, 4 * ci_s, 4 * cf_s])
+        ws, ws_bytes = _index_workspace(dev, E, max(nd, ns))
+        lib.call('gv_graph_index_build', ptr(self.src32), ptr(self.dst32), E, nd, ns, 1 if dst_sorted else 0, chunk,
+                 None if dst_sorted else ptr(perm_d), ptr(nbr_d), ptr(rp_d), ptr(it_d), ci_d, ptr(fx_d), cf_d, ptr(perm_s),
+                 ptr(nbr_s), ptr(rp_s), ptr(it_s), ci_s, ptr(fx_s), cf_s, ptr(ws), ws_bytes, lib.stream())
+        self.nbr_by_dst, self.nbr_by_src = nbr_d, nbr_s
+        self.by_dst = EdgeOrder(None if dst_sorted else perm_d,
+                                SegmentItems(it_d.view(-1, 4), fx_d.view(-1, 4), ci_d, cf_d, slots_d, rp_d, chunk))
+        self.by_src = EdgeOrder(perm_s, SegmentItems(it_s.view(-1, 4), fx_s.view(-1, 4), ci_s, cf_s, slots_s, rp_s, chunk))
 
     def coef_in_src_order(self, coef: torch.Tensor) -> torch.Tensor:
         """Per-edge coefficients (given in the caller's edge order) permuted into the by-source order of the backward-x
@@ -276,6 +321,18 @@ class RelationIndex:
             raise ValueError(f'edge types must lie in [0, {num_rels})')
         self.num_rels = int(num_rels)
         self.keepalive = etypes
+        if g.sync_free and NATIVE_INDEX:
+            E, dev = g.num_edges, g.device
+            et32 = et.to(torch.int32).contiguous()
+            ci, cf, slots = _index_caps(E, self.num_rels, chunk)
+            (self.et_by_dst, self.et_by_src, perm_r, self.src_by_rel, self.dst_by_rel, rp, it, fx) = _carve_i32(
+                dev, [E, E, E, E, E, self.num_rels + 1, 4 * ci, 4 * cf])
+            ws, ws_bytes = _index_workspace(dev, E, self.num_rels)
+            lib.call('gv_relation_index_build', ptr(g.src32), ptr(g.dst32), ptr(et32), ptr(g.by_dst.perm), ptr(g.by_src.perm),
+                     E, self.num_rels, chunk, ptr(self.et_by_dst), ptr(self.et_by_src), ptr(perm_r), ptr(self.src_by_rel),
+                     ptr(self.dst_by_rel), ptr(rp), ptr(it), ci, ptr(fx), cf, ptr(ws), ws_bytes, lib.stream())
+            self.by_rel = EdgeOrder(perm_r, SegmentItems(it.view(-1, 4), fx.view(-1, 4), ci, cf, slots, rp, chunk))
+            return
         self.et_by_dst = (et if g.by_dst.perm is None else et[g.by_dst.perm.long()]).to(torch.int32).contiguous()
         self.et_by_src = et[g.by_src.perm.long()].to(torch.int32).contiguous()
         perm_r = torch.sort(et, stable=True)[1]
@@ -320,6 +377,21 @@ class TripletIndex:
         if locality is None:       # extra sorts per index: for a batch that is used many times (not rebuilt every step)
             locality = not sync_free and self.num_entities * 800 >= (4 << 20)
         self.trip32 = t.to(torch.int32).contiguous()
+        if sync_free and not locality and NATIVE_INDEX:
+            T, dev, ne, nr = self.T, t.device, self.num_entities, self.num_rels
+            ci_i, cf_i, slots_i = _index_caps(2 * T, ne, chunk)
+            ci_r, cf_r, slots_r = _index_caps(T, nr, chunk_rel)
+            (self.inc_other, self.inc_rel, self.inc_tid, rp_i, it_i, fx_i, self.rel_s, self.rel_o, self.rel_tid, rp_r, it_r,
+             fx_r) = _carve_i32(dev, [2 * T, 2 * T, 2 * T, ne + 1, 4 * ci_i, 4 * cf_i, T, T, T, nr + 1, 4 * ci_r, 4 * cf_r])
+            ws, ws_bytes = _index_workspace(dev, 2 * T, max(ne, nr))
+            lib.call('gv_triplet_index_build', ptr(self.trip32), T, ne, nr, chunk, chunk_rel, ptr(self.inc_other),
+                     ptr(self.inc_rel), ptr(self.inc_tid), ptr(rp_i), ptr(it_i), ci_i, ptr(fx_i), cf_i, ptr(self.rel_s),
+                     ptr(self.rel_o), ptr(self.rel_tid), ptr(rp_r), ptr(it_r), ci_r, ptr(fx_r), cf_r, ptr(ws), ws_bytes,
+                     lib.stream())
+            self.inc = SegmentItems(it_i.view(-1, 4), fx_i.view(-1, 4), ci_i, cf_i, slots_i, rp_i, chunk)
+            self.rel = SegmentItems(it_r.view(-1, 4), fx_r.view(-1, 4), ci_r, cf_r, slots_r, rp_r, chunk_rel)
+            self.fwd_order = self.pos3 = None
+            return
         s, r, o = t[:, 0], t[:, 1], t[:, 2]
         ent = torch.cat([s, o])
         other = torch.cat([o, s])

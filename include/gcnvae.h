@@ -285,6 +285,39 @@ int gv_clip_adam_step(float* p, float* g, float* exp_avg, float* exp_avg_sq, int
                       float* sumsq_out, float max_norm, float lr, float beta1, float beta2, float eps, float* step,
                       int zero_grad, void* stream);
 
+/* ---- index construction on the device (replaces python sorted(zip(dst, src, rel)) + numpy of kgvae/utils.py:127-150 and the
+ * torch sort / searchsorted / cumsum chains of the host modules; SURVEY 8(b) "gv_build_csr", 8(f-1)) ---------------------------
+ * All calls are asynchronous, allocation-free and synchronisation-free.  An ORDERING of n entries by an int32 key in
+ * [0, n_seg) is: perm = stable argsort(key), rowptr[s] = #{key < s} (n_seg + 1 entries), and work-item lists as produced
+ * by gv_segment_items_count/_fill -- but sized by their UPPER BOUNDS (gv_index_caps) and padded with -1 entries, which the
+ * K1 kernels skip, so no count travels back to the host.  workspace: gv_index_workspace_bytes(n, largest n_seg). */
+void gv_index_caps(int64_t n_entries, int n_seg, int chunk, int* items_cap, int* fix_cap, int* slots_cap);
+int64_t gv_index_workspace_bytes(int64_t n_entries, int n_seg_max);
+/* one ordering; perm == NULL: the keys are already sorted (identity order) */
+int gv_build_csr(const int32_t* keys, int64_t n, int n_seg, int chunk, int32_t* perm, int32_t* rowptr, int32_t* items,
+                 int items_cap, int32_t* fix, int fix_cap, void* workspace, int64_t workspace_bytes, void* stream);
+/* by-destination (CSR) and by-source (CSC) orderings of an edge list + the neighbour column of each:
+ * nbr_by_dst = src[perm_d], nbr_by_src = dst[perm_s].  dst_sorted != 0: the edges already are in the reference's
+ * (dst, src, rel) order (kgvae/utils.py:146-147), perm_d is not written.  Rectangular graphs: n_dst != n_src. */
+int gv_graph_index_build(const int32_t* src, const int32_t* dst, int64_t n_edges, int n_dst, int n_src, int dst_sorted,
+                         int chunk, int32_t* perm_d, int32_t* nbr_by_dst, int32_t* rowptr_d, int32_t* items_d,
+                         int items_d_cap, int32_t* fix_d, int fix_d_cap, int32_t* perm_s, int32_t* nbr_by_src,
+                         int32_t* rowptr_s, int32_t* items_s, int items_s_cap, int32_t* fix_s, int fix_s_cap,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+/* relation types in the two orderings above + the by-relation ordering (grad-W): src/dst_by_rel = src/dst[perm_r] */
+int gv_relation_index_build(const int32_t* src, const int32_t* dst, const int32_t* etype, const int32_t* perm_d /* NULL = identity */,
+                            const int32_t* perm_s, int64_t n_edges, int n_rel, int chunk, int32_t* et_by_dst,
+                            int32_t* et_by_src, int32_t* perm_r, int32_t* src_by_rel, int32_t* dst_by_rel, int32_t* rowptr_r,
+                            int32_t* items_r, int items_cap, int32_t* fix_r, int fix_cap, void* workspace,
+                            int64_t workspace_bytes, void* stream);
+/* triplet batch (T, 3) int32 for the DistMult backward: the 2T entity incidences (entity, other entity, relation, triplet id)
+ * ordered by entity, and the T triplets ordered by relation (rel_tid = the permutation) */
+int gv_triplet_index_build(const int32_t* trip, int64_t T, int n_ent, int n_rel, int chunk, int chunk_rel, int32_t* inc_other,
+                           int32_t* inc_rel, int32_t* inc_tid, int32_t* rowptr_inc, int32_t* items_inc, int items_inc_cap,
+                           int32_t* fix_inc, int fix_inc_cap, int32_t* rel_s, int32_t* rel_o, int32_t* rel_tid,
+                           int32_t* rowptr_rel, int32_t* items_rel, int items_rel_cap, int32_t* fix_rel, int fix_rel_cap,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

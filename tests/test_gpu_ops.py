@@ -676,3 +676,90 @@ def test_rank_scores_full_fb15k237_eval_properties(ops):
     assert torch.equal(shuffled, full[perm])
     pick = torch.arange(0, n, 97, device='cuda')
     assert torch.equal(full[pick], _ranks_by_definition(ops, emb, w, s[pick], r[pick], o[pick], None))
+
+
+# ------------------------------------------------------------------------------------------------
+# SURVEY 8(f-1) / 8(b) gv_build_csr: native, synchronisation-free index construction == the torch formulation
+def _same_items(a, b):
+    return (a.n_items == b.n_items and a.n_fix == b.n_fix and a.n_slots == b.n_slots and a.chunk == b.chunk
+            and torch.equal(a.rowptr, b.rowptr) and torch.equal(a.items, b.items) and torch.equal(a.fix, b.fix))
+
+
+@pytest.mark.parametrize('n,e,r,sorted_dst,n_src', [(50, 0, 4, True, None), (1, 7, 1, True, None), (300, 5000, 12, True, None),
+                                                     (300, 5000, 12, False, None), (2000, 60000, 474, True, None),
+                                                     (120, 9000, 30, True, 700), (97, 4001, 7, False, 350)])
+def test_native_index_build_equals_torch_formulation(ops, n, e, r, sorted_dst, n_src):
+    rs = np.random.RandomState(n + e)
+    ns = n if n_src is None else n_src
+    p = (np.arange(n) + 1.0) ** -1.2
+    dst = rs.choice(n, size=e, p=p / p.sum())                    # hubs: rows longer than one work item
+    src = rs.randint(0, ns, size=e)
+    et = rs.randint(0, r, size=e)
+    if sorted_dst:
+        order = np.lexsort((et, src, dst))
+        src, dst, et = src[order], dst[order], et[order]
+    src_t, dst_t, et_t = (torch.from_numpy(a).cuda() for a in (src, dst, et))
+    built = {}
+    old = ops.NATIVE_INDEX
+    try:
+        for native in (True, False):
+            ops.NATIVE_INDEX = native
+            g = ops.GraphIndex(src_t, dst_t, n, chunk=64, dst_sorted=sorted_dst, sync_free=True, num_src_nodes=n_src)
+            built[native] = (g, ops.RelationIndex(g, et_t, r, chunk=32))
+    finally:
+        ops.NATIVE_INDEX = old
+    (gn, rn), (gt, rt) = built[True], built[False]
+    assert (gn.by_dst.perm is None) == (gt.by_dst.perm is None) == sorted_dst
+    if not sorted_dst:
+        assert torch.equal(gn.by_dst.perm, gt.by_dst.perm)
+    assert torch.equal(gn.by_src.perm, gt.by_src.perm)
+    assert torch.equal(gn.nbr_by_dst, gt.nbr_by_dst) and torch.equal(gn.nbr_by_src, gt.nbr_by_src)
+    assert torch.equal(gn.src32, gt.src32) and torch.equal(gn.dst32, gt.dst32)
+    assert _same_items(gn.by_dst.seg, gt.by_dst.seg) and _same_items(gn.by_src.seg, gt.by_src.seg)
+    for name in ('et_by_dst', 'et_by_src', 'src_by_rel', 'dst_by_rel'):
+        assert torch.equal(getattr(rn, name), getattr(rt, name)), name
+    assert torch.equal(rn.by_rel.perm, rt.by_rel.perm) and _same_items(rn.by_rel.seg, rt.by_rel.seg)
+
+
+@pytest.mark.parametrize('T,n_ent,n_rel', [(0, 10, 3), (1, 5, 2), (5000, 300, 7), (220000, 10000, 237)])
+def test_native_triplet_index_equals_torch_formulation(ops, T, n_ent, n_rel):
+    rs = np.random.RandomState(T + 1)
+    p = (np.arange(n_ent) + 1.0) ** -1.0
+    trip = np.stack([rs.choice(n_ent, size=T, p=p / p.sum()), rs.randint(0, n_rel, size=T), rs.randint(0, n_ent, size=T)], 1)
+    trip_t = torch.from_numpy(trip.astype(np.int64)).cuda().reshape(T, 3)
+    built = {}
+    old = ops.NATIVE_INDEX
+    try:
+        for native in (True, False):
+            ops.NATIVE_INDEX = native
+            built[native] = ops.TripletIndex(trip_t, n_ent, n_rel, sync_free=True, locality=False)
+    finally:
+        ops.NATIVE_INDEX = old
+    a, b = built[True], built[False]
+    for name in ('trip32', 'inc_other', 'inc_rel', 'inc_tid', 'rel_s', 'rel_o', 'rel_tid'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert _same_items(a.inc, b.inc) and _same_items(a.rel, b.rel)
+    assert a.fwd_order is None and a.pos3 is None and b.fwd_order is None and b.pos3 is None
+
+
+def test_gv_build_csr_single_ordering(ops):
+    from gcn_vae_amd import lib
+    from gcn_vae_amd.lib import ptr
+    rs = np.random.RandomState(3)
+    n, n_seg, chunk = 10000, 37, 128
+    keys = torch.from_numpy(rs.randint(0, n_seg, size=n).astype(np.int32)).cuda()
+    ci, cf, _ = ops._index_caps(n, n_seg, chunk)
+    perm, rowptr, items, fix = ops._carve_i32(keys.device, [n, n_seg + 1, 4 * ci, 4 * cf])
+    ws, nbytes = ops._index_workspace(keys.device, n, n_seg)
+    lib.call('gv_build_csr', ptr(keys), n, n_seg, chunk, ptr(perm), ptr(rowptr), ptr(items), ci, ptr(fix), cf, ptr(ws), nbytes,
+             lib.stream())
+    want_perm = torch.sort(keys.long(), stable=True)[1].to(torch.int32)
+    assert torch.equal(perm, want_perm)
+    counts = torch.bincount(keys.long(), minlength=n_seg)
+    assert torch.equal(rowptr.long(), torch.cat([torch.zeros(1, dtype=torch.long, device='cuda'), counts.cumsum(0)]))
+    it = items.view(-1, 4)
+    valid = it[it[:, 0] >= 0]
+    assert int((valid[:, 2] - valid[:, 1]).sum()) == n and int((valid[:, 2] - valid[:, 1]).max()) <= chunk
+    assert torch.equal(valid[:, 0].long().unique(), torch.arange(n_seg, device='cuda'))       # every segment has an item
+    lib_rc = lib.load().gv_build_csr(None, 5, 3, 16, None, None, None, 1, None, 1, None, 0, None)
+    assert lib_rc < 0
