@@ -134,4 +134,18 @@ __device__ __forceinline__ float sum_slices_16x64(const float* __restrict__ part
 
 __device__ __forceinline__ float apply_act(float v, int act) { return act == GV_ACT_RELU ? fmaxf(v, 0.f) : v; }
 
+// Philox4x32-10 (Salmon et al., SC'11), the one random generator of the library (gv_rng_fill, the batch sampler)
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+
 }  // namespace gv

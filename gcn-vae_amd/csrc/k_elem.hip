@@ -212,18 +212,6 @@ __global__ __launch_bounds__(256) void k_reverse_cols(const float* x, float* out
 // so a captured hipGraph draws fresh numbers on every replay; `stream` separates the jobs of one tick.
 //   kind 0: keep mask, byte = (u32 >= floor(p_drop * 2^32))            (nn.Dropout's Bernoulli(1-p) decision)
 //   kind 1: standard normals by Box-Muller, (u1, u2) = ((x0 + 1) * 2^-32, x1 * 2^-32)  (torch.randn_like)
-__device__ __forceinline__ uint4 philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return make_uint4(c0, c1, c2, c3);
-}
-
 struct RngJobs {
     void* ptr[GV_RNG_MAX_JOBS];
     long long n[GV_RNG_MAX_JOBS];

@@ -1,0 +1,246 @@
+// Mini-batch preparation on the device: the reference samples edges, relabels nodes, draws negatives and
+// builds the message-passing graph with numpy and python loops on the host (kgvae/utils.py:79-171).  Four entry points do
+// the same on the GPU with a handful of launches:
+//
+//   gv_perm_sample          k distinct indices of [0, n)        (np.random.choice(n, k, replace=False), utils.py:79-82)
+//   gv_relabel_pairs        np.unique((a, b), return_inverse)   (utils.py:103-105): sorted unique ids + the relabelled pair
+//   gv_negative_sampling    utils.negative_sampling (:158-171): positives followed by neg_rate corrupted copies, labels
+//   gv_graph_from_triplets  utils.build_graph_from_triplets (:135-150) + comp_deg_norm (:127-132): reverse edges, the
+//                           (dst, src, rel) edge order, 1/in-degree of every edge's destination
+//
+// The deterministic parts (relabel, negatives from given draws, graph build) reproduce the host pipeline -- itself pinned
+// by vectors captured from the reference -- array for array.  The random draws are counter-based (Philox4x32-10, the
+// generator of gv_rng_fill), so a batch is a pure function of (seed, tick): the index sample is the first k outputs of a
+// keyed PERMUTATION of [0, n) (4-round unbalanced Feistel network over ceil(log2 n) bits with cycle walking: distinct by
+// construction, no sort of n keys as torch.randperm / np.random.choice do); a negative's entity is mulhi(u32, n_entities)
+// and its coin is the top bit of a second u32.  That is this library's random stream, not numpy's.
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace gv {
+
+__device__ __forceinline__ uint32_t feistel_permute(uint32_t x, int bits, uint32_t k0, uint32_t k1, uint32_t stream,
+                                                    uint32_t t0, uint32_t t1) {
+    int la = bits / 2, rb = bits - la;                     // left has la bits, right has rb bits
+    uint32_t l = x >> rb, r = x & ((1u << rb) - 1u);
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+        const uint32_t f = philox4x32_10(k0, k1, r, stream + 0x10000u * (uint32_t)(round + 1), t0, t1).x & ((1u << la) - 1u);
+        const uint32_t nl = r, nr = l ^ f;                 // new left: rb bits, new right: la bits
+        l = nl; r = nr;
+        const int t = la; la = rb; rb = t;
+    }
+    return (l << rb) | r;
+}
+
+__global__ void k_perm_sample(long long n, long long k, int bits, uint32_t k0, uint32_t k1, uint32_t stream, uint32_t t0,
+                              uint32_t t1, int* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    uint32_t x = (uint32_t)i;
+    do {
+        x = feistel_permute(x, bits, k0, k1, stream, t0, t1);
+    } while ((long long)x >= n);                           // cycle walking: the walk of i < n returns to [0, n)
+    out[i] = (int)x;
+}
+
+__global__ void k_mark_pairs(const int* a, const int* b, long long k, int* flags) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    flags[a[i]] = 1;
+    flags[b[i]] = 1;
+}
+
+__global__ void k_compact_ids(const int* flags, const int* rank, int num_ids, int* uniq, int cap, int* count) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id == 0) *count = rank[num_ids];
+    if (id >= num_ids) return;
+    if (flags[id] && rank[id] < cap) uniq[rank[id]] = id;
+}
+
+__global__ void k_map_pairs(const int* a, const int* b, long long k, const int* rank, int* a_local, int* b_local) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    a_local[i] = rank[a[i]];
+    b_local[i] = rank[b[i]];
+}
+
+// samples (k * (neg_rate + 1), 3) int64: rows [0, k) = positives, row k + j*k + p = positive p with its subject
+// (hit_subject) or object replaced by values[j*k + p]  (np.tile(pos, (neg_rate, 1)) order); labels 1 / 0
+__global__ void k_negative_sampling(const int* s, const int* r, const int* o, long long k, int neg_rate, const int* n_ent_dev,
+                                    const int* values, const uint8_t* hit, uint32_t k0, uint32_t k1, uint32_t stream,
+                                    uint32_t t0, uint32_t t1, long long* samples, float* labels) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = k * (neg_rate + 1);
+    if (i >= total) return;
+    long long* row = samples + 3 * i;
+    if (i < k) {
+        row[0] = s[i]; row[1] = r[i]; row[2] = o[i];
+        labels[i] = 1.f;
+        return;
+    }
+    const long long q = i - k, p = q % k;
+    int v;
+    bool subj;
+    if (values) {
+        v = values[q];
+        subj = hit[q] != 0;
+    } else {
+        const uint4 x = philox4x32_10(k0, k1, (uint32_t)q, stream, t0, t1);
+        v = (int)__umulhi(x.x, (uint32_t)(*n_ent_dev));
+        subj = (x.y >> 31) != 0u;
+    }
+    row[0] = subj ? v : s[p];
+    row[1] = r[p];
+    row[2] = subj ? o[p] : v;
+    labels[i] = 0.f;
+}
+
+__global__ void k_edge_keys(const int* s, const int* r, const int* o, const int* keep, long long m, long long bound,
+                            int num_rels, unsigned long long* keys, int* src2, int* dst2, int* rel2, int* iota) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * m) return;
+    const long long p = i < m ? i : i - m;
+    const long long t = keep ? keep[p] : p;
+    const int a = s[t], b = o[t], rr = r[t];
+    const int sv = i < m ? a : b, dv = i < m ? b : a, rv = i < m ? rr : rr + num_rels;      // reverse edges: rel + num_rels
+    src2[i] = sv; dst2[i] = dv; rel2[i] = rv;
+    keys[i] = ((unsigned long long)dv * (unsigned long long)bound + (unsigned long long)sv) * (2ull * num_rels) + rv;
+    iota[i] = (int)i;
+}
+
+__global__ void k_gather3(const int* perm, long long n, const int* a, const int* b, const int* c, int* oa, int* ob, int* oc) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = perm[i];
+    oa[i] = a[p]; ob[i] = b[p]; oc[i] = c[p];
+}
+
+// dst sorted ascending: in-degree of d = #entries equal to d, by two binary searches; norm = 1 / in-degree (fp32 division)
+__global__ void k_edge_norm(const int* dst_sorted, long long n, float* norm) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int d = dst_sorted[i];
+    long long lo = 0, hi = n;
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (dst_sorted[mid] < d) lo = mid + 1; else hi = mid; }
+    const long long first = lo;
+    hi = n;
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (dst_sorted[mid] <= d) lo = mid + 1; else hi = mid; }
+    norm[i] = 1.0f / (float)(lo - first);
+}
+
+}  // namespace gv
+
+using namespace gv;
+
+namespace {
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+
+int key_bits(long long bound, int num_rels) {
+    const unsigned long long top = (unsigned long long)bound * bound * 2ull * (unsigned long long)(num_rels > 0 ? num_rels : 1);
+    int b = 1;
+    while (b < 64 && (1ull << b) < top) ++b;
+    return b;
+}
+
+size_t relabel_temp(int num_ids) {
+    size_t t = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t, (const int*)nullptr, (int*)nullptr, num_ids + 1);
+    return al256(t);
+}
+
+size_t graph_temp(long long n2, long long bound, int num_rels) {
+    size_t t = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                             (const int*)nullptr, (int*)nullptr, (int)n2, 0, key_bits(bound, num_rels));
+    return al256(t);
+}
+}  // namespace
+
+extern "C" int gv_perm_sample(int64_t n, int64_t k, uint64_t seed, uint64_t tick, uint32_t stream_id, int32_t* out,
+                              void* stream) {
+    GV_REQUIRE(n >= 0 && k >= 0 && k <= n && n < (1ll << 31), GV_ERR_SHAPE, "gv_perm_sample: n=%lld k=%lld", (long long)n,
+               (long long)k);
+    if (k == 0) return GV_OK;
+    GV_REQUIRE(out, GV_ERR_NULL, "gv_perm_sample: NULL output");
+    int bits = 2;
+    while ((1ll << bits) < n) ++bits;
+    hipLaunchKernelGGL(k_perm_sample, dim3(blocks_for(k)), dim3(256), 0, (hipStream_t)stream, (long long)n, (long long)k, bits,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, (uint32_t)tick, (uint32_t)(tick >> 32), out);
+    return launch_status("gv_perm_sample");
+}
+
+extern "C" int64_t gv_relabel_workspace_bytes(int num_ids) {
+    return (int64_t)(2 * al256((size_t)(num_ids + 1) * sizeof(int)) + relabel_temp(num_ids));
+}
+
+extern "C" int gv_relabel_pairs(const int32_t* a, const int32_t* b, int64_t k, int num_ids, int32_t* uniq, int uniq_cap,
+                                int32_t* a_local, int32_t* b_local, int32_t* count, void* workspace, int64_t workspace_bytes,
+                                void* stream) {
+    GV_REQUIRE(k >= 0 && num_ids > 0 && uniq_cap >= 0, GV_ERR_SHAPE, "gv_relabel_pairs: k=%lld num_ids=%d", (long long)k, num_ids);
+    GV_REQUIRE(count && workspace && ((a && b && a_local && b_local && uniq) || k == 0), GV_ERR_NULL, "gv_relabel_pairs: NULL pointer");
+    GV_REQUIRE(workspace_bytes >= gv_relabel_workspace_bytes(num_ids), GV_ERR_WORKSPACE, "gv_relabel_pairs: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* p = (char*)workspace;
+    int* flags = (int*)p; p += al256((size_t)(num_ids + 1) * sizeof(int));
+    int* rank = (int*)p; p += al256((size_t)(num_ids + 1) * sizeof(int));
+    size_t tb = relabel_temp(num_ids);
+    if (hipMemsetAsync(flags, 0, (size_t)(num_ids + 1) * sizeof(int), st) != hipSuccess) return launch_status("gv_relabel_pairs(memset)");
+    if (k > 0) hipLaunchKernelGGL(k_mark_pairs, dim3(blocks_for(k)), dim3(256), 0, st, a, b, (long long)k, flags);
+    if (hipcub::DeviceScan::ExclusiveSum(p, tb, (const int*)flags, rank, num_ids + 1, st) != hipSuccess)
+        return launch_status("gv_relabel_pairs(scan)");
+    hipLaunchKernelGGL(k_compact_ids, dim3(blocks_for(num_ids)), dim3(256), 0, st, flags, rank, num_ids, uniq, uniq_cap, count);
+    if (k > 0) hipLaunchKernelGGL(k_map_pairs, dim3(blocks_for(k)), dim3(256), 0, st, a, b, (long long)k, rank, a_local, b_local);
+    return launch_status("gv_relabel_pairs");
+}
+
+extern "C" int gv_negative_sampling(const int32_t* s, const int32_t* r, const int32_t* o, int64_t k, int neg_rate,
+                                    const int32_t* n_entities_dev, const int32_t* values, const uint8_t* hit_subject,
+                                    uint64_t seed, uint64_t tick, uint32_t stream_id, int64_t* samples, float* labels,
+                                    void* stream) {
+    GV_REQUIRE(k >= 0 && neg_rate >= 0, GV_ERR_SHAPE, "gv_negative_sampling: k=%lld neg_rate=%d", (long long)k, neg_rate);
+    if (k == 0) return GV_OK;
+    GV_REQUIRE(s && r && o && samples && labels, GV_ERR_NULL, "gv_negative_sampling: NULL pointer");
+    GV_REQUIRE((values && hit_subject) || (!values && !hit_subject && n_entities_dev), GV_ERR_NULL,
+               "gv_negative_sampling: pass both draws (values, hit_subject) or neither (then n_entities_dev)");
+    hipLaunchKernelGGL(k_negative_sampling, dim3(blocks_for(k * (neg_rate + 1))), dim3(256), 0, (hipStream_t)stream, s, r, o,
+                       (long long)k, neg_rate, n_entities_dev, values, hit_subject, (uint32_t)seed, (uint32_t)(seed >> 32),
+                       stream_id, (uint32_t)tick, (uint32_t)(tick >> 32), (long long*)samples, labels);
+    return launch_status("gv_negative_sampling");
+}
+
+extern "C" int64_t gv_graph_from_triplets_workspace_bytes(int64_t m, int n_nodes_bound, int num_rels) {
+    const long long n2 = 2 * m;
+    return (int64_t)(2 * al256((size_t)n2 * 8) + 5 * al256((size_t)n2 * 4) + graph_temp(n2, n_nodes_bound, num_rels));
+}
+
+extern "C" int gv_graph_from_triplets(const int32_t* s, const int32_t* r, const int32_t* o, const int32_t* keep, int64_t m,
+                                      int n_nodes_bound, int num_rels, int32_t* src2, int32_t* dst2, int32_t* rel2,
+                                      float* norm, void* workspace, int64_t workspace_bytes, void* stream) {
+    GV_REQUIRE(m >= 0 && 2 * m < (1ll << 31) && n_nodes_bound > 0 && num_rels > 0, GV_ERR_SHAPE, "gv_graph_from_triplets: bad sizes");
+    if (m == 0) return GV_OK;
+    GV_REQUIRE(s && r && o && src2 && dst2 && rel2 && norm && workspace, GV_ERR_NULL, "gv_graph_from_triplets: NULL pointer");
+    GV_REQUIRE(workspace_bytes >= gv_graph_from_triplets_workspace_bytes(m, n_nodes_bound, num_rels), GV_ERR_WORKSPACE,
+               "gv_graph_from_triplets: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const long long n2 = 2 * m;
+    char* p = (char*)workspace;
+    unsigned long long* keys = (unsigned long long*)p; p += al256((size_t)n2 * 8);
+    unsigned long long* keys_sorted = (unsigned long long*)p; p += al256((size_t)n2 * 8);
+    int* ts = (int*)p; p += al256((size_t)n2 * 4);
+    int* td = (int*)p; p += al256((size_t)n2 * 4);
+    int* tr = (int*)p; p += al256((size_t)n2 * 4);
+    int* iota = (int*)p; p += al256((size_t)n2 * 4);
+    int* perm = (int*)p; p += al256((size_t)n2 * 4);
+    size_t tb = graph_temp(n2, n_nodes_bound, num_rels);
+    hipLaunchKernelGGL(k_edge_keys, dim3(blocks_for(n2)), dim3(256), 0, st, s, r, o, keep, (long long)m, (long long)n_nodes_bound,
+                       num_rels, keys, ts, td, tr, iota);
+    if (hipcub::DeviceRadixSort::SortPairs(p, tb, (const unsigned long long*)keys, keys_sorted, (const int*)iota, perm, (int)n2, 0,
+                                           key_bits(n_nodes_bound, num_rels), st) != hipSuccess)
+        return launch_status("gv_graph_from_triplets(sort)");
+    hipLaunchKernelGGL(k_gather3, dim3(blocks_for(n2)), dim3(256), 0, st, perm, n2, ts, td, tr, src2, dst2, rel2);
+    hipLaunchKernelGGL(k_edge_norm, dim3(blocks_for(n2)), dim3(256), 0, st, dst2, n2, norm);
+    return launch_status("gv_graph_from_triplets");
+}

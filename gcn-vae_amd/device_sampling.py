@@ -6,16 +6,29 @@ edges -> sort by (dst, src, rel) -> 1/in-degree norm); restated faithfully in ``
 25-30 ms per step here against ~2 ms of GPU compute.  ``DeviceSampler`` does the same pipeline with device
 tensor ops (sort / unique / bincount) and hands the model a graph handle whose edges already live on the GPU.
 
-It draws from torch's device generator, NOT from numpy's global stream, so batches differ from the
-reference's for a given seed: this is the throughput mode.  ``sampling.generate_sampled_graph_and_labels``
-stays the reference-exact path (golden-vector tested).  Only the uniform edge sampler is offered (the
-neighbourhood sampler is inherently sequential).
+It does NOT draw from numpy's global stream, so batches differ from the reference's for a given seed: this is
+the throughput mode.  ``sampling.generate_sampled_graph_and_labels`` stays the reference-exact path
+(golden-vector tested).  Only the uniform edge sampler is offered (the neighbourhood sampler is inherently
+sequential).
+
+Two implementations of the same pipeline:
+  * native (default): ``gv_perm_sample`` / ``gv_relabel_pairs`` / ``gv_negative_sampling`` / ``gv_graph_from_triplets``
+    (csrc/k_sample.hip) -- ~15 launches per batch, counter-based draws (Philox4x32-10 keyed by (seed, batch number)), the
+    index sample from a keyed permutation instead of a sort of all triplet ids.  The deterministic stages equal the host
+    pipeline array for array (tests/test_gpu_ops.py::test_native_sampler_*);
+  * torch ops (``native=False`` / GV_NATIVE_SAMPLER=0): sort / unique / bincount on torch's device generator.
+Both synchronise once per batch (the sub-graph's node count sizes the model's activations).
 """
+import os
 from dataclasses import dataclass
 
 import torch
 
+from . import lib, ops
 from .graph import KGraph
+from .lib import ptr
+
+STREAM_EDGES, STREAM_NEG, STREAM_SPLIT = 0x5A01, 0x5A02, 0x5A03      # Philox stream ids of the three draws of a batch
 
 
 @dataclass
@@ -29,7 +42,7 @@ class DeviceBatch:
 
 
 class DeviceSampler:
-    def __init__(self, triplets, num_nodes, num_rels, device, seed=None):
+    def __init__(self, triplets, num_nodes, num_rels, device, seed=None, native=None):
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError('DeviceSampler prepares batches on a ROCm device; use gcn_vae_amd.sampling on the host')
@@ -38,6 +51,47 @@ class DeviceSampler:
         self.gen = torch.Generator(device=self.device)
         if seed is not None:
             self.gen.manual_seed(int(seed))
+        self.native = (os.environ.get('GV_NATIVE_SAMPLER', '1') == '1') if native is None else bool(native)
+        self.seed = int(seed) if seed is not None else int(torch.initial_seed())
+        self.seed &= 0xFFFFFFFFFFFFFFFF
+        self.tick = 0                                              # batch number: the Philox counter's high words
+        if self.native:
+            t32 = self.triplets.to(torch.int32)
+            self._s, self._r, self._o = (t32[:, i].contiguous() for i in range(3))
+
+    # -- native pipeline ----------------------------------------------------------------------------------------
+    def _sample_native(self, sample_size, split_size, negative_rate):
+        dev, k, st = self.device, int(sample_size), lib.stream()
+        n_trip = int(self.triplets.shape[0])
+        self.tick += 1
+        i32 = dict(dtype=torch.int32, device=dev)
+        chosen = torch.empty(k, **i32)
+        lib.call('gv_perm_sample', n_trip, k, self.seed, self.tick, STREAM_EDGES, ptr(chosen), st)
+        ci = chosen.long()
+        src_g, rel, dst_g = self._s[ci], self._r[ci], self._o[ci]             # global ids of the sampled triplets
+        cap = min(2 * k, self.num_nodes)
+        uniq, src, dst, count = (torch.empty(cap, **i32), torch.empty(k, **i32), torch.empty(k, **i32), torch.empty(1, **i32))
+        ws_bytes = int(lib.load().gv_relabel_workspace_bytes(self.num_nodes))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        lib.call('gv_relabel_pairs', ptr(src_g), ptr(dst_g), k, self.num_nodes, ptr(uniq), cap, ptr(src), ptr(dst), ptr(count),
+                 ptr(ws), ws_bytes, st)
+        total = k * (negative_rate + 1)
+        samples = torch.empty(total, 3, dtype=torch.int64, device=dev)
+        labels = torch.empty(total, dtype=torch.float32, device=dev)
+        lib.call('gv_negative_sampling', ptr(src), ptr(rel), ptr(dst), k, int(negative_rate), ptr(count), None, None, self.seed,
+                 self.tick, STREAM_NEG, ptr(samples), ptr(labels), st)
+        m = int(k * split_size)
+        keep = torch.empty(max(m, 1), **i32)
+        lib.call('gv_perm_sample', k, m, self.seed, self.tick, STREAM_SPLIT, ptr(keep), st)
+        src2, dst2, rel2 = torch.empty(2 * m, **i32), torch.empty(2 * m, **i32), torch.empty(2 * m, **i32)
+        norm = torch.empty(2 * m, 1, dtype=torch.float32, device=dev)
+        gb = int(lib.load().gv_graph_from_triplets_workspace_bytes(m, cap, self.num_rels))
+        gws = torch.empty(gb, dtype=torch.uint8, device=dev)
+        lib.call('gv_graph_from_triplets', ptr(src), ptr(rel), ptr(dst), ptr(keep), m, cap, self.num_rels, ptr(src2), ptr(dst2),
+                 ptr(rel2), ptr(norm), ptr(gws), gb, st)
+        n = int(count.item())                                                    # the one host sync per batch
+        g = KGraph.from_device_edges(n, src2, dst2, dst_sorted=True)
+        return DeviceBatch(g, uniq[:n].long().view(-1, 1), rel2.long(), norm, samples, labels)
 
     def _sorted_graph(self, n, src, rel, dst):
         """build_graph_from_triplets: add reverse edges, order by (dst, src, rel), 1/in-degree norm."""
@@ -56,6 +110,8 @@ class DeviceSampler:
 
     def sample(self, sample_size, split_size=0.5, negative_rate=10):
         """generate_sampled_graph_and_labels(..., sampler='uniform') on the device."""
+        if self.native:
+            return self._sample_native(sample_size, split_size, negative_rate)
         dev, gen = self.device, self.gen
         n_trip = self.triplets.shape[0]
         pick = torch.randperm(n_trip, device=dev, generator=gen)[:sample_size]

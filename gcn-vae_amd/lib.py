@@ -23,6 +23,12 @@ SIGNATURES = {
     'gv_relation_index_build': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _L, _P]),
     'gv_triplet_index_build': (_I, [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I,
                                     _P, _L, _P]),
+    'gv_perm_sample': (_I, [_L, _L, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _P, _P]),
+    'gv_relabel_workspace_bytes': (_L, [_I]),
+    'gv_relabel_pairs': (_I, [_P, _P, _L, _I, _P, _I, _P, _P, _P, _P, _L, _P]),
+    'gv_negative_sampling': (_I, [_P, _P, _P, _L, _I, _P, _P, _P, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _P, _P, _P]),
+    'gv_graph_from_triplets_workspace_bytes': (_L, [_L, _I, _I]),
+    'gv_graph_from_triplets': (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
     'gv_segment_items_count': (_I, [_P, _I, _I, _P, _P, _P, _P]),
     'gv_segment_items_fill': (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P]),
     'gv_rgcn_bdd_aggregate': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I,

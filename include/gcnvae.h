@@ -318,6 +318,31 @@ int gv_triplet_index_build(const int32_t* trip, int64_t T, int n_ent, int n_rel,
                            int32_t* rowptr_rel, int32_t* items_rel, int items_rel_cap, int32_t* fix_rel, int fix_rel_cap,
                            void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- mini-batch preparation on the device (kgvae/utils.py:79-171) -------------------------------------------
+ * Random draws are Philox4x32-10 outputs keyed by (seed, tick, stream_id): a batch is a pure function of those three. */
+/* out[i] = i-th output of a keyed permutation of [0, n), i < k <= n: k DISTINCT indices (np.random.choice(n, k, replace=False),
+ * kgvae/utils.py:79-82) without sorting n keys: 4-round unbalanced Feistel network over ceil(log2 n) bits, cycle walking */
+int gv_perm_sample(int64_t n, int64_t k, uint64_t seed, uint64_t tick, uint32_t stream_id, int32_t* out, void* stream);
+/* np.unique((a, b), return_inverse=True) (kgvae/utils.py:103-105) for ids in [0, num_ids): uniq = the sorted distinct ids
+ * (first min(count, uniq_cap) of them), a_local / b_local = their ranks, *count = how many (device int32) */
+int64_t gv_relabel_workspace_bytes(int num_ids);
+int gv_relabel_pairs(const int32_t* a, const int32_t* b, int64_t k, int num_ids, int32_t* uniq, int uniq_cap, int32_t* a_local,
+                     int32_t* b_local, int32_t* count, void* workspace, int64_t workspace_bytes, void* stream);
+/* utils.negative_sampling (kgvae/utils.py:158-171): samples (k*(neg_rate+1), 3) int64 = the k positives (s, r, o) followed by
+ * neg_rate corrupted copies in np.tile order, labels 1 / 0.  Corruption j*k + p replaces the subject (hit_subject != 0) or the
+ * object of positive p by values[j*k + p]; with values == hit_subject == NULL the draws are made here: value =
+ * mulhi(u32, *n_entities_dev), hit_subject = top bit of a second u32 (Philox counter = the corruption's index). */
+int gv_negative_sampling(const int32_t* s, const int32_t* r, const int32_t* o, int64_t k, int neg_rate,
+                         const int32_t* n_entities_dev, const int32_t* values, const uint8_t* hit_subject, uint64_t seed,
+                         uint64_t tick, uint32_t stream_id, int64_t* samples, float* labels, void* stream);
+/* utils.build_graph_from_triplets + comp_deg_norm (kgvae/utils.py:127-150): triplets keep[0..m) (keep == NULL: the first m) of
+ * (s, r, o) plus their reverse edges (relation + num_rels), 2m edges in (dst, src, rel) order, norm = 1 / in-degree of each
+ * edge's destination.  n_nodes_bound: any bound on the node ids (it only sizes the sort key). */
+int64_t gv_graph_from_triplets_workspace_bytes(int64_t m, int n_nodes_bound, int num_rels);
+int gv_graph_from_triplets(const int32_t* s, const int32_t* r, const int32_t* o, const int32_t* keep, int64_t m,
+                           int n_nodes_bound, int num_rels, int32_t* src2, int32_t* dst2, int32_t* rel2, float* norm,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,3 +53,45 @@ def normals(seed, tick, stream, n):
         th = np.float32(6.283185307179586) * (x[:, b] * s)
         out[:, o], out[:, o + 1] = r * np.cos(th), r * np.sin(th)
     return out.reshape(-1)[:n]
+
+
+# ---- the batch sampler's draws (include/gcnvae.h: gv_perm_sample, gv_negative_sampling) ---------------------------------
+def _philox_x(seed, tick, stream, c0):
+    ctr = np.zeros((len(c0), 4), dtype=np.uint32)
+    ctr[:, 0] = np.asarray(c0, dtype=np.uint64).astype(np.uint32)
+    ctr[:, 1] = np.uint32(stream & 0xFFFFFFFF)
+    ctr[:, 2] = tick & 0xFFFFFFFF
+    ctr[:, 3] = (tick >> 32) & 0xFFFFFFFF
+    return philox4x32_10((seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF), ctr)
+
+
+def feistel_permute(x, bits, seed, tick, stream):
+    """One application of the keyed permutation of [0, 2^bits): 4-round unbalanced Feistel network."""
+    x = np.asarray(x, dtype=np.uint64)
+    la, rb = bits // 2, bits - bits // 2
+    l, r = x >> np.uint64(rb), x & np.uint64((1 << rb) - 1)
+    for rnd in range(4):
+        f = _philox_x(seed, tick, (stream + 0x10000 * (rnd + 1)) & 0xFFFFFFFF, r)[:, 0].astype(np.uint64) & np.uint64((1 << la) - 1)
+        l, r = r, l ^ f
+        la, rb = rb, la
+    return (l << np.uint64(rb)) | r
+
+
+def perm_sample(n, k, seed, tick, stream):
+    """First k outputs of the keyed permutation of [0, n) (cycle walking), int64 (k,)."""
+    bits = 2
+    while (1 << bits) < n:
+        bits += 1
+    x = np.arange(k, dtype=np.uint64)
+    todo = np.ones(k, dtype=bool)
+    while todo.any():
+        x[todo] = feistel_permute(x[todo], bits, seed, tick, stream)
+        todo = x >= n
+    return x.astype(np.int64)
+
+
+def negative_draws(total, n_entities, seed, tick, stream):
+    """(values int64 (total,), hit_subject bool (total,)): value = mulhi(u32, n_entities), coin = top bit of the second u32."""
+    raw = _philox_x(seed, tick, stream, np.arange(total, dtype=np.uint64))
+    values = (raw[:, 0].astype(np.uint64) * np.uint64(n_entities)) >> np.uint64(32)
+    return values.astype(np.int64), (raw[:, 1] >> np.uint32(31)).astype(bool)

@@ -763,3 +763,141 @@ def test_gv_build_csr_single_ordering(ops):
     assert torch.equal(valid[:, 0].long().unique(), torch.arange(n_seg, device='cuda'))       # every segment has an item
     lib_rc = lib.load().gv_build_csr(None, 5, 3, 16, None, None, None, 1, None, 1, None, 0, None)
     assert lib_rc < 0
+
+
+# ------------------------------------------------------------------------------------------------
+# the batch sampler's stages on the device == the host pipeline (sampling.py, pinned to the reference)
+def _i32(a):
+    return torch.from_numpy(np.asarray(a).astype(np.int32)).cuda().contiguous()
+
+
+@pytest.mark.parametrize('n,k', [(1, 1), (7, 7), (1000, 1000), (272115, 20000), (65536, 300), (65537, 65537)])
+def test_native_sampler_perm_sample_is_a_keyed_permutation(ops, n, k):
+    from gcn_vae_amd import lib
+    from gcn_vae_amd.lib import ptr
+    from oracle import philox
+    out = torch.empty(k, dtype=torch.int32, device='cuda')
+    lib.call('gv_perm_sample', n, k, 0x1234567890ABCDEF, 7, 0x5A01, ptr(out), lib.stream())
+    got = out.cpu().numpy().astype(np.int64)
+    assert len(np.unique(got)) == k and got.min() >= 0 and got.max() < n            # distinct: sampling without replacement
+    if k == n:
+        assert (np.sort(got) == np.arange(n)).all()
+    assert np.array_equal(got, philox.perm_sample(n, k, 0x1234567890ABCDEF, 7, 0x5A01))    # the numpy restatement, bit for bit
+    other = torch.empty(k, dtype=torch.int32, device='cuda')
+    lib.call('gv_perm_sample', n, k, 0x1234567890ABCDEF, 8, 0x5A01, ptr(other), lib.stream())
+    if n > 1000:
+        assert not torch.equal(out, other)                                               # the tick selects another permutation
+
+
+def test_native_sampler_stages_equal_host_pipeline(ops):
+    """chosen triplets -> relabel (np.unique) -> negatives from GIVEN draws -> graph from the kept half: every array equals
+    gcn_vae_amd.sampling's (whose outputs are pinned to vectors captured from the reference, tests/test_host_pipeline.py)."""
+    from gcn_vae_amd import lib, sampling
+    from gcn_vae_amd.data import synthetic_kg
+    from gcn_vae_amd.lib import ptr
+    data = synthetic_kg(3000, 17, 40000, seed=4)
+    k, neg, n_rel, num_nodes = 5000, 6, 17, 3000
+    rs = np.random.RandomState(11)
+    chosen = rs.choice(len(data.train), k, replace=False)
+    sub = data.train[chosen]
+    st = lib.stream()
+    # relabel
+    uniq_v, inv = np.unique((sub[:, 0], sub[:, 2]), return_inverse=True)
+    src_h, dst_h = np.reshape(inv, (2, -1))
+    cap = min(2 * k, num_nodes)
+    uniq, src, dst, count = (torch.empty(cap, dtype=torch.int32, device='cuda'), torch.empty(k, dtype=torch.int32, device='cuda'),
+                             torch.empty(k, dtype=torch.int32, device='cuda'), torch.empty(1, dtype=torch.int32, device='cuda'))
+    wb = int(lib.load().gv_relabel_workspace_bytes(num_nodes))
+    ws = torch.empty(wb, dtype=torch.uint8, device='cuda')
+    a_g, b_g, rel_d = _i32(sub[:, 0]), _i32(sub[:, 2]), _i32(sub[:, 1])        # held: ptr() of a temporary would dangle
+    lib.call('gv_relabel_pairs', ptr(a_g), ptr(b_g), k, num_nodes, ptr(uniq), cap, ptr(src), ptr(dst),
+             ptr(count), ptr(ws), wb, st)
+    n = int(count.item())
+    assert n == len(uniq_v) and np.array_equal(uniq[:n].cpu().numpy(), uniq_v)
+    assert np.array_equal(src.cpu().numpy(), src_h) and np.array_equal(dst.cpu().numpy(), dst_h)
+    # negatives: the host routine consumes numpy's global stream (randint, then uniform); hand the same draws to the device
+    pos = np.stack((src_h, sub[:, 1], dst_h)).transpose()
+    np.random.seed(5)
+    samples_h, labels_h = sampling.negative_sampling(pos, n, neg)
+    np.random.seed(5)
+    values = np.random.randint(n, size=k * neg)
+    coin = np.random.uniform(size=k * neg)
+    samples = torch.empty(k * (neg + 1), 3, dtype=torch.int64, device='cuda')
+    labels = torch.empty(k * (neg + 1), dtype=torch.float32, device='cuda')
+    hit = torch.from_numpy((coin > 0.5).astype(np.uint8)).cuda()
+    values_d = _i32(values)
+    lib.call('gv_negative_sampling', ptr(src), ptr(rel_d), ptr(dst), k, neg, None, ptr(values_d), ptr(hit), 0, 0, 0,
+             ptr(samples), ptr(labels), st)
+    assert np.array_equal(samples.cpu().numpy(), samples_h) and np.array_equal(labels.cpu().numpy(), labels_h)
+    # graph from a kept subset
+    keep = rs.choice(k, size=k // 2, replace=False)
+    g_h, rel_h, norm_h = sampling.build_graph_from_triplets(n, n_rel, (src_h[keep], sub[keep, 1], dst_h[keep]))
+    m = len(keep)
+    src2, dst2, rel2 = (torch.empty(2 * m, dtype=torch.int32, device='cuda') for _ in range(3))
+    norm = torch.empty(2 * m, dtype=torch.float32, device='cuda')
+    gb = int(lib.load().gv_graph_from_triplets_workspace_bytes(m, cap, n_rel))
+    gws = torch.empty(gb, dtype=torch.uint8, device='cuda')
+    keep_d = _i32(keep)
+    lib.call('gv_graph_from_triplets', ptr(src), ptr(rel_d), ptr(dst), ptr(keep_d), m, cap, n_rel, ptr(src2),
+             ptr(dst2), ptr(rel2), ptr(norm), ptr(gws), gb, st)
+    es, ed = g_h.edges()
+    assert np.array_equal(src2.cpu().numpy(), es.numpy()) and np.array_equal(dst2.cpu().numpy(), ed.numpy())
+    assert np.array_equal(rel2.cpu().numpy(), rel_h)
+    assert np.array_equal(norm.cpu().numpy(), norm_h[ed.numpy()].astype(np.float32))       # 1 / in-degree, bit for bit
+
+
+def test_native_sampler_negative_draws_match_numpy_restatement(ops):
+    from gcn_vae_amd import lib
+    from gcn_vae_amd.lib import ptr
+    from oracle import philox
+    k, neg, n_ent = 999, 4, 4321
+    rs = np.random.RandomState(0)
+    s, r, o = rs.randint(0, n_ent, k), rs.randint(0, 9, k), rs.randint(0, n_ent, k)
+    samples = torch.empty(k * (neg + 1), 3, dtype=torch.int64, device='cuda')
+    labels = torch.empty(k * (neg + 1), dtype=torch.float32, device='cuda')
+    cnt = torch.tensor([n_ent], dtype=torch.int32, device='cuda')
+    s_d, r_d, o_d = _i32(s), _i32(r), _i32(o)
+    lib.call('gv_negative_sampling', ptr(s_d), ptr(r_d), ptr(o_d), k, neg, ptr(cnt), None, None, 99, 3, 0x5A02,
+             ptr(samples), ptr(labels), lib.stream())
+    values, hit = philox.negative_draws(k * neg, n_ent, 99, 3, 0x5A02)
+    want = np.tile(np.stack([s, r, o], 1), (neg, 1))
+    want[hit, 0] = values[hit]
+    want[~hit, 2] = values[~hit]
+    got = samples.cpu().numpy()
+    assert np.array_equal(got[:k], np.stack([s, r, o], 1)) and np.array_equal(got[k:], want)
+    assert np.array_equal(labels.cpu().numpy(), np.r_[np.ones(k), np.zeros(k * neg)].astype(np.float32))
+    assert 0.4 < hit.mean() < 0.6 and values.min() >= 0 and values.max() < n_ent
+
+
+@pytest.mark.parametrize('native', [True, False])
+def test_device_sampler_batch_invariants(ops, native):
+    """Either implementation: distinct sampled triplets, sorted unique node ids, (dst, src, rel)-ordered symmetric graph,
+    norm = 1 / in-degree, positives present in the data, negatives differ from their positive in one endpoint."""
+    from gcn_vae_amd.data import synthetic_kg
+    from gcn_vae_amd.device_sampling import DeviceSampler
+    data = synthetic_kg(2000, 11, 30000, seed=1)
+    sm = DeviceSampler(data.train, 2000, 11, 'cuda', seed=3, native=native)
+    b1, b2 = sm.sample(4000, 0.5, 5), sm.sample(4000, 0.5, 5)
+    for b in (b1, b2):
+        n = b.g.number_of_nodes()
+        ids = b.node_id.view(-1).cpu().numpy()
+        assert len(ids) == n and (np.diff(ids) > 0).all()
+        samples, labels = b.samples.cpu().numpy(), b.labels.cpu().numpy()
+        assert samples.shape == (4000 * 6, 3) and labels[:4000].all() and not labels[4000:].any()
+        pos_global = np.stack([ids[samples[:4000, 0]], samples[:4000, 1], ids[samples[:4000, 2]]], 1)
+        have = set(map(tuple, data.train.tolist()))
+        assert all(tuple(t) in have for t in pos_global[:200].tolist())
+        neg = samples[4000:].reshape(5, 4000, 3)
+        same_s, same_o = neg[:, :, 0] == samples[None, :4000, 0], neg[:, :, 2] == samples[None, :4000, 2]
+        assert (same_s | same_o).all() and (neg[:, :, 1] == samples[None, :4000, 1]).all() and samples.min() >= 0 and samples[:, [0, 2]].max() < n
+        src, dst = (t.numpy() for t in b.g.edges())
+        et, norm = b.edge_type.cpu().numpy(), b.edge_norm.view(-1).cpu().numpy()
+        assert len(src) == 4000 and ((et[:, None] >= 0).all()) and et.max() < 22
+        key = (dst.astype(np.int64) * n + src) * 22 + et
+        assert (np.diff(key) >= 0).all()
+        deg = np.bincount(dst, minlength=n)
+        assert np.array_equal(norm, (1.0 / deg[dst]).astype(np.float32))
+        fwd = set(zip(src[et < 11].tolist(), dst[et < 11].tolist(), et[et < 11].tolist()))
+        rev = set(zip(dst[et >= 11].tolist(), src[et >= 11].tolist(), (et[et >= 11] - 11).tolist()))
+        assert fwd == rev
+    assert not torch.equal(b1.samples, b2.samples)

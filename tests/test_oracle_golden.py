@@ -172,3 +172,19 @@ def test_philox_known_answers():
     assert run([0xffffffff] * 4, (0xffffffff, 0xffffffff)) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert run([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], (0xa4093822, 0x299f31d0)) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_sampler_draw_restatement_known_answers():
+    """oracle/philox.py's restatement of the batch sampler's draws (gv_perm_sample, gv_negative_sampling): structural
+    properties and pinned values (the GPU tests compare the kernels against these functions bit for bit)."""
+    from oracle import philox
+    x = philox.perm_sample(272115, 20000, 123, 5, 0x5A01)
+    assert x[:8].tolist() == [97718, 268098, 203867, 234506, 222920, 146317, 253150, 53913]
+    assert len(set(x.tolist())) == 20000 and x.min() >= 0 and x.max() < 272115
+    for n in (1, 2, 3, 64, 65, 1000):
+        full = philox.perm_sample(n, n, 9, 1, 7)
+        assert sorted(full.tolist()) == list(range(n))
+    assert not np.array_equal(philox.perm_sample(1000, 1000, 9, 1, 7), philox.perm_sample(1000, 1000, 9, 2, 7))
+    v, h = philox.negative_draws(100000, 10212, 1, 2, 3)
+    assert v.min() >= 0 and v.max() < 10212 and 0.49 < h.mean() < 0.51
+    assert np.bincount(v * 10 // 10212, minlength=10).min() > 9500          # uniform over the entities
