@@ -263,6 +263,130 @@ __global__ __launch_bounds__(256) void k_rank_scores(const RankParams rp) {
     }
 }
 
+// ---- relation-grouped products for dense per-relation weights (the `basis` regulariser) ----------------
+// With W_r = sum_b w_comp[r, b] V_b a full (in x out) matrix, a message is a 2*in*out-flop mat-vec: MFMA work.  Edges are
+// taken in BY-RELATION order (ops.RelationIndex.by_rel), so the messages of one relation are one GEMM whose A rows are
+// GATHERED through an index (no materialised x[src] copy):
+//   rows, TB = false  Msg[p]  = x[src_by_rel[p]] @ W_r           p in relation r's range       (forward)
+//   rows, TB = true   Msg2[p] = g[dst_by_rel[p]] @ W_r^T                                       (backward w.r.t. x)
+//   gradw             dW_r    = sum_{p in r} x[src_by_rel[p]]^T (norm_p g[dst_by_rel[p]])      (K = the relation's edge range)
+// A 64-row tile never crosses a relation boundary: `tiles` lists (first row, end row, relation) per block row.  The
+// per-destination sum of the messages (x norm) is the K1 aggregation with 1x1 blocks over Msg (k_bdd.hip), as in DistMult.
+struct RelGemmParams {
+    const float* a;          // feature table the A rows are gathered from
+    const int* a_rows;       // row id per position (by-relation order)
+    const float* w;          // [R, in, out] dense relation weights
+    float* c;                // rows: [E, n]; gradw: [R, in, out]
+    const int4* tiles;       // rows: (row0, row_end, relation, -)
+    const float* b_feat;     // gradw: second gathered table (g)
+    const int* b_rows;       // gradw: row id per position into b_feat
+    const float* b_scale;    // gradw: per-position scale (edge norm in by-relation order), may be NULL
+    const int* relptr;       // gradw: [R + 1] position ranges
+    int lda, ldb_feat, in_feat, out_feat, n, k;      // rows: C is [*, n], inner dimension k
+    int vec;
+};
+
+template <bool TB>
+__global__ __launch_bounds__(256) void k_rel_rows(const RelGemmParams p) {
+    constexpr int BM = 64, BN = 64, BK = 16, LDA_S = BM + 1, LDB_S = BN + 1, APT = 4, BPT = 4;
+    __shared__ float As[BK * LDA_S];
+    __shared__ float Bs[BK * LDB_S];
+    const int4 tile = p.tiles[blockIdx.y];
+    const int m0 = tile.x, m_end = tile.y;
+    const float* wr = p.w + (size_t)tile.z * p.in_feat * p.out_feat;
+    const int ldb = p.out_feat;                           // W_r is [in, out] row-major
+    const int n0 = blockIdx.x * BN;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int wm = (wid >> 1) * 32, wn = (wid & 1) * 32, l31 = lane & 31, lhi = lane >> 5;
+    // A: 4 threads per row (4 consecutive k each); the row pointer is resolved once
+    const int am = m0 + t / 4, akk = (t % 4) * APT;
+    const bool a_ok = am < m_end;
+    const float* arow = p.a + (size_t)(a_ok ? p.a_rows[am] : 0) * p.lda;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float ra[APT], rb[BPT];
+    auto load_tiles = [&](int k0) {
+        load_run<APT>(arow + k0 + akk, k0 + akk, p.k, a_ok, p.vec, ra, 0);
+        if (!TB) {          // B[k][n] = W_r[k][n]: 16 threads per k row
+            const int kq = k0 + t / 16, n = n0 + (t % 16) * BPT;
+            load_run<BPT>(wr + (size_t)kq * ldb + n, n, p.n, kq < p.k, p.vec, rb, 0);
+        } else {            // B[k][n] = W_r[n][k]: 4 threads per n
+            const int n = n0 + t / 4, kq = k0 + (t % 4) * BPT;
+            load_run<BPT>(wr + (size_t)n * ldb + kq, kq, p.k, n < p.n, p.vec, rb, 0);
+        }
+    };
+    load_tiles(0);
+    for (int k0 = 0; k0 < p.k; k0 += BK) {
+        stage_a<false, BM, BK>(As, ra);
+        stage_b<TB, BN, BK>(Bs, rb);
+        __syncthreads();
+        if (k0 + BK < p.k) load_tiles(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kk + lhi) * LDA_S + wm + l31], Bs[(kk + lhi) * LDB_S + wn + l31],
+                                                       acc, 0, 0, 0);
+        __syncthreads();
+    }
+    const int col = n0 + wn + l31;
+    if (col >= p.n) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row < m_end) p.c[(size_t)row * p.n + col] = acc[r];
+    }
+}
+
+// dW_r[i][o] = sum_p x[a_rows[p]][i] * scale_p * g[b_rows[p]][o] over the relation's positions; grid (out/64, in/64, R)
+__global__ __launch_bounds__(256) void k_rel_gradw(const RelGemmParams p) {
+    constexpr int BM = 64, BN = 64, BK = 16, LDA_S = BM + 1, LDB_S = BN + 1, APT = 4, BPT = 4;
+    __shared__ float As[BK * LDA_S];
+    __shared__ float Bs[BK * LDB_S];
+    const int rel = blockIdx.z;
+    const int kbeg = p.relptr[rel], kend = p.relptr[rel + 1];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int wm = (wid >> 1) * 32, wn = (wid & 1) * 32, l31 = lane & 31, lhi = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float ra[APT], rb[BPT];
+    auto load_tiles = [&](int k0) {      // both operands: 16 threads per position (k), 4 consecutive columns each
+        const int kq = k0 + t / 16;
+        const bool ok = kq < kend;
+        const int m = m0 + (t % 16) * APT, n = n0 + (t % 16) * BPT;
+        const float* xa = p.a + (size_t)(ok ? p.a_rows[kq] : 0) * p.lda + m;
+        const float* gb = p.b_feat + (size_t)(ok ? p.b_rows[kq] : 0) * p.ldb_feat + n;
+        load_run<APT>(xa, m, p.in_feat, ok, p.vec, ra, 0);
+        load_run<BPT>(gb, n, p.out_feat, ok, p.vec, rb, 0);
+        if (p.b_scale && ok) {
+            const float sc = p.b_scale[kq];
+#pragma unroll
+            for (int i = 0; i < BPT; ++i) rb[i] *= sc;
+        }
+    };
+    if (kbeg < kend) load_tiles(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        stage_a<true, BM, BK>(As, ra);
+        stage_b<false, BN, BK>(Bs, rb);
+        __syncthreads();
+        if (k0 + BK < kend) load_tiles(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kk + lhi) * LDA_S + wm + l31], Bs[(kk + lhi) * LDB_S + wn + l31],
+                                                       acc, 0, 0, 0);
+        __syncthreads();
+    }
+    const int col = n0 + wn + l31;
+    if (col >= p.out_feat) return;
+    float* cr = p.c + (size_t)rel * p.in_feat * p.out_feat;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row < p.in_feat) cr[(size_t)row * p.out_feat + col] = acc[r];
+    }
+}
+
 // ---- bf16-operand variant (BASELINE configs[2]: bf16 with fp32 accumulation) --------------------------------------
 // Same contract and epilogue as k_gemm_f32; A and B are read as fp32 from memory, rounded to bf16 (RNE,
 // v_cvt_pk_bf16_f32) on their way into LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulators:
@@ -572,6 +696,39 @@ extern "C" int gv_rank_scores(const float* q, int ld_q, const float* e, int ld_e
     hipLaunchKernelGGL(k_rank_scores<0>, grid, block, 0, st, rp);
     hipLaunchKernelGGL(k_rank_scores<1>, grid, block, 0, st, rp);
     return launch_status("gv_rank_scores");
+}
+
+extern "C" int gv_rel_rows_gemm(const float* feat, int ld_feat, const int32_t* rows, const float* w, int num_rels, int in_feat,
+                                int out_feat, int transpose_w, const int32_t* tiles, int n_tiles, float* msg, void* stream) {
+    GV_REQUIRE(num_rels > 0 && in_feat > 0 && out_feat > 0 && n_tiles >= 0, GV_ERR_SHAPE, "gv_rel_rows_gemm: bad sizes");
+    if (n_tiles == 0) return GV_OK;
+    GV_REQUIRE(feat && rows && w && tiles && msg, GV_ERR_NULL, "gv_rel_rows_gemm: NULL pointer");
+    const int k = transpose_w ? out_feat : in_feat, n = transpose_w ? in_feat : out_feat;
+    GV_REQUIRE(ld_feat >= k, GV_ERR_SHAPE, "gv_rel_rows_gemm: ld_feat=%d < %d", ld_feat, k);
+    RelGemmParams p{};
+    p.a = feat; p.a_rows = rows; p.w = w; p.c = msg; p.tiles = (const int4*)tiles;
+    p.lda = ld_feat; p.in_feat = in_feat; p.out_feat = out_feat; p.n = n; p.k = k;
+    p.vec = aligned16(feat) && aligned16(w) && (ld_feat % 4 == 0) && (in_feat % 4 == 0) && (out_feat % 4 == 0);
+    dim3 grid((n + 63) / 64, n_tiles), block(256);
+    if (transpose_w) hipLaunchKernelGGL(k_rel_rows<true>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(k_rel_rows<false>, grid, block, 0, (hipStream_t)stream, p);
+    return launch_status("gv_rel_rows_gemm");
+}
+
+extern "C" int gv_rel_gradw_gemm(const float* x, int ld_x, const int32_t* x_rows, const float* g, int ld_g, const int32_t* g_rows,
+                                 const float* scale, const int32_t* relptr, int num_rels, int in_feat, int out_feat,
+                                 float* grad_w, void* stream) {
+    GV_REQUIRE(num_rels > 0 && in_feat > 0 && out_feat > 0, GV_ERR_SHAPE, "gv_rel_gradw_gemm: bad sizes");
+    GV_REQUIRE(x && x_rows && g && g_rows && relptr && grad_w, GV_ERR_NULL, "gv_rel_gradw_gemm: NULL pointer");
+    GV_REQUIRE(ld_x >= in_feat && ld_g >= out_feat, GV_ERR_SHAPE, "gv_rel_gradw_gemm: leading dimension too small");
+    GV_REQUIRE(num_rels <= 65535, GV_ERR_SHAPE, "gv_rel_gradw_gemm: more than 65535 relation types");
+    RelGemmParams p{};
+    p.a = x; p.a_rows = x_rows; p.lda = ld_x; p.b_feat = g; p.b_rows = g_rows; p.ldb_feat = ld_g; p.b_scale = scale;
+    p.relptr = relptr; p.c = grad_w; p.in_feat = in_feat; p.out_feat = out_feat;
+    p.vec = aligned16(x) && aligned16(g) && (ld_x % 4 == 0) && (ld_g % 4 == 0);
+    dim3 grid((out_feat + 63) / 64, (in_feat + 63) / 64, num_rels), block(256);
+    hipLaunchKernelGGL(k_rel_gradw, grid, block, 0, (hipStream_t)stream, p);
+    return launch_status("gv_rel_gradw_gemm");
 }
 
 extern "C" int gv_colsum_finish(const float* part, int n, int n_slices, float* out, int accumulate, void* stream) {

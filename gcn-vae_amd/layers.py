@@ -10,6 +10,8 @@ parameters ``weight`` [(R, B*si*so) for "bdd", (nb, in, out) for "basis"], ``w_c
 ``h_bias`` (zeros), ``loop_weight``; xavier_uniform with relu gain, created in DGL's order so that a
 seeded construction reproduces the reference's initial weights.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -120,14 +122,19 @@ class RelGraphConv(nn.Module):
         else:
             late_keep = None
         if self.regularizer == 'bdd':
-            weight, nb = self.weight, self.num_bases
+            h = ops.rel_graph_conv_bdd(x, self.weight, h_bias, loop_w, norm, gidx, ridx, self.num_bases, act_id, keep,
+                                       scale if keep is not None else 1.0, self.reduce_hook)
         else:
-            # basis: W_r = sum_b w_comp[r, b] V_b, then one dense (in x out) "block" per relation
+            # basis: W_r = sum_b w_comp[r, b] V_b (one MFMA GEMM), then a full (in x out) matrix per relation
             flat = self.weight.view(self.num_bases, self.in_feat * self.out_feat)
             weight = ops.matmul(self.w_comp, flat) if self.num_bases < self.num_rels else flat
-            nb = 1
-        h = ops.rel_graph_conv_bdd(x, weight, h_bias, loop_w, norm, gidx, ridx, nb, act_id, keep,
-                                   scale if keep is not None else 1.0, self.reduce_hook)
+            if self.reduce_hook is not None or os.environ.get('GV_BASIS_GENERIC', '0') == '1':
+                # edge-sharded multi-GPU hook / cross-check: the generic K1 kernels (one dense "block" per relation)
+                h = ops.rel_graph_conv_bdd(x, weight, h_bias, loop_w, norm, gidx, ridx, 1, act_id, keep,
+                                           scale if keep is not None else 1.0, self.reduce_hook)
+            else:
+                h = ops.rel_graph_conv_dense(x, weight.view(self.num_rels, self.in_feat, self.out_feat), h_bias, loop_w, norm,
+                                             gidx, ridx, act_id, keep, scale if keep is not None else 1.0)
         if post_act is not None:
             h = post_act(h)
             if late_keep is not None:

@@ -345,6 +345,29 @@ class RelationIndex:
         if _os.environ.get('GV_GRADW_XCD', '1') == '1' and not g.sync_free and self.by_rel.seg.n_items >= 1024:
             self._xcd_order_items()
 
+    def dense_plan(self, g: 'GraphIndex'):
+        """Extras of the dense-weight (`basis`) path, built once per index: 64-row GEMM tiles that never cross a relation
+        boundary, and for every position of the by-destination / by-source orders the position of the same edge in the
+        by-relation order (where its message row lives)."""
+        hit = getattr(self, '_dense_plan', None)
+        if hit is None:
+            dev, E = g.device, g.num_edges
+            rp = self.by_rel.seg.rowptr.long()
+            n_t = (rp[1:] - rp[:-1] + 63) // 64                                   # tiles per relation
+            rel_of_tile = torch.repeat_interleave(torch.arange(self.num_rels, device=dev), n_t)
+            first = torch.cumsum(n_t, 0) - n_t
+            k_in_rel = torch.arange(rel_of_tile.numel(), device=dev) - first[rel_of_tile]
+            row0 = rp[:-1][rel_of_tile] + 64 * k_in_rel
+            row1 = torch.minimum(row0 + 64, rp[1:][rel_of_tile])
+            tiles = torch.stack([row0, row1, rel_of_tile, torch.zeros_like(row0)], 1).to(torch.int32).contiguous()
+            inv = torch.empty(E, dtype=torch.int64, device=dev)
+            inv[self.by_rel.perm.long()] = torch.arange(E, device=dev)
+            pos_by_dst = (inv if g.by_dst.perm is None else inv[g.by_dst.perm.long()]).to(torch.int32).contiguous()
+            pos_by_src = inv[g.by_src.perm.long()].to(torch.int32).contiguous()
+            zeros = torch.zeros(max(E, 1), dtype=torch.int32, device=dev)
+            hit = self._dense_plan = (tiles, int(tiles.shape[0]), pos_by_dst, pos_by_src, zeros)
+        return hit
+
     def coef_in_rel_order(self, coef: torch.Tensor) -> torch.Tensor:
         """Per-edge coefficients permuted into the by-relation order of the grad-W launch (cached like
         GraphIndex.coef_in_src_order)."""
@@ -874,6 +897,89 @@ def rel_graph_conv_bdd(x, weight, h_bias, loop_weight, norm, gidx, ridx, num_bas
                        keep_scale=1.0, reduce_hook=None):
     return _RelGraphConvBdd.apply(x, weight, h_bias, loop_weight, norm, gidx, ridx, num_bases, act, keep,
                                   float(keep_scale), reduce_hook)
+
+
+def rel_rows_gemm(feat, rows, w3, transpose_w, tiles, n_tiles, n_edges):
+    """msg[p] = feat[rows[p]] @ W_r (or W_r^T) for the edges in by-relation order; w3 is (R, in, out)."""
+    feat, ld = _row_major(feat, 'feat')
+    w3 = _chk(w3, name='dense relation weights')
+    r, fin, fout = w3.shape
+    msg = torch.empty(n_edges, fin if transpose_w else fout, dtype=torch.float32, device=feat.device)
+    lib.call('gv_rel_rows_gemm', ptr(feat), ld, ptr(rows), ptr(w3), r, fin, fout, 1 if transpose_w else 0, ptr(tiles), n_tiles,
+             ptr(msg), lib.stream())
+    return msg
+
+
+class _RelGraphConvDense(torch.autograd.Function):
+    """RelGraphConv with a full (in x out) matrix per relation -- the `basis` regulariser after W_r = sum_b w_comp[r,b] V_b
+    (DGL's basis_message_func).  Messages are relation-grouped f32 MFMA GEMMs with gathered rows
+    (gv_rel_rows_gemm, edges in by-relation order); their per-destination sum, x norm, + self loop + bias, activation and
+    dropout is the K1 aggregation with 1x1 blocks over the message rows.  Backward: the same two steps transposed for
+    dL/dx, one relation-grouped (in x E_r) @ (E_r x out) product per relation for dL/dW."""
+
+    @staticmethod
+    def forward(ctx, x, w3, h_bias, loop_weight, norm, gidx, ridx, act, keep, keep_scale):
+        x, _ = _row_major(x, 'x')
+        n, fin = x.shape
+        r, fin_w, fout = w3.shape
+        if fin_w != fin:
+            raise ValueError(f'dense relation weights are {tuple(w3.shape)}, x has {fin} columns')
+        coef = None if norm is None else norm.reshape(-1)
+        tiles, n_tiles, pos_d, pos_s, zeros = ridx.dense_plan(gidx)
+        addend = None
+        if loop_weight is not None:
+            addend = gemm(x, loop_weight, bias=h_bias)
+        elif h_bias is not None:
+            addend = h_bias.unsqueeze(0).expand(n, fout).contiguous()
+        msg = rel_rows_gemm(x, ridx.src_by_rel, w3, False, tiles, n_tiles, gidx.num_edges)
+        ones = torch.ones(1, fout, dtype=torch.float32, device=x.device)
+        out = bdd_aggregate(gidx.by_dst.seg, pos_d, zeros, coef, gidx.by_dst.perm, msg, ones, fout, 1, 1, False, addend, act,
+                            keep, keep_scale)
+        ctx.save_for_backward(x, w3, loop_weight, coef, out if act == ACT_RELU else None, keep)
+        ctx.meta = (gidx, ridx, act, keep_scale, h_bias is not None)
+        ctx.direct = (_direct(h_bias), _direct(loop_weight))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, w3, loop_weight, coef, out, keep = ctx.saved_tensors
+        gidx, ridx, act, keep_scale, has_bias = ctx.meta
+        d_b, d_l = ctx.direct
+        r, fin, fout = w3.shape
+        tiles, n_tiles, pos_d, pos_s, zeros = ridx.dense_plan(gidx)
+        grad_bias = grad_loop = grad_x = grad_w = None
+        if has_bias and ctx.needs_input_grad[2]:
+            grad_bias = d_b if d_b is not None else torch.empty(fout, dtype=torch.float32, device=x.device)
+            g = epilogue_bwd(out, grad_out, act, keep, keep_scale, colsum_out=grad_bias, colsum_accumulate=d_b is not None)
+            if d_b is not None:
+                grad_bias = None
+        else:
+            g = epilogue_bwd(out, grad_out, act, keep, keep_scale)
+        gx_loop = None
+        if loop_weight is not None:
+            if ctx.needs_input_grad[3]:
+                grad_loop = gemm(x, g, trans_a=True, split_k=pick_split_k(fin, fout, x.shape[0]), out=d_l,
+                                 accumulate=d_l is not None)
+                if d_l is not None:
+                    grad_loop = None
+            if ctx.needs_input_grad[0]:
+                gx_loop = gemm(g, loop_weight, trans_b=True)
+        if ctx.needs_input_grad[0]:
+            msg2 = rel_rows_gemm(g, ridx.dst_by_rel, w3, True, tiles, n_tiles, gidx.num_edges)
+            ones = torch.ones(1, fin, dtype=torch.float32, device=x.device)
+            coef_s, idx_s = (gidx.coef_in_src_order(coef), None) if coef is not None else (None, None)
+            grad_x = bdd_aggregate(gidx.by_src.seg, pos_s, zeros, coef_s, idx_s, msg2, ones, fin, 1, 1, False, gx_loop)
+        if ctx.needs_input_grad[1]:
+            g2, ld_g = _row_major(g, 'g')
+            grad_w = torch.empty_like(w3)
+            scale = ridx.coef_in_rel_order(coef) if coef is not None else None
+            lib.call('gv_rel_gradw_gemm', ptr(x), x.stride(0), ptr(ridx.src_by_rel), ptr(g2), ld_g, ptr(ridx.dst_by_rel),
+                     ptr(scale), ptr(ridx.by_rel.seg.rowptr), r, fin, fout, ptr(grad_w), lib.stream())
+        return grad_x, grad_w, grad_bias, grad_loop, None, None, None, None, None, None
+
+
+def rel_graph_conv_dense(x, w3, h_bias, loop_weight, norm, gidx, ridx, act=ACT_NONE, keep=None, keep_scale=1.0):
+    return _RelGraphConvDense.apply(x, w3, h_bias, loop_weight, norm, gidx, ridx, act, keep, float(keep_scale))
 
 
 class _RelGraphConvRows(torch.autograd.Function):

@@ -119,6 +119,18 @@ int gv_rgcn_epilogue_bwd(const float* out, const float* grad_out, int act, const
  * slices in a fixed order. */
 #define GV_EPILOGUE_COLSUM_SLICES 1024
 int gv_colsum_finish(const float* part, int n, int n_slices, float* out, int accumulate, void* stream);
+/* ---- dense per-relation weights (the `basis` regulariser after W_r = sum_b w_comp[r, b] V_b) -----------------
+ * Edges in BY-RELATION order; one f32 MFMA GEMM per relation with GATHERED A rows, 64-row tiles that never cross a relation
+ * boundary (tiles: int32 [n_tiles, 4] = first position, end position, relation, 0):
+ *   msg[p, :] = feat[rows[p], :] @ W_r (transpose_w = 0: feat = x, rows = sources; msg is [E, out])
+ *             = feat[rows[p], :] @ W_r^T (transpose_w = 1: feat = dL/dh, rows = destinations; msg is [E, in])
+ * w is [R, in, out] row-major.  The per-node sums of the messages are gv_rgcn_bdd_aggregate with 1x1 blocks over msg. */
+int gv_rel_rows_gemm(const float* feat, int ld_feat, const int32_t* rows, const float* w, int num_rels, int in_feat,
+                     int out_feat, int transpose_w, const int32_t* tiles, int n_tiles, float* msg, void* stream);
+/* grad_w[r] = sum_{p in [relptr[r], relptr[r+1])} x[x_rows[p], :]^T (scale[p] * g[g_rows[p], :])   ([R, in, out], overwritten) */
+int gv_rel_gradw_gemm(const float* x, int ld_x, const int32_t* x_rows, const float* g, int ld_g, const int32_t* g_rows,
+                      const float* scale, const int32_t* relptr, int num_rels, int in_feat, int out_feat, float* grad_w,
+                      void* stream);
 /* Evaluation scorer with a fused rank count (replaces the (h, Eb, V) outer-product tensor + sort of
  * utils.perturb_and_get_rank / sort_and_rank, kgvae/utils.py:180-221): prob = sigmoid(q @ e^T + *bias) is formed tile by
  * tile on the f32 MFMA and never stored;  count[i] = #{ j != target[i] : prob[i, j] > prob[i, target[i]] }  = the raw rank

@@ -440,6 +440,48 @@ def test_basis_regularizer_layer(ops):
             close(v.grad, po[k].grad, rtol=2e-4, atol_scale=2e-5, msg='basis grad ' + k)
 
 
+@pytest.mark.parametrize('fin,fout,act', [(200, 200, 'relu'), (200, 400, None), (64, 36, 'relu')])
+def test_basis_dense_path_equals_generic_path_and_oracle(ops, fin, fout, act, monkeypatch):
+    """SURVEY 8(f-3) at FB15k-237 widths: the relation-grouped MFMA path (gv_rel_rows_gemm / gv_rel_gradw_gemm + 1x1 K1
+    aggregation) against the generic per-edge kernels on the same inputs, and against the CPU oracle."""
+    from gcn_vae_amd.graph import KGraph
+    from gcn_vae_amd.layers import RelGraphConv
+    n, e, r, nb = 1500, 6000, 40, 8
+    src, dst, et, norm = zipf_graph(n, e, r, seed=21)
+    torch.manual_seed(3)
+    activation = torch.relu if act == 'relu' else None
+    layer = RelGraphConv(fin, fout, r, 'basis', nb, activation=activation, self_loop=True, dropout=0.0)
+    with torch.no_grad():
+        layer.h_bias.normal_(0, 0.1)
+    x, gout = torch.randn(n, fin), torch.randn(n, fout)
+    po = {k: v.detach().clone().requires_grad_(True) for k, v in layer.named_parameters()}
+    xo = x.clone().requires_grad_(True)
+    ho = orgcn.rel_graph_conv(xo, src, dst, et, norm, po, 'basis', nb, activation)
+    ho.backward(gout)
+    g = KGraph()
+    g.add_nodes(n)
+    g.add_edges(src, dst)
+    layer = layer.cuda()
+    results = {}
+    for mode in ('dense', 'generic'):
+        monkeypatch.setenv('GV_BASIS_GENERIC', '1' if mode == 'generic' else '0')
+        layer.zero_grad()
+        xg = x.cuda().requires_grad_(True)
+        hg = layer(g, xg, et.cuda(), norm.cuda())
+        hg.backward(gout.cuda())
+        results[mode] = (hg.detach(), xg.grad.detach(), {k: v.grad.detach().clone() for k, v in layer.named_parameters()})
+    hd, gxd, gpd = results['dense']
+    hgn, gxg, gpg = results['generic']
+    close(hd, hgn, rtol=2e-5, atol_scale=2e-6, msg='dense vs generic forward')
+    close(gxd, gxg, rtol=2e-5, atol_scale=2e-6, msg='dense vs generic grad_x')
+    for k in gpd:
+        close(gpd[k], gpg[k], rtol=1e-4, atol_scale=1e-5, msg='dense vs generic grad ' + k)
+    close(hd, ho, msg='basis forward vs oracle')
+    close(gxd, xo.grad, msg='basis grad_x vs oracle')
+    for k, v in gpd.items():
+        close(v, po[k].grad, rtol=2e-4, atol_scale=2e-5, msg='basis grad vs oracle ' + k)
+
+
 def test_odd_widths_and_degenerate_graphs(ops):
     # feature widths that are not multiples of 4 take the generic kernels and the scalar GEMM loads
     n, e, r, fin, fout, nb = 70, 400, 5, 9, 15, 3
