@@ -294,10 +294,16 @@ def main():
     if want in ('edge', 'auto') or not dist_on:
         modes['edge'] = edge_in
     if dist_on and want in ('row', 'auto'):
-        wr = make_workload_rows(rank, world, args, dev, w)
-        modes['row'] = dict(g=wr['g'], node_id=wr['node_id'], etype=wr['rel'], enorm=wr['enorm'], samples=wr['samples'],
-                            labels=wr['labels'], pick_map=wr['pos_of_node'], part=wr['part'], seed=1000 + rank,
-                            edges=wr['edges'])
+        try:
+            wr = make_workload_rows(rank, world, args, dev, w)
+            modes['row'] = dict(g=wr['g'], node_id=wr['node_id'], etype=wr['rel'], enorm=wr['enorm'], samples=wr['samples'],
+                                labels=wr['labels'], pick_map=wr['pos_of_node'], part=wr['part'], seed=1000 + rank,
+                                edges=wr['edges'])
+        except Exception as exc:
+            if want == 'row':
+                raise
+            print(f'[bench] row-partition workload failed on rank {rank}: {type(exc).__name__}: {exc}', file=sys.stderr)
+            modes['row'] = None           # dropped by every rank at the agreement point below
     hook = gdist.make_reduce_hook() if dist_on else None
     cur = {}
 
@@ -402,17 +408,36 @@ def main():
     # remove the per-kernel host cost but add a graph launch per segment; "auto" measures instead of guessing.
     programs, probe = {}, {}
     auto = dist_on and args.partition == 'auto'
-    for name in modes:
-        configure(name)
-        warm(2)
+    def agreed(ok):
+        """True only if EVERY rank got through the stage: all ranks keep or drop a scheme together."""
+        if world > 1:
+            flag = torch.tensor([1 if ok else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+        return ok
+
+    for name in list(modes):
+        ok = modes[name] is not None
+        try:
+            if ok:
+                configure(name)
+                warm(2)
+        except Exception as exc:      # a scheme that cannot even step is dropped (by every rank), not fatal
+            print(f'[bench] scheme {name!r} failed on rank {rank}: {type(exc).__name__}: {exc}', file=sys.stderr)
+            ok = False
+        if not agreed(ok):
+            del modes[name]
+            continue
         variants = [use_segments] if not (auto and use_segments) else [True, False]
         for sgm in variants:
-            key = name if len(variants) == 1 else '%s/%s' % (name, 'segments' if sgm else 'eager')
+            key = name if (len(variants) == 1 and not auto) else '%s/%s' % (name, 'segments' if sgm else 'eager')
             programs[key] = (name,) + capture_current(sgm)
-            if len(modes) * len(variants) > 1:
+            if auto or len(modes) * len(variants) > 1:
                 k = max(1, args.probe_steps)
                 timed_run(1, programs[key][2])
                 probe[key] = timed_run(k, programs[key][2])[0] / k * 1e3
+    if not programs:
+        raise RuntimeError('bench.py: no multi-GPU scheme could run a step (see the messages above)')
     chosen = min(probe, key=probe.get) if probe else next(iter(programs))   # identical on all ranks (max-reduced times)
     mode_name, launch, replay, static_loss = programs[chosen]
     if cur.get('name') != mode_name:
