@@ -78,13 +78,15 @@ class AllReduceSum(torch.autograd.Function):
     def forward(ctx, x, group):
         ctx.group = group
         y = x.clone()
-        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        if dist.is_initialized():
+            start_collective(lambda: dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group, async_op=True)).wait()
         return y
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous().clone()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        if dist.is_initialized():
+            start_collective(lambda: dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group, async_op=True)).wait()
         return g, None
 
 

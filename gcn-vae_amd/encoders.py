@@ -168,9 +168,8 @@ class KGVAE(nn.Module):
         """forward() under the destination-row partition: embedding lookup of all positions (replicated), layer 1 on the
         rank's rows, all-gather, layer 2 on the rank's rows, reparameterisation of the rank's rows, all-gather of z."""
         from .distributed import AllGatherRows
+        from .distributed import AllReduceSum
         part = self.row_part
-        if self.n_flows > 0:
-            raise NotImplementedError('the row partition runs the flow-free encoder (n_flows = 0)')
         c = part.own_rows
         x0 = self.input_layer(g, h, r, norm)                                   # (total_rows, h)
         eps = self._draw_noise(c, x0.device)
@@ -179,10 +178,31 @@ class KGVAE(nn.Module):
         h1 = self.rconv_layer_1.forward_rows(g, x0, r, norm, part, gather_input=False, pad_output=True)
         h2 = self.rconv_layer_2.forward_rows(g, h1, r, norm, part, gather_input=True, pad_output=False)
         z, self.z_mean, self.z_sigma = ops.reparam(h2, eps)
-        self.z_own = z
         self.flow_log_prob = None
         self._z_pri_flowed = None
+        if self.n_flows > 0:
+            # the flows are row-wise: they run on the rank's rows; flow_log_prob = mean over ALL rows of the row sums
+            z, log_det_sum = self._apply_flows(z)
+            self.flow_log_prob = (AllReduceSum.apply(log_det_sum.sum().reshape(1), part.group) / part.real_rows).reshape(())
+        self.z_own = z
         return AllGatherRows.apply(ops.pad_rows(z, part.slot_rows), part)
+
+    def _apply_flows(self, z):
+        """The IAF stack on the rows of z (kgvae/model.py:116-123); get_mmd's prior rows ride along when announced.
+        Returns (z after the flows, per-row sum of the MADE log-determinants)."""
+        n = z.shape[0]
+        ride_along = self.batch_mmd_prior_with_forward and self.training
+        if ride_along:
+            z = torch.cat([z, self._prior_draw(z.device, z.dtype)], dim=0)
+        log_det_sum = None
+        for flow in self.nf:
+            z, log_det = flow.forward(z)
+            if isinstance(flow, MADE):            # PermuteLayer contributes zeros
+                log_det_sum = log_det if log_det_sum is None else log_det_sum + log_det
+        if ride_along:
+            self._z_pri_flowed = z[n:]
+            z, log_det_sum = z[:n], log_det_sum[:n]
+        return z, log_det_sum
 
     def forward(self, g, h, r, norm):
         self.node_id = h.squeeze()
@@ -195,18 +215,7 @@ class KGVAE(nn.Module):
         z, self.z_mean, self.z_sigma = ops.reparam(h, eps)
         self._z_pri_flowed = None
         if self.n_flows > 0:
-            n = z.shape[0]
-            ride_along = self.batch_mmd_prior_with_forward and self.training
-            if ride_along:
-                z = torch.cat([z, self._prior_draw(z.device, z.dtype)], dim=0)
-            log_det_sum = None
-            for flow in self.nf:
-                z, log_det = flow.forward(z)
-                if isinstance(flow, MADE):            # PermuteLayer contributes zeros
-                    log_det_sum = log_det if log_det_sum is None else log_det_sum + log_det
-            if ride_along:
-                self._z_pri_flowed = z[n:]
-                z, log_det_sum = z[:n], log_det_sum[:n]
+            z, log_det_sum = self._apply_flows(z)
             self.flow_log_prob = torch.mean(log_det_sum.view(-1, 1))
         return z
 

@@ -103,19 +103,23 @@ def test_bench_two_ranks_each_partition(partition):
         assert sum(ec) == 2 * d['config']['edges_per_gpu'] and max(ec) < 1.2 * min(ec)
 
 
-def test_row_partition_single_rank_equals_whole_graph_run():
+@pytest.mark.parametrize('flows', ['0', '2'])
+def test_row_partition_single_rank_equals_whole_graph_run(flows):
     """world 1: the destination-row path (rectangular index, ops.rel_graph_conv_rows, the loss shares) with local copies
-    in place of the collectives equals the ordinary single-GPU path."""
+    in place of the collectives equals the ordinary single-GPU path (flows = IAF blocks on the rank's rows)."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'workers', 'dist_rows_worker.py')], cwd=ROOT,
-                         env=dict(os.environ, WORLD_SIZE='1'), capture_output=True, text=True, timeout=600)
+                         env=dict(os.environ, WORLD_SIZE='1', GV_WORKER_FLOWS=flows), capture_output=True, text=True,
+                         timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:] + '\n' + out.stderr[-2500:])
     assert out.stdout.count('worst rel err') == 1, out.stdout[-1500:]
 
 
-def test_two_ranks_row_partition_equals_single_process():
+@pytest.mark.parametrize('flows', ['0', '2'])
+def test_two_ranks_row_partition_equals_single_process(flows):
     """world_size 2 on ONE GPU (gloo): every rank owns a block of node rows and the edges ending in them; all-gather of
-    layer-1 rows and of z, reduce-scatter of their gradients, summed parameter gradients == the single-process run."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    layer-1 rows and of z, reduce-scatter of their gradients, summed parameter gradients == the single-process run.
+    flows = 2: the IAF stack runs on the rank's rows, flow_log_prob is the all-reduced mean of the row sums."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GV_WORKER_FLOWS=flows)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(free_port()), os.path.join(ROOT, 'tests', 'workers', 'dist_rows_worker.py')]
     out = run_ranks(cmd, env, 600)

@@ -39,7 +39,7 @@ def main():
     src, dst = (t.numpy() for t in g_full.edges())
     torch.manual_seed(0)
     net = LinkPredict(KGVAE, n, h, n_rel, num_bases=nb, num_hidden_layers=2, dropout=0.2, use_cuda=True, reg_param=0.01,
-                      kl_param=1e-3, mmd_param=1.0, k=10, n_flows=0).to(dev).train()
+                      kl_param=1e-3, mmd_param=1.0, k=10, n_flows=int(os.environ.get('GV_WORKER_FLOWS', '0'))).to(dev).train()
     gen = torch.Generator().manual_seed(1)
     eps, eps_prior = torch.randn(n, h, generator=gen).to(dev), torch.randn(200, h, generator=gen).to(dev)
     keep1 = (torch.rand(n, h, generator=gen) > 0.2).to(torch.uint8).to(dev)
