@@ -338,8 +338,10 @@ def main():
         opt.step()
         return loss
 
+    side = torch.cuda.Stream()      # ONE side stream for warm-up and capture (autograd pins AccumulateGrad nodes to the
+    #                                 stream of a parameter's first use: capturing elsewhere drags that stream into the capture)
+
     def warm(k):
-        side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(k):
@@ -358,7 +360,7 @@ def main():
             sg, out = SegmentedGraph(), None
             try:
                 refresh_host_inputs()
-                out = sg.capture(step_body)
+                out = sg.capture(step_body, stream=side)
             except Exception as exc:
                 print(f'[bench] segmented capture failed on rank {rank}: {type(exc).__name__}: {exc}; running eagerly',
                       file=sys.stderr)
@@ -374,7 +376,7 @@ def main():
         elif use_graph:
             try:
                 gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr):
+                with torch.cuda.graph(gr, stream=side):
                     out = step_body()
                 return 'hipgraph', gr.replay, out
             except Exception as exc:      # capture refused (e.g. a collective that cannot be captured): run eagerly

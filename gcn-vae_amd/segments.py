@@ -72,8 +72,11 @@ class SegmentedGraph:
         self.actions.append(('wait', idx))
         self._begin()
 
-    def capture(self, fn):
-        """Run ``fn()`` once on a side stream, recording it as segments.  Returns fn's result (static tensors)."""
+    def capture(self, fn, stream=None):
+        """Run ``fn()`` once on a side stream, recording it as segments.  Returns fn's result (static tensors).
+        ``stream``: the side stream the step was WARMED UP on.  autograd pins every AccumulateGrad node to the stream of
+        the parameter's first use; a capture on another stream makes the engine synchronise the two, the warm-up stream
+        joins the capture, and a segment that ends in the middle of the backward pass then ends with unjoined work."""
         from . import distributed as gdist
         if gdist.RECORDER is not None:
             raise RuntimeError('a SegmentedGraph capture is already running')
@@ -81,7 +84,7 @@ class SegmentedGraph:
         gc.collect()
         torch.cuda.empty_cache()
         self.pool = torch.cuda.graph_pool_handle()
-        side = torch.cuda.Stream()
+        side = stream if stream is not None else torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         gdist.RECORDER = self
         self.recording = True

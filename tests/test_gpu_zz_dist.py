@@ -35,6 +35,7 @@ def free_port():
 
 @pytest.mark.parametrize('extra', [['--partition', 'edge'], ['--no-graph', '--partition', 'edge'],
                                    ['--no-graph', '--partition', 'row'], ['--partition', 'row'], [],
+                                   ['--partition', 'row', '--n-flows', '1'], ['--partition', 'edge', '--n-flows', '1'],
                                    ['--graph-collectives', '--partition', 'edge']])
 def test_bench_single_rank_rccl(extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
