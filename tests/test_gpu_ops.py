@@ -372,6 +372,49 @@ def test_lane_packed_weights_are_bit_identical(ops, fin, fout, nb):
     assert not ops.pack_supported(200, 1, 1, False) and not ops.pack_supported(20, 10, 10, False)
 
 
+@pytest.mark.parametrize('fin,fout,nb,n,e,r', [(500, 1000, 100, 400, 9000, 120), (200, 400, 100, 300, 5000, 120), (16, 16, 4, 50, 0, 5),
+                                               (40, 40, 40, 700, 30000, 47)])
+def test_relation_grouped_order_equals_plain_order(ops, fin, fout, nb, n, e, r):
+    """RelationIndex.grouped_order (a row's edges by relation range, one range per XCD -- for weight tables that overflow
+    an XCD's L2): the layer's forward and every gradient equal the plain (neighbour, relation) order up to fp32 rounding."""
+    src, dst, et, norm = zipf_graph(n, e, r, seed=fin + e)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(n, fin, generator=gen)
+    p = orgcn.init_params(fin, fout, r, 'bdd', nb, True, True, gen)
+    p['h_bias'] = torch.randn(fout, generator=gen) * 0.1
+    keep = (torch.rand(n, fout, generator=gen) > 0.2).to(torch.uint8).cuda()
+    gout = torch.randn(n, fout, generator=gen).cuda()
+    gidx = ops.GraphIndex(src.cuda(), dst.cuda(), n, chunk=64)          # exact-size index (static graph)
+    ridx = gidx.relation_index(et.cuda(), r)
+    if e:
+        seg, nbr, ety, perm = ridx.grouped_order(gidx, 'dst', chunk=64)
+        it = seg.items[seg.items[:, 0] >= 0]
+        assert int((it[:, 2] - it[:, 1]).sum()) == e and int((it[:, 2] - it[:, 1]).max()) <= 64
+        assert torch.equal(torch.sort(perm)[0], torch.arange(e, device='cuda'))
+        blocks = torch.arange(seg.items.shape[0], device='cuda') // 4 % 8          # the XCD a position is dealt to
+        valid = seg.items[:, 0] >= 0
+        cnt = torch.bincount(et.cuda(), minlength=r)
+        grp_of_rel = torch.clamp((torch.cumsum(cnt, 0) - cnt) * 8 // e, max=7)
+        nonempty = valid & (seg.items[:, 2] > seg.items[:, 1])
+        first_edge_group = grp_of_rel[ety.long()[seg.items[nonempty, 1].long()]]
+        assert torch.equal(first_edge_group, blocks[nonempty])                          # every item sits on its group's XCD
+    res = {}
+    old = ops.REL_GROUPS
+    try:
+        for mode in ('1', '0'):
+            ops.REL_GROUPS = mode
+            xg = x.cuda().requires_grad_(True)
+            pg = {k: v.cuda().requires_grad_(True) for k, v in p.items()}
+            h = ops.rel_graph_conv_bdd(xg, pg['weight'], pg['h_bias'], pg['loop_weight'], norm.cuda(), gidx, ridx, nb, 1, keep,
+                                       1.25)
+            h.backward(gout)
+            res[mode] = [h.detach(), xg.grad] + [pg[k].grad for k in sorted(pg)]
+    finally:
+        ops.REL_GROUPS = old
+    for a, b in zip(res['1'], res['0']):
+        close(a, b, rtol=2e-5, atol_scale=2e-6, msg='grouped vs plain order')
+
+
 def test_edge_shard_code_path_equals_fused_path(ops):
     """The multi-GPU branch of the layer (chunked raw aggregate -> reduce hook -> separate epilogue; reduce hook on the
     backward gradient) with a no-op hook must reproduce the single-GPU fused path."""
