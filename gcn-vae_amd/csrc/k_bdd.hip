@@ -591,14 +591,22 @@ namespace {
 // P=10 -> 1 block = 40 B) and `parts` column parts (grid.y) when the row needs more than 64 lanes.
 // Returns false when no such mapping exists -> generic kernel.
 struct LanePlan { int bpl; int parts; };
-bool lane_plan(int nb, int p, LanePlan* out) {
+bool lane_plan(int nb, int p, LanePlan* out, bool aggregate = false) {
     int cands[3] = {0, 0, 0};
     switch (p) {
         case 1: cands[0] = 4; cands[1] = 2; break;
         case 2: cands[0] = 2; cands[1] = 4; cands[2] = 1; break;
         case 4: cands[0] = 1; cands[1] = 2; break;
         case 8: cands[0] = 1; break;
-        case 5: cands[0] = 2; break;
+        case 5: {
+            // aggregation: ONE 5-wide block per lane and two column parts (grid.y) instead of two blocks per lane: half the
+            // weight registers (50 instead of 100 floats per edge), 3-4 waves per SIMD instead of 1-2 with two edges in flight
+            // -- measured at h = 500: 5x10 forward 1201 -> 891 us, 5x5 forward / backward-x 529 / 523 -> 436 us, step
+            // 5.44 -> 4.91 ms, bit-identical results (GV_K1_BPL1=0 restores two blocks per lane)
+            static const int bpl1 = getenv("GV_K1_BPL1") ? atoi(getenv("GV_K1_BPL1")) : 1;
+            if (bpl1 && aggregate) { cands[0] = 1; cands[1] = 2; } else cands[0] = 2;
+            break;
+        }
         case 10: cands[0] = 1; break;
         default: return false;
     }
@@ -734,7 +742,7 @@ extern "C" int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const in
 #undef GV_PK_CASE
     }
     LanePlan lp{0, 1};
-    const bool has_plan = lane_plan(num_bases, blk_in, &lp);
+    const bool has_plan = lane_plan(num_bases, blk_in, &lp, true);
     const int bpl = has_plan ? lp.bpl : 0;
     a.nbp = has_plan ? num_bases / lp.parts : num_bases;
 #define GV_AGG_CASE(P_, Q_, T_, B_, U_)                                                               \
@@ -764,6 +772,9 @@ extern "C" int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const in
     GV_AGG_CASE(4, 4, true, 1, 4)
     GV_AGG_CASE(4, 4, true, 2, 2)
     GV_AGG_CASE(8, 4, true, 1, 2)
+    GV_AGG_CASE(5, 5, false, 1, 2)
+    GV_AGG_CASE(5, 10, false, 1, 2)
+    GV_AGG_CASE(5, 5, true, 1, 2)
     GV_AGG_CASE(5, 5, false, 2, 2)
     GV_AGG_CASE(5, 10, false, 2, 1)
     GV_AGG_CASE(5, 5, true, 2, 2)
