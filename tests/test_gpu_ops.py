@@ -986,3 +986,48 @@ def test_device_sampler_batch_invariants(ops, native):
         rev = set(zip(dst[et >= 11].tolist(), src[et >= 11].tolist(), (et[et >= 11] - 11).tolist()))
         assert fwd == rev
     assert not torch.equal(b1.samples, b2.samples)
+
+
+def test_segmented_graph_replays_the_recorded_program(ops):
+    """segments.SegmentedGraph: kernels between two "collectives" become hipGraph segments, the collectives' closures run
+    eagerly between them on every replay, a wait() directly behind its collective leaves no empty segment, tensors created
+    inside a segment stay valid for later segments, and nothing captured executes during the recording pass."""
+    from gcn_vae_amd import distributed as gdist
+    from gcn_vae_amd.segments import SegmentedGraph
+    x = torch.zeros(4096, device='cuda')
+    y = torch.zeros(4096, device='cuda')
+    calls = []
+
+    def exchange():                      # stands in for an all-reduce: an eager op on the step's own tensors
+        calls.append('exchange')
+        y.copy_(x)
+        y.mul_(2.0)
+
+    def step():
+        x.add_(1.0)                                              # segment 0
+        h = gdist.start_collective(exchange)                    # eager, between segments
+        t = x * 10.0                                             # segment 1 (runs beside the "collective")
+        h.wait()
+        z = t + y                                                # segment 2
+        gdist.start_collective(lambda: calls.append('second')).wait()      # wait right behind the call: no empty segment
+        return z + 0.5                                           # segment 3
+
+    assert gdist.RECORDER is None
+    sg = SegmentedGraph()
+    out = sg.capture(step)
+    assert gdist.RECORDER is None and calls == ['exchange', 'second']
+    assert float(x.max()) == 0.0                                 # recording executed no captured kernel
+    kinds = [k for k, _ in sg.actions]
+    assert kinds == ['graph', 'call', 'graph', 'wait', 'graph', 'call', 'wait', 'graph'], kinds
+    for i in range(1, 4):
+        sg.replay()
+        torch.cuda.synchronize()
+        assert float(x.min()) == float(i) and float(y.min()) == 2.0 * i
+        assert float(out.min()) == float(out.max()) == 10.0 * i + 2.0 * i + 0.5
+    assert calls.count('exchange') == 4 and calls.count('second') == 4
+    with pytest.raises(RuntimeError):                            # a failing step must not leave the recorder armed
+        SegmentedGraph().capture(lambda: (_ for _ in ()).throw(RuntimeError('boom')))
+    assert gdist.RECORDER is None
+    x.add_(1.0)                                                  # and ordinary eager work still runs
+    torch.cuda.synchronize()
+    assert float(x.min()) == 4.0
