@@ -24,7 +24,7 @@ from dataclasses import dataclass
 
 import torch
 
-from . import lib, ops
+from . import lib
 from .graph import KGraph
 from .lib import ptr
 
