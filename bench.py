@@ -430,10 +430,15 @@ def main():
         if not agreed(ok):
             del modes[name]
             continue
-        variants = [use_segments] if not (auto and use_segments) else [True, False]
-        for sgm in variants:
-            key = name if (len(variants) == 1 and not auto) else '%s/%s' % (name, 'segments' if sgm else 'eager')
-            programs[key] = (name,) + capture_current(sgm)
+        # (segments?, destination-row blocks of the edge scheme's chunked forward all-reduce)
+        variants = [(use_segments, 2)] if not (auto and use_segments) else [(True, 2), (False, 2)]
+        if auto and use_segments and name == 'edge':
+            variants.append((True, 1))        # one all-reduce per layer instead of two overlapped halves: 2 collectives fewer
+        for sgm, chunks in variants:
+            _ops.DIST_FWD_CHUNKS = chunks
+            key = name if (len(variants) == 1 and not auto) else '%s/%s%s' % (name, 'segments' if sgm else 'eager',
+                                                                               '' if chunks == 2 else '/1-block')
+            programs[key] = (name,) + capture_current(sgm) + (chunks,)
             if auto or len(modes) * len(variants) > 1:
                 k = max(1, args.probe_steps)
                 timed_run(1, programs[key][2])
@@ -441,7 +446,7 @@ def main():
     if not programs:
         raise RuntimeError('bench.py: no multi-GPU scheme could run a step (see the messages above)')
     chosen = min(probe, key=probe.get) if probe else next(iter(programs))   # identical on all ranks (max-reduced times)
-    mode_name, launch, replay, static_loss = programs[chosen]
+    mode_name, launch, replay, static_loss, _ops.DIST_FWD_CHUNKS = programs[chosen]
     if cur.get('name') != mode_name:
         configure(mode_name)
     T = int(cur['samples'].shape[0])

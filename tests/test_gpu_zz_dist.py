@@ -84,7 +84,8 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert d['config']['launch'] == 'eager' or d['config']['launch'].startswith('hipgraph segments')
     assert d['value'] > 0 and d['final_loss'] == d['final_loss']
     # "auto" probes both multi-GPU schemes during warm-up and runs the faster one
-    assert set(d['config']['partition_probe_ms_per_step']) == {'edge/segments', 'edge/eager', 'row/segments', 'row/eager'}
+    assert set(d['config']['partition_probe_ms_per_step']) == {'edge/segments', 'edge/eager', 'edge/segments/1-block',
+                                                               'row/segments', 'row/eager'}
     assert d['config']['partition'] in ('edge', 'row')
 
 
