@@ -20,7 +20,8 @@ class EmbeddingLayer(nn.Module):
 
     def forward(self, g, h, r, norm):
         # the lookup opens every forward pass: the device RNG's tick advances on this launch
-        return ops.embedding(self.embedding.weight, h.squeeze(), ops.device_rng(self.embedding.weight.device))
+        return ops.embedding(self.embedding.weight, h.squeeze(), ops.device_rng(self.embedding.weight.device),
+                             sole_consumer=True)
 
 
 class DistLayer(nn.Module):

@@ -858,7 +858,61 @@ class _Embedding(torch.autograd.Function):
         return (None if tgt is not None else gt), None, None
 
 
-def embedding(table, ids, tick_rng=None):
+class _EmbeddingIdentity(torch.autograd.Function):
+    """The lookup when ids == arange(num_rows) (full-graph training, kgvae/link_predict.py:141-147): no gathered copy --
+    the output aliases the table -- and no scatter-add in backward: the consuming layer writes the gradient rows straight
+    into the table's gradient (``_gv_grad_target`` on the output tells it where), or, failing that, one add."""
+
+    @staticmethod
+    def forward(ctx, table, tick_rng):
+        ctx.set_materialize_grads(False)
+        if tick_rng is not None:
+            tick_rng.tick()
+        ctx.direct = _direct(table)
+        return table.detach().view(table.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:                  # the layer already wrote the rows into the gradient arena
+            return None, None
+        g = _chk(g.contiguous(), name='grad')
+        tgt = ctx.direct
+        if tgt is None:
+            return g, None
+        lib.call('gv_axpby', g.numel(), None, 1.0, ptr(g), 1.0, ptr(tgt), lib.stream())
+        return None, None
+
+
+_identity_ids = {}
+
+
+def _ids_are_identity(table, ids):
+    """ids == arange(table rows)?  Decided once per ids tensor (one host synchronisation), cached on identity + version."""
+    if ids.numel() != table.shape[0]:
+        return False
+    key = (ids.data_ptr(), ids._version, ids.numel())
+    hit = _identity_ids.get(key)
+    if hit is None:
+        if len(_identity_ids) > 64:
+            _identity_ids.clear()
+        hit = _identity_ids[key] = bool((ids.reshape(-1) == torch.arange(ids.numel(), device=ids.device)).all())
+    return hit
+
+
+def embedding(table, ids, tick_rng=None, sole_consumer=False):
+    """table[ids].  ``sole_consumer``: the caller guarantees that ONE R-GCN layer consumes the result (the encoders' input
+    layer): with an identity lookup that layer may then write dL/dx straight into the table's gradient rows."""
+    identity = False
+    if table.is_cuda and isinstance(ids, torch.Tensor) and ids.is_cuda and ids.dtype == torch.int64:
+        if torch.cuda.is_current_stream_capturing():      # no host synchronisation under capture: only a cached verdict counts
+            identity = bool(_identity_ids.get((ids.data_ptr(), ids._version, ids.numel())))
+        else:
+            identity = _ids_are_identity(table, ids)
+    if identity:
+        out = _EmbeddingIdentity.apply(table, tick_rng)
+        if sole_consumer:
+            out._gv_grad_target = _direct(table)
+        return out
     return _Embedding.apply(table, ids, tick_rng)
 
 
@@ -926,6 +980,10 @@ class _RelGraphConvBdd(torch.autograd.Function):
         ctx.meta = (gidx, ridx, num_bases, si, so, act, keep_scale, h_bias is not None, reduce_hook)
         ctx.w_version = weight._version
         ctx.direct = (_direct(weight), _direct(h_bias), _direct(loop_weight))
+        # x is the embedding table itself (identity lookup) and this layer is its only consumer: dL/dx rows go straight
+        # into the table's gradient (zero at this point of the step: the optimiser cleared it, nothing else adds to it)
+        tgt = getattr(x, '_gv_grad_target', None)
+        ctx.x_grad_target = tgt if (tgt is not None and reduce_hook is None and tuple(tgt.shape) == tuple(x.shape)) else None
         return out
 
     @staticmethod
@@ -966,14 +1024,17 @@ class _RelGraphConvBdd(torch.autograd.Function):
                 w_bwd = pack_weight(weight, nb, so, si, True) if pk else weight
             # static graphs: the edge norm is cached in this launch's order; per-batch graphs read it through the index
             static = not gidx.sync_free and coef is not None
+            x_tgt = ctx.x_grad_target
             if ctx.grouped:
                 seg, nbr, ety, perm = ridx.grouped_order(gidx, 'src')
                 coef_g = None if coef is None else ridx.grouped_coef_src(coef, perm)
-                grad_x = bdd_aggregate(seg, nbr, ety, coef_g, None, g_agg, w_bwd, nb, so, si, True, gx_loop, packed=pk)
+                grad_x = bdd_aggregate(seg, nbr, ety, coef_g, None, g_agg, w_bwd, nb, so, si, True, gx_loop, out=x_tgt, packed=pk)
             else:
                 coef_s, idx_s = (gidx.coef_in_src_order(coef), None) if static else (coef, gidx.by_src.perm)
                 grad_x = bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, coef_s, idx_s, g_agg,
-                                       w_bwd, nb, so, si, True, gx_loop, packed=pk)
+                                       w_bwd, nb, so, si, True, gx_loop, out=x_tgt, packed=pk)
+            if x_tgt is not None:
+                grad_x = None
         grad_w = None
         if ctx.needs_input_grad[1]:
             static = not gidx.sync_free and coef is not None
