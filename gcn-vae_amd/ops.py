@@ -414,6 +414,15 @@ class RelationIndex:
                                                 perm)
         return hit
 
+    def phase_order(self, g: 'GraphIndex', side: str, num_bases: int, blk_in: int, blk_out: int) -> Optional['PhaseOrder']:
+        """Tiles x relation phases x waves edge lists for the K1 phase kernel (csrc/k_phase.hip), built once per static
+        graph, side ('dst': forward, 'src': backward w.r.t. x) and block shape; None when no phase kernel covers the shape."""
+        cache = self.__dict__.setdefault('_phases', {})
+        key = (side, int(num_bases), int(blk_in), int(blk_out), PHASE_LDS_BYTES, PHASE_ROWS, PHASE_THREADS, PHASE_BUFFERS)
+        if key not in cache:
+            cache[key] = PhaseOrder.build(self, g, side, num_bases, blk_in, blk_out)
+        return cache[key]
+
     def grouped_coef(self, coef: torch.Tensor, side: str, perm: torch.Tensor) -> torch.Tensor:
         """Per-edge coefficients in a grouped order (cached per side on the tensor's identity and version)."""
         key = (coef.data_ptr(), coef._version, coef.numel())
@@ -462,6 +471,167 @@ class RelationIndex:
         """Workgroups of one XCD cover one window of destination rows: within a relation the edges are in destination
         order, so an item gathers g[dst] rows from a narrow window, and items of similar windows then share an L2."""
         xcd_order_items(self.by_rel.seg, self.dst_by_rel)
+
+
+# K1 by relation phases (csrc/k_phase.hip).  GV_K1_PHASES: '0' never, '1' whenever a phase kernel exists, 'auto' (default):
+# static graphs, where measured faster than the per-row kernels (tools/phase_bench.py, tools/scale_check_phase.py):
+#   * the gathered table is HBM scale (>= PHASE_MIN_TABLE_BYTES: the per-row kernels then also pull the relation weights
+#     through L2 misses -- 1 M x 200 table, 2 000 relation types: 10.7 -> 7.7 ms per launch), or
+#   * the 5x10 / 10x5 blocks of the reference's default width h = 500 (20 kB of weights per relation: 892 -> 515 us and
+#     965 -> 692 us on the FB15k-237-shaped graph).
+# At h = 200 on FB15k-237 (cache-resident tables) the per-row kernels stay ahead: the phase kernel executes ~2x the
+# instructions per edge (82 vs 40, rocprofv3 SQ_INSTS_*) and is issue-bound there.
+K1_PHASES = _os.environ.get('GV_K1_PHASES', 'auto')
+PHASE_MIN_EDGES = 100_000
+PHASE_MIN_TABLE_BYTES = 192 << 20
+PHASE_LDS_BYTES = int(_os.environ.get('GV_PHASE_LDS', str(160 * 1024)))    # weight buffer(s) of one workgroup
+PHASE_ROWS = int(_os.environ.get('GV_PHASE_ROWS', '0'))                     # rows per wave (0: the shape's default)
+PHASE_THREADS = int(_os.environ.get('GV_PHASE_THREADS', '1024'))
+PHASE_BUFFERS = int(_os.environ.get('GV_PHASE_BUFFERS', '1'))               # 1: twice the relations per phase (measured faster); 2: staging overlaps compute
+
+
+def use_phases(gidx, blk_in, blk_out, transpose_w, table_rows, table_cols):
+    if K1_PHASES == '0' or gidx.sync_free or gidx.num_edges == 0:
+        return False
+    if K1_PHASES == '1':
+        return True
+    if gidx.num_edges < PHASE_MIN_EDGES:
+        return False
+    if int(table_rows) * int(table_cols) * 4 >= PHASE_MIN_TABLE_BYTES:
+        return True
+    return (blk_in, blk_out, bool(transpose_w)) in ((5, 10, False), (10, 5, True))
+
+
+@dataclass
+class PhaseOrder:
+    off: torch.Tensor          # int32 [n_tiles * nw * n_phases + 1]
+    nbr: torch.Tensor          # int32 [E]
+    meta: torch.Tensor         # int32 [E]
+    perm: torch.Tensor         # int64 [E] original edge id of each position
+    tile_items: torch.Tensor   # int32 [n_tiles, nw*K, 4]
+    n_tiles: int
+    fix: torch.Tensor
+    n_fix: int
+    n_slots: int
+    n_rows: int
+    rows_per_wave: int
+    rels_per_phase: int
+    n_phases: int
+    threads: int
+    buffers: int
+    packed_floats: int
+    transpose: bool
+
+    @staticmethod
+    def build(ridx: 'RelationIndex', g: 'GraphIndex', side: str, num_bases: int, blk_in: int, blk_out: int):
+        trans = side == 'src'
+        plan = (_ct.c_int32 * 6)()
+        if not lib.load().gv_rgcn_bdd_phase_plan(int(num_bases), int(blk_in), int(blk_out), 1 if trans else 0, ridx.num_rels,
+                                                 PHASE_LDS_BYTES, PHASE_BUFFERS, PHASE_ROWS, _ct.addressof(plan)):
+            return None
+        _bpl, _parts, K, G, n_phases, packed_floats = (int(v) for v in plan)
+        order = g.by_dst if side == 'dst' else g.by_src
+        nbr_sorted = g.nbr_by_dst if side == 'dst' else g.nbr_by_src
+        et_sorted = (ridx.et_by_dst if side == 'dst' else ridx.et_by_src).long()
+        n_rows = g.num_nodes if side == 'dst' else g.num_src_nodes
+        dev, E = g.device, g.num_edges
+        seg = order.seg
+        items = seg.items[:seg.n_items]
+        items = items[items[:, 0] >= 0].long()                   # drop the -1 padding of upper-bound-sized lists
+        n_items = int(items.shape[0])
+        nw = PHASE_THREADS // 64
+        T = nw * K
+        n_tiles = max(1, -(-n_items // T))
+        # deal the items to (tile, wave, slot) heaviest first, snake order: similar edge totals per tile and per wave
+        size = items[:, 2] - items[:, 1]
+        by_size = torch.sort(size, descending=True, stable=True)[1]
+        j = torch.arange(n_items, device=dev)
+        rnd, pos = j // n_tiles, j % n_tiles
+        tile_s = torch.where(rnd % 2 == 0, pos, n_tiles - 1 - pos)          # tile of the j-th heaviest item
+        s_in = rnd                                                          # arrival index inside the tile, < T
+        rw, pw = s_in // nw, s_in % nw
+        wave_s = torch.where(rw % 2 == 0, pw, nw - 1 - pw)
+        k_s = rw
+        tile_of_item = torch.empty(n_items, dtype=torch.long, device=dev)
+        wave_of_item = torch.empty_like(tile_of_item)
+        k_of_item = torch.empty_like(tile_of_item)
+        tile_of_item[by_size], wave_of_item[by_size], k_of_item[by_size] = tile_s, wave_s, k_s
+        tile_items = torch.full((n_tiles, T, 4), -1, dtype=torch.int32, device=dev)
+        flat = (tile_of_item * T + wave_of_item * K + k_of_item)
+        ti = torch.zeros(n_items, 4, dtype=torch.int32, device=dev)
+        ti[:, 0], ti[:, 1] = items[:, 0].to(torch.int32), items[:, 3].to(torch.int32)
+        tile_items.view(-1, 4)[flat] = ti
+        # edge position -> item (items are contiguous position ranges in row order; an empty item shares its begin with
+        # the next one, which searchsorted(right) resolves to the later, non-empty item)
+        pos_e = torch.arange(E, device=dev)
+        item_of = torch.searchsorted(items[:, 1].contiguous(), pos_e, right=True) - 1
+        phase = et_sorted // G
+        key = (tile_of_item[item_of] * nw + wave_of_item[item_of]) * n_phases + phase
+        # a wave's lists are contiguous (it streams its metadata); inside a (tile, wave, phase) list: by item slot (the kernel walks the slots with static accumulators), then in
+        # the caller's edge order -> a fixed summation order per row
+        perm_pos = torch.sort(key * K + k_of_item[item_of], stable=True)[1]
+        counts = torch.bincount(key, minlength=n_tiles * nw * n_phases)
+        off = torch.zeros(n_tiles * nw * n_phases + 1, dtype=torch.int32, device=dev)
+        off[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        meta = (((et_sorted - phase * G) << 4) | k_of_item[item_of])[perm_pos].to(torch.int32).contiguous()
+        nbr = nbr_sorted[perm_pos].contiguous()
+        perm = perm_pos if order.perm is None else order.perm.long()[perm_pos]
+        n_fix = int((seg.fix[:seg.n_fix, 0] >= 0).sum()) if seg.n_fix > 0 else 0
+        return PhaseOrder(off, nbr, meta, perm, tile_items.contiguous(), n_tiles, seg.fix, n_fix, seg.n_slots, n_rows, K, G,
+                          n_phases, PHASE_THREADS, PHASE_BUFFERS, packed_floats, trans)
+
+    def coef(self, coef: torch.Tensor) -> torch.Tensor:
+        """Per-edge coefficients (caller's edge order) in list order; cached on the tensor (kept alive) and its version."""
+        hit = getattr(self, '_coef', None)
+        if hit is None or hit[0] is not coef or hit[1] != coef._version:
+            hit = self._coef = (coef, coef._version, coef.reshape(-1)[self.perm].contiguous())
+        return hit[2]
+
+
+def pack_weight_phase(ph: PhaseOrder, weight, num_bases, blk_in, blk_out):
+    """Lane-packed [parts][R][NQ][L] copy of a bdd relation-weight matrix for the phase kernel of one launch kind."""
+    weight = _chk(weight, name='weight')
+    packed = torch.empty(ph.packed_floats, dtype=torch.float32, device=weight.device)
+    lib.call('gv_rgcn_bdd_pack_weight_phase', ptr(weight), weight.shape[0], num_bases, blk_in, blk_out,
+             1 if ph.transpose else 0, ptr(packed), lib.stream())
+    return packed
+
+
+def bdd_aggregate_phases(ph: PhaseOrder, coef_p, feat, weight_packed, num_rels, num_bases, blk_in, blk_out, addend=None,
+                         act=ACT_NONE, keep=None, keep_scale=1.0, out=None):
+    """gv_rgcn_bdd_aggregate_phases: K1 with the relation weights staged through LDS phase by phase (``coef_p`` already in
+    list order: PhaseOrder.coef; ``weight_packed``: pack_weight_phase)."""
+    feat, ld_feat = _row_major(feat, 'feat')
+    out_dim = num_bases * blk_out
+    if feat.shape[1] != num_bases * blk_in:
+        raise ValueError(f'feat has {feat.shape[1]} columns, expected num_bases*blk_in = {num_bases * blk_in}')
+    if weight_packed.numel() != ph.packed_floats:
+        raise ValueError('weight_packed does not have the size the phase plan asks for')
+    if out is None:
+        out = torch.empty(ph.n_rows, out_dim, dtype=torch.float32, device=feat.device)
+    ld_add = 0
+    if addend is not None:
+        addend, ld_add = _row_major(addend, 'addend')
+        if tuple(addend.shape) != (ph.n_rows, out_dim):
+            raise ValueError('addend shape mismatch')
+    if keep is not None:
+        _chk(keep, torch.uint8, 'keep')
+        if tuple(keep.shape) != (ph.n_rows, out_dim):
+            raise ValueError('keep shape mismatch')
+    if coef_p is not None:
+        coef_p = _chk(coef_p.reshape(-1), name='coef')
+    partial = torch.empty(ph.n_slots, out_dim, dtype=torch.float32, device=feat.device) if ph.n_fix > 0 else None
+    ld_out = out.stride(0) if ph.n_rows > 1 else out_dim
+    tag = f'agg_{"T" if ph.transpose else "N"}_{blk_in}x{blk_out}_nb{num_bases}'
+    timed = lib.TIMER is not None
+    lib.call('gv_rgcn_bdd_aggregate_phases', ptr(ph.off), ptr(ph.nbr), ptr(ph.meta), ptr(coef_p), ptr(ph.tile_items),
+             ph.n_tiles, ptr(ph.fix), 0 if timed else ph.n_fix, ptr(feat), ld_feat, ptr(weight_packed), num_rels, num_bases,
+             blk_in, blk_out, 1 if ph.transpose else 0, ph.rows_per_wave, ph.rels_per_phase, ph.buffers, ph.threads, ptr(addend), ld_add,
+             act, ptr(keep), float(keep_scale), ptr(out), ld_out, ptr(partial), lib.stream(), tag=tag)
+    if timed and ph.n_fix > 0:
+        lib.call('gv_rgcn_bdd_fixup', ptr(ph.fix), ph.n_fix, ptr(partial), out_dim, ptr(addend), ld_add, act, ptr(keep),
+                 float(keep_scale), ptr(out), ld_out, lib.stream())
+    return out
 
 
 class TripletIndex:
@@ -935,10 +1105,16 @@ class _RelGraphConvBdd(torch.autograd.Function):
         so = weight.shape[1] // (num_bases * si)
         out_feat = num_bases * so
         coef = None if norm is None else norm.reshape(-1)
+        # relation phases (weights staged through LDS once per tile, csrc/k_phase.hip): static single-GPU graphs
+        tl = None
+        if reduce_hook is None and use_phases(gidx, si, so, False, x.shape[0], in_feat):
+            tl = ridx.phase_order(gidx, 'dst', num_bases, si, so)
+        ctx.tiles = tl is not None
         # lane-packed weights pay off once a block's weights span >= 32 B (measured: 2x4 / 4x2 blocks -24 % / -19 %,
         # 2x2 blocks +-0): pack per launch kind, a ~1.5 MB pass per layer
-        pk = si * so >= 8 and pack_supported(num_bases, si, so, False)
-        pk_bwd = si * so >= 8 and pack_supported(num_bases, so, si, True)
+        pk = not ctx.tiles and si * so >= 8 and pack_supported(num_bases, si, so, False)
+        bwd_phases = reduce_hook is None and use_phases(gidx, so, si, True, n, out_feat)
+        pk_bwd = not bwd_phases and si * so >= 8 and pack_supported(num_bases, so, si, True)
         ctx.w_bwd_packed = None
         if pk and pk_bwd and ctx.needs_input_grad[0]:      # one launch writes both layouts; backward-x reuses its copy
             w_fwd, ctx.w_bwd_packed = torch.empty_like(weight), torch.empty_like(weight)
@@ -954,8 +1130,12 @@ class _RelGraphConvBdd(torch.autograd.Function):
                 return h_bias.unsqueeze(0).expand(n, out_feat).contiguous()
             return None
 
-        ctx.grouped = reduce_hook is None and use_relation_groups(weight, gidx)
-        if ctx.grouped:
+        ctx.grouped = not ctx.tiles and reduce_hook is None and use_relation_groups(weight, gidx)
+        if ctx.tiles:
+            out = bdd_aggregate_phases(tl, None if coef is None else tl.coef(coef), x,
+                                       pack_weight_phase(tl, weight, num_bases, si, so), weight.shape[0], num_bases, si, so,
+                                       self_loop_term(), act, keep, keep_scale)
+        elif ctx.grouped:
             seg, nbr, ety, perm = ridx.grouped_order(gidx, 'dst')
             coef_g = None if coef is None else ridx.grouped_coef(coef, 'dst', perm)
             out = bdd_aggregate(seg, nbr, ety, coef_g, None, x, w_fwd, num_bases, si, so, False, self_loop_term(), act, keep,
@@ -1016,7 +1196,17 @@ class _RelGraphConvBdd(torch.autograd.Function):
         if pending is not None:
             pending.wait()
         grad_x = None
-        if ctx.needs_input_grad[0]:
+        tl = None
+        if reduce_hook is None and ctx.needs_input_grad[0] and use_phases(gidx, so, si, True, g_agg.shape[0], g_agg.shape[1]):
+            tl = ridx.phase_order(gidx, 'src', nb, so, si)
+        if tl is not None:
+            x_tgt = ctx.x_grad_target
+            grad_x = bdd_aggregate_phases(tl, None if coef is None else tl.coef(coef), g_agg,
+                                          pack_weight_phase(tl, weight, nb, so, si), weight.shape[0], nb, so, si, gx_loop,
+                                          out=x_tgt)
+            if x_tgt is not None:
+                grad_x = None
+        elif ctx.needs_input_grad[0]:
             pk = si * so >= 8 and pack_supported(nb, so, si, True)
             if ctx.w_bwd_packed is not None and weight._version == ctx.w_version:
                 w_bwd = ctx.w_bwd_packed

@@ -93,6 +93,35 @@ int gv_rgcn_bdd_pack_weight(const float* weight, int num_rels, int num_bases, in
 int gv_rgcn_bdd_pack_weight_pair(const float* weight, int num_rels, int num_bases, int blk_in, int blk_out, float* packed_fwd,
                                  float* packed_bwd, void* stream);
 
+/* K1 by RELATION PHASES (same contract as gv_rgcn_bdd_aggregate: same formula, addend / act / keep epilogue, split hub rows
+ * through partial + fix): the per-edge weight read -- DGL materialises W[etype] per edge (index_select in bdd_message_func;
+ * call sites kgvae/model.py:54-59) -- goes through LDS instead of the vector-memory path.  A workgroup of nw waves owns a
+ * tile of nw*K work items (rows, or <= chunk-edge slices of hub rows; K = rows_per_wave); wave w keeps its K output rows in
+ * registers and the workgroup walks the relation types in phases of rels_per_phase consecutive types whose lane-packed
+ * block weights are staged once per tile into LDS (double buffered LDS-DMA).
+ *   off        int32 [n_tiles * nw * n_phases + 1]  first edge position of every (tile, wave, phase) list; n_phases =
+ *              ceil(num_rels / rels_per_phase), nw = block_threads / 64
+ *   nbr        int32 [E]  gathered row of each edge, edges in (tile, wave, phase, slot) order
+ *   meta       int32 [E]  ((etype - phase*rels_per_phase) << 4) | item slot k (0 <= k < K)
+ *   coef       float [E]  edge coefficient in the same order (or NULL)
+ *   tile_items int32 [n_tiles][nw*K][4] = {row (-1: empty slot), partial slot (-1: final row), 0, 0}
+ *   weight_packed  gv_rgcn_bdd_pack_weight_phase(weight): [parts][R][NQ][L] float4, plan[5] floats
+ * Every row is summed by one wave in (phase, list) order: no atomics, bitwise reproducible.
+ * gv_rgcn_bdd_phase_plan returns 1 when a phase kernel exists for the block shape and writes (HOST pointer)
+ *   plan[6] = {blocks per lane, column parts, K, rels_per_phase for lds_bytes of LDS, n_phases, floats of weight_packed};
+ * num_buffers = 2: phase p+1's weights land while phase p is computed; 1: one buffer with twice the relations per phase,
+ * refilled between two barriers.  rows_per_wave = 0: the shape's default K, 4: small tiles (the 8-row shapes). */
+int gv_rgcn_bdd_phase_plan(int num_bases, int blk_in, int blk_out, int transpose_w, int num_rels, int lds_bytes,
+                           int num_buffers, int rows_per_wave, int32_t* plan_host);
+int gv_rgcn_bdd_pack_weight_phase(const float* weight, int num_rels, int num_bases, int blk_in, int blk_out, int transpose_w,
+                                  float* packed, void* stream);
+int gv_rgcn_bdd_aggregate_phases(const int32_t* off, const int32_t* nbr, const int32_t* meta, const float* coef,
+                                 const int32_t* tile_items, int n_tiles, const int32_t* fix, int n_fix, const float* feat,
+                                 int ld_feat, const float* weight_packed, int num_rels, int num_bases, int blk_in,
+                                 int blk_out, int transpose_w, int rows_per_wave, int rels_per_phase, int num_buffers,
+                                 int block_threads, const float* addend, int ld_addend, int act, const uint8_t* keep,
+                                 float keep_scale, float* out, int ld_out, float* partial, void* stream);
+
 /* The fix-up pass of gv_rgcn_bdd_aggregate on its own (a caller that passed n_fix = 0 there, e.g. to
  * time the aggregation kernel alone, finishes the split rows with this). */
 int gv_rgcn_bdd_fixup(const int32_t* fix, int n_fix, const float* partial, int out_dim, const float* addend,

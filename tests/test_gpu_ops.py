@@ -95,6 +95,84 @@ def test_sync_free_index_gives_identical_results(ops):
         assert torch.equal(a, b)
 
 
+PHASE_CASES = [(200, 200, 100), (200, 400, 100), (500, 500, 100), (500, 1000, 100), (20, 40, 10), (40, 40, 20)]
+
+
+@pytest.mark.parametrize('fin,fout,nb', PHASE_CASES)
+@pytest.mark.parametrize('lds,threads,rows,chunk,nbuf', [(163840, 1024, 0, 256, 2), (24576, 256, 4, 8, 2), (40960, 128, 0, 32, 1)])
+def test_rel_graph_conv_relation_phases(ops, monkeypatch, fin, fout, nb, lds, threads, rows, chunk, nbuf):
+    """K1 by relation phases (csrc/k_phase.hip: weights staged through LDS once per tile, K rows per wave in registers)
+    against the oracle, forward and every gradient: the planned geometry; short LDS budgets (many phases, a last phase
+    with fewer relations), small workgroups, 4 rows per wave, and hub rows split into 8-edge items."""
+    si, so = fin // nb, fout // nb
+    if rows == 4 and not (si == 2 and so == 2):
+        rows = 0
+    monkeypatch.setattr(ops, 'K1_PHASES', '1')
+    monkeypatch.setattr(ops, 'PHASE_LDS_BYTES', lds)
+    monkeypatch.setattr(ops, 'PHASE_THREADS', threads)
+    monkeypatch.setattr(ops, 'PHASE_ROWS', rows)
+    monkeypatch.setattr(ops, 'PHASE_BUFFERS', nbuf)
+    n, e, r = 300, 4000, 120
+    src, dst, et, norm = zipf_graph(n, e, r, seed=fin + fout + nb)
+    gen = torch.Generator().manual_seed(fin * 7 + nb)
+    x = torch.randn(n, fin, generator=gen)
+    p = orgcn.init_params(fin, fout, r, 'bdd', nb, True, True, gen)
+    p['h_bias'] = torch.randn(fout, generator=gen) * 0.1
+    keep = (torch.rand(n, fout, generator=gen) > 0.2).to(torch.uint8)
+    gout = torch.randn(n, fout, generator=gen)
+    gidx = ops.GraphIndex(src.cuda(), dst.cuda(), n, chunk=chunk)
+    ridx = ops.RelationIndex(gidx, et.cuda(), r)
+    ph = ridx.phase_order(gidx, 'dst', nb, si, so)
+    assert ph is not None and ridx.phase_order(gidx, 'src', nb, so, si) is not None
+    if chunk == 8:
+        assert ph.n_fix > 0 and ph.n_tiles > 4 and ph.n_phases > 2
+    for act_id, act in ((1, torch.relu), (0, None)):
+        xo = x.clone().requires_grad_(True)
+        po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        ho = orgcn.rel_graph_conv(xo, src, dst, et, norm, po, 'bdd', nb, act, dropout_keep=keep, dropout_p=0.2)
+        ho.backward(gout)
+        xg = x.cuda().requires_grad_(True)
+        pg = {k: v.cuda().requires_grad_(True) for k, v in p.items()}
+        hg = ops.rel_graph_conv_bdd(xg, pg['weight'], pg['h_bias'], pg['loop_weight'], norm.cuda(), gidx, ridx, nb,
+                                    act_id, keep.cuda(), 1.0 / 0.8)
+        hg.backward(gout.cuda())
+        close(hg, ho, msg='forward')
+        close(xg.grad, xo.grad, msg='grad_x')
+        close(pg['weight'].grad, po['weight'].grad, msg='grad_weight')
+        close(pg['loop_weight'].grad, po['loop_weight'].grad, msg='grad_loop')
+
+
+def test_relation_phase_lists_cover_every_edge_once(ops, monkeypatch):
+    """Index property: the (tile, phase, wave) lists partition the edges; every edge sits in the list of its relation's
+    phase and of the wave that owns its row's item, and carries that item's slot; every item has exactly one slot."""
+    monkeypatch.setattr(ops, 'PHASE_LDS_BYTES', 16384)
+    monkeypatch.setattr(ops, 'PHASE_THREADS', 256)
+    n, e, r, nb = 500, 3000, 37, 10
+    src, dst, et, _ = zipf_graph(n, e, r, seed=3)
+    gidx = ops.GraphIndex(src.cuda(), dst.cuda(), n, chunk=16)
+    ridx = ops.RelationIndex(gidx, et.cuda(), r)
+    for side, rows_of, blk in (('dst', dst, (2, 4)), ('src', src, (4, 2))):
+        ph = ridx.phase_order(gidx, side, nb, *blk)
+        nw, K, G = ph.threads // 64, ph.rows_per_wave, ph.rels_per_phase
+        off, meta, perm = ph.off.cpu().numpy(), ph.meta.cpu().numpy(), ph.perm.cpu().numpy()
+        ti = ph.tile_items.cpu().numpy()
+        assert off[0] == 0 and off[-1] == e and (np.diff(off) >= 0).all() and len(off) == ph.n_tiles * nw * ph.n_phases + 1
+        assert sorted(perm.tolist()) == list(range(e))
+        seg = (gidx.by_dst if side == 'dst' else gidx.by_src).seg
+        rows_with_slot = ti[..., 0][ti[..., 0] >= 0]
+        assert len(rows_with_slot) == seg.n_items
+        for t in range(ph.n_tiles):
+            for p_ in range(ph.n_phases):
+                for w in range(nw):
+                    idx = (t * nw + w) * ph.n_phases + p_
+                    assert (np.diff(meta[off[idx]:off[idx + 1]] & 15) >= 0).all()       # sorted by item slot
+                    for pos in range(off[idx], off[idx + 1]):
+                        k, rl = meta[pos] & 15, meta[pos] >> 4
+                        assert k < K and rl < G
+                        assert et.numpy()[perm[pos]] == p_ * G + rl
+                        assert ti[t, w * K + k, 0] == rows_of.numpy()[perm[pos]]
+
+
 CASES = [  # (in, out, num_bases)  -> block sizes; covers the fast instantiations and the generic kernel
     (200, 200, 100), (200, 400, 100),   # C2 layer 1 / 2   (2x2, 2x4)
     (16, 16, 4), (16, 32, 4),           # C1               (4x4, 4x8)
