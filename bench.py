@@ -3,18 +3,24 @@
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--scaling weak|strong]
 
-Workload (BASELINE.json configs[1]): FB15k-237-shaped synthetic knowledge graph (14 541 entities,
-237 relations = 474 directed edge types, 272 115 triplets with Zipf(0.8) endpoints => 544 230 directed
-edges), 2-layer R-GCN-VAE encoder (bdd, num_bases=100, emb_dim=200, fp32, dropout 0.2) on the FULL
-graph + DistMult decoder on 220 000 triplets (20 000 positives x (1 + 10 negatives)).
-One step = forward + loss (BCE + 0.01 reg + 1e-5 KL + 1.0 MMD) + backward + grad-clip + Adam,
-i.e. the reference's t0..t2 span (kgvae/link_predict.py:222-229) with device synchronisation.
-At N GPUs every rank holds one such edge block and triplet slice (weak scaling); node embeddings are
-all-reduced over RCCL once per layer per direction, parameter gradients once per step.
+Workloads (BASELINE.json configs, all seeded synthetics -- no dataset on disk, no network):
+  c2 (default, configs[1]) FB15k-237-shaped: 14 541 entities, 237 relations = 474 directed edge types, 272 115 triplets
+     with Zipf(0.8) endpoints => 544 230 directed edges, 2-layer R-GCN-VAE encoder (bdd, num_bases=100, emb_dim=200, fp32,
+     dropout 0.2) on the FULL graph + DistMult decoder on 220 000 triplets (20 000 positives x (1 + 10 negatives))
+  c3 (configs[2]) WN18RR-shaped: 40 943 entities, 11 relations, 86 835 triplets, emb_dim=200, num_bases=20, 3 IAF blocks,
+     dense products with bf16 operands
+  c4 (configs[3]) the c2 graph at emb_dim=500
+  c5 (configs[4]) 1 M entities, 1 000 relations, 25 M triplets => 50 M directed edges, emb_dim=200 (generated on the device)
+One step = forward + loss (BCE + 0.01 reg + 1e-5 KL + 1.0 MMD) + backward + grad-clip + Adam, i.e. the reference's
+t0..t2 span (kgvae/link_predict.py:222-229) with device synchronisation.
+--scaling weak (default): every rank holds one such edge block (seed = rank) and triplet slice; the graph trained is the
+union.  --scaling strong: ONE graph (seed 0), its directed edges cut by RELATION across the ranks
+(distributed.shard_edges_by_relation, north_star) or by destination row (--partition row), its triplets dealt round-robin.
+Node embeddings are exchanged over RCCL once per layer per direction, parameter gradients once per step.
 
-Rank 0 prints ONE JSON line: value = all ranks' directed edges x steps / max-over-ranks seconds.
+Rank 0 prints ONE JSON line: value = directed edges of the trained graph x steps / max-over-ranks seconds.
 """
 import argparse
 import json
@@ -31,6 +37,20 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MALL_GATHER_GBS = 8600.0  # indexed rows served from the Infinity Cache (same guide, "Indexed rows: gather into LDS")
+L2_GATHER_GBS = 17800.0   # ... from an XCD's L2 (16.8-18.8 TB/s)
+
+# BASELINE.json configs[1..4]; c2 is the configuration the metric is quoted on
+CONFIGS = {
+    'c2': dict(idx=1, label='FB15k-237-shaped synthetic full graph (BASELINE configs[1])', nodes=14541, rels=237,
+               train=272115, hidden=200, bases=100, flows=0, gemm='f32', device_gen=False),
+    'c3': dict(idx=2, label='WN18RR-shaped synthetic full graph + 3 IAF blocks (BASELINE configs[2])', nodes=40943, rels=11,
+               train=86835, hidden=200, bases=20, flows=3, gemm='bf16', device_gen=False),
+    'c4': dict(idx=3, label='FB15k-237-shaped synthetic full graph at emb_dim=500 (BASELINE configs[3])', nodes=14541, rels=237,
+               train=272115, hidden=500, bases=100, flows=0, gemm='f32', device_gen=False),
+    'c5': dict(idx=4, label='synthetic KG 1M entities / 50M directed edges / 1k relations (BASELINE configs[4])',
+               nodes=1_000_000, rels=1000, train=25_000_000, hidden=200, bases=100, flows=0, gemm='f32', device_gen=True),
+}
 
 
 def parse():
@@ -38,11 +58,15 @@ def parse():
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=30)
     p.add_argument('--warmup', type=int, default=5)
-    p.add_argument('--hidden', type=int, default=200)
-    p.add_argument('--n-bases', type=int, default=100)
-    p.add_argument('--n-flows', type=int, default=0)
-    p.add_argument('--gemm-precision', choices=['f32', 'bf16'], default='f32',
-                   help="bf16: dense products with bf16 operands / fp32 accumulation (configs[2]'s precision); default fp32")
+    p.add_argument('--config', choices=sorted(CONFIGS), default='c2', help='BASELINE.json workload (see the module docstring)')
+    p.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                   help='world size > 1: weak = one edge block per rank (union graph), strong = ONE graph cut across the ranks')
+    p.add_argument('--hidden', type=int, default=None, help='override the config\'s emb_dim')
+    p.add_argument('--n-bases', type=int, default=None)
+    p.add_argument('--n-flows', type=int, default=None)
+    p.add_argument('--gemm-precision', choices=['f32', 'bf16'], default=None,
+                   help="bf16: dense products with bf16 operands / fp32 accumulation (configs[2]'s precision)")
+    p.add_argument('--no-check', action='store_true', help='skip the parity leg (one HIP step against the CPU oracle)')
     p.add_argument('--positives', type=int, default=20000)
     p.add_argument('--negative-sample', type=int, default=10)
     p.add_argument('--dropout', type=float, default=0.2)
@@ -61,46 +85,91 @@ def parse():
                         '--probe-steps steps of each during warm-up and run the faster one')
     p.add_argument('--probe-steps', type=int, default=10)
     p.add_argument('--profile-steps', type=int, default=3, help='instrumented eager steps for the roofline figure')
-    return p.parse_args()
+    args = p.parse_args()
+    cfg = CONFIGS[args.config]
+    for name, key in (('hidden', 'hidden'), ('n_bases', 'bases'), ('n_flows', 'flows'), ('gemm_precision', 'gemm')):
+        if getattr(args, name) is None:
+            setattr(args, name, cfg[key])
+    return args
+
+
+class _Data:
+    def __init__(self, num_nodes, num_rels, train):
+        self.num_nodes, self.num_rels, self.train = num_nodes, num_rels, train
+
+
+def directed_graph(cfg, seed, dev):
+    """One synthetic knowledge graph as the reference hands it to the encoder (kgvae/utils.py:135-150): reverse edges
+    added (relation id + num_rels), edges sorted by (dst, src, rel).  Returns CPU int64 tensors (src, dst, rel) and the
+    (n, 3) triplets; the 50 M-edge configuration is generated and sorted on the device."""
+    from gcn_vae_amd import sampling
+    from gcn_vae_amd.data import synthetic_kg
+    n, nr, t = cfg['nodes'], cfg['rels'], cfg['train']
+    if not cfg['device_gen']:
+        data = synthetic_kg(n, nr, t, seed=seed)
+        g, rel, _ = sampling.build_test_graph(n, nr, data.train)
+        src, dst = g.edges()
+        return src, dst, torch.from_numpy(rel).long(), data.train
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    # Zipf(0.8) endpoints by inverse CDF (P(i) ~ (i+1)^-0.8  =>  i ~ n u^5), uniform relations
+    s = (torch.rand(t, device=dev, generator=gen) ** 5 * n).long().clamp_(max=n - 1)
+    o = (torch.rand(t, device=dev, generator=gen) ** 5 * n).long().clamp_(max=n - 1)
+    r = torch.randint(0, nr, (t,), device=dev, generator=gen)
+    src, dst, rel = torch.cat([s, o]), torch.cat([o, s]), torch.cat([r, r + nr])
+    order = torch.sort((dst * n + src) * (2 * nr) + rel)[1]
+    trip = torch.stack([s, r, o], 1)
+    return src[order], dst[order], rel[order], trip
 
 
 def make_workload(rank, world, args, dev):
     from gcn_vae_amd import distributed as gdist
     from gcn_vae_amd import sampling
-    from gcn_vae_amd.data import FB15K237, synthetic_kg
-    cfg = FB15K237
-    data = synthetic_kg(cfg['num_nodes'], cfg['num_rels'], cfg['n_train'], seed=rank)
-    g, rel, node_norm = sampling.build_test_graph(data.num_nodes, data.num_rels, data.train)
-    src, dst = g.edges()
-    if world > 1:      # 1/in-degree over the union of all ranks' edge blocks
-        norm = gdist.global_in_degree_norm(dst, data.num_nodes, device=dev)
-    else:
-        norm = torch.from_numpy(node_norm).to(dev)
+    from gcn_vae_amd.graph import KGraph
+    cfg = CONFIGS[args.config]
+    n, nr = cfg['nodes'], cfg['rels']
+    strong = args.scaling == 'strong' and world > 1
+    src, dst, rel, trip = directed_graph(cfg, 0 if strong else rank, dev)
+    e_total = int(src.numel())
+    deg = torch.bincount(dst.to(dev), minlength=n).to(torch.float32)
+    shard = None
+    if strong:      # ONE graph, its directed edges cut by relation range (whole relations): the (dst, src, rel) order survives
+        ids, shard = gdist.shard_edges_by_relation(rel.cpu().numpy(), 2 * nr, world, rank)
+        ids = torch.from_numpy(ids).to(src.device)
+        src, dst, rel = src[ids], dst[ids], rel[ids]
+    elif world > 1:      # 1/in-degree over the union of all ranks' edge blocks
+        import torch.distributed as dist
+        dist.all_reduce(deg)
+    norm = torch.where(deg > 0, 1.0 / deg.clamp(min=1), torch.zeros_like(deg))
     enorm = norm[dst.to(dev)].view(-1, 1).contiguous()
-    rs = np.random.RandomState(1000 + rank)
-    pos = data.train[rs.permutation(len(data.train))[:args.positives]]
-    np.random.seed(7 + rank)
-    samples, labels = sampling.negative_sampling(pos, data.num_nodes, args.negative_sample)
-    return dict(data=data, g=g, src=src, dst=dst, rel=torch.from_numpy(rel), enorm=enorm,
-                node_id=torch.arange(data.num_nodes, dtype=torch.long).view(-1, 1),
-                samples=torch.from_numpy(samples), labels=torch.from_numpy(labels))
+    if cfg['device_gen']:
+        g = KGraph.from_device_edges(n, src.to(dev), dst.to(dev), dst_sorted=True)
+    else:
+        g = KGraph()
+        g.add_nodes(n)
+        g.add_edges(src, dst)
+    rs = np.random.RandomState(1000 + (0 if strong else rank))
+    trip_np = trip.cpu().numpy() if isinstance(trip, torch.Tensor) else trip
+    pos = trip_np[rs.permutation(len(trip_np))[:args.positives]]
+    np.random.seed(7 + (0 if strong else rank))
+    samples, labels = sampling.negative_sampling(pos, n, args.negative_sample)
+    if strong:      # the ONE triplet batch dealt round-robin
+        samples, labels = samples[rank::world], labels[rank::world]
+    return dict(data=_Data(n, nr, trip_np), g=g, src=src, dst=dst, rel=rel.cpu() if not cfg['device_gen'] else rel,
+                enorm=enorm, node_id=torch.arange(n, dtype=torch.long).view(-1, 1), samples=torch.from_numpy(samples),
+                labels=torch.from_numpy(labels), e_total=e_total, shard=shard, strong=strong)
 
 
 def make_workload_rows(rank, world, args, dev, own):
-    """Destination-row partition of the SAME union graph: the union of all ranks' edge blocks (seed = 0..world-1) is cut
-    by destination row; this rank keeps the edges that end in its rows.  Triplets are the rank's own (as in the edge-block
-    workload ``own``), relabelled to row positions."""
+    """Destination-row partition of the SAME trained graph (weak: the union of all ranks' edge blocks, seeds 0..world-1;
+    strong: the one graph): cut by destination row; this rank keeps the edges that end in its rows.  Triplets are the
+    rank's own (as in the edge-block workload ``own``), relabelled to row positions."""
     from gcn_vae_amd import distributed as gdist
-    from gcn_vae_amd.data import FB15K237, synthetic_kg
-    cfg = FB15K237
-    n, n_rel = cfg['num_nodes'], cfg['num_rels']
+    cfg = CONFIGS[args.config]
+    n = cfg['nodes']
     src, dst, rel = [], [], []
-    for r in range(world):        # every rank regenerates all blocks (cheap) instead of exchanging edge lists
-        t = own['data'].train if r == rank else synthetic_kg(n, n_rel, cfg['n_train'], seed=r).train
-        s_, r_, o_ = (torch.from_numpy(np.ascontiguousarray(t[:, i])) for i in range(3))
-        src += [s_, o_]
-        dst += [o_, s_]
-        rel += [r_, r_ + n_rel]          # reverse edges carry relation id + num_rels (kgvae/utils.py:135-150)
+    for r in ([0] if own['strong'] else range(world)):   # every rank regenerates all blocks (cheap) instead of exchanging them
+        s_, d_, r_, _ = directed_graph(cfg, r, dev)
+        src.append(s_); dst.append(d_); rel.append(r_)
     src, dst, rel = (torch.cat(x).to(dev) for x in (src, dst, rel))
     deg = torch.bincount(dst, minlength=n)
     norm = torch.where(deg > 0, 1.0 / deg.clamp(min=1).float(), torch.zeros(n, device=dev))
@@ -147,47 +216,53 @@ def algorithmic_bytes(tag, E, N, R, T):
 
 
 def pmc_traffic_for(tag):
-    """HBM-side bytes per launch of the kernel behind a K1 tag, from the committed rocprofv3 PMC passes of this same
-    command (profiles/<round>/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc runs, gfx950 correction
-    per MI355X_MICROARCH.md).  None when no profile of that kernel is committed."""
+    """(HBM-side bytes per launch, provenance) of the kernel behind a K1 tag, from the newest committed rocprofv3 PMC
+    passes of this command (profiles/round*/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc runs, gfx950
+    correction per MI355X_MICROARCH.md; the file's "_meta" names the commit and date it was measured at).  (None, None)
+    when no profile of that kernel is committed."""
     import glob
     import re
     kind, rest = tag.split('_', 1)
     if kind != 'agg':
-        return None
+        return None, None
     tr, blk, _ = rest.split('_')
     p, q = blk.split('x')
-    pat = re.compile(r'k_agg_(fast|packed)<%s,%s,%s,' % (p, q, 'true' if tr == 'T' else 'false'))
-    best = None
+    pat = re.compile(r'k_agg_(fast|packed|phase)<%s, ?%s, ?%s,' % (p, q, 'true' if tr == 'T' else 'false'))
+    best, src = None, None
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*', 'pmc_traffic.json'))):
         try:
             data = json.load(open(path))
         except Exception:
             continue
         for k, v in data.items():
-            if pat.match(k):
+            if k != '_meta' and pat.search(k):
                 best = v['traffic_bytes']
-    return best
+                src = dict(data.get('_meta', {}), file=os.path.relpath(path, ROOT))
+    return best, src
 
 
 def cpu_baseline(w, model, args, budget_s):
-    """The CPU oracle (oracle/, a torch-CPU port of the reference's op sequence) on the same inputs."""
+    """The CPU oracle (oracle/, a torch-CPU port of the reference's op sequence; test infrastructure, used here as the
+    reported baseline and as the checker of ``parity_check``) on the same inputs.  Returns (baseline record, reference
+    outputs of the last oracle step for the parity leg)."""
     from oracle import kgvae as okg
     from oracle import rgcn as orgcn
     ncpu = os.cpu_count() or 1
+    src, dst, rel = (t.cpu() for t in (w['src'], w['dst'], w['rel']))
     # torch's CPU ops do not scale to hundreds of threads on this op mix: pick the fastest of a few thread
     # counts on the dominant op (one layer-1 message pass) and report the count actually used.
     xs = model.state_dict()
     probe = {'weight': xs['encoder.rconv_layer_1.weight'].detach().cpu(), 'h_bias': xs['encoder.rconv_layer_1.h_bias'].detach().cpu(),
              'loop_weight': xs['encoder.rconv_layer_1.loop_weight'].detach().cpu()}
     xprobe = xs['encoder.input_layer.embedding.weight'].detach().cpu()
+    enorm = w['enorm'].cpu()
     best_t, threads = None, 1
     for cand in [c for c in (8, 16, 32, 64, 128) if c <= ncpu] or [ncpu]:
         torch.set_num_threads(cand)
         with torch.no_grad():
-            orgcn.rel_graph_conv(xprobe, w['src'], w['dst'], w['rel'], w['enorm'].cpu(), probe, 'bdd', args.n_bases, torch.relu)
+            orgcn.rel_graph_conv(xprobe, src, dst, rel, enorm, probe, 'bdd', args.n_bases, torch.relu)
             t0 = time.time()
-            orgcn.rel_graph_conv(xprobe, w['src'], w['dst'], w['rel'], w['enorm'].cpu(), probe, 'bdd', args.n_bases, torch.relu)
+            orgcn.rel_graph_conv(xprobe, src, dst, rel, enorm, probe, 'bdd', args.n_bases, torch.relu)
             dt = time.time() - t0
         if best_t is None or dt < best_t:
             best_t, threads = dt, cand
@@ -200,28 +275,106 @@ def cpu_baseline(w, model, args, budget_s):
     keep1 = (torch.rand(n, h, generator=gen) > args.dropout).to(torch.uint8)
     keep2 = (torch.rand(n, 2 * h, generator=gen) > args.dropout).to(torch.uint8)
     post_idx = torch.tensor(random.Random(0).sample(range(n), 200))
-    enorm = w['enorm'].cpu()
-    times = []
-    t_start = time.time()
-    for it in range(4):
+
+    def one_step(anomaly=False):
         for v in state.values():
             v.grad = None
         t0 = time.time()
-        enc = okg.kgvae_encode(state, w['src'], w['dst'], w['node_id'], w['rel'], enorm, eps, args.n_bases,
-                               args.n_flows, args.dropout, keep1, keep2)
-        loss = okg.link_predict_loss(state, enc, w['samples'], w['labels'], 0.01, 1e-5, 1.0, 10, args.n_flows,
-                                     eps_prior, post_idx)[0]
-        loss.backward()
-        dt = time.time() - t0
-        if it > 0:
-            times.append(dt)
-        if time.time() - t_start + dt > budget_s and times:
-            break
-    E = int(w['src'].numel())
+        with torch.autograd.set_detect_anomaly(anomaly):
+            enc = okg.kgvae_encode(state, src, dst, w['node_id'], rel, enorm, eps, args.n_bases, args.n_flows, args.dropout,
+                                   keep1, keep2)
+            loss = okg.link_predict_loss(state, enc, w['samples'], w['labels'], 0.01, 1e-5, 1.0, 10, args.n_flows,
+                                         eps_prior, post_idx)[0]
+            loss.backward()
+        return time.time() - t0, enc, loss
+
+    # SURVEY 8(d) asks for >= 5 warm-up + >= 20 timed steps; a step costs seconds here, and the contract bounds this leg to
+    # ~10-30 s of CPU work: 1 warm-up, then as many timed steps (at most 20) as the budget allows, at least 2
+    times, t_start = [], time.time()
+    dt, enc, loss = one_step()
+    while len(times) < 20 and (len(times) < 2 or time.time() - t_start + dt < budget_s):
+        dt, enc, loss = one_step()
+        times.append(dt)
+    anomaly_dt = one_step(anomaly=True)[0] if time.time() - t_start + 2 * dt < budget_s + 15 else None
+    E = int(src.numel())
     med = float(np.median(times))
-    return {'value': E / med, 'unit': 'edges/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{len(times)} timed full steps (fwd+loss+bwd, no optimizer) of the same workload after 1 warm-up; '
-                      f'median {med:.3f} s/step; torch {torch.__version__} CPU with {threads} of {ncpu} host threads (fastest of 8..128 on a probe), anomaly mode off'}
+    rec = {'value': E / med, 'unit': 'edges/s', 'cores': threads, 'kind': 'port',
+           'sample': f'{len(times)} timed full steps (fwd+loss+bwd of the same workload; clip+Adam, which the GPU span includes, '
+                     f'are NOT in this span) after 1 warm-up, bounded by --cpu-seconds {budget_s:g} (SURVEY 8(d)\'s 5 + 20 steps '
+                     f'would take minutes); median {med:.3f} s/step; torch {torch.__version__} CPU with {threads} of {ncpu} host '
+                     f'threads (fastest of 8..128 on a probe), anomaly mode off'
+                     + (f'; one step with the reference\'s torch.autograd.set_detect_anomaly(True) (kgvae/model.py:10): '
+                        f'{anomaly_dt:.3f} s' if anomaly_dt is not None else '')}
+    names = ['encoder.rconv_layer_1.weight', 'encoder.rconv_layer_2.weight', 'encoder.rconv_layer_2.loop_weight',
+             'encoder.input_layer.embedding.weight', 'w_relation', 'encoder.z_pre']
+    ref = dict(loss=loss.detach(), z=enc['z'].detach(), h1=enc['h1'].detach(), grads={k: state[k].grad.detach().clone() for k in names},
+               eps=eps, eps_prior=eps_prior, keep1=keep1, keep2=keep2, post_idx=post_idx,
+               state={k: v.detach() for k, v in state.items()})
+    return rec, ref
+
+
+def parity_check(model, opt, inputs, ref, dev):
+    """ONE eager HIP step (forward + loss + backward, no optimiser step) on the timed workload with the random draws the
+    oracle used, compared with the oracle's step on the same weights: loss, z and six parameter gradients.
+    Returns the JSON record; raises AssertionError beyond north_star's tolerance (1e-4 on outputs, 5e-4 on gradients,
+    relative to the tensor's largest magnitude)."""
+    enc = model.encoder
+    saved = (enc.eps_override, enc.mmd_eps_override, enc.mmd_index_override, enc.rconv_layer_1.keep_mask_override,
+             enc.rconv_layer_2.keep_mask_override)
+    with torch.no_grad():      # the oracle ran on a snapshot of the weights: make sure the device holds the same values
+        for k, v in model.state_dict().items():
+            if k in ref['state'] and v.is_floating_point():
+                v.copy_(ref['state'][k].to(dev))
+    enc.eps_override, enc.mmd_eps_override = ref['eps'].to(dev), ref['eps_prior'].to(dev)
+    enc.mmd_index_override = ref['post_idx'].to(dev)
+    enc.rconv_layer_1.keep_mask_override, enc.rconv_layer_2.keep_mask_override = ref['keep1'].to(dev), ref['keep2'].to(dev)
+    seen = {}
+    hook = enc.rconv_layer_1.register_forward_hook(lambda _m, _i, o: seen.__setitem__('h1', o.detach()))
+    try:
+        opt.flat_g.zero_()
+        embed = model(inputs['g'], inputs['node_id'], inputs['etype'], inputs['enorm'])
+        loss = model.get_loss(inputs['g'], embed, inputs['samples'], inputs['labels'])[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        named = dict(model.named_parameters())
+
+        def rel_err(a, b):          # largest deviation relative to the reference tensor's largest magnitude
+            a, b = a.detach().double().cpu(), b.double()
+            return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+        def rel_l2(a, b):
+            a, b = a.detach().double().cpu(), b.double()
+            return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+        errs = {'loss': rel_err(loss.reshape(()), ref['loss'].reshape(())), 'z': rel_err(embed, ref['z'])}
+        l2 = {}
+        for k, g in ref['grads'].items():
+            errs['grad ' + k] = rel_err(named[k].grad, g)
+            l2['grad ' + k] = rel_l2(named[k].grad, g)
+        # ReLU kink: a layer-1 pre-activation within fp32 rounding of 0 may land on different sides in the two
+        # implementations (different summation orders); that element's gradient is then switched on in one and off in the
+        # other -- a discrete, legitimate difference that a max-norm bound on the layer-1 gradients cannot absorb.  Count
+        # them; with any such element the gradients are held to the Frobenius-norm bound only.
+        flips = int(((seen['h1'].cpu() > 0) != (ref['h1'] > 0)).sum())
+        worst_out = max(errs['loss'], errs['z'])
+        worst_grad = max(v for k, v in errs.items() if k.startswith('grad '))
+        worst_l2 = max(l2.values())
+        ok = worst_out <= 1e-4 and worst_l2 <= 5e-4 and (worst_grad <= 5e-4 or flips > 0)
+        rec = {'parity_max_rel_err': max(worst_out, worst_l2 if flips else worst_grad), 'outputs_max_rel_err': worst_out,
+               'gradients_max_rel_err': worst_grad, 'gradients_max_rel_l2_err': worst_l2, 'relu_sign_flips': flips,
+               'tolerance': {'outputs': 1e-4, 'gradients': 5e-4}, 'passed': ok,
+               'checked': sorted(errs), 'detail': {k: float('%.3g' % v) for k, v in errs.items()},
+               'detail_rel_l2': {k: float('%.3g' % v) for k, v in l2.items()},
+               'against': 'oracle/ (CPU restatement) on the timed workload, same weights and random draws; errors are '
+                          'max |a-b| / max |b| per tensor (rel_l2: Frobenius); gradients are held to the max-norm bound '
+                          'unless a layer-1 pre-activation changed sign between the two implementations (relu_sign_flips)'}
+        opt.flat_g.zero_()
+        assert ok, f'bench parity check failed: {errs} (rel. Frobenius: {l2}; ReLU sign flips: {flips})'
+        return rec
+    finally:
+        hook.remove()
+        (enc.eps_override, enc.mmd_eps_override, enc.mmd_index_override, enc.rconv_layer_1.keep_mask_override,
+         enc.rconv_layer_2.keep_mask_override) = saved
 
 
 def main():
@@ -271,6 +424,8 @@ def main():
     w = make_workload(rank, world, args, dev)
     model = build_model(w, args).to(dev).train()
     n_nodes, E = w['data'].num_nodes, int(w['src'].numel())
+    cfg = CONFIGS[args.config]
+    trained_edges = w['e_total'] if w['strong'] else world * E      # directed edges of the graph one step trains on
     model.static_batch = True      # the same triplets every step: build their index once, exact and locality-ordered
     params = [p for p in model.parameters() if p.requires_grad]
     # One GPU: the step is replayed as a hipGraph.  With RCCL collectives in the step (world > 1) the default is eager
@@ -283,7 +438,9 @@ def main():
     pick_rng = random.Random(rank)
     post_idx = torch.zeros(200, dtype=torch.long, device=dev)
     model.encoder.mmd_index_override = post_idx          # static buffer: contents refreshed per step on the host
-    pinned = torch.zeros(200, dtype=torch.long).pin_memory()
+    # two pinned staging buffers used in turn, each rewritten only after the H2D copy that last read it has completed
+    pinned = [torch.zeros(200, dtype=torch.long).pin_memory() for _ in range(2)]
+    pinned_evt, pinned_turn = [None, None], [0]
     one = torch.ones((), device=dev)        # d(loss)/d(loss): handed to backward instead of a ones_like fill per step
 
     # ---- the two multi-GPU schemes.  Each mode = inputs + how the exchange is wired into the model ----------
@@ -322,8 +479,14 @@ def main():
         ids = pick_rng.sample(range(n_nodes), 200)
         if cur['pick_map'] is not None:
             ids = cur['pick_map'][ids]
-        pinned.copy_(torch.as_tensor(ids))
-        post_idx.copy_(pinned, non_blocking=True)
+        k = pinned_turn[0]
+        pinned_turn[0] ^= 1
+        if pinned_evt[k] is not None:
+            pinned_evt[k].synchronize()
+        pinned[k].copy_(torch.as_tensor(ids))
+        post_idx.copy_(pinned[k], non_blocking=True)
+        pinned_evt[k] = torch.cuda.Event()
+        pinned_evt[k].record()
 
     def step_body():
         opt.zero_grad()
@@ -506,46 +669,70 @@ def main():
             detail[tag] = {'avg_us': round(avg_ms * 1e3, 2), 'launches': len(vals),
                            'algorithmic_MB': round(nbytes / 1e6, 2),
                            'achieved_GBs': round(nbytes / 1e9 / (avg_ms * 1e-3), 1) if avg_ms > 0 else None}
-        rg = {k: v for k, v in detail.items() if k.startswith('agg_') and not k.startswith('agg_N_1x1')}
+        # Every K1 instance against the memory level that serves its gathers: tables beyond the 256 MiB Infinity Cache are
+        # an HBM test (8 TB/s); cache-resident ones (FB15k-237: 11.6-58 MB) are graded against the guide's indexed-row
+        # rates -- Infinity Cache 8.6 TB/s for the aggregations, an XCD's L2 17.8 TB/s for grad-W, whose items are laid
+        # out in L2 windows -- and ALSO against 8 TB/s (frac_of_hbm_peak), the figure north_star's 40 % target is stated in
+        for tag, d in detail.items():
+            kind, rest = tag.split('_', 1)
+            blk = rest.split('_')[1 if kind == 'agg' else 0]
+            nbk = int(rest.split('_')[-1][2:])
+            gathered = n_nodes * nbk * int(blk.split('x')[0]) * 4 * (2 if kind == 'gradw' else 1)
+            hbm = gathered > (256 << 20)
+            d['bound'] = 'hbm' if hbm else 'l2/mall'
+            d['peak_GBs'] = HBM_PEAK_GBS if hbm else (L2_GATHER_GBS if kind == 'gradw' else MALL_GATHER_GBS)
+            if d['achieved_GBs']:
+                d['frac'] = round(d['achieved_GBs'] / d['peak_GBs'], 4)
+                d['frac_of_hbm_peak'] = round(d['achieved_GBs'] / HBM_PEAK_GBS, 4)
+        rg = {k: v for k, v in detail.items() if k.startswith('agg_') and not k.startswith('agg_N_1x1') and v.get('frac')}
         if rg:
-            dom = max(rg, key=lambda k: rg[k]['avg_us'])
-            ach = rg[dom]['achieved_GBs']
-            roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic_for(dom),
-                        'avg_us': rg[dom]['avg_us'], 'algorithmic_MB': rg[dom]['algorithmic_MB']}
+            # the headline is the WORST R-GCN aggregation instance (lowest fraction of its peak), not the best one
+            dom = min(rg, key=lambda k: rg[k]['frac'])
+            traffic, traffic_src = pmc_traffic_for(dom)
+            roofline = {'kernel': dom, 'bound': rg[dom]['bound'], 'achieved': rg[dom]['achieved_GBs'],
+                        'peak': rg[dom]['peak_GBs'], 'unit': 'GB/s', 'frac': rg[dom]['frac'],
+                        'frac_of_hbm_peak': rg[dom]['frac_of_hbm_peak'], 'traffic': traffic, 'traffic_source': traffic_src,
+                        'avg_us': rg[dom]['avg_us'], 'algorithmic_MB': rg[dom]['algorithmic_MB'],
+                        'frac_min': min(v['frac'] for v in rg.values()), 'frac_max': max(v['frac'] for v in rg.values()),
+                        'frac_of_hbm_peak_min': min(v['frac_of_hbm_peak'] for v in rg.values()),
+                        'instances': {k: v['frac'] for k, v in sorted(rg.items())}}
     if world > 1:
         dist.barrier()
 
     if rank == 0:
         out = {
             'metric': 'edges/sec R-GCN forward+backward, FB15k-237 emb=200',
-            'value': world * E * args.steps / elapsed, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps,
+            'value': trained_edges * args.steps / elapsed, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None,
+            'scaling': 'strong' if w['strong'] else 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.gemm_precision == 'f32' else 'f32 (dense products: bf16 operands, f32 accumulate)',
             'data': 'synthetic',
-            'config': {'workload': 'FB15k-237-shaped synthetic full graph (BASELINE configs[1]): 14541 entities, '
-                                   '474 directed relation types, E=%d directed edges per GPU, 2-layer R-GCN-VAE bdd '
-                                   'num_bases=%d emb_dim=%d fp32 dropout %.1f, DistMult decoder on T=%d triplets, '
-                                   'step = fwd + loss(BCE+reg+KL+MMD) + bwd + clip + Adam' %
-                                   (E, args.n_bases, args.hidden, args.dropout, T),
-                       'edges_per_gpu': E, 'nodes': n_nodes, 'triplets_per_gpu': T, 'n_flows': args.n_flows,
+            'config': {'workload': '%s: %d entities, %d directed relation types, E=%d directed edges on this rank (%d in the '
+                                   'trained graph), 2-layer R-GCN-VAE bdd num_bases=%d emb_dim=%d dropout %.1f, %d IAF blocks, '
+                                   'DistMult decoder on T=%d triplets per rank, step = fwd + loss(BCE+reg+KL+MMD) + bwd + clip + '
+                                   'Adam' % (cfg['label'], n_nodes, 2 * cfg['rels'], E, trained_edges, args.n_bases, args.hidden,
+                                             args.dropout, args.n_flows, T),
+                       'baseline_config': 'configs[%d]' % cfg['idx'],
+                       'edges_per_gpu': E, 'trained_graph_edges': trained_edges, 'nodes': n_nodes, 'triplets_per_gpu': T,
+                       'n_flows': args.n_flows, 'relation_shard': list(w['shard']) if w['shard'] else None,
                        'gemm_precision': args.gemm_precision, 'launch': launch,
                        'parallelism': ('single GPU' if not dist_on else
-                                       'edge-block sharding x%d, RCCL all-reduce of node embeddings' % world
-                                       if cur['name'] == 'edge' else
-                                       'destination-row partition x%d of the union of the ranks\' edge blocks, RCCL '
-                                       'all-gather / reduce-scatter of node rows' % world),
+                                       ('ONE graph cut by relation range' if w['strong'] else 'edge-block sharding') +
+                                       ' x%d, RCCL all-reduce of node embeddings' % world if cur['name'] == 'edge' else
+                                       'destination-row partition x%d of %s, RCCL all-gather / reduce-scatter of node rows'
+                                       % (world, 'the one graph' if w['strong'] else 'the union of the ranks\' edge blocks')),
                        'partition': cur['name'] if dist_on else None,
                        'partition_probe_ms_per_step': {k: round(v, 4) for k, v in probe.items()} or None,
                        'row_partition_edges_per_rank': edge_counts},
             'final_loss': final_loss,
             'roofline': roofline, 'roofline_detail': detail,
         }
+        out['cpu_baseline'], out['parity_check'] = None, None
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(w, model, args, args.cpu_seconds)
-        else:
-            out['cpu_baseline'] = None
+            out['cpu_baseline'], ref = cpu_baseline(w, model, args, args.cpu_seconds)
+            if not args.no_check:      # the timed workload, checked at its own size against the oracle (raises on failure)
+                out['parity_check'] = parity_check(model, opt, modes['edge'], ref, dev)
+                out['parity_max_rel_err'] = out['parity_check']['parity_max_rel_err']
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -582,9 +582,10 @@ class PhaseOrder:
 
     def coef(self, coef: torch.Tensor) -> torch.Tensor:
         """Per-edge coefficients (caller's edge order) in list order; cached on the tensor (kept alive) and its version."""
+        key = (coef.data_ptr(), coef._version, coef.numel())      # views / saved-tensor unpacks are new objects every call
         hit = getattr(self, '_coef', None)
-        if hit is None or hit[0] is not coef or hit[1] != coef._version:
-            hit = self._coef = (coef, coef._version, coef.reshape(-1)[self.perm].contiguous())
+        if hit is None or hit[0] != key:
+            hit = self._coef = (key, coef, coef.reshape(-1)[self.perm].contiguous())      # holds the tensor: no address reuse
         return hit[2]
 
 

@@ -31,7 +31,8 @@ def main():
             gg = torch.randn(N, fout, device='cuda')
             w = torch.randn(R, nb * si * so, device='cuda') * 0.1
             pre = torch.randn(N, fout, device='cuda')
-            for side, feat, p, q, tr, add in (('dst', x, si, so, False, pre), ('src', gg, so, si, True, None)):
+            pre_in = torch.randn(N, fin, device='cuda')
+            for side, feat, p, q, tr, add in (('dst', x, si, so, False, pre), ('src', gg, so, si, True, pre_in)):
                 order = gidx.by_dst if side == 'dst' else gidx.by_src
                 nbr = gidx.nbr_by_dst if side == 'dst' else gidx.nbr_by_src
                 ety = ridx.et_by_dst if side == 'dst' else ridx.et_by_src
