@@ -58,10 +58,13 @@ def test_bench_single_rank_rccl(extra):
     assert d['final_loss'] == d['final_loss']          # not NaN
 
 
-def test_two_ranks_edge_sharded_equals_single_process():
-    """world_size 2 on ONE GPU (gloo, both ranks on cuda:0): the edge-sharded HIP path -- reduce hooks in both layers'
-    forward and backward, averaged gradients -- equals the single-process HIP run on the union graph."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+@pytest.mark.parametrize('hidden', ['200', '500'])
+def test_two_ranks_edge_sharded_equals_single_process(hidden):
+    """world_size 2 on ONE GPU (gloo, both ranks on cuda:0): the edge-sharded HIP path -- the ONE graph's edges cut by
+    relation range (distributed.shard_edges_by_relation), reduce hooks in both layers' forward and backward, averaged
+    gradients -- equals the single-process HIP run on the whole graph.  hidden = 500: BASELINE configs[3]'s width
+    (5x5 / 5x10 blocks)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GV_WORKER_HIDDEN=hidden)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(free_port()), os.path.join(ROOT, 'tests', 'workers', 'dist_gpu_worker.py')]
     out = run_ranks(cmd, env, 600)
@@ -87,6 +90,27 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert set(d['config']['partition_probe_ms_per_step']) == {'edge/segments', 'edge/eager', 'edge/segments/1-block',
                                                                'row/segments', 'row/eager'}
     assert d['config']['partition'] in ('edge', 'row')
+
+
+@pytest.mark.parametrize('extra', [['--scaling', 'strong', '--partition', 'edge'], ['--scaling', 'strong', '--partition', 'row'],
+                                   ['--config', 'c4', '--scaling', 'strong', '--partition', 'edge']])
+def test_bench_two_ranks_strong_scaling_one_graph(extra):
+    """bench.py --scaling strong on two ranks sharing one GPU (gloo): ONE FB15k-237-shaped graph, its directed edges cut by
+    relation range (or by destination row), its triplets dealt round-robin; value counts the one graph's edges once."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GV_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--no-cpu-baseline', '--profile-steps', '0', '--positives', '2000'] + extra
+    out = run_ranks(cmd, env, 900)
+    assert out.returncode == 0, (out.stdout[-1500:] + '\n' + out.stderr[-2500:])
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['config']['trained_graph_edges'] == 544230
+    assert 0.3 < d['final_loss'] < 3.0, d['final_loss']
+    if 'edge' in extra:
+        lo, hi = d['config']['relation_shard']
+        assert 0 <= lo < hi <= 474 and 0.3 * 544230 < d['config']['edges_per_gpu'] < 0.7 * 544230
+    if 'c4' in extra:
+        assert d['config']['baseline_config'] == 'configs[3]' and 'emb_dim=500' in d['config']['workload']
 
 
 @pytest.mark.parametrize('partition', ['edge', 'row'])

@@ -27,7 +27,8 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
-    n, n_rel, h, nb = 1500, 60, 200, 100       # num_bases is clamped to the number of relation types: keep R >= 100
+    # num_bases is clamped to the number of relation types: keep R >= 100.  GV_WORKER_HIDDEN=500: BASELINE configs[3]'s width
+    n, n_rel, h, nb = 1500, 60, int(os.environ.get('GV_WORKER_HIDDEN', '200')), 100
     data = synthetic_kg(n, n_rel, 9000, seed=0)
     g_full, rel, node_norm = sampling.build_test_graph(n, n_rel, data.train)
     src, dst = (t.numpy() for t in g_full.edges())
