@@ -245,6 +245,7 @@ def cpu_baseline(w, model, args, budget_s):
     """The CPU oracle (oracle/, a torch-CPU port of the reference's op sequence; test infrastructure, used here as the
     reported baseline and as the checker of ``parity_check``) on the same inputs.  Returns (baseline record, reference
     outputs of the last oracle step for the parity leg)."""
+    from oracle import bf16 as obf16
     from oracle import kgvae as okg
     from oracle import rgcn as orgcn
     ncpu = os.cpu_count() or 1
@@ -280,7 +281,8 @@ def cpu_baseline(w, model, args, budget_s):
         for v in state.values():
             v.grad = None
         t0 = time.time()
-        with torch.autograd.set_detect_anomaly(anomaly):
+        # configs[2]: the oracle emulates the product's bf16-operand / fp32-accumulate dense products (oracle/bf16.py)
+        with torch.autograd.set_detect_anomaly(anomaly), obf16.enabled(args.gemm_precision == 'bf16'):
             enc = okg.kgvae_encode(state, src, dst, w['node_id'], rel, enorm, eps, args.n_bases, args.n_flows, args.dropout,
                                    keep1, keep2)
             loss = okg.link_predict_loss(state, enc, w['samples'], w['labels'], 0.01, 1e-5, 1.0, 10, args.n_flows,
@@ -313,11 +315,14 @@ def cpu_baseline(w, model, args, budget_s):
     return rec, ref
 
 
-def parity_check(model, opt, inputs, ref, dev):
+def parity_check(model, opt, inputs, ref, dev, bf16_products=False):
     """ONE eager HIP step (forward + loss + backward, no optimiser step) on the timed workload with the random draws the
     oracle used, compared with the oracle's step on the same weights: loss, z and six parameter gradients.
     Returns the JSON record; raises AssertionError beyond north_star's tolerance (1e-4 on outputs, 5e-4 on gradients,
-    relative to the tensor's largest magnitude)."""
+    relative to the tensor's largest magnitude).  ``bf16_products`` (configs[2]): the dense products take bf16 operands on
+    both sides; a last-bit difference in an fp32 activation can flip its bf16 rounding (2^-9 relative on that operand),
+    so the bounds are 5e-3 / 2e-2 there, as in tests/test_gpu_model.py::test_c3_wn18rr_shape_bf16_operand_gemms."""
+    tol_out, tol_grad = (5e-3, 2e-2) if bf16_products else (1e-4, 5e-4)
     enc = model.encoder
     saved = (enc.eps_override, enc.mmd_eps_override, enc.mmd_index_override, enc.rconv_layer_1.keep_mask_override,
              enc.rconv_layer_2.keep_mask_override)
@@ -359,10 +364,10 @@ def parity_check(model, opt, inputs, ref, dev):
         worst_out = max(errs['loss'], errs['z'])
         worst_grad = max(v for k, v in errs.items() if k.startswith('grad '))
         worst_l2 = max(l2.values())
-        ok = worst_out <= 1e-4 and worst_l2 <= 5e-4 and (worst_grad <= 5e-4 or flips > 0)
+        ok = worst_out <= tol_out and worst_l2 <= tol_grad and (worst_grad <= tol_grad or flips > 0)
         rec = {'parity_max_rel_err': max(worst_out, worst_l2 if flips else worst_grad), 'outputs_max_rel_err': worst_out,
                'gradients_max_rel_err': worst_grad, 'gradients_max_rel_l2_err': worst_l2, 'relu_sign_flips': flips,
-               'tolerance': {'outputs': 1e-4, 'gradients': 5e-4}, 'passed': ok,
+               'tolerance': {'outputs': tol_out, 'gradients': tol_grad}, 'passed': ok,
                'checked': sorted(errs), 'detail': {k: float('%.3g' % v) for k, v in errs.items()},
                'detail_rel_l2': {k: float('%.3g' % v) for k, v in l2.items()},
                'against': 'oracle/ (CPU restatement) on the timed workload, same weights and random draws; errors are '
@@ -731,7 +736,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'], ref = cpu_baseline(w, model, args, args.cpu_seconds)
             if not args.no_check:      # the timed workload, checked at its own size against the oracle (raises on failure)
-                out['parity_check'] = parity_check(model, opt, modes['edge'], ref, dev)
+                out['parity_check'] = parity_check(model, opt, modes['edge'], ref, dev, args.gemm_precision == 'bf16')
                 out['parity_max_rel_err'] = out['parity_check']['parity_max_rel_err']
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
