@@ -337,6 +337,7 @@ def parity_check(model, opt, inputs, ref, dev, bf16_products=False):
     hook = enc.rconv_layer_1.register_forward_hook(lambda _m, _i, o: seen.__setitem__('h1', o.detach()))
     try:
         opt.flat_g.zero_()
+        opt._mark_fresh()
         embed = model(inputs['g'], inputs['node_id'], inputs['etype'], inputs['enorm'])
         loss = model.get_loss(inputs['g'], embed, inputs['samples'], inputs['labels'])[0]
         loss.backward()

@@ -248,15 +248,22 @@ __global__ __launch_bounds__(256) void k_rank_scores(const RankParams rp) {
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         const bool in = row < p.m && col < p.n;
-        const float prob = 1.f / (1.f + expf(-(acc[r] + bv)));
+        // ranked on the LOGIT: monotone with the reference's sigmoid (kgvae/utils.py:208) but free of its saturation,
+        // where every candidate ties at 1.0f.  count = 2 * #better + #equal, i.e. twice the mid-rank under ties; a
+        // candidate that is NaN, or any candidate when the target itself is NaN, counts as better (never optimistic).
+        const float logit = acc[r] + bv;
         const int tcol = row < p.m ? rp.target[row] : -1;
         if (PASS == 0) {
-            if (in && col == tcol) rp.tgt[row] = prob;
+            if (in && col == tcol) rp.tgt[row] = logit;
         } else {
-            const bool above = in && col != tcol && prob > rp.tgt[row];
-            const unsigned long long mask = __ballot(above);
+            const float t = row < p.m ? rp.tgt[row] : 0.f;
+            const bool other = in && col != tcol;
+            const bool above = other && !(logit <= t);          // greater, or either side NaN
+            const bool equal = other && logit == t;
+            const unsigned long long ma = __ballot(above), me = __ballot(equal);
             if (l31 == 0 && row < p.m) {
-                const int c = __popc((unsigned)(lhi ? (mask >> 32) : (mask & 0xffffffffull)));
+                const int c = 2 * __popc((unsigned)(lhi ? (ma >> 32) : (ma & 0xffffffffull))) +
+                              __popc((unsigned)(lhi ? (me >> 32) : (me & 0xffffffffull)));
                 if (c) atomicAdd(rp.count + row, c);
             }
         }

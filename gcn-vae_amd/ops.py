@@ -23,6 +23,10 @@ ACT_NONE, ACT_RELU = 0, 1
 # parameter here accumulates in place and returns None for it, so autograd launches no zero-fill and no
 # AccumulateGrad add for that parameter.  Empty registry = ordinary autograd behaviour.
 DIRECT_GRAD = {}
+# Gradient buffers (keyed by address) that are known to be all-zero right now: the optimiser adds its arena slices after
+# zero_grad() / step(); the first backward kernel that writes one removes it.  Only a buffer listed here may be
+# OVERWRITTEN by a backward kernel (the identity-embedding path below); anything else is accumulated into.
+GRAD_FRESH = set()
 
 
 def _direct(t):
@@ -837,9 +841,10 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, 
 
 
 def rank_scores(q, entities, target, bias=None):
-    """Raw ranks (0-based, int64) of ``target[i]`` among all entities under prob = sigmoid(q @ entities^T + bias):
-    the number of OTHER entities with a strictly larger probability (gv_rank_scores: MFMA tiles with a rank-count
-    epilogue; the (m, V) score matrix is never stored)."""
+    """Raw ranks (0-based, float: x.5 under ties) of ``target[i]`` among all entities under score = q @ entities^T + bias:
+    the number of OTHER entities with a strictly larger logit plus HALF the number that tie with it (gv_rank_scores:
+    MFMA tiles with a rank-count epilogue; the (m, V) score matrix is never stored).  Logits, not sigmoid outputs: same
+    order, no saturation ties.  A NaN target score ranks last."""
     q, ld_q = _row_major(q, 'q')
     entities, ld_e = _row_major(entities, 'entities')
     if q.shape[1] != entities.shape[1]:
@@ -857,7 +862,7 @@ def rank_scores(q, entities, target, bias=None):
     count = torch.empty(max(m, 1), dtype=torch.int32, device=q.device)
     lib.call('gv_rank_scores', ptr(q), ld_q, ptr(entities), ld_e, ptr(tgt32), ptr(bias), ptr(ws), ptr(count), m, v,
              q.shape[1], lib.stream())
-    return count[:m].to(torch.int64)
+    return count[:m].to(torch.float32) * 0.5
 
 
 def pick_split_k(m_out, n_out, k):
@@ -1026,6 +1031,8 @@ class _Embedding(torch.autograd.Function):
         tgt = ctx.direct
         gt = tgt if tgt is not None else torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
         lib.call('gv_scatter_add_rows', ptr(g), ptr(ids), ptr(gt), ids.numel(), ctx.shape[1], lib.stream())
+        if tgt is not None:
+            GRAD_FRESH.discard(tgt.data_ptr())
         return (None if tgt is not None else gt), None, None
 
 
@@ -1051,6 +1058,7 @@ class _EmbeddingIdentity(torch.autograd.Function):
         if tgt is None:
             return g, None
         lib.call('gv_axpby', g.numel(), None, 1.0, ptr(g), 1.0, ptr(tgt), lib.stream())
+        GRAD_FRESH.discard(tgt.data_ptr())
         return None, None
 
 
@@ -1079,12 +1087,11 @@ def embedding(table, ids, tick_rng=None, sole_consumer=False):
             identity = bool(_identity_ids.get((ids.data_ptr(), ids._version, ids.numel())))
         else:
             identity = _ids_are_identity(table, ids)
-    if identity:
+    if identity and sole_consumer:      # the output ALIASES the table: only for the fused layer, which never writes its input
         out = _EmbeddingIdentity.apply(table, tick_rng)
-        if sole_consumer:
-            out._gv_grad_target = _direct(table)
+        out._gv_grad_target = _direct(table)
         return out
-    return _Embedding.apply(table, ids, tick_rng)
+    return _Embedding.apply(table, ids, tick_rng)      # a real copy, as nn.Embedding returns
 
 
 class _RelGraphConvBdd(torch.autograd.Function):
@@ -1200,13 +1207,20 @@ class _RelGraphConvBdd(torch.autograd.Function):
         tl = None
         if reduce_hook is None and ctx.needs_input_grad[0] and use_phases(gidx, so, si, True, g_agg.shape[0], g_agg.shape[1]):
             tl = ridx.phase_order(gidx, 'src', nb, so, si)
+        # dL/dx rows may be stored straight into the embedding table's gradient (identity lookup) -- but only while that
+        # buffer is known to be zero (fresh from zero_grad / step); a second backward before the next step, or another
+        # lookup of the table whose gradient landed first, must be added to, not erased
+        x_tgt = x_add = ctx.x_grad_target if ctx.needs_input_grad[0] else None
+        if x_tgt is not None:
+            if x_tgt.data_ptr() in GRAD_FRESH:
+                GRAD_FRESH.discard(x_tgt.data_ptr())
+                x_add = None
+            else:
+                x_tgt = None
         if tl is not None:
-            x_tgt = ctx.x_grad_target
             grad_x = bdd_aggregate_phases(tl, None if coef is None else tl.coef(coef), g_agg,
                                           pack_weight_phase(tl, weight, nb, so, si), weight.shape[0], nb, so, si, gx_loop,
                                           out=x_tgt)
-            if x_tgt is not None:
-                grad_x = None
         elif ctx.needs_input_grad[0]:
             pk = si * so >= 8 and pack_supported(nb, so, si, True)
             if ctx.w_bwd_packed is not None and weight._version == ctx.w_version:
@@ -1215,7 +1229,6 @@ class _RelGraphConvBdd(torch.autograd.Function):
                 w_bwd = pack_weight(weight, nb, so, si, True) if pk else weight
             # static graphs: the edge norm is cached in this launch's order; per-batch graphs read it through the index
             static = not gidx.sync_free and coef is not None
-            x_tgt = ctx.x_grad_target
             if ctx.grouped:
                 seg, nbr, ety, perm = ridx.grouped_order(gidx, 'src')
                 coef_g = None if coef is None else ridx.grouped_coef_src(coef, perm)
@@ -1224,8 +1237,11 @@ class _RelGraphConvBdd(torch.autograd.Function):
                 coef_s, idx_s = (gidx.coef_in_src_order(coef), None) if static else (coef, gidx.by_src.perm)
                 grad_x = bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, coef_s, idx_s, g_agg,
                                        w_bwd, nb, so, si, True, gx_loop, out=x_tgt, packed=pk)
-            if x_tgt is not None:
-                grad_x = None
+        if grad_x is not None and x_tgt is not None:
+            grad_x = None                                  # written in place
+        elif grad_x is not None and x_add is not None:     # the table's gradient already holds something: add
+            lib.call('gv_axpby', grad_x.numel(), None, 1.0, ptr(grad_x), 1.0, ptr(x_add), lib.stream())
+            grad_x = None
         grad_w = None
         if ctx.needs_input_grad[1]:
             static = not gidx.sync_free and coef is not None

@@ -51,15 +51,25 @@ class FlatAdam:
         try:
             for k in getattr(self, '_direct_keys', ()):
                 ops.DIRECT_GRAD.pop(k, None)
+            for p in getattr(self, 'params', ()):
+                if p.grad is not None:
+                    ops.GRAD_FRESH.discard(p.grad.data_ptr())
         except Exception:
             pass
+
+    def _mark_fresh(self):
+        # every gradient slice is zero now: backward kernels that can store a gradient instead of adding it may do so once
+        for p in self.params:
+            ops.GRAD_FRESH.add(p.grad.data_ptr())
 
     def zero_grad(self):
         # the clip+Adam kernel clears the arena as it consumes it: right after step() there is nothing to do
         if self._clean:
             self._clean = False
+            self._mark_fresh()
             return
         self.flat_g.zero_()
+        self._mark_fresh()
 
     def grad_norm(self):
         """Total gradient norm of the last ``step`` (device scalar)."""

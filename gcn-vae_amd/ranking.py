@@ -2,13 +2,15 @@
 
 The reference scores a batch against every entity by materialising a (h, Eb, V) outer-product
 tensor and summing over h, adds ``flow_log_prob``, applies a sigmoid, sorts every row and looks the
-target up.  Here ``ops.rank_scores`` (gv_rank_scores) forms sigmoid((e_a * w_r) @ E^T + flow_log_prob)
-tile by tile on the f32 MFMA and counts, per query, the entities with a strictly larger probability than
-the target's -- the score matrix is never stored and thousands of queries go through one launch.  The
-count equals the reference's sort-and-find whenever the probabilities are tie free (ties are broken
-towards the better rank); sigmoid saturation makes the reference's own ranks depend on ``torch.sort``'s
-unspecified tie order, so no implementation can match it there.  ``perturb_and_get_rank_unfused`` keeps
-the materialised form (one GEMM + torch ops) as the in-repo cross-check of the fused kernel.
+target up.  Here ``ops.rank_scores`` (gv_rank_scores) forms (e_a * w_r) @ E^T + flow_log_prob tile by tile on the
+f32 MFMA and counts, per query, the entities that beat the target -- the score matrix is never stored and
+thousands of queries go through one launch.  Ranking is done on the LOGITS: the sigmoid is monotone, so tie-free
+ranks equal the reference's sort-and-find, but it saturates (every candidate at 1.0f once the logits are large --
+likely with ``flow_log_prob`` added to all of them), where the reference's rank is wherever ``torch.sort`` happens
+to leave the target inside the tie block.  Ties are counted explicitly: rank = #better + #equal / 2 (the expected
+position in such a block; ranks are floats), and a NaN target score (diverged run) ranks LAST -- never the
+optimistic rank 1 that would make ``main`` keep a broken checkpoint as "best".
+``perturb_and_get_rank_unfused`` keeps the materialised form (one GEMM + torch ops) as the in-repo cross-check.
 """
 import torch
 
@@ -16,8 +18,12 @@ from . import ops
 
 
 def sort_and_rank(score, target):
+    """0-based mid-rank of ``target`` in every row of a materialised (logit) score matrix; NaN never ranks well."""
     tgt = score.gather(1, target.view(-1, 1))
-    return (score > tgt).sum(dim=1)
+    other = torch.ones_like(score, dtype=torch.bool).scatter_(1, target.view(-1, 1), False)
+    better = (~(score <= tgt)) & other
+    equal = (score == tgt) & other
+    return better.sum(dim=1).float() + 0.5 * equal.sum(dim=1).float()
 
 
 MAX_QUERY_ROWS = 16384      # queries per gv_rank_scores launch (bounds the (rows, h) query matrix, nothing else)
@@ -38,7 +44,7 @@ def perturb_and_get_rank(embedding, w, a, r, b, test_size, batch_size=100, all_b
         if verbose:
             rr = 1.0 + torch.cat(ranks).float()
             print("rows {} / {}: MR : {:.6f} |  MRR : {:.6f}".format(hi, n, rr.mean().item(), (1.0 / rr).mean().item()))
-    return torch.cat(ranks) if ranks else torch.zeros(0, dtype=torch.int64, device=emb.device)
+    return torch.cat(ranks) if ranks else torch.zeros(0, dtype=torch.float32, device=emb.device)
 
 
 def perturb_and_get_rank_unfused(embedding, w, a, r, b, test_size, batch_size=100, all_batches=True, flow_log_prob=None,
@@ -54,8 +60,7 @@ def perturb_and_get_rank_unfused(embedding, w, a, r, b, test_size, batch_size=10
         score = ops.gemm(emb_ar, emb, trans_b=True)                       # (Eb, V)
         if flow_log_prob is not None:
             score = score + flow_log_prob
-        score = torch.sigmoid(score)
-        ranks.append(sort_and_rank(score, b[lo:hi]))
+        ranks.append(sort_and_rank(score, b[lo:hi]))              # on the logits (see the module docstring)
         if verbose:
             rr = 1.0 + torch.cat(ranks).float()
             print("batch {} / {}: MR : {:.6f} |  MRR : {:.6f}".format(idx, n_batch, rr.mean().item(),

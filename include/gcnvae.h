@@ -161,10 +161,14 @@ int gv_rel_gradw_gemm(const float* x, int ld_x, const int32_t* x_rows, const flo
                       const float* scale, const int32_t* relptr, int num_rels, int in_feat, int out_feat, float* grad_w,
                       void* stream);
 /* Evaluation scorer with a fused rank count (replaces the (h, Eb, V) outer-product tensor + sort of
- * utils.perturb_and_get_rank / sort_and_rank, kgvae/utils.py:180-221): prob = sigmoid(q @ e^T + *bias) is formed tile by
- * tile on the f32 MFMA and never stored;  count[i] = #{ j != target[i] : prob[i, j] > prob[i, target[i]] }  = the raw rank
- * (0-based) of the target with ties broken towards the better rank.  q (m, h), e (v, h) row-major fp32, target int32 [m] in
- * [0, v), bias optional device scalar (flow_log_prob), tgt: m floats of workspace, count int32 [m] (zeroed here). */
+ * utils.perturb_and_get_rank / sort_and_rank, kgvae/utils.py:180-221): logit = q @ e^T + *bias is formed tile by tile on
+ * the f32 MFMA and never stored.  Ranking happens on the LOGIT -- monotone with the reference's sigmoid but without its
+ * saturation (all candidates tie at 1.0f once the logits are large, e.g. with flow_log_prob added) -- with explicit ties:
+ *   count[i] = 2 * #{ j != t_i : logit[i, j] > logit[i, t_i] } + #{ j != t_i : logit[i, j] == logit[i, t_i] }
+ * = twice the 0-based mid-rank of the target (the expected position under the arbitrary tie order of the reference's
+ * torch.sort); a NaN candidate, or every candidate when the target's logit is NaN, counts as better.
+ * q (m, h), e (v, h) row-major fp32, target int32 [m] in [0, v), bias optional device scalar (flow_log_prob),
+ * tgt: m floats of workspace, count int32 [m] (zeroed here). */
 int gv_rank_scores(const float* q, int ld_q, const float* e, int ld_e, const int* target, const float* bias, float* tgt,
                    int* count, int m, int v, int h, void* stream);
 

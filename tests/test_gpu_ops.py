@@ -739,16 +739,14 @@ def test_xcd_ordered_grad_w_items_give_identical_bits(ops):
 # ------------------------------------------------------------------------------------------------
 # evaluation scorer with the fused rank count (gv_rank_scores)
 def _ranks_by_definition(ops, emb, w, a, r, b, flp):
-    """count of OTHER entities with a strictly larger sigmoid(score); scores from the same f32 MFMA GEMM."""
+    """#OTHER entities with a strictly larger logit + half of those that tie; scores from the same f32 MFMA GEMM."""
     q = ops.mul(emb[a].contiguous(), w[r].contiguous())
     score = ops.gemm(q, emb, trans_b=True)
     if flp is not None:
         score = score + flp
-    prob = torch.sigmoid(score)
-    tgt = prob.gather(1, b.view(-1, 1))
-    above = prob > tgt
-    above.scatter_(1, b.view(-1, 1), False)
-    return above.sum(1)
+    tgt = score.gather(1, b.view(-1, 1))
+    other = torch.ones_like(score, dtype=torch.bool).scatter_(1, b.view(-1, 1), False)
+    return ((score > tgt) & other).sum(1).float() + 0.5 * ((score == tgt) & other).sum(1).float()
 
 
 @pytest.mark.parametrize('m,v,h,flp', [(1, 5, 4, None), (37, 1000, 16, 0.25), (300, 14541, 200, -1.5), (129, 777, 200, None),
@@ -764,13 +762,14 @@ def test_rank_scores_equals_materialised_count(ops, m, v, h, flp):
     q = ops.mul(emb[a].contiguous(), w[r].contiguous())
     got = ops.rank_scores(q, emb, b, bias)
     want = _ranks_by_definition(ops, emb, w, a, r, b, bias)
-    assert got.dtype == torch.int64 and torch.equal(got, want)
-    assert int(got.min()) >= 0 and int(got.max()) < v
+    assert got.dtype == torch.float32 and torch.equal(got, want)
+    assert float(got.min()) >= 0 and float(got.max()) < v
 
 
-def test_rank_scores_ties_and_saturation(ops):
-    """Duplicate entity rows tie with each other (neither counts as larger); saturated sigmoids (prob == 1.0f) tie too;
-    the target never counts itself."""
+def test_rank_scores_ties_saturation_and_nan(ops):
+    """Ties are counted, never broken in the target's favour: duplicate entity rows share the MID rank of their block; scores
+    that would saturate the reference's sigmoid (all 1.0f) still rank by their logits; all-equal scores give the middle
+    rank, not rank 1; a NaN target score (diverged run) ranks last; the target never counts itself."""
     h, v = 8, 130
     emb = torch.randn(v, h, generator=torch.Generator().manual_seed(0)).cuda()
     emb[7] = emb[3]                       # entity 7 duplicates entity 3
@@ -778,17 +777,30 @@ def test_rank_scores_ties_and_saturation(ops):
     q = emb[[3, 3]].clone()               # query = entity 3's own row: its self score is the squared norm
     target = torch.tensor([3, 7], device='cuda')
     got = ops.rank_scores(q, emb, target)
-    prob = torch.sigmoid(ops.gemm(q, emb, trans_b=True))
+    score = ops.gemm(q, emb, trans_b=True)
     for i in range(2):
         t = int(target[i])
-        want = int((prob[i] > prob[i, t]).sum())
-        assert int(got[i]) == want
-    assert int(got[0]) == int(got[1])     # the three copies share one rank
-    big = (emb * 50.0).contiguous()       # every positive score saturates the sigmoid: those entities all tie at 1.0
+        better = int((score[i] > score[i, t]).sum())
+        ties = int((score[i] == score[i, t]).sum()) - 1
+        assert ties == 2 and float(got[i]) == better + 0.5 * ties
+    assert float(got[0]) == float(got[1])     # the three copies share one rank
+    # logits of +-2500: the reference's sigmoid is exactly 1.0f / 0.0f there and everything ties; the logits still order
+    big = (emb * 50.0).contiguous()
     got_big = ops.rank_scores((q * 50.0).contiguous(), big, target)
-    prob_big = torch.sigmoid(ops.gemm((q * 50.0).contiguous(), big, trans_b=True))
-    assert float(prob_big.max()) == 1.0
-    assert int(got_big[0]) == int((prob_big[0] > prob_big[0, 3]).sum()) == 0
+    score_big = ops.gemm((q * 50.0).contiguous(), big, trans_b=True)
+    assert float(torch.sigmoid(score_big).max()) == 1.0
+    assert float(got_big[0]) == float((score_big[0] > score_big[0, 3]).sum()) + 1.0
+    # every candidate scores the same (e.g. collapsed embeddings): the middle rank, not the best one
+    same = torch.ones(v, h, device='cuda')
+    got_same = ops.rank_scores(torch.ones(4, h, device='cuda'), same, torch.tensor([0, 5, 64, 129], device='cuda'))
+    assert torch.equal(got_same.cpu(), torch.full((4,), (v - 1) / 2.0))
+    # NaN scores (a diverged run) never help: a NaN target ranks last, a NaN candidate counts as better than the target
+    bad = emb.clone()
+    bad[3] = float('nan')
+    got_nan = ops.rank_scores(q, bad, target)
+    sc = ops.gemm(q, bad, trans_b=True)
+    assert float(got_nan[0]) == v - 1                                    # target 3's own score is NaN
+    assert float(got_nan[1]) == float((sc[1] > sc[1, 7]).sum()) + 1 + 0.5  # entity 3 (NaN) better, entity 129 ties with 7
     with pytest.raises(ValueError):
         ops.rank_scores(q, emb, torch.tensor([0, v], device='cuda'))
 
@@ -802,7 +814,7 @@ def test_fused_ranker_matches_golden_ranks_and_unfused_path():
     s, r, o = trip[:, 0], trip[:, 1], trip[:, 2]
     n = trip.shape[0]
     rs = ranking.perturb_and_get_rank(emb, w, o, r, s, n, 10, True, flp)          # vectors captured from the reference
-    assert torch.equal(rs.cpu(), g['ranks_s'].to(torch.int64))
+    assert torch.equal(rs.cpu(), g['ranks_s'].to(torch.float32))       # tie-free vectors: same ranks as the reference
     for a, b in ((o, s), (s, o)):
         assert torch.equal(ranking.perturb_and_get_rank(emb, w, a, r, b, n, 10, True, flp),
                            ranking.perturb_and_get_rank_unfused(emb, w, a, r, b, n, 10, True, flp))
@@ -826,7 +838,7 @@ def test_rank_scores_full_fb15k237_eval_properties(ops):
                         torch.randint(0, v, (n,), generator=gen)], 1).cuda()
     s, r, o = trip[:, 0], trip[:, 1], trip[:, 2]
     full = ranking.perturb_and_get_rank(emb, w, s, r, o, n, 100, True, None)
-    assert full.shape == (n,) and int(full.min()) >= 0 and int(full.max()) < v
+    assert full.shape == (n,) and float(full.min()) >= 0 and float(full.max()) < v
     old = ranking.MAX_QUERY_ROWS
     try:
         ranking.MAX_QUERY_ROWS = 5000
