@@ -251,8 +251,8 @@ class GraphIndex:
         batch).  Cached on the tensor's identity and version: the edge norm of a graph is the same every step."""
         key = (coef.data_ptr(), coef._version, coef.numel())
         hit = getattr(self, '_coef_src_cache', None)
-        if hit is None or hit[0] != key:
-            hit = self._coef_src_cache = (key, coef.reshape(-1)[self.by_src.perm.long()].contiguous())
+        if hit is None or hit[0] != key:      # the entry holds the tensor, so its address cannot be recycled while cached
+            hit = self._coef_src_cache = (key, coef.reshape(-1)[self.by_src.perm.long()].contiguous(), coef)
         return hit[1]
 
     def dst_chunks(self, n_chunks: int):
@@ -433,7 +433,7 @@ class RelationIndex:
         cache = self.__dict__.setdefault('_grouped_coef', {})
         hit = cache.get(side)
         if hit is None or hit[0] != key:
-            hit = cache[side] = (key, coef.reshape(-1)[perm].contiguous())
+            hit = cache[side] = (key, coef.reshape(-1)[perm].contiguous(), coef)       # holds the key tensor alive
         return hit[1]
 
     def grouped_coef_src(self, coef, perm):
@@ -468,7 +468,7 @@ class RelationIndex:
         key = (coef.data_ptr(), coef._version, coef.numel())
         hit = getattr(self, '_coef_rel_cache', None)
         if hit is None or hit[0] != key:
-            hit = self._coef_rel_cache = (key, coef.reshape(-1)[self.by_rel.perm.long()].contiguous())
+            hit = self._coef_rel_cache = (key, coef.reshape(-1)[self.by_rel.perm.long()].contiguous(), coef)
         return hit[1]
 
     def _xcd_order_items(self):
@@ -1074,8 +1074,9 @@ def _ids_are_identity(table, ids):
     if hit is None:
         if len(_identity_ids) > 64:
             _identity_ids.clear()
-        hit = _identity_ids[key] = bool((ids.reshape(-1) == torch.arange(ids.numel(), device=ids.device)).all())
-    return hit
+        # the entry holds the ids tensor: its address cannot be handed to another tensor while the verdict is cached
+        hit = _identity_ids[key] = (bool((ids.reshape(-1) == torch.arange(ids.numel(), device=ids.device)).all()), ids)
+    return hit[0]
 
 
 def embedding(table, ids, tick_rng=None, sole_consumer=False):
@@ -1084,7 +1085,8 @@ def embedding(table, ids, tick_rng=None, sole_consumer=False):
     identity = False
     if table.is_cuda and isinstance(ids, torch.Tensor) and ids.is_cuda and ids.dtype == torch.int64:
         if torch.cuda.is_current_stream_capturing():      # no host synchronisation under capture: only a cached verdict counts
-            identity = bool(_identity_ids.get((ids.data_ptr(), ids._version, ids.numel())))
+            hit = _identity_ids.get((ids.data_ptr(), ids._version, ids.numel()))
+            identity = bool(hit and hit[0]) and ids.numel() == table.shape[0]
         else:
             identity = _ids_are_identity(table, ids)
     if identity and sole_consumer:      # the output ALIASES the table: only for the fused layer, which never writes its input
