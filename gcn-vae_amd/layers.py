@@ -107,10 +107,9 @@ class RelGraphConv(nn.Module):
                                        part, act_id, keep, scale if keep is not None else 1.0, gather_input, pad_output)
 
     def forward(self, g, x, etypes, norm=None):
-        if x.dtype == torch.int64 and x.dim() == 1:
-            if self.regularizer == 'bdd':
-                raise TypeError('Block decomposition does not allow integer ID feature.')
-            raise NotImplementedError('integer-id node features (entity_classify input layer) are out of scope')
+        int_ids = x.dtype == torch.int64 and x.dim() == 1
+        if int_ids and self.regularizer == 'bdd':
+            raise TypeError('Block decomposition does not allow integer ID feature.')
         gidx = graph_index_of(g, x.device)
         ridx = gidx.relation_index(etypes, self.num_rels)
         act_id, post_act = _activation_id(self.activation if self.activation else None)
@@ -121,7 +120,17 @@ class RelGraphConv(nn.Module):
             late_keep, keep = keep, None
         else:
             late_keep = None
-        if self.regularizer == 'bdd':
+        if int_ids:
+            # integer-id features (kgvae/entity_classify.py:25-34, :63: features = arange(num_nodes) into a basis layer
+            # with in_feat = num_nodes): a message is a ROW of the relation's matrix (DGL bmm_maybe_select), the
+            # self-loop term a row of loop_weight (matmul_maybe_select)
+            if self.reduce_hook is not None:
+                raise NotImplementedError('integer-id features are not wired into the multi-GPU edge sharding')
+            flat = self.weight.view(self.num_bases, self.in_feat * self.out_feat)
+            weight = ops.matmul(self.w_comp, flat) if self.num_bases < self.num_rels else flat
+            h = ops.rel_graph_conv_select(x, weight.view(self.num_rels, self.in_feat, self.out_feat), h_bias, loop_w, norm,
+                                          gidx, ridx, act_id, keep, scale if keep is not None else 1.0)
+        elif self.regularizer == 'bdd':
             h = ops.rel_graph_conv_bdd(x, self.weight, h_bias, loop_w, norm, gidx, ridx, self.num_bases, act_id, keep,
                                        scale if keep is not None else 1.0, self.reduce_hook)
         else:

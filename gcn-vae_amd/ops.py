@@ -1353,6 +1353,94 @@ class _RelGraphConvDense(torch.autograd.Function):
         return grad_x, grad_w, grad_bias, grad_loop, None, None, None, None, None, None
 
 
+class _RelGraphConvSelect(torch.autograd.Function):
+    """RelGraphConv('basis') on INTEGER-ID node features (the one-hot input layer of kgvae/entity_classify.py:25-34, :63;
+    DGL utils.bmm_maybe_select): a message is ROW (etype, id[src]) of the relation's (in x out) matrix, no product --
+
+        out[v] = keep*scale*act( sum_{e: dst=v} norm_e * W[etype_e * in + id[src_e], :]  +  loop_rows[v] + h_bias )
+
+    Forward = the K1 aggregation with 1x1 blocks gathering rows of W (R*in, out) through a per-edge row index; backward
+    w.r.t. W = the same aggregation over the transposed incidence (destination = W row, source = node row of dL/dh), a
+    rectangular graph index built once per (graph, ids); ``loop_rows`` = loop_weight[id] comes in through ops.embedding,
+    whose backward scatter-adds its gradient."""
+
+    @staticmethod
+    def forward(ctx, wflat, loop_rows, h_bias, norm, gidx, plan, act, keep, keep_scale):
+        wflat, _ = _row_major(wflat, 'relation rows')
+        n, fout = gidx.num_nodes, wflat.shape[1]
+        coef = None if norm is None else norm.reshape(-1)
+        addend = None
+        if h_bias is not None:
+            addend = h_bias.unsqueeze(0).expand(n, fout).contiguous()
+            if loop_rows is not None:
+                lib.call('gv_axpby', addend.numel(), None, 1.0, ptr(_chk(loop_rows.contiguous(), name='loop rows')), 1.0,
+                         ptr(addend), lib.stream())
+        elif loop_rows is not None:
+            addend = _chk(loop_rows.contiguous(), name='loop rows')
+        ones = torch.ones(1, fout, dtype=torch.float32, device=wflat.device)
+        out = bdd_aggregate(gidx.by_dst.seg, plan['row_by_dst'], plan['zeros'], coef, gidx.by_dst.perm, wflat, ones, fout, 1, 1,
+                            False, addend, act, keep, keep_scale)
+        ctx.save_for_backward(coef, out if act == ACT_RELU else None, keep)
+        ctx.meta = (plan, act, keep_scale, h_bias is not None, loop_rows is not None, tuple(wflat.shape))
+        ctx.direct_b = _direct(h_bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        coef, out, keep = ctx.saved_tensors
+        plan, act, keep_scale, has_bias, has_loop, wshape = ctx.meta
+        d_b = ctx.direct_b
+        grad_bias = None
+        if has_bias and ctx.needs_input_grad[2]:
+            grad_bias = d_b if d_b is not None else torch.empty(grad_out.shape[1], dtype=torch.float32, device=grad_out.device)
+            g = epilogue_bwd(out, grad_out, act, keep, keep_scale, colsum_out=grad_bias, colsum_accumulate=d_b is not None)
+            if d_b is not None:
+                grad_bias = None
+        else:
+            g = epilogue_bwd(out, grad_out, act, keep, keep_scale)
+        grad_w = None
+        if ctx.needs_input_grad[0]:
+            gi = plan['by_row']                      # destinations = rows of W, sources = node rows of g
+            ones = torch.ones(1, wshape[1], dtype=torch.float32, device=g.device)
+            coef_r = None if coef is None else coef[plan['edge_of_by_row']].contiguous()
+            grad_w = bdd_aggregate(gi.by_dst.seg, gi.nbr_by_dst, plan['zeros'], coef_r, None, g, ones, wshape[1], 1, 1)
+        return grad_w, (g if has_loop else None), grad_bias, None, None, None, None, None, None
+
+
+def select_plan(gidx, ridx, ids, in_feat):
+    """Index of the row-select layer, once per (graph, relation types, ids): the W row of every edge in by-destination
+    order, and the rectangular graph (W row <- destination node) of its weight gradient."""
+    cache = ridx.__dict__.setdefault('_select', {})
+    key = (ids.data_ptr(), ids._version, ids.numel(), int(in_feat))
+    hit = cache.get(key)
+    if hit is None:
+        ids = ids.reshape(-1)
+        if ids.numel() != gidx.num_src_nodes:
+            raise ValueError(f'{ids.numel()} node ids for a graph of {gidx.num_src_nodes} nodes')
+        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= in_feat):
+            raise ValueError(f'integer node features must lie in [0, in_feat = {in_feat})')
+        et = ridx.keepalive.reshape(-1).to(torch.int64)
+        row = et * in_feat + ids[gidx.src32.long()]                         # caller's edge order
+        if int(ridx.num_rels) * int(in_feat) >= 2 ** 31:
+            raise ValueError('num_rels * in_feat must fit int32')
+        perm_d = gidx.by_dst.perm
+        row_by_dst = (row if perm_d is None else row[perm_d.long()]).to(torch.int32).contiguous()
+        # weight gradient: a graph whose destinations are W rows and whose sources are the edges' destination NODES
+        by_row = GraphIndex(gidx.dst32.long(), row, int(ridx.num_rels) * int(in_feat), num_src_nodes=gidx.num_nodes)
+        edge_of = torch.arange(gidx.num_edges, device=gidx.device) if by_row.by_dst.perm is None else by_row.by_dst.perm.long()
+        hit = cache[key] = dict(row_by_dst=row_by_dst, by_row=by_row, edge_of_by_row=edge_of,
+                                zeros=torch.zeros(max(gidx.num_edges, 1), dtype=torch.int32, device=gidx.device), keep=ids)
+    return hit
+
+
+def rel_graph_conv_select(ids, w3, h_bias, loop_weight, norm, gidx, ridx, act=ACT_NONE, keep=None, keep_scale=1.0):
+    """RelGraphConv('basis') with integer-id features: w3 is (R, in, out), ids int64 (N,)."""
+    r, fin, fout = w3.shape
+    plan = select_plan(gidx, ridx, ids, fin)
+    loop_rows = embedding(loop_weight, ids.reshape(-1)) if loop_weight is not None else None
+    return _RelGraphConvSelect.apply(w3.reshape(r * fin, fout), loop_rows, h_bias, norm, gidx, plan, act, keep, float(keep_scale))
+
+
 def rel_graph_conv_dense(x, w3, h_bias, loop_weight, norm, gidx, ridx, act=ACT_NONE, keep=None, keep_scale=1.0):
     return _RelGraphConvDense.apply(x, w3, h_bias, loop_weight, norm, gidx, ridx, act, keep, float(keep_scale))
 

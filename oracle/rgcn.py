@@ -13,6 +13,10 @@ Semantics restated from DGL 0.4.x ``python/dgl/nn/pytorch/conv/relgraphconv.py``
           msg = bmm(x[src].view(-1, 1, si), W_e).view(-1, out) * norm
   basis : W   = (w_comp @ weight.view(nb, in*out)).view(R, in, out)   (if nb < R)
           msg = bmm(x[src].unsqueeze(1), W[etype]).squeeze(1) * norm
+          integer-id features (x int64 (N,), the one-hot input layer of kgvae/entity_classify.py:25, :31-34, :63 --
+          ``features = torch.arange(num_nodes)`` into ``RelGraphConv(num_nodes, h, R, "basis", ...)``):
+          msg = W.view(-1, out)[etype * in + x[src]] * norm     (DGL utils.bmm_maybe_select: a row select, no product)
+          and the self-loop term is loop_weight[x]               (DGL utils.matmul_maybe_select)
   h[v]  = sum of msg over in-edges of v (0 for in-degree 0)
   h     = h + h_bias ; h = h + x @ loop_weight ; h = activation(h) ; h = dropout(h)
 
@@ -81,7 +85,10 @@ def _messages(x, src, etypes, norm, params, regularizer, num_bases):
         if 'w_comp' in params:
             nbv, fi, fo = w.shape
             w = torch.matmul(params['w_comp'], w.view(nbv, fi * fo)).view(num_rels, fi, fo)
-        msg = torch.bmm(x.index_select(0, src).unsqueeze(1), w.index_select(0, etypes)).squeeze(1)
+        if x.dtype == torch.int64 and x.dim() == 1:       # integer ids: row (etype, id) of the relation's matrix
+            msg = w.reshape(-1, w.shape[2]).index_select(0, etypes * w.shape[1] + x.index_select(0, src))
+        else:
+            msg = torch.bmm(x.index_select(0, src).unsqueeze(1), w.index_select(0, etypes)).squeeze(1)
     else:
         raise ValueError("Regularizer must be either 'basis' or 'bdd'")
     if norm is not None:
@@ -96,12 +103,18 @@ def rel_graph_conv(x, src, dst, etypes, norm, params, regularizer='bdd', num_bas
     ``dropout_keep``: optional 0/1 tensor (N,out); the output is multiplied by
     ``keep / (1 - dropout_p)`` (what ``nn.Dropout`` does in training mode with that mask).
     """
+    int_ids = x.dtype == torch.int64 and x.dim() == 1
+    if int_ids and regularizer == 'bdd':
+        raise TypeError('Block decomposition does not allow integer ID feature.')
     msg = _messages(x, src, etypes, norm, params, regularizer, num_bases)
-    h = torch.zeros(x.shape[0], msg.shape[1], dtype=x.dtype).index_add(0, dst, msg)
+    h = torch.zeros(x.shape[0], msg.shape[1], dtype=msg.dtype).index_add(0, dst, msg)
     if 'h_bias' in params:
         h = h + params['h_bias']
     if 'loop_weight' in params:
-        h = h + bf16.mm(x, params['loop_weight'])      # fp32 unless oracle.bf16.enabled()
+        if int_ids:
+            h = h + params['loop_weight'].index_select(0, x)
+        else:
+            h = h + bf16.mm(x, params['loop_weight'])      # fp32 unless oracle.bf16.enabled()
     if activation is not None:
         h = activation(h)
     if dropout_keep is not None:

@@ -561,6 +561,42 @@ def test_basis_regularizer_layer(ops):
             close(v.grad, po[k].grad, rtol=2e-4, atol_scale=2e-5, msg='basis grad ' + k)
 
 
+@pytest.mark.parametrize('self_loop', [True, False])
+def test_basis_layer_with_integer_id_features(ops, self_loop):
+    """SURVEY 8(f-3), second half: the input layer of kgvae/entity_classify.py:25-34, :63 -- ``features = arange(num_nodes)``
+    into ``RelGraphConv(num_nodes, h, R, "basis", num_bases, activation=relu, self_loop=...)``: a message is ROW
+    (etype, id) of the relation's matrix (DGL bmm_maybe_select), the self-loop term a row of loop_weight.  Forward and all
+    gradients (weight, w_comp, h_bias, loop_weight) against the oracle; a permuted id list as well as arange; the bdd
+    regulariser refuses integer ids as DGL does."""
+    from gcn_vae_amd.graph import KGraph
+    from gcn_vae_amd.layers import RelGraphConv
+    n, e, r, fout = 150, 1100, 10, 16
+    src, dst, et, norm = zipf_graph(n, e, r, seed=21)
+    torch.manual_seed(3)
+    gen = torch.Generator().manual_seed(4)
+    for nb, ids in ((4, torch.arange(n)), (r, torch.randperm(n, generator=gen))):
+        layer = RelGraphConv(n, fout, r, 'basis', nb, activation=torch.relu, self_loop=self_loop, dropout=0.0)
+        with torch.no_grad():
+            layer.h_bias.normal_(0, 0.1)
+        gout = torch.randn(n, fout, generator=gen)
+        po = {k: v.detach().clone().requires_grad_(True) for k, v in layer.named_parameters()}
+        ho = orgcn.rel_graph_conv(ids, src, dst, et, norm, po, 'basis', nb, torch.relu)
+        ho.backward(gout)
+        g = KGraph()
+        g.add_nodes(n)
+        g.add_edges(src, dst)
+        layer = layer.cuda()
+        hg = layer(g, ids.cuda(), et.cuda(), norm.cuda())
+        hg.backward(gout.cuda())
+        close(hg, ho, msg='integer-id forward')
+        for k, v in layer.named_parameters():
+            close(v.grad, po[k].grad, rtol=2e-4, atol_scale=2e-5, msg='integer-id grad ' + k)
+    with pytest.raises(TypeError):
+        RelGraphConv(16, 16, r, 'bdd', 4).cuda()(g, torch.arange(n).cuda(), et.cuda(), norm.cuda())
+    with pytest.raises(ValueError):
+        layer(g, (ids + 1).cuda(), et.cuda(), norm.cuda())         # an id outside [0, in_feat)
+
+
 @pytest.mark.parametrize('fin,fout,act', [(200, 200, 'relu'), (200, 400, None), (64, 36, 'relu')])
 def test_basis_dense_path_equals_generic_path_and_oracle(ops, fin, fout, act, monkeypatch):
     """SURVEY 8(f-3) at FB15k-237 widths: the relation-grouped MFMA path (gv_rel_rows_gemm / gv_rel_gradw_gemm + 1x1 K1

@@ -103,3 +103,45 @@ def test_modules_construct_and_reject_cpu():
                         model_state_file='model_state.pth', model_class='KGVAE', load=False, generate=False)
     for k, v in ref_defaults.items():
         assert getattr(args, k) == v, k
+
+
+def test_compat_install_aliases_and_state_dict_manifest():
+    """``gcn_vae_amd.compat.install()`` -- the route by which the reference's own ``link_predict.py`` finds this package:
+    every module name the reference imports (kgvae/model.py:4-8, kgvae/link_predict.py:22-27, kgvae/utils.py:10) resolves
+    to the gfx950 classes, and models built THROUGH the aliases have the reference's state_dict keys and shapes
+    (tests/golden/state_dict_manifest.json, captured from the reference)."""
+    import importlib
+    import json
+    import os
+    import sys
+    from gcn_vae_amd import compat, data, encoders, flows, graph, layers, train
+    names = ('dgl', 'dgl.nn', 'dgl.nn.pytorch', 'dgl.contrib', 'dgl.contrib.data', 'model', 'flow_network', 'utils')
+    saved = {k: sys.modules.get(k) for k in names}
+    try:
+        compat.install()
+        assert importlib.import_module('dgl').DGLGraph is graph.KGraph
+        assert importlib.import_module('dgl.nn.pytorch').RelGraphConv is layers.RelGraphConv
+        assert importlib.import_module('dgl.contrib.data').load_data is data.load_data
+        model = importlib.import_module('model')
+        assert model.KGVAE is encoders.KGVAE and model.RGCN is encoders.RGCN and model.BaseRGCN is encoders.BaseRGCN
+        fn = importlib.import_module('flow_network')
+        assert fn.MADE is flows.MADE and fn.PermuteLayer is flows.PermuteLayer and fn.MaskedLinear is flows.MaskedLinear
+        utils = importlib.import_module('utils')
+        for f in ('get_adj_and_degrees', 'generate_sampled_graph_and_labels', 'build_test_graph', 'calc_mrr',
+                  'gaussian_parameters', 'sample_gaussian', 'log_normal', 'log_normal_mixture'):
+            assert callable(getattr(utils, f)), f
+        here = os.path.dirname(os.path.abspath(__file__))
+        manifest = json.load(open(os.path.join(here, 'golden', 'state_dict_manifest.json')))
+        for n_flows in (0, 3):      # the constructor call of kgvae/link_predict.py:123-135 at the fixtures' C1 size
+            net = train.LinkPredict(model.KGVAE, 1000, 16, 20, num_bases=4, num_hidden_layers=2, dropout=0.2, use_cuda=False,
+                                    reg_param=0.01, kl_param=1e-5, mmd_param=1.0, k=10, n_flows=n_flows)
+            got = {k: list(v.shape) for k, v in net.state_dict().items()}
+            assert got == manifest['LinkPredict(KGVAE,n_flows=%d)' % n_flows]
+        rg = model.RGCN(50, 8, 8, 6, 2, num_hidden_layers=2, dropout=0.0, use_self_loop=True, use_cuda=False)
+        assert {k: list(v.shape) for k, v in rg.state_dict().items()} == manifest['RGCN(num_hidden_layers=2)']
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v

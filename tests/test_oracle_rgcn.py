@@ -79,3 +79,29 @@ def test_gradcheck_fp64():
         return rgcn.rel_graph_conv(x_, src, dst, et, norm, dict(weight=w_, h_bias=b_, loop_weight=lw_), 'bdd', 2,
                                    torch.tanh)
     assert torch.autograd.gradcheck(f, (x, w, b, lw), eps=1e-6, atol=1e-5)
+
+
+def test_integer_id_features_equal_one_hot_features():
+    """DGL bmm_maybe_select / matmul_maybe_select (kgvae/entity_classify.py:25-34, :63): integer ids select rows -- the same
+    numbers as multiplying the one-hot matrix of those ids, forward and gradients."""
+    gen = torch.Generator().manual_seed(0)
+    n, e, r, fout, nb = 40, 300, 6, 8, 3
+    src = torch.randint(0, n, (e,), generator=gen)
+    dst = torch.randint(0, n, (e,), generator=gen)
+    et = torch.randint(0, r, (e,), generator=gen)
+    norm = torch.rand(e, 1, generator=gen)
+    ids = torch.randperm(n, generator=gen)
+    p = rgcn.init_params(n, fout, r, 'basis', nb, True, True, gen)
+    p['h_bias'] = torch.randn(fout, generator=gen) * 0.1
+    pa = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    pb = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ha = rgcn.rel_graph_conv(ids, src, dst, et, norm, pa, 'basis', nb, torch.relu)
+    hb = rgcn.rel_graph_conv(torch.eye(n)[ids], src, dst, et, norm, pb, 'basis', nb, torch.relu)
+    gout = torch.randn(n, fout, generator=gen)
+    ha.backward(gout)
+    hb.backward(gout)
+    torch.testing.assert_close(ha, hb, rtol=1e-5, atol=1e-6)
+    for k in pa:
+        torch.testing.assert_close(pa[k].grad, pb[k].grad, rtol=1e-4, atol=1e-6)
+    with pytest.raises(TypeError):
+        rgcn.rel_graph_conv(ids, src, dst, et, norm, rgcn.init_params(8, 8, r, 'bdd', 2, True, True, gen), 'bdd', 2)
