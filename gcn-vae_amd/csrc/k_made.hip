@@ -1,0 +1,338 @@
+// K4 in bf16: the masked-MLP products of MADE / IAF (kgvae/flow_network.py:7-98) with bf16 STORAGE of weights and
+// activations, v_mfma_f32_32x32x16_bf16, fp32 accumulation (BASELINE configs[2]).
+//
+// gv_gemm_bf16 (k_gemm.hip) only rounds fp32 operands while staging them, so its tile loop stays bound by fp32 global
+// loads.  Here the operands ARE bf16 in memory: a 64 x 64 output tile stages 64 x K bf16 rows of both
+// operands (K <= 224 per chunk: the whole reduction of a 200-wide layer in ONE shot, one barrier pair per chunk), every
+// fragment is one conflict-free ds_read_b128 (464-B padded LDS rows), and the epilogue fuses bias, ReLU, the ReLU mask of
+// the backward pass (sign of the stored bf16 activation) and up to three stores: fp32 (optionally accumulating), bf16, and
+// a bf16 TRANSPOSED copy -- four consecutive rows of an accumulator register group are four consecutive elements of a
+// transposed row, one 8-B store.  With the transposed copies of activations and gradients at hand, every product of the
+// masked MLP is the same NT kernel:
+//   forward      a_l      = relu(a_{l-1} W_l^T + b)        A = a_{l-1} [M][in],   B = W_l   [out][in]
+//   backward-x   g_{l-1}  = (g_l W_l) * [a_{l-1} > 0]      A = g_l     [M][out],  B = W_l^T [in][out]
+//   backward-W   dW_l     = g_l^T a_{l-1}                  A = g_l^T   [out][M],  B = a_{l-1}^T [in][M]   (split over M)
+// Semantics (pinned by the tests' CPU emulation): operands rounded to bf16 (round to nearest even), products and sums in fp32.
+#include "common.h"
+
+namespace gv {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+struct BfGemm {
+    const void* a;            // [M][lda] bf16, or fp32 (a_f32) rounded while staged
+    int lda;
+    const uint16_t* b;        // [N][ldb] bf16
+    int ldb;
+    int m, n, k;
+    const float* bias;        // [N] or NULL
+    int relu;
+    const uint16_t* mask;     // [M][ldmask] bf16 or NULL: the result is kept where mask > 0, zero elsewhere
+    int ldmask;
+    float* c_f32;             // [M][ldc] or NULL
+    int ldc;
+    int accumulate;           // c_f32 += result
+    uint16_t* c_bf;           // [M][ldcb] or NULL
+    int ldcb;
+    uint16_t* c_bft;          // [N][ldct] transposed, or NULL
+    int ldct;
+    float* partial;           // split-K: [gridDim.z][M][N] fp32 (then no epilogue, no other output)
+    int k_per_split;
+};
+
+__device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+
+template <bool A_F32>
+__global__ __launch_bounds__(256) void k_gemm_bf16s(const BfGemm p) {
+    constexpr int BM = 64, BN = 64, KC = 224, LDK = 232;        // 464-B LDS rows: conflict-free 16-B fragment reads
+    __shared__ __attribute__((aligned(16))) uint16_t As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * LDK];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k_begin = blockIdx.z * p.k_per_split, k_end = min(p.k, k_begin + p.k_per_split);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm = wid >> 1, wn = wid & 1, r = lane & 31, h = lane >> 5;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    // Staging: a chunk is 64 rows x 28 pieces of 8 bf16 (16 B) per operand = 7 pieces per thread and operand.  All 14 loads of
+    // a thread are issued before the first LDS write, so a block pays ONE global round trip per chunk, not fourteen.
+    constexpr int PPR = KC / 8, PPT = BM * PPR / 256;
+    static_assert(BM * PPR % 256 == 0 && BM == BN, "staging assumes whole pieces per thread");
+    for (int k0 = k_begin; k0 < k_end; k0 += KC) {
+        const int kc = min(KC, k_end - k0);          // multiple of 8 (host-checked)
+        const int kc16 = (kc + 15) & ~15;
+        uint4 va[PPT], vb[PPT];
+        float4 fa[A_F32 ? PPT : 1][2];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int idx = threadIdx.x + j * 256, row = idx / PPR, kk = (idx - row * PPR) << 3;
+            va[j] = make_uint4(0, 0, 0, 0);
+            vb[j] = make_uint4(0, 0, 0, 0);
+            if constexpr (A_F32) { fa[j][0] = make_float4(0.f, 0.f, 0.f, 0.f); fa[j][1] = fa[j][0]; }
+            if (kk < kc) {
+                if (m0 + row < p.m) {
+                    if constexpr (A_F32) {
+                        const float4* src = reinterpret_cast<const float4*>(static_cast<const float*>(p.a) +
+                                                                            (size_t)(m0 + row) * p.lda + k0 + kk);
+                        fa[j][0] = src[0];
+                        fa[j][1] = src[1];
+                    } else {
+                        va[j] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.a) + (size_t)(m0 + row) * p.lda + k0 + kk);
+                    }
+                }
+                if (n0 + row < p.n) vb[j] = *reinterpret_cast<const uint4*>(p.b + (size_t)(n0 + row) * p.ldb + k0 + kk);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int idx = threadIdx.x + j * 256, row = idx / PPR, kk = (idx - row * PPR) << 3;
+            if (kk < kc16) {
+                if constexpr (A_F32) {
+                    const float4 lo = fa[j][0], hi = fa[j][1];
+                    va[j].x = f2bf(lo.x) | ((uint32_t)f2bf(lo.y) << 16); va[j].y = f2bf(lo.z) | ((uint32_t)f2bf(lo.w) << 16);
+                    va[j].z = f2bf(hi.x) | ((uint32_t)f2bf(hi.y) << 16); va[j].w = f2bf(hi.z) | ((uint32_t)f2bf(hi.w) << 16);
+                }
+                *reinterpret_cast<uint4*>(&As[row * LDK + kk]) = va[j];
+                *reinterpret_cast<uint4*>(&Bs[row * LDK + kk]) = vb[j];
+            }
+        }
+        __syncthreads();
+        const uint16_t* ap = &As[(wm * 32 + r) * LDK + 8 * h];
+        const uint16_t* bp = &Bs[(wn * 32 + r) * LDK + 8 * h];
+        for (int kk = 0; kk < kc16; kk += 16) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + kk);
+            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + kk);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    if (p.partial) {
+        const int col = n0 + wn * 32 + r;
+        if (col >= p.n) return;
+        float* dst = p.partial + (size_t)blockIdx.z * p.m * p.n;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (row < p.m) dst[(size_t)row * p.n + col] = acc[i];
+        }
+        return;
+    }
+    // Epilogue through an fp32 LDS tile (the operand buffers are free now): the accumulator layout has one column per lane,
+    // which would make every global access a 2- or 4-byte one.  Phase 1: acc + bias (ReLU) -> tile.  Phase 2: 4-column
+    // pieces, one per thread and step -- ReLU mask (8-B load), accumulate (16-B load), 16-B fp32 / 8-B bf16 stores, masked
+    // value back into the tile.  Phase 3: the transposed copy, 4 consecutive rows of one column = one 8-B store.
+    constexpr int LDC = 65;
+    float* Ct = reinterpret_cast<float*>(As);
+    static_assert(BM * LDC * 4 <= BM * LDK * 2, "the epilogue tile must fit the A buffer");
+    {
+        const int cl = wn * 32 + r;
+        const float bv = (p.bias && n0 + cl < p.n) ? p.bias[n0 + cl] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = acc[i] + bv;
+            if (p.relu) v = fmaxf(v, 0.f);
+            Ct[(wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * LDC + cl] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = threadIdx.x + j * 256, rr = idx >> 4, cc = (idx & 15) << 2;
+        const int row = m0 + rr, col = n0 + cc;
+        if (row < p.m && col < p.n) {          // n % 4 == 0 (host-checked): a piece is inside or outside as a whole
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = Ct[rr * LDC + cc + e];
+            if (p.mask) {
+                const uint2 mv = *reinterpret_cast<const uint2*>(p.mask + (size_t)row * p.ldmask + col);
+                if ((int16_t)(mv.x & 0xffff) <= 0) v[0] = 0.f;
+                if ((int16_t)(mv.x >> 16) <= 0) v[1] = 0.f;
+                if ((int16_t)(mv.y & 0xffff) <= 0) v[2] = 0.f;
+                if ((int16_t)(mv.y >> 16) <= 0) v[3] = 0.f;
+                if (p.c_bft) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Ct[rr * LDC + cc + e] = v[e];
+                }
+            }
+            if (p.c_f32) {
+                float4* o = reinterpret_cast<float4*>(p.c_f32 + (size_t)row * p.ldc + col);
+                float4 ov = make_float4(v[0], v[1], v[2], v[3]);
+                if (p.accumulate) { const float4 old = *o; ov.x += old.x; ov.y += old.y; ov.z += old.z; ov.w += old.w; }
+                *o = ov;
+            }
+            if (p.c_bf)
+                *reinterpret_cast<uint2*>(p.c_bf + (size_t)row * p.ldcb + col) =
+                    make_uint2(f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
+        }
+    }
+    if (!p.c_bft) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = threadIdx.x + j * 256, cc = idx >> 4, rr = (idx & 15) << 2;
+        const int col = n0 + cc, row = m0 + rr;
+        if (col < p.n && row < p.m) {
+            uint16_t* o = p.c_bft + (size_t)col * p.ldct + row;
+            const uint16_t b0 = f2bf(Ct[rr * LDC + cc]), b1 = f2bf(Ct[(rr + 1) * LDC + cc]), b2 = f2bf(Ct[(rr + 2) * LDC + cc]),
+                           b3 = f2bf(Ct[(rr + 3) * LDC + cc]);
+            if (row + 3 < p.m) {
+                *reinterpret_cast<uint2*>(o) = make_uint2(b0 | ((uint32_t)b1 << 16), b2 | ((uint32_t)b3 << 16));
+            } else {
+                o[0] = b0;
+                if (row + 1 < p.m) o[1] = b1;
+                if (row + 2 < p.m) o[2] = b2;
+            }
+        }
+    }
+}
+
+// y[r][c] = bf16(x[r][c]) (row-major, ld ldy) and / or yT[c][r] (ld ldt); 64 x 64 tiles through LDS for the transposed copy
+__global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ x, int ldx, int rows, int cols, uint16_t* y,
+                                                   int ldy, uint16_t* yT, int ldt) {
+    __shared__ uint16_t t[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int rr = i >> 6, cc = i & 63;
+        uint16_t v = 0;
+        if (r0 + rr < rows && c0 + cc < cols) {
+            v = f2bf(x[(size_t)(r0 + rr) * ldx + c0 + cc]);
+            if (y) y[(size_t)(r0 + rr) * ldy + c0 + cc] = v;
+        }
+        t[rr][cc] = v;
+    }
+    if (!yT) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int cc = i >> 6, rr = i & 63;
+        if (r0 + rr < rows && c0 + cc < cols) yT[(size_t)(c0 + cc) * ldt + r0 + rr] = t[rr][cc];
+    }
+}
+
+// Sums over bf16 rows (bias gradients from the transposed gradient copies): stage 1, one wave per (row, 4096-column chunk),
+// writes part[row][chunk]; stage 2 adds a row's chunk sums in order.  fp32 sums, fixed order.
+constexpr int ROWSUM_CHUNK = 4096;
+__global__ __launch_bounds__(256) void k_rowsum_bf16(const uint16_t* __restrict__ x, int ld, int rows, int cols, int nchunks,
+                                                     float* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= rows * nchunks) return;
+    const int row = item / nchunks, ch = item - row * nchunks;
+    const int c0 = ch * ROWSUM_CHUNK, c1 = min(cols, c0 + ROWSUM_CHUNK);
+    const uint16_t* p = x + (size_t)row * ld;
+    float s0 = 0.f, s1 = 0.f;
+    int c = c0 + lane * 8;
+    for (; c + 8 <= c1; c += 512) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p + c);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0 += __uint_as_float(w[j] << 16);
+            s1 += __uint_as_float(w[j] & 0xffff0000u);
+        }
+    }
+    if (c < c1)
+        for (int cc = c; cc < c1; ++cc) s0 += __uint_as_float((uint32_t)p[cc] << 16);
+    const float s = wave_sum(s0 + s1);
+    if (lane == 0) part[item] = s;
+}
+
+__global__ __launch_bounds__(256) void k_rowsum_finish(const float* __restrict__ part, int rows, int nchunks, float* out,
+                                                       int accumulate) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += part[(size_t)row * nchunks + c];
+    out[row] = accumulate ? out[row] + s : s;
+}
+
+// out[i] (+)= sum_z partial[z][i], z in order
+__global__ __launch_bounds__(256) void k_splitk_sum(const float* __restrict__ partial, int splits, size_t mn, float* out,
+                                                    int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += partial[(size_t)z * mn + i];
+        out[i] = accumulate ? out[i] + s : s;
+    }
+}
+
+}  // namespace gv
+
+using namespace gv;
+
+extern "C" int64_t gv_gemm_bf16_nt_workspace_bytes(int m, int n, int split_k) {
+    return split_k > 1 ? (int64_t)split_k * m * n * 4 : 0;
+}
+
+extern "C" int gv_gemm_bf16_nt(const void* a, int a_is_f32, int lda, const uint16_t* b, int ldb, int m, int n, int k,
+                               const float* bias, int relu, const uint16_t* mask, int ldmask, float* c_f32, int ldc,
+                               int accumulate, uint16_t* c_bf16, int ldcb, uint16_t* c_bf16_t, int ldct, int split_k,
+                               void* workspace, int64_t workspace_bytes, void* stream) {
+    GV_REQUIRE(m >= 0 && n > 0 && k > 0 && split_k >= 1, GV_ERR_SHAPE, "gv_gemm_bf16_nt: m=%d n=%d k=%d split_k=%d", m, n, k, split_k);
+    if (m == 0) return GV_OK;
+    GV_REQUIRE(a && b && (c_f32 || c_bf16 || c_bf16_t), GV_ERR_NULL, "gv_gemm_bf16_nt: NULL pointer");
+    GV_REQUIRE(k % 8 == 0 && lda >= k && ldb >= k && lda % (a_is_f32 ? 4 : 8) == 0 && ldb % 8 == 0 && aligned16(a) && aligned16(b),
+               GV_ERR_ALIGN, "gv_gemm_bf16_nt: k, lda, ldb must allow 16-B row pieces (k=%d lda=%d ldb=%d)", k, lda, ldb);
+    GV_REQUIRE((!c_f32 || ldc >= n) && (!c_bf16 || ldcb >= n) && (!c_bf16_t || (ldct >= m && ldct % 4 == 0)) &&
+               (!mask || ldmask >= n), GV_ERR_SHAPE, "gv_gemm_bf16_nt: leading dimension too small");
+    GV_REQUIRE(n % 4 == 0 && (!c_f32 || (ldc % 4 == 0 && aligned16(c_f32))) && (!c_bf16 || (ldcb % 4 == 0 && aligned16(c_bf16))) &&
+               (!mask || (ldmask % 4 == 0 && aligned16(mask))) && (!c_bf16_t || aligned16(c_bf16_t)), GV_ERR_ALIGN,
+               "gv_gemm_bf16_nt: n and the output / mask row pitches must be multiples of 4 elements");
+    BfGemm p;
+    p.a = a; p.lda = lda; p.b = b; p.ldb = ldb; p.m = m; p.n = n; p.k = k; p.bias = bias; p.relu = relu; p.mask = mask;
+    p.ldmask = ldmask; p.c_f32 = c_f32; p.ldc = ldc; p.accumulate = accumulate; p.c_bf = c_bf16; p.ldcb = ldcb;
+    p.c_bft = c_bf16_t; p.ldct = ldct; p.partial = nullptr; p.k_per_split = k;
+    hipStream_t st = (hipStream_t)stream;
+    int splits = 1;
+    if (split_k > 1) {
+        GV_REQUIRE(c_f32 && !c_bf16 && !c_bf16_t && !bias && !relu && !mask, GV_ERR_SHAPE,
+                   "gv_gemm_bf16_nt: split-K writes a plain fp32 result only");
+        int per = ((k + split_k - 1) / split_k + 223) / 224 * 224;      // whole 224-deep chunks per split
+        splits = (k + per - 1) / per;
+        GV_REQUIRE(workspace && workspace_bytes >= (int64_t)splits * m * n * 4, GV_ERR_WORKSPACE,
+                   "gv_gemm_bf16_nt: workspace too small for %d splits", splits);
+        p.partial = (float*)workspace; p.k_per_split = per;
+    }
+    dim3 grid((n + 63) / 64, (m + 63) / 64, splits), block(256);
+    if (a_is_f32) hipLaunchKernelGGL(k_gemm_bf16s<true>, grid, block, 0, st, p);
+    else hipLaunchKernelGGL(k_gemm_bf16s<false>, grid, block, 0, st, p);
+    int rc = launch_status("gv_gemm_bf16_nt");
+    if (rc != GV_OK || split_k <= 1) return rc;
+    const size_t mn = (size_t)m * n;
+    GV_REQUIRE(ldc == n, GV_ERR_SHAPE, "gv_gemm_bf16_nt: split-K needs a dense result (ldc == n)");
+    hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)min((size_t)1024, (mn + 255) / 256)), dim3(256), 0, st,
+                       (const float*)workspace, splits, mn, c_f32, accumulate);
+    return launch_status("gv_gemm_bf16_nt(split-k sum)");
+}
+
+extern "C" int gv_cast_bf16(const float* x, int ldx, int rows, int cols, uint16_t* y, int ldy, uint16_t* y_t, int ldt,
+                            void* stream) {
+    GV_REQUIRE(rows >= 0 && cols > 0, GV_ERR_SHAPE, "gv_cast_bf16: rows=%d cols=%d", rows, cols);
+    if (rows == 0) return GV_OK;
+    GV_REQUIRE(x && (y || y_t), GV_ERR_NULL, "gv_cast_bf16: NULL pointer");
+    GV_REQUIRE(ldx >= cols && (!y || ldy >= cols) && (!y_t || ldt >= rows), GV_ERR_SHAPE, "gv_cast_bf16: leading dimension too small");
+    hipLaunchKernelGGL(k_cast_bf16, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, rows,
+                       cols, y, ldy, y_t, ldt);
+    return launch_status("gv_cast_bf16");
+}
+
+extern "C" int gv_rowsum_bf16(const uint16_t* x, int ld, int rows, int cols, float* out, int accumulate, float* workspace,
+                              void* stream) {
+    GV_REQUIRE(rows >= 0 && cols >= 0, GV_ERR_SHAPE, "gv_rowsum_bf16: rows=%d cols=%d", rows, cols);
+    if (rows == 0) return GV_OK;
+    GV_REQUIRE(x && out && workspace, GV_ERR_NULL, "gv_rowsum_bf16: NULL pointer");
+    GV_REQUIRE(ld >= cols && ld % 8 == 0 && aligned16(x), GV_ERR_ALIGN, "gv_rowsum_bf16: rows must start on 16-B boundaries");
+    const int nchunks = max(1, (cols + ROWSUM_CHUNK - 1) / ROWSUM_CHUNK);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_rowsum_bf16, dim3((rows * nchunks + 3) / 4), dim3(256), 0, st, x, ld, rows, cols, nchunks, workspace);
+    hipLaunchKernelGGL(k_rowsum_finish, dim3((rows + 255) / 256), dim3(256), 0, st, (const float*)workspace, rows, nchunks, out,
+                       accumulate);
+    return launch_status("gv_rowsum_bf16");
+}
+
+/* floats of workspace gv_rowsum_bf16 needs */
+extern "C" int64_t gv_rowsum_bf16_workspace_floats(int rows, int cols) {
+    return (int64_t)rows * ((cols + ROWSUM_CHUNK - 1) / ROWSUM_CHUNK + 1);
+}

@@ -2260,5 +2260,191 @@ class _MADEForward(torch.autograd.Function):
         return (g_z, None, *g_ws, *g_bs)
 
 
+# ---- K4 in bf16 (csrc/k_made.hip): bf16 storage of weights and activations, every product the same NT kernel ----------------
+def _pad8(n):
+    return (int(n) + 7) // 8 * 8
+
+
+def _empty_t_padded(width, passes, n, npad, kw):
+    """(width, passes*npad) transposed-copy buffer: only the pad columns [n, npad) of every pass are zeroed (they take part
+    in the weight-gradient reduction); the data columns are written by the producing kernels."""
+    t = torch.empty(width, passes * npad, **kw)
+    if npad > n:
+        t.view(width, passes, npad)[:, :, n:].zero_()
+    return t
+
+
+def cast_bf16(x, y=None, y_t=None):
+    """y = bf16(x) row-major and / or y_t[c, r] = bf16(x[r, c]); x fp32 (rows, cols) with unit inner stride."""
+    x, ldx = _row_major(x, 'x')
+    rows, cols = x.shape
+    lib.call('gv_cast_bf16', ptr(x), ldx, rows, cols, ptr(y), y.stride(0) if y is not None else 0, ptr(y_t),
+             y_t.stride(0) if y_t is not None else 0, lib.stream())
+
+
+def gemm_bf16_nt(a, b, m, n, k, bias=None, relu=False, mask=None, c_f32=None, accumulate=False, c_bf16=None, c_bf16_t=None,
+                 split_k=1):
+    """C[m, n] = epilogue(A[m, k] @ B[n, k]^T) on gv_gemm_bf16_nt; A bf16 or fp32 (rounded while staged), B bf16; row strides
+    are taken from the tensors (views of stacked / padded buffers)."""
+    ws, ws_bytes = None, 0
+    if split_k > 1:
+        ws_bytes = int(lib.load().gv_gemm_bf16_nt_workspace_bytes(m, n, split_k))
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=a.device)
+    lib.call('gv_gemm_bf16_nt', ptr(a), 1 if a.dtype == torch.float32 else 0, a.stride(0), ptr(b), b.stride(0), m, n, k,
+             ptr(bias), 1 if relu else 0, ptr(mask), mask.stride(0) if mask is not None else 0, ptr(c_f32),
+             c_f32.stride(0) if c_f32 is not None else 0, 1 if accumulate else 0, ptr(c_bf16),
+             c_bf16.stride(0) if c_bf16 is not None else 0, ptr(c_bf16_t), c_bf16_t.stride(0) if c_bf16_t is not None else 0,
+             split_k, ptr(ws), ws_bytes, lib.stream())
+
+
+class _MADEForwardBF16(torch.autograd.Function):
+    """MADE.forward (kgvae/flow_network.py:85-98) with bf16 operands in MEMORY (BASELINE configs[2]; semantics as the
+    tests' CPU emulation pins them: operands rounded to bf16, fp32 products and sums).  Same structure as _MADEForward -- pass 0 on one
+    broadcast row, the later passes stacked -- but the stacked activations are stored as bf16 row-major PLUS a bf16
+    transposed copy (written by the producing GEMM's epilogue), the backward keeps the ReLU-masked gradients of every layer the
+    same way, and all three product kinds (forward, backward-x, backward-W) run on gv_gemm_bf16_nt.  Per-pass column offset
+    in the transposed buffers is rounded up to 8 rows (8-B aligned stores); the pad columns stay zero."""
+
+    @staticmethod
+    def forward(ctx, z, colcount, *wb):
+        ctx.set_materialize_grads(False)
+        L = len(wb) // 2
+        ws, bs = wb[:L], wb[L:]
+        z = _chk(z.contiguous(), name='z')
+        n, d = z.shape
+        P = colcount.shape[0]
+        S = P - 1
+        dev = z.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        st = lib.stream()
+        npad = _pad8(n)
+        widths = [w.shape[0] for w in ws]                       # layer output widths; inputs: d, then widths[:-1]
+        # weights: bf16 (out, in) and bf16 transposed (in, out), once per call
+        wbf = [torch.empty(w.shape[0], _pad8(w.shape[1]), **bf) for w in ws]
+        wbt = [torch.empty(w.shape[1], _pad8(w.shape[0]), **bf) for w in ws]
+        for w, a_, t_ in zip(ws, wbf, wbt):
+            cast_bf16(w, a_, t_)
+        xin = torch.empty(max(S, 1) * n, d, **f32)               # fp32 pass inputs (update pass-through, backward)
+        xin_b = torch.empty(max(S, 1) * n, _pad8(d), **bf)
+        xin_t = _empty_t_padded(d, max(S, 1), n, npad, bf)
+        acts_b = [torch.empty(max(S, 1) * n, _pad8(widths[l]), **bf) for l in range(L - 1)]
+        acts_t = [_empty_t_padded(widths[l], max(S, 1), n, npad, bf) for l in range(L - 1)]
+        net_out = torch.empty(max(S, 1) * n, widths[L - 1], **f32)   # [mu | alpha] of every stacked pass
+        x_out = torch.empty(n, d, **f32)
+        # pass 0 on a single zero row (tiny: the generic GEMM with bf16-rounded operands)
+        zero_row = torch.zeros(1, d, **f32)
+        acts0, inp = [], zero_row
+        for l in range(L):
+            inp = gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE, precision='bf16')
+            acts0.append(inp)
+        first_out = xin[0:n] if P > 1 else x_out
+        lib.call('gv_iaf_update_fwd', ptr(z), ptr(acts0[L - 1]), 0, ptr(z), ptr(colcount[0]), ptr(first_out), n, d, st)
+        for p in range(1, P):
+            sl = slice((p - 1) * n, p * n)
+            tsl = slice((p - 1) * npad, (p - 1) * npad + n)
+            cast_bf16(xin[sl], xin_b[sl], xin_t[:, tsl])
+            inp = xin_b[sl]
+            for l in range(L - 1):
+                gemm_bf16_nt(inp, wbf[l], n, widths[l], ws[l].shape[1], bias=bs[l], relu=True, c_bf16=acts_b[l][sl],
+                             c_bf16_t=acts_t[l][:, tsl])
+                inp = acts_b[l][sl]
+            gemm_bf16_nt(inp, wbf[L - 1], n, widths[L - 1], ws[L - 1].shape[1], bias=bs[L - 1], c_f32=net_out[sl])
+            nxt = xin[p * n:(p + 1) * n] if p + 1 < P else x_out
+            lib.call('gv_iaf_update_fwd', ptr(z), ptr(net_out[sl]), 2 * d, ptr(xin[sl]), ptr(colcount[p]), ptr(nxt), n, d, st)
+        log_det = torch.empty(n, **f32)
+        if P > 1:
+            lib.call('gv_rowsum', ptr(net_out[(S - 1) * n:]), 2 * d, d, d, ptr(log_det), n, st)
+        else:
+            log_det = acts0[L - 1][:, d:].sum(dim=1).expand(n).contiguous()
+        ctx.save_for_backward(z, colcount, xin_t, zero_row, net_out, *acts_b, *acts_t, *acts0, *wbt, *ws)
+        ctx.L = L
+        ctx.has_bias = [b is not None for b in bs]
+        return x_out, log_det
+
+    @staticmethod
+    def backward(ctx, gx, gld):
+        L = ctx.L
+        saved = ctx.saved_tensors
+        z, colcount, xin_t, zero_row, net_out = saved[:5]
+        o = 5
+        acts_b, acts_t = saved[o:o + L - 1], saved[o + L - 1:o + 2 * (L - 1)]
+        o += 2 * (L - 1)
+        acts0, wbt, ws = saved[o:o + L], saved[o + L:o + 2 * L], saved[o + 2 * L:o + 3 * L]
+        n, d = z.shape
+        P = colcount.shape[0]
+        S = P - 1
+        dev = z.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        st = lib.stream()
+        npad = _pad8(n)
+        widths = [w.shape[0] for w in ws]
+        gx = torch.zeros(n, d, **f32) if gx is None else _chk(gx.contiguous(), name='gx')
+        gld = None if gld is None else _chk(gld.contiguous(), name='gld')
+        # ReLU-masked gradients w.r.t. every layer's pre-activation: bf16 row-major (operand of backward-x) and transposed
+        # (operand of backward-W and of the bias sums)
+        gm_b = [torch.empty(max(S, 1) * n, _pad8(widths[l]), **bf) for l in range(L)]
+        gm_t = [_empty_t_padded(widths[l], max(S, 1), n, npad, bf) for l in range(L)]
+        g_net = torch.empty(n, 2 * d, **f32)
+        g_z = torch.zeros(n, d, **f32)
+        gz_p = torch.empty(n, d, **f32)
+        g_cur = gx
+        for p in reversed(range(1, P)):
+            sl = slice((p - 1) * n, p * n)
+            tsl = slice((p - 1) * npad, (p - 1) * npad + n)
+            g_old = torch.empty(n, d, **f32)
+            lib.call('gv_iaf_update_bwd', ptr(z), ptr(net_out[sl]), 2 * d, ptr(colcount[p]), ptr(g_cur),
+                     ptr(gld) if p == P - 1 else None, ptr(gz_p), ptr(g_net), ptr(g_old), n, d, st)
+            lib.call('gv_axpby', n * d, None, 1.0, ptr(gz_p), 1.0, ptr(g_z), st)
+            cast_bf16(g_net, gm_b[L - 1][sl], gm_t[L - 1][:, tsl])
+            for l in reversed(range(1, L)):      # g_{l-1} = (g_l W_l) * [a_{l-1} > 0]
+                gemm_bf16_nt(gm_b[l][sl], wbt[l], n, widths[l - 1], widths[l], mask=acts_b[l - 1][sl], c_bf16=gm_b[l - 1][sl],
+                             c_bf16_t=gm_t[l - 1][:, tsl])
+            gemm_bf16_nt(gm_b[0][sl], wbt[0], n, d, widths[0], c_f32=g_old, accumulate=True)
+            g_cur = g_old
+        # pass 0: the update's gradient w.r.t. the broadcast net row is its column sum; x_old was the zero matrix
+        g_net0 = torch.empty(n, 2 * d, **f32)
+        g_dump = torch.empty(n, d, **f32)
+        lib.call('gv_iaf_update_bwd', ptr(z), ptr(acts0[L - 1]), 0, ptr(colcount[0]), ptr(g_cur),
+                 ptr(gld) if P == 1 else None, ptr(gz_p), ptr(g_net0), ptr(g_dump), n, d, st)
+        lib.call('gv_axpby', n * d, None, 1.0, ptr(gz_p), 1.0, ptr(g_z), st)
+        g_row = colsum(g_net0).view(1, -1)
+        rows0 = [None] * L
+        for l in reversed(range(L)):
+            rows0[l] = g_row
+            if l > 0:
+                mask = acts0[l] if l < L - 1 else None
+                g_row = gemm(g_row, ws[l], a_relu_mask=mask, precision='bf16')
+        g_ws, g_bs = [], []
+        mtot = max(S, 1) * npad
+        for l in range(L):
+            mask0 = acts0[l] if l < L - 1 else None
+            inp0 = zero_row if l == 0 else acts0[l - 1]
+            gw = gb = None
+            if ctx.needs_input_grad[2 + l]:
+                gw = gemm(rows0[l], inp0, trans_a=True, a_relu_mask=mask0, precision='bf16')
+                if S > 0:       # dW_l = g_l^T a_{l-1}: the NT kernel on the transposed copies, reduction over all stacked rows
+                    in_t = xin_t if l == 0 else acts_t[l - 1]
+                    gemm_bf16_nt(gm_t[l], in_t, widths[l], ws[l].shape[1], mtot, c_f32=gw, accumulate=True,
+                                 split_k=max(2, min(64, mtot // 2240)))
+            if ctx.has_bias[l] and ctx.needs_input_grad[2 + L + l]:
+                gb = colsum(rows0[l], relu_mask=mask0)
+                if S > 0:
+                    rws = torch.empty(int(lib.load().gv_rowsum_bf16_workspace_floats(widths[l], mtot)), **f32)
+                    lib.call('gv_rowsum_bf16', ptr(gm_t[l]), gm_t[l].stride(0), widths[l], mtot, ptr(gb), 1, ptr(rws), st)
+            g_ws.append(gw)
+            g_bs.append(gb)
+        return (g_z, None, *g_ws, *g_bs)
+
+
+MADE_BF16_STORAGE = _os.environ.get('GV_MADE_BF16', '1') == '1'
+
+
 def made_forward(z, colcount, weights, biases):
+    """MADE.forward as one autograd node; with bf16 dense products (set_gemm_precision('bf16'), BASELINE configs[2]) and
+    layer widths that are multiples of 8 the bf16-storage pipeline of csrc/k_made.hip runs."""
+    if (GEMM_PRECISION == 'bf16' and MADE_BF16_STORAGE and z.shape[1] % 8 == 0 and all(w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0
+                                                                                       for w in weights)):
+        return _MADEForwardBF16.apply(z, colcount, *weights, *biases)
     return _MADEForward.apply(z, colcount, *weights, *biases)

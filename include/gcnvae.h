@@ -160,6 +160,26 @@ int gv_rel_rows_gemm(const float* feat, int ld_feat, const int32_t* rows, const 
 int gv_rel_gradw_gemm(const float* x, int ld_x, const int32_t* x_rows, const float* g, int ld_g, const int32_t* g_rows,
                       const float* scale, const int32_t* relptr, int num_rels, int in_feat, int out_feat, float* grad_w,
                       void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * K4 in bf16 (BASELINE configs[2]): the masked-MLP products of MADE / IAF (kgvae/flow_network.py:7-98, called from
+ * kgvae/model.py:116-123) with bf16 STORAGE of weights and activations, bf16 MFMA, fp32 accumulation.
+ *   C = epilogue(A @ B^T):  A [M][lda] bf16 (or fp32 with a_is_f32, rounded to nearest even while staged), B [N][ldb] bf16,
+ *   epilogue: + bias[N], ReLU, then zero where mask[M][ldmask] (bf16) <= 0 (the ReLU mask of the backward pass); stores any of
+ *   c_f32 [M][ldc] (accumulate != 0: +=), c_bf16 [M][ldcb], c_bf16_t [N][ldct] (the transposed copy: the A / B operand of the
+ *   weight-gradient product, which is this same NT form over the rows).  k % 8 == 0, lda % 8 == 0 (bf16) / % 4 (fp32),
+ *   ldb % 8 == 0, ldct % 4 == 0.  split_k > 1: the reduction is cut into whole 224-deep chunks, partials (workspace of
+ *   gv_gemm_bf16_nt_workspace_bytes) are summed in order into a dense c_f32 (no bias / ReLU / mask / bf16 outputs).
+ * gv_cast_bf16: y = bf16(x) row-major and / or y_t = its transpose.  gv_rowsum_bf16: out[r] (+)= sum over a bf16 row (bias
+ * gradients from the transposed gradient copies), fp32 sums in a fixed order. */
+int64_t gv_gemm_bf16_nt_workspace_bytes(int m, int n, int split_k);
+int gv_gemm_bf16_nt(const void* a, int a_is_f32, int lda, const uint16_t* b, int ldb, int m, int n, int k, const float* bias,
+                    int relu, const uint16_t* mask, int ldmask, float* c_f32, int ldc, int accumulate, uint16_t* c_bf16,
+                    int ldcb, uint16_t* c_bf16_t, int ldct, int split_k, void* workspace, int64_t workspace_bytes,
+                    void* stream);
+int gv_cast_bf16(const float* x, int ldx, int rows, int cols, uint16_t* y, int ldy, uint16_t* y_t, int ldt, void* stream);
+int64_t gv_rowsum_bf16_workspace_floats(int rows, int cols);
+int gv_rowsum_bf16(const uint16_t* x, int ld, int rows, int cols, float* out, int accumulate, float* workspace, void* stream);
+
 /* Evaluation scorer with a fused rank count (replaces the (h, Eb, V) outer-product tensor + sort of
  * utils.perturb_and_get_rank / sort_and_rank, kgvae/utils.py:180-221): logit = q @ e^T + *bias is formed tile by tile on
  * the f32 MFMA and never stored.  Ranking happens on the LOGIT -- monotone with the reference's sigmoid but without its
