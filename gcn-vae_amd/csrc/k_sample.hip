@@ -244,3 +244,157 @@ extern "C" int gv_graph_from_triplets(const int32_t* s, const int32_t* r, const 
     hipLaunchKernelGGL(k_edge_norm, dim3(blocks_for(n2)), dim3(256), 0, st, dst2, n2, norm);
     return launch_status("gv_graph_from_triplets");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Neighbourhood-expansion edge sampler (kgvae/utils.py:33-76 sample_edge_neighborhood, selected by --edge-sampler
+// neighbor, kgvae/link_predict.py:311).  Inherently sequential -- every draw conditions the next -- so ONE 1024-thread
+// workgroup walks the sample_size draws; what is parallel is each draw's inverse-CDF search over the vertices:
+// thread t owns a contiguous block of vertices and keeps its block's weight sum  sum(budget * seen)  (and the count of
+// vertices with budget left, for the reference's "nothing seen has budget" fallback) in registers; a block scan locates
+// the owner of the drawn position, the owner walks its few vertices, picks the edge (rejection loop over the vertex's
+// incidence list, as the reference) and updates budget / seen / picked; only the two touched owners re-sum.
+// Draws: Philox4x32-10(seed; counter = (draw i, stream + 0x10000 * attempt a, tick lo, tick hi)).x -- a = 0 selects the vertex as
+// floor(u * total weight / 2^32) in the integer weight CDF, a >= 1 the incidence-list entry floor(u * degree / 2^32).
+namespace gv {
+__device__ __forceinline__ uint32_t nbr_draw(uint32_t k0, uint32_t k1, uint32_t i, uint32_t attempt, uint32_t stream, uint64_t tick) {
+    return philox4x32_10(k0, k1, i, stream + 0x10000u * attempt, (uint32_t)tick, (uint32_t)(tick >> 32)).x;
+}
+
+__global__ __launch_bounds__(1024) void k_neighborhood_sample(const int* __restrict__ adj_ptr, const int* __restrict__ adj_edge,
+                                                              const int* __restrict__ adj_other, int n_vertices, int sample_size,
+                                                              uint32_t k0, uint32_t k1, uint32_t stream, uint64_t tick,
+                                                              int* budget_g, uint8_t* seen_g, uint8_t* picked, int* edges,
+                                                              int state_in_lds) {
+    __shared__ long long wave_tot[16];
+    __shared__ int sh_v, sh_other;
+    extern __shared__ int lds_state[];              // budget (V ints) then seen (V bytes) when they fit: no global round trips
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int per = (n_vertices + 1023) / 1024;
+    const int lo = min(n_vertices, tid * per), hi = min(n_vertices, lo + per);
+    int* budget = budget_g;
+    uint8_t* seen = seen_g;
+    if (state_in_lds) {
+        budget = lds_state;
+        seen = (uint8_t*)(lds_state + n_vertices);
+        for (int v = tid; v < n_vertices; v += 1024) {
+            budget[v] = budget_g[v];
+            seen[v] = 0;
+        }
+        __syncthreads();
+    }
+    long long ws = 0, cs = 0;                       // this thread's block: sum(budget * seen), #(budget > 0)
+    for (int v = lo; v < hi; ++v) {
+        ws += seen[v] ? budget[v] : 0;
+        cs += budget[v] > 0;
+    }
+    for (int i = 0; i < sample_size; ++i) {
+        // ---- total weight and this thread's exclusive prefix (two-level scan; a second one for the fallback) ----
+        long long val = ws, excl = 0, total = 0;
+        bool use_cs = false;
+        for (;;) {
+            long long inc = val;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const long long up = __shfl_up(inc, d);
+                if (lane >= d) inc += up;
+            }
+            if (lane == 63) wave_tot[wid] = inc;
+            __syncthreads();
+            long long base = 0;
+            total = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                const long long t = wave_tot[w];
+                if (w < wid) base += t;
+                total += t;
+            }
+            excl = base + inc - val;
+            __syncthreads();
+            if (total > 0 || use_cs) break;
+            use_cs = true;                         // nothing seen has budget left: uniform over the vertices that do
+            val = cs;
+        }
+        if (total <= 0) {                          // every edge is picked (sample_size > number of triplets): stop
+            if (tid == 0) for (int j = i; j < sample_size; ++j) edges[j] = -1;
+            break;
+        }
+        const long long pos = (long long)(((unsigned long long)nbr_draw(k0, k1, (uint32_t)i, 0u, stream, tick) *
+                                           (unsigned long long)total) >> 32);
+        if (pos >= excl && pos < excl + val) {      // the owner of the drawn position
+            long long run = excl;
+            int v = lo;
+            for (; v < hi; ++v) {
+                const long long w = use_cs ? (budget[v] > 0 ? 1 : 0) : (seen[v] ? budget[v] : 0);
+                if (pos < run + w) break;
+                run += w;
+            }
+            seen[v] = 1;
+            const int a0 = adj_ptr[v], deg = adj_ptr[v + 1] - a0;
+            int e, j;
+            uint32_t attempt = 1;
+            do {
+                if (attempt > 4096u) {             // sampling.NEIGHBOR_MAX_ATTEMPTS: take the first unpicked entry
+                    for (j = 0; picked[adj_edge[a0 + j]]; ++j) {}
+                } else {
+                    j = (int)(((unsigned long long)nbr_draw(k0, k1, (uint32_t)i, attempt, stream, tick) * (unsigned long long)deg) >> 32);
+                }
+                ++attempt;
+                e = adj_edge[a0 + j];
+            } while (picked[e]);
+            const int other = adj_other[a0 + j];
+            edges[i] = e;
+            picked[e] = 1;
+            budget[v] -= 1;
+            budget[other] -= 1;
+            seen[other] = 1;
+            sh_v = v;
+            sh_other = other;
+        }
+        __syncthreads();
+        const int cv = sh_v, co = sh_other;
+        if ((cv >= lo && cv < hi) || (co >= lo && co < hi)) {      // the touched owners re-sum their blocks
+            ws = 0; cs = 0;
+            for (int v = lo; v < hi; ++v) {
+                ws += seen[v] ? budget[v] : 0;
+                cs += budget[v] > 0;
+            }
+        }
+        __syncthreads();
+    }
+}
+}  // namespace gv
+
+extern "C" int gv_neighborhood_sample(const int32_t* adj_ptr, const int32_t* adj_edge, const int32_t* adj_other,
+                                      const int32_t* degrees, int num_vertices, int64_t num_triplets, int sample_size,
+                                      uint64_t seed, uint64_t tick, uint32_t stream_id, int32_t* edges, void* workspace,
+                                      int64_t workspace_bytes, void* stream) {
+    GV_REQUIRE(num_vertices > 0 && num_triplets > 0 && sample_size >= 0, GV_ERR_SHAPE,
+               "gv_neighborhood_sample: num_vertices=%d num_triplets=%lld sample_size=%d", num_vertices, (long long)num_triplets,
+               sample_size);
+    if (sample_size == 0) return GV_OK;
+    GV_REQUIRE(adj_ptr && adj_edge && adj_other && degrees && edges && workspace, GV_ERR_NULL, "gv_neighborhood_sample: NULL pointer");
+    const size_t b_budget = al256((size_t)num_vertices * sizeof(int)), b_seen = al256((size_t)num_vertices),
+                 b_picked = al256((size_t)num_triplets);
+    GV_REQUIRE(workspace_bytes >= (int64_t)(b_budget + b_seen + b_picked), GV_ERR_WORKSPACE,
+               "gv_neighborhood_sample: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* p = (char*)workspace;
+    int* budget = (int*)p; p += b_budget;
+    uint8_t* seen = (uint8_t*)p; p += b_seen;
+    uint8_t* picked = (uint8_t*)p;
+    if (hipMemcpyAsync(budget, degrees, (size_t)num_vertices * sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemsetAsync(seen, 0, b_seen + b_picked, st) != hipSuccess)
+        return launch_status("gv_neighborhood_sample(init)");
+    const size_t lds = (size_t)num_vertices * 5 + 16;
+    const int in_lds = lds <= 150 * 1024;
+    if (in_lds && lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)k_neighborhood_sample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return launch_status("gv_neighborhood_sample(lds)");
+    hipLaunchKernelGGL(k_neighborhood_sample, dim3(1), dim3(1024), in_lds ? lds : 0, st, adj_ptr, adj_edge, adj_other, num_vertices,
+                       sample_size, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, tick, budget, seen, picked, edges, in_lds);
+    return launch_status("gv_neighborhood_sample");
+}
+
+extern "C" int64_t gv_neighborhood_sample_workspace_bytes(int num_vertices, int64_t num_triplets) {
+    return (int64_t)(al256((size_t)num_vertices * sizeof(int)) + al256((size_t)num_vertices) + al256((size_t)num_triplets));
+}

@@ -8,8 +8,9 @@ tensor ops (sort / unique / bincount) and hands the model a graph handle whose e
 
 It does NOT draw from numpy's global stream, so batches differ from the reference's for a given seed: this is
 the throughput mode.  ``sampling.generate_sampled_graph_and_labels`` stays the reference-exact path
-(golden-vector tested).  Only the uniform edge sampler is offered (the neighbourhood sampler is inherently
-sequential).
+(golden-vector tested).  Both edge samplers of kgvae/utils.py are offered: ``uniform`` (a keyed permutation) and
+``neighbor`` (kgvae/utils.py:33-76, sequential by nature: one workgroup walks the draws, each draw's CDF search runs in
+parallel; it equals ``sampling.sample_edge_neighborhood_draws`` fed the same Philox outputs, draw for draw).
 
 Two implementations of the same pipeline:
   * native (default): ``gv_perm_sample`` / ``gv_relabel_pairs`` / ``gv_negative_sampling`` / ``gv_graph_from_triplets``
@@ -28,7 +29,7 @@ from . import lib
 from .graph import KGraph
 from .lib import ptr
 
-STREAM_EDGES, STREAM_NEG, STREAM_SPLIT = 0x5A01, 0x5A02, 0x5A03      # Philox stream ids of the three draws of a batch
+STREAM_EDGES, STREAM_NEG, STREAM_SPLIT, STREAM_NBR = 0x5A01, 0x5A02, 0x5A03, 0x5A04   # Philox stream ids of a batch's draws
 
 
 @dataclass
@@ -42,8 +43,11 @@ class DeviceBatch:
 
 
 class DeviceSampler:
-    def __init__(self, triplets, num_nodes, num_rels, device, seed=None, native=None):
+    def __init__(self, triplets, num_nodes, num_rels, device, seed=None, native=None, sampler='uniform'):
         self.device = torch.device(device)
+        if sampler not in ('uniform', 'neighbor'):
+            raise ValueError("Sampler type must be either 'uniform' or 'neighbor'.")      # kgvae/utils.py:98
+        self.sampler = sampler
         if self.device.type != 'cuda':
             raise RuntimeError('DeviceSampler prepares batches on a ROCm device; use gcn_vae_amd.sampling on the host')
         self.triplets = torch.as_tensor(triplets, dtype=torch.int64).to(self.device)
@@ -58,6 +62,14 @@ class DeviceSampler:
         if self.native:
             t32 = self.triplets.to(torch.int32)
             self._s, self._r, self._o = (t32[:, i].contiguous() for i in range(3))
+        if sampler == 'neighbor':
+            if not self.native:
+                raise RuntimeError("the 'neighbor' edge sampler runs on the native pipeline only (GV_NATIVE_SAMPLER=1)")
+            from .sampling import adjacency_csr
+            self._adj = tuple(torch.from_numpy(a).to(self.device) for a in
+                              adjacency_csr(self.num_nodes, self.triplets.cpu().numpy()))
+            nb = int(lib.load().gv_neighborhood_sample_workspace_bytes(self.num_nodes, int(self.triplets.shape[0])))
+            self._nbr_ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
 
     # -- native pipeline ----------------------------------------------------------------------------------------
     def _sample_native(self, sample_size, split_size, negative_rate):
@@ -66,7 +78,15 @@ class DeviceSampler:
         self.tick += 1
         i32 = dict(dtype=torch.int32, device=dev)
         chosen = torch.empty(k, **i32)
-        lib.call('gv_perm_sample', n_trip, k, self.seed, self.tick, STREAM_EDGES, ptr(chosen), st)
+        if self.sampler == 'neighbor':
+            if k > n_trip:
+                raise ValueError(f'sample_size {k} exceeds the {n_trip} training triplets')
+            adj_ptr, adj_edge, adj_other, degrees = self._adj
+            lib.call('gv_neighborhood_sample', ptr(adj_ptr), ptr(adj_edge), ptr(adj_other), ptr(degrees), self.num_nodes, n_trip,
+                     k, self.seed, self.tick, STREAM_NBR, ptr(chosen), ptr(self._nbr_ws), self._nbr_ws.numel(), st)
+        else:
+            lib.call('gv_perm_sample', n_trip, k, self.seed, self.tick, STREAM_EDGES, ptr(chosen), st)
+        self.last_chosen = chosen
         ci = chosen.long()
         src_g, rel, dst_g = self._s[ci], self._r[ci], self._o[ci]             # global ids of the sampled triplets
         cap = min(2 * k, self.num_nodes)
@@ -109,7 +129,7 @@ class DeviceSampler:
         return g, r, norm[d].view(-1, 1)
 
     def sample(self, sample_size, split_size=0.5, negative_rate=10):
-        """generate_sampled_graph_and_labels(..., sampler='uniform') on the device."""
+        """generate_sampled_graph_and_labels(..., sampler=self.sampler) on the device."""
         if self.native:
             return self._sample_native(sample_size, split_size, negative_rate)
         dev, gen = self.device, self.gen

@@ -24,6 +24,8 @@ SIGNATURES = {
     'gv_triplet_index_build': (_I, [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I,
                                     _P, _L, _P]),
     'gv_perm_sample': (_I, [_L, _L, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _P, _P]),
+    'gv_neighborhood_sample_workspace_bytes': (_L, [_I, _L]),
+    'gv_neighborhood_sample': (_I, [_P, _P, _P, _P, _I, _L, _I, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _P, _P, _L, _P]),
     'gv_relabel_workspace_bytes': (_L, [_I]),
     'gv_relabel_pairs': (_I, [_P, _P, _L, _I, _P, _I, _P, _P, _P, _P, _L, _P]),
     'gv_negative_sampling': (_I, [_P, _P, _P, _L, _I, _P, _P, _P, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _P, _P, _P]),

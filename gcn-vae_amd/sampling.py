@@ -13,22 +13,28 @@ import torch
 from .graph import KGraph
 
 
-def get_adj_and_degrees(num_nodes, triplets):
-    """adj_list[v] = array of [triplet id, other endpoint] in triplet order (subject entry before object
-    entry for a self loop); degrees[v] = len(adj_list[v])."""
+def adjacency_csr(num_nodes, triplets):
+    """The incidence lists of get_adj_and_degrees as three flat int32 arrays: vertex v's entries are
+    [adj_ptr[v], adj_ptr[v + 1]) of (adj_edge = triplet id, adj_other = other endpoint), in triplet order (subject entry
+    before object entry for a self loop); degrees = np.diff(adj_ptr).  This is what the device sampler uploads."""
     triplets = np.asarray(triplets)
-    n = len(triplets)
-    ids = np.arange(n)
+    ids = np.arange(len(triplets))
     owner = np.stack([triplets[:, 0], triplets[:, 2]], 1).reshape(-1)
     other = np.stack([triplets[:, 2], triplets[:, 0]], 1).reshape(-1)
     tid = np.repeat(ids, 2)
     order = np.argsort(owner, kind='stable')
-    owner_s = owner[order]
-    pairs = np.stack([tid[order], other[order]], 1)
     degrees = np.bincount(owner, minlength=num_nodes)
-    bounds = np.concatenate([[0], np.cumsum(degrees)])
+    adj_ptr = np.concatenate([[0], np.cumsum(degrees)])
+    return adj_ptr.astype(np.int32), tid[order].astype(np.int32), other[order].astype(np.int32), degrees.astype(np.int32)
+
+
+def get_adj_and_degrees(num_nodes, triplets):
+    """adj_list[v] = array of [triplet id, other endpoint] in triplet order (subject entry before object
+    entry for a self loop); degrees[v] = len(adj_list[v])."""
+    bounds, tid, other, degrees = adjacency_csr(num_nodes, triplets)
+    pairs = np.stack([tid, other], 1).astype(np.int64)
+    degrees = degrees.astype(np.int64)
     adj_list = [pairs[bounds[v]:bounds[v + 1]] if degrees[v] else np.array([]) for v in range(num_nodes)]
-    del owner_s
     return adj_list, degrees
 
 
@@ -60,6 +66,52 @@ def sample_edge_neighborhood(adj_list, degrees, n_triplets, sample_size):
         budget[v] -= 1
         budget[cand[1]] -= 1
         seen[cand[1]] = True
+    return edges
+
+
+NEIGHBOR_MAX_ATTEMPTS = 4096    # rejection draws per edge before the first unpicked entry of the list is taken
+
+
+def sample_edge_neighborhood_draws(adj_ptr, adj_edge, adj_other, degrees, n_triplets, sample_size, draw):
+    """sample_edge_neighborhood with the random source handed in: ``draw(i, attempt) -> uint32``.
+
+    The same distribution as the reference's sampler (vertex ~ budget * seen, or uniform over the vertices with budget
+    left when nothing seen has any; edge uniform over the vertex's unpicked incidence entries by rejection), stated on
+    integers so a device kernel can reproduce it bit for bit: attempt 0 selects the vertex at position
+    floor(u * W / 2^32) of the integer weight CDF (W = total weight, vertices in id order), attempts >= 1 select the
+    incidence entry floor(u * degree / 2^32).  csrc/k_sample.hip k_neighborhood_sample is this loop on the device;
+    tests/test_gpu_ops.py holds the two equal draw for draw."""
+    edges = np.full(sample_size, -1, dtype=np.int32)
+    budget = np.asarray(degrees, dtype=np.int64).copy()
+    picked = np.zeros(n_triplets, dtype=bool)
+    seen = np.zeros(len(budget), dtype=bool)
+    for i in range(sample_size):
+        w = budget * seen
+        total = int(w.sum())
+        if total == 0:
+            w = (budget > 0).astype(np.int64)
+            total = int(w.sum())
+            if total == 0:
+                break
+        pos = (int(draw(i, 0)) * total) >> 32
+        v = int(np.searchsorted(np.cumsum(w), pos, side='right'))
+        seen[v] = True
+        a0, deg = int(adj_ptr[v]), int(adj_ptr[v + 1] - adj_ptr[v])
+        attempt = 1
+        while True:
+            if attempt > NEIGHBOR_MAX_ATTEMPTS:
+                j = int(np.flatnonzero(~picked[adj_edge[a0:a0 + deg]])[0])
+            else:
+                j = (int(draw(i, attempt)) * deg) >> 32
+            attempt += 1
+            if not picked[adj_edge[a0 + j]]:
+                break
+        e, other = int(adj_edge[a0 + j]), int(adj_other[a0 + j])
+        edges[i] = e
+        picked[e] = True
+        budget[v] -= 1
+        budget[other] -= 1
+        seen[other] = True
     return edges
 
 

@@ -169,10 +169,8 @@ def main(args):
 
     dev_sampler = None
     if getattr(args, 'device_sampler', False):
-        if args.edge_sampler != 'uniform':
-            raise ValueError("--device-sampler supports --edge-sampler uniform only")
         from .device_sampling import DeviceSampler
-        dev_sampler = DeviceSampler(train_data, num_nodes, num_rels, dev)
+        dev_sampler = DeviceSampler(train_data, num_nodes, num_rels, dev, sampler=args.edge_sampler)
 
     while True:
         model.train()

@@ -388,6 +388,17 @@ int gv_triplet_index_build(const int32_t* trip, int64_t T, int n_ent, int n_rel,
 /* out[i] = i-th output of a keyed permutation of [0, n), i < k <= n: k DISTINCT indices (np.random.choice(n, k, replace=False),
  * kgvae/utils.py:79-82) without sorting n keys: 4-round unbalanced Feistel network over ceil(log2 n) bits, cycle walking */
 int gv_perm_sample(int64_t n, int64_t k, uint64_t seed, uint64_t tick, uint32_t stream_id, int32_t* out, void* stream);
+/* sample_edge_neighborhood (kgvae/utils.py:33-76; --edge-sampler neighbor, kgvae/link_predict.py:311): sample_size triplet ids by
+ * neighbourhood expansion -- vertex ~ (remaining degree * seen), or uniform over vertices with degree left when nothing seen has
+ * any; then an unpicked incident triplet uniformly (rejection).  adj_ptr (V+1) / adj_edge / adj_other (2 * num_triplets) are the
+ * reference's adj_list flattened (get_adj_and_degrees, kgvae/utils.py:20-31), degrees (V) its degree vector.  Sequential by
+ * nature: one workgroup, the per-draw CDF search is what runs in parallel.  Draw (i, attempt) = Philox4x32-10(seed;
+ * (i, stream_id + 0x10000 * attempt, tick lo, tick hi)).x; attempt 0 picks the vertex at floor(u * W / 2^32) of the integer weight CDF, attempts >= 1
+ * the incidence entry floor(u * degree / 2^32).  edges[i] = -1 once every triplet is picked. */
+int64_t gv_neighborhood_sample_workspace_bytes(int num_vertices, int64_t num_triplets);
+int gv_neighborhood_sample(const int32_t* adj_ptr, const int32_t* adj_edge, const int32_t* adj_other, const int32_t* degrees,
+                           int num_vertices, int64_t num_triplets, int sample_size, uint64_t seed, uint64_t tick,
+                           uint32_t stream_id, int32_t* edges, void* workspace, int64_t workspace_bytes, void* stream);
 /* np.unique((a, b), return_inverse=True) (kgvae/utils.py:103-105) for ids in [0, num_ids): uniq = the sorted distinct ids
  * (first min(count, uniq_cap) of them), a_local / b_local = their ranks, *count = how many (device int32) */
 int64_t gv_relabel_workspace_bytes(int num_ids);

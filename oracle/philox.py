@@ -95,3 +95,11 @@ def negative_draws(total, n_entities, seed, tick, stream):
     raw = _philox_x(seed, tick, stream, np.arange(total, dtype=np.uint64))
     values = (raw[:, 0].astype(np.uint64) * np.uint64(n_entities)) >> np.uint64(32)
     return values.astype(np.int64), (raw[:, 1] >> np.uint32(31)).astype(bool)
+
+
+def neighborhood_draw(seed, tick, stream):
+    """draw(i, attempt) -> uint32 of gv_neighborhood_sample (include/gcnvae.h): Philox counter
+    (i, stream + 0x10000 * attempt, tick lo, tick hi), output word x."""
+    def draw(i, attempt):
+        return int(_philox_x(seed, tick, stream + 0x10000 * attempt, [i])[0, 0])
+    return draw

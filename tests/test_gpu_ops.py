@@ -1080,6 +1080,59 @@ def test_native_sampler_negative_draws_match_numpy_restatement(ops):
     assert 0.4 < hit.mean() < 0.6 and values.min() >= 0 and values.max() < n_ent
 
 
+@pytest.mark.parametrize('n,n_rel,n_trip,k', [(300, 5, 2000, 700), (2000, 11, 30000, 3000), (50, 3, 120, 120), (5000, 7, 6000, 2500)])
+def test_neighborhood_sampler_equals_host_restatement_draw_for_draw(ops, n, n_rel, n_trip, k):
+    """kgvae/utils.py:33-76 on the device: gv_neighborhood_sample == sampling.sample_edge_neighborhood_draws fed the same
+    Philox outputs (the oracle's numpy Philox), edge for edge -- including the 'nothing seen has budget' restarts (sparse
+    graphs with many components: n = 5000 / 6000 triplets) and the sample that exhausts every triplet (k = n_trip)."""
+    from gcn_vae_amd import lib, sampling
+    from gcn_vae_amd.data import synthetic_kg
+    from gcn_vae_amd.lib import ptr
+    from oracle import philox
+    data = synthetic_kg(n, n_rel, n_trip, seed=n)
+    trip = data.train
+    adj = sampling.adjacency_csr(n, trip)
+    adj_d = [torch.from_numpy(a).cuda() for a in adj]
+    nb = int(lib.load().gv_neighborhood_sample_workspace_bytes(n, len(trip)))
+    ws = torch.empty(nb, dtype=torch.uint8, device='cuda')
+    k = min(k, len(trip))
+    out = torch.empty(k, dtype=torch.int32, device='cuda')
+    seed, tick, stream = 0xFEDCBA9876543210, 5, 0x5A04
+    lib.call('gv_neighborhood_sample', *(ptr(a) for a in adj_d), n, len(trip), k, seed, tick, stream, ptr(out), ptr(ws), nb,
+             lib.stream())
+    got = out.cpu().numpy()
+    want = sampling.sample_edge_neighborhood_draws(*adj, len(trip), k, philox.neighborhood_draw(seed, tick, stream))
+    assert np.array_equal(got, want)
+    assert len(np.unique(got)) == k and got.min() >= 0 and got.max() < len(trip)         # distinct triplets
+    # neighbourhood property: after the first pick every pick touches an already-seen vertex unless a restart happened
+    seen, restarts = set(), 0
+    for e in got.tolist():
+        s_, o_ = int(trip[e, 0]), int(trip[e, 2])
+        restarts += not (s_ in seen or o_ in seen)
+        seen.update((s_, o_))
+    assert restarts >= 1 and (restarts < k // 4 or n > 2 * n_trip // 3)
+
+
+def test_device_sampler_neighbor_mode(ops):
+    from gcn_vae_amd import sampling
+    from gcn_vae_amd.data import synthetic_kg
+    from gcn_vae_amd.device_sampling import STREAM_NBR, DeviceSampler
+    from oracle import philox
+    data = synthetic_kg(2000, 11, 30000, seed=1)
+    sm = DeviceSampler(data.train, 2000, 11, 'cuda', seed=3, sampler='neighbor')
+    b = sm.sample(3000, 0.5, 5)
+    chosen = sm.last_chosen.cpu().numpy()
+    want = sampling.sample_edge_neighborhood_draws(*sampling.adjacency_csr(2000, data.train), len(data.train), 3000,
+                                                   philox.neighborhood_draw(sm.seed, sm.tick, STREAM_NBR))
+    assert np.array_equal(chosen, want)
+    ids = b.node_id.view(-1).cpu().numpy()
+    samples = b.samples.cpu().numpy()
+    pos_global = np.stack([ids[samples[:3000, 0]], samples[:3000, 1], ids[samples[:3000, 2]]], 1)
+    assert np.array_equal(pos_global, data.train[chosen])
+    with pytest.raises(ValueError):
+        DeviceSampler(data.train, 2000, 11, 'cuda', sampler='random-walk')
+
+
 @pytest.mark.parametrize('native', [True, False])
 def test_device_sampler_batch_invariants(ops, native):
     """Either implementation: distinct sampled triplets, sorted unique node ids, (dst, src, rel)-ordered symmetric graph,

@@ -145,3 +145,33 @@ def test_compat_install_aliases_and_state_dict_manifest():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_neighborhood_sampler_with_injected_draws_has_the_reference_distribution():
+    """sampling.sample_edge_neighborhood_draws (the integer-CDF statement the device kernel reproduces) against
+    sampling.sample_edge_neighborhood (numpy's stream, pinned to the reference's golden vector above): the same
+    distribution over pick sequences on a small graph, and the same invariants."""
+    from collections import Counter
+
+    from gcn_vae_amd import sampling
+    trip = np.array([[0, 0, 1], [1, 0, 2], [2, 1, 0], [3, 0, 4], [4, 1, 4], [1, 1, 3], [5, 0, 0], [2, 0, 3]])
+    n, k, trials = 6, 3, 6000
+    adj_list, deg = sampling.get_adj_and_degrees(n, trip)
+    csr = sampling.adjacency_csr(n, trip)
+    assert np.array_equal(csr[3], deg) and all(np.array_equal(np.stack([csr[1], csr[2]], 1)[csr[0][v]:csr[0][v + 1]], adj_list[v])
+                                               for v in range(n) if deg[v])
+    np.random.seed(0)
+    ref = Counter(tuple(sampling.sample_edge_neighborhood(adj_list, deg, len(trip), k).tolist()) for _ in range(trials))
+    rs = np.random.RandomState(1)
+    got = Counter()
+    for _ in range(trials):
+        u = rs.randint(0, 2 ** 32, size=(k, 64), dtype=np.uint64)
+        got[tuple(sampling.sample_edge_neighborhood_draws(*csr, len(trip), k, lambda i, a: int(u[i, a])).tolist())] += 1
+    for seq in set(ref) | set(got):
+        assert len(set(seq)) == k
+        p, q = ref[seq] / trials, got[seq] / trials
+        assert abs(p - q) < 4.0 * np.sqrt(max(p, q, 1e-3) / trials) + 2e-3, (seq, p, q)
+    # exhausting every triplet: all picked once, then -1
+    u = rs.randint(0, 2 ** 32, size=(len(trip) + 2, 4200), dtype=np.uint64)
+    full = sampling.sample_edge_neighborhood_draws(*csr, len(trip), len(trip) + 2, lambda i, a: int(u[i, a]))
+    assert sorted(full[:len(trip)].tolist()) == list(range(len(trip))) and (full[len(trip):] == -1).all()
