@@ -241,7 +241,7 @@ def test_rel_graph_conv_unsorted_edges_and_empty_rows(ops):
 
 
 @pytest.mark.parametrize('m,n,k', [(300, 200, 200), (1000, 400, 200), (37, 19, 53), (128, 64, 16), (5, 3, 2),
-                                   (200, 400, 3000)])
+                                   (200, 400, 3000), (260, 500, 1000), (64, 64, 40), (68, 132, 100), (4, 4, 4)])
 def test_gemm_all_layouts(ops, m, n, k):
     gen = torch.Generator().manual_seed(m + n + k)
     a = torch.randn(m, k, generator=gen)
