@@ -433,7 +433,7 @@ def main():
     cfg = CONFIGS[args.config]
     trained_edges = w['e_total'] if w['strong'] else world * E      # directed edges of the graph one step trains on
     model.static_batch = True      # the same triplets every step: build their index once, exact and locality-ordered
-    params = [p for p in model.parameters() if p.requires_grad]
+    params = gdist.arena_order(model)      # last-finished-in-backward first: the arena's tail reduces under layer 1's backward
     # One GPU: the step is replayed as a hipGraph.  With RCCL collectives in the step (world > 1) the default is eager
     # launching -- measured equal to graph replay on one GPU (the step is GPU-bound: ~55 launches of 5-130 us against
     # ~15 us of host work each), and it keeps RCCL out of stream capture, which only a 1-rank group could verify here.
@@ -441,6 +441,7 @@ def main():
     use_segments = dist_on and not use_graph and not args.no_graph and not args.no_segments
     from gcn_vae_amd.optim import FlatAdam
     opt = FlatAdam(params, lr=1e-3, max_grad_norm=1.0)      # clip_grad_norm_(1.0) + Adam over one flat arena
+    reducer = gdist.BucketedArenaReduce(opt.flat_g, opt.offsets) if dist_on else None
     pick_rng = random.Random(rank)
     post_idx = torch.zeros(200, dtype=torch.long, device=dev)
     model.encoder.mmd_index_override = post_idx          # static buffer: contents refreshed per step on the host
@@ -475,6 +476,9 @@ def main():
         enc = model.encoder
         enc.row_part = m.get('part')
         enc.rconv_layer_1.reduce_hook = enc.rconv_layer_2.reduce_hook = hook if (dist_on and name == 'edge') else None
+        enc.grad_reducer = reducer if (dist_on and name == 'edge') else None      # row scheme: one piece, at the end
+        if reducer is not None:
+            reducer.average = name != 'row'       # row partition: every gradient is a partial sum over the ranks' rows
         # edge-block sharding replicates the node-level work: all ranks must draw the SAME dropout masks / noise;
         # the row partition draws per-rank noise for its own rows
         torch.manual_seed(m['seed'])
@@ -500,10 +504,7 @@ def main():
         loss, pred, kl, mmd = model.get_loss(cur['g'], embed, cur['samples'], cur['labels'])
         loss.backward(gradient=one)
         if dist_on:
-            if cur['name'] == 'row':
-                gdist.sum_flat(opt.flat_g)
-            else:
-                gdist.average_flat(opt.flat_g)
+            reducer.finish()               # what backward could not start early, the waits, the 1/world scale
         opt.step()
         return loss
 

@@ -66,6 +66,7 @@ class KGVAE(nn.Module):
         # so when the task head announces that MMD will be evaluated (LinkPredict sets this for mmd_param > 0) the
         # prior rows ride along in forward() as extra rows of the same GEMMs instead of ~150 tiny launches of their own.
         self.batch_mmd_prior_with_forward = False
+        self.grad_reducer = None          # distributed.BucketedArenaReduce: multi-GPU gradient exchange started under backward
         self._z_pri_flowed = None
         # multi-GPU destination-row partition (distributed.RowPartition): this rank computes its own row block only;
         # forward() then takes the rank's distributed.RowBlockGraph and the node ids of ALL positions, and returns the
@@ -212,6 +213,8 @@ class KGVAE(nn.Module):
         h = self.input_layer(g, h, r, norm)
         eps = self._draw_noise(h.shape[0], h.device)
         h = self.rconv_layer_1(g, h, r, norm)
+        if self.grad_reducer is not None:     # layer 2 onwards is final once dL/dh1 exists: its arena suffix reduces under layer 1's backward
+            h = self.grad_reducer.milestone(h, next(self.rconv_layer_2.parameters()))
         h = self.rconv_layer_2(g, h, r, norm)
         z, self.z_mean, self.z_sigma = ops.reparam(h, eps)
         self._z_pri_flowed = None

@@ -39,6 +39,7 @@ class FlatAdam:
         self._ws = torch.empty(1024, dtype=torch.float32, device=dev)
         self._direct_keys = []
         self._clean = False
+        self.offsets = {p: o for p, o in zip(self.params, offs)}     # parameter -> first float of its arena slice
         for p, o in zip(self.params, offs):
             n = p.numel()
             self.flat_p[o:o + n].copy_(p.data.reshape(-1))

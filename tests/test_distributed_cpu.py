@@ -45,9 +45,11 @@ def layer(x, src, dst, et, norm, w, b, lw, act, reduce):
     return act(h) if act is not None else h
 
 
-def loss_on(params, src, dst, et, norm, trip, labels, reduce):
+def loss_on(params, src, dst, et, norm, trip, labels, reduce, tap=None):
     x = params['emb']
     h1 = layer(x, src, dst, et, norm, params['w1'], params['b1'], params['l1'], torch.relu, reduce)
+    if tap is not None:
+        h1 = tap(h1)
     h2 = layer(h1, src, dst, et, norm, params['w2'], params['b2'], params['l2'], None, reduce)
     score = okg.distmult_score(h2, params['w_rel'], trip)
     return torch.nn.functional.binary_cross_entropy_with_logits(score, labels)
@@ -108,6 +110,23 @@ def worker(rank, world, port, out_q):
             t = torch.full((3,), float(rank))
             h(t).wait()
             assert torch.equal(t, torch.full((3,), 1.0))                           # in place, summed over ranks
+        # the same step with the gradient arena reduced in two pieces: layer 2 + decoder as soon as dL/dh1 exists (under
+        # layer 1's backward), the rest at the end -- equal to the one-shot average, bit for bit
+        sizes = [v.numel() for v in params.values()]
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        flat_g = torch.zeros(int(offs[-1]))
+        p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        for (k, v), o in zip(p2.items(), offs):
+            v.grad = flat_g[o:o + v.numel()].view_as(v)
+        red = gdist.BucketedArenaReduce(flat_g, {v: int(o) for v, o in zip(p2.values(), offs)})
+        loss2 = loss_on(p2, src_l, dst_l, et_l, norm, tr, lb, lambda t: gdist.AllReduceSum.apply(t, None),
+                        tap=lambda h1: red.milestone(h1, p2['w2']))
+        loss2.backward()
+        off_w2 = int(offs[list(p2).index('w2')])
+        assert red.log == [(off_w2, int(offs[-1]))], red.log              # the suffix went out DURING backward
+        red.finish()
+        assert torch.equal(flat_g, flat), float((flat_g - flat).abs().max())
+        assert all(v.grad.data_ptr() == flat_g[o:].data_ptr() for v, o in zip(p2.values(), offs))      # grads still alias the arena
         mean_loss = torch.tensor([float(loss)])
         dist.all_reduce(mean_loss)
         out_q.put((rank, {k: v.grad.clone().numpy() for k, v in p.items()}, float(mean_loss) / world, flat.numpy()))

@@ -87,10 +87,19 @@ def main():
     T = len(samples)
     sl = slice(rank * T // world, (rank + 1) * T // world)
     configure(net)
+    # the gradient arena in backward-completion order; its tail (layer 2, decoder, prior) is all-reduced under layer 1's backward
+    from gcn_vae_amd.optim import FlatAdam
+    opt = FlatAdam(gdist.arena_order(net), lr=1e-3, max_grad_norm=1.0)
+    red = gdist.BucketedArenaReduce(opt.flat_g, opt.offsets)
+    net.encoder.grad_reducer = red
+    opt.zero_grad()
+    net.zero_grad = lambda *a, **k: None          # step() clears through the module: the arena is already clean
     loss_rank = step(net, g_loc, torch.from_numpy(rel[ids]).to(dev), enorm_loc, torch.from_numpy(samples[sl]).to(dev),
                      torch.from_numpy(labels[sl]).to(dev), gdist.make_reduce_hook(async_op=True))
-    params = [p for p in net.parameters() if p.requires_grad]
-    gdist.average_gradients(params)
+    launched = list(red.log)
+    l2_off = opt.offsets[next(net.encoder.rconv_layer_2.parameters())]
+    assert launched == [(l2_off, opt.flat_g.numel())], f'the arena tail was not reduced under backward: {launched}'
+    red.finish()
     mean_loss = loss_rank.clone()
     dist.all_reduce(mean_loss)
     mean_loss /= world
