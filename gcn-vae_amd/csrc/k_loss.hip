@@ -29,10 +29,12 @@ __global__ __launch_bounds__(256) void k_final_sum(const float* part, int n, flo
 //   scal = {s0*sum(p0), s1*sum(p1), s2*sum(p2), s3*sum(p3)},  loss = scal[0] + w1*scal[1] + w2*scal[2] + w3*scal[3]
 __global__ __launch_bounds__(256) void k_loss_combine(const float* p0, int n0, float s0, const float* p1, int n1, float s1,
                                                       const float* p2, int n2, float s2, const float* p3, int n3, float s3,
-                                                      float w1, float w2, float w3, float* scal, float* loss) {
+                                                      float w1, float w2, float w3, float* scal, float* loss,
+                                                      const int* rows_dev, float rows_host) {
     __shared__ float sm[4];
     const float* ps[4] = {p0, p1, p2, p3};
     const int ns[4] = {n0, n1, n2, n3};
+    if (rows_dev) s2 *= rows_host / (float)*rows_dev;          // the KL mean runs over the rows that exist
     const float ss[4] = {s0, s1, s2, s3};
     float term[4];
 #pragma unroll
@@ -188,9 +190,10 @@ constexpr int KL_KMAX = 64;   // mixture components (lane j keeps component j's 
 template <int CPL>
 __global__ __launch_bounds__(256) void k_kl_fwd(const float* z, const float* m, int ld_m, const float* v,
                                                 const float* mix, const float* flp, float* resp, float* part,
-                                                int64_t n, int h, int k) {
+                                                int64_t n, int h, int k, const int* rows_dev) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float wsum[4];
+    if (rows_dev) n = *rows_dev;               // rows beyond it are padding of a static-shape batch
     __shared__ float lconst[KL_KMAX];          // sum_c (log sqrt v_jc + log sqrt 2 pi): independent of the node
     const int kh = k * h;
     if ((kh & 3) == 0) {
@@ -292,8 +295,13 @@ __global__ __launch_bounds__(256) void k_kl_bwd_nodes(const float* z, const floa
 template <int KT>
 __global__ __launch_bounds__(256) void k_kl_bwd_fused(const float* z, const float* m, int ld_m, const float* v, const float* mix,
                                                       const float* resp, const float* gkl, float gscale, float z_extra,
-                                                      float* gz, float* gm, float* gv, float* part, int64_t n, int h, int k) {
+                                                      float* gz, float* gm, float* gv, float* part, int64_t n, int h, int k,
+                                                      const int* rows_dev) {
     __shared__ float sm[2 * KT][4][64];
+    // static-shape batches: rows [*rows_dev, n) are padding -- zero gradients, no share in the sums; the 1/n factors of the
+    // two means (KL and the regulariser's z_extra) become 1/*rows_dev
+    const int64_t n_real = rows_dev ? (int64_t)*rows_dev : n;
+    const float refit = (float)n / (float)n_real;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // uniform: resp rows become scalar loads
     const int c = blockIdx.x * 64 + lane;
@@ -302,8 +310,8 @@ __global__ __launch_bounds__(256) void k_kl_bwd_fused(const float* z, const floa
     const int nsl = gridDim.y;
     const int64_t per = (n + nsl - 1) / nsl;
     const int64_t r0 = blockIdx.y * per, r1 = min(n, r0 + per);
-    const float cg = gscale * (gkl ? *gkl : 1.f) / (float)n;
-    const float cz = z_extra * (gkl ? *gkl : 1.f);           // an extra upstream * z_extra * z term on gz (the regulariser)
+    const float cg = gscale * (gkl ? *gkl : 1.f) / (float)n * refit;
+    const float cz = z_extra * (gkl ? *gkl : 1.f) * refit;   // an extra upstream * z_extra * z term on gz (the regulariser)
     float mu[KT], i2[KT], amu[KT], av[KT];
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(256) void k_kl_bwd_fused(const float* z, const floa
         float rv = 0.f;
         {
             const int64_t rr = rb + 4 * (lane >> 4);
-            if ((lane & 15) < k && rr < r1) rv = resp[rr * k + (lane & 15)];
+            if ((lane & 15) < k && rr < r1 && rr < n_real) rv = resp[rr * k + (lane & 15)];
         }
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
@@ -336,6 +344,10 @@ __global__ __launch_bounds__(256) void k_kl_bwd_fused(const float* z, const floa
         for (int u = 0; u < RU; ++u) {
             const int64_t r = rb + 4 * u;
             if (r >= r1) break;                            // wave-uniform
+            if (r >= n_real) {                             // padding row (wave-uniform)
+                if (ok) { gz[r * h + c] = 0.f; gm[r * h + c] = 0.f; gv[r * h + c] = 0.f; }
+                continue;
+            }
             const float d = zz[u] - mm[u];
             float mixg = 0.f;
 #pragma unroll
@@ -416,13 +428,13 @@ __global__ __launch_bounds__(256) void k_kl_bwd_mix_part(const float* z, const f
 
 __global__ __launch_bounds__(1024) void k_kl_bwd_mix_final(const float* part, const float* z_pre, const float* gkl,
                                                            float gscale, float* g_zpre, int accumulate, int64_t n, int h,
-                                                           int k, int nsl) {
+                                                           int k, int nsl, const int* rows_dev) {
     __shared__ float sm[64][16];
     const int total = 2 * k * h, kh = k * h;
     const int i = blockIdx.x * 16 + (threadIdx.x & 15);
     float acc = sum_slices_16x64(part, total, nsl, i, sm);     // slices added in a fixed order
     if ((threadIdx.x >> 4) != 0 || i >= total) return;
-    const float cg = gscale * (gkl ? *gkl : 1.f) / (float)n;
+    const float cg = gscale * (gkl ? *gkl : 1.f) / (float)(rows_dev ? (int64_t)*rows_dev : n);
     if (i >= kh) {  // chain through v_j = softplus(raw) + 1e-8
         const float raw = z_pre[i];
         acc *= raw > 20.f ? 1.f : 1.f / (1.f + expf(-raw));
@@ -632,8 +644,13 @@ extern "C" int gv_mean_sq(const float* x, int64_t n, float scale, float* out, fl
 }
 
 __global__ __launch_bounds__(256) void k_sumsq2_part(const float* x1, int64_t n1, float s1, int nb1, const float* x2,
-                                                     int64_t n2, float s2, float* part) {
+                                                     int64_t n2, float s2, float* part, const int* rows_dev, int64_t rows_host) {
     __shared__ float sm[4];
+    if (rows_dev) {                        // x1 = rows_host rows of which only the first *rows_dev exist: mean over those
+        const int64_t rows = *rows_dev;
+        n1 = n1 / rows_host * rows;
+        s1 *= (float)rows_host / (float)rows;
+    }
     const bool first = (int)blockIdx.x < nb1;
     const float* x = first ? x1 : x2;
     const int64_t n = first ? n1 : n2;
@@ -645,11 +662,14 @@ __global__ __launch_bounds__(256) void k_sumsq2_part(const float* x1, int64_t n1
 }
 
 extern "C" int gv_mean_sq2(const float* x1, int64_t n1, float scale1, const float* x2, int64_t n2, float scale2, float* out,
-                           float* workspace, void* stream) {
+                           float* workspace, const int32_t* rows_dev, int64_t rows_host, void* stream) {
     GV_REQUIRE(x1 && x2 && workspace, GV_ERR_NULL, "gv_mean_sq2: NULL pointer");
     GV_REQUIRE(n1 > 0 && n2 > 0, GV_ERR_SHAPE, "gv_mean_sq2: empty input");
+    GV_REQUIRE(!rows_dev || (rows_host > 0 && n1 % rows_host == 0), GV_ERR_SHAPE, "gv_mean_sq2: rows_host=%lld does not divide n1",
+               (long long)rows_host);
     const int nb1 = sq2_blocks(n1, 768), nb2 = sq2_blocks(n2, 255);
-    hipLaunchKernelGGL(k_sumsq2_part, dim3(nb1 + nb2), dim3(256), 0, GV_ST, x1, n1, scale1, nb1, x2, n2, scale2, workspace);
+    hipLaunchKernelGGL(k_sumsq2_part, dim3(nb1 + nb2), dim3(256), 0, GV_ST, x1, n1, scale1, nb1, x2, n2, scale2, workspace, rows_dev,
+                       rows_host);
     if (out) hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, nb1 + nb2, 1.f, out, 0);
     return launch_status("gv_mean_sq2");
 }
@@ -661,18 +681,19 @@ extern "C" int64_t gv_kl_workspace_bytes(int64_t n, int h, int k) {
 
 extern "C" int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre,
                          const float* flp, float* resp, float* kl, float* workspace, int64_t n, int h, int k,
-                         void* stream) {
+                         const int32_t* rows_dev, void* stream) {
     GV_REQUIRE(z && m && v && z_pre && resp && workspace, GV_ERR_NULL, "gv_kl_fwd: NULL pointer");
     GV_REQUIRE(n > 0 && h > 0 && k > 0 && k <= KL_KMAX && ld_m >= h, GV_ERR_SHAPE, "gv_kl_fwd: n=%lld h=%d k=%d",
                (long long)n, h, k);
     const size_t lds = (size_t)2 * k * h * sizeof(float);
     GV_REQUIRE(lds <= 64 * 1024, GV_ERR_SHAPE, "gv_kl_fwd: mixture table %zu B exceeds the 64 KiB LDS budget", lds);
+    GV_REQUIRE(!(rows_dev && kl), GV_ERR_SHAPE, "gv_kl_fwd: with rows_dev the mean is finished by gv_loss_combine (kl must be NULL)");
     float* mix = workspace;
     float* part = workspace + 3 * (size_t)k * h;
     hipLaunchKernelGGL(k_kl_mix, dim3((k * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, k, h, mix);
     const int nb = kl_blocks(n);
     GV_REQUIRE(h <= 1024, GV_ERR_SHAPE, "gv_kl_fwd: h=%d > 1024 unsupported", h);
-#define GV_KL_FWD(CPL_) hipLaunchKernelGGL(k_kl_fwd<CPL_>, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, flp, resp, part, n, h, k)
+#define GV_KL_FWD(CPL_) hipLaunchKernelGGL(k_kl_fwd<CPL_>, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, flp, resp, part, n, h, k, rows_dev)
     if (h <= 64) GV_KL_FWD(1);
     else if (h <= 128) GV_KL_FWD(2);
     else if (h <= 256) GV_KL_FWD(4);
@@ -687,7 +708,7 @@ extern "C" int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* 
 extern "C" int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre,
                          const float* resp, const float* gkl, float gscale, float z_extra, float* gz, float* gm,
                          float* gv, float* g_zpre, int accumulate_zpre, float* workspace, int mix_ready, int64_t n, int h,
-                         int k, void* stream) {
+                         int k, const int32_t* rows_dev, void* stream) {
     GV_REQUIRE(z && m && v && z_pre && resp && gz && gm && gv && g_zpre && workspace, GV_ERR_NULL,
                "gv_kl_bwd: NULL pointer");
     GV_REQUIRE(n > 0 && h > 0 && k > 0 && k <= KL_KMAX && ld_m >= h, GV_ERR_SHAPE, "gv_kl_bwd: bad shape");
@@ -696,8 +717,9 @@ extern "C" int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* 
     float* part = workspace + 3 * (size_t)k * h + RED_BLOCKS;
     if (k <= KL_FUSED_KT) {
         hipLaunchKernelGGL(k_kl_bwd_fused<KL_FUSED_KT>, dim3((h + 63) / 64, KL_SLICES), dim3(256), 0, GV_ST, z, m, ld_m, v, mix,
-                           resp, gkl, gscale, z_extra, gz, gm, gv, part, n, h, k);
+                           resp, gkl, gscale, z_extra, gz, gm, gv, part, n, h, k, rows_dev);
     } else {
+        GV_REQUIRE(!rows_dev, GV_ERR_SHAPE, "gv_kl_bwd: rows_dev needs k <= %d mixture components", KL_FUSED_KT);
         const size_t lds = (size_t)2 * k * h * sizeof(float);
         const int nb = (int)((n + 3) / 4 > 1024 ? 1024 : (n + 3) / 4);
         hipLaunchKernelGGL(k_kl_bwd_nodes, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, resp, gkl, gscale, z_extra,
@@ -706,7 +728,7 @@ extern "C" int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* 
                            h, k);
     }
     hipLaunchKernelGGL(k_kl_bwd_mix_final, dim3((2 * k * h + 15) / 16), dim3(1024), 0, GV_ST, part, z_pre, gkl,
-                       gscale, g_zpre, accumulate_zpre, n, h, k, KL_SLICES);
+                       gscale, g_zpre, accumulate_zpre, n, h, k, KL_SLICES, rows_dev);
     return launch_status("gv_kl_bwd");
 }
 
@@ -742,7 +764,8 @@ extern "C" int gv_mmd_fwd(const float* x, const float* y, const int64_t* y_index
 
 extern "C" int gv_loss_combine(const float* ws_pred, int64_t t, const float* ws_reg, int64_t n_embed, int64_t n_wrel,
                                const float* ws_kl, int64_t n_nodes, int h, int k, const float* ws_mmd, int sx, int sy,
-                               float reg_w, float kl_w, float mmd_w, float* scal, float* loss, void* stream) {
+                               float reg_w, float kl_w, float mmd_w, float* scal, float* loss, const int32_t* rows_dev,
+                               void* stream) {
     GV_REQUIRE(ws_pred && loss, GV_ERR_NULL, "gv_loss_combine: NULL pointer");
     GV_REQUIRE(t > 0, GV_ERR_SHAPE, "gv_loss_combine: t=%lld", (long long)t);
     const int n0 = red_blocks(t, 16);
@@ -751,7 +774,8 @@ extern "C" int gv_loss_combine(const float* ws_pred, int64_t t, const float* ws_
     const int n3 = ws_mmd ? sx + sy : 0;
     const float* kl_part = ws_kl ? ws_kl + 3 * (size_t)k * h : nullptr;     // partials follow the mixture table
     hipLaunchKernelGGL(k_loss_combine, dim3(1), dim3(256), 0, GV_ST, ws_pred, n0, 1.f / (float)t, ws_reg, n1, 1.f, kl_part,
-                       n2, ws_kl ? 1.f / (float)n_nodes : 0.f, ws_mmd, n3, 1.f, reg_w, kl_w, mmd_w, scal, loss);
+                       n2, ws_kl ? 1.f / (float)n_nodes : 0.f, ws_mmd, n3, 1.f, reg_w, kl_w, mmd_w, scal, loss, rows_dev,
+                       (float)n_nodes);
     return launch_status("gv_loss_combine");
 }
 

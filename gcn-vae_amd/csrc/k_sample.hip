@@ -34,10 +34,20 @@ __device__ __forceinline__ uint32_t feistel_permute(uint32_t x, int bits, uint32
     return (l << rb) | r;
 }
 
-__global__ void k_perm_sample(long long n, long long k, int bits, uint32_t k0, uint32_t k1, uint32_t stream, uint32_t t0,
-                              uint32_t t1, int* out) {
+// tick_dev / n_dev (optional): the batch counter and the range are read on the device at execution time, so a launch recorded
+// in a hipGraph draws a fresh sample on every replay (the counter is advanced by gv_rng_tick inside the same graph)
+__global__ void k_perm_sample(long long n, long long k, int bits, uint32_t k0, uint32_t k1, uint32_t stream, unsigned long long tick,
+                              const unsigned long long* tick_dev, const int* n_dev, int* out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k) return;
+    if (tick_dev) tick += *tick_dev;
+    const uint32_t t0 = (uint32_t)tick, t1 = (uint32_t)(tick >> 32);
+    if (n_dev) {
+        n = *n_dev;
+        bits = 2;
+        while ((1ll << bits) < n) ++bits;
+        if (i >= n) { out[i] = (int)(i % max(n, 1ll)); return; }        // k > n: no k distinct values exist; stay in range
+    }
     uint32_t x = (uint32_t)i;
     do {
         x = feistel_permute(x, bits, k0, k1, stream, t0, t1);
@@ -70,7 +80,10 @@ __global__ void k_map_pairs(const int* a, const int* b, long long k, const int* 
 // (hit_subject) or object replaced by values[j*k + p]  (np.tile(pos, (neg_rate, 1)) order); labels 1 / 0
 __global__ void k_negative_sampling(const int* s, const int* r, const int* o, long long k, int neg_rate, const int* n_ent_dev,
                                     const int* values, const uint8_t* hit, uint32_t k0, uint32_t k1, uint32_t stream,
-                                    uint32_t t0, uint32_t t1, long long* samples, float* labels) {
+                                    unsigned long long tick, const unsigned long long* tick_dev, long long* samples,
+                                    float* labels) {
+    if (tick_dev) tick += *tick_dev;
+    const uint32_t t0 = (uint32_t)tick, t1 = (uint32_t)(tick >> 32);
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = k * (neg_rate + 1);
     if (i >= total) return;
@@ -159,8 +172,8 @@ size_t graph_temp(long long n2, long long bound, int num_rels) {
 }
 }  // namespace
 
-extern "C" int gv_perm_sample(int64_t n, int64_t k, uint64_t seed, uint64_t tick, uint32_t stream_id, int32_t* out,
-                              void* stream) {
+extern "C" int gv_perm_sample(int64_t n, int64_t k, uint64_t seed, uint64_t tick, const uint64_t* tick_dev,
+                              const int32_t* n_dev, uint32_t stream_id, int32_t* out, void* stream) {
     GV_REQUIRE(n >= 0 && k >= 0 && k <= n && n < (1ll << 31), GV_ERR_SHAPE, "gv_perm_sample: n=%lld k=%lld", (long long)n,
                (long long)k);
     if (k == 0) return GV_OK;
@@ -168,7 +181,8 @@ extern "C" int gv_perm_sample(int64_t n, int64_t k, uint64_t seed, uint64_t tick
     int bits = 2;
     while ((1ll << bits) < n) ++bits;
     hipLaunchKernelGGL(k_perm_sample, dim3(blocks_for(k)), dim3(256), 0, (hipStream_t)stream, (long long)n, (long long)k, bits,
-                       (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, (uint32_t)tick, (uint32_t)(tick >> 32), out);
+                       (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, (unsigned long long)tick,
+                       (const unsigned long long*)tick_dev, n_dev, out);
     return launch_status("gv_perm_sample");
 }
 
@@ -198,8 +212,8 @@ extern "C" int gv_relabel_pairs(const int32_t* a, const int32_t* b, int64_t k, i
 
 extern "C" int gv_negative_sampling(const int32_t* s, const int32_t* r, const int32_t* o, int64_t k, int neg_rate,
                                     const int32_t* n_entities_dev, const int32_t* values, const uint8_t* hit_subject,
-                                    uint64_t seed, uint64_t tick, uint32_t stream_id, int64_t* samples, float* labels,
-                                    void* stream) {
+                                    uint64_t seed, uint64_t tick, const uint64_t* tick_dev, uint32_t stream_id, int64_t* samples,
+                                    float* labels, void* stream) {
     GV_REQUIRE(k >= 0 && neg_rate >= 0, GV_ERR_SHAPE, "gv_negative_sampling: k=%lld neg_rate=%d", (long long)k, neg_rate);
     if (k == 0) return GV_OK;
     GV_REQUIRE(s && r && o && samples && labels, GV_ERR_NULL, "gv_negative_sampling: NULL pointer");
@@ -207,7 +221,7 @@ extern "C" int gv_negative_sampling(const int32_t* s, const int32_t* r, const in
                "gv_negative_sampling: pass both draws (values, hit_subject) or neither (then n_entities_dev)");
     hipLaunchKernelGGL(k_negative_sampling, dim3(blocks_for(k * (neg_rate + 1))), dim3(256), 0, (hipStream_t)stream, s, r, o,
                        (long long)k, neg_rate, n_entities_dev, values, hit_subject, (uint32_t)seed, (uint32_t)(seed >> 32),
-                       stream_id, (uint32_t)tick, (uint32_t)(tick >> 32), (long long*)samples, labels);
+                       stream_id, (unsigned long long)tick, (const unsigned long long*)tick_dev, (long long*)samples, labels);
     return launch_status("gv_negative_sampling");
 }
 
@@ -263,11 +277,12 @@ __device__ __forceinline__ uint32_t nbr_draw(uint32_t k0, uint32_t k1, uint32_t 
 __global__ __launch_bounds__(1024) void k_neighborhood_sample(const int* __restrict__ adj_ptr, const int* __restrict__ adj_edge,
                                                               const int* __restrict__ adj_other, int n_vertices, int sample_size,
                                                               uint32_t k0, uint32_t k1, uint32_t stream, uint64_t tick,
-                                                              int* budget_g, uint8_t* seen_g, uint8_t* picked, int* edges,
+                                                              const unsigned long long* tick_dev, int* budget_g, uint8_t* seen_g, uint8_t* picked, int* edges,
                                                               int state_in_lds) {
     __shared__ long long wave_tot[16];
     __shared__ int sh_v, sh_other;
     extern __shared__ int lds_state[];              // budget (V ints) then seen (V bytes) when they fit: no global round trips
+    if (tick_dev) tick += *tick_dev;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int per = (n_vertices + 1023) / 1024;
     const int lo = min(n_vertices, tid * per), hi = min(n_vertices, lo + per);
@@ -366,8 +381,8 @@ __global__ __launch_bounds__(1024) void k_neighborhood_sample(const int* __restr
 
 extern "C" int gv_neighborhood_sample(const int32_t* adj_ptr, const int32_t* adj_edge, const int32_t* adj_other,
                                       const int32_t* degrees, int num_vertices, int64_t num_triplets, int sample_size,
-                                      uint64_t seed, uint64_t tick, uint32_t stream_id, int32_t* edges, void* workspace,
-                                      int64_t workspace_bytes, void* stream) {
+                                      uint64_t seed, uint64_t tick, const uint64_t* tick_dev, uint32_t stream_id, int32_t* edges,
+                                      void* workspace, int64_t workspace_bytes, void* stream) {
     GV_REQUIRE(num_vertices > 0 && num_triplets > 0 && sample_size >= 0, GV_ERR_SHAPE,
                "gv_neighborhood_sample: num_vertices=%d num_triplets=%lld sample_size=%d", num_vertices, (long long)num_triplets,
                sample_size);
@@ -391,7 +406,8 @@ extern "C" int gv_neighborhood_sample(const int32_t* adj_ptr, const int32_t* adj
         hipFuncSetAttribute((const void*)k_neighborhood_sample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return launch_status("gv_neighborhood_sample(lds)");
     hipLaunchKernelGGL(k_neighborhood_sample, dim3(1), dim3(1024), in_lds ? lds : 0, st, adj_ptr, adj_edge, adj_other, num_vertices,
-                       sample_size, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, tick, budget, seen, picked, edges, in_lds);
+                       sample_size, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, tick, (const unsigned long long*)tick_dev,
+                       budget, seen, picked, edges, in_lds);
     return launch_status("gv_neighborhood_sample");
 }
 

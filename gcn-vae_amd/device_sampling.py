@@ -29,7 +29,7 @@ from . import lib
 from .graph import KGraph
 from .lib import ptr
 
-STREAM_EDGES, STREAM_NEG, STREAM_SPLIT, STREAM_NBR = 0x5A01, 0x5A02, 0x5A03, 0x5A04   # Philox stream ids of a batch's draws
+STREAM_EDGES, STREAM_NEG, STREAM_SPLIT, STREAM_NBR, STREAM_PICK = 0x5A01, 0x5A02, 0x5A03, 0x5A04, 0x5A05   # Philox stream ids of a batch's draws
 
 
 @dataclass
@@ -40,6 +40,7 @@ class DeviceBatch:
     edge_norm: torch.Tensor    # (E, 1) fp32   1 / in-degree of the edge's destination
     samples: torch.Tensor      # (T, 3) int64  positives followed by negatives, relabelled ids
     labels: torch.Tensor       # (T,)  fp32
+    rows_dev: torch.Tensor = None   # static-shape batches: device int32 (1,) = how many of the node rows exist (the rest is padding)
 
 
 class DeviceSampler:
@@ -59,6 +60,7 @@ class DeviceSampler:
         self.seed = int(seed) if seed is not None else int(torch.initial_seed())
         self.seed &= 0xFFFFFFFFFFFFFFFF
         self.tick = 0                                              # batch number: the Philox counter's high words
+        self._state = None                                         # its device-side twin (sample_static)
         if self.native:
             t32 = self.triplets.to(torch.int32)
             self._s, self._r, self._o = (t32[:, i].contiguous() for i in range(3))
@@ -72,10 +74,21 @@ class DeviceSampler:
             self._nbr_ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
 
     # -- native pipeline ----------------------------------------------------------------------------------------
-    def _sample_native(self, sample_size, split_size, negative_rate):
+    def _sample_native(self, sample_size, split_size, negative_rate, static=False, mmd_pick=None):
+        """static=False: one host sync (the node count sizes the arrays).  static=True (``sample_static``): no sync and no
+        data-dependent shape -- node arrays are padded to cap = min(2k, num_nodes) rows, the node count stays on the device
+        (``rows_dev``) and the batch number is read from device memory, so the whole call can sit in a hipGraph."""
         dev, k, st = self.device, int(sample_size), lib.stream()
         n_trip = int(self.triplets.shape[0])
-        self.tick += 1
+        if static:
+            if self._state is None:
+                self._state = torch.zeros(2, dtype=torch.int64, device=dev)
+                self._state[1] = self.tick
+            lib.call('gv_rng_tick', ptr(self._state), st)                 # the device-side batch number
+            tick, tick_dev = 0, ptr(self._state[1:])
+        else:
+            self.tick += 1
+            tick, tick_dev = self.tick, None
         i32 = dict(dtype=torch.int32, device=dev)
         chosen = torch.empty(k, **i32)
         if self.sampler == 'neighbor':
@@ -83,14 +96,17 @@ class DeviceSampler:
                 raise ValueError(f'sample_size {k} exceeds the {n_trip} training triplets')
             adj_ptr, adj_edge, adj_other, degrees = self._adj
             lib.call('gv_neighborhood_sample', ptr(adj_ptr), ptr(adj_edge), ptr(adj_other), ptr(degrees), self.num_nodes, n_trip,
-                     k, self.seed, self.tick, STREAM_NBR, ptr(chosen), ptr(self._nbr_ws), self._nbr_ws.numel(), st)
+                     k, self.seed, tick, tick_dev, STREAM_NBR, ptr(chosen), ptr(self._nbr_ws), self._nbr_ws.numel(), st)
         else:
-            lib.call('gv_perm_sample', n_trip, k, self.seed, self.tick, STREAM_EDGES, ptr(chosen), st)
+            lib.call('gv_perm_sample', n_trip, k, self.seed, tick, tick_dev, None, STREAM_EDGES, ptr(chosen), st)
         self.last_chosen = chosen
         ci = chosen.long()
         src_g, rel, dst_g = self._s[ci], self._r[ci], self._o[ci]             # global ids of the sampled triplets
         cap = min(2 * k, self.num_nodes)
-        uniq, src, dst, count = (torch.empty(cap, **i32), torch.empty(k, **i32), torch.empty(k, **i32), torch.empty(1, **i32))
+        # static: padding rows carry their own position as node id (any valid id would do; distinct ones keep the embedding
+        # backward's scatter-add of their zero gradients off a single row)
+        uniq = torch.arange(cap, **i32) if static else torch.empty(cap, **i32)
+        src, dst, count = torch.empty(k, **i32), torch.empty(k, **i32), torch.empty(1, **i32)
         ws_bytes = int(lib.load().gv_relabel_workspace_bytes(self.num_nodes))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         lib.call('gv_relabel_pairs', ptr(src_g), ptr(dst_g), k, self.num_nodes, ptr(uniq), cap, ptr(src), ptr(dst), ptr(count),
@@ -99,19 +115,33 @@ class DeviceSampler:
         samples = torch.empty(total, 3, dtype=torch.int64, device=dev)
         labels = torch.empty(total, dtype=torch.float32, device=dev)
         lib.call('gv_negative_sampling', ptr(src), ptr(rel), ptr(dst), k, int(negative_rate), ptr(count), None, None, self.seed,
-                 self.tick, STREAM_NEG, ptr(samples), ptr(labels), st)
+                 tick, tick_dev, STREAM_NEG, ptr(samples), ptr(labels), st)
         m = int(k * split_size)
         keep = torch.empty(max(m, 1), **i32)
-        lib.call('gv_perm_sample', k, m, self.seed, self.tick, STREAM_SPLIT, ptr(keep), st)
+        lib.call('gv_perm_sample', k, m, self.seed, tick, tick_dev, None, STREAM_SPLIT, ptr(keep), st)
         src2, dst2, rel2 = torch.empty(2 * m, **i32), torch.empty(2 * m, **i32), torch.empty(2 * m, **i32)
         norm = torch.empty(2 * m, 1, dtype=torch.float32, device=dev)
         gb = int(lib.load().gv_graph_from_triplets_workspace_bytes(m, cap, self.num_rels))
         gws = torch.empty(gb, dtype=torch.uint8, device=dev)
         lib.call('gv_graph_from_triplets', ptr(src), ptr(rel), ptr(dst), ptr(keep), m, cap, self.num_rels, ptr(src2), ptr(dst2),
                  ptr(rel2), ptr(norm), ptr(gws), gb, st)
+        if static:
+            if mmd_pick is not None:       # KGVAE.get_mmd's posterior rows: distinct rows of the ones that exist (kgvae/model.py:96)
+                pick32 = torch.empty(mmd_pick.numel(), **i32)
+                lib.call('gv_perm_sample', cap, mmd_pick.numel(), self.seed, tick, tick_dev, ptr(count), STREAM_PICK, ptr(pick32), st)
+                mmd_pick.copy_(pick32)
+            g = KGraph.from_device_edges(cap, src2, dst2, dst_sorted=True)       # rows [count, cap): isolated padding nodes
+            return DeviceBatch(g, uniq.long().view(-1, 1), rel2.long(), norm, samples, labels, rows_dev=count)
         n = int(count.item())                                                    # the one host sync per batch
         g = KGraph.from_device_edges(n, src2, dst2, dst_sorted=True)
         return DeviceBatch(g, uniq[:n].long().view(-1, 1), rel2.long(), norm, samples, labels)
+
+    def sample_static(self, sample_size, split_size=0.5, negative_rate=10, mmd_pick=None):
+        """``sample`` with static shapes and no host synchronisation (hipGraph-capturable; native pipeline only).
+        ``mmd_pick`` (optional int64 buffer): filled with that many distinct rows of the batch's existing nodes."""
+        if not self.native:
+            raise RuntimeError('sample_static runs on the native pipeline only (GV_NATIVE_SAMPLER=1)')
+        return self._sample_native(sample_size, split_size, negative_rate, static=True, mmd_pick=mmd_pick)
 
     def _sorted_graph(self, n, src, rel, dst):
         """build_graph_from_triplets: add reverse edges, order by (dst, src, rel), 1/in-degree norm."""

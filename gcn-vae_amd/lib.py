@@ -23,12 +23,12 @@ SIGNATURES = {
     'gv_relation_index_build': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _L, _P]),
     'gv_triplet_index_build': (_I, [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I,
                                     _P, _L, _P]),
-    'gv_perm_sample': (_I, [_L, _L, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _P, _P]),
+    'gv_perm_sample': (_I, [_L, _L, ctypes.c_uint64, ctypes.c_uint64, _P, _P, ctypes.c_uint32, _P, _P]),
     'gv_neighborhood_sample_workspace_bytes': (_L, [_I, _L]),
-    'gv_neighborhood_sample': (_I, [_P, _P, _P, _P, _I, _L, _I, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _P, _P, _L, _P]),
+    'gv_neighborhood_sample': (_I, [_P, _P, _P, _P, _I, _L, _I, ctypes.c_uint64, ctypes.c_uint64, _P, ctypes.c_uint32, _P, _P, _L, _P]),
     'gv_relabel_workspace_bytes': (_L, [_I]),
     'gv_relabel_pairs': (_I, [_P, _P, _L, _I, _P, _I, _P, _P, _P, _P, _L, _P]),
-    'gv_negative_sampling': (_I, [_P, _P, _P, _L, _I, _P, _P, _P, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _P, _P, _P]),
+    'gv_negative_sampling': (_I, [_P, _P, _P, _L, _I, _P, _P, _P, ctypes.c_uint64, ctypes.c_uint64, _P, ctypes.c_uint32, _P, _P, _P]),
     'gv_graph_from_triplets_workspace_bytes': (_L, [_L, _I, _I]),
     'gv_graph_from_triplets': (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
     'gv_segment_items_count': (_I, [_P, _I, _I, _P, _P, _P, _P]),
@@ -69,13 +69,13 @@ SIGNATURES = {
     'gv_distmult_bce_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     'gv_bce_grad': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     'gv_mean_sq': (_I, [_P, _L, _F, _P, _P, _I, _P]),
-    'gv_mean_sq2': (_I, [_P, _L, _F, _P, _L, _F, _P, _P, _P]),
+    'gv_mean_sq2': (_I, [_P, _L, _F, _P, _L, _F, _P, _P, _P, _L, _P]),
     'gv_axpby': (_I, [_L, _P, _F, _P, _F, _P, _P]),
     'gv_mul': (_I, [_L, _P, _P, _P, _P]),
     'gv_kl_workspace_bytes': (_L, [_L, _I, _I]),
-    'gv_kl_fwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
-    'gv_kl_bwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P, _I, _L, _I, _I, _P]),
-    'gv_loss_combine': (_I, [_P, _L, _P, _L, _L, _P, _L, _I, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P]),
+    'gv_kl_fwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
+    'gv_kl_bwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P, _I, _L, _I, _I, _P, _P]),
+    'gv_loss_combine': (_I, [_P, _L, _P, _L, _L, _P, _L, _I, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P]),
     'gv_lincomb4': (_I, [_P, _F, _P, _F, _P, _F, _P, _F, _P, _P]),
     'gv_mmd_fwd': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     'gv_mmd_bwd': (_I, [_P, _P, _P, _I, _I, _I, _P, _F, _P, _P, _P]),

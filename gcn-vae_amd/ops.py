@@ -321,7 +321,8 @@ class RelationIndex:
         if etypes.numel() != g.num_edges:
             raise ValueError(f'etypes has {etypes.numel()} entries for {g.num_edges} edges')
         et = etypes.reshape(-1).to(torch.int64)
-        if g.num_edges and (int(et.min()) < 0 or int(et.max()) >= num_rels):
+        # (device-built graphs come with device-built relation ids: no host round trip to validate them)
+        if g.num_edges and not g.sync_free and (int(et.min()) < 0 or int(et.max()) >= num_rels):
             raise ValueError(f'edge types must lie in [0, {num_rels})')
         self.num_rels = int(num_rels)
         self.keepalive = etypes
@@ -1825,7 +1826,7 @@ class _KL(torch.autograd.Function):
         resp = torch.empty(n, k, dtype=torch.float32, device=z.device)
         kl = torch.empty((), dtype=torch.float32, device=z.device)
         lib.call('gv_kl_fwd', ptr(z), ptr(m), h, ptr(v), ptr(z_pre), ptr(flp), ptr(resp), ptr(kl), ptr(ws), n, h, k,
-                 lib.stream())
+                 None, lib.stream())
         ctx.save_for_backward(z, m, v, z_pre, resp, ws)
         ctx.has_flp = flp is not None
         ctx.zp_version = z_pre._version
@@ -1841,7 +1842,7 @@ class _KL(torch.autograd.Function):
         d_zp = _direct_flat(z_pre)
         gzp = d_zp if d_zp is not None else torch.empty_like(z_pre)
         lib.call('gv_kl_bwd', ptr(z), ptr(m), h, ptr(v), ptr(z_pre), ptr(resp), ptr(gkl), 1.0, 0.0, ptr(gz), ptr(gm), ptr(gv),
-                 ptr(gzp), 1 if d_zp is not None else 0, ptr(ws), 1, n, h, k, lib.stream())
+                 ptr(gzp), 1 if d_zp is not None else 0, ptr(ws), 1, n, h, k, None, lib.stream())
         return gz, gm, gv, (None if d_zp is not None else gzp), (gkl.reshape(()).clone() if ctx.has_flp else None)
 
 
@@ -2012,8 +2013,12 @@ class _LossHead(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, reg_w, kl_w, mmd_w, score_bias,
-                embed_rows=None):
+                embed_rows=None, rows_dev=None):
         z, ld_z = _row_major(z, 'embed')
+        if rows_dev is not None:          # static-shape batch: rows [*rows_dev, n) of z are padding (include/gcnvae.h, rows_dev)
+            rows_dev = _chk(rows_dev.reshape(-1), torch.int32, 'rows_dev')
+            if kl_w <= 0 or embed_rows is not None:
+                raise NotImplementedError('rows_dev needs kl_w > 0 (the padding rows are masked in the KL pass) and no embed_rows')
         w_rel, ld_w = _row_major(w_rel, 'w_relation')
         labels = _chk(labels.reshape(-1), name='labels')
         dev, (n, h), T = z.device, z.shape, tidx.T
@@ -2044,24 +2049,24 @@ class _LossHead(torch.autograd.Function):
         # every term leaves its per-block partial sums in its workspace; ONE combine launch finishes the four sums
         if kl_w > 0:
             lib.call('gv_kl_fwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(flp), ptr(resp), None, ptr(wsk),
-                     n, h, k, st)
+                     n, h, k, ptr(rows_dev), st)
         if mmd_w > 0:      # the posterior sample set is rows `pick` of z, read in place
             lib.call('gv_mmd_fwd', ptr(z_pri), ptr(z), ptr(pick), z_pri.shape[0], pick.numel(), h, None, ptr(wsm), st)
         # embed_rows: the regulariser's mean runs over that many rows (the rest of z are all-zero padding rows of the
         # multi-GPU row partition)
         z_count = z.numel() if embed_rows is None else int(embed_rows) * h
         lib.call('gv_mean_sq2', ptr(z), z.numel(), 1.0 / z_count, ptr(w_rel), w_rel.numel(), 1.0 / w_rel.numel(), None,
-                 ptr(ws2), st)
+                 ptr(ws2), ptr(rows_dev), n, st)
         # DistMult scorer + BCE (three 800-B row gathers per triplet: the bandwidth-bound part)
         lib.call('gv_distmult_bce_fwd', ptr(z), ld_z, ptr(w_rel), ld_w, ptr(tidx.trip32), ptr(tidx.fwd_order), ptr(labels),
                  ptr(bias), ptr(score), None, ptr(ws), T, h, st)
         lib.call('gv_loss_combine', ptr(ws), T, ptr(ws2), z.numel(), w_rel.numel(), ptr(wsk) if kl_w > 0 else None, n, h,
                  (z_pre.shape[0] // 2) if kl_w > 0 else 0, ptr(wsm) if mmd_w > 0 else None,
                  z_pri.shape[0] if mmd_w > 0 else 0, pick.numel() if mmd_w > 0 else 0, float(reg_w), float(kl_w),
-                 float(mmd_w), ptr(scal), ptr(loss), st)
+                 float(mmd_w), ptr(scal), ptr(loss), ptr(rows_dev), st)
         ctx.save_for_backward(z, z_mean if kl_w > 0 else None, z_sigma if kl_w > 0 else None, w_rel,
                               z_pre if kl_w > 0 else None, resp, z_pri if mmd_w > 0 else None, z_post,
-                              pick if mmd_w > 0 else None, labels, score, wsk)
+                              pick if mmd_w > 0 else None, labels, score, wsk, rows_dev)
         ctx.meta = (tidx, float(reg_w), float(kl_w), float(mmd_w), bias is not None, flp is not None and kl_w > 0)
         ctx.z_count = z_count
         ctx.direct_w = _direct(w_rel) if ld_w == h else None
@@ -2072,8 +2077,8 @@ class _LossHead(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gp, _gk, _gm):
         if g is None:
-            return (None,) * 15
-        z, z_mean, z_sigma, w_rel, z_pre, resp, z_pri, z_post, pick, labels, score, wsk = ctx.saved_tensors
+            return (None,) * 16
+        z, z_mean, z_sigma, w_rel, z_pre, resp, z_pri, z_post, pick, labels, score, wsk, rows_dev = ctx.saved_tensors
         z_count = ctx.z_count
         tidx, reg_w, kl_w, mmd_w, has_bias, flp_in_kl = ctx.meta
         dev, (n, h), T = z.device, z.shape, tidx.T
@@ -2103,7 +2108,7 @@ class _LossHead(torch.autograd.Function):
                 # the embedding regulariser's gradient g * (2 reg_w / numel) * z rides on the same pass over z
                 lib.call('gv_kl_bwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(resp), ptr(g), kl_w,
                          2.0 * reg_w / z_count, ptr(gz), ptr(gm), ptr(gv), ptr(gzp), 1 if d_zp is not None else 0, ptr(wsk),
-                         1, n, h, k, s1)
+                         1, n, h, k, ptr(rows_dev), s1)
             else:
                 lib.call('gv_axpby', z.numel(), ptr(g), 2.0 * reg_w / z_count, ptr(z), 0.0, ptr(gz), s1)
             if mmd_w > 0:      # MMD backward: prior rows -> g_pri, posterior rows ADDED into rows `pick` of gz (now complete)
@@ -2127,13 +2132,13 @@ class _LossHead(torch.autograd.Function):
             lib.call('gv_lincomb4', ptr(dbias) if has_bias else None, 1.0, ptr(g) if flp_in_kl else None, kl_w, None, 0.0,
                      None, 0.0, ptr(g_flp), st)
         return (g_z, gm, gv, (None if d_w is not None else g_w), (None if d_zp is not None else gzp), g_flp, g_pri, None,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 def loss_head(z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, reg_w, kl_w, mmd_w, score_bias,
-              embed_rows=None):
+              embed_rows=None, rows_dev=None):
     return _LossHead.apply(z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, float(reg_w), float(kl_w),
-                           float(mmd_w), bool(score_bias), embed_rows)
+                           float(mmd_w), bool(score_bias), embed_rows, rows_dev)
 
 
 class _MADEForward(torch.autograd.Function):

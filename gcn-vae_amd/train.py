@@ -79,7 +79,7 @@ class LinkPredict(nn.Module):
         loss, predict_loss, kl, mmd = ops.loss_head(
             embed, enc.z_mean if kl_w > 0 else None, enc.z_sigma if kl_w > 0 else None, self.w_relation,
             enc.z_pre.squeeze(0) if kl_w > 0 else None, flp, z_pri, pick, labels, tidx, self.reg_param, kl_w, mmd_w,
-            score_bias=self.n_flows > 0)
+            score_bias=self.n_flows > 0, rows_dev=getattr(self, 'rows_dev', None))
         # shapes as the reference returns them: a disabled term is ``zeros(1)`` there and broadcasts the loss to (1,)
         kl = kl.reshape(()) if kl_w > 0 else kl.reshape(1)
         mmd = mmd.reshape(()) if mmd_w > 0 else mmd.reshape(1)
@@ -172,10 +172,29 @@ def main(args):
         from .device_sampling import DeviceSampler
         dev_sampler = DeviceSampler(train_data, num_nodes, num_rels, dev, sampler=args.edge_sampler)
 
+    graphed = None
+    if getattr(args, 'graph_step', False):
+        if dev_sampler is None:
+            raise ValueError('--graph-step records the device sampler with the step: pass --device-sampler too')
+        from .graph_step import GraphedMiniBatchStep
+        model.train()
+        graphed = GraphedMiniBatchStep(model, optimizer, dev_sampler, args.graph_batch_size, args.graph_split_size,
+                                       args.negative_sample).capture()
+        epoch += 3                                   # the capture's eager warm-up steps were training steps
+
     while True:
         model.train()
         epoch += 1
-        if dev_sampler is not None:
+        if graphed is not None:      # the whole step -- sampling to Adam -- is one hipGraph replay
+            _sync()
+            t0 = time.time()
+            loss, pred_loss, kl, mmd = graphed()
+            _sync()
+            forward_time.append(0.0)
+            backward_time.append(time.time() - t0)
+            print("Epoch {:04d} | Loss {:.4f} | Best MRR {:.4f} | pred_loss {:.4f} | kl {:.4f} | mmd {:.4f}".format(
+                epoch, loss.item(), best_mrr, pred_loss.item(), kl.item(), mmd.item()))
+        elif dev_sampler is not None:
             b = dev_sampler.sample(args.graph_batch_size, args.graph_split_size, args.negative_sample)
             g, node_id, edge_type, edge_norm, batch, labels = b.g, b.node_id, b.edge_type, b.edge_norm, b.samples, b.labels
         else:
@@ -187,21 +206,22 @@ def main(args):
             edge_norm = node_norm_to_edge_norm(g, torch.from_numpy(node_norm).view(-1, 1)).to(dev)
             batch, labels = torch.from_numpy(batch).to(dev), torch.from_numpy(labels).to(dev)
 
-        _sync()
-        t0 = time.time()
-        embed = model(g, node_id, edge_type, edge_norm)
-        loss, pred_loss, kl, mmd = model.get_loss(g, embed, batch, labels)
-        _sync()
-        t1 = time.time()
-        loss.backward()
-        optimizer.step()              # clip_grad_norm_(grad_norm) + Adam, fused
-        _sync()
-        t2 = time.time()
-        forward_time.append(t1 - t0)
-        backward_time.append(t2 - t1)
-        print("Epoch {:04d} | Loss {:.4f} | Best MRR {:.4f} | pred_loss {:.4f} | kl {:.4f} | mmd {:.4f}".format(
-            epoch, loss.item(), best_mrr, pred_loss.item(), kl.item(), mmd.item()))
-        optimizer.zero_grad()
+        if graphed is None:
+            _sync()
+            t0 = time.time()
+            embed = model(g, node_id, edge_type, edge_norm)
+            loss, pred_loss, kl, mmd = model.get_loss(g, embed, batch, labels)
+            _sync()
+            t1 = time.time()
+            loss.backward()
+            optimizer.step()              # clip_grad_norm_(grad_norm) + Adam, fused
+            _sync()
+            t2 = time.time()
+            forward_time.append(t1 - t0)
+            backward_time.append(t2 - t1)
+            print("Epoch {:04d} | Loss {:.4f} | Best MRR {:.4f} | pred_loss {:.4f} | kl {:.4f} | mmd {:.4f}".format(
+                epoch, loss.item(), best_mrr, pred_loss.item(), kl.item(), mmd.item()))
+            optimizer.zero_grad()
 
         if epoch % args.evaluate_every == 0:
             model.eval()
@@ -255,6 +275,9 @@ def build_parser():
     p.add_argument("--bf16", action="store_true",
                    help="dense products (MaskedLinear, self-loop term, evaluation scorer) with bf16 operands and fp32 "
                         "accumulation (BASELINE configs[2]); not a reference flag, default fp32")
+    p.add_argument("--graph-step", action="store_true",
+                   help="with --device-sampler: record sampling + forward + loss + backward + clip/Adam once and replay it "
+                        "as one hipGraph per step (static shapes: node rows padded, counts kept on the device)")
     p.add_argument("--device-sampler", action="store_true",
                    help="prepare batches on the GPU (uniform sampler, torch's device RNG instead of numpy's: not the "
                         "reference's random stream, ~10x less host time per step)")

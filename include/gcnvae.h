@@ -279,19 +279,25 @@ int gv_bce_grad(const float* score, const float* labels, const float* gloss, flo
  */
 int gv_mean_sq(const float* x, int64_t n, float scale, float* out, float* workspace, int accumulate, void* stream);
 /* *out = scale1*sum(x1^2) + scale2*sum(x2^2) in one pass pair (the two regulariser terms); workspace: 1024 floats */
+/* rows_dev (optional, device int32) -- the STATIC-SHAPE mini-batch step (one hipGraph, kgvae/link_predict.py:200-236): node
+ * arrays are padded to a bound n of which only the first *rows_dev rows exist (the sampler's node count, never read on the
+ * host).  Where a routine takes rows_dev, sums skip the padding rows and every 1/n of a mean becomes 1/(*rows_dev);
+ * NULL = all n rows exist.  Here: x1 is rows_host rows, its mean runs over the first *rows_dev of them. */
 int gv_mean_sq2(const float* x1, int64_t n1, float scale1, const float* x2, int64_t n2, float scale2, float* out,
-                float* workspace, void* stream);
+                float* workspace, const int32_t* rows_dev, int64_t rows_host, void* stream);
 int gv_axpby(int64_t n, const float* a, float alpha, const float* x, float beta, float* y, void* stream);
 int gv_mul(int64_t n, const float* a, const float* b, float* out, void* stream);
 int64_t gv_kl_workspace_bytes(int64_t n, int h, int k);
 int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre, const float* flp,
-              float* resp, float* kl, float* workspace, int64_t n, int h, int k, void* stream);
+              float* resp, float* kl, float* workspace, int64_t n, int h, int k, const int32_t* rows_dev, void* stream);
 int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre, const float* resp,
               const float* gkl, float gscale, float z_extra, float* gz, float* gm, float* gv, float* g_zpre,
-              int accumulate_zpre, float* workspace, int mix_ready, int64_t n, int h, int k, void* stream);
+              int accumulate_zpre, float* workspace, int mix_ready, int64_t n, int h, int k, const int32_t* rows_dev,
+              void* stream);
 /* upstream gradient = gscale * (*gkl); gz additionally receives (*gkl) * z_extra * z (the embedding regulariser's
  * gradient, kgvae/link_predict.py:68-69, folded into the same pass); accumulate_zpre adds into g_zpre; mix_ready = 1 when `workspace` is the one
- * gv_kl_fwd filled for the same z_pre (skips recomputing the mixture table). */
+ * gv_kl_fwd filled for the same z_pre (skips recomputing the mixture table).  With rows_dev: padding rows get zero gz / gm / gv
+ * (k <= 16 components), and gv_kl_fwd leaves the mean to gv_loss_combine (kl must be NULL). */
 
 /*   gv_mmd_*  : KGVAE.get_mmd / compute_kernel (kgvae/model.py:71-80, :89-102) on x = prior samples (sx, h),
  *       y = posterior rows (sy, h):  K(a,b) = exp(-mean_d (a_d-b_d)^2 / h);  mmd = mean Kxx + mean Kyy - 2 mean Kxy.
@@ -306,7 +312,8 @@ int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* v, const fl
  *   scal = {pred, reg, kl, mmd},  *loss = pred + reg_w*reg + kl_w*kl + mmd_w*mmd   (kgvae/link_predict.py:86-91) */
 int gv_loss_combine(const float* ws_pred, int64_t t, const float* ws_reg, int64_t n_embed, int64_t n_wrel,
                     const float* ws_kl, int64_t n_nodes, int h, int k, const float* ws_mmd, int sx, int sy, float reg_w,
-                    float kl_w, float mmd_w, float* scal /* 4 floats, optional */, float* loss, void* stream);
+                    float kl_w, float mmd_w, float* scal /* 4 floats, optional */, float* loss, const int32_t* rows_dev,
+                    void* stream);
 int gv_lincomb4(const float* a0, float c0, const float* a1, float c1, const float* a2, float c2, const float* a3,
                 float c3, float* out, void* stream);
 /* y_index (optional, int64[sy]): sample j of the second set is row y_index[j] of y (KGVAE.get_mmd's posterior rows are a
@@ -387,7 +394,10 @@ int gv_triplet_index_build(const int32_t* trip, int64_t T, int n_ent, int n_rel,
  * Random draws are Philox4x32-10 outputs keyed by (seed, tick, stream_id): a batch is a pure function of those three. */
 /* out[i] = i-th output of a keyed permutation of [0, n), i < k <= n: k DISTINCT indices (np.random.choice(n, k, replace=False),
  * kgvae/utils.py:79-82) without sorting n keys: 4-round unbalanced Feistel network over ceil(log2 n) bits, cycle walking */
-int gv_perm_sample(int64_t n, int64_t k, uint64_t seed, uint64_t tick, uint32_t stream_id, int32_t* out, void* stream);
+/* tick_dev (optional, device uint64): added to tick when the kernel RUNS, n_dev (optional, device int32): replaces n then -- a
+ * launch recorded in a hipGraph draws a fresh sample per replay once gv_rng_tick advances *tick_dev inside the same graph */
+int gv_perm_sample(int64_t n, int64_t k, uint64_t seed, uint64_t tick, const uint64_t* tick_dev, const int32_t* n_dev,
+                   uint32_t stream_id, int32_t* out, void* stream);
 /* sample_edge_neighborhood (kgvae/utils.py:33-76; --edge-sampler neighbor, kgvae/link_predict.py:311): sample_size triplet ids by
  * neighbourhood expansion -- vertex ~ (remaining degree * seen), or uniform over vertices with degree left when nothing seen has
  * any; then an unpicked incident triplet uniformly (rejection).  adj_ptr (V+1) / adj_edge / adj_other (2 * num_triplets) are the
@@ -398,7 +408,8 @@ int gv_perm_sample(int64_t n, int64_t k, uint64_t seed, uint64_t tick, uint32_t 
 int64_t gv_neighborhood_sample_workspace_bytes(int num_vertices, int64_t num_triplets);
 int gv_neighborhood_sample(const int32_t* adj_ptr, const int32_t* adj_edge, const int32_t* adj_other, const int32_t* degrees,
                            int num_vertices, int64_t num_triplets, int sample_size, uint64_t seed, uint64_t tick,
-                           uint32_t stream_id, int32_t* edges, void* workspace, int64_t workspace_bytes, void* stream);
+                           const uint64_t* tick_dev, uint32_t stream_id, int32_t* edges, void* workspace,
+                           int64_t workspace_bytes, void* stream);
 /* np.unique((a, b), return_inverse=True) (kgvae/utils.py:103-105) for ids in [0, num_ids): uniq = the sorted distinct ids
  * (first min(count, uniq_cap) of them), a_local / b_local = their ranks, *count = how many (device int32) */
 int64_t gv_relabel_workspace_bytes(int num_ids);
@@ -410,7 +421,8 @@ int gv_relabel_pairs(const int32_t* a, const int32_t* b, int64_t k, int num_ids,
  * mulhi(u32, *n_entities_dev), hit_subject = top bit of a second u32 (Philox counter = the corruption's index). */
 int gv_negative_sampling(const int32_t* s, const int32_t* r, const int32_t* o, int64_t k, int neg_rate,
                          const int32_t* n_entities_dev, const int32_t* values, const uint8_t* hit_subject, uint64_t seed,
-                         uint64_t tick, uint32_t stream_id, int64_t* samples, float* labels, void* stream);
+                         uint64_t tick, const uint64_t* tick_dev, uint32_t stream_id, int64_t* samples, float* labels,
+                         void* stream);
 /* utils.build_graph_from_triplets + comp_deg_norm (kgvae/utils.py:127-150): triplets keep[0..m) (keep == NULL: the first m) of
  * (s, r, o) plus their reverse edges (relation + num_rels), 2m edges in (dst, src, rel) order, norm = 1 / in-degree of each
  * edge's destination.  n_nodes_bound: any bound on the node ids (it only sizes the sort key). */

@@ -512,3 +512,121 @@ def test_identity_embedding_gradient_accumulates_and_output_does_not_alias_for_o
     before = table.detach().clone()
     out.detach().mul_(0.0)
     assert torch.equal(table.detach(), before)
+
+
+def _minibatch_net(data, h=32, n_flows=0, seed=0):
+    from gcn_vae_amd.encoders import KGVAE
+    from gcn_vae_amd.train import LinkPredict
+    import itertools
+    from gcn_vae_amd import ops
+    ops._rngs.clear()                            # a fresh device generator (tick 0) and the same stream ids for every net built
+    ops._rng_streams = itertools.count(1)        # here: two nets of one test then draw the same dropout masks and noise
+    torch.manual_seed(seed)
+    return LinkPredict(KGVAE, data.num_nodes, h, data.num_rels, num_bases=8, num_hidden_layers=2, dropout=0.2, use_cuda=True,
+                       reg_param=0.01, kl_param=1e-3, mmd_param=1.0, k=10, n_flows=n_flows).cuda().train()
+
+
+@pytest.mark.parametrize('sampler', ['uniform', 'neighbor'])
+def test_static_shape_sampler_equals_the_synchronising_one(sampler):
+    """DeviceSampler.sample_static (no host sync, node arrays padded to cap, batch number read from device memory) builds the
+    batch that DeviceSampler.sample builds for the same seed and batch number: same triplets, same graph, same negatives;
+    the node count is on the device, a padding row's node id is its own position."""
+    from gcn_vae_amd.data import synthetic_kg
+    from gcn_vae_amd.device_sampling import DeviceSampler
+    data = synthetic_kg(3000, 11, 20000, seed=2)
+    a = DeviceSampler(data.train, data.num_nodes, data.num_rels, 'cuda', seed=5, sampler=sampler)
+    b = DeviceSampler(data.train, data.num_nodes, data.num_rels, 'cuda', seed=5, sampler=sampler)
+    pick = torch.zeros(200, dtype=torch.int64, device='cuda')
+    for _ in range(3):
+        dyn, sta = a.sample(900, 0.5, 4), b.sample_static(900, 0.5, 4, mmd_pick=pick)
+        n = int(sta.rows_dev.item())
+        cap = min(1800, data.num_nodes)
+        assert n == dyn.node_id.shape[0] and sta.node_id.shape == (cap, 1) and sta.g.number_of_nodes() == cap
+        assert torch.equal(sta.node_id[:n], dyn.node_id)
+        assert torch.equal(sta.node_id[n:].view(-1), torch.arange(n, cap, device='cuda'))        # padding: distinct valid ids
+        assert torch.equal(sta.samples, dyn.samples) and torch.equal(sta.labels, dyn.labels)
+        assert torch.equal(sta.edge_type, dyn.edge_type) and torch.equal(sta.edge_norm, dyn.edge_norm)
+        for x, y in zip(sta.g.edges(), dyn.g.edges()):
+            assert torch.equal(x, y)
+        p = pick.cpu().numpy()
+        assert len(np.unique(p)) == 200 and p.min() >= 0 and p.max() < n           # distinct existing rows
+
+
+def test_loss_head_with_padding_rows_equals_the_loss_on_the_existing_rows():
+    """include/gcnvae.h rows_dev: z padded with garbage rows + the device row count gives the loss and the gradients of the
+    unpadded call (padding rows: zero gradient)."""
+    from gcn_vae_amd import ops
+    gen = torch.Generator().manual_seed(0)
+    n, cap, h, k, T, R = 700, 1000, 64, 10, 5000, 9
+    z = torch.randn(cap, h, generator=gen)
+    m, v = torch.randn(cap, h, generator=gen), torch.rand(cap, h, generator=gen) + 0.1
+    w_rel, z_pre = torch.randn(R, h, generator=gen) * 0.3, torch.randn(2 * k, h, generator=gen) * 0.5
+    z_pri = torch.randn(200, h, generator=gen)
+    pick = torch.randperm(n, generator=gen)[:200]
+    trip = torch.stack([torch.randint(0, n, (T,), generator=gen), torch.randint(0, R, (T,), generator=gen),
+                        torch.randint(0, n, (T,), generator=gen)], 1)
+    labels = (torch.rand(T, generator=gen) > 0.5).float()
+
+    def run(rows, rows_dev):
+        ins = [t[:rows].clone().cuda().requires_grad_(True) for t in (z, m, v)] + \
+              [t.clone().cuda().requires_grad_(True) for t in (w_rel, z_pre, z_pri)]
+        tidx = ops.TripletIndex(trip.cuda(), rows, R, sync_free=True)
+        out = ops.loss_head(ins[0], ins[1], ins[2], ins[3], ins[4], None, ins[5], pick.cuda(), labels.cuda(), tidx, 0.01, 1e-2, 1.0,
+                            False, rows_dev=rows_dev)
+        out[0].backward()
+        return [o.detach().cpu() for o in out], [t.grad.cpu() for t in ins]
+    (la, pa, ka, ma), ga = run(n, None)
+    (lb, pb, kb, mb), gb = run(cap, torch.tensor([n], dtype=torch.int32, device='cuda'))
+    for x, y, nm in ((la, lb, 'loss'), (pa, pb, 'pred'), (ka, kb, 'kl'), (ma, mb, 'mmd')):
+        torch.testing.assert_close(y.reshape(-1), x.reshape(-1), rtol=1e-5, atol=1e-6, msg=lambda s, nm=nm: f'{nm}: {s}')
+    for i, nm in enumerate(('z', 'z_mean', 'z_sigma')):
+        torch.testing.assert_close(gb[i][:n], ga[i], rtol=1e-4, atol=1e-7, msg=lambda s, nm=nm: f'grad {nm}: {s}')
+        assert float(gb[i][n:].abs().max()) == 0.0, nm
+    for i, nm in ((3, 'w_rel'), (4, 'z_pre'), (5, 'z_pri')):
+        torch.testing.assert_close(gb[i], ga[i], rtol=1e-4, atol=1e-7, msg=lambda s, nm=nm: f'grad {nm}: {s}')
+
+
+def test_graphed_minibatch_step_equals_eager_steps():
+    """kgvae/link_predict.py:200-236 as one hipGraph (gcn_vae_amd.graph_step): six training steps -- three eager warm-up steps of
+    the static-shape body, then three replays -- follow the same losses as six eager steps with the synchronising sampler
+    (dynamic shapes, host-side MMD row pick replaced by the same device draw), and end at the same parameters."""
+    from gcn_vae_amd.data import synthetic_kg
+    from gcn_vae_amd.device_sampling import STREAM_PICK, DeviceSampler
+    from gcn_vae_amd.graph_step import GraphedMiniBatchStep
+    from gcn_vae_amd import lib
+    from gcn_vae_amd.lib import ptr
+    from gcn_vae_amd.optim import FlatAdam
+    data = synthetic_kg(3000, 11, 20000, seed=2)
+    k, split, neg = 1500, 0.5, 5
+    # --- eager, dynamic shapes
+    net_e = _minibatch_net(data)
+    opt_e = FlatAdam(net_e.parameters(), lr=1e-2, max_grad_norm=1.0)
+    sm_e = DeviceSampler(data.train, data.num_nodes, data.num_rels, 'cuda', seed=9)
+    pick_e = torch.zeros(200, dtype=torch.int64, device='cuda')
+    net_e.encoder.mmd_index_override = pick_e
+    losses_e = []
+    for _ in range(6):
+        b = sm_e.sample(k, split, neg)
+        n = b.node_id.shape[0]
+        p32 = torch.empty(200, dtype=torch.int32, device='cuda')
+        lib.call('gv_perm_sample', n, 200, sm_e.seed, sm_e.tick, None, None, STREAM_PICK, ptr(p32), lib.stream())
+        pick_e.copy_(p32)
+        opt_e.zero_grad()
+        embed = net_e(b.g, b.node_id, b.edge_type, b.edge_norm)
+        out = net_e.get_loss(b.g, embed, b.samples, b.labels)
+        out[0].backward()
+        opt_e.step()
+        losses_e.append([float(t.detach()) for t in out])
+    # --- captured
+    net_g = _minibatch_net(data)
+    opt_g = FlatAdam(net_g.parameters(), lr=1e-2, max_grad_norm=1.0)
+    sm_g = DeviceSampler(data.train, data.num_nodes, data.num_rels, 'cuda', seed=9)
+    step = GraphedMiniBatchStep(net_g, opt_g, sm_g, k, split, neg)
+    step.capture(warmup=3)               # three eager steps of the static-shape body, then the recording (nothing runs in it)
+    losses_g = [[float(t.detach()) for t in step()] for _ in range(3)]
+    # steps 4, 5, 6 of both runs
+    for e, g in zip(losses_e[3:], losses_g):
+        np.testing.assert_allclose(g, e, rtol=2e-3, atol=1e-5)
+    for (kk, pe), (_, pg) in zip(net_e.named_parameters(), net_g.named_parameters()):
+        torch.testing.assert_close(pg, pe, rtol=2e-2, atol=2e-3, msg=lambda s, kk=kk: f'{kk}: {s}')
+    assert losses_g[0] != losses_g[1] != losses_g[2]                       # every replay draws a fresh batch

@@ -988,16 +988,22 @@ def test_native_sampler_perm_sample_is_a_keyed_permutation(ops, n, k):
     from gcn_vae_amd.lib import ptr
     from oracle import philox
     out = torch.empty(k, dtype=torch.int32, device='cuda')
-    lib.call('gv_perm_sample', n, k, 0x1234567890ABCDEF, 7, 0x5A01, ptr(out), lib.stream())
+    lib.call('gv_perm_sample', n, k, 0x1234567890ABCDEF, 7, None, None, 0x5A01, ptr(out), lib.stream())
     got = out.cpu().numpy().astype(np.int64)
     assert len(np.unique(got)) == k and got.min() >= 0 and got.max() < n            # distinct: sampling without replacement
     if k == n:
         assert (np.sort(got) == np.arange(n)).all()
     assert np.array_equal(got, philox.perm_sample(n, k, 0x1234567890ABCDEF, 7, 0x5A01))    # the numpy restatement, bit for bit
     other = torch.empty(k, dtype=torch.int32, device='cuda')
-    lib.call('gv_perm_sample', n, k, 0x1234567890ABCDEF, 8, 0x5A01, ptr(other), lib.stream())
+    lib.call('gv_perm_sample', n, k, 0x1234567890ABCDEF, 8, None, None, 0x5A01, ptr(other), lib.stream())
     if n > 1000:
         assert not torch.equal(out, other)                                               # the tick selects another permutation
+    # the hipGraph form: batch counter and range read from device memory when the kernel runs (tick 5 + *tick_dev 3 = 8)
+    tick_dev = torch.tensor([3], dtype=torch.int64, device='cuda')
+    n_dev = torch.tensor([n], dtype=torch.int32, device='cuda')
+    third = torch.empty(k, dtype=torch.int32, device='cuda')
+    lib.call('gv_perm_sample', 2 * n + 5, k, 0x1234567890ABCDEF, 5, ptr(tick_dev), ptr(n_dev), 0x5A01, ptr(third), lib.stream())
+    assert torch.equal(third, other)
 
 
 def test_native_sampler_stages_equal_host_pipeline(ops):
@@ -1037,7 +1043,7 @@ def test_native_sampler_stages_equal_host_pipeline(ops):
     labels = torch.empty(k * (neg + 1), dtype=torch.float32, device='cuda')
     hit = torch.from_numpy((coin > 0.5).astype(np.uint8)).cuda()
     values_d = _i32(values)
-    lib.call('gv_negative_sampling', ptr(src), ptr(rel_d), ptr(dst), k, neg, None, ptr(values_d), ptr(hit), 0, 0, 0,
+    lib.call('gv_negative_sampling', ptr(src), ptr(rel_d), ptr(dst), k, neg, None, ptr(values_d), ptr(hit), 0, 0, None, 0,
              ptr(samples), ptr(labels), st)
     assert np.array_equal(samples.cpu().numpy(), samples_h) and np.array_equal(labels.cpu().numpy(), labels_h)
     # graph from a kept subset
@@ -1068,7 +1074,7 @@ def test_native_sampler_negative_draws_match_numpy_restatement(ops):
     labels = torch.empty(k * (neg + 1), dtype=torch.float32, device='cuda')
     cnt = torch.tensor([n_ent], dtype=torch.int32, device='cuda')
     s_d, r_d, o_d = _i32(s), _i32(r), _i32(o)
-    lib.call('gv_negative_sampling', ptr(s_d), ptr(r_d), ptr(o_d), k, neg, ptr(cnt), None, None, 99, 3, 0x5A02,
+    lib.call('gv_negative_sampling', ptr(s_d), ptr(r_d), ptr(o_d), k, neg, ptr(cnt), None, None, 99, 3, None, 0x5A02,
              ptr(samples), ptr(labels), lib.stream())
     values, hit = philox.negative_draws(k * neg, n_ent, 99, 3, 0x5A02)
     want = np.tile(np.stack([s, r, o], 1), (neg, 1))
@@ -1098,7 +1104,7 @@ def test_neighborhood_sampler_equals_host_restatement_draw_for_draw(ops, n, n_re
     k = min(k, len(trip))
     out = torch.empty(k, dtype=torch.int32, device='cuda')
     seed, tick, stream = 0xFEDCBA9876543210, 5, 0x5A04
-    lib.call('gv_neighborhood_sample', *(ptr(a) for a in adj_d), n, len(trip), k, seed, tick, stream, ptr(out), ptr(ws), nb,
+    lib.call('gv_neighborhood_sample', *(ptr(a) for a in adj_d), n, len(trip), k, seed, tick, None, stream, ptr(out), ptr(ws), nb,
              lib.stream())
     got = out.cpu().numpy()
     want = sampling.sample_edge_neighborhood_draws(*adj, len(trip), k, philox.neighborhood_draw(seed, tick, stream))
