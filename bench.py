@@ -215,11 +215,11 @@ def algorithmic_bytes(tag, E, N, R, T):
     return 0
 
 
-def pmc_traffic_for(tag):
-    """(HBM-side bytes per launch, provenance) of the kernel behind a K1 tag, from the newest committed rocprofv3 PMC
-    passes of this command (profiles/round*/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc runs, gfx950
-    correction per MI355X_MICROARCH.md; the file's "_meta" names the commit and date it was measured at).  (None, None)
-    when no profile of that kernel is committed."""
+def pmc_traffic_for(tag, config='c2'):
+    """(HBM-side bytes per launch, provenance) of the kernel behind a K1 tag IN THIS CONFIGURATION, from the newest committed
+    rocprofv3 PMC passes of this command (profiles/round*/pmc_traffic_<config>.json, or the round-1 pmc_traffic.json for c2:
+    (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc runs, gfx950 correction per MI355X_MICROARCH.md; the file's "_meta" names
+    the commit and date it was measured at).  (None, None) when no profile of that kernel and configuration is committed."""
     import glob
     import re
     kind, rest = tag.split('_', 1)
@@ -229,7 +229,10 @@ def pmc_traffic_for(tag):
     p, q = blk.split('x')
     pat = re.compile(r'k_agg_(fast|packed|phase)<%s, ?%s, ?%s,' % (p, q, 'true' if tr == 'T' else 'false'))
     best, src = None, None
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*', 'pmc_traffic.json'))):
+    paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*', f'pmc_traffic_{config}.json')))
+    if config == 'c2':
+        paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*', 'pmc_traffic.json'))) + paths
+    for path in paths:
         try:
             data = json.load(open(path))
         except Exception:
@@ -695,10 +698,11 @@ def main():
         if rg:
             # the headline is the WORST R-GCN aggregation instance (lowest fraction of its peak), not the best one
             dom = min(rg, key=lambda k: rg[k]['frac'])
-            traffic, traffic_src = pmc_traffic_for(dom)
+            traffic, traffic_src = pmc_traffic_for(dom, args.config if args.hidden == CONFIGS[args.config].get('hidden', args.hidden) else '-')
             roofline = {'kernel': dom, 'bound': rg[dom]['bound'], 'achieved': rg[dom]['achieved_GBs'],
                         'peak': rg[dom]['peak_GBs'], 'unit': 'GB/s', 'frac': rg[dom]['frac'],
                         'frac_of_hbm_peak': rg[dom]['frac_of_hbm_peak'], 'traffic': traffic, 'traffic_source': traffic_src,
+                        'traffic_over_algorithmic': round(traffic / (rg[dom]['algorithmic_MB'] * 1e6), 3) if traffic else None,
                         'avg_us': rg[dom]['avg_us'], 'algorithmic_MB': rg[dom]['algorithmic_MB'],
                         'frac_min': min(v['frac'] for v in rg.values()), 'frac_max': max(v['frac'] for v in rg.values()),
                         'frac_of_hbm_peak_min': min(v['frac_of_hbm_peak'] for v in rg.values()),
