@@ -190,7 +190,9 @@ constexpr int KL_KMAX = 64;   // mixture components (lane j keeps component j's 
 template <int CPL>
 __global__ __launch_bounds__(256) void k_kl_fwd(const float* z, const float* m, int ld_m, const float* v,
                                                 const float* mix, const float* flp, float* resp, float* part,
-                                                int64_t n, int h, int k, const int* rows_dev) {
+                                                int64_t n, int h, int k, const int* rows_dev, const float* h2 = nullptr,
+                                                const float* eps = nullptr, float* z_out = nullptr, float* v_out = nullptr,
+                                                float* m_out = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float wsum[4];
     if (rows_dev) n = *rows_dev;               // rows beyond it are padding of a static-shape batch
@@ -223,8 +225,20 @@ __global__ __launch_bounds__(256) void k_kl_fwd(const float* z, const float* m, 
             const int c = lane + 64 * i;
             zz[i] = 0.f;
             if (c < h) {
-                zz[i] = z[r * h + c];
-                const float d = zz[i] - m[r * ld_m + c], vv = v[r * h + c];
+                float mm, vv;
+                if (h2) {      // fused reparameterisation (K3): (m, v, z) are made here from h2 and eps, and stored for the rest of the step
+                    mm = h2[r * 2 * h + c];
+                    vv = softplus_t(h2[r * 2 * h + h + c]) + 1e-8f;
+                    zz[i] = mm + eps[r * h + c] * sqrtf(vv);
+                    z_out[r * h + c] = zz[i];
+                    v_out[r * h + c] = vv;
+                    if (m_out) m_out[r * h + c] = mm;
+                } else {
+                    zz[i] = z[r * h + c];
+                    mm = m[r * ld_m + c];
+                    vv = v[r * h + c];
+                }
+                const float d = zz[i] - mm;
                 a += -(d * d) / (2.f * vv) - logf(sqrtf(vv)) - LOG_SQRT_2PI;
             }
         }
@@ -296,7 +310,8 @@ template <int KT>
 __global__ __launch_bounds__(256) void k_kl_bwd_fused(const float* z, const float* m, int ld_m, const float* v, const float* mix,
                                                       const float* resp, const float* gkl, float gscale, float z_extra,
                                                       float* gz, float* gm, float* gv, float* part, int64_t n, int h, int k,
-                                                      const int* rows_dev) {
+                                                      const int* rows_dev, const float* h2 = nullptr, const float* eps = nullptr,
+                                                      const float* gz_up = nullptr, float* gh2 = nullptr) {
     __shared__ float sm[2 * KT][4][64];
     // static-shape batches: rows [*rows_dev, n) are padding -- zero gradients, no share in the sums; the 1/n factors of the
     // two means (KL and the regulariser's z_extra) become 1/*rows_dev
@@ -361,9 +376,20 @@ __global__ __launch_bounds__(256) void k_kl_bwd_fused(const float* z, const floa
                 }
             }
             if (ok) {
-                gz[r * h + c] = fmaf(cz, zz[u], cg * (-d / vv[u] + mixg));
-                gm[r * h + c] = cg * (d / vv[u]);
-                gv[r * h + c] = cg * (d * d / (2.f * vv[u] * vv[u]) - 0.5f / vv[u]);
+                const float gzk = fmaf(cz, zz[u], cg * (-d / vv[u] + mixg));
+                const float gmk = cg * (d / vv[u]);
+                const float gvk = cg * (d * d / (2.f * vv[u] * vv[u]) - 0.5f / vv[u]);
+                if (gh2) {     // fused reparameterisation backward (K3): the three node gradients never reach memory
+                    const float g = gzk + (gz_up ? gz_up[r * h + c] : 0.f);
+                    const float raw = h2[r * 2 * h + h + c];
+                    const float dv = g * eps[r * h + c] * 0.5f / sqrtf(vv[u]) + gvk;
+                    gh2[r * 2 * h + c] = g + gmk;
+                    gh2[r * 2 * h + h + c] = raw > 20.f ? dv : dv / (1.f + expf(-raw));
+                } else {
+                    gz[r * h + c] = gzk;
+                    gm[r * h + c] = gmk;
+                    gv[r * h + c] = gvk;
+                }
             }
         }
     }
@@ -730,6 +756,53 @@ extern "C" int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* 
     hipLaunchKernelGGL(k_kl_bwd_mix_final, dim3((2 * k * h + 15) / 16), dim3(1024), 0, GV_ST, part, z_pre, gkl,
                        gscale, g_zpre, accumulate_zpre, n, h, k, KL_SLICES, rows_dev);
     return launch_status("gv_kl_bwd");
+}
+
+// K3 fused into K6 (the reparameterisation and the KL term read the same node rows):
+//   fwd: (m, v, z) = reparameterise(h2, eps) AND the KL forward pass over them (resp, per-block partial sums) in one sweep;
+//   bwd: KL's node gradients, the regulariser's z_extra * z and the upstream dL/dz are chained through the reparameterisation
+//        in registers: gh2 is the only node-sized output (gz / gm / gv of gv_kl_bwd are never materialised).
+extern "C" int gv_reparam_kl_fwd(const float* h2, const float* eps, const float* z_pre, float* z, float* v, float* m_out,
+                                 float* resp, float* workspace, int64_t n, int h, int k, void* stream) {
+    GV_REQUIRE(h2 && eps && z_pre && z && v && resp && workspace, GV_ERR_NULL, "gv_reparam_kl_fwd: NULL pointer");
+    GV_REQUIRE(n > 0 && h > 0 && h <= 1024 && k > 0 && k <= KL_KMAX, GV_ERR_SHAPE, "gv_reparam_kl_fwd: n=%lld h=%d k=%d", (long long)n,
+               h, k);
+    const size_t lds = (size_t)2 * k * h * sizeof(float);
+    GV_REQUIRE(lds <= 64 * 1024, GV_ERR_SHAPE, "gv_reparam_kl_fwd: mixture table %zu B exceeds the 64 KiB LDS budget", lds);
+    float* mix = workspace;
+    float* part = workspace + 3 * (size_t)k * h;
+    hipLaunchKernelGGL(k_kl_mix, dim3((k * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, k, h, mix);
+    const int nb = kl_blocks(n);
+    const float* none = nullptr;
+    const int* no_rows = nullptr;
+#define GV_RKL_FWD(CPL_)                                                                                                       \
+    hipLaunchKernelGGL(k_kl_fwd<CPL_>, dim3(nb), dim3(256), lds, GV_ST, none, none, h, none, (const float*)mix, none, resp, part, n, h, \
+                       k, no_rows, h2, eps, z, v, m_out)
+    if (h <= 64) GV_RKL_FWD(1);
+    else if (h <= 128) GV_RKL_FWD(2);
+    else if (h <= 256) GV_RKL_FWD(4);
+    else if (h <= 512) GV_RKL_FWD(8);
+    else GV_RKL_FWD(16);
+#undef GV_RKL_FWD
+    return launch_status("gv_reparam_kl_fwd");
+}
+
+extern "C" int gv_reparam_kl_bwd(const float* z, const float* h2, const float* v, const float* eps, const float* z_pre,
+                                 const float* resp, const float* gkl, float gscale, float z_extra, const float* gz_up,
+                                 float* gh2, float* g_zpre, int accumulate_zpre, float* workspace, int64_t n, int h, int k,
+                                 void* stream) {
+    GV_REQUIRE(z && h2 && v && eps && z_pre && resp && gh2 && g_zpre && workspace, GV_ERR_NULL, "gv_reparam_kl_bwd: NULL pointer");
+    GV_REQUIRE(n > 0 && h > 0 && k > 0 && k <= KL_FUSED_KT, GV_ERR_SHAPE, "gv_reparam_kl_bwd: n=%lld h=%d k=%d (k <= %d)", (long long)n,
+               h, k, KL_FUSED_KT);
+    float* mix = workspace;                    // the table gv_reparam_kl_fwd left there for the same z_pre
+    float* part = workspace + 3 * (size_t)k * h + RED_BLOCKS;
+    float* none = nullptr;
+    const int* no_rows = nullptr;
+    hipLaunchKernelGGL(k_kl_bwd_fused<KL_FUSED_KT>, dim3((h + 63) / 64, KL_SLICES), dim3(256), 0, GV_ST, z, h2, 2 * h, v,
+                       (const float*)mix, resp, gkl, gscale, z_extra, none, none, none, part, n, h, k, no_rows, h2, eps, gz_up, gh2);
+    hipLaunchKernelGGL(k_kl_bwd_mix_final, dim3((2 * k * h + 15) / 16), dim3(1024), 0, GV_ST, (const float*)part, z_pre, gkl, gscale,
+                       g_zpre, accumulate_zpre, n, h, k, KL_SLICES, no_rows);
+    return launch_status("gv_reparam_kl_bwd");
 }
 
 __global__ void k_lincomb(const float* a0, float c0, const float* a1, float c1, const float* a2, float c2, const float* a3,

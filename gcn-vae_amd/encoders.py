@@ -66,6 +66,7 @@ class KGVAE(nn.Module):
         # so when the task head announces that MMD will be evaluated (LinkPredict sets this for mmd_param > 0) the
         # prior rows ride along in forward() as extra rows of the same GEMMs instead of ~150 tiny launches of their own.
         self.batch_mmd_prior_with_forward = False
+        self.fuse_kl_with_reparam = False # set by the task head when it will evaluate get_kl on forward()'s z (LinkPredict, kl_param > 0)
         self.grad_reducer = None          # distributed.BucketedArenaReduce: multi-GPU gradient exchange started under backward
         self._z_pri_flowed = None
         # multi-GPU destination-row partition (distributed.RowPartition): this rank computes its own row block only;
@@ -216,7 +217,10 @@ class KGVAE(nn.Module):
         if self.grad_reducer is not None:     # layer 2 onwards is final once dL/dh1 exists: its arena suffix reduces under layer 1's backward
             h = self.grad_reducer.milestone(h, next(self.rconv_layer_2.parameters()))
         h = self.rconv_layer_2(g, h, r, norm)
-        z, self.z_mean, self.z_sigma = ops.reparam(h, eps)
+        # no flow between z and the KL term: the KL forward pass rides on the reparameterisation's sweep over the rows, and
+        # its backward is chained through the reparameterisation's (ops.reparam); with flows the two stay separate
+        fuse_kl = self.training and self.n_flows == 0 and self.fuse_kl_with_reparam
+        z, self.z_mean, self.z_sigma = ops.reparam(h, eps, self.z_pre.squeeze(0) if fuse_kl else None)
         self._z_pri_flowed = None
         if self.n_flows > 0:
             z, log_det_sum = self._apply_flows(z)

@@ -75,6 +75,8 @@ SIGNATURES = {
     'gv_kl_workspace_bytes': (_L, [_L, _I, _I]),
     'gv_kl_fwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
     'gv_kl_bwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P, _I, _L, _I, _I, _P, _P]),
+    'gv_reparam_kl_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    'gv_reparam_kl_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P, _L, _I, _I, _P]),
     'gv_loss_combine': (_I, [_P, _L, _P, _L, _L, _P, _L, _I, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P]),
     'gv_lincomb4': (_I, [_P, _F, _P, _F, _P, _F, _P, _F, _P, _P]),
     'gv_mmd_fwd': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),

@@ -1675,11 +1675,31 @@ def masked_weight(mask, w):
     return _Mul.apply(mask, w)
 
 
+class KLLink:
+    """Hand-off between the reparameterisation node and the loss head when K3 and K6 are fused (gv_reparam_kl_fwd / _bwd):
+    the forward leaves the KL pass's responsibilities and workspace here for the loss head; the loss head's backward leaves
+    the upstream scalar and its two scales here and lets the reparameterisation's backward do KL's node gradients."""
+    __slots__ = ('resp', 'ws', 'z_pre_ptr', 'z_pre_version', 'gkl', 'gscale', 'z_extra')
+
+    def __init__(self, resp, ws, z_pre):
+        self.resp, self.ws = resp, ws
+        self.z_pre_ptr, self.z_pre_version = z_pre.data_ptr(), z_pre._version
+        self.gkl = None
+        self.gscale = self.z_extra = 0.0
+
+    def matches(self, z_pre):
+        return z_pre is not None and z_pre.data_ptr() == self.z_pre_ptr and z_pre._version == self.z_pre_version
+
+
+FUSE_REPARAM_KL = _os.environ.get('GV_FUSE_REPARAM_KL', '1') == '1'
+
+
 class _Reparam(torch.autograd.Function):
-    """(z, m, v) = reparameterise(h2, eps): m = h2[:, :h], v = softplus(h2[:, h:]) + 1e-8, z = m + eps*sqrt(v)."""
+    """(z, m, v) = reparameterise(h2, eps): m = h2[:, :h], v = softplus(h2[:, h:]) + 1e-8, z = m + eps*sqrt(v).
+    With ``z_pre`` (the mixture prior's parameters, (2k, h)) the KL forward pass over the same rows rides along."""
 
     @staticmethod
-    def forward(ctx, h2, eps):
+    def forward(ctx, h2, eps, z_pre, link_box):
         ctx.set_materialize_grads(False)
         h2 = _chk(h2.contiguous(), name='h2')
         n, h = h2.shape[0], h2.shape[1] // 2
@@ -1687,24 +1707,57 @@ class _Reparam(torch.autograd.Function):
         z = torch.empty(n, h, dtype=torch.float32, device=h2.device)
         v = torch.empty_like(z)
         m = torch.empty_like(z)
-        lib.call('gv_reparam_fwd', ptr(h2), ptr(eps), ptr(z), ptr(v), ptr(m), n, h, lib.stream())
-        ctx.save_for_backward(h2, eps, v)
+        ctx.link = None
+        if z_pre is not None:
+            z_pre = _chk(z_pre.contiguous(), name='z_pre')
+            k = z_pre.shape[0] // 2
+            ws = torch.empty(int(lib.load().gv_kl_workspace_bytes(n, h, k)) // 4, dtype=torch.float32, device=h2.device)
+            resp = torch.empty(n, k, dtype=torch.float32, device=h2.device)
+            lib.call('gv_reparam_kl_fwd', ptr(h2), ptr(eps), ptr(z_pre), ptr(z), ptr(v), ptr(m), ptr(resp), ptr(ws), n, h, k,
+                     lib.stream())
+            ctx.link = link_box[0] = KLLink(resp, ws, z_pre)
+            ctx.save_for_backward(h2, eps, v, z, z_pre)
+        else:
+            lib.call('gv_reparam_fwd', ptr(h2), ptr(eps), ptr(z), ptr(v), ptr(m), n, h, lib.stream())
+            ctx.save_for_backward(h2, eps, v)
         return z, m, v
 
     @staticmethod
     def backward(ctx, gz, gm, gv):
-        h2, eps, v = ctx.saved_tensors
+        link = ctx.link
+        if link is not None and link.gkl is not None:      # the loss head left KL's backward to this node
+            h2, eps, v, z, z_pre = ctx.saved_tensors
+            n, h = v.shape
+            if gm is not None or gv is not None:
+                raise RuntimeError('fused reparameterisation + KL backward: z_mean / z_sigma received a gradient of their own')
+            gz = None if gz is None else _chk(gz.contiguous(), name='gz')
+            d_zp = _direct_flat(z_pre)
+            gzp = d_zp if d_zp is not None else torch.empty_like(z_pre)
+            gh2 = torch.empty_like(h2)
+            lib.call('gv_reparam_kl_bwd', ptr(z), ptr(h2), ptr(v), ptr(eps), ptr(z_pre), ptr(link.resp), ptr(link.gkl),
+                     float(link.gscale), float(link.z_extra), ptr(gz), ptr(gh2), ptr(gzp), 1 if d_zp is not None else 0,
+                     ptr(link.ws), n, h, z_pre.shape[0] // 2, lib.stream())
+            link.gkl = None
+            return gh2, None, (None if d_zp is not None else gzp), None
+        h2, eps, v = ctx.saved_tensors[:3]
         n, h = v.shape
         gz = None if gz is None else _chk(gz.contiguous(), name='gz')
         gm = None if gm is None else _chk(gm.contiguous(), name='gm')
         gv = None if gv is None else _chk(gv.contiguous(), name='gv')
         gh2 = torch.empty_like(h2)
         lib.call('gv_reparam_bwd', ptr(h2), ptr(eps), ptr(v), ptr(gz), ptr(gm), ptr(gv), ptr(gh2), n, h, lib.stream())
-        return gh2, None
+        return gh2, None, None, None
 
 
-def reparam(h2, eps):
-    return _Reparam.apply(h2, eps)
+def reparam(h2, eps, z_pre=None):
+    """``z_pre``: when the caller knows that the loss head will evaluate KL(z) against this mixture with no flow in between,
+    the KL forward pass is done in the same sweep; the returned z then carries the hand-off (``z._gv_kl_link``)."""
+    if z_pre is None or not FUSE_REPARAM_KL:
+        return _Reparam.apply(h2, eps, None, None)
+    box = [None]
+    z, m, v = _Reparam.apply(h2, eps, z_pre, box)
+    z._gv_kl_link = box[0]
+    return z, m, v
 
 
 class _DistMultBCE(torch.autograd.Function):
@@ -2013,7 +2066,7 @@ class _LossHead(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, reg_w, kl_w, mmd_w, score_bias,
-                embed_rows=None, rows_dev=None):
+                embed_rows=None, rows_dev=None, kl_link=None):
         z, ld_z = _row_major(z, 'embed')
         if rows_dev is not None:          # static-shape batch: rows [*rows_dev, n) of z are padding (include/gcnvae.h, rows_dev)
             rows_dev = _chk(rows_dev.reshape(-1), torch.int32, 'rows_dev')
@@ -2033,12 +2086,15 @@ class _LossHead(torch.autograd.Function):
         loss = torch.empty((), **f32)
         bias = flp if (score_bias and flp is not None) else None
         resp = wsk = z_post = wsm = None
+        link = kl_link if (kl_link is not None and kl_w > 0 and flp is None and rows_dev is None and embed_rows is None
+                           and kl_link.matches(z_pre) and kl_link.resp.shape[0] == n) else None
         if kl_w > 0:
             z_mean, z_sigma = _chk(z_mean.contiguous(), name='z_mean'), _chk(z_sigma.contiguous(), name='z_sigma')
             z_pre = _chk(z_pre.contiguous(), name='z_pre')
             k = z_pre.shape[0] // 2
-            wsk = torch.empty(int(lib.load().gv_kl_workspace_bytes(n, h, k)) // 4, **f32)
-            resp = torch.empty(n, k, **f32)
+            if link is None:
+                wsk = torch.empty(int(lib.load().gv_kl_workspace_bytes(n, h, k)) // 4, **f32)
+                resp = torch.empty(n, k, **f32)
         if mmd_w > 0:
             z_pri = _chk(z_pri.contiguous(), name='z_pri')
             pick = _chk(pick.reshape(-1), torch.int64, 'pick')
@@ -2047,7 +2103,9 @@ class _LossHead(torch.autograd.Function):
             raise ValueError('loss_head needs contiguous embeddings and relation table')
         st = lib.stream()
         # every term leaves its per-block partial sums in its workspace; ONE combine launch finishes the four sums
-        if kl_w > 0:
+        if link is not None:
+            resp, wsk = link.resp, link.ws                 # the KL pass already ran with the reparameterisation
+        elif kl_w > 0:
             lib.call('gv_kl_fwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(flp), ptr(resp), None, ptr(wsk),
                      n, h, k, ptr(rows_dev), st)
         if mmd_w > 0:      # the posterior sample set is rows `pick` of z, read in place
@@ -2069,6 +2127,7 @@ class _LossHead(torch.autograd.Function):
                               pick if mmd_w > 0 else None, labels, score, wsk, rows_dev)
         ctx.meta = (tidx, float(reg_w), float(kl_w), float(mmd_w), bias is not None, flp is not None and kl_w > 0)
         ctx.z_count = z_count
+        ctx.kl_link = link
         ctx.direct_w = _direct(w_rel) if ld_w == h else None
         out_pred, out_kl, out_mmd = pred.reshape(()), kl.reshape(1), mmd.reshape(())
         ctx.mark_non_differentiable(out_pred, out_kl, out_mmd)
@@ -2077,7 +2136,7 @@ class _LossHead(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gp, _gk, _gm):
         if g is None:
-            return (None,) * 16
+            return (None,) * 17
         z, z_mean, z_sigma, w_rel, z_pre, resp, z_pri, z_post, pick, labels, score, wsk, rows_dev = ctx.saved_tensors
         z_count = ctx.z_count
         tidx, reg_w, kl_w, mmd_w, has_bias, flp_in_kl = ctx.meta
@@ -2088,9 +2147,15 @@ class _LossHead(torch.autograd.Function):
         dscore = torch.empty(T, **f32)
         dbias = torch.zeros((), **f32) if has_bias else None
         ws = torch.empty(1024, **f32)
-        gz = torch.empty_like(z)
+        link = ctx.kl_link
+        gz = torch.empty_like(z) if link is None else None
         gm = gv = gzp = d_zp = g_pri = g_post = None
-        if kl_w > 0:
+        if link is not None:
+            # KL's node gradients and the regulariser's are chained through the reparameterisation by ITS backward
+            # (gv_reparam_kl_bwd): here only the scalar and the two scales are handed over
+            link.gkl, link.gscale, link.z_extra = g, kl_w, 2.0 * reg_w / z_count
+            d_zp = True          # z_pre's gradient is produced there too
+        elif kl_w > 0:
             k = z_pre.shape[0] // 2                       # wsk: the forward's workspace, mixture table still valid
             d_zp = _direct_flat(z_pre)
             gm, gv = torch.empty_like(z), torch.empty_like(z)
@@ -2104,14 +2169,16 @@ class _LossHead(torch.autograd.Function):
         # branch 1: KL backward (writes gz, gm, gv, gzp), then the regulariser folded into gz
         with fork(1):
             s1 = lib.stream()
-            if kl_w > 0:
+            if link is not None:
+                pass
+            elif kl_w > 0:
                 # the embedding regulariser's gradient g * (2 reg_w / numel) * z rides on the same pass over z
                 lib.call('gv_kl_bwd', ptr(z), ptr(z_mean), h, ptr(z_sigma), ptr(z_pre), ptr(resp), ptr(g), kl_w,
                          2.0 * reg_w / z_count, ptr(gz), ptr(gm), ptr(gv), ptr(gzp), 1 if d_zp is not None else 0, ptr(wsk),
                          1, n, h, k, ptr(rows_dev), s1)
             else:
                 lib.call('gv_axpby', z.numel(), ptr(g), 2.0 * reg_w / z_count, ptr(z), 0.0, ptr(gz), s1)
-            if mmd_w > 0:      # MMD backward: prior rows -> g_pri, posterior rows ADDED into rows `pick` of gz (now complete)
+            if mmd_w > 0 and link is None:      # MMD backward: prior rows -> g_pri, posterior rows ADDED into rows `pick` of gz (now complete)
                 lib.call('gv_mmd_bwd', ptr(z_pri), ptr(z), ptr(pick), z_pri.shape[0], pick.numel(), h, ptr(g), mmd_w,
                          ptr(g_pri), ptr(gz), s1)
         # main: dL/dscore, then the relation-side gradient (does not need gz)
@@ -2128,17 +2195,20 @@ class _LossHead(torch.autograd.Function):
         join(1)
         g_z = bdd_aggregate(tidx.inc, tidx.inc_other, tidx.inc_rel, d_inc, idx_inc, z, w_rel, h, 1, 1,
                             addend=gz)
+        if link is not None and mmd_w > 0:       # no KL buffer to ride on: the MMD rows are added to the decoder's gradient
+            lib.call('gv_mmd_bwd', ptr(z_pri), ptr(z), ptr(pick), z_pri.shape[0], pick.numel(), h, ptr(g), mmd_w,
+                     ptr(g_pri), ptr(g_z), st)
         if g_flp is not None:
             lib.call('gv_lincomb4', ptr(dbias) if has_bias else None, 1.0, ptr(g) if flp_in_kl else None, kl_w, None, 0.0,
                      None, 0.0, ptr(g_flp), st)
         return (g_z, gm, gv, (None if d_w is not None else g_w), (None if d_zp is not None else gzp), g_flp, g_pri, None,
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 def loss_head(z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, reg_w, kl_w, mmd_w, score_bias,
               embed_rows=None, rows_dev=None):
     return _LossHead.apply(z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, float(reg_w), float(kl_w),
-                           float(mmd_w), bool(score_bias), embed_rows, rows_dev)
+                           float(mmd_w), bool(score_bias), embed_rows, rows_dev, getattr(z, '_gv_kl_link', None))
 
 
 class _MADEForward(torch.autograd.Function):

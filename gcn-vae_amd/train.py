@@ -34,6 +34,8 @@ class LinkPredict(nn.Module):
                                    num_bases=num_bases, num_hidden_layers=num_hidden_layers, dropout=dropout,
                                    use_self_loop=use_cuda, use_cuda=use_cuda, k=k, n_flows=n_flows)
         self.reg_param, self.kl_param, self.mmd_param = reg_param, kl_param, mmd_param
+        if kl_param > 0 and hasattr(self.encoder, 'fuse_kl_with_reparam'):
+            self.encoder.fuse_kl_with_reparam = True             # get_loss will ask for KL(z): its forward pass rides on the reparameterisation
         if mmd_param > 0 and hasattr(self.encoder, 'batch_mmd_prior_with_forward'):
             self.encoder.batch_mmd_prior_with_forward = True     # get_loss will ask for MMD: batch its flow passes
         self.w_relation = nn.Parameter(torch.Tensor(num_rels, h_dim))

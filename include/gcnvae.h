@@ -294,6 +294,17 @@ int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* v, const fl
               const float* gkl, float gscale, float z_extra, float* gz, float* gm, float* gv, float* g_zpre,
               int accumulate_zpre, float* workspace, int mix_ready, int64_t n, int h, int k, const int32_t* rows_dev,
               void* stream);
+/* K3 + K6 in one sweep over the node rows (they read the same rows; kgvae/model.py:112-113 then :81-87):
+ *   gv_reparam_kl_fwd = gv_reparam_fwd (z, v, m_out written) + gv_kl_fwd with kl == NULL (resp, partial sums and the mixture table
+ *                       left in `workspace`, gv_kl_workspace_bytes; finish with gv_loss_combine);
+ *   gv_reparam_kl_bwd = gv_kl_bwd + gv_reparam_bwd without their intermediate gz / gm / gv: gz_up (optional) is the gradient z
+ *                       receives from everything else, gh2 [n, 2h] the result; g_zpre / accumulate_zpre / gscale / z_extra as in
+ *                       gv_kl_bwd; `workspace` must be the one gv_reparam_kl_fwd (or gv_kl_fwd) filled for the same z_pre; k <= 16. */
+int gv_reparam_kl_fwd(const float* h2, const float* eps, const float* z_pre, float* z, float* v, float* m_out, float* resp,
+                      float* workspace, int64_t n, int h, int k, void* stream);
+int gv_reparam_kl_bwd(const float* z, const float* h2, const float* v, const float* eps, const float* z_pre, const float* resp,
+                      const float* gkl, float gscale, float z_extra, const float* gz_up, float* gh2, float* g_zpre,
+                      int accumulate_zpre, float* workspace, int64_t n, int h, int k, void* stream);
 /* upstream gradient = gscale * (*gkl); gz additionally receives (*gkl) * z_extra * z (the embedding regulariser's
  * gradient, kgvae/link_predict.py:68-69, folded into the same pass); accumulate_zpre adds into g_zpre; mix_ready = 1 when `workspace` is the one
  * gv_kl_fwd filled for the same z_pre (skips recomputing the mixture table).  With rows_dev: padding rows get zero gz / gm / gv

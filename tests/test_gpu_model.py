@@ -630,3 +630,38 @@ def test_graphed_minibatch_step_equals_eager_steps():
     for (kk, pe), (_, pg) in zip(net_e.named_parameters(), net_g.named_parameters()):
         torch.testing.assert_close(pg, pe, rtol=2e-2, atol=2e-3, msg=lambda s, kk=kk: f'{kk}: {s}')
     assert losses_g[0] != losses_g[1] != losses_g[2]                       # every replay draws a fresh batch
+
+
+def test_fused_reparam_kl_equals_the_separate_nodes(monkeypatch):
+    """ops.reparam(h2, eps, z_pre) + loss_head (K3 fused into K6: gv_reparam_kl_fwd / gv_reparam_kl_bwd) against the separate
+    reparameterisation and KL passes on the same inputs: loss terms and every gradient, incl. dL/dh2 and the mixture's."""
+    from gcn_vae_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    n, h, k, T, R = 900, 72, 10, 4000, 7
+    h2 = torch.randn(n, 2 * h, generator=gen)
+    h2[0, h:h + 4] = torch.tensor([25.0, -30.0, 19.99, 20.01])           # softplus threshold on both sides
+    eps = torch.randn(n, h, generator=gen)
+    w_rel, z_pre = torch.randn(R, h, generator=gen) * 0.3, torch.randn(2 * k, h, generator=gen) * 0.5
+    z_pri = torch.randn(200, h, generator=gen)
+    pick = torch.randperm(n, generator=gen)[:200].cuda()
+    trip = torch.stack([torch.randint(0, n, (T,), generator=gen), torch.randint(0, R, (T,), generator=gen),
+                        torch.randint(0, n, (T,), generator=gen)], 1).cuda()
+    labels = (torch.rand(T, generator=gen) > 0.5).float().cuda()
+
+    def run(fused):
+        monkeypatch.setattr(ops, 'FUSE_REPARAM_KL', fused)
+        ins = [t.clone().cuda().requires_grad_(True) for t in (h2, w_rel, z_pre, z_pri)]
+        z, m, v = ops.reparam(ins[0], eps.cuda(), ins[2])
+        assert (getattr(z, '_gv_kl_link', None) is not None) == fused
+        tidx = ops.TripletIndex(trip, n, R, sync_free=True)
+        out = ops.loss_head(z, m, v, ins[1], ins[2], None, ins[3], pick, labels, tidx, 0.01, 1e-2, 1.0, False)
+        out[0].backward()
+        return [o.detach().cpu() for o in out], [t.grad.cpu() for t in ins], (z.detach().cpu(), m.detach().cpu(), v.detach().cpu())
+    oa, ga, za = run(False)
+    ob, gb, zb = run(True)
+    for x, y in zip(za, zb):
+        assert torch.equal(x, y)                                       # same arithmetic, same bits
+    for x, y, nm in zip(oa, ob, ('loss', 'pred', 'kl', 'mmd')):
+        torch.testing.assert_close(y.reshape(-1), x.reshape(-1), rtol=1e-6, atol=1e-7, msg=lambda s, nm=nm: f'{nm}: {s}')
+    for x, y, nm in zip(ga, gb, ('h2', 'w_rel', 'z_pre', 'z_pri')):
+        torch.testing.assert_close(y, x, rtol=1e-5, atol=1e-8, msg=lambda s, nm=nm: f'grad {nm}: {s}')
