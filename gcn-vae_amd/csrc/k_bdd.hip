@@ -142,6 +142,116 @@ __global__ __launch_bounds__(256) void k_agg_fast(const AggParams a) {
     store_vec<PV>(a.out + (size_t)it.x * a.ld_out + col0, acc);
 }
 
+// ---- few, large diagonal blocks (BASELINE configs[2]: B = 20 blocks of 10x10 / 10x20) -------------------------------------
+// One block per lane would leave 44 of 64 lanes idle and put 100-200 weights into a lane's registers.  Here LPB lanes share a
+// block: lane l owns QS = Q_out / LPB consecutive OUTPUT columns of block l / LPB, gathers that block's whole input slice (the
+// LPB lanes of a block read the same addresses -- one L1 access) and its P_in x QS weight sub-matrix.  P_in / Q_out are the
+// gathered / produced block widths (for the transposed product the stored block is Q_out... see the weight index below).
+template <int PI, int QO, bool TRANS, int QS, int U>
+__global__ __launch_bounds__(256) void k_agg_split(const AggParams a) {
+    constexpr int LPB = QO / QS;
+    static_assert(QO % QS == 0, "the output columns of a block are dealt evenly to its lanes");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (wave >= a.n_items) return;
+    const int4 it = a.items[wave];
+    if (it.x < 0) return;
+    if (it.w >= 0 && !a.partial) return;
+    const bool active = lane < a.nbp * LPB;                       // a.nbp blocks per column part
+    const int blk = blockIdx.y * a.nbp + lane / LPB, sub = lane % LPB;
+    const float* __restrict__ fbase = a.feat + blk * PI;
+    // stored block: (blk_in x blk_out) row-major = PI x QO for the plain product, QO x PI (read transposed) for TRANS
+    const float* __restrict__ wbase = a.w + blk * (PI * QO);
+
+    float acc[QS];
+#pragma unroll
+    for (int i = 0; i < QS; ++i) acc[i] = 0.f;
+
+    auto one_edge = [&](const float (&xv)[PI], const float (&wv)[PI * QS], float c) {
+#pragma unroll
+        for (int q = 0; q < QS; ++q) {
+            float t = 0.f;
+#pragma unroll
+            for (int p = 0; p < PI; ++p) t = fmaf(xv[p], wv[TRANS ? q * PI + p : p * QS + q], t);
+            acc[q] = fmaf(t, c, acc[q]);
+        }
+    };
+    auto load_w = [&](int r, float (&wv)[PI * QS]) {
+        const float* wr = wbase + (size_t)r * a.w_row;
+        if constexpr (TRANS) {       // rows sub*QS .. sub*QS+QS-1 of the stored QO x PI block: QS*PI contiguous floats
+            load_vec<PI * QS>(wr + sub * QS * PI, wv);
+        } else {                     // columns sub*QS .. of every row of the stored PI x QO block: PI pieces of QS floats
+#pragma unroll
+            for (int p = 0; p < PI; ++p) {
+                float t[QS];
+                load_vec<QS>(wr + p * QO + sub * QS, t);
+#pragma unroll
+                for (int q = 0; q < QS; ++q) wv[p * QS + q] = t[q];
+            }
+        }
+    };
+
+    for (int e0 = it.y; e0 < it.z; e0 += 64) {
+        const int cnt = min(64, it.z - e0);
+        int my_n = 0, my_t = 0;
+        float my_c = 1.f;
+        if (lane < cnt) {
+            my_n = a.nbr[e0 + lane];
+            my_t = a.etype[e0 + lane];
+            if (a.coef) my_c = a.coef_idx ? a.coef[a.coef_idx[e0 + lane]] : a.coef[e0 + lane];
+        }
+        int j = 0;
+        for (; j + U <= cnt; j += U) {
+            float xv[U][PI], wv[U][PI * QS], cc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s = rl_i(my_n, j + u);
+                const int r = rl_i(my_t, j + u);
+                cc[u] = rl_f(my_c, j + u);
+                if (active) {
+                    load_vec<PI>(fbase + (size_t)s * a.ld_feat, xv[u]);
+                    load_w(r, wv[u]);
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) one_edge(xv[u], wv[u], cc[u]);
+            }
+        }
+        for (; j < cnt; ++j) {
+            float xv[PI], wv[PI * QS];
+            const int s = rl_i(my_n, j);
+            const int r = rl_i(my_t, j);
+            const float c = rl_f(my_c, j);
+            if (active) {
+                load_vec<PI>(fbase + (size_t)s * a.ld_feat, xv);
+                load_w(r, wv);
+                one_edge(xv, wv, c);
+            }
+        }
+    }
+    if (!active) return;
+    const int col0 = blk * QO + sub * QS;
+    if (it.w >= 0) {
+        store_vec<QS>(a.partial + (size_t)it.w * a.out_dim + col0, acc);
+        return;
+    }
+    if (a.addend) {
+        float ad[QS];
+        load_vec<QS>(a.addend + (size_t)it.x * a.ld_add + col0, ad);
+#pragma unroll
+        for (int i = 0; i < QS; ++i) acc[i] += ad[i];
+    }
+#pragma unroll
+    for (int i = 0; i < QS; ++i) acc[i] = apply_act(acc[i], a.act);
+    if (a.keep) {
+        const uint8_t* kp = a.keep + (size_t)it.x * a.out_dim + col0;
+#pragma unroll
+        for (int i = 0; i < QS; ++i) acc[i] = kp[i] ? acc[i] * a.keep_scale : 0.f;
+    }
+    store_vec<QS>(a.out + (size_t)it.x * a.ld_out + col0, acc);
+}
+
 // ---- lane-packed weight variant -------------------------------------------------------------------
 // The per-edge relation-weight read dominates K1's cache traffic.  With the row layout a lane's weights
 // are BPL*P*Q contiguous floats, so one 16-B load instruction touches ~25 cache lines at 25-50 % use.
@@ -469,6 +579,93 @@ __global__ __launch_bounds__(256) void k_gradw_fast(const GradWParams a) {
     }
 }
 
+// grad-W for few, large blocks: lane l owns QS consecutive COLUMNS of block l / LPB of the P x Q stored block -- P x QS
+// outer-product sums in registers (instead of P x Q), x's block slice shared by the LPB lanes of a block
+template <int P, int Q, int QS, int U>
+__global__ __launch_bounds__(256) void k_gradw_split(const GradWParams a) {
+    constexpr int LPB = Q / QS;
+    static_assert(Q % QS == 0, "the columns of a block are dealt evenly to its lanes");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (wave >= a.n_items) return;
+    const int4 it = a.items[wave];
+    if (it.x < 0) return;
+    if (it.w >= 0 && !a.partial) return;
+    const bool active = lane < a.nbp * LPB;
+    const int blk = blockIdx.y * a.nbp + lane / LPB, sub = lane % LPB;
+    const float* __restrict__ xbase = a.x + blk * P;
+    const float* __restrict__ gbase = a.g + blk * Q + sub * QS;
+    float acc[P * QS];
+#pragma unroll
+    for (int i = 0; i < P * QS; ++i) acc[i] = 0.f;
+    for (int e0 = it.y; e0 < it.z; e0 += 64) {
+        const int cnt = min(64, it.z - e0);
+        int my_s = 0, my_d = 0;
+        float my_c = 1.f;
+        if (lane < cnt) {
+            my_s = a.src[e0 + lane];
+            my_d = a.dst[e0 + lane];
+            if (a.coef) my_c = a.coef_idx ? a.coef[a.coef_idx[e0 + lane]] : a.coef[e0 + lane];
+        }
+        int j = 0;
+        for (; j + U <= cnt; j += U) {
+            float xv[U][P], gvv[U][QS], cc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int sidx = rl_i(my_s, j + u);
+                const int d = rl_i(my_d, j + u);
+                cc[u] = rl_f(my_c, j + u);
+                if (active) {
+                    load_vec<P>(xbase + (size_t)sidx * a.ld_x, xv[u]);
+                    load_vec<QS>(gbase + (size_t)d * a.ld_g, gvv[u]);
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const float xc = xv[u][p] * cc[u];
+#pragma unroll
+                        for (int q = 0; q < QS; ++q) acc[p * QS + q] = fmaf(xc, gvv[u][q], acc[p * QS + q]);
+                    }
+            }
+        }
+        for (; j < cnt; ++j) {
+            float xv[P], gvv[QS];
+            const int sidx = rl_i(my_s, j);
+            const int d = rl_i(my_d, j);
+            const float c = rl_f(my_c, j);
+            if (active) {
+                load_vec<P>(xbase + (size_t)sidx * a.ld_x, xv);
+                load_vec<QS>(gbase + (size_t)d * a.ld_g, gvv);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const float xc = xv[p] * c;
+#pragma unroll
+                    for (int q = 0; q < QS; ++q) acc[p * QS + q] = fmaf(xc, gvv[q], acc[p * QS + q]);
+                }
+            }
+        }
+    }
+    if (!active) return;
+    float* o = (it.w >= 0 ? a.partial + (size_t)it.w * a.w_row : a.grad_w + (size_t)it.x * a.w_row) + blk * (P * Q) + sub * QS;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        float t[QS];
+#pragma unroll
+        for (int q = 0; q < QS; ++q) t[q] = acc[p * QS + q];
+        if (it.w < 0 && a.accumulate) {
+            float old[QS];
+            load_vec<QS>(o + p * Q, old);
+#pragma unroll
+            for (int q = 0; q < QS; ++q) t[q] += old[q];
+        }
+        store_vec<QS>(o + p * Q, t);
+    }
+}
+
+
 __global__ __launch_bounds__(256) void k_gradw_generic(const GradWParams a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
@@ -741,10 +938,20 @@ extern "C" int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const in
         GV_PK_CASE(8, 4, true, 1, 0, 2) GV_PK_CASE(8, 4, true, 2, 0, 2)
 #undef GV_PK_CASE
     }
+    // few, large blocks (B <= 32 of width >= 10): output columns of a block split over lanes (k_agg_split)
+#define GV_SPLIT_CASE(PI_, QO_, T_, QS_, U_, PARTS_)                                                                       \
+    if (rc == -1000 && vec_ok && blk_in == PI_ && blk_out == QO_ && (transpose_w != 0) == T_ && num_bases % PARTS_ == 0 &&  \
+        (num_bases / PARTS_) * (QO_ / QS_) <= 64 && num_bases <= 32) {                                                      \
+        a.nbp = num_bases / PARTS_;                                                                                         \
+        rc = launch_items(k_agg_split<PI_, QO_, T_, QS_, U_>, a, n_items, st, "gv_rgcn_bdd_aggregate(split)", PARTS_);      \
+    }
+    GV_SPLIT_CASE(10, 10, false, 5, 2, 1) GV_SPLIT_CASE(10, 10, true, 5, 2, 1)
+    GV_SPLIT_CASE(10, 20, false, 4, 2, 2) GV_SPLIT_CASE(20, 10, true, 2, 2, 2)
+#undef GV_SPLIT_CASE
     LanePlan lp{0, 1};
     const bool has_plan = lane_plan(num_bases, blk_in, &lp, true);
     const int bpl = has_plan ? lp.bpl : 0;
-    a.nbp = has_plan ? num_bases / lp.parts : num_bases;
+    if (rc == -1000) a.nbp = has_plan ? num_bases / lp.parts : num_bases;
 #define GV_AGG_CASE(P_, Q_, T_, B_, U_)                                                               \
     if (rc == -1000 && vec_ok && blk_in == P_ && blk_out == Q_ && (transpose_w != 0) == T_ && bpl == B_) \
         rc = launch_items(k_agg_fast<P_, Q_, T_, B_, U_>, a, n_items, st, "gv_rgcn_bdd_aggregate", lp.parts);
@@ -830,10 +1037,18 @@ extern "C" int gv_rgcn_bdd_grad_weight(const int32_t* items, int n_items, const 
     const bool vec_ok = aligned16(x) && aligned16(g) && aligned16(grad_w) && (ld_x % 4 == 0) && (ld_g % 4 == 0) &&
                         (!partial || aligned16(partial)) && (a.w_row % 4 == 0);
     int rc = -1000;
+#define GV_GW_SPLIT(P_, Q_, QS_, U_, PARTS_)                                                                              \
+    if (rc == -1000 && vec_ok && blk_in == P_ && blk_out == Q_ && num_bases % PARTS_ == 0 && num_bases <= 32 &&          \
+        (num_bases / PARTS_) * (Q_ / QS_) <= 64) {                                                                        \
+        a.nbp = num_bases / PARTS_;                                                                                       \
+        rc = launch_items(k_gradw_split<P_, Q_, QS_, U_>, a, n_items, st, "gv_rgcn_bdd_grad_weight(split)", PARTS_);      \
+    }
+    GV_GW_SPLIT(10, 10, 5, 2, 1) GV_GW_SPLIT(10, 20, 4, 2, 2)
+#undef GV_GW_SPLIT
     LanePlan lp{0, 1};
     const bool has_plan = lane_plan(num_bases, blk_in, &lp);
     const int bpl = has_plan ? lp.bpl : 0;
-    a.nbp = has_plan ? num_bases / lp.parts : num_bases;
+    if (rc == -1000) a.nbp = has_plan ? num_bases / lp.parts : num_bases;
 #define GV_GW_CASE(P_, Q_, B_, U_)                                                  \
     if (rc == -1000 && vec_ok && blk_in == P_ && blk_out == Q_ && bpl == B_)        \
         rc = launch_items(k_gradw_fast<P_, Q_, B_, U_>, a, n_items, st, "gv_rgcn_bdd_grad_weight", lp.parts);

@@ -178,7 +178,8 @@ CASES = [  # (in, out, num_bases)  -> block sizes; covers the fast instantiation
     (16, 16, 4), (16, 32, 4),           # C1               (4x4, 4x8)
     (40, 40, 40), (40, 80, 40),         # 1x1, 1x2
     (30, 30, 6), (30, 60, 6),           # 5x5, 5x10 -> generic
-    (200, 200, 20),                     # C3 10x10 -> generic
+    (200, 200, 20), (200, 400, 20),     # C3 (configs[2]): 10x10, 10x20 -> column-split kernels (k_agg_split / k_gradw_split)
+    (100, 200, 10), (60, 60, 6),        # the same blocks with fewer of them (partly filled waves)
     (24, 12, 3),                        # 8x4 -> generic (non-transposed), bwd-x 4x8
     (500, 500, 100), (500, 1000, 100),  # C4 / the reference's default --n-hidden 500: 5x5, 5x10, two column parts
 ]
