@@ -27,6 +27,20 @@ DIRECT_GRAD = {}
 # zero_grad() / step(); the first backward kernel that writes one removes it.  Only a buffer listed here may be
 # OVERWRITTEN by a backward kernel (the identity-embedding path below); anything else is accumulated into.
 GRAD_FRESH = set()
+# Bumped whenever the registry changes (an optimiser is built or dropped).  A Function that resolved a direct target in its
+# forward stamps the value on its ctx; its backward refuses to run if the registry changed in between (it would add into an
+# arena that is no longer the parameters' -- INTEGRATION.md, "The optimiser contract").
+DIRECT_EPOCH = [0]
+
+
+def _stamp_direct(ctx):
+    ctx._gv_direct_epoch = DIRECT_EPOCH[0]
+
+
+def _verify_direct(ctx):
+    if getattr(ctx, '_gv_direct_epoch', DIRECT_EPOCH[0]) != DIRECT_EPOCH[0]:
+        raise RuntimeError('the optimiser gradient arena (ops.DIRECT_GRAD) changed between this forward and its backward: '
+                           'build / drop FlatAdam outside a forward-backward pair')
 
 
 def _direct(t):
@@ -1023,12 +1037,14 @@ class _Embedding(torch.autograd.Function):
         ctx.save_for_backward(ids)
         ctx.shape = tuple(table.shape)
         ctx.direct = _direct(table)
+        _stamp_direct(ctx)
         return out
 
     @staticmethod
     def backward(ctx, g):
         (ids,) = ctx.saved_tensors
         g = _chk(g.contiguous(), name='grad')
+        _verify_direct(ctx)
         tgt = ctx.direct
         gt = tgt if tgt is not None else torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
         lib.call('gv_scatter_add_rows', ptr(g), ptr(ids), ptr(gt), ids.numel(), ctx.shape[1], lib.stream())
@@ -1048,6 +1064,7 @@ class _EmbeddingIdentity(torch.autograd.Function):
         if tick_rng is not None:
             tick_rng.tick()
         ctx.direct = _direct(table)
+        _stamp_direct(ctx)
         return table.detach().view(table.shape)
 
     @staticmethod
@@ -1055,6 +1072,7 @@ class _EmbeddingIdentity(torch.autograd.Function):
         if g is None:                  # the layer already wrote the rows into the gradient arena
             return None, None
         g = _chk(g.contiguous(), name='grad')
+        _verify_direct(ctx)
         tgt = ctx.direct
         if tgt is None:
             return g, None
@@ -1171,6 +1189,7 @@ class _RelGraphConvBdd(torch.autograd.Function):
         ctx.meta = (gidx, ridx, num_bases, si, so, act, keep_scale, h_bias is not None, reduce_hook)
         ctx.w_version = weight._version
         ctx.direct = (_direct(weight), _direct(h_bias), _direct(loop_weight))
+        _stamp_direct(ctx)
         # x is the embedding table itself (identity lookup) and this layer is its only consumer: dL/dx rows go straight
         # into the table's gradient (zero at this point of the step: the optimiser cleared it, nothing else adds to it)
         tgt = getattr(x, '_gv_grad_target', None)
@@ -1181,6 +1200,7 @@ class _RelGraphConvBdd(torch.autograd.Function):
     def backward(ctx, grad_out):
         x, weight, loop_weight, coef, out, keep = ctx.saved_tensors
         gidx, ridx, nb, si, so, act, keep_scale, has_bias, reduce_hook = ctx.meta
+        _verify_direct(ctx)
         d_w, d_b, d_l = ctx.direct
         grad_bias = None
         if has_bias and ctx.needs_input_grad[2]:         # bias gradient = column sums of g, from the same pass
@@ -1314,12 +1334,14 @@ class _RelGraphConvDense(torch.autograd.Function):
         ctx.save_for_backward(x, w3, loop_weight, coef, out if act == ACT_RELU else None, keep)
         ctx.meta = (gidx, ridx, act, keep_scale, h_bias is not None)
         ctx.direct = (_direct(h_bias), _direct(loop_weight))
+        _stamp_direct(ctx)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         x, w3, loop_weight, coef, out, keep = ctx.saved_tensors
         gidx, ridx, act, keep_scale, has_bias = ctx.meta
+        _verify_direct(ctx)
         d_b, d_l = ctx.direct
         r, fin, fout = w3.shape
         tiles, n_tiles, pos_d, pos_s, zeros = ridx.dense_plan(gidx)
@@ -1384,12 +1406,14 @@ class _RelGraphConvSelect(torch.autograd.Function):
         ctx.save_for_backward(coef, out if act == ACT_RELU else None, keep)
         ctx.meta = (plan, act, keep_scale, h_bias is not None, loop_rows is not None, tuple(wflat.shape))
         ctx.direct_b = _direct(h_bias)
+        _stamp_direct(ctx)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         coef, out, keep = ctx.saved_tensors
         plan, act, keep_scale, has_bias, has_loop, wshape = ctx.meta
+        _verify_direct(ctx)
         d_b = ctx.direct_b
         grad_bias = None
         if has_bias and ctx.needs_input_grad[2]:
@@ -1509,6 +1533,7 @@ class _RelGraphConvRows(torch.autograd.Function):
         ctx.meta = (gidx, ridx, num_bases, si, so, act, keep_scale, h_bias is not None, part, gather_input)
         ctx.w_version = weight._version
         ctx.direct = (_direct(weight), _direct(h_bias), _direct(loop_weight))
+        _stamp_direct(ctx)
         return buf
 
     @staticmethod
@@ -1516,6 +1541,7 @@ class _RelGraphConvRows(torch.autograd.Function):
         x_full, weight, loop_weight, coef, out, keep = ctx.saved_tensors
         gidx, ridx, nb, si, so, act, keep_scale, has_bias, part, gather_input = ctx.meta
         c, slot, row0, total = part.own_rows, part.slot_rows, part.row0, part.total_rows
+        _verify_direct(ctx)
         d_w, d_b, d_l = ctx.direct
         dev, in_feat = x_full.device, x_full.shape[1]
         grad_out = grad_out[:c]
@@ -2129,6 +2155,7 @@ class _LossHead(torch.autograd.Function):
         ctx.z_count = z_count
         ctx.kl_link = link
         ctx.direct_w = _direct(w_rel) if ld_w == h else None
+        _stamp_direct(ctx)
         out_pred, out_kl, out_mmd = pred.reshape(()), kl.reshape(1), mmd.reshape(())
         ctx.mark_non_differentiable(out_pred, out_kl, out_mmd)
         return loss, out_pred, out_kl, out_mmd
@@ -2162,6 +2189,7 @@ class _LossHead(torch.autograd.Function):
             gzp = d_zp if d_zp is not None else torch.empty_like(z_pre)
         if mmd_w > 0:
             g_pri = torch.empty_like(z_pri)
+        _verify_direct(ctx)
         d_w = ctx.direct_w
         g_w = d_w if d_w is not None else torch.empty_like(w_rel)
         g_flp = torch.empty((), **f32) if (has_bias or flp_in_kl) else None

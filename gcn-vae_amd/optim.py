@@ -39,6 +39,7 @@ class FlatAdam:
         self._ws = torch.empty(1024, dtype=torch.float32, device=dev)
         self._direct_keys = []
         self._clean = False
+        ops.DIRECT_EPOCH[0] += 1
         self.offsets = {p: o for p, o in zip(self.params, offs)}     # parameter -> first float of its arena slice
         for p, o in zip(self.params, offs):
             n = p.numel()
@@ -52,6 +53,7 @@ class FlatAdam:
         try:
             for k in getattr(self, '_direct_keys', ()):
                 ops.DIRECT_GRAD.pop(k, None)
+            ops.DIRECT_EPOCH[0] += 1
             for p in getattr(self, 'params', ()):
                 if p.grad is not None:
                     ops.GRAD_FRESH.discard(p.grad.data_ptr())

@@ -665,3 +665,25 @@ def test_fused_reparam_kl_equals_the_separate_nodes(monkeypatch):
         torch.testing.assert_close(y.reshape(-1), x.reshape(-1), rtol=1e-6, atol=1e-7, msg=lambda s, nm=nm: f'{nm}: {s}')
     for x, y, nm in zip(ga, gb, ('h2', 'w_rel', 'z_pre', 'z_pri')):
         torch.testing.assert_close(y, x, rtol=1e-5, atol=1e-8, msg=lambda s, nm=nm: f'grad {nm}: {s}')
+
+
+def test_direct_gradient_registry_change_between_forward_and_backward_is_refused():
+    """INTEGRATION.md, the optimiser contract: a backward whose forward resolved a gradient-arena target refuses to run after
+    the registry changed (a FlatAdam built or dropped in between) instead of adding into an arena nobody reads."""
+    from gcn_vae_amd import ops
+    from gcn_vae_amd.optim import FlatAdam
+    w = torch.nn.Parameter(torch.randn(12, 8, device='cuda'))
+    b = torch.nn.Parameter(torch.randn(12, device='cuda'))
+    table = torch.nn.Parameter(torch.randn(30, 8, device='cuda'))
+    opt = FlatAdam([w, b, table], lr=1e-3)
+    ids = torch.tensor([3, 5, 5, 7], device='cuda').view(-1, 1)
+    out = ops.embedding(table, ids)
+    y = ops.linear(out, w, b, 0).sum()
+    opt2 = FlatAdam([torch.nn.Parameter(torch.randn(4, device='cuda'))], lr=1e-3)       # registry changes here
+    with pytest.raises(RuntimeError, match='gradient arena'):
+        y.backward()
+    del opt2
+    opt.zero_grad()
+    y2 = ops.linear(ops.embedding(table, ids), w, b, 0).sum()
+    y2.backward()                                                                       # an undisturbed pair works
+    assert float(table.grad.abs().sum()) > 0 and table.grad.data_ptr() == opt.flat_g[opt.offsets[table]:].data_ptr()
