@@ -211,6 +211,85 @@ __global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ x, 
     }
 }
 
+// The IAF update (kgvae/flow_network.py:92-97) and its backward with the bf16 copies the NEXT products read written by the same
+// launch (row-major + transposed through a 64 x 64 LDS tile) -- instead of an fp32 result followed by a k_cast_bf16 pass:
+//   fwd: x_new = colcount > 0 ? z * exp(alpha + mu) : x_old    -> x_new (fp32), x_b (bf16), x_t (bf16, transposed)
+//   bwd: g_net = [g_mu | g_alpha] -> bf16 row-major + transposed only; g_z ACCUMULATED (the passes' contributions add up);
+//        g_xold fp32.  Same arithmetic as k_iaf_fwd / k_iaf_bwd (csrc/k_elem.hip).
+__global__ __launch_bounds__(256) void k_iaf_fwd_bf16(const float* __restrict__ z, const float* __restrict__ net, int ld_net,
+                                                      const float* __restrict__ xold, const int* __restrict__ colcount,
+                                                      float* __restrict__ xnew, uint16_t* xb, int ldb, uint16_t* xt, int ldt,
+                                                      int rows, int d) {
+    __shared__ uint16_t t[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int rr = i >> 6, cc = i & 63;
+        const int r = r0 + rr, c = c0 + cc;
+        uint16_t v = 0;
+        if (r < rows && c < d) {
+            const size_t e = (size_t)r * d + c;
+            float x;
+            if (colcount[c] > 0) {
+                const float mu = net[(size_t)r * ld_net + c], al = net[(size_t)r * ld_net + d + c];
+                x = z[e] * expf(al + mu);
+            } else {
+                x = xold[e];
+            }
+            xnew[e] = x;
+            v = f2bf(x);
+            xb[(size_t)r * ldb + c] = v;
+        }
+        t[rr][cc] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int cc = i >> 6, rr = i & 63;
+        if (r0 + rr < rows && c0 + cc < d) xt[(size_t)(c0 + cc) * ldt + r0 + rr] = t[rr][cc];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_iaf_bwd_bf16(const float* __restrict__ z, const float* __restrict__ net, int ld_net,
+                                                      const int* __restrict__ colcount, const float* __restrict__ gx,
+                                                      const float* __restrict__ gld, float* __restrict__ gz_acc,
+                                                      uint16_t* gnb, int ldb, uint16_t* gnt, int ldt, float* __restrict__ gxold,
+                                                      int rows, int d) {
+    __shared__ uint16_t t[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;        // c0 runs over the 2d columns of [g_mu | g_alpha]
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int rr = i >> 6, cc = i & 63;
+        const int r = r0 + rr, c2 = c0 + cc;
+        uint16_t v = 0;
+        if (r < rows && c2 < 2 * d) {
+            const bool alpha = c2 >= d;
+            const int c = alpha ? c2 - d : c2;
+            const size_t e = (size_t)r * d + c;
+            const int cnt = colcount[c];
+            const float g = gx[e];
+            float g_mu = 0.f, g_al = gld ? gld[r] : 0.f, g_z = 0.f, g_old = g;
+            if (cnt > 0) {
+                const float ex = expf(net[(size_t)r * ld_net + d + c] + net[(size_t)r * ld_net + c]);
+                const float gc = g * (float)cnt;
+                g_z = gc * ex;
+                g_mu = gc * z[e] * ex;
+                g_al += g_mu;
+                g_old = 0.f;
+            }
+            if (!alpha) {
+                gz_acc[e] += g_z;
+                gxold[e] = g_old;
+            }
+            v = f2bf(alpha ? g_al : g_mu);
+            gnb[(size_t)r * ldb + c2] = v;
+        }
+        t[rr][cc] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int cc = i >> 6, rr = i & 63;
+        if (r0 + rr < rows && c0 + cc < 2 * d) gnt[(size_t)(c0 + cc) * ldt + r0 + rr] = t[rr][cc];
+    }
+}
+
 // Sums over bf16 rows (bias gradients from the transposed gradient copies): stage 1, one wave per (row, 4096-column chunk),
 // writes part[row][chunk]; stage 2 adds a row's chunk sums in order.  fp32 sums, fixed order.
 constexpr int ROWSUM_CHUNK = 4096;
@@ -316,6 +395,31 @@ extern "C" int gv_cast_bf16(const float* x, int ldx, int rows, int cols, uint16_
     hipLaunchKernelGGL(k_cast_bf16, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, rows,
                        cols, y, ldy, y_t, ldt);
     return launch_status("gv_cast_bf16");
+}
+
+extern "C" int gv_iaf_update_fwd_bf16(const float* z, const float* net, int ld_net, const float* x_old, const int32_t* colcount,
+                                     float* x_new, uint16_t* x_b, int ldb, uint16_t* x_t, int ldt, int64_t n, int d,
+                                     void* stream) {
+    GV_REQUIRE(n >= 0 && d > 0 && n < (1ll << 31), GV_ERR_SHAPE, "gv_iaf_update_fwd_bf16: n=%lld d=%d", (long long)n, d);
+    if (n == 0) return GV_OK;
+    GV_REQUIRE(z && net && x_old && colcount && x_new && x_b && x_t, GV_ERR_NULL, "gv_iaf_update_fwd_bf16: NULL pointer");
+    GV_REQUIRE(ldb >= d && ldt >= n, GV_ERR_SHAPE, "gv_iaf_update_fwd_bf16: leading dimension too small");
+    hipLaunchKernelGGL(k_iaf_fwd_bf16, dim3((d + 63) / 64, (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, z, net,
+                       ld_net, x_old, colcount, x_new, x_b, ldb, x_t, ldt, (int)n, d);
+    return launch_status("gv_iaf_update_fwd_bf16");
+}
+
+extern "C" int gv_iaf_update_bwd_bf16(const float* z, const float* net, int ld_net, const int32_t* colcount, const float* gx,
+                                     const float* gld, float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t, int ldt,
+                                     float* gx_old, int64_t n, int d, void* stream) {
+    GV_REQUIRE(n >= 0 && d > 0 && n < (1ll << 31), GV_ERR_SHAPE, "gv_iaf_update_bwd_bf16: n=%lld d=%d", (long long)n, d);
+    if (n == 0) return GV_OK;
+    GV_REQUIRE(z && net && colcount && gx && gz_accumulate && gnet_b && gnet_t && gx_old, GV_ERR_NULL,
+               "gv_iaf_update_bwd_bf16: NULL pointer");
+    GV_REQUIRE(ldb >= 2 * d && ldt >= n, GV_ERR_SHAPE, "gv_iaf_update_bwd_bf16: leading dimension too small");
+    hipLaunchKernelGGL(k_iaf_bwd_bf16, dim3((2 * d + 63) / 64, (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, z,
+                       net, ld_net, colcount, gx, gld, gz_accumulate, gnet_b, ldb, gnet_t, ldt, gx_old, (int)n, d);
+    return launch_status("gv_iaf_update_bwd_bf16");
 }
 
 extern "C" int gv_rowsum_bf16(const uint16_t* x, int ld, int rows, int cols, float* out, int accumulate, float* workspace,

@@ -54,6 +54,8 @@ SIGNATURES = {
     'gv_gemm_bf16_nt': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P, _L, _P]),
     'gv_cast_bf16': (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P]),
     'gv_rowsum_bf16_workspace_floats': (_L, [_I, _I]),
+    'gv_iaf_update_fwd_bf16': (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _L, _I, _P]),
+    'gv_iaf_update_bwd_bf16': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _L, _I, _P]),
     'gv_rowsum_bf16': (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     'gv_rel_rows_gemm': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
     'gv_rel_gradw_gemm': (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P]),

@@ -2441,20 +2441,26 @@ class _MADEForwardBF16(torch.autograd.Function):
         for l in range(L):
             inp = gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE, precision='bf16')
             acts0.append(inp)
-        first_out = xin[0:n] if P > 1 else x_out
-        lib.call('gv_iaf_update_fwd', ptr(z), ptr(acts0[L - 1]), 0, ptr(z), ptr(colcount[0]), ptr(first_out), n, d, st)
+        def update(net, ld_net, x_old, cc, q):
+            """The IAF update of one pass.  Its result is pass q + 1's input (slice q of the stacked buffers: fp32 + the bf16
+            row-major and transposed copies the products read, written by the same launch) or, after the last pass, x_out."""
+            if q < S:
+                lib.call('gv_iaf_update_fwd_bf16', ptr(z), ptr(net), ld_net, ptr(x_old), ptr(cc), ptr(xin[q * n:(q + 1) * n]),
+                         ptr(xin_b[q * n:(q + 1) * n]), xin_b.stride(0), ptr(xin_t[:, q * npad:q * npad + n]), xin_t.stride(0),
+                         n, d, st)
+            else:
+                lib.call('gv_iaf_update_fwd', ptr(z), ptr(net), ld_net, ptr(x_old), ptr(cc), ptr(x_out), n, d, st)
+        update(acts0[L - 1], 0, z, colcount[0], 0)
         for p in range(1, P):
             sl = slice((p - 1) * n, p * n)
             tsl = slice((p - 1) * npad, (p - 1) * npad + n)
-            cast_bf16(xin[sl], xin_b[sl], xin_t[:, tsl])
             inp = xin_b[sl]
             for l in range(L - 1):
                 gemm_bf16_nt(inp, wbf[l], n, widths[l], ws[l].shape[1], bias=bs[l], relu=True, c_bf16=acts_b[l][sl],
                              c_bf16_t=acts_t[l][:, tsl])
                 inp = acts_b[l][sl]
             gemm_bf16_nt(inp, wbf[L - 1], n, widths[L - 1], ws[L - 1].shape[1], bias=bs[L - 1], c_f32=net_out[sl])
-            nxt = xin[p * n:(p + 1) * n] if p + 1 < P else x_out
-            lib.call('gv_iaf_update_fwd', ptr(z), ptr(net_out[sl]), 2 * d, ptr(xin[sl]), ptr(colcount[p]), ptr(nxt), n, d, st)
+            update(net_out[sl], 2 * d, xin[sl], colcount[p], p)
         log_det = torch.empty(n, **f32)
         if P > 1:
             lib.call('gv_rowsum', ptr(net_out[(S - 1) * n:]), 2 * d, d, d, ptr(log_det), n, st)
@@ -2489,7 +2495,6 @@ class _MADEForwardBF16(torch.autograd.Function):
         # (operand of backward-W and of the bias sums)
         gm_b = [torch.empty(max(S, 1) * n, _pad8(widths[l]), **bf) for l in range(L)]
         gm_t = [_empty_t_padded(widths[l], max(S, 1), n, npad, bf) for l in range(L)]
-        g_net = torch.empty(n, 2 * d, **f32)
         g_z = torch.zeros(n, d, **f32)
         gz_p = torch.empty(n, d, **f32)
         g_cur = gx
@@ -2497,10 +2502,10 @@ class _MADEForwardBF16(torch.autograd.Function):
             sl = slice((p - 1) * n, p * n)
             tsl = slice((p - 1) * npad, (p - 1) * npad + n)
             g_old = torch.empty(n, d, **f32)
-            lib.call('gv_iaf_update_bwd', ptr(z), ptr(net_out[sl]), 2 * d, ptr(colcount[p]), ptr(g_cur),
-                     ptr(gld) if p == P - 1 else None, ptr(gz_p), ptr(g_net), ptr(g_old), n, d, st)
-            lib.call('gv_axpby', n * d, None, 1.0, ptr(gz_p), 1.0, ptr(g_z), st)
-            cast_bf16(g_net, gm_b[L - 1][sl], gm_t[L - 1][:, tsl])
+            # the update's backward: g_z accumulated in place, [g_mu | g_alpha] straight into the bf16 operands of the products
+            lib.call('gv_iaf_update_bwd_bf16', ptr(z), ptr(net_out[sl]), 2 * d, ptr(colcount[p]), ptr(g_cur),
+                     ptr(gld) if p == P - 1 else None, ptr(g_z), ptr(gm_b[L - 1][sl]), gm_b[L - 1].stride(0),
+                     ptr(gm_t[L - 1][:, tsl]), gm_t[L - 1].stride(0), ptr(g_old), n, d, st)
             for l in reversed(range(1, L)):      # g_{l-1} = (g_l W_l) * [a_{l-1} > 0]
                 gemm_bf16_nt(gm_b[l][sl], wbt[l], n, widths[l - 1], widths[l], mask=acts_b[l - 1][sl], c_bf16=gm_b[l - 1][sl],
                              c_bf16_t=gm_t[l - 1][:, tsl])

@@ -160,6 +160,14 @@ int gv_rel_rows_gemm(const float* feat, int ld_feat, const int32_t* rows, const 
 int gv_rel_gradw_gemm(const float* x, int ld_x, const int32_t* x_rows, const float* g, int ld_g, const int32_t* g_rows,
                       const float* scale, const int32_t* relptr, int num_rels, int in_feat, int out_feat, float* grad_w,
                       void* stream);
+/* gv_iaf_update_fwd / _bwd (kgvae/flow_network.py:92-97) that also produce what the bf16 products read next: fwd writes x_new as
+ * fp32 AND as bf16 row-major (x_b, ld ldb) and transposed (x_t [d, >= n], ld ldt); bwd writes g_net = [g_mu | g_alpha] ONLY as bf16
+ * row-major (gnet_b, ld >= 2d) and transposed (gnet_t [2d, >= n]), ADDS g_z into gz_accumulate and writes gx_old (fp32). */
+int gv_iaf_update_fwd_bf16(const float* z, const float* net, int ld_net, const float* x_old, const int32_t* colcount, float* x_new,
+                           uint16_t* x_b, int ldb, uint16_t* x_t, int ldt, int64_t n, int d, void* stream);
+int gv_iaf_update_bwd_bf16(const float* z, const float* net, int ld_net, const int32_t* colcount, const float* gx, const float* gld,
+                           float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t, int ldt, float* gx_old, int64_t n,
+                           int d, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * K4 in bf16 (BASELINE configs[2]): the masked-MLP products of MADE / IAF (kgvae/flow_network.py:7-98, called from
  * kgvae/model.py:116-123) with bf16 STORAGE of weights and activations, bf16 MFMA, fp32 accumulation.
