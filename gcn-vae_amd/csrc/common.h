@@ -132,6 +132,32 @@ __device__ __forceinline__ float sum_slices_16x64(const float* __restrict__ part
     return tot;
 }
 
+// Word fill / copy as ordinary kernels.  hipMemsetAsync / hipMemcpyAsync recorded into a hipGraph become memset / memcpy NODES; on
+// this stack a replay that follows other runtime work (a device-to-host copy between two replays is enough) ran such a node with
+// stale parameters and faulted (tools/sampler_fault_probe2.py).  Launches of our own kernels are recorded as kernel nodes with
+// their arguments by value, which replay correctly, so everything the library clears or copies on the stream goes through these.
+__global__ __launch_bounds__(256) inline void k_fill_u32(unsigned* __restrict__ p, unsigned v, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = v;
+}
+__global__ __launch_bounds__(256) inline void k_copy_u32(unsigned* __restrict__ d, const unsigned* __restrict__ s, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) d[i] = s[i];
+}
+// n_bytes must be a multiple of 4 and p 4-byte aligned (every caller clears int / float arrays)
+inline hipError_t fill_words(void* p, unsigned word, size_t n_bytes, hipStream_t st) {
+    const long long n = (long long)(n_bytes / 4);
+    if (n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, st, (unsigned*)p, word, n);
+    return hipGetLastError();
+}
+inline hipError_t copy_words(void* d, const void* s, size_t n_bytes, hipStream_t st) {
+    const long long n = (long long)(n_bytes / 4);
+    if (n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(k_copy_u32, dim3(blocks), dim3(256), 0, st, (unsigned*)d, (const unsigned*)s, n);
+    return hipGetLastError();
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) { return act == GV_ACT_RELU ? fmaxf(v, 0.f) : v; }
 
 // Philox4x32-10 (Salmon et al., SC'11), the one random generator of the library (gv_rng_fill, the batch sampler)

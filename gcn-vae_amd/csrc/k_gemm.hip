@@ -698,7 +698,7 @@ extern "C" int gv_rank_scores(const float* q, int ld_q, const float* e, int ld_e
     p.vec_b = aligned16(e) && (ld_e % 4 == 0);
     rp.target = target; rp.bias = bias; rp.tgt = tgt; rp.count = count;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(count, 0, (size_t)m * sizeof(int), st) != hipSuccess) return launch_status("gv_rank_scores(memset)");
+    if (fill_words(count, 0u, (size_t)m * sizeof(int), st) != hipSuccess) return launch_status("gv_rank_scores(fill)");
     dim3 grid((v + 63) / 64, (m + 63) / 64), block(256);
     hipLaunchKernelGGL(k_rank_scores<0>, grid, block, 0, st, rp);
     hipLaunchKernelGGL(k_rank_scores<1>, grid, block, 0, st, rp);

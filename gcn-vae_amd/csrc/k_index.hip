@@ -145,8 +145,8 @@ int order_and_items(const int* keys, int64_t n, int n_seg, int chunk, int* perm,
         sorted = sc.keys_sorted;
     }
     hipLaunchKernelGGL(k_lower_bounds, dim3((n_seg + 1 + 255) / 256), dim3(256), 0, st, sorted, n, n_seg, rowptr);
-    GV_HIP_OK(hipMemsetAsync(items, 0xFF, (size_t)items_cap * 16, st), "gv index: memset items");
-    GV_HIP_OK(hipMemsetAsync(fix, 0xFF, (size_t)fix_cap * 16, st), "gv index: memset fix");
+    GV_HIP_OK(fill_words(items, 0xFFFFFFFFu, (size_t)items_cap * 16, st), "gv index: fill items");
+    GV_HIP_OK(fill_words(fix, 0xFFFFFFFFu, (size_t)fix_cap * 16, st), "gv index: fill fix");
     if (n_seg > 0) {
         hipLaunchKernelGGL(k_item_counts, dim3((n_seg + 255) / 256), dim3(256), 0, st, rowptr, n_seg, chunk, sc.counts);
         size_t tb = sc.cub_bytes;

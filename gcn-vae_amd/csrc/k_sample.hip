@@ -201,7 +201,7 @@ extern "C" int gv_relabel_pairs(const int32_t* a, const int32_t* b, int64_t k, i
     int* flags = (int*)p; p += al256((size_t)(num_ids + 1) * sizeof(int));
     int* rank = (int*)p; p += al256((size_t)(num_ids + 1) * sizeof(int));
     size_t tb = relabel_temp(num_ids);
-    if (hipMemsetAsync(flags, 0, (size_t)(num_ids + 1) * sizeof(int), st) != hipSuccess) return launch_status("gv_relabel_pairs(memset)");
+    if (fill_words(flags, 0u, (size_t)(num_ids + 1) * sizeof(int), st) != hipSuccess) return launch_status("gv_relabel_pairs(memset)");
     if (k > 0) hipLaunchKernelGGL(k_mark_pairs, dim3(blocks_for(k)), dim3(256), 0, st, a, b, (long long)k, flags);
     if (hipcub::DeviceScan::ExclusiveSum(p, tb, (const int*)flags, rank, num_ids + 1, st) != hipSuccess)
         return launch_status("gv_relabel_pairs(scan)");
@@ -397,8 +397,8 @@ extern "C" int gv_neighborhood_sample(const int32_t* adj_ptr, const int32_t* adj
     int* budget = (int*)p; p += b_budget;
     uint8_t* seen = (uint8_t*)p; p += b_seen;
     uint8_t* picked = (uint8_t*)p;
-    if (hipMemcpyAsync(budget, degrees, (size_t)num_vertices * sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess ||
-        hipMemsetAsync(seen, 0, b_seen + b_picked, st) != hipSuccess)
+    if (copy_words(budget, degrees, (size_t)num_vertices * sizeof(int), st) != hipSuccess ||
+        fill_words(seen, 0u, b_seen + b_picked, st) != hipSuccess)
         return launch_status("gv_neighborhood_sample(init)");
     const size_t lds = (size_t)num_vertices * 5 + 16;
     const int in_lds = lds <= 150 * 1024;

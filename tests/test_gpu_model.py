@@ -687,3 +687,22 @@ def test_direct_gradient_registry_change_between_forward_and_backward_is_refused
     y2 = ops.linear(ops.embedding(table, ids), w, b, 0).sum()
     y2.backward()                                                                       # an undisturbed pair works
     assert float(table.grad.abs().sum()) > 0 and table.grad.data_ptr() == opt.flat_g[opt.offsets[table]:].data_ptr()
+
+
+def test_train_driver_with_graph_step(tmp_path, capsys):
+    """gcn_vae_amd.train.main --device-sampler --graph-step: every step is one hipGraph replay; evaluation and the checkpoint
+    round trip work as in the eager loop; --n-flows > 0 is refused (padding rows and flow_log_prob)."""
+    from gcn_vae_amd import train
+    ckpt = str(tmp_path / 'model_state.pth')
+    argv = ['-d', 'synthetic:400:9:3000:150:150:1', '--gpu', '0', '--n-hidden', '16', '--n-bases', '4', '--n-epochs', '8',
+            '--evaluate-every', '4', '--graph-batch-size', '600', '--eval-batch-size', '50', '--mmd-param', '1.0', '--kl-param', '1e-3',
+            '--n-flows', '0', '--mog-k', '4', '--model-state-file', ckpt, '--device-sampler', '--graph-step']
+    torch.manual_seed(0)
+    best = train.main(train.build_parser().parse_args(argv))
+    out = capsys.readouterr().out
+    assert out.count('Epoch 00') == 5 and 'training done' in out and 0.0 < best <= 1.0       # 3 warm-up steps + 5 replays = 8
+    losses = [float(line.split('Loss ')[1].split(' |')[0]) for line in out.splitlines() if line.startswith('Epoch 00')]
+    assert all(np.isfinite(losses)) and len(set(losses)) == len(losses)
+    argv[argv.index('--n-flows') + 1] = '2'
+    with pytest.raises(NotImplementedError):
+        train.main(train.build_parser().parse_args(argv))
