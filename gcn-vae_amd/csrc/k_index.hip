@@ -22,14 +22,22 @@ __global__ void k_iota(int* x, int64_t n) {
     if (i < n) x[i] = (int)i;
 }
 
+// iota + the keys narrowed to 16 bits (segment ids below 65 536): rocPRIM sorts 2-byte keys of >= 100 000 items with its
+// onesweep radix sort (a histogram pass + two scatter passes) instead of ~10 merge passes
+__global__ void k_iota_narrow(int* x, const int* keys, unsigned short* k16, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { x[i] = (int)i; k16[i] = (unsigned short)keys[i]; }
+}
+
 // rowptr[s] = number of sorted keys < s  (s = 0 .. n_seg)
-__global__ void k_lower_bounds(const int* keys_sorted, int64_t n, int n_seg, int* rowptr) {
+template <typename KeyT>
+__global__ void k_lower_bounds(const KeyT* keys_sorted, int64_t n, int n_seg, int* rowptr) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s > n_seg) return;
     int64_t lo = 0, hi = n;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if (keys_sorted[mid] < s) lo = mid + 1; else hi = mid;
+        if ((int)keys_sorted[mid] < s) lo = mid + 1; else hi = mid;
     }
     rowptr[s] = (int)lo;
 }
@@ -102,6 +110,10 @@ size_t cub_temp_bytes(int64_t n, int n_seg) {
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const int*)nullptr, (int*)nullptr, (const int*)nullptr, (int*)nullptr,
                                        (int)n, 0, bits_for(n_seg));
     (void)hipcub::DeviceScan::ExclusiveScan(nullptr, b, (const Tri*)nullptr, (Tri*)nullptr, hipcub::Sum(), Tri{0, 0, 0}, n_seg + 1);
+    size_t c = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, c, (const unsigned short*)nullptr, (unsigned short*)nullptr, (const int*)nullptr,
+                                             (int*)nullptr, (int)n, 0, 16);
+    a = a > c ? a : c;
     return align256(a > b ? a : b);
 }
 
@@ -136,7 +148,17 @@ struct Scratch {
 int order_and_items(const int* keys, int64_t n, int n_seg, int chunk, int* perm, int* rowptr, int* items, int items_cap,
                     int* fix, int fix_cap, const Scratch& sc, hipStream_t st) {
     const int* sorted = keys;
-    if (perm && n > 0) {
+    const unsigned short* sorted16 = nullptr;
+    if (perm && n >= 100000 && n_seg <= 65536) {      // 2-byte keys: the two halves of the keys_sorted area hold them (in / out)
+        unsigned short* k16_in = (unsigned short*)sc.keys_sorted;
+        unsigned short* k16_out = k16_in + ((n + 127) & ~(int64_t)127);
+        hipLaunchKernelGGL(k_iota_narrow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc.iota, keys, k16_in, n);
+        size_t tb = sc.cub_bytes;
+        GV_HIP_OK(hipcub::DeviceRadixSort::SortPairs(sc.cub, tb, (const unsigned short*)k16_in, k16_out, (const int*)sc.iota, perm,
+                                                     (int)n, 0, bits_for(n_seg), st),
+                  "gv index: radix sort (16-bit keys)");
+        sorted16 = k16_out;
+    } else if (perm && n > 0) {
         hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc.iota, n);
         size_t tb = sc.cub_bytes;
         GV_HIP_OK(hipcub::DeviceRadixSort::SortPairs(sc.cub, tb, keys, sc.keys_sorted, (const int*)sc.iota, perm, (int)n, 0,
@@ -144,7 +166,10 @@ int order_and_items(const int* keys, int64_t n, int n_seg, int chunk, int* perm,
                   "gv index: radix sort");
         sorted = sc.keys_sorted;
     }
-    hipLaunchKernelGGL(k_lower_bounds, dim3((n_seg + 1 + 255) / 256), dim3(256), 0, st, sorted, n, n_seg, rowptr);
+    if (sorted16)
+        hipLaunchKernelGGL(k_lower_bounds<unsigned short>, dim3((n_seg + 1 + 255) / 256), dim3(256), 0, st, sorted16, n, n_seg, rowptr);
+    else
+        hipLaunchKernelGGL(k_lower_bounds<int>, dim3((n_seg + 1 + 255) / 256), dim3(256), 0, st, sorted, n, n_seg, rowptr);
     GV_HIP_OK(fill_words(items, 0xFFFFFFFFu, (size_t)items_cap * 16, st), "gv index: fill items");
     GV_HIP_OK(fill_words(fix, 0xFFFFFFFFu, (size_t)fix_cap * 16, st), "gv index: fill fix");
     if (n_seg > 0) {

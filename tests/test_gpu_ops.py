@@ -899,7 +899,8 @@ def _same_items(a, b):
 
 @pytest.mark.parametrize('n,e,r,sorted_dst,n_src', [(50, 0, 4, True, None), (1, 7, 1, True, None), (300, 5000, 12, True, None),
                                                      (300, 5000, 12, False, None), (2000, 60000, 474, True, None),
-                                                     (120, 9000, 30, True, 700), (97, 4001, 7, False, 350)])
+                                                     (120, 9000, 30, True, 700), (97, 4001, 7, False, 350),
+                                                     (3000, 150000, 60, False, None)])       # >= 100 000 entries: the 16-bit-key sort path
 def test_native_index_build_equals_torch_formulation(ops, n, e, r, sorted_dst, n_src):
     rs = np.random.RandomState(n + e)
     ns = n if n_src is None else n_src
