@@ -34,6 +34,8 @@ class GraphedMiniBatchStep:
         if getattr(model, 'mmd_param', 0) > 0 and hasattr(enc, 'mmd_index_override'):
             self.pick = torch.zeros(num_mmd_rows, dtype=torch.int64, device=dev)
             enc.mmd_index_override = self.pick          # refilled on the device inside the step
+        if hasattr(enc, 'fuse_kl_with_reparam'):
+            enc.fuse_kl_with_reparam = False            # the KL pass needs the device row count: it stays in the loss head here
         self.one = torch.ones((), device=dev)
         self.graph = None
         self.out = None
