@@ -281,7 +281,7 @@ bool phase_plan(int nb, int p, int q, bool trans, int k_req, PhasePlan* out) {
     int bpl = 0, u = 8, k = 0;
     if (!trans) {
         if (p == 2 && q == 2) { bpl = 2; k = 8; }
-        else if (p == 2 && q == 4) { bpl = 1; k = 8; }       // one block per lane, two column parts: 8 rows per wave fit (32 accumulators)
+        else if (p == 2 && q == 4) { bpl = 2; u = 6; k = 8; }   // two blocks per lane (one column part): 8 rows x 8 accumulators, 6 rows in flight
         else if (p == 5 && q == 5) { bpl = 2; u = 3; k = 3; }
         else if (p == 5 && q == 10) { bpl = 1; u = 2; k = 4; }
     } else {
@@ -403,7 +403,7 @@ extern "C" int gv_rgcn_bdd_aggregate_phases(const int32_t* off, const int32_t* n
         rc = launch_status("gv_rgcn_bdd_aggregate_phases");                                                         \
     }
     GV_PHASE_CASE(2, 2, false, 2, 8, 8) GV_PHASE_CASE(2, 2, false, 2, 4, 8)
-    GV_PHASE_CASE(2, 4, false, 1, 8, 8) GV_PHASE_CASE(2, 4, false, 1, 4, 8)
+    GV_PHASE_CASE(2, 4, false, 2, 8, 6) GV_PHASE_CASE(2, 4, false, 2, 4, 6)
     GV_PHASE_CASE(2, 2, true, 2, 8, 8) GV_PHASE_CASE(2, 2, true, 2, 4, 8)
     GV_PHASE_CASE(4, 2, true, 2, 8, 4) GV_PHASE_CASE(4, 2, true, 2, 4, 4)
     GV_PHASE_CASE(5, 5, false, 2, 3, 3)
