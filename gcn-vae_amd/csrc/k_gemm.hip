@@ -131,7 +131,20 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmParams p) {
     constexpr int BM = 64 * MT, BN = 64 * NT, LDA_S = BM + 1, LDB_S = BN + 1;
     __shared__ float As[BK * LDA_S];
     __shared__ float Bs[BK * LDB_S];
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // Workgroups are dealt round-robin to the 8 XCDs.  The n-tiles of one m-tile share the A rows: give them CONSECUTIVE slots of
+    // the SAME XCD, so that a tall A (configs[4]: 800 MB, far beyond the Infinity Cache) crosses the fabric once instead of once
+    // per n-tile.  (Whole groups of 8 m-tiles only; the ragged end keeps the plain order.)
+    int mt_i = blockIdx.y, nt_i = blockIdx.x;
+    {
+        const int ntn = gridDim.x, lin = blockIdx.y * ntn + blockIdx.x;
+        const int full = (gridDim.y / 8) * 8 * ntn;
+        if (lin < full) {
+            const int xcd = lin & 7, j = lin >> 3;
+            nt_i = j % ntn;
+            mt_i = (j / ntn) * 8 + xcd;
+        }
+    }
+    const int m0 = mt_i * BM, n0 = nt_i * BN;
     const int kbeg = blockIdx.z * p.k_chunk;
     const int kend = min(p.k, kbeg + p.k_chunk);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
