@@ -1705,13 +1705,14 @@ class KLLink:
     """Hand-off between the reparameterisation node and the loss head when K3 and K6 are fused (gv_reparam_kl_fwd / _bwd):
     the forward leaves the KL pass's responsibilities and workspace here for the loss head; the loss head's backward leaves
     the upstream scalar and its two scales here and lets the reparameterisation's backward do KL's node gradients."""
-    __slots__ = ('resp', 'ws', 'z_pre_ptr', 'z_pre_version', 'gkl', 'gscale', 'z_extra')
+    __slots__ = ('resp', 'ws', 'z_pre_ptr', 'z_pre_version', 'gkl', 'gscale', 'z_extra', 'claimed')
 
     def __init__(self, resp, ws, z_pre):
         self.resp, self.ws = resp, ws
         self.z_pre_ptr, self.z_pre_version = z_pre.data_ptr(), z_pre._version
         self.gkl = None
         self.gscale = self.z_extra = 0.0
+        self.claimed = False          # ONE loss head may take the hand-off; a second one on the same z runs its own KL passes
 
     def matches(self, z_pre):
         return z_pre is not None and z_pre.data_ptr() == self.z_pre_ptr and z_pre._version == self.z_pre_version
@@ -1754,8 +1755,6 @@ class _Reparam(torch.autograd.Function):
         if link is not None and link.gkl is not None:      # the loss head left KL's backward to this node
             h2, eps, v, z, z_pre = ctx.saved_tensors
             n, h = v.shape
-            if gm is not None or gv is not None:
-                raise RuntimeError('fused reparameterisation + KL backward: z_mean / z_sigma received a gradient of their own')
             gz = None if gz is None else _chk(gz.contiguous(), name='gz')
             d_zp = _direct_flat(z_pre)
             gzp = d_zp if d_zp is not None else torch.empty_like(z_pre)
@@ -1764,6 +1763,12 @@ class _Reparam(torch.autograd.Function):
                      float(link.gscale), float(link.z_extra), ptr(gz), ptr(gh2), ptr(gzp), 1 if d_zp is not None else 0,
                      ptr(link.ws), n, h, z_pre.shape[0] // 2, lib.stream())
             link.gkl = None
+            if gm is not None or gv is not None:       # z_mean / z_sigma have another consumer (a second loss head, a user's own term)
+                extra = torch.empty_like(h2)
+                gm = None if gm is None else _chk(gm.contiguous(), name='gm')
+                gv = None if gv is None else _chk(gv.contiguous(), name='gv')
+                lib.call('gv_reparam_bwd', ptr(h2), ptr(eps), ptr(v), None, ptr(gm), ptr(gv), ptr(extra), n, h, lib.stream())
+                gh2 += extra
             return gh2, None, (None if d_zp is not None else gzp), None
         h2, eps, v = ctx.saved_tensors[:3]
         n, h = v.shape
@@ -2112,8 +2117,10 @@ class _LossHead(torch.autograd.Function):
         loss = torch.empty((), **f32)
         bias = flp if (score_bias and flp is not None) else None
         resp = wsk = z_post = wsm = None
-        link = kl_link if (kl_link is not None and kl_w > 0 and flp is None and rows_dev is None and embed_rows is None
-                           and kl_link.matches(z_pre) and kl_link.resp.shape[0] == n) else None
+        link = kl_link if (kl_link is not None and not kl_link.claimed and kl_w > 0 and flp is None and rows_dev is None
+                           and embed_rows is None and kl_link.matches(z_pre) and kl_link.resp.shape[0] == n) else None
+        if link is not None:
+            link.claimed = True
         if kl_w > 0:
             z_mean, z_sigma = _chk(z_mean.contiguous(), name='z_mean'), _chk(z_sigma.contiguous(), name='z_sigma')
             z_pre = _chk(z_pre.contiguous(), name='z_pre')

@@ -706,3 +706,36 @@ def test_train_driver_with_graph_step(tmp_path, capsys):
     argv[argv.index('--n-flows') + 1] = '2'
     with pytest.raises(NotImplementedError):
         train.main(train.build_parser().parse_args(argv))
+
+
+def test_two_loss_heads_on_one_reparameterised_z():
+    """The K3/K6 hand-off is taken by ONE loss head; a second get_loss-style call on the same z runs its own KL passes, and the
+    summed gradients equal two separate (unfused) evaluations."""
+    from gcn_vae_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    n, h, k, T, R = 300, 40, 6, 1500, 5
+    h2, eps = torch.randn(n, 2 * h, generator=gen), torch.randn(n, h, generator=gen)
+    w_rel, z_pre = torch.randn(R, h, generator=gen) * 0.3, torch.randn(2 * k, h, generator=gen) * 0.5
+    trips = [torch.stack([torch.randint(0, n, (T,), generator=gen), torch.randint(0, R, (T,), generator=gen),
+                          torch.randint(0, n, (T,), generator=gen)], 1).cuda() for _ in range(2)]
+    labels = (torch.rand(T, generator=gen) > 0.5).float().cuda()
+
+    def run(fused):
+        old = ops.FUSE_REPARAM_KL
+        ops.FUSE_REPARAM_KL = fused
+        try:
+            ins = [t.clone().cuda().requires_grad_(True) for t in (h2, w_rel, z_pre)]
+            z, m, v = ops.reparam(ins[0], eps.cuda(), ins[2])
+            total = 0
+            for tr in trips:
+                tidx = ops.TripletIndex(tr, n, R, sync_free=True)
+                total = total + ops.loss_head(z, m, v, ins[1], ins[2], None, None, None, labels, tidx, 0.01, 1e-2, 0.0, False)[0]
+            total.backward()
+            return float(total), [t.grad.cpu() for t in ins]
+        finally:
+            ops.FUSE_REPARAM_KL = old
+    la, ga = run(False)
+    lb, gb = run(True)
+    assert abs(la - lb) < 1e-5 * max(1.0, abs(la))
+    for x, y, nm in zip(ga, gb, ('h2', 'w_rel', 'z_pre')):
+        torch.testing.assert_close(y, x, rtol=1e-5, atol=1e-7, msg=lambda s, nm=nm: f'grad {nm}: {s}')
