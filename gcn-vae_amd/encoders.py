@@ -66,6 +66,7 @@ class KGVAE(nn.Module):
         # so when the task head announces that MMD will be evaluated (LinkPredict sets this for mmd_param > 0) the
         # prior rows ride along in forward() as extra rows of the same GEMMs instead of ~150 tiny launches of their own.
         self.batch_mmd_prior_with_forward = False
+        self.rows_dev = None              # device int32 (1,): how many node rows of a padded static-shape batch exist (graph_step)
         self.fuse_kl_with_reparam = False # set by the task head when it will evaluate get_kl on forward()'s z (LinkPredict, kl_param > 0)
         self.grad_reducer = None          # distributed.BucketedArenaReduce: multi-GPU gradient exchange started under backward
         self._z_pri_flowed = None
@@ -224,7 +225,12 @@ class KGVAE(nn.Module):
         self._z_pri_flowed = None
         if self.n_flows > 0:
             z, log_det_sum = self._apply_flows(z)
-            self.flow_log_prob = torch.mean(log_det_sum.view(-1, 1))
+            if self.rows_dev is None:
+                self.flow_log_prob = torch.mean(log_det_sum.view(-1, 1))
+            else:       # static-shape batch: the mean runs over the rows that exist (device count), padding rows masked out
+                rows = self.rows_dev.reshape(()).to(log_det_sum.dtype)
+                live = torch.arange(log_det_sum.numel(), device=log_det_sum.device) < self.rows_dev.reshape(())
+                self.flow_log_prob = (log_det_sum.reshape(-1) * live).sum() / rows
         return z
 
 

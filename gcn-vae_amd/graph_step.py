@@ -23,9 +23,6 @@ class GraphedMiniBatchStep:
     def __init__(self, model, optimizer, sampler, sample_size, split_size=0.5, negative_rate=10, num_mmd_rows=200):
         if not isinstance(optimizer, FlatAdam):
             raise TypeError('the captured step needs FlatAdam (static gradient arena, two-launch clip + Adam)')
-        if getattr(model, 'n_flows', 0) > 0:
-            raise NotImplementedError('the static-shape step pads the node rows; flow_log_prob is a mean over rows that does not '
-                                      'know about the padding yet: use the eager loop with --n-flows > 0')
         self.model, self.opt, self.sampler = model, optimizer, sampler
         self.args = (int(sample_size), float(split_size), int(negative_rate))
         dev = sampler.device
@@ -45,6 +42,8 @@ class GraphedMiniBatchStep:
         """The step, launched eagerly (also what the capture records)."""
         b = self.sampler.sample_static(*self.args, mmd_pick=self.pick)
         self.model.rows_dev = b.rows_dev
+        if hasattr(self.model.encoder, 'rows_dev'):
+            self.model.encoder.rows_dev = b.rows_dev       # flow_log_prob is a mean over the rows that exist
         self.opt.zero_grad()
         embed = self.model(b.g, b.node_id, b.edge_type, b.edge_norm)
         loss, pred, kl, mmd = self.model.get_loss(b.g, embed, b.samples, b.labels)
