@@ -282,18 +282,19 @@ bool phase_plan(int nb, int p, int q, bool trans, int k_req, PhasePlan* out) {
     if (!trans) {
         if (p == 2 && q == 2) { bpl = 2; k = 8; }
         else if (p == 2 && q == 4) { bpl = 2; u = 6; k = 8; }   // two blocks per lane (one column part): 8 rows x 8 accumulators, 6 rows in flight
-        else if (p == 5 && q == 5) { bpl = 2; u = 3; k = 3; }
+        else if (p == 5 && q == 5) { bpl = 1; u = 4; k = 8; }     // one block per lane, two column parts: 8 rows x 5 accumulators; 228 tile-parts = one round of workgroups at FB15k-237 size
         else if (p == 5 && q == 10) { bpl = 1; u = 2; k = 4; }
     } else {
         if (p == 2 && q == 2) { bpl = 2; k = 8; }
         else if (p == 4 && q == 2) { bpl = 2; u = 4; k = 8; }
-        else if (p == 5 && q == 5) { bpl = 2; u = 3; k = 3; }
+        else if (p == 5 && q == 5) { bpl = 1; u = 4; k = 8; }
         else if (p == 10 && q == 5) { bpl = 1; u = 3; k = 3; }
     }
     if (!bpl || nb % bpl) return false;
     if (k_req && k_req != k) {
         if (k_req != 4 || k < 4) return false;       // the 8-row shapes also come with 4 rows per wave (smaller tiles)
         k = k_req;
+        if (p == 5 && q == 5) u = 6;
     }
     const int slots = nb / bpl;
     int parts = 0;
@@ -406,9 +407,9 @@ extern "C" int gv_rgcn_bdd_aggregate_phases(const int32_t* off, const int32_t* n
     GV_PHASE_CASE(2, 4, false, 2, 8, 6) GV_PHASE_CASE(2, 4, false, 2, 4, 6)
     GV_PHASE_CASE(2, 2, true, 2, 8, 8) GV_PHASE_CASE(2, 2, true, 2, 4, 8)
     GV_PHASE_CASE(4, 2, true, 2, 8, 4) GV_PHASE_CASE(4, 2, true, 2, 4, 4)
-    GV_PHASE_CASE(5, 5, false, 2, 3, 3)
+    GV_PHASE_CASE(5, 5, false, 1, 8, 4) GV_PHASE_CASE(5, 5, false, 1, 4, 6)
     GV_PHASE_CASE(5, 10, false, 1, 4, 2)
-    GV_PHASE_CASE(5, 5, true, 2, 3, 3)
+    GV_PHASE_CASE(5, 5, true, 1, 8, 4) GV_PHASE_CASE(5, 5, true, 1, 4, 6)
     GV_PHASE_CASE(10, 5, true, 1, 3, 3)
 #undef GV_PHASE_CASE
     GV_REQUIRE(rc != -1000, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate_phases: no instantiation for blocks %dx%d trans=%d", blk_in,

@@ -518,7 +518,8 @@ def use_phases(gidx, blk_in, blk_out, transpose_w, table_rows, table_cols):
         return False
     if int(table_rows) * int(table_cols) * 4 >= PHASE_MIN_TABLE_BYTES:
         return True
-    return (blk_in, blk_out, bool(transpose_w)) in ((5, 10, False), (10, 5, True))
+    # h = 500 (5-wide blocks): 10-20 kB of block weights per edge overflow an XCD's L2 -- staged per phase they win on every launch
+    return (blk_in, blk_out, bool(transpose_w)) in ((5, 10, False), (10, 5, True), (5, 5, False), (5, 5, True))
 
 
 @dataclass

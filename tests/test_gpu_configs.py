@@ -80,7 +80,7 @@ def _oracle_layer_chunked(x, src, dst, et, norm, p, nb, gout, chunk=40000):
 def test_c4_layer_full_size_h500_against_oracle(fin, fout):
     """BASELINE configs[3] / the reference's default --n-hidden 500 at FULL FB15k-237 size: one R-GCN layer (B = 100:
     5x5 or 5x10 blocks, 474 relation types, 544 230 edges), forward and every gradient, against the oracle (evaluated
-    over edge chunks).  The 5x10 / 10x5 launches run on the relation-phase kernel, the 5x5 ones on the per-row kernels."""
+    over edge chunks).  All four aggregation launches run on the relation-phase kernel (the per-row kernels are covered by test_gpu_ops)."""
     from gcn_vae_amd import ops, sampling
     from gcn_vae_amd.data import FB15K237, synthetic_kg
     from oracle import rgcn as orgcn
@@ -100,6 +100,8 @@ def test_c4_layer_full_size_h500_against_oracle(fin, fout):
     ridx = gidx.relation_index(et.cuda(), r)
     if fout == 1000:
         assert ops.use_phases(gidx, 5, 10, False, n, fin) and ops.use_phases(gidx, 10, 5, True, n, fout)
+    else:
+        assert ops.use_phases(gidx, 5, 5, False, n, fin) and ops.use_phases(gidx, 5, 5, True, n, fout)
     xg = x.cuda().requires_grad_(True)
     pg = {k: v.cuda().requires_grad_(True) for k, v in p.items()}
     hg = ops.rel_graph_conv_bdd(xg, pg['weight'], pg['h_bias'], pg['loop_weight'], norm.cuda(), gidx, ridx, nb, 0)
