@@ -64,8 +64,13 @@ __device__ __forceinline__ void glds16(const float4* gsrc, unsigned lds_byte_add
 // structurizer copy registers around and spill).
 template <int N> struct AccVec { typedef float type __attribute__((ext_vector_type(N))); };
 
-template <int P, int Q, bool TRANS, int BPL, int K, int M>
+// LEAN (wide blocks, where registers decide how many rows a wave can own): one block per lane whose weights are q-major in the
+// lane's list (the transposed product's natural order); the weights are fetched and used in two halves of the output columns,
+// and with M <= 2 rows in flight the row is picked by a select instead of through the indexed register vector -- ~45 registers
+// less, which buys 8 rows per wave (one round of workgroups at FB15k-237 size) for the 10x5 blocks.
+template <int P, int Q, bool TRANS, int BPL, int K, int M, bool LEAN = false>
 __global__ __launch_bounds__(1024) void k_agg_phase(const PhaseParams a) {
+    static_assert(!LEAN || (BPL == 1 && M <= 2), "lean mode: one q-major block per lane, at most two rows in flight");
     extern __shared__ __attribute__((aligned(16))) float4 wlds[];
     constexpr int GV = BPL * P, PV = BPL * Q, WV = BPL * P * Q, NQ = (WV + 3) / 4;
     const int lane = threadIdx.x & 63;
@@ -173,8 +178,10 @@ __global__ __launch_bounds__(1024) void k_agg_phase(const PhaseParams a) {
             constexpr int NX = M * GV <= 16 ? 16 : 32;
             static_assert(M * GV <= 32, "the feature rows in flight must fit one 32-register vector");
             typename AccVec<NX>::type xb;
+            if constexpr (!LEAN) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) xb[i] = i < M * GV ? xt[i / GV][i % GV] : 0.f;
+                for (int i = 0; i < NX; ++i) xb[i] = i < M * GV ? xt[i / GV][i % GV] : 0.f;
+            }
             int jj = j0;
 #pragma unroll
             for (int kk = 0; kk < K; ++kk) {
@@ -184,6 +191,47 @@ __global__ __launch_bounds__(1024) void k_agg_phase(const PhaseParams a) {
                     const int m = prl_i(cur_m, jj);
                     const float cf = prl_f(cur_c, jj);
                     const float4* wq = wcur + (m >> 4) * rel_quads;
+                    if constexpr (LEAN) {
+                        const bool first = (M == 1) || (jj == j0);
+                        float xc[GV];
+#pragma unroll
+                        for (int i = 0; i < GV; ++i) xc[i] = first ? xt[0][i] : xt[M - 1][i];
+                        constexpr int QH = (Q + 1) / 2;                     // output columns of the first half
+                        constexpr int Q0 = (QH * P + 3) / 4;                // its quads: floats [0, QH*P)
+                        constexpr int QB = (QH * P) / 4, OFF = QH * P - 4 * QB;      // second half starts inside quad QB
+                        {
+                            float w0[Q0 * 4];
+#pragma unroll
+                            for (int jq = 0; jq < Q0; ++jq) {
+                                const float4 t = wq[jq * L];
+                                w0[4 * jq] = t.x; w0[4 * jq + 1] = t.y; w0[4 * jq + 2] = t.z; w0[4 * jq + 3] = t.w;
+                            }
+#pragma unroll
+                            for (int q = 0; q < QH; ++q) {
+                                float t = 0.f;
+#pragma unroll
+                                for (int pp = 0; pp < P; ++pp) t = fmaf(xc[pp], w0[q * P + pp], t);
+                                acc[kk][q] = fmaf(t, cf, acc[kk][q]);
+                            }
+                        }
+                        asm volatile("" ::: "memory");                      // the second half's fetch stays behind the first half's use
+                        {
+                            float w1[(NQ - QB) * 4];
+#pragma unroll
+                            for (int jq = QB; jq < NQ; ++jq) {
+                                const float4 t = wq[jq * L];
+                                w1[4 * (jq - QB)] = t.x; w1[4 * (jq - QB) + 1] = t.y; w1[4 * (jq - QB) + 2] = t.z; w1[4 * (jq - QB) + 3] = t.w;
+                            }
+#pragma unroll
+                            for (int q = QH; q < Q; ++q) {
+                                float t = 0.f;
+#pragma unroll
+                                for (int pp = 0; pp < P; ++pp) t = fmaf(xc[pp], w1[(q - QH) * P + pp + OFF], t);
+                                acc[kk][q] = fmaf(t, cf, acc[kk][q]);
+                            }
+                        }
+                        continue;
+                    }
                     float wr[NQ * 4];
 #pragma unroll
                     for (int jq = 0; jq < NQ; ++jq) {
@@ -250,8 +298,10 @@ __global__ __launch_bounds__(1024) void k_agg_phase(const PhaseParams a) {
 
 // row layout [R][nb*P*Q] -> [parts][R][NQ][L] float4: quad jq of the WV = BPL*P*Q weights of lane l of a column part
 // (zero padded to whole quads); one thread per output quad
+// qmajor_q > 0 (one block per lane): element e of the lane's list is stored block element (e % p, e / p), i.e. the p x q block is
+// transposed on the way -- the order the lean kernel walks (two halves of the output columns)
 __global__ __launch_bounds__(256) void k_pack_weight_phase(const float* __restrict__ w, float4* __restrict__ out, int num_rels,
-                                                           int nb, int pq, int bpl, int parts) {
+                                                           int nb, int pq, int bpl, int parts, int qmajor_q) {
     const int wv = bpl * pq, nq = (wv + 3) / 4;
     const int L = nb / (bpl * parts);
     const size_t total = (size_t)parts * num_rels * nq * L;
@@ -261,40 +311,55 @@ __global__ __launch_bounds__(256) void k_pack_weight_phase(const float* __restri
         const int jq = (int)(t % nq);
         t /= nq;
         const int r = (int)(t % num_rels), part = (int)(t / num_rels);
-        const float* src = w + (size_t)r * nb * pq + ((size_t)part * L + l) * wv + 4 * jq;
+        const float* blk = w + (size_t)r * nb * pq + ((size_t)part * L + l) * wv;
+        const float* src = blk + 4 * jq;
         float4 v;
-        v.x = 4 * jq + 0 < wv ? src[0] : 0.f;
-        v.y = 4 * jq + 1 < wv ? src[1] : 0.f;
-        v.z = 4 * jq + 2 < wv ? src[2] : 0.f;
-        v.w = 4 * jq + 3 < wv ? src[3] : 0.f;
+        if (qmajor_q > 0) {
+            const int pw = pq / qmajor_q;                       // block is pw x qmajor_q, row-major
+            float e4[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int e = 4 * jq + c;                       // list element e = (q, p) with q = e / pw
+                e4[c] = e < wv ? blk[(e % pw) * qmajor_q + e / pw] : 0.f;
+            }
+            v = make_float4(e4[0], e4[1], e4[2], e4[3]);
+        } else {
+            v.x = 4 * jq + 0 < wv ? src[0] : 0.f;
+            v.y = 4 * jq + 1 < wv ? src[1] : 0.f;
+            v.z = 4 * jq + 2 < wv ? src[2] : 0.f;
+            v.w = 4 * jq + 3 < wv ? src[3] : 0.f;
+        }
         out[i] = v;
     }
 }
 
 namespace {
-struct PhasePlan { int bpl, parts, lanes, nq, k, u; };
+struct PhasePlan { int bpl, parts, lanes, nq, k, u, qmajor; };
 
 // instantiated shapes: blocks per lane as in k_agg_fast where the lane's gather then is 16 B (2-wide blocks: two per lane),
 // one 5- or 10-wide block per lane otherwise; the fewest column parts that fit a part's lanes into one wave
 bool phase_plan(int nb, int p, int q, bool trans, int k_req, PhasePlan* out) {
     // k = rows per wave (K * PV accumulator registers); M feature rows in flight (<= 32 registers), per instantiation below
-    int bpl = 0, u = 8, k = 0;
+    int bpl = 0, u = 8, k = 0, qmajor = 0;
     if (!trans) {
         if (p == 2 && q == 2) { bpl = 2; k = 8; }
         else if (p == 2 && q == 4) { bpl = 2; u = 6; k = 8; }   // two blocks per lane (one column part): 8 rows x 8 accumulators, 6 rows in flight
         else if (p == 5 && q == 5) { bpl = 1; u = 4; k = 8; }     // one block per lane, two column parts: 8 rows x 5 accumulators; 228 tile-parts = one round of workgroups at FB15k-237 size
-        else if (p == 5 && q == 10) { bpl = 1; u = 2; k = 4; }
+        else if (p == 5 && q == 10) { bpl = 1; u = 2; k = 4; qmajor = 1; }     // lean kernel on a q-major packed block (5, 6 rows: spills)     // lean kernel on a q-major packed block
     } else {
         if (p == 2 && q == 2) { bpl = 2; k = 8; }
         else if (p == 4 && q == 2) { bpl = 2; u = 4; k = 8; }
         else if (p == 5 && q == 5) { bpl = 1; u = 4; k = 8; }
-        else if (p == 10 && q == 5) { bpl = 1; u = 3; k = 3; }
+        else if (p == 10 && q == 5) { bpl = 1; u = 2; k = 8; }      // lean kernel: 8 rows x 5 accumulators, weights in two halves
     }
     if (!bpl || nb % bpl) return false;
     if (k_req && k_req != k) {
-        if (k_req != 4 || k < 4) return false;       // the 8-row shapes also come with 4 rows per wave (smaller tiles)
-        k = k_req;
-        if (p == 5 && q == 5) u = 6;
+        if (trans && p == 10 && q == 5 && k_req == 3) { k = 3; u = 3; }      // the plain kernel, 3 rows per wave
+        else if (k_req != 4 || k < 4 || (trans && p == 10 && q == 5)) return false;       // the 8-row shapes also come with 4 rows per wave
+        else {
+            k = k_req;
+            if (p == 5 && q == 5) u = 6;
+        }
     }
     const int slots = nb / bpl;
     int parts = 0;
@@ -302,6 +367,7 @@ bool phase_plan(int nb, int p, int q, bool trans, int k_req, PhasePlan* out) {
         if (slots % c == 0 && slots / c <= 64) parts = c;
     if (!parts) return false;
     out->bpl = bpl; out->parts = parts; out->lanes = slots / parts; out->nq = (bpl * p * q + 3) / 4; out->k = k; out->u = u;
+    out->qmajor = qmajor;
     return true;
 }
 }  // namespace
@@ -337,7 +403,8 @@ extern "C" int gv_rgcn_bdd_pack_weight_phase(const float* weight, int num_rels, 
     GV_REQUIRE(aligned16(packed), GV_ERR_ALIGN, "gv_rgcn_bdd_pack_weight_phase: 16-B alignment required");
     const size_t total = (size_t)pl.parts * num_rels * pl.nq * pl.lanes;
     hipLaunchKernelGGL(k_pack_weight_phase, dim3((unsigned)min((size_t)2048, (total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, weight, (float4*)packed, num_rels, num_bases, blk_in * blk_out, pl.bpl, pl.parts);
+                       (hipStream_t)stream, weight, (float4*)packed, num_rels, num_bases, blk_in * blk_out, pl.bpl, pl.parts,
+                       pl.qmajor ? blk_out : 0);
     return launch_status("gv_rgcn_bdd_pack_weight_phase");
 }
 
@@ -391,9 +458,10 @@ extern "C" int gv_rgcn_bdd_aggregate_phases(const int32_t* off, const int32_t* n
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(n_tiles, pl.parts), block(block_threads);
     int rc = -1000;
-#define GV_PHASE_CASE(P_, Q_, T_, B_, K_, U_)  /* U_ = M: feature rows in flight */                                                                        \
+#define GV_PHASE_CASE(P_, Q_, T_, B_, K_, U_) GV_PHASE_CASE_L(P_, Q_, T_, B_, K_, U_, false)
+#define GV_PHASE_CASE_L(P_, Q_, T_, B_, K_, U_, LEAN_)  /* U_ = M: feature rows in flight */                                                                        \
     if (rc == -1000 && blk_in == P_ && blk_out == Q_ && (transpose_w != 0) == T_ && pl.bpl == B_ && pl.k == K_) {    \
-        auto kern = k_agg_phase<P_, Q_, T_, B_, K_, U_>;                                                             \
+        auto kern = k_agg_phase<P_, Q_, T_, B_, K_, U_, LEAN_>;                                                             \
         static bool attr_done = false;                                                                               \
         if (!attr_done) {                                                                                            \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
@@ -408,10 +476,11 @@ extern "C" int gv_rgcn_bdd_aggregate_phases(const int32_t* off, const int32_t* n
     GV_PHASE_CASE(2, 2, true, 2, 8, 8) GV_PHASE_CASE(2, 2, true, 2, 4, 8)
     GV_PHASE_CASE(4, 2, true, 2, 8, 4) GV_PHASE_CASE(4, 2, true, 2, 4, 4)
     GV_PHASE_CASE(5, 5, false, 1, 8, 4) GV_PHASE_CASE(5, 5, false, 1, 4, 6)
-    GV_PHASE_CASE(5, 10, false, 1, 4, 2)
+    GV_PHASE_CASE_L(5, 10, false, 1, 4, 2, true)
     GV_PHASE_CASE(5, 5, true, 1, 8, 4) GV_PHASE_CASE(5, 5, true, 1, 4, 6)
-    GV_PHASE_CASE(10, 5, true, 1, 3, 3)
+    GV_PHASE_CASE_L(10, 5, true, 1, 8, 2, true) GV_PHASE_CASE(10, 5, true, 1, 3, 3)
 #undef GV_PHASE_CASE
+#undef GV_PHASE_CASE_L
     GV_REQUIRE(rc != -1000, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate_phases: no instantiation for blocks %dx%d trans=%d", blk_in,
                blk_out, transpose_w);
     if (rc != GV_OK) return rc;
