@@ -66,6 +66,22 @@ __global__ void k_items_fill_packed(const int* rowptr, int n_seg, int chunk, con
     if (nch > 1 && o.c < fix_cap) fix[o.c] = make_int4(s, o.b, nch, 0);
 }
 
+__global__ void k_gather3_i32(const int* s1, int* o1, const int* s2, int* o2, const int* s3, int* o3, const int* idx, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int j = idx ? idx[i] : (int)i;
+    o1[i] = s1[j];
+    if (s2) o2[i] = s2[j];
+    if (s3) o3[i] = s3[j];
+}
+
+// two fills in one launch (the -1 padding of the work-item and fix-up lists)
+__global__ void k_fill2_u32(unsigned* p1, long long n1, unsigned* p2, long long n2, unsigned v) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2; i += (long long)gridDim.x * 256) {
+        if (i < n1) p1[i] = v; else p2[i - n1] = v;
+    }
+}
+
 __global__ void k_gather_i32(const int* src, const int* idx, int* out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = idx ? src[idx[i]] : src[i];
@@ -170,8 +186,12 @@ int order_and_items(const int* keys, int64_t n, int n_seg, int chunk, int* perm,
         hipLaunchKernelGGL(k_lower_bounds<unsigned short>, dim3((n_seg + 1 + 255) / 256), dim3(256), 0, st, sorted16, n, n_seg, rowptr);
     else
         hipLaunchKernelGGL(k_lower_bounds<int>, dim3((n_seg + 1 + 255) / 256), dim3(256), 0, st, sorted, n, n_seg, rowptr);
-    GV_HIP_OK(fill_words(items, 0xFFFFFFFFu, (size_t)items_cap * 16, st), "gv index: fill items");
-    GV_HIP_OK(fill_words(fix, 0xFFFFFFFFu, (size_t)fix_cap * 16, st), "gv index: fill fix");
+    {
+        const long long n1 = (long long)items_cap * 4, n2 = (long long)fix_cap * 4;
+        const unsigned blocks = (unsigned)((n1 + n2 + 255) / 256 > 4096 ? 4096 : (n1 + n2 + 255) / 256);
+        if (n1 + n2 > 0)
+            hipLaunchKernelGGL(k_fill2_u32, dim3(blocks), dim3(256), 0, st, (unsigned*)items, n1, (unsigned*)fix, n2, 0xFFFFFFFFu);
+    }
     if (n_seg > 0) {
         hipLaunchKernelGGL(k_item_counts, dim3((n_seg + 255) / 256), dim3(256), 0, st, rowptr, n_seg, chunk, sc.counts);
         size_t tb = sc.cub_bytes;
@@ -186,6 +206,10 @@ int order_and_items(const int* keys, int64_t n, int n_seg, int chunk, int* perm,
 
 inline void gather(const int* src, const int* idx, int* out, int64_t n, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(k_gather_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, idx, out, n);
+}
+// up to three arrays through the same permutation in one launch (s2 / s3 may be NULL)
+inline void gather3(const int* s1, int* o1, const int* s2, int* o2, const int* s3, int* o3, const int* idx, int64_t n, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_gather3_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s1, o1, s2, o2, s3, o3, idx, n);
 }
 
 }  // namespace
@@ -260,8 +284,7 @@ extern "C" int gv_relation_index_build(const int32_t* src, const int32_t* dst, c
     gather(etype, perm_s, et_by_src, n_edges, st);
     int rc = order_and_items(etype, n_edges, n_rel, chunk, perm_r, rowptr_r, items_r, items_cap, fix_r, fix_cap, sc, st);
     if (rc != GV_OK) return rc;
-    gather(src, perm_r, src_by_rel, n_edges, st);
-    gather(dst, perm_r, dst_by_rel, n_edges, st);
+    gather3(src, src_by_rel, dst, dst_by_rel, nullptr, nullptr, perm_r, n_edges, st);
     return launch_status("gv_relation_index_build");
 }
 
@@ -292,16 +315,13 @@ extern "C" int gv_triplet_index_build(const int32_t* trip, int64_t T, int n_ent,
         hipLaunchKernelGGL(k_triplet_incidence, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, trip, T, ent, other, rel2, tid);
     int rc = order_and_items(ent, n2, n_ent, chunk, perm, rowptr_inc, items_inc, items_inc_cap, fix_inc, fix_inc_cap, sc, st);
     if (rc != GV_OK) return rc;
-    gather(other, perm, inc_other, n2, st);
-    gather(rel2, perm, inc_rel, n2, st);
-    gather(tid, perm, inc_tid, n2, st);
+    gather3(other, inc_other, rel2, inc_rel, tid, inc_tid, perm, n2, st);
     // by relation: columns of the triplet list (reusing the incidence temporaries), stable sort by relation
     int* cs = ent; int* cr = other; int* co = rel2;
     if (T > 0) hipLaunchKernelGGL(k_triplet_columns, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, trip, T, cs, cr, co);
     rc = order_and_items(cr, T, n_rel, chunk_rel, rel_tid, rowptr_rel, items_rel, items_rel_cap, fix_rel, fix_rel_cap, sc, st);
     if (rc != GV_OK) return rc;
-    gather(cs, rel_tid, rel_s, T, st);
-    gather(co, rel_tid, rel_o, T, st);
+    gather3(cs, rel_s, co, rel_o, nullptr, nullptr, rel_tid, T, st);
     (void)col;
     return launch_status("gv_triplet_index_build");
 }
