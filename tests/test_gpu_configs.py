@@ -113,17 +113,17 @@ def test_c4_layer_full_size_h500_against_oracle(fin, fout):
     close(pg['h_bias'].grad, gpo['h_bias'], rtol=3e-4, atol_scale=3e-5, msg='grad_bias')
 
 
-@pytest.mark.parametrize('phases', ['0', 'auto'])
-def test_c5_scale_properties_and_sampled_rows(monkeypatch, phases):
+@pytest.mark.parametrize('phases,so', [('0', 2), ('auto', 2), ('auto', 4)])
+def test_c5_scale_properties_and_sampled_rows(monkeypatch, phases, so):
     """BASELINE configs[4] on ONE GPU: 1 M entities, 50 M directed edges, 2 000 relation types, emb_dim 200, B = 100
     (9-10 GiB).  The oracle cannot materialise this graph, so: (1) linearity of the aggregate in x, (2) invariance to the
     order the edges are handed in, (3) the backward-x aggregation as the adjoint of the forward one, (4) equality with
     the oracle on 256 sampled destination rows (the oracle on those rows' in-edges only).  phases = '0': per-row
-    kernels, 'auto': the relation-phase kernel (the 800 MB feature table is HBM scale)."""
+    kernels, 'auto': the relation-phase kernel (the 800 MB feature table is HBM scale); so = 4 runs layer 2's block shapes."""
     from gcn_vae_amd import ops
     from oracle import rgcn as orgcn
     monkeypatch.setattr(ops, 'K1_PHASES', phases)
-    n, e, r, nb, si, so = 1_000_000, 50_000_000, 2000, 100, 2, 2
+    n, e, r, nb, si = 1_000_000, 50_000_000, 2000, 100, 2          # so = 4: layer 2's 2x4 blocks (forward) / 4x2 (adjoint)
     dev = torch.device('cuda', 0)
     gen = torch.Generator(device=dev).manual_seed(0)
     src = (torch.rand(e, device=dev, generator=gen) ** 2 * n).long().clamp_(max=n - 1)
@@ -141,12 +141,13 @@ def test_c5_scale_properties_and_sampled_rows(monkeypatch, phases):
 
     def agg(g_, r_, xx, coef, trans=False):
         side = 'src' if trans else 'dst'
+        p, q = (so, si) if trans else (si, so)          # gathered / produced block width of this launch
         if use_ph:
-            ph = r_.phase_order(g_, side, nb, si, so)
-            return ops.bdd_aggregate_phases(ph, ph.coef(coef), xx, ops.pack_weight_phase(ph, w, nb, si, so), r, nb, si, so)
+            ph = r_.phase_order(g_, side, nb, p, q)
+            return ops.bdd_aggregate_phases(ph, ph.coef(coef), xx, ops.pack_weight_phase(ph, w, nb, p, q), r, nb, p, q)
         order = g_.by_src if trans else g_.by_dst
         return ops.bdd_aggregate(order.seg, g_.nbr_by_src if trans else g_.nbr_by_dst, r_.et_by_src if trans else r_.et_by_dst,
-                                 coef, order.perm, xx, w, nb, si, so, trans)
+                                 coef, order.perm, xx, w, nb, p, q, trans)
 
     a1, a2 = agg(gidx, ridx, x1, norm), agg(gidx, ridx, x2, norm)
     scale = float(a1.abs().max())
