@@ -355,7 +355,7 @@ bool phase_plan(int nb, int p, int q, bool trans, int k_req, PhasePlan* out) {
     if (!bpl || nb % bpl) return false;
     if (k_req && k_req != k) {
         if (trans && p == 10 && q == 5 && k_req == 3) { k = 3; u = 3; }      // the plain kernel, 3 rows per wave
-        else if (k_req != 4 || k < 4 || (trans && p == 10 && q == 5)) return false;       // the 8-row shapes also come with 4 rows per wave
+        else if (k_req != 4 || k < 4) return false;       // the 8-row shapes also come with 4 rows per wave
         else {
             k = k_req;
             if (p == 5 && q == 5) u = 6;
@@ -478,7 +478,7 @@ extern "C" int gv_rgcn_bdd_aggregate_phases(const int32_t* off, const int32_t* n
     GV_PHASE_CASE(5, 5, false, 1, 8, 4) GV_PHASE_CASE(5, 5, false, 1, 4, 6)
     GV_PHASE_CASE_L(5, 10, false, 1, 4, 2, true)
     GV_PHASE_CASE(5, 5, true, 1, 8, 4) GV_PHASE_CASE(5, 5, true, 1, 4, 6)
-    GV_PHASE_CASE_L(10, 5, true, 1, 8, 2, true) GV_PHASE_CASE(10, 5, true, 1, 3, 3)
+    GV_PHASE_CASE_L(10, 5, true, 1, 8, 2, true) GV_PHASE_CASE_L(10, 5, true, 1, 4, 2, true) GV_PHASE_CASE(10, 5, true, 1, 3, 3)
 #undef GV_PHASE_CASE
 #undef GV_PHASE_CASE_L
     GV_REQUIRE(rc != -1000, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate_phases: no instantiation for blocks %dx%d trans=%d", blk_in,
