@@ -253,15 +253,16 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16(const float* __restrict__ 
                                                       const float* __restrict__ gld, float* __restrict__ gz_acc,
                                                       uint16_t* gnb, int ldb, uint16_t* gnt, int ldt, float* __restrict__ gxold,
                                                       int rows, int d) {
-    __shared__ uint16_t t[64][66];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;        // c0 runs over the 2d columns of [g_mu | g_alpha]
+    // one thread element = column c of [0, d): its g_mu goes to column c and its g_alpha to column d + c of g_net (one exp per
+    // element for both), two 64 x 64 LDS tiles for the two transposed copies
+    __shared__ uint16_t tm[64][66];
+    __shared__ uint16_t ta[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int rr = i >> 6, cc = i & 63;
-        const int r = r0 + rr, c2 = c0 + cc;
-        uint16_t v = 0;
-        if (r < rows && c2 < 2 * d) {
-            const bool alpha = c2 >= d;
-            const int c = alpha ? c2 - d : c2;
+        const int r = r0 + rr, c = c0 + cc;
+        uint16_t vm = 0, va = 0;
+        if (r < rows && c < d) {
             const size_t e = (size_t)r * d + c;
             const int cnt = colcount[c];
             const float g = gx[e];
@@ -274,19 +275,23 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16(const float* __restrict__ 
                 g_al += g_mu;
                 g_old = 0.f;
             }
-            if (!alpha) {
-                gz_acc[e] += g_z;
-                gxold[e] = g_old;
-            }
-            v = f2bf(alpha ? g_al : g_mu);
-            gnb[(size_t)r * ldb + c2] = v;
+            gz_acc[e] += g_z;
+            gxold[e] = g_old;
+            vm = f2bf(g_mu);
+            va = f2bf(g_al);
+            gnb[(size_t)r * ldb + c] = vm;
+            gnb[(size_t)r * ldb + d + c] = va;
         }
-        t[rr][cc] = v;
+        tm[rr][cc] = vm;
+        ta[rr][cc] = va;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int cc = i >> 6, rr = i & 63;
-        if (r0 + rr < rows && c0 + cc < 2 * d) gnt[(size_t)(c0 + cc) * ldt + r0 + rr] = t[rr][cc];
+        if (r0 + rr < rows && c0 + cc < d) {
+            gnt[(size_t)(c0 + cc) * ldt + r0 + rr] = tm[rr][cc];
+            gnt[(size_t)(d + c0 + cc) * ldt + r0 + rr] = ta[rr][cc];
+        }
     }
 }
 
@@ -417,7 +422,7 @@ extern "C" int gv_iaf_update_bwd_bf16(const float* z, const float* net, int ld_n
     GV_REQUIRE(z && net && colcount && gx && gz_accumulate && gnet_b && gnet_t && gx_old, GV_ERR_NULL,
                "gv_iaf_update_bwd_bf16: NULL pointer");
     GV_REQUIRE(ldb >= 2 * d && ldt >= n, GV_ERR_SHAPE, "gv_iaf_update_bwd_bf16: leading dimension too small");
-    hipLaunchKernelGGL(k_iaf_bwd_bf16, dim3((2 * d + 63) / 64, (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, z,
+    hipLaunchKernelGGL(k_iaf_bwd_bf16, dim3((d + 63) / 64, (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, z,
                        net, ld_net, colcount, gx, gld, gz_accumulate, gnet_b, ldb, gnet_t, ldt, gx_old, (int)n, d);
     return launch_status("gv_iaf_update_bwd_bf16");
 }
