@@ -1218,3 +1218,49 @@ def test_segmented_graph_replays_the_recorded_program(ops):
     x.add_(1.0)                                                  # and ordinary eager work still runs
     torch.cuda.synchronize()
     assert float(x.min()) == 4.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('m,n,k,a_f32', [(300, 200, 200, False), (300, 200, 200, True), (257, 400, 200, False), (64, 72, 64, True),
+                                         (130, 96, 456, False), (1000, 100, 224, True), (33, 64, 8, False), (90, 68, 40, False),
+                                         (70, 36, 232, True), (500, 132, 200, False)])
+def test_gemm_bf16_nt_every_epilogue_and_ragged_column_counts(ops, m, n, k, a_f32):
+    """gv_gemm_bf16_nt against fp32 matmul of the bf16-rounded operands (the semantics oracle/bf16.py states): ragged row /
+    column / depth counts around the 64-wide tiles, each epilogue output (fp32, fp32 accumulate, bf16, transposed bf16, bias,
+    ReLU, ReLU mask) and split-K."""
+    from oracle import bf16 as obf
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(m * 1000 + n)
+    a = torch.randn(m, k, generator=g)
+    b = torch.randn(n, k, generator=g) * 0.2
+    bias = torch.randn(n, generator=g)
+    maskv = torch.randn(m, n, generator=g)
+    ref = obf._r(a) @ obf._r(b).t()
+    a_d = a.to(dev) if a_f32 else a.to(dev).to(torch.bfloat16)
+    b_d = b.to(dev).to(torch.bfloat16)
+    ldt = (m + 3) // 4 * 4
+
+    def outs():
+        return (torch.full((m, n), 7.0, device=dev), torch.zeros(m, n, dtype=torch.bfloat16, device=dev),
+                torch.zeros(n, ldt, dtype=torch.bfloat16, device=dev))
+    # plain: fp32 + bf16 + transposed bf16
+    c, cb, ct = outs()
+    ops.gemm_bf16_nt(a_d, b_d, m, n, k, c_f32=c, c_bf16=cb, c_bf16_t=ct)
+    close(c, ref, rtol=1e-4, atol_scale=1e-5, msg='plain')
+    assert torch.equal(cb.float(), c.to(torch.bfloat16).float()) and torch.equal(ct[:, :m].float().t(), cb.float())
+    # bias + relu, accumulate
+    c, cb, ct = outs()
+    ops.gemm_bf16_nt(a_d, b_d, m, n, k, bias=bias.to(dev), relu=True, c_f32=c, accumulate=True)
+    close(c, torch.relu(ref + bias) + 7.0, rtol=1e-4, atol_scale=1e-5, msg='bias relu accumulate')
+    # ReLU mask (kept where mask > 0), every output
+    c, cb, ct = outs()
+    mk = maskv.to(dev).to(torch.bfloat16)
+    ops.gemm_bf16_nt(a_d, b_d, m, n, k, mask=mk, c_f32=c, c_bf16=cb, c_bf16_t=ct)
+    want = torch.where(mk.float().cpu() > 0, ref, torch.zeros(()))
+    close(c, want, rtol=1e-4, atol_scale=1e-5, msg='masked')
+    assert torch.equal(cb.float(), c.to(torch.bfloat16).float()) and torch.equal(ct[:, :m].float().t(), cb.float())
+    # split-K (fp32 result only), with accumulate
+    for split in (2, 3):
+        c = torch.full((m, n), -3.0, device=dev)
+        ops.gemm_bf16_nt(a_d, b_d, m, n, k, c_f32=c, accumulate=True, split_k=split)
+        close(c, ref - 3.0, rtol=1e-4, atol_scale=1e-5, msg=f'split-k {split}')
