@@ -1,0 +1,438 @@
+// K4 fused: the CHAIN of masked-MLP products of one MADE pass (kgvae/flow_network.py:85-98: x -> relu(W1 x + b1) -> ... ->
+// [mu | alpha]; and the backward-x chain g_L -> (g_L W_L) * [a_{L-1} > 0] -> ... -> g_x) in ONE launch.
+//
+// Why: at FB15k-237 size one product is 1.2 GFLOP over 14541 rows -- 12-20 us as its own launch, of which 6 us are fixed cost
+// (profiles/round2/made_gemm_ablation.txt) -- and a step with 3 IAF blocks holds ~140 of them in one dependency chain.  Here a
+// workgroup owns 64 rows for the WHOLE chain: the activations of a layer never leave the CU (two ping-pong LDS tiles
+// of 64 x K bf16), only the copies the backward pass needs are stored (bf16 row-major from the LDS tile, 16-B pieces; the
+// transposed bf16 copy as four consecutive rows of a column = one 8-B store), and they are stored by four extra STORE waves
+// while the eight MMA waves are already in the next layer: an MMA wave never has a store in flight (gfx950 counts loads and
+// stores in one in-order counter: a wait for a weight fragment behind a store waits for the store's round trip too).
+//
+// Operands: A fragments from LDS (conflict-free ds_read_b128: rows of LDK = 16 j + 8 elements); B fragments (the weights)
+// from a FRAGMENT-PACKED copy in global memory (gv_made_pack_weight: tile of 32 output columns x 16-deep step = 64 lanes x 16 B,
+// contiguous), loaded by the wave that owns the columns straight into registers -- no LDS traffic, no barrier for B.  A wave owns
+// 64 rows x 32 columns (2 accumulator tiles of v_mfma_f32_32x32x16_bf16, eight waves per workgroup: two per SIMD hide each other's waits).
+// The B fragments of the wave's NEXT unit (next 13 steps: next column tile, reduction chunk or layer) are requested at the start
+// of the current unit into a second register set: in flight for a whole unit of MFMAs + the epilogue + the barrier.
+//
+// Same arithmetic as gv_gemm_bf16_nt per product (operands rounded to bf16, k accumulated in 16-deep steps in order, fp32
+// accumulators, epilogue order bias -> ReLU -> mask -> stores): results are bit-identical to the launch-per-product path.
+#include "common.h"
+
+namespace gv {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int CH_BM = 64;        // rows per workgroup
+constexpr int CH_KS = 13;        // 16-deep steps per register set of B fragments (208 of k)
+constexpr int CH_MMA_WAVES = 7, CH_STORE_WAVES = 1;      // 8 waves: two per SIMD, 256 VGPRs each
+constexpr int CH_MMA_THREADS = CH_MMA_WAVES * 64, CH_STORE_THREADS = CH_STORE_WAVES * 64;
+constexpr int CH_THREADS = CH_MMA_THREADS + CH_STORE_THREADS;
+constexpr int CH_L = GV_CHAIN_MAX_LAYERS;
+
+struct ChainArgs {
+    const uint16_t* x;           // [m][ldx] bf16: input of layer 0
+    int ldx, m, n_layers, ldk, has_mask;
+    gv_chain_layer L[CH_L];
+};
+
+__device__ __forceinline__ uint16_t bf_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+
+struct ChainUnit { int l, tile, ch; };
+
+// successor of unit u in this wave's order (l == n_layers: none)
+__device__ __forceinline__ ChainUnit chain_next(const ChainArgs& p, int nl, ChainUnit u, int wave) {
+    const int ks = (p.L[u.l].k + 15) >> 4, nch = (ks + CH_KS - 1) / CH_KS;
+    if (u.ch + 1 < nch) return {u.l, u.tile, u.ch + 1};
+    if (u.tile + CH_MMA_WAVES < ((p.L[u.l].n + 31) >> 5)) return {u.l, u.tile + CH_MMA_WAVES, 0};
+    int l = u.l + 1;
+    while (l < nl && wave >= ((p.L[l].n + 31) >> 5)) ++l;
+    return {l, wave, 0};
+}
+
+// where the B fragments of unit u start (packed weight of its layer + this lane's 16-B slot of tile u.tile, step 13 u.ch)
+// and how many steps it has
+__device__ __forceinline__ void chain_unit_b(const ChainArgs& p, ChainUnit u, int lane, const uint4*& base, unsigned& off, int& ksc) {
+    const int ks = (p.L[u.l].k + 15) >> 4;
+    ksc = min(CH_KS, ks - u.ch * CH_KS);
+    base = reinterpret_cast<const uint4*>(p.L[u.l].w_packed);
+    off = (unsigned)((u.tile * ks + u.ch * CH_KS) * 64 + lane);
+}
+
+// One unit: up to 13 16-deep steps of a 64 x 32 accumulator block (two MFMAs per step share the B fragment).  Two register
+// sets of B fragments: at the start of a unit the set it consumes is fenced (its loads were issued a whole unit ago), THEN the
+// other set's loads for the wave's next unit are issued, then the steps run without a single vector-memory wait.  (Reloading a
+// fragment's registers right after its step needs one set only, but the compiler cannot count the loads in flight across the
+// unit loop and puts s_waitcnt vmcnt(0) -- a full L2 round trip -- in front of every step: 6 us per unit instead of 0.4.)
+// (the lane offset of the next loads passes through the fence too: otherwise the scheduler hoists them above it and the fence
+// waits for them as well; the offset, not the pointer -- a laundered pointer loses its address space and turns the loads into
+// flat ones, which count against the LDS counter too)
+__device__ __forceinline__ void chain_landed(uint4 (&q)[CH_KS], unsigned& next_b) {
+    asm volatile("" : "+v"(q[0].x), "+v"(q[1].x), "+v"(q[2].x), "+v"(q[3].x), "+v"(q[4].x), "+v"(q[5].x), "+v"(q[6].x),
+                 "+v"(q[7].x), "+v"(q[8].x), "+v"(q[9].x), "+v"(q[10].x), "+v"(q[11].x), "+v"(q[12].x), "+v"(next_b));
+}
+static_assert(CH_KS == 13, "chain_landed names every fragment");
+
+// all 13 loads, unconditionally (steps past the unit's last re-read its last fragment): a conditional load leaves a register
+// half-defined, and the compiler answers a set of those with copies and spills
+__device__ __forceinline__ void chain_issue(uint4 (&q)[CH_KS], const uint4* base, unsigned off, int ksc) {
+#pragma unroll
+    for (int s = 0; s < CH_KS; ++s) q[s] = base[off + min(s, ksc - 1) * 64];
+}
+
+// The A fragments of step s + 1 are read from LDS while the MFMAs of step s run; a scheduling barrier per step keeps the
+// compiler from hoisting all 26 fragment reads (104 registers) to the top.
+__device__ __forceinline__ void chain_mma(f32x16_t (&acc)[2], const uint4 (&q)[CH_KS], const uint16_t* a0, int ldk32, int ksc) {
+    bf16x8 c0 = *reinterpret_cast<const bf16x8*>(a0), c1 = *reinterpret_cast<const bf16x8*>(a0 + ldk32);
+#pragma unroll
+    for (int s = 0; s < CH_KS; ++s)
+        if (s < ksc) {
+            bf16x8 n0 = c0, n1 = c1;
+            if (s + 1 < CH_KS) {
+                n0 = *reinterpret_cast<const bf16x8*>(a0 + (s + 1) * 16);
+                n1 = *reinterpret_cast<const bf16x8*>(a0 + ldk32 + (s + 1) * 16);
+            }
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, q[s]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, b0, acc[1], 0, 0, 0);
+            c0 = n0;
+            c1 = n1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+// 64 rows x (cols / 8) 16-B pieces between global rows and an LDS tile; zero outside [0, m) x [0, cols)
+__device__ __forceinline__ void chain_stage(uint16_t* tile, int ldk, const uint16_t* src, int lds_, int m0, int m, int cols,
+                                            int cols_padded) {
+    const int ppr = cols_padded >> 3, total = CH_BM * ppr;
+    for (int base = 0; base < total; base += CH_THREADS * 4) {
+        uint4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = base + j * CH_THREADS + (int)threadIdx.x;
+            v[j] = make_uint4(0, 0, 0, 0);
+            if (idx < total) {
+                const int row = idx / ppr, kk = (idx - row * ppr) << 3;
+                if (m0 + row < m && kk < cols) v[j] = *reinterpret_cast<const uint4*>(src + (size_t)(m0 + row) * lds_ + kk);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = base + j * CH_THREADS + (int)threadIdx.x;
+            if (idx < total) {
+                const int row = idx / ppr, kk = (idx - row * ppr) << 3;
+                *reinterpret_cast<uint4*>(tile + row * ldk + kk) = v[j];
+            }
+        }
+    }
+}
+
+// MMA waves: accumulators -> bias, ReLU, mask -> bf16 into the LDS tile the next layer reads (the store waves copy it out);
+// only the LAST layer's fp32 result goes to memory from here (nothing waits behind those stores)
+__device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const gv_chain_layer& Ly, int tile, int m0, int m,
+                                               uint16_t* An, int ldk, int kp_next, const uint16_t* mbuf, const float* bias_l,
+                                               int r, int h) {
+    // opaque copies: without them the compiler hoists the per-row predicates and 64-bit offsets of all 32 rows out of the layer
+    // loop and pays for it with spills
+    asm volatile("" : "+v"(r), "+v"(h));
+    const int col = tile * 32 + r;
+    const bool cv = col < Ly.n;
+    const float bv = (Ly.bias && cv) ? bias_l[col] : 0.f;
+    float old[2][16];       // accumulate: all 32 previous values requested at once (one round trip, not 32)
+    if (Ly.out_f32 && Ly.accumulate) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                old[mt][i] = (cv && m0 + row < m) ? Ly.out_f32[(size_t)(m0 + row) * Ly.ldc + col] : 0.f;
+            }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * g + e, row = mt * 32 + e + 8 * g + 4 * h;
+                float v = acc[mt][i] + bv;
+                if (Ly.relu) v = fmaxf(v, 0.f);
+                if (Ly.mask && cv && (int16_t)mbuf[row * ldk + col] <= 0) v = 0.f;
+                if (Ly.out_f32 && cv && m0 + row < m) {
+                    Ly.out_f32[(size_t)(m0 + row) * Ly.ldc + col] = Ly.accumulate ? v + old[mt][i] : v;
+                }
+                if (col < kp_next) An[row * ldk + col] = cv ? bf_bits(v) : (uint16_t)0;
+            }
+            __builtin_amdgcn_sched_barrier(0);      // four rows at a time: the addresses of all 32 would cost 64 registers
+        }
+    }
+}
+
+// store wave: the bf16 copies of a layer's result out of its LDS tile -- row-major in 16-B pieces; transposed: a lane owns two
+// adjacent columns (4-B LDS reads, conflict-free across the lanes) and turns four consecutive rows into one 8-B store per
+// column.  Reads are issued in large batches: this single wave must not become the workgroup's critical path.
+__device__ __forceinline__ void chain_store(const gv_chain_layer& Ly, const uint16_t* An, int ldk, int m0, int m, int ts) {
+    const int n = Ly.n;
+    if (Ly.out_bf16) {
+        const int ppr = n >> 3, total = CH_BM * ppr;
+        for (int base = 0; base < total; base += CH_STORE_THREADS * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = base + j * CH_STORE_THREADS + ts;
+                const int row = idx / ppr, kk = (idx - row * ppr) << 3;
+                if (idx < total) v[j] = *reinterpret_cast<const uint4*>(An + row * ldk + kk);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = base + j * CH_STORE_THREADS + ts;
+                const int row = idx / ppr, kk = (idx - row * ppr) << 3;
+                if (idx < total && m0 + row < m) *reinterpret_cast<uint4*>(Ly.out_bf16 + (size_t)(m0 + row) * Ly.ldb + kk) = v[j];
+            }
+        }
+    }
+    if (Ly.out_bf16_t) {
+        const int half = ldk >> 1;          // LDS row pitch in 4-B words
+        for (int cp = ts; cp < (n >> 1); cp += CH_STORE_THREADS) {
+            const uint32_t* a = reinterpret_cast<const uint32_t*>(An) + cp;
+            uint16_t* o0 = Ly.out_bf16_t + (size_t)(2 * cp) * Ly.ldt + m0;
+            uint16_t* o1 = o0 + Ly.ldt;
+            uint32_t w[CH_BM];
+#pragma unroll
+            for (int row = 0; row < CH_BM; ++row) w[row] = a[row * half];
+#pragma unroll
+            for (int g = 0; g < CH_BM / 4; ++g) {
+                const int row = 4 * g;
+                const uint32_t w0 = w[row], w1 = w[row + 1], w2 = w[row + 2], w3 = w[row + 3];
+                const uint2 lo = make_uint2((w0 & 0xffffu) | (w1 << 16), (w2 & 0xffffu) | (w3 << 16));
+                const uint2 hi = make_uint2((w0 >> 16) | (w1 & 0xffff0000u), (w2 >> 16) | (w3 & 0xffff0000u));
+                if (m0 + row + 3 < m) {
+                    *reinterpret_cast<uint2*>(o0 + row) = lo;
+                    *reinterpret_cast<uint2*>(o1 + row) = hi;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+                        if (m0 + row + e < m) {
+                            o0[row + e] = (uint16_t)(w[row + e] & 0xffffu);
+                            o1[row + e] = (uint16_t)(w[row + e] >> 16);
+                        }
+                }
+            }
+        }
+    }
+}
+
+// Every wave walks its own list of units (layer, column tile, 13-step chunk) in ONE flat loop, unrolled by two so that the two
+// fragment register sets keep fixed roles (body A consumes qa and fills qb, body B the reverse: no copies at the back edge).
+// Between units a wave crosses layer boundaries; crossing layer l -> l + 1 is the same for every wave of the workgroup:
+//   barrier (layer l's tile complete)  ->  [mask of layer l + 1 staged by everyone, barrier]  ->  store wave: layer l's copies.
+__global__ __launch_bounds__(CH_THREADS) void k_made_chain(const ChainArgs p) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t chain_lds[];
+    const int ldk = p.ldk, nl = p.n_layers, m0 = blockIdx.x * CH_BM;
+    uint16_t* mbuf = chain_lds + 2 * CH_BM * ldk;
+    float* bias_lds = reinterpret_cast<float*>(chain_lds + (p.has_mask ? 3 : 2) * CH_BM * ldk);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const bool mma_wave = wave < CH_MMA_WAVES;
+
+    // the first B fragments of an MMA wave are requested before anything else
+    uint4 qa[CH_KS], qb[CH_KS];
+    ChainUnit u = {nl, wave, 0};
+    const uint4* const any_b = reinterpret_cast<const uint4*>(p.L[0].w_packed);      // a readable address for idle loads
+    {
+        const uint4* b0 = any_b;
+        unsigned off = lane;
+        int ksc = 1;
+        if (mma_wave) {
+            u.l = 0;
+            while (u.l < nl && wave >= ((p.L[u.l].n + 31) >> 5)) ++u.l;
+            if (u.l < nl) chain_unit_b(p, u, lane, b0, off, ksc);
+        }
+        chain_issue(qa, b0, off, ksc);
+    }
+    {       // every layer's bias into LDS (all loads in flight together): no global round trip in an epilogue
+        float bv[CH_L];
+        int off = 0;
+#pragma unroll
+        for (int l = 0; l < CH_L; ++l) {
+            bv[l] = 0.f;
+            if (l < nl && p.L[l].bias && (int)threadIdx.x < p.L[l].n) bv[l] = p.L[l].bias[threadIdx.x];
+        }
+#pragma unroll
+        for (int l = 0; l < CH_L; ++l)
+            if (l < nl) {
+                if ((int)threadIdx.x < p.L[l].n) bias_lds[off + threadIdx.x] = bv[l];
+                off += p.L[l].n;
+            }
+    }
+    chain_stage(chain_lds, ldk, p.x, p.ldx, m0, p.m, p.L[0].k, (p.L[0].k + 15) & ~15);
+    if (p.L[0].mask) chain_stage(mbuf, ldk, p.L[0].mask, p.L[0].ldmask, m0, p.m, p.L[0].n, p.L[0].n);
+    __syncthreads();
+
+    f32x16_t acc[2];
+    int layer = 0, bias_off = 0;
+
+    // cross layer boundaries until this wave stands in layer `target` (nl: past the last layer)
+#define CHAIN_CROSS(target)                                                                                              \
+    while (layer < (target)) {                                                                                          \
+        __syncthreads();                                                                                                \
+        if (layer + 1 < nl && p.L[layer + 1].mask) {                                                                    \
+            chain_stage(mbuf, ldk, p.L[layer + 1].mask, p.L[layer + 1].ldmask, m0, p.m, p.L[layer + 1].n, p.L[layer + 1].n); \
+            __syncthreads();                                                                                            \
+        }                                                                                                               \
+        if (!mma_wave && layer + 1 < nl)                                                                                \
+            chain_store(p.L[layer], chain_lds + ((layer + 1) & 1) * CH_BM * ldk, ldk, m0, p.m, (int)threadIdx.x - CH_MMA_THREADS); \
+        bias_off += p.L[layer].n;                                                                                       \
+        ++layer;                                                                                                        \
+    }
+
+    // one unit: QC holds its fragments (requested a unit ago), QF receives the next unit's
+#define CHAIN_UNIT(QC, QF)                                                                                               \
+    {                                                                                                                   \
+        const gv_chain_layer& Ly = p.L[u.l];                                                                            \
+        const int ks = (Ly.k + 15) >> 4, nch = (ks + CH_KS - 1) / CH_KS;                                                \
+        const ChainUnit nu = chain_next(p, nl, u, wave);                                                                \
+        const uint4* nb0 = any_b;                                                                                       \
+        unsigned noff = lane;                                                                                           \
+        int nksc = 1;                                                                                                   \
+        if (nu.l < nl) chain_unit_b(p, nu, lane, nb0, noff, nksc);                                                      \
+        chain_landed(QC, noff);                                                                                         \
+        chain_issue(QF, nb0, noff, nksc);                                                                               \
+        if (u.ch == 0) {                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;                                 \
+        }                                                                                                               \
+        const uint16_t* A = chain_lds + (u.l & 1) * CH_BM * ldk;                                                        \
+        chain_mma(acc, QC, A + r * ldk + 8 * h + u.ch * CH_KS * 16, 32 * ldk, min(CH_KS, ks - u.ch * CH_KS));           \
+        if (u.ch + 1 == nch)                                                                                            \
+            chain_epilogue(acc, Ly, u.tile, m0, p.m, chain_lds + ((u.l + 1) & 1) * CH_BM * ldk, ldk,                    \
+                           u.l + 1 < nl ? (Ly.n + 15) & ~15 : 0, mbuf, bias_lds + bias_off, r, h);                      \
+        u = nu;                                                                                                         \
+    }
+
+    for (;;) {
+        CHAIN_CROSS(u.l)
+        if (u.l >= nl) break;
+        CHAIN_UNIT(qa, qb)
+        CHAIN_CROSS(u.l)
+        if (u.l >= nl) break;
+        CHAIN_UNIT(qb, qa)
+    }
+#undef CHAIN_CROSS
+#undef CHAIN_UNIT
+}
+
+// packed[(t * ks + s) * 64 + lane][e] = bf16(B[32 t + (lane & 31)][16 s + 8 (lane >> 5) + e]), zero outside B;
+// forward: B = W [n][k]; backward: B = W^T [k][n] (its tiles run over k, its steps over n)
+__global__ __launch_bounds__(256) void k_pack_b_frag(const float* __restrict__ w, int ld, int n, int k, uint4* fwd, uint4* bwd) {
+    const int ks_f = (k + 15) >> 4, nt_f = (n + 31) >> 5, tot_f = nt_f * ks_f * 64;
+    const int ks_b = (n + 15) >> 4, nt_b = (k + 31) >> 5, tot_b = nt_b * ks_b * 64;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < tot_f + tot_b; idx += gridDim.x * 256) {
+        const bool is_b = idx >= tot_f;
+        const int j = is_b ? idx - tot_f : idx, ks = is_b ? ks_b : ks_f;
+        const int lane = j & 63, ts = j >> 6, s = ts % ks, t = ts / ks;
+        const int row = t * 32 + (lane & 31), c0 = s * 16 + 8 * (lane >> 5);
+        uint16_t b[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            float v = 0.f;
+            if (!is_b) { if (row < n && c < k) v = w[(size_t)row * ld + c]; }
+            else { if (row < k && c < n) v = w[(size_t)c * ld + row]; }
+            b[e] = bf_bits(v);
+        }
+        const uint4 o = make_uint4(b[0] | ((uint32_t)b[1] << 16), b[2] | ((uint32_t)b[3] << 16), b[4] | ((uint32_t)b[5] << 16),
+                                   b[6] | ((uint32_t)b[7] << 16));
+        if (is_b) { if (bwd) bwd[j] = o; }
+        else if (fwd) fwd[j] = o;
+    }
+}
+
+}  // namespace gv
+
+using namespace gv;
+
+/* bf16 elements of one packed copy of a [n][k] operand */
+extern "C" int64_t gv_made_pack_weight_elems(int n, int k) {
+    if (n <= 0 || k <= 0) return 0;
+    return (int64_t)((n + 31) / 32) * ((k + 15) / 16) * 64 * 8;
+}
+
+extern "C" int gv_made_pack_weight(const float* w, int ld, int n, int k, uint16_t* packed_fwd, uint16_t* packed_bwd, void* stream) {
+    GV_REQUIRE(n > 0 && k > 0 && ld >= k, GV_ERR_SHAPE, "gv_made_pack_weight: n=%d k=%d ld=%d", n, k, ld);
+    GV_REQUIRE(w && (packed_fwd || packed_bwd), GV_ERR_NULL, "gv_made_pack_weight: NULL pointer");
+    GV_REQUIRE((!packed_fwd || aligned16(packed_fwd)) && (!packed_bwd || aligned16(packed_bwd)), GV_ERR_ALIGN,
+               "gv_made_pack_weight: packed buffers must be 16-B aligned");
+    const int64_t total = (gv_made_pack_weight_elems(n, k) + gv_made_pack_weight_elems(k, n)) / 8;
+    hipLaunchKernelGGL(k_pack_b_frag, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ld, n, k,
+                       (uint4*)packed_fwd, (uint4*)packed_bwd);
+    return launch_status("gv_made_pack_weight");
+}
+
+/* bytes of LDS a chain needs (0: the chain does not fit this kernel) */
+static int chain_ldk(int n_layers, const gv_chain_layer* layers, bool* has_mask) {
+    int kmax = 0;
+    *has_mask = false;
+    for (int i = 0; i < n_layers; ++i) {
+        kmax = max(kmax, (layers[i].k + 15) & ~15);
+        if (layers[i].mask) { *has_mask = true; kmax = max(kmax, layers[i].n); }
+    }
+    int ldk = (kmax + 15) / 16 * 16 + 8;          // 16 j + 8 elements: 16-B fragment reads of 8 rows hit 32 distinct banks
+    return ldk;
+}
+
+extern "C" int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, void* stream) {
+    GV_REQUIRE(m >= 0 && n_layers >= 1 && n_layers <= GV_CHAIN_MAX_LAYERS, GV_ERR_SHAPE, "gv_made_chain: m=%d n_layers=%d", m, n_layers);
+    if (m == 0) return GV_OK;
+    GV_REQUIRE(x && layers, GV_ERR_NULL, "gv_made_chain: NULL pointer");
+    GV_REQUIRE(ldx % 8 == 0 && aligned16(x) && ldx >= layers[0].k, GV_ERR_ALIGN, "gv_made_chain: x rows must be 16-B aligned pieces (ldx=%d)", ldx);
+    ChainArgs p;
+    for (int i = 0; i < n_layers; ++i) {
+        const gv_chain_layer& L = layers[i];
+        GV_REQUIRE(L.n > 0 && L.k > 0 && L.n % 8 == 0 && L.k % 8 == 0 && L.n <= CH_THREADS && (i == 0 || L.k == layers[i - 1].n), GV_ERR_SHAPE,
+                   "gv_made_chain: layer %d is %d x %d (widths are multiples of 8, k = the previous layer's n)", i, L.n, L.k);
+        GV_REQUIRE(L.w_packed && aligned16(L.w_packed), GV_ERR_NULL, "gv_made_chain: layer %d has no packed weight", i);
+        GV_REQUIRE(L.out_bf16 || L.out_bf16_t || L.out_f32 || i + 1 < n_layers, GV_ERR_NULL, "gv_made_chain: the last layer stores nothing");
+        GV_REQUIRE(!(L.out_bf16 && i + 1 == n_layers), GV_ERR_SHAPE, "gv_made_chain: the last layer has no row-major bf16 output");
+        GV_REQUIRE((!L.mask || (L.ldmask >= L.n && L.ldmask % 8 == 0 && aligned16(L.mask))) &&
+                   (!L.out_bf16 || (L.ldb >= L.n && L.ldb % 8 == 0 && aligned16(L.out_bf16))) &&
+                   (!L.out_bf16_t || (L.ldt >= m && L.ldt % 4 == 0 && (reinterpret_cast<uintptr_t>(L.out_bf16_t) & 7u) == 0)) &&
+                   (!L.out_f32 || L.ldc >= L.n), GV_ERR_ALIGN, "gv_made_chain: layer %d: leading dimension / alignment", i);
+        p.L[i] = L;
+    }
+    bool has_mask;
+    const int ldk = chain_ldk(n_layers, layers, &has_mask);
+    size_t bias_floats = 0;
+    for (int i = 0; i < n_layers; ++i) bias_floats += (size_t)layers[i].n;
+    const size_t lds = (size_t)(has_mask ? 3 : 2) * CH_BM * ldk * sizeof(uint16_t) + bias_floats * sizeof(float);
+    GV_REQUIRE(lds <= 160 * 1024, GV_ERR_SHAPE, "gv_made_chain: layers this wide need %zu B of LDS (160 KB per CU)", lds);
+    p.x = x; p.ldx = ldx; p.m = m; p.n_layers = n_layers; p.ldk = ldk; p.has_mask = has_mask ? 1 : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_made_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("gv_made_chain: cannot raise the dynamic LDS limit");
+            return GV_ERR_SHAPE;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_made_chain, dim3((unsigned)((m + CH_BM - 1) / CH_BM)), dim3(CH_THREADS), lds, (hipStream_t)stream, p);
+    return launch_status("gv_made_chain");
+}
+
+/* 1 when gv_made_chain can run this chain (widths; LDS), 0 otherwise -- callers then launch product by product */
+extern "C" int gv_made_chain_fits(int n_layers, const int32_t* n_of_layer, const int32_t* k_of_layer, int any_mask) {
+    if (n_layers < 1 || n_layers > GV_CHAIN_MAX_LAYERS || !n_of_layer || !k_of_layer) return 0;
+    int kmax = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        if (n_of_layer[i] <= 0 || k_of_layer[i] <= 0 || n_of_layer[i] % 8 || k_of_layer[i] % 8 || n_of_layer[i] > 768) return 0;
+        if (i > 0 && k_of_layer[i] != n_of_layer[i - 1]) return 0;
+        kmax = max(kmax, (k_of_layer[i] + 15) & ~15);
+        if (any_mask) kmax = max(kmax, n_of_layer[i]);
+    }
+    const int ldk = (kmax + 15) / 16 * 16 + 8;
+    size_t bias_floats = 0;
+    for (int i = 0; i < n_layers; ++i) bias_floats += (size_t)n_of_layer[i];
+    return (size_t)(any_mask ? 3 : 2) * CH_BM * ldk * 2 + bias_floats * 4 <= 160 * 1024 ? 1 : 0;
+}

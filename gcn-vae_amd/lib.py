@@ -57,6 +57,10 @@ SIGNATURES = {
     'gv_iaf_update_fwd_bf16': (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _L, _I, _P]),
     'gv_iaf_update_bwd_bf16': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _L, _I, _P]),
     'gv_rowsum_bf16': (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
+    'gv_made_pack_weight_elems': (_L, [_I, _I]),
+    'gv_made_pack_weight': (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    'gv_made_chain_fits': (_I, [_I, _P, _P, _I]),
+    'gv_made_chain': (_I, [_P, _I, _I, _I, _P, _P]),
     'gv_rel_rows_gemm': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
     'gv_rel_gradw_gemm': (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
     'gv_rank_scores': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -2408,6 +2408,51 @@ def gemm_bf16_nt(a, b, m, n, k, bias=None, relu=False, mask=None, c_f32=None, ac
              split_k, ptr(ws), ws_bytes, lib.stream())
 
 
+class _ChainLayer(_ct.Structure):
+    """gv_chain_layer of include/gcnvae.h."""
+    _fields_ = [('w_packed', _ct.c_void_p), ('bias', _ct.c_void_p), ('mask', _ct.c_void_p), ('out_bf16', _ct.c_void_p),
+                ('out_bf16_t', _ct.c_void_p), ('out_f32', _ct.c_void_p), ('n', _ct.c_int32), ('k', _ct.c_int32),
+                ('relu', _ct.c_int32), ('accumulate', _ct.c_int32), ('ldmask', _ct.c_int32), ('ldb', _ct.c_int32),
+                ('ldt', _ct.c_int32), ('ldc', _ct.c_int32)]
+
+
+MADE_CHAIN = _os.environ.get('GV_MADE_CHAIN', '1') == '1'
+
+
+def made_pack_weight(w, fwd=True, bwd=True):
+    """Both fragment-packed bf16 copies of a fp32 weight W (n, k): for B = W (a forward layer) and B = W^T (backward-x)."""
+    w, ld = _row_major(w, 'w')
+    n, k = w.shape
+    l = lib.load()
+    pf = torch.empty(int(l.gv_made_pack_weight_elems(n, k)), dtype=torch.bfloat16, device=w.device) if fwd else None
+    pb = torch.empty(int(l.gv_made_pack_weight_elems(k, n)), dtype=torch.bfloat16, device=w.device) if bwd else None
+    lib.call('gv_made_pack_weight', ptr(w), ld, n, k, ptr(pf), ptr(pb), lib.stream())
+    return pf, pb
+
+
+def made_chain_fits(widths_n, widths_k, any_mask):
+    nl = len(widths_n)
+    arr_n = (_ct.c_int32 * nl)(*[int(v) for v in widths_n])
+    arr_k = (_ct.c_int32 * nl)(*[int(v) for v in widths_k])
+    return bool(lib.load().gv_made_chain_fits(nl, _ct.addressof(arr_n), _ct.addressof(arr_k), 1 if any_mask else 0))
+
+
+def made_chain(x, m, layers):
+    """One launch for a chain of NT products (gv_made_chain): layers = dicts with w_packed, n, k and optional bias, relu, mask,
+    out_bf16, out_bf16_t, out_f32, accumulate.  Row strides are taken from the tensors."""
+    arr = (_ChainLayer * len(layers))()
+    for c, d in zip(arr, layers):
+        mask, ob, ot, of = d.get('mask'), d.get('out_bf16'), d.get('out_bf16_t'), d.get('out_f32')
+        c.w_packed, c.bias, c.mask = ptr(d['w_packed']), ptr(d.get('bias')), ptr(mask)
+        c.out_bf16, c.out_bf16_t, c.out_f32 = ptr(ob), ptr(ot), ptr(of)
+        c.n, c.k, c.relu, c.accumulate = int(d['n']), int(d['k']), 1 if d.get('relu') else 0, 1 if d.get('accumulate') else 0
+        c.ldmask = mask.stride(0) if mask is not None else 0
+        c.ldb = ob.stride(0) if ob is not None else 0
+        c.ldt = ot.stride(0) if ot is not None else 0
+        c.ldc = of.stride(0) if of is not None else 0
+    lib.call('gv_made_chain', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), lib.stream())
+
+
 class _MADEForwardBF16(torch.autograd.Function):
     """MADE.forward (kgvae/flow_network.py:85-98) with bf16 operands in MEMORY (BASELINE configs[2]; semantics as the
     tests' CPU emulation pins them: operands rounded to bf16, fp32 products and sums).  Same structure as _MADEForward -- pass 0 on one
@@ -2432,10 +2477,16 @@ class _MADEForwardBF16(torch.autograd.Function):
         npad = _pad8(n)
         widths = [w.shape[0] for w in ws]                       # layer output widths; inputs: d, then widths[:-1]
         # weights: bf16 (out, in) and bf16 transposed (in, out), once per call
-        wbf = [torch.empty(w.shape[0], _pad8(w.shape[1]), **bf) for w in ws]
-        wbt = [torch.empty(w.shape[1], _pad8(w.shape[0]), **bf) for w in ws]
-        for w, a_, t_ in zip(ws, wbf, wbt):
-            cast_bf16(w, a_, t_)
+        chain = (MADE_CHAIN and S > 0 and L <= 8 and made_chain_fits(widths, [w.shape[1] for w in ws], False)
+                 and made_chain_fits([w.shape[1] for w in reversed(ws)], [w.shape[0] for w in reversed(ws)], True))
+        if chain:       # one launch per pass: fragment-packed weights (forward and transposed form from one launch per layer)
+            packed = [made_pack_weight(w) for w in ws]
+            wbf, wbt = [pk[0] for pk in packed], [pk[1] for pk in packed]
+        else:
+            wbf = [torch.empty(w.shape[0], _pad8(w.shape[1]), **bf) for w in ws]
+            wbt = [torch.empty(w.shape[1], _pad8(w.shape[0]), **bf) for w in ws]
+            for w, a_, t_ in zip(ws, wbf, wbt):
+                cast_bf16(w, a_, t_)
         xin = torch.empty(max(S, 1) * n, d, **f32)               # fp32 pass inputs (update pass-through, backward)
         xin_b = torch.empty(max(S, 1) * n, _pad8(d), **bf)
         xin_t = _empty_t_padded(d, max(S, 1), n, npad, bf)
@@ -2463,11 +2514,16 @@ class _MADEForwardBF16(torch.autograd.Function):
             sl = slice((p - 1) * n, p * n)
             tsl = slice((p - 1) * npad, (p - 1) * npad + n)
             inp = xin_b[sl]
-            for l in range(L - 1):
-                gemm_bf16_nt(inp, wbf[l], n, widths[l], ws[l].shape[1], bias=bs[l], relu=True, c_bf16=acts_b[l][sl],
-                             c_bf16_t=acts_t[l][:, tsl])
-                inp = acts_b[l][sl]
-            gemm_bf16_nt(inp, wbf[L - 1], n, widths[L - 1], ws[L - 1].shape[1], bias=bs[L - 1], c_f32=net_out[sl])
+            if chain:
+                made_chain(inp, n, [dict(w_packed=wbf[l], n=widths[l], k=ws[l].shape[1], bias=bs[l], relu=True,
+                                         out_bf16=acts_b[l][sl], out_bf16_t=acts_t[l][:, tsl]) for l in range(L - 1)] +
+                           [dict(w_packed=wbf[L - 1], n=widths[L - 1], k=ws[L - 1].shape[1], bias=bs[L - 1], out_f32=net_out[sl])])
+            else:
+                for l in range(L - 1):
+                    gemm_bf16_nt(inp, wbf[l], n, widths[l], ws[l].shape[1], bias=bs[l], relu=True, c_bf16=acts_b[l][sl],
+                                 c_bf16_t=acts_t[l][:, tsl])
+                    inp = acts_b[l][sl]
+                gemm_bf16_nt(inp, wbf[L - 1], n, widths[L - 1], ws[L - 1].shape[1], bias=bs[L - 1], c_f32=net_out[sl])
             update(net_out[sl], 2 * d, xin[sl], colcount[p], p)
         log_det = torch.empty(n, **f32)
         if P > 1:
@@ -2476,6 +2532,7 @@ class _MADEForwardBF16(torch.autograd.Function):
             log_det = acts0[L - 1][:, d:].sum(dim=1).expand(n).contiguous()
         ctx.save_for_backward(z, colcount, xin_t, zero_row, net_out, *acts_b, *acts_t, *acts0, *wbt, *ws)
         ctx.L = L
+        ctx.chain = chain
         ctx.has_bias = [b is not None for b in bs]
         return x_out, log_det
 
@@ -2514,10 +2571,16 @@ class _MADEForwardBF16(torch.autograd.Function):
             lib.call('gv_iaf_update_bwd_bf16', ptr(z), ptr(net_out[sl]), 2 * d, ptr(colcount[p]), ptr(g_cur),
                      ptr(gld) if p == P - 1 else None, ptr(g_z), ptr(gm_b[L - 1][sl]), gm_b[L - 1].stride(0),
                      ptr(gm_t[L - 1][:, tsl]), gm_t[L - 1].stride(0), ptr(g_old), n, d, st)
-            for l in reversed(range(1, L)):      # g_{l-1} = (g_l W_l) * [a_{l-1} > 0]
-                gemm_bf16_nt(gm_b[l][sl], wbt[l], n, widths[l - 1], widths[l], mask=acts_b[l - 1][sl], c_bf16=gm_b[l - 1][sl],
-                             c_bf16_t=gm_t[l - 1][:, tsl])
-            gemm_bf16_nt(gm_b[0][sl], wbt[0], n, d, widths[0], c_f32=g_old, accumulate=True)
+            if ctx.chain:                        # g_{l-1} = (g_l W_l) * [a_{l-1} > 0] down to g_x, one launch
+                made_chain(gm_b[L - 1][sl], n,
+                           [dict(w_packed=wbt[l], n=widths[l - 1], k=widths[l], mask=acts_b[l - 1][sl], out_bf16=gm_b[l - 1][sl],
+                                 out_bf16_t=gm_t[l - 1][:, tsl]) for l in reversed(range(1, L))] +
+                           [dict(w_packed=wbt[0], n=d, k=widths[0], out_f32=g_old, accumulate=True)])
+            else:
+                for l in reversed(range(1, L)):      # g_{l-1} = (g_l W_l) * [a_{l-1} > 0]
+                    gemm_bf16_nt(gm_b[l][sl], wbt[l], n, widths[l - 1], widths[l], mask=acts_b[l - 1][sl], c_bf16=gm_b[l - 1][sl],
+                                 c_bf16_t=gm_t[l - 1][:, tsl])
+                gemm_bf16_nt(gm_b[0][sl], wbt[0], n, d, widths[0], c_f32=g_old, accumulate=True)
             g_cur = g_old
         # pass 0: the update's gradient w.r.t. the broadcast net row is its column sum; x_old was the zero matrix
         g_net0 = torch.empty(n, 2 * d, **f32)

@@ -187,6 +187,34 @@ int gv_gemm_bf16_nt(const void* a, int a_is_f32, int lda, const uint16_t* b, int
 int gv_cast_bf16(const float* x, int ldx, int rows, int cols, uint16_t* y, int ldy, uint16_t* y_t, int ldt, void* stream);
 int64_t gv_rowsum_bf16_workspace_floats(int rows, int cols);
 int gv_rowsum_bf16(const uint16_t* x, int ld, int rows, int cols, float* out, int accumulate, float* workspace, void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * K4 fused: a CHAIN of such products in one launch -- the masked MLP of one MADE pass (kgvae/flow_network.py:85-98:
+ * x -> relu(W1 x + b1) -> ... -> [mu | alpha]) or its backward-x chain (g_L -> (g_L W_L) * [a_{L-1} > 0] -> ... -> g_x).
+ * A workgroup owns 64 rows for the whole chain; the activations stay in LDS between layers.  Layer i computes
+ *   y_i = epilogue_i(y_{i-1} @ B_i^T),  B_i [n][k] given FRAGMENT-PACKED (gv_made_pack_weight),  y_{-1} = x [m][ldx] bf16,
+ *   epilogue as gv_gemm_bf16_nt: + bias, ReLU, zero where mask <= 0; y_i is rounded to bf16 for the next layer (exactly what
+ *   the next gv_gemm_bf16_nt launch would read back) and stored to any of out_bf16 [m][ldb] (not on the last layer),
+ *   out_bf16_t [n][ldt] (transposed), out_f32 [m][ldc] (accumulate != 0: +=).  Results are bit-identical to the
+ *   launch-per-product path.  Widths are multiples of 8, layers[i].k == layers[i-1].n, at most GV_CHAIN_MAX_LAYERS layers,
+ *   (2 or, with a mask, 3) x 64 x (max width + 8..23) bf16 of LDS <= 160 KB (gv_made_chain_fits tells; GV_ERR_SHAPE otherwise).
+ * gv_made_pack_weight: both packings of one fp32 weight W [n][k] (row pitch ld), rounded to bf16: packed_fwd for B = W (forward
+ *   layer), packed_bwd for B = W^T (backward-x); either may be NULL.  Sizes: gv_made_pack_weight_elems(n, k) and (k, n) bf16
+ *   elements.  Layout: [tile of 32 B-rows][16-deep step][lane 0..63][8 bf16] = B[32 t + (lane & 31)][16 s + 8 (lane >> 5) + e],
+ *   zero outside B. */
+#define GV_CHAIN_MAX_LAYERS 8
+typedef struct gv_chain_layer {
+    const uint16_t* w_packed; /* B of this layer, fragment-packed */
+    const float* bias;        /* [n] or NULL */
+    const uint16_t* mask;     /* [m][ldmask] bf16 or NULL: the result is kept where mask > 0 */
+    uint16_t* out_bf16;       /* [m][ldb] or NULL */
+    uint16_t* out_bf16_t;     /* [n][ldt] or NULL */
+    float* out_f32;           /* [m][ldc] or NULL */
+    int32_t n, k, relu, accumulate, ldmask, ldb, ldt, ldc;
+} gv_chain_layer;
+int64_t gv_made_pack_weight_elems(int n, int k);
+int gv_made_pack_weight(const float* w, int ld, int n, int k, uint16_t* packed_fwd, uint16_t* packed_bwd, void* stream);
+int gv_made_chain_fits(int n_layers, const int32_t* n_of_layer, const int32_t* k_of_layer, int any_mask);
+int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, void* stream);
 
 /* Evaluation scorer with a fused rank count (replaces the (h, Eb, V) outer-product tensor + sort of
  * utils.perturb_and_get_rank / sort_and_rank, kgvae/utils.py:180-221): logit = q @ e^T + *bias is formed tile by tile on

@@ -1264,3 +1264,85 @@ def test_gemm_bf16_nt_every_epilogue_and_ragged_column_counts(ops, m, n, k, a_f3
         c = torch.full((m, n), -3.0, device=dev)
         ops.gemm_bf16_nt(a_d, b_d, m, n, k, c_f32=c, accumulate=True, split_k=split)
         close(c, ref - 3.0, rtol=1e-4, atol_scale=1e-5, msg=f'split-k {split}')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('m,widths,masked', [(300, [200, 200, 200, 400], False), (14541, [200, 200, 200, 200, 200, 400], False),
+                                             (257, [400, 200, 200, 200], True), (64, [72, 40, 136, 8], False),
+                                             (1, [8, 8], True), (130, [400, 264, 24, 200], True), (1000, [200, 400], False)])
+def test_made_chain_is_bit_identical_to_the_product_by_product_launches(ops, m, widths, masked):
+    """gv_made_chain (one launch for a chain of NT products, activations in LDS, fragment-packed weights) against the same
+    chain on gv_gemm_bf16_nt launches: every stored tensor bit for bit -- forward form (bias, ReLU, bf16 + transposed copies,
+    fp32 head) and backward form (ReLU masks of stored activations, accumulating fp32 tail) -- and against the fp32 matmul of
+    the bf16-rounded operands."""
+    from oracle import bf16 as obf
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(m + len(widths))
+    L = len(widths) - 1
+    x = torch.randn(m, widths[0], generator=g).to(dev).to(torch.bfloat16)
+    ws = [(torch.randn(widths[i + 1], widths[i], generator=g) * (1.5 / widths[i] ** 0.5)).to(dev) for i in range(L)]
+    bs = [None if masked else torch.randn(widths[i + 1], generator=g).to(dev) for i in range(L)]
+    masks = [torch.randn(m, widths[i + 1], generator=g).to(dev).to(torch.bfloat16) if masked else None for i in range(L)]
+    mp = (m + 7) // 8 * 8
+
+    def buffers():
+        ob = [torch.zeros(m, (widths[i + 1] + 7) // 8 * 8, dtype=torch.bfloat16, device=dev) for i in range(L - 1)]
+        ot = [torch.zeros(widths[i + 1], mp, dtype=torch.bfloat16, device=dev) for i in range(L - 1)]
+        of = torch.full((m, widths[L]), 0.25, device=dev)
+        return ob, ot, of
+    # product by product
+    ob1, ot1, of1 = buffers()
+    inp = x
+    for i in range(L):
+        wb = ws[i].to(torch.bfloat16)
+        last = i == L - 1
+        ops.gemm_bf16_nt(inp, wb, m, widths[i + 1], widths[i], bias=bs[i], relu=not masked and not last, mask=masks[i] if not last else None,
+                         c_f32=of1 if last else None, accumulate=last and masked, c_bf16=None if last else ob1[i],
+                         c_bf16_t=None if last else ot1[i])
+        inp = None if last else ob1[i]
+    # one launch
+    assert ops.made_chain_fits(widths[1:], widths[:-1], masked)
+    ob2, ot2, of2 = buffers()
+    layers = []
+    for i in range(L):
+        last = i == L - 1
+        pf, pb = ops.made_pack_weight(ws[i], bwd=False)
+        assert pb is None
+        layers.append(dict(w_packed=pf, n=widths[i + 1], k=widths[i], bias=bs[i], relu=not masked and not last,
+                           mask=masks[i] if not last else None, out_f32=of2 if last else None, accumulate=last and masked,
+                           out_bf16=None if last else ob2[i], out_bf16_t=None if last else ot2[i]))
+    ops.made_chain(x, m, layers)
+    torch.cuda.synchronize()
+    assert torch.equal(of1, of2)
+    for a, b in zip(ob1 + ot1, ob2 + ot2):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    # and the arithmetic itself
+    ref = x.float().cpu()
+    for i in range(L):
+        ref = ref @ obf._r(ws[i].cpu()).t()
+        if bs[i] is not None:
+            ref = ref + bs[i].cpu()
+        if i < L - 1:
+            ref = torch.relu(ref) if not masked else torch.where(masks[i].float().cpu() > 0, ref, torch.zeros(()))
+            ref = obf._r(ref)
+    close(of2, ref + (0.25 if masked else 0.0), rtol=2e-3, atol_scale=2e-3, msg='chain vs fp32 matmul of rounded operands')
+
+
+@pytest.mark.gpu
+def test_made_pack_weight_transposed_form_equals_packing_the_transpose(ops):
+    dev = torch.device('cuda:0')
+    w = torch.randn(136, 72, device=dev)
+    pf, pb = ops.made_pack_weight(w)
+    pt, _ = ops.made_pack_weight(w.t().contiguous(), bwd=False)
+    assert torch.equal(pb.view(torch.int16), pt.view(torch.int16))
+    # layout: [tile of 32 rows][16-deep step][lane][8]
+    ks = (72 + 15) // 16
+    frag = pf.view(-1, ks, 64, 8).float().cpu()
+    wb = w.to(torch.bfloat16).float().cpu()
+    for t, s, lane in ((0, 0, 0), (1, 2, 37), (4, 4, 63), (4, 4, 7)):
+        row, c0 = 32 * t + (lane & 31), 16 * s + 8 * (lane >> 5)
+        want = torch.zeros(8)
+        if row < 136:
+            seg = wb[row, c0:min(c0 + 8, 72)]
+            want[:seg.numel()] = seg
+        assert torch.equal(frag[t, s, lane], want), (t, s, lane)
