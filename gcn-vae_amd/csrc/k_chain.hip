@@ -5,9 +5,8 @@
 // (profiles/round2/made_gemm_ablation.txt) -- and a step with 3 IAF blocks holds ~140 of them in one dependency chain.  Here a
 // workgroup owns 64 rows for the WHOLE chain: the activations of a layer never leave the CU (two ping-pong LDS tiles
 // of 64 x K bf16), only the copies the backward pass needs are stored (bf16 row-major from the LDS tile, 16-B pieces; the
-// transposed bf16 copy as four consecutive rows of a column = one 8-B store), and they are stored by four extra STORE waves
-// while the eight MMA waves are already in the next layer: an MMA wave never has a store in flight (gfx950 counts loads and
-// stores in one in-order counter: a wait for a weight fragment behind a store waits for the store's round trip too).
+// transposed bf16 copy straight from the accumulators: 32 lanes = 32 consecutive rows of one column = 64 contiguous bytes per
+// store).  Seven MMA waves own the column tiles; an eighth wave copies the row-major tile out while they are in the next layer.
 //
 // Operands: A fragments from LDS (conflict-free ds_read_b128: rows of LDK = 16 j + 8 elements); B fragments (the weights)
 // from a FRAGMENT-PACKED copy in global memory (gv_made_pack_weight: tile of 32 output columns x 16-deep step = 64 lanes x 16 B,
@@ -95,8 +94,8 @@ __device__ __forceinline__ void chain_mma(f32x16_t (&acc)[2], const uint4 (&q)[C
                 n1 = *reinterpret_cast<const bf16x8*>(a0 + ldk32 + (s + 1) * 16);
             }
             const bf16x8 b0 = __builtin_bit_cast(bf16x8, q[s]);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, b0, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, c0, acc[0], 0, 0, 0);      // W fragment first: lane <-> row
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, c1, acc[1], 0, 0, 0);
             c0 = n0;
             c1 = n1;
             __builtin_amdgcn_sched_barrier(0);
@@ -129,97 +128,85 @@ __device__ __forceinline__ void chain_stage(uint16_t* tile, int ldk, const uint1
     }
 }
 
-// MMA waves: accumulators -> bias, ReLU, mask -> bf16 into the LDS tile the next layer reads (the store waves copy it out);
-// only the LAST layer's fp32 result goes to memory from here (nothing waits behind those stores)
+// MMA waves.  The weight fragment is the FIRST MFMA operand, so a lane owns ONE ROW of the tile (lane & 31, two accumulator
+// tiles = rows r and 32 + r) and its 16 registers are 4 groups of 4 consecutive columns (8 g + 4 (lane >> 5) + 0..3):
+//   next layer's LDS tile: one ds_write_b64 per group;  ReLU mask: one ds_read_b64 per group;  fp32 output: one 16-B store per
+//   group;  transposed bf16 copy: per register a 2-B store whose 32 lanes are 32 consecutive rows = 64 contiguous bytes.
 __device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const gv_chain_layer& Ly, int tile, int m0, int m,
                                                uint16_t* An, int ldk, int kp_next, const uint16_t* mbuf, const float* bias_l,
                                                int r, int h) {
-    // opaque copies: without them the compiler hoists the per-row predicates and 64-bit offsets of all 32 rows out of the layer
-    // loop and pays for it with spills
+    // opaque copies: without them the compiler hoists per-row predicates and 64-bit offsets out of the unit loop and spills
     asm volatile("" : "+v"(r), "+v"(h));
-    const int col = tile * 32 + r;
-    const bool cv = col < Ly.n;
-    const float bv = (Ly.bias && cv) ? bias_l[col] : 0.f;
-    float old[2][16];       // accumulate: all 32 previous values requested at once (one round trip, not 32)
-    if (Ly.out_f32 && Ly.accumulate) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                old[mt][i] = (cv && m0 + row < m) ? Ly.out_f32[(size_t)(m0 + row) * Ly.ldc + col] : 0.f;
-            }
-    }
+    float4 old[2][4];       // accumulate: all previous values requested at once (one round trip)
+    const bool acc_old = Ly.out_f32 && Ly.accumulate;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = 4 * g + e, row = mt * 32 + e + 8 * g + 4 * h;
-                float v = acc[mt][i] + bv;
-                if (Ly.relu) v = fmaxf(v, 0.f);
-                if (Ly.mask && cv && (int16_t)mbuf[row * ldk + col] <= 0) v = 0.f;
-                if (Ly.out_f32 && cv && m0 + row < m) {
-                    Ly.out_f32[(size_t)(m0 + row) * Ly.ldc + col] = Ly.accumulate ? v + old[mt][i] : v;
-                }
-                if (col < kp_next) An[row * ldk + col] = cv ? bf_bits(v) : (uint16_t)0;
-            }
-            __builtin_amdgcn_sched_barrier(0);      // four rows at a time: the addresses of all 32 would cost 64 registers
+            const int c0 = tile * 32 + 8 * g + 4 * h, row = mt * 32 + r;
+            old[mt][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (acc_old && c0 < Ly.n && m0 + row < m)
+                old[mt][g] = *reinterpret_cast<const float4*>(Ly.out_f32 + (size_t)(m0 + row) * Ly.ldc + c0);
         }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c0 = tile * 32 + 8 * g + 4 * h;       // widths are multiples of 8: a group is inside or outside as a whole
+        const bool cv = c0 < Ly.n;
+        const float4 bv = (Ly.bias && cv) ? *reinterpret_cast<const float4*>(bias_l + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int row = mt * 32 + r;
+            float v[4] = {acc[mt][4 * g] + bv.x, acc[mt][4 * g + 1] + bv.y, acc[mt][4 * g + 2] + bv.z, acc[mt][4 * g + 3] + bv.w};
+            if (Ly.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (Ly.mask && cv) {
+                const uint2 mv = *reinterpret_cast<const uint2*>(mbuf + row * ldk + c0);
+                if ((int16_t)(mv.x & 0xffff) <= 0) v[0] = 0.f;
+                if ((int16_t)(mv.x >> 16) <= 0) v[1] = 0.f;
+                if ((int16_t)(mv.y & 0xffff) <= 0) v[2] = 0.f;
+                if ((int16_t)(mv.y >> 16) <= 0) v[3] = 0.f;
+            }
+            if (Ly.out_f32 && cv && m0 + row < m) {
+                float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                if (acc_old) { o.x += old[mt][g].x; o.y += old[mt][g].y; o.z += old[mt][g].z; o.w += old[mt][g].w; }
+                *reinterpret_cast<float4*>(Ly.out_f32 + (size_t)(m0 + row) * Ly.ldc + c0) = o;
+            }
+            const uint16_t b0 = bf_bits(v[0]), b1 = bf_bits(v[1]), b2 = bf_bits(v[2]), b3 = bf_bits(v[3]);
+            if (c0 < kp_next)
+                *reinterpret_cast<uint2*>(An + row * ldk + c0) =
+                    cv ? make_uint2(b0 | ((uint32_t)b1 << 16), b2 | ((uint32_t)b3 << 16)) : make_uint2(0, 0);
+            if (Ly.out_bf16_t && cv && m0 + row < m) {
+                uint16_t* o = Ly.out_bf16_t + (size_t)c0 * Ly.ldt + m0 + row;
+                o[0] = b0;
+                o[Ly.ldt] = b1;
+                o[2 * (size_t)Ly.ldt] = b2;
+                o[3 * (size_t)Ly.ldt] = b3;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // one group at a time keeps the address registers few
     }
 }
 
-// store wave: the bf16 copies of a layer's result out of its LDS tile -- row-major in 16-B pieces; transposed: a lane owns two
-// adjacent columns (4-B LDS reads, conflict-free across the lanes) and turns four consecutive rows into one 8-B store per
-// column.  Reads are issued in large batches: this single wave must not become the workgroup's critical path.
+// store wave: the row-major bf16 copy of a layer's result out of its LDS tile, 16-B pieces, reads issued in batches of 8
 __device__ __forceinline__ void chain_store(const gv_chain_layer& Ly, const uint16_t* An, int ldk, int m0, int m, int ts) {
-    const int n = Ly.n;
-    if (Ly.out_bf16) {
-        const int ppr = n >> 3, total = CH_BM * ppr;
-        for (int base = 0; base < total; base += CH_STORE_THREADS * 8) {
-            uint4 v[8];
+    if (!Ly.out_bf16) return;
+    const int ppr = Ly.n >> 3, total = CH_BM * ppr;
+    for (int base = 0; base < total; base += CH_STORE_THREADS * 8) {
+        uint4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int idx = base + j * CH_STORE_THREADS + ts;
-                const int row = idx / ppr, kk = (idx - row * ppr) << 3;
-                if (idx < total) v[j] = *reinterpret_cast<const uint4*>(An + row * ldk + kk);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int idx = base + j * CH_STORE_THREADS + ts;
-                const int row = idx / ppr, kk = (idx - row * ppr) << 3;
-                if (idx < total && m0 + row < m) *reinterpret_cast<uint4*>(Ly.out_bf16 + (size_t)(m0 + row) * Ly.ldb + kk) = v[j];
-            }
+        for (int j = 0; j < 8; ++j) {
+            const int idx = min(base + j * CH_STORE_THREADS + ts, total - 1);      // unconditional: no half-defined registers
+            const int row = idx / ppr, kk = (idx - row * ppr) << 3;
+            v[j] = *reinterpret_cast<const uint4*>(An + row * ldk + kk);
         }
-    }
-    if (Ly.out_bf16_t) {
-        const int half = ldk >> 1;          // LDS row pitch in 4-B words
-        for (int cp = ts; cp < (n >> 1); cp += CH_STORE_THREADS) {
-            const uint32_t* a = reinterpret_cast<const uint32_t*>(An) + cp;
-            uint16_t* o0 = Ly.out_bf16_t + (size_t)(2 * cp) * Ly.ldt + m0;
-            uint16_t* o1 = o0 + Ly.ldt;
-            uint32_t w[CH_BM];
 #pragma unroll
-            for (int row = 0; row < CH_BM; ++row) w[row] = a[row * half];
-#pragma unroll
-            for (int g = 0; g < CH_BM / 4; ++g) {
-                const int row = 4 * g;
-                const uint32_t w0 = w[row], w1 = w[row + 1], w2 = w[row + 2], w3 = w[row + 3];
-                const uint2 lo = make_uint2((w0 & 0xffffu) | (w1 << 16), (w2 & 0xffffu) | (w3 << 16));
-                const uint2 hi = make_uint2((w0 >> 16) | (w1 & 0xffff0000u), (w2 >> 16) | (w3 & 0xffff0000u));
-                if (m0 + row + 3 < m) {
-                    *reinterpret_cast<uint2*>(o0 + row) = lo;
-                    *reinterpret_cast<uint2*>(o1 + row) = hi;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 3; ++e)
-                        if (m0 + row + e < m) {
-                            o0[row + e] = (uint16_t)(w[row + e] & 0xffffu);
-                            o1[row + e] = (uint16_t)(w[row + e] >> 16);
-                        }
-                }
-            }
+        for (int j = 0; j < 8; ++j) {
+            const int idx = base + j * CH_STORE_THREADS + ts;
+            const int row = idx / ppr, kk = (idx - row * ppr) << 3;
+            if (idx < total && m0 + row < m) *reinterpret_cast<uint4*>(Ly.out_bf16 + (size_t)(m0 + row) * Ly.ldb + kk) = v[j];
         }
     }
 }
@@ -397,8 +384,8 @@ extern "C" int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, co
         GV_REQUIRE(!(L.out_bf16 && i + 1 == n_layers), GV_ERR_SHAPE, "gv_made_chain: the last layer has no row-major bf16 output");
         GV_REQUIRE((!L.mask || (L.ldmask >= L.n && L.ldmask % 8 == 0 && aligned16(L.mask))) &&
                    (!L.out_bf16 || (L.ldb >= L.n && L.ldb % 8 == 0 && aligned16(L.out_bf16))) &&
-                   (!L.out_bf16_t || (L.ldt >= m && L.ldt % 4 == 0 && (reinterpret_cast<uintptr_t>(L.out_bf16_t) & 7u) == 0)) &&
-                   (!L.out_f32 || L.ldc >= L.n), GV_ERR_ALIGN, "gv_made_chain: layer %d: leading dimension / alignment", i);
+                   (!L.out_bf16_t || L.ldt >= m) &&
+                   (!L.out_f32 || (L.ldc >= L.n && L.ldc % 4 == 0 && aligned16(L.out_f32))), GV_ERR_ALIGN, "gv_made_chain: layer %d: leading dimension / alignment", i);
         p.L[i] = L;
     }
     bool has_mask;
