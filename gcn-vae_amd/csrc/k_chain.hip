@@ -102,29 +102,29 @@ __device__ __forceinline__ void chain_mma(f32x16_t (&acc)[2], const uint4 (&q)[C
         }
 }
 
-// 64 rows x (cols / 8) 16-B pieces between global rows and an LDS tile; zero outside [0, m) x [0, cols)
+// 64 rows x (cols / 8) 16-B pieces between global rows and an LDS tile; zero outside [0, m) x [0, cols).  (row, piece) advance
+// incrementally -- no integer division per piece.
 __device__ __forceinline__ void chain_stage(uint16_t* tile, int ldk, const uint16_t* src, int lds_, int m0, int m, int cols,
                                             int cols_padded) {
     const int ppr = cols_padded >> 3, total = CH_BM * ppr;
+    const int drow = CH_THREADS / ppr, dpc = CH_THREADS - drow * ppr;
+    int row = (int)threadIdx.x / ppr, pc = (int)threadIdx.x - row * ppr;
     for (int base = 0; base < total; base += CH_THREADS * 4) {
         uint4 v[4];
+        int rw[4], kk[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int idx = base + j * CH_THREADS + (int)threadIdx.x;
+            rw[j] = row;
+            kk[j] = pc << 3;
             v[j] = make_uint4(0, 0, 0, 0);
-            if (idx < total) {
-                const int row = idx / ppr, kk = (idx - row * ppr) << 3;
-                if (m0 + row < m && kk < cols) v[j] = *reinterpret_cast<const uint4*>(src + (size_t)(m0 + row) * lds_ + kk);
-            }
+            if (row < CH_BM && m0 + row < m && kk[j] < cols) v[j] = *reinterpret_cast<const uint4*>(src + (size_t)(m0 + row) * lds_ + kk[j]);
+            row += drow;
+            pc += dpc;
+            if (pc >= ppr) { pc -= ppr; ++row; }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int idx = base + j * CH_THREADS + (int)threadIdx.x;
-            if (idx < total) {
-                const int row = idx / ppr, kk = (idx - row * ppr) << 3;
-                *reinterpret_cast<uint4*>(tile + row * ldk + kk) = v[j];
-            }
-        }
+        for (int j = 0; j < 4; ++j)
+            if (rw[j] < CH_BM) *reinterpret_cast<uint4*>(tile + rw[j] * ldk + kk[j]) = v[j];
     }
 }
 
@@ -190,24 +190,29 @@ __device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const g
     }
 }
 
-// store wave: the row-major bf16 copy of a layer's result out of its LDS tile, 16-B pieces, reads issued in batches of 8
+// store wave: the row-major bf16 copy of a layer's result out of its LDS tile, 16-B pieces, reads issued in batches of 8.
+// (row, piece) advance incrementally: an integer division per piece would cost this single wave more than the copy itself
 __device__ __forceinline__ void chain_store(const gv_chain_layer& Ly, const uint16_t* An, int ldk, int m0, int m, int ts) {
     if (!Ly.out_bf16) return;
     const int ppr = Ly.n >> 3, total = CH_BM * ppr;
+    const int drow = CH_STORE_THREADS / ppr, dpc = CH_STORE_THREADS - drow * ppr;      // one step of 64 pieces
+    int row = ts / ppr, pc = ts - row * ppr;
     for (int base = 0; base < total; base += CH_STORE_THREADS * 8) {
         uint4 v[8];
+        int rw[8], kk[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int idx = min(base + j * CH_STORE_THREADS + ts, total - 1);      // unconditional: no half-defined registers
-            const int row = idx / ppr, kk = (idx - row * ppr) << 3;
-            v[j] = *reinterpret_cast<const uint4*>(An + row * ldk + kk);
+            rw[j] = min(row, CH_BM - 1);                  // unconditional reads: no half-defined registers
+            kk[j] = pc << 3;
+            v[j] = *reinterpret_cast<const uint4*>(An + rw[j] * ldk + kk[j]);
+            rw[j] = row;
+            row += drow;
+            pc += dpc;
+            if (pc >= ppr) { pc -= ppr; ++row; }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = base + j * CH_STORE_THREADS + ts;
-            const int row = idx / ppr, kk = (idx - row * ppr) << 3;
-            if (idx < total && m0 + row < m) *reinterpret_cast<uint4*>(Ly.out_bf16 + (size_t)(m0 + row) * Ly.ldb + kk) = v[j];
-        }
+        for (int j = 0; j < 8; ++j)
+            if (rw[j] < CH_BM && m0 + rw[j] < m) *reinterpret_cast<uint4*>(Ly.out_bf16 + (size_t)(m0 + rw[j]) * Ly.ldb + kk[j]) = v[j];
     }
 }
 
