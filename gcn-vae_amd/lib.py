@@ -61,6 +61,8 @@ SIGNATURES = {
     'gv_made_pack_weight': (_I, [_P, _I, _I, _I, _P, _P, _P]),
     'gv_made_chain_fits': (_I, [_I, _P, _P, _I]),
     'gv_made_chain': (_I, [_P, _I, _I, _I, _P, _P]),
+    'gv_made_row_fwd': (_I, [_P, _I, _P, _P]),
+    'gv_made_row_bwd': (_I, [_P, _I, _P, _P, _P]),
     'gv_rel_rows_gemm': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
     'gv_rel_gradw_gemm': (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
     'gv_rank_scores': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),

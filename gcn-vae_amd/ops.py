@@ -2376,13 +2376,18 @@ def _pad8(n):
     return (int(n) + 7) // 8 * 8
 
 
-def _empty_t_padded(width, passes, n, npad, kw):
-    """(width, passes*npad) transposed-copy buffer: only the pad columns [n, npad) of every pass are zeroed (they take part
-    in the weight-gradient reduction); the data columns are written by the producing kernels."""
-    t = torch.empty(width, passes * npad, **kw)
+def _empty_t_padded(widths, passes, n, npad, kw):
+    """Transposed-copy buffers (width_i, passes*npad), carved out of ONE allocation so that one fill zeroes the pad columns
+    [n, npad) of every pass of every buffer (they take part in the weight-gradient reduction); the data columns are written
+    by the producing kernels."""
+    t = torch.empty(sum(widths), passes * npad, **kw)
     if npad > n:
-        t.view(width, passes, npad)[:, :, n:].zero_()
-    return t
+        t.view(sum(widths), passes, npad)[:, :, n:].zero_()
+    out, o = [], 0
+    for w in widths:
+        out.append(t[o:o + w])
+        o += w
+    return out
 
 
 def cast_bf16(x, y=None, y_t=None):
@@ -2416,6 +2421,40 @@ class _ChainLayer(_ct.Structure):
                 ('ldt', _ct.c_int32), ('ldc', _ct.c_int32)]
 
 
+class _RowLayer(_ct.Structure):
+    """gv_row_layer of include/gcnvae.h."""
+    _fields_ = [('w', _ct.c_void_p), ('bias', _ct.c_void_p), ('act', _ct.c_void_p), ('inp', _ct.c_void_p), ('out', _ct.c_void_p),
+                ('gw', _ct.c_void_p), ('gb', _ct.c_void_p), ('n', _ct.c_int32), ('k', _ct.c_int32), ('ld', _ct.c_int32),
+                ('relu', _ct.c_int32), ('ldgw', _ct.c_int32), ('reserved', _ct.c_int32)]
+
+
+def _row_layers(layers):
+    arr = (_RowLayer * len(layers))()
+    for c, d in zip(arr, layers):
+        w, ld = _row_major(d['w'], 'w')
+        gw = d.get('gw')
+        c.w, c.ld, c.n, c.k = ptr(w), ld, w.shape[0], w.shape[1]
+        c.bias, c.act, c.inp, c.out = ptr(d.get('bias')), ptr(d.get('act')), ptr(d.get('inp')), ptr(d.get('out'))
+        c.gw, c.gb = ptr(gw), ptr(d.get('gb'))
+        c.relu = 1 if d.get('relu') else 0
+        c.ldgw = gw.stride(0) if gw is not None else 0
+    return arr
+
+
+def made_row_fwd(x, layers):
+    """The masked MLP on ONE row (MADE's pass 0), one single-workgroup launch: layers = dicts with w (n, k) and optional bias,
+    relu, out (n,)."""
+    arr = _row_layers(layers)
+    lib.call('gv_made_row_fwd', ptr(x), len(layers), _ct.addressof(arr), lib.stream())
+
+
+def made_row_bwd(g_out, layers, g_x=None):
+    """Backward of made_row_fwd: layers = dicts with w and optional act (ReLU mask), inp (the layer's input row), gw, gb."""
+    arr = _row_layers(layers)
+    lib.call('gv_made_row_bwd', ptr(g_out), len(layers), _ct.addressof(arr), ptr(g_x), lib.stream())
+
+
+MADE_ROW = _os.environ.get('GV_MADE_ROW', '1') == '1'
 MADE_CHAIN = _os.environ.get('GV_MADE_CHAIN', '1') == '1'
 
 
@@ -2489,17 +2528,23 @@ class _MADEForwardBF16(torch.autograd.Function):
                 cast_bf16(w, a_, t_)
         xin = torch.empty(max(S, 1) * n, d, **f32)               # fp32 pass inputs (update pass-through, backward)
         xin_b = torch.empty(max(S, 1) * n, _pad8(d), **bf)
-        xin_t = _empty_t_padded(d, max(S, 1), n, npad, bf)
+        tbufs = _empty_t_padded([d] + widths[:L - 1], max(S, 1), n, npad, bf)
+        xin_t = tbufs[0]
         acts_b = [torch.empty(max(S, 1) * n, _pad8(widths[l]), **bf) for l in range(L - 1)]
-        acts_t = [_empty_t_padded(widths[l], max(S, 1), n, npad, bf) for l in range(L - 1)]
+        acts_t = tbufs[1:]
         net_out = torch.empty(max(S, 1) * n, widths[L - 1], **f32)   # [mu | alpha] of every stacked pass
         x_out = torch.empty(n, d, **f32)
         # pass 0 on a single zero row (tiny: the generic GEMM with bf16-rounded operands)
         zero_row = torch.zeros(1, d, **f32)
-        acts0, inp = [], zero_row
-        for l in range(L):
-            inp = gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE, precision='bf16')
-            acts0.append(inp)
+        row = MADE_ROW and L <= 8 and d <= 512 and max(widths) <= 512 and all(w.shape[1] % 4 == 0 for w in ws)
+        if row:         # one single-workgroup launch for the whole row
+            acts0 = [torch.empty(1, widths[l], **f32) for l in range(L)]
+            made_row_fwd(None, [dict(w=ws[l], bias=bs[l], relu=l < L - 1, out=acts0[l]) for l in range(L)])
+        else:
+            acts0, inp = [], zero_row
+            for l in range(L):
+                inp = gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE, precision='bf16')
+                acts0.append(inp)
         def update(net, ld_net, x_old, cc, q):
             """The IAF update of one pass.  Its result is pass q + 1's input (slice q of the stacked buffers: fp32 + the bf16
             row-major and transposed copies the products read, written by the same launch) or, after the last pass, x_out."""
@@ -2533,6 +2578,7 @@ class _MADEForwardBF16(torch.autograd.Function):
         ctx.save_for_backward(z, colcount, xin_t, zero_row, net_out, *acts_b, *acts_t, *acts0, *wbt, *ws)
         ctx.L = L
         ctx.chain = chain
+        ctx.row = row
         ctx.has_bias = [b is not None for b in bs]
         return x_out, log_det
 
@@ -2559,7 +2605,7 @@ class _MADEForwardBF16(torch.autograd.Function):
         # ReLU-masked gradients w.r.t. every layer's pre-activation: bf16 row-major (operand of backward-x) and transposed
         # (operand of backward-W and of the bias sums)
         gm_b = [torch.empty(max(S, 1) * n, _pad8(widths[l]), **bf) for l in range(L)]
-        gm_t = [_empty_t_padded(widths[l], max(S, 1), n, npad, bf) for l in range(L)]
+        gm_t = _empty_t_padded(widths, max(S, 1), n, npad, bf)
         g_z = torch.zeros(n, d, **f32)
         gz_p = torch.empty(n, d, **f32)
         g_cur = gx
@@ -2590,11 +2636,19 @@ class _MADEForwardBF16(torch.autograd.Function):
         lib.call('gv_axpby', n * d, None, 1.0, ptr(gz_p), 1.0, ptr(g_z), st)
         g_row = colsum(g_net0).view(1, -1)
         rows0 = [None] * L
-        for l in reversed(range(L)):
-            rows0[l] = g_row
-            if l > 0:
-                mask = acts0[l] if l < L - 1 else None
-                g_row = gemm(g_row, ws[l], a_relu_mask=mask, precision='bf16')
+        row_gw = row_gb = None
+        if ctx.row:     # the row's whole backward chain (masked row gradients, outer products, bias gradients): one launch
+            row_gw = [torch.empty(widths[l], ws[l].shape[1], **f32) if ctx.needs_input_grad[2 + l] else None for l in range(L)]
+            row_gb = [torch.empty(widths[l], **f32) if ctx.has_bias[l] and ctx.needs_input_grad[2 + L + l] else None
+                      for l in range(L)]
+            made_row_bwd(g_row, [dict(w=ws[l], act=acts0[l] if l < L - 1 else None, inp=acts0[l - 1] if l > 0 else None,
+                                      gw=row_gw[l], gb=row_gb[l]) for l in range(L)])
+        else:
+            for l in reversed(range(L)):
+                rows0[l] = g_row
+                if l > 0:
+                    mask = acts0[l] if l < L - 1 else None
+                    g_row = gemm(g_row, ws[l], a_relu_mask=mask, precision='bf16')
         g_ws, g_bs = [], []
         mtot = max(S, 1) * npad
         for l in range(L):
@@ -2602,13 +2656,13 @@ class _MADEForwardBF16(torch.autograd.Function):
             inp0 = zero_row if l == 0 else acts0[l - 1]
             gw = gb = None
             if ctx.needs_input_grad[2 + l]:
-                gw = gemm(rows0[l], inp0, trans_a=True, a_relu_mask=mask0, precision='bf16')
+                gw = row_gw[l] if ctx.row else gemm(rows0[l], inp0, trans_a=True, a_relu_mask=mask0, precision='bf16')
                 if S > 0:       # dW_l = g_l^T a_{l-1}: the NT kernel on the transposed copies, reduction over all stacked rows
                     in_t = xin_t if l == 0 else acts_t[l - 1]
                     gemm_bf16_nt(gm_t[l], in_t, widths[l], ws[l].shape[1], mtot, c_f32=gw, accumulate=True,
                                  split_k=max(2, min(64, mtot // 2240)))
             if ctx.has_bias[l] and ctx.needs_input_grad[2 + L + l]:
-                gb = colsum(rows0[l], relu_mask=mask0)
+                gb = row_gb[l] if ctx.row else colsum(rows0[l], relu_mask=mask0)
                 if S > 0:
                     rws = torch.empty(int(lib.load().gv_rowsum_bf16_workspace_floats(widths[l], mtot)), **f32)
                     lib.call('gv_rowsum_bf16', ptr(gm_t[l]), gm_t[l].stride(0), widths[l], mtot, ptr(gb), 1, ptr(rws), st)

@@ -215,6 +215,27 @@ int64_t gv_made_pack_weight_elems(int n, int k);
 int gv_made_pack_weight(const float* w, int ld, int n, int k, uint16_t* packed_fwd, uint16_t* packed_bwd, void* stream);
 int gv_made_chain_fits(int n_layers, const int32_t* n_of_layer, const int32_t* k_of_layer, int any_mask);
 int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * K4, pass 0 of MADE (kgvae/flow_network.py:85-98): the first pass feeds the masked MLP an all-zero input, so every node sees
+ * the same ROW; the whole chain of 1 x k by k x n products is one single-workgroup launch.  Operands rounded to bf16, fp32
+ * products and sums (the precision of BASELINE configs[2]).
+ *   gv_made_row_fwd: y_l = act(y_{l-1} W_l^T + b_l); x = y_{-1} [k_0] (NULL: zeros); layer.out [n] receives y_l (fp32).
+ *   gv_made_row_bwd: g_out = dL/dy_last [n_last]; per layer gm = g * [act > 0] (act NULL: no mask), gb [n] = gm,
+ *     gw [n][ldgw] = gm^T inp (inp [k] = the layer's input row, NULL: zeros; gw is WRITTEN, not accumulated),
+ *     g_{l-1} = gm W_l; g_x [k_0] (may be NULL) receives the gradient of the input row.
+ * Widths <= 512, k % 4 == 0 and 16-B aligned rows (w, gw), layers[i].k == layers[i-1].n, at most GV_CHAIN_MAX_LAYERS layers. */
+typedef struct gv_row_layer {
+    const float* w;           /* [n][ld] fp32 (the mask already folded in) */
+    const float* bias;        /* [n] or NULL (forward) */
+    const float* act;         /* [n] or NULL: y_l of the forward pass, the ReLU mask of the backward pass */
+    const float* inp;         /* [k] or NULL: y_{l-1} (backward: the other factor of gw) */
+    float* out;               /* [n] or NULL (forward) */
+    float* gw;                /* [n][ldgw] or NULL (backward) */
+    float* gb;                /* [n] or NULL (backward) */
+    int32_t n, k, ld, relu, ldgw, reserved;
+} gv_row_layer;
+int gv_made_row_fwd(const float* x, int n_layers, const gv_row_layer* layers, void* stream);
+int gv_made_row_bwd(const float* g_out, int n_layers, const gv_row_layer* layers, float* g_x, void* stream);
 
 /* Evaluation scorer with a fused rank count (replaces the (h, Eb, V) outer-product tensor + sort of
  * utils.perturb_and_get_rank / sort_and_rank, kgvae/utils.py:180-221): logit = q @ e^T + *bias is formed tile by tile on

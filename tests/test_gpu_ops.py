@@ -1346,3 +1346,52 @@ def test_made_pack_weight_transposed_form_equals_packing_the_transpose(ops):
             seg = wb[row, c0:min(c0 + 8, 72)]
             want[:seg.numel()] = seg
         assert torch.equal(frag[t, s, lane], want), (t, s, lane)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('widths', [[200, 200, 200, 200, 200, 400], [16, 8, 32], [500, 512, 24, 400], [260, 300, 4, 256]])
+def test_made_row_chain_matches_bf16_operand_products(ops, widths):
+    """gv_made_row_fwd / gv_made_row_bwd (MADE's pass 0: the masked MLP on ONE row, one workgroup) against the same chain
+    written with fp32 matmuls of bf16-rounded operands (oracle/bf16.py's semantics): activations, the row gradients, the
+    outer-product weight gradients and the bias gradients."""
+    from oracle import bf16 as obf
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(sum(widths))
+    L = len(widths) - 1
+    ws = [(torch.randn(widths[i + 1], widths[i], generator=g) * (1.5 / widths[i] ** 0.5)) for i in range(L)]
+    bs = [torch.randn(widths[i + 1], generator=g) * 0.3 for i in range(L)]
+    x = torch.randn(1, widths[0], generator=g)
+    gy = torch.randn(1, widths[L], generator=g)
+    # reference
+    with obf.enabled():
+        xr = x.clone().requires_grad_(True)
+        wr = [w.clone().requires_grad_(True) for w in ws]
+        br = [b.clone().requires_grad_(True) for b in bs]
+        acts, inp = [], xr
+        for i in range(L):
+            inp = obf.linear(inp, wr[i], br[i])
+            if i < L - 1:
+                inp = torch.relu(inp)
+            acts.append(inp)
+        inp.backward(gy)
+    # device
+    wd = [w.to(dev) for w in ws]
+    outs = [torch.empty(1, widths[i + 1], device=dev) for i in range(L)]
+    ops.made_row_fwd(x.to(dev), [dict(w=wd[i], bias=bs[i].to(dev), relu=i < L - 1, out=outs[i]) for i in range(L)])
+    for i in range(L):
+        close(outs[i], acts[i].detach(), rtol=2e-3, atol_scale=2e-3, msg=f'y_{i}')
+    gws = [torch.full((widths[i + 1], widths[i]), 9.0, device=dev) for i in range(L)]
+    gbs = [torch.full((widths[i + 1],), 9.0, device=dev) for i in range(L)]
+    gx = torch.empty(1, widths[0], device=dev)
+    ops.made_row_bwd(gy.to(dev), [dict(w=wd[i], act=outs[i] if i < L - 1 else None, inp=outs[i - 1] if i > 0 else x.to(dev),
+                                       gw=gws[i], gb=gbs[i]) for i in range(L)], g_x=gx)
+    close(gx, xr.grad, rtol=5e-3, atol_scale=5e-3, msg='g_x')
+    for i in range(L):
+        close(gws[i], wr[i].grad, rtol=5e-3, atol_scale=5e-3, msg=f'gW_{i}')
+        close(gbs[i], br[i].grad, rtol=5e-3, atol_scale=5e-3, msg=f'gb_{i}')
+    # the all-zero input row of pass 0: x NULL, first layer's gw zero
+    ops.made_row_fwd(None, [dict(w=wd[i], bias=bs[i].to(dev), relu=i < L - 1, out=outs[i]) for i in range(L)])
+    close(outs[0], torch.relu(bs[0]).view(1, -1) if L > 1 else bs[0].view(1, -1), msg='zero row')
+    ops.made_row_bwd(gy.to(dev), [dict(w=wd[i], act=outs[i] if i < L - 1 else None, inp=outs[i - 1] if i > 0 else None,
+                                       gw=gws[i]) for i in range(L)])
+    assert float(gws[0].abs().max()) == 0.0
