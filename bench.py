@@ -38,6 +38,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MALL_GATHER_GBS = 8600.0  # indexed rows served from the Infinity Cache (same guide, "Indexed rows: gather into LDS")
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (same guide; AMD's 5 PFLOP/s headline includes 2:1 sparsity)
 L2_GATHER_GBS = 17800.0   # ... from an XCD's L2 (16.8-18.8 TB/s)
 
 # BASELINE.json configs[1..4]; c2 is the configuration the metric is quoted on
@@ -662,7 +663,7 @@ def main():
         edge_counts = [int(v) for v in ec.tolist()]
 
     # ---- roofline leg: the same step, eager, with HIP events around the K1 launches --------------
-    roofline, detail = None, {}
+    roofline, detail, k4 = None, {}, {}
     if rank == 0 and args.profile_steps > 0:
         lib.TIMER = lib.KernelTimer()
         if world == 1:
@@ -672,6 +673,19 @@ def main():
         ms = lib.TIMER.results_ms()
         lib.TIMER = None
         R = 2 * w['data'].num_rels
+        # K4 (the fused MADE pass, gv_made_chain): an MFMA kernel -- flops of one launch over its HIP-event time, against the
+        # dense bf16 MFMA peak of MI355X_MICROARCH.md.  At these sizes (1.2 GFLOP per product, 228 workgroups on 256 CUs) the
+        # launch is bound by its per-layer dependency chain, not by the matrix cores: the fraction says how far.
+        for tag in [t for t in ms if t.startswith('madechain')]:
+            vals = ms.pop(tag)
+            vals = vals[len(vals) // 3:] if len(vals) >= 3 else vals
+            avg_ms = float(np.mean(vals))
+            flops = _ops.MADE_CHAIN_FLOPS.get(tag, 0.0)
+            k4[tag] = {'avg_us': round(avg_ms * 1e3, 2), 'launches': len(vals), 'GFLOP': round(flops / 1e9, 3), 'bound': 'mfma',
+                       'achieved_TFLOPs': round(flops / 1e12 / (avg_ms * 1e-3), 1) if avg_ms > 0 else None,
+                       'peak_TFLOPs': BF16_MFMA_PEAK_TFLOPS}
+            if k4[tag]['achieved_TFLOPs']:
+                k4[tag]['frac'] = round(k4[tag]['achieved_TFLOPs'] / BF16_MFMA_PEAK_TFLOPS, 4)
         for tag, vals in sorted(ms.items()):
             vals = vals[len(vals) // 3:] if len(vals) >= 3 else vals     # drop the first (cold) third
             avg_ms = float(np.mean(vals))
@@ -736,7 +750,7 @@ def main():
                        'partition_probe_ms_per_step': {k: round(v, 4) for k, v in probe.items()} or None,
                        'row_partition_edges_per_rank': edge_counts},
             'final_loss': final_loss,
-            'roofline': roofline, 'roofline_detail': detail,
+            'roofline': roofline, 'roofline_detail': detail, 'roofline_k4': k4 or None,
         }
         out['cpu_baseline'], out['parity_check'] = None, None
         if world == 1 and not args.no_cpu_baseline:

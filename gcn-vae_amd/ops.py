@@ -2476,9 +2476,14 @@ def made_chain_fits(widths_n, widths_k, any_mask):
     return bool(lib.load().gv_made_chain_fits(nl, _ct.addressof(arr_n), _ct.addressof(arr_k), 1 if any_mask else 0))
 
 
-def made_chain(x, m, layers):
+MADE_CHAIN_FLOPS = {}        # tag -> flops of one launch (filled while a KernelTimer is installed: bench.py's K4 roofline line)
+
+
+def made_chain(x, m, layers, tag=None):
     """One launch for a chain of NT products (gv_made_chain): layers = dicts with w_packed, n, k and optional bias, relu, mask,
     out_bf16, out_bf16_t, out_f32, accumulate.  Row strides are taken from the tensors."""
+    if tag is not None and lib.TIMER is not None:
+        MADE_CHAIN_FLOPS[tag] = 2.0 * int(m) * sum(int(d['n']) * int(d['k']) for d in layers)
     arr = (_ChainLayer * len(layers))()
     for c, d in zip(arr, layers):
         mask, ob, ot, of = d.get('mask'), d.get('out_bf16'), d.get('out_bf16_t'), d.get('out_f32')
@@ -2489,7 +2494,7 @@ def made_chain(x, m, layers):
         c.ldb = ob.stride(0) if ob is not None else 0
         c.ldt = ot.stride(0) if ot is not None else 0
         c.ldc = of.stride(0) if of is not None else 0
-    lib.call('gv_made_chain', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), lib.stream())
+    lib.call('gv_made_chain', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), lib.stream(), tag=tag)
 
 
 class _MADEForwardBF16(torch.autograd.Function):
@@ -2562,7 +2567,8 @@ class _MADEForwardBF16(torch.autograd.Function):
             if chain:
                 made_chain(inp, n, [dict(w_packed=wbf[l], n=widths[l], k=ws[l].shape[1], bias=bs[l], relu=True,
                                          out_bf16=acts_b[l][sl], out_bf16_t=acts_t[l][:, tsl]) for l in range(L - 1)] +
-                           [dict(w_packed=wbf[L - 1], n=widths[L - 1], k=ws[L - 1].shape[1], bias=bs[L - 1], out_f32=net_out[sl])])
+                           [dict(w_packed=wbf[L - 1], n=widths[L - 1], k=ws[L - 1].shape[1], bias=bs[L - 1], out_f32=net_out[sl])],
+                           tag='madechain_fwd')
             else:
                 for l in range(L - 1):
                     gemm_bf16_nt(inp, wbf[l], n, widths[l], ws[l].shape[1], bias=bs[l], relu=True, c_bf16=acts_b[l][sl],
@@ -2621,7 +2627,7 @@ class _MADEForwardBF16(torch.autograd.Function):
                 made_chain(gm_b[L - 1][sl], n,
                            [dict(w_packed=wbt[l], n=widths[l - 1], k=widths[l], mask=acts_b[l - 1][sl], out_bf16=gm_b[l - 1][sl],
                                  out_bf16_t=gm_t[l - 1][:, tsl]) for l in reversed(range(1, L))] +
-                           [dict(w_packed=wbt[0], n=d, k=widths[0], out_f32=g_old, accumulate=True)])
+                           [dict(w_packed=wbt[0], n=d, k=widths[0], out_f32=g_old, accumulate=True)], tag='madechain_bwd')
             else:
                 for l in reversed(range(1, L)):      # g_{l-1} = (g_l W_l) * [a_{l-1} > 0]
                     gemm_bf16_nt(gm_b[l][sl], wbt[l], n, widths[l - 1], widths[l], mask=acts_b[l - 1][sl], c_bf16=gm_b[l - 1][sl],
