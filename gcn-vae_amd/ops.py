@@ -1690,11 +1690,22 @@ class _Mul(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mask, w):
         ctx.save_for_backward(mask)
+        ctx.direct = _direct(w)
+        _stamp_direct(ctx)
         return mul(mask, w)
 
     @staticmethod
     def backward(ctx, g):
         (mask,) = ctx.saved_tensors
+        _verify_direct(ctx)
+        tgt = ctx.direct
+        if tgt is not None and tgt.data_ptr() in GRAD_FRESH and tgt.is_contiguous():
+            # the weight's slice of the optimiser arena is still all-zero: the masked gradient is written straight into it
+            # (no temporary, no AccumulateGrad add)
+            g = _chk(g.contiguous(), name='grad')
+            lib.call('gv_mul', g.numel(), ptr(mask), ptr(g), ptr(tgt), lib.stream())
+            GRAD_FRESH.discard(tgt.data_ptr())
+            return None, None
         return None, mul(mask, g)
 
 
@@ -2585,6 +2596,8 @@ class _MADEForwardBF16(torch.autograd.Function):
         ctx.L = L
         ctx.chain = chain
         ctx.row = row
+        ctx.direct_b = [_direct(b) if b is not None else None for b in bs]
+        _stamp_direct(ctx)
         ctx.has_bias = [b is not None for b in bs]
         return x_out, log_det
 
@@ -2645,8 +2658,11 @@ class _MADEForwardBF16(torch.autograd.Function):
         row_gw = row_gb = None
         if ctx.row:     # the row's whole backward chain (masked row gradients, outer products, bias gradients): one launch
             row_gw = [torch.empty(widths[l], ws[l].shape[1], **f32) if ctx.needs_input_grad[2 + l] else None for l in range(L)]
-            row_gb = [torch.empty(widths[l], **f32) if ctx.has_bias[l] and ctx.needs_input_grad[2 + L + l] else None
-                      for l in range(L)]
+            # a bias whose slice of the optimiser arena is still all-zero takes its gradient there directly
+            _verify_direct(ctx)
+            direct_b = [t if (t is not None and t.data_ptr() in GRAD_FRESH and t.is_contiguous()) else None for t in ctx.direct_b]
+            row_gb = [(direct_b[l] if direct_b[l] is not None else torch.empty(widths[l], **f32))
+                      if ctx.has_bias[l] and ctx.needs_input_grad[2 + L + l] else None for l in range(L)]
             made_row_bwd(g_row, [dict(w=ws[l], act=acts0[l] if l < L - 1 else None, inp=acts0[l - 1] if l > 0 else None,
                                       gw=row_gw[l], gb=row_gb[l]) for l in range(L)])
         else:
@@ -2672,6 +2688,9 @@ class _MADEForwardBF16(torch.autograd.Function):
                 if S > 0:
                     rws = torch.empty(int(lib.load().gv_rowsum_bf16_workspace_floats(widths[l], mtot)), **f32)
                     lib.call('gv_rowsum_bf16', ptr(gm_t[l]), gm_t[l].stride(0), widths[l], mtot, ptr(gb), 1, ptr(rws), st)
+            if ctx.row and gb is not None and direct_b[l] is not None:
+                GRAD_FRESH.discard(gb.data_ptr())
+                gb = None
             g_ws.append(gw)
             g_bs.append(gb)
         return (g_z, None, *g_ws, *g_bs)

@@ -704,3 +704,56 @@ def test_train_driver_with_graph_step(tmp_path, capsys):
     assert out.count('Epoch 00') == 5 and 'training done' in out and 0.0 < best <= 1.0       # 3 warm-up steps + 5 replays = 8
     losses = [float(line.split('Loss ')[1].split(' |')[0]) for line in out.splitlines() if line.startswith('Epoch 00')]
     assert all(np.isfinite(losses)) and len(set(losses)) == len(losses)
+
+
+@pytest.mark.gpu
+def test_made_gradients_written_straight_into_the_optimiser_arena_equal_autograd():
+    """With FlatAdam registered, MaskedLinear's masked weight gradient and the bf16 MADE node's bias gradients are stored
+    straight into the (all-zero) arena slices instead of going through AccumulateGrad: same numbers as plain autograd, and a
+    second backward() without zero_grad() in between doubles them (the slices are then no longer 'fresh': accumulate)."""
+    from gcn_vae_amd import ops, sampling
+    from gcn_vae_amd.data import synthetic_kg
+    from gcn_vae_amd.encoders import KGVAE
+    from gcn_vae_amd.optim import FlatAdam
+    from gcn_vae_amd.train import LinkPredict
+    n, n_rel, h = 400, 8, 16
+    data = synthetic_kg(n, n_rel, 3000, seed=0)
+    g, rel, node_norm = sampling.build_test_graph(n, n_rel, data.train)
+    _, dst = g.edges()
+    node_id = torch.arange(n, device='cuda').view(-1, 1)
+    et = torch.from_numpy(rel).cuda()
+    enorm = torch.from_numpy(node_norm).cuda()[dst.cuda()].view(-1, 1).contiguous()
+    np.random.seed(0)
+    samples, labels = sampling.negative_sampling(data.train[:500], n, 3)
+    trip, lab = torch.from_numpy(samples).cuda(), torch.from_numpy(labels).cuda()
+    eps = torch.randn(n, h, generator=torch.Generator().manual_seed(1)).cuda()
+
+    def build():
+        torch.manual_seed(0)
+        net = LinkPredict(KGVAE, n, h, n_rel, num_bases=4, num_hidden_layers=2, dropout=0.0, use_cuda=True, reg_param=0.01,
+                          kl_param=1e-3, mmd_param=0.0, k=4, n_flows=2).cuda().train()
+        net.encoder.eps_override = eps
+        return net
+
+    def backward_once(net):
+        embed = net(g, node_id, et, enorm)
+        net.get_loss(g, embed, trip, lab)[0].backward()
+
+    with ops.gemm_precision('bf16'):
+        ref = build()
+        backward_once(ref)
+        want = {k: p.grad.detach().clone() for k, p in ref.named_parameters() if p.grad is not None}
+        net = build()
+        opt = FlatAdam([p for p in net.parameters() if p.requires_grad], lr=1e-3, max_grad_norm=1.0)
+        opt.zero_grad()
+        backward_once(net)
+        flow_keys = [k for k in want if 'flow' in k.lower() or 'made' in k.lower() or '.net.' in k]
+        assert flow_keys, sorted(want)
+        for k, p in net.named_parameters():
+            if k in want:
+                torch.testing.assert_close(p.grad, want[k], rtol=1e-5, atol=1e-7 * float(want[k].abs().max() + 1e-30), msg=k)
+        backward_once(net)
+        for k, p in net.named_parameters():
+            if k in want:
+                torch.testing.assert_close(p.grad, 2 * want[k], rtol=1e-5, atol=1e-7 * float(want[k].abs().max() + 1e-30), msg=k)
+        del opt
