@@ -295,6 +295,130 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16(const float* __restrict__ 
     }
 }
 
+// The same two updates with FOUR columns per thread (d % 4 == 0, 16-B aligned rows): 16-B loads and stores of the fp32 operands,
+// 8-B stores of the bf16 row-major copies, and the transposed copies leave the LDS tile as four consecutive rows of a column
+// per 8-B store (16 lanes = 128 contiguous bytes).  Same arithmetic, element by element, as the scalar kernels above.
+__device__ __forceinline__ void iaf_tile_out(const uint16_t (*t)[68], uint16_t* dst_t, int ldt, int r0, int c0, int rows, int d) {
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+        const int cc = i >> 4, rq = (i & 15) << 2;
+        if (c0 + cc >= d || r0 + rq >= rows) continue;
+        uint16_t* o = dst_t + (size_t)(c0 + cc) * ldt + r0 + rq;
+        const uint2 v = *reinterpret_cast<const uint2*>(&t[cc][rq]);
+        if (r0 + rq + 3 < rows) {
+            *reinterpret_cast<uint2*>(o) = v;
+        } else {
+            o[0] = (uint16_t)(v.x & 0xffff);
+            if (r0 + rq + 1 < rows) o[1] = (uint16_t)(v.x >> 16);
+            if (r0 + rq + 2 < rows) o[2] = (uint16_t)(v.y & 0xffff);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_iaf_fwd_bf16_v4(const float* __restrict__ z, const float* __restrict__ net, int ld_net,
+                                                         const float* __restrict__ xold, const int* __restrict__ colcount,
+                                                         float* __restrict__ xnew, uint16_t* xb, int ldb, uint16_t* xt, int ldt,
+                                                         int rows, int d) {
+    __shared__ __attribute__((aligned(8))) uint16_t t[64][68];          // [column][row]
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int cq = (threadIdx.x & 15) << 2, c = c0 + cq;
+    int4 cnt = make_int4(0, 0, 0, 0);
+    if (c < d) cnt = *reinterpret_cast<const int4*>(colcount + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rr = (threadIdx.x >> 4) + 16 * j, r = r0 + rr;
+        uint16_t b[4] = {0, 0, 0, 0};
+        if (r < rows && c < d) {
+            const size_t e = (size_t)r * d + c;
+            const float4 zv = *reinterpret_cast<const float4*>(z + e), ov = *reinterpret_cast<const float4*>(xold + e);
+            float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), al = mu;
+            if (cnt.x > 0 || cnt.y > 0 || cnt.z > 0 || cnt.w > 0) {
+                mu = *reinterpret_cast<const float4*>(net + (size_t)r * ld_net + c);
+                al = *reinterpret_cast<const float4*>(net + (size_t)r * ld_net + d + c);
+            }
+            float4 x;
+            x.x = cnt.x > 0 ? zv.x * expf(al.x + mu.x) : ov.x;
+            x.y = cnt.y > 0 ? zv.y * expf(al.y + mu.y) : ov.y;
+            x.z = cnt.z > 0 ? zv.z * expf(al.z + mu.z) : ov.z;
+            x.w = cnt.w > 0 ? zv.w * expf(al.w + mu.w) : ov.w;
+            *reinterpret_cast<float4*>(xnew + e) = x;
+            b[0] = f2bf(x.x); b[1] = f2bf(x.y); b[2] = f2bf(x.z); b[3] = f2bf(x.w);
+            *reinterpret_cast<uint2*>(xb + (size_t)r * ldb + c) = make_uint2(b[0] | ((uint32_t)b[1] << 16), b[2] | ((uint32_t)b[3] << 16));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[cq + e][rr] = b[e];
+    }
+    __syncthreads();
+    iaf_tile_out(t, xt, ldt, r0, c0, rows, d);
+}
+
+__global__ __launch_bounds__(256) void k_iaf_bwd_bf16_v4(const float* __restrict__ z, const float* __restrict__ net, int ld_net,
+                                                         const int* __restrict__ colcount, const float* __restrict__ gx,
+                                                         const float* __restrict__ gld, float* __restrict__ gz_acc,
+                                                         uint16_t* gnb, int ldb, uint16_t* gnt, int ldt, float* __restrict__ gxold,
+                                                         int rows, int d) {
+    __shared__ __attribute__((aligned(8))) uint16_t tm[64][68];
+    __shared__ __attribute__((aligned(8))) uint16_t ta[64][68];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int cq = (threadIdx.x & 15) << 2, c = c0 + cq;
+    int cn[4] = {0, 0, 0, 0};
+    if (c < d) {
+        const int4 cv = *reinterpret_cast<const int4*>(colcount + c);
+        cn[0] = cv.x; cn[1] = cv.y; cn[2] = cv.z; cn[3] = cv.w;
+    }
+    const bool any = cn[0] > 0 || cn[1] > 0 || cn[2] > 0 || cn[3] > 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rr = (threadIdx.x >> 4) + 16 * j, r = r0 + rr;
+        uint16_t bm[4] = {0, 0, 0, 0}, ba[4] = {0, 0, 0, 0};
+        if (r < rows && c < d) {
+            const size_t e = (size_t)r * d + c;
+            const float4 g4 = *reinterpret_cast<const float4*>(gx + e);
+            float4 acc4 = *reinterpret_cast<const float4*>(gz_acc + e);
+            float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f), mu4 = z4, al4 = z4;
+            if (any) {
+                z4 = *reinterpret_cast<const float4*>(z + e);
+                mu4 = *reinterpret_cast<const float4*>(net + (size_t)r * ld_net + c);
+                al4 = *reinterpret_cast<const float4*>(net + (size_t)r * ld_net + d + c);
+            }
+            const float gl = gld ? gld[r] : 0.f;
+            const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w}, mv[4] = {mu4.x, mu4.y, mu4.z, mu4.w},
+                        av[4] = {al4.x, al4.y, al4.z, al4.w};
+            float gz[4], go[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float g = gv[q];
+                float g_mu = 0.f, g_al = gl, g_z = 0.f, g_old = g;
+                if (cn[q] > 0) {
+                    const float ex = expf(av[q] + mv[q]);
+                    const float gc = g * (float)cn[q];
+                    g_z = gc * ex;
+                    g_mu = gc * zv[q] * ex;
+                    g_al += g_mu;
+                    g_old = 0.f;
+                }
+                gz[q] = g_z;
+                go[q] = g_old;
+                bm[q] = f2bf(g_mu);
+                ba[q] = f2bf(g_al);
+            }
+            acc4.x += gz[0]; acc4.y += gz[1]; acc4.z += gz[2]; acc4.w += gz[3];
+            *reinterpret_cast<float4*>(gz_acc + e) = acc4;
+            *reinterpret_cast<float4*>(gxold + e) = make_float4(go[0], go[1], go[2], go[3]);
+            uint16_t* ob = gnb + (size_t)r * ldb + c;
+            *reinterpret_cast<uint2*>(ob) = make_uint2(bm[0] | ((uint32_t)bm[1] << 16), bm[2] | ((uint32_t)bm[3] << 16));
+            *reinterpret_cast<uint2*>(ob + d) = make_uint2(ba[0] | ((uint32_t)ba[1] << 16), ba[2] | ((uint32_t)ba[3] << 16));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            tm[cq + q][rr] = bm[q];
+            ta[cq + q][rr] = ba[q];
+        }
+    }
+    __syncthreads();
+    iaf_tile_out(tm, gnt, ldt, r0, c0, rows, d);
+    iaf_tile_out(ta, gnt + (size_t)d * ldt, ldt, r0, c0, rows, d);
+}
+
 // Sums over bf16 rows (bias gradients from the transposed gradient copies): stage 1, one wave per (row, 4096-column chunk),
 // writes part[row][chunk]; stage 2 adds a row's chunk sums in order.  fp32 sums, fixed order.
 constexpr int ROWSUM_CHUNK = 4096;
@@ -409,8 +533,15 @@ extern "C" int gv_iaf_update_fwd_bf16(const float* z, const float* net, int ld_n
     if (n == 0) return GV_OK;
     GV_REQUIRE(z && net && x_old && colcount && x_new && x_b && x_t, GV_ERR_NULL, "gv_iaf_update_fwd_bf16: NULL pointer");
     GV_REQUIRE(ldb >= d && ldt >= n, GV_ERR_SHAPE, "gv_iaf_update_fwd_bf16: leading dimension too small");
-    hipLaunchKernelGGL(k_iaf_fwd_bf16, dim3((d + 63) / 64, (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, z, net,
-                       ld_net, x_old, colcount, x_new, x_b, ldb, x_t, ldt, (int)n, d);
+    const bool v4 = d % 4 == 0 && ld_net % 4 == 0 && ldb % 4 == 0 && ldt % 4 == 0 && aligned16(z) && aligned16(net) && aligned16(x_old) &&
+                    aligned16(x_new) && aligned16(colcount) && (reinterpret_cast<uintptr_t>(x_b) & 7u) == 0 &&
+                    (reinterpret_cast<uintptr_t>(x_t) & 7u) == 0;
+    if (v4)
+        hipLaunchKernelGGL(k_iaf_fwd_bf16_v4, dim3((d + 63) / 64, (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, z,
+                           net, ld_net, x_old, colcount, x_new, x_b, ldb, x_t, ldt, (int)n, d);
+    else
+        hipLaunchKernelGGL(k_iaf_fwd_bf16, dim3((d + 63) / 64, (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, z,
+                           net, ld_net, x_old, colcount, x_new, x_b, ldb, x_t, ldt, (int)n, d);
     return launch_status("gv_iaf_update_fwd_bf16");
 }
 
@@ -422,8 +553,15 @@ extern "C" int gv_iaf_update_bwd_bf16(const float* z, const float* net, int ld_n
     GV_REQUIRE(z && net && colcount && gx && gz_accumulate && gnet_b && gnet_t && gx_old, GV_ERR_NULL,
                "gv_iaf_update_bwd_bf16: NULL pointer");
     GV_REQUIRE(ldb >= 2 * d && ldt >= n, GV_ERR_SHAPE, "gv_iaf_update_bwd_bf16: leading dimension too small");
-    hipLaunchKernelGGL(k_iaf_bwd_bf16, dim3((d + 63) / 64, (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, z,
-                       net, ld_net, colcount, gx, gld, gz_accumulate, gnet_b, ldb, gnet_t, ldt, gx_old, (int)n, d);
+    const bool v4 = d % 4 == 0 && ld_net % 4 == 0 && ldb % 4 == 0 && ldt % 4 == 0 && aligned16(z) && aligned16(net) && aligned16(gx) &&
+                    aligned16(gz_accumulate) && aligned16(gx_old) && aligned16(colcount) &&
+                    (reinterpret_cast<uintptr_t>(gnet_b) & 7u) == 0 && (reinterpret_cast<uintptr_t>(gnet_t) & 7u) == 0;
+    if (v4)
+        hipLaunchKernelGGL(k_iaf_bwd_bf16_v4, dim3((d + 63) / 64, (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, z,
+                           net, ld_net, colcount, gx, gld, gz_accumulate, gnet_b, ldb, gnet_t, ldt, gx_old, (int)n, d);
+    else
+        hipLaunchKernelGGL(k_iaf_bwd_bf16, dim3((d + 63) / 64, (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, z,
+                           net, ld_net, colcount, gx, gld, gz_accumulate, gnet_b, ldb, gnet_t, ldt, gx_old, (int)n, d);
     return launch_status("gv_iaf_update_bwd_bf16");
 }
 

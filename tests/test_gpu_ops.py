@@ -1395,3 +1395,50 @@ def test_made_row_chain_matches_bf16_operand_products(ops, widths):
     ops.made_row_bwd(gy.to(dev), [dict(w=wd[i], act=outs[i] if i < L - 1 else None, inp=outs[i - 1] if i > 0 else None,
                                        gw=gws[i]) for i in range(L)])
     assert float(gws[0].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,d', [(130, 200), (64, 24), (77, 6), (1, 8)])
+def test_iaf_update_bf16_kernels_match_the_formulas(ops, n, d):
+    """gv_iaf_update_fwd_bf16 / _bwd_bf16 (the 4-column form when d % 4 == 0, the scalar form otherwise) against the update
+    written out in torch (kgvae/flow_network.py:93-96 and its derivative): fp32 outputs, the bf16 row-major copies and the
+    bf16 transposed copies."""
+    from gcn_vae_amd import lib
+    from gcn_vae_amd.lib import ptr
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(n * 7 + d)
+    z = torch.randn(n, d, generator=g).to(dev)
+    net = (torch.randn(n, 2 * d, generator=g) * 0.3).to(dev)
+    xold = torch.randn(n, d, generator=g).to(dev)
+    cnt = torch.randint(0, 3, (d,), generator=g).to(torch.int32).to(dev)
+    npad = (n + 7) // 8 * 8
+    dp = (d + 7) // 8 * 8
+    xnew = torch.empty(n, d, device=dev)
+    xb = torch.zeros(n, dp, dtype=torch.bfloat16, device=dev)
+    xt = torch.zeros(d, npad, dtype=torch.bfloat16, device=dev)
+    lib.call('gv_iaf_update_fwd_bf16', ptr(z), ptr(net), 2 * d, ptr(xold), ptr(cnt), ptr(xnew), ptr(xb), dp, ptr(xt), npad, n, d,
+             lib.stream())
+    act = (cnt > 0).view(1, -1)
+    want = torch.where(act, z * torch.exp(net[:, d:] + net[:, :d]), xold)
+    close(xnew, want, rtol=1e-5, atol_scale=1e-6, msg='x_new')
+    assert torch.equal(xb[:, :d].float(), xnew.to(torch.bfloat16).float())
+    assert torch.equal(xt[:, :n].float(), xb[:, :d].float().t()) and float(xt[:, n:].abs().max() if npad > n else 0.0) == 0.0
+    # backward
+    gx = torch.randn(n, d, generator=g).to(dev)
+    gld = torch.randn(n, generator=g).to(dev)
+    gz = torch.full((n, d), 0.5, device=dev)
+    gnb = torch.zeros(n, 2 * dp, dtype=torch.bfloat16, device=dev)
+    gnt = torch.zeros(2 * d, npad, dtype=torch.bfloat16, device=dev)
+    gxold = torch.empty(n, d, device=dev)
+    lib.call('gv_iaf_update_bwd_bf16', ptr(z), ptr(net), 2 * d, ptr(cnt), ptr(gx), ptr(gld), ptr(gz), ptr(gnb), 2 * dp, ptr(gnt),
+             npad, ptr(gxold), n, d, lib.stream())
+    ex = torch.exp(net[:, d:] + net[:, :d])
+    gc = gx * cnt.view(1, -1).float()
+    w_gz = torch.where(act, gc * ex, torch.zeros((), device=dev))
+    w_gmu = torch.where(act, gc * z * ex, torch.zeros((), device=dev))
+    w_gal = gld.view(-1, 1) + w_gmu
+    close(gz, 0.5 + w_gz, rtol=1e-5, atol_scale=1e-6, msg='g_z accumulates')
+    close(gxold, torch.where(act, torch.zeros((), device=dev), gx), msg='g_xold')
+    close(gnb[:, :d].float(), w_gmu, rtol=1e-2, atol_scale=1e-2, msg='g_mu (bf16)')
+    close(gnb[:, d:2 * d].float(), w_gal, rtol=1e-2, atol_scale=1e-2, msg='g_alpha (bf16)')
+    assert torch.equal(gnt[:d, :n].float(), gnb[:, :d].float().t()) and torch.equal(gnt[d:, :n].float(), gnb[:, d:2 * d].float().t())
