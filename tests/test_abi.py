@@ -42,3 +42,31 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
                 assert 'oracle/' not in src or f.endswith('.md'), f
+
+
+def test_header_is_plain_c_and_struct_layouts_match_the_ctypes_mirrors(tmp_path):
+    """include/gcnvae.h compiles as C99 on its own (no C++, no HIP, no torch types), and the two descriptor structs the MADE
+    entry points take (gv_chain_layer, gv_row_layer) have the size and field offsets of their ctypes mirrors in ops.py."""
+    import shutil
+    import subprocess
+    import pytest
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    from gcn_vae_amd import ops
+    fields = {'gv_chain_layer': ops._ChainLayer, 'gv_row_layer': ops._RowLayer}
+    lines = []
+    for name, cls in fields.items():
+        lines.append(f'printf("{name} %zu", sizeof({name}));')
+        for f, _ in cls._fields_:
+            lines.append(f'printf(" %zu", offsetof({name}, {f}));')
+        lines.append('printf("\\n");')
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "gcnvae.h"\nint main(void) {\n' + '\n'.join(lines) + '\nreturn 0;\n}\n')
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    for line in out:
+        name, size, *offs = line.split()
+        cls = fields[name]
+        assert int(size) == ctypes.sizeof(cls), name
+        assert [int(o) for o in offs] == [getattr(cls, f).offset for f, _ in cls._fields_], name
