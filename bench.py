@@ -538,6 +538,9 @@ def main():
             except Exception as exc:
                 print(f'[bench] segmented capture failed on rank {rank}: {type(exc).__name__}: {exc}; running eagerly',
                       file=sys.stderr)
+                if os.environ.get('GV_BENCH_TRACEBACK'):
+                    import traceback
+                    traceback.print_exc()
                 sg = None
                 torch.cuda.synchronize()
             if world > 1:      # all ranks must run the same program: one failed capture sends everybody to eager launches
@@ -610,6 +613,8 @@ def main():
             variants.append((True, 1))        # one all-reduce per layer instead of two overlapped halves: 2 collectives fewer
         for sgm, chunks in variants:
             _ops.DIST_FWD_CHUNKS = chunks
+            if chunks != 2:
+                warm(1)        # the row-block cut of this variant is built (one host synchronisation) outside the capture
             key = name if (len(variants) == 1 and not auto) else '%s/%s%s' % (name, 'segments' if sgm else 'eager',
                                                                                '' if chunks == 2 else '/1-block')
             programs[key] = (name,) + capture_current(sgm) + (chunks,)
