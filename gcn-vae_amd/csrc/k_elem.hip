@@ -146,6 +146,22 @@ __global__ __launch_bounds__(256) void k_mul(int64_t n, const float* a, const fl
     GV_GRID_STRIDE(i, n) out[i] = a[i] * b[i];
 }
 
+// several element-wise products in ONE launch (blockIdx.y = which): the mask folds of a MADE's layers
+struct MulMulti {
+    const float* a[GV_MUL_MULTI_MAX];
+    const float* b[GV_MUL_MULTI_MAX];
+    float* out[GV_MUL_MULTI_MAX];
+    int64_t n[GV_MUL_MULTI_MAX];
+};
+__global__ __launch_bounds__(256) void k_mul_multi(const MulMulti p) {
+    const int t = blockIdx.y;
+    const float* a = p.a[t];
+    const float* b = p.b[t];
+    float* out = p.out[t];
+    const int64_t n = p.n[t];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = a[i] * b[i];
+}
+
 __global__ __launch_bounds__(256) void k_iaf_fwd(const float* z, const float* net, int ld_net, const float* xold,
                                                  const int* colcount, float* xnew, int64_t n, int d) {
     const int64_t total = n * d;
@@ -443,6 +459,23 @@ extern "C" int gv_mul(int64_t n, const float* a, const float* b, float* out, voi
     if (n <= 0) return GV_OK;
     hipLaunchKernelGGL(k_mul, dim3(grid_for(n, 1024)), dim3(256), 0, GV_ST, n, a, b, out);
     return launch_status("gv_mul");
+}
+
+extern "C" int gv_mul_multi(int count, const float* const* a, const float* const* b, float* const* out, const int64_t* n,
+                            void* stream) {
+    GV_REQUIRE(count >= 0 && count <= GV_MUL_MULTI_MAX, GV_ERR_SHAPE, "gv_mul_multi: count=%d (at most %d)", count, GV_MUL_MULTI_MAX);
+    if (count == 0) return GV_OK;
+    GV_REQUIRE(a && b && out && n, GV_ERR_NULL, "gv_mul_multi: NULL table");
+    MulMulti p;
+    int64_t nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        GV_REQUIRE(n[i] >= 0 && (n[i] == 0 || (a[i] && b[i] && out[i])), GV_ERR_NULL, "gv_mul_multi: NULL pointer in entry %d", i);
+        p.a[i] = a[i]; p.b[i] = b[i]; p.out[i] = out[i]; p.n[i] = n[i];
+        nmax = n[i] > nmax ? n[i] : nmax;
+    }
+    if (nmax == 0) return GV_OK;
+    hipLaunchKernelGGL(k_mul_multi, dim3(grid_for(nmax, 256), count), dim3(256), 0, GV_ST, p);
+    return launch_status("gv_mul_multi");
 }
 
 extern "C" int gv_iaf_update_fwd(const float* z, const float* net, int ld_net, const float* x_old,

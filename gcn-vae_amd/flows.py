@@ -68,8 +68,8 @@ class MADE(nn.Module):
 
     def forward(self, z):
         lin = self._linears()
-        weights = [l.masked_weight() for l in lin]                 # mask folded once per call, not per pass
-        return ops.made_forward(z, self._colcount, weights, [l.bias for l in lin])
+        # masks folded once per call, not per pass (the bf16 node folds all layers in one launch, forward and backward)
+        return ops.made_forward(z, self._colcount, [l.weight for l in lin], [l.bias for l in lin], masks=[l.mask for l in lin])
 
     def forward_unfused(self, z):
         """The same computation as a chain of per-op autograd nodes (kept for cross-checking the fused node)."""

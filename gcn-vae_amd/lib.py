@@ -80,6 +80,7 @@ SIGNATURES = {
     'gv_mean_sq2': (_I, [_P, _L, _F, _P, _L, _F, _P, _P, _P, _L, _P]),
     'gv_axpby': (_I, [_L, _P, _F, _P, _F, _P, _P]),
     'gv_mul': (_I, [_L, _P, _P, _P, _P]),
+    'gv_mul_multi': (_I, [_I, _P, _P, _P, _P, _P]),
     'gv_kl_workspace_bytes': (_L, [_L, _I, _I]),
     'gv_kl_fwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
     'gv_kl_bwd': (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P, _I, _L, _I, _I, _P, _P]),

@@ -947,6 +947,20 @@ def mul(a, b):
     return out
 
 
+def mul_multi(as_, bs, outs=None):
+    """[a * b for a, b in zip(as_, bs)] in ONE launch (at most 8 pairs; gv_mul_multi).  ``outs``: per pair a contiguous
+    tensor to write into, or None for a new one."""
+    as_ = [_chk(a.contiguous(), name='a') for a in as_]
+    bs = [_chk(b.contiguous(), name='b') for b in bs]
+    outs = [torch.empty_like(a) if (outs is None or outs[i] is None) else outs[i] for i, a in enumerate(as_)]
+    k = len(as_)
+    tab = lambda ts: (_ct.c_void_p * k)(*[ptr(t) for t in ts])
+    ta, tb, to = tab(as_), tab(bs), tab(outs)
+    tn = (_ct.c_int64 * k)(*[a.numel() for a in as_])
+    lib.call('gv_mul_multi', k, _ct.addressof(ta), _ct.addressof(tb), _ct.addressof(to), _ct.addressof(tn), lib.stream())
+    return outs
+
+
 # ------------------------------------------------------------------------------------------------
 # autograd Functions
 # ------------------------------------------------------------------------------------------------
@@ -2517,10 +2531,14 @@ class _MADEForwardBF16(torch.autograd.Function):
     in the transposed buffers is rounded up to 8 rows (8-B aligned stores); the pad columns stay zero."""
 
     @staticmethod
-    def forward(ctx, z, colcount, *wb):
+    def forward(ctx, z, colcount, masks, *wb):
         ctx.set_materialize_grads(False)
         L = len(wb) // 2
         ws, bs = wb[:L], wb[L:]
+        ctx.masks = masks
+        if masks is not None:          # raw weights + their masks: folded here, all layers in one launch (and in backward likewise)
+            ctx.direct_w = [_direct(w) for w in ws]
+            ws = mul_multi(masks, ws)
         z = _chk(z.contiguous(), name='z')
         n, d = z.shape
         P = colcount.shape[0]
@@ -2657,12 +2675,12 @@ class _MADEForwardBF16(torch.autograd.Function):
         rows0 = [None] * L
         row_gw = row_gb = None
         if ctx.row:     # the row's whole backward chain (masked row gradients, outer products, bias gradients): one launch
-            row_gw = [torch.empty(widths[l], ws[l].shape[1], **f32) if ctx.needs_input_grad[2 + l] else None for l in range(L)]
+            row_gw = [torch.empty(widths[l], ws[l].shape[1], **f32) if ctx.needs_input_grad[3 + l] else None for l in range(L)]
             # a bias whose slice of the optimiser arena is still all-zero takes its gradient there directly
             _verify_direct(ctx)
             direct_b = [t if (t is not None and t.data_ptr() in GRAD_FRESH and t.is_contiguous()) else None for t in ctx.direct_b]
             row_gb = [(direct_b[l] if direct_b[l] is not None else torch.empty(widths[l], **f32))
-                      if ctx.has_bias[l] and ctx.needs_input_grad[2 + L + l] else None for l in range(L)]
+                      if ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l] else None for l in range(L)]
             made_row_bwd(g_row, [dict(w=ws[l], act=acts0[l] if l < L - 1 else None, inp=acts0[l - 1] if l > 0 else None,
                                       gw=row_gw[l], gb=row_gb[l]) for l in range(L)])
         else:
@@ -2677,13 +2695,13 @@ class _MADEForwardBF16(torch.autograd.Function):
             mask0 = acts0[l] if l < L - 1 else None
             inp0 = zero_row if l == 0 else acts0[l - 1]
             gw = gb = None
-            if ctx.needs_input_grad[2 + l]:
+            if ctx.needs_input_grad[3 + l]:
                 gw = row_gw[l] if ctx.row else gemm(rows0[l], inp0, trans_a=True, a_relu_mask=mask0, precision='bf16')
                 if S > 0:       # dW_l = g_l^T a_{l-1}: the NT kernel on the transposed copies, reduction over all stacked rows
                     in_t = xin_t if l == 0 else acts_t[l - 1]
                     gemm_bf16_nt(gm_t[l], in_t, widths[l], ws[l].shape[1], mtot, c_f32=gw, accumulate=True,
                                  split_k=max(2, min(64, mtot // 2240)))
-            if ctx.has_bias[l] and ctx.needs_input_grad[2 + L + l]:
+            if ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l]:
                 gb = row_gb[l] if ctx.row else colsum(rows0[l], relu_mask=mask0)
                 if S > 0:
                     rws = torch.empty(int(lib.load().gv_rowsum_bf16_workspace_floats(widths[l], mtot)), **f32)
@@ -2693,16 +2711,33 @@ class _MADEForwardBF16(torch.autograd.Function):
                 gb = None
             g_ws.append(gw)
             g_bs.append(gb)
-        return (g_z, None, *g_ws, *g_bs)
+        if ctx.masks is not None:       # dL/dW = mask * dL/d(mask * W): one launch for all layers, straight into the arena where fresh
+            _verify_direct(ctx)
+            idx = [l for l in range(L) if g_ws[l] is not None]
+            tgt = [ctx.direct_w[l] if (ctx.direct_w[l] is not None and ctx.direct_w[l].data_ptr() in GRAD_FRESH
+                                       and ctx.direct_w[l].is_contiguous()) else None for l in idx]
+            res = mul_multi([ctx.masks[l] for l in idx], [g_ws[l] for l in idx], outs=tgt) if idx else []
+            for l, t, r in zip(idx, tgt, res):
+                if t is not None:
+                    GRAD_FRESH.discard(t.data_ptr())
+                    g_ws[l] = None
+                else:
+                    g_ws[l] = r
+        return (g_z, None, None, *g_ws, *g_bs)
 
 
 MADE_BF16_STORAGE = _os.environ.get('GV_MADE_BF16', '1') == '1'
 
 
-def made_forward(z, colcount, weights, biases):
+def made_forward(z, colcount, weights, biases, masks=None):
     """MADE.forward as one autograd node; with bf16 dense products (set_gemm_precision('bf16'), BASELINE configs[2]) and
-    layer widths that are multiples of 8 the bf16-storage pipeline of csrc/k_made.hip runs."""
+    layer widths that are multiples of 8 the bf16-storage pipeline of csrc/k_made.hip runs.  ``masks``: the autoregressive
+    masks when ``weights`` are the RAW parameters (MaskedLinear.weight); None when the masks are folded in already."""
     if (GEMM_PRECISION == 'bf16' and MADE_BF16_STORAGE and z.shape[1] % 8 == 0 and all(w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0
                                                                                        for w in weights)):
-        return _MADEForwardBF16.apply(z, colcount, *weights, *biases)
+        if masks is not None and len(weights) > 8:           # gv_mul_multi's table holds 8 entries
+            weights, masks = [masked_weight(m, w) for m, w in zip(masks, weights)], None
+        return _MADEForwardBF16.apply(z, colcount, tuple(masks) if masks is not None else None, *weights, *biases)
+    if masks is not None:
+        weights = [masked_weight(m, w) for m, w in zip(masks, weights)]
     return _MADEForward.apply(z, colcount, *weights, *biases)

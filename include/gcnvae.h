@@ -344,6 +344,10 @@ int gv_mean_sq2(const float* x1, int64_t n1, float scale1, const float* x2, int6
                 float* workspace, const int32_t* rows_dev, int64_t rows_host, void* stream);
 int gv_axpby(int64_t n, const float* a, float alpha, const float* x, float beta, float* y, void* stream);
 int gv_mul(int64_t n, const float* a, const float* b, float* out, void* stream);
+/* out[i] = a[i] * b[i] for up to GV_MUL_MULTI_MAX (a, b, out, n) quadruples in ONE launch: the mask folds of a MADE's layers
+ * (mask * W forward, mask * dW backward; kgvae/flow_network.py:14-15).  The tables are host arrays, read during the call. */
+#define GV_MUL_MULTI_MAX 8
+int gv_mul_multi(int count, const float* const* a, const float* const* b, float* const* out, const int64_t* n, void* stream);
 int64_t gv_kl_workspace_bytes(int64_t n, int h, int k);
 int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre, const float* flp,
               float* resp, float* kl, float* workspace, int64_t n, int h, int k, const int32_t* rows_dev, void* stream);
