@@ -456,6 +456,32 @@ __global__ __launch_bounds__(256) void k_rowsum_finish(const float* __restrict__
     out[row] = accumulate ? out[row] + s : s;
 }
 
+// the same finish with the rows cut into consecutive segments, each with its own output vector (the bias gradients of all
+// layers of a MADE from ONE pass over their stacked transposed gradients)
+struct RowsumSegs {
+    float* out[GV_ROWSUM_SEG_MAX];
+    int first[GV_ROWSUM_SEG_MAX + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void k_rowsum_finish_seg(const float* __restrict__ part, int rows, int nchunks, const RowsumSegs sg,
+                                                           int accumulate) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    int t = 0;
+#pragma unroll
+    for (int i = 1; i < GV_ROWSUM_SEG_MAX; ++i)
+        if (i < sg.count && row >= sg.first[i]) t = i;
+    float* out = sg.out[0];
+#pragma unroll
+    for (int i = 1; i < GV_ROWSUM_SEG_MAX; ++i)
+        if (t == i) out = sg.out[i];
+    if (!out) return;
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += part[(size_t)row * nchunks + c];
+    const int r = row - sg.first[t];
+    out[r] = accumulate ? out[r] + s : s;
+}
+
 // out[i] (+)= sum_z partial[z][i], z in order
 __global__ __launch_bounds__(256) void k_splitk_sum(const float* __restrict__ partial, int splits, size_t mn, float* out,
                                                     int accumulate) {
@@ -577,6 +603,32 @@ extern "C" int gv_rowsum_bf16(const uint16_t* x, int ld, int rows, int cols, flo
     hipLaunchKernelGGL(k_rowsum_finish, dim3((rows + 255) / 256), dim3(256), 0, st, (const float*)workspace, rows, nchunks, out,
                        accumulate);
     return launch_status("gv_rowsum_bf16");
+}
+
+extern "C" int gv_rowsum_bf16_segments(const uint16_t* x, int ld, int rows, int cols, int count, float* const* outs,
+                                       const int32_t* seg_rows, int accumulate, float* workspace, void* stream) {
+    GV_REQUIRE(rows >= 0 && cols >= 0 && count >= 1 && count <= GV_ROWSUM_SEG_MAX, GV_ERR_SHAPE,
+               "gv_rowsum_bf16_segments: rows=%d cols=%d count=%d", rows, cols, count);
+    if (rows == 0) return GV_OK;
+    GV_REQUIRE(x && outs && seg_rows && workspace, GV_ERR_NULL, "gv_rowsum_bf16_segments: NULL pointer");
+    GV_REQUIRE(ld >= cols && ld % 8 == 0 && aligned16(x), GV_ERR_ALIGN, "gv_rowsum_bf16_segments: rows must start on 16-B boundaries");
+    RowsumSegs sg;
+    sg.count = count;
+    int first = 0;
+    for (int i = 0; i < count; ++i) {
+        GV_REQUIRE(seg_rows[i] >= 0, GV_ERR_SHAPE, "gv_rowsum_bf16_segments: segment %d has %d rows", i, seg_rows[i]);
+        sg.out[i] = outs[i];
+        sg.first[i] = first;
+        first += seg_rows[i];
+    }
+    sg.first[count] = first;
+    GV_REQUIRE(first == rows, GV_ERR_SHAPE, "gv_rowsum_bf16_segments: segments cover %d of %d rows", first, rows);
+    const int nchunks = max(1, (cols + ROWSUM_CHUNK - 1) / ROWSUM_CHUNK);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_rowsum_bf16, dim3((rows * nchunks + 3) / 4), dim3(256), 0, st, x, ld, rows, cols, nchunks, workspace);
+    hipLaunchKernelGGL(k_rowsum_finish_seg, dim3((rows + 255) / 256), dim3(256), 0, st, (const float*)workspace, rows, nchunks, sg,
+                       accumulate);
+    return launch_status("gv_rowsum_bf16_segments");
 }
 
 /* floats of workspace gv_rowsum_bf16 needs */

@@ -57,6 +57,7 @@ SIGNATURES = {
     'gv_iaf_update_fwd_bf16': (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _L, _I, _P]),
     'gv_iaf_update_bwd_bf16': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _L, _I, _P]),
     'gv_rowsum_bf16': (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
+    'gv_rowsum_bf16_segments': (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     'gv_made_pack_weight_elems': (_L, [_I, _I]),
     'gv_made_pack_weight': (_I, [_P, _I, _I, _I, _P, _P, _P]),
     'gv_made_chain_fits': (_I, [_I, _P, _P, _I]),

@@ -2412,6 +2412,7 @@ def _empty_t_padded(widths, passes, n, npad, kw):
     for w in widths:
         out.append(t[o:o + w])
         o += w
+    out.append(t)          # last: the whole allocation (one row-sum pass over all of it)
     return out
 
 
@@ -2562,7 +2563,7 @@ class _MADEForwardBF16(torch.autograd.Function):
                 cast_bf16(w, a_, t_)
         xin = torch.empty(max(S, 1) * n, d, **f32)               # fp32 pass inputs (update pass-through, backward)
         xin_b = torch.empty(max(S, 1) * n, _pad8(d), **bf)
-        tbufs = _empty_t_padded([d] + widths[:L - 1], max(S, 1), n, npad, bf)
+        tbufs = _empty_t_padded([d] + widths[:L - 1], max(S, 1), n, npad, bf)[:-1]
         xin_t = tbufs[0]
         acts_b = [torch.empty(max(S, 1) * n, _pad8(widths[l]), **bf) for l in range(L - 1)]
         acts_t = tbufs[1:]
@@ -2642,7 +2643,7 @@ class _MADEForwardBF16(torch.autograd.Function):
         # ReLU-masked gradients w.r.t. every layer's pre-activation: bf16 row-major (operand of backward-x) and transposed
         # (operand of backward-W and of the bias sums)
         gm_b = [torch.empty(max(S, 1) * n, _pad8(widths[l]), **bf) for l in range(L)]
-        gm_t = _empty_t_padded(widths, max(S, 1), n, npad, bf)
+        *gm_t, gm_t_all = _empty_t_padded(widths, max(S, 1), n, npad, bf)
         g_z = torch.zeros(n, d, **f32)
         gz_p = torch.empty(n, d, **f32)
         g_cur = gx
@@ -2689,7 +2690,7 @@ class _MADEForwardBF16(torch.autograd.Function):
                 if l > 0:
                     mask = acts0[l] if l < L - 1 else None
                     g_row = gemm(g_row, ws[l], a_relu_mask=mask, precision='bf16')
-        g_ws, g_bs = [], []
+        g_ws, g_bs, g_bs_acc = [], [], []
         mtot = max(S, 1) * npad
         for l in range(L):
             mask0 = acts0[l] if l < L - 1 else None
@@ -2703,14 +2704,22 @@ class _MADEForwardBF16(torch.autograd.Function):
                                  split_k=max(2, min(64, mtot // 2240)))
             if ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l]:
                 gb = row_gb[l] if ctx.row else colsum(rows0[l], relu_mask=mask0)
-                if S > 0:
+                if S > 0 and L > 8:
                     rws = torch.empty(int(lib.load().gv_rowsum_bf16_workspace_floats(widths[l], mtot)), **f32)
                     lib.call('gv_rowsum_bf16', ptr(gm_t[l]), gm_t[l].stride(0), widths[l], mtot, ptr(gb), 1, ptr(rws), st)
+            g_bs_acc.append(gb)             # where the stacked passes' row sums of this layer are added (may be an arena slice)
             if ctx.row and gb is not None and direct_b[l] is not None:
                 GRAD_FRESH.discard(gb.data_ptr())
                 gb = None
             g_ws.append(gw)
             g_bs.append(gb)
+        if S > 0 and L <= 8 and any(b is not None for b in g_bs_acc):
+            # the stacked passes' share of every bias gradient: ONE pass over the transposed gradient buffers of all layers
+            rws = torch.empty(int(lib.load().gv_rowsum_bf16_workspace_floats(sum(widths), mtot)), **f32)
+            outs = (_ct.c_void_p * L)(*[ptr(b) for b in g_bs_acc])
+            segs = (_ct.c_int32 * L)(*widths)
+            lib.call('gv_rowsum_bf16_segments', ptr(gm_t_all), gm_t_all.stride(0), sum(widths), mtot, L, _ct.addressof(outs),
+                     _ct.addressof(segs), 1, ptr(rws), st)
         if ctx.masks is not None:       # dL/dW = mask * dL/d(mask * W): one launch for all layers, straight into the arena where fresh
             _verify_direct(ctx)
             idx = [l for l in range(L) if g_ws[l] is not None]

@@ -187,6 +187,11 @@ int gv_gemm_bf16_nt(const void* a, int a_is_f32, int lda, const uint16_t* b, int
 int gv_cast_bf16(const float* x, int ldx, int rows, int cols, uint16_t* y, int ldy, uint16_t* y_t, int ldt, void* stream);
 int64_t gv_rowsum_bf16_workspace_floats(int rows, int cols);
 int gv_rowsum_bf16(const uint16_t* x, int ld, int rows, int cols, float* out, int accumulate, float* workspace, void* stream);
+/* The same over rows cut into `count` (<= GV_ROWSUM_SEG_MAX) consecutive segments of seg_rows[i] rows, segment i summing into
+ * outs[i] (NULL: skipped): the bias gradients of every layer of a MADE from one pass over their stacked buffers.  Host tables. */
+#define GV_ROWSUM_SEG_MAX 8
+int gv_rowsum_bf16_segments(const uint16_t* x, int ld, int rows, int cols, int count, float* const* outs, const int32_t* seg_rows,
+                            int accumulate, float* workspace, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * K4 fused: a CHAIN of such products in one launch -- the masked MLP of one MADE pass (kgvae/flow_network.py:85-98:
  * x -> relu(W1 x + b1) -> ... -> [mu | alpha]) or its backward-x chain (g_L -> (g_L W_L) * [a_{L-1} > 0] -> ... -> g_x).
