@@ -81,23 +81,26 @@ __device__ __forceinline__ void chain_issue(uint4 (&q)[CH_KS], const uint4* base
     for (int s = 0; s < CH_KS; ++s) q[s] = base[off + min(s, ksc - 1) * 64];
 }
 
-// The A fragments of step s + 1 are read from LDS while the MFMAs of step s run; a scheduling barrier per step keeps the
-// compiler from hoisting all 26 fragment reads (104 registers) to the top.
+// The A fragments are read from LDS TWO steps ahead of the MFMAs that use them (an LDS round trip is longer than one step's
+// two MFMAs); a scheduling barrier per step keeps the compiler from hoisting all 26 fragment reads (104 registers) to the top.
 __device__ __forceinline__ void chain_mma(f32x16_t (&acc)[2], const uint4 (&q)[CH_KS], const uint16_t* a0, int ldk32, int ksc) {
     bf16x8 c0 = *reinterpret_cast<const bf16x8*>(a0), c1 = *reinterpret_cast<const bf16x8*>(a0 + ldk32);
+    bf16x8 d0 = *reinterpret_cast<const bf16x8*>(a0 + 16), d1 = *reinterpret_cast<const bf16x8*>(a0 + ldk32 + 16);
 #pragma unroll
     for (int s = 0; s < CH_KS; ++s)
         if (s < ksc) {
-            bf16x8 n0 = c0, n1 = c1;
-            if (s + 1 < CH_KS) {
-                n0 = *reinterpret_cast<const bf16x8*>(a0 + (s + 1) * 16);
-                n1 = *reinterpret_cast<const bf16x8*>(a0 + ldk32 + (s + 1) * 16);
+            bf16x8 n0 = d0, n1 = d1;
+            if (s + 2 < CH_KS) {
+                n0 = *reinterpret_cast<const bf16x8*>(a0 + (s + 2) * 16);
+                n1 = *reinterpret_cast<const bf16x8*>(a0 + ldk32 + (s + 2) * 16);
             }
             const bf16x8 b0 = __builtin_bit_cast(bf16x8, q[s]);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, c0, acc[0], 0, 0, 0);      // W fragment first: lane <-> row
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, c1, acc[1], 0, 0, 0);
-            c0 = n0;
-            c1 = n1;
+            c0 = d0;
+            c1 = d1;
+            d0 = n0;
+            d1 = n1;
             __builtin_amdgcn_sched_barrier(0);
         }
 }
@@ -149,11 +152,17 @@ __device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const g
                 old[mt][g] = *reinterpret_cast<const float4*>(Ly.out_f32 + (size_t)(m0 + row) * Ly.ldc + c0);
         }
     }
+    float4 bias4[4];        // all four groups' biases requested before the first group's arithmetic (one LDS round trip)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c0 = tile * 32 + 8 * g + 4 * h;
+        bias4[g] = (Ly.bias && c0 < Ly.n) ? *reinterpret_cast<const float4*>(bias_l + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int c0 = tile * 32 + 8 * g + 4 * h;       // widths are multiples of 8: a group is inside or outside as a whole
         const bool cv = c0 < Ly.n;
-        const float4 bv = (Ly.bias && cv) ? *reinterpret_cast<const float4*>(bias_l + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 bv = bias4[g];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int row = mt * 32 + r;
