@@ -27,13 +27,22 @@ constexpr int ROW_WAVES = ROW_THREADS / 64;
 template <bool WIDE> struct RowJB { static constexpr int v = WIDE ? 8 : 16; };
 
 // a wave's lane owns columns [4 lane, 4 lane + 4) and [256 + 4 lane, ...): one or two 16-B loads per weight row
+// UNCONDITIONAL loads from clamped (always valid) addresses, zeroed afterwards where the lane is outside the matrix: a load
+// under a condition into a pre-zeroed register makes the compiler wait for each load before issuing the next (16 round trips
+// per layer instead of one)
+// (the layer's fields are passed as values read ONCE per layer: through the kernel-argument struct the compiler re-reads them with
+// a scalar load + wait at every use that follows a store)
 template <bool WIDE>
-__device__ __forceinline__ void row_load(const gv_row_layer& Ly, int j, int lane, float4& a, float4& b) {
-    a = b = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < Ly.n) {
-        const float* wr = Ly.w + (size_t)j * Ly.ld;
-        if (4 * lane < Ly.k) a = *reinterpret_cast<const float4*>(wr + 4 * lane);
-        if (WIDE && 256 + 4 * lane < Ly.k) b = *reinterpret_cast<const float4*>(wr + 256 + 4 * lane);
+__device__ __forceinline__ void row_load(const float* w, int ld, int n, int k, int j, int lane, float4& a, float4& b) {
+    const float* wr = w + (size_t)min(j, n - 1) * ld;
+    const bool oka = j < n && 4 * lane < k, okb = WIDE && j < n && 256 + 4 * lane < k;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 va = *reinterpret_cast<const float4*>(wr + (4 * lane < k ? 4 * lane : 0));
+    a = oka ? va : z;
+    b = z;
+    if (WIDE) {
+        const float4 vb = *reinterpret_cast<const float4*>(wr + (256 + 4 * lane < k ? 256 + 4 * lane : 0));
+        b = okb ? vb : z;
     }
 }
 
@@ -48,41 +57,45 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row_fwd(const RowArgs p) {
     }
     __syncthreads();
     for (int l = 0; l < p.n_layers; ++l) {
-        const gv_row_layer& Ly = p.L[l];
+        const float* const w = p.L[l].w;
+        const float* const bias = p.L[l].bias;
+        float* const outp = p.L[l].out;
+        const int n = p.L[l].n, k = p.L[l].k, ld = p.L[l].ld, relu = p.L[l].relu;
         const float* xin = xs[l & 1];
         float* xout = xs[(l + 1) & 1];
         const float4 xa = *reinterpret_cast<const float4*>(xin + 4 * lane), xb = *reinterpret_cast<const float4*>(xin + 256 + 4 * lane);
-        for (int j0 = wave; j0 < Ly.n; j0 += ROW_WAVES * ROW_JB) {
+        for (int j0 = wave; j0 < n; j0 += ROW_WAVES * ROW_JB) {
             float4 wa[ROW_JB], wb[ROW_JB];
-            float bj[ROW_JB];       // the biases ride with the weight rows: no dependent load per output
+            // the biases of this wave's rows: ONE vector load (lane jb holds row jb's) in flight with the weight rows -- a load per
+            // row at a wave-uniform address becomes a scalar load the compiler waits for on the spot
+            const int jl = j0 + (lane & (ROW_JB - 1)) * ROW_WAVES;
+            float bvec = 0.f;
+            if (bias) bvec = bias[min(jl, n - 1)];
 #pragma unroll
-            for (int jb = 0; jb < ROW_JB; ++jb) {
-                const int j = j0 + jb * ROW_WAVES;
-                row_load<WIDE>(Ly, j, lane, wa[jb], wb[jb]);
-                bj[jb] = (Ly.bias && j < Ly.n) ? Ly.bias[j] : 0.f;
-            }
+            for (int jb = 0; jb < ROW_JB; ++jb) row_load<WIDE>(w, ld, n, k, j0 + jb * ROW_WAVES, lane, wa[jb], wb[jb]);
 #pragma unroll
             for (int jb = 0; jb < ROW_JB; ++jb) {
                 const int j = j0 + jb * ROW_WAVES;
                 const float s = wave_sum(dot4(xa, rbf4(wa[jb])) + dot4(xb, rbf4(wb[jb])));
-                if (lane == 0 && j < Ly.n) {
-                    float y = s + bj[jb];
-                    if (Ly.relu) y = fmaxf(y, 0.f);
-                    if (Ly.out) Ly.out[j] = y;
+                const float bj = rl_bcast_f(bvec, jb);
+                if (lane == 0 && j < n) {
+                    float y = s + bj;
+                    if (relu) y = fmaxf(y, 0.f);
+                    if (outp) outp[j] = y;
                     xout[j] = rbf(y);
                 }
             }
         }
         __syncthreads();
         // columns past this layer's width must read as zero in the next layer's 16-B pieces
-        for (int i = Ly.n + (int)threadIdx.x; i < ROW_MAXW; i += ROW_THREADS) xout[i] = 0.f;
+        for (int i = n + (int)threadIdx.x; i < ROW_MAXW; i += ROW_THREADS) xout[i] = 0.f;
         __syncthreads();
     }
 }
 
 template <bool WIDE>
 __global__ __launch_bounds__(ROW_THREADS) void k_row_bwd(const RowArgs p) {
-    constexpr int ROW_JB = RowJB<WIDE>::v;
+    constexpr int ROW_JB = WIDE ? 4 : 8;          // more rows in flight would spill here (128 registers per lane at 1024 threads)
     __shared__ __attribute__((aligned(16))) float g[2][ROW_MAXW];          // gradient w.r.t. a layer's output, fp32
     __shared__ __attribute__((aligned(16))) float gm[ROW_MAXW];            // masked and rounded to bf16
     __shared__ __attribute__((aligned(16))) float rin[ROW_MAXW];           // the layer's input row, rounded
@@ -91,34 +104,39 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row_bwd(const RowArgs p) {
     for (int i = threadIdx.x; i < p.L[nl - 1].n; i += ROW_THREADS) g[(nl - 1) & 1][i] = p.x[i];
     __syncthreads();
     for (int l = nl - 1; l >= 0; --l) {
-        const gv_row_layer& Ly = p.L[l];
+        const float* const w = p.L[l].w;
+        const float* const act = p.L[l].act;
+        const float* const inp = p.L[l].inp;
+        float* const gw = p.L[l].gw;
+        float* const gb = p.L[l].gb;
+        const int n = p.L[l].n, k = p.L[l].k, ld = p.L[l].ld, ldgw = p.L[l].ldgw;
         const float* gl = g[l & 1];
-        for (int j = threadIdx.x; j < Ly.n; j += ROW_THREADS) {
+        for (int j = threadIdx.x; j < n; j += ROW_THREADS) {
             float v = gl[j];
-            if (Ly.act && !(Ly.act[j] > 0.f)) v = 0.f;
-            if (Ly.gb) Ly.gb[j] = v;
+            if (act && !(act[j] > 0.f)) v = 0.f;
+            if (gb) gb[j] = v;
             gm[j] = rbf(v);
         }
-        for (int k = threadIdx.x; k < ROW_MAXW; k += ROW_THREADS) rin[k] = (Ly.inp && k < Ly.k) ? rbf(Ly.inp[k]) : 0.f;
+        for (int c = threadIdx.x; c < ROW_MAXW; c += ROW_THREADS) rin[c] = (inp && c < k) ? rbf(inp[c]) : 0.f;
         __syncthreads();
         const bool need_g = l > 0 || p.gx;
         const float4 ra = *reinterpret_cast<const float4*>(rin + 4 * lane), rb = *reinterpret_cast<const float4*>(rin + 256 + 4 * lane);
         float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
-        for (int j0 = wave; j0 < Ly.n; j0 += ROW_WAVES * ROW_JB) {
+        for (int j0 = wave; j0 < n; j0 += ROW_WAVES * ROW_JB) {
             float4 wa[ROW_JB], wb[ROW_JB];
             if (need_g) {
 #pragma unroll
-                for (int jb = 0; jb < ROW_JB; ++jb) row_load<WIDE>(Ly, j0 + jb * ROW_WAVES, lane, wa[jb], wb[jb]);
+                for (int jb = 0; jb < ROW_JB; ++jb) row_load<WIDE>(w, ld, n, k, j0 + jb * ROW_WAVES, lane, wa[jb], wb[jb]);
             }
 #pragma unroll
             for (int jb = 0; jb < ROW_JB; ++jb) {
                 const int j = j0 + jb * ROW_WAVES;
-                if (j >= Ly.n) continue;
+                if (j >= n) continue;
                 const float gj = gm[j];
-                if (Ly.gw) {        // outer product with the layer's input row (all-zero row: zeros)
-                    float* o = Ly.gw + (size_t)j * Ly.ldgw;
-                    if (4 * lane < Ly.k) *reinterpret_cast<float4*>(o + 4 * lane) = make_float4(gj * ra.x, gj * ra.y, gj * ra.z, gj * ra.w);
-                    if (256 + 4 * lane < Ly.k)
+                if (gw) {        // outer product with the layer's input row (all-zero row: zeros)
+                    float* o = gw + (size_t)j * ldgw;
+                    if (4 * lane < k) *reinterpret_cast<float4*>(o + 4 * lane) = make_float4(gj * ra.x, gj * ra.y, gj * ra.z, gj * ra.w);
+                    if (256 + 4 * lane < k)
                         *reinterpret_cast<float4*>(o + 256 + 4 * lane) = make_float4(gj * rb.x, gj * rb.y, gj * rb.z, gj * rb.w);
                 }
                 if (need_g) {       // g_{l-1} += gm[j] W[j][:]: this wave's rows in order
@@ -132,10 +150,10 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row_bwd(const RowArgs p) {
             *reinterpret_cast<float4*>(&part[wave][4 * lane]) = sa;
             *reinterpret_cast<float4*>(&part[wave][256 + 4 * lane]) = sb;
             __syncthreads();
-            if ((int)threadIdx.x < Ly.k) {
+            if ((int)threadIdx.x < k) {
                 float v = 0.f;
 #pragma unroll
-                for (int w = 0; w < ROW_WAVES; ++w) v += part[w][threadIdx.x];      // the 16 waves' partial sums, in order
+                for (int q = 0; q < ROW_WAVES; ++q) v += part[q][threadIdx.x];      // the 16 waves' partial sums, in order
                 if (l > 0) g[(l - 1) & 1][threadIdx.x] = v;
                 else p.gx[threadIdx.x] = v;
             }
