@@ -12,8 +12,8 @@
 // from a FRAGMENT-PACKED copy in global memory (gv_made_pack_weight: tile of 32 output columns x 16-deep step = 64 lanes x 16 B,
 // contiguous), loaded by the wave that owns the columns straight into registers -- no LDS traffic, no barrier for B.  A wave owns
 // 64 rows x 32 columns (2 accumulator tiles of v_mfma_f32_32x32x16_bf16, eight waves per workgroup: two per SIMD hide each other's waits).
-// The B fragments of the wave's NEXT unit (next 13 steps: next column tile, reduction chunk or layer) are requested at the start
-// of the current unit into a second register set: in flight for a whole unit of MFMAs + the epilogue + the barrier.
+// The B fragments of the wave's NEXT unit (next 13 steps: next column tile, reduction chunk or layer) are requested right after
+// the current unit's last MFMA, into the same registers: in flight during the epilogue and the barrier.
 //
 // Same arithmetic as gv_gemm_bf16_nt per product (operands rounded to bf16, k accumulated in 16-deep steps in order, fp32
 // accumulators, epilogue order bias -> ReLU -> mask -> stores): results are bit-identical to the launch-per-product path.
@@ -60,14 +60,14 @@ __device__ __forceinline__ void chain_unit_b(const ChainArgs& p, ChainUnit u, in
     off = (unsigned)((u.tile * ks + u.ch * CH_KS) * 64 + lane);
 }
 
-// One unit: up to 13 16-deep steps of a 64 x 32 accumulator block (two MFMAs per step share the B fragment).  Two register
-// sets of B fragments: at the start of a unit the set it consumes is fenced (its loads were issued a whole unit ago), THEN the
-// other set's loads for the wave's next unit are issued, then the steps run without a single vector-memory wait.  (Reloading a
-// fragment's registers right after its step needs one set only, but the compiler cannot count the loads in flight across the
-// unit loop and puts s_waitcnt vmcnt(0) -- a full L2 round trip -- in front of every step: 6 us per unit instead of 0.4.)
-// (the lane offset of the next loads passes through the fence too: otherwise the scheduler hoists them above it and the fence
-// waits for them as well; the offset, not the pointer -- a laundered pointer loses its address space and turns the loads into
-// flat ones, which count against the LDS counter too)
+// One unit: up to 13 16-deep steps of a 64 x 32 accumulator block (two MFMAs per step share the B fragment).  At the start of a
+// unit its fragment set is fenced (the loads were issued after the previous unit's last MFMA); the steps then run without a
+// single vector-memory wait, and the set is reloaded as a whole for the next unit.  (Reloading a fragment's registers right after
+// ITS step looks better, but the compiler cannot count the loads in flight across the unit loop and puts s_waitcnt vmcnt(0) -- a
+// full L2 round trip -- in front of every step: 6 us per unit instead of 0.4.)
+// (the lane offset of the next loads passes through the fence too: otherwise the scheduler may hoist them above it; the offset,
+// not the pointer -- a laundered pointer loses its address space and turns the loads into flat ones, which count against the LDS
+// counter too)
 __device__ __forceinline__ void chain_landed(uint4 (&q)[CH_KS], unsigned& next_b) {
     asm volatile("" : "+v"(q[0].x), "+v"(q[1].x), "+v"(q[2].x), "+v"(q[3].x), "+v"(q[4].x), "+v"(q[5].x), "+v"(q[6].x),
                  "+v"(q[7].x), "+v"(q[8].x), "+v"(q[9].x), "+v"(q[10].x), "+v"(q[11].x), "+v"(q[12].x), "+v"(next_b));
@@ -135,34 +135,40 @@ __device__ __forceinline__ void chain_stage(uint16_t* tile, int ldk, const uint1
 // tiles = rows r and 32 + r) and its 16 registers are 4 groups of 4 consecutive columns (8 g + 4 (lane >> 5) + 0..3):
 //   next layer's LDS tile: one ds_write_b64 per group;  ReLU mask: one ds_read_b64 per group;  fp32 output: one 16-B store per
 //   group;  transposed bf16 copy: per register a 2-B store whose 32 lanes are 32 consecutive rows = 64 contiguous bytes.
+// (biases and the accumulate operand are fetched group by group, not up front: the kernel has to fit 128 registers)
+constexpr bool LEAN = true;
 __device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const gv_chain_layer& Ly, int tile, int m0, int m,
                                                uint16_t* An, int ldk, int kp_next, const uint16_t* mbuf, const float* bias_l,
                                                int r, int h) {
     // opaque copies: without them the compiler hoists per-row predicates and 64-bit offsets out of the unit loop and spills
     asm volatile("" : "+v"(r), "+v"(h));
-    float4 old[2][4];       // accumulate: all previous values requested at once (one round trip)
+    float4 old[LEAN ? 1 : 2][LEAN ? 1 : 4];       // accumulate: all previous values requested at once (one round trip)
     const bool acc_old = Ly.out_f32 && Ly.accumulate;
+    float4 bias4[LEAN ? 1 : 4];        // all four groups' biases requested before the first group's arithmetic (one LDS round trip)
+    if constexpr (!LEAN) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = tile * 32 + 8 * g + 4 * h, row = mt * 32 + r;
+                old[mt][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (acc_old && c0 < Ly.n && m0 + row < m)
+                    old[mt][g] = *reinterpret_cast<const float4*>(Ly.out_f32 + (size_t)(m0 + row) * Ly.ldc + c0);
+            }
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int c0 = tile * 32 + 8 * g + 4 * h, row = mt * 32 + r;
-            old[mt][g] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (acc_old && c0 < Ly.n && m0 + row < m)
-                old[mt][g] = *reinterpret_cast<const float4*>(Ly.out_f32 + (size_t)(m0 + row) * Ly.ldc + c0);
+            const int c0 = tile * 32 + 8 * g + 4 * h;
+            bias4[g] = (Ly.bias && c0 < Ly.n) ? *reinterpret_cast<const float4*>(bias_l + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    }
-    float4 bias4[4];        // all four groups' biases requested before the first group's arithmetic (one LDS round trip)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int c0 = tile * 32 + 8 * g + 4 * h;
-        bias4[g] = (Ly.bias && c0 < Ly.n) ? *reinterpret_cast<const float4*>(bias_l + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int c0 = tile * 32 + 8 * g + 4 * h;       // widths are multiples of 8: a group is inside or outside as a whole
         const bool cv = c0 < Ly.n;
-        const float4 bv = bias4[g];
+        float4 bv;
+        if constexpr (LEAN) bv = (Ly.bias && cv) ? *reinterpret_cast<const float4*>(bias_l + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        else bv = bias4[g];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int row = mt * 32 + r;
@@ -180,7 +186,12 @@ __device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const g
             }
             if (Ly.out_f32 && cv && m0 + row < m) {
                 float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                if (acc_old) { o.x += old[mt][g].x; o.y += old[mt][g].y; o.z += old[mt][g].z; o.w += old[mt][g].w; }
+                if (acc_old) {
+                    float4 pv;
+                    if constexpr (LEAN) pv = *reinterpret_cast<const float4*>(Ly.out_f32 + (size_t)(m0 + row) * Ly.ldc + c0);
+                    else pv = old[mt][g];
+                    o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
+                }
                 *reinterpret_cast<float4*>(Ly.out_f32 + (size_t)(m0 + row) * Ly.ldc + c0) = o;
             }
             const uint16_t b0 = bf_bits(v[0]), b1 = bf_bits(v[1]), b2 = bf_bits(v[2]), b3 = bf_bits(v[3]);
@@ -225,11 +236,15 @@ __device__ __forceinline__ void chain_store(const gv_chain_layer& Ly, const uint
     }
 }
 
-// Every wave walks its own list of units (layer, column tile, 13-step chunk) in ONE flat loop, unrolled by two so that the two
-// fragment register sets keep fixed roles (body A consumes qa and fills qb, body B the reverse: no copies at the back edge).
-// Between units a wave crosses layer boundaries; crossing layer l -> l + 1 is the same for every wave of the workgroup:
+// Every wave walks its own list of units (layer, column tile, 13-step chunk) in ONE flat loop.  Between units a wave crosses layer
+// boundaries; crossing layer l -> l + 1 is the same for every wave of the workgroup:
 //   barrier (layer l's tile complete)  ->  [mask of layer l + 1 staged by everyone, barrier]  ->  store wave: layer l's copies.
-__global__ __launch_bounds__(CH_THREADS) void k_made_chain(const ChainArgs p) {
+// ONE fragment register set, reloaded for the wave's next unit right after the unit's last MFMA: the loads land during the
+// epilogue and the barrier (2-3 us, several L2 round trips).  With it the kernel fits 128 registers per lane = four waves per
+// SIMD = TWO workgroups per CU where the LDS tiles allow (the forward chain: 60 KB), which is what counts once there are more row
+// tiles than CUs (WN18RR: 640 tiles, forward chain 93 -> 72 us).  A second set requested a whole unit ahead (the first design,
+// two unit bodies with fixed set roles) measured the same at 228 tiles and cost 52 registers.
+__global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_made_chain(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t chain_lds[];
     const int ldk = p.ldk, nl = p.n_layers, m0 = blockIdx.x * CH_BM;
     uint16_t* mbuf = chain_lds + 2 * CH_BM * ldk;
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_made_chain(const ChainArgs p) {
     const bool mma_wave = wave < CH_MMA_WAVES;
 
     // the first B fragments of an MMA wave are requested before anything else
-    uint4 qa[CH_KS], qb[CH_KS];
+    uint4 qa[CH_KS];
     ChainUnit u = {nl, wave, 0};
     const uint4* const any_b = reinterpret_cast<const uint4*>(p.L[0].w_packed);      // a readable address for idle loads
     {
@@ -289,8 +304,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_made_chain(const ChainArgs p) {
         ++layer;                                                                                                        \
     }
 
-    // one unit: QC holds its fragments (requested a unit ago), QF receives the next unit's
-#define CHAIN_UNIT(QC, QF)                                                                                               \
+    // one unit: fence (its fragments were requested during the previous unit's epilogue), MFMAs, reload for the next unit, epilogue
+#define CHAIN_UNIT1(Q)                                                                                                   \
     {                                                                                                                   \
         const gv_chain_layer& Ly = p.L[u.l];                                                                            \
         const int ks = (Ly.k + 15) >> 4, nch = (ks + CH_KS - 1) / CH_KS;                                                \
@@ -299,13 +314,13 @@ __global__ __launch_bounds__(CH_THREADS) void k_made_chain(const ChainArgs p) {
         unsigned noff = lane;                                                                                           \
         int nksc = 1;                                                                                                   \
         if (nu.l < nl) chain_unit_b(p, nu, lane, nb0, noff, nksc);                                                      \
-        chain_landed(QC, noff);                                                                                         \
-        chain_issue(QF, nb0, noff, nksc);                                                                               \
+        chain_landed(Q, noff);                                                                                          \
         if (u.ch == 0) {                                                                                                \
             _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;                                 \
         }                                                                                                               \
         const uint16_t* A = chain_lds + (u.l & 1) * CH_BM * ldk;                                                        \
-        chain_mma(acc, QC, A + r * ldk + 8 * h + u.ch * CH_KS * 16, 32 * ldk, min(CH_KS, ks - u.ch * CH_KS));           \
+        chain_mma(acc, Q, A + r * ldk + 8 * h + u.ch * CH_KS * 16, 32 * ldk, min(CH_KS, ks - u.ch * CH_KS));            \
+        chain_issue(Q, nb0, noff, nksc);                                                                                \
         if (u.ch + 1 == nch)                                                                                            \
             chain_epilogue(acc, Ly, u.tile, m0, p.m, chain_lds + ((u.l + 1) & 1) * CH_BM * ldk, ldk,                    \
                            u.l + 1 < nl ? (Ly.n + 15) & ~15 : 0, mbuf, bias_lds + bias_off, r, h);                      \
@@ -315,13 +330,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_made_chain(const ChainArgs p) {
     for (;;) {
         CHAIN_CROSS(u.l)
         if (u.l >= nl) break;
-        CHAIN_UNIT(qa, qb)
-        CHAIN_CROSS(u.l)
-        if (u.l >= nl) break;
-        CHAIN_UNIT(qb, qa)
+        CHAIN_UNIT1(qa)
     }
 #undef CHAIN_CROSS
-#undef CHAIN_UNIT
+#undef CHAIN_UNIT1
 }
 
 // packed[(t * ks + s) * 64 + lane][e] = bf16(B[32 t + (lane & 31)][16 s + 8 (lane >> 5) + e]), zero outside B;
