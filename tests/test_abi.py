@@ -32,6 +32,26 @@ def test_argument_errors_are_reported_not_thrown():
     assert rc == -1 and 'NULL' in lib.last_error()
     rc = l.gv_segment_items_count(None, 3, 0, None, None, None, None)
     assert rc < 0
+    # the MADE entry points of round 2: descriptor tables are validated on the host, before anything is launched
+    from gcn_vae_amd import ops
+    layers = (ops._ChainLayer * 2)()
+    assert l.gv_made_chain(None, 200, 64, 2, ctypes.addressof(layers), None) != 0 and 'NULL' in lib.last_error()
+    assert l.gv_made_chain(None, 200, 64, 9, ctypes.addressof(layers), None) != 0            # more layers than the table holds
+    assert l.gv_made_chain(None, 200, 0, 2, ctypes.addressof(layers), None) == 0             # no rows: nothing to do
+    n_ok = (ctypes.c_int32 * 2)(200, 400)
+    k_ok = (ctypes.c_int32 * 2)(200, 200)
+    k_bad = (ctypes.c_int32 * 2)(200, 208)
+    wide = (ctypes.c_int32 * 2)(2048, 2048)
+    assert l.gv_made_chain_fits(2, ctypes.addressof(n_ok), ctypes.addressof(k_ok), 1) == 1
+    assert l.gv_made_chain_fits(2, ctypes.addressof(n_ok), ctypes.addressof(k_bad), 0) == 0   # k of a layer != n of the one before
+    assert l.gv_made_chain_fits(2, ctypes.addressof(wide), ctypes.addressof(wide), 0) == 0    # tiles larger than the LDS
+    assert l.gv_made_pack_weight_elems(200, 200) == 7 * 13 * 64 * 8
+    rows = (ops._RowLayer * 1)()
+    assert l.gv_made_row_fwd(None, 1, ctypes.addressof(rows), None) != 0
+    assert l.gv_mul_multi(9, None, None, None, None, None) != 0 and l.gv_mul_multi(0, None, None, None, None, None) == 0
+    outs = (ctypes.c_void_p * 2)()
+    segs = (ctypes.c_int32 * 2)(3, 4)
+    assert l.gv_rowsum_bf16_segments(None, 8, 7, 8, 2, ctypes.addressof(outs), ctypes.addressof(segs), 1, None, None) != 0
 
 
 def test_product_never_imports_the_oracle():
