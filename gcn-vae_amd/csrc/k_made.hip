@@ -13,6 +13,7 @@
 //   backward-x   g_{l-1}  = (g_l W_l) * [a_{l-1} > 0]      A = g_l     [M][out],  B = W_l^T [in][out]
 //   backward-W   dW_l     = g_l^T a_{l-1}                  A = g_l^T   [out][M],  B = a_{l-1}^T [in][M]   (split over M)
 // Semantics (pinned by the tests' CPU emulation): operands rounded to bf16 (round to nearest even), products and sums in fp32.
+#include <cstdlib>
 #include "common.h"
 
 namespace gv {
@@ -188,6 +189,101 @@ __global__ __launch_bounds__(256) void k_gemm_bf16s(const BfGemm p) {
         }
     }
 }
+
+// Split-K partial products for SMALL outputs over a LONG reduction (the weight gradients dW = g^T a: 200-400 x 200 outputs,
+// 65 000 - 184 000 rows): a workgroup computes the WHOLE <= 224 x <= 224 output block of its K slice, so every operand element
+// is read exactly once (the 64 x 64 tiling above re-reads both operands four times from L2 and is bound by that: 41 us for
+// 52 MB at FB15k-237 size).  8 waves as 4 (M) x 2 (N), a wave owns 2 x 4 accumulator tiles of 32 x 32; 64-deep chunks staged
+// through LDS (72-element rows: conflict-free ds_read_b128), the next chunk's global loads in flight during the MFMAs.
+constexpr int TK_T = 224, TK_KC = 128, TK_LDK = 136, TK_THREADS = 512;      // 128-deep chunks: a chunk's MFMAs (~1.7 us) cover a memory round trip
+constexpr int TK_PPR = TK_KC / 8, TK_PIECES = TK_T * TK_PPR, TK_PPT = (TK_PIECES + TK_THREADS - 1) / TK_THREADS;     // 16-B pieces per operand / thread
+constexpr size_t TK_LDS_BYTES = (size_t)2 * TK_T * TK_LDK * sizeof(uint16_t);
+
+// an UNCONDITIONAL load from a clamped (always valid) address; the piece is zeroed where it lies outside the operand only when it
+// is written to LDS (tk_keep), a chunk later: a load under a condition, or a select right behind it, makes the compiler wait for
+// the data on the spot instead of leaving it in flight during the MFMAs
+__device__ __forceinline__ uint4 tk_load(const uint16_t* base, int ld, int rows, int row0, int idx, int k0, int k_end, int k_safe) {
+    const int row = idx / TK_PPR, kk = (idx % TK_PPR) << 3;
+    return *reinterpret_cast<const uint4*>(base + (size_t)min(row0 + row, rows - 1) * ld + (k0 + kk < k_end ? k0 + kk : k_safe));
+}
+__device__ __forceinline__ bool tk_keep(int rows, int row0, int idx, int k0, int k_end) {
+    return row0 + idx / TK_PPR < rows && k0 + ((idx % TK_PPR) << 3) < k_end;
+}
+
+__global__ __launch_bounds__(TK_THREADS) void k_gemm_bf16_tallk(const BfGemm p) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t tk_lds[];
+    uint16_t* const As = tk_lds;
+    uint16_t* const Bs = tk_lds + TK_T * TK_LDK;
+    const int m0 = blockIdx.y * TK_T, n0 = blockIdx.x * TK_T;
+    const int k_begin = blockIdx.z * p.k_per_split, k_end = min(p.k, k_begin + p.k_per_split);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm = wid & 3, wn = wid >> 2, r = lane & 31, h = lane >> 5;
+    const int mt_n = (min(TK_T, p.m - m0) + 31) >> 5, nt_n = (min(TK_T, p.n - n0) + 31) >> 5;      // 32-row tiles that exist
+    const uint16_t* const a = static_cast<const uint16_t*>(p.a);
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    uint4 va[TK_PPT], vb[TK_PPT];
+#pragma unroll
+    for (int j = 0; j < TK_PPT; ++j) {
+        va[j] = tk_load(a, p.lda, p.m, m0, threadIdx.x + j * TK_THREADS, k_begin, k_end, k_begin);
+        vb[j] = tk_load(p.b, p.ldb, p.n, n0, threadIdx.x + j * TK_THREADS, k_begin, k_end, k_begin);
+    }
+    for (int k0 = k_begin; k0 < k_end; k0 += TK_KC) {
+#pragma unroll
+        for (int j = 0; j < TK_PPT; ++j) {
+            const int idx = threadIdx.x + j * TK_THREADS;
+            if (idx < TK_PIECES) {
+                // (component-wise masks: a ?: between two uint4 objects becomes a select of ADDRESSES and sends the arrays to scratch)
+                const uint32_t ka = tk_keep(p.m, m0, idx, k0, k_end) ? 0xffffffffu : 0u, kb = tk_keep(p.n, n0, idx, k0, k_end) ? 0xffffffffu : 0u;
+                const int off = (idx / TK_PPR) * TK_LDK + ((idx % TK_PPR) << 3);
+                *reinterpret_cast<uint4*>(&As[off]) = make_uint4(va[j].x & ka, va[j].y & ka, va[j].z & ka, va[j].w & ka);
+                *reinterpret_cast<uint4*>(&Bs[off]) = make_uint4(vb[j].x & kb, vb[j].y & kb, vb[j].z & kb, vb[j].w & kb);
+            }
+        }
+        __syncthreads();
+        // the next chunk's loads fly while this one's MFMAs run (unconditional: past the slice's end they re-read its first
+        // columns and are never used)
+#pragma unroll
+        for (int j = 0; j < TK_PPT; ++j) {
+            va[j] = tk_load(a, p.lda, p.m, m0, threadIdx.x + j * TK_THREADS, k0 + TK_KC, k_end, k_begin);
+            vb[j] = tk_load(p.b, p.ldb, p.n, n0, threadIdx.x + j * TK_THREADS, k0 + TK_KC, k_end, k_begin);
+        }
+#pragma unroll
+        for (int kk = 0; kk < TK_KC; kk += 16) {
+            bf16x8 af[2], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[((2 * wm + i) * 32 + r) * TK_LDK + kk + 8 * h]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[((4 * wn + j) * 32 + r) * TK_LDK + kk + 8 * h]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (2 * wm + i < mt_n && 4 * wn + j < nt_n)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* dst = p.partial + (size_t)blockIdx.z * p.m * p.n;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + (4 * wn + j) * 32 + r;
+            if (2 * wm + i >= mt_n || 4 * wn + j >= nt_n || col >= p.n) continue;      // (tile 7 belongs to the next block)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + (2 * wm + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < p.m) dst[(size_t)row * p.n + col] = acc[i][j][e];
+            }
+        }
+}
+static_assert(TK_T == 7 * 32 && TK_LDS_BYTES <= 160 * 1024 && (TK_LDK / 2) % 8 == 4, "two 224-row chunks in LDS, conflict-free pitch");
 
 // y[r][c] = bf16(x[r][c]) (row-major, ld ldy) and / or yT[c][r] (ld ldt); 64 x 64 tiles through LDS for the transposed copy
 __global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ x, int ldx, int rows, int cols, uint16_t* y,
@@ -487,7 +583,15 @@ __global__ __launch_bounds__(256) void k_splitk_sum(const float* __restrict__ pa
                                                     int accumulate) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (size_t)gridDim.x * 256) {
         float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += partial[(size_t)z * mn + i];
+        int z = 0;
+        for (; z + 8 <= splits; z += 8) {          // eight partials in flight, added in order
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = partial[(size_t)(z + j) * mn + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; z < splits; ++z) s += partial[(size_t)z * mn + i];
         out[i] = accumulate ? out[i] + s : s;
     }
 }
@@ -520,18 +624,37 @@ extern "C" int gv_gemm_bf16_nt(const void* a, int a_is_f32, int lda, const uint1
     p.c_bft = c_bf16_t; p.ldct = ldct; p.partial = nullptr; p.k_per_split = k;
     hipStream_t st = (hipStream_t)stream;
     int splits = 1;
+    bool tall = false;
     if (split_k > 1) {
         GV_REQUIRE(c_f32 && !c_bf16 && !c_bf16_t && !bias && !relu && !mask, GV_ERR_SHAPE,
                    "gv_gemm_bf16_nt: split-K writes a plain fp32 result only");
-        int per = ((k + split_k - 1) / split_k + 223) / 224 * 224;      // whole 224-deep chunks per split
+        // small outputs over a long reduction: whole-output workgroups (every operand element read once)
+        static const bool tall_ok = !(getenv("GV_GEMM_TALL") && getenv("GV_GEMM_TALL")[0] == '0');
+        tall = tall_ok && !a_is_f32 && n <= 2 * TK_T && m <= 4 * TK_T && k >= TK_KC * split_k;
+        const int chunk = tall ? TK_KC : 224;
+        int per = ((k + split_k - 1) / split_k + chunk - 1) / chunk * chunk;      // whole chunks per split
         splits = (k + per - 1) / per;
         GV_REQUIRE(workspace && workspace_bytes >= (int64_t)splits * m * n * 4, GV_ERR_WORKSPACE,
                    "gv_gemm_bf16_nt: workspace too small for %d splits", splits);
         p.partial = (float*)workspace; p.k_per_split = per;
     }
-    dim3 grid((n + 63) / 64, (m + 63) / 64, splits), block(256);
-    if (a_is_f32) hipLaunchKernelGGL(k_gemm_bf16s<true>, grid, block, 0, st, p);
-    else hipLaunchKernelGGL(k_gemm_bf16s<false>, grid, block, 0, st, p);
+    if (tall) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)k_gemm_bf16_tallk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TK_LDS_BYTES) != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("gv_gemm_bf16_nt: cannot raise the dynamic LDS limit");
+                return GV_ERR_SHAPE;
+            }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_gemm_bf16_tallk, dim3((n + TK_T - 1) / TK_T, (m + TK_T - 1) / TK_T, splits), dim3(TK_THREADS), TK_LDS_BYTES,
+                           st, p);
+    } else {
+        dim3 grid((n + 63) / 64, (m + 63) / 64, splits), block(256);
+        if (a_is_f32) hipLaunchKernelGGL(k_gemm_bf16s<true>, grid, block, 0, st, p);
+        else hipLaunchKernelGGL(k_gemm_bf16s<false>, grid, block, 0, st, p);
+    }
     int rc = launch_status("gv_gemm_bf16_nt");
     if (rc != GV_OK || split_k <= 1) return rc;
     const size_t mn = (size_t)m * n;

@@ -2701,7 +2701,7 @@ class _MADEForwardBF16(torch.autograd.Function):
                 if S > 0:       # dW_l = g_l^T a_{l-1}: the NT kernel on the transposed copies, reduction over all stacked rows
                     in_t = xin_t if l == 0 else acts_t[l - 1]
                     gemm_bf16_nt(gm_t[l], in_t, widths[l], ws[l].shape[1], mtot, c_f32=gw, accumulate=True,
-                                 split_k=max(2, min(64, mtot // 2240)))
+                                 split_k=max(2, min(256, mtot // 512)))
             if ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l]:
                 gb = row_gb[l] if ctx.row else colsum(rows0[l], relu_mask=mask0)
                 if S > 0 and L > 8:

@@ -1223,11 +1223,11 @@ def test_segmented_graph_replays_the_recorded_program(ops):
 @pytest.mark.gpu
 @pytest.mark.parametrize('m,n,k,a_f32', [(300, 200, 200, False), (300, 200, 200, True), (257, 400, 200, False), (64, 72, 64, True),
                                          (130, 96, 456, False), (1000, 100, 224, True), (33, 64, 8, False), (90, 68, 40, False),
-                                         (70, 36, 232, True), (500, 132, 200, False)])
+                                         (70, 36, 232, True), (500, 132, 200, False), (230, 200, 1000, False), (400, 232, 776, False)])
 def test_gemm_bf16_nt_every_epilogue_and_ragged_column_counts(ops, m, n, k, a_f32):
     """gv_gemm_bf16_nt against fp32 matmul of the bf16-rounded operands (the semantics oracle/bf16.py states): ragged row /
     column / depth counts around the 64-wide tiles, each epilogue output (fp32, fp32 accumulate, bf16, transposed bf16, bias,
-    ReLU, ReLU mask) and split-K."""
+    ReLU, ReLU mask) and split-K (the two deep cases take the whole-output kernel of the weight-gradient products)."""
     from oracle import bf16 as obf
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(m * 1000 + n)
