@@ -193,18 +193,33 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmParams p) {
         const float bv = (p.bias && p.split_k == 1) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
+            // accumulate: the 16 previous values of this tile column are requested TOGETHER (load, add, store per element in
+            // source order makes the compiler wait for every load before the next: 16 round trips per tile)
+            float old[16];
+            const bool acc_old = p.accumulate && p.split_k == 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                old[r] = 0.f;
+                if (acc_old && row < p.m) old[r] = p.c[(size_t)row * p.ldc + col];
+            }
+            // ... added in a loop of their own, and stored in a third: a store loop that reads no loaded register needs no wait
+            float val[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[t][u][r];
+                if (p.split_k == 1) {
+                    v = apply_act(v + bv, p.act);
+                    v = acc_old ? old[r] + v : v;
+                }
+                val[r] = v;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (row >= p.m) continue;
-                float v = acc[t][u][r];
-                if (p.split_k > 1) {
-                    p.ws[((size_t)blockIdx.z * p.m + row) * p.n + col] = v;
-                } else {
-                    v = apply_act(v + bv, p.act);
-                    float* dst = p.c + (size_t)row * p.ldc + col;
-                    *dst = p.accumulate ? *dst + v : v;
-                }
+                if (p.split_k > 1) p.ws[((size_t)blockIdx.z * p.m + row) * p.n + col] = val[r];
+                else p.c[(size_t)row * p.ldc + col] = val[r];
             }
         }
     }
