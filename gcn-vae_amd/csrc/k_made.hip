@@ -40,6 +40,8 @@ struct BfGemm {
     int ldct;
     float* partial;           // split-K: [gridDim.z][M][N] fp32 (then no epilogue, no other output)
     int k_per_split;
+    float* rowsum_partial;    // whole-output kernel only: sums of A's rows over the block's K slice (split z at z * partial_stride), or NULL
+    size_t partial_stride;    // floats between two splits' partial results
 };
 
 __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(TK_THREADS) void k_gemm_bf16_tallk(const BfGemm p) 
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float rs0 = 0.f, rs1 = 0.f;
     uint4 va[TK_PPT], vb[TK_PPT];
 #pragma unroll
     for (int j = 0; j < TK_PPT; ++j) {
@@ -246,6 +249,19 @@ __global__ __launch_bounds__(TK_THREADS) void k_gemm_bf16_tallk(const BfGemm p) 
             }
         }
         __syncthreads();
+        if (p.rowsum_partial && blockIdx.x == 0 && threadIdx.x < TK_T) {       // sum of A's row over this chunk (zero-padded in LDS)
+            const uint16_t* ar = &As[threadIdx.x * TK_LDK];
+#pragma unroll
+            for (int c = 0; c < TK_KC; c += 8) {
+                const uint4 v = *reinterpret_cast<const uint4*>(ar + c);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    rs0 += __uint_as_float(w[j] << 16);
+                    rs1 += __uint_as_float(w[j] & 0xffff0000u);
+                }
+            }
+        }
         // the next chunk's loads fly while this one's MFMAs run (unconditional: past the slice's end they re-read its first
         // columns and are never used)
 #pragma unroll
@@ -269,7 +285,9 @@ __global__ __launch_bounds__(TK_THREADS) void k_gemm_bf16_tallk(const BfGemm p) 
         }
         __syncthreads();
     }
-    float* dst = p.partial + (size_t)blockIdx.z * p.m * p.n;
+    if (p.rowsum_partial && blockIdx.x == 0 && threadIdx.x < TK_T && m0 + (int)threadIdx.x < p.m)
+        p.rowsum_partial[(size_t)blockIdx.z * p.partial_stride + m0 + threadIdx.x] = rs0 + rs1;
+    float* dst = p.partial + (size_t)blockIdx.z * p.partial_stride;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -579,20 +597,23 @@ __global__ __launch_bounds__(256) void k_rowsum_finish_seg(const float* __restri
 }
 
 // out[i] (+)= sum_z partial[z][i], z in order
-__global__ __launch_bounds__(256) void k_splitk_sum(const float* __restrict__ partial, int splits, size_t mn, float* out,
-                                                    int accumulate) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (size_t)gridDim.x * 256) {
+// (a split's partial is `stride` floats: mn of the product, then -- out2 != NULL -- m2 row sums that go to out2, always added)
+__global__ __launch_bounds__(256) void k_splitk_sum(const float* __restrict__ partial, int splits, size_t mn, size_t stride, float* out,
+                                                    int accumulate, size_t m2, float* out2) {
+    const size_t total = mn + (out2 ? m2 : 0);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         float s = 0.f;
         int z = 0;
         for (; z + 8 <= splits; z += 8) {          // eight partials in flight, added in order
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = partial[(size_t)(z + j) * mn + i];
+            for (int j = 0; j < 8; ++j) v[j] = partial[(size_t)(z + j) * stride + i];
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += v[j];
         }
-        for (; z < splits; ++z) s += partial[(size_t)z * mn + i];
-        out[i] = accumulate ? out[i] + s : s;
+        for (; z < splits; ++z) s += partial[(size_t)z * stride + i];
+        if (i < mn) out[i] = accumulate ? out[i] + s : s;
+        else out2[i - mn] += s;
     }
 }
 
@@ -621,7 +642,8 @@ extern "C" int gv_gemm_bf16_nt(const void* a, int a_is_f32, int lda, const uint1
     BfGemm p;
     p.a = a; p.lda = lda; p.b = b; p.ldb = ldb; p.m = m; p.n = n; p.k = k; p.bias = bias; p.relu = relu; p.mask = mask;
     p.ldmask = ldmask; p.c_f32 = c_f32; p.ldc = ldc; p.accumulate = accumulate; p.c_bf = c_bf16; p.ldcb = ldcb;
-    p.c_bft = c_bf16_t; p.ldct = ldct; p.partial = nullptr; p.k_per_split = k;
+    p.c_bft = c_bf16_t; p.ldct = ldct; p.partial = nullptr; p.k_per_split = k; p.rowsum_partial = nullptr;
+    p.partial_stride = (size_t)m * n;
     hipStream_t st = (hipStream_t)stream;
     int splits = 1;
     bool tall = false;
@@ -660,8 +682,60 @@ extern "C" int gv_gemm_bf16_nt(const void* a, int a_is_f32, int lda, const uint1
     const size_t mn = (size_t)m * n;
     GV_REQUIRE(ldc == n, GV_ERR_SHAPE, "gv_gemm_bf16_nt: split-K needs a dense result (ldc == n)");
     hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)min((size_t)1024, (mn + 255) / 256)), dim3(256), 0, st,
-                       (const float*)workspace, splits, mn, c_f32, accumulate);
+                       (const float*)workspace, splits, mn, mn, c_f32, accumulate, (size_t)0, (float*)nullptr);
     return launch_status("gv_gemm_bf16_nt(split-k sum)");
+}
+
+/* The weight-gradient product of the masked MLP with its bias gradient from the same pass: c (+)= A B^T over a long reduction
+ * on the whole-output kernel, a_rowsum[i] += sum_k A[i][k].  Both dense fp32; fits: small outputs, bf16 operands, enough k. */
+static bool gradw_splits(int m, int n, int k, int split_k, int* per, int* splits) {
+    if (split_k < 2 || n > 2 * TK_T || m > 4 * TK_T || k < TK_KC * split_k) return false;
+    *per = ((k + split_k - 1) / split_k + TK_KC - 1) / TK_KC * TK_KC;
+    *splits = (k + *per - 1) / *per;
+    return true;
+}
+
+extern "C" int gv_gemm_bf16_gradw_fits(int m, int n, int k, int split_k) {
+    int per, splits;
+    return gradw_splits(m, n, k, split_k, &per, &splits) ? 1 : 0;
+}
+
+extern "C" int64_t gv_gemm_bf16_gradw_workspace_bytes(int m, int n, int split_k) {
+    return split_k > 1 ? (int64_t)split_k * m * (n + 1) * 4 : 0;
+}
+
+extern "C" int gv_gemm_bf16_gradw(const uint16_t* a, int lda, const uint16_t* b, int ldb, int m, int n, int k, float* c_f32,
+                                  int accumulate, float* a_rowsum, int split_k, void* workspace, int64_t workspace_bytes,
+                                  void* stream) {
+    GV_REQUIRE(m > 0 && n > 0 && k > 0, GV_ERR_SHAPE, "gv_gemm_bf16_gradw: m=%d n=%d k=%d", m, n, k);
+    GV_REQUIRE(a && b && c_f32 && workspace, GV_ERR_NULL, "gv_gemm_bf16_gradw: NULL pointer");
+    GV_REQUIRE(k % 8 == 0 && lda >= k && ldb >= k && lda % 8 == 0 && ldb % 8 == 0 && aligned16(a) && aligned16(b), GV_ERR_ALIGN,
+               "gv_gemm_bf16_gradw: k, lda, ldb must allow 16-B row pieces (k=%d lda=%d ldb=%d)", k, lda, ldb);
+    int per, splits;
+    GV_REQUIRE(gradw_splits(m, n, k, split_k, &per, &splits), GV_ERR_SHAPE,
+               "gv_gemm_bf16_gradw: %d x %d over k=%d with %d splits does not fit the whole-output kernel", m, n, k, split_k);
+    GV_REQUIRE(workspace_bytes >= (int64_t)splits * m * (n + 1) * 4, GV_ERR_WORKSPACE, "gv_gemm_bf16_gradw: workspace too small");
+    BfGemm p;
+    p.a = a; p.lda = lda; p.b = b; p.ldb = ldb; p.m = m; p.n = n; p.k = k; p.bias = nullptr; p.relu = 0; p.mask = nullptr;
+    p.ldmask = 0; p.c_f32 = c_f32; p.ldc = n; p.accumulate = accumulate; p.c_bf = nullptr; p.ldcb = 0; p.c_bft = nullptr; p.ldct = 0;
+    p.partial = (float*)workspace; p.k_per_split = per;
+    p.partial_stride = (size_t)m * (n + 1);         // a split's product, then its row sums
+    p.rowsum_partial = a_rowsum ? (float*)workspace + (size_t)m * n : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_gemm_bf16_tallk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TK_LDS_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("gv_gemm_bf16_gradw: cannot raise the dynamic LDS limit");
+            return GV_ERR_SHAPE;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_gemm_bf16_tallk, dim3((n + TK_T - 1) / TK_T, (m + TK_T - 1) / TK_T, splits), dim3(TK_THREADS), TK_LDS_BYTES, st, p);
+    const size_t mn = (size_t)m * n;
+    hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)min((size_t)1024, (mn + m + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+                       splits, mn, p.partial_stride, c_f32, accumulate, (size_t)m, a_rowsum);
+    return launch_status("gv_gemm_bf16_gradw");
 }
 
 extern "C" int gv_cast_bf16(const float* x, int ldx, int rows, int cols, uint16_t* y, int ldy, uint16_t* y_t, int ldt,

@@ -51,6 +51,9 @@ SIGNATURES = {
     'gv_gemm_f32': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P]),
     'gv_gemm_bf16': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P]),
     'gv_gemm_bf16_nt_workspace_bytes': (_L, [_I, _I, _I]),
+    'gv_gemm_bf16_gradw_fits': (_I, [_I, _I, _I, _I]),
+    'gv_gemm_bf16_gradw_workspace_bytes': (_L, [_I, _I, _I]),
+    'gv_gemm_bf16_gradw': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _L, _P]),
     'gv_gemm_bf16_nt': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P, _L, _P]),
     'gv_cast_bf16': (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P]),
     'gv_rowsum_bf16_workspace_floats': (_L, [_I, _I]),

@@ -2439,6 +2439,21 @@ def gemm_bf16_nt(a, b, m, n, k, bias=None, relu=False, mask=None, c_f32=None, ac
              split_k, ptr(ws), ws_bytes, lib.stream())
 
 
+def gemm_bf16_gradw_fits(m, n, k, split_k):
+    return bool(lib.load().gv_gemm_bf16_gradw_fits(int(m), int(n), int(k), int(split_k)))
+
+
+def gemm_bf16_gradw(a, b, m, n, k, c_f32, accumulate=True, a_rowsum=None, split_k=2):
+    """c_f32 (+)= A[m, k] @ B[n, k]^T over a long reduction on the whole-output kernel (gv_gemm_bf16_gradw), and, from the same
+    pass over A, a_rowsum[i] += sum_k A[i, k] (the bias gradient next to the weight gradient).  c_f32 dense (m, n)."""
+    if c_f32.stride(0) != n:
+        raise ValueError('gemm_bf16_gradw: the result must be dense')
+    ws_bytes = int(lib.load().gv_gemm_bf16_gradw_workspace_bytes(m, n, split_k))
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=a.device)
+    lib.call('gv_gemm_bf16_gradw', ptr(a), a.stride(0), ptr(b), b.stride(0), m, n, k, ptr(c_f32), 1 if accumulate else 0,
+             ptr(a_rowsum), split_k, ptr(ws), ws_bytes, lib.stream())
+
+
 class _ChainLayer(_ct.Structure):
     """gv_chain_layer of include/gcnvae.h."""
     _fields_ = [('w_packed', _ct.c_void_p), ('bias', _ct.c_void_p), ('mask', _ct.c_void_p), ('out_bf16', _ct.c_void_p),
@@ -2692,6 +2707,12 @@ class _MADEForwardBF16(torch.autograd.Function):
                     g_row = gemm(g_row, ws[l], a_relu_mask=mask, precision='bf16')
         g_ws, g_bs, g_bs_acc = [], [], []
         mtot = max(S, 1) * npad
+        # where each layer's bias gradient accumulates, and whether the weight-gradient launch can take it along
+        wants_gb = [ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l] for l in range(L)]
+        gb_target = [(row_gb[l] if ctx.row else None) if wants_gb[l] else None for l in range(L)]
+        fused_gb = [S > 0 and ctx.row and gb_target[l] is not None and ctx.needs_input_grad[3 + l] and row_gw[l] is not None
+                    and row_gw[l].stride(0) == ws[l].shape[1]
+                    and gemm_bf16_gradw_fits(widths[l], ws[l].shape[1], mtot, max(2, min(256, mtot // 512))) for l in range(L)]
         for l in range(L):
             mask0 = acts0[l] if l < L - 1 else None
             inp0 = zero_row if l == 0 else acts0[l - 1]
@@ -2700,14 +2721,18 @@ class _MADEForwardBF16(torch.autograd.Function):
                 gw = row_gw[l] if ctx.row else gemm(rows0[l], inp0, trans_a=True, a_relu_mask=mask0, precision='bf16')
                 if S > 0:       # dW_l = g_l^T a_{l-1}: the NT kernel on the transposed copies, reduction over all stacked rows
                     in_t = xin_t if l == 0 else acts_t[l - 1]
-                    gemm_bf16_nt(gm_t[l], in_t, widths[l], ws[l].shape[1], mtot, c_f32=gw, accumulate=True,
-                                 split_k=max(2, min(256, mtot // 512)))
+                    split = max(2, min(256, mtot // 512))
+                    if fused_gb[l]:      # ... and the stacked passes' share of the bias gradient from the same pass over g_l^T
+                        gemm_bf16_gradw(gm_t[l], in_t, widths[l], ws[l].shape[1], mtot, gw, accumulate=True,
+                                        a_rowsum=gb_target[l], split_k=split)
+                    else:
+                        gemm_bf16_nt(gm_t[l], in_t, widths[l], ws[l].shape[1], mtot, c_f32=gw, accumulate=True, split_k=split)
             if ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l]:
                 gb = row_gb[l] if ctx.row else colsum(rows0[l], relu_mask=mask0)
                 if S > 0 and L > 8:
                     rws = torch.empty(int(lib.load().gv_rowsum_bf16_workspace_floats(widths[l], mtot)), **f32)
                     lib.call('gv_rowsum_bf16', ptr(gm_t[l]), gm_t[l].stride(0), widths[l], mtot, ptr(gb), 1, ptr(rws), st)
-            g_bs_acc.append(gb)             # where the stacked passes' row sums of this layer are added (may be an arena slice)
+            g_bs_acc.append(None if fused_gb[l] else gb)      # where the row-sum pass still has to add this layer's share
             if ctx.row and gb is not None and direct_b[l] is not None:
                 GRAD_FRESH.discard(gb.data_ptr())
                 gb = None

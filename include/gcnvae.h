@@ -184,6 +184,14 @@ int gv_gemm_bf16_nt(const void* a, int a_is_f32, int lda, const uint16_t* b, int
                     int relu, const uint16_t* mask, int ldmask, float* c_f32, int ldc, int accumulate, uint16_t* c_bf16,
                     int ldcb, uint16_t* c_bf16_t, int ldct, int split_k, void* workspace, int64_t workspace_bytes,
                     void* stream);
+/* The weight-gradient product of the masked MLP, dW = g^T a over all stacked rows, with the bias gradient from the same pass:
+ * c_f32 [m][n] (+)= A B^T (A [m][lda], B [n][ldb] bf16, k the long reduction), a_rowsum[i] += sum_k A[i][k] (NULL: skipped).
+ * Whole-output kernel: every operand element is read once.  gv_gemm_bf16_gradw_fits: 1 when (m, n, k, split_k) suit it
+ * (n <= 448, m <= 896, k >= 128 split_k) -- otherwise use gv_gemm_bf16_nt with split_k and gv_rowsum_bf16. */
+int gv_gemm_bf16_gradw_fits(int m, int n, int k, int split_k);
+int64_t gv_gemm_bf16_gradw_workspace_bytes(int m, int n, int split_k);
+int gv_gemm_bf16_gradw(const uint16_t* a, int lda, const uint16_t* b, int ldb, int m, int n, int k, float* c_f32, int accumulate,
+                       float* a_rowsum, int split_k, void* workspace, int64_t workspace_bytes, void* stream);
 int gv_cast_bf16(const float* x, int ldx, int rows, int cols, uint16_t* y, int ldy, uint16_t* y_t, int ldt, void* stream);
 int64_t gv_rowsum_bf16_workspace_floats(int rows, int cols);
 int gv_rowsum_bf16(const uint16_t* x, int ld, int rows, int cols, float* out, int accumulate, float* workspace, void* stream);

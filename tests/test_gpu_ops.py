@@ -1442,3 +1442,24 @@ def test_iaf_update_bf16_kernels_match_the_formulas(ops, n, d):
     close(gnb[:, :d].float(), w_gmu, rtol=1e-2, atol_scale=1e-2, msg='g_mu (bf16)')
     close(gnb[:, d:2 * d].float(), w_gal, rtol=1e-2, atol_scale=1e-2, msg='g_alpha (bf16)')
     assert torch.equal(gnt[:d, :n].float(), gnb[:, :d].float().t()) and torch.equal(gnt[d:, :n].float(), gnb[:, d:2 * d].float().t())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('m,n,k,split', [(200, 200, 4096, 8), (400, 200, 5000, 12), (72, 40, 1032, 3), (230, 448, 2048, 5)])
+def test_gemm_bf16_gradw_weight_gradient_with_bias_gradient_from_the_same_pass(ops, m, n, k, split):
+    """gv_gemm_bf16_gradw: c += A B^T over a long reduction on the whole-output kernel, a_rowsum += row sums of A -- against
+    fp32 matmul / sums of the bf16 operands; both outputs ACCUMULATE."""
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).to(dev).to(torch.bfloat16)
+    b = torch.randn(n, k, generator=g).to(dev).to(torch.bfloat16)
+    assert ops.gemm_bf16_gradw_fits(m, n, k, split)
+    c = torch.full((m, n), 2.0, device=dev)
+    rs = torch.full((m,), -1.0, device=dev)
+    ops.gemm_bf16_gradw(a, b, m, n, k, c, accumulate=True, a_rowsum=rs, split_k=split)
+    close(c, a.float().cpu() @ b.float().cpu().t() + 2.0, rtol=1e-4, atol_scale=1e-5, msg='c')
+    close(rs, a.float().cpu().sum(dim=1) - 1.0, rtol=1e-4, atol_scale=1e-5, msg='row sums')
+    c2 = torch.zeros(m, n, device=dev)
+    ops.gemm_bf16_gradw(a, b, m, n, k, c2, accumulate=False, a_rowsum=None, split_k=split)
+    close(c2, a.float().cpu() @ b.float().cpu().t(), rtol=1e-4, atol_scale=1e-5, msg='c, no row sums')
+    assert not ops.gemm_bf16_gradw_fits(m, 1000, k, split) and not ops.gemm_bf16_gradw_fits(m, n, 64, split)
