@@ -690,16 +690,20 @@ def test_direct_gradient_registry_change_between_forward_and_backward_is_refused
     assert float(table.grad.abs().sum()) > 0 and table.grad.data_ptr() == opt.flat_g[opt.offsets[table]:].data_ptr()
 
 
-def test_train_driver_with_graph_step(tmp_path, capsys):
+@pytest.mark.parametrize('bf16', [False, True])
+def test_train_driver_with_graph_step(tmp_path, capsys, bf16):
     """gcn_vae_amd.train.main --device-sampler --graph-step: every step is one hipGraph replay; evaluation and the checkpoint
-    round trip work as in the eager loop."""
-    from gcn_vae_amd import train
+    round trip work as in the eager loop.  With --bf16 the flows run on the one-launch-per-pass MADE kernels inside the graph."""
+    from gcn_vae_amd import ops, train
     ckpt = str(tmp_path / 'model_state.pth')
     argv = ['-d', 'synthetic:400:9:3000:150:150:1', '--gpu', '0', '--n-hidden', '16', '--n-bases', '4', '--n-epochs', '8',
             '--evaluate-every', '4', '--graph-batch-size', '600', '--eval-batch-size', '50', '--mmd-param', '1.0', '--kl-param', '1e-3',
-            '--n-flows', '2', '--mog-k', '4', '--model-state-file', ckpt, '--device-sampler', '--graph-step']
+            '--n-flows', '2', '--mog-k', '4', '--model-state-file', ckpt, '--device-sampler', '--graph-step'] + (['--bf16'] if bf16 else [])
     torch.manual_seed(0)
-    best = train.main(train.build_parser().parse_args(argv))
+    try:
+        best = train.main(train.build_parser().parse_args(argv))
+    finally:
+        ops.set_gemm_precision('f32')
     out = capsys.readouterr().out
     assert out.count('Epoch 00') == 5 and 'training done' in out and 0.0 < best <= 1.0       # 3 warm-up steps + 5 replays = 8
     losses = [float(line.split('Loss ')[1].split(' |')[0]) for line in out.splitlines() if line.startswith('Epoch 00')]
