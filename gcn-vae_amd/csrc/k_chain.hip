@@ -338,7 +338,21 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 
 // packed[(t * ks + s) * 64 + lane][e] = bf16(B[32 t + (lane & 31)][16 s + 8 (lane >> 5) + e]), zero outside B;
 // forward: B = W [n][k]; backward: B = W^T [k][n] (its tiles run over k, its steps over n)
+struct PackOne { const float* w; int ld, n, k; uint4* fwd; uint4* bwd; };
+struct PackMulti { PackOne e[GV_CHAIN_MAX_LAYERS]; };
+
+__device__ __forceinline__ void pack_b_frag(const float* __restrict__ w, int ld, int n, int k, uint4* fwd, uint4* bwd);
+
 __global__ __launch_bounds__(256) void k_pack_b_frag(const float* __restrict__ w, int ld, int n, int k, uint4* fwd, uint4* bwd) {
+    pack_b_frag(w, ld, n, k, fwd, bwd);
+}
+// every layer of a MADE in one launch (blockIdx.y = layer)
+__global__ __launch_bounds__(256) void k_pack_b_frag_multi(const PackMulti p) {
+    const PackOne& e = p.e[blockIdx.y];
+    pack_b_frag(e.w, e.ld, e.n, e.k, e.fwd, e.bwd);
+}
+
+__device__ __forceinline__ void pack_b_frag(const float* __restrict__ w, int ld, int n, int k, uint4* fwd, uint4* bwd) {
     const int ks_f = (k + 15) >> 4, nt_f = (n + 31) >> 5, tot_f = nt_f * ks_f * 64;
     const int ks_b = (n + 15) >> 4, nt_b = (k + 31) >> 5, tot_b = nt_b * ks_b * 64;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < tot_f + tot_b; idx += gridDim.x * 256) {
@@ -381,6 +395,25 @@ extern "C" int gv_made_pack_weight(const float* w, int ld, int n, int k, uint16_
     hipLaunchKernelGGL(k_pack_b_frag, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ld, n, k,
                        (uint4*)packed_fwd, (uint4*)packed_bwd);
     return launch_status("gv_made_pack_weight");
+}
+
+extern "C" int gv_made_pack_weight_multi(int count, const float* const* w, const int32_t* ld, const int32_t* n, const int32_t* k,
+                                         uint16_t* const* packed_fwd, uint16_t* const* packed_bwd, void* stream) {
+    GV_REQUIRE(count >= 1 && count <= GV_CHAIN_MAX_LAYERS, GV_ERR_SHAPE, "gv_made_pack_weight_multi: count=%d", count);
+    GV_REQUIRE(w && ld && n && k && packed_fwd && packed_bwd, GV_ERR_NULL, "gv_made_pack_weight_multi: NULL table");
+    PackMulti p;
+    int64_t most = 0;
+    for (int i = 0; i < count; ++i) {
+        GV_REQUIRE(n[i] > 0 && k[i] > 0 && ld[i] >= k[i] && w[i] && (packed_fwd[i] || packed_bwd[i]), GV_ERR_SHAPE,
+                   "gv_made_pack_weight_multi: entry %d: n=%d k=%d ld=%d", i, n[i], k[i], ld[i]);
+        GV_REQUIRE((!packed_fwd[i] || aligned16(packed_fwd[i])) && (!packed_bwd[i] || aligned16(packed_bwd[i])), GV_ERR_ALIGN,
+                   "gv_made_pack_weight_multi: packed buffers must be 16-B aligned");
+        p.e[i].w = w[i]; p.e[i].ld = ld[i]; p.e[i].n = n[i]; p.e[i].k = k[i];
+        p.e[i].fwd = (uint4*)packed_fwd[i]; p.e[i].bwd = (uint4*)packed_bwd[i];
+        most = max(most, (gv_made_pack_weight_elems(n[i], k[i]) + gv_made_pack_weight_elems(k[i], n[i])) / 8);
+    }
+    hipLaunchKernelGGL(k_pack_b_frag_multi, dim3((unsigned)((most + 255) / 256), count), dim3(256), 0, (hipStream_t)stream, p);
+    return launch_status("gv_made_pack_weight_multi");
 }
 
 /* bytes of LDS a chain needs (0: the chain does not fit this kernel) */

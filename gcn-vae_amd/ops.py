@@ -2510,6 +2510,23 @@ def made_pack_weight(w, fwd=True, bwd=True):
     return pf, pb
 
 
+def made_pack_weights(ws):
+    """made_pack_weight for every layer of a MADE (at most 8) in one launch: [(packed W, packed W^T), ...]."""
+    ws = [_row_major(w, 'w') for w in ws]
+    l = lib.load()
+    dev = ws[0][0].device
+    pf = [torch.empty(int(l.gv_made_pack_weight_elems(w.shape[0], w.shape[1])), dtype=torch.bfloat16, device=dev) for w, _ in ws]
+    pb = [torch.empty(int(l.gv_made_pack_weight_elems(w.shape[1], w.shape[0])), dtype=torch.bfloat16, device=dev) for w, _ in ws]
+    k = len(ws)
+    tp = lambda ts: (_ct.c_void_p * k)(*[ptr(t) for t in ts])
+    ti = lambda vs: (_ct.c_int32 * k)(*[int(v) for v in vs])
+    tw, tf, tb = tp([w for w, _ in ws]), tp(pf), tp(pb)
+    tl, tn, tk = ti([ld for _, ld in ws]), ti([w.shape[0] for w, _ in ws]), ti([w.shape[1] for w, _ in ws])
+    lib.call('gv_made_pack_weight_multi', k, _ct.addressof(tw), _ct.addressof(tl), _ct.addressof(tn), _ct.addressof(tk),
+             _ct.addressof(tf), _ct.addressof(tb), lib.stream())
+    return list(zip(pf, pb))
+
+
 def made_chain_fits(widths_n, widths_k, any_mask):
     nl = len(widths_n)
     arr_n = (_ct.c_int32 * nl)(*[int(v) for v in widths_n])
@@ -2569,7 +2586,7 @@ class _MADEForwardBF16(torch.autograd.Function):
         chain = (MADE_CHAIN and S > 0 and L <= 8 and made_chain_fits(widths, [w.shape[1] for w in ws], False)
                  and made_chain_fits([w.shape[1] for w in reversed(ws)], [w.shape[0] for w in reversed(ws)], True))
         if chain:       # one launch per pass: fragment-packed weights (forward and transposed form from one launch per layer)
-            packed = [made_pack_weight(w) for w in ws]
+            packed = made_pack_weights(ws)
             wbf, wbt = [pk[0] for pk in packed], [pk[1] for pk in packed]
         else:
             wbf = [torch.empty(w.shape[0], _pad8(w.shape[1]), **bf) for w in ws]

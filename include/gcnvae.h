@@ -226,6 +226,9 @@ typedef struct gv_chain_layer {
 } gv_chain_layer;
 int64_t gv_made_pack_weight_elems(int n, int k);
 int gv_made_pack_weight(const float* w, int ld, int n, int k, uint16_t* packed_fwd, uint16_t* packed_bwd, void* stream);
+/* ... of up to GV_CHAIN_MAX_LAYERS weights in one launch (host tables, read during the call). */
+int gv_made_pack_weight_multi(int count, const float* const* w, const int32_t* ld, const int32_t* n, const int32_t* k,
+                              uint16_t* const* packed_fwd, uint16_t* const* packed_bwd, void* stream);
 int gv_made_chain_fits(int n_layers, const int32_t* n_of_layer, const int32_t* k_of_layer, int any_mask);
 int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, void* stream);
 /* ---------------------------------------------------------------------------------------------
