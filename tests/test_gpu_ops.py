@@ -1463,3 +1463,43 @@ def test_gemm_bf16_gradw_weight_gradient_with_bias_gradient_from_the_same_pass(o
     ops.gemm_bf16_gradw(a, b, m, n, k, c2, accumulate=False, a_rowsum=None, split_k=split)
     close(c2, a.float().cpu() @ b.float().cpu().t(), rtol=1e-4, atol_scale=1e-5, msg='c, no row sums')
     assert not ops.gemm_bf16_gradw_fits(m, 1000, k, split) and not ops.gemm_bf16_gradw_fits(m, n, 64, split)
+
+
+@pytest.mark.gpu
+def test_multi_tensor_entry_points_of_the_made_path(ops):
+    """gv_mul_multi, gv_made_pack_weight_multi and gv_rowsum_bf16_segments (several tensors per launch, host pointer tables)
+    against their one-tensor counterparts."""
+    import ctypes
+    from gcn_vae_amd import lib
+    from gcn_vae_amd.lib import ptr
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(7)
+    shapes = [(200, 200), (400, 200), (8, 24), (1, 1)]
+    a = [torch.randn(*s, generator=g).to(dev) for s in shapes]
+    b = [torch.randn(*s, generator=g).to(dev) for s in shapes]
+    # products: new outputs, and written into given tensors
+    outs = ops.mul_multi(a, b)
+    for o, x, y in zip(outs, a, b):
+        assert torch.equal(o, x * y)
+    given = [torch.full(s, 3.0, device=dev) for s in shapes]
+    res = ops.mul_multi(a, b, outs=[given[0], None, given[2], None])
+    assert res[0] is given[0] and res[2] is given[2] and torch.equal(given[0], a[0] * b[0]) and torch.equal(res[1], a[1] * b[1])
+    # packing: every layer in one launch == one launch per layer
+    ws = [x for x in a[:3]]
+    multi = ops.made_pack_weights(ws)
+    for w, (pf, pb) in zip(ws, multi):
+        sf, sb = ops.made_pack_weight(w)
+        assert torch.equal(pf.view(torch.int16), sf.view(torch.int16)) and torch.equal(pb.view(torch.int16), sb.view(torch.int16))
+    # row sums of stacked bf16 rows, cut into segments with their own (accumulating) outputs; a NULL output skips its segment
+    rows, cols, segs = 37, 9000, [5, 20, 12]
+    x = torch.randn(rows, cols, generator=g).to(dev).to(torch.bfloat16)
+    o = [torch.full((s,), 0.5, device=dev) for s in segs]
+    tab = (ctypes.c_void_p * 3)(ptr(o[0]), None, ptr(o[2]))
+    sg = (ctypes.c_int32 * 3)(*segs)
+    wsp = torch.empty(int(lib.load().gv_rowsum_bf16_workspace_floats(rows, cols)), device=dev)
+    lib.call('gv_rowsum_bf16_segments', ptr(x), x.stride(0), rows, cols, 3, ctypes.addressof(tab), ctypes.addressof(sg), 1, ptr(wsp),
+             lib.stream())
+    want = x.float().sum(dim=1)
+    close(o[0], 0.5 + want[:5], rtol=1e-4, atol_scale=1e-5, msg='segment 0')
+    close(o[2], 0.5 + want[25:], rtol=1e-4, atol_scale=1e-5, msg='segment 2')
+    assert torch.equal(o[1], torch.full((20,), 0.5, device=dev))
