@@ -28,7 +28,12 @@ class PermuteLayer(nn.Module):
         self.perm = np.array(np.arange(0, num_inputs)[::-1])
 
     def forward(self, inputs):
-        return ops.reverse_cols(inputs), torch.zeros(inputs.size(0), 1, device=inputs.device)
+        # log-det of a permutation: zeros (kgvae/flow_network.py:28-30) -- one constant tensor per shape, not a fill per call
+        key = (inputs.size(0), inputs.device)
+        zero = getattr(self, '_zero', None)
+        if zero is None or zero[0] != key:
+            zero = self._zero = (key, torch.zeros(inputs.size(0), 1, device=inputs.device))
+        return ops.reverse_cols(inputs), zero[1]
 
     def inverse(self, inputs):
         return self.forward(inputs)
