@@ -2,8 +2,10 @@
 """bench.py -- edges/sec of the R-GCN-VAE forward+backward hot path on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W      (no launcher: bench.py starts the N ranks itself, as a CHILD
+                                                        torch.distributed.run job, before it touches the GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--scaling weak|strong]
+        bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--scaling strong|weak]
 
 Workloads (BASELINE.json configs, all seeded synthetics -- no dataset on disk, no network):
   c2 (default, configs[1]) FB15k-237-shaped: 14 541 entities, 237 relations = 474 directed edge types, 272 115 triplets
@@ -15,9 +17,10 @@ Workloads (BASELINE.json configs, all seeded synthetics -- no dataset on disk, n
   c5 (configs[4]) 1 M entities, 1 000 relations, 25 M triplets => 50 M directed edges, emb_dim=200 (generated on the device)
 One step = forward + loss (BCE + 0.01 reg + 1e-5 KL + 1.0 MMD) + backward + grad-clip + Adam, i.e. the reference's
 t0..t2 span (kgvae/link_predict.py:222-229) with device synchronisation.
---scaling weak (default): every rank holds one such edge block (seed = rank) and triplet slice; the graph trained is the
-union.  --scaling strong: ONE graph (seed 0), its directed edges cut by RELATION across the ranks
-(distributed.shard_edges_by_relation, north_star) or by destination row (--partition row), its triplets dealt round-robin.
+--scaling strong (default): ONE graph (seed 0), whatever the rank count: its directed edges are cut by RELATION across the
+ranks (distributed.shard_edges_by_relation, north_star / BASELINE configs[3..4]) or by destination row (--partition row),
+its triplets dealt round-robin.  --scaling weak: every rank brings its own edge block (seed = rank) and triplet slice;
+the graph trained is the union of the blocks.
 Node embeddings are exchanged over RCCL once per layer per direction, parameter gradients once per step.
 
 Rank 0 prints ONE JSON line: value = directed edges of the trained graph x steps / max-over-ranks seconds.
@@ -60,8 +63,15 @@ def parse():
     p.add_argument('--steps', type=int, default=30)
     p.add_argument('--warmup', type=int, default=5)
     p.add_argument('--config', choices=sorted(CONFIGS), default='c2', help='BASELINE.json workload (see the module docstring)')
-    p.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
-                   help='world size > 1: weak = one edge block per rank (union graph), strong = ONE graph cut across the ranks')
+    p.add_argument('--scaling', choices=['weak', 'strong'], default='strong',
+                   help='world size > 1: strong = ONE graph cut across the ranks (BASELINE configs[3..4]), weak = one edge '
+                        'block per rank (the union graph grows with the rank count)')
+    p.add_argument('--repeats', type=int, default=3,
+                   help='timed regions of --steps steps each: the first one is `value` (the contract\'s EXACTLY K steps), '
+                        'the median over all of them is reported beside it')
+    p.add_argument('--launch-check', action='store_true',
+                   help='only start the ranks, form the process group (gloo when there is no GPU) and report how many ranks '
+                        'met; no compute (tests/test_distributed_cpu.py runs it on CPU)')
     p.add_argument('--hidden', type=int, default=None, help='override the config\'s emb_dim')
     p.add_argument('--n-bases', type=int, default=None)
     p.add_argument('--n-flows', type=int, default=None)
@@ -387,8 +397,68 @@ def parity_check(model, opt, inputs, ref, dev, bf16_products=False):
          enc.rconv_layer_2.keep_mask_override) = saved
 
 
+def self_launch(n):
+    """``bench.py --gpus N`` without a launcher (WORLD_SIZE unset): start the N ranks as a CHILD ``torch.distributed.run``
+    job -- one process per GPU, rendezvous on 127.0.0.1 -- relay rank 0's JSON line and return the child's exit code.
+    Called before this process has made any HIP call (a process that has initialised the GPU must not be replaced or
+    forked into GPU work on this pool); the parent never touches the GPU at all."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+               GV_BENCH_SELF_LAUNCHED='1')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 1) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:          # rank 0 prints the one JSON line; anything else a library wrote to fd 1 goes to stderr
+        text = line.strip()
+        is_result = False
+        if text.startswith('{'):
+            try:
+                is_result = isinstance(json.loads(text), dict)
+            except ValueError:
+                pass
+        print(text, file=sys.stdout if is_result else sys.stderr, flush=True)
+    return proc.wait()
+
+
+def launch_check(args):
+    """--launch-check: the ranks meet (process group over 127.0.0.1; RCCL when every rank has a GPU, else gloo), count each
+    other with one all-reduce and rank 0 prints what the real run would claim about the job.  No kernels."""
+    import torch.distributed as dist
+    rank, local_rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    n_dev = torch.cuda.device_count()        # counting devices does not initialise the GPU
+    backend = os.environ.get('GV_DIST_BACKEND', 'nccl' if n_dev >= world else 'gloo')
+    seen = 1
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            one = torch.ones(1, device='cuda')
+        else:
+            dist.init_process_group('gloo')
+            one = torch.ones(1)
+        dist.all_reduce(one)
+        seen = int(one.item())
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({'launch_check': True, 'n_gpus': world, 'ranks_seen': seen, 'requested_gpus': args.gpus,
+                          'scaling': args.scaling, 'backend': backend if world > 1 else None,
+                          'self_launched': bool(os.environ.get('GV_BENCH_SELF_LAUNCHED'))}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))       # before any HIP call in this process
+    if args.launch_check:
+        return launch_check(args)
     # stdout carries ONE JSON line: libraries that print banners to fd 1 (RCCL prints its version block there when a
     # communicator is created) write to stderr instead until the result line is printed
     sys.stdout.flush()
@@ -397,9 +467,8 @@ def main():
     from gcn_vae_amd import distributed as gdist
     from gcn_vae_amd import lib
     rank, local_rank, world = gdist.env_world()
-    if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run', file=sys.stderr)
+    if world != args.gpus:      # a launcher's WORLD_SIZE wins (the driver passes the same number to both)
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; running {world} rank(s)', file=sys.stderr)
         world = max(world, 1)
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs an MI355X (no CPU path); the cpu_baseline leg alone is not a benchmark')
@@ -639,26 +708,32 @@ def main():
 
     for _ in range(args.warmup):
         loss = run_step()
-    torch.cuda.synchronize()
+    # EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks: the first region is `value`; the
+    # further --repeats - 1 regions (same bracket) give the median reported beside it
+    regions = []
+    for _rep in range(max(1, args.repeats)):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = run_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        regions.append(time.perf_counter() - t0)
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = run_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        tt = torch.tensor(regions, device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        regions = [float(v) for v in tt.tolist()]
+    elapsed = regions[0]
     lt = loss.detach().reshape(1).clone()
     if world > 1:      # edge-block: mean of the ranks' losses; row partition: the ranks hold SHARES of the loss
         dist.all_reduce(lt)
         if cur['name'] != 'row':
             lt /= world
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
     final_loss = float(lt.item())
     edge_counts = None
     if world > 1 and cur['name'] == 'row':
@@ -669,15 +744,22 @@ def main():
 
     # ---- roofline leg: the same step, eager, with HIP events around the K1 launches --------------
     roofline, detail, k4 = None, {}, {}
-    if rank == 0 and args.profile_steps > 0:
+    per_rank_k1 = None
+    if args.profile_steps > 0:
+        # every rank runs the instrumented steps (the collectives need all of them); each grades its OWN launches against
+        # its OWN edge count, rank 0's detail goes into the line and all ranks' K1 GB/s into `k1_GBs_per_rank`
         lib.TIMER = lib.KernelTimer()
-        if world == 1:
-            for _ in range(args.profile_steps):
-                refresh_host_inputs()
-                step_body()
+        for _ in range(args.profile_steps):
+            refresh_host_inputs()
+            step_body()
+            if dist_on:
+                torch.cuda.synchronize()
         ms = lib.TIMER.results_ms()
         lib.TIMER = None
         R = 2 * w['data'].num_rels
+        E_all = E
+        if cur['name'] == 'row':
+            E = int(cur['edges'])
         # K4 (the fused MADE pass, gv_made_chain): an MFMA kernel -- flops of one launch over its HIP-event time, against the
         # dense bf16 MFMA peak of MI355X_MICROARCH.md.  At these sizes (1.2 GFLOP per product, 228 workgroups on 256 CUs) the
         # launch is bound by its per-layer dependency chain, not by the matrix cores: the fraction says how far.
@@ -726,6 +808,12 @@ def main():
                         'frac_min': min(v['frac'] for v in rg.values()), 'frac_max': max(v['frac'] for v in rg.values()),
                         'frac_of_hbm_peak_min': min(v['frac_of_hbm_peak'] for v in rg.values()),
                         'instances': {k: v['frac'] for k, v in sorted(rg.items())}}
+        E = E_all
+        if world > 1:      # every rank's K1 aggregation rates (GB/s of its own algorithmic bytes), keyed by instance
+            mine = {k: v['achieved_GBs'] for k, v in detail.items() if k.startswith('agg_') and not k.startswith('agg_N_1x1')}
+            per_rank_k1 = [None] * world
+            dist.all_gather_object(per_rank_k1, mine)
+    ranks_seen = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     if world > 1:
         dist.barrier()
 
@@ -734,7 +822,9 @@ def main():
             'metric': 'edges/sec R-GCN forward+backward, FB15k-237 emb=200',
             'value': trained_edges * args.steps / elapsed, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'strong' if w['strong'] else 'weak', 'vs_baseline': None,
+            'ms_per_step_median': float(np.median(regions)) / args.steps * 1e3,
+            'ms_per_step_repeats': [round(r / args.steps * 1e3, 5) for r in regions],
+            'ranks_seen': ranks_seen, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32' if args.gemm_precision == 'f32' else 'f32 (dense products: bf16 operands, f32 accumulate)',
             'data': 'synthetic',
             'config': {'workload': '%s: %d entities, %d directed relation types, E=%d directed edges on this rank (%d in the '
@@ -755,7 +845,7 @@ def main():
                        'partition_probe_ms_per_step': {k: round(v, 4) for k, v in probe.items()} or None,
                        'row_partition_edges_per_rank': edge_counts},
             'final_loss': final_loss,
-            'roofline': roofline, 'roofline_detail': detail, 'roofline_k4': k4 or None,
+            'roofline': roofline, 'roofline_detail': detail, 'roofline_k4': k4 or None, 'k1_GBs_per_rank': per_rank_k1,
         }
         out['cpu_baseline'], out['parity_check'] = None, None
         if world == 1 and not args.no_cpu_baseline:

@@ -166,8 +166,14 @@ int order_and_items(const int* keys, int64_t n, int n_seg, int chunk, int* perm,
     const int* sorted = keys;
     const unsigned short* sorted16 = nullptr;
     if (perm && n >= 100000 && n_seg <= 65536) {      // 2-byte keys: the two halves of the keys_sorted area hold them (in / out)
+        // the area is align256(4 n) bytes; the output half starts n shorts in, rounded up to 16 B: it ends at most
+        // 4 n + 14 bytes in, and whenever that rounding adds anything (n % 8 = m > 0) the area's own padding,
+        // 256 - 4 (n % 64) >= 32 - 4 m bytes, covers the 16 - 2 m added -- the sort never writes into sc.iota behind it
         unsigned short* k16_in = (unsigned short*)sc.keys_sorted;
-        unsigned short* k16_out = k16_in + ((n + 127) & ~(int64_t)127);
+        const int64_t out_at = (n + 7) & ~(int64_t)7;
+        if ((size_t)(out_at + n) * sizeof(unsigned short) > align256((size_t)n * sizeof(int)))
+            GV_REQUIRE(false, GV_ERR_SHAPE, "gv index: 16-bit key halves do not fit the key area (n=%lld)", (long long)n);
+        unsigned short* k16_out = k16_in + out_at;
         hipLaunchKernelGGL(k_iota_narrow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc.iota, keys, k16_in, n);
         size_t tb = sc.cub_bytes;
         GV_HIP_OK(hipcub::DeviceRadixSort::SortPairs(sc.cub, tb, (const unsigned short*)k16_in, k16_out, (const int*)sc.iota, perm,

@@ -6,6 +6,8 @@ is device independent; here the local arithmetic is the CPU oracle and the resul
 single-process run on the union graph with loss = mean of the ranks' losses."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -17,6 +19,7 @@ from oracle import kgvae as okg
 from oracle import rgcn as orgcn
 
 N, R, H, NB, E, T = 60, 8, 8, 4, 500, 120
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def make_problem():
@@ -303,3 +306,45 @@ def test_row_partitioned_training_step_equals_single_process():
         assert abs(total - ref_loss) < 1e-5
         np.testing.assert_allclose(arena, ref_flat, rtol=1e-4, atol=1e-6, err_msg=f'rank {rank}')
     np.testing.assert_array_equal(results[0][1], results[1][1])
+
+
+def _bench_env():
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'GV_DIST_BACKEND'):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts its own 2-rank torch.distributed.run child (before any HIP
+    call), the ranks meet over 127.0.0.1 (gloo on this GPU-less box), rank 0's one JSON line is relayed: n_gpus = 2,
+    ranks_seen = 2, strong scaling by default.  --launch-check stops before the compute, which needs an MI355X."""
+    import json
+    bench = os.path.join(ROOT, 'bench.py')
+    out = subprocess.run([sys.executable, bench, '--gpus', '2', '--launch-check'], cwd=ROOT, env=_bench_env(),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['self_launched'] and d['scaling'] == 'strong'
+    # under a launcher (the driver's form) the same flags do not start a second job
+    port = free_port()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), bench, '--gpus', '2', '--launch-check', '--scaling', 'weak']
+    out = subprocess.run(cmd, cwd=ROOT, env=_bench_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and not d['self_launched'] and d['scaling'] == 'weak'
+
+
+def test_bench_self_launch_returns_the_childs_exit_code():
+    """No GPU here: the ranks of a self-launched run refuse to compute (there is no CPU path) and bench.py exits non-zero
+    with their message on stderr instead of printing a result line."""
+    if torch.cuda.is_available():
+        pytest.skip('needs a GPU-less box')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         cwd=ROOT, env=_bench_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert 'needs an MI355X' in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{')]

@@ -955,11 +955,15 @@ def test_native_triplet_index_equals_torch_formulation(ops, T, n_ent, n_rel):
     assert a.fwd_order is None and a.pos3 is None and b.fwd_order is None and b.pos3 is None
 
 
-def test_gv_build_csr_single_ordering(ops):
+@pytest.mark.parametrize('n,n_seg', [(10000, 37),
+                                     # the 16-bit-key path (n >= 100 000) in ONE scatter pass (n_seg <= 256) at the lengths where the
+                                     # sorted-key half once ran past its area into the sort's own value input: n % 128 in [1, 64]
+                                     (100000 + 33, 200), (131072 + 64, 256), (440000, 237), (100000 + 1, 3), (100000 + 57, 255)])
+def test_gv_build_csr_single_ordering(ops, n, n_seg):
     from gcn_vae_amd import lib
     from gcn_vae_amd.lib import ptr
     rs = np.random.RandomState(3)
-    n, n_seg, chunk = 10000, 37, 128
+    chunk = 128
     keys = torch.from_numpy(rs.randint(0, n_seg, size=n).astype(np.int32)).cuda()
     ci, cf, _ = ops._index_caps(n, n_seg, chunk)
     perm, rowptr, items, fix = ops._carve_i32(keys.device, [n, n_seg + 1, 4 * ci, 4 * cf])

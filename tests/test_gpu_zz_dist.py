@@ -78,12 +78,12 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GV_DIST_BACKEND='gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-           '--no-cpu-baseline', '--profile-steps', '0', '--positives', '2000']
+           '--no-cpu-baseline', '--profile-steps', '0', '--positives', '2000', '--scaling', 'weak']
     out = run_ranks(cmd, env, 900)
     assert out.returncode == 0, (out.stdout[-1500:] + '\n' + out.stderr[-2500:])
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
     d = json.loads(line)
-    assert d['n_gpus'] == 2 and d['scaling'] == 'weak'
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['ranks_seen'] == 2
     assert d['config']['launch'] == 'eager' or d['config']['launch'].startswith('hipgraph segments')
     assert d['value'] > 0 and d['final_loss'] == d['final_loss']
     # "auto" probes both multi-GPU schemes during warm-up and runs the faster one
@@ -113,12 +113,34 @@ def test_bench_two_ranks_strong_scaling_one_graph(extra):
         assert d['config']['baseline_config'] == 'configs[3]' and 'emb_dim=500' in d['config']['workload']
 
 
+def test_bench_starts_its_own_ranks_strong_scaling_by_default():
+    """`python bench.py --gpus 2` with NO launcher (what the driver's contract line may be run as): bench.py starts the two
+    ranks itself as a child torch.distributed.run job before touching the GPU, relays rank 0's JSON line and its exit code.
+    Defaults: ONE graph cut across the ranks (strong scaling), both schemes probed, K1 rates of every rank in the line,
+    three timed regions with their median.  (gloo: the two ranks share the box's one GPU.)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GV_DIST_BACKEND='gloo')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+           '--profile-steps', '2', '--positives', '2000', '--probe-steps', '2']
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:] + '\n' + out.stderr[-2500:])
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines          # stdout carries the one JSON line and nothing else
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['scaling'] == 'strong'
+    assert d['config']['trained_graph_edges'] == 544230
+    assert len(d['ms_per_step_repeats']) == 3 and d['ms_per_step_median'] > 0
+    assert abs(d['ms_per_step'] - d['ms_per_step_repeats'][0]) < 1e-3
+    assert len(d['k1_GBs_per_rank']) == 2 and all(v and min(v.values()) > 0 for v in d['k1_GBs_per_rank'])
+
+
 @pytest.mark.parametrize('partition', ['edge', 'row'])
 def test_bench_two_ranks_each_partition(partition):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GV_DIST_BACKEND='gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-           '--no-cpu-baseline', '--profile-steps', '0', '--positives', '2000', '--partition', partition]
+           '--no-cpu-baseline', '--profile-steps', '0', '--positives', '2000', '--partition', partition, '--scaling', 'weak']
     out = run_ranks(cmd, env, 900)
     assert out.returncode == 0, (out.stdout[-1500:] + '\n' + out.stderr[-2500:])
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
