@@ -219,6 +219,7 @@ class GraphIndex:
         ne = self.num_edges if sync_free else None
         self._rel_cache = {}
         self._chunk_cache = {}
+        self._lds_seg_cache = {}
         if sync_free and NATIVE_INDEX:
             self._build_native(src, dst, chunk, bool(dst_sorted))
             return
@@ -258,6 +259,18 @@ class GraphIndex:
         self.by_dst = EdgeOrder(None if dst_sorted else perm_d,
                                 SegmentItems(it_d.view(-1, 4), fx_d.view(-1, 4), ci_d, cf_d, slots_d, rp_d, chunk))
         self.by_src = EdgeOrder(perm_s, SegmentItems(it_s.view(-1, 4), fx_s.view(-1, 4), ci_s, cf_s, slots_s, rp_s, chunk))
+
+    def lds_seg(self, side: str, chunk: int) -> SegmentItems:
+        """The work items of one ordering cut at ``chunk`` edges instead of this index's own chunk (same rowptr, same edge
+        positions): the LDS-resident K1 kernel walks items wave by wave, so a hub slice must be short (ops.lds_plan)."""
+        own = self.by_dst.seg if side == 'dst' else self.by_src.seg
+        if own.chunk <= chunk:
+            return own
+        key = (side, int(chunk))
+        hit = self._lds_seg_cache.get(key)
+        if hit is None:
+            hit = self._lds_seg_cache[key] = build_segment_items(own.rowptr, int(chunk), self.num_edges if self.sync_free else None)
+        return hit
 
     def coef_in_src_order(self, coef: torch.Tensor) -> torch.Tensor:
         """Per-edge coefficients (given in the caller's edge order) permuted into the by-source order of the backward-x
@@ -651,6 +664,72 @@ def bdd_aggregate_phases(ph: PhaseOrder, coef_p, feat, weight_packed, num_rels, 
              act, ptr(keep), float(keep_scale), ptr(out), ld_out, ptr(partial), lib.stream(), tag=tag)
     if timed and ph.n_fix > 0:
         lib.call('gv_rgcn_bdd_fixup', ptr(ph.fix), ph.n_fix, ptr(partial), out_dim, ptr(addend), ld_add, act, ptr(keep),
+                 float(keep_scale), ptr(out), ld_out, lib.stream())
+    return out
+
+
+K1_LDS = _os.environ.get('GV_K1_LDS', 'auto')               # LDS-resident relation weights: 'auto' | '0'
+K1_LDS_WORKGROUPS = int(_os.environ.get('GV_K1_LDS_WGS', '0'))      # 0: one workgroup per CU
+_LDS_PLANS = {}
+
+
+def lds_plan(num_rels, num_bases, blk_in, blk_out):
+    """(column parts, floats of the packed table, preferred work-item chunk) when the LDS-resident K1 kernel exists for the
+    block shape AND the relation table fits a CU's LDS (few relation types: WN18RR-shaped graphs), else None."""
+    if K1_LDS == '0':
+        return None
+    key = (int(num_rels), int(num_bases), int(blk_in), int(blk_out))
+    if key not in _LDS_PLANS:
+        plan = (_ct.c_int32 * 3)()
+        ok = lib.load().gv_rgcn_bdd_lds_plan(key[1], key[2], key[3], key[0], _ct.addressof(plan))
+        _LDS_PLANS[key] = tuple(int(v) for v in plan) if ok else None
+    return _LDS_PLANS[key]
+
+
+def pack_weight_lds(weight, num_bases, blk_in, blk_out, transpose_w, plan):
+    weight = _chk(weight, name='weight')
+    packed = torch.empty(plan[1], dtype=torch.float32, device=weight.device)
+    lib.call('gv_rgcn_bdd_pack_weight_lds', ptr(weight), weight.shape[0], num_bases, blk_in, blk_out, 1 if transpose_w else 0,
+             ptr(packed), lib.stream())
+    return packed
+
+
+def bdd_aggregate_lds(seg: SegmentItems, nbr, etype, coef, coef_idx, feat, weight_packed, num_rels, num_bases, blk_in, blk_out,
+                      transpose_w=False, addend=None, act=ACT_NONE, keep=None, keep_scale=1.0, out=None):
+    """gv_rgcn_bdd_aggregate_lds: K1 with every relation's block weights resident in LDS (``weight_packed``:
+    pack_weight_lds).  Same lists, formula and epilogue as ``bdd_aggregate``; ``transpose_w`` only names the launch."""
+    feat, ld_feat = _row_major(feat, 'feat')
+    n_seg = seg.rowptr.numel() - 1
+    out_dim = num_bases * blk_out
+    if feat.shape[1] != num_bases * blk_in:
+        raise ValueError(f'feat has {feat.shape[1]} columns, expected num_bases*blk_in = {num_bases * blk_in}')
+    plan = lds_plan(num_rels, num_bases, blk_in, blk_out)
+    if plan is None or weight_packed.numel() != plan[1]:
+        raise ValueError('weight_packed does not have the size the LDS plan asks for (or no plan for this shape)')
+    if out is None:
+        out = torch.empty(n_seg, out_dim, dtype=torch.float32, device=feat.device)
+    ld_add = 0
+    if addend is not None:
+        addend, ld_add = _row_major(addend, 'addend')
+        if tuple(addend.shape) != (n_seg, out_dim):
+            raise ValueError('addend shape mismatch')
+    if keep is not None:
+        _chk(keep, torch.uint8, 'keep')
+        if tuple(keep.shape) != (n_seg, out_dim):
+            raise ValueError('keep shape mismatch')
+    if coef is not None:
+        coef = _chk(coef.reshape(-1), name='coef')
+    _check_items(seg)
+    partial = torch.empty(seg.n_slots, out_dim, dtype=torch.float32, device=feat.device) if seg.n_fix > 0 else None
+    ld_out = out.stride(0) if n_seg > 1 else out_dim
+    tag = f'agg_{"T" if transpose_w else "N"}_{blk_in}x{blk_out}_nb{num_bases}'
+    timed = lib.TIMER is not None
+    lib.call('gv_rgcn_bdd_aggregate_lds', ptr(seg.items), seg.n_items, ptr(seg.fix), 0 if timed else seg.n_fix, ptr(nbr),
+             ptr(etype), ptr(coef), ptr(coef_idx), ptr(feat), ld_feat, ptr(weight_packed), num_rels, num_bases, blk_in, blk_out,
+             ptr(addend), ld_add, act, ptr(keep), float(keep_scale), ptr(out), ld_out, ptr(partial), K1_LDS_WORKGROUPS,
+             lib.stream(), tag=tag)
+    if timed and seg.n_fix > 0:
+        lib.call('gv_rgcn_bdd_fixup', ptr(seg.fix), seg.n_fix, ptr(partial), out_dim, ptr(addend), ld_add, act, ptr(keep),
                  float(keep_scale), ptr(out), ld_out, lib.stream())
     return out
 
@@ -1175,7 +1254,12 @@ class _RelGraphConvBdd(torch.autograd.Function):
             return None
 
         ctx.grouped = not ctx.tiles and reduce_hook is None and use_relation_groups(weight, gidx)
-        if ctx.tiles:
+        lp = None if (ctx.tiles or ctx.grouped or reduce_hook is not None) else lds_plan(weight.shape[0], num_bases, si, so)
+        if lp is not None:       # few relation types: the whole table resident in LDS (csrc/k_lds.hip)
+            out = bdd_aggregate_lds(gidx.lds_seg('dst', lp[2]), gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x,
+                                    pack_weight_lds(weight, num_bases, si, so, False, lp), weight.shape[0], num_bases, si, so,
+                                    False, self_loop_term(), act, keep, keep_scale)
+        elif ctx.tiles:
             out = bdd_aggregate_phases(tl, None if coef is None else tl.coef(coef), x,
                                        pack_weight_phase(tl, weight, num_bases, si, so), weight.shape[0], num_bases, si, so,
                                        self_loop_term(), act, keep, keep_scale)
@@ -1259,6 +1343,14 @@ class _RelGraphConvBdd(torch.autograd.Function):
             grad_x = bdd_aggregate_phases(tl, None if coef is None else tl.coef(coef), g_agg,
                                           pack_weight_phase(tl, weight, nb, so, si), weight.shape[0], nb, so, si, gx_loop,
                                           out=x_tgt)
+        elif ctx.needs_input_grad[0] and not ctx.grouped and reduce_hook is None and \
+                lds_plan(weight.shape[0], nb, so, si) is not None:
+            lp = lds_plan(weight.shape[0], nb, so, si)
+            static = not gidx.sync_free and coef is not None
+            coef_s, idx_s = (gidx.coef_in_src_order(coef), None) if static else (coef, gidx.by_src.perm)
+            grad_x = bdd_aggregate_lds(gidx.lds_seg('src', lp[2]), gidx.nbr_by_src, ridx.et_by_src, coef_s, idx_s, g_agg,
+                                       pack_weight_lds(weight, nb, so, si, True, lp), weight.shape[0], nb, so, si, True,
+                                       gx_loop, out=x_tgt)
         elif ctx.needs_input_grad[0]:
             pk = si * so >= 8 and pack_supported(nb, so, si, True)
             if ctx.w_bwd_packed is not None and weight._version == ctx.w_version:

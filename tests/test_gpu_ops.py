@@ -218,6 +218,68 @@ def test_rel_graph_conv_fwd_bwd(ops, fin, fout, nb, chunk):
         close(pg['loop_weight'].grad, po['loop_weight'].grad, msg='grad_loop')
 
 
+@pytest.mark.parametrize('fin,fout,nb,r', [(200, 200, 20, 22), (200, 400, 20, 22), (200, 400, 20, 5), (100, 100, 10, 22)])
+@pytest.mark.parametrize('chunk,shuffle', [(8, False), (256, False), (256, True)])
+def test_rel_graph_conv_lds_resident_weights(ops, monkeypatch, fin, fout, nb, r, chunk, shuffle):
+    """K1 with all relation weights resident in LDS (csrc/k_lds.hip; BASELINE configs[2]'s shape: 22 directed relation types,
+    20 blocks of 10x10 / 10x20) against the oracle, forward and every gradient; hub rows cut into 8-edge items (the index's
+    own lists) and into the kernel's preferred 64-edge items (a second cut of the same rowptr), edges in arbitrary order
+    (coefficients read through the permutation), rows without edges; and, on the same work items, bit for bit the
+    per-row kernels' results."""
+    n, e = 400, 5000
+    assert ops.lds_plan(r, nb, fin // nb, fout // nb) is not None and ops.lds_plan(r, nb, fout // nb, fin // nb) is not None
+    assert ops.lds_plan(474, nb, fin // nb, fout // nb) is None          # the table must fit a CU's LDS
+    src, dst, et, norm = zipf_graph(n, e, r, seed=fin + fout + nb + r)
+    dst = torch.where(dst >= n - 7, torch.zeros_like(dst), dst)          # the last rows: in-degree 0
+    if shuffle:
+        perm = torch.randperm(e, generator=torch.Generator().manual_seed(2))
+        src, dst, et, norm = src[perm], dst[perm], et[perm], norm[perm]
+    else:
+        order = np.lexsort((et.numpy(), src.numpy(), dst.numpy()))
+        src, dst, et, norm = src[order], dst[order], et[order], norm[order]
+    gen = torch.Generator().manual_seed(fin * 7 + nb)
+    x = torch.randn(n, fin, generator=gen)
+    p = orgcn.init_params(fin, fout, r, 'bdd', nb, True, True, gen)
+    p['h_bias'] = torch.randn(fout, generator=gen) * 0.1
+    keep = (torch.rand(n, fout, generator=gen) > 0.2).to(torch.uint8)
+    gout = torch.randn(n, fout, generator=gen)
+    gidx = ops.GraphIndex(src.cuda(), dst.cuda(), n, chunk=chunk)
+    assert (gidx.by_dst.perm is not None) == shuffle
+    ridx = ops.RelationIndex(gidx, et.cuda(), r, chunk=max(4, chunk // 2))
+    if chunk > 64:
+        assert gidx.lds_seg('dst', 64).chunk == 64 and gidx.lds_seg('dst', 64).n_fix > 0
+    calls = []
+    real = ops.bdd_aggregate_lds
+    monkeypatch.setattr(ops, 'bdd_aggregate_lds', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    got = {}
+    for act_id, act in ((1, torch.relu), (0, None)):
+        xo = x.clone().requires_grad_(True)
+        po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        ho = orgcn.rel_graph_conv(xo, src, dst, et, norm, po, 'bdd', nb, act, dropout_keep=keep, dropout_p=0.2)
+        ho.backward(gout)
+        xg = x.cuda().requires_grad_(True)
+        pg = {k: v.cuda().requires_grad_(True) for k, v in p.items()}
+        hg = ops.rel_graph_conv_bdd(xg, pg['weight'], pg['h_bias'], pg['loop_weight'], norm.cuda(), gidx, ridx, nb,
+                                    act_id, keep.cuda(), 1.0 / 0.8)
+        hg.backward(gout.cuda())
+        close(hg, ho, msg='forward')
+        close(xg.grad, xo.grad, msg='grad_x')
+        close(pg['weight'].grad, po['weight'].grad, msg='grad_weight')
+        close(pg['h_bias'].grad, po['h_bias'].grad, msg='grad_bias')
+        close(pg['loop_weight'].grad, po['loop_weight'].grad, msg='grad_loop')
+        got[act_id] = (hg.detach().clone(), xg.grad.clone())
+    assert len(calls) == 4                                               # forward and backward-x of both runs took the LDS kernel
+    if chunk <= 64:       # same work items -> the per-row kernels (k_agg_split) give the same bits
+        monkeypatch.setattr(ops, 'K1_LDS', '0')
+        xg = x.cuda().requires_grad_(True)
+        pg = {k: v.cuda().requires_grad_(True) for k, v in p.items()}
+        hg = ops.rel_graph_conv_bdd(xg, pg['weight'], pg['h_bias'], pg['loop_weight'], norm.cuda(), gidx, ridx, nb, 0, keep.cuda(),
+                                    1.0 / 0.8)
+        hg.backward(gout.cuda())
+        assert len(calls) == 4
+        assert torch.equal(hg, got[0][0]) and torch.equal(xg.grad, got[0][1])
+
+
 def test_rel_graph_conv_unsorted_edges_and_empty_rows(ops):
     n, e, r, fin, fout, nb = 120, 900, 5, 8, 16, 4
     src, dst, et, norm = zipf_graph(n, e, r, seed=3)
