@@ -43,12 +43,16 @@ struct LdsAggParams {
     int ld_out;
     float* partial;
     int out_dim;
+    int debug;               // ablation switches (GV_K1_LDS_DEBUG; 0 in production): 1 = no LDS reads / fmas, 2 = no ring writes
 };
 
 __device__ __forceinline__ int lrl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ float lrl_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+
+__device__ __forceinline__ void rot_i(int& d, int s) { asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(s) : "memory"); }
+__device__ __forceinline__ void rot_f(float& d, float s) { asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(s) : "memory"); }
 
 // One LDS-DMA wave-instruction: 64 x 16 B from per-lane global addresses to lds_byte_addr + lane*16 (see k_phase.hip)
 __device__ __forceinline__ void lds_dma16(const float4* gsrc, unsigned lds_byte_addr) {
@@ -60,12 +64,21 @@ __device__ __forceinline__ void lds_dma16(const float4* gsrc, unsigned lds_byte_
 }
 
 // P = gathered block width, Q = output block width, QS = output columns per lane, BPP = diagonal blocks per column
-// part, U = edges staged per batch (ring slots per wave)
+// part, U = edges per step (ring slots per wave).  Work items must not be longer than 64 edges (one metadata fetch each).
+//
+// A wave's work is a sequence of STEPS: a step = up to U consecutive edges of one item (an item without edges is one empty
+// step).  Software pipeline, everything one stage ahead of its use:
+//   descriptors   64 items per fetch (lane k = the wave's k-th item)
+//   edge metadata of item k+2          requested when item k starts
+//   epilogue operands (addend, keep)   of item k+1, requested when item k starts
+//   feature pieces of step s+1         requested (two register sets used in turn: no copies) before step s is computed
+// so the only wait in front of a step is for loads that had a whole step of LDS reads and fmas to land, and the three
+// other waves of the SIMD fill what is left.
 template <int P, int Q, int QS, int BPP, int U>
 __global__ __launch_bounds__(1024) void k_agg_lds(const LdsAggParams a) {
     constexpr int LPB = Q / QS, LANES = BPP * LPB, NW = P * QS, NQ = NW / 4;
     constexpr int PF = BPP * P;                            // floats of a feature row this part reads
-    constexpr int VW = (PF % 4 == 0) ? 4 : 2;              // floats per staging lane
+    constexpr int VW = (PF % 100 == 0) ? 2 : 1;            // floats per staging lane: 50 lanes x 8 B / 50 lanes x 4 B
     constexpr int XL = PF / VW;                            // staging lanes
     static_assert(Q % QS == 0 && NW % 4 == 0 && LANES <= 64 && PF % VW == 0 && XL <= 64, "lane mapping");
     static_assert(P % 2 == 0, "block inputs are read back from LDS in 8- or 16-B pieces");
@@ -90,124 +103,179 @@ __global__ __launch_bounds__(1024) void k_agg_lds(const LdsAggParams a) {
     float* const ring = reinterpret_cast<float*>(smem + tq_pad) + wv * (U * PF);
     const float4* const wl = smem + ln;
     const float* const xr_base = ring + blk_l * P;
+    float* const xw_base = ring + min(lane, XL - 1) * VW;
     const bool xl_on = lane < XL;
     const float* const fsrc = a.feat + part * PF + min(lane, XL - 1) * VW;
     const size_t ld = (size_t)a.ld_feat;
     const int col0 = (part * BPP + blk_l) * Q + sub * QS;
     const int nwaves = gridDim.x * nw;
     const int gw = blockIdx.x * nw + wv;
+    const bool has_add = a.addend != nullptr, has_keep = a.keep != nullptr;
 
-    auto load_meta = [&](int pos, int cnt, int& n_, int& t_, float& c_) {
-        n_ = 0; t_ = 0; c_ = 1.f;
+    struct Meta { int n, t; float c; };
+    struct Epi { float ad[QS]; unsigned kp; };
+    auto load_meta = [&](int pos, int cnt) {
+        Meta m{0, 0, 1.f};
         if (lane < cnt) {
-            n_ = a.nbr[pos + lane];
-            t_ = a.etype[pos + lane];
-            if (a.coef) c_ = a.coef_idx ? a.coef[a.coef_idx[pos + lane]] : a.coef[pos + lane];
+            m.n = a.nbr[pos + lane];
+            m.t = a.etype[pos + lane];
+            if (a.coef) m.c = a.coef_idx ? a.coef[a.coef_idx[pos + lane]] : a.coef[pos + lane];
+        }
+        return m;
+    };
+    // Epilogue operands of a row, requested one item ahead.  The loads are UNCONDITIONAL (a conditional load into a
+    // pre-set register makes hipcc copy it behind a full wait): rows that need none read row 0, an absent operand reads the
+    // output buffer instead; what was read is selected away where it is used (finish).
+    const float* const add_base = (has_add ? a.addend : a.out) + col0;
+    const size_t add_ld = has_add ? (size_t)a.ld_add : (size_t)a.ld_out;
+    const uint8_t* const keep_base = has_keep ? a.keep + col0 : reinterpret_cast<const uint8_t*>(a.out + col0);
+    const size_t keep_ld = has_keep ? (size_t)a.out_dim : (size_t)a.ld_out * 4;
+    auto load_epi = [&](int row, int slot) {
+        Epi e;
+        const size_t r = (size_t)(unsigned)max(row, 0);
+        load_vec<QS>(add_base + r * add_ld, e.ad);
+        const uint8_t* kp = keep_base + r * keep_ld;
+        if constexpr (QS == 2) e.kp = *reinterpret_cast<const uint16_t*>(kp);
+        else if constexpr (QS == 4) e.kp = *reinterpret_cast<const uint32_t*>(kp);
+        else {
+            e.kp = 0;
+#pragma unroll
+            for (int i = 0; i < QS; ++i) e.kp |= (unsigned)kp[i] << (8 * i);
+        }
+        return e;
+    };
+    // the feature pieces of one step: U loads back to back, no branch between them (edges beyond the step re-read its last
+    // one, a step without edges reads row 0)
+    auto issue_x = [&](const Meta& m, int j, int cnt, float (&xs)[U][VW]) {
+        const int last = max(cnt, 1) - 1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = lrl_i(m.n, min(j + u, last));
+            load_vec<VW>(fsrc + (size_t)(unsigned)s * ld, xs[u]);
         }
     };
+    auto edge_fma = [&](int u, int r, float c, float (&acc)[QS]) {
+        float xv[P], wr[NW];
+        load_vec<P>(xr_base + u * PF, xv);
+        const float4* wq = wl + (size_t)r * (NQ * LANES);
+#pragma unroll
+        for (int q4 = 0; q4 < NQ; ++q4) {
+            const float4 t = wq[q4 * LANES];
+            wr[4 * q4] = t.x; wr[4 * q4 + 1] = t.y; wr[4 * q4 + 2] = t.z; wr[4 * q4 + 3] = t.w;
+        }
+#pragma unroll
+        for (int q = 0; q < QS; ++q) {
+            float t = 0.f;
+#pragma unroll
+            for (int p = 0; p < P; ++p) t = fmaf(xv[p], wr[q * P + p], t);
+            acc[q] = fmaf(t, c, acc[q]);
+        }
+    };
+    // park the step's pieces in the wave's ring and run its edges
+    auto consume = [&](const Meta& m, int j, int nb, const float (&xs)[U][VW], float (&acc)[QS]) {
+        if (xl_on && !(a.debug & 2)) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (u < nb) store_vec<VW>(xw_base + u * PF, xs[u]);
+        }
+        if (a.debug & 1) nb = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // other lanes of this wave read the pieces
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int u = 0;
+        for (; u + 2 <= nb; u += 2) {                             // pairs: the second edge's LDS reads under the first one's fmas
+            edge_fma(u, lrl_i(m.t, j + u), lrl_f(m.c, j + u), acc);
+            edge_fma(u + 1, lrl_i(m.t, j + u + 1), lrl_f(m.c, j + u + 1), acc);
+        }
+        if (u < nb) edge_fma(u, lrl_i(m.t, j + u), lrl_f(m.c, j + u), acc);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next step overwrites the ring
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto finish = [&](int row, int slot, const Epi& e, float (&acc)[QS]) {
+        if (!active || row < 0) return;
+        const bool fin = slot < 0;                                 // else: a slice of a hub row, summed by the fix-up pass
+        float* dstp = fin ? a.out + (size_t)row * a.ld_out + col0 : a.partial + (size_t)slot * a.out_dim + col0;
+#pragma unroll
+        for (int i = 0; i < QS; ++i) {
+            float v = apply_act(has_add ? acc[i] + e.ad[i] : acc[i], a.act);
+            if (has_keep) v = ((e.kp >> (8 * i)) & 0xffu) ? v * a.keep_scale : 0.f;
+            acc[i] = fin ? v : acc[i];
+        }
+        store_vec<QS>(dstp, acc);
+    };
 
-    // this wave's items: gw, gw + nwaves, ... ; 64 descriptors per fetch (lane k = k-th of them)
-    int4 itv = make_int4(-1, 0, 0, -1);
-    {
-        const long long i0 = (long long)gw + (long long)lane * nwaves;
-        if (i0 < a.n_items) itv = a.items[i0];
-    }
-    int nx_n, nx_t;
-    float nx_c;
-    {
-        const int y = lrl_i(itv.y, 0), z = lrl_i(itv.z, 0);
-        load_meta(y, min(64, z - y), nx_n, nx_t, nx_c);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the weight copy (the compiler does not count the DMAs)
-    __syncthreads();
-
-    for (long long ib = gw, k = 0; ib < a.n_items; ib += nwaves, ++k) {
-        if (k == 64) {                                     // next 64 descriptors
-            k = 0;
-            itv = make_int4(-1, 0, 0, -1);
-            const long long i0 = ib + (long long)lane * nwaves;
+    bool first = true;
+    for (long long base = gw; base < a.n_items; base += 64ll * nwaves) {
+        // this wave's next 64 items: base, base + nwaves, ...
+        int4 itv = make_int4(-1, 0, 0, -1);
+        {
+            const long long i0 = base + (long long)lane * nwaves;
             if (i0 < a.n_items) itv = a.items[i0];
-            const int y = lrl_i(itv.y, 0), z = lrl_i(itv.z, 0);
-            load_meta(y, min(64, z - y), nx_n, nx_t, nx_c);
         }
-        const int kk = (int)k;
-        const int row = lrl_i(itv.x, kk), e_beg = lrl_i(itv.y, kk), e_end = lrl_i(itv.z, kk), slot = lrl_i(itv.w, kk);
-        int my_n = nx_n, my_t = nx_t;
-        float my_c = nx_c;
-        if (kk + 1 < 64) {                                 // metadata of the wave's next item, one item ahead
-            const int y = lrl_i(itv.y, kk + 1), z = lrl_i(itv.z, kk + 1);
-            load_meta(y, min(64, z - y), nx_n, nx_t, nx_c);      // descriptor -1 (none): y = z = 0, nothing is read
+        const int nk = (int)min(64ll, (a.n_items - base + nwaves - 1) / nwaves);
+        auto desc = [&](int k, int& row, int& slot, int& beg, int& cnt) {      // k >= nk: none
+            const int kk = min(k, 63);
+            row = lrl_i(itv.x, kk); slot = lrl_i(itv.w, kk); beg = lrl_i(itv.y, kk);
+            cnt = min(64, lrl_i(itv.z, kk) - beg);
+            if (k >= nk || row < 0) { row = -1; cnt = 0; }
+            if (slot >= 0 && !a.partial) { row = -1; cnt = 0; }
+        };
+        int rowA, slotA, begA, cntA, rowB, slotB, begB, cntB, rowC, slotC, begC, cntC;
+        desc(0, rowA, slotA, begA, cntA);
+        desc(1, rowB, slotB, begB, cntB);
+        desc(2, rowC, slotC, begC, cntC);
+        Meta mA = load_meta(begA, cntA), mB = load_meta(begB, cntB), mC = load_meta(begC, cntC);
+        Epi eA = load_epi(rowA, slotA), eB = load_epi(rowB, slotB);
+        float x0[U][VW], x1[U][VW];
+        issue_x(mA, 0, cntA, x0);
+        if (first) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the weight copy (the compiler does not count the DMAs)
+            __syncthreads();
+            first = false;
         }
-        if (row < 0 || (slot >= 0 && !a.partial)) continue;
-
         float acc[QS];
 #pragma unroll
         for (int i = 0; i < QS; ++i) acc[i] = 0.f;
-
-        for (int e0 = e_beg; e0 < e_end; e0 += 64) {
-            const int cnt = min(64, e_end - e0);
-            if (e0 != e_beg) load_meta(e0, cnt, my_n, my_t, my_c);      // slices longer than 64 edges: fetched in place
-            for (int j = 0; j < cnt; j += U) {
-                const int nb = min(U, cnt - j);
-                // stage: U pieces requested together (edges beyond the batch re-read its last one: no branch between loads)
-                float xs[U][VW];
+        int k = 0, j = 0;
+        // one step: request the NEXT step's pieces into xn, run this step out of xc; the two register sets swap roles by
+        // the call sequence below (static names: no copies, so the wait in front of a step never covers the loads just issued)
+        auto step = [&](const float (&xc)[U][VW], float (&xn)[U][VW]) -> bool {
+            const int nb = min(U, cntA - j);
+            const bool same = j + U < cntA;                        // the next step is in this item, else the next item's first
+            Meta mN;
+            mN.n = same ? mA.n : mB.n; mN.t = 0; mN.c = 0.f;
+            issue_x(mN, same ? j + U : 0, same ? cntA : cntB, xn);
+            consume(mA, j, nb, xc, acc);
+            j += U;
+            if (j < cntA) return false;
+            finish(rowA, slotA, eA, acc);
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int s = lrl_i(my_n, min(j + u, cnt - 1));
-                    load_vec<VW>(fsrc + (size_t)(unsigned)s * ld, xs[u]);
-                }
-                if (xl_on) {
+            for (int i = 0; i < QS; ++i) acc[i] = 0.f;
+            if (++k >= nk) return true;
+            rowA = rowB; slotA = slotB; begA = begB; cntA = cntB;
+            rowB = rowC; slotB = slotC; begB = begC; cntB = cntC;
+            // The register rotation is done by OPAQUE moves, before the next requests are issued: left to hipcc, the loop-carried
+            // values get their copies at the end of the block, i.e. behind the new loads, which then land in temporaries and are
+            // copied over behind a full wait.
+            rot_i(mA.n, mB.n); rot_i(mA.t, mB.t); rot_f(mA.c, mB.c);
+            rot_i(mB.n, mC.n); rot_i(mB.t, mC.t); rot_f(mB.c, mC.c);
 #pragma unroll
-                    for (int u = 0; u < U; ++u) store_vec<VW>(ring + u * PF + lane * VW, xs[u]);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // other lanes of this wave read the pieces
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (u < nb) {
-                        const int r = lrl_i(my_t, j + u);
-                        const float c = lrl_f(my_c, j + u);
-                        float xv[P], wr[NW];
-                        load_vec<P>(xr_base + u * PF, xv);
-                        const float4* wq = wl + (size_t)r * (NQ * LANES);
-#pragma unroll
-                        for (int q4 = 0; q4 < NQ; ++q4) {
-                            const float4 t = wq[q4 * LANES];
-                            wr[4 * q4] = t.x; wr[4 * q4 + 1] = t.y; wr[4 * q4 + 2] = t.z; wr[4 * q4 + 3] = t.w;
-                        }
-#pragma unroll
-                        for (int q = 0; q < QS; ++q) {
-                            float t = 0.f;
-#pragma unroll
-                            for (int p = 0; p < P; ++p) t = fmaf(xv[p], wr[q * P + p], t);
-                            acc[q] = fmaf(t, c, acc[q]);
-                        }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next batch overwrites the ring
-                __builtin_amdgcn_wave_barrier();
-            }
+            for (int i = 0; i < QS; ++i) rot_f(eA.ad[i], eB.ad[i]);
+            { int t; rot_i(t, (int)eB.kp); eA.kp = (unsigned)t; }
+            desc(k + 2, rowC, slotC, begC, cntC);
+            mC = load_meta(begC, cntC);
+            eB = load_epi(rowB, slotB);
+            j = 0;
+            return false;
+        };
+        for (;;) {
+            if (step(x0, x1)) break;
+            if (step(x1, x0)) break;
         }
-        if (!active) continue;
-        if (slot >= 0) {
-            store_vec<QS>(a.partial + (size_t)slot * a.out_dim + col0, acc);
-            continue;
-        }
-        if (a.addend) {
-            float ad[QS];
-            load_vec<QS>(a.addend + (size_t)row * a.ld_add + col0, ad);
-#pragma unroll
-            for (int i = 0; i < QS; ++i) acc[i] += ad[i];
-        }
-#pragma unroll
-        for (int i = 0; i < QS; ++i) acc[i] = apply_act(acc[i], a.act);
-        if (a.keep) {
-            const uint8_t* kp = a.keep + (size_t)row * a.out_dim + col0;
-#pragma unroll
-            for (int i = 0; i < QS; ++i) acc[i] = kp[i] ? acc[i] * a.keep_scale : 0.f;
-        }
-        store_vec<QS>(a.out + (size_t)row * a.ld_out + col0, acc);
+    }
+    if (first) {                                                   // a wave without items still joins the staging barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
 }
 
@@ -317,6 +385,8 @@ extern "C" int gv_rgcn_bdd_aggregate_lds(const int32_t* items, int n_items, cons
     a.feat = feat; a.ld_feat = ld_feat; a.wpk = (const float4*)weight_packed; a.R = num_rels; a.addend = addend;
     a.ld_add = ld_addend; a.act = act; a.keep = keep; a.keep_scale = keep_scale; a.out = out; a.ld_out = ld_out;
     a.partial = partial; a.out_dim = out_dim;
+    static const int dbg = getenv("GV_K1_LDS_DEBUG") ? atoi(getenv("GV_K1_LDS_DEBUG")) : 0;
+    a.debug = dbg;
     hipStream_t st = (hipStream_t)stream;
     const size_t tq = (size_t)num_rels * pl.nq * pl.lanes;
     const size_t lds = ((tq + 63) & ~(size_t)63) * 16 + (size_t)LDS_WAVES * pl.u * pl.pf * 4;
