@@ -3,20 +3,24 @@
 //
 // The per-row kernels of k_bdd.hip read, per EDGE, the whole block-weight row of the edge's relation (8-16 kB at this
 // shape) through the L1 -> VGPR path for 812 B of algorithmic bytes; with R = 22 the whole table is 176 / 352 kB, so a
-// column part of it (88 kB) stays in a CU's LDS for the whole launch:
+// column part of it (88 kB) stays in a CU's LDS for the whole launch.  At ~4 edges per row the other cost is per-ROW
+// overhead, so the unit of work here is not a row but a SUPER-ITEM: a run of consecutive rows with <= 64 edges in all (or a
+// <= 64-edge slice of a hub row), whose edge metadata is ONE coalesced fetch and whose rows cost an epilogue each, no more.
 //   * grid = (workgroups, column parts); one 1 024-thread workgroup per CU copies its part of the lane-packed table
-//     [R][NQ][LANES] float4 into LDS once (LDS-DMA, 1 KiB per wave-instruction) and then walks work items
-//     (destination rows / <= chunk-edge slices of hub rows, the same int4 lists as gv_rgcn_bdd_aggregate) in a
-//     wave-strided order, so hub slices spread over all waves;
-//   * a block-diagonal product only needs the part's own input columns: per edge and part ONE coalesced piece of the
-//     feature row (PF = blocks-per-part x P floats: 400 or 200 B) is loaded once (16 / 8 B per lane, no duplicates),
-//     parked in a wave-private LDS ring and read back block-wise (lanes of a block broadcast-read its P inputs);
-//   * lane = (block, QS output columns): P x QS weights per edge by NQ conflict-free ds_read_b128 (lane-consecutive
-//     quads), QS register accumulators for the whole row, epilogue (+ self-loop addend, ReLU, dropout mask) fused
-//     into the single store of the row.  No atomics; same fma chains as k_agg_split -> bit-identical results for the
-//     same work-item lists.
-// Item descriptors are fetched 64 per wave-instruction (lane k = the wave's k-th item) and an item's edge metadata
-// one item ahead, so a wave's dependent chain per item is the feature gather alone.
+//     [R][NQ][CL] float4 into LDS once (LDS-DMA, 1 KiB per wave-instruction); waves take super-items in a strided order;
+//   * lane = (diagonal block, group of IPL INPUT columns, half of the output columns): per edge it loads just its own IPL
+//     inputs of the neighbour's row (8 / 16 B, the lanes of a block cover its inputs once -- nothing is exchanged between
+//     lanes per edge), reads its IPL x OPL weights by NQ conflict-free ds_read_b128 and adds into OPL partial sums; the five
+//     input groups of a block sit in adjacent lanes of one 16-lane DPP row and are summed ONCE PER ROW (3 row_shr adds per
+//     output), the row's part then goes through 400 B of wave-private LDS into column order for a coalesced epilogue
+//     (+ self-loop addend, ReLU, dropout mask) and store;
+//   * finished rows wait in a wave-private LDS buffer (KB rows) and get their epilogue in BATCHES: the operands (addend,
+//     keep) of all buffered rows are requested together, so the edge loop itself contains no load but the feature pieces
+//     and no wait but theirs;
+//   * software pipeline: the feature pieces of step s+1 (U edges) are requested before step s is computed (two register
+//     sets with static names), the next super-item's metadata one super-item ahead.
+// No atomics; every row is summed by one wave in a fixed order -> bitwise reproducible (the order differs from the per-row
+// kernels': inputs are grouped before edges are summed).  Rows without edges are written by a second loop of the same launch.
 #include <stdlib.h>
 
 #include "common.h"
@@ -24,15 +28,18 @@
 namespace gv {
 
 struct LdsAggParams {
-    const int4* items;
-    int n_items;
+    const int4* sitems;      // {first edge position, end position, partial slot (-1: whole rows), 0}
+    int n_sitems;
+    const int* erow;         // [E] row of every edge position
+    const int* empty;        // rows without edges
+    int n_empty;
     const int* nbr;
     const int* etype;
     const float* coef;
     const int* coef_idx;
     const float* feat;
     int ld_feat;
-    const float4* wpk;       // [parts][R][NQ][LANES] float4 (+ 64 float4 of slack behind the table)
+    const float4* wpk;       // [parts][R][NQ][CL] float4 (+ 64 float4 of slack behind the table)
     int R;
     const float* addend;
     int ld_add;
@@ -43,7 +50,7 @@ struct LdsAggParams {
     int ld_out;
     float* partial;
     int out_dim;
-    int debug;               // ablation switches (GV_K1_LDS_DEBUG; 0 in production): 1 = no LDS reads / fmas, 2 = no ring writes
+    int debug;               // ablation switch (GV_K1_LDS_DEBUG; 0 in production): 1 = no LDS weight reads / fmas
 };
 
 __device__ __forceinline__ int lrl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -51,6 +58,8 @@ __device__ __forceinline__ float lrl_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// Register rotation by OPAQUE moves: left to hipcc, loop-carried values get their copies at the end of the block, i.e. behind
+// the new loads, which then land in temporaries and are copied over behind a full wait.
 __device__ __forceinline__ void rot_i(int& d, int s) { asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(s) : "memory"); }
 __device__ __forceinline__ void rot_f(float& d, float s) { asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(s) : "memory"); }
 
@@ -63,31 +72,32 @@ __device__ __forceinline__ void lds_dma16(const float4* gsrc, unsigned lds_byte_
                  : "memory");
 }
 
-// P = gathered block width, Q = output block width, QS = output columns per lane, BPP = diagonal blocks per column
-// part, U = edges per step (ring slots per wave).  Work items must not be longer than 64 edges (one metadata fetch each).
-//
-// A wave's work is a sequence of STEPS: a step = up to U consecutive edges of one item (an item without edges is one empty
-// step).  Software pipeline, everything one stage ahead of its use:
-//   descriptors   64 items per fetch (lane k = the wave's k-th item)
-//   edge metadata of item k+2          requested when item k starts
-//   epilogue operands (addend, keep)   of item k+1, requested when item k starts
-//   feature pieces of step s+1         requested (two register sets used in turn: no copies) before step s is computed
-// so the only wait in front of a step is for loads that had a whole step of LDS reads and fmas to land, and the three
-// other waves of the SIMD fill what is left.
-template <int P, int Q, int QS, int BPP, int U>
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114;
+
+template <int N> struct XVec { typedef float type __attribute__((ext_vector_type(N))); };
+
+// P = gathered block width, Q = output block width, IPL = inputs per lane (P / IPL = 5 input groups per block), OH = lanes
+// sharing a block's outputs (each Q / OH of them), BPP = diagonal blocks per column part, U = edges per step.
+// Lane layout: slot = block * OH + half (<= 12 slots), three slots per 16-lane DPP row, lane = 16 * (slot / 3) + 5 * (slot % 3) + g.
+template <int P, int Q, int IPL, int OH, int BPP, int U>
 __global__ __launch_bounds__(1024) void k_agg_lds(const LdsAggParams a) {
-    constexpr int LPB = Q / QS, LANES = BPP * LPB, NW = P * QS, NQ = NW / 4;
-    constexpr int PF = BPP * P;                            // floats of a feature row this part reads
-    constexpr int VW = (PF % 100 == 0) ? 2 : 1;            // floats per staging lane: 50 lanes x 8 B / 50 lanes x 4 B
-    constexpr int XL = PF / VW;                            // staging lanes
-    static_assert(Q % QS == 0 && NW % 4 == 0 && LANES <= 64 && PF % VW == 0 && XL <= 64, "lane mapping");
-    static_assert(P % 2 == 0, "block inputs are read back from LDS in 8- or 16-B pieces");
+    constexpr int NIG = P / IPL, OPL = Q / OH, NW = IPL * OPL, NQ = NW / 4, SLOTS = BPP * OH;
+    // the weight table is indexed by LANE (lane-consecutive 16-B quads: conflict-free ds_read_b128), CL = lanes up to the last slot's
+    constexpr int CL = 16 * ((SLOTS - 1) / 3) + 5 * ((SLOTS - 1) % 3) + NIG;
+    constexpr int PO = BPP * Q;                            // output columns of a part
+    constexpr int EW = (PO % 100 == 0) ? 2 : 1, EL = PO / EW;      // epilogue: EL lanes x EW columns
+    constexpr int XN = U * IPL;
+    constexpr int KB = 8;                                  // finished rows parked per wave before their epilogue
+    static_assert(NIG == 5 && P % IPL == 0 && Q % OH == 0 && NW % 4 == 0 && SLOTS <= 12 && EL <= 64 && PO % EW == 0, "lane mapping");
+    static_assert(IPL == 2 || IPL == 4, "a lane's inputs are one 8- or 16-B load");
+    static_assert(XN == 8 || XN == 16, "the pieces of a step are one indexable register vector");
+    typedef typename XVec<XN>::type xvec;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nw = blockDim.x >> 6;
     const int part = blockIdx.y;
-    const int tq = a.R * NQ * LANES;                       // quads of this part's table
+    const int tq = a.R * NQ * CL;                          // quads of this part's table
     const int tq_pad = (tq + 63) & ~63;
 
     {   // the part's weights: a straight copy, 1 KiB per wave-instruction; the slack behind the table absorbs the tail
@@ -97,231 +107,291 @@ __global__ __launch_bounds__(1024) void k_agg_lds(const LdsAggParams a) {
             lds_dma16(src + i + lane, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)i * 16u));
     }
 
-    const bool active = lane < LANES;
-    const int ln = min(lane, LANES - 1);                   // lanes beyond the part shadow the last one (uniform control flow)
-    const int blk_l = ln / LPB, sub = ln % LPB;
-    float* const ring = reinterpret_cast<float*>(smem + tq_pad) + wv * (U * PF);
-    const float4* const wl = smem + ln;
-    const float* const xr_base = ring + blk_l * P;
-    float* const xw_base = ring + min(lane, XL - 1) * VW;
-    const bool xl_on = lane < XL;
-    const float* const fsrc = a.feat + part * PF + min(lane, XL - 1) * VW;
+    // lanes without a slot (position 15 of a row, slots beyond the part's) shadow a real lane: same addresses, uniform control
+    // flow; nothing they compute is read
+    const int pos = min(lane & 15, 14), slot_raw = (lane >> 4) * 3 + pos / 5, g = pos % 5;
+    const bool valid = (lane & 15) < 15 && slot_raw < SLOTS;
+    const int slot_l = min(slot_raw, SLOTS - 1);
+    const int blk_l = slot_l / OH, half = slot_l % OH;
+    const int cl = valid ? lane : 16 * (slot_l / 3) + 5 * (slot_l % 3) + g;      // table column of this lane (shadow lanes: their twin's)
+    const float4* const wl = smem + cl;
+    float* const rbuf = reinterpret_cast<float*>(smem + tq_pad) + wv * (KB * PO);     // wave-private: KB finished rows (this part's columns)
+    const float* const fsrc = a.feat + (part * BPP + blk_l) * P + g * IPL;
     const size_t ld = (size_t)a.ld_feat;
-    const int col0 = (part * BPP + blk_l) * Q + sub * QS;
+    const int el = min(lane, EL - 1);
+    const int colE = part * PO + el * EW;
+    const bool e_on = lane < EL;
     const int nwaves = gridDim.x * nw;
     const int gw = blockIdx.x * nw + wv;
     const bool has_add = a.addend != nullptr, has_keep = a.keep != nullptr;
 
-    struct Meta { int n, t; float c; };
-    struct Epi { float ad[QS]; unsigned kp; };
-    auto load_meta = [&](int pos, int cnt) {
-        Meta m{0, 0, 1.f};
+    struct Meta { int n, t, r; float c; };
+    struct Epi { float ad[EW]; unsigned kp; };
+    auto load_meta = [&](int pos0, int cnt) {
+        Meta m{0, 0, 0, 1.f};
         if (lane < cnt) {
-            m.n = a.nbr[pos + lane];
-            m.t = a.etype[pos + lane];
-            if (a.coef) m.c = a.coef_idx ? a.coef[a.coef_idx[pos + lane]] : a.coef[pos + lane];
+            m.n = a.nbr[pos0 + lane];
+            m.t = a.etype[pos0 + lane];
+            m.r = a.erow[pos0 + lane];
+            if (a.coef) m.c = a.coef_idx ? a.coef[a.coef_idx[pos0 + lane]] : a.coef[pos0 + lane];
         }
         return m;
     };
-    // Epilogue operands of a row, requested one item ahead.  The loads are UNCONDITIONAL (a conditional load into a
-    // pre-set register makes hipcc copy it behind a full wait): rows that need none read row 0, an absent operand reads the
-    // output buffer instead; what was read is selected away where it is used (finish).
-    const float* const add_base = (has_add ? a.addend : a.out) + col0;
+    // Epilogue operands of a row.  The loads are UNCONDITIONAL: an absent operand reads the output buffer instead (what was
+    // read is selected away where it is used), a row id < 0 (the slice of a hub row: no epilogue) reads row 0.
+    const float* const add_base = (has_add ? a.addend : a.out) + colE;
     const size_t add_ld = has_add ? (size_t)a.ld_add : (size_t)a.ld_out;
-    const uint8_t* const keep_base = has_keep ? a.keep + col0 : reinterpret_cast<const uint8_t*>(a.out + col0);
+    const uint8_t* const keep_base = has_keep ? a.keep + colE : reinterpret_cast<const uint8_t*>(a.out + colE);
     const size_t keep_ld = has_keep ? (size_t)a.out_dim : (size_t)a.ld_out * 4;
-    auto load_epi = [&](int row, int slot) {
+    auto load_epi = [&](int row) {
         Epi e;
         const size_t r = (size_t)(unsigned)max(row, 0);
-        load_vec<QS>(add_base + r * add_ld, e.ad);
+        load_vec<EW>(add_base + r * add_ld, e.ad);
         const uint8_t* kp = keep_base + r * keep_ld;
-        if constexpr (QS == 2) e.kp = *reinterpret_cast<const uint16_t*>(kp);
-        else if constexpr (QS == 4) e.kp = *reinterpret_cast<const uint32_t*>(kp);
-        else {
-            e.kp = 0;
-#pragma unroll
-            for (int i = 0; i < QS; ++i) e.kp |= (unsigned)kp[i] << (8 * i);
-        }
+        if constexpr (EW == 2) e.kp = *reinterpret_cast<const uint16_t*>(kp);
+        else e.kp = *kp;
         return e;
     };
-    // the feature pieces of one step: U loads back to back, no branch between them (edges beyond the step re-read its last
-    // one, a step without edges reads row 0)
-    auto issue_x = [&](const Meta& m, int j, int cnt, float (&xs)[U][VW]) {
+    auto store_row = [&](int row, const Epi& e, float (&v)[EW]) {      // epilogue + store of the part's columns of one final row
+#pragma unroll
+        for (int i = 0; i < EW; ++i) {
+            float t = apply_act(has_add ? v[i] + e.ad[i] : v[i], a.act);
+            if (has_keep) t = ((e.kp >> (8 * i)) & 0xffu) ? t * a.keep_scale : 0.f;
+            v[i] = t;
+        }
+        if (e_on) store_vec<EW>(a.out + (size_t)row * a.ld_out + colE, v);
+    };
+    // Finished rows: ids in `rid` (lane i = buffer slot i; id >= 0: a final row, -(slot + 1): the slice of a hub row that goes
+    // raw to partial[slot]), their sums in rbuf.
+    int rid = 0, nbuf = 0;
+    // a row is complete: the block's five input groups summed (row_shr adds inside the 16-lane DPP row: valid at g = 4) and
+    // the part of the row parked in column order
+    auto park = [&](int id, const float (&acc)[OPL]) {
+        float t[OPL];
+#pragma unroll
+        for (int o = 0; o < OPL; ++o) {
+            // one instruction per add (hipcc pairs the adds into v_pk_add_f32 otherwise, which cannot take the DPP operand)
+            float s1, s2;
+            asm("v_add_f32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(s1) : "v"(acc[o]));
+            asm("v_add_f32_dpp %0, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(s2) : "v"(s1));
+            asm("v_add_f32_dpp %0, %1, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(t[o]) : "v"(acc[o]), "v"(s2));
+        }
+        if (valid && g == NIG - 1) store_vec<OPL>(rbuf + nbuf * PO + slot_l * OPL, t);
+        rid = lane == nbuf ? id : rid;
+        ++nbuf;
+    };
+    // epilogue of all parked rows: every row's operands requested first, then read back / finished / stored row by row
+    auto drain = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the parked sums are read by other lanes of this wave
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        Epi e[KB];
+        int ids[KB];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            ids[i] = lrl_i(rid, i);
+            e[i] = load_epi(i < nbuf ? ids[i] : 0);
+        }
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            if (i < nbuf) {
+                float v[EW];
+                load_vec<EW>(rbuf + i * PO + el * EW, v);
+                if (ids[i] >= 0) store_row(ids[i], e[i], v);
+                else if (e_on) store_vec<EW>(a.partial + (size_t)(-ids[i] - 1) * a.out_dim + colE, v);
+            }
+        }
+        nbuf = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the buffer is free again
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // Super-items are dealt to the workgroups in a strided order (workgroup b takes b, b + gridDim.x, ...: hub slices and
+    // short runs spread evenly) and, inside a workgroup, to whichever wave asks next: the wave's first two are fixed (wave w:
+    // shares w and nw + w, requested while the weights are still landing), from share 2 nw on a counter in LDS hands them out.
+    // A wave always knows three: A (running), B (metadata in registers), C (descriptor requested).
+    int* const ctr = reinterpret_cast<int*>(reinterpret_cast<float*>(smem + tq_pad) + nw * (KB * PO));
+    if (threadIdx.x == 0) *ctr = 2 * nw;
+    const long long wg0 = blockIdx.x, wgs = gridDim.x;
+    auto fetch = [&](int share, int& slot, int& beg, int& cnt) {      // share = this workgroup's share-th super-item (uniform)
+        const long long id = wg0 + (long long)share * wgs;
+        beg = 0; cnt = 0; slot = -1;
+        if (id < a.n_sitems) {
+            const int4 d = a.sitems[id];                               // a uniform address: a scalar load
+            beg = d.x; slot = d.z;
+            cnt = max(0, min(64, d.y - d.x));
+            if (slot >= 0 && !a.partial) cnt = 0;
+        }
+        return id < a.n_sitems;
+    };
+    auto grab = [&]() {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(ctr, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    int slotA, begA, cntA, slotB, begB, cntB, slotC, begC, cntC;
+    bool moreA = fetch(wv, slotA, begA, cntA);
+    bool moreB = fetch(nw + wv, slotB, begB, cntB);
+    Meta mA = load_meta(begA, cntA), mB = load_meta(begB, cntB);
+    auto issue_x = [&](int nsrc, int j, int cnt, xvec& xs) {       // U loads back to back, no branch between them
         const int last = max(cnt, 1) - 1;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int s = lrl_i(m.n, min(j + u, last));
-            load_vec<VW>(fsrc + (size_t)(unsigned)s * ld, xs[u]);
+            const int s = lrl_i(nsrc, min(j + u, last));
+            float tmp[IPL];
+            load_vec<IPL>(fsrc + (size_t)(unsigned)s * ld, tmp);
+#pragma unroll
+            for (int i = 0; i < IPL; ++i) xs[u * IPL + i] = tmp[i];
         }
     };
-    auto edge_fma = [&](int u, int r, float c, float (&acc)[QS]) {
-        float xv[P], wr[NW];
-        load_vec<P>(xr_base + u * PF, xv);
-        const float4* wq = wl + (size_t)r * (NQ * LANES);
+    xvec x0, x1;
+    issue_x(mA.n, 0, cntA, x0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the weight copy (the compiler does not count the DMAs)
+    __syncthreads();
+    bool moreC = fetch(grab(), slotC, begC, cntC);
+    float acc[OPL];
 #pragma unroll
-        for (int q4 = 0; q4 < NQ; ++q4) {
-            const float4 t = wq[q4 * LANES];
-            wr[4 * q4] = t.x; wr[4 * q4 + 1] = t.y; wr[4 * q4 + 2] = t.z; wr[4 * q4 + 3] = t.w;
+    for (int o = 0; o < OPL; ++o) acc[o] = 0.f;
+    int j = 0, cur_row = -1;
+    // one step: request the NEXT step's pieces into xn, run this step out of xc; the two register sets swap roles by the call
+    // sequence below (static names: no copies, so the wait in front of a step never covers the loads just issued)
+    auto step = [&](const xvec& xc, xvec& xn) -> bool {
+        const int nb = (a.debug & 1) ? 0 : min(U, cntA - j);
+        const bool same = j + U < cntA;                            // the next step is in this super-item, else the next one's first
+        issue_x(same ? mA.n : mB.n, same ? j + U : 0, same ? cntA : cntB, xn);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                              // unrolled: the pieces are picked by static register names
+            if (u >= nb) break;
+            const int p = j + u;
+            const int r = lrl_i(mA.r, p);
+            if (r != cur_row) {                                    // first edge of a row: the previous one is complete
+                if (cur_row >= 0) park(cur_row, acc);
+#pragma unroll
+                for (int o = 0; o < OPL; ++o) acc[o] = 0.f;
+                cur_row = r;
+            }
+            const int rel = lrl_i(mA.t, p);
+            const float c = lrl_f(mA.c, p);
+            const float4* wq = wl + (size_t)rel * (NQ * CL);
+            float wr[NW];
+#pragma unroll
+            for (int q4 = 0; q4 < NQ; ++q4) {
+                const float4 t = wq[q4 * CL];
+                wr[4 * q4] = t.x; wr[4 * q4 + 1] = t.y; wr[4 * q4 + 2] = t.z; wr[4 * q4 + 3] = t.w;
+            }
+#pragma unroll
+            for (int i = 0; i < IPL; ++i) {
+                const float xs = xc[u * IPL + i] * c;
+#pragma unroll
+                for (int o = 0; o < OPL; ++o) acc[o] = fmaf(xs, wr[i * OPL + o], acc[o]);
+            }
         }
+        j += U;
+        bool done = false;
+        if (j >= cntA) {                                           // the super-item's last row (or the slice of a hub row)
+            if (cur_row >= 0) park(slotA >= 0 ? -(slotA + 1) : cur_row, acc);
 #pragma unroll
-        for (int q = 0; q < QS; ++q) {
-            float t = 0.f;
-#pragma unroll
-            for (int p = 0; p < P; ++p) t = fmaf(xv[p], wr[q * P + p], t);
-            acc[q] = fmaf(t, c, acc[q]);
+            for (int o = 0; o < OPL; ++o) acc[o] = 0.f;
+            cur_row = -1;
+            if (!moreB) done = true;
+            else {
+                slotA = slotB; begA = begB; cntA = cntB; moreA = moreB;
+                rot_i(mA.n, mB.n); rot_i(mA.t, mB.t); rot_i(mA.r, mB.r); rot_f(mA.c, mB.c);
+                slotB = slotC; begB = begC; cntB = cntC; moreB = moreC;
+                mB = load_meta(begB, cntB);
+                moreC = moreC && fetch(grab(), slotC, begC, cntC);
+                if (!moreC) cntC = 0;
+                j = 0;
+            }
         }
+        if (nbuf + U + 1 > KB || done) drain();                    // room for every row the next step can complete
+        return done;
     };
-    // park the step's pieces in the wave's ring and run its edges
-    auto consume = [&](const Meta& m, int j, int nb, const float (&xs)[U][VW], float (&acc)[QS]) {
-        if (xl_on && !(a.debug & 2)) {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (u < nb) store_vec<VW>(xw_base + u * PF, xs[u]);
-        }
-        if (a.debug & 1) nb = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // other lanes of this wave read the pieces
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int u = 0;
-        for (; u + 2 <= nb; u += 2) {                             // pairs: the second edge's LDS reads under the first one's fmas
-            edge_fma(u, lrl_i(m.t, j + u), lrl_f(m.c, j + u), acc);
-            edge_fma(u + 1, lrl_i(m.t, j + u + 1), lrl_f(m.c, j + u + 1), acc);
-        }
-        if (u < nb) edge_fma(u, lrl_i(m.t, j + u), lrl_f(m.c, j + u), acc);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next step overwrites the ring
-        __builtin_amdgcn_wave_barrier();
-    };
-    auto finish = [&](int row, int slot, const Epi& e, float (&acc)[QS]) {
-        if (!active || row < 0) return;
-        const bool fin = slot < 0;                                 // else: a slice of a hub row, summed by the fix-up pass
-        float* dstp = fin ? a.out + (size_t)row * a.ld_out + col0 : a.partial + (size_t)slot * a.out_dim + col0;
-#pragma unroll
-        for (int i = 0; i < QS; ++i) {
-            float v = apply_act(has_add ? acc[i] + e.ad[i] : acc[i], a.act);
-            if (has_keep) v = ((e.kp >> (8 * i)) & 0xffu) ? v * a.keep_scale : 0.f;
-            acc[i] = fin ? v : acc[i];
-        }
-        store_vec<QS>(dstp, acc);
-    };
-
-    bool first = true;
-    for (long long base = gw; base < a.n_items; base += 64ll * nwaves) {
-        // this wave's next 64 items: base, base + nwaves, ...
-        int4 itv = make_int4(-1, 0, 0, -1);
-        {
-            const long long i0 = base + (long long)lane * nwaves;
-            if (i0 < a.n_items) itv = a.items[i0];
-        }
-        const int nk = (int)min(64ll, (a.n_items - base + nwaves - 1) / nwaves);
-        auto desc = [&](int k, int& row, int& slot, int& beg, int& cnt) {      // k >= nk: none
-            const int kk = min(k, 63);
-            row = lrl_i(itv.x, kk); slot = lrl_i(itv.w, kk); beg = lrl_i(itv.y, kk);
-            cnt = min(64, lrl_i(itv.z, kk) - beg);
-            if (k >= nk || row < 0) { row = -1; cnt = 0; }
-            if (slot >= 0 && !a.partial) { row = -1; cnt = 0; }
-        };
-        int rowA, slotA, begA, cntA, rowB, slotB, begB, cntB, rowC, slotC, begC, cntC;
-        desc(0, rowA, slotA, begA, cntA);
-        desc(1, rowB, slotB, begB, cntB);
-        desc(2, rowC, slotC, begC, cntC);
-        Meta mA = load_meta(begA, cntA), mB = load_meta(begB, cntB), mC = load_meta(begC, cntC);
-        Epi eA = load_epi(rowA, slotA), eB = load_epi(rowB, slotB);
-        float x0[U][VW], x1[U][VW];
-        issue_x(mA, 0, cntA, x0);
-        if (first) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the weight copy (the compiler does not count the DMAs)
-            __syncthreads();
-            first = false;
-        }
-        float acc[QS];
-#pragma unroll
-        for (int i = 0; i < QS; ++i) acc[i] = 0.f;
-        int k = 0, j = 0;
-        // one step: request the NEXT step's pieces into xn, run this step out of xc; the two register sets swap roles by
-        // the call sequence below (static names: no copies, so the wait in front of a step never covers the loads just issued)
-        auto step = [&](const float (&xc)[U][VW], float (&xn)[U][VW]) -> bool {
-            const int nb = min(U, cntA - j);
-            const bool same = j + U < cntA;                        // the next step is in this item, else the next item's first
-            Meta mN;
-            mN.n = same ? mA.n : mB.n; mN.t = 0; mN.c = 0.f;
-            issue_x(mN, same ? j + U : 0, same ? cntA : cntB, xn);
-            consume(mA, j, nb, xc, acc);
-            j += U;
-            if (j < cntA) return false;
-            finish(rowA, slotA, eA, acc);
-#pragma unroll
-            for (int i = 0; i < QS; ++i) acc[i] = 0.f;
-            if (++k >= nk) return true;
-            rowA = rowB; slotA = slotB; begA = begB; cntA = cntB;
-            rowB = rowC; slotB = slotC; begB = begC; cntB = cntC;
-            // The register rotation is done by OPAQUE moves, before the next requests are issued: left to hipcc, the loop-carried
-            // values get their copies at the end of the block, i.e. behind the new loads, which then land in temporaries and are
-            // copied over behind a full wait.
-            rot_i(mA.n, mB.n); rot_i(mA.t, mB.t); rot_f(mA.c, mB.c);
-            rot_i(mB.n, mC.n); rot_i(mB.t, mC.t); rot_f(mB.c, mC.c);
-#pragma unroll
-            for (int i = 0; i < QS; ++i) rot_f(eA.ad[i], eB.ad[i]);
-            { int t; rot_i(t, (int)eB.kp); eA.kp = (unsigned)t; }
-            desc(k + 2, rowC, slotC, begC, cntC);
-            mC = load_meta(begC, cntC);
-            eB = load_epi(rowB, slotB);
-            j = 0;
-            return false;
-        };
+    if (moreA) {
         for (;;) {
             if (step(x0, x1)) break;
             if (step(x1, x0)) break;
         }
     }
-    if (first) {                                                   // a wave without items still joins the staging barrier
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    // rows without edges: epilogue of a zero aggregate, four rows' operands in flight
+    for (long long base = gw; base < a.n_empty; base += 64ll * nwaves) {
+        int myrow = -1;
+        {
+            const long long i0 = base + (long long)lane * nwaves;
+            if (i0 < a.n_empty) myrow = a.empty[i0];
+        }
+        const int nk = (int)min(64ll, (a.n_empty - base + nwaves - 1) / nwaves);
+        for (int k = 0; k < nk; k += 4) {
+            int rows[4];
+            Epi e[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                rows[t] = (k + t < nk) ? lrl_i(myrow, min(k + t, 63)) : -1;
+                e[t] = load_epi(rows[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (rows[t] >= 0) {
+                    float v[EW];
+#pragma unroll
+                    for (int i = 0; i < EW; ++i) v[i] = 0.f;
+                    store_row(rows[t], e[t], v);
+                }
+            }
+        }
     }
 }
 
-// row layout [R][nb * bi * bo] -> [parts][R][NQ][LANES] float4.  Lane l of a part owns block part*BPP + l / LPB and its
-// output columns sub*QS .. (sub = l % LPB); its list is q-major: element q*P + p multiplies input p into output q.
-// Stored block: P x Q row-major for the plain product, Q x P (read transposed) for transpose_w.
+// row layout [R][nb * bi * bo] -> [parts][R][NQ][CL] float4, CL = the kernel's lanes up to the last used one.  Lane (slot, g) of a part owns block
+// part*BPP + slot / OH, its inputs g*IPL .. and its outputs half*OPL .. (half = slot % OH); its list is input-major: element
+// i*OPL + o multiplies input g*IPL + i into output half*OPL + o.  Stored block: P x Q row-major for the plain product,
+// Q x P (read transposed) for transpose_w.
 __global__ __launch_bounds__(256) void k_pack_weight_lds(const float* __restrict__ w, float4* __restrict__ out, int num_rels,
-                                                         int nb, int P, int Q, int QS, int BPP, int trans) {
-    const int LPB = Q / QS, LANES = BPP * LPB, NQ = P * QS / 4, parts = nb / BPP;
-    const size_t total = (size_t)parts * num_rels * NQ * LANES;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int l = (int)(i % LANES);
-        size_t t = i / LANES;
+                                                         int nb, int P, int Q, int IPL, int OH, int BPP, int CL, int trans) {
+    const int OPL = Q / OH, NQ = IPL * OPL / 4, NIG = P / IPL, SLOTS = BPP * OH, parts = nb / BPP;
+    const size_t total = (size_t)parts * num_rels * NQ * CL;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int lane = (int)(idx % CL);
+        size_t t = idx / CL;
         const int jq = (int)(t % NQ);
         t /= NQ;
         const int r = (int)(t % num_rels), part = (int)(t / num_rels);
-        const int blk = part * BPP + l / LPB, sub = l % LPB;
-        const float* wb = w + ((size_t)r * nb + blk) * (P * Q);
-        float e4[4];
+        const int pos = lane & 15, slot = (lane >> 4) * 3 + pos / NIG, g = pos % NIG;
+        float e4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pos < 15 && slot < SLOTS) {                 // lanes without a slot: zeros
+            const int blk = part * BPP + slot / OH, half = slot % OH;
+            const float* wb = w + ((size_t)r * nb + blk) * (P * Q);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int e = 4 * jq + c, q = e / P, p = e % P, col = sub * QS + q;
-            e4[c] = trans ? wb[col * P + p] : wb[p * Q + col];
+            for (int c = 0; c < 4; ++c) {
+                const int e = 4 * jq + c, i = e / OPL, o = e % OPL, in = g * IPL + i, col = half * OPL + o;
+                e4[c] = trans ? wb[col * P + in] : wb[in * Q + col];
+            }
         }
-        out[i] = make_float4(e4[0], e4[1], e4[2], e4[3]);
+        out[idx] = make_float4(e4[0], e4[1], e4[2], e4[3]);
     }
 }
 
 namespace {
-struct LdsPlan { int qs, bpp, parts, lanes, nq, u, pf; };
+struct LdsPlan { int ipl, oh, bpp, parts, cl, nq, u, po; };
 constexpr int LDS_WAVES = 16;
 constexpr int LDS_BUDGET = 160 * 1024;
+constexpr int LDS_SITEM_EDGES = 64;
+constexpr int LDS_ROWBUF = 8;          // = KB of k_agg_lds
 
 // instantiated shapes (gathered block width, output block width); transpose_w only changes the packing
 bool lds_plan(int nb, int p, int q, int num_rels, LdsPlan* out) {
-    int qs = 0, bpp = 0, u = 4;
-    if (p == 10 && q == 10) { qs = 2; bpp = 10; }
-    else if (p == 10 && q == 20) { qs = 2; bpp = 5; }
-    else if (p == 20 && q == 10) { qs = 1; bpp = 5; }
+    int ipl = 0, oh = 0, bpp = 0, u = 4;
+    if (p == 10 && q == 10) { ipl = 2; oh = 1; bpp = 10; }
+    else if (p == 10 && q == 20) { ipl = 2; oh = 2; bpp = 5; }
+    else if (p == 20 && q == 10) { ipl = 4; oh = 2; bpp = 5; }
     else return false;
     if (nb % bpp) return false;
-    const int lanes = bpp * (q / qs), nq = p * qs / 4, pf = bpp * p;
-    const size_t tq = (size_t)num_rels * nq * lanes;
-    const size_t lds = ((tq + 63) & ~(size_t)63) * 16 + (size_t)LDS_WAVES * u * pf * 4;
+    const int slots = bpp * oh, cl = 16 * ((slots - 1) / 3) + 5 * ((slots - 1) % 3) + p / ipl;      // table columns = lanes
+    const int nq = ipl * (q / oh) / 4, po = bpp * q;
+    const size_t tq = (size_t)num_rels * nq * cl;
+    const size_t lds = ((tq + 63) & ~(size_t)63) * 16 + (size_t)LDS_WAVES * LDS_ROWBUF * po * 4 + 16;
     if (lds > (size_t)LDS_BUDGET) return false;
-    out->qs = qs; out->bpp = bpp; out->parts = nb / bpp; out->lanes = lanes; out->nq = nq; out->u = u; out->pf = pf;
+    out->ipl = ipl; out->oh = oh; out->bpp = bpp; out->parts = nb / bpp; out->cl = cl; out->nq = nq; out->u = u; out->po = po;
     return true;
 }
 }  // namespace
@@ -336,8 +406,8 @@ extern "C" int gv_rgcn_bdd_lds_plan(int num_bases, int blk_in, int blk_out, int 
     if (!lds_plan(num_bases, blk_in, blk_out, num_rels, &pl)) return 0;
     if (plan_host) {
         plan_host[0] = pl.parts;
-        plan_host[1] = pl.parts * num_rels * pl.nq * pl.lanes * 4 + 64 * 4;      /* floats of the packed weight buffer */
-        plan_host[2] = 64;                                                        /* preferred work-item chunk (edges) */
+        plan_host[1] = pl.parts * num_rels * pl.nq * pl.cl * 4 + 64 * 4;      /* floats of the packed weight buffer */
+        plan_host[2] = LDS_SITEM_EDGES;                                        /* most edges a super-item may hold */
     }
     return 1;
 }
@@ -350,23 +420,24 @@ extern "C" int gv_rgcn_bdd_pack_weight_lds(const float* weight, int num_rels, in
                "gv_rgcn_bdd_pack_weight_lds: no LDS-resident kernel for num_bases=%d blocks %dx%d with %d relations", num_bases,
                blk_in, blk_out, num_rels);
     GV_REQUIRE(aligned16(packed), GV_ERR_ALIGN, "gv_rgcn_bdd_pack_weight_lds: 16-B alignment required");
-    const size_t total = (size_t)pl.parts * num_rels * pl.nq * pl.lanes;
+    const size_t total = (size_t)pl.parts * num_rels * pl.nq * pl.cl;
     hipLaunchKernelGGL(k_pack_weight_lds, dim3((unsigned)min((size_t)2048, (total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, weight, (float4*)packed, num_rels, num_bases, blk_in, blk_out, pl.qs, pl.bpp,
-                       transpose_w ? 1 : 0);
+                       (hipStream_t)stream, weight, (float4*)packed, num_rels, num_bases, blk_in, blk_out, pl.ipl, pl.oh, pl.bpp,
+                       pl.cl, transpose_w ? 1 : 0);
     return launch_status("gv_rgcn_bdd_pack_weight_lds");
 }
 
-extern "C" int gv_rgcn_bdd_aggregate_lds(const int32_t* items, int n_items, const int32_t* fix, int n_fix,
-                                         const int32_t* nbr, const int32_t* etype, const float* coef,
-                                         const int32_t* coef_idx, const float* feat, int ld_feat, const float* weight_packed,
-                                         int num_rels, int num_bases, int blk_in, int blk_out, const float* addend,
-                                         int ld_addend, int act, const uint8_t* keep, float keep_scale, float* out, int ld_out,
-                                         float* partial, int max_workgroups, void* stream) {
-    GV_REQUIRE(n_items >= 0 && n_fix >= 0, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate_lds: negative item count");
-    if (n_items == 0) return GV_OK;
-    GV_REQUIRE(items && feat && weight_packed && out, GV_ERR_NULL, "gv_rgcn_bdd_aggregate_lds: NULL pointer");
-    GV_REQUIRE(n_fix == 0 || (fix && partial), GV_ERR_NULL, "gv_rgcn_bdd_aggregate_lds: split segments need fix+partial");
+extern "C" int gv_rgcn_bdd_aggregate_lds(const int32_t* sitems, int n_sitems, const int32_t* erow, const int32_t* empty_rows,
+                                         int n_empty, const int32_t* fix, int n_fix, const int32_t* nbr, const int32_t* etype,
+                                         const float* coef, const int32_t* coef_idx, const float* feat, int ld_feat,
+                                         const float* weight_packed, int num_rels, int num_bases, int blk_in, int blk_out,
+                                         const float* addend, int ld_addend, int act, const uint8_t* keep, float keep_scale,
+                                         float* out, int ld_out, float* partial, int max_workgroups, void* stream) {
+    GV_REQUIRE(n_sitems >= 0 && n_fix >= 0 && n_empty >= 0, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate_lds: negative count");
+    if (n_sitems == 0 && n_empty == 0) return GV_OK;
+    GV_REQUIRE(feat && weight_packed && out && (n_sitems == 0 || (sitems && erow && nbr && etype)) && (n_empty == 0 || empty_rows),
+               GV_ERR_NULL, "gv_rgcn_bdd_aggregate_lds: NULL pointer");
+    GV_REQUIRE(n_fix == 0 || (fix && partial), GV_ERR_NULL, "gv_rgcn_bdd_aggregate_lds: split rows need fix+partial");
     GV_REQUIRE(act == GV_ACT_NONE || act == GV_ACT_RELU, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate_lds: unknown act %d", act);
     LdsPlan pl;
     GV_REQUIRE(num_bases > 0 && num_rels > 0 && lds_plan(num_bases, blk_in, blk_out, num_rels, &pl), GV_ERR_SHAPE,
@@ -375,22 +446,23 @@ extern "C" int gv_rgcn_bdd_aggregate_lds(const int32_t* items, int n_items, cons
     GV_REQUIRE(ld_feat >= num_bases * blk_in && ld_out >= num_bases * blk_out, GV_ERR_SHAPE,
                "gv_rgcn_bdd_aggregate_lds: leading dimension smaller than the row");
     const int out_dim = num_bases * blk_out;
-    // 16-B pieces of the feature rows, 8-B (QS = 2) or 4-B stores: row bases 16-B aligned, even leading dimensions
+    // 8- / 16-B pieces of the feature rows, 8- or 4-B stores: row bases 16-B aligned, leading dimensions multiples of 4 / 2
     const bool al_ok = aligned16(feat) && aligned16(weight_packed) && aligned16(out) && ld_feat % 4 == 0 && ld_out % 2 == 0 &&
                        (!addend || (aligned16(addend) && ld_addend % 2 == 0)) && (!partial || aligned16(partial)) &&
                        out_dim % 2 == 0;
     GV_REQUIRE(al_ok, GV_ERR_ALIGN, "gv_rgcn_bdd_aggregate_lds: rows must be 16-B aligned");
     LdsAggParams a;
-    a.items = (const int4*)items; a.n_items = n_items; a.nbr = nbr; a.etype = etype; a.coef = coef; a.coef_idx = coef_idx;
+    a.sitems = (const int4*)sitems; a.n_sitems = n_sitems; a.erow = erow; a.empty = empty_rows; a.n_empty = n_empty;
+    a.nbr = nbr; a.etype = etype; a.coef = coef; a.coef_idx = coef_idx;
     a.feat = feat; a.ld_feat = ld_feat; a.wpk = (const float4*)weight_packed; a.R = num_rels; a.addend = addend;
     a.ld_add = ld_addend; a.act = act; a.keep = keep; a.keep_scale = keep_scale; a.out = out; a.ld_out = ld_out;
     a.partial = partial; a.out_dim = out_dim;
     static const int dbg = getenv("GV_K1_LDS_DEBUG") ? atoi(getenv("GV_K1_LDS_DEBUG")) : 0;
     a.debug = dbg;
     hipStream_t st = (hipStream_t)stream;
-    const size_t tq = (size_t)num_rels * pl.nq * pl.lanes;
-    const size_t lds = ((tq + 63) & ~(size_t)63) * 16 + (size_t)LDS_WAVES * pl.u * pl.pf * 4;
-    // one workgroup per CU over all column parts; never more workgroups than 16-item shares of the list
+    const size_t tq = (size_t)num_rels * pl.nq * pl.cl;
+    const size_t lds = ((tq + 63) & ~(size_t)63) * 16 + (size_t)LDS_WAVES * LDS_ROWBUF * pl.po * 4 + 16;
+    // one workgroup per CU over all column parts; never more workgroups than 16-wave shares of the two lists
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0, v = 0;
@@ -401,14 +473,15 @@ extern "C" int gv_rgcn_bdd_aggregate_lds(const int32_t* items, int n_items, cons
         (void)hipGetLastError();
     }
     int wgs = (max_workgroups > 0 ? max_workgroups : n_cu) / pl.parts;
-    const int need = (n_items + LDS_WAVES - 1) / LDS_WAVES;
+    const int longest = n_sitems > n_empty ? n_sitems : n_empty;
+    const int need = (longest + LDS_WAVES - 1) / LDS_WAVES;
     if (wgs > need) wgs = need;
     if (wgs < 1) wgs = 1;
     const dim3 grid(wgs, pl.parts), block(64 * LDS_WAVES);
     int rc = -1000;
-#define GV_LDS_CASE(P_, Q_, QS_, BPP_, U_)                                                                              \
-    if (rc == -1000 && blk_in == P_ && blk_out == Q_ && pl.qs == QS_ && pl.bpp == BPP_ && pl.u == U_) {                 \
-        auto kern = k_agg_lds<P_, Q_, QS_, BPP_, U_>;                                                                   \
+#define GV_LDS_CASE(P_, Q_, IPL_, OH_, BPP_, U_)                                                                        \
+    if (rc == -1000 && blk_in == P_ && blk_out == Q_ && pl.ipl == IPL_ && pl.oh == OH_ && pl.bpp == BPP_ && pl.u == U_) { \
+        auto kern = k_agg_lds<P_, Q_, IPL_, OH_, BPP_, U_>;                                                             \
         static bool attr_done = false;                                                                                  \
         if (!attr_done) {                                                                                               \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET) != hipSuccess) \
@@ -418,9 +491,9 @@ extern "C" int gv_rgcn_bdd_aggregate_lds(const int32_t* items, int n_items, cons
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                              \
         rc = launch_status("gv_rgcn_bdd_aggregate_lds");                                                               \
     }
-    GV_LDS_CASE(10, 10, 2, 10, 4)
-    GV_LDS_CASE(10, 20, 2, 5, 4)
-    GV_LDS_CASE(20, 10, 1, 5, 4)
+    GV_LDS_CASE(10, 10, 2, 1, 10, 4)
+    GV_LDS_CASE(10, 20, 2, 2, 5, 4)
+    GV_LDS_CASE(20, 10, 4, 2, 5, 4)
 #undef GV_LDS_CASE
     GV_REQUIRE(rc != -1000, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate_lds: no instantiation for blocks %dx%d", blk_in, blk_out);
     if (rc != GV_OK) return rc;

@@ -260,16 +260,13 @@ class GraphIndex:
                                 SegmentItems(it_d.view(-1, 4), fx_d.view(-1, 4), ci_d, cf_d, slots_d, rp_d, chunk))
         self.by_src = EdgeOrder(perm_s, SegmentItems(it_s.view(-1, 4), fx_s.view(-1, 4), ci_s, cf_s, slots_s, rp_s, chunk))
 
-    def lds_seg(self, side: str, chunk: int) -> SegmentItems:
-        """The work items of one ordering cut at ``chunk`` edges instead of this index's own chunk (same rowptr, same edge
-        positions): the LDS-resident K1 kernel walks items wave by wave, so a hub slice must be short (ops.lds_plan)."""
-        own = self.by_dst.seg if side == 'dst' else self.by_src.seg
-        if own.chunk <= chunk:
-            return own
-        key = (side, int(chunk))
+    def lds_order(self, side: str, max_edges: int) -> 'LdsOrder':
+        """Super-items of one ordering for the LDS-resident K1 kernel (csrc/k_lds.hip); built once per graph, cached."""
+        key = (side, int(max_edges))
         hit = self._lds_seg_cache.get(key)
         if hit is None:
-            hit = self._lds_seg_cache[key] = build_segment_items(own.rowptr, int(chunk), self.num_edges if self.sync_free else None)
+            own = self.by_dst.seg if side == 'dst' else self.by_src.seg
+            hit = self._lds_seg_cache[key] = LdsOrder.build(own.rowptr, self.num_edges, int(max_edges))
         return hit
 
     def coef_in_src_order(self, coef: torch.Tensor) -> torch.Tensor:
@@ -668,9 +665,87 @@ def bdd_aggregate_phases(ph: PhaseOrder, coef_p, feat, weight_packed, num_rels, 
     return out
 
 
+@dataclass
+class LdsOrder:
+    """Work lists of the LDS-resident K1 kernel over one row ordering (rowptr): SUPER-ITEMS = runs of consecutive rows with
+    <= G edges in all (one coalesced metadata fetch each) or <= G-edge slices of longer rows (partial slots + a fix-up
+    entry per such row), the row of every edge position, and the rows without edges."""
+    sitems: torch.Tensor       # int32 [n_sitems, 4] {first edge position, end position, partial slot (-1: whole rows), 0}
+    n_sitems: int
+    erow: torch.Tensor         # int32 [E]
+    empty: torch.Tensor        # int32 [n_empty]
+    n_empty: int
+    fix: torch.Tensor          # int32 [n_fix, 4] {row, first slot, slices, 0}
+    n_fix: int
+    n_slots: int
+    n_rows: int
+    max_edges: int
+
+    @staticmethod
+    def build(rowptr: torch.Tensor, n_edges: int, G: int = 64) -> 'LdsOrder':
+        """Small rows (<= G/2 edges) are grouped by the G/2-wide window their first edge falls in -- a group then spans at
+        most G/2 - 1 + G/2 < G positions -- and never across a longer row; a longer row is its own item, cut into G-edge
+        slices beyond G edges.  Torch ops on the device + one read-back of the list sizes (a static graph's index)."""
+        dev = rowptr.device
+        rp = rowptr.long()
+        n_rows = rp.numel() - 1
+        deg = rp[1:] - rp[:-1]
+        rows = torch.arange(n_rows, device=dev)
+        half = max(1, G // 2)
+        small = (deg > 0) & (deg <= half)
+        big = deg > half
+        empty = rows[deg == 0].to(torch.int32).contiguous()
+        erow = torch.repeat_interleave(rows, deg).to(torch.int32).contiguous()
+        lists = []
+        # small rows: group key = (long rows before it, window of its first edge)
+        rs = rows[small]
+        if rs.numel():
+            nbig_before = torch.cumsum(big.long(), 0)[rs]
+            key = nbig_before * (int(n_edges) // half + 2) + rp[rs] // half
+            first = torch.ones_like(key, dtype=torch.bool)
+            first[1:] = key[1:] != key[:-1]
+            gi = torch.nonzero(first).flatten()                       # index into rs of every group's first row
+            last = torch.cat([gi[1:] - 1, torch.tensor([rs.numel() - 1], device=dev)])
+            e0, e1 = rp[rs[gi]], rp[rs[last] + 1]
+            lists.append(torch.stack([e0, e1, torch.full_like(e0, -1), torch.zeros_like(e0)], 1))
+        rb = rows[big]
+        fix = torch.zeros(0, 4, dtype=torch.int32, device=dev)
+        n_slots = 0
+        if rb.numel():
+            nsl = (deg[rb] + G - 1) // G
+            split = nsl > 1
+            slot0 = torch.cumsum(torch.where(split, nsl, torch.zeros_like(nsl)), 0) - torch.where(split, nsl, torch.zeros_like(nsl))
+            n_slots = int(torch.where(split, nsl, torch.zeros_like(nsl)).sum())
+            rep = torch.repeat_interleave(torch.arange(rb.numel(), device=dev), nsl)
+            kk = torch.arange(rep.numel(), device=dev) - torch.repeat_interleave(torch.cumsum(nsl, 0) - nsl, nsl)
+            e0 = rp[rb][rep] + kk * G
+            e1 = torch.minimum(e0 + G, rp[rb + 1][rep])
+            slot = torch.where(split[rep], slot0[rep] + kk, torch.full_like(kk, -1))
+            lists.append(torch.stack([e0, e1, slot, torch.zeros_like(e0)], 1))
+            fr = rb[split]
+            fix = torch.stack([fr, slot0[split], nsl[split], torch.zeros_like(fr)], 1).to(torch.int32).contiguous()
+        if lists:
+            sit = torch.cat(lists)
+            sit = sit[torch.sort(sit[:, 0], stable=True)[1]].to(torch.int32).contiguous()
+        else:
+            sit = torch.zeros(0, 4, dtype=torch.int32, device=dev)
+        pad = torch.zeros(1, 4, dtype=torch.int32, device=dev)
+        return LdsOrder(sit if sit.numel() else pad, int(sit.shape[0]), erow if erow.numel() else torch.zeros(1, dtype=torch.int32, device=dev),
+                        empty if empty.numel() else torch.zeros(1, dtype=torch.int32, device=dev), int(empty.numel()),
+                        fix if fix.numel() else pad, int(fix.shape[0]), n_slots, n_rows, int(G))
+
+
 K1_LDS = _os.environ.get('GV_K1_LDS', 'auto')               # LDS-resident relation weights: 'auto' | '0'
 K1_LDS_WORKGROUPS = int(_os.environ.get('GV_K1_LDS_WGS', '0'))      # 0: one workgroup per CU
+K1_LDS_G = int(_os.environ.get('GV_K1_LDS_G', '64'))                # most edges of a super-item (the kernel takes up to 64)
 _LDS_PLANS = {}
+LDS_MIN_EDGES = 100_000     # its work lists are built with one host read-back: graphs that are rebuilt every step (mini-batches,
+#                             indexed sync-free) stay on the per-row kernels below this size
+
+
+def lds_graph(gidx):
+    return (not gidx.sync_free) or gidx.num_edges >= LDS_MIN_EDGES
+
 
 
 def lds_plan(num_rels, num_bases, blk_in, blk_out):
@@ -682,7 +757,7 @@ def lds_plan(num_rels, num_bases, blk_in, blk_out):
     if key not in _LDS_PLANS:
         plan = (_ct.c_int32 * 3)()
         ok = lib.load().gv_rgcn_bdd_lds_plan(key[1], key[2], key[3], key[0], _ct.addressof(plan))
-        _LDS_PLANS[key] = tuple(int(v) for v in plan) if ok else None
+        _LDS_PLANS[key] = (int(plan[0]), int(plan[1]), max(4, min(int(plan[2]), K1_LDS_G))) if ok else None
     return _LDS_PLANS[key]
 
 
@@ -694,18 +769,21 @@ def pack_weight_lds(weight, num_bases, blk_in, blk_out, transpose_w, plan):
     return packed
 
 
-def bdd_aggregate_lds(seg: SegmentItems, nbr, etype, coef, coef_idx, feat, weight_packed, num_rels, num_bases, blk_in, blk_out,
+def bdd_aggregate_lds(order: LdsOrder, nbr, etype, coef, coef_idx, feat, weight_packed, num_rels, num_bases, blk_in, blk_out,
                       transpose_w=False, addend=None, act=ACT_NONE, keep=None, keep_scale=1.0, out=None):
-    """gv_rgcn_bdd_aggregate_lds: K1 with every relation's block weights resident in LDS (``weight_packed``:
-    pack_weight_lds).  Same lists, formula and epilogue as ``bdd_aggregate``; ``transpose_w`` only names the launch."""
+    """gv_rgcn_bdd_aggregate_lds: K1 with every relation's block weights resident in LDS (``order``: GraphIndex.lds_order,
+    ``weight_packed``: pack_weight_lds).  Same formula and epilogue as ``bdd_aggregate``; ``transpose_w`` only names the
+    launch (the packing holds the orientation)."""
     feat, ld_feat = _row_major(feat, 'feat')
-    n_seg = seg.rowptr.numel() - 1
+    n_seg = order.n_rows
     out_dim = num_bases * blk_out
     if feat.shape[1] != num_bases * blk_in:
         raise ValueError(f'feat has {feat.shape[1]} columns, expected num_bases*blk_in = {num_bases * blk_in}')
     plan = lds_plan(num_rels, num_bases, blk_in, blk_out)
     if plan is None or weight_packed.numel() != plan[1]:
         raise ValueError('weight_packed does not have the size the LDS plan asks for (or no plan for this shape)')
+    if order.max_edges > plan[2]:
+        raise ValueError(f'super-items of up to {order.max_edges} edges, the kernel takes {plan[2]}')
     if out is None:
         out = torch.empty(n_seg, out_dim, dtype=torch.float32, device=feat.device)
     ld_add = 0
@@ -719,17 +797,16 @@ def bdd_aggregate_lds(seg: SegmentItems, nbr, etype, coef, coef_idx, feat, weigh
             raise ValueError('keep shape mismatch')
     if coef is not None:
         coef = _chk(coef.reshape(-1), name='coef')
-    _check_items(seg)
-    partial = torch.empty(seg.n_slots, out_dim, dtype=torch.float32, device=feat.device) if seg.n_fix > 0 else None
+    partial = torch.empty(order.n_slots, out_dim, dtype=torch.float32, device=feat.device) if order.n_fix > 0 else None
     ld_out = out.stride(0) if n_seg > 1 else out_dim
     tag = f'agg_{"T" if transpose_w else "N"}_{blk_in}x{blk_out}_nb{num_bases}'
     timed = lib.TIMER is not None
-    lib.call('gv_rgcn_bdd_aggregate_lds', ptr(seg.items), seg.n_items, ptr(seg.fix), 0 if timed else seg.n_fix, ptr(nbr),
-             ptr(etype), ptr(coef), ptr(coef_idx), ptr(feat), ld_feat, ptr(weight_packed), num_rels, num_bases, blk_in, blk_out,
-             ptr(addend), ld_add, act, ptr(keep), float(keep_scale), ptr(out), ld_out, ptr(partial), K1_LDS_WORKGROUPS,
-             lib.stream(), tag=tag)
-    if timed and seg.n_fix > 0:
-        lib.call('gv_rgcn_bdd_fixup', ptr(seg.fix), seg.n_fix, ptr(partial), out_dim, ptr(addend), ld_add, act, ptr(keep),
+    lib.call('gv_rgcn_bdd_aggregate_lds', ptr(order.sitems), order.n_sitems, ptr(order.erow), ptr(order.empty), order.n_empty,
+             ptr(order.fix), 0 if timed else order.n_fix, ptr(nbr), ptr(etype), ptr(coef), ptr(coef_idx), ptr(feat), ld_feat,
+             ptr(weight_packed), num_rels, num_bases, blk_in, blk_out, ptr(addend), ld_add, act, ptr(keep), float(keep_scale),
+             ptr(out), ld_out, ptr(partial), K1_LDS_WORKGROUPS, lib.stream(), tag=tag)
+    if timed and order.n_fix > 0:
+        lib.call('gv_rgcn_bdd_fixup', ptr(order.fix), order.n_fix, ptr(partial), out_dim, ptr(addend), ld_add, act, ptr(keep),
                  float(keep_scale), ptr(out), ld_out, lib.stream())
     return out
 
@@ -1254,9 +1331,9 @@ class _RelGraphConvBdd(torch.autograd.Function):
             return None
 
         ctx.grouped = not ctx.tiles and reduce_hook is None and use_relation_groups(weight, gidx)
-        lp = None if (ctx.tiles or ctx.grouped or reduce_hook is not None) else lds_plan(weight.shape[0], num_bases, si, so)
+        lp = lds_plan(weight.shape[0], num_bases, si, so) if (not ctx.tiles and not ctx.grouped and reduce_hook is None and lds_graph(gidx)) else None
         if lp is not None:       # few relation types: the whole table resident in LDS (csrc/k_lds.hip)
-            out = bdd_aggregate_lds(gidx.lds_seg('dst', lp[2]), gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x,
+            out = bdd_aggregate_lds(gidx.lds_order('dst', lp[2]), gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x,
                                     pack_weight_lds(weight, num_bases, si, so, False, lp), weight.shape[0], num_bases, si, so,
                                     False, self_loop_term(), act, keep, keep_scale)
         elif ctx.tiles:
@@ -1343,12 +1420,12 @@ class _RelGraphConvBdd(torch.autograd.Function):
             grad_x = bdd_aggregate_phases(tl, None if coef is None else tl.coef(coef), g_agg,
                                           pack_weight_phase(tl, weight, nb, so, si), weight.shape[0], nb, so, si, gx_loop,
                                           out=x_tgt)
-        elif ctx.needs_input_grad[0] and not ctx.grouped and reduce_hook is None and \
+        elif ctx.needs_input_grad[0] and not ctx.grouped and reduce_hook is None and lds_graph(gidx) and \
                 lds_plan(weight.shape[0], nb, so, si) is not None:
             lp = lds_plan(weight.shape[0], nb, so, si)
             static = not gidx.sync_free and coef is not None
             coef_s, idx_s = (gidx.coef_in_src_order(coef), None) if static else (coef, gidx.by_src.perm)
-            grad_x = bdd_aggregate_lds(gidx.lds_seg('src', lp[2]), gidx.nbr_by_src, ridx.et_by_src, coef_s, idx_s, g_agg,
+            grad_x = bdd_aggregate_lds(gidx.lds_order('src', lp[2]), gidx.nbr_by_src, ridx.et_by_src, coef_s, idx_s, g_agg,
                                        pack_weight_lds(weight, nb, so, si, True, lp), weight.shape[0], nb, so, si, True,
                                        gx_loop, out=x_tgt)
         elif ctx.needs_input_grad[0]:

@@ -122,27 +122,35 @@ int gv_rgcn_bdd_aggregate_phases(const int32_t* off, const int32_t* nbr, const i
                                  int block_threads, const float* addend, int ld_addend, int act, const uint8_t* keep,
                                  float keep_scale, float* out, int ld_out, float* partial, void* stream);
 
-/* K1 with ALL relation weights RESIDENT IN LDS (same contract, work-item lists and epilogue as gv_rgcn_bdd_aggregate; call
- * sites kgvae/model.py:54-59 at BASELINE configs[2]'s shape: R = 22 directed types, num_bases = 20 -> 10x10 / 10x20 / 20x10
- * blocks).  With few relation types a column part of the whole table fits a CU's LDS (88 kB at that shape): one 1 024-thread
- * workgroup per CU copies it once and then walks work items in a wave-strided order; per edge the part's piece of the feature
- * row is loaded once (coalesced, no duplicates), parked in a wave-private LDS ring, and the block weights come from LDS by
- * conflict-free ds_read_b128 instead of 8-16 kB per edge through the L1 -> VGPR path.  Same fma chains as the per-row kernels:
- * results are bit-identical for the same work-item lists.
- *   gv_rgcn_bdd_lds_plan    1 when an instantiation exists AND the table fits (HOST pointer, may be NULL):
- *                           plan[3] = {column parts, floats of weight_packed, preferred work-item chunk in edges}
- *   blk_in / blk_out        gathered / produced block width; for the backward-x launch (blk_out_fwd, blk_in_fwd) and
- *                           transpose_w = 1 in the pack call (the stored block is then blk_out x blk_in, read transposed)
- *   weight_packed           gv_rgcn_bdd_pack_weight_lds(weight): [parts][R][NQ][LANES] float4 (+ 64 float4 of slack)
- *   max_workgroups          0 = one per CU; the grid is (max_workgroups / parts, parts) */
+/* K1 with ALL relation weights RESIDENT IN LDS (same formula and epilogue as gv_rgcn_bdd_aggregate; call sites
+ * kgvae/model.py:54-59 at BASELINE configs[2]'s shape: R = 22 directed types, num_bases = 20 -> 10x10 / 10x20 / 20x10 blocks).
+ * With few relation types a column part of the whole table fits a CU's LDS (88 kB at that shape): one 1 024-thread workgroup
+ * per CU copies it once; the block weights then come from LDS by conflict-free ds_read_b128 instead of 8-16 kB per edge through
+ * the L1 -> VGPR path.  The unit of work is a SUPER-ITEM: a run of consecutive rows with <= plan[2] edges in all, or a slice
+ * of <= plan[2] edges of a longer (hub) row -- its edge metadata is one coalesced fetch, its rows cost an epilogue each.
+ *   sitems      int32 [n_sitems][4] = {first edge position, end position, partial slot (-1: whole rows), 0}; positions index
+ *               nbr / etype / erow (edges ordered by row); a hub row's slices carry consecutive partial slots
+ *   erow        int32 [E]  row of every edge position
+ *   empty_rows  int32 [n_empty]  rows without edges (their output is the epilogue of a zero aggregate)
+ *   fix         int32 [n_fix][4] = {row, first partial slot, slices, 0} for the hub rows (summed in slot order by the fix-up
+ *               pass, which applies the epilogue); partial: [slots][num_bases*blk_out] workspace
+ *   coef / coef_idx   edge coefficient by position (or through coef_idx), as in gv_rgcn_bdd_aggregate
+ *   blk_in / blk_out  gathered / produced block width; for the backward-x launch (blk_out_fwd, blk_in_fwd) and
+ *               transpose_w = 1 in the pack call (the stored block is then blk_out x blk_in, read transposed)
+ *   weight_packed     gv_rgcn_bdd_pack_weight_lds(weight): [parts][R][NQ][CL] float4 (+ 64 float4 of slack)
+ *   max_workgroups    0 = one per CU; the grid is (max_workgroups / parts, parts)
+ * gv_rgcn_bdd_lds_plan returns 1 when an instantiation exists AND the table fits (HOST pointer, may be NULL):
+ *   plan[3] = {column parts, floats of weight_packed, most edges of a super-item}.
+ * Every row is summed by one wave in a fixed order (bitwise reproducible); the order differs from gv_rgcn_bdd_aggregate's. */
 int gv_rgcn_bdd_lds_plan(int num_bases, int blk_in, int blk_out, int num_rels, int32_t* plan_host);
 int gv_rgcn_bdd_pack_weight_lds(const float* weight, int num_rels, int num_bases, int blk_in, int blk_out, int transpose_w,
                                 float* packed, void* stream);
-int gv_rgcn_bdd_aggregate_lds(const int32_t* items, int n_items, const int32_t* fix, int n_fix, const int32_t* nbr,
-                              const int32_t* etype, const float* coef, const int32_t* coef_idx, const float* feat, int ld_feat,
-                              const float* weight_packed, int num_rels, int num_bases, int blk_in, int blk_out,
-                              const float* addend, int ld_addend, int act, const uint8_t* keep, float keep_scale, float* out,
-                              int ld_out, float* partial, int max_workgroups, void* stream);
+int gv_rgcn_bdd_aggregate_lds(const int32_t* sitems, int n_sitems, const int32_t* erow, const int32_t* empty_rows, int n_empty,
+                              const int32_t* fix, int n_fix, const int32_t* nbr, const int32_t* etype, const float* coef,
+                              const int32_t* coef_idx, const float* feat, int ld_feat, const float* weight_packed,
+                              int num_rels, int num_bases, int blk_in, int blk_out, const float* addend, int ld_addend, int act,
+                              const uint8_t* keep, float keep_scale, float* out, int ld_out, float* partial,
+                              int max_workgroups, void* stream);
 
 /* The fix-up pass of gv_rgcn_bdd_aggregate on its own (a caller that passed n_fix = 0 there, e.g. to
  * time the aggregation kernel alone, finishes the split rows with this). */

@@ -24,7 +24,7 @@ def main(probe):
     ridx = ops.RelationIndex(gidx, torch.from_numpy(rel).cuda(), R)
     norm = torch.from_numpy(node_norm).cuda()[dst.cuda()].contiguous()
     norm_s = norm[gidx.by_src.perm.long()].contiguous()
-    chunks = [int(c) for c in os.environ.get('LB_CHUNKS', '64').split(',')]
+    chunks = [int(c) for c in os.environ.get('LB_CHUNKS', '64').split(',')]      # most edges of a super-item
     for fin, fout in ((200, 200), (200, 400)):
         si, so = fin // nb, fout // nb
         x = torch.randn(N, fin, device='cuda')
@@ -41,7 +41,7 @@ def main(probe):
         t = timeit(lambda: ops.bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, norm_s, None, gg, w, nb, so, si, True))
         print(f'{so}x{si} bwd-x per-row kernels (chunk 256): {t:7.1f} us  {by_b / t / 1e3:7.1f} GB/s')
         for chunk in chunks:
-            sd, ss = gidx.lds_seg('dst', chunk), gidx.lds_seg('src', chunk)
+            sd, ss = gidx.lds_order('dst', chunk), gidx.lds_order('src', chunk)
             variants = [('as is', gidx.nbr_by_dst, ridx.et_by_dst, gidx.nbr_by_src, ridx.et_by_src)]
             if probe:
                 z = torch.zeros_like
@@ -50,7 +50,7 @@ def main(probe):
             for tag, nd, ed, ns, es in variants:
                 tf = timeit(lambda: ops.bdd_aggregate_lds(sd, nd, ed, norm, None, x, wf, R, nb, si, so, False, pre, 1, keep, 1.25))
                 tb = timeit(lambda: ops.bdd_aggregate_lds(ss, ns, es, norm_s, None, gg, wb, R, nb, so, si, True))
-                print(f'{si}x{so} LDS-resident chunk {chunk:3d} [{tag:13s}] items {sd.n_items}/{ss.n_items} split rows {sd.n_fix}/{ss.n_fix}: '
+                print(f'{si}x{so} LDS-resident <= {chunk:3d} edges [{tag:13s}] super-items {sd.n_sitems}/{ss.n_sitems} split rows {sd.n_fix}/{ss.n_fix} empty {sd.n_empty}/{ss.n_empty}: '
                       f'fwd {tf:6.1f} us {by_f / tf / 1e3:7.1f} GB/s   bwd-x {tb:6.1f} us {by_b / tb / 1e3:7.1f} GB/s')
         tp = timeit(lambda: ops.pack_weight_lds(w, nb, si, so, False, pf))
         print(f'pack W {si}x{so}: {tp:5.1f} us')
