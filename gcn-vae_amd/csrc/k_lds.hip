@@ -79,18 +79,21 @@ template <int N> struct XVec { typedef float type __attribute__((ext_vector_type
 // P = gathered block width, Q = output block width, IPL = inputs per lane (P / IPL = 5 input groups per block), OH = lanes
 // sharing a block's outputs (each Q / OH of them), BPP = diagonal blocks per column part, U = edges per step.
 // Lane layout: slot = block * OH + half (<= 12 slots), three slots per 16-lane DPP row, lane = 16 * (slot / 3) + 5 * (slot % 3) + g.
-template <int P, int Q, int IPL, int OH, int BPP, int U>
+template <int P, int Q, int IPL, int OH, int BPP, int U, int KB, bool BF>
 __global__ __launch_bounds__(1024) void k_agg_lds(const LdsAggParams a) {
-    constexpr int NIG = P / IPL, OPL = Q / OH, NW = IPL * OPL, NQ = NW / 4, SLOTS = BPP * OH;
+    // BF: bf16 operands, fp32 accumulate (BASELINE configs[2]'s precision): the table holds bf16 PAIRS (the weights of two
+    // adjacent inputs into one output), an edge's inputs are scaled by its coefficient in fp32, rounded to bf16 pairs
+    // (v_cvt_pk_bf16_f32, nearest even) and fed to v_dot2c_f32_bf16 -- half the LDS bytes per product, so twice the output
+    // columns per part; feature rows and sums stay fp32 in memory.
+    constexpr int NIG = P / IPL, OPL = Q / OH, NW = BF ? (IPL / 2) * OPL : IPL * OPL, NQ = (NW + 3) / 4, SLOTS = BPP * OH;
     // the weight table is indexed by LANE (lane-consecutive 16-B quads: conflict-free ds_read_b128), CL = lanes up to the last slot's
     constexpr int CL = 16 * ((SLOTS - 1) / 3) + 5 * ((SLOTS - 1) % 3) + NIG;
     constexpr int PO = BPP * Q;                            // output columns of a part
-    constexpr int EW = (PO % 100 == 0) ? 2 : 1, EL = PO / EW;      // epilogue: EL lanes x EW columns
-    constexpr int XN = U * IPL;
-    constexpr int KB = 8;                                  // finished rows parked per wave before their epilogue
-    static_assert(NIG == 5 && P % IPL == 0 && Q % OH == 0 && NW % 4 == 0 && SLOTS <= 12 && EL <= 64 && PO % EW == 0, "lane mapping");
+    constexpr int EW = PO / 50, EL = PO / EW;              // epilogue: 50 lanes x EW columns (1, 2 or 4)
+    constexpr int XN = U * IPL;                            // KB: finished rows parked per wave before their epilogue
+    static_assert(NIG == 5 && P % IPL == 0 && Q % OH == 0 && (BF || NW % 4 == 0) && SLOTS <= 12 && PO % 50 == 0 && (EW == 1 || EW == 2 || EW == 4), "lane mapping");
+    static_assert(KB >= U + 2, "room for the rows one step can complete");
     static_assert(IPL == 2 || IPL == 4, "a lane's inputs are one 8- or 16-B load");
-    static_assert(XN == 8 || XN == 16, "the pieces of a step are one indexable register vector");
     typedef typename XVec<XN>::type xvec;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     const int lane = threadIdx.x & 63;
@@ -148,7 +151,8 @@ __global__ __launch_bounds__(1024) void k_agg_lds(const LdsAggParams a) {
         const size_t r = (size_t)(unsigned)max(row, 0);
         load_vec<EW>(add_base + r * add_ld, e.ad);
         const uint8_t* kp = keep_base + r * keep_ld;
-        if constexpr (EW == 2) e.kp = *reinterpret_cast<const uint16_t*>(kp);
+        if constexpr (EW == 4) e.kp = *reinterpret_cast<const uint32_t*>(kp);
+        else if constexpr (EW == 2) e.kp = *reinterpret_cast<const uint16_t*>(kp);
         else e.kp = *kp;
         return e;
     };
@@ -273,17 +277,33 @@ __global__ __launch_bounds__(1024) void k_agg_lds(const LdsAggParams a) {
             const int rel = lrl_i(mA.t, p);
             const float c = lrl_f(mA.c, p);
             const float4* wq = wl + (size_t)rel * (NQ * CL);
-            float wr[NW];
+            float wr[NQ * 4];
 #pragma unroll
             for (int q4 = 0; q4 < NQ; ++q4) {
                 const float4 t = wq[q4 * CL];
                 wr[4 * q4] = t.x; wr[4 * q4 + 1] = t.y; wr[4 * q4 + 2] = t.z; wr[4 * q4 + 3] = t.w;
             }
+            if constexpr (BF) {
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int i = 0; i < IPL; ++i) {
-                const float xs = xc[u * IPL + i] * c;
+                for (int k2 = 0; k2 < IPL / 2; ++k2) {
+                    const f32x2 xs = {xc[u * IPL + 2 * k2] * c, xc[u * IPL + 2 * k2 + 1] * c};
+                    const bf16x2 xp = __builtin_convertvector(xs, bf16x2);
 #pragma unroll
-                for (int o = 0; o < OPL; ++o) acc[o] = fmaf(xs, wr[i * OPL + o], acc[o]);
+                    for (int o = 0; o < OPL; ++o) {
+                        bf16x2 wp;
+                        __builtin_memcpy(&wp, &wr[k2 * OPL + o], 4);
+                        acc[o] = __builtin_amdgcn_fdot2_f32_bf16(xp, wp, acc[o], false);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < IPL; ++i) {
+                    const float xs = xc[u * IPL + i] * c;
+#pragma unroll
+                    for (int o = 0; o < OPL; ++o) acc[o] = fmaf(xs, wr[i * OPL + o], acc[o]);
+                }
             }
         }
         j += U;
@@ -346,9 +366,19 @@ __global__ __launch_bounds__(1024) void k_agg_lds(const LdsAggParams a) {
 // part*BPP + slot / OH, its inputs g*IPL .. and its outputs half*OPL .. (half = slot % OH); its list is input-major: element
 // i*OPL + o multiplies input g*IPL + i into output half*OPL + o.  Stored block: P x Q row-major for the plain product,
 // Q x P (read transposed) for transpose_w.
+__device__ __forceinline__ unsigned bf16_bits_rne(float f) {       // round to nearest even, as torch's .to(bfloat16) and v_cvt_pk_bf16_f32
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {f, 0.f};
+    const bf16x2 b = __builtin_convertvector(v, bf16x2);
+    unsigned u;
+    __builtin_memcpy(&u, &b, 4);
+    return u & 0xffffu;
+}
+
 __global__ __launch_bounds__(256) void k_pack_weight_lds(const float* __restrict__ w, float4* __restrict__ out, int num_rels,
-                                                         int nb, int P, int Q, int IPL, int OH, int BPP, int CL, int trans) {
-    const int OPL = Q / OH, NQ = IPL * OPL / 4, NIG = P / IPL, SLOTS = BPP * OH, parts = nb / BPP;
+                                                         int nb, int P, int Q, int IPL, int OH, int BPP, int CL, int trans, int bf) {
+    const int OPL = Q / OH, NW = bf ? (IPL / 2) * OPL : IPL * OPL, NQ = (NW + 3) / 4, NIG = P / IPL, SLOTS = BPP * OH, parts = nb / BPP;
     const size_t total = (size_t)parts * num_rels * NQ * CL;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int lane = (int)(idx % CL);
@@ -363,8 +393,17 @@ __global__ __launch_bounds__(256) void k_pack_weight_lds(const float* __restrict
             const float* wb = w + ((size_t)r * nb + blk) * (P * Q);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int e = 4 * jq + c, i = e / OPL, o = e % OPL, in = g * IPL + i, col = half * OPL + o;
-                e4[c] = trans ? wb[col * P + in] : wb[in * Q + col];
+                const int e = 4 * jq + c;
+                if (e >= NW) continue;
+                if (bf) {                               // dword e = (input pair k2, output o): inputs g*IPL + 2 k2 (low half), + 1
+                    const int k2 = e / OPL, o = e % OPL, in = g * IPL + 2 * k2, col = half * OPL + o;
+                    const float lo = trans ? wb[col * P + in] : wb[in * Q + col];
+                    const float hi = trans ? wb[col * P + in + 1] : wb[(in + 1) * Q + col];
+                    e4[c] = __uint_as_float(bf16_bits_rne(lo) | (bf16_bits_rne(hi) << 16));
+                } else {
+                    const int i = e / OPL, o = e % OPL, in = g * IPL + i, col = half * OPL + o;
+                    e4[c] = trans ? wb[col * P + in] : wb[in * Q + col];
+                }
             }
         }
         out[idx] = make_float4(e4[0], e4[1], e4[2], e4[3]);
@@ -372,26 +411,33 @@ __global__ __launch_bounds__(256) void k_pack_weight_lds(const float* __restrict
 }
 
 namespace {
-struct LdsPlan { int ipl, oh, bpp, parts, cl, nq, u, po; };
+struct LdsPlan { int ipl, oh, bpp, parts, cl, nq, u, kb, po; };
 constexpr int LDS_WAVES = 16;
 constexpr int LDS_BUDGET = 160 * 1024;
 constexpr int LDS_SITEM_EDGES = 64;
-constexpr int LDS_ROWBUF = 8;          // = KB of k_agg_lds
 
-// instantiated shapes (gathered block width, output block width); transpose_w only changes the packing
-bool lds_plan(int nb, int p, int q, int num_rels, LdsPlan* out) {
-    int ipl = 0, oh = 0, bpp = 0, u = 4;
-    if (p == 10 && q == 10) { ipl = 2; oh = 1; bpp = 10; }
-    else if (p == 10 && q == 20) { ipl = 2; oh = 2; bpp = 5; }
-    else if (p == 20 && q == 10) { ipl = 4; oh = 2; bpp = 5; }
-    else return false;
+// instantiated shapes (gathered block width, output block width, bf16 operands); transpose_w only changes the packing
+bool lds_plan(int nb, int p, int q, int num_rels, bool bf, LdsPlan* out) {
+    int ipl = 0, oh = 0, bpp = 0, u = 4, kb = 8;
+    if (!bf) {
+        if (p == 10 && q == 10) { ipl = 2; oh = 1; bpp = 10; }
+        else if (p == 10 && q == 20) { ipl = 2; oh = 2; bpp = 5; }
+        else if (p == 20 && q == 10) { ipl = 4; oh = 2; bpp = 5; }
+        else return false;
+    } else {      // half the LDS bytes per product: twice the output columns per part where the lanes allow
+        if (p == 10 && q == 10) { ipl = 2; oh = 1; bpp = 10; }
+        else if (p == 10 && q == 20) { ipl = 2; oh = 1; bpp = 10; u = 3; kb = 5; }
+        else if (p == 20 && q == 10) { ipl = 4; oh = 1; bpp = 10; }
+        else return false;
+    }
     if (nb % bpp) return false;
     const int slots = bpp * oh, cl = 16 * ((slots - 1) / 3) + 5 * ((slots - 1) % 3) + p / ipl;      // table columns = lanes
-    const int nq = ipl * (q / oh) / 4, po = bpp * q;
+    const int opl = q / oh, nw = bf ? (ipl / 2) * opl : ipl * opl, nq = (nw + 3) / 4, po = bpp * q;
     const size_t tq = (size_t)num_rels * nq * cl;
-    const size_t lds = ((tq + 63) & ~(size_t)63) * 16 + (size_t)LDS_WAVES * LDS_ROWBUF * po * 4 + 16;
+    const size_t lds = ((tq + 63) & ~(size_t)63) * 16 + (size_t)LDS_WAVES * kb * po * 4 + 16;
     if (lds > (size_t)LDS_BUDGET) return false;
-    out->ipl = ipl; out->oh = oh; out->bpp = bpp; out->parts = nb / bpp; out->cl = cl; out->nq = nq; out->u = u; out->po = po;
+    out->ipl = ipl; out->oh = oh; out->bpp = bpp; out->parts = nb / bpp; out->cl = cl; out->nq = nq; out->u = u; out->kb = kb;
+    out->po = po;
     return true;
 }
 }  // namespace
@@ -400,10 +446,11 @@ bool lds_plan(int nb, int p, int q, int num_rels, LdsPlan* out) {
 
 using namespace gv;
 
-extern "C" int gv_rgcn_bdd_lds_plan(int num_bases, int blk_in, int blk_out, int num_rels, int32_t* plan_host /*[3]*/) {
+extern "C" int gv_rgcn_bdd_lds_plan(int num_bases, int blk_in, int blk_out, int num_rels, int bf16_operands,
+                                    int32_t* plan_host /*[3]*/) {
     LdsPlan pl;
     if (num_bases <= 0 || blk_in <= 0 || blk_out <= 0 || num_rels <= 0) return 0;
-    if (!lds_plan(num_bases, blk_in, blk_out, num_rels, &pl)) return 0;
+    if (!lds_plan(num_bases, blk_in, blk_out, num_rels, bf16_operands != 0, &pl)) return 0;
     if (plan_host) {
         plan_host[0] = pl.parts;
         plan_host[1] = pl.parts * num_rels * pl.nq * pl.cl * 4 + 64 * 4;      /* floats of the packed weight buffer */
@@ -413,17 +460,17 @@ extern "C" int gv_rgcn_bdd_lds_plan(int num_bases, int blk_in, int blk_out, int 
 }
 
 extern "C" int gv_rgcn_bdd_pack_weight_lds(const float* weight, int num_rels, int num_bases, int blk_in, int blk_out,
-                                           int transpose_w, float* packed, void* stream) {
+                                           int transpose_w, int bf16_operands, float* packed, void* stream) {
     GV_REQUIRE(weight && packed, GV_ERR_NULL, "gv_rgcn_bdd_pack_weight_lds: NULL pointer");
     LdsPlan pl;
-    GV_REQUIRE(num_bases > 0 && num_rels > 0 && lds_plan(num_bases, blk_in, blk_out, num_rels, &pl), GV_ERR_SHAPE,
-               "gv_rgcn_bdd_pack_weight_lds: no LDS-resident kernel for num_bases=%d blocks %dx%d with %d relations", num_bases,
-               blk_in, blk_out, num_rels);
+    GV_REQUIRE(num_bases > 0 && num_rels > 0 && lds_plan(num_bases, blk_in, blk_out, num_rels, bf16_operands != 0, &pl),
+               GV_ERR_SHAPE, "gv_rgcn_bdd_pack_weight_lds: no LDS-resident kernel for num_bases=%d blocks %dx%d with %d relations",
+               num_bases, blk_in, blk_out, num_rels);
     GV_REQUIRE(aligned16(packed), GV_ERR_ALIGN, "gv_rgcn_bdd_pack_weight_lds: 16-B alignment required");
     const size_t total = (size_t)pl.parts * num_rels * pl.nq * pl.cl;
     hipLaunchKernelGGL(k_pack_weight_lds, dim3((unsigned)min((size_t)2048, (total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, weight, (float4*)packed, num_rels, num_bases, blk_in, blk_out, pl.ipl, pl.oh, pl.bpp,
-                       pl.cl, transpose_w ? 1 : 0);
+                       pl.cl, transpose_w ? 1 : 0, bf16_operands ? 1 : 0);
     return launch_status("gv_rgcn_bdd_pack_weight_lds");
 }
 
@@ -431,25 +478,28 @@ extern "C" int gv_rgcn_bdd_aggregate_lds(const int32_t* sitems, int n_sitems, co
                                          int n_empty, const int32_t* fix, int n_fix, const int32_t* nbr, const int32_t* etype,
                                          const float* coef, const int32_t* coef_idx, const float* feat, int ld_feat,
                                          const float* weight_packed, int num_rels, int num_bases, int blk_in, int blk_out,
-                                         const float* addend, int ld_addend, int act, const uint8_t* keep, float keep_scale,
-                                         float* out, int ld_out, float* partial, int max_workgroups, void* stream) {
+                                         int bf16_operands, const float* addend, int ld_addend, int act, const uint8_t* keep,
+                                         float keep_scale, float* out, int ld_out, float* partial, int max_workgroups,
+                                         void* stream) {
     GV_REQUIRE(n_sitems >= 0 && n_fix >= 0 && n_empty >= 0, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate_lds: negative count");
     if (n_sitems == 0 && n_empty == 0) return GV_OK;
     GV_REQUIRE(feat && weight_packed && out && (n_sitems == 0 || (sitems && erow && nbr && etype)) && (n_empty == 0 || empty_rows),
                GV_ERR_NULL, "gv_rgcn_bdd_aggregate_lds: NULL pointer");
     GV_REQUIRE(n_fix == 0 || (fix && partial), GV_ERR_NULL, "gv_rgcn_bdd_aggregate_lds: split rows need fix+partial");
     GV_REQUIRE(act == GV_ACT_NONE || act == GV_ACT_RELU, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate_lds: unknown act %d", act);
+    const bool bf = bf16_operands != 0;
     LdsPlan pl;
-    GV_REQUIRE(num_bases > 0 && num_rels > 0 && lds_plan(num_bases, blk_in, blk_out, num_rels, &pl), GV_ERR_SHAPE,
+    GV_REQUIRE(num_bases > 0 && num_rels > 0 && lds_plan(num_bases, blk_in, blk_out, num_rels, bf, &pl), GV_ERR_SHAPE,
                "gv_rgcn_bdd_aggregate_lds: no LDS-resident kernel for num_bases=%d blocks %dx%d with %d relations", num_bases,
                blk_in, blk_out, num_rels);
     GV_REQUIRE(ld_feat >= num_bases * blk_in && ld_out >= num_bases * blk_out, GV_ERR_SHAPE,
                "gv_rgcn_bdd_aggregate_lds: leading dimension smaller than the row");
     const int out_dim = num_bases * blk_out;
     // 8- / 16-B pieces of the feature rows, 8- or 4-B stores: row bases 16-B aligned, leading dimensions multiples of 4 / 2
-    const bool al_ok = aligned16(feat) && aligned16(weight_packed) && aligned16(out) && ld_feat % 4 == 0 && ld_out % 2 == 0 &&
-                       (!addend || (aligned16(addend) && ld_addend % 2 == 0)) && (!partial || aligned16(partial)) &&
-                       out_dim % 2 == 0;
+    const int ew = pl.po / 50 >= 2 ? pl.po / 50 : 2;      // widest epilogue access in floats
+    const bool al_ok = aligned16(feat) && aligned16(weight_packed) && aligned16(out) && ld_feat % 4 == 0 && ld_out % ew == 0 &&
+                       (!addend || (aligned16(addend) && ld_addend % ew == 0)) && (!partial || aligned16(partial)) &&
+                       out_dim % ew == 0;
     GV_REQUIRE(al_ok, GV_ERR_ALIGN, "gv_rgcn_bdd_aggregate_lds: rows must be 16-B aligned");
     LdsAggParams a;
     a.sitems = (const int4*)sitems; a.n_sitems = n_sitems; a.erow = erow; a.empty = empty_rows; a.n_empty = n_empty;
@@ -461,8 +511,8 @@ extern "C" int gv_rgcn_bdd_aggregate_lds(const int32_t* sitems, int n_sitems, co
     a.debug = dbg;
     hipStream_t st = (hipStream_t)stream;
     const size_t tq = (size_t)num_rels * pl.nq * pl.cl;
-    const size_t lds = ((tq + 63) & ~(size_t)63) * 16 + (size_t)LDS_WAVES * LDS_ROWBUF * pl.po * 4 + 16;
-    // one workgroup per CU over all column parts; never more workgroups than 16-wave shares of the two lists
+    const size_t lds = ((tq + 63) & ~(size_t)63) * 16 + (size_t)LDS_WAVES * pl.kb * pl.po * 4 + 16;
+    // one workgroup per CU over all column parts (its waves share a counter that deals out the workgroup's super-items)
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0, v = 0;
@@ -479,9 +529,10 @@ extern "C" int gv_rgcn_bdd_aggregate_lds(const int32_t* sitems, int n_sitems, co
     if (wgs < 1) wgs = 1;
     const dim3 grid(wgs, pl.parts), block(64 * LDS_WAVES);
     int rc = -1000;
-#define GV_LDS_CASE(P_, Q_, IPL_, OH_, BPP_, U_)                                                                        \
-    if (rc == -1000 && blk_in == P_ && blk_out == Q_ && pl.ipl == IPL_ && pl.oh == OH_ && pl.bpp == BPP_ && pl.u == U_) { \
-        auto kern = k_agg_lds<P_, Q_, IPL_, OH_, BPP_, U_>;                                                             \
+#define GV_LDS_CASE(P_, Q_, IPL_, OH_, BPP_, U_, KB_, BF_)                                                              \
+    if (rc == -1000 && blk_in == P_ && blk_out == Q_ && bf == BF_ && pl.ipl == IPL_ && pl.oh == OH_ && pl.bpp == BPP_ && \
+        pl.u == U_ && pl.kb == KB_) {                                                                                   \
+        auto kern = k_agg_lds<P_, Q_, IPL_, OH_, BPP_, U_, KB_, BF_>;                                                   \
         static bool attr_done = false;                                                                                  \
         if (!attr_done) {                                                                                               \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET) != hipSuccess) \
@@ -491,9 +542,12 @@ extern "C" int gv_rgcn_bdd_aggregate_lds(const int32_t* sitems, int n_sitems, co
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                              \
         rc = launch_status("gv_rgcn_bdd_aggregate_lds");                                                               \
     }
-    GV_LDS_CASE(10, 10, 2, 1, 10, 4)
-    GV_LDS_CASE(10, 20, 2, 2, 5, 4)
-    GV_LDS_CASE(20, 10, 4, 2, 5, 4)
+    GV_LDS_CASE(10, 10, 2, 1, 10, 4, 8, false)
+    GV_LDS_CASE(10, 20, 2, 2, 5, 4, 8, false)
+    GV_LDS_CASE(20, 10, 4, 2, 5, 4, 8, false)
+    GV_LDS_CASE(10, 10, 2, 1, 10, 4, 8, true)
+    GV_LDS_CASE(10, 20, 2, 1, 10, 3, 5, true)
+    GV_LDS_CASE(20, 10, 4, 1, 10, 4, 8, true)
 #undef GV_LDS_CASE
     GV_REQUIRE(rc != -1000, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate_lds: no instantiation for blocks %dx%d", blk_in, blk_out);
     if (rc != GV_OK) return rc;

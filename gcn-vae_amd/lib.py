@@ -39,10 +39,10 @@ SIGNATURES = {
     'gv_rgcn_bdd_pack_weight_phase': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'gv_rgcn_bdd_aggregate_phases': (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                           _P, _I, _I, _P, _F, _P, _I, _P, _P]),
-    'gv_rgcn_bdd_lds_plan': (_I, [_I, _I, _I, _I, _P]),
-    'gv_rgcn_bdd_pack_weight_lds': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
-    'gv_rgcn_bdd_aggregate_lds': (_I, [_P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _P,
-                                       _F, _P, _I, _P, _I, _P]),
+    'gv_rgcn_bdd_lds_plan': (_I, [_I, _I, _I, _I, _I, _P]),
+    'gv_rgcn_bdd_pack_weight_lds': (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'gv_rgcn_bdd_aggregate_lds': (_I, [_P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _I,
+                                       _P, _F, _P, _I, _P, _I, _P]),
     'gv_rgcn_bdd_pack_supported': (_I, [_I, _I, _I, _I]),
     'gv_rgcn_bdd_pack_weight': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'gv_rgcn_bdd_pack_weight_pair': (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),

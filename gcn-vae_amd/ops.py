@@ -748,16 +748,22 @@ def lds_graph(gidx):
 
 
 
-def lds_plan(num_rels, num_bases, blk_in, blk_out):
-    """(column parts, floats of the packed table, preferred work-item chunk) when the LDS-resident K1 kernel exists for the
-    block shape AND the relation table fits a CU's LDS (few relation types: WN18RR-shaped graphs), else None."""
+def k1_bf16():
+    """BASELINE configs[2]'s precision on K1: bf16 operands / fp32 accumulate where the LDS-resident kernel runs."""
+    return GEMM_PRECISION == 'bf16'
+
+
+def lds_plan(num_rels, num_bases, blk_in, blk_out, bf=None):
+    """(column parts, floats of the packed table, most edges of a super-item, bf16 operands) when the LDS-resident K1 kernel
+    exists for the block shape AND the relation table fits a CU's LDS (few relation types: WN18RR-shaped graphs), else None."""
     if K1_LDS == '0':
         return None
-    key = (int(num_rels), int(num_bases), int(blk_in), int(blk_out))
+    bf = k1_bf16() if bf is None else bool(bf)
+    key = (int(num_rels), int(num_bases), int(blk_in), int(blk_out), bf)
     if key not in _LDS_PLANS:
         plan = (_ct.c_int32 * 3)()
-        ok = lib.load().gv_rgcn_bdd_lds_plan(key[1], key[2], key[3], key[0], _ct.addressof(plan))
-        _LDS_PLANS[key] = (int(plan[0]), int(plan[1]), max(4, min(int(plan[2]), K1_LDS_G))) if ok else None
+        ok = lib.load().gv_rgcn_bdd_lds_plan(key[1], key[2], key[3], key[0], 1 if bf else 0, _ct.addressof(plan))
+        _LDS_PLANS[key] = (int(plan[0]), int(plan[1]), max(4, min(int(plan[2]), K1_LDS_G)), bf) if ok else None
     return _LDS_PLANS[key]
 
 
@@ -765,12 +771,12 @@ def pack_weight_lds(weight, num_bases, blk_in, blk_out, transpose_w, plan):
     weight = _chk(weight, name='weight')
     packed = torch.empty(plan[1], dtype=torch.float32, device=weight.device)
     lib.call('gv_rgcn_bdd_pack_weight_lds', ptr(weight), weight.shape[0], num_bases, blk_in, blk_out, 1 if transpose_w else 0,
-             ptr(packed), lib.stream())
+             1 if plan[3] else 0, ptr(packed), lib.stream())
     return packed
 
 
 def bdd_aggregate_lds(order: LdsOrder, nbr, etype, coef, coef_idx, feat, weight_packed, num_rels, num_bases, blk_in, blk_out,
-                      transpose_w=False, addend=None, act=ACT_NONE, keep=None, keep_scale=1.0, out=None):
+                      transpose_w=False, addend=None, act=ACT_NONE, keep=None, keep_scale=1.0, out=None, plan=None):
     """gv_rgcn_bdd_aggregate_lds: K1 with every relation's block weights resident in LDS (``order``: GraphIndex.lds_order,
     ``weight_packed``: pack_weight_lds).  Same formula and epilogue as ``bdd_aggregate``; ``transpose_w`` only names the
     launch (the packing holds the orientation)."""
@@ -779,7 +785,7 @@ def bdd_aggregate_lds(order: LdsOrder, nbr, etype, coef, coef_idx, feat, weight_
     out_dim = num_bases * blk_out
     if feat.shape[1] != num_bases * blk_in:
         raise ValueError(f'feat has {feat.shape[1]} columns, expected num_bases*blk_in = {num_bases * blk_in}')
-    plan = lds_plan(num_rels, num_bases, blk_in, blk_out)
+    plan = lds_plan(num_rels, num_bases, blk_in, blk_out) if plan is None else plan
     if plan is None or weight_packed.numel() != plan[1]:
         raise ValueError('weight_packed does not have the size the LDS plan asks for (or no plan for this shape)')
     if order.max_edges > plan[2]:
@@ -803,8 +809,8 @@ def bdd_aggregate_lds(order: LdsOrder, nbr, etype, coef, coef_idx, feat, weight_
     timed = lib.TIMER is not None
     lib.call('gv_rgcn_bdd_aggregate_lds', ptr(order.sitems), order.n_sitems, ptr(order.erow), ptr(order.empty), order.n_empty,
              ptr(order.fix), 0 if timed else order.n_fix, ptr(nbr), ptr(etype), ptr(coef), ptr(coef_idx), ptr(feat), ld_feat,
-             ptr(weight_packed), num_rels, num_bases, blk_in, blk_out, ptr(addend), ld_add, act, ptr(keep), float(keep_scale),
-             ptr(out), ld_out, ptr(partial), K1_LDS_WORKGROUPS, lib.stream(), tag=tag)
+             ptr(weight_packed), num_rels, num_bases, blk_in, blk_out, 1 if plan[3] else 0, ptr(addend), ld_add, act, ptr(keep),
+             float(keep_scale), ptr(out), ld_out, ptr(partial), K1_LDS_WORKGROUPS, lib.stream(), tag=tag)
     if timed and order.n_fix > 0:
         lib.call('gv_rgcn_bdd_fixup', ptr(order.fix), order.n_fix, ptr(partial), out_dim, ptr(addend), ld_add, act, ptr(keep),
                  float(keep_scale), ptr(out), ld_out, lib.stream())
@@ -1332,10 +1338,11 @@ class _RelGraphConvBdd(torch.autograd.Function):
 
         ctx.grouped = not ctx.tiles and reduce_hook is None and use_relation_groups(weight, gidx)
         lp = lds_plan(weight.shape[0], num_bases, si, so) if (not ctx.tiles and not ctx.grouped and reduce_hook is None and lds_graph(gidx)) else None
+        ctx.k1_bf = bool(lp[3]) if lp is not None else False
         if lp is not None:       # few relation types: the whole table resident in LDS (csrc/k_lds.hip)
             out = bdd_aggregate_lds(gidx.lds_order('dst', lp[2]), gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x,
                                     pack_weight_lds(weight, num_bases, si, so, False, lp), weight.shape[0], num_bases, si, so,
-                                    False, self_loop_term(), act, keep, keep_scale)
+                                    False, self_loop_term(), act, keep, keep_scale, plan=lp)
         elif ctx.tiles:
             out = bdd_aggregate_phases(tl, None if coef is None else tl.coef(coef), x,
                                        pack_weight_phase(tl, weight, num_bases, si, so), weight.shape[0], num_bases, si, so,
@@ -1421,13 +1428,13 @@ class _RelGraphConvBdd(torch.autograd.Function):
                                           pack_weight_phase(tl, weight, nb, so, si), weight.shape[0], nb, so, si, gx_loop,
                                           out=x_tgt)
         elif ctx.needs_input_grad[0] and not ctx.grouped and reduce_hook is None and lds_graph(gidx) and \
-                lds_plan(weight.shape[0], nb, so, si) is not None:
-            lp = lds_plan(weight.shape[0], nb, so, si)
+                lds_plan(weight.shape[0], nb, so, si, bf=ctx.k1_bf) is not None:
+            lp = lds_plan(weight.shape[0], nb, so, si, bf=ctx.k1_bf)
             static = not gidx.sync_free and coef is not None
             coef_s, idx_s = (gidx.coef_in_src_order(coef), None) if static else (coef, gidx.by_src.perm)
             grad_x = bdd_aggregate_lds(gidx.lds_order('src', lp[2]), gidx.nbr_by_src, ridx.et_by_src, coef_s, idx_s, g_agg,
                                        pack_weight_lds(weight, nb, so, si, True, lp), weight.shape[0], nb, so, si, True,
-                                       gx_loop, out=x_tgt)
+                                       gx_loop, out=x_tgt, plan=lp)
         elif ctx.needs_input_grad[0]:
             pk = si * so >= 8 and pack_supported(nb, so, si, True)
             if ctx.w_bwd_packed is not None and weight._version == ctx.w_version:

@@ -141,16 +141,19 @@ int gv_rgcn_bdd_aggregate_phases(const int32_t* off, const int32_t* nbr, const i
  *   max_workgroups    0 = one per CU; the grid is (max_workgroups / parts, parts)
  * gv_rgcn_bdd_lds_plan returns 1 when an instantiation exists AND the table fits (HOST pointer, may be NULL):
  *   plan[3] = {column parts, floats of weight_packed, most edges of a super-item}.
+ *   bf16_operands     BASELINE configs[2]'s precision: the table holds bf16 (round to nearest even) weights, an edge's inputs are
+ *               scaled by its coefficient in fp32 and rounded to bf16, products and sums in fp32 (v_dot2c_f32_bf16); feature
+ *               rows and outputs stay fp32 in memory.  Half the LDS bytes per product: twice the output columns per part.
  * Every row is summed by one wave in a fixed order (bitwise reproducible); the order differs from gv_rgcn_bdd_aggregate's. */
-int gv_rgcn_bdd_lds_plan(int num_bases, int blk_in, int blk_out, int num_rels, int32_t* plan_host);
+int gv_rgcn_bdd_lds_plan(int num_bases, int blk_in, int blk_out, int num_rels, int bf16_operands, int32_t* plan_host);
 int gv_rgcn_bdd_pack_weight_lds(const float* weight, int num_rels, int num_bases, int blk_in, int blk_out, int transpose_w,
-                                float* packed, void* stream);
+                                int bf16_operands, float* packed, void* stream);
 int gv_rgcn_bdd_aggregate_lds(const int32_t* sitems, int n_sitems, const int32_t* erow, const int32_t* empty_rows, int n_empty,
                               const int32_t* fix, int n_fix, const int32_t* nbr, const int32_t* etype, const float* coef,
                               const int32_t* coef_idx, const float* feat, int ld_feat, const float* weight_packed,
-                              int num_rels, int num_bases, int blk_in, int blk_out, const float* addend, int ld_addend, int act,
-                              const uint8_t* keep, float keep_scale, float* out, int ld_out, float* partial,
-                              int max_workgroups, void* stream);
+                              int num_rels, int num_bases, int blk_in, int blk_out, int bf16_operands, const float* addend,
+                              int ld_addend, int act, const uint8_t* keep, float keep_scale, float* out, int ld_out,
+                              float* partial, int max_workgroups, void* stream);
 
 /* The fix-up pass of gv_rgcn_bdd_aggregate on its own (a caller that passed n_fix = 0 there, e.g. to
  * time the aggregation kernel alone, finishes the split rows with this). */

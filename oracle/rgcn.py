@@ -106,8 +106,11 @@ def rel_graph_conv(x, src, dst, etypes, norm, params, regularizer='bdd', num_bas
     int_ids = x.dtype == torch.int64 and x.dim() == 1
     if int_ids and regularizer == 'bdd':
         raise TypeError('Block decomposition does not allow integer ID feature.')
-    msg = _messages(x, src, etypes, norm, params, regularizer, num_bases)
-    h = torch.zeros(x.shape[0], msg.shape[1], dtype=msg.dtype).index_add(0, dst, msg)
+    if regularizer == 'bdd' and bf16.k1_enabled():      # the product's bf16-operand aggregation (oracle/bf16.py)
+        h = bf16.bdd_aggregate(x, params['weight'], src, dst, etypes, norm, clamp_num_bases(num_bases, params['weight'].shape[0]))
+    else:
+        msg = _messages(x, src, etypes, norm, params, regularizer, num_bases)
+        h = torch.zeros(x.shape[0], msg.shape[1], dtype=msg.dtype).index_add(0, dst, msg)
     if 'h_bias' in params:
         h = h + params['h_bias']
     if 'loop_weight' in params:

@@ -246,7 +246,8 @@ def test_rel_graph_conv_lds_resident_weights(ops, monkeypatch, fin, fout, nb, r,
     assert (gidx.by_dst.perm is not None) == shuffle
     ridx = ops.RelationIndex(gidx, et.cuda(), r)
     real_plan = ops.lds_plan
-    monkeypatch.setattr(ops, 'lds_plan', lambda *a: None if real_plan(*a) is None else real_plan(*a)[:2] + (max_edges,))
+    monkeypatch.setattr(ops, 'lds_plan', lambda *a, **k: None if real_plan(*a, **k) is None else
+                        real_plan(*a, **k)[:2] + (max_edges,) + real_plan(*a, **k)[3:])
     od = gidx.lds_order('dst', max_edges)
     si = od.sitems[:od.n_sitems]
     assert od.n_fix > 0 and od.n_empty >= 7 and int((si[:, 1] - si[:, 0]).max()) <= max_edges
@@ -280,6 +281,48 @@ def test_rel_graph_conv_lds_resident_weights(ops, monkeypatch, fin, fout, nb, r,
     hg3 = ops.rel_graph_conv_bdd(x.cuda(), p['weight'].cuda(), None, None, None, gidx, ridx, nb, 0)
     close(hg3, ho3)
     assert float(hg3[n - 7:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('fin,fout,nb,r', [(200, 200, 20, 22), (200, 400, 20, 22), (100, 200, 10, 22)])
+def test_rel_graph_conv_lds_resident_bf16_operands(ops, fin, fout, nb, r):
+    """BASELINE configs[2]'s precision on K1 (gv_rgcn_bdd_aggregate_lds with bf16_operands): the relation weights and the
+    coefficient-scaled inputs rounded to bf16 (nearest even), products and sums in fp32 -- against the oracle's statement of
+    exactly that (oracle/bf16.py, ``enabled(k1=True)``), forward, backward-x (bf16 operands too) and the fp32 weight gradient.
+    The roundings are the same on both sides, so the tolerance stays that of a different summation order."""
+    from oracle import bf16 as obf16
+    n, e = 500, 6000
+    src, dst, et, norm = zipf_graph(n, e, r, seed=fin + nb + r)
+    dst = torch.where(dst >= n - 5, torch.zeros_like(dst), dst)
+    order = np.lexsort((et.numpy(), src.numpy(), dst.numpy()))
+    src, dst, et, norm = src[order], dst[order], et[order], norm[order]
+    gen = torch.Generator().manual_seed(fin + 3 * nb)
+    x = torch.randn(n, fin, generator=gen)
+    p = orgcn.init_params(fin, fout, r, 'bdd', nb, True, True, gen)
+    p['h_bias'] = torch.randn(fout, generator=gen) * 0.1
+    keep = (torch.rand(n, fout, generator=gen) > 0.2).to(torch.uint8)
+    gout = torch.randn(n, fout, generator=gen)
+    with ops.gemm_precision('bf16'):
+        assert ops.lds_plan(r, nb, fin // nb, fout // nb)[3] and ops.lds_plan(r, nb, fout // nb, fin // nb)[3]
+        fp, bp = ops.lds_plan(r, nb, fin // nb, fout // nb), ops.lds_plan(r, nb, fin // nb, fout // nb, bf=False)
+        assert fp[0] <= bp[0]                                            # never more column parts than the fp32 table needs
+        gidx = ops.GraphIndex(src.cuda(), dst.cuda(), n)
+        ridx = ops.RelationIndex(gidx, et.cuda(), r)
+        xg = x.cuda().requires_grad_(True)
+        pg = {k: v.cuda().requires_grad_(True) for k, v in p.items()}
+        hg = ops.rel_graph_conv_bdd(xg, pg['weight'], pg['h_bias'], pg['loop_weight'], norm.cuda(), gidx, ridx, nb, 1, keep.cuda(),
+                                    1.0 / 0.8)
+        hg.backward(gout.cuda())
+    with obf16.enabled(True, k1=True):
+        xo = x.clone().requires_grad_(True)
+        po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        ho = orgcn.rel_graph_conv(xo, src, dst, et, norm, po, 'bdd', nb, torch.relu, dropout_keep=keep, dropout_p=0.2)
+        ho.backward(gout)
+    close(hg, ho, rtol=2e-4, atol_scale=2e-5, msg='forward')
+    close(xg.grad, xo.grad, rtol=2e-4, atol_scale=2e-5, msg='grad_x')
+    close(pg['weight'].grad, po['weight'].grad, rtol=2e-4, atol_scale=2e-5, msg='grad_weight')
+    # and the rounding is really there: the fp32 oracle differs by about a bf16 ulp of the operands
+    ho32 = orgcn.rel_graph_conv(x, src, dst, et, norm, p, 'bdd', nb, torch.relu, dropout_keep=keep, dropout_p=0.2)
+    assert float((hg.detach().cpu() - ho32).abs().max()) > 1e-4 * float(ho32.abs().max())
 
 
 def test_rel_graph_conv_unsorted_edges_and_empty_rows(ops):

@@ -32,7 +32,8 @@ def main(probe):
         w = torch.randn(R, nb * si * so, device='cuda') * 0.1
         pre = torch.randn(N, fout, device='cuda')
         keep = (torch.rand(N, fout, device='cuda') > 0.2).to(torch.uint8)
-        pf, pb = ops.lds_plan(R, nb, si, so), ops.lds_plan(R, nb, so, si)
+        bf = os.environ.get('LB_BF16', '0') == '1'
+        pf, pb = ops.lds_plan(R, nb, si, so, bf=bf), ops.lds_plan(R, nb, so, si, bf=bf)
         wf, wb = ops.pack_weight_lds(w, nb, si, so, False, pf), ops.pack_weight_lds(w, nb, so, si, True, pb)
         by_f = E * (fin * 4 + 12) + N * (fout * 4 + 4) + R * fin * fout // nb * 4
         by_b = E * (fout * 4 + 12) + N * (fin * 4 + 4) + R * fin * fout // nb * 4
@@ -48,9 +49,9 @@ def main(probe):
                 variants += [('one neighbour', z(gidx.nbr_by_dst), ridx.et_by_dst, z(gidx.nbr_by_src), ridx.et_by_src),
                              ('one relation', gidx.nbr_by_dst, z(ridx.et_by_dst), gidx.nbr_by_src, z(ridx.et_by_src))]
             for tag, nd, ed, ns, es in variants:
-                tf = timeit(lambda: ops.bdd_aggregate_lds(sd, nd, ed, norm, None, x, wf, R, nb, si, so, False, pre, 1, keep, 1.25))
-                tb = timeit(lambda: ops.bdd_aggregate_lds(ss, ns, es, norm_s, None, gg, wb, R, nb, so, si, True))
-                print(f'{si}x{so} LDS-resident <= {chunk:3d} edges [{tag:13s}] super-items {sd.n_sitems}/{ss.n_sitems} split rows {sd.n_fix}/{ss.n_fix} empty {sd.n_empty}/{ss.n_empty}: '
+                tf = timeit(lambda: ops.bdd_aggregate_lds(sd, nd, ed, norm, None, x, wf, R, nb, si, so, False, pre, 1, keep, 1.25, plan=pf))
+                tb = timeit(lambda: ops.bdd_aggregate_lds(ss, ns, es, norm_s, None, gg, wb, R, nb, so, si, True, plan=pb))
+                print(f'{si}x{so} LDS-resident{" bf16" if bf else ""} ({pf[0]}/{pb[0]} parts) <= {chunk:3d} edges [{tag:13s}] super-items {sd.n_sitems}/{ss.n_sitems} split rows {sd.n_fix}/{ss.n_fix} empty {sd.n_empty}/{ss.n_empty}: '
                       f'fwd {tf:6.1f} us {by_f / tf / 1e3:7.1f} GB/s   bwd-x {tb:6.1f} us {by_b / tb / 1e3:7.1f} GB/s')
         tp = timeit(lambda: ops.pack_weight_lds(w, nb, si, so, False, pf))
         print(f'pack W {si}x{so}: {tp:5.1f} us')
