@@ -255,7 +255,18 @@ def pmc_traffic_for(tag, config='c2'):
     return best, src
 
 
-def cpu_baseline(w, model, args, budget_s):
+def k1_bf16_mode(w, args, dev):
+    """Does the product run both R-GCN layers' aggregations on bf16 operands for this workload (--gemm-precision bf16 and few
+    enough relation types for the LDS-resident kernel)?  The oracle mirrors exactly that (oracle/bf16.py)."""
+    from gcn_vae_amd import ops as _ops
+    _ops.set_gemm_precision(args.gemm_precision)
+    gi = w['g'].device_index(dev)
+    r2 = 2 * w['data'].num_rels
+    return bool(_ops.k1_bf16_applies(gi, r2, args.n_bases, args.hidden, args.hidden) and
+                _ops.k1_bf16_applies(gi, r2, args.n_bases, args.hidden, 2 * args.hidden))
+
+
+def cpu_baseline(w, model, args, budget_s, k1_bf16=False):
     """The CPU oracle (oracle/, a torch-CPU port of the reference's op sequence; test infrastructure, used here as the
     reported baseline and as the checker of ``parity_check``) on the same inputs.  Returns (baseline record, reference
     outputs of the last oracle step for the parity leg)."""
@@ -296,7 +307,7 @@ def cpu_baseline(w, model, args, budget_s):
             v.grad = None
         t0 = time.time()
         # configs[2]: the oracle emulates the product's bf16-operand / fp32-accumulate dense products (oracle/bf16.py)
-        with torch.autograd.set_detect_anomaly(anomaly), obf16.enabled(args.gemm_precision == 'bf16'):
+        with torch.autograd.set_detect_anomaly(anomaly), obf16.enabled(args.gemm_precision == 'bf16', k1=k1_bf16):
             enc = okg.kgvae_encode(state, src, dst, w['node_id'], rel, enorm, eps, args.n_bases, args.n_flows, args.dropout,
                                    keep1, keep2)
             loss = okg.link_predict_loss(state, enc, w['samples'], w['labels'], 0.01, 1e-5, 1.0, 10, args.n_flows,
@@ -849,7 +860,9 @@ def main():
         }
         out['cpu_baseline'], out['parity_check'] = None, None
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'], ref = cpu_baseline(w, model, args, args.cpu_seconds)
+            k1_bf = k1_bf16_mode(w, args, dev)
+            out['config']['k1_operands'] = 'bf16 (fp32 accumulate, fp32 rows in memory)' if k1_bf else 'f32'
+            out['cpu_baseline'], ref = cpu_baseline(w, model, args, args.cpu_seconds, k1_bf16=k1_bf)
             if not args.no_check:      # the timed workload, checked at its own size against the oracle (raises on failure)
                 out['parity_check'] = parity_check(model, opt, modes['edge'], ref, dev, args.gemm_precision == 'bf16')
                 out['parity_max_rel_err'] = out['parity_check']['parity_max_rel_err']

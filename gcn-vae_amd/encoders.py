@@ -13,18 +13,19 @@ from .flows import MADE, PermuteLayer
 from .layers import RelGraphConv
 
 
-class EmbeddingLayer(nn.Module):
+class EmbeddingLayer(ops.StayOnDevice, nn.Module):
     def __init__(self, num_nodes, h_dim):
         super().__init__()
         self.embedding = nn.Embedding(num_nodes, h_dim)
 
     def forward(self, g, h, r, norm):
+        h = ops.to_module_device(self.embedding.weight, h)
         # the lookup opens every forward pass: the device RNG's tick advances on this launch
         return ops.embedding(self.embedding.weight, h.squeeze(), ops.device_rng(self.embedding.weight.device),
                              sole_consumer=True)
 
 
-class DistLayer(nn.Module):
+class DistLayer(ops.StayOnDevice, nn.Module):
     """Present in the reference (kgvae/model.py:194-200) but never instantiated."""
 
     def __init__(self, in_dim, out_dim):
@@ -35,7 +36,7 @@ class DistLayer(nn.Module):
         return ops.linear(h.squeeze(), self.linear.weight, self.linear.bias)
 
 
-class KGVAE(nn.Module):
+class KGVAE(ops.StayOnDevice, nn.Module):
     def __init__(self, num_nodes, h_dim, out_dim, num_rels, num_bases, num_hidden_layers=1, dropout=0,
                  use_self_loop=False, use_cuda=True, k=10, n_flows=0, verbose=False):
         super().__init__()
@@ -209,6 +210,7 @@ class KGVAE(nn.Module):
         return z, log_det_sum
 
     def forward(self, g, h, r, norm):
+        h, r, norm = ops.to_module_device(self.z_pre, h, r, norm)      # host tensors (the reference's validation block) come to the device
         self.node_id = h.squeeze()
         if self.row_part is not None:
             return self._forward_rows(g, h, r, norm)
@@ -234,7 +236,7 @@ class KGVAE(nn.Module):
         return z
 
 
-class BaseRGCN(nn.Module):
+class BaseRGCN(ops.StayOnDevice, nn.Module):
     def __init__(self, num_nodes, h_dim, out_dim, num_rels, num_bases, num_hidden_layers=1, dropout=0,
                  use_self_loop=False, use_cuda=False, **unused):
         # **unused: LinkPredict passes k= / n_flows= to every encoder class; the reference's BaseRGCN

@@ -10,7 +10,7 @@ import torch.nn as nn
 from . import ops
 
 
-class MaskedLinear(nn.Linear):
+class MaskedLinear(ops.StayOnDevice, nn.Linear):
     def __init__(self, input_size, output_size, mask):
         super().__init__(input_size, output_size)
         self.register_buffer('mask', mask)
@@ -39,7 +39,7 @@ class PermuteLayer(nn.Module):
         return self.forward(inputs)
 
 
-class MADE(nn.Module):
+class MADE(ops.StayOnDevice, nn.Module):
     def __init__(self, input_size, hidden_size, n_hidden):
         super().__init__()
         self.input_size, self.hidden_size, self.n_hidden = input_size, hidden_size, n_hidden

@@ -29,7 +29,7 @@ def _activation_id(activation):
     return ops.ACT_NONE, activation
 
 
-class RelGraphConv(nn.Module):
+class RelGraphConv(ops.StayOnDevice, nn.Module):
     def __init__(self, in_feat, out_feat, num_rels, regularizer="basis", num_bases=None, bias=True,
                  activation=None, self_loop=False, dropout=0.0):
         super().__init__()
@@ -107,6 +107,7 @@ class RelGraphConv(nn.Module):
                                        part, act_id, keep, scale if keep is not None else 1.0, gather_input, pad_output)
 
     def forward(self, g, x, etypes, norm=None):
+        x, etypes, norm = ops.to_module_device(self.weight, x, etypes, norm)
         int_ids = x.dtype == torch.int64 and x.dim() == 1
         if int_ids and self.regularizer == 'bdd':
             raise TypeError('Block decomposition does not allow integer ID feature.')

@@ -94,6 +94,37 @@ def join(*ids):
             cur.wait_stream(_side(i))
 
 
+class StayOnDevice:
+    """Mixin of the HIP modules: once their parameters live on a ROCm device, ``module.cpu()`` / ``.to('cpu')`` leaves them
+    there.  The reference moves its model to the host for validation (kgvae/link_predict.py:239-242, "full graph is too
+    large") and back; there is no CPU path here to move to -- the compute stays on the GPU and ``to_module_device`` brings
+    whatever the caller hands in (node ids, relation types, norms on the host) to the parameters.  Not a fallback."""
+    _gv_warned = False
+
+    def _apply(self, fn, *args, **kwargs):
+        dev = next((t.device for t in list(self.parameters()) + list(self.buffers()) if t.is_cuda), None)
+        if dev is not None:
+            try:
+                moved = fn(torch.zeros(1, device=dev))
+            except Exception:          # a fn that does not take a plain tensor: not a device move
+                moved = None
+            if moved is not None and moved.device.type == 'cpu':
+                if not StayOnDevice._gv_warned:
+                    StayOnDevice._gv_warned = True
+                    import sys
+                    print('[gcn_vae_amd] .cpu() on a HIP module is a no-op: parameters stay on %s, inputs are copied to them'
+                          % dev, file=sys.stderr)
+                return self
+        return super()._apply(fn, *args, **kwargs)
+
+
+def to_module_device(param, *tensors):
+    """The caller's tensors on the device of ``param`` (a host -> device copy when they are elsewhere; None passes through)."""
+    dev = param.device
+    out = tuple(t if (t is None or not isinstance(t, torch.Tensor) or t.device == dev) else t.to(dev) for t in tensors)
+    return out if len(out) != 1 else out[0]
+
+
 def _chk(t, dtype=torch.float32, name='tensor'):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError(f'{name}: the gfx950 path needs a CUDA/ROCm tensor (got '
@@ -745,6 +776,14 @@ LDS_MIN_EDGES = 100_000     # its work lists are built with one host read-back: 
 
 def lds_graph(gidx):
     return (not gidx.sync_free) or gidx.num_edges >= LDS_MIN_EDGES
+
+
+def k1_bf16_applies(gidx, num_rels, num_bases, in_feat, out_feat):
+    """True when a bdd layer of this shape on this graph runs its aggregations (forward and backward-x) on bf16 operands:
+    --gemm-precision bf16 AND the LDS-resident kernel takes the layer (few relation types).  What an oracle has to mirror."""
+    si, so = in_feat // num_bases, out_feat // num_bases
+    return (k1_bf16() and lds_graph(gidx) and lds_plan(num_rels, num_bases, si, so, bf=True) is not None
+            and lds_plan(num_rels, num_bases, so, si, bf=True) is not None)
 
 
 

@@ -71,7 +71,12 @@ def perturb_and_get_rank_unfused(embedding, w, a, r, b, test_size, batch_size=10
 def calc_mrr(embedding, w, test_triplets, hits=[], eval_bz=100, all_batches=True, flow_log_prob=None,
              verbose=True):
     with torch.no_grad():
+        # the reference validates with the model "on the CPU" (kgvae/link_predict.py:239-251): whatever side the caller's
+        # tensors are on, the scorer runs where the embedding is
         test_triplets = test_triplets.to(embedding.device)
+        w = w.to(embedding.device)
+        if isinstance(flow_log_prob, torch.Tensor):
+            flow_log_prob = flow_log_prob.to(embedding.device)
         s, r, o = test_triplets[:, 0], test_triplets[:, 1], test_triplets[:, 2]
         n = test_triplets.shape[0]
         ranks_s = perturb_and_get_rank(embedding, w, o, r, s, n, eval_bz, all_batches, flow_log_prob)

@@ -26,7 +26,7 @@ from .encoders import KGVAE, RGCN
 from .sampling import node_norm_to_edge_norm
 
 
-class LinkPredict(nn.Module):
+class LinkPredict(ops.StayOnDevice, nn.Module):
     def __init__(self, model_class, in_dim, h_dim, num_rels, num_bases=-1, num_hidden_layers=1, dropout=0,
                  use_cuda=True, reg_param=0, kl_param=0, mmd_param=0, k=1, n_flows=0):
         super().__init__()

@@ -51,6 +51,48 @@ def test_c2_full_training_step_against_oracle():
     assert len([k for k in rec['checked'] if k.startswith('grad ')]) >= 3
 
 
+def _full_step_parity(config, edges, triplets):
+    """bench.py's parity leg at the configuration's FULL size: one HIP forward + loss + backward against the oracle's step on
+    the same weights and random draws (loss, z, six parameter gradients); raises beyond the configuration's tolerance."""
+    from gcn_vae_amd import ops
+    bench, args = _bench_args('--config', config)
+    dev = torch.device('cuda', 0)
+    old = ops.GEMM_PRECISION
+    ops.set_gemm_precision(args.gemm_precision)
+    try:
+        w = bench.make_workload(0, 1, args, dev)
+        assert int(w['src'].numel()) == edges and int(w['samples'].shape[0]) == triplets
+        model = bench.build_model(w, args).to(dev).train()
+        model.static_batch = True
+        from gcn_vae_amd.optim import FlatAdam
+        opt = FlatAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, max_grad_norm=1.0)
+        inputs = dict(g=w['g'], node_id=w['node_id'].to(dev), etype=w['rel'].to(dev), enorm=w['enorm'],
+                      samples=w['samples'].to(dev), labels=w['labels'].to(dev))
+        k1_bf = bench.k1_bf16_mode(w, args, dev)
+        _, ref = bench.cpu_baseline(w, model, args, budget_s=1.0, k1_bf16=k1_bf)      # 1 warm-up + 2 oracle steps
+        rec = bench.parity_check(model, opt, inputs, ref, dev, args.gemm_precision == 'bf16')
+        return rec, k1_bf, args
+    finally:
+        ops.set_gemm_precision(old)
+
+
+def test_c3_full_training_step_against_oracle():
+    """BASELINE configs[2] at FULL WN18RR size (40 943 entities, 22 directed relation types, 173 670 edges, num_bases = 20,
+    3 IAF blocks, bf16 operands): the LDS-resident K1 kernel with bf16 operands in both layers and both directions, the
+    bf16 MADE chain, the loss head -- against the oracle under oracle.bf16.enabled(k1=True)."""
+    rec, k1_bf, args = _full_step_parity('c3', 173670, 220000)
+    assert k1_bf and args.n_flows == 3 and args.gemm_precision == 'bf16'
+    assert rec['passed'] and rec['outputs_max_rel_err'] <= 5e-3 and rec['gradients_max_rel_l2_err'] <= 2e-2
+
+
+def test_c4_full_training_step_h500_against_oracle():
+    """BASELINE configs[3]'s width (emb_dim = 500: 5x5 / 5x10 blocks on the relation-phase kernel) as a WHOLE training step at
+    full FB15k-237 size; the oracle evaluates its per-edge weight gather over edge chunks (oracle.rgcn, 5.4 / 10.9 GB otherwise)."""
+    rec, k1_bf, args = _full_step_parity('c4', 544230, 220000)
+    assert not k1_bf and args.hidden == 500
+    assert rec['passed'] and rec['outputs_max_rel_err'] <= 1e-4 and rec['gradients_max_rel_l2_err'] <= 5e-4
+
+
 def _oracle_layer_chunked(x, src, dst, et, norm, p, nb, gout, chunk=40000):
     """oracle.rgcn.rel_graph_conv (bdd, identity activation) without its E x (in*out/B) weight gather alive at once:
     the aggregate is linear in the messages, so it is summed over edge chunks (forward, no graph), the non-linear tail
@@ -180,3 +222,92 @@ def test_c5_scale_properties_and_sampled_rows(monkeypatch, phases, so):
     r2 = g2.relation_index(et[perm].contiguous(), r)
     b1 = agg(g2, r2, x1, norm[perm].contiguous())
     assert float((b1 - a1).abs().max()) < 1e-4 * max(1.0, scale)
+
+
+@pytest.mark.parametrize('tag', ['u', 'n'])
+def test_device_batch_stages_equal_the_reference_captured_pipeline(tag):
+    """SURVEY 8(f-1) against tests/golden/pipeline.npz DIRECTLY (arrays captured from the reference's utils.py under a fixed
+    numpy stream): the batch's chosen triplets -- read back out of the golden samples -- go through the device relabel
+    (np.unique semantics), the negative sampler fed the draws the golden negatives imply, and the graph builder on the kept
+    half; every device array must equal the reference's: uniq_v, relabelled triplets, samples, labels, src, dst, rel, the
+    edge norm.  (test_gpu_ops compares the same kernels with the product's host restatement on bigger inputs.)"""
+    from gcn_vae_amd import lib
+    from gcn_vae_amd.lib import ptr
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'pipeline.npz'))
+    num_nodes, n_rel, neg, k = 300, 12, 4, 200
+    uniq_v, samples, labels = g[f'{tag}_uniq_v'], g[f'{tag}_samples'], g[f'{tag}_labels']
+    pos = samples[:k]                                            # relabelled positives, in the sampler's order
+    s_orig, o_orig, rel = uniq_v[pos[:, 0]], uniq_v[pos[:, 2]], pos[:, 1]
+
+    def i32(a):
+        return torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)).cuda()
+
+    st = lib.stream()
+    cap = min(2 * k, num_nodes)
+    uniq, src, dst, count = (torch.empty(cap, dtype=torch.int32, device='cuda'), torch.empty(k, dtype=torch.int32, device='cuda'),
+                             torch.empty(k, dtype=torch.int32, device='cuda'), torch.empty(1, dtype=torch.int32, device='cuda'))
+    wb = int(lib.load().gv_relabel_workspace_bytes(num_nodes))
+    ws = torch.empty(wb, dtype=torch.uint8, device='cuda')
+    a_g, b_g, rel_d = i32(s_orig), i32(o_orig), i32(rel)
+    lib.call('gv_relabel_pairs', ptr(a_g), ptr(b_g), k, num_nodes, ptr(uniq), cap, ptr(src), ptr(dst), ptr(count), ptr(ws), wb, st)
+    n = int(count.item())
+    assert n == len(uniq_v) and np.array_equal(uniq[:n].cpu().numpy(), uniq_v)
+    assert np.array_equal(src.cpu().numpy(), pos[:, 0]) and np.array_equal(dst.cpu().numpy(), pos[:, 2])
+    # negatives: the draws the golden rows imply (a row equal to its positive: the draw hit the value it replaced)
+    negs, tiled = samples[k:], np.tile(pos, (neg, 1))
+    subj = negs[:, 0] != tiled[:, 0]
+    obj = negs[:, 2] != tiled[:, 2]
+    assert not (subj & obj).any() and np.array_equal(negs[:, 1], tiled[:, 1])
+    hit = subj | ~obj
+    values = np.where(hit, negs[:, 0], negs[:, 2])
+    out_s = torch.empty(k * (neg + 1), 3, dtype=torch.int64, device='cuda')
+    out_l = torch.empty(k * (neg + 1), dtype=torch.float32, device='cuda')
+    hit_d, val_d = torch.from_numpy(hit.astype(np.uint8)).cuda(), i32(values)
+    lib.call('gv_negative_sampling', ptr(src), ptr(rel_d), ptr(dst), k, neg, None, ptr(val_d), ptr(hit_d), 0, 0, None, 0,
+             ptr(out_s), ptr(out_l), st)
+    assert np.array_equal(out_s.cpu().numpy(), samples) and np.array_equal(out_l.cpu().numpy(), labels)
+    # the graph of the kept half: its forward edges (relation < n_rel) name the kept triplets
+    gs, gd, gr = g[f'{tag}_src'], g[f'{tag}_dst'], g[f'{tag}_rel']
+    fwd = gr < n_rel
+    pool = {}
+    for i, t in enumerate(map(tuple, pos)):
+        pool.setdefault(t, []).append(i)
+    keep = np.array([pool[(int(a), int(r_), int(b))].pop() for a, r_, b in zip(gs[fwd], gr[fwd], gd[fwd])])
+    m = len(keep)
+    assert m == k // 2 and len(gs) == 2 * m
+    src2, dst2, rel2 = (torch.empty(2 * m, dtype=torch.int32, device='cuda') for _ in range(3))
+    norm = torch.empty(2 * m, dtype=torch.float32, device='cuda')
+    gb = int(lib.load().gv_graph_from_triplets_workspace_bytes(m, cap, n_rel))
+    gws = torch.empty(gb, dtype=torch.uint8, device='cuda')
+    keep_d = i32(keep)
+    lib.call('gv_graph_from_triplets', ptr(src), ptr(rel_d), ptr(dst), ptr(keep_d), m, cap, n_rel, ptr(src2), ptr(dst2), ptr(rel2),
+             ptr(norm), ptr(gws), gb, st)
+    assert np.array_equal(src2.cpu().numpy(), gs) and np.array_equal(dst2.cpu().numpy(), gd) and np.array_equal(rel2.cpu().numpy(), gr)
+    assert np.array_equal(norm.cpu().numpy(), g[f'{tag}_edge_norm'].reshape(-1))       # 1 / in-degree of the destination, bit for bit
+    assert np.array_equal(g[f'{tag}_norm'][gd], g[f'{tag}_edge_norm'].reshape(-1))
+
+
+@pytest.mark.parametrize('n_flows', [0, 2])
+def test_kgvae_sample_z_against_oracle_with_the_same_draws(n_flows):
+    """KGVAE.sample_z (kgvae/model.py:60-69: mixture component by Categorical(pi), reparameterised draw, the flows' inverse
+    chain) on the HIP modules against oracle.kgvae.sample_z fed the very draws the device generator produced."""
+    from gcn_vae_amd.encoders import KGVAE
+    from oracle import kgvae as okg
+    torch.manual_seed(0)
+    enc = KGVAE(50, 16, 16, 6, num_bases=4, num_hidden_layers=2, dropout=0.0, use_self_loop=True, use_cuda=True, k=5,
+                n_flows=n_flows).cuda()
+    with torch.no_grad():
+        enc.z_pre.normal_(0, 0.7)
+        for p in enc.nf.parameters() if n_flows else []:
+            p.mul_(1.5)
+    batch = 37
+    torch.manual_seed(123)
+    with torch.no_grad():
+        got = enc.sample_z(batch)
+    torch.manual_seed(123)                                           # replay the two draws in the order sample_z makes them
+    idx = torch.distributions.categorical.Categorical(enc.pi).sample((batch,))
+    eps = torch.randn(batch, 16, device='cuda')
+    state = {'encoder.' + k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    want = okg.sample_z(state, idx.cpu(), eps.cpu(), n_flows)
+    assert got.shape == (batch, 16)
+    close(got, want, rtol=2e-4, atol_scale=2e-5, msg='sample_z')

@@ -761,3 +761,82 @@ def test_made_gradients_written_straight_into_the_optimiser_arena_equal_autograd
             if k in want:
                 torch.testing.assert_close(p.grad, 2 * want[k], rtol=1e-5, atol=1e-7 * float(want[k].abs().max() + 1e-30), msg=k)
         del opt
+
+
+@pytest.mark.parametrize('n_flows', [0, 2])
+def test_reference_validation_block_runs_unchanged_through_compat(tmp_path, n_flows):
+    """kgvae/link_predict.py:239-261 replayed line for line on the aliases compat.install() registers: the reference moves its
+    model to the CPU for validation (``model.cpu()``), forwards HOST tensors, ranks with ``utils.calc_mrr`` and moves back.
+    The scorer class below is the reference's own Python in shape (an nn.Module owning ``w_relation`` and the encoder), so
+    ``.cpu()`` really moves ITS parameter; the HIP modules keep theirs on the device, copy the host inputs over and compute
+    there -- same embedding and same MRR as with everything on the GPU.  No ``--evaluate-every`` workaround needed."""
+    import sys
+    import torch.nn as nn
+    from gcn_vae_amd import compat
+    saved = {k: sys.modules.get(k) for k in ('dgl', 'dgl.nn', 'dgl.nn.pytorch', 'dgl.contrib', 'dgl.contrib.data', 'model',
+                                             'flow_network', 'utils')}
+    try:
+        compat.install()
+        import utils
+        from model import KGVAE
+
+        class LinkPredict(nn.Module):          # kgvae/link_predict.py:30-63, constructor and forward
+            def __init__(self, in_dim, h_dim, num_rels):
+                super().__init__()
+                self.encoder = KGVAE(in_dim, h_dim, h_dim, num_rels * 2, 4, 2, 0.2, True, True, k=3, n_flows=n_flows)
+                self.w_relation = nn.Parameter(torch.Tensor(num_rels, h_dim))
+                nn.init.xavier_uniform_(self.w_relation, gain=nn.init.calculate_gain('relu'))
+
+            def forward(self, g, h, r, norm):
+                return self.encoder.forward(g, h, r, norm)
+
+        from gcn_vae_amd.data import synthetic_kg
+        data = synthetic_kg(400, 7, 3000, seed=2)
+        num_nodes, num_rels = data.num_nodes, data.num_rels
+        torch.manual_seed(0)
+        model = LinkPredict(num_nodes, 16, num_rels)
+        valid_data = torch.LongTensor(data.valid)
+        val_graph, val_rel, val_norm = utils.build_test_graph(num_nodes, num_rels, data.train)
+        val_deg = val_graph.in_degrees(range(val_graph.number_of_nodes())).float().view(-1, 1)
+        val_node_id = torch.arange(0, num_nodes, dtype=torch.long).view(-1, 1)
+        val_rel = torch.from_numpy(val_rel)
+        val_norm = utils.node_norm_to_edge_norm(val_graph, torch.from_numpy(val_norm).view(-1, 1))
+        use_cuda = True
+        model.cuda()
+        # everything on the GPU: the result the block below has to reproduce
+        model.eval()
+        with torch.no_grad():
+            embed_gpu = model(val_graph, val_node_id.cuda(), val_rel.cuda(), val_norm.cuda())
+            mrr_gpu = utils.calc_mrr(embed_gpu, model.w_relation, valid_data, hits=[1, 3, 10], eval_bz=100, all_batches=False,
+                                     flow_log_prob=model.encoder.get_flow_log_prob() if n_flows else None, verbose=False)
+        # ---- kgvae/link_predict.py:239-261 ----
+        if use_cuda:
+            model.cpu()
+        model.eval()
+        state_file = str(tmp_path / 'model_state.pth')
+        torch.save({'state_dict': model.state_dict(), 'epoch': 1}, state_file)
+        embed = model(val_graph, val_node_id, val_rel, val_norm)
+        mrr = utils.calc_mrr(embed, model.w_relation, valid_data, hits=[1, 3, 10], eval_bz=100, all_batches=False,
+                             flow_log_prob=model.encoder.get_flow_log_prob() if n_flows else None, verbose=False)
+        if use_cuda:
+            model.cuda()
+        # ----
+        assert embed.is_cuda and all(p.is_cuda for p in model.parameters())
+        assert torch.equal(embed.detach(), embed_gpu) and mrr == mrr_gpu and 0.0 < mrr <= 1.0
+        ck = torch.load(state_file)
+        assert set(ck['state_dict']) == set(model.state_dict()) and ck['epoch'] == 1
+        # the reference's own parameter did move to the host in between (the HIP modules' did not)
+        model.cpu()
+        assert not model.w_relation.is_cuda and all(p.is_cuda for p in model.encoder.parameters())
+        model.cuda()
+        # a training step still works after the round trip
+        model.train()
+        z = model(val_graph, val_node_id.cuda(), val_rel.cuda(), val_norm.cuda())
+        (z.sum() + model.encoder.get_kl(z)).backward()
+        assert model.encoder.rconv_layer_1.weight.grad is not None
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
