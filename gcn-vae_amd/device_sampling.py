@@ -87,7 +87,11 @@ class DeviceSampler:
             lib.call('gv_rng_tick', ptr(self._state), st)                 # the device-side batch number
             tick, tick_dev = 0, ptr(self._state[1:])
         else:
+            if self._state is not None:      # static batches advanced the device-side twin: ONE counter, continue from it
+                self.tick = int(self._state[1].item())
             self.tick += 1
+            if self._state is not None:
+                self._state[1] = self.tick
             tick, tick_dev = self.tick, None
         i32 = dict(dtype=torch.int32, device=dev)
         chosen = torch.empty(k, **i32)

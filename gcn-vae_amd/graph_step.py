@@ -23,32 +23,49 @@ class GraphedMiniBatchStep:
     def __init__(self, model, optimizer, sampler, sample_size, split_size=0.5, negative_rate=10, num_mmd_rows=200):
         if not isinstance(optimizer, FlatAdam):
             raise TypeError('the captured step needs FlatAdam (static gradient arena, two-launch clip + Adam)')
+        if getattr(model, 'kl_param', 1) <= 0:
+            raise ValueError('the captured mini-batch step needs kl_param > 0 (the loss head reads the device row count there)')
         self.model, self.opt, self.sampler = model, optimizer, sampler
         self.args = (int(sample_size), float(split_size), int(negative_rate))
         dev = sampler.device
         enc = model.encoder
         self.pick = None
         if getattr(model, 'mmd_param', 0) > 0 and hasattr(enc, 'mmd_index_override'):
-            self.pick = torch.zeros(num_mmd_rows, dtype=torch.int64, device=dev)
-            enc.mmd_index_override = self.pick          # refilled on the device inside the step
-        if hasattr(enc, 'fuse_kl_with_reparam'):
-            enc.fuse_kl_with_reparam = False            # the KL pass needs the device row count: it stays in the loss head here
+            self.pick = torch.zeros(num_mmd_rows, dtype=torch.int64, device=dev)      # refilled on the device inside the step
         self.one = torch.ones((), device=dev)
         self.graph = None
         self.out = None
         self.side = torch.cuda.Stream(device=dev)
 
     def body(self):
-        """The step, launched eagerly (also what the capture records)."""
+        """The step, launched eagerly (also what the capture records).  The model's static-batch settings (device row count,
+        device-side MMD pick, KL kept in the loss head) hold for the duration of the step only: an evaluation forward on
+        another graph between two steps sees the model as it was (the recorded kernels keep what they captured)."""
+        m, enc = self.model, self.model.encoder
         b = self.sampler.sample_static(*self.args, mmd_pick=self.pick)
-        self.model.rows_dev = b.rows_dev
-        if hasattr(self.model.encoder, 'rows_dev'):
-            self.model.encoder.rows_dev = b.rows_dev       # flow_log_prob is a mean over the rows that exist
-        self.opt.zero_grad()
-        embed = self.model(b.g, b.node_id, b.edge_type, b.edge_norm)
-        loss, pred, kl, mmd = self.model.get_loss(b.g, embed, b.samples, b.labels)
-        loss.backward(gradient=self.one.expand_as(loss))
-        self.opt.step()
+        saved = (getattr(m, 'rows_dev', None), getattr(enc, 'rows_dev', None), getattr(enc, 'mmd_index_override', None),
+                 getattr(enc, 'fuse_kl_with_reparam', None))
+        m.rows_dev = b.rows_dev
+        if hasattr(enc, 'rows_dev'):
+            enc.rows_dev = b.rows_dev                      # flow_log_prob is a mean over the rows that exist
+        if self.pick is not None:
+            enc.mmd_index_override = self.pick
+        if hasattr(enc, 'fuse_kl_with_reparam'):
+            enc.fuse_kl_with_reparam = False               # the KL pass needs the device row count: it stays in the loss head here
+        try:
+            self.opt.zero_grad()
+            embed = m(b.g, b.node_id, b.edge_type, b.edge_norm)
+            loss, pred, kl, mmd = m.get_loss(b.g, embed, b.samples, b.labels)
+            loss.backward(gradient=self.one.expand_as(loss))
+            self.opt.step()
+        finally:
+            m.rows_dev = saved[0]
+            if hasattr(enc, 'rows_dev'):
+                enc.rows_dev = saved[1]
+            if self.pick is not None:
+                enc.mmd_index_override = saved[2]
+            if saved[3] is not None:
+                enc.fuse_kl_with_reparam = saved[3]
         self.batch = b
         return loss, pred, kl, mmd
 
@@ -65,9 +82,18 @@ class GraphedMiniBatchStep:
             self.out = self.body()
         return self
 
+    def eager_step(self):
+        """One step launched eagerly ON THE CAPTURE STREAM (autograd pins a parameter's AccumulateGrad node to the stream of its
+        first use; warming up elsewhere would drag that stream into the later capture)."""
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            out = self.body()
+        torch.cuda.current_stream().wait_stream(self.side)
+        return out
+
     def __call__(self):
         """One training step; returns (loss, predict_loss, kl, mmd) as device scalars (static storage: read before the next call)."""
         if self.graph is None:
-            return self.body()
+            return self.eager_step()
         self.graph.replay()
         return self.out

@@ -49,14 +49,26 @@ class FlatAdam:
             ops.DIRECT_GRAD[p.data.data_ptr()] = p.grad      # backward kernels add straight into the arena
             self._direct_keys.append(p.data.data_ptr())
 
+    def close(self):
+        """Withdraw this optimiser's direct-gradient registrations.  Only entries that still point at THIS arena are touched
+        (and the epoch only bumped if any was): an optimiser collected late -- e.g. out of a reference cycle, between a newer
+        optimiser's forward and backward -- must not invalidate the live one's registrations."""
+        mine = False
+        for p in getattr(self, 'params', ()):
+            k = p.data.data_ptr()
+            g = ops.DIRECT_GRAD.get(k)
+            if g is not None and g.data_ptr() >= self.flat_g.data_ptr() and \
+                    g.data_ptr() < self.flat_g.data_ptr() + self.flat_g.numel() * 4:
+                ops.DIRECT_GRAD.pop(k, None)
+                ops.GRAD_FRESH.discard(g.data_ptr())
+                mine = True
+        if mine:
+            ops.DIRECT_EPOCH[0] += 1
+        self._direct_keys = []
+
     def __del__(self):
         try:
-            for k in getattr(self, '_direct_keys', ()):
-                ops.DIRECT_GRAD.pop(k, None)
-            ops.DIRECT_EPOCH[0] += 1
-            for p in getattr(self, 'params', ()):
-                if p.grad is not None:
-                    ops.GRAD_FRESH.discard(p.grad.data_ptr())
+            self.close()
         except Exception:
             pass
 

@@ -146,7 +146,7 @@ def main(args):
     val_graph, val_node_id, val_rel, val_norm = graph_inputs(valid_data)     # eval graph from VALID triplets (:141-147)
     adj_list, degrees = sampling.get_adj_and_degrees(num_nodes, train_data)
     optimizer = FlatAdam(model.parameters(), lr=args.lr, max_grad_norm=args.grad_norm)   # clip + Adam, one arena
-    forward_time, backward_time = [], []
+    forward_time, backward_time, step_time = [], [], []
 
     if args.test_mode is True:
         print("\nstart testing:")
@@ -179,21 +179,25 @@ def main(args):
         if dev_sampler is None:
             raise ValueError('--graph-step records the device sampler with the step: pass --device-sampler too')
         from .graph_step import GraphedMiniBatchStep
+        if args.kl_param <= 0:
+            raise ValueError('--graph-step needs --kl-param > 0 (the captured loss head reads the device row count there)')
         model.train()
         graphed = GraphedMiniBatchStep(model, optimizer, dev_sampler, args.graph_batch_size, args.graph_split_size,
-                                       args.negative_sample).capture()
-        epoch += 3                                   # the capture's eager warm-up steps were training steps
+                                       args.negative_sample)
+        graph_warmup = 3                             # the first steps run eagerly (ordinary epochs: printed, evaluated), then the recording
 
     while True:
         model.train()
         epoch += 1
         if graphed is not None:      # the whole step -- sampling to Adam -- is one hipGraph replay
+            if graphed.graph is None and graph_warmup == 0:
+                graphed.capture(warmup=0)
+            graph_warmup = max(0, graph_warmup - 1)
             _sync()
             t0 = time.time()
             loss, pred_loss, kl, mmd = graphed()
             _sync()
-            forward_time.append(0.0)
-            backward_time.append(time.time() - t0)
+            step_time.append(time.time() - t0)
             print("Epoch {:04d} | Loss {:.4f} | Best MRR {:.4f} | pred_loss {:.4f} | kl {:.4f} | mmd {:.4f}".format(
                 epoch, loss.item(), best_mrr, pred_loss.item(), kl.item(), mmd.item()))
         elif dev_sampler is not None:
@@ -242,8 +246,11 @@ def main(args):
             break
 
     print("training done")
-    print("Mean forward time: {:4f}s".format(np.mean(forward_time)))
-    print("Mean Backward time: {:4f}s".format(np.mean(backward_time)))
+    if step_time:     # the captured step has no forward / backward boundary on the host: one figure
+        print("Mean step time (forward + backward + update, one hipGraph): {:4f}s".format(np.mean(step_time)))
+    else:
+        print("Mean forward time: {:4f}s".format(np.mean(forward_time)))
+        print("Mean Backward time: {:4f}s".format(np.mean(backward_time)))
     return best_mrr
 
 
