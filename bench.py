@@ -6,6 +6,7 @@
                                                         torch.distributed.run job, before it touches the GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--scaling strong|weak]
+    python bench.py --config mb [--n-flows 3]          (the reference's mini-batch regime, one GPU)
 
 Workloads (BASELINE.json configs, all seeded synthetics -- no dataset on disk, no network):
   c2 (default, configs[1]) FB15k-237-shaped: 14 541 entities, 237 relations = 474 directed edge types, 272 115 triplets
@@ -15,6 +16,8 @@ Workloads (BASELINE.json configs, all seeded synthetics -- no dataset on disk, n
      dense products with bf16 operands
   c4 (configs[3]) the c2 graph at emb_dim=500
   c5 (configs[4]) 1 M entities, 1 000 relations, 25 M triplets => 50 M directed edges, emb_dim=200 (generated on the device)
+  mb (configs[1]'s data, the regime of kgvae/README.md:4-7) a fresh 20 000-triplet sample per step: E = 20 000 directed edges,
+     T = 220 000 scored triplets; device sampler + index builders + step replayed as ONE hipGraph
 One step = forward + loss (BCE + 0.01 reg + 1e-5 KL + 1.0 MMD) + backward + grad-clip + Adam, i.e. the reference's
 t0..t2 span (kgvae/link_predict.py:222-229) with device synchronisation.
 --scaling strong (default): ONE graph (seed 0), whatever the rank count: its directed edges are cut by RELATION across the
@@ -54,6 +57,11 @@ CONFIGS = {
                train=272115, hidden=500, bases=100, flows=0, gemm='f32', device_gen=False),
     'c5': dict(idx=4, label='synthetic KG 1M entities / 50M directed edges / 1k relations (BASELINE configs[4])',
                nodes=1_000_000, rels=1000, train=25_000_000, hidden=200, bases=100, flows=0, gemm='f32', device_gen=True),
+    # the regime the reference actually trains in (kgvae/README.md:4-7, kgvae/link_predict.py:200-236): every step samples
+    # 20 000 triplets of the FB15k-237-shaped set, keeps half as the message-passing graph (E = 20 000 directed edges, N ~ 10 k)
+    # and scores all 20 000 x (1 + 10 negatives) = 220 000 triplets; sampler + indices + step are ONE hipGraph replay
+    'mb': dict(idx=1, label='FB15k-237-shaped synthetic, MINI-BATCH regime of kgvae/README.md:4-7 (SURVEY 8(d) C2(i))', nodes=14541,
+               rels=237, train=272115, hidden=200, bases=100, flows=0, gemm='f32', device_gen=False),
 }
 
 
@@ -295,7 +303,7 @@ def cpu_baseline(w, model, args, budget_s, k1_bf16=False):
     torch.set_num_threads(threads)
     state = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and 'mask' not in k and not k.endswith('.pi'))
              for k, v in model.state_dict().items()}
-    n, h = w['data'].num_nodes, args.hidden
+    n, h = int(w['node_id'].shape[0]), args.hidden
     gen = torch.Generator().manual_seed(0)
     eps, eps_prior = torch.randn(n, h, generator=gen), torch.randn(200, h, generator=gen)
     keep1 = (torch.rand(n, h, generator=gen) > args.dropout).to(torch.uint8)
@@ -322,7 +330,12 @@ def cpu_baseline(w, model, args, budget_s, k1_bf16=False):
     while len(times) < 20 and (len(times) < 2 or time.time() - t_start + dt < budget_s):
         dt, enc, loss = one_step()
         times.append(dt)
-    anomaly_dt = one_step(anomaly=True)[0] if time.time() - t_start + 2 * dt < budget_s + 15 else None
+    anomaly_dt = None
+    if time.time() - t_start + 2 * dt < budget_s + 15:
+        try:
+            anomaly_dt = one_step(anomaly=True)[0]
+        except RuntimeError as exc:       # the reference's global anomaly mode turns a NaN in ANY backward function into an exception
+            print(f'[bench] oracle step under set_detect_anomaly(True) raised: {str(exc).splitlines()[0]}', file=sys.stderr)
     E = int(src.numel())
     med = float(np.median(times))
     rec = {'value': E / med, 'unit': 'edges/s', 'cores': threads, 'kind': 'port',
@@ -464,8 +477,129 @@ def launch_check(args):
         dist.destroy_process_group()
 
 
+def run_minibatch(args):
+    """--config mb: the reference's own training regime.  One step = device batch sampler (edge sample -> relabel -> negatives
+    -> split -> (dst, src, rel)-ordered graph) + CSR / relation / triplet index builders + forward + loss + backward + clip +
+    Adam, recorded once and replayed as ONE hipGraph (gcn_vae_amd.graph_step); every replay draws a fresh batch.  Single GPU."""
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 or args.gpus > 1:
+        raise SystemExit('bench.py --config mb is a single-GPU configuration (the sampled sub-graph is 20 000 edges)')
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    if not torch.cuda.is_available():
+        raise RuntimeError('bench.py needs an MI355X (no CPU path); the cpu_baseline leg alone is not a benchmark')
+    from gcn_vae_amd import lib
+    from gcn_vae_amd import ops as _ops
+    from gcn_vae_amd.data import synthetic_kg
+    from gcn_vae_amd.device_sampling import DeviceSampler
+    from gcn_vae_amd.encoders import KGVAE
+    from gcn_vae_amd.graph_step import GraphedMiniBatchStep
+    from gcn_vae_amd.optim import FlatAdam
+    from gcn_vae_amd.train import LinkPredict
+    cfg = CONFIGS['mb']
+    _ops.set_gemm_precision(args.gemm_precision)
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    lib.load()
+    data = synthetic_kg(cfg['nodes'], cfg['rels'], cfg['train'], seed=0)
+    k, split, neg = args.positives, 0.5, args.negative_sample
+    torch.manual_seed(0)
+    model = LinkPredict(KGVAE, data.num_nodes, args.hidden, data.num_rels, num_bases=args.n_bases, num_hidden_layers=2,
+                        dropout=args.dropout, use_cuda=True, reg_param=0.01, kl_param=1e-5, mmd_param=1.0, k=10,
+                        n_flows=args.n_flows).to(dev).train()
+    opt = FlatAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, max_grad_norm=1.0)
+    sm = DeviceSampler(data.train, data.num_nodes, data.num_rels, dev, seed=0)
+    step = GraphedMiniBatchStep(model, opt, sm, k, split, neg)
+    launch = 'eager'
+    if not args.no_graph:
+        step.capture(warmup=3)
+        launch = 'hipgraph (sampler + index builders + step)'
+    else:
+        for _ in range(3):
+            step()
+    cpu_rec = parity_rec = None
+    if not args.no_cpu_baseline:
+        # one batch of the synchronising sampler, BEFORE the timed steps (weights a few updates from their initialisation): the
+        # oracle's step on it (reported baseline) and the HIP step held to it
+        b = sm.sample(k, split, neg)
+        src, dst = b.g.edges()
+        wb = dict(data=_Data(data.num_nodes, data.num_rels, data.train), g=b.g, src=src.cpu(), dst=dst.cpu(), rel=b.edge_type.cpu(),
+                  enorm=b.edge_norm, node_id=b.node_id.cpu(), samples=b.samples.cpu(), labels=b.labels.cpu())
+        cpu_rec, ref = cpu_baseline(wb, model, args, args.cpu_seconds)
+        if not args.no_check:
+            inputs = dict(g=b.g, node_id=b.node_id, etype=b.edge_type, enorm=b.edge_norm, samples=b.samples, labels=b.labels)
+            parity_rec = parity_check(model, opt, inputs, ref, dev, args.gemm_precision == 'bf16')
+    for _ in range(args.warmup):
+        out = step()
+    regions = []
+    for _rep in range(max(1, args.repeats)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        regions.append(time.perf_counter() - t0)
+    elapsed = regions[0]
+    final_loss = float(out[0].detach())
+    E = 2 * int(k * split)                       # directed edges of a batch's message-passing graph
+    T = k * (neg + 1)
+    # ---- K1 launch times of the same step, eager, HIP events (launch-latency regime: reported, not a roofline claim) ------
+    detail = {}
+    if args.profile_steps > 0:
+        lib.TIMER = lib.KernelTimer()
+        for _ in range(args.profile_steps):
+            step.eager_step()
+        ms = lib.TIMER.results_ms()
+        lib.TIMER = None
+        n_rows = min(2 * k, data.num_nodes)
+        for tag, vals in sorted(ms.items()):
+            if tag.startswith('madechain'):
+                continue
+            vals = vals[len(vals) // 3:] if len(vals) >= 3 else vals
+            avg_ms = float(np.mean(vals))
+            nbytes = algorithmic_bytes(tag, E, n_rows, 2 * data.num_rels, T)
+            detail[tag] = {'avg_us': round(avg_ms * 1e3, 2), 'launches': len(vals), 'algorithmic_MB': round(nbytes / 1e6, 2),
+                           'achieved_GBs': round(nbytes / 1e9 / (avg_ms * 1e-3), 1) if avg_ms > 0 else None}
+    rg = {t: d for t, d in detail.items() if t.startswith('agg_') and not t.startswith('agg_N_1x1') and d['achieved_GBs']}
+    roofline = None
+    if rg:
+        dom = min(rg, key=lambda t: rg[t]['achieved_GBs'])
+        roofline = {'kernel': dom, 'bound': 'launch latency (24 MB of algorithmic bytes per launch: SURVEY 8(d) says report, do not '
+                                            'use for the roofline)', 'achieved': rg[dom]['achieved_GBs'], 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': round(rg[dom]['achieved_GBs'] / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'avg_us': rg[dom]['avg_us'], 'algorithmic_MB': rg[dom]['algorithmic_MB']}
+    out_rec = {
+        'metric': 'edges/sec R-GCN forward+backward, FB15k-237 emb=200',
+        'value': E * args.steps / elapsed, 'unit': 'edges/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+        'ms_per_step_median': float(np.median(regions)) / args.steps * 1e3,
+        'ms_per_step_repeats': [round(r / args.steps * 1e3, 5) for r in regions], 'ranks_seen': 1, 'scaling': args.scaling,
+        'vs_baseline': None,
+        'dtype': 'f32' if args.gemm_precision == 'f32' else 'f32 (dense products: bf16 operands, f32 accumulate)',
+        'data': 'synthetic',
+        'config': {'workload': '%s: per step %d triplets sampled uniformly from %d (device sampler), relabelled, %d negatives each '
+                               '=> T=%d scored triplets; split %.1f => E=%d directed edges over ~10k nodes (arrays padded to %d rows); '
+                               '2-layer R-GCN-VAE bdd num_bases=%d emb_dim=%d dropout %.1f, %d IAF blocks; step = sampling + index '
+                               'build + fwd + loss(BCE+reg+KL+MMD) + bwd + clip + Adam'
+                               % (cfg['label'], k, len(data.train), neg, T, split, E, min(2 * k, data.num_nodes), args.n_bases,
+                                  args.hidden, args.dropout, args.n_flows),
+                   'baseline_config': 'configs[1], mini-batch regime', 'edges_per_gpu': E, 'trained_graph_edges': E,
+                   'nodes': data.num_nodes, 'triplets_per_gpu': T, 'n_flows': args.n_flows, 'gemm_precision': args.gemm_precision,
+                   'launch': launch, 'parallelism': 'single GPU'},
+        'final_loss': final_loss, 'roofline': roofline, 'roofline_detail': detail, 'roofline_k4': None, 'k1_GBs_per_rank': None,
+        'cpu_baseline': cpu_rec, 'parity_check': parity_rec,
+    }
+    if parity_rec is not None:
+        out_rec['parity_max_rel_err'] = parity_rec['parity_max_rel_err']
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    print(json.dumps(out_rec), flush=True)
+
+
 def main():
     args = parse()
+    if args.config == 'mb':
+        return run_minibatch(args)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args.gpus))       # before any HIP call in this process
     if args.launch_check:

@@ -29,6 +29,11 @@ __global__ void k_iota_narrow(int* x, const int* keys, unsigned short* k16, int6
     if (i < n) { x[i] = (int)i; k16[i] = (unsigned short)keys[i]; }
 }
 
+__global__ void k_iota_copy(int* x, const int* keys, int* copy, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { x[i] = (int)i; copy[i] = keys[i]; }
+}
+
 // rowptr[s] = number of sorted keys < s  (s = 0 .. n_seg)
 template <typename KeyT>
 __global__ void k_lower_bounds(const KeyT* keys_sorted, int64_t n, int n_seg, int* rowptr) {
@@ -121,6 +126,24 @@ inline int bits_for(int n_seg) {
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+struct KeyLess {
+    template <typename T>
+    __host__ __device__ bool operator()(const T& a, const T& b) const { return a < b; }
+};
+
+// rocPRIM's onesweep radix sort clears its counters with hipMemsetAsync, which a hipGraph records as MEMSET NODES; on this
+// stack such nodes can replay with stale parameters once other runtime work ran between two replays ('Memory access fault by
+// GPU').  While the stream is being captured the orderings therefore come from rocPRIM's merge sort (kernels only; ~10
+// passes instead of 3); GV_INDEX_SORT = radix | merge overrides.
+bool use_merge_sort(hipStream_t st) {
+    const char* mode = getenv("GV_INDEX_SORT");      // read per build (tests flip it)
+    if (mode && mode[0] == 'r') return false;
+    if (mode && mode[0] == 'm') return true;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs == hipStreamCaptureStatusActive;
+}
+
 size_t cub_temp_bytes(int64_t n, int n_seg) {
     size_t a = 0, b = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const int*)nullptr, (int*)nullptr, (const int*)nullptr, (int*)nullptr,
@@ -130,6 +153,11 @@ size_t cub_temp_bytes(int64_t n, int n_seg) {
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, c, (const unsigned short*)nullptr, (unsigned short*)nullptr, (const int*)nullptr,
                                              (int*)nullptr, (int)n, 0, 16);
     a = a > c ? a : c;
+    size_t d = 0, e = 0;      // the merge-sort form (no memset nodes: used while the stream is being captured)
+    (void)hipcub::DeviceMergeSort::StableSortPairs(nullptr, d, (unsigned short*)nullptr, (int*)nullptr, (int)n, KeyLess(), (hipStream_t)0);
+    (void)hipcub::DeviceMergeSort::StableSortPairs(nullptr, e, (int*)nullptr, (int*)nullptr, (int)n, KeyLess(), (hipStream_t)0);
+    d = d > e ? d : e;
+    a = a > d ? a : d;
     return align256(a > b ? a : b);
 }
 
@@ -165,7 +193,21 @@ int order_and_items(const int* keys, int64_t n, int n_seg, int chunk, int* perm,
                     int* fix, int fix_cap, const Scratch& sc, hipStream_t st) {
     const int* sorted = keys;
     const unsigned short* sorted16 = nullptr;
-    if (perm && n >= 100000 && n_seg <= 65536) {      // 2-byte keys: the two halves of the keys_sorted area hold them (in / out)
+    if (perm && n > 0 && use_merge_sort(st)) {      // stable merge sort in place: (keys, perm = iota); no memset / memcpy nodes
+        size_t tb = sc.cub_bytes;
+        if (n_seg <= 65536) {
+            unsigned short* k16 = (unsigned short*)sc.keys_sorted;
+            hipLaunchKernelGGL(k_iota_narrow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, perm, keys, k16, n);
+            GV_HIP_OK(hipcub::DeviceMergeSort::StableSortPairs(sc.cub, tb, k16, perm, (int)n, KeyLess(), st),
+                      "gv index: merge sort (16-bit keys)");
+            sorted16 = k16;
+        } else {
+            hipLaunchKernelGGL(k_iota_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, perm, keys, sc.keys_sorted, n);
+            GV_HIP_OK(hipcub::DeviceMergeSort::StableSortPairs(sc.cub, tb, sc.keys_sorted, perm, (int)n, KeyLess(), st),
+                      "gv index: merge sort");
+            sorted = sc.keys_sorted;
+        }
+    } else if (perm && n >= 100000 && n_seg <= 65536) {      // 2-byte keys: the two halves of the keys_sorted area hold them (in / out)
         // the area is align256(4 n) bytes; the output half starts n shorts in, rounded up to 16 B: it ends at most
         // 4 n + 14 bytes in, and whenever that rounding adds anything (n % 8 = m > 0) the area's own padding,
         // 256 - 4 (n % 64) >= 32 - 4 m bytes, covers the 16 - 2 m added -- the sort never writes into sc.iota behind it

@@ -198,15 +198,15 @@ class KGVAE(ops.StayOnDevice, nn.Module):
         n = z.shape[0]
         ride_along = self.batch_mmd_prior_with_forward and self.training
         if ride_along:
-            z = torch.cat([z, self._prior_draw(z.device, z.dtype)], dim=0)
+            z = ops.cat_rows(z, self._prior_draw(z.device, z.dtype))      # (kernel copies: no memcpy node in a captured step)
         log_det_sum = None
         for flow in self.nf:
             z, log_det = flow.forward(z)
             if isinstance(flow, MADE):            # PermuteLayer contributes zeros
                 log_det_sum = log_det if log_det_sum is None else log_det_sum + log_det
-        if ride_along:
-            self._z_pri_flowed = z[n:]
-            z, log_det_sum = z[:n], log_det_sum[:n]
+        if ride_along:      # (ops.split_rows: the slices' backward without a memcpy node in a captured step)
+            z, self._z_pri_flowed = ops.split_rows(z, n)
+            log_det_sum = ops.split_rows(log_det_sum, n)[0]
         return z, log_det_sum
 
     def forward(self, g, h, r, norm):

@@ -1141,6 +1141,73 @@ def axpby(alpha, x, beta=0.0, y=None, a=None):
     return y
 
 
+def copy_into(dst, src):
+    """dst <- src (contiguous fp32, same size) as an ordinary KERNEL.  torch's copy_ / clone / cat of contiguous tensors go through
+    hipMemcpyAsync, which a hipGraph records as a memcpy NODE -- and on this stack such a node can replay with stale parameters
+    after any other runtime work between two replays ('Memory access fault by GPU'; DESIGN.md, hipGraph hazards).  Nothing on
+    a capturable path may copy that way."""
+    src = _chk(src.contiguous(), name='src')
+    if dst.numel() != src.numel() or not dst.is_contiguous():
+        raise ValueError('copy_into: same size, contiguous destination')
+    lib.call('gv_axpby', src.numel(), None, 1.0, ptr(src), 0.0, ptr(dst), lib.stream())
+    return dst
+
+
+def copy_of(x):
+    return copy_into(torch.empty_like(x, memory_format=torch.contiguous_format), x)
+
+
+class _CatRows(torch.autograd.Function):
+    """torch.cat([a, b], dim=0) of two (rows, d) matrices with kernel copies (see copy_into)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty(a.shape[0] + b.shape[0], a.shape[1], dtype=torch.float32, device=a.device)
+        copy_into(out[:a.shape[0]], a)
+        copy_into(out[a.shape[0]:], b)
+        ctx.na = a.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:ctx.na], g[ctx.na:]
+
+
+def cat_rows(a, b):
+    return _CatRows.apply(a, b)
+
+
+class _SplitRows(torch.autograd.Function):
+    """(x[:n], x[n:]) whose backward assembles the gradient with kernel copies: autograd's own SliceBackward is zeros + copy_,
+    i.e. a memcpy node in a captured step (see copy_into)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.shape = int(n), tuple(x.shape)
+        ctx.set_materialize_grads(False)
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None
+        ref = ga if ga is not None else gb
+        out = torch.empty(ctx.shape, dtype=ref.dtype, device=ref.device)
+        for part, g in ((out[:ctx.n], ga), (out[ctx.n:], gb)):
+            if part.numel() == 0:
+                continue
+            if g is None:
+                part.zero_()
+            else:
+                copy_into(part, g)
+        return out, None
+
+
+def split_rows(x, n):
+    """The first ``n`` rows of ``x`` and the rest (differentiable; capturable)."""
+    return _SplitRows.apply(x, n)
+
+
 def mul(a, b):
     a, b = _chk(a.contiguous(), name='a'), _chk(b.contiguous(), name='b')
     out = torch.empty_like(a)
@@ -1435,7 +1502,7 @@ class _RelGraphConvBdd(torch.autograd.Function):
         pending = None
         g_agg = g
         if reduce_hook is not None:      # gradient of this rank's partial aggregate = sum over ranks; overlapped below
-            g_agg = g.clone()
+            g_agg = copy_of(g)
             pending = reduce_hook(g_agg)
         grad_loop = gx_loop = None
         if loop_weight is not None:
@@ -2168,7 +2235,7 @@ class _KL(torch.autograd.Function):
         gzp = d_zp if d_zp is not None else torch.empty_like(z_pre)
         lib.call('gv_kl_bwd', ptr(z), ptr(m), h, ptr(v), ptr(z_pre), ptr(resp), ptr(gkl), 1.0, 0.0, ptr(gz), ptr(gm), ptr(gv),
                  ptr(gzp), 1 if d_zp is not None else 0, ptr(ws), 1, n, h, k, None, lib.stream())
-        return gz, gm, gv, (None if d_zp is not None else gzp), (gkl.reshape(()).clone() if ctx.has_flp else None)
+        return gz, gm, gv, (None if d_zp is not None else gzp), (copy_of(gkl.reshape(1)).reshape(()) if ctx.has_flp else None)
 
 
 def kl_to_mixture(z, m, v, z_pre, flp=None):

@@ -1008,7 +1008,10 @@ def _same_items(a, b):
                                                      (300, 5000, 12, False, None), (2000, 60000, 474, True, None),
                                                      (120, 9000, 30, True, 700), (97, 4001, 7, False, 350),
                                                      (3000, 150000, 60, False, None)])       # >= 100 000 entries: the 16-bit-key sort path
-def test_native_index_build_equals_torch_formulation(ops, n, e, r, sorted_dst, n_src):
+@pytest.mark.parametrize('sort', ['radix', 'merge'])
+def test_native_index_build_equals_torch_formulation(ops, monkeypatch, n, e, r, sorted_dst, n_src, sort):
+    # 'merge': the memset-free form the builders switch to while their stream is being captured (csrc/k_index.hip)
+    monkeypatch.setenv('GV_INDEX_SORT', sort)
     rs = np.random.RandomState(n + e)
     ns = n if n_src is None else n_src
     p = (np.arange(n) + 1.0) ** -1.2
@@ -1041,8 +1044,10 @@ def test_native_index_build_equals_torch_formulation(ops, n, e, r, sorted_dst, n
     assert torch.equal(rn.by_rel.perm, rt.by_rel.perm) and _same_items(rn.by_rel.seg, rt.by_rel.seg)
 
 
+@pytest.mark.parametrize('sort', ['radix', 'merge'])
 @pytest.mark.parametrize('T,n_ent,n_rel', [(0, 10, 3), (1, 5, 2), (5000, 300, 7), (220000, 10000, 237)])
-def test_native_triplet_index_equals_torch_formulation(ops, T, n_ent, n_rel):
+def test_native_triplet_index_equals_torch_formulation(ops, monkeypatch, T, n_ent, n_rel, sort):
+    monkeypatch.setenv('GV_INDEX_SORT', sort)
     rs = np.random.RandomState(T + 1)
     p = (np.arange(n_ent) + 1.0) ** -1.0
     trip = np.stack([rs.choice(n_ent, size=T, p=p / p.sum()), rs.randint(0, n_rel, size=T), rs.randint(0, n_ent, size=T)], 1)
