@@ -246,7 +246,8 @@ def pmc_traffic_for(tag, config='c2'):
         return None, None
     tr, blk, _ = rest.split('_')
     p, q = blk.split('x')
-    pat = re.compile(r'k_agg_(fast|packed|phase)<%s, ?%s, ?%s,' % (p, q, 'true' if tr == 'T' else 'false'))
+    # (the LDS-resident kernel's name carries no orientation -- its packing does: both directions of a square block share it)
+    pat = re.compile(r'k_agg_(fast|packed|phase|split)<%s, ?%s, ?%s,|k_agg_lds<%s, ?%s,' % (p, q, 'true' if tr == 'T' else 'false', p, q))
     best, src = None, None
     paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*', f'pmc_traffic_{config}.json')))
     if config == 'c2':

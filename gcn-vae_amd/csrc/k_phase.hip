@@ -51,11 +51,13 @@ __device__ __forceinline__ float prl_f(float v, int lane) {
 // asm on purpose: hipcc does not count it, so its waits for the feature gathers stay COUNTED (vmcnt(U-1)) instead of
 // draining to vmcnt(0) as they do beside a builtin LDS-DMA; the gathers are younger than the phase's DMAs, so every such
 // wait still covers them, and the phase ends with an explicit vmcnt(0) before the barrier (cdna_hip_programming.md 5.7).
-__device__ __forceinline__ void glds16(const float4* gsrc, unsigned lds_byte_addr) {
+__device__ __forceinline__ void glds16(const float4* gbase, unsigned byte_off, unsigned lds_byte_addr) {
+    // scalar base + 32-bit per-lane byte offset: no 64-bit per-lane pointer stays live across the launch (it was the one
+    // value the 128-register kernels spilled)
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_byte_addr)
+                 : "v"(byte_off), "s"(gbase), "s"(lds_byte_addr)
                  : "memory");
 }
 
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(1024) void k_agg_phase(const PhaseParams a) {
         const float4* src = wsrc + (size_t)r0 * rel_quads;
         const unsigned dst = lds_base + (unsigned)(b * a.slab) * 16u;
         for (int i = wv * 64; i < total; i += nw * 64)
-            glds16(src + i + lane, __builtin_amdgcn_readfirstlane(dst + (unsigned)i * 16u));
+            glds16(src, (unsigned)(i + lane) * 16u, __builtin_amdgcn_readfirstlane(dst + (unsigned)i * 16u));
     };
 
     float acc[K][PV];
