@@ -250,6 +250,34 @@ __global__ __launch_bounds__(1024) void k_agg_lds(const LdsAggParams a) {
     };
     xvec x0, x1;
     issue_x(mA.n, 0, cntA, x0);
+    // rows without edges: epilogue of a zero aggregate, four rows' operands in flight -- done FIRST, while the weight copy
+    // lands (they need no weights)
+    for (long long base = gw; base < a.n_empty; base += 64ll * nwaves) {
+        int myrow = -1;
+        {
+            const long long i0 = base + (long long)lane * nwaves;
+            if (i0 < a.n_empty) myrow = a.empty[i0];
+        }
+        const int nk = (int)min(64ll, (a.n_empty - base + nwaves - 1) / nwaves);
+        for (int k = 0; k < nk; k += 4) {
+            int rows[4];
+            Epi e[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                rows[t] = (k + t < nk) ? lrl_i(myrow, min(k + t, 63)) : -1;
+                e[t] = load_epi(rows[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (rows[t] >= 0) {
+                    float v[EW];
+#pragma unroll
+                    for (int i = 0; i < EW; ++i) v[i] = 0.f;
+                    store_row(rows[t], e[t], v);
+                }
+            }
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the weight copy (the compiler does not count the DMAs)
     __syncthreads();
     bool moreC = fetch(grab(), slotC, begC, cntC);
@@ -333,33 +361,6 @@ __global__ __launch_bounds__(1024) void k_agg_lds(const LdsAggParams a) {
             if (step(x1, x0)) break;
         }
     }
-    // rows without edges: epilogue of a zero aggregate, four rows' operands in flight
-    for (long long base = gw; base < a.n_empty; base += 64ll * nwaves) {
-        int myrow = -1;
-        {
-            const long long i0 = base + (long long)lane * nwaves;
-            if (i0 < a.n_empty) myrow = a.empty[i0];
-        }
-        const int nk = (int)min(64ll, (a.n_empty - base + nwaves - 1) / nwaves);
-        for (int k = 0; k < nk; k += 4) {
-            int rows[4];
-            Epi e[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                rows[t] = (k + t < nk) ? lrl_i(myrow, min(k + t, 63)) : -1;
-                e[t] = load_epi(rows[t]);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (rows[t] >= 0) {
-                    float v[EW];
-#pragma unroll
-                    for (int i = 0; i < EW; ++i) v[i] = 0.f;
-                    store_row(rows[t], e[t], v);
-                }
-            }
-        }
-    }
 }
 
 // row layout [R][nb * bi * bo] -> [parts][R][NQ][CL] float4, CL = the kernel's lanes up to the last used one.  Lane (slot, g) of a part owns block
@@ -430,6 +431,8 @@ bool lds_plan(int nb, int p, int q, int num_rels, bool bf, LdsPlan* out) {
         else if (p == 20 && q == 10) { ipl = 4; oh = 1; bpp = 10; }
         else return false;
     }
+    static const int u_env = getenv("GV_K1_LDS_U") ? atoi(getenv("GV_K1_LDS_U")) : 0;      // tuning knob: 6 = longer steps
+    if (u_env == 6 && bpp * q == 100) { u = 6; kb = 10; }
     if (nb % bpp) return false;
     const int slots = bpp * oh, cl = 16 * ((slots - 1) / 3) + 5 * ((slots - 1) % 3) + p / ipl;      // table columns = lanes
     const int opl = q / oh, nw = bf ? (ipl / 2) * opl : ipl * opl, nq = (nw + 3) / 4, po = bpp * q;
@@ -543,6 +546,10 @@ extern "C" int gv_rgcn_bdd_aggregate_lds(const int32_t* sitems, int n_sitems, co
         rc = launch_status("gv_rgcn_bdd_aggregate_lds");                                                               \
     }
     GV_LDS_CASE(10, 10, 2, 1, 10, 4, 8, false)
+    GV_LDS_CASE(10, 10, 2, 1, 10, 6, 10, false)
+    GV_LDS_CASE(10, 20, 2, 2, 5, 6, 10, false)
+    GV_LDS_CASE(10, 10, 2, 1, 10, 6, 10, true)
+    GV_LDS_CASE(20, 10, 4, 1, 10, 6, 10, true)
     GV_LDS_CASE(10, 20, 2, 2, 5, 4, 8, false)
     GV_LDS_CASE(20, 10, 4, 2, 5, 4, 8, false)
     GV_LDS_CASE(10, 10, 2, 1, 10, 4, 8, true)
