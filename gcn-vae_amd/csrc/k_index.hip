@@ -71,6 +71,280 @@ __global__ void k_items_fill_packed(const int* rowptr, int n_seg, int chunk, con
     if (nch > 1 && o.c < fix_cap) fix[o.c] = make_int4(s, o.b, nch, 0);
 }
 
+// ---- own stable LSD radix sort for segment ids below 65 536 -------------------------------------------------------------
+// Kernels only (nothing a hipGraph would record as a memset / memcpy node) and few of them: a batch's index is ~0.3-0.7 M
+// entries, so every pass is launch-latency bound and what counts is the number of dependent launches -- per pass one
+// histogram kernel and one scatter kernel that redoes the (tiny) cross-block scan itself; ids of <= 9 bits sort in one pass.
+// A block owns `tile` consecutive entries, a wave tile/16 consecutive ones of those, so (digit, block, wave, lane) order is
+// input order and the sort is stable.
+constexpr int RS_T = 1024, RS_W = 16, RS_MAXB = 512;
+
+template <typename KIn>
+__global__ __launch_bounds__(1024) void k_rs_hist(const KIn* keys, int n, int tile, int shift, int nbits, int* hist) {
+    __shared__ int bins[RS_MAXB];
+    const int nbins = 1 << nbits;
+    for (int d = threadIdx.x; d < nbins; d += RS_T) bins[d] = 0;
+    __syncthreads();
+    const int b = blockIdx.x, B = gridDim.x;
+    const int beg = b * tile, end = min(n, beg + tile);
+    for (int i = beg + threadIdx.x; i < end; i += RS_T) atomicAdd(&bins[((int)keys[i] >> shift) & (nbins - 1)], 1);
+    __syncthreads();
+    for (int d = threadIdx.x; d < nbins; d += RS_T) hist[d * B + b] = bins[d];      // [digit][block]: the scan order
+}
+
+// one more array carried through the final pass's permutation (the gathers the builders need anyway)
+struct RsCarry {
+    const int* src[3];
+    int* out[3];
+};
+
+// MAXR = the most rounds (64 entries per wave each) a wave makes over its share of the tile; keys / values sit in registers from
+// one batch of loads.  The pass is bound by memory TRANSACTIONS, not bytes (a wave's 64 entries go to ~64 different lines), so
+// with MAXR = 4 (tiles of <= 4096 entries: everything up to 0.5 M entries) the block first puts its tile in digit order in LDS
+// and then writes it out with consecutive threads on consecutive addresses (runs of tile / nbins entries per digit).
+template <typename KIn, bool IOTA, int MAXR>
+__global__ __launch_bounds__(1024) void k_rs_scatter(const KIn* keys, const int* vals, int n, int tile, int shift, int nbits,
+                                                     const int* hist, unsigned short* keys_out, int* vals_out, RsCarry carry) {
+    constexpr bool STAGE = MAXR <= 4;
+    constexpr int STAGED = STAGE ? MAXR * RS_T : 1;
+    __shared__ int wh[RS_W][RS_MAXB];      // per (wave, digit): count, then the wave's first position for the digit
+    __shared__ int tot[RS_MAXB];           // per digit: entries in all blocks, then this block's first GLOBAL position (- local, staged)
+    __shared__ int pre[RS_MAXB];           // per digit: entries in the blocks before this one
+    __shared__ int ltot[RS_MAXB];          // per digit: entries in this block
+    __shared__ int sval[STAGED];
+    __shared__ unsigned short skey[STAGED];
+    const int nbins = 1 << nbits, mask = nbins - 1;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, b = blockIdx.x, B = gridDim.x;
+    const int beg = b * tile, end = min(n, beg + tile);
+    const int rounds = tile / RS_T;
+    const int wbeg = beg + w * rounds * 64 + lane;
+    int kreg[MAXR], vreg[MAXR], preg[MAXR];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int i = wbeg + r * 64;
+        const bool valid = r < rounds && i < end;
+        kreg[r] = valid ? (int)keys[i] : -1;
+        vreg[r] = IOTA ? i : (valid ? vals[i] : 0);
+    }
+    for (int i = t; i < RS_W * RS_MAXB; i += RS_T) (&wh[0][0])[i] = 0;
+    {   // the [digit][block] histogram: G = 1024 / nbins threads per digit (nbins in 16 .. 512)
+        const int G = RS_T >> nbits;
+        const int d = t / G, j = t - d * G;
+        int ts = 0, ps = 0;
+        for (int bb0 = j; bb0 < B; bb0 += 8 * G) {      // eight loads in flight: other XCDs wrote these, they come from memory
+            int h[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int bb = bb0 + k * G;
+                h[k] = bb < B ? hist[d * B + bb] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                ts += h[k];
+                ps += bb0 + k * G < b ? h[k] : 0;
+            }
+        }
+        for (int o = 1; o < G; o <<= 1) {
+            ts += __shfl_xor(ts, o);
+            ps += __shfl_xor(ps, o);
+        }
+        if (j == 0) { tot[d] = ts; pre[d] = ps; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r)
+        if (kreg[r] >= 0) atomicAdd(&wh[w][(kreg[r] >> shift) & mask], 1);
+    __syncthreads();
+    if (t < nbins) {      // counts -> exclusive prefix over the waves
+        int run = 0;
+        for (int ww = 0; ww < RS_W; ++ww) {
+            const int c = wh[ww][t];
+            wh[ww][t] = run;
+            run += c;
+        }
+        ltot[t] = run;
+    }
+    __syncthreads();
+    if (w == 0) {   // exclusive scans over the digits: all blocks' totals (global start of a digit) and this block's (local start)
+        const int per = nbins > 64 ? nbins >> 6 : 1;
+        int gl[8], lo[8], gs = 0, ls = 0;
+        for (int k = 0; k < 8; ++k) {
+            const int d = lane * per + k;
+            const bool in = k < per && d < nbins;
+            gl[k] = in ? tot[d] : 0;
+            lo[k] = in ? ltot[d] : 0;
+            gs += gl[k];
+            ls += lo[k];
+        }
+        int ginc = gs, linc = ls;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int gv_ = __shfl_up(ginc, o), lv = __shfl_up(linc, o);
+            if (lane >= o) { ginc += gv_; linc += lv; }
+        }
+        int grun = ginc - gs, lrun = linc - ls;
+        for (int k = 0; k < 8; ++k) {
+            const int d = lane * per + k;
+            if (k < per && d < nbins) {
+                const int gstart = grun + pre[d];                 // where this block's entries of digit d start in the output
+                tot[d] = STAGE ? gstart - lrun : gstart;          // staged: output position = position in the tile + tot[d]
+                ltot[d] = STAGE ? lrun : 0;
+                grun += gl[k];
+                lrun += lo[k];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        if (r >= rounds) break;                       // uniform
+        const bool valid = kreg[r] >= 0;
+        const int d = (kreg[r] >> shift) & mask;
+        unsigned long long peers = __ballot(valid);
+        for (int bit = 0; bit < nbits; ++bit) {
+            const bool set = (d >> bit) & 1;
+            const unsigned long long bm = __ballot(valid && set);
+            peers &= set ? bm : ~bm;
+        }
+        const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+        volatile int* c = &wh[w][d];
+        const int base = valid ? *c : 0;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) *c = base + __popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        preg[r] = base + rank + (STAGE ? ltot[d] : tot[d]);
+    }
+    if constexpr (STAGE) {
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            if (kreg[r] < 0) continue;
+            skey[preg[r]] = (unsigned short)kreg[r];
+            sval[preg[r]] = vreg[r];
+        }
+        __syncthreads();
+        const int count = end - beg;
+        int pos[MAXR], cr[3][MAXR];
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            const int j = r * RS_T + t;
+            const bool valid = j < count;
+            kreg[r] = valid ? (int)skey[j] : -1;
+            vreg[r] = valid ? sval[j] : 0;
+            pos[r] = j + tot[(kreg[r] >> shift) & mask];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {      // all gathers of the carried arrays before any store (loads and stores share one counter)
+            if (!carry.src[a]) continue;
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) cr[a][r] = kreg[r] >= 0 ? carry.src[a][vreg[r]] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            if (kreg[r] < 0) continue;
+            keys_out[pos[r]] = (unsigned short)kreg[r];
+            vals_out[pos[r]] = vreg[r];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (!carry.src[a]) continue;
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r)
+                if (kreg[r] >= 0) carry.out[a][pos[r]] = cr[a][r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            if (kreg[r] < 0) continue;
+            keys_out[preg[r]] = (unsigned short)kreg[r];
+            vals_out[preg[r]] = vreg[r];
+            if (carry.src[0]) carry.out[0][preg[r]] = carry.src[0][vreg[r]];
+            if (carry.src[1]) carry.out[1][preg[r]] = carry.src[1][vreg[r]];
+            if (carry.src[2]) carry.out[2][preg[r]] = carry.src[2][vreg[r]];
+        }
+    }
+}
+
+// work-item counts, their exclusive scan, the item / fix-up lists and the -1 padding behind them in ONE launch (n_seg <=
+// 65 536): a block owns 1024 consecutive segments and adds up the counts of all segments before its own itself (the rowptr is
+// <= 256 KB and L2-resident: cheaper than a scan kernel in between).  Same lists as k_item_counts + scan + k_items_fill_packed.
+__device__ inline Tri item_count(int deg, int chunk, int chunk_shift) {
+    const int nch = max(1, chunk_shift >= 0 ? (deg + chunk - 1) >> chunk_shift : (deg + chunk - 1) / chunk);
+    return Tri{nch, nch > 1 ? nch : 0, nch > 1 ? 1 : 0};
+}
+
+__device__ inline Tri tri_shfl_up(const Tri& v, int o) { return Tri{__shfl_up(v.a, o), __shfl_up(v.b, o), __shfl_up(v.c, o)}; }
+__device__ inline Tri tri_shfl_xor(const Tri& v, int o) { return Tri{__shfl_xor(v.a, o), __shfl_xor(v.b, o), __shfl_xor(v.c, o)}; }
+
+__global__ __launch_bounds__(1024) void k_items_blocks(const int* rowptr, int n_seg, int chunk, int chunk_shift, int4* items,
+                                                       int items_cap, int4* fix, int fix_cap) {
+    __shared__ Tri red[3][RS_W];
+    __shared__ int s_oa[RS_T + 1], s_ob[RS_T], s_beg[RS_T], s_end[RS_T];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int base = blockIdx.x * RS_T;
+    Tri before{0, 0, 0}, total{0, 0, 0};
+    for (int s0 = 0; s0 < n_seg; s0 += 8 * RS_T) {      // eight independent pairs of loads in flight
+        int lo[8], hi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int s = s0 + k * RS_T + t;
+            lo[k] = s < n_seg ? rowptr[s] : 0;
+            hi[k] = s < n_seg ? rowptr[s + 1] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int s = s0 + k * RS_T + t;
+            if (s >= n_seg) continue;
+            const Tri c = item_count(hi[k] - lo[k], chunk, chunk_shift);
+            total = total + c;
+            if (s < base) before = before + c;
+        }
+    }
+    const int s = base + t;
+    const int beg = s < n_seg ? rowptr[s] : 0, end = s < n_seg ? rowptr[s + 1] : 0;
+    const Tri mine = s < n_seg ? item_count(end - beg, chunk, chunk_shift) : Tri{0, 0, 0};
+    Tri inc = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const Tri v = tri_shfl_up(inc, o);
+        if (lane >= o) inc = inc + v;
+        before = before + tri_shfl_xor(before, o);
+        total = total + tri_shfl_xor(total, o);
+    }
+    if (lane == 63) { red[0][w] = inc; red[1][w] = before; red[2][w] = total; }
+    __syncthreads();
+    Tri o{inc.a - mine.a, inc.b - mine.b, inc.c - mine.c}, first{0, 0, 0}, tot{0, 0, 0};
+    int block_items = 0;
+    for (int ww = 0; ww < RS_W; ++ww) {
+        if (ww < w) o = o + red[0][ww];
+        block_items += red[0][ww].a;
+        first = first + red[1][ww];
+        tot = tot + red[2][ww];
+    }
+    // the lists are written item by item (a relation's or a hub's row is hundreds of items): item i of this block belongs to the
+    // last segment whose first item is <= i
+    s_oa[t] = o.a;
+    s_ob[t] = o.b + first.b;
+    s_beg[t] = beg;
+    s_end[t] = end;
+    if (t == 0) s_oa[RS_T] = block_items;
+    __syncthreads();
+    const int nch = mine.a;
+    if (nch > 1 && o.c + first.c < fix_cap) fix[o.c + first.c] = make_int4(s, o.b + first.b, nch, 0);
+    for (int i = t; i < block_items; i += RS_T) {
+        int lo = 0, hi = RS_T;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_oa[mid] <= i) lo = mid + 1; else hi = mid;
+        }
+        const int seg = lo - 1, k = i - s_oa[seg], n_it = s_oa[seg + 1] - s_oa[seg];
+        const int bb = s_beg[seg] + k * chunk;
+        if (first.a + i < items_cap)
+            items[first.a + i] = make_int4(base + seg, bb, min(s_end[seg], bb + chunk), n_it > 1 ? s_ob[seg] + k : -1);
+    }
+    const int4 none = make_int4(-1, -1, -1, -1);
+    const int stride = gridDim.x * RS_T;
+    for (int i = tot.a + base + t; i < items_cap; i += stride) items[i] = none;
+    for (int i = tot.c + base + t; i < fix_cap; i += stride) fix[i] = none;
+}
+
 __global__ void k_gather3_i32(const int* s1, int* o1, const int* s2, int* o2, const int* s3, int* o3, const int* idx, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -87,9 +361,12 @@ __global__ void k_fill2_u32(unsigned* p1, long long n1, unsigned* p2, long long 
     }
 }
 
-__global__ void k_gather_i32(const int* src, const int* idx, int* out, int64_t n) {
+// one array through two permutations (idx NULL = identity)
+__global__ void k_gather_two_i32(const int* src, const int* idx1, int* out1, const int* idx2, int* out2, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = idx ? src[idx[i]] : src[i];
+    if (i >= n) return;
+    out1[i] = idx1 ? src[idx1[i]] : src[i];
+    out2[i] = idx2 ? src[idx2[i]] : src[i];
 }
 
 // triplet incidence list: entry i < T = (subject, object, rel, i); entry T + i = (object, subject, rel, i)
@@ -131,17 +408,42 @@ struct KeyLess {
     __host__ __device__ bool operator()(const T& a, const T& b) const { return a < b; }
 };
 
-// rocPRIM's onesweep radix sort clears its counters with hipMemsetAsync, which a hipGraph records as MEMSET NODES; on this
-// stack such nodes can replay with stale parameters once other runtime work ran between two replays ('Memory access fault by
-// GPU').  While the stream is being captured the orderings therefore come from rocPRIM's merge sort (kernels only; ~10
-// passes instead of 3); GV_INDEX_SORT = radix | merge overrides.
-bool use_merge_sort(hipStream_t st) {
+// Which sort orders the entries.  'own' (k_rs_*, above) whenever the ids fit 16 bits and the entries fit <= 512 tiles: the same
+// kernels eagerly and under capture.  Otherwise rocPRIM: its onesweep radix sort clears its counters with hipMemsetAsync,
+// which a hipGraph records as MEMSET NODES, and on this stack such nodes can replay with stale parameters once other runtime
+// work ran between two replays ('Memory access fault by GPU') -- so while the stream is being captured the fallback is
+// rocPRIM's merge sort (kernels only; ~10 passes instead of 3).  GV_INDEX_SORT = own | radix | merge overrides (tests).
+struct RsPlan {
+    int tile, blocks, passes, bits[2];
+};
+
+bool rs_plan(int64_t n, int n_seg, RsPlan& p) {
+    if (n <= 0 || n_seg > 65536) return false;
+    int64_t tile = (((n + 127) / 128) + RS_T - 1) / RS_T * RS_T;
+    tile = tile < RS_T ? RS_T : (tile > 16384 ? 16384 : tile);
+    const int64_t blocks = (n + tile - 1) / tile;
+    if (blocks > 512) return false;
+    p.tile = (int)tile;
+    p.blocks = (int)blocks;
+    int bits = 1;
+    while ((1ll << bits) < (long long)n_seg) ++bits;
+    bits = bits < 4 ? 4 : bits;
+    if (bits <= 9) { p.passes = 1; p.bits[0] = bits; p.bits[1] = 0; }
+    else { p.passes = 2; p.bits[0] = (bits + 1) / 2; p.bits[1] = bits - p.bits[0]; }
+    return true;
+}
+
+enum SortMode { SORT_OWN, SORT_RADIX, SORT_MERGE };
+
+SortMode sort_mode(hipStream_t st, int64_t n, int n_seg) {
     const char* mode = getenv("GV_INDEX_SORT");      // read per build (tests flip it)
-    if (mode && mode[0] == 'r') return false;
-    if (mode && mode[0] == 'm') return true;
+    if (mode && mode[0] == 'r') return SORT_RADIX;
+    if (mode && mode[0] == 'm') return SORT_MERGE;
+    RsPlan p;
+    if (rs_plan(n, n_seg, p)) return SORT_OWN;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return cs == hipStreamCaptureStatusActive;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return SORT_RADIX; }
+    return cs == hipStreamCaptureStatusActive ? SORT_MERGE : SORT_RADIX;
 }
 
 size_t cub_temp_bytes(int64_t n, int n_seg) {
@@ -158,6 +460,8 @@ size_t cub_temp_bytes(int64_t n, int n_seg) {
     (void)hipcub::DeviceMergeSort::StableSortPairs(nullptr, e, (int*)nullptr, (int*)nullptr, (int)n, KeyLess(), (hipStream_t)0);
     d = d > e ? d : e;
     a = a > d ? a : d;
+    const size_t own = (size_t)512 * RS_MAXB * sizeof(int);      // the own sort's [digit][block] histogram at its largest
+    a = a > own ? a : own;
     return align256(a > b ? a : b);
 }
 
@@ -188,12 +492,71 @@ struct Scratch {
         if ((expr) != hipSuccess) return launch_status(what);          \
     } while (0)
 
-// perm (optional: NULL = keys are already sorted, identity order) + rowptr + work items for one ordering
+// up to three arrays through the same permutation in one launch (s2 / s3 may be NULL)
+inline void gather3(const int* s1, int* o1, const int* s2, int* o2, const int* s3, int* o3, const int* idx, int64_t n, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_gather3_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s1, o1, s2, o2, s3, o3, idx, n);
+}
+
+inline RsCarry carry_of(const int* s1, int* o1, const int* s2 = nullptr, int* o2 = nullptr, const int* s3 = nullptr,
+                        int* o3 = nullptr) {
+    RsCarry c;
+    c.src[0] = s1; c.out[0] = o1; c.src[1] = s2; c.out[1] = o2; c.src[2] = s3; c.out[2] = o3;
+    return c;
+}
+
+// the own sort: (keys, 0 .. n-1) -> (16-bit sorted keys, perm), `carry` arrays permuted along in the last pass
+const unsigned short* own_sort(const int* keys, int64_t n, const RsPlan& pl, int* perm, const Scratch& sc, const RsCarry& carry,
+                               hipStream_t st) {
+    unsigned short* k16_a = (unsigned short*)sc.keys_sorted;                     // the two halves of the 4 n-byte key area
+    unsigned short* k16_b = k16_a + ((n + 7) & ~(int64_t)7);
+    int* hist = (int*)sc.cub;
+    const dim3 grid((unsigned)pl.blocks), block(RS_T);
+    const RsCarry none = carry_of(nullptr, nullptr);
+    hipLaunchKernelGGL(k_rs_hist<int>, grid, block, 0, st, keys, (int)n, pl.tile, 0, pl.bits[0], hist);
+    const bool few = pl.tile <= 4 * RS_T;
+#define GV_RS_SCATTER(KIN, IOTA, ...)                                                                                   \
+    do {                                                                                                                \
+        if (few) hipLaunchKernelGGL((k_rs_scatter<KIN, IOTA, 4>), grid, block, 0, st, __VA_ARGS__);                     \
+        else hipLaunchKernelGGL((k_rs_scatter<KIN, IOTA, 16>), grid, block, 0, st, __VA_ARGS__);                        \
+    } while (0)
+    if (pl.passes == 1) {
+        GV_RS_SCATTER(int, true, keys, (const int*)nullptr, (int)n, pl.tile, 0, pl.bits[0], (const int*)hist, k16_a, perm, carry);
+        return k16_a;
+    }
+    GV_RS_SCATTER(int, true, keys, (const int*)nullptr, (int)n, pl.tile, 0, pl.bits[0], (const int*)hist, k16_a, sc.iota, none);
+    hipLaunchKernelGGL(k_rs_hist<unsigned short>, grid, block, 0, st, (const unsigned short*)k16_a, (int)n, pl.tile, pl.bits[0],
+                       pl.bits[1], hist);
+    GV_RS_SCATTER(unsigned short, false, (const unsigned short*)k16_a, (const int*)sc.iota, (int)n, pl.tile, pl.bits[0], pl.bits[1],
+                  (const int*)hist, k16_b, perm, carry);
+#undef GV_RS_SCATTER
+    return k16_b;
+}
+
+// perm (optional: NULL = keys are already sorted, identity order) + rowptr + work items for one ordering; the `carry` arrays
+// (optional) come out permuted the same way (carry.out[k][i] = carry.src[k][perm[i]])
 int order_and_items(const int* keys, int64_t n, int n_seg, int chunk, int* perm, int* rowptr, int* items, int items_cap,
-                    int* fix, int fix_cap, const Scratch& sc, hipStream_t st) {
+                    int* fix, int fix_cap, const Scratch& sc, hipStream_t st, const RsCarry* carry = nullptr) {
     const int* sorted = keys;
     const unsigned short* sorted16 = nullptr;
-    if (perm && n > 0 && use_merge_sort(st)) {      // stable merge sort in place: (keys, perm = iota); no memset / memcpy nodes
+    bool carried = false;
+    const SortMode mode = (perm && n > 0) ? sort_mode(st, n, n_seg) : SORT_RADIX;
+    if (perm && n > 0 && n_seg <= 65536 && (mode == SORT_OWN || (mode == SORT_RADIX && n >= 100000))) {
+        // two 16-bit halves in the 4 n-byte key area: the second starts n shorts in, rounded up to 16 B; it ends at most
+        // 4 n + 14 bytes in, and whenever that rounding adds anything (n % 8 = m > 0) the area's own padding,
+        // 256 - 4 (n % 64) >= 32 - 4 m bytes, covers the 16 - 2 m added -- the sort never writes into sc.iota behind it
+        if ((size_t)(((n + 7) & ~(int64_t)7) + n) * sizeof(unsigned short) > align256((size_t)n * sizeof(int)))
+            GV_REQUIRE(false, GV_ERR_SHAPE, "gv index: 16-bit key halves do not fit the key area (n=%lld)", (long long)n);
+    }
+    if (perm && n > 0 && mode == SORT_OWN) {
+        RsPlan pl;
+        rs_plan(n, n_seg, pl);
+        // the carried arrays ride in the last pass only for small inputs: its <= 128 workgroups have too few gathers in flight for
+        // more, and a separate full-occupancy gather is faster there (GV_INDEX_FUSE_CARRY = the largest n that fuses)
+        const char* lim = getenv("GV_INDEX_FUSE_CARRY");
+        const bool fuse = carry && n <= (lim ? atoll(lim) : 262144);
+        sorted16 = own_sort(keys, n, pl, perm, sc, fuse ? *carry : carry_of(nullptr, nullptr), st);
+        carried = fuse;
+    } else if (perm && n > 0 && mode == SORT_MERGE) {      // stable merge sort in place: (keys, perm = iota)
         size_t tb = sc.cub_bytes;
         if (n_seg <= 65536) {
             unsigned short* k16 = (unsigned short*)sc.keys_sorted;
@@ -207,15 +570,9 @@ int order_and_items(const int* keys, int64_t n, int n_seg, int chunk, int* perm,
                       "gv index: merge sort");
             sorted = sc.keys_sorted;
         }
-    } else if (perm && n >= 100000 && n_seg <= 65536) {      // 2-byte keys: the two halves of the keys_sorted area hold them (in / out)
-        // the area is align256(4 n) bytes; the output half starts n shorts in, rounded up to 16 B: it ends at most
-        // 4 n + 14 bytes in, and whenever that rounding adds anything (n % 8 = m > 0) the area's own padding,
-        // 256 - 4 (n % 64) >= 32 - 4 m bytes, covers the 16 - 2 m added -- the sort never writes into sc.iota behind it
+    } else if (perm && n >= 100000 && n_seg <= 65536) {      // rocPRIM onesweep on 2-byte keys (in / out halves of the key area)
         unsigned short* k16_in = (unsigned short*)sc.keys_sorted;
-        const int64_t out_at = (n + 7) & ~(int64_t)7;
-        if ((size_t)(out_at + n) * sizeof(unsigned short) > align256((size_t)n * sizeof(int)))
-            GV_REQUIRE(false, GV_ERR_SHAPE, "gv index: 16-bit key halves do not fit the key area (n=%lld)", (long long)n);
-        unsigned short* k16_out = k16_in + out_at;
+        unsigned short* k16_out = k16_in + ((n + 7) & ~(int64_t)7);
         hipLaunchKernelGGL(k_iota_narrow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc.iota, keys, k16_in, n);
         size_t tb = sc.cub_bytes;
         GV_HIP_OK(hipcub::DeviceRadixSort::SortPairs(sc.cub, tb, (const unsigned short*)k16_in, k16_out, (const int*)sc.iota, perm,
@@ -230,10 +587,19 @@ int order_and_items(const int* keys, int64_t n, int n_seg, int chunk, int* perm,
                   "gv index: radix sort");
         sorted = sc.keys_sorted;
     }
+    if (carry && !carried) gather3(carry->src[0], carry->out[0], carry->src[1], carry->out[1], carry->src[2], carry->out[2], perm, n, st);
     if (sorted16)
         hipLaunchKernelGGL(k_lower_bounds<unsigned short>, dim3((n_seg + 1 + 255) / 256), dim3(256), 0, st, sorted16, n, n_seg, rowptr);
     else
         hipLaunchKernelGGL(k_lower_bounds<int>, dim3((n_seg + 1 + 255) / 256), dim3(256), 0, st, sorted, n, n_seg, rowptr);
+    if (n_seg <= 65536) {      // counts + scan + lists + padding in one launch
+        int chunk_shift = -1;
+        for (int k = 0; k < 31; ++k)
+            if (chunk == (1 << k)) chunk_shift = k;
+        hipLaunchKernelGGL(k_items_blocks, dim3(n_seg > 0 ? (n_seg + RS_T - 1) / RS_T : 1), dim3(RS_T), 0, st, (const int*)rowptr, n_seg,
+                           chunk, chunk_shift, (int4*)items, items_cap, (int4*)fix, fix_cap);
+        return launch_status("gv index: order_and_items");
+    }
     {
         const long long n1 = (long long)items_cap * 4, n2 = (long long)fix_cap * 4;
         const unsigned blocks = (unsigned)((n1 + n2 + 255) / 256 > 4096 ? 4096 : (n1 + n2 + 255) / 256);
@@ -250,14 +616,6 @@ int order_and_items(const int* keys, int64_t n, int n_seg, int chunk, int* perm,
                            (int4*)items, items_cap, (int4*)fix, fix_cap);
     }
     return launch_status("gv index: order_and_items");
-}
-
-inline void gather(const int* src, const int* idx, int* out, int64_t n, hipStream_t st) {
-    if (n > 0) hipLaunchKernelGGL(k_gather_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, idx, out, n);
-}
-// up to three arrays through the same permutation in one launch (s2 / s3 may be NULL)
-inline void gather3(const int* s1, int* o1, const int* s2, int* o2, const int* s3, int* o3, const int* idx, int64_t n, hipStream_t st) {
-    if (n > 0) hipLaunchKernelGGL(k_gather3_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s1, o1, s2, o2, s3, o3, idx, n);
 }
 
 }  // namespace
@@ -304,13 +662,12 @@ extern "C" int gv_graph_index_build(const int32_t* src, const int32_t* dst, int6
                "gv_graph_index_build: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     Scratch sc(workspace, n_edges, seg_max);
+    const RsCarry by_dst = carry_of(src, nbr_by_dst), by_src = carry_of(dst, nbr_by_src);
     int rc = order_and_items(dst, n_edges, n_dst, chunk, dst_sorted ? nullptr : perm_d, rowptr_d, items_d, items_d_cap, fix_d,
-                             fix_d_cap, sc, st);
+                             fix_d_cap, sc, st, &by_dst);
     if (rc != GV_OK) return rc;
-    gather(src, dst_sorted ? nullptr : perm_d, nbr_by_dst, n_edges, st);
-    rc = order_and_items(src, n_edges, n_src, chunk, perm_s, rowptr_s, items_s, items_s_cap, fix_s, fix_s_cap, sc, st);
+    rc = order_and_items(src, n_edges, n_src, chunk, perm_s, rowptr_s, items_s, items_s_cap, fix_s, fix_s_cap, sc, st, &by_src);
     if (rc != GV_OK) return rc;
-    gather(dst, perm_s, nbr_by_src, n_edges, st);
     return launch_status("gv_graph_index_build");
 }
 
@@ -328,11 +685,12 @@ extern "C" int gv_relation_index_build(const int32_t* src, const int32_t* dst, c
                "gv_relation_index_build: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     Scratch sc(workspace, n_edges, n_rel);
-    gather(etype, perm_d, et_by_dst, n_edges, st);
-    gather(etype, perm_s, et_by_src, n_edges, st);
-    int rc = order_and_items(etype, n_edges, n_rel, chunk, perm_r, rowptr_r, items_r, items_cap, fix_r, fix_cap, sc, st);
+    if (n_edges > 0)
+        hipLaunchKernelGGL(k_gather_two_i32, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, st, etype, perm_d, et_by_dst,
+                           perm_s, et_by_src, n_edges);
+    const RsCarry by_rel = carry_of(src, src_by_rel, dst, dst_by_rel);
+    int rc = order_and_items(etype, n_edges, n_rel, chunk, perm_r, rowptr_r, items_r, items_cap, fix_r, fix_cap, sc, st, &by_rel);
     if (rc != GV_OK) return rc;
-    gather3(src, src_by_rel, dst, dst_by_rel, nullptr, nullptr, perm_r, n_edges, st);
     return launch_status("gv_relation_index_build");
 }
 
@@ -361,15 +719,15 @@ extern "C" int gv_triplet_index_build(const int32_t* trip, int64_t T, int n_ent,
     int* perm = (int*)(p + 4 * step); int* col = (int*)(p + 5 * step);
     if (n2 > 0)
         hipLaunchKernelGGL(k_triplet_incidence, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, trip, T, ent, other, rel2, tid);
-    int rc = order_and_items(ent, n2, n_ent, chunk, perm, rowptr_inc, items_inc, items_inc_cap, fix_inc, fix_inc_cap, sc, st);
+    const RsCarry inc = carry_of(other, inc_other, rel2, inc_rel, tid, inc_tid);
+    int rc = order_and_items(ent, n2, n_ent, chunk, perm, rowptr_inc, items_inc, items_inc_cap, fix_inc, fix_inc_cap, sc, st, &inc);
     if (rc != GV_OK) return rc;
-    gather3(other, inc_other, rel2, inc_rel, tid, inc_tid, perm, n2, st);
     // by relation: columns of the triplet list (reusing the incidence temporaries), stable sort by relation
     int* cs = ent; int* cr = other; int* co = rel2;
     if (T > 0) hipLaunchKernelGGL(k_triplet_columns, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, trip, T, cs, cr, co);
-    rc = order_and_items(cr, T, n_rel, chunk_rel, rel_tid, rowptr_rel, items_rel, items_rel_cap, fix_rel, fix_rel_cap, sc, st);
+    const RsCarry by_rel = carry_of(cs, rel_s, co, rel_o);
+    rc = order_and_items(cr, T, n_rel, chunk_rel, rel_tid, rowptr_rel, items_rel, items_rel_cap, fix_rel, fix_rel_cap, sc, st, &by_rel);
     if (rc != GV_OK) return rc;
-    gather3(cs, rel_s, co, rel_o, nullptr, nullptr, rel_tid, T, st);
     (void)col;
     return launch_status("gv_triplet_index_build");
 }

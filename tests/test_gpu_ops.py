@@ -1008,9 +1008,10 @@ def _same_items(a, b):
                                                      (300, 5000, 12, False, None), (2000, 60000, 474, True, None),
                                                      (120, 9000, 30, True, 700), (97, 4001, 7, False, 350),
                                                      (3000, 150000, 60, False, None)])       # >= 100 000 entries: the 16-bit-key sort path
-@pytest.mark.parametrize('sort', ['radix', 'merge'])
+@pytest.mark.parametrize('sort', ['own', 'radix', 'merge'])
 def test_native_index_build_equals_torch_formulation(ops, monkeypatch, n, e, r, sorted_dst, n_src, sort):
-    # 'merge': the memset-free form the builders switch to while their stream is being captured (csrc/k_index.hip)
+    # 'own': the library's kernel-only LSD radix sort (the default when ids fit 16 bits); 'radix' / 'merge': the rocPRIM
+    # fallbacks for larger inputs, eager and while the stream is being captured (csrc/k_index.hip)
     monkeypatch.setenv('GV_INDEX_SORT', sort)
     rs = np.random.RandomState(n + e)
     ns = n if n_src is None else n_src
@@ -1044,8 +1045,8 @@ def test_native_index_build_equals_torch_formulation(ops, monkeypatch, n, e, r, 
     assert torch.equal(rn.by_rel.perm, rt.by_rel.perm) and _same_items(rn.by_rel.seg, rt.by_rel.seg)
 
 
-@pytest.mark.parametrize('sort', ['radix', 'merge'])
-@pytest.mark.parametrize('T,n_ent,n_rel', [(0, 10, 3), (1, 5, 2), (5000, 300, 7), (220000, 10000, 237)])
+@pytest.mark.parametrize('sort', ['own', 'radix', 'merge'])
+@pytest.mark.parametrize('T,n_ent,n_rel', [(0, 10, 3), (1, 5, 2), (5000, 300, 7), (220000, 10000, 237), (330000, 14541, 474)])
 def test_native_triplet_index_equals_torch_formulation(ops, monkeypatch, T, n_ent, n_rel, sort):
     monkeypatch.setenv('GV_INDEX_SORT', sort)
     rs = np.random.RandomState(T + 1)
@@ -1070,8 +1071,13 @@ def test_native_triplet_index_equals_torch_formulation(ops, monkeypatch, T, n_en
 @pytest.mark.parametrize('n,n_seg', [(10000, 37),
                                      # the 16-bit-key path (n >= 100 000) in ONE scatter pass (n_seg <= 256) at the lengths where the
                                      # sorted-key half once ran past its area into the sort's own value input: n % 128 in [1, 64]
-                                     (100000 + 33, 200), (131072 + 64, 256), (440000, 237), (100000 + 1, 3), (100000 + 57, 255)])
-def test_gv_build_csr_single_ordering(ops, n, n_seg):
+                                     (100000 + 33, 200), (131072 + 64, 256), (440000, 237), (100000 + 1, 3), (100000 + 57, 255),
+                                     # the own sort: one tile / many tiles, 1 and 2 passes, the widest ids, a ragged last tile
+                                     (1, 1), (1023, 16), (1025, 17), (70001, 513), (660000, 14541), (300007, 65536),
+                                     (2200000, 40000)])
+@pytest.mark.parametrize('sort', ['own', 'radix'])
+def test_gv_build_csr_single_ordering(ops, monkeypatch, n, n_seg, sort):
+    monkeypatch.setenv('GV_INDEX_SORT', sort)
     from gcn_vae_amd import lib
     from gcn_vae_amd.lib import ptr
     rs = np.random.RandomState(3)
