@@ -41,14 +41,20 @@ __device__ __forceinline__ uint16_t bf_bits(float v) { return __builtin_bit_cast
 
 struct ChainUnit { int l, tile, ch; };
 
+// column tiles of a layer: 32 output columns each; an IAF layer's tile is 16 mu columns + their 16 alpha columns
+__device__ __forceinline__ int chain_tiles(const gv_chain_layer& L) { return L.iaf_z ? ((L.n >> 1) + 15) >> 4 : (L.n + 31) >> 5; }
+__device__ __forceinline__ int chain_first_tile(const gv_chain_layer&, int wave) { return wave; }
+__device__ __forceinline__ int chain_next_tile(const gv_chain_layer&, int tile) { return tile + CH_MMA_WAVES; }
+// (giving a wave PAIRS of neighbouring IAF tiles -- the two 64-B halves of a row's cache line -- measured 5 us slower)
+
 // successor of unit u in this wave's order (l == n_layers: none)
 __device__ __forceinline__ ChainUnit chain_next(const ChainArgs& p, int nl, ChainUnit u, int wave) {
     const int ks = (p.L[u.l].k + 15) >> 4, nch = (ks + CH_KS - 1) / CH_KS;
     if (u.ch + 1 < nch) return {u.l, u.tile, u.ch + 1};
-    if (u.tile + CH_MMA_WAVES < ((p.L[u.l].n + 31) >> 5)) return {u.l, u.tile + CH_MMA_WAVES, 0};
+    if (chain_next_tile(p.L[u.l], u.tile) < chain_tiles(p.L[u.l])) return {u.l, chain_next_tile(p.L[u.l], u.tile), 0};
     int l = u.l + 1;
-    while (l < nl && wave >= ((p.L[l].n + 31) >> 5)) ++l;
-    return {l, wave, 0};
+    while (l < nl && chain_first_tile(p.L[l], wave) >= chain_tiles(p.L[l])) ++l;
+    return {l, l < nl ? chain_first_tile(p.L[l], wave) : wave, 0};
 }
 
 // where the B fragments of unit u start (packed weight of its layer + this lane's 16-B slot of tile u.tile, step 13 u.ch)
@@ -131,6 +137,61 @@ __device__ __forceinline__ void chain_stage(uint16_t* tile, int ldk, const uint1
     }
 }
 
+// a layer's ReLU mask into its LDS tile, from a TRANSPOSED source [cols][ld] (a forward chain's out_bf16_t: what the MADE
+// backward uses) or a row-major one [m][ld].  Every extra address register at a layer boundary is a spill (the next unit's 52
+// fragment registers are in flight there), hence the rolled loops.  Rows past m are zero.
+__device__ __forceinline__ void chain_stage_mask(uint16_t* tile, int ldk, const gv_chain_layer& L, int m0, int m) {
+    if (L.mask_t) {
+        // 16-B pieces = 8 consecutive rows of one column, four in flight; each lands through a ROLLED loop of 2-B LDS writes (one
+        // address register walking down the rows, the piece shifted along in two 64-bit halves)
+        const int total = L.n * (CH_BM / 8);
+        for (int base = (int)threadIdx.x; base < total; base += CH_THREADS * 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = min(base + j * CH_THREADS, total - 1), r8 = (i & 7) << 3;
+                v[j] = *reinterpret_cast<const uint4*>(L.mask_t + (size_t)(i >> 3) * L.ldmask_t + min(m0 + r8, (m - 1) & ~7));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = base + j * CH_THREADS, r8 = (i & 7) << 3;
+                if (i >= total) break;
+                uint16_t* o = tile + r8 * ldk + (i >> 3);
+                unsigned long long lo = ((unsigned long long)v[j].y << 32) | v[j].x, hi = ((unsigned long long)v[j].w << 32) | v[j].z;
+                int left = m - m0 - r8;       // rows of the piece that exist (the others are zero)
+#pragma unroll 1
+                for (int e = 0; e < 8; ++e) {
+                    *o = left > 0 ? (uint16_t)(lo & 0xffffu) : (uint16_t)0;
+                    lo = (lo >> 16) | (hi << 48);
+                    hi >>= 16;
+                    o += ldk;
+                    --left;
+                }
+            }
+        }
+        return;
+    }
+    // row-major [m][ld]: element by element, consecutive lanes along a row, eight 2-B loads in flight per lane
+    const int cols = L.n, total = cols * CH_BM;
+    const int dslow = CH_THREADS / cols, dfast = CH_THREADS - dslow * cols;
+    int slow = (int)threadIdx.x / cols, fast = (int)threadIdx.x - slow * cols;
+    for (int base = (int)threadIdx.x; base < total; base += CH_THREADS * 8) {
+        uint16_t v[8];
+        int at[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            at[j] = base + j * CH_THREADS < total ? slow * ldk + fast : -1;
+            v[j] = (at[j] >= 0 && m0 + slow < m) ? L.mask[(size_t)(m0 + slow) * L.ldmask + fast] : (uint16_t)0;
+            slow += dslow;
+            fast += dfast;
+            if (fast >= cols) { fast -= cols; ++slow; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (at[j] >= 0) tile[at[j]] = v[j];
+    }
+}
+
 // MMA waves.  The weight fragment is the FIRST MFMA operand, so a lane owns ONE ROW of the tile (lane & 31, two accumulator
 // tiles = rows r and 32 + r) and its 16 registers are 4 groups of 4 consecutive columns (8 g + 4 (lane >> 5) + 0..3):
 //   next layer's LDS tile: one ds_write_b64 per group;  ReLU mask: one ds_read_b64 per group;  fp32 output: one 16-B store per
@@ -139,7 +200,7 @@ __device__ __forceinline__ void chain_stage(uint16_t* tile, int ldk, const uint1
 constexpr bool LEAN = true;
 __device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const gv_chain_layer& Ly, int tile, int m0, int m,
                                                uint16_t* An, int ldk, int kp_next, const uint16_t* mbuf, const float* bias_l,
-                                               int r, int h) {
+                                               const int* cnt_lds, int r, int h) {
     // opaque copies: without them the compiler hoists per-row predicates and 64-bit offsets out of the unit loop and spills
     asm volatile("" : "+v"(r), "+v"(h));
     float4 old[LEAN ? 1 : 2][LEAN ? 1 : 4];       // accumulate: all previous values requested at once (one round trip)
@@ -177,7 +238,7 @@ __device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const g
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            if (Ly.mask && cv) {
+            if ((Ly.mask || Ly.mask_t) && cv) {
                 const uint2 mv = *reinterpret_cast<const uint2*>(mbuf + row * ldk + c0);
                 if ((int16_t)(mv.x & 0xffff) <= 0) v[0] = 0.f;
                 if ((int16_t)(mv.x >> 16) <= 0) v[1] = 0.f;
@@ -191,6 +252,16 @@ __device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const g
                     if constexpr (LEAN) pv = *reinterpret_cast<const float4*>(Ly.out_f32 + (size_t)(m0 + row) * Ly.ldc + c0);
                     else pv = old[mt][g];
                     o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
+                }
+                if (Ly.add_src) {      // the gradient the IAF update hands through: only where a column's count is 0 (counts in LDS)
+                    const int4 ac = *reinterpret_cast<const int4*>(cnt_lds + c0);
+                    if (ac.x <= 0 || ac.y <= 0 || ac.z <= 0 || ac.w <= 0) {
+                        const float4 av = *reinterpret_cast<const float4*>(Ly.add_src + (size_t)(m0 + row) * Ly.ldc + c0);
+                        if (ac.x <= 0) o.x += av.x;
+                        if (ac.y <= 0) o.y += av.y;
+                        if (ac.z <= 0) o.z += av.z;
+                        if (ac.w <= 0) o.w += av.w;
+                    }
                 }
                 *reinterpret_cast<float4*>(Ly.out_f32 + (size_t)(m0 + row) * Ly.ldc + c0) = o;
             }
@@ -210,11 +281,104 @@ __device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const g
     }
 }
 
+// The IAF update in the last layer's epilogue (kgvae/flow_network.py:92-96): the layer's weight is packed so that a tile holds
+// 16 mu columns (accumulator groups 0, 1) and the SAME columns' alpha (groups 2, 3), so a lane has both halves of
+//   x_new[r][c] = colcount[c] > 0 ? z[r][c] * expf(alpha + mu) : x_old[r][c]
+// in registers.  x_new leaves as fp32 (iaf_x_new), as the bf16 tile the store wave copies out (out_bf16) and transposed
+// (out_bf16_t); expf(alpha + mu) (iaf_ex: all the backward needs), alpha (iaf_alpha: the log-det row sums of the last pass) and
+// [mu | alpha] (out_f32, natural column order) are optional.  Same arithmetic, element by element, as gv_iaf_update_fwd_bf16
+// on the stored [mu | alpha].
+__device__ __forceinline__ void chain_epilogue_iaf(const f32x16_t (&acc)[2], const gv_chain_layer& Ly, int tile,
+                                                   int m0, int m, uint16_t* An, int ldk, int kp_next, const float* bias_l,
+                                                   const int* cnt_lds, int r, int h) {
+    asm volatile("" : "+v"(r), "+v"(h));
+    const int d = Ly.n >> 1;
+    // z of the lane's four (column group, row) pairs FIRST (clamped, unconditional): loads and stores share one in-order counter
+    // on this ISA, so a load issued behind the epilogue's stores waits for every one of them to be acknowledged (measured:
+    // 131 us per chain with the loads interleaved, ~75 with them in front).  16 registers: the caller requests the next unit's
+    // weight fragments AFTER this epilogue, not before it.
+    float4 zp[4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            zp[2 * g + mt] = (Ly.iaf_reserved & 1) ? make_float4(1.f, 1.f, 1.f, 1.f)
+                                                   : *reinterpret_cast<const float4*>(Ly.iaf_z + (size_t)min(m0 + mt * 32 + r, m - 1) * Ly.iaf_ld +
+                                                                                      min(tile * 16 + 8 * g + 4 * h, d - 4));
+    int4 cn[2];
+    float4 xo[4];
+    bool keep[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {      // ... and x_old where a column of the group is passed through (the middle passes' last column)
+        const int c0 = tile * 16 + 8 * g + 4 * h;
+        cn[g] = c0 < d ? *reinterpret_cast<const int4*>(cnt_lds + c0) : make_int4(1, 1, 1, 1);
+        keep[g] = true;
+        if (Ly.iaf_keep_colcount && c0 < d) {
+            const int4 kc = *reinterpret_cast<const int4*>(Ly.iaf_keep_colcount + c0);
+            keep[g] = kc.x <= 0 || kc.y <= 0 || kc.z <= 0 || kc.w <= 0;
+        }
+        const bool pass = cn[g].x <= 0 || cn[g].y <= 0 || cn[g].z <= 0 || cn[g].w <= 0;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            xo[2 * g + mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pass && m0 + mt * 32 + r < m)
+                xo[2 * g + mt] = *reinterpret_cast<const float4*>(Ly.iaf_x_old + (size_t)(m0 + mt * 32 + r) * Ly.iaf_ld + c0);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int c0 = tile * 16 + 8 * g + 4 * h;
+            const bool cv = c0 < d;
+            const int row = mt * 32 + r;
+            const bool live = cv && m0 + row < m;
+            const size_t e = (size_t)(m0 + row) * Ly.iaf_ld + c0;
+            float4 v = make_float4(acc[mt][4 * g + 8], acc[mt][4 * g + 9], acc[mt][4 * g + 10], acc[mt][4 * g + 11]);      // alpha
+            float4 s = make_float4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);            // mu
+            if (Ly.bias && cv) {
+                const float4 ba = *reinterpret_cast<const float4*>(bias_l + d + c0), bm = *reinterpret_cast<const float4*>(bias_l + c0);
+                v.x += ba.x; v.y += ba.y; v.z += ba.z; v.w += ba.w;
+                s.x += bm.x; s.y += bm.y; s.z += bm.z; s.w += bm.w;
+            }
+            const int dbg = Ly.iaf_reserved;      // ablation switches of tools/probes/chain_iaf_probe.py (0 in production)
+            if (live && Ly.out_f32 && !(dbg & 2)) {
+                float* o = Ly.out_f32 + (size_t)(m0 + row) * Ly.ldc + c0;
+                *reinterpret_cast<float4*>(o) = s;
+                *reinterpret_cast<float4*>(o + d) = v;
+            }
+            if (live && Ly.iaf_alpha && !(dbg & 2)) *reinterpret_cast<float4*>(Ly.iaf_alpha + e) = v;
+            if (!(dbg & 16)) { v.x = expf(v.x + s.x); v.y = expf(v.y + s.y); v.z = expf(v.z + s.z); v.w = expf(v.w + s.w); }
+            if (live && Ly.iaf_ex && !(dbg & 2)) *reinterpret_cast<float4*>(Ly.iaf_ex + e) = v;
+            s = zp[2 * g + mt];
+            v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+            s = xo[2 * g + mt];
+            if (cn[g].x <= 0) v.x = s.x;
+            if (cn[g].y <= 0) v.y = s.y;
+            if (cn[g].z <= 0) v.z = s.z;
+            if (cn[g].w <= 0) v.w = s.w;
+            if (live && Ly.iaf_x_new && keep[g] && !(dbg & 2)) *reinterpret_cast<float4*>(Ly.iaf_x_new + e) = v;
+            const uint16_t b0 = bf_bits(v.x), b1 = bf_bits(v.y), b2 = bf_bits(v.z), b3 = bf_bits(v.w);
+            if (c0 < kp_next && !(dbg & 8))
+                *reinterpret_cast<uint2*>(An + row * ldk + c0) =
+                    cv ? make_uint2(b0 | ((uint32_t)b1 << 16), b2 | ((uint32_t)b3 << 16)) : make_uint2(0, 0);
+            if (Ly.out_bf16_t && live && !(dbg & 4)) {
+                uint16_t* o = Ly.out_bf16_t + (size_t)c0 * Ly.ldt + m0 + row;
+                o[0] = b0;
+                o[Ly.ldt] = b1;
+                o[2 * (size_t)Ly.ldt] = b2;
+                o[3 * (size_t)Ly.ldt] = b3;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // store wave: the row-major bf16 copy of a layer's result out of its LDS tile, 16-B pieces, reads issued in batches of 8.
 // (row, piece) advance incrementally: an integer division per piece would cost this single wave more than the copy itself
 __device__ __forceinline__ void chain_store(const gv_chain_layer& Ly, const uint16_t* An, int ldk, int m0, int m, int ts) {
     if (!Ly.out_bf16) return;
-    const int ppr = Ly.n >> 3, total = CH_BM * ppr;
+    const int ppr = (Ly.iaf_z ? Ly.n >> 1 : Ly.n) >> 3, total = CH_BM * ppr;      // an IAF layer's tile holds x_new: d columns
     const int drow = CH_STORE_THREADS / ppr, dpc = CH_STORE_THREADS - drow * ppr;      // one step of 64 pieces
     int row = ts / ppr, pc = ts - row * ppr;
     for (int base = 0; base < total; base += CH_STORE_THREADS * 8) {
@@ -263,11 +427,13 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         int ksc = 1;
         if (mma_wave) {
             u.l = 0;
-            while (u.l < nl && wave >= ((p.L[u.l].n + 31) >> 5)) ++u.l;
+            while (u.l < nl && chain_first_tile(p.L[u.l], wave) >= chain_tiles(p.L[u.l])) ++u.l;
+            if (u.l < nl) u.tile = chain_first_tile(p.L[u.l], wave);
             if (u.l < nl) chain_unit_b(p, u, lane, b0, off, ksc);
         }
         chain_issue(qa, b0, off, ksc);
     }
+    int bias_total = 0;
     {       // every layer's bias into LDS (all loads in flight together): no global round trip in an epilogue
         float bv[CH_L];
         int off = 0;
@@ -282,9 +448,15 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 if ((int)threadIdx.x < p.L[l].n) bias_lds[off + threadIdx.x] = bv[l];
                 off += p.L[l].n;
             }
+        bias_total = off;
+        const gv_chain_layer& Ll = p.L[nl - 1];      // an IAF layer's column counts behind the biases
+        if (Ll.iaf_z && (int)threadIdx.x < (Ll.n >> 1))
+            reinterpret_cast<int*>(bias_lds + off)[threadIdx.x] = Ll.iaf_colcount[threadIdx.x];
+        else if (Ll.add_src && (int)threadIdx.x < Ll.n)
+            reinterpret_cast<int*>(bias_lds + off)[threadIdx.x] = Ll.add_colcount[threadIdx.x];
     }
     chain_stage(chain_lds, ldk, p.x, p.ldx, m0, p.m, p.L[0].k, (p.L[0].k + 15) & ~15);
-    if (p.L[0].mask) chain_stage(mbuf, ldk, p.L[0].mask, p.L[0].ldmask, m0, p.m, p.L[0].n, p.L[0].n);
+    if (p.L[0].mask || p.L[0].mask_t) chain_stage_mask(mbuf, ldk, p.L[0], m0, p.m);
     __syncthreads();
 
     f32x16_t acc[2];
@@ -294,11 +466,11 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #define CHAIN_CROSS(target)                                                                                              \
     while (layer < (target)) {                                                                                          \
         __syncthreads();                                                                                                \
-        if (layer + 1 < nl && p.L[layer + 1].mask) {                                                                    \
-            chain_stage(mbuf, ldk, p.L[layer + 1].mask, p.L[layer + 1].ldmask, m0, p.m, p.L[layer + 1].n, p.L[layer + 1].n); \
+        if (layer + 1 < nl && (p.L[layer + 1].mask || p.L[layer + 1].mask_t)) {                                         \
+            chain_stage_mask(mbuf, ldk, p.L[layer + 1], m0, p.m);                                                       \
             __syncthreads();                                                                                            \
         }                                                                                                               \
-        if (!mma_wave && layer + 1 < nl)                                                                                \
+        if (!mma_wave && (layer + 1 < nl || p.L[layer].iaf_z))                                                          \
             chain_store(p.L[layer], chain_lds + ((layer + 1) & 1) * CH_BM * ldk, ldk, m0, p.m, (int)threadIdx.x - CH_MMA_THREADS); \
         bias_off += p.L[layer].n;                                                                                       \
         ++layer;                                                                                                        \
@@ -320,10 +492,16 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         }                                                                                                               \
         const uint16_t* A = chain_lds + (u.l & 1) * CH_BM * ldk;                                                        \
         chain_mma(acc, Q, A + r * ldk + 8 * h + u.ch * CH_KS * 16, 32 * ldk, min(CH_KS, ks - u.ch * CH_KS));            \
+        const bool iaf_unit = Ly.iaf_z && u.ch + 1 == nch;                                                              \
+        if (iaf_unit)                                                                                                   \
+            chain_epilogue_iaf(acc, Ly, u.tile, m0, p.m, chain_lds + ((u.l + 1) & 1) * CH_BM * ldk, ldk,                \
+                               Ly.out_bf16 ? ((Ly.n >> 1) + 15) & ~15 : 0, bias_lds + bias_off,                         \
+                               reinterpret_cast<const int*>(bias_lds + bias_total), r, h);                              \
         chain_issue(Q, nb0, noff, nksc);                                                                                \
-        if (u.ch + 1 == nch)                                                                                            \
+        if (u.ch + 1 == nch && !iaf_unit)                                                                               \
             chain_epilogue(acc, Ly, u.tile, m0, p.m, chain_lds + ((u.l + 1) & 1) * CH_BM * ldk, ldk,                    \
-                           u.l + 1 < nl ? (Ly.n + 15) & ~15 : 0, mbuf, bias_lds + bias_off, r, h);                      \
+                           u.l + 1 < nl ? (Ly.n + 15) & ~15 : 0, mbuf, bias_lds + bias_off,                             \
+                           reinterpret_cast<const int*>(bias_lds + bias_total), r, h);                                  \
         u = nu;                                                                                                         \
     }
 
@@ -338,34 +516,42 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 
 // packed[(t * ks + s) * 64 + lane][e] = bf16(B[32 t + (lane & 31)][16 s + 8 (lane >> 5) + e]), zero outside B;
 // forward: B = W [n][k]; backward: B = W^T [k][n] (its tiles run over k, its steps over n)
-struct PackOne { const float* w; int ld, n, k; uint4* fwd; uint4* bwd; };
+struct PackOne { const float* w; int ld, n, k; uint4* fwd; uint4* bwd; int iaf; };      // iaf: fwd tiles = 16 mu + 16 alpha rows
 struct PackMulti { PackOne e[GV_CHAIN_MAX_LAYERS]; };
 
-__device__ __forceinline__ void pack_b_frag(const float* __restrict__ w, int ld, int n, int k, uint4* fwd, uint4* bwd);
+__device__ __forceinline__ void pack_b_frag(const float* __restrict__ w, int ld, int n, int k, uint4* fwd, uint4* bwd, int iaf);
 
-__global__ __launch_bounds__(256) void k_pack_b_frag(const float* __restrict__ w, int ld, int n, int k, uint4* fwd, uint4* bwd) {
-    pack_b_frag(w, ld, n, k, fwd, bwd);
+__global__ __launch_bounds__(256) void k_pack_b_frag(const float* __restrict__ w, int ld, int n, int k, uint4* fwd, uint4* bwd, int iaf) {
+    pack_b_frag(w, ld, n, k, fwd, bwd, iaf);
 }
 // every layer of a MADE in one launch (blockIdx.y = layer)
 __global__ __launch_bounds__(256) void k_pack_b_frag_multi(const PackMulti p) {
     const PackOne& e = p.e[blockIdx.y];
-    pack_b_frag(e.w, e.ld, e.n, e.k, e.fwd, e.bwd);
+    pack_b_frag(e.w, e.ld, e.n, e.k, e.fwd, e.bwd, e.iaf);
 }
 
-__device__ __forceinline__ void pack_b_frag(const float* __restrict__ w, int ld, int n, int k, uint4* fwd, uint4* bwd) {
-    const int ks_f = (k + 15) >> 4, nt_f = (n + 31) >> 5, tot_f = nt_f * ks_f * 64;
+__device__ __forceinline__ void pack_b_frag(const float* __restrict__ w, int ld, int n, int k, uint4* fwd, uint4* bwd, int iaf) {
+    const int half = n >> 1;
+    const int ks_f = (k + 15) >> 4, nt_f = iaf ? (half + 15) >> 4 : (n + 31) >> 5, tot_f = nt_f * ks_f * 64;
     const int ks_b = (n + 15) >> 4, nt_b = (k + 31) >> 5, tot_b = nt_b * ks_b * 64;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < tot_f + tot_b; idx += gridDim.x * 256) {
         const bool is_b = idx >= tot_f;
         const int j = is_b ? idx - tot_f : idx, ks = is_b ? ks_b : ks_f;
         const int lane = j & 63, ts = j >> 6, s = ts % ks, t = ts / ks;
-        const int row = t * 32 + (lane & 31), c0 = s * 16 + 8 * (lane >> 5);
+        int row = t * 32 + (lane & 31);
+        const int c0 = s * 16 + 8 * (lane >> 5);
+        bool row_ok = true;
+        if (iaf && !is_b) {      // B-row j of tile t: mu column 16 t + j (j < 16), alpha column 16 t + j - 16 = W row half + that
+            const int j = lane & 31, c = t * 16 + (j & 15);
+            row = j < 16 ? c : half + c;
+            row_ok = c < half;
+        }
         uint16_t b[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = c0 + e;
             float v = 0.f;
-            if (!is_b) { if (row < n && c < k) v = w[(size_t)row * ld + c]; }
+            if (!is_b) { if (row_ok && row < n && c < k) v = w[(size_t)row * ld + c]; }
             else { if (row < k && c < n) v = w[(size_t)c * ld + row]; }
             b[e] = bf_bits(v);
         }
@@ -393,12 +579,35 @@ extern "C" int gv_made_pack_weight(const float* w, int ld, int n, int k, uint16_
                "gv_made_pack_weight: packed buffers must be 16-B aligned");
     const int64_t total = (gv_made_pack_weight_elems(n, k) + gv_made_pack_weight_elems(k, n)) / 8;
     hipLaunchKernelGGL(k_pack_b_frag, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ld, n, k,
-                       (uint4*)packed_fwd, (uint4*)packed_bwd);
+                       (uint4*)packed_fwd, (uint4*)packed_bwd, 0);
     return launch_status("gv_made_pack_weight");
 }
 
+extern "C" int gv_made_pack_weight_iaf(const float* w, int ld, int n, int k, uint16_t* packed_fwd, void* stream) {
+    GV_REQUIRE(n > 0 && k > 0 && ld >= k && n % 16 == 0, GV_ERR_SHAPE, "gv_made_pack_weight_iaf: n=%d (= 2 d, d %% 8 == 0) k=%d ld=%d", n, k, ld);
+    GV_REQUIRE(w && packed_fwd, GV_ERR_NULL, "gv_made_pack_weight_iaf: NULL pointer");
+    GV_REQUIRE(aligned16(packed_fwd), GV_ERR_ALIGN, "gv_made_pack_weight_iaf: packed buffer must be 16-B aligned");
+    const int64_t total = gv_made_pack_weight_elems(n, k) / 8;
+    hipLaunchKernelGGL(k_pack_b_frag, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ld, n, k,
+                       (uint4*)packed_fwd, (uint4*)nullptr, 1);
+    return launch_status("gv_made_pack_weight_iaf");
+}
+
+static int pack_weight_multi(int count, const float* const* w, const int32_t* ld, const int32_t* n, const int32_t* k,
+                             uint16_t* const* packed_fwd, uint16_t* const* packed_bwd, int iaf_last, void* stream);
+
 extern "C" int gv_made_pack_weight_multi(int count, const float* const* w, const int32_t* ld, const int32_t* n, const int32_t* k,
                                          uint16_t* const* packed_fwd, uint16_t* const* packed_bwd, void* stream) {
+    return pack_weight_multi(count, w, ld, n, k, packed_fwd, packed_bwd, 0, stream);
+}
+
+extern "C" int gv_made_pack_weight_multi_iaf(int count, const float* const* w, const int32_t* ld, const int32_t* n, const int32_t* k,
+                                             uint16_t* const* packed_fwd, uint16_t* const* packed_bwd, void* stream) {
+    return pack_weight_multi(count, w, ld, n, k, packed_fwd, packed_bwd, 1, stream);
+}
+
+static int pack_weight_multi(int count, const float* const* w, const int32_t* ld, const int32_t* n, const int32_t* k,
+                             uint16_t* const* packed_fwd, uint16_t* const* packed_bwd, int iaf_last, void* stream) {
     GV_REQUIRE(count >= 1 && count <= GV_CHAIN_MAX_LAYERS, GV_ERR_SHAPE, "gv_made_pack_weight_multi: count=%d", count);
     GV_REQUIRE(w && ld && n && k && packed_fwd && packed_bwd, GV_ERR_NULL, "gv_made_pack_weight_multi: NULL table");
     PackMulti p;
@@ -410,6 +619,8 @@ extern "C" int gv_made_pack_weight_multi(int count, const float* const* w, const
                    "gv_made_pack_weight_multi: packed buffers must be 16-B aligned");
         p.e[i].w = w[i]; p.e[i].ld = ld[i]; p.e[i].n = n[i]; p.e[i].k = k[i];
         p.e[i].fwd = (uint4*)packed_fwd[i]; p.e[i].bwd = (uint4*)packed_bwd[i];
+        p.e[i].iaf = (iaf_last && i + 1 == count) ? 1 : 0;
+        GV_REQUIRE(!p.e[i].iaf || n[i] % 16 == 0, GV_ERR_SHAPE, "gv_made_pack_weight_multi_iaf: the last layer is [mu | alpha], n = 2 d with d %% 8 == 0 (n=%d)", n[i]);
         most = max(most, (gv_made_pack_weight_elems(n[i], k[i]) + gv_made_pack_weight_elems(k[i], n[i])) / 8);
     }
     hipLaunchKernelGGL(k_pack_b_frag_multi, dim3((unsigned)((most + 255) / 256), count), dim3(256), 0, (hipStream_t)stream, p);
@@ -422,7 +633,7 @@ static int chain_ldk(int n_layers, const gv_chain_layer* layers, bool* has_mask)
     *has_mask = false;
     for (int i = 0; i < n_layers; ++i) {
         kmax = max(kmax, (layers[i].k + 15) & ~15);
-        if (layers[i].mask) { *has_mask = true; kmax = max(kmax, layers[i].n); }
+        if (layers[i].mask || layers[i].mask_t) { *has_mask = true; kmax = max(kmax, layers[i].n); }
     }
     int ldk = (kmax + 15) / 16 * 16 + 8;          // 16 j + 8 elements: 16-B fragment reads of 8 rows hit 32 distinct banks
     return ldk;
@@ -439,10 +650,23 @@ extern "C" int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, co
         GV_REQUIRE(L.n > 0 && L.k > 0 && L.n % 8 == 0 && L.k % 8 == 0 && L.n <= CH_THREADS && (i == 0 || L.k == layers[i - 1].n), GV_ERR_SHAPE,
                    "gv_made_chain: layer %d is %d x %d (widths are multiples of 8, k = the previous layer's n)", i, L.n, L.k);
         GV_REQUIRE(L.w_packed && aligned16(L.w_packed), GV_ERR_NULL, "gv_made_chain: layer %d has no packed weight", i);
-        GV_REQUIRE(L.out_bf16 || L.out_bf16_t || L.out_f32 || i + 1 < n_layers, GV_ERR_NULL, "gv_made_chain: the last layer stores nothing");
-        GV_REQUIRE(!(L.out_bf16 && i + 1 == n_layers), GV_ERR_SHAPE, "gv_made_chain: the last layer has no row-major bf16 output");
+        GV_REQUIRE(L.out_bf16 || L.out_bf16_t || L.out_f32 || L.iaf_z || i + 1 < n_layers, GV_ERR_NULL, "gv_made_chain: the last layer stores nothing");
+        GV_REQUIRE(!(L.out_bf16 && i + 1 == n_layers && !L.iaf_z), GV_ERR_SHAPE, "gv_made_chain: the last layer has no row-major bf16 output");
+        GV_REQUIRE(!(L.mask && L.mask_t) && (!L.mask_t || (L.ldmask_t >= m && L.ldmask_t % 8 == 0 && aligned16(L.mask_t))), GV_ERR_ALIGN,
+                   "gv_made_chain: layer %d: one mask form; the transposed one has 16-B aligned rows of >= m entries", i);
+        GV_REQUIRE(!L.add_src || (i + 1 == n_layers && L.out_f32 && L.add_colcount && aligned16(L.add_src) && aligned16(L.add_colcount) &&
+                                  L.n % 4 == 0), GV_ERR_NULL, "gv_made_chain: add_src belongs to the last layer's fp32 output, with its column counts");
+        if (L.iaf_z) {
+            GV_REQUIRE(i + 1 == n_layers && L.n % 16 == 0 && !L.relu && !L.mask && !L.accumulate, GV_ERR_SHAPE,
+                       "gv_made_chain: the IAF update belongs to the last layer, n = 2 d with d %% 8 == 0, no ReLU / mask / accumulate");
+            GV_REQUIRE(L.iaf_x_old && L.iaf_colcount && (L.iaf_x_new || L.iaf_ex || L.out_bf16 || L.out_bf16_t), GV_ERR_NULL,
+                       "gv_made_chain: IAF layer needs x_old, colcount and an output");
+            GV_REQUIRE(L.iaf_ld >= L.n / 2 && L.iaf_ld % 4 == 0 && aligned16(L.iaf_z) && aligned16(L.iaf_x_old) && aligned16(L.iaf_colcount) &&
+                       (!L.iaf_x_new || aligned16(L.iaf_x_new)) && (!L.iaf_ex || aligned16(L.iaf_ex)) && (!L.iaf_alpha || aligned16(L.iaf_alpha)),
+                       GV_ERR_ALIGN, "gv_made_chain: IAF operands are [m][iaf_ld] fp32 with 16-B aligned rows");
+        }
         GV_REQUIRE((!L.mask || (L.ldmask >= L.n && L.ldmask % 8 == 0 && aligned16(L.mask))) &&
-                   (!L.out_bf16 || (L.ldb >= L.n && L.ldb % 8 == 0 && aligned16(L.out_bf16))) &&
+                   (!L.out_bf16 || (L.ldb >= (L.iaf_z ? L.n / 2 : L.n) && L.ldb % 8 == 0 && aligned16(L.out_bf16))) &&
                    (!L.out_bf16_t || L.ldt >= m) &&
                    (!L.out_f32 || (L.ldc >= L.n && L.ldc % 4 == 0 && aligned16(L.out_f32))), GV_ERR_ALIGN, "gv_made_chain: layer %d: leading dimension / alignment", i);
         p.L[i] = L;
@@ -451,6 +675,8 @@ extern "C" int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, co
     const int ldk = chain_ldk(n_layers, layers, &has_mask);
     size_t bias_floats = 0;
     for (int i = 0; i < n_layers; ++i) bias_floats += (size_t)layers[i].n;
+    if (layers[n_layers - 1].iaf_z) bias_floats += (size_t)layers[n_layers - 1].n / 2;      // its column counts
+    else if (layers[n_layers - 1].add_src) bias_floats += (size_t)layers[n_layers - 1].n;
     const size_t lds = (size_t)(has_mask ? 3 : 2) * CH_BM * ldk * sizeof(uint16_t) + bias_floats * sizeof(float);
     GV_REQUIRE(lds <= 160 * 1024, GV_ERR_SHAPE, "gv_made_chain: layers this wide need %zu B of LDS (160 KB per CU)", lds);
     p.x = x; p.ldx = ldx; p.m = m; p.n_layers = n_layers; p.ldk = ldk; p.has_mask = has_mask ? 1 : 0;
@@ -480,5 +706,6 @@ extern "C" int gv_made_chain_fits(int n_layers, const int32_t* n_of_layer, const
     const int ldk = (kmax + 15) / 16 * 16 + 8;
     size_t bias_floats = 0;
     for (int i = 0; i < n_layers; ++i) bias_floats += (size_t)n_of_layer[i];
+    bias_floats += (size_t)n_of_layer[n_layers - 1];      // room for the last layer's column counts (IAF update / handed-through gradient)
     return (size_t)(any_mask ? 3 : 2) * CH_BM * ldk * 2 + bias_floats * 4 <= 160 * 1024 ? 1 : 0;
 }

@@ -362,6 +362,9 @@ __global__ __launch_bounds__(256) void k_iaf_fwd_bf16(const float* __restrict__ 
     }
 }
 
+// EX: `net` holds expf(alpha + mu) [rows][ld_net] (what a chain with the fused update stores) instead of [mu | alpha];
+// gxold may be NULL then (the backward chain adds the passed-through gradient itself)
+template <bool EX>
 __global__ __launch_bounds__(256) void k_iaf_bwd_bf16(const float* __restrict__ z, const float* __restrict__ net, int ld_net,
                                                       const int* __restrict__ colcount, const float* __restrict__ gx,
                                                       const float* __restrict__ gld, float* __restrict__ gz_acc,
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16(const float* __restrict__ 
             const float g = gx[e];
             float g_mu = 0.f, g_al = gld ? gld[r] : 0.f, g_z = 0.f, g_old = g;
             if (cnt > 0) {
-                const float ex = expf(net[(size_t)r * ld_net + d + c] + net[(size_t)r * ld_net + c]);
+                const float ex = EX ? net[(size_t)r * ld_net + c] : expf(net[(size_t)r * ld_net + d + c] + net[(size_t)r * ld_net + c]);
                 const float gc = g * (float)cnt;
                 g_z = gc * ex;
                 g_mu = gc * z[e] * ex;
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16(const float* __restrict__ 
                 g_old = 0.f;
             }
             gz_acc[e] += g_z;
-            gxold[e] = g_old;
+            if (gxold) gxold[e] = g_old;
             vm = f2bf(g_mu);
             va = f2bf(g_al);
             gnb[(size_t)r * ldb + c] = vm;
@@ -465,6 +468,7 @@ __global__ __launch_bounds__(256) void k_iaf_fwd_bf16_v4(const float* __restrict
     iaf_tile_out(t, xt, ldt, r0, c0, rows, d);
 }
 
+template <bool EX>
 __global__ __launch_bounds__(256) void k_iaf_bwd_bf16_v4(const float* __restrict__ z, const float* __restrict__ net, int ld_net,
                                                          const int* __restrict__ colcount, const float* __restrict__ gx,
                                                          const float* __restrict__ gld, float* __restrict__ gz_acc,
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16_v4(const float* __restrict
             if (any) {
                 z4 = *reinterpret_cast<const float4*>(z + e);
                 mu4 = *reinterpret_cast<const float4*>(net + (size_t)r * ld_net + c);
-                al4 = *reinterpret_cast<const float4*>(net + (size_t)r * ld_net + d + c);
+                if (!EX) al4 = *reinterpret_cast<const float4*>(net + (size_t)r * ld_net + d + c);
             }
             const float gl = gld ? gld[r] : 0.f;
             const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w}, mv[4] = {mu4.x, mu4.y, mu4.z, mu4.w},
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16_v4(const float* __restrict
                 const float g = gv[q];
                 float g_mu = 0.f, g_al = gl, g_z = 0.f, g_old = g;
                 if (cn[q] > 0) {
-                    const float ex = expf(av[q] + mv[q]);
+                    const float ex = EX ? mv[q] : expf(av[q] + mv[q]);
                     const float gc = g * (float)cn[q];
                     g_z = gc * ex;
                     g_mu = gc * zv[q] * ex;
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16_v4(const float* __restrict
             }
             acc4.x += gz[0]; acc4.y += gz[1]; acc4.z += gz[2]; acc4.w += gz[3];
             *reinterpret_cast<float4*>(gz_acc + e) = acc4;
-            *reinterpret_cast<float4*>(gxold + e) = make_float4(go[0], go[1], go[2], go[3]);
+            if (gxold) *reinterpret_cast<float4*>(gxold + e) = make_float4(go[0], go[1], go[2], go[3]);
             uint16_t* ob = gnb + (size_t)r * ldb + c;
             *reinterpret_cast<uint2*>(ob) = make_uint2(bm[0] | ((uint32_t)bm[1] << 16), bm[2] | ((uint32_t)bm[3] << 16));
             *reinterpret_cast<uint2*>(ob + d) = make_uint2(ba[0] | ((uint32_t)ba[1] << 16), ba[2] | ((uint32_t)ba[3] << 16));
@@ -768,24 +772,40 @@ extern "C" int gv_iaf_update_fwd_bf16(const float* z, const float* net, int ld_n
     return launch_status("gv_iaf_update_fwd_bf16");
 }
 
+static int iaf_update_bwd_bf16(const char* what, bool ex, const float* z, const float* net, int ld_net, const int32_t* colcount,
+                               const float* gx, const float* gld, float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t,
+                               int ldt, float* gx_old, int64_t n, int d, void* stream) {
+    GV_REQUIRE(n >= 0 && d > 0 && n < (1ll << 31), GV_ERR_SHAPE, "%s: n=%lld d=%d", what, (long long)n, d);
+    if (n == 0) return GV_OK;
+    GV_REQUIRE(z && net && colcount && gx && gz_accumulate && gnet_b && gnet_t && (gx_old || ex), GV_ERR_NULL, "%s: NULL pointer", what);
+    GV_REQUIRE(ldb >= 2 * d && ldt >= n && ld_net >= (ex ? d : 2 * d), GV_ERR_SHAPE, "%s: leading dimension too small", what);
+    const bool v4 = d % 4 == 0 && ld_net % 4 == 0 && ldb % 4 == 0 && ldt % 4 == 0 && aligned16(z) && aligned16(net) && aligned16(gx) &&
+                    aligned16(gz_accumulate) && (!gx_old || aligned16(gx_old)) && aligned16(colcount) &&
+                    (reinterpret_cast<uintptr_t>(gnet_b) & 7u) == 0 && (reinterpret_cast<uintptr_t>(gnet_t) & 7u) == 0;
+    const dim3 grid((d + 63) / 64, (unsigned)((n + 63) / 64));
+#define GV_IAF_BWD(K)                                                                                                        \
+    hipLaunchKernelGGL(K, grid, dim3(256), 0, (hipStream_t)stream, z, net, ld_net, colcount, gx, gld, gz_accumulate, gnet_b, ldb,   \
+                       gnet_t, ldt, gx_old, (int)n, d)
+    if (v4 && ex) GV_IAF_BWD(k_iaf_bwd_bf16_v4<true>);
+    else if (v4) GV_IAF_BWD(k_iaf_bwd_bf16_v4<false>);
+    else if (ex) GV_IAF_BWD(k_iaf_bwd_bf16<true>);
+    else GV_IAF_BWD(k_iaf_bwd_bf16<false>);
+#undef GV_IAF_BWD
+    return launch_status(what);
+}
+
 extern "C" int gv_iaf_update_bwd_bf16(const float* z, const float* net, int ld_net, const int32_t* colcount, const float* gx,
                                      const float* gld, float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t, int ldt,
                                      float* gx_old, int64_t n, int d, void* stream) {
-    GV_REQUIRE(n >= 0 && d > 0 && n < (1ll << 31), GV_ERR_SHAPE, "gv_iaf_update_bwd_bf16: n=%lld d=%d", (long long)n, d);
-    if (n == 0) return GV_OK;
-    GV_REQUIRE(z && net && colcount && gx && gz_accumulate && gnet_b && gnet_t && gx_old, GV_ERR_NULL,
-               "gv_iaf_update_bwd_bf16: NULL pointer");
-    GV_REQUIRE(ldb >= 2 * d && ldt >= n, GV_ERR_SHAPE, "gv_iaf_update_bwd_bf16: leading dimension too small");
-    const bool v4 = d % 4 == 0 && ld_net % 4 == 0 && ldb % 4 == 0 && ldt % 4 == 0 && aligned16(z) && aligned16(net) && aligned16(gx) &&
-                    aligned16(gz_accumulate) && aligned16(gx_old) && aligned16(colcount) &&
-                    (reinterpret_cast<uintptr_t>(gnet_b) & 7u) == 0 && (reinterpret_cast<uintptr_t>(gnet_t) & 7u) == 0;
-    if (v4)
-        hipLaunchKernelGGL(k_iaf_bwd_bf16_v4, dim3((d + 63) / 64, (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, z,
-                           net, ld_net, colcount, gx, gld, gz_accumulate, gnet_b, ldb, gnet_t, ldt, gx_old, (int)n, d);
-    else
-        hipLaunchKernelGGL(k_iaf_bwd_bf16, dim3((d + 63) / 64, (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, z,
-                           net, ld_net, colcount, gx, gld, gz_accumulate, gnet_b, ldb, gnet_t, ldt, gx_old, (int)n, d);
-    return launch_status("gv_iaf_update_bwd_bf16");
+    return iaf_update_bwd_bf16("gv_iaf_update_bwd_bf16", false, z, net, ld_net, colcount, gx, gld, gz_accumulate, gnet_b, ldb, gnet_t,
+                               ldt, gx_old, n, d, stream);
+}
+
+extern "C" int gv_iaf_update_bwd_bf16_ex(const float* z, const float* ex, int ld_ex, const int32_t* colcount, const float* gx,
+                                        const float* gld, float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t, int ldt,
+                                        float* gx_old, int64_t n, int d, void* stream) {
+    return iaf_update_bwd_bf16("gv_iaf_update_bwd_bf16_ex", true, z, ex, ld_ex, colcount, gx, gld, gz_accumulate, gnet_b, ldb, gnet_t,
+                               ldt, gx_old, n, d, stream);
 }
 
 extern "C" int gv_rowsum_bf16(const uint16_t* x, int ld, int rows, int cols, float* out, int accumulate, float* workspace,

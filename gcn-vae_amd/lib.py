@@ -63,11 +63,14 @@ SIGNATURES = {
     'gv_rowsum_bf16_workspace_floats': (_L, [_I, _I]),
     'gv_iaf_update_fwd_bf16': (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _L, _I, _P]),
     'gv_iaf_update_bwd_bf16': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _L, _I, _P]),
+    'gv_iaf_update_bwd_bf16_ex': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _L, _I, _P]),
     'gv_rowsum_bf16': (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     'gv_rowsum_bf16_segments': (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     'gv_made_pack_weight_elems': (_L, [_I, _I]),
     'gv_made_pack_weight': (_I, [_P, _I, _I, _I, _P, _P, _P]),
     'gv_made_pack_weight_multi': (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),
+    'gv_made_pack_weight_multi_iaf': (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),
+    'gv_made_pack_weight_iaf': (_I, [_P, _I, _I, _I, _P, _P]),
     'gv_made_chain_fits': (_I, [_I, _P, _P, _I]),
     'gv_made_chain': (_I, [_P, _I, _I, _I, _P, _P]),
     'gv_made_row_fwd': (_I, [_P, _I, _P, _P]),

@@ -2741,7 +2741,10 @@ class _ChainLayer(_ct.Structure):
     _fields_ = [('w_packed', _ct.c_void_p), ('bias', _ct.c_void_p), ('mask', _ct.c_void_p), ('out_bf16', _ct.c_void_p),
                 ('out_bf16_t', _ct.c_void_p), ('out_f32', _ct.c_void_p), ('n', _ct.c_int32), ('k', _ct.c_int32),
                 ('relu', _ct.c_int32), ('accumulate', _ct.c_int32), ('ldmask', _ct.c_int32), ('ldb', _ct.c_int32),
-                ('ldt', _ct.c_int32), ('ldc', _ct.c_int32)]
+                ('ldt', _ct.c_int32), ('ldc', _ct.c_int32), ('iaf_z', _ct.c_void_p), ('iaf_x_old', _ct.c_void_p),
+                ('iaf_colcount', _ct.c_void_p), ('iaf_x_new', _ct.c_void_p), ('iaf_ex', _ct.c_void_p), ('iaf_alpha', _ct.c_void_p),
+                ('iaf_ld', _ct.c_int32), ('iaf_reserved', _ct.c_int32), ('iaf_keep_colcount', _ct.c_void_p), ('mask_t', _ct.c_void_p),
+                ('add_src', _ct.c_void_p), ('add_colcount', _ct.c_void_p), ('ldmask_t', _ct.c_int32), ('reserved2', _ct.c_int32)]
 
 
 class _RowLayer(_ct.Structure):
@@ -2792,8 +2795,18 @@ def made_pack_weight(w, fwd=True, bwd=True):
     return pf, pb
 
 
-def made_pack_weights(ws):
-    """made_pack_weight for every layer of a MADE (at most 8) in one launch: [(packed W, packed W^T), ...]."""
+def made_pack_weight_iaf(w):
+    """Forward packing of a [mu | alpha] layer whose chain carries the IAF update (gv_made_pack_weight_iaf)."""
+    w, ld = _row_major(w, 'w')
+    n, k = w.shape
+    pf = torch.empty(int(lib.load().gv_made_pack_weight_elems(n, k)), dtype=torch.bfloat16, device=w.device)
+    lib.call('gv_made_pack_weight_iaf', ptr(w), ld, n, k, ptr(pf), lib.stream())
+    return pf
+
+
+def made_pack_weights(ws, iaf_last=False):
+    """made_pack_weight for every layer of a MADE (at most 8) in one launch: [(packed W, packed W^T), ...]; iaf_last: the last
+    layer's forward copy in the tile order of a chain that carries the IAF update."""
     ws = [_row_major(w, 'w') for w in ws]
     l = lib.load()
     dev = ws[0][0].device
@@ -2804,7 +2817,7 @@ def made_pack_weights(ws):
     ti = lambda vs: (_ct.c_int32 * k)(*[int(v) for v in vs])
     tw, tf, tb = tp([w for w, _ in ws]), tp(pf), tp(pb)
     tl, tn, tk = ti([ld for _, ld in ws]), ti([w.shape[0] for w, _ in ws]), ti([w.shape[1] for w, _ in ws])
-    lib.call('gv_made_pack_weight_multi', k, _ct.addressof(tw), _ct.addressof(tl), _ct.addressof(tn), _ct.addressof(tk),
+    lib.call('gv_made_pack_weight_multi_iaf' if iaf_last else 'gv_made_pack_weight_multi', k, _ct.addressof(tw), _ct.addressof(tl), _ct.addressof(tn), _ct.addressof(tk),
              _ct.addressof(tf), _ct.addressof(tb), lib.stream())
     return list(zip(pf, pb))
 
@@ -2834,6 +2847,23 @@ def made_chain(x, m, layers, tag=None):
         c.ldb = ob.stride(0) if ob is not None else 0
         c.ldt = ot.stride(0) if ot is not None else 0
         c.ldc = of.stride(0) if of is not None else 0
+        iaf = d.get('iaf')
+        if iaf is not None:      # dict(z, x_old, colcount, x_new=None, ex=None, alpha=None): fp32 [m][ld] with one common row stride
+            ts = [iaf[k_] for k_ in ('z', 'x_old', 'x_new', 'ex', 'alpha') if iaf.get(k_) is not None]
+            if len({t.stride(0) for t in ts}) != 1:
+                raise ValueError('made_chain: the IAF operands share one row stride')
+            c.iaf_z, c.iaf_x_old, c.iaf_colcount = ptr(iaf['z']), ptr(iaf['x_old']), ptr(iaf['colcount'])
+            c.iaf_x_new, c.iaf_ex, c.iaf_alpha = ptr(iaf.get('x_new')), ptr(iaf.get('ex')), ptr(iaf.get('alpha'))
+            c.iaf_ld = ts[0].stride(0)
+            c.iaf_reserved = int(iaf.get('debug', 0))
+            c.iaf_keep_colcount = ptr(iaf.get('keep'))
+        mt_, add = d.get('mask_t'), d.get('add')
+        if mt_ is not None:
+            c.mask_t, c.ldmask_t = ptr(mt_), mt_.stride(0)
+        if add is not None:      # (src fp32 [m][ldc], colcount): out_f32 += src where colcount == 0
+            if of is None or add[0].stride(0) != of.stride(0):
+                raise ValueError('made_chain: add_src shares the row stride of out_f32')
+            c.add_src, c.add_colcount = ptr(add[0]), ptr(add[1])
     lib.call('gv_made_chain', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), lib.stream(), tag=tag)
 
 
@@ -2867,8 +2897,9 @@ class _MADEForwardBF16(torch.autograd.Function):
         # weights: bf16 (out, in) and bf16 transposed (in, out), once per call
         chain = (MADE_CHAIN and S > 0 and L <= 8 and made_chain_fits(widths, [w.shape[1] for w in ws], False)
                  and made_chain_fits([w.shape[1] for w in reversed(ws)], [w.shape[0] for w in reversed(ws)], True))
+        fused = chain and MADE_CHAIN_IAF and d % 8 == 0 and widths[L - 1] == 2 * d
         if chain:       # one launch per pass: fragment-packed weights (forward and transposed form from one launch per layer)
-            packed = made_pack_weights(ws)
+            packed = made_pack_weights(ws, iaf_last=fused)
             wbf, wbt = [pk[0] for pk in packed], [pk[1] for pk in packed]
         else:
             wbf = [torch.empty(w.shape[0], _pad8(w.shape[1]), **bf) for w in ws]
@@ -2879,9 +2910,15 @@ class _MADEForwardBF16(torch.autograd.Function):
         xin_b = torch.empty(max(S, 1) * n, _pad8(d), **bf)
         tbufs = _empty_t_padded([d] + widths[:L - 1], max(S, 1), n, npad, bf)[:-1]
         xin_t = tbufs[0]
-        acts_b = [torch.empty(max(S, 1) * n, _pad8(widths[l]), **bf) for l in range(L - 1)]
+        # fused (the IAF update inside the chain): row-major activations never leave the chain (the backward chain stages its ReLU
+        # masks from the transposed copies), and of [mu | alpha] only exp(alpha + mu) is kept (+ alpha of the last pass)
+        acts_b = [] if fused else [torch.empty(max(S, 1) * n, _pad8(widths[l]), **bf) for l in range(L - 1)]
         acts_t = tbufs[1:]
-        net_out = torch.empty(max(S, 1) * n, widths[L - 1], **f32)   # [mu | alpha] of every stacked pass
+        if fused:
+            net_out = torch.empty(max(S, 1) * n, d, **f32)           # exp(alpha + mu) of every stacked pass
+            alpha_last = torch.empty(n, d, **f32)
+        else:
+            net_out = torch.empty(max(S, 1) * n, widths[L - 1], **f32)   # [mu | alpha] of every stacked pass
         x_out = torch.empty(n, d, **f32)
         # pass 0 on a single zero row (tiny: the generic GEMM with bf16-rounded operands)
         zero_row = torch.zeros(1, d, **f32)
@@ -2909,9 +2946,21 @@ class _MADEForwardBF16(torch.autograd.Function):
             tsl = slice((p - 1) * npad, (p - 1) * npad + n)
             inp = xin_b[sl]
             if chain:
+                head = dict(w_packed=wbf[L - 1], n=widths[L - 1], k=ws[L - 1].shape[1], bias=bs[L - 1])
+                if fused:       # the pass's IAF update in the last layer's epilogue: x_new and its operand copies leave the chain
+                    nsl = slice(p * n, (p + 1) * n)
+                    head['iaf'] = dict(z=z, x_old=xin[sl], colcount=colcount[p], ex=net_out[sl])
+                    if p < S:   # fp32 x_new only where the next pass hands a column through; its operands in bf16
+                        head['iaf'].update(x_new=xin[nsl], keep=colcount[p + 1])
+                        head.update(out_bf16=xin_b[nsl], out_bf16_t=xin_t[:, p * npad:p * npad + n])
+                    else:
+                        head['iaf'].update(x_new=x_out, alpha=alpha_last)
+                    made_chain(inp, n, [dict(w_packed=wbf[l], n=widths[l], k=ws[l].shape[1], bias=bs[l], relu=True,
+                                             out_bf16_t=acts_t[l][:, tsl]) for l in range(L - 1)] + [head], tag='madechain_fwd')
+                    continue
+                head['out_f32'] = net_out[sl]
                 made_chain(inp, n, [dict(w_packed=wbf[l], n=widths[l], k=ws[l].shape[1], bias=bs[l], relu=True,
-                                         out_bf16=acts_b[l][sl], out_bf16_t=acts_t[l][:, tsl]) for l in range(L - 1)] +
-                           [dict(w_packed=wbf[L - 1], n=widths[L - 1], k=ws[L - 1].shape[1], bias=bs[L - 1], out_f32=net_out[sl])],
+                                         out_bf16=acts_b[l][sl], out_bf16_t=acts_t[l][:, tsl]) for l in range(L - 1)] + [head],
                            tag='madechain_fwd')
             else:
                 for l in range(L - 1):
@@ -2921,13 +2970,16 @@ class _MADEForwardBF16(torch.autograd.Function):
                 gemm_bf16_nt(inp, wbf[L - 1], n, widths[L - 1], ws[L - 1].shape[1], bias=bs[L - 1], c_f32=net_out[sl])
             update(net_out[sl], 2 * d, xin[sl], colcount[p], p)
         log_det = torch.empty(n, **f32)
-        if P > 1:
+        if P > 1 and fused:
+            lib.call('gv_rowsum', ptr(alpha_last), d, 0, d, ptr(log_det), n, st)
+        elif P > 1:
             lib.call('gv_rowsum', ptr(net_out[(S - 1) * n:]), 2 * d, d, d, ptr(log_det), n, st)
         else:
             log_det = acts0[L - 1][:, d:].sum(dim=1).expand(n).contiguous()
         ctx.save_for_backward(z, colcount, xin_t, zero_row, net_out, *acts_b, *acts_t, *acts0, *wbt, *ws)
         ctx.L = L
         ctx.chain = chain
+        ctx.fused = fused
         ctx.row = row
         ctx.direct_b = [_direct(b) if b is not None else None for b in bs]
         _stamp_direct(ctx)
@@ -2940,8 +2992,9 @@ class _MADEForwardBF16(torch.autograd.Function):
         saved = ctx.saved_tensors
         z, colcount, xin_t, zero_row, net_out = saved[:5]
         o = 5
-        acts_b, acts_t = saved[o:o + L - 1], saved[o + L - 1:o + 2 * (L - 1)]
-        o += 2 * (L - 1)
+        nb_ = 0 if ctx.fused else L - 1          # fused: no row-major activations were kept
+        acts_b, acts_t = saved[o:o + nb_], saved[o + nb_:o + nb_ + L - 1]
+        o += nb_ + L - 1
         acts0, wbt, ws = saved[o:o + L], saved[o + L:o + 2 * L], saved[o + 2 * L:o + 3 * L]
         n, d = z.shape
         P = colcount.shape[0]
@@ -2956,7 +3009,10 @@ class _MADEForwardBF16(torch.autograd.Function):
         gld = None if gld is None else _chk(gld.contiguous(), name='gld')
         # ReLU-masked gradients w.r.t. every layer's pre-activation: bf16 row-major (operand of backward-x) and transposed
         # (operand of backward-W and of the bias sums)
-        gm_b = [torch.empty(max(S, 1) * n, _pad8(widths[l]), **bf) for l in range(L)]
+        if ctx.fused:   # only the chain's input [g_mu | g_alpha], one pass at a time; the hidden layers' stay inside the chain
+            gm_in = torch.empty(n, _pad8(widths[L - 1]), **bf)
+        else:
+            gm_b = [torch.empty(max(S, 1) * n, _pad8(widths[l]), **bf) for l in range(L)]
         *gm_t, gm_t_all = _empty_t_padded(widths, max(S, 1), n, npad, bf)
         g_z = torch.zeros(n, d, **f32)
         gz_p = torch.empty(n, d, **f32)
@@ -2965,6 +3021,17 @@ class _MADEForwardBF16(torch.autograd.Function):
             sl = slice((p - 1) * n, p * n)
             tsl = slice((p - 1) * npad, (p - 1) * npad + n)
             g_old = torch.empty(n, d, **f32)
+            if ctx.fused:
+                # from exp(alpha + mu); the gradient handed through to x_old (columns of count 0) is added by the chain's last layer
+                lib.call('gv_iaf_update_bwd_bf16_ex', ptr(z), ptr(net_out[sl]), d, ptr(colcount[p]), ptr(g_cur),
+                         ptr(gld) if p == P - 1 else None, ptr(g_z), ptr(gm_in), gm_in.stride(0), ptr(gm_t[L - 1][:, tsl]),
+                         gm_t[L - 1].stride(0), None, n, d, st)
+                made_chain(gm_in, n,
+                           [dict(w_packed=wbt[l], n=widths[l - 1], k=widths[l], mask_t=acts_t[l - 1][:, tsl],
+                                 out_bf16_t=gm_t[l - 1][:, tsl]) for l in reversed(range(1, L))] +
+                           [dict(w_packed=wbt[0], n=d, k=widths[0], out_f32=g_old, add=(g_cur, colcount[p]))], tag='madechain_bwd')
+                g_cur = g_old
+                continue
             # the update's backward: g_z accumulated in place, [g_mu | g_alpha] straight into the bf16 operands of the products
             lib.call('gv_iaf_update_bwd_bf16', ptr(z), ptr(net_out[sl]), 2 * d, ptr(colcount[p]), ptr(g_cur),
                      ptr(gld) if p == P - 1 else None, ptr(g_z), ptr(gm_b[L - 1][sl]), gm_b[L - 1].stride(0),
@@ -3060,6 +3127,7 @@ class _MADEForwardBF16(torch.autograd.Function):
 
 
 MADE_BF16_STORAGE = _os.environ.get('GV_MADE_BF16', '1') == '1'
+MADE_CHAIN_IAF = _os.environ.get('GV_MADE_CHAIN_IAF', '1') == '1'      # the IAF update inside the chain's last layer
 
 
 def made_forward(z, colcount, weights, biases, masks=None):

@@ -201,6 +201,11 @@ int gv_iaf_update_fwd_bf16(const float* z, const float* net, int ld_net, const f
 int gv_iaf_update_bwd_bf16(const float* z, const float* net, int ld_net, const int32_t* colcount, const float* gx, const float* gld,
                            float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t, int ldt, float* gx_old, int64_t n,
                            int d, void* stream);
+/* ... from ex = expf(alpha + mu) [n][ld_ex] (what a forward chain with the fused update stores, gv_chain_layer.iaf_ex) instead
+ * of [mu | alpha]; gx_old may be NULL (the backward chain adds the handed-through gradient itself: gv_chain_layer.add_src). */
+int gv_iaf_update_bwd_bf16_ex(const float* z, const float* ex, int ld_ex, const int32_t* colcount, const float* gx, const float* gld,
+                              float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t, int ldt, float* gx_old, int64_t n,
+                              int d, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * K4 in bf16 (BASELINE configs[2]): the masked-MLP products of MADE / IAF (kgvae/flow_network.py:7-98, called from
  * kgvae/model.py:116-123) with bf16 STORAGE of weights and activations, bf16 MFMA, fp32 accumulation.
@@ -256,12 +261,37 @@ typedef struct gv_chain_layer {
     uint16_t* out_bf16_t;     /* [n][ldt] or NULL */
     float* out_f32;           /* [m][ldc] or NULL */
     int32_t n, k, relu, accumulate, ldmask, ldb, ldt, ldc;
+    /* The IAF update (kgvae/flow_network.py:92-96) fused into the LAST layer of a forward chain: iaf_z != NULL, n = 2 d, weight
+     * packed by gv_made_pack_weight_iaf (a tile = 16 mu columns + the same columns' alpha).  The layer's result [mu | alpha] is
+     * consumed in registers:  x_new[r][c] = colcount[c] > 0 ? z[r][c] * expf(alpha[r][c] + mu[r][c]) : x_old[r][c].
+     * out_bf16 [m][ldb] / out_bf16_t [d][ldt] then receive x_new rounded to bf16 (the next pass's operands), out_f32 [m][ldc]
+     * (optional) [mu | alpha] in natural column order.  Same values as gv_iaf_update_fwd_bf16 on the stored [mu | alpha]. */
+    const float* iaf_z;           /* [m][iaf_ld] or NULL: no update */
+    const float* iaf_x_old;       /* [m][iaf_ld]: the pass's fp32 input (read where colcount == 0) */
+    const int32_t* iaf_colcount;  /* [d] */
+    float* iaf_x_new;             /* [m][iaf_ld] or NULL */
+    float* iaf_ex;                /* [m][iaf_ld] or NULL: expf(alpha + mu), all the update's backward needs */
+    float* iaf_alpha;             /* [m][iaf_ld] or NULL: alpha (log-det = its row sums) */
+    int32_t iaf_ld, iaf_reserved;
+    const int32_t* iaf_keep_colcount; /* [d] or NULL: iaf_x_new is stored only for the groups of 4 columns in which this count is 0
+                                       * somewhere -- the columns the NEXT pass hands through from its x_old; NULL: all columns */
+    /* backward chains */
+    const uint16_t* mask_t;       /* [n][ldmask_t] bf16 or NULL: the mask given TRANSPOSED (a forward chain's out_bf16_t); instead of mask */
+    const float* add_src;         /* [m][ldc] fp32 or NULL: out_f32 += add_src in the columns where add_colcount == 0 (the */
+    const int32_t* add_colcount;  /* [n]                    gradient the IAF update hands through to its x_old) */
+    int32_t ldmask_t, reserved2;
 } gv_chain_layer;
 int64_t gv_made_pack_weight_elems(int n, int k);
 int gv_made_pack_weight(const float* w, int ld, int n, int k, uint16_t* packed_fwd, uint16_t* packed_bwd, void* stream);
 /* ... of up to GV_CHAIN_MAX_LAYERS weights in one launch (host tables, read during the call). */
 int gv_made_pack_weight_multi(int count, const float* const* w, const int32_t* ld, const int32_t* n, const int32_t* k,
                               uint16_t* const* packed_fwd, uint16_t* const* packed_bwd, void* stream);
+/* The forward packing of a [mu | alpha] layer (n = 2 d) for a chain whose last layer carries the IAF update: B-row j of tile t
+ * is W row 16 t + j (j < 16) or d + 16 t + j - 16; same size as the plain packing.  _multi_iaf: as _multi, the LAST entry's
+ * forward copy in this order (its transposed copy, the backward chain's first layer, stays plain). */
+int gv_made_pack_weight_iaf(const float* w, int ld, int n, int k, uint16_t* packed_fwd, void* stream);
+int gv_made_pack_weight_multi_iaf(int count, const float* const* w, const int32_t* ld, const int32_t* n, const int32_t* k,
+                                  uint16_t* const* packed_fwd, uint16_t* const* packed_bwd, void* stream);
 int gv_made_chain_fits(int n_layers, const int32_t* n_of_layer, const int32_t* k_of_layer, int any_mask);
 int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, void* stream);
 /* ---------------------------------------------------------------------------------------------

@@ -1438,6 +1438,30 @@ def test_made_chain_is_bit_identical_to_the_product_by_product_launches(ops, m, 
     assert torch.equal(of1, of2)
     for a, b in zip(ob1 + ot1, ob2 + ot2):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    if masked:
+        # the form the fused MADE backward uses: masks given TRANSPOSED (a forward chain's out_bf16_t), no row-major copies,
+        # and the last layer adding add_src in the columns whose count is 0 instead of accumulating
+        ob3, ot3, of3 = buffers()
+        src = torch.randn(m, widths[L], generator=g).to(dev)
+        cnt = torch.randint(0, 2, (widths[L],), generator=g).to(torch.int32).to(dev)
+        layers_t = []
+        for i in range(L):
+            last = i == L - 1
+            mt = None
+            if not last:
+                mt = torch.zeros(widths[i + 1], mp, dtype=torch.bfloat16, device=dev)
+                mt[:, :m] = masks[i].t()
+            layers_t.append(dict(w_packed=layers[i]['w_packed'], n=widths[i + 1], k=widths[i], mask_t=mt,
+                                 out_f32=of3 if last else None, add=(src, cnt) if last else None,
+                                 out_bf16_t=None if last else ot3[i]))
+        ops.made_chain(x, m, layers_t)
+        torch.cuda.synchronize()
+        plain = torch.empty(m, widths[L], device=dev)
+        ops.made_chain(x, m, [dict(l_, out_bf16=None, out_bf16_t=None) for l_ in layers[:-1]] + [dict(layers[-1], out_f32=plain, accumulate=False)])
+        want = plain + torch.where(cnt == 0, src, torch.zeros((), device=dev))
+        assert torch.equal(of3, want)
+        for a, b in zip(ot2, ot3):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16))
     # and the arithmetic itself
     ref = x.float().cpu()
     for i in range(L):
@@ -1448,6 +1472,80 @@ def test_made_chain_is_bit_identical_to_the_product_by_product_launches(ops, m, 
             ref = torch.relu(ref) if not masked else torch.where(masks[i].float().cpu() > 0, ref, torch.zeros(()))
             ref = obf._r(ref)
     close(of2, ref + (0.25 if masked else 0.0), rtol=2e-3, atol_scale=2e-3, msg='chain vs fp32 matmul of rounded operands')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('m,d,hidden,n_hidden,with_copies', [(300, 200, 200, 2, True), (14541, 200, 200, 3, True), (65, 8, 8, 1, True),
+                                                            (1000, 200, 264, 1, False), (130, 24, 40, 2, True)])
+def test_made_chain_with_the_iaf_update_in_its_last_layer_is_bit_identical_to_the_separate_update(ops, m, d, hidden, n_hidden,
+                                                                                                 with_copies):
+    """The IAF update fused into the chain's last layer (kgvae/flow_network.py:92-96; gv_chain_layer.iaf_*) against the same chain
+    storing [mu | alpha] followed by gv_iaf_update_fwd_bf16: x_new (fp32, bf16 row-major, bf16 transposed) bit for bit, with
+    columns of count 0 passed through; exp(alpha + mu) and alpha equal what the stored [mu | alpha] gives."""
+    from gcn_vae_amd import lib
+    from gcn_vae_amd.lib import ptr
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(m + d)
+    widths = [d] + [hidden] * (n_hidden + 1) + [2 * d]
+    L = len(widths) - 1
+    x_old = torch.randn(m, d, generator=g).to(dev)
+    xb = x_old.to(torch.bfloat16)
+    z = torch.randn(m, d, generator=g).to(dev)
+    ws = [(torch.randn(widths[i + 1], widths[i], generator=g) * (1.0 / widths[i] ** 0.5)).to(dev) for i in range(L)]
+    bs = [torch.randn(widths[i + 1], generator=g).to(dev) * 0.1 for i in range(L)]
+    cc = torch.randint(0, 3, (d,), generator=g).to(torch.int32).to(dev)
+    cc[-1] = 0                                              # the reference's middle passes leave the last column alone
+    mp = (m + 7) // 8 * 8
+    dp = (d + 7) // 8 * 8
+    packed = ops.made_pack_weights(ws)
+    hidden_layers = [dict(w_packed=packed[i][0], n=widths[i + 1], k=widths[i], bias=bs[i], relu=True) for i in range(L - 1)]
+    # separate: chain -> [mu | alpha] -> update kernel
+    net = torch.empty(m, 2 * d, device=dev)
+    ops.made_chain(xb, m, hidden_layers + [dict(w_packed=packed[L - 1][0], n=2 * d, k=widths[L - 1], bias=bs[L - 1], out_f32=net)])
+    x1, x1b, x1t = torch.zeros(m, d, device=dev), torch.zeros(m, dp, dtype=torch.bfloat16, device=dev), \
+        torch.zeros(d, mp, dtype=torch.bfloat16, device=dev)
+    lib.call('gv_iaf_update_fwd_bf16', ptr(z), ptr(net), 2 * d, ptr(x_old), ptr(cc), ptr(x1), ptr(x1b), x1b.stride(0), ptr(x1t),
+             x1t.stride(0), m, d, lib.stream())
+    # fused
+    packed_iaf = ops.made_pack_weights(ws, iaf_last=True)
+    for i in range(L - 1):
+        assert torch.equal(packed[i][0].view(torch.int16), packed_iaf[i][0].view(torch.int16))
+    for i in range(L):
+        assert torch.equal(packed[i][1].view(torch.int16), packed_iaf[i][1].view(torch.int16))     # the transposed copies stay plain
+    assert torch.equal(ops.made_pack_weight_iaf(ws[L - 1]).view(torch.int16), packed_iaf[L - 1][0].view(torch.int16))
+    x2, x2b, x2t = torch.zeros(m, d, device=dev), torch.zeros(m, dp, dtype=torch.bfloat16, device=dev), \
+        torch.zeros(d, mp, dtype=torch.bfloat16, device=dev)
+    ex, alpha, net2 = torch.zeros(m, d, device=dev), torch.zeros(m, d, device=dev), torch.zeros(m, 2 * d, device=dev)
+    last = dict(w_packed=packed_iaf[L - 1][0], n=2 * d, k=widths[L - 1], bias=bs[L - 1], out_f32=net2,
+                iaf=dict(z=z, x_old=x_old, colcount=cc, x_new=x2, ex=ex, alpha=alpha))
+    if with_copies:
+        last.update(out_bf16=x2b, out_bf16_t=x2t)
+    ops.made_chain(xb, m, hidden_layers + [last])
+    torch.cuda.synchronize()
+    assert torch.equal(net, net2)
+    assert torch.equal(x1, x2)
+    assert bool((x2[:, cc == 0] == x_old[:, cc == 0]).all())
+    if with_copies:
+        assert torch.equal(x1b.view(torch.int16), x2b.view(torch.int16)) and torch.equal(x1t.view(torch.int16), x2t.view(torch.int16))
+    assert torch.equal(alpha, net[:, d:])
+    # exp(alpha + mu) is what the backward kernel recomputes from [mu | alpha]: x_new = z * ex where the column is updated
+    upd = cc > 0
+    assert torch.equal((z * ex)[:, upd], x1[:, upd])
+    # x_new alone (the last pass: no operand copies, no [mu | alpha])
+    x3 = torch.zeros(m, d, device=dev)
+    ops.made_chain(xb, m, hidden_layers + [dict(w_packed=packed_iaf[L - 1][0], n=2 * d, k=widths[L - 1], bias=bs[L - 1],
+                                                iaf=dict(z=z, x_old=x_old, colcount=cc, x_new=x3))])
+    assert torch.equal(x3, x1)
+    # fp32 x_new only where the NEXT pass hands a column through (groups of 4 columns holding a count of 0)
+    nxt = torch.ones(d, dtype=torch.int32, device=dev)
+    nxt[-1] = 0
+    if d > 8:
+        nxt[5] = 0
+    x4 = torch.full((m, d), -7.0, device=dev)
+    ops.made_chain(xb, m, hidden_layers + [dict(w_packed=packed_iaf[L - 1][0], n=2 * d, k=widths[L - 1], bias=bs[L - 1],
+                                                iaf=dict(z=z, x_old=x_old, colcount=cc, x_new=x4, keep=nxt))])
+    kept = (nxt.view(-1, 4) == 0).any(dim=1).repeat_interleave(4)
+    assert torch.equal(x4[:, kept], x1[:, kept]) and bool((x4[:, ~kept] == -7.0).all())
 
 
 @pytest.mark.gpu
