@@ -198,13 +198,14 @@ __device__ __forceinline__ void chain_stage_mask(uint16_t* tile, int ldk, const 
 //   group;  transposed bf16 copy: per register a 2-B store whose 32 lanes are 32 consecutive rows = 64 contiguous bytes.
 // (biases and the accumulate operand are fetched group by group, not up front: the kernel has to fit 128 registers)
 constexpr bool LEAN = true;
+template <bool FULL>
 __device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const gv_chain_layer& Ly, int tile, int m0, int m,
                                                uint16_t* An, int ldk, int kp_next, const uint16_t* mbuf, const float* bias_l,
-                                               const int* cnt_lds, int r, int h) {
+                                               const int* cnt_lds, const uint32_t* bits_l, int r, int h) {
     // opaque copies: without them the compiler hoists per-row predicates and 64-bit offsets out of the unit loop and spills
     asm volatile("" : "+v"(r), "+v"(h));
     float4 old[LEAN ? 1 : 2][LEAN ? 1 : 4];       // accumulate: all previous values requested at once (one round trip)
-    const bool acc_old = Ly.out_f32 && Ly.accumulate;
+    const bool acc_old = FULL && Ly.out_f32 && Ly.accumulate;
     float4 bias4[LEAN ? 1 : 4];        // all four groups' biases requested before the first group's arithmetic (one LDS round trip)
     if constexpr (!LEAN) {
 #pragma unroll
@@ -238,12 +239,19 @@ __device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const g
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            if ((Ly.mask || Ly.mask_t) && cv) {
+            if (FULL && (Ly.mask || Ly.mask_t) && cv) {
                 const uint2 mv = *reinterpret_cast<const uint2*>(mbuf + row * ldk + c0);
                 if ((int16_t)(mv.x & 0xffff) <= 0) v[0] = 0.f;
                 if ((int16_t)(mv.x >> 16) <= 0) v[1] = 0.f;
                 if ((int16_t)(mv.y & 0xffff) <= 0) v[2] = 0.f;
                 if ((int16_t)(mv.y >> 16) <= 0) v[3] = 0.f;
+            }
+            if (!FULL && Ly.mask_bits && cv) {      // the row's word of this column tile (staged in LDS at the start of the kernel)
+                const uint32_t wbits = bits_l[row * ((Ly.n + 31) >> 5) + tile] >> (8 * g + 4 * h);
+                if (!(wbits & 1u)) v[0] = 0.f;
+                if (!(wbits & 2u)) v[1] = 0.f;
+                if (!(wbits & 4u)) v[2] = 0.f;
+                if (!(wbits & 8u)) v[3] = 0.f;
             }
             if (Ly.out_f32 && cv && m0 + row < m) {
                 float4 o = make_float4(v[0], v[1], v[2], v[3]);
@@ -376,7 +384,27 @@ __device__ __forceinline__ void chain_epilogue_iaf(const f32x16_t (&acc)[2], con
 
 // store wave: the row-major bf16 copy of a layer's result out of its LDS tile, 16-B pieces, reads issued in batches of 8.
 // (row, piece) advance incrementally: an integer division per piece would cost this single wave more than the copy itself
+template <bool FULL>
 __device__ __forceinline__ void chain_store(const gv_chain_layer& Ly, const uint16_t* An, int ldk, int m0, int m, int ts) {
+    if (!FULL && Ly.out_bits) {       // sign bits of the layer's (bf16-rounded) result, word [row][tile of 32 columns], out of the finished tile
+        const int nt = (Ly.n + 31) >> 5;
+        for (int i = ts; i < CH_BM * nt; i += CH_STORE_THREADS) {
+            const int row = i / nt, t = i - row * nt;
+            uint32_t word = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = t * 32 + q * 8;
+                if (c < Ly.n) {      // widths are multiples of 8: a piece is inside or outside as a whole
+                    const uint4 v = *reinterpret_cast<const uint4*>(An + row * ldk + c);
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        word |= (((int16_t)(w[e] & 0xffffu) > 0 ? 1u : 0u) | ((int16_t)(w[e] >> 16) > 0 ? 2u : 0u)) << (q * 8 + 2 * e);
+                }
+            }
+            if (m0 + row < m) Ly.out_bits[(size_t)(m0 + row) * Ly.ldbits + t] = word;
+        }
+    }
     if (!Ly.out_bf16) return;
     const int ppr = (Ly.iaf_z ? Ly.n >> 1 : Ly.n) >> 3, total = CH_BM * ppr;      // an IAF layer's tile holds x_new: d columns
     const int drow = CH_STORE_THREADS / ppr, dpc = CH_STORE_THREADS - drow * ppr;      // one step of 64 pieces
@@ -408,6 +436,9 @@ __device__ __forceinline__ void chain_store(const gv_chain_layer& Ly, const uint
 // SIMD = TWO workgroups per CU where the LDS tiles allow (the forward chain: 60 KB), which is what counts once there are more row
 // tiles than CUs (WN18RR: 640 tiles, forward chain 93 -> 72 us).  A second set requested a whole unit ahead (the first design,
 // two unit bodies with fixed set roles) measured the same at 228 tiles and cost 52 registers.
+// FULL = false: the instance for chains without tile masks (mask / mask_t) and without an accumulating fp32 output -- every
+// MADE pass of the fused path; without that code it keeps clear of the 128-register limit (the full instance spills ~30 B)
+template <bool FULL>
 __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_made_chain(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t chain_lds[];
     const int ldk = p.ldk, nl = p.n_layers, m0 = blockIdx.x * CH_BM;
@@ -433,7 +464,7 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         }
         chain_issue(qa, b0, off, ksc);
     }
-    int bias_total = 0;
+    int bias_total = 0, bits_base = 0;
     {       // every layer's bias into LDS (all loads in flight together): no global round trip in an epilogue
         float bv[CH_L];
         int off = 0;
@@ -454,25 +485,51 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             reinterpret_cast<int*>(bias_lds + off)[threadIdx.x] = Ll.iaf_colcount[threadIdx.x];
         else if (Ll.add_src && (int)threadIdx.x < Ll.n)
             reinterpret_cast<int*>(bias_lds + off)[threadIdx.x] = Ll.add_colcount[threadIdx.x];
+        off += Ll.iaf_z ? Ll.n >> 1 : (Ll.add_src ? Ll.n : 0);
+        bits_base = off;
+    }
+    if constexpr (!FULL) {       // every layer's mask bits of this workgroup's 64 rows behind them ([row][tile] words), requested together as well
+        uint32_t bw[CH_L];
+#pragma unroll
+        for (int l = 0; l < CH_L; ++l) {
+            bw[l] = 0u;
+            if (l < nl && p.L[l].mask_bits) {
+                const int nt = (p.L[l].n + 31) >> 5, row = (int)threadIdx.x / nt, t = (int)threadIdx.x - row * nt;
+                if (row < CH_BM && m0 + row < p.m) bw[l] = p.L[l].mask_bits[(size_t)(m0 + row) * p.L[l].ldbits + t];
+            }
+        }
+        uint32_t* bl = reinterpret_cast<uint32_t*>(bias_lds + bits_base);
+#pragma unroll
+        for (int l = 0; l < CH_L; ++l)
+            if (l < nl && p.L[l].mask_bits) {
+                const int nt = (p.L[l].n + 31) >> 5;
+                if ((int)threadIdx.x < CH_BM * nt) bl[threadIdx.x] = bw[l];
+                for (int i = (int)threadIdx.x + CH_THREADS; i < CH_BM * nt; i += CH_THREADS) {      // layers wider than 256 columns
+                    const int row = i / nt, t = i - row * nt;
+                    bl[i] = m0 + row < p.m ? p.L[l].mask_bits[(size_t)(m0 + row) * p.L[l].ldbits + t] : 0u;
+                }
+                bl += CH_BM * nt;
+            }
     }
     chain_stage(chain_lds, ldk, p.x, p.ldx, m0, p.m, p.L[0].k, (p.L[0].k + 15) & ~15);
-    if (p.L[0].mask || p.L[0].mask_t) chain_stage_mask(mbuf, ldk, p.L[0], m0, p.m);
+    if (FULL && (p.L[0].mask || p.L[0].mask_t)) chain_stage_mask(mbuf, ldk, p.L[0], m0, p.m);
     __syncthreads();
 
     f32x16_t acc[2];
-    int layer = 0, bias_off = 0;
+    int layer = 0, bias_off = 0, bits_off = 0;
 
     // cross layer boundaries until this wave stands in layer `target` (nl: past the last layer)
 #define CHAIN_CROSS(target)                                                                                              \
     while (layer < (target)) {                                                                                          \
         __syncthreads();                                                                                                \
-        if (layer + 1 < nl && (p.L[layer + 1].mask || p.L[layer + 1].mask_t)) {                                         \
+        if (FULL && layer + 1 < nl && (p.L[layer + 1].mask || p.L[layer + 1].mask_t)) {                                 \
             chain_stage_mask(mbuf, ldk, p.L[layer + 1], m0, p.m);                                                       \
             __syncthreads();                                                                                            \
         }                                                                                                               \
         if (!mma_wave && (layer + 1 < nl || p.L[layer].iaf_z))                                                          \
-            chain_store(p.L[layer], chain_lds + ((layer + 1) & 1) * CH_BM * ldk, ldk, m0, p.m, (int)threadIdx.x - CH_MMA_THREADS); \
+            chain_store<FULL>(p.L[layer], chain_lds + ((layer + 1) & 1) * CH_BM * ldk, ldk, m0, p.m, (int)threadIdx.x - CH_MMA_THREADS); \
         bias_off += p.L[layer].n;                                                                                       \
+        bits_off += p.L[layer].mask_bits ? CH_BM * ((p.L[layer].n + 31) >> 5) : 0;                                      \
         ++layer;                                                                                                        \
     }
 
@@ -491,7 +548,9 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;                                 \
         }                                                                                                               \
         const uint16_t* A = chain_lds + (u.l & 1) * CH_BM * ldk;                                                        \
-        chain_mma(acc, Q, A + r * ldk + 8 * h + u.ch * CH_KS * 16, 32 * ldk, min(CH_KS, ks - u.ch * CH_KS));            \
+        int ra = r, ha = h;        /* opaque: a hoisted fragment address is one more register held across the whole loop */ \
+        asm volatile("" : "+v"(ra), "+v"(ha));                                                                          \
+        chain_mma(acc, Q, A + ra * ldk + 8 * ha + u.ch * CH_KS * 16, 32 * ldk, min(CH_KS, ks - u.ch * CH_KS));          \
         const bool iaf_unit = Ly.iaf_z && u.ch + 1 == nch;                                                              \
         if (iaf_unit)                                                                                                   \
             chain_epilogue_iaf(acc, Ly, u.tile, m0, p.m, chain_lds + ((u.l + 1) & 1) * CH_BM * ldk, ldk,                \
@@ -499,9 +558,10 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                                reinterpret_cast<const int*>(bias_lds + bias_total), r, h);                              \
         chain_issue(Q, nb0, noff, nksc);                                                                                \
         if (u.ch + 1 == nch && !iaf_unit)                                                                               \
-            chain_epilogue(acc, Ly, u.tile, m0, p.m, chain_lds + ((u.l + 1) & 1) * CH_BM * ldk, ldk,                    \
+            chain_epilogue<FULL>(acc, Ly, u.tile, m0, p.m, chain_lds + ((u.l + 1) & 1) * CH_BM * ldk, ldk,              \
                            u.l + 1 < nl ? (Ly.n + 15) & ~15 : 0, mbuf, bias_lds + bias_off,                             \
-                           reinterpret_cast<const int*>(bias_lds + bias_total), r, h);                                  \
+                           reinterpret_cast<const int*>(bias_lds + bias_total),                                         \
+                           reinterpret_cast<const uint32_t*>(bias_lds + bits_base) + bits_off, r, h);                   \
         u = nu;                                                                                                         \
     }
 
@@ -652,6 +712,8 @@ extern "C" int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, co
         GV_REQUIRE(L.w_packed && aligned16(L.w_packed), GV_ERR_NULL, "gv_made_chain: layer %d has no packed weight", i);
         GV_REQUIRE(L.out_bf16 || L.out_bf16_t || L.out_f32 || L.iaf_z || i + 1 < n_layers, GV_ERR_NULL, "gv_made_chain: the last layer stores nothing");
         GV_REQUIRE(!(L.out_bf16 && i + 1 == n_layers && !L.iaf_z), GV_ERR_SHAPE, "gv_made_chain: the last layer has no row-major bf16 output");
+        GV_REQUIRE((!L.out_bits && !L.mask_bits) || (L.ldbits >= (L.n + 31) / 32 && !(L.mask_bits && (L.mask || L.mask_t)) && !L.iaf_z),
+                   GV_ERR_SHAPE, "gv_made_chain: layer %d: mask bits are [m][ldbits >= ceil(n / 32)] words, one mask form per layer", i);
         GV_REQUIRE(!(L.mask && L.mask_t) && (!L.mask_t || (L.ldmask_t >= m && L.ldmask_t % 8 == 0 && aligned16(L.mask_t))), GV_ERR_ALIGN,
                    "gv_made_chain: layer %d: one mask form; the transposed one has 16-B aligned rows of >= m entries", i);
         GV_REQUIRE(!L.add_src || (i + 1 == n_layers && L.out_f32 && L.add_colcount && aligned16(L.add_src) && aligned16(L.add_colcount) &&
@@ -677,19 +739,30 @@ extern "C" int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, co
     for (int i = 0; i < n_layers; ++i) bias_floats += (size_t)layers[i].n;
     if (layers[n_layers - 1].iaf_z) bias_floats += (size_t)layers[n_layers - 1].n / 2;      // its column counts
     else if (layers[n_layers - 1].add_src) bias_floats += (size_t)layers[n_layers - 1].n;
+    for (int i = 0; i < n_layers; ++i)
+        if (layers[i].mask_bits) bias_floats += (size_t)CH_BM * ((layers[i].n + 31) / 32);      // its bit tile
     const size_t lds = (size_t)(has_mask ? 3 : 2) * CH_BM * ldk * sizeof(uint16_t) + bias_floats * sizeof(float);
     GV_REQUIRE(lds <= 160 * 1024, GV_ERR_SHAPE, "gv_made_chain: layers this wide need %zu B of LDS (160 KB per CU)", lds);
     p.x = x; p.ldx = ldx; p.m = m; p.n_layers = n_layers; p.ldk = ldk; p.has_mask = has_mask ? 1 : 0;
+    bool full = false, bits = false;
+    for (int i = 0; i < n_layers; ++i) {
+        full = full || layers[i].mask || layers[i].mask_t || layers[i].accumulate;
+        bits = bits || layers[i].mask_bits || layers[i].out_bits;
+    }
+    GV_REQUIRE(!(full && bits), GV_ERR_SHAPE, "gv_made_chain: mask bits do not combine with tile masks or an accumulating output in one chain");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_made_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_made_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_made_chain<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             (void)hipGetLastError();
             set_error("gv_made_chain: cannot raise the dynamic LDS limit");
             return GV_ERR_SHAPE;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_made_chain, dim3((unsigned)((m + CH_BM - 1) / CH_BM)), dim3(CH_THREADS), lds, (hipStream_t)stream, p);
+    const dim3 grid((unsigned)((m + CH_BM - 1) / CH_BM));
+    if (full) hipLaunchKernelGGL(k_made_chain<true>, grid, dim3(CH_THREADS), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(k_made_chain<false>, grid, dim3(CH_THREADS), lds, (hipStream_t)stream, p);
     return launch_status("gv_made_chain");
 }
 

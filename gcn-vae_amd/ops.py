@@ -2744,7 +2744,8 @@ class _ChainLayer(_ct.Structure):
                 ('ldt', _ct.c_int32), ('ldc', _ct.c_int32), ('iaf_z', _ct.c_void_p), ('iaf_x_old', _ct.c_void_p),
                 ('iaf_colcount', _ct.c_void_p), ('iaf_x_new', _ct.c_void_p), ('iaf_ex', _ct.c_void_p), ('iaf_alpha', _ct.c_void_p),
                 ('iaf_ld', _ct.c_int32), ('iaf_reserved', _ct.c_int32), ('iaf_keep_colcount', _ct.c_void_p), ('mask_t', _ct.c_void_p),
-                ('add_src', _ct.c_void_p), ('add_colcount', _ct.c_void_p), ('ldmask_t', _ct.c_int32), ('reserved2', _ct.c_int32)]
+                ('add_src', _ct.c_void_p), ('add_colcount', _ct.c_void_p), ('ldmask_t', _ct.c_int32), ('ldbits', _ct.c_int32),
+                ('out_bits', _ct.c_void_p), ('mask_bits', _ct.c_void_p)]
 
 
 class _RowLayer(_ct.Structure):
@@ -2860,6 +2861,12 @@ def made_chain(x, m, layers, tag=None):
         mt_, add = d.get('mask_t'), d.get('add')
         if mt_ is not None:
             c.mask_t, c.ldmask_t = ptr(mt_), mt_.stride(0)
+        obits, mbits = d.get('out_bits'), d.get('mask_bits')       # int32 (m, >= ceil(n / 32)) sign bits of a hidden activation
+        if obits is not None or mbits is not None:
+            bt = obits if obits is not None else mbits
+            if bt.dtype != torch.int32:
+                raise ValueError('made_chain: mask bits are int32 words')
+            c.out_bits, c.mask_bits, c.ldbits = ptr(obits), ptr(mbits), bt.stride(0)
         if add is not None:      # (src fp32 [m][ldc], colcount): out_f32 += src where colcount == 0
             if of is None or add[0].stride(0) != of.stride(0):
                 raise ValueError('made_chain: add_src shares the row stride of out_f32')
@@ -2913,6 +2920,8 @@ class _MADEForwardBF16(torch.autograd.Function):
         # fused (the IAF update inside the chain): row-major activations never leave the chain (the backward chain stages its ReLU
         # masks from the transposed copies), and of [mu | alpha] only exp(alpha + mu) is kept (+ alpha of the last pass)
         acts_b = [] if fused else [torch.empty(max(S, 1) * n, _pad8(widths[l]), **bf) for l in range(L - 1)]
+        # ... as sign BITS, one int32 word per (row, 32 columns)
+        sign = [torch.empty(max(S, 1) * n, (widths[l] + 31) // 32, dtype=torch.int32, device=dev) for l in range(L - 1)] if fused else []
         acts_t = tbufs[1:]
         if fused:
             net_out = torch.empty(max(S, 1) * n, d, **f32)           # exp(alpha + mu) of every stacked pass
@@ -2956,7 +2965,8 @@ class _MADEForwardBF16(torch.autograd.Function):
                     else:
                         head['iaf'].update(x_new=x_out, alpha=alpha_last)
                     made_chain(inp, n, [dict(w_packed=wbf[l], n=widths[l], k=ws[l].shape[1], bias=bs[l], relu=True,
-                                             out_bf16_t=acts_t[l][:, tsl]) for l in range(L - 1)] + [head], tag='madechain_fwd')
+                                             out_bf16_t=acts_t[l][:, tsl], out_bits=sign[l][sl]) for l in range(L - 1)] + [head],
+                               tag='madechain_fwd')
                     continue
                 head['out_f32'] = net_out[sl]
                 made_chain(inp, n, [dict(w_packed=wbf[l], n=widths[l], k=ws[l].shape[1], bias=bs[l], relu=True,
@@ -2976,7 +2986,7 @@ class _MADEForwardBF16(torch.autograd.Function):
             lib.call('gv_rowsum', ptr(net_out[(S - 1) * n:]), 2 * d, d, d, ptr(log_det), n, st)
         else:
             log_det = acts0[L - 1][:, d:].sum(dim=1).expand(n).contiguous()
-        ctx.save_for_backward(z, colcount, xin_t, zero_row, net_out, *acts_b, *acts_t, *acts0, *wbt, *ws)
+        ctx.save_for_backward(z, colcount, xin_t, zero_row, net_out, *(sign if fused else acts_b), *acts_t, *acts0, *wbt, *ws)
         ctx.L = L
         ctx.chain = chain
         ctx.fused = fused
@@ -2992,9 +3002,8 @@ class _MADEForwardBF16(torch.autograd.Function):
         saved = ctx.saved_tensors
         z, colcount, xin_t, zero_row, net_out = saved[:5]
         o = 5
-        nb_ = 0 if ctx.fused else L - 1          # fused: no row-major activations were kept
-        acts_b, acts_t = saved[o:o + nb_], saved[o + nb_:o + nb_ + L - 1]
-        o += nb_ + L - 1
+        acts_b, acts_t = saved[o:o + L - 1], saved[o + L - 1:o + 2 * (L - 1)]      # fused: acts_b holds the sign-bit words instead
+        o += 2 * (L - 1)
         acts0, wbt, ws = saved[o:o + L], saved[o + L:o + 2 * L], saved[o + 2 * L:o + 3 * L]
         n, d = z.shape
         P = colcount.shape[0]
@@ -3027,7 +3036,7 @@ class _MADEForwardBF16(torch.autograd.Function):
                          ptr(gld) if p == P - 1 else None, ptr(g_z), ptr(gm_in), gm_in.stride(0), ptr(gm_t[L - 1][:, tsl]),
                          gm_t[L - 1].stride(0), None, n, d, st)
                 made_chain(gm_in, n,
-                           [dict(w_packed=wbt[l], n=widths[l - 1], k=widths[l], mask_t=acts_t[l - 1][:, tsl],
+                           [dict(w_packed=wbt[l], n=widths[l - 1], k=widths[l], mask_bits=acts_b[l - 1][sl],
                                  out_bf16_t=gm_t[l - 1][:, tsl]) for l in reversed(range(1, L))] +
                            [dict(w_packed=wbt[0], n=d, k=widths[0], out_f32=g_old, add=(g_cur, colcount[p]))], tag='madechain_bwd')
                 g_cur = g_old

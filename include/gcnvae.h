@@ -279,7 +279,12 @@ typedef struct gv_chain_layer {
     const uint16_t* mask_t;       /* [n][ldmask_t] bf16 or NULL: the mask given TRANSPOSED (a forward chain's out_bf16_t); instead of mask */
     const float* add_src;         /* [m][ldc] fp32 or NULL: out_f32 += add_src in the columns where add_colcount == 0 (the */
     const int32_t* add_colcount;  /* [n]                    gradient the IAF update hands through to its x_old) */
-    int32_t ldmask_t, reserved2;
+    int32_t ldmask_t, ldbits;
+    /* ReLU masks as BITS (what the MADE backward needs of a hidden activation is its sign): word [r][t] holds the 32 columns of
+     * column tile t of row r, bit j = (the bf16-rounded result of column 32 t + j > 0).  A forward layer writes them (out_bits),
+     * a backward layer keeps its result where the bit is set (mask_bits; instead of mask / mask_t).  ldbits >= ceil(n / 32). */
+    uint32_t* out_bits;           /* [m][ldbits] or NULL */
+    const uint32_t* mask_bits;    /* [m][ldbits] or NULL */
 } gv_chain_layer;
 int64_t gv_made_pack_weight_elems(int n, int k);
 int gv_made_pack_weight(const float* w, int ld, int n, int k, uint16_t* packed_fwd, uint16_t* packed_bwd, void* stream);

@@ -1462,6 +1462,36 @@ def test_made_chain_is_bit_identical_to_the_product_by_product_launches(ops, m, 
         assert torch.equal(of3, want)
         for a, b in zip(ot2, ot3):
             assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+        # ... and with the masks as sign BITS (gv_chain_layer.mask_bits: word [row][tile of 32 columns])
+        def words(t):
+            nt = (t.shape[1] + 31) // 32
+            pos = torch.zeros(t.shape[0], nt * 32, dtype=torch.int64, device=dev)
+            pos[:, :t.shape[1]] = (t.float() > 0).long()
+            w = (pos.view(t.shape[0], nt, 32) << torch.arange(32, device=dev)).sum(dim=2)
+            return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+        ob4, ot4, of4 = buffers()
+        layers_b = [dict(l_, mask_t=None, mask_bits=None if i == L - 1 else words(masks[i]), out_bf16_t=None if i == L - 1 else ot4[i],
+                         out_f32=of4 if i == L - 1 else None) for i, l_ in enumerate(layers_t)]
+        ops.made_chain(x, m, layers_b)
+        torch.cuda.synchronize()
+        assert torch.equal(of4, want)
+        for a, b in zip(ot2, ot4):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    else:
+        # sign bits written by a forward chain (out_bits) = the signs of its stored bf16 activations
+        bits = [torch.zeros(m, (widths[i + 1] + 31) // 32 + 1, dtype=torch.int32, device=dev) for i in range(L - 1)]
+        ob5, ot5, of5 = buffers()
+        ops.made_chain(x, m, [dict(l_, out_bf16=None, out_bits=bits[i] if i < L - 1 else None, out_bf16_t=ot5[i] if i < L - 1 else None,
+                                   out_f32=of5 if i == L - 1 else None) for i, l_ in enumerate(layers)])
+        torch.cuda.synchronize()
+        assert torch.equal(of5, of2)
+        for i in range(L - 1):
+            n_i = widths[i + 1]
+            got = ((bits[i][:, :(n_i + 31) // 32].long().unsqueeze(2) >> torch.arange(32, device=dev)) & 1).reshape(m, -1)[:, :n_i]
+            assert torch.equal(got.bool(), ob2[i][:, :n_i].float() > 0)
+            assert bool((bits[i][:, (n_i + 31) // 32:] == 0).all())            # the pad word is not touched
+            if n_i % 32:
+                assert bool((got.new_tensor(0) == ((bits[i][:, (n_i - 1) // 32].long() & 0xffffffff) >> (n_i % 32))).all())
     # and the arithmetic itself
     ref = x.float().cpu()
     for i in range(L):
