@@ -55,6 +55,20 @@ def _direct_flat(t):
 EPILOGUE_COLSUM_SLICES = 1024  # = GV_EPILOGUE_COLSUM_SLICES (include/gcnvae.h)
 DEFAULT_CHUNK = 256        # max edges per work item of the dst/src-sorted aggregations
 DEFAULT_CHUNK_REL = 128    # max edges per work item of the by-relation weight gradient
+
+
+def chunk_for(n_entries: int, most: int = DEFAULT_CHUNK) -> int:
+    """Edges per work item for a list of ``n_entries``.  One wave walks an item's edges in order (four in flight), so on a SMALL
+    graph the longest item, not the edge count, sets a launch's duration: a sampled batch of 20 000 edges whose hub rows were
+    cut into 256-edge items spent 40-80 us per aggregation on 64 serial steps of one wave.  Items shrink with the list (a power of
+    two, n / 2048 rounded down, between 16 and ``most``): full-size graphs (>= 0.5 M entries) keep 256."""
+    env = _os.environ.get('GV_CHUNK')
+    if env:
+        return max(1, int(env))
+    c = 16
+    while c * 2 <= most and c * 2 * 2048 <= int(n_entries):
+        c *= 2
+    return c
 DIST_FWD_CHUNKS = 2        # destination-row blocks whose all-reduce overlaps the next block's aggregation
 
 
@@ -235,7 +249,7 @@ class GraphIndex:
     Relation-dependent arrays live in ``RelationIndex`` (etypes arrive per forward call).
     """
 
-    def __init__(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: int, chunk: int = DEFAULT_CHUNK,
+    def __init__(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: int, chunk: Optional[int] = None,
                  dst_sorted: Optional[bool] = None, sync_free: bool = False, num_src_nodes: Optional[int] = None):
         """``dst_sorted``: None = check (one host synchronisation), True = the caller guarantees dst is non-decreasing.
         ``sync_free``: size the work-item lists by upper bounds instead of reading their totals back (per-batch graphs).
@@ -244,6 +258,7 @@ class GraphIndex:
         if not src.is_cuda:
             raise RuntimeError('GraphIndex needs CUDA index tensors; there is no CPU fallback')
         self.num_nodes, self.num_edges = int(num_nodes), int(src.numel())
+        chunk = chunk_for(self.num_edges) if chunk is None else int(chunk)
         self.num_src_nodes = self.num_nodes if num_src_nodes is None else int(num_src_nodes)
         self.device = src.device
         self.sync_free = bool(sync_free)
@@ -372,7 +387,7 @@ def xcd_order_items(seg: SegmentItems, key_by_pos: torch.Tensor, n_xcd: int = 8,
 
 
 class RelationIndex:
-    def __init__(self, g: GraphIndex, etypes: torch.Tensor, num_rels: int, chunk: int = DEFAULT_CHUNK_REL):
+    def __init__(self, g: GraphIndex, etypes: torch.Tensor, num_rels: int, chunk: Optional[int] = None):
         if etypes.numel() != g.num_edges:
             raise ValueError(f'etypes has {etypes.numel()} entries for {g.num_edges} edges')
         et = etypes.reshape(-1).to(torch.int64)
@@ -381,6 +396,7 @@ class RelationIndex:
             raise ValueError(f'edge types must lie in [0, {num_rels})')
         self.num_rels = int(num_rels)
         self.keepalive = etypes
+        chunk = chunk_for(g.num_edges, DEFAULT_CHUNK_REL) if chunk is None else int(chunk)
         if g.sync_free and NATIVE_INDEX:
             E, dev = g.num_edges, g.device
             et32 = et.to(torch.int32).contiguous()
@@ -863,12 +879,14 @@ class TripletIndex:
     relation list : T entries sorted by relation
     """
 
-    def __init__(self, triplets: torch.Tensor, num_entities: int, num_rels: int, chunk: int = DEFAULT_CHUNK,
-                 chunk_rel: int = DEFAULT_CHUNK_REL, sync_free: bool = False, locality: Optional[bool] = None):
+    def __init__(self, triplets: torch.Tensor, num_entities: int, num_rels: int, chunk: Optional[int] = None,
+                 chunk_rel: Optional[int] = None, sync_free: bool = False, locality: Optional[bool] = None):
         if not triplets.is_cuda:
             raise RuntimeError('TripletIndex needs a CUDA tensor; there is no CPU fallback')
         t = triplets.to(torch.int64)
         self.T = int(t.shape[0])
+        chunk = chunk_for(2 * self.T) if chunk is None else int(chunk)
+        chunk_rel = chunk_for(self.T, DEFAULT_CHUNK_REL) if chunk_rel is None else int(chunk_rel)
         self.num_entities, self.num_rels = int(num_entities), int(num_rels)
         if locality is None:       # extra sorts per index: for a batch that is used many times (not rebuilt every step)
             locality = not sync_free and self.num_entities * 800 >= (4 << 20)
