@@ -621,6 +621,103 @@ __global__ __launch_bounds__(256) void k_splitk_sum(const float* __restrict__ pa
     }
 }
 
+
+// ---- pass 0 of a MADE backward: the update fed by ONE broadcast [mu | alpha] row ------------------------------------------
+// (kgvae/flow_network.py:85-98: the first pass's input is the zero matrix, so every node sees the same net output.)  The generic
+// update backward materialises g_net (n x 2d fp32) only for its column sums to be taken -- the gradient w.r.t. the row --, writes a
+// g_x_old nobody reads (x_old was the zero matrix) and leaves g_z to an axpby.  Here: exp(alpha + mu) once per column, g_z
+// ACCUMULATED in place, the two column sums carried in registers: per element the same expressions as k_iaf_bwd
+// (gc = g * cnt; g_z = gc * e; g_mu = gc * z * e; g_alpha = g_ld + g_mu), summed per column over row slices in a fixed order.
+constexpr int ROW0_SLICES = 1024;
+
+__global__ __launch_bounds__(256) void k_iaf_bwd_row0(const float* __restrict__ z, const float* __restrict__ net_row,
+                                                      const int* __restrict__ colcount, const float* __restrict__ gx,
+                                                      const float* __restrict__ gld, float* __restrict__ gz_acc,
+                                                      float* __restrict__ part, int rows, int d, int rows_per_slice) {
+    __shared__ float sm[256][8];
+    const int d4 = d >> 2, rpi = 256 / d4;                 // column groups of 4; rows per sweep of the block
+    const int cg = (int)threadIdx.x % d4, ri = (int)threadIdx.x / d4;
+    const bool on = ri < rpi;
+    const int c = cg << 2;
+    float e[4], cn[4];
+    {
+        const float4 mu = *reinterpret_cast<const float4*>(net_row + c), al = *reinterpret_cast<const float4*>(net_row + d + c);
+        const int4 cc = *reinterpret_cast<const int4*>(colcount + c);
+        e[0] = expf(al.x + mu.x); e[1] = expf(al.y + mu.y); e[2] = expf(al.z + mu.z); e[3] = expf(al.w + mu.w);
+        cn[0] = (float)cc.x; cn[1] = (float)cc.y; cn[2] = (float)cc.z; cn[3] = (float)cc.w;
+    }
+    float sm_mu[4] = {0.f, 0.f, 0.f, 0.f}, sm_al[4] = {0.f, 0.f, 0.f, 0.f};
+    const int r_begin = blockIdx.x * rows_per_slice, r_end = min(rows, r_begin + rows_per_slice);
+    if (on) {
+        for (int r0 = r_begin + ri; r0 < r_end; r0 += 2 * rpi) {      // two rows in flight
+            float4 g4[2], z4[2], a4[2];
+            float gl[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = min(r0 + u * rpi, r_end - 1);
+                const size_t o = (size_t)r * d + c;
+                g4[u] = *reinterpret_cast<const float4*>(gx + o);
+                z4[u] = *reinterpret_cast<const float4*>(z + o);
+                a4[u] = *reinterpret_cast<const float4*>(gz_acc + o);
+                gl[u] = gld ? gld[r] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = r0 + u * rpi;
+                if (r >= r_end) break;
+                const float gv_[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w}, zv[4] = {z4[u].x, z4[u].y, z4[u].z, z4[u].w};
+                float gz[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float g_mu = 0.f, g_al = gl[u];
+                    gz[q] = 0.f;
+                    if (cn[q] > 0.f) {
+                        const float gc = gv_[q] * cn[q];
+                        gz[q] = gc * e[q];
+                        g_mu = gc * zv[q] * e[q];
+                        g_al += g_mu;
+                    }
+                    sm_mu[q] += g_mu;
+                    sm_al[q] += g_al;
+                }
+                *reinterpret_cast<float4*>(gz_acc + (size_t)r * d + c) =
+                    make_float4(a4[u].x + gz[0], a4[u].y + gz[1], a4[u].z + gz[2], a4[u].w + gz[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sm[threadIdx.x][q] = sm_mu[q];
+        sm[threadIdx.x][4 + q] = sm_al[q];
+    }
+    __syncthreads();
+    if (on && ri == 0) {          // the block's row lanes in order
+        float t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = sm[cg][q];
+        for (int k = 1; k < rpi; ++k)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] += sm[k * d4 + cg][q];
+        float* o = part + (size_t)blockIdx.x * 2 * d;
+        *reinterpret_cast<float4*>(o + c) = make_float4(t[0], t[1], t[2], t[3]);
+        *reinterpret_cast<float4*>(o + d + c) = make_float4(t[4], t[5], t[6], t[7]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_iaf_row0_final(const float* __restrict__ part, int n2, int nsl, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n2) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 4 <= nsl; s += 4) {
+        const float v0 = part[(size_t)s * n2 + c], v1 = part[(size_t)(s + 1) * n2 + c];
+        const float v2 = part[(size_t)(s + 2) * n2 + c], v3 = part[(size_t)(s + 3) * n2 + c];
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; s < nsl; ++s) a0 += part[(size_t)s * n2 + c];
+    out[c] = (a0 + a1) + (a2 + a3);
+}
+
 }  // namespace gv
 
 using namespace gv;
@@ -806,6 +903,28 @@ extern "C" int gv_iaf_update_bwd_bf16_ex(const float* z, const float* ex, int ld
                                         float* gx_old, int64_t n, int d, void* stream) {
     return iaf_update_bwd_bf16("gv_iaf_update_bwd_bf16_ex", true, z, ex, ld_ex, colcount, gx, gld, gz_accumulate, gnet_b, ldb, gnet_t,
                                ldt, gx_old, n, d, stream);
+}
+
+
+extern "C" int64_t gv_iaf_update_bwd_row0_workspace_floats(int d) { return (int64_t)ROW0_SLICES * 2 * d; }
+
+extern "C" int gv_iaf_update_bwd_row0(const float* z, const float* net_row, const int32_t* colcount, const float* gx, const float* gld,
+                                      float* gz_accumulate, float* g_row, float* workspace, int64_t n, int d, void* stream) {
+    GV_REQUIRE(n >= 0 && n < (1ll << 31) && d > 0 && d % 4 == 0 && d <= 1024, GV_ERR_SHAPE, "gv_iaf_update_bwd_row0: n=%lld d=%d (d %% 4 == 0, <= 1024)",
+               (long long)n, d);
+    GV_REQUIRE(z && net_row && colcount && gx && gz_accumulate && g_row && workspace, GV_ERR_NULL, "gv_iaf_update_bwd_row0: NULL pointer");
+    GV_REQUIRE(aligned16(z) && aligned16(net_row) && aligned16(colcount) && aligned16(gx) && aligned16(gz_accumulate) && aligned16(workspace),
+               GV_ERR_ALIGN, "gv_iaf_update_bwd_row0: 16-B aligned operands");
+    hipStream_t st = (hipStream_t)stream;
+    const int rpi = 256 / (d / 4);
+    int per = (int)((n + ROW0_SLICES - 1) / ROW0_SLICES);
+    per = (per + 2 * rpi - 1) / (2 * rpi) * (2 * rpi);          // whole sweeps of the block
+    if (per < 2 * rpi) per = 2 * rpi;
+    const int nsl = n > 0 ? (int)((n + per - 1) / per) : 0;
+    if (nsl > 0)
+        hipLaunchKernelGGL(k_iaf_bwd_row0, dim3(nsl), dim3(256), 0, st, z, net_row, colcount, gx, gld, gz_accumulate, workspace, (int)n, d, per);
+    hipLaunchKernelGGL(k_iaf_row0_final, dim3((2 * d + 255) / 256), dim3(256), 0, st, (const float*)workspace, 2 * d, nsl, g_row);
+    return launch_status("gv_iaf_update_bwd_row0");
 }
 
 extern "C" int gv_rowsum_bf16(const uint16_t* x, int ld, int rows, int cols, float* out, int accumulate, float* workspace,

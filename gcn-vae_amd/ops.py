@@ -2283,6 +2283,29 @@ class _IAFUpdate(torch.autograd.Function):
         return gz, gnet, gold, None
 
 
+MADE_ROW0_BWD = _os.environ.get('GV_MADE_ROW0_BWD', '1') == '1'
+
+
+def iaf_bwd_row0(z, net_row, colcount0, g_cur, gld, g_z):
+    """Pass 0 of a MADE backward (the update was fed one broadcast [mu | alpha] row): g_z += the pass's share, returns the
+    gradient w.r.t. that row (1, 2d) -- gv_iaf_update_bwd_row0, or the generic update backward + column sums + axpby."""
+    n, d = z.shape
+    st = lib.stream()
+    if MADE_ROW0_BWD and d % 4 == 0 and d <= 1024 and net_row.is_contiguous():
+        ws = torch.empty(int(lib.load().gv_iaf_update_bwd_row0_workspace_floats(d)), dtype=torch.float32, device=z.device)
+        g_row = torch.empty(1, 2 * d, dtype=torch.float32, device=z.device)
+        lib.call('gv_iaf_update_bwd_row0', ptr(z), ptr(net_row), ptr(colcount0), ptr(g_cur), ptr(gld), ptr(g_z), ptr(g_row), ptr(ws),
+                 n, d, st)
+        return g_row
+    gz_p = torch.empty(n, d, dtype=torch.float32, device=z.device)
+    g_net0 = torch.empty(n, 2 * d, dtype=torch.float32, device=z.device)
+    g_dump = torch.empty(n, d, dtype=torch.float32, device=z.device)
+    lib.call('gv_iaf_update_bwd', ptr(z), ptr(net_row), 0, ptr(colcount0), ptr(g_cur), ptr(gld), ptr(gz_p), ptr(g_net0), ptr(g_dump),
+             n, d, st)
+    lib.call('gv_axpby', n * d, None, 1.0, ptr(gz_p), 1.0, ptr(g_z), st)
+    return colsum(g_net0).view(1, -1)
+
+
 def iaf_update(z, net, x_old, colcount):
     return _IAFUpdate.apply(z, net, x_old, colcount)
 
@@ -2662,12 +2685,7 @@ class _MADEForward(torch.autograd.Function):
                     gemm(grads[0][sl], ws[0], out=g_old, accumulate=True, a_relu_mask=mask)
             g_cur = g_old
         # pass 0: the update's gradient w.r.t. the broadcast net row is its column sum; x_old was the zero matrix
-        g_net0 = torch.empty(n, 2 * d, **f32)
-        g_dump = torch.empty(n, d, **f32)
-        lib.call('gv_iaf_update_bwd', ptr(z), ptr(acts0[L - 1]), 0, ptr(colcount[0]), ptr(g_cur),
-                 ptr(gld) if P == 1 else None, ptr(gz_p), ptr(g_net0), ptr(g_dump), n, d, st)
-        lib.call('gv_axpby', n * d, None, 1.0, ptr(gz_p), 1.0, ptr(g_z), st)
-        g_row = colsum(g_net0).view(1, -1)                      # (1, 2D)
+        g_row = iaf_bwd_row0(z, acts0[L - 1], colcount[0], g_cur, gld if P == 1 else None, g_z)      # (1, 2D)
         rows0 = [None] * L                                        # masked single-row gradients per layer output
         for l in reversed(range(L)):
             rows0[l] = g_row
@@ -3075,12 +3093,7 @@ class _MADEForwardBF16(torch.autograd.Function):
                 gemm_bf16_nt(gm_b[0][sl], wbt[0], n, d, widths[0], c_f32=g_old, accumulate=True)
             g_cur = g_old
         # pass 0: the update's gradient w.r.t. the broadcast net row is its column sum; x_old was the zero matrix
-        g_net0 = torch.empty(n, 2 * d, **f32)
-        g_dump = torch.empty(n, d, **f32)
-        lib.call('gv_iaf_update_bwd', ptr(z), ptr(acts0[L - 1]), 0, ptr(colcount[0]), ptr(g_cur),
-                 ptr(gld) if P == 1 else None, ptr(gz_p), ptr(g_net0), ptr(g_dump), n, d, st)
-        lib.call('gv_axpby', n * d, None, 1.0, ptr(gz_p), 1.0, ptr(g_z), st)
-        g_row = colsum(g_net0).view(1, -1)
+        g_row = iaf_bwd_row0(z, acts0[L - 1], colcount[0], g_cur, gld if P == 1 else None, g_z)
         rows0 = [None] * L
         row_gw = row_gb = None
         if ctx.row:     # the row's whole backward chain (masked row gradients, outer products, bias gradients): one launch

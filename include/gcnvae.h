@@ -206,6 +206,13 @@ int gv_iaf_update_bwd_bf16(const float* z, const float* net, int ld_net, const i
 int gv_iaf_update_bwd_bf16_ex(const float* z, const float* ex, int ld_ex, const int32_t* colcount, const float* gx, const float* gld,
                               float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t, int ldt, float* gx_old, int64_t n,
                               int d, void* stream);
+/* Pass 0 of a MADE backward: the update was fed ONE broadcast row net_row = [mu | alpha] (2 d floats; the first pass's input is
+ * the zero matrix, kgvae/flow_network.py:85-98).  ADDS g_z into gz_accumulate [n][d] and writes the gradient w.r.t. that row,
+ * g_row [2 d] = column sums of [g_mu | g_alpha], without materialising the (n, 2d) gradient; gld [n] or NULL; d % 4 == 0,
+ * d <= 1024; workspace = gv_iaf_update_bwd_row0_workspace_floats(d) floats.  Fixed summation order. */
+int64_t gv_iaf_update_bwd_row0_workspace_floats(int d);
+int gv_iaf_update_bwd_row0(const float* z, const float* net_row, const int32_t* colcount, const float* gx, const float* gld,
+                           float* gz_accumulate, float* g_row, float* workspace, int64_t n, int d, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * K4 in bf16 (BASELINE configs[2]): the masked-MLP products of MADE / IAF (kgvae/flow_network.py:7-98, called from
  * kgvae/model.py:116-123) with bf16 STORAGE of weights and activations, bf16 MFMA, fp32 accumulation.

@@ -1579,6 +1579,39 @@ def test_made_chain_with_the_iaf_update_in_its_last_layer_is_bit_identical_to_th
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n,d,with_ld', [(1, 8, True), (300, 40, False), (14541, 200, True), (4099, 200, False), (257, 1024, True)])
+def test_iaf_update_backward_of_the_broadcast_row_pass(ops, n, d, with_ld):
+    """gv_iaf_update_bwd_row0 (pass 0 of a MADE backward: one [mu | alpha] row for every node; kgvae/flow_network.py:85-98)
+    against the generic update backward + column sums + axpby it replaces: g_z accumulated, the row's gradient."""
+    from gcn_vae_amd import lib
+    from gcn_vae_amd.lib import ptr
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(n + d)
+    z, gx, gz0 = (torch.randn(n, d, generator=g).to(dev) for _ in range(3))
+    row = (torch.randn(1, 2 * d, generator=g) * 0.5).to(dev)
+    cc = torch.randint(0, 3, (d,), generator=g).to(torch.int32).to(dev)
+    gld = torch.randn(n, generator=g).to(dev) if with_ld else None
+    old = ops.MADE_ROW0_BWD
+    res = {}
+    try:
+        for on in (True, False):
+            ops.MADE_ROW0_BWD = on
+            gz = gz0.clone()
+            res[on] = (ops.iaf_bwd_row0(z, row, cc, gx, gld, gz), gz)
+    finally:
+        ops.MADE_ROW0_BWD = old
+    torch.cuda.synchronize()
+    assert torch.equal(res[True][1], res[False][1])                 # per element the same expressions
+    close(res[True][0], res[False][0], rtol=2e-5, atol_scale=2e-6, msg='row gradient (column sums in another fixed order)')
+    # and against the definition
+    e = torch.exp(row[0, d:] + row[0, :d]).double()
+    gc = gx.double() * cc.double()
+    g_mu = torch.where(cc > 0, gc * z.double() * e, torch.zeros((), dtype=torch.float64, device=dev))
+    want = torch.cat([g_mu.sum(0), g_mu.sum(0) + (gld.double().sum() if with_ld else 0.0)])
+    close(res[True][0].view(-1), want.float(), rtol=2e-4, atol_scale=2e-5, msg='row gradient vs float64')
+
+
+@pytest.mark.gpu
 def test_made_pack_weight_transposed_form_equals_packing_the_transpose(ops):
     dev = torch.device('cuda:0')
     w = torch.randn(136, 72, device=dev)
