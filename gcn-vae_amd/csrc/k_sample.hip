@@ -259,6 +259,15 @@ extern "C" int gv_graph_from_triplets(const int32_t* s, const int32_t* r, const 
     return launch_status("gv_graph_from_triplets");
 }
 
+extern "C" int gv_gather3_i32(const int32_t* idx, int64_t n, const int32_t* a, const int32_t* b, const int32_t* c, int32_t* out_a,
+                              int32_t* out_b, int32_t* out_c, void* stream) {
+    GV_REQUIRE(n >= 0, GV_ERR_SHAPE, "gv_gather3_i32: n=%lld", (long long)n);
+    if (n == 0) return GV_OK;
+    GV_REQUIRE(idx && a && b && c && out_a && out_b && out_c, GV_ERR_NULL, "gv_gather3_i32: NULL pointer");
+    hipLaunchKernelGGL(k_gather3, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, idx, (long long)n, a, b, c, out_a, out_b, out_c);
+    return launch_status("gv_gather3_i32");
+}
+
 // ---------------------------------------------------------------------------------------------
 // Neighbourhood-expansion edge sampler (kgvae/utils.py:33-76 sample_edge_neighborhood, selected by --edge-sampler
 // neighbor, kgvae/link_predict.py:311).  Inherently sequential -- every draw conditions the next -- so ONE 1024-thread

@@ -104,8 +104,9 @@ class DeviceSampler:
         else:
             lib.call('gv_perm_sample', n_trip, k, self.seed, tick, tick_dev, None, STREAM_EDGES, ptr(chosen), st)
         self.last_chosen = chosen
-        ci = chosen.long()
-        src_g, rel, dst_g = self._s[ci], self._r[ci], self._o[ci]             # global ids of the sampled triplets
+        src_g, rel, dst_g = torch.empty(k, **i32), torch.empty(k, **i32), torch.empty(k, **i32)
+        lib.call('gv_gather3_i32', ptr(chosen), k, ptr(self._s), ptr(self._r), ptr(self._o), ptr(src_g), ptr(rel), ptr(dst_g),
+                 st)                                                             # global ids of the sampled triplets
         cap = min(2 * k, self.num_nodes)
         # static: padding rows carry their own position as node id (any valid id would do; distinct ones keep the embedding
         # backward's scatter-add of their zero gradients off a single row)
@@ -135,7 +136,8 @@ class DeviceSampler:
                 lib.call('gv_perm_sample', cap, mmd_pick.numel(), self.seed, tick, tick_dev, ptr(count), STREAM_PICK, ptr(pick32), st)
                 mmd_pick.copy_(pick32)
             g = KGraph.from_device_edges(cap, src2, dst2, dst_sorted=True)       # rows [count, cap): isolated padding nodes
-            return DeviceBatch(g, uniq.long().view(-1, 1), rel2.long(), norm, samples, labels, rows_dev=count)
+            # (relation ids stay int32 here: the index builders take them as they are -- one conversion kernel less per step)
+            return DeviceBatch(g, uniq.long().view(-1, 1), rel2, norm, samples, labels, rows_dev=count)
         n = int(count.item())                                                    # the one host sync per batch
         g = KGraph.from_device_edges(n, src2, dst2, dst_sorted=True)
         return DeviceBatch(g, uniq[:n].long().view(-1, 1), rel2.long(), norm, samples, labels)

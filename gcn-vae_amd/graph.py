@@ -33,13 +33,13 @@ class KGraph:
         g = cls()
         g._dst_sorted = dst_sorted
         g._n = int(num_nodes)
-        g._dev_edges = (src.to(torch.int64), dst.to(torch.int64))
+        g._dev_edges = (src, dst)          # int32 or int64, as the builder made them: no conversion kernel per batch
         g._src = g._dst = None
         return g
 
     def _host_edges(self):
         if self._src is None:
-            self._src, self._dst = (t.cpu() for t in self._dev_edges)
+            self._src, self._dst = (t.cpu().to(torch.int64) for t in self._dev_edges)
         return self._src, self._dst
 
     def add_nodes(self, n):

@@ -390,7 +390,9 @@ class RelationIndex:
     def __init__(self, g: GraphIndex, etypes: torch.Tensor, num_rels: int, chunk: Optional[int] = None):
         if etypes.numel() != g.num_edges:
             raise ValueError(f'etypes has {etypes.numel()} entries for {g.num_edges} edges')
-        et = etypes.reshape(-1).to(torch.int64)
+        native = g.sync_free and NATIVE_INDEX
+        # (the native builder takes int32 ids: a batch sampler's int32 relation ids skip the int64 round trip)
+        et = etypes.reshape(-1) if (native and etypes.dtype == torch.int32) else etypes.reshape(-1).to(torch.int64)
         # (device-built graphs come with device-built relation ids: no host round trip to validate them)
         if g.num_edges and not g.sync_free and (int(et.min()) < 0 or int(et.max()) >= num_rels):
             raise ValueError(f'edge types must lie in [0, {num_rels})')
@@ -883,7 +885,7 @@ class TripletIndex:
                  chunk_rel: Optional[int] = None, sync_free: bool = False, locality: Optional[bool] = None):
         if not triplets.is_cuda:
             raise RuntimeError('TripletIndex needs a CUDA tensor; there is no CPU fallback')
-        t = triplets.to(torch.int64)
+        t = triplets if triplets.dtype == torch.int32 else triplets.to(torch.int64)
         self.T = int(t.shape[0])
         chunk = chunk_for(2 * self.T) if chunk is None else int(chunk)
         chunk_rel = chunk_for(self.T, DEFAULT_CHUNK_REL) if chunk_rel is None else int(chunk_rel)
@@ -906,6 +908,7 @@ class TripletIndex:
             self.rel = SegmentItems(it_r.view(-1, 4), fx_r.view(-1, 4), ci_r, cf_r, slots_r, rp_r, chunk_rel)
             self.fwd_order = self.pos3 = None
             return
+        t = t.to(torch.int64)
         s, r, o = t[:, 0], t[:, 1], t[:, 2]
         ent = torch.cat([s, o])
         other = torch.cat([o, s])

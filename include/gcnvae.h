@@ -593,6 +593,9 @@ int64_t gv_graph_from_triplets_workspace_bytes(int64_t m, int n_nodes_bound, int
 int gv_graph_from_triplets(const int32_t* s, const int32_t* r, const int32_t* o, const int32_t* keep, int64_t m,
                            int n_nodes_bound, int num_rels, int32_t* src2, int32_t* dst2, int32_t* rel2, float* norm,
                            void* workspace, int64_t workspace_bytes, void* stream);
+/* out_x[i] = x[idx[i]] for three int32 arrays in one launch (the sampled triplets' columns: kgvae/utils.py:100-101). */
+int gv_gather3_i32(const int32_t* idx, int64_t n, const int32_t* a, const int32_t* b, const int32_t* c, int32_t* out_a, int32_t* out_b,
+                   int32_t* out_c, void* stream);
 
 #ifdef __cplusplus
 }
