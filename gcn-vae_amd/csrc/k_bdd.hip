@@ -80,6 +80,10 @@ __global__ __launch_bounds__(256) void k_agg_fast(const AggParams a) {
     float acc[PV];
 #pragma unroll
     for (int i = 0; i < PV; ++i) acc[i] = 0.f;
+    float wkeep[WV];                  // the weights of relation r_keep (-1: none), kept in registers while its run lasts
+#pragma unroll
+    for (int i = 0; i < WV; ++i) wkeep[i] = 0.f;
+    int r_keep = -1;
 
     for (int e0 = it.y; e0 < it.z; e0 += 64) {
         const int cnt = min(64, it.z - e0);
@@ -90,34 +94,63 @@ __global__ __launch_bounds__(256) void k_agg_fast(const AggParams a) {
             my_t = a.etype[e0 + lane];
             if (a.coef) my_c = a.coef_idx ? a.coef[a.coef_idx[e0 + lane]] : a.coef[e0 + lane];
         }
+        // Consecutive edges of ONE relation share their weights: the registers of the run's first edge serve the whole run (r_keep /
+        // wkeep carry an open run across batches and metadata chunks).  All of it is wave-uniform scalar control; per edge the
+        // arithmetic is what it was.  Rows whose edges come sorted by relation (static graphs: ops.GraphIndex.rel_sorted) turn every
+        // repeated (row, relation) pair into a skipped weight fetch -- the per-edge weight read is what bounds this kernel.
+        const bool more_chunks = e0 + 64 < it.z;
         int j = 0;
         for (; j + U <= cnt; j += U) {
             float xv[U][GV], wv[U][WV], cc[U];
+            int rr[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int s = rl_i(my_n, j + u);
-                const int r = rl_i(my_t, j + u);
+                rr[u] = rl_i(my_t, j + u);
                 cc[u] = rl_f(my_c, j + u);
                 if (active) {
                     load_vec<GV>(fbase + (size_t)s * a.ld_feat, xv[u]);
-                    load_vec<WV>(wbase + (size_t)r * a.w_row, wv[u]);
+                    if (rr[u] != (u ? rr[u - 1] : r_keep)) load_vec<WV>(wbase + (size_t)rr[u] * a.w_row, wv[u]);
                 }
             }
-            if (active) {
+            int src = -1;
 #pragma unroll
-                for (int u = 0; u < U; ++u) block_fma<P, Q, TRANS, BPL>(xv[u], wv[u], cc[u], acc);
+            for (int u = 0; u < U; ++u) {
+                if (rr[u] != (u ? rr[u - 1] : r_keep)) src = u;
+                if (active) {
+                    if (src < 0) block_fma<P, Q, TRANS, BPL>(xv[u], wkeep, cc[u], acc);
+#pragma unroll
+                    for (int v = 0; v <= u; ++v)
+                        if (src == v) block_fma<P, Q, TRANS, BPL>(xv[u], wv[v], cc[u], acc);
+                }
+            }
+            // does the run go on behind this batch?  (at the end of a metadata chunk: assume so if the item has another one)
+            const bool cont = j + U < cnt ? rl_i(my_t, j + U) == rr[U - 1] : more_chunks;
+            if (src >= 0) {
+                if (cont) {
+#pragma unroll
+                    for (int v = 0; v < U; ++v)
+                        if (src == v) {
+#pragma unroll
+                            for (int i = 0; i < WV; ++i) wkeep[i] = wv[v][i];
+                        }
+                    r_keep = rr[U - 1];
+                } else {
+                    r_keep = -1;
+                }
             }
         }
         for (; j < cnt; ++j) {
-            float xv[GV], wv[WV];
+            float xv[GV];
             const int s = rl_i(my_n, j);
             const int r = rl_i(my_t, j);
             const float c = rl_f(my_c, j);
             if (active) {
                 load_vec<GV>(fbase + (size_t)s * a.ld_feat, xv);
-                load_vec<WV>(wbase + (size_t)r * a.w_row, wv);
-                block_fma<P, Q, TRANS, BPL>(xv, wv, c, acc);
+                if (r != r_keep) load_vec<WV>(wbase + (size_t)r * a.w_row, wkeep);
+                block_fma<P, Q, TRANS, BPL>(xv, wkeep, c, acc);
             }
+            r_keep = r;
         }
     }
     if (!active) return;
@@ -282,7 +315,7 @@ __global__ __launch_bounds__(256) void k_agg_packed(const AggParams a) {
 #pragma unroll
     for (int i = 0; i < BPL * Q; ++i) acc[i] = 0.f;
 
-    auto load_edge = [&](int sidx, int r, float (&xv)[BPL * P], float (&wv)[BPL * PQ]) {
+    auto load_x = [&](int sidx, float (&xv)[BPL * P]) {
         const float* xr = a.feat + (size_t)sidx * a.ld_feat;
         if constexpr (ADJ) {
             load_vec<BPL * P>(xr + lane * BPL * P, xv);
@@ -295,6 +328,8 @@ __global__ __launch_bounds__(256) void k_agg_packed(const AggParams a) {
                 for (int i = 0; i < P; ++i) xv[sb * P + i] = t[i];
             }
         }
+    };
+    auto load_w = [&](int r, float (&wv)[BPL * PQ]) {
         const float4* wr = wbase + (size_t)r * (a.w_row / 4);
 #pragma unroll
         for (int jq = 0; jq < NQ; ++jq) {
@@ -302,6 +337,10 @@ __global__ __launch_bounds__(256) void k_agg_packed(const AggParams a) {
             wv[4 * jq] = q4.x; wv[4 * jq + 1] = q4.y; wv[4 * jq + 2] = q4.z; wv[4 * jq + 3] = q4.w;
         }
     };
+    float wkeep[BPL * PQ];            // the weights of relation r_keep (-1: none): see k_agg_fast
+#pragma unroll
+    for (int i = 0; i < BPL * PQ; ++i) wkeep[i] = 0.f;
+    int r_keep = -1;
 
     for (int e0 = it.y; e0 < it.z; e0 += 64) {
         const int cnt = min(64, it.z - e0);
@@ -312,30 +351,58 @@ __global__ __launch_bounds__(256) void k_agg_packed(const AggParams a) {
             my_t = a.etype[e0 + lane];
             if (a.coef) my_c = a.coef_idx ? a.coef[a.coef_idx[e0 + lane]] : a.coef[e0 + lane];
         }
+        const bool more_chunks = e0 + 64 < it.z;
         int j0 = 0;
         for (; j0 + U <= cnt; j0 += U) {
             float xv[U][BPL * P], wv[U][BPL * PQ], cc[U];
+            int rr[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int sidx = rl_i(my_n, j0 + u);
-                const int r = rl_i(my_t, j0 + u);
+                rr[u] = rl_i(my_t, j0 + u);
                 cc[u] = rl_f(my_c, j0 + u);
-                if (active) load_edge(sidx, r, xv[u], wv[u]);
+                if (active) {
+                    load_x(sidx, xv[u]);
+                    if (rr[u] != (u ? rr[u - 1] : r_keep)) load_w(rr[u], wv[u]);
+                }
             }
-            if (active) {
+            int src = -1;
 #pragma unroll
-                for (int u = 0; u < U; ++u) block_fma<P, Q, TRANS, BPL>(xv[u], wv[u], cc[u], acc);
+            for (int u = 0; u < U; ++u) {
+                if (rr[u] != (u ? rr[u - 1] : r_keep)) src = u;
+                if (active) {
+                    if (src < 0) block_fma<P, Q, TRANS, BPL>(xv[u], wkeep, cc[u], acc);
+#pragma unroll
+                    for (int v = 0; v <= u; ++v)
+                        if (src == v) block_fma<P, Q, TRANS, BPL>(xv[u], wv[v], cc[u], acc);
+                }
+            }
+            const bool cont = j0 + U < cnt ? rl_i(my_t, j0 + U) == rr[U - 1] : more_chunks;
+            if (src >= 0) {
+                if (cont) {
+#pragma unroll
+                    for (int v = 0; v < U; ++v)
+                        if (src == v) {
+#pragma unroll
+                            for (int i = 0; i < BPL * PQ; ++i) wkeep[i] = wv[v][i];
+                        }
+                    r_keep = rr[U - 1];
+                } else {
+                    r_keep = -1;
+                }
             }
         }
         for (; j0 < cnt; ++j0) {
-            float xv[BPL * P], wv[BPL * PQ];
+            float xv[BPL * P];
             const int sidx = rl_i(my_n, j0);
             const int r = rl_i(my_t, j0);
             const float c = rl_f(my_c, j0);
             if (active) {
-                load_edge(sidx, r, xv, wv);
-                block_fma<P, Q, TRANS, BPL>(xv, wv, c, acc);
+                load_x(sidx, xv);
+                if (r != r_keep) load_w(r, wkeep);
+                block_fma<P, Q, TRANS, BPL>(xv, wkeep, c, acc);
             }
+            r_keep = r;
         }
     }
     if (!active) return;

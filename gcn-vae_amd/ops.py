@@ -398,6 +398,7 @@ class RelationIndex:
             raise ValueError(f'edge types must lie in [0, {num_rels})')
         self.num_rels = int(num_rels)
         self.keepalive = etypes
+        self._rel_sorted = {}
         chunk = chunk_for(g.num_edges, DEFAULT_CHUNK_REL) if chunk is None else int(chunk)
         if g.sync_free and NATIVE_INDEX:
             E, dev = g.num_edges, g.device
@@ -535,6 +536,37 @@ class RelationIndex:
             zeros = torch.zeros(max(E, 1), dtype=torch.int32, device=dev)
             hit = self._dense_plan = (tiles, int(tiles.shape[0]), pos_by_dst, pos_by_src, zeros)
         return hit
+
+    def rel_sorted(self, g: 'GraphIndex', side: str, coef: Optional[torch.Tensor] = None):
+        """The ``side`` ('dst' / 'src') ordering of a STATIC graph with every row's edges sorted by relation (stable: the reference's
+        order within a relation): (nbr, etype, edge ids, coef in that order or None).  Row pointers and work items are those of
+        ``g.by_dst`` / ``g.by_src`` -- only positions inside a row move.  The per-row aggregation kernels keep a relation's weights
+        in registers while consecutive edges share it, so each repeated (row, relation) pair saves a weight fetch (26 % of the
+        edges of the FB15k-237-shaped graph; far more on real knowledge graphs, whose rows use few relations)."""
+        hit = self._rel_sorted.get(side)
+        if hit is None:
+            order = g.by_dst if side == 'dst' else g.by_src
+            nbr = g.nbr_by_dst if side == 'dst' else g.nbr_by_src
+            et = self.et_by_dst if side == 'dst' else self.et_by_src
+            rp = order.seg.rowptr.long()
+            n_seg, E = rp.numel() - 1, g.num_edges
+            deg = rp[1:] - rp[:-1]
+            row = torch.repeat_interleave(torch.arange(n_seg, device=rp.device), deg, output_size=E)
+            # (GV_K1_REL_RUNS_MIN_DEG = x: only rows of >= x * num_rels edges are re-sorted, the others keep their neighbour order;
+            # measured at FB15k-237 size: sorting every row is best, 1.099 ms per step against 1.102 / 1.107 / 1.109 / 1.116 for x = 0.5 .. 4)
+            min_deg = int(float(_os.environ.get('GV_K1_REL_RUNS_MIN_DEG', '0')) * self.num_rels)
+            sub = torch.where(deg[row] >= min_deg, et.long(), torch.zeros((), dtype=torch.int64, device=rp.device))
+            p2 = torch.sort(row * self.num_rels + sub, stable=True)[1]
+            eid = order.perm.long() if order.perm is not None else torch.arange(E, device=rp.device)
+            hit = self._rel_sorted[side] = (nbr[p2].contiguous(), et[p2].contiguous(), eid[p2].to(torch.int32).contiguous(), {})
+        c = None
+        if coef is not None:
+            key = (coef.data_ptr(), coef._version, coef.numel())
+            ent = hit[3].get('coef')
+            if ent is None or ent[0] != key:
+                ent = hit[3]['coef'] = (key, coef.reshape(-1)[hit[2].long()].contiguous(), coef)
+            c = ent[1]
+        return hit[0], hit[1], hit[2], c
 
     def coef_in_rel_order(self, coef: torch.Tensor) -> torch.Tensor:
         """Per-edge coefficients permuted into the by-relation order of the grad-W launch (cached like
@@ -1479,6 +1511,10 @@ class _RelGraphConvBdd(torch.autograd.Function):
             coef_g = None if coef is None else ridx.grouped_coef(coef, 'dst', perm)
             out = bdd_aggregate(seg, nbr, ety, coef_g, None, x, w_fwd, num_bases, si, so, False, self_loop_term(), act, keep,
                                 keep_scale, packed=pk)
+        elif reduce_hook is None and K1_REL_RUNS and not gidx.sync_free:
+            nbr_r, et_r, eid_r, coef_r = ridx.rel_sorted(gidx, 'dst', coef)      # rows sorted by relation: weight reuse along runs
+            out = bdd_aggregate(gidx.by_dst.seg, nbr_r, et_r, coef_r, None, x, w_fwd,
+                                num_bases, si, so, False, self_loop_term(), act, keep, keep_scale, packed=pk)
         elif reduce_hook is None:
             out = bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x, w_fwd,
                                 num_bases, si, so, False, self_loop_term(), act, keep, keep_scale, packed=pk)
@@ -1574,6 +1610,10 @@ class _RelGraphConvBdd(torch.autograd.Function):
                 seg, nbr, ety, perm = ridx.grouped_order(gidx, 'src')
                 coef_g = None if coef is None else ridx.grouped_coef_src(coef, perm)
                 grad_x = bdd_aggregate(seg, nbr, ety, coef_g, None, g_agg, w_bwd, nb, so, si, True, gx_loop, out=x_tgt, packed=pk)
+            elif K1_REL_RUNS and not gidx.sync_free and reduce_hook is None:
+                nbr_r, et_r, eid_r, coef_r = ridx.rel_sorted(gidx, 'src', coef)
+                grad_x = bdd_aggregate(gidx.by_src.seg, nbr_r, et_r, coef_r, None, g_agg,
+                                       w_bwd, nb, so, si, True, gx_loop, out=x_tgt, packed=pk)
             else:
                 coef_s, idx_s = (gidx.coef_in_src_order(coef), None) if static else (coef, gidx.by_src.perm)
                 grad_x = bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, coef_s, idx_s, g_agg,
@@ -1594,6 +1634,7 @@ class _RelGraphConvBdd(torch.autograd.Function):
         return grad_x, grad_w, grad_bias, grad_loop, None, None, None, None, None, None, None, None
 
 
+K1_REL_RUNS = _os.environ.get('GV_K1_REL_RUNS', '1') == '1'     # static graphs: rows sorted by relation (weight reuse along runs)
 REL_GROUPS = _os.environ.get('GV_REL_GROUPS', '0')         # '0' (default: off) | 'auto' | '1'
 L2_WEIGHT_BUDGET = 3 << 20                                  # bytes of relation weights one XCD's 4 MiB L2 can keep hot
 

@@ -283,6 +283,49 @@ def test_rel_graph_conv_lds_resident_weights(ops, monkeypatch, fin, fout, nb, r,
     assert float(hg3[n - 7:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('fin,fout,nb,r,chunk', [(200, 200, 100, 100, 256), (200, 400, 100, 100, 64), (400, 200, 100, 100, 16),
+                                                 (200, 200, 200, 200, 256), (40, 80, 10, 10, 8)])        # (DGL clamps num_bases to num_rels)
+def test_rel_graph_conv_rows_sorted_by_relation_reuse_the_weights_of_a_run(ops, monkeypatch, fin, fout, nb, r, chunk):
+    """Static graphs hand the per-row kernels every row's edges sorted by relation (ops.RelationIndex.rel_sorted); the kernels keep a
+    relation's weights in registers while consecutive edges share it (csrc/k_bdd.hip: r_keep / wkeep).  Hub rows (Zipf 1.1: a quarter of the edges in the top row) make the runs long: they cross the kernels' edge batches, the 64-edge metadata chunks and (small work items) item
+    boundaries.  Against the oracle, forward and every gradient; and against the same launch without the re-ordering."""
+    n, e = 300, 12000
+    src, dst, et, norm = zipf_graph(n, e, r, seed=fin + fout + nb + r)
+    order = np.lexsort((et.numpy(), src.numpy(), dst.numpy()))
+    src, dst, et, norm = src[order], dst[order], et[order], norm[order]
+    gen = torch.Generator().manual_seed(fin * 3 + nb)
+    x = torch.randn(n, fin, generator=gen)
+    p = orgcn.init_params(fin, fout, r, 'bdd', nb, True, True, gen)
+    gout = torch.randn(n, fout, generator=gen)
+    monkeypatch.setattr(ops, 'lds_plan', lambda *a, **k: None)                 # keep these shapes on the per-row kernels
+    res = {}
+    for runs in (True, False):
+        monkeypatch.setattr(ops, 'K1_REL_RUNS', runs)
+        gidx = ops.GraphIndex(src.cuda(), dst.cuda(), n, chunk=chunk)
+        ridx = ops.RelationIndex(gidx, et.cuda(), r)
+        if runs:
+            nbr_r, et_r, eid_r, coef_r = ridx.rel_sorted(gidx, 'dst', norm.cuda())
+            rp = gidx.by_dst.seg.rowptr.long()
+            rows = torch.repeat_interleave(torch.arange(n, device='cuda'), rp[1:] - rp[:-1])
+            key = rows * r + et_r.long()
+            assert bool((key[1:] >= key[:-1]).all())                             # rows in place, relations ascending inside a row
+            assert torch.equal(torch.sort(eid_r.long())[0], torch.arange(e, device='cuda'))
+            assert torch.equal(coef_r.view(-1), norm.cuda().view(-1)[eid_r.long()]) and torch.equal(nbr_r.long(), src.cuda()[eid_r.long()])
+        xg = x.cuda().requires_grad_(True)
+        pg = {k: v.cuda().requires_grad_(True) for k, v in p.items()}
+        hg = ops.rel_graph_conv_bdd(xg, pg['weight'], None, pg['loop_weight'], norm.cuda(), gidx, ridx, nb, 1)
+        hg.backward(gout.cuda())
+        res[runs] = (hg.detach(), xg.grad, pg['weight'].grad, pg['loop_weight'].grad)
+    xo = x.clone().requires_grad_(True)
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ho = orgcn.rel_graph_conv(xo, src, dst, et, norm, {k: v for k, v in po.items() if k != 'h_bias'}, 'bdd', nb, torch.relu)
+    ho.backward(gout)
+    want = (ho.detach(), xo.grad, po['weight'].grad, po['loop_weight'].grad)
+    for name, a, b, c in zip(('forward', 'grad_x', 'grad_weight', 'grad_loop'), res[True], res[False], want):
+        close(a, c, msg=name + ' (relation-sorted rows) vs oracle')
+        close(a, b, rtol=1e-5, atol_scale=1e-6, msg=name + ': relation-sorted vs neighbour-sorted rows (summation order only)')
+
+
 @pytest.mark.parametrize('fin,fout,nb,r', [(200, 200, 20, 22), (200, 400, 20, 22), (100, 200, 10, 22)])
 def test_rel_graph_conv_lds_resident_bf16_operands(ops, fin, fout, nb, r):
     """BASELINE configs[2]'s precision on K1 (gv_rgcn_bdd_aggregate_lds with bf16_operands): the relation weights and the
