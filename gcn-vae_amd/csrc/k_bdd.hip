@@ -66,6 +66,9 @@ __device__ __forceinline__ void block_fma(const float (&x)[BPL * P], const float
 template <int P, int Q, bool TRANS, int BPL, int U>
 __global__ __launch_bounds__(256) void k_agg_fast(const AggParams a) {
     constexpr int GV = BPL * P, PV = BPL * Q, WV = BPL * P * Q;
+    // weight reuse along runs of one relation: where a block's weights outweigh the bookkeeping (1x1 blocks -- the DistMult-shaped
+    // launches -- lose: 45 -> 68 us at FB15k-237 size with the conditional loads in their 8-edge batches)
+    constexpr bool RUNS = P * Q >= 4;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (wave >= a.n_items) return;
@@ -94,63 +97,97 @@ __global__ __launch_bounds__(256) void k_agg_fast(const AggParams a) {
             my_t = a.etype[e0 + lane];
             if (a.coef) my_c = a.coef_idx ? a.coef[a.coef_idx[e0 + lane]] : a.coef[e0 + lane];
         }
-        // Consecutive edges of ONE relation share their weights: the registers of the run's first edge serve the whole run (r_keep /
-        // wkeep carry an open run across batches and metadata chunks).  All of it is wave-uniform scalar control; per edge the
-        // arithmetic is what it was.  Rows whose edges come sorted by relation (static graphs: ops.GraphIndex.rel_sorted) turn every
-        // repeated (row, relation) pair into a skipped weight fetch -- the per-edge weight read is what bounds this kernel.
-        const bool more_chunks = e0 + 64 < it.z;
-        int j = 0;
-        for (; j + U <= cnt; j += U) {
-            float xv[U][GV], wv[U][WV], cc[U];
-            int rr[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int s = rl_i(my_n, j + u);
-                rr[u] = rl_i(my_t, j + u);
-                cc[u] = rl_f(my_c, j + u);
+        if constexpr (RUNS) {
+            // Consecutive edges of ONE relation share their weights: the registers of the run's first edge serve the whole run (r_keep /
+            // wkeep carry an open run across batches and metadata chunks).  All of it is wave-uniform scalar control; per edge the
+            // arithmetic is what it was.  Rows whose edges come sorted by relation (static graphs: ops.GraphIndex.rel_sorted) turn every
+            // repeated (row, relation) pair into a skipped weight fetch -- the per-edge weight read is what bounds this kernel.
+            const bool more_chunks = e0 + 64 < it.z;
+            int j = 0;
+            for (; j + U <= cnt; j += U) {
+                float xv[U][GV], wv[U][WV], cc[U];
+                int rr[U];
+    #pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int s = rl_i(my_n, j + u);
+                    rr[u] = rl_i(my_t, j + u);
+                    cc[u] = rl_f(my_c, j + u);
+                    if (active) {
+                        load_vec<GV>(fbase + (size_t)s * a.ld_feat, xv[u]);
+                        if (rr[u] != (u ? rr[u - 1] : r_keep)) load_vec<WV>(wbase + (size_t)rr[u] * a.w_row, wv[u]);
+                    }
+                }
+                int src = -1;
+    #pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (rr[u] != (u ? rr[u - 1] : r_keep)) src = u;
+                    if (active) {
+                        if (src < 0) block_fma<P, Q, TRANS, BPL>(xv[u], wkeep, cc[u], acc);
+    #pragma unroll
+                        for (int v = 0; v <= u; ++v)
+                            if (src == v) block_fma<P, Q, TRANS, BPL>(xv[u], wv[v], cc[u], acc);
+                    }
+                }
+                // does the run go on behind this batch?  (at the end of a metadata chunk: assume so if the item has another one)
+                const bool cont = j + U < cnt ? rl_i(my_t, j + U) == rr[U - 1] : more_chunks;
+                if (src >= 0) {
+                    if (cont) {
+    #pragma unroll
+                        for (int v = 0; v < U; ++v)
+                            if (src == v) {
+    #pragma unroll
+                                for (int i = 0; i < WV; ++i) wkeep[i] = wv[v][i];
+                            }
+                        r_keep = rr[U - 1];
+                    } else {
+                        r_keep = -1;
+                    }
+                }
+            }
+            for (; j < cnt; ++j) {
+                float xv[GV];
+                const int s = rl_i(my_n, j);
+                const int r = rl_i(my_t, j);
+                const float c = rl_f(my_c, j);
                 if (active) {
-                    load_vec<GV>(fbase + (size_t)s * a.ld_feat, xv[u]);
-                    if (rr[u] != (u ? rr[u - 1] : r_keep)) load_vec<WV>(wbase + (size_t)rr[u] * a.w_row, wv[u]);
+                    load_vec<GV>(fbase + (size_t)s * a.ld_feat, xv);
+                    if (r != r_keep) load_vec<WV>(wbase + (size_t)r * a.w_row, wkeep);
+                    block_fma<P, Q, TRANS, BPL>(xv, wkeep, c, acc);
                 }
+                r_keep = r;
             }
-            int src = -1;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (rr[u] != (u ? rr[u - 1] : r_keep)) src = u;
+    
+        } else {
+            int j = 0;
+            for (; j + U <= cnt; j += U) {
+                float xv[U][GV], wv[U][WV], cc[U];
+    #pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int s = rl_i(my_n, j + u);
+                    const int r = rl_i(my_t, j + u);
+                    cc[u] = rl_f(my_c, j + u);
+                    if (active) {
+                        load_vec<GV>(fbase + (size_t)s * a.ld_feat, xv[u]);
+                        load_vec<WV>(wbase + (size_t)r * a.w_row, wv[u]);
+                    }
+                }
                 if (active) {
-                    if (src < 0) block_fma<P, Q, TRANS, BPL>(xv[u], wkeep, cc[u], acc);
-#pragma unroll
-                    for (int v = 0; v <= u; ++v)
-                        if (src == v) block_fma<P, Q, TRANS, BPL>(xv[u], wv[v], cc[u], acc);
+    #pragma unroll
+                    for (int u = 0; u < U; ++u) block_fma<P, Q, TRANS, BPL>(xv[u], wv[u], cc[u], acc);
                 }
             }
-            // does the run go on behind this batch?  (at the end of a metadata chunk: assume so if the item has another one)
-            const bool cont = j + U < cnt ? rl_i(my_t, j + U) == rr[U - 1] : more_chunks;
-            if (src >= 0) {
-                if (cont) {
-#pragma unroll
-                    for (int v = 0; v < U; ++v)
-                        if (src == v) {
-#pragma unroll
-                            for (int i = 0; i < WV; ++i) wkeep[i] = wv[v][i];
-                        }
-                    r_keep = rr[U - 1];
-                } else {
-                    r_keep = -1;
+            for (; j < cnt; ++j) {
+                float xv[GV], wv[WV];
+                const int s = rl_i(my_n, j);
+                const int r = rl_i(my_t, j);
+                const float c = rl_f(my_c, j);
+                if (active) {
+                    load_vec<GV>(fbase + (size_t)s * a.ld_feat, xv);
+                    load_vec<WV>(wbase + (size_t)r * a.w_row, wv);
+                    block_fma<P, Q, TRANS, BPL>(xv, wv, c, acc);
                 }
             }
-        }
-        for (; j < cnt; ++j) {
-            float xv[GV];
-            const int s = rl_i(my_n, j);
-            const int r = rl_i(my_t, j);
-            const float c = rl_f(my_c, j);
-            if (active) {
-                load_vec<GV>(fbase + (size_t)s * a.ld_feat, xv);
-                if (r != r_keep) load_vec<WV>(wbase + (size_t)r * a.w_row, wkeep);
-                block_fma<P, Q, TRANS, BPL>(xv, wkeep, c, acc);
-            }
-            r_keep = r;
+    
         }
     }
     if (!active) return;
