@@ -268,6 +268,108 @@ __global__ __launch_bounds__(256) void k_kl_fwd(const float* z, const float* m, 
     if (threadIdx.x == 0) part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
+// The same pass with a lane owning FOUR CONSECUTIVE columns per group (h % 4 == 0, G = ceil(h / 256) groups): 16-B loads and
+// stores of the node rows, one ds_read_b128 per operand and component instead of four ds_read_b32, no per-element column
+// guards (a group is inside or outside as a whole).  The per-lane kernel above issues ~1700 VALU instructions per node -- it is
+// VALU-bound, 4 cycles per wave64 instruction -- most of them in the component loop; this form halves that.  Per element the
+// same expressions; the sums over a row's columns run in another (fixed) order.
+template <int G>
+__global__ __launch_bounds__(256) void k_kl_fwd_v4(const float* z, const float* m, int ld_m, const float* v,
+                                                   const float* mix, const float* flp, float* resp, float* part,
+                                                   int64_t n, int h, int k, const int* rows_dev, const float* h2,
+                                                   const float* eps, float* z_out, float* v_out, float* m_out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float wsum[4];
+    __shared__ float lconst[KL_KMAX];
+    if (rows_dev) n = *rows_dev;
+    const int kh = k * h;
+    for (int i = threadIdx.x; i < 2 * kh / 4; i += 256) reinterpret_cast<float4*>(sm)[i] = reinterpret_cast<const float4*>(mix)[i];
+    for (int j = threadIdx.x >> 6; j < k; j += 4) {
+        float t = 0.f;
+        for (int c = threadIdx.x & 63; c < h; c += 64) t += mix[2 * kh + j * h + c];
+        t = wave_sum(t);
+        if ((threadIdx.x & 63) == 0) lconst[j] = t;
+    }
+    __syncthreads();
+    const float* mu = sm;
+    const float* i2v = sm + kh;
+    const int lane = threadIdx.x & 63;
+    const float fl = flp ? *flp : 0.f;
+    const float logk = logf((float)k);
+    float my_terms = 0.f;
+    bool on[G];
+    int col[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        col[g] = 4 * (lane + 64 * g);
+        on[g] = col[g] < h;
+    }
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {
+        float zz[G][4];
+        float a = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) zz[g][i] = 0.f;
+            if (!on[g]) continue;
+            float mm[4], vv[4];
+            if (h2) {      // fused reparameterisation (K3)
+                const float4 m4 = *reinterpret_cast<const float4*>(h2 + r * 2 * h + col[g]);
+                const float4 r4 = *reinterpret_cast<const float4*>(h2 + r * 2 * h + h + col[g]);
+                const float4 e4 = *reinterpret_cast<const float4*>(eps + r * h + col[g]);
+                const float raw[4] = {r4.x, r4.y, r4.z, r4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
+                mm[0] = m4.x; mm[1] = m4.y; mm[2] = m4.z; mm[3] = m4.w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    vv[i] = softplus_t(raw[i]) + 1e-8f;
+                    zz[g][i] = mm[i] + ee[i] * sqrtf(vv[i]);
+                }
+                *reinterpret_cast<float4*>(z_out + r * h + col[g]) = make_float4(zz[g][0], zz[g][1], zz[g][2], zz[g][3]);
+                *reinterpret_cast<float4*>(v_out + r * h + col[g]) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                if (m_out) *reinterpret_cast<float4*>(m_out + r * h + col[g]) = m4;
+            } else {
+                const float4 z4 = *reinterpret_cast<const float4*>(z + r * h + col[g]);
+                const float4 m4 = *reinterpret_cast<const float4*>(m + r * ld_m + col[g]);
+                const float4 v4 = *reinterpret_cast<const float4*>(v + r * h + col[g]);
+                zz[g][0] = z4.x; zz[g][1] = z4.y; zz[g][2] = z4.z; zz[g][3] = z4.w;
+                mm[0] = m4.x; mm[1] = m4.y; mm[2] = m4.z; mm[3] = m4.w;
+                vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = zz[g][i] - mm[i];
+                a += -(d * d) / (2.f * vv[i]) - logf(sqrtf(vv[i])) - LOG_SQRT_2PI;
+            }
+        }
+        a = wave_sum(a);
+        float my_l = -INFINITY;
+        for (int j = 0; j < k; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (!on[g]) continue;
+                const float4 mu4 = *reinterpret_cast<const float4*>(mu + j * h + col[g]);
+                const float4 iv4 = *reinterpret_cast<const float4*>(i2v + j * h + col[g]);
+                const float d0 = zz[g][0] - mu4.x, d1 = zz[g][1] - mu4.y, d2 = zz[g][2] - mu4.z, d3 = zz[g][3] - mu4.w;
+                acc = fmaf(-(d0 * d0), iv4.x, acc);
+                acc = fmaf(-(d1 * d1), iv4.y, acc);
+                acc = fmaf(-(d2 * d2), iv4.z, acc);
+                acc = fmaf(-(d3 * d3), iv4.w, acc);
+            }
+            acc = wave_sum(acc) - lconst[j];
+            if (lane == j) my_l = acc;
+        }
+        const float mx = wave_max(my_l);
+        const float e = lane < k ? expf(my_l - mx) : 0.f;
+        const float se = wave_sum(e);
+        if (lane < k) resp[r * k + lane] = e / se;
+        my_terms += a + fl - (mx + logf(se) - logk);
+    }
+    if (lane == 0) wsum[threadIdx.x >> 6] = my_terms;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
 // per-node gradients gz, gm, gv (scaled by *gkl / n)
 __global__ __launch_bounds__(256) void k_kl_bwd_nodes(const float* z, const float* m, int ld_m, const float* v,
                                                       const float* mix, const float* resp, const float* gkl, float gscale,
@@ -705,6 +807,23 @@ extern "C" int64_t gv_kl_workspace_bytes(int64_t n, int h, int k) {
     return (int64_t)sizeof(float) * (3 * (int64_t)k * h + RED_BLOCKS + (int64_t)KL_SLICES * 2 * k * h);
 }
 
+// the float4-column form where rows are 16-B aligned (h % 4 == 0, every operand 16-B aligned; GV_KL_V4=0 keeps the per-lane form)
+static bool kl_fwd_v4(int nb, size_t lds, hipStream_t st, const float* z, const float* m, int ld_m, const float* v, const float* mix,
+                      const float* flp, float* resp, float* part, int64_t n, int h, int k, const int* rows_dev, const float* h2,
+                      const float* eps, float* z_out, float* v_out, float* m_out) {
+    static const int env = getenv("GV_KL_V4") ? atoi(getenv("GV_KL_V4")) : 1;
+    const bool al = aligned16(mix) && (!z || aligned16(z)) && (!m || (aligned16(m) && ld_m % 4 == 0)) && (!v || aligned16(v)) &&
+                    (!h2 || aligned16(h2)) && (!eps || aligned16(eps)) && (!z_out || aligned16(z_out)) && (!v_out || aligned16(v_out)) &&
+                    (!m_out || aligned16(m_out));
+    if (!env || h % 4 != 0 || h > 1024 || !al) return false;
+#define GV_KL_V4(G_) hipLaunchKernelGGL(k_kl_fwd_v4<G_>, dim3(nb), dim3(256), lds, st, z, m, ld_m, v, mix, flp, resp, part, n, h, k, rows_dev, h2, eps, z_out, v_out, m_out)
+    if (h <= 256) GV_KL_V4(1);
+    else if (h <= 512) GV_KL_V4(2);
+    else GV_KL_V4(4);
+#undef GV_KL_V4
+    return true;
+}
+
 extern "C" int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre,
                          const float* flp, float* resp, float* kl, float* workspace, int64_t n, int h, int k,
                          const int32_t* rows_dev, void* stream) {
@@ -720,7 +839,8 @@ extern "C" int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* 
     const int nb = kl_blocks(n);
     GV_REQUIRE(h <= 1024, GV_ERR_SHAPE, "gv_kl_fwd: h=%d > 1024 unsupported", h);
 #define GV_KL_FWD(CPL_) hipLaunchKernelGGL(k_kl_fwd<CPL_>, dim3(nb), dim3(256), lds, GV_ST, z, m, ld_m, v, mix, flp, resp, part, n, h, k, rows_dev)
-    if (h <= 64) GV_KL_FWD(1);
+    if (kl_fwd_v4(nb, lds, GV_ST, z, m, ld_m, v, mix, flp, resp, part, n, h, k, rows_dev, nullptr, nullptr, nullptr, nullptr, nullptr)) {}
+    else if (h <= 64) GV_KL_FWD(1);
     else if (h <= 128) GV_KL_FWD(2);
     else if (h <= 256) GV_KL_FWD(4);
     else if (h <= 512) GV_KL_FWD(8);
@@ -778,7 +898,8 @@ extern "C" int gv_reparam_kl_fwd(const float* h2, const float* eps, const float*
 #define GV_RKL_FWD(CPL_)                                                                                                       \
     hipLaunchKernelGGL(k_kl_fwd<CPL_>, dim3(nb), dim3(256), lds, GV_ST, none, none, h, none, (const float*)mix, none, resp, part, n, h, \
                        k, no_rows, h2, eps, z, v, m_out)
-    if (h <= 64) GV_RKL_FWD(1);
+    if (kl_fwd_v4(nb, lds, GV_ST, none, none, h, none, mix, none, resp, part, n, h, k, no_rows, h2, eps, z, v, m_out)) {}
+    else if (h <= 64) GV_RKL_FWD(1);
     else if (h <= 128) GV_RKL_FWD(2);
     else if (h <= 256) GV_RKL_FWD(4);
     else if (h <= 512) GV_RKL_FWD(8);
