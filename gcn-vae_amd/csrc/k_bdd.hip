@@ -555,18 +555,26 @@ __device__ __forceinline__ float ordered_slot_sum(const float* __restrict__ p, i
     return (a0 + a1) + (a2 + a3);
 }
 
-__global__ __launch_bounds__(256) void k_agg_fixup(const int4* fix, int n_fix, const float* partial, int out_dim,
-                                                   const float* addend, int ld_add, int act, const uint8_t* keep,
-                                                   float keep_scale, float* out, int ld_out) {
-    const int lane = threadIdx.x & 63;
+// One WORKGROUP per (split row, 64-column tile): its waves sum consecutive shares of the row's partial slots, each in slot order,
+// and the shares are added in wave order through LDS -- a fixed order, whatever the launch.  (One wave per pair left a hub row of a
+// 50 M-edge graph -- thousands of slots -- to a single wave: 630 us per launch, 3 ms per step at BASELINE configs[4].)
+__global__ __launch_bounds__(1024) void k_agg_fixup(const int4* fix, int n_fix, const float* partial, int out_dim,
+                                                    const float* addend, int ld_add, int act, const uint8_t* keep,
+                                                    float keep_scale, float* out, int ld_out) {
+    __shared__ float share[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int tiles = (out_dim + 63) >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    if (wave >= n_fix * tiles) return;
-    const int4 f = fix[wave / tiles];
-    if (f.x < 0) return;                  // unused tail entry of an upper-bound-sized fix list
-    const int c = (wave % tiles) * 64 + lane;
-    if (c >= out_dim) return;
-    float acc = ordered_slot_sum(partial + (size_t)f.y * out_dim + c, f.z, out_dim);
+    const int4 f = fix[blockIdx.x / tiles];
+    if (f.x < 0) return;                  // unused tail entry of an upper-bound-sized fix list (uniform for the workgroup)
+    const int c = (blockIdx.x % tiles) * 64 + lane;
+    const int per = (f.z + nw - 1) / nw, k0 = min(f.z, w * per), k1 = min(f.z, k0 + per);
+    float acc = 0.f;
+    if (c < out_dim && k1 > k0) acc = ordered_slot_sum(partial + (size_t)(f.y + k0) * out_dim + c, k1 - k0, out_dim);
+    share[w][lane] = acc;
+    __syncthreads();
+    if (w != 0 || c >= out_dim) return;
+    acc = share[0][lane];
+    for (int i = 1; i < nw; ++i) acc += share[i][lane];
     if (addend) acc += addend[(size_t)f.x * ld_add + c];
     acc = apply_act(acc, act);
     if (keep) acc = keep[(size_t)f.x * out_dim + c] ? acc * keep_scale : 0.f;
@@ -1101,8 +1109,8 @@ extern "C" int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const in
     }
     if (rc != GV_OK) return rc;
     if (n_fix > 0) {
-        const int waves = n_fix * ((a.out_dim + 63) / 64);
-        hipLaunchKernelGGL(k_agg_fixup, dim3((waves + 3) / 4), dim3(256), 0, st, (const int4*)fix, n_fix, partial,
+        const int pairs = n_fix * ((a.out_dim + 63) / 64);
+        hipLaunchKernelGGL(k_agg_fixup, dim3(pairs), dim3(pairs >= 65536 ? 1024 : 256), 0, st, (const int4*)fix, n_fix, partial,
                            a.out_dim, addend, ld_addend, act, keep, keep_scale, out, ld_out);
         return launch_status("gv_rgcn_bdd_aggregate(fixup)");
     }
@@ -1115,8 +1123,8 @@ extern "C" int gv_rgcn_bdd_fixup(const int32_t* fix, int n_fix, const float* par
     GV_REQUIRE(n_fix >= 0, GV_ERR_SHAPE, "gv_rgcn_bdd_fixup: negative count");
     if (n_fix == 0) return GV_OK;
     GV_REQUIRE(fix && partial && out, GV_ERR_NULL, "gv_rgcn_bdd_fixup: NULL pointer");
-    const int waves = n_fix * ((out_dim + 63) / 64);
-    hipLaunchKernelGGL(k_agg_fixup, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const int4*)fix, n_fix,
+    const int pairs = n_fix * ((out_dim + 63) / 64);
+    hipLaunchKernelGGL(k_agg_fixup, dim3(pairs), dim3(pairs >= 65536 ? 1024 : 256), 0, (hipStream_t)stream, (const int4*)fix, n_fix,
                        partial, out_dim, addend, ld_addend, act, keep, keep_scale, out, ld_out);
     return launch_status("gv_rgcn_bdd_fixup");
 }
