@@ -724,7 +724,8 @@ extern "C" int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, co
             GV_REQUIRE(L.iaf_x_old && L.iaf_colcount && (L.iaf_x_new || L.iaf_ex || L.out_bf16 || L.out_bf16_t), GV_ERR_NULL,
                        "gv_made_chain: IAF layer needs x_old, colcount and an output");
             GV_REQUIRE(L.iaf_ld >= L.n / 2 && L.iaf_ld % 4 == 0 && aligned16(L.iaf_z) && aligned16(L.iaf_x_old) && aligned16(L.iaf_colcount) &&
-                       (!L.iaf_x_new || aligned16(L.iaf_x_new)) && (!L.iaf_ex || aligned16(L.iaf_ex)) && (!L.iaf_alpha || aligned16(L.iaf_alpha)),
+                       (!L.iaf_x_new || aligned16(L.iaf_x_new)) && (!L.iaf_ex || aligned16(L.iaf_ex)) && (!L.iaf_alpha || aligned16(L.iaf_alpha)) &&
+                       (!L.iaf_keep_colcount || aligned16(L.iaf_keep_colcount)),
                        GV_ERR_ALIGN, "gv_made_chain: IAF operands are [m][iaf_ld] fp32 with 16-B aligned rows");
         }
         GV_REQUIRE((!L.mask || (L.ldmask >= L.n && L.ldmask % 8 == 0 && aligned16(L.mask))) &&
