@@ -1488,7 +1488,11 @@ class _RelGraphConvBdd(torch.autograd.Function):
         else:
             w_fwd = pack_weight(weight, num_bases, si, so, False) if pk else weight
 
+        ctx.loop_bf = dense_bf16_forms(loop_weight) if (loop_weight is not None and x.shape[0] >= 4096) else None
+
         def self_loop_term():
+            if loop_weight is not None and ctx.loop_bf is not None:
+                return dense_bf16(x, ctx.loop_bf[0], loop_weight.shape[1], loop_weight.shape[0], bias=h_bias)
             if loop_weight is not None:
                 return gemm(x, loop_weight, bias=h_bias)
             if h_bias is not None:
@@ -1569,7 +1573,10 @@ class _RelGraphConvBdd(torch.autograd.Function):
                 if d_l is not None:
                     grad_loop = None
             if ctx.needs_input_grad[0]:
-                gx_loop = gemm(g, loop_weight, trans_b=True)
+                if getattr(ctx, 'loop_bf', None) is not None:
+                    gx_loop = dense_bf16(g, ctx.loop_bf[1], loop_weight.shape[0], loop_weight.shape[1])
+                else:
+                    gx_loop = gemm(g, loop_weight, trans_b=True)
         if pending is not None:
             pending.wait()
         grad_x = None
@@ -2799,6 +2806,30 @@ def gemm_bf16_nt(a, b, m, n, k, bias=None, relu=False, mask=None, c_f32=None, ac
              c_f32.stride(0) if c_f32 is not None else 0, 1 if accumulate else 0, ptr(c_bf16),
              c_bf16.stride(0) if c_bf16 is not None else 0, ptr(c_bf16_t), c_bf16_t.stride(0) if c_bf16_t is not None else 0,
              split_k, ptr(ws), ws_bytes, lib.stream())
+
+
+DENSE_BF16_NT = _os.environ.get('GV_DENSE_BF16_NT', '1') == '1'
+
+
+def dense_bf16_forms(w):
+    """bf16 copies of a dense weight W (k_in, n_out) for the self-loop products on gv_gemm_bf16_nt (one launch): (W^T as (n_out,
+    pad8(k_in)), W as (k_in, pad8(n_out))); None when the bf16 dense path does not apply (fp32 precision, small or odd shapes)."""
+    if not (DENSE_BF16_NT and GEMM_PRECISION == 'bf16' and w.dim() == 2 and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0):
+        return None
+    kin, nout = w.shape
+    wt = torch.empty(nout, _pad8(kin), dtype=torch.bfloat16, device=w.device)
+    wb = torch.empty(kin, _pad8(nout), dtype=torch.bfloat16, device=w.device)
+    cast_bf16(w, wb, wt)
+    return wt, wb
+
+
+def dense_bf16(a, b_nt, n, k, bias=None):
+    """a (m, k) fp32 @ b_nt (n, k)^T bf16 -> (m, n) fp32: operands rounded to bf16, fp32 accumulation (gv_gemm_bf16_nt; the tiled
+    gv_gemm_bf16 takes 63 us for 40 943 x 200 x 200, this kernel 28)."""
+    a, _ = _row_major(a, 'a')
+    out = torch.empty(a.shape[0], n, dtype=torch.float32, device=a.device)
+    gemm_bf16_nt(a, b_nt, a.shape[0], n, k, bias=bias, c_f32=out)
+    return out
 
 
 def gemm_bf16_gradw_fits(m, n, k, split_k):
