@@ -704,18 +704,13 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_row0(const float* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void k_iaf_row0_final(const float* __restrict__ part, int n2, int nsl, float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n2) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int s = 0;
-    for (; s + 4 <= nsl; s += 4) {
-        const float v0 = part[(size_t)s * n2 + c], v1 = part[(size_t)(s + 1) * n2 + c];
-        const float v2 = part[(size_t)(s + 2) * n2 + c], v3 = part[(size_t)(s + 3) * n2 + c];
-        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
-    }
-    for (; s < nsl; ++s) a0 += part[(size_t)s * n2 + c];
-    out[c] = (a0 + a1) + (a2 + a3);
+// the slices summed per column: 16 columns per 1024-thread block, 64 groups of slices each (common.h: sum_slices_16x64) -- two
+// 256-thread blocks walking 1024 slices one after the other took 60 us
+__global__ __launch_bounds__(1024) void k_iaf_row0_final(const float* __restrict__ part, int n2, int nsl, float* __restrict__ out) {
+    __shared__ float sm[64][16];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const float acc = sum_slices_16x64(part, n2, nsl, c, sm);
+    if ((threadIdx.x >> 4) == 0 && c < n2) out[c] = acc;
 }
 
 }  // namespace gv
@@ -923,7 +918,7 @@ extern "C" int gv_iaf_update_bwd_row0(const float* z, const float* net_row, cons
     const int nsl = n > 0 ? (int)((n + per - 1) / per) : 0;
     if (nsl > 0)
         hipLaunchKernelGGL(k_iaf_bwd_row0, dim3(nsl), dim3(256), 0, st, z, net_row, colcount, gx, gld, gz_accumulate, workspace, (int)n, d, per);
-    hipLaunchKernelGGL(k_iaf_row0_final, dim3((2 * d + 255) / 256), dim3(256), 0, st, (const float*)workspace, 2 * d, nsl, g_row);
+    hipLaunchKernelGGL(k_iaf_row0_final, dim3((2 * d + 15) / 16), dim3(1024), 0, st, (const float*)workspace, 2 * d, nsl, g_row);
     return launch_status("gv_iaf_update_bwd_row0");
 }
 
