@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16(const float* __restrict__ 
                                                       const int* __restrict__ colcount, const float* __restrict__ gx,
                                                       const float* __restrict__ gld, float* __restrict__ gz_acc,
                                                       uint16_t* gnb, int ldb, uint16_t* gnt, int ldt, float* __restrict__ gxold,
-                                                      int rows, int d) {
+                                                      int rows, int d, int gz_overwrite) {
     // one thread element = column c of [0, d): its g_mu goes to column c and its g_alpha to column d + c of g_net (one exp per
     // element for both), two 64 x 64 LDS tiles for the two transposed copies
     __shared__ uint16_t tm[64][66];
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16(const float* __restrict__ 
                 g_al += g_mu;
                 g_old = 0.f;
             }
-            gz_acc[e] += g_z;
+            gz_acc[e] = gz_overwrite ? g_z : gz_acc[e] + g_z;
             if (gxold) gxold[e] = g_old;
             vm = f2bf(g_mu);
             va = f2bf(g_al);
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16_v4(const float* __restrict
                                                          const int* __restrict__ colcount, const float* __restrict__ gx,
                                                          const float* __restrict__ gld, float* __restrict__ gz_acc,
                                                          uint16_t* gnb, int ldb, uint16_t* gnt, int ldt, float* __restrict__ gxold,
-                                                         int rows, int d) {
+                                                         int rows, int d, int gz_overwrite) {
     __shared__ __attribute__((aligned(8))) uint16_t tm[64][68];
     __shared__ __attribute__((aligned(8))) uint16_t ta[64][68];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -491,7 +491,8 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16_v4(const float* __restrict
         if (r < rows && c < d) {
             const size_t e = (size_t)r * d + c;
             const float4 g4 = *reinterpret_cast<const float4*>(gx + e);
-            float4 acc4 = *reinterpret_cast<const float4*>(gz_acc + e);
+            float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);      // gz_overwrite: the first pass of a backward starts g_z (no zero fill, no read)
+            if (!gz_overwrite) acc4 = *reinterpret_cast<const float4*>(gz_acc + e);
             float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f), mu4 = z4, al4 = z4;
             if (any) {
                 z4 = *reinterpret_cast<const float4*>(z + e);
@@ -866,7 +867,7 @@ extern "C" int gv_iaf_update_fwd_bf16(const float* z, const float* net, int ld_n
 
 static int iaf_update_bwd_bf16(const char* what, bool ex, const float* z, const float* net, int ld_net, const int32_t* colcount,
                                const float* gx, const float* gld, float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t,
-                               int ldt, float* gx_old, int64_t n, int d, void* stream) {
+                               int ldt, float* gx_old, int gz_overwrite, int64_t n, int d, void* stream) {
     GV_REQUIRE(n >= 0 && d > 0 && n < (1ll << 31), GV_ERR_SHAPE, "%s: n=%lld d=%d", what, (long long)n, d);
     if (n == 0) return GV_OK;
     GV_REQUIRE(z && net && colcount && gx && gz_accumulate && gnet_b && gnet_t && (gx_old || ex), GV_ERR_NULL, "%s: NULL pointer", what);
@@ -877,7 +878,7 @@ static int iaf_update_bwd_bf16(const char* what, bool ex, const float* z, const 
     const dim3 grid((d + 63) / 64, (unsigned)((n + 63) / 64));
 #define GV_IAF_BWD(K)                                                                                                        \
     hipLaunchKernelGGL(K, grid, dim3(256), 0, (hipStream_t)stream, z, net, ld_net, colcount, gx, gld, gz_accumulate, gnet_b, ldb,   \
-                       gnet_t, ldt, gx_old, (int)n, d)
+                       gnet_t, ldt, gx_old, (int)n, d, gz_overwrite)
     if (v4 && ex) GV_IAF_BWD(k_iaf_bwd_bf16_v4<true>);
     else if (v4) GV_IAF_BWD(k_iaf_bwd_bf16_v4<false>);
     else if (ex) GV_IAF_BWD(k_iaf_bwd_bf16<true>);
@@ -890,14 +891,14 @@ extern "C" int gv_iaf_update_bwd_bf16(const float* z, const float* net, int ld_n
                                      const float* gld, float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t, int ldt,
                                      float* gx_old, int64_t n, int d, void* stream) {
     return iaf_update_bwd_bf16("gv_iaf_update_bwd_bf16", false, z, net, ld_net, colcount, gx, gld, gz_accumulate, gnet_b, ldb, gnet_t,
-                               ldt, gx_old, n, d, stream);
+                               ldt, gx_old, 0, n, d, stream);
 }
 
 extern "C" int gv_iaf_update_bwd_bf16_ex(const float* z, const float* ex, int ld_ex, const int32_t* colcount, const float* gx,
                                         const float* gld, float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t, int ldt,
-                                        float* gx_old, int64_t n, int d, void* stream) {
+                                        float* gx_old, int gz_overwrite, int64_t n, int d, void* stream) {
     return iaf_update_bwd_bf16("gv_iaf_update_bwd_bf16_ex", true, z, ex, ld_ex, colcount, gx, gld, gz_accumulate, gnet_b, ldb, gnet_t,
-                               ldt, gx_old, n, d, stream);
+                               ldt, gx_old, gz_overwrite, n, d, stream);
 }
 
 

@@ -66,7 +66,7 @@ SIGNATURES = {
     'gv_gather3_i32': (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _P]),
     'gv_iaf_update_bwd_row0_workspace_floats': (_L, [_I]),
     'gv_iaf_update_bwd_row0': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
-    'gv_iaf_update_bwd_bf16_ex': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _L, _I, _P]),
+    'gv_iaf_update_bwd_bf16_ex': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _L, _I, _P]),
     'gv_rowsum_bf16': (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     'gv_rowsum_bf16_segments': (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     'gv_made_pack_weight_elems': (_L, [_I, _I]),

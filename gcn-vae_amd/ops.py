@@ -3134,7 +3134,7 @@ class _MADEForwardBF16(torch.autograd.Function):
         else:
             gm_b = [torch.empty(max(S, 1) * n, _pad8(widths[l]), **bf) for l in range(L)]
         *gm_t, gm_t_all = _empty_t_padded(widths, max(S, 1), n, npad, bf)
-        g_z = torch.zeros(n, d, **f32)
+        g_z = torch.empty(n, d, **f32) if (ctx.fused and P > 1) else torch.zeros(n, d, **f32)      # fused: the first pass writes it
         gz_p = torch.empty(n, d, **f32)
         g_cur = gx
         for p in reversed(range(1, P)):
@@ -3145,7 +3145,7 @@ class _MADEForwardBF16(torch.autograd.Function):
                 # from exp(alpha + mu); the gradient handed through to x_old (columns of count 0) is added by the chain's last layer
                 lib.call('gv_iaf_update_bwd_bf16_ex', ptr(z), ptr(net_out[sl]), d, ptr(colcount[p]), ptr(g_cur),
                          ptr(gld) if p == P - 1 else None, ptr(g_z), ptr(gm_in), gm_in.stride(0), ptr(gm_t[L - 1][:, tsl]),
-                         gm_t[L - 1].stride(0), None, n, d, st)
+                         gm_t[L - 1].stride(0), None, 1 if p == P - 1 else 0, n, d, st)
                 made_chain(gm_in, n,
                            [dict(w_packed=wbt[l], n=widths[l - 1], k=widths[l], mask_bits=acts_b[l - 1][sl],
                                  out_bf16_t=gm_t[l - 1][:, tsl]) for l in reversed(range(1, L))] +

@@ -202,10 +202,11 @@ int gv_iaf_update_bwd_bf16(const float* z, const float* net, int ld_net, const i
                            float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t, int ldt, float* gx_old, int64_t n,
                            int d, void* stream);
 /* ... from ex = expf(alpha + mu) [n][ld_ex] (what a forward chain with the fused update stores, gv_chain_layer.iaf_ex) instead
- * of [mu | alpha]; gx_old may be NULL (the backward chain adds the handed-through gradient itself: gv_chain_layer.add_src). */
+ * of [mu | alpha]; gx_old may be NULL (the backward chain adds the handed-through gradient itself: gv_chain_layer.add_src);
+ * gz_overwrite != 0: g_z is WRITTEN to gz_accumulate (the first pass of a backward: no zero fill, no read). */
 int gv_iaf_update_bwd_bf16_ex(const float* z, const float* ex, int ld_ex, const int32_t* colcount, const float* gx, const float* gld,
-                              float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t, int ldt, float* gx_old, int64_t n,
-                              int d, void* stream);
+                              float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t, int ldt, float* gx_old,
+                              int gz_overwrite, int64_t n, int d, void* stream);
 /* Pass 0 of a MADE backward: the update was fed ONE broadcast row net_row = [mu | alpha] (2 d floats; the first pass's input is
  * the zero matrix, kgvae/flow_network.py:85-98).  ADDS g_z into gz_accumulate [n][d] and writes the gradient w.r.t. that row,
  * g_row [2 d] = column sums of [g_mu | g_alpha], without materialising the (n, 2d) gradient; gld [n] or NULL; d % 4 == 0,
