@@ -511,7 +511,13 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 bl += CH_BM * nt;
             }
     }
-    chain_stage(chain_lds, ldk, p.x, p.ldx, m0, p.m, p.L[0].k, (p.L[0].k + 15) & ~15);
+    if (p.L[0].x_dup_half) {      // x holds one half of the columns, the other half repeats it ([g_mu | g_alpha] with g_alpha == g_mu)
+        const int half = p.L[0].k >> 1;
+        chain_stage(chain_lds, ldk, p.x, p.ldx, m0, p.m, half, half);
+        chain_stage(chain_lds + half, ldk, p.x, p.ldx, m0, p.m, half, half);
+    } else {
+        chain_stage(chain_lds, ldk, p.x, p.ldx, m0, p.m, p.L[0].k, (p.L[0].k + 15) & ~15);
+    }
     if (FULL && (p.L[0].mask || p.L[0].mask_t)) chain_stage_mask(mbuf, ldk, p.L[0], m0, p.m);
     __syncthreads();
 
@@ -703,7 +709,9 @@ extern "C" int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, co
     GV_REQUIRE(m >= 0 && n_layers >= 1 && n_layers <= GV_CHAIN_MAX_LAYERS, GV_ERR_SHAPE, "gv_made_chain: m=%d n_layers=%d", m, n_layers);
     if (m == 0) return GV_OK;
     GV_REQUIRE(x && layers, GV_ERR_NULL, "gv_made_chain: NULL pointer");
-    GV_REQUIRE(ldx % 8 == 0 && aligned16(x) && ldx >= layers[0].k, GV_ERR_ALIGN, "gv_made_chain: x rows must be 16-B aligned pieces (ldx=%d)", ldx);
+    GV_REQUIRE(ldx % 8 == 0 && aligned16(x) && ldx >= (layers[0].x_dup_half ? layers[0].k / 2 : layers[0].k), GV_ERR_ALIGN,
+               "gv_made_chain: x rows must be 16-B aligned pieces (ldx=%d)", ldx);
+    GV_REQUIRE(!layers[0].x_dup_half || layers[0].k % 16 == 0, GV_ERR_SHAPE, "gv_made_chain: x_dup_half needs k %% 16 == 0");
     ChainArgs p;
     for (int i = 0; i < n_layers; ++i) {
         const gv_chain_layer& L = layers[i];

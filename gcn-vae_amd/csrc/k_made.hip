@@ -392,12 +392,12 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16(const float* __restrict__ 
                 g_al += g_mu;
                 g_old = 0.f;
             }
-            gz_acc[e] = gz_overwrite ? g_z : gz_acc[e] + g_z;
+            gz_acc[e] = (gz_overwrite & 1) ? g_z : gz_acc[e] + g_z;
             if (gxold) gxold[e] = g_old;
             vm = f2bf(g_mu);
             va = f2bf(g_al);
             gnb[(size_t)r * ldb + c] = vm;
-            gnb[(size_t)r * ldb + d + c] = va;
+            if (!(gz_overwrite & 2)) gnb[(size_t)r * ldb + d + c] = va;
         }
         tm[rr][cc] = vm;
         ta[rr][cc] = va;
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16_v4(const float* __restrict
             const size_t e = (size_t)r * d + c;
             const float4 g4 = *reinterpret_cast<const float4*>(gx + e);
             float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);      // gz_overwrite: the first pass of a backward starts g_z (no zero fill, no read)
-            if (!gz_overwrite) acc4 = *reinterpret_cast<const float4*>(gz_acc + e);
+            if (!(gz_overwrite & 1)) acc4 = *reinterpret_cast<const float4*>(gz_acc + e);
             float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f), mu4 = z4, al4 = z4;
             if (any) {
                 z4 = *reinterpret_cast<const float4*>(z + e);
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16_v4(const float* __restrict
             if (gxold) *reinterpret_cast<float4*>(gxold + e) = make_float4(go[0], go[1], go[2], go[3]);
             uint16_t* ob = gnb + (size_t)r * ldb + c;
             *reinterpret_cast<uint2*>(ob) = make_uint2(bm[0] | ((uint32_t)bm[1] << 16), bm[2] | ((uint32_t)bm[3] << 16));
-            *reinterpret_cast<uint2*>(ob + d) = make_uint2(ba[0] | ((uint32_t)ba[1] << 16), ba[2] | ((uint32_t)ba[3] << 16));
+            if (!(gz_overwrite & 2)) *reinterpret_cast<uint2*>(ob + d) = make_uint2(ba[0] | ((uint32_t)ba[1] << 16), ba[2] | ((uint32_t)ba[3] << 16));
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -871,7 +871,8 @@ static int iaf_update_bwd_bf16(const char* what, bool ex, const float* z, const 
     GV_REQUIRE(n >= 0 && d > 0 && n < (1ll << 31), GV_ERR_SHAPE, "%s: n=%lld d=%d", what, (long long)n, d);
     if (n == 0) return GV_OK;
     GV_REQUIRE(z && net && colcount && gx && gz_accumulate && gnet_b && gnet_t && (gx_old || ex), GV_ERR_NULL, "%s: NULL pointer", what);
-    GV_REQUIRE(ldb >= 2 * d && ldt >= n && ld_net >= (ex ? d : 2 * d), GV_ERR_SHAPE, "%s: leading dimension too small", what);
+    GV_REQUIRE(ldb >= ((gz_overwrite & 2) ? d : 2 * d) && ldt >= n && ld_net >= (ex ? d : 2 * d), GV_ERR_SHAPE, "%s: leading dimension too small", what);
+    GV_REQUIRE(!(gz_overwrite & 2) || !gld, GV_ERR_SHAPE, "%s: the mu-half-only form needs g_logdet == NULL (g_alpha == g_mu then)", what);
     const bool v4 = d % 4 == 0 && ld_net % 4 == 0 && ldb % 4 == 0 && ldt % 4 == 0 && aligned16(z) && aligned16(net) && aligned16(gx) &&
                     aligned16(gz_accumulate) && (!gx_old || aligned16(gx_old)) && aligned16(colcount) &&
                     (reinterpret_cast<uintptr_t>(gnet_b) & 7u) == 0 && (reinterpret_cast<uintptr_t>(gnet_t) & 7u) == 0;

@@ -2856,7 +2856,7 @@ class _ChainLayer(_ct.Structure):
                 ('iaf_colcount', _ct.c_void_p), ('iaf_x_new', _ct.c_void_p), ('iaf_ex', _ct.c_void_p), ('iaf_alpha', _ct.c_void_p),
                 ('iaf_ld', _ct.c_int32), ('iaf_reserved', _ct.c_int32), ('iaf_keep_colcount', _ct.c_void_p), ('mask_t', _ct.c_void_p),
                 ('add_src', _ct.c_void_p), ('add_colcount', _ct.c_void_p), ('ldmask_t', _ct.c_int32), ('ldbits', _ct.c_int32),
-                ('out_bits', _ct.c_void_p), ('mask_bits', _ct.c_void_p)]
+                ('out_bits', _ct.c_void_p), ('mask_bits', _ct.c_void_p), ('x_dup_half', _ct.c_int32), ('reserved3', _ct.c_int32)]
 
 
 class _RowLayer(_ct.Structure):
@@ -2972,6 +2972,7 @@ def made_chain(x, m, layers, tag=None):
         mt_, add = d.get('mask_t'), d.get('add')
         if mt_ is not None:
             c.mask_t, c.ldmask_t = ptr(mt_), mt_.stride(0)
+        c.x_dup_half = 1 if d.get('x_dup_half') else 0
         obits, mbits = d.get('out_bits'), d.get('mask_bits')       # int32 (m, >= ceil(n / 32)) sign bits of a hidden activation
         if obits is not None or mbits is not None:
             bt = obits if obits is not None else mbits
@@ -3143,12 +3144,18 @@ class _MADEForwardBF16(torch.autograd.Function):
             g_old = torch.empty(n, d, **f32)
             if ctx.fused:
                 # from exp(alpha + mu); the gradient handed through to x_old (columns of count 0) is added by the chain's last layer
+                # without a log-det gradient (every pass but the last) g_alpha == g_mu: the chain's row-major input holds the g_mu half
+                # alone and the chain stages it twice (x_dup_half)
+                half = (gld is None or p != P - 1) and widths[L - 1] % 16 == 0 and L > 1
                 lib.call('gv_iaf_update_bwd_bf16_ex', ptr(z), ptr(net_out[sl]), d, ptr(colcount[p]), ptr(g_cur),
                          ptr(gld) if p == P - 1 else None, ptr(g_z), ptr(gm_in), gm_in.stride(0), ptr(gm_t[L - 1][:, tsl]),
-                         gm_t[L - 1].stride(0), None, 1 if p == P - 1 else 0, n, d, st)
+                         gm_t[L - 1].stride(0), None, (1 if p == P - 1 else 0) | (2 if half else 0), n, d, st)
+                first = dict(w_packed=wbt[L - 1], n=widths[L - 2], k=widths[L - 1], mask_bits=acts_b[L - 2][sl],
+                             out_bf16_t=gm_t[L - 2][:, tsl], x_dup_half=half) if L > 1 else None
                 made_chain(gm_in, n,
+                           ([first] if first is not None else []) +
                            [dict(w_packed=wbt[l], n=widths[l - 1], k=widths[l], mask_bits=acts_b[l - 1][sl],
-                                 out_bf16_t=gm_t[l - 1][:, tsl]) for l in reversed(range(1, L))] +
+                                 out_bf16_t=gm_t[l - 1][:, tsl]) for l in reversed(range(1, L - 1))] +
                            [dict(w_packed=wbt[0], n=d, k=widths[0], out_f32=g_old, add=(g_cur, colcount[p]))], tag='madechain_bwd')
                 g_cur = g_old
                 continue

@@ -203,10 +203,11 @@ int gv_iaf_update_bwd_bf16(const float* z, const float* net, int ld_net, const i
                            int d, void* stream);
 /* ... from ex = expf(alpha + mu) [n][ld_ex] (what a forward chain with the fused update stores, gv_chain_layer.iaf_ex) instead
  * of [mu | alpha]; gx_old may be NULL (the backward chain adds the handed-through gradient itself: gv_chain_layer.add_src);
- * gz_overwrite != 0: g_z is WRITTEN to gz_accumulate (the first pass of a backward: no zero fill, no read). */
+ * flags bit 0: g_z is WRITTEN to gz_accumulate (the first pass of a backward: no zero fill, no read); bit 1 (gld == NULL only:
+ * g_alpha == g_mu then): gnet_b [n][ldb >= d] receives the g_mu half alone -- a chain reads it with x_dup_half. */
 int gv_iaf_update_bwd_bf16_ex(const float* z, const float* ex, int ld_ex, const int32_t* colcount, const float* gx, const float* gld,
                               float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t, int ldt, float* gx_old,
-                              int gz_overwrite, int64_t n, int d, void* stream);
+                              int flags, int64_t n, int d, void* stream);
 /* Pass 0 of a MADE backward: the update was fed ONE broadcast row net_row = [mu | alpha] (2 d floats; the first pass's input is
  * the zero matrix, kgvae/flow_network.py:85-98).  ADDS g_z into gz_accumulate [n][d] and writes the gradient w.r.t. that row,
  * g_row [2 d] = column sums of [g_mu | g_alpha], without materialising the (n, 2d) gradient; gld [n] or NULL; d % 4 == 0,
@@ -293,6 +294,7 @@ typedef struct gv_chain_layer {
      * a backward layer keeps its result where the bit is set (mask_bits; instead of mask / mask_t).  ldbits >= ceil(n / 32). */
     uint32_t* out_bits;           /* [m][ldbits] or NULL */
     const uint32_t* mask_bits;    /* [m][ldbits] or NULL */
+    int32_t x_dup_half, reserved3; /* layer 0 only: x holds columns [0, k / 2) alone and columns [k / 2, k) repeat them (k % 16 == 0) */
 } gv_chain_layer;
 int64_t gv_made_pack_weight_elems(int n, int k);
 int gv_made_pack_weight(const float* w, int ld, int n, int k, uint16_t* packed_fwd, uint16_t* packed_bwd, void* stream);

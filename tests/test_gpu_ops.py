@@ -1655,6 +1655,49 @@ def test_iaf_update_backward_of_the_broadcast_row_pass(ops, n, d, with_ld):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('m,d', [(300, 200), (65, 8), (4099, 24)])
+def test_made_chain_half_width_input_and_the_update_backward_that_writes_it(ops, m, d):
+    """gv_chain_layer.x_dup_half (the chain stages the g_mu half of [g_mu | g_alpha] twice) against the full-width input, and
+    gv_iaf_update_bwd_bf16_ex's flags: bit 1 writes the g_mu half alone (valid without a log-det gradient: g_alpha == g_mu),
+    bit 0 starts g_z instead of adding to it."""
+    from gcn_vae_amd import lib
+    from gcn_vae_amd.lib import ptr
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(m + d)
+    z, ex, gx, gz0 = (torch.randn(n_, d, generator=g).to(dev) for n_ in (m, m, m, m))
+    ex = ex.exp()
+    cc = torch.randint(0, 3, (d,), generator=g).to(torch.int32).to(dev)
+    mp = (m + 7) // 8 * 8
+    bf = dict(dtype=torch.bfloat16, device=dev)
+    out = {}
+    for flags in (0, 1, 2, 3):
+        gz = gz0.clone()
+        gb, gt = torch.zeros(m, 2 * d, **bf), torch.zeros(2 * d, mp, **bf)
+        lib.call('gv_iaf_update_bwd_bf16_ex', ptr(z), ptr(ex), d, ptr(cc), ptr(gx), None, ptr(gz), ptr(gb), gb.stride(0), ptr(gt),
+                 gt.stride(0), None, flags, m, d, lib.stream())
+        out[flags] = (gz, gb, gt)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0][1][:, :d].view(torch.int16), out[0][1][:, d:].view(torch.int16)) or bool((out[0][1][:, :d].float() == out[0][1][:, d:].float()).all())
+    for flags in (1, 2, 3):
+        assert torch.equal(out[flags][2].view(torch.int16), out[0][2].view(torch.int16))                 # the transposed copy is always whole
+        assert torch.equal(out[flags][1][:, :d].view(torch.int16), out[0][1][:, :d].view(torch.int16))
+    assert bool((out[2][1][:, d:] == 0).all()) and bool((out[3][1][:, d:] == 0).all())                 # alpha half untouched
+    assert torch.equal(out[0][0], out[2][0]) and torch.equal(out[1][0], out[3][0])
+    assert torch.equal(out[0][0], gz0 + out[1][0])                                                       # written, not added
+    # the chain on the half-width input == the chain on [g_mu | g_mu]
+    widths = [2 * d, d, d]
+    ws = [(torch.randn(widths[i + 1], widths[i], generator=g) / widths[i] ** 0.5).to(dev) for i in range(2)]
+    packed = [ops.made_pack_weight(w, bwd=False)[0] for w in ws]
+    full = torch.cat([out[2][1][:, :d], out[2][1][:, :d]], dim=1).contiguous()
+    res = []
+    for x, dup in ((full, False), (out[2][1], True)):
+        o = torch.empty(m, d, device=dev)
+        ops.made_chain(x, m, [dict(w_packed=packed[0], n=d, k=2 * d, relu=True, x_dup_half=dup), dict(w_packed=packed[1], n=d, k=d, out_f32=o)])
+        res.append(o)
+    assert torch.equal(res[0], res[1])
+
+
+@pytest.mark.gpu
 def test_made_pack_weight_transposed_form_equals_packing_the_transpose(ops):
     dev = torch.device('cuda:0')
     w = torch.randn(136, 72, device=dev)
