@@ -3200,7 +3200,7 @@ class _MADEForwardBF16(torch.autograd.Function):
         gb_target = [(row_gb[l] if ctx.row else None) if wants_gb[l] else None for l in range(L)]
         fused_gb = [S > 0 and ctx.row and gb_target[l] is not None and ctx.needs_input_grad[3 + l] and row_gw[l] is not None
                     and row_gw[l].stride(0) == ws[l].shape[1]
-                    and gemm_bf16_gradw_fits(widths[l], ws[l].shape[1], mtot, max(2, min(256, mtot // 512))) for l in range(L)]
+                    and gemm_bf16_gradw_fits(widths[l], ws[l].shape[1], mtot, max(2, min(GRADW_SPLIT_MAX, mtot // 512))) for l in range(L)]
         for l in range(L):
             mask0 = acts0[l] if l < L - 1 else None
             inp0 = zero_row if l == 0 else acts0[l - 1]
@@ -3209,7 +3209,7 @@ class _MADEForwardBF16(torch.autograd.Function):
                 gw = row_gw[l] if ctx.row else gemm(rows0[l], inp0, trans_a=True, a_relu_mask=mask0, precision='bf16')
                 if S > 0:       # dW_l = g_l^T a_{l-1}: the NT kernel on the transposed copies, reduction over all stacked rows
                     in_t = xin_t if l == 0 else acts_t[l - 1]
-                    split = max(2, min(256, mtot // 512))
+                    split = max(2, min(GRADW_SPLIT_MAX, mtot // 512))
                     if fused_gb[l]:      # ... and the stacked passes' share of the bias gradient from the same pass over g_l^T
                         gemm_bf16_gradw(gm_t[l], in_t, widths[l], ws[l].shape[1], mtot, gw, accumulate=True,
                                         a_rowsum=gb_target[l], split_k=split)
@@ -3249,6 +3249,7 @@ class _MADEForwardBF16(torch.autograd.Function):
 
 
 MADE_BF16_STORAGE = _os.environ.get('GV_MADE_BF16', '1') == '1'
+GRADW_SPLIT_MAX = int(_os.environ.get('GV_GRADW_SPLIT_MAX', '256'))      # most K slices of a MADE weight-gradient product
 MADE_CHAIN_IAF = _os.environ.get('GV_MADE_CHAIN_IAF', '1') == '1'      # the IAF update inside the chain's last layer
 
 
