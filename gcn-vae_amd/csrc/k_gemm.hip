@@ -30,6 +30,7 @@ struct GemmParams {
     int m, n, k, lda, ldb, ldc;
     int act, accumulate, split_k, k_chunk;
     int vec_a, vec_b;
+    const int* rows_dev;   // optional device scalar: only the first *rows_dev rows of the stored A exist (padding of a static-shape batch)
 };
 
 // guarded load of VPT consecutive floats (VPT % 4 == 0) along the contiguous dimension; `lim` bounds that
@@ -146,10 +147,25 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmParams p) {
     }
     const int m0 = mt_i * BM, n0 = nt_i * BN;
     const int kbeg = blockIdx.z * p.k_chunk;
-    const int kend = min(p.k, kbeg + p.k_chunk);
+    int kend = min(p.k, kbeg + p.k_chunk);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int wm = (wid >> 1) * 32 * MT, wn = (wid & 1) * 32 * NT;
     const int l31 = lane & 31, lhi = lane >> 5;
+    if (p.rows_dev) {
+        // a static-shape batch pads its node arrays: rows [*rows_dev, ...) of the stored A are padding.  A row-major A: a tile that
+        // holds only padding rows is not computed -- zeros are stored (nothing when accumulating); A stored [K, M]: K ends there
+        const int live = *p.rows_dev;
+        if constexpr (TA) {
+            kend = max(kbeg, min(kend, live));
+        } else if (m0 >= live && p.split_k == 1) {
+            if (!p.accumulate)
+                for (int i = threadIdx.x; i < BM * BN; i += 256) {
+                    const int row = m0 + i / BN, col = n0 + i % BN;
+                    if (row < p.m && col < p.n) p.c[(size_t)row * p.ldc + col] = 0.f;
+                }
+            return;
+        }
+    }
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -619,7 +635,7 @@ extern "C" int64_t gv_gemm_workspace_bytes(int m, int n, int k, int split_k) {
 
 static int gemm_any(bool bf16, int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b,
                     int ldb, float* c, int ldc, const float* bias, int act, int accumulate, int split_k,
-                    const float* a_relu_mask, void* workspace, int64_t workspace_bytes, void* stream) {
+                    const float* a_relu_mask, void* workspace, int64_t workspace_bytes, void* stream, const int32_t* rows_dev = nullptr) {
     GV_REQUIRE(m >= 0 && n >= 0 && k >= 0, GV_ERR_SHAPE, "gv_gemm_f32: negative size");
     if (m == 0 || n == 0) return GV_OK;
     GV_REQUIRE(a && b && c, GV_ERR_NULL, "gv_gemm_f32: NULL matrix");
@@ -637,6 +653,7 @@ static int gemm_any(bool bf16, int trans_a, int trans_b, int m, int n, int k, co
     p.split_k = split_k;
     p.vec_a = aligned16(a) && (lda % 4 == 0) && (!a_relu_mask || aligned16(a_relu_mask));
     p.vec_b = aligned16(b) && (ldb % 4 == 0);
+    p.rows_dev = bf16 ? nullptr : rows_dev;
     if (split_k > 1) {
         GV_REQUIRE(workspace, GV_ERR_NULL, "gv_gemm_f32: split_k needs a workspace");
         GV_REQUIRE(workspace_bytes >= gv_gemm_workspace_bytes(m, n, k, split_k), GV_ERR_WORKSPACE,
@@ -704,6 +721,14 @@ extern "C" int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const 
                     workspace, workspace_bytes, stream);
 }
 
+extern "C" int gv_gemm_f32_live_rows(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b,
+                                     int ldb, float* c, int ldc, const float* bias, int act, int accumulate, int split_k,
+                                     const float* a_relu_mask, void* workspace, int64_t workspace_bytes, const int32_t* rows_dev,
+                                     void* stream) {
+    return gemm_any(false, trans_a, trans_b, m, n, k, a, lda, b, ldb, c, ldc, bias, act, accumulate, split_k, a_relu_mask,
+                    workspace, workspace_bytes, stream, rows_dev);
+}
+
 extern "C" int gv_gemm_bf16(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b,
                             int ldb, float* c, int ldc, const float* bias, int act, int accumulate, int split_k,
                             const float* a_relu_mask, void* workspace, int64_t workspace_bytes, void* stream) {
@@ -724,6 +749,7 @@ extern "C" int gv_rank_scores(const float* q, int ld_q, const float* e, int ld_e
     p.act = GV_ACT_NONE; p.accumulate = 0; p.split_k = 1; p.k_chunk = h;
     p.vec_a = aligned16(q) && (ld_q % 4 == 0);
     p.vec_b = aligned16(e) && (ld_e % 4 == 0);
+    p.rows_dev = nullptr;
     rp.target = target; rp.bias = bias; rp.tgt = tgt; rp.count = count;
     hipStream_t st = (hipStream_t)stream;
     if (fill_words(count, 0u, (size_t)m * sizeof(int), st) != hipSuccess) return launch_status("gv_rank_scores(fill)");

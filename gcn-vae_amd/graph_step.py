@@ -16,6 +16,7 @@ removes the host from the loop.  tests/test_gpu_model.py holds the replayed step
 """
 import torch
 
+from . import ops
 from .optim import FlatAdam
 
 
@@ -54,9 +55,10 @@ class GraphedMiniBatchStep:
             enc.fuse_kl_with_reparam = False               # the KL pass needs the device row count: it stays in the loss head here
         try:
             self.opt.zero_grad()
-            embed = m(b.g, b.node_id, b.edge_type, b.edge_norm)
-            loss, pred, kl, mmd = m.get_loss(b.g, embed, b.samples, b.labels)
-            loss.backward(gradient=self.one.expand_as(loss))
+            with ops.live_rows(b.rows_dev, b.node_id.shape[0]):      # the dense products skip the padding rows
+                embed = m(b.g, b.node_id, b.edge_type, b.edge_norm)
+                loss, pred, kl, mmd = m.get_loss(b.g, embed, b.samples, b.labels)
+                loss.backward(gradient=self.one.expand_as(loss))
             self.opt.step()
         finally:
             m.rows_dev = saved[0]

@@ -353,6 +353,12 @@ int64_t gv_gemm_workspace_bytes(int m, int n, int k, int split_k);
 int gv_gemm_f32(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b, int ldb,
                 float* c, int ldc, const float* bias, int act, int accumulate, int split_k, const float* a_relu_mask,
                 void* workspace, int64_t workspace_bytes, void* stream);
+/* ... for a STATIC-SHAPE batch whose node arrays are padded: only the first *rows_dev (device int32) rows of the stored A exist.
+ * Row-major A (trans_a == 0): 64-row tiles of padding rows are not computed, their C rows receive ZEROS (nothing when
+ * accumulating); A stored [K, M] (trans_a != 0): the reduction ends at row *rows_dev.  The padding rows of A must be finite. */
+int gv_gemm_f32_live_rows(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b, int ldb, float* c,
+                          int ldc, const float* bias, int act, int accumulate, int split_k, const float* a_relu_mask, void* workspace,
+                          int64_t workspace_bytes, const int32_t* rows_dev, void* stream);
 /* The same product with bf16 OPERANDS and fp32 accumulation (BASELINE configs[2]: "bf16"): A and B are fp32 in memory,
  * rounded to bf16 (round-to-nearest-even) as they are staged, multiplied on v_mfma_f32_32x32x16_bf16; bias, act,
  * accumulate, split-K and the result stay fp32.  Equals an fp32 GEMM of the rounded operands up to summation order. */

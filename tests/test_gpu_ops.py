@@ -1698,6 +1698,36 @@ def test_made_chain_half_width_input_and_the_update_backward_that_writes_it(ops,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('cap,live,n,k', [(1000, 700, 200, 200), (14541, 10211, 400, 200), (300, 300, 72, 40), (257, 0, 64, 64)])
+def test_gemm_skips_the_padding_rows_of_a_static_shape_batch(ops, cap, live, n, k):
+    """gv_gemm_f32_live_rows through ops.live_rows: rows of a row-major A behind *rows_dev are padding -- whole 64-row tiles of them
+    come out as zeros without being computed, every row before them as from the plain product (bit for bit); for A stored [K, M]
+    (the weight-gradient form) the reduction stops at *rows_dev."""
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(cap + live)
+    a = torch.randn(cap, k, generator=g).to(dev)
+    b = torch.randn(k, n, generator=g).to(dev)
+    bias = torch.randn(n, generator=g).to(dev)
+    rows = torch.tensor([live], dtype=torch.int32, device=dev)
+    plain = ops.gemm(a, b, bias=bias, act=ops.ACT_RELU)
+    with ops.live_rows(rows, cap):
+        got = ops.gemm(a, b, bias=bias, act=ops.ACT_RELU)
+        other = ops.gemm(a[:cap - 1], b, bias=bias)                    # another row count: not a node array, untouched
+    first_skipped = (live + 63) // 64 * 64
+    assert torch.equal(got[:first_skipped], plain[:first_skipped])
+    assert bool((got[first_skipped:] == 0).all())
+    assert torch.equal(other, ops.gemm(a[:cap - 1], b, bias=bias))
+    # weight-gradient form: x^T g over the rows that exist
+    gr = torch.randn(cap, n, generator=g).to(dev)
+    for split in (1, ops.pick_split_k(k, n, cap)):
+        want = ops.gemm(a[:live].contiguous(), gr[:live].contiguous(), trans_a=True, split_k=max(1, split)) if live else torch.zeros(k, n, device=dev)
+        with ops.live_rows(rows, cap):
+            got_w = ops.gemm(a, gr, trans_a=True, split_k=max(1, split))
+        close(got_w, want, rtol=1e-5, atol_scale=1e-6, msg=f'x^T g, split_k={split}')
+    assert ops.LIVE_ROWS is None
+
+
+@pytest.mark.gpu
 def test_made_pack_weight_transposed_form_equals_packing_the_transpose(ops):
     dev = torch.device('cuda:0')
     w = torch.randn(136, 72, device=dev)
