@@ -281,25 +281,28 @@ __global__ __launch_bounds__(1024) void k_items_blocks(const int* rowptr, int n_
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int base = blockIdx.x * RS_T;
     Tri before{0, 0, 0}, total{0, 0, 0};
-    for (int s0 = 0; s0 < n_seg; s0 += 8 * RS_T) {      // eight independent pairs of loads in flight
-        int lo[8], hi[8];
+    const int s = base + t;
+    int beg = 0, end = 0;
+    // sixteen independent pairs of loads in flight: up to 16 384 segments (a sampled batch's padded node rows) in ONE round trip -- the
+    // row pointers were written by another launch on other XCDs and come from memory; this thread's own segment is among them
+    for (int s0 = 0; s0 < n_seg; s0 += 16 * RS_T) {
+        int lo[16], hi[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int s = s0 + k * RS_T + t;
-            lo[k] = s < n_seg ? rowptr[s] : 0;
-            hi[k] = s < n_seg ? rowptr[s + 1] : 0;
+        for (int k = 0; k < 16; ++k) {
+            const int q = s0 + k * RS_T + t;
+            lo[k] = q < n_seg ? rowptr[q] : 0;
+            hi[k] = q < n_seg ? rowptr[q + 1] : 0;
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int s = s0 + k * RS_T + t;
-            if (s >= n_seg) continue;
+        for (int k = 0; k < 16; ++k) {
+            const int q = s0 + k * RS_T + t;
+            if (q >= n_seg) continue;
             const Tri c = item_count(hi[k] - lo[k], chunk, chunk_shift);
             total = total + c;
-            if (s < base) before = before + c;
+            if (q < base) before = before + c;
+            if (q == s) { beg = lo[k]; end = hi[k]; }
         }
     }
-    const int s = base + t;
-    const int beg = s < n_seg ? rowptr[s] : 0, end = s < n_seg ? rowptr[s + 1] : 0;
     const Tri mine = s < n_seg ? item_count(end - beg, chunk, chunk_shift) : Tri{0, 0, 0};
     Tri inc = mine;
     for (int o = 1; o < 64; o <<= 1) {
