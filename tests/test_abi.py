@@ -105,3 +105,24 @@ def test_work_item_size_follows_the_edge_list(monkeypatch):
     assert all(c & (c - 1) == 0 and 16 <= c <= 256 for c in cs) and cs == sorted(cs)
     monkeypatch.setenv('GV_CHUNK', '48')
     assert ops.chunk_for(10) == 48 and ops.chunk_for(10_000_000) == 48
+
+
+def test_round3_entry_points_validate_their_arguments_on_the_host():
+    """The entry points added in round 3 report bad arguments through the return code (nothing is launched: runs without a GPU)."""
+    from gcn_vae_amd import lib, ops
+    l = lib.load()
+    assert l.gv_gather3_i32(None, 5, None, None, None, None, None, None, None) != 0 and 'NULL' in lib.last_error()
+    assert l.gv_gather3_i32(None, 0, None, None, None, None, None, None, None) == 0                      # nothing to do
+    assert l.gv_iaf_update_bwd_row0(None, None, None, None, None, None, None, None, 10, 202, None) != 0    # d % 4 != 0
+    assert l.gv_iaf_update_bwd_row0(None, None, None, None, None, None, None, None, 10, 200, None) != 0 and 'NULL' in lib.last_error()
+    assert l.gv_iaf_update_bwd_row0_workspace_floats(200) == 1024 * 400
+    assert l.gv_iaf_update_bwd_bf16_ex(None, None, 200, None, None, None, None, None, 400, None, 16, None, 0, 0, 200, None) == 0   # n == 0
+    assert l.gv_iaf_update_bwd_bf16_ex(None, None, 200, None, None, None, None, None, 400, None, 16, None, 0, 8, 200, None) != 0
+    assert l.gv_made_pack_weight_iaf(None, 200, 400, 200, None, None) != 0
+    assert l.gv_made_pack_weight_iaf(None, 200, 404, 200, None, None) != 0 and 'n=' in lib.last_error()    # n = 2 d, d % 8 == 0
+    plan = (ctypes.c_int32 * 3)()
+    assert l.gv_rgcn_bdd_lds_plan(20, 10, 10, 22, 0, ctypes.addressof(plan)) in (0, 1)
+    # a chain layer that asks for mask bits together with a tile mask is refused before any launch
+    layers = (ops._ChainLayer * 1)()
+    layers[0].n, layers[0].k = 200, 200
+    assert l.gv_made_chain(None, 200, 64, 1, ctypes.addressof(layers), None) != 0
