@@ -57,16 +57,20 @@ DEFAULT_CHUNK = 256        # max edges per work item of the dst/src-sorted aggre
 DEFAULT_CHUNK_REL = 128    # max edges per work item of the by-relation weight gradient
 
 
+CHUNK_DIV = int(_os.environ.get('GV_CHUNK_DIV', '4096'))
+
+
 def chunk_for(n_entries: int, most: int = DEFAULT_CHUNK) -> int:
     """Edges per work item for a list of ``n_entries``.  One wave walks an item's edges in order (four in flight), so on a SMALL
     graph the longest item, not the edge count, sets a launch's duration: a sampled batch of 20 000 edges whose hub rows were
-    cut into 256-edge items spent 40-80 us per aggregation on 64 serial steps of one wave.  Items shrink with the list (a power of
-    two, n / 2048 rounded down, between 16 and ``most``): full-size graphs (>= 0.5 M entries) keep 256."""
+    cut into 256-edge items spent 40-80 us per aggregation on 64 serial steps of one wave.  Items shrink with the list: a power of
+    two, n / 4096 rounded down, between 16 and ``most`` (measured over n / 2048, 4096, 8192: FB15k-237-sized graphs -- 0.54 M
+    edges -- run best on 128-edge items: 1.049 vs 1.058 ms at h = 200, 3.46 vs 3.56 ms at h = 500; lists of >= 1 M entries keep 256)."""
     env = _os.environ.get('GV_CHUNK')
     if env:
         return max(1, int(env))
     c = 16
-    while c * 2 <= most and c * 2 * 2048 <= int(n_entries):
+    while c * 2 <= most and c * 2 * CHUNK_DIV <= int(n_entries):
         c *= 2
     return c
 DIST_FWD_CHUNKS = 2        # destination-row blocks whose all-reduce overlaps the next block's aggregation

@@ -93,13 +93,13 @@ def test_header_is_plain_c_and_struct_layouts_match_the_ctypes_mirrors(tmp_path)
 
 
 def test_work_item_size_follows_the_edge_list(monkeypatch):
-    """ops.chunk_for: items of 16 edges for a sampled batch, 256 for the full-size graphs (the tuned value), powers of two between;
+    """ops.chunk_for: items of 16 edges for a sampled batch, 128 at FB15k-237 size, 256 from a million entries on, powers of two between;
     the by-relation lists are capped at their own default; GV_CHUNK overrides."""
     from gcn_vae_amd import ops
     monkeypatch.delenv('GV_CHUNK', raising=False)
-    assert ops.chunk_for(0) == 16 and ops.chunk_for(20000) == 16 and ops.chunk_for(65536) == 32
-    assert ops.chunk_for(173670) == 64 and ops.chunk_for(440000) == 128
-    assert ops.chunk_for(544230) == 256 and ops.chunk_for(50_000_000) == 256
+    assert ops.chunk_for(0) == 16 and ops.chunk_for(20000) == 16 and ops.chunk_for(131072) == 32
+    assert ops.chunk_for(173670) == 32 and ops.chunk_for(440000) == 64
+    assert ops.chunk_for(544230) == 128 and ops.chunk_for(1_048_576) == 256 and ops.chunk_for(50_000_000) == 256
     assert ops.chunk_for(50_000_000, ops.DEFAULT_CHUNK_REL) == 128 and ops.chunk_for(20000, ops.DEFAULT_CHUNK_REL) == 16
     cs = [ops.chunk_for(n) for n in range(0, 2_000_000, 4099)]
     assert all(c & (c - 1) == 0 and 16 <= c <= 256 for c in cs) and cs == sorted(cs)
