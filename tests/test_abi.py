@@ -101,6 +101,7 @@ def test_work_item_size_follows_the_edge_list(monkeypatch):
     assert ops.chunk_for(173670) == 32 and ops.chunk_for(440000) == 64
     assert ops.chunk_for(544230) == 128 and ops.chunk_for(1_048_576) == 256 and ops.chunk_for(50_000_000) == 256
     assert ops.chunk_for(50_000_000, ops.DEFAULT_CHUNK_REL) == 128 and ops.chunk_for(20000, ops.DEFAULT_CHUNK_REL) == 16
+    assert ops.chunk_for(173670, ops.DEFAULT_CHUNK_REL) == 128 and ops.chunk_for(544230, ops.DEFAULT_CHUNK_REL) == 128
     cs = [ops.chunk_for(n) for n in range(0, 2_000_000, 4099)]
     assert all(c & (c - 1) == 0 and 16 <= c <= 256 for c in cs) and cs == sorted(cs)
     monkeypatch.setenv('GV_CHUNK', '48')
