@@ -278,7 +278,7 @@ __device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const g
                 *reinterpret_cast<uint2*>(An + row * ldk + c0) =
                     cv ? make_uint2(b0 | ((uint32_t)b1 << 16), b2 | ((uint32_t)b3 << 16)) : make_uint2(0, 0);
             if (Ly.out_bf16_t && cv && m0 + row < m) {
-                uint16_t* o = Ly.out_bf16_t + (size_t)c0 * Ly.ldt + m0 + row;
+                uint16_t* o = Ly.out_bf16_t + (size_t)c0 * Ly.ldt + (Ly.t_tile ? (int)blockIdx.x * Ly.t_tile : m0) + row;
                 o[0] = b0;
                 o[Ly.ldt] = b1;
                 o[2 * (size_t)Ly.ldt] = b2;
@@ -371,7 +371,7 @@ __device__ __forceinline__ void chain_epilogue_iaf(const f32x16_t (&acc)[2], con
                 *reinterpret_cast<uint2*>(An + row * ldk + c0) =
                     cv ? make_uint2(b0 | ((uint32_t)b1 << 16), b2 | ((uint32_t)b3 << 16)) : make_uint2(0, 0);
             if (Ly.out_bf16_t && live && !(dbg & 4)) {
-                uint16_t* o = Ly.out_bf16_t + (size_t)c0 * Ly.ldt + m0 + row;
+                uint16_t* o = Ly.out_bf16_t + (size_t)c0 * Ly.ldt + (Ly.t_tile ? (int)blockIdx.x * Ly.t_tile : m0) + row;
                 o[0] = b0;
                 o[Ly.ldt] = b1;
                 o[2 * (size_t)Ly.ldt] = b2;
@@ -738,7 +738,8 @@ extern "C" int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, co
         }
         GV_REQUIRE((!L.mask || (L.ldmask >= L.n && L.ldmask % 8 == 0 && aligned16(L.mask))) &&
                    (!L.out_bf16 || (L.ldb >= (L.iaf_z ? L.n / 2 : L.n) && L.ldb % 8 == 0 && aligned16(L.out_bf16))) &&
-                   (!L.out_bf16_t || L.ldt >= m) &&
+                   (!L.out_bf16_t || (L.t_tile == 0 ? L.ldt >= m : (L.ldt == CH_BM && L.t_tile >= CH_BM * (L.iaf_z ? L.n / 2 : L.n) &&
+                                                                      (int64_t)L.t_tile * ((m + CH_BM - 1) / CH_BM) <= INT32_MAX))) &&
                    (!L.out_f32 || (L.ldc >= L.n && L.ldc % 4 == 0 && aligned16(L.out_f32))), GV_ERR_ALIGN, "gv_made_chain: layer %d: leading dimension / alignment", i);
         p.L[i] = L;
     }

@@ -42,6 +42,8 @@ struct BfGemm {
     int k_per_split;
     float* rowsum_partial;    // whole-output kernel only: sums of A's rows over the block's K slice (split z at z * partial_stride), or NULL
     size_t partial_stride;    // floats between two splits' partial results
+    unsigned a_tile, b_tile;  // whole-output kernel, TILES instance: the operands are given in 64-deep K TILES, element (row, kk) at
+                              // [kk / 64][row][kk % 64] with `tile` elements between tiles (lda / ldb unused)
 };
 
 __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
@@ -203,15 +205,21 @@ constexpr size_t TK_LDS_BYTES = (size_t)2 * TK_T * TK_LDK * sizeof(uint16_t);
 
 // an UNCONDITIONAL load from a clamped (always valid) address; the piece is zeroed where it lies outside the operand only when it
 // is written to LDS (tk_keep), a chunk later: a load under a condition, or a select right behind it, makes the compiler wait for
-// the data on the spot instead of leaving it in flight during the MFMAs
-__device__ __forceinline__ uint4 tk_load(const uint16_t* base, int ld, int rows, int row0, int idx, int k0, int k_end, int k_safe) {
-    const int row = idx / TK_PPR, kk = (idx % TK_PPR) << 3;
-    return *reinterpret_cast<const uint4*>(base + (size_t)min(row0 + row, rows - 1) * ld + (k0 + kk < k_end ? k0 + kk : k_safe));
+// the data on the spot instead of leaving it in flight during the MFMAs.
+// TILES: the operand in 64-deep K tiles ([kk / 64][row][64], `tile` elements apart; 32-bit element offsets, checked on the host):
+// the 128-deep chunk of a workgroup is then two contiguous blocks of 128 B x rows instead of a 256-B piece out of each of `rows`
+// rows that lie k elements apart (WN18RR: 400 pieces 409 KB apart per chunk -- 80.6 -> 52.4 us per product).
+template <bool TILES>
+__device__ __forceinline__ uint4 tk_load(const uint16_t* base, int ld, unsigned tile, int rows, int row0, int idx, int k0, int k_end, int k_safe) {
+    const int row = min(row0 + idx / TK_PPR, rows - 1), kk = (idx % TK_PPR) << 3, kc = k0 + kk < k_end ? k0 + kk : k_safe;
+    if constexpr (TILES) return *reinterpret_cast<const uint4*>(base + ((unsigned)(kc >> 6) * tile + (unsigned)((row << 6) + (kc & 63))));
+    else return *reinterpret_cast<const uint4*>(base + (size_t)row * ld + kc);
 }
 __device__ __forceinline__ bool tk_keep(int rows, int row0, int idx, int k0, int k_end) {
     return row0 + idx / TK_PPR < rows && k0 + ((idx % TK_PPR) << 3) < k_end;
 }
 
+template <bool TILES>
 __global__ __launch_bounds__(TK_THREADS) void k_gemm_bf16_tallk(const BfGemm p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t tk_lds[];
     uint16_t* const As = tk_lds;
@@ -233,8 +241,8 @@ __global__ __launch_bounds__(TK_THREADS) void k_gemm_bf16_tallk(const BfGemm p) 
     uint4 va[TK_PPT], vb[TK_PPT];
 #pragma unroll
     for (int j = 0; j < TK_PPT; ++j) {
-        va[j] = tk_load(a, p.lda, p.m, m0, threadIdx.x + j * TK_THREADS, k_begin, k_end, k_begin);
-        vb[j] = tk_load(p.b, p.ldb, p.n, n0, threadIdx.x + j * TK_THREADS, k_begin, k_end, k_begin);
+        va[j] = tk_load<TILES>(a, p.lda, p.a_tile, p.m, m0, threadIdx.x + j * TK_THREADS, k_begin, k_end, k_begin);
+        vb[j] = tk_load<TILES>(p.b, p.ldb, p.b_tile, p.n, n0, threadIdx.x + j * TK_THREADS, k_begin, k_end, k_begin);
     }
     for (int k0 = k_begin; k0 < k_end; k0 += TK_KC) {
 #pragma unroll
@@ -262,12 +270,15 @@ __global__ __launch_bounds__(TK_THREADS) void k_gemm_bf16_tallk(const BfGemm p) 
                 }
             }
         }
-        // the next chunk's loads fly while this one's MFMAs run (unconditional: past the slice's end they re-read its first
-        // columns and are never used)
+        // the next chunk's loads fly while this one's MFMAs run (every lane loads, from clamped addresses; the only condition is
+        // the workgroup-uniform "there is a next chunk": without it the last chunk re-read the slice's first one -- 1/7 more
+        // traffic at WN18RR size; the [row][k] instance keeps the unconditional form, the branch costs it its last free registers)
+        if (!TILES || k0 + TK_KC < k_end) {
 #pragma unroll
-        for (int j = 0; j < TK_PPT; ++j) {
-            va[j] = tk_load(a, p.lda, p.m, m0, threadIdx.x + j * TK_THREADS, k0 + TK_KC, k_end, k_begin);
-            vb[j] = tk_load(p.b, p.ldb, p.n, n0, threadIdx.x + j * TK_THREADS, k0 + TK_KC, k_end, k_begin);
+            for (int j = 0; j < TK_PPT; ++j) {
+                va[j] = tk_load<TILES>(a, p.lda, p.a_tile, p.m, m0, threadIdx.x + j * TK_THREADS, k0 + TK_KC, k_end, k_begin);
+                vb[j] = tk_load<TILES>(p.b, p.ldb, p.b_tile, p.n, n0, threadIdx.x + j * TK_THREADS, k0 + TK_KC, k_end, k_begin);
+            }
         }
 #pragma unroll
         for (int kk = 0; kk < TK_KC; kk += 16) {
@@ -415,11 +426,14 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16(const float* __restrict__ 
 // The same two updates with FOUR columns per thread (d % 4 == 0, 16-B aligned rows): 16-B loads and stores of the fp32 operands,
 // 8-B stores of the bf16 row-major copies, and the transposed copies leave the LDS tile as four consecutive rows of a column
 // per 8-B store (16 lanes = 128 contiguous bytes).  Same arithmetic, element by element, as the scalar kernels above.
-__device__ __forceinline__ void iaf_tile_out(const uint16_t (*t)[68], uint16_t* dst_t, int ldt, int r0, int c0, int rows, int d) {
+// t_tile > 0: the destination in tiles of 64 rows ([row tile][column][64], t_tile elements apart: what gv_gemm_bf16_gradw_tiles reads)
+__device__ __forceinline__ void iaf_tile_out(const uint16_t (*t)[68], uint16_t* dst_t, int ldt, int t_tile, int r0, int c0, int rows, int d) {
+    const size_t roff = t_tile > 0 ? (size_t)blockIdx.y * t_tile : (size_t)r0;
+    if (t_tile > 0) ldt = 64;
     for (int i = threadIdx.x; i < 64 * 16; i += 256) {
         const int cc = i >> 4, rq = (i & 15) << 2;
         if (c0 + cc >= d || r0 + rq >= rows) continue;
-        uint16_t* o = dst_t + (size_t)(c0 + cc) * ldt + r0 + rq;
+        uint16_t* o = dst_t + (size_t)(c0 + cc) * ldt + roff + rq;
         const uint2 v = *reinterpret_cast<const uint2*>(&t[cc][rq]);
         if (r0 + rq + 3 < rows) {
             *reinterpret_cast<uint2*>(o) = v;
@@ -434,7 +448,7 @@ __device__ __forceinline__ void iaf_tile_out(const uint16_t (*t)[68], uint16_t* 
 __global__ __launch_bounds__(256) void k_iaf_fwd_bf16_v4(const float* __restrict__ z, const float* __restrict__ net, int ld_net,
                                                          const float* __restrict__ xold, const int* __restrict__ colcount,
                                                          float* __restrict__ xnew, uint16_t* xb, int ldb, uint16_t* xt, int ldt,
-                                                         int rows, int d) {
+                                                         int rows, int d, int t_tile) {
     __shared__ __attribute__((aligned(8))) uint16_t t[64][68];          // [column][row]
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int cq = (threadIdx.x & 15) << 2, c = c0 + cq;
@@ -465,7 +479,7 @@ __global__ __launch_bounds__(256) void k_iaf_fwd_bf16_v4(const float* __restrict
         for (int e = 0; e < 4; ++e) t[cq + e][rr] = b[e];
     }
     __syncthreads();
-    iaf_tile_out(t, xt, ldt, r0, c0, rows, d);
+    iaf_tile_out(t, xt, ldt, t_tile, r0, c0, rows, d);
 }
 
 template <bool EX>
@@ -474,6 +488,7 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16_v4(const float* __restrict
                                                          const float* __restrict__ gld, float* __restrict__ gz_acc,
                                                          uint16_t* gnb, int ldb, uint16_t* gnt, int ldt, float* __restrict__ gxold,
                                                          int rows, int d, int gz_overwrite) {
+    const int t_tile = (gz_overwrite & 4) ? ldt : 0;
     __shared__ __attribute__((aligned(8))) uint16_t tm[64][68];
     __shared__ __attribute__((aligned(8))) uint16_t ta[64][68];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -534,8 +549,8 @@ __global__ __launch_bounds__(256) void k_iaf_bwd_bf16_v4(const float* __restrict
         }
     }
     __syncthreads();
-    iaf_tile_out(tm, gnt, ldt, r0, c0, rows, d);
-    iaf_tile_out(ta, gnt + (size_t)d * ldt, ldt, r0, c0, rows, d);
+    iaf_tile_out(tm, gnt, ldt, t_tile, r0, c0, rows, d);
+    iaf_tile_out(ta, gnt + (size_t)d * (t_tile > 0 ? 64 : ldt), ldt, t_tile, r0, c0, rows, d);
 }
 
 // Sums over bf16 rows (bias gradients from the transposed gradient copies): stage 1, one wave per (row, 4096-column chunk),
@@ -601,25 +616,46 @@ __global__ __launch_bounds__(256) void k_rowsum_finish_seg(const float* __restri
     out[r] = accumulate ? out[r] + s : s;
 }
 
-// out[i] (+)= sum_z partial[z][i], z in order
+// out[i] (+)= sum_z partial[z][i]: a workgroup owns 64 consecutive outputs, its waves consecutive ranges of the splits (each summed
+// in order, eight partials in flight), the waves' sums added in wave order -- the same bits on every run.  (One thread per output
+// walking all ~230 splits of a MADE weight gradient was 29 dependent memory round trips on 157 workgroups: 15.5 us.)
 // (a split's partial is `stride` floats: mn of the product, then -- out2 != NULL -- m2 row sums that go to out2, always added)
-__global__ __launch_bounds__(256) void k_splitk_sum(const float* __restrict__ partial, int splits, size_t mn, size_t stride, float* out,
-                                                    int accumulate, size_t m2, float* out2) {
+__global__ __launch_bounds__(1024) void k_splitk_sum(const float* __restrict__ partial, int splits, size_t mn, size_t stride, float* out,
+                                                     int accumulate, size_t m2, float* out2) {
+    __shared__ float share[16][64];
     const size_t total = mn + (out2 ? m2 : 0);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        float s = 0.f;
-        int z = 0;
-        for (; z + 8 <= splits; z += 8) {          // eight partials in flight, added in order
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int per = (splits + nw - 1) / nw, z0 = w * per, z1 = min(splits, z0 + per);
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (i < total) {
+        int z = z0;
+        for (; z + 8 <= z1; z += 8) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = partial[(size_t)(z + j) * stride + i];
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += v[j];
         }
-        for (; z < splits; ++z) s += partial[(size_t)z * stride + i];
-        if (i < mn) out[i] = accumulate ? out[i] + s : s;
-        else out2[i - mn] += s;
+        for (; z < z1; ++z) s += partial[(size_t)z * stride + i];
     }
+    if (nw > 1) {
+        share[w][lane] = s;
+        __syncthreads();
+        if (w != 0) return;
+        for (int j = 1; j < nw; ++j) s += share[j][lane];
+    }
+    if (i >= total) return;
+    if (i < mn) out[i] = accumulate ? out[i] + s : s;
+    else out2[i - mn] += s;
+}
+
+static void launch_splitk_sum(hipStream_t st, const float* partial, int splits, size_t mn, size_t stride, float* out, int accumulate,
+                              size_t m2, float* out2) {
+    const size_t total = mn + (out2 ? m2 : 0);
+    const int nw = splits >= 64 ? 16 : splits >= 16 ? 4 : 1;      // ~>= 4 partials per wave
+    hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)((total + 63) / 64)), dim3(64 * nw), 0, st, partial, splits, mn, stride, out, accumulate,
+                       m2, out2);
 }
 
 
@@ -741,6 +777,7 @@ extern "C" int gv_gemm_bf16_nt(const void* a, int a_is_f32, int lda, const uint1
     p.ldmask = ldmask; p.c_f32 = c_f32; p.ldc = ldc; p.accumulate = accumulate; p.c_bf = c_bf16; p.ldcb = ldcb;
     p.c_bft = c_bf16_t; p.ldct = ldct; p.partial = nullptr; p.k_per_split = k; p.rowsum_partial = nullptr;
     p.partial_stride = (size_t)m * n;
+    p.a_tile = p.b_tile = 0;
     hipStream_t st = (hipStream_t)stream;
     int splits = 1;
     bool tall = false;
@@ -760,14 +797,14 @@ extern "C" int gv_gemm_bf16_nt(const void* a, int a_is_f32, int lda, const uint1
     if (tall) {
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)k_gemm_bf16_tallk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TK_LDS_BYTES) != hipSuccess) {
+            if (hipFuncSetAttribute((const void*)k_gemm_bf16_tallk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TK_LDS_BYTES) != hipSuccess) {
                 (void)hipGetLastError();
                 set_error("gv_gemm_bf16_nt: cannot raise the dynamic LDS limit");
                 return GV_ERR_SHAPE;
             }
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_gemm_bf16_tallk, dim3((n + TK_T - 1) / TK_T, (m + TK_T - 1) / TK_T, splits), dim3(TK_THREADS), TK_LDS_BYTES,
+        hipLaunchKernelGGL(k_gemm_bf16_tallk<false>, dim3((n + TK_T - 1) / TK_T, (m + TK_T - 1) / TK_T, splits), dim3(TK_THREADS), TK_LDS_BYTES,
                            st, p);
     } else {
         dim3 grid((n + 63) / 64, (m + 63) / 64, splits), block(256);
@@ -778,8 +815,7 @@ extern "C" int gv_gemm_bf16_nt(const void* a, int a_is_f32, int lda, const uint1
     if (rc != GV_OK || split_k <= 1) return rc;
     const size_t mn = (size_t)m * n;
     GV_REQUIRE(ldc == n, GV_ERR_SHAPE, "gv_gemm_bf16_nt: split-K needs a dense result (ldc == n)");
-    hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)min((size_t)1024, (mn + 255) / 256)), dim3(256), 0, st,
-                       (const float*)workspace, splits, mn, mn, c_f32, accumulate, (size_t)0, (float*)nullptr);
+    launch_splitk_sum(st, (const float*)workspace, splits, mn, mn, c_f32, accumulate, (size_t)0, nullptr);
     return launch_status("gv_gemm_bf16_nt(split-k sum)");
 }
 
@@ -801,6 +837,37 @@ extern "C" int64_t gv_gemm_bf16_gradw_workspace_bytes(int m, int n, int split_k)
     return split_k > 1 ? (int64_t)split_k * m * (n + 1) * 4 : 0;
 }
 
+template <bool TILES>
+static int gemm_bf16_gradw(const char* who, const uint16_t* a, int lda, unsigned a_tile, const uint16_t* b, int ldb, unsigned b_tile,
+                           int m, int n, int k, float* c_f32, int accumulate, float* a_rowsum, int split_k, void* workspace,
+                           int64_t workspace_bytes, void* stream) {
+    int per, splits;
+    GV_REQUIRE(gradw_splits(m, n, k, split_k, &per, &splits), GV_ERR_SHAPE,
+               "%s: %d x %d over k=%d with %d splits does not fit the whole-output kernel", who, m, n, k, split_k);
+    GV_REQUIRE(workspace_bytes >= (int64_t)splits * m * (n + 1) * 4, GV_ERR_WORKSPACE, "%s: workspace too small", who);
+    BfGemm p;
+    p.a = a; p.lda = lda; p.b = b; p.ldb = ldb; p.m = m; p.n = n; p.k = k; p.bias = nullptr; p.relu = 0; p.mask = nullptr;
+    p.ldmask = 0; p.c_f32 = c_f32; p.ldc = n; p.accumulate = accumulate; p.c_bf = nullptr; p.ldcb = 0; p.c_bft = nullptr; p.ldct = 0;
+    p.partial = (float*)workspace; p.k_per_split = per;
+    p.partial_stride = (size_t)m * (n + 1);         // a split's product, then its row sums
+    p.rowsum_partial = a_rowsum ? (float*)workspace + (size_t)m * n : nullptr;
+    p.a_tile = a_tile; p.b_tile = b_tile;
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_gemm_bf16_tallk<TILES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TK_LDS_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("%s: cannot raise the dynamic LDS limit", who);
+            return GV_ERR_SHAPE;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_gemm_bf16_tallk<TILES>, dim3((n + TK_T - 1) / TK_T, (m + TK_T - 1) / TK_T, splits), dim3(TK_THREADS), TK_LDS_BYTES, st, p);
+    const size_t mn = (size_t)m * n;
+    launch_splitk_sum(st, (const float*)workspace, splits, mn, p.partial_stride, c_f32, accumulate, (size_t)m, a_rowsum);
+    return launch_status(who);
+}
+
 extern "C" int gv_gemm_bf16_gradw(const uint16_t* a, int lda, const uint16_t* b, int ldb, int m, int n, int k, float* c_f32,
                                   int accumulate, float* a_rowsum, int split_k, void* workspace, int64_t workspace_bytes,
                                   void* stream) {
@@ -808,31 +875,26 @@ extern "C" int gv_gemm_bf16_gradw(const uint16_t* a, int lda, const uint16_t* b,
     GV_REQUIRE(a && b && c_f32 && workspace, GV_ERR_NULL, "gv_gemm_bf16_gradw: NULL pointer");
     GV_REQUIRE(k % 8 == 0 && lda >= k && ldb >= k && lda % 8 == 0 && ldb % 8 == 0 && aligned16(a) && aligned16(b), GV_ERR_ALIGN,
                "gv_gemm_bf16_gradw: k, lda, ldb must allow 16-B row pieces (k=%d lda=%d ldb=%d)", k, lda, ldb);
-    int per, splits;
-    GV_REQUIRE(gradw_splits(m, n, k, split_k, &per, &splits), GV_ERR_SHAPE,
-               "gv_gemm_bf16_gradw: %d x %d over k=%d with %d splits does not fit the whole-output kernel", m, n, k, split_k);
-    GV_REQUIRE(workspace_bytes >= (int64_t)splits * m * (n + 1) * 4, GV_ERR_WORKSPACE, "gv_gemm_bf16_gradw: workspace too small");
-    BfGemm p;
-    p.a = a; p.lda = lda; p.b = b; p.ldb = ldb; p.m = m; p.n = n; p.k = k; p.bias = nullptr; p.relu = 0; p.mask = nullptr;
-    p.ldmask = 0; p.c_f32 = c_f32; p.ldc = n; p.accumulate = accumulate; p.c_bf = nullptr; p.ldcb = 0; p.c_bft = nullptr; p.ldct = 0;
-    p.partial = (float*)workspace; p.k_per_split = per;
-    p.partial_stride = (size_t)m * (n + 1);         // a split's product, then its row sums
-    p.rowsum_partial = a_rowsum ? (float*)workspace + (size_t)m * n : nullptr;
-    hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_gemm_bf16_tallk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TK_LDS_BYTES) != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("gv_gemm_bf16_gradw: cannot raise the dynamic LDS limit");
-            return GV_ERR_SHAPE;
-        }
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_gemm_bf16_tallk, dim3((n + TK_T - 1) / TK_T, (m + TK_T - 1) / TK_T, splits), dim3(TK_THREADS), TK_LDS_BYTES, st, p);
-    const size_t mn = (size_t)m * n;
-    hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)min((size_t)1024, (mn + m + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
-                       splits, mn, p.partial_stride, c_f32, accumulate, (size_t)m, a_rowsum);
-    return launch_status("gv_gemm_bf16_gradw");
+    return gemm_bf16_gradw<false>("gv_gemm_bf16_gradw", a, lda, 0u, b, ldb, 0u, m, n, k, c_f32, accumulate, a_rowsum, split_k, workspace,
+                                  workspace_bytes, stream);
+}
+
+/* ... with both operands in 64-deep K TILES: element (row, kk) of A at a[(kk / 64) * a_tile + row * 64 + kk % 64] (a_tile >= 64 m
+ * elements between tiles; B likewise): a workgroup's K slice is a few CONTIGUOUS blocks of memory instead of one short piece
+ * out of each of m + n rows that lie k elements apart. */
+extern "C" int gv_gemm_bf16_gradw_tiles(const uint16_t* a, int64_t a_tile, const uint16_t* b, int64_t b_tile, int m, int n, int k,
+                                        float* c_f32, int accumulate, float* a_rowsum, int split_k, void* workspace,
+                                        int64_t workspace_bytes, void* stream) {
+    GV_REQUIRE(m > 0 && n > 0 && k > 0, GV_ERR_SHAPE, "gv_gemm_bf16_gradw_tiles: m=%d n=%d k=%d", m, n, k);
+    GV_REQUIRE(a && b && c_f32 && workspace, GV_ERR_NULL, "gv_gemm_bf16_gradw_tiles: NULL pointer");
+    GV_REQUIRE(k % 64 == 0 && a_tile >= (int64_t)64 * m && b_tile >= (int64_t)64 * n && a_tile % 8 == 0 && b_tile % 8 == 0 &&
+               aligned16(a) && aligned16(b), GV_ERR_ALIGN,
+               "gv_gemm_bf16_gradw_tiles: k must be whole 64-deep tiles of >= 64 * rows elements (k=%d a_tile=%lld b_tile=%lld)", k,
+               (long long)a_tile, (long long)b_tile);
+    GV_REQUIRE((int64_t)(k / 64) * a_tile <= (int64_t)UINT32_MAX && (int64_t)(k / 64) * b_tile <= (int64_t)UINT32_MAX, GV_ERR_SHAPE,
+               "gv_gemm_bf16_gradw_tiles: an operand spans more than 2^32 elements");
+    return gemm_bf16_gradw<true>("gv_gemm_bf16_gradw_tiles", a, 0, (unsigned)a_tile, b, 0, (unsigned)b_tile, m, n, k, c_f32, accumulate,
+                                 a_rowsum, split_k, workspace, workspace_bytes, stream);
 }
 
 extern "C" int gv_cast_bf16(const float* x, int ldx, int rows, int cols, uint16_t* y, int ldy, uint16_t* y_t, int ldt,
@@ -846,23 +908,37 @@ extern "C" int gv_cast_bf16(const float* x, int ldx, int rows, int cols, uint16_
     return launch_status("gv_cast_bf16");
 }
 
-extern "C" int gv_iaf_update_fwd_bf16(const float* z, const float* net, int ld_net, const float* x_old, const int32_t* colcount,
-                                     float* x_new, uint16_t* x_b, int ldb, uint16_t* x_t, int ldt, int64_t n, int d,
-                                     void* stream) {
-    GV_REQUIRE(n >= 0 && d > 0 && n < (1ll << 31), GV_ERR_SHAPE, "gv_iaf_update_fwd_bf16: n=%lld d=%d", (long long)n, d);
+static int iaf_update_fwd_bf16(const char* what, const float* z, const float* net, int ld_net, const float* x_old, const int32_t* colcount,
+                               float* x_new, uint16_t* x_b, int ldb, uint16_t* x_t, int ldt, int64_t t_tile, int64_t n, int d, void* stream) {
+    GV_REQUIRE(n >= 0 && d > 0 && n < (1ll << 31), GV_ERR_SHAPE, "%s: n=%lld d=%d", what, (long long)n, d);
     if (n == 0) return GV_OK;
-    GV_REQUIRE(z && net && x_old && colcount && x_new && x_b && x_t, GV_ERR_NULL, "gv_iaf_update_fwd_bf16: NULL pointer");
-    GV_REQUIRE(ldb >= d && ldt >= n, GV_ERR_SHAPE, "gv_iaf_update_fwd_bf16: leading dimension too small");
-    const bool v4 = d % 4 == 0 && ld_net % 4 == 0 && ldb % 4 == 0 && ldt % 4 == 0 && aligned16(z) && aligned16(net) && aligned16(x_old) &&
-                    aligned16(x_new) && aligned16(colcount) && (reinterpret_cast<uintptr_t>(x_b) & 7u) == 0 &&
-                    (reinterpret_cast<uintptr_t>(x_t) & 7u) == 0;
+    GV_REQUIRE(z && net && x_old && colcount && x_new && x_b && x_t, GV_ERR_NULL, "%s: NULL pointer", what);
+    GV_REQUIRE(ldb >= d && (t_tile > 0 ? (t_tile >= (int64_t)64 * d && t_tile <= INT32_MAX) : ldt >= n), GV_ERR_SHAPE,
+               "%s: leading dimension too small", what);
+    const bool v4 = d % 4 == 0 && ld_net % 4 == 0 && ldb % 4 == 0 && (t_tile > 0 ? t_tile % 4 == 0 : ldt % 4 == 0) && aligned16(z) &&
+                    aligned16(net) && aligned16(x_old) && aligned16(x_new) && aligned16(colcount) &&
+                    (reinterpret_cast<uintptr_t>(x_b) & 7u) == 0 && (reinterpret_cast<uintptr_t>(x_t) & 7u) == 0;
+    GV_REQUIRE(v4 || t_tile == 0, GV_ERR_ALIGN, "%s: the tiled copy needs d %% 4 == 0 and 16-B aligned fp32 rows", what);
     if (v4)
         hipLaunchKernelGGL(k_iaf_fwd_bf16_v4, dim3((d + 63) / 64, (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, z,
-                           net, ld_net, x_old, colcount, x_new, x_b, ldb, x_t, ldt, (int)n, d);
+                           net, ld_net, x_old, colcount, x_new, x_b, ldb, x_t, ldt, (int)n, d, (int)t_tile);
     else
         hipLaunchKernelGGL(k_iaf_fwd_bf16, dim3((d + 63) / 64, (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, z,
                            net, ld_net, x_old, colcount, x_new, x_b, ldb, x_t, ldt, (int)n, d);
-    return launch_status("gv_iaf_update_fwd_bf16");
+    return launch_status(what);
+}
+
+extern "C" int gv_iaf_update_fwd_bf16(const float* z, const float* net, int ld_net, const float* x_old, const int32_t* colcount,
+                                     float* x_new, uint16_t* x_b, int ldb, uint16_t* x_t, int ldt, int64_t n, int d,
+                                     void* stream) {
+    return iaf_update_fwd_bf16("gv_iaf_update_fwd_bf16", z, net, ld_net, x_old, colcount, x_new, x_b, ldb, x_t, ldt, 0, n, d, stream);
+}
+
+extern "C" int gv_iaf_update_fwd_bf16_tiles(const float* z, const float* net, int ld_net, const float* x_old, const int32_t* colcount,
+                                           float* x_new, uint16_t* x_b, int ldb, uint16_t* x_t, int64_t t_tile, int64_t n, int d,
+                                           void* stream) {
+    GV_REQUIRE(t_tile > 0, GV_ERR_SHAPE, "gv_iaf_update_fwd_bf16_tiles: t_tile=%lld", (long long)t_tile);
+    return iaf_update_fwd_bf16("gv_iaf_update_fwd_bf16_tiles", z, net, ld_net, x_old, colcount, x_new, x_b, ldb, x_t, 0, t_tile, n, d, stream);
 }
 
 static int iaf_update_bwd_bf16(const char* what, bool ex, const float* z, const float* net, int ld_net, const int32_t* colcount,
@@ -871,11 +947,14 @@ static int iaf_update_bwd_bf16(const char* what, bool ex, const float* z, const 
     GV_REQUIRE(n >= 0 && d > 0 && n < (1ll << 31), GV_ERR_SHAPE, "%s: n=%lld d=%d", what, (long long)n, d);
     if (n == 0) return GV_OK;
     GV_REQUIRE(z && net && colcount && gx && gz_accumulate && gnet_b && gnet_t && (gx_old || ex), GV_ERR_NULL, "%s: NULL pointer", what);
-    GV_REQUIRE(ldb >= ((gz_overwrite & 2) ? d : 2 * d) && ldt >= n && ld_net >= (ex ? d : 2 * d), GV_ERR_SHAPE, "%s: leading dimension too small", what);
+    const bool tiles = (gz_overwrite & 4) != 0;      // gnet_t in tiles of 64 rows, ldt elements apart
+    GV_REQUIRE(ldb >= ((gz_overwrite & 2) ? d : 2 * d) && (tiles ? ldt >= 128 * d : ldt >= n) && ld_net >= (ex ? d : 2 * d), GV_ERR_SHAPE,
+               "%s: leading dimension too small", what);
     GV_REQUIRE(!(gz_overwrite & 2) || !gld, GV_ERR_SHAPE, "%s: the mu-half-only form needs g_logdet == NULL (g_alpha == g_mu then)", what);
     const bool v4 = d % 4 == 0 && ld_net % 4 == 0 && ldb % 4 == 0 && ldt % 4 == 0 && aligned16(z) && aligned16(net) && aligned16(gx) &&
                     aligned16(gz_accumulate) && (!gx_old || aligned16(gx_old)) && aligned16(colcount) &&
                     (reinterpret_cast<uintptr_t>(gnet_b) & 7u) == 0 && (reinterpret_cast<uintptr_t>(gnet_t) & 7u) == 0;
+    GV_REQUIRE(v4 || !tiles, GV_ERR_ALIGN, "%s: the tiled copy needs d %% 4 == 0 and 16-B aligned fp32 rows", what);
     const dim3 grid((d + 63) / 64, (unsigned)((n + 63) / 64));
 #define GV_IAF_BWD(K)                                                                                                        \
     hipLaunchKernelGGL(K, grid, dim3(256), 0, (hipStream_t)stream, z, net, ld_net, colcount, gx, gld, gz_accumulate, gnet_b, ldb,   \

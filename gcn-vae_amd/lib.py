@@ -59,10 +59,12 @@ SIGNATURES = {
     'gv_gemm_bf16_gradw_fits': (_I, [_I, _I, _I, _I]),
     'gv_gemm_bf16_gradw_workspace_bytes': (_L, [_I, _I, _I]),
     'gv_gemm_bf16_gradw': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _L, _P]),
+    'gv_gemm_bf16_gradw_tiles': (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _I, _P, _I, _P, _L, _P]),
     'gv_gemm_bf16_nt': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P, _L, _P]),
     'gv_cast_bf16': (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P]),
     'gv_rowsum_bf16_workspace_floats': (_L, [_I, _I]),
     'gv_iaf_update_fwd_bf16': (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _L, _I, _P]),
+    'gv_iaf_update_fwd_bf16_tiles': (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _P, _L, _L, _I, _P]),
     'gv_iaf_update_bwd_bf16': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _L, _I, _P]),
     'gv_gather3_i32': (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _P]),
     'gv_iaf_update_bwd_row0_workspace_floats': (_L, [_I]),

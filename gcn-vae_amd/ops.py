@@ -2820,6 +2820,23 @@ def _empty_t_padded(widths, passes, n, npad, kw):
     return out
 
 
+def _empty_t_tiles(widths, passes, n, kw):
+    """Transposed-copy buffers in tiles of 64 rows: ONE allocation [passes * T][sum(widths)][64] (T = ceil(n / 64) tiles per
+    pass), buffer i = the column range of width_i -- element (column c, stacked row r) at [r // 64][c][r % 64].  A workgroup of the
+    weight-gradient product (gv_gemm_bf16_gradw_tiles) then reads contiguous 128-B x width blocks, and a chain workgroup (64
+    rows) writes one.  The rows [n, 64 T) of every pass's last tile stay zero (they take part in the reduction).
+    Returns (buffers, tiles per pass, elements between two tiles)."""
+    T = (int(n) + 63) // 64
+    t = torch.empty(passes * T, sum(widths), 64, **kw)
+    if n % 64:
+        t.view(passes, T, sum(widths), 64)[:, T - 1, :, n % 64:].zero_()
+    out, o = [], 0
+    for w in widths:
+        out.append(t[:, o:o + w])
+        o += w
+    return out, T, sum(widths) * 64
+
+
 def cast_bf16(x, y=None, y_t=None):
     """y = bf16(x) row-major and / or y_t[c, r] = bf16(x[r, c]); x fp32 (rows, cols) with unit inner stride."""
     x, ldx = _row_major(x, 'x')
@@ -2891,7 +2908,7 @@ class _ChainLayer(_ct.Structure):
                 ('iaf_colcount', _ct.c_void_p), ('iaf_x_new', _ct.c_void_p), ('iaf_ex', _ct.c_void_p), ('iaf_alpha', _ct.c_void_p),
                 ('iaf_ld', _ct.c_int32), ('iaf_reserved', _ct.c_int32), ('iaf_keep_colcount', _ct.c_void_p), ('mask_t', _ct.c_void_p),
                 ('add_src', _ct.c_void_p), ('add_colcount', _ct.c_void_p), ('ldmask_t', _ct.c_int32), ('ldbits', _ct.c_int32),
-                ('out_bits', _ct.c_void_p), ('mask_bits', _ct.c_void_p), ('x_dup_half', _ct.c_int32), ('reserved3', _ct.c_int32)]
+                ('out_bits', _ct.c_void_p), ('mask_bits', _ct.c_void_p), ('x_dup_half', _ct.c_int32), ('t_tile', _ct.c_int32)]
 
 
 class _RowLayer(_ct.Structure):
@@ -2981,7 +2998,8 @@ MADE_CHAIN_FLOPS = {}        # tag -> flops of one launch (filled while a Kernel
 
 def made_chain(x, m, layers, tag=None):
     """One launch for a chain of NT products (gv_made_chain): layers = dicts with w_packed, n, k and optional bias, relu, mask,
-    out_bf16, out_bf16_t, out_f32, accumulate.  Row strides are taken from the tensors."""
+    out_bf16, out_bf16_t (t_tile: in tiles of 64 rows, that many elements apart), out_f32, accumulate.  Row strides are taken
+    from the tensors."""
     if tag is not None and lib.TIMER is not None:
         MADE_CHAIN_FLOPS[tag] = 2.0 * int(m) * sum(int(d['n']) * int(d['k']) for d in layers)
     arr = (_ChainLayer * len(layers))()
@@ -2993,6 +3011,8 @@ def made_chain(x, m, layers, tag=None):
         c.ldmask = mask.stride(0) if mask is not None else 0
         c.ldb = ob.stride(0) if ob is not None else 0
         c.ldt = ot.stride(0) if ot is not None else 0
+        if ot is not None and d.get('t_tile'):      # out_bf16_t in tiles of 64 rows (what gemm_bf16_gradw_tiles reads): ot starts at tile 0
+            c.ldt, c.t_tile = 64, int(d['t_tile'])
         c.ldc = of.stride(0) if of is not None else 0
         iaf = d.get('iaf')
         if iaf is not None:      # dict(z, x_old, colcount, x_new=None, ex=None, alpha=None): fp32 [m][ld] with one common row stride
@@ -3019,6 +3039,17 @@ def made_chain(x, m, layers, tag=None):
                 raise ValueError('made_chain: add_src shares the row stride of out_f32')
             c.add_src, c.add_colcount = ptr(add[0]), ptr(add[1])
     lib.call('gv_made_chain', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), lib.stream(), tag=tag)
+
+
+def gemm_bf16_gradw_tiles(a, a_tile, b, b_tile, m, n, k, c_f32, accumulate=True, a_rowsum=None, split_k=2):
+    """gemm_bf16_gradw with both operands in 64-deep K tiles (gv_gemm_bf16_gradw_tiles): element (row, kk) of A at
+    a.flatten()[(kk // 64) * a_tile + row * 64 + kk % 64]; a, b: bf16 tensors whose first element is tile 0 of row 0."""
+    if c_f32.stride(0) != n:
+        raise ValueError('gemm_bf16_gradw_tiles: the result must be dense')
+    ws_bytes = int(lib.load().gv_gemm_bf16_gradw_workspace_bytes(m, n, split_k))
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=c_f32.device)
+    lib.call('gv_gemm_bf16_gradw_tiles', ptr(a), int(a_tile), ptr(b), int(b_tile), m, n, k, ptr(c_f32), 1 if accumulate else 0,
+             ptr(a_rowsum), split_k, ptr(ws), ws_bytes, lib.stream())
 
 
 class _MADEForwardBF16(torch.autograd.Function):
@@ -3062,7 +3093,18 @@ class _MADEForwardBF16(torch.autograd.Function):
                 cast_bf16(w, a_, t_)
         xin = torch.empty(max(S, 1) * n, d, **f32)               # fp32 pass inputs (update pass-through, backward)
         xin_b = torch.empty(max(S, 1) * n, _pad8(d), **bf)
-        tbufs = _empty_t_padded([d] + widths[:L - 1], max(S, 1), n, npad, bf)[:-1]
+        # fused: the transposed copies (read by the weight-gradient products alone) in tiles of 64 rows, when every product fits
+        # the whole-output kernel; pass p then starts at tile p * T
+        T = (n + 63) // 64
+        split_t = max(2, min(GRADW_SPLIT_MAX, S * T * 64 // 512))
+        tiled = (fused and MADE_T_TILES and S > 0 and d % 4 == 0
+                 and all(gemm_bf16_gradw_fits(widths[l], ws[l].shape[1], S * T * 64, split_t) for l in range(L)))
+        if tiled:
+            tbufs, T, tt = _empty_t_tiles([d] + widths[:L - 1], S, n, bf)
+        else:
+            tbufs, tt = _empty_t_padded([d] + widths[:L - 1], max(S, 1), n, npad, bf)[:-1], 0
+        t_of = (lambda buf, q: dict(out_bf16_t=buf[q * T:], t_tile=tt)) if tiled else \
+               (lambda buf, q: dict(out_bf16_t=buf[:, q * npad:q * npad + n]))
         xin_t = tbufs[0]
         # fused (the IAF update inside the chain): row-major activations never leave the chain (the backward chain stages its ReLU
         # masks from the transposed copies), and of [mu | alpha] only exp(alpha + mu) is kept (+ alpha of the last pass)
@@ -3090,7 +3132,10 @@ class _MADEForwardBF16(torch.autograd.Function):
         def update(net, ld_net, x_old, cc, q):
             """The IAF update of one pass.  Its result is pass q + 1's input (slice q of the stacked buffers: fp32 + the bf16
             row-major and transposed copies the products read, written by the same launch) or, after the last pass, x_out."""
-            if q < S:
+            if q < S and tiled:
+                lib.call('gv_iaf_update_fwd_bf16_tiles', ptr(z), ptr(net), ld_net, ptr(x_old), ptr(cc), ptr(xin[q * n:(q + 1) * n]),
+                         ptr(xin_b[q * n:(q + 1) * n]), xin_b.stride(0), ptr(xin_t[q * T:]), tt, n, d, st)
+            elif q < S:
                 lib.call('gv_iaf_update_fwd_bf16', ptr(z), ptr(net), ld_net, ptr(x_old), ptr(cc), ptr(xin[q * n:(q + 1) * n]),
                          ptr(xin_b[q * n:(q + 1) * n]), xin_b.stride(0), ptr(xin_t[:, q * npad:q * npad + n]), xin_t.stride(0),
                          n, d, st)
@@ -3108,11 +3153,11 @@ class _MADEForwardBF16(torch.autograd.Function):
                     head['iaf'] = dict(z=z, x_old=xin[sl], colcount=colcount[p], ex=net_out[sl])
                     if p < S:   # fp32 x_new only where the next pass hands a column through; its operands in bf16
                         head['iaf'].update(x_new=xin[nsl], keep=colcount[p + 1])
-                        head.update(out_bf16=xin_b[nsl], out_bf16_t=xin_t[:, p * npad:p * npad + n])
+                        head.update(out_bf16=xin_b[nsl], **t_of(xin_t, p))
                     else:
                         head['iaf'].update(x_new=x_out, alpha=alpha_last)
                     made_chain(inp, n, [dict(w_packed=wbf[l], n=widths[l], k=ws[l].shape[1], bias=bs[l], relu=True,
-                                             out_bf16_t=acts_t[l][:, tsl], out_bits=sign[l][sl]) for l in range(L - 1)] + [head],
+                                             out_bits=sign[l][sl], **t_of(acts_t[l], p - 1)) for l in range(L - 1)] + [head],
                                tag='madechain_fwd')
                     continue
                 head['out_f32'] = net_out[sl]
@@ -3137,6 +3182,7 @@ class _MADEForwardBF16(torch.autograd.Function):
         ctx.L = L
         ctx.chain = chain
         ctx.fused = fused
+        ctx.tiled, ctx.t_tile = tiled, tt
         ctx.row = row
         ctx.direct_b = [_direct(b) if b is not None else None for b in bs]
         _stamp_direct(ctx)
@@ -3169,7 +3215,14 @@ class _MADEForwardBF16(torch.autograd.Function):
             gm_in = torch.empty(n, _pad8(widths[L - 1]), **bf)
         else:
             gm_b = [torch.empty(max(S, 1) * n, _pad8(widths[l]), **bf) for l in range(L)]
-        *gm_t, gm_t_all = _empty_t_padded(widths, max(S, 1), n, npad, bf)
+        tiled, T = ctx.tiled, (n + 63) // 64
+        if tiled:
+            gm_t, _, tb = _empty_t_tiles(widths, S, n, bf)
+            gm_t_all = None
+            t_of = lambda buf, q: dict(out_bf16_t=buf[q * T:], t_tile=tb)
+        else:
+            *gm_t, gm_t_all = _empty_t_padded(widths, max(S, 1), n, npad, bf)
+            t_of = lambda buf, q: dict(out_bf16_t=buf[:, q * npad:q * npad + n])
         g_z = torch.empty(n, d, **f32) if (ctx.fused and P > 1) else torch.zeros(n, d, **f32)      # fused: the first pass writes it
         gz_p = torch.empty(n, d, **f32)
         g_cur = gx
@@ -3183,14 +3236,15 @@ class _MADEForwardBF16(torch.autograd.Function):
                 # alone and the chain stages it twice (x_dup_half)
                 half = (gld is None or p != P - 1) and widths[L - 1] % 16 == 0 and L > 1
                 lib.call('gv_iaf_update_bwd_bf16_ex', ptr(z), ptr(net_out[sl]), d, ptr(colcount[p]), ptr(g_cur),
-                         ptr(gld) if p == P - 1 else None, ptr(g_z), ptr(gm_in), gm_in.stride(0), ptr(gm_t[L - 1][:, tsl]),
-                         gm_t[L - 1].stride(0), None, (1 if p == P - 1 else 0) | (2 if half else 0), n, d, st)
+                         ptr(gld) if p == P - 1 else None, ptr(g_z), ptr(gm_in), gm_in.stride(0),
+                         ptr(gm_t[L - 1][(p - 1) * T:] if tiled else gm_t[L - 1][:, tsl]), tb if tiled else gm_t[L - 1].stride(0), None,
+                         (1 if p == P - 1 else 0) | (2 if half else 0) | (4 if tiled else 0), n, d, st)
                 first = dict(w_packed=wbt[L - 1], n=widths[L - 2], k=widths[L - 1], mask_bits=acts_b[L - 2][sl],
-                             out_bf16_t=gm_t[L - 2][:, tsl], x_dup_half=half) if L > 1 else None
+                             x_dup_half=half, **t_of(gm_t[L - 2], p - 1)) if L > 1 else None
                 made_chain(gm_in, n,
                            ([first] if first is not None else []) +
                            [dict(w_packed=wbt[l], n=widths[l - 1], k=widths[l], mask_bits=acts_b[l - 1][sl],
-                                 out_bf16_t=gm_t[l - 1][:, tsl]) for l in reversed(range(1, L - 1))] +
+                                 **t_of(gm_t[l - 1], p - 1)) for l in reversed(range(1, L - 1))] +
                            [dict(w_packed=wbt[0], n=d, k=widths[0], out_f32=g_old, add=(g_cur, colcount[p]))], tag='madechain_bwd')
                 g_cur = g_old
                 continue
@@ -3229,20 +3283,22 @@ class _MADEForwardBF16(torch.autograd.Function):
                     mask = acts0[l] if l < L - 1 else None
                     g_row = gemm(g_row, ws[l], a_relu_mask=mask, precision='bf16')
         g_ws, g_bs, g_bs_acc = [], [], []
-        mtot = max(S, 1) * npad
+        mtot = S * T * 64 if tiled else max(S, 1) * npad
         # where each layer's bias gradient accumulates, and whether the weight-gradient launch can take it along
         wants_gb = [ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l] for l in range(L)]
         gb_target = [(row_gb[l] if ctx.row else None) if wants_gb[l] else None for l in range(L)]
         fused_gb = [S > 0 and ctx.row and gb_target[l] is not None and ctx.needs_input_grad[3 + l] and row_gw[l] is not None
                     and row_gw[l].stride(0) == ws[l].shape[1]
                     and gemm_bf16_gradw_fits(widths[l], ws[l].shape[1], mtot, max(2, min(GRADW_SPLIT_MAX, mtot // 512))) for l in range(L)]
+        if tiled:       # the tiled copies are read by the whole-output product alone: it takes every bias gradient along
+            fused_gb = [wants_gb[l] for l in range(L)]
         for l in range(L):
             mask0 = acts0[l] if l < L - 1 else None
             inp0 = zero_row if l == 0 else acts0[l - 1]
             gw = gb = None
             if ctx.needs_input_grad[3 + l]:
                 gw = row_gw[l] if ctx.row else gemm(rows0[l], inp0, trans_a=True, a_relu_mask=mask0, precision='bf16')
-                if S > 0:       # dW_l = g_l^T a_{l-1}: the NT kernel on the transposed copies, reduction over all stacked rows
+                if S > 0 and not tiled:       # dW_l = g_l^T a_{l-1}: the NT kernel on the transposed copies, reduction over all stacked rows
                     in_t = xin_t if l == 0 else acts_t[l - 1]
                     split = max(2, min(GRADW_SPLIT_MAX, mtot // 512))
                     if fused_gb[l]:      # ... and the stacked passes' share of the bias gradient from the same pass over g_l^T
@@ -3252,6 +3308,12 @@ class _MADEForwardBF16(torch.autograd.Function):
                         gemm_bf16_nt(gm_t[l], in_t, widths[l], ws[l].shape[1], mtot, c_f32=gw, accumulate=True, split_k=split)
             if ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l]:
                 gb = row_gb[l] if ctx.row else colsum(rows0[l], relu_mask=mask0)
+            if tiled and (gw is not None or gb is not None):
+                # dW_l = g_l^T a_{l-1} over all stacked rows, both operands in 64-row tiles, db_l from the same pass over g_l^T
+                gemm_bf16_gradw_tiles(gm_t[l], tb, xin_t if l == 0 else acts_t[l - 1], ctx.t_tile, widths[l], ws[l].shape[1], mtot,
+                                      gw if gw is not None else torch.empty(widths[l], ws[l].shape[1], **f32), accumulate=gw is not None,
+                                      a_rowsum=gb, split_k=max(2, min(GRADW_SPLIT_MAX, mtot // 512)))
+            if ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l]:
                 if S > 0 and L > 8:
                     rws = torch.empty(int(lib.load().gv_rowsum_bf16_workspace_floats(widths[l], mtot)), **f32)
                     lib.call('gv_rowsum_bf16', ptr(gm_t[l]), gm_t[l].stride(0), widths[l], mtot, ptr(gb), 1, ptr(rws), st)
@@ -3286,6 +3348,7 @@ class _MADEForwardBF16(torch.autograd.Function):
 MADE_BF16_STORAGE = _os.environ.get('GV_MADE_BF16', '1') == '1'
 GRADW_SPLIT_MAX = int(_os.environ.get('GV_GRADW_SPLIT_MAX', '256'))      # most K slices of a MADE weight-gradient product
 MADE_CHAIN_IAF = _os.environ.get('GV_MADE_CHAIN_IAF', '1') == '1'      # the IAF update inside the chain's last layer
+MADE_T_TILES = _os.environ.get('GV_MADE_T_TILES', '1') == '1'          # ... and the transposed copies in tiles of 64 rows
 
 
 def made_forward(z, colcount, weights, biases, masks=None):

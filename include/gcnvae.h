@@ -198,13 +198,18 @@ int gv_rel_gradw_gemm(const float* x, int ld_x, const int32_t* x_rows, const flo
  * row-major (gnet_b, ld >= 2d) and transposed (gnet_t [2d, >= n]), ADDS g_z into gz_accumulate and writes gx_old (fp32). */
 int gv_iaf_update_fwd_bf16(const float* z, const float* net, int ld_net, const float* x_old, const int32_t* colcount, float* x_new,
                            uint16_t* x_b, int ldb, uint16_t* x_t, int ldt, int64_t n, int d, void* stream);
+/* ... x_t in tiles of 64 rows: element (column c, row r) at x_t[(r / 64) * t_tile + c * 64 + r % 64], t_tile >= 64 d elements
+ * between tiles -- the operand form of gv_gemm_bf16_gradw_tiles; rows [n, 64 ceil(n / 64)) of the last tile are not written. */
+int gv_iaf_update_fwd_bf16_tiles(const float* z, const float* net, int ld_net, const float* x_old, const int32_t* colcount,
+                                 float* x_new, uint16_t* x_b, int ldb, uint16_t* x_t, int64_t t_tile, int64_t n, int d, void* stream);
 int gv_iaf_update_bwd_bf16(const float* z, const float* net, int ld_net, const int32_t* colcount, const float* gx, const float* gld,
                            float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t, int ldt, float* gx_old, int64_t n,
                            int d, void* stream);
 /* ... from ex = expf(alpha + mu) [n][ld_ex] (what a forward chain with the fused update stores, gv_chain_layer.iaf_ex) instead
  * of [mu | alpha]; gx_old may be NULL (the backward chain adds the handed-through gradient itself: gv_chain_layer.add_src);
  * flags bit 0: g_z is WRITTEN to gz_accumulate (the first pass of a backward: no zero fill, no read); bit 1 (gld == NULL only:
- * g_alpha == g_mu then): gnet_b [n][ldb >= d] receives the g_mu half alone -- a chain reads it with x_dup_half. */
+ * g_alpha == g_mu then): gnet_b [n][ldb >= d] receives the g_mu half alone -- a chain reads it with x_dup_half; bit 2: gnet_t in
+ * tiles of 64 rows (element (column c, row r) at [(r / 64) * ldt + c * 64 + r % 64]: ldt >= 128 d is then the distance of two tiles). */
 int gv_iaf_update_bwd_bf16_ex(const float* z, const float* ex, int ld_ex, const int32_t* colcount, const float* gx, const float* gld,
                               float* gz_accumulate, uint16_t* gnet_b, int ldb, uint16_t* gnet_t, int ldt, float* gx_old,
                               int flags, int64_t n, int d, void* stream);
@@ -239,6 +244,12 @@ int gv_gemm_bf16_gradw_fits(int m, int n, int k, int split_k);
 int64_t gv_gemm_bf16_gradw_workspace_bytes(int m, int n, int split_k);
 int gv_gemm_bf16_gradw(const uint16_t* a, int lda, const uint16_t* b, int ldb, int m, int n, int k, float* c_f32, int accumulate,
                        float* a_rowsum, int split_k, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same with both operands in 64-deep K TILES: element (row, kk) of A at a[(kk / 64) * a_tile + row * 64 + kk % 64], a_tile
+ * (>= 64 m, a multiple of 8) elements between tiles, B likewise; k % 64 == 0.  A workgroup's K slice is then a few contiguous
+ * blocks of memory instead of a short piece out of each of m + n rows k elements apart.  This is the form gv_made_chain
+ * (t_tile), gv_iaf_update_fwd_bf16_tiles and gv_iaf_update_bwd_bf16_ex (flags bit 2) write their transposed copies in. */
+int gv_gemm_bf16_gradw_tiles(const uint16_t* a, int64_t a_tile, const uint16_t* b, int64_t b_tile, int m, int n, int k, float* c_f32,
+                             int accumulate, float* a_rowsum, int split_k, void* workspace, int64_t workspace_bytes, void* stream);
 int gv_cast_bf16(const float* x, int ldx, int rows, int cols, uint16_t* y, int ldy, uint16_t* y_t, int ldt, void* stream);
 int64_t gv_rowsum_bf16_workspace_floats(int rows, int cols);
 int gv_rowsum_bf16(const uint16_t* x, int ld, int rows, int cols, float* out, int accumulate, float* workspace, void* stream);
@@ -294,7 +305,10 @@ typedef struct gv_chain_layer {
      * a backward layer keeps its result where the bit is set (mask_bits; instead of mask / mask_t).  ldbits >= ceil(n / 32). */
     uint32_t* out_bits;           /* [m][ldbits] or NULL */
     const uint32_t* mask_bits;    /* [m][ldbits] or NULL */
-    int32_t x_dup_half, reserved3; /* layer 0 only: x holds columns [0, k / 2) alone and columns [k / 2, k) repeat them (k % 16 == 0) */
+    int32_t x_dup_half;           /* layer 0 only: x holds columns [0, k / 2) alone and columns [k / 2, k) repeat them (k % 16 == 0) */
+    int32_t t_tile;               /* > 0: out_bf16_t in tiles of 64 ROWS -- element (column c, row r) at [(r / 64) * t_tile + c * 64 + r % 64]
+                                   * (ldt == 64, t_tile >= 64 n elements between tiles): what gv_gemm_bf16_gradw_tiles reads; rows
+                                   * [m, 64 ceil(m / 64)) of the last tile are not written.  0: [n][ldt] */
 } gv_chain_layer;
 int64_t gv_made_pack_weight_elems(int n, int k);
 int gv_made_pack_weight(const float* w, int ld, int n, int k, uint16_t* packed_fwd, uint16_t* packed_bwd, void* stream);

@@ -1697,6 +1697,94 @@ def test_made_chain_half_width_input_and_the_update_backward_that_writes_it(ops,
     assert torch.equal(res[0], res[1])
 
 
+def _untile(t, rows):
+    """[tiles][cols][64] -> [cols][rows]: the plain transposed form of a copy stored in tiles of 64 rows."""
+    return t.permute(1, 0, 2).reshape(t.shape[1], -1)[:, :rows]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('m,d', [(300, 200), (64, 24), (1000, 72)])
+def test_transposed_copies_in_tiles_of_64_rows_hold_the_same_values_and_the_product_reads_them(ops, m, d):
+    """The 64-row-tile form of the transposed bf16 copies (gv_chain_layer.t_tile, gv_iaf_update_fwd_bf16_tiles,
+    gv_iaf_update_bwd_bf16_ex flag 4) against the [column][row] form of the same launches, bit for bit, rows behind m untouched;
+    gv_gemm_bf16_gradw_tiles on tiled operands against gv_gemm_bf16_gradw on the same operands as [row][k], bit for bit."""
+    from gcn_vae_amd import lib
+    from gcn_vae_amd.lib import ptr
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(m * 3 + d)
+    bf = dict(dtype=torch.bfloat16, device=dev)
+    T, mp = (m + 63) // 64, (m + 7) // 8 * 8
+    extra = 16                                                # the buffers are column ranges of a wider allocation
+    i16 = lambda t: t.contiguous().view(torch.int16)
+    # forward update
+    z, xold = (torch.randn(m, d, generator=g).to(dev) for _ in range(2))
+    net = (torch.randn(m, 2 * d, generator=g) * 0.3).to(dev)
+    cnt = torch.randint(0, 3, (d,), generator=g).to(torch.int32).to(dev)
+    xn, xb, xt = torch.empty(m, d, device=dev), torch.zeros(m, d, **bf), torch.zeros(d, mp, **bf)
+    lib.call('gv_iaf_update_fwd_bf16', ptr(z), ptr(net), 2 * d, ptr(xold), ptr(cnt), ptr(xn), ptr(xb), d, ptr(xt), mp, m, d, lib.stream())
+    xn2, xb2 = torch.empty(m, d, device=dev), torch.zeros(m, d, **bf)
+    big = torch.full((T, d + extra, 64), 7.0, **bf)
+    lib.call('gv_iaf_update_fwd_bf16_tiles', ptr(z), ptr(net), 2 * d, ptr(xold), ptr(cnt), ptr(xn2), ptr(xb2), d, ptr(big[:, extra:]),
+             (d + extra) * 64, m, d, lib.stream())
+    assert torch.equal(xn, xn2) and torch.equal(i16(xb), i16(xb2))
+    assert torch.equal(i16(_untile(big[:, extra:], m)), i16(xt[:, :m]))
+    assert bool((big[:, :extra] == 7.0).all()) and (m % 64 == 0 or bool((big[T - 1, :, m % 64:] == 7.0).all()))
+    # backward update
+    ex, gx = torch.randn(m, d, generator=g).to(dev).exp(), torch.randn(m, d, generator=g).to(dev)
+    gld = torch.randn(m, generator=g).to(dev)
+    res = []
+    for tiles in (False, True):
+        gz, gb = torch.ones(m, d, device=dev), torch.zeros(m, 2 * d, **bf)
+        gt = torch.full((T, 2 * d + extra, 64), 7.0, **bf) if tiles else torch.zeros(2 * d, mp, **bf)
+        lib.call('gv_iaf_update_bwd_bf16_ex', ptr(z), ptr(ex), d, ptr(cnt), ptr(gx), ptr(gld), ptr(gz), ptr(gb), 2 * d,
+                 ptr(gt[:, extra:] if tiles else gt), (2 * d + extra) * 64 if tiles else mp, None, 4 if tiles else 0, m, d, lib.stream())
+        res.append((gz, gb, gt))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(i16(res[0][1]), i16(res[1][1]))
+    assert torch.equal(i16(_untile(res[1][2][:, extra:], m)), i16(res[0][2][:, :m]))
+    assert bool((res[1][2][:, :extra] == 7.0).all()) and (m % 64 == 0 or bool((res[1][2][T - 1, :, m % 64:] == 7.0).all()))
+    # a chain: hidden layer and a last layer that carries the update, both with a transposed copy
+    k0 = 40
+    ws = [(torch.randn(d, k0, generator=g) / k0 ** 0.5).to(dev), (torch.randn(2 * d, d, generator=g) / d ** 0.5).to(dev)]
+    bs = [torch.randn(d, generator=g).to(dev) * 0.1, torch.randn(2 * d, generator=g).to(dev) * 0.1]
+    x = torch.randn(m, k0, generator=g).to(dev).to(torch.bfloat16)
+    packed = ops.made_pack_weights(ws, iaf_last=True)
+    outs = []
+    for tiles in (False, True):
+        if tiles:
+            buf = torch.full((T, 2 * d + extra, 64), 7.0, **bf)
+            t0, t1 = dict(out_bf16_t=buf[:, extra:extra + d], t_tile=(2 * d + extra) * 64), dict(out_bf16_t=buf[:, extra + d:], t_tile=(2 * d + extra) * 64)
+        else:
+            buf = torch.zeros(2 * d, mp, **bf)
+            t0, t1 = dict(out_bf16_t=buf[:d]), dict(out_bf16_t=buf[d:])
+        x1, x1b = torch.empty(m, d, device=dev), torch.zeros(m, d, **bf)
+        ops.made_chain(x, m, [dict(w_packed=packed[0][0], n=d, k=k0, bias=bs[0], relu=True, **t0),
+                              dict(w_packed=packed[1][0], n=2 * d, k=d, bias=bs[1], iaf=dict(z=z, x_old=xold, colcount=cnt, x_new=x1),
+                                   out_bf16=x1b, **t1)])
+        outs.append((x1, x1b, buf))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(i16(outs[0][1]), i16(outs[1][1]))
+    assert torch.equal(i16(_untile(outs[1][2][:, extra:], m)), i16(outs[0][2][:, :m]))
+    assert bool((outs[1][2][:, :extra] == 7.0).all()) and (m % 64 == 0 or bool((outs[1][2][T - 1, :, m % 64:] == 7.0).all()))
+    # the weight-gradient product on the tiled copies of two passes == on the same operands as [row][k]
+    S = 2
+    tl = torch.zeros(S * T, 3 * d + extra, 64, **bf)
+    tl[:, :, :] = torch.randn(S * T, 3 * d + extra, 64, generator=g).to(dev).to(torch.bfloat16)
+    if m % 64:
+        tl.view(S, T, -1, 64)[:, T - 1, :, m % 64:] = 0
+    a_t, b_t = tl[:, extra:extra + 2 * d], tl[:, extra + 2 * d:]
+    k = S * T * 64
+    split = 2 if k < 512 else 3
+    if ops.gemm_bf16_gradw_fits(2 * d, d, k, split):
+        a_p, b_p = _untile(a_t, k).contiguous(), _untile(b_t, k).contiguous()
+        c0, r0 = torch.full((2 * d, d), 0.5, device=dev), torch.full((2 * d,), -1.0, device=dev)
+        c1, r1 = c0.clone(), r0.clone()
+        ops.gemm_bf16_gradw(a_p, b_p, 2 * d, d, k, c0, accumulate=True, a_rowsum=r0, split_k=split)
+        ops.gemm_bf16_gradw_tiles(a_t, (3 * d + extra) * 64, b_t, (3 * d + extra) * 64, 2 * d, d, k, c1, accumulate=True, a_rowsum=r1, split_k=split)
+        assert torch.equal(c0, c1) and torch.equal(r0, r1)
+        close(c1, a_p.float().cpu() @ b_p.float().cpu().t() + 0.5, rtol=1e-4, atol_scale=1e-5, msg='c')
+    else:
+        assert k < 128 * split
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('cap,live,n,k', [(1000, 700, 200, 200), (14541, 10211, 400, 200), (300, 300, 72, 40), (257, 0, 64, 64)])
 def test_gemm_skips_the_padding_rows_of_a_static_shape_batch(ops, cap, live, n, k):
