@@ -3274,15 +3274,12 @@ class _MADEForwardBF16(torch.autograd.Function):
             direct_b = [t if (t is not None and t.data_ptr() in GRAD_FRESH and t.is_contiguous()) else None for t in ctx.direct_b]
             row_gb = [(direct_b[l] if direct_b[l] is not None else torch.empty(widths[l], **f32))
                       if ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l] else None for l in range(L)]
-            made_row_bwd(g_row, [dict(w=ws[l], act=acts0[l] if l < L - 1 else None, inp=acts0[l - 1] if l > 0 else None,
-                                      gw=row_gw[l], gb=row_gb[l]) for l in range(L)])
         else:
             for l in reversed(range(L)):
                 rows0[l] = g_row
                 if l > 0:
                     mask = acts0[l] if l < L - 1 else None
                     g_row = gemm(g_row, ws[l], a_relu_mask=mask, precision='bf16')
-        g_ws, g_bs, g_bs_acc = [], [], []
         mtot = S * T * 64 if tiled else max(S, 1) * npad
         # where each layer's bias gradient accumulates, and whether the weight-gradient launch can take it along
         wants_gb = [ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l] for l in range(L)]
@@ -3292,6 +3289,39 @@ class _MADEForwardBF16(torch.autograd.Function):
                     and gemm_bf16_gradw_fits(widths[l], ws[l].shape[1], mtot, max(2, min(GRADW_SPLIT_MAX, mtot // 512))) for l in range(L)]
         if tiled:       # the tiled copies are read by the whole-output product alone: it takes every bias gradient along
             fused_gb = [wants_gb[l] for l in range(L)]
+        # The weight-gradient products of this MADE on a SIDE stream (a parallel branch of a captured graph): they depend on
+        # nothing later in the backward pass, and the next MADE's backward chains leave half of the CUs idle in their second
+        # round of workgroups.  Only when every result goes straight into the optimiser's gradient arena (nothing is handed
+        # back to autograd on this stream); the side stream is joined when the whole backward pass has run.
+        side = None
+        if MADE_GRADW_SIDE and tiled and ctx.row and ctx.masks is not None and S > 0 and not _several_ranks():
+            _verify_direct(ctx)
+            if (all(ctx.direct_w[l] is not None and ctx.direct_w[l].data_ptr() in GRAD_FRESH and ctx.direct_w[l].is_contiguous()
+                    for l in range(L) if ctx.needs_input_grad[3 + l])
+                    and all(direct_b[l] is not None for l in range(L) if wants_gb[l])):
+                side, main = _side('made_gradw'), torch.cuda.current_stream()
+                side.wait_stream(main)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            if ctx.row:
+                made_row_bwd(g_row, [dict(w=ws[l], act=acts0[l] if l < L - 1 else None, inp=acts0[l - 1] if l > 0 else None,
+                                          gw=row_gw[l], gb=row_gb[l]) for l in range(L)])
+            g_ws, g_bs = _MADEForwardBF16._weight_gradients(ctx, L, S, T, tiled, mtot, widths, ws, acts0, rows0, zero_row, row_gw, row_gb,
+                                                            direct_b if ctx.row else None, wants_gb, gb_target, fused_gb, gm_t, gm_t_all,
+                                                            tb if tiled else 0, xin_t, acts_t, f32, st if side is None else lib.stream())
+        if side is not None:
+            held = [gm_t, xin_t, acts_t, row_gw, row_gb, g_row, acts0, ws]      # what the side launches read, kept from the allocator until the join
+
+            def _join():
+                main.wait_stream(side)
+                held.clear()
+            torch.autograd.Variable._execution_engine.queue_callback(_join)
+        return (g_z, None, None, *g_ws, *g_bs)
+
+    @staticmethod
+    def _weight_gradients(ctx, L, S, T, tiled, mtot, widths, ws, acts0, rows0, zero_row, row_gw, row_gb, direct_b, wants_gb, gb_target,
+                          fused_gb, gm_t, gm_t_all, tb, xin_t, acts_t, f32, st):
+        """dL/dW_l, dL/db_l of every layer from the stacked passes (+ pass 0's share, already in row_gw / row_gb), the mask fold."""
+        g_ws, g_bs, g_bs_acc = [], [], []
         for l in range(L):
             mask0 = acts0[l] if l < L - 1 else None
             inp0 = zero_row if l == 0 else acts0[l - 1]
@@ -3342,13 +3372,19 @@ class _MADEForwardBF16(torch.autograd.Function):
                     g_ws[l] = None
                 else:
                     g_ws[l] = r
-        return (g_z, None, None, *g_ws, *g_bs)
+        return g_ws, g_bs
 
 
 MADE_BF16_STORAGE = _os.environ.get('GV_MADE_BF16', '1') == '1'
 GRADW_SPLIT_MAX = int(_os.environ.get('GV_GRADW_SPLIT_MAX', '256'))      # most K slices of a MADE weight-gradient product
 MADE_CHAIN_IAF = _os.environ.get('GV_MADE_CHAIN_IAF', '1') == '1'      # the IAF update inside the chain's last layer
 MADE_T_TILES = _os.environ.get('GV_MADE_T_TILES', '1') == '1'          # ... and the transposed copies in tiles of 64 rows
+MADE_GRADW_SIDE = _os.environ.get('GV_MADE_GRADW_SIDE', '1') == '1'    # a MADE's weight-gradient products beside the rest of the backward pass
+
+
+def _several_ranks():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 def made_forward(z, colcount, weights, biases, masks=None):
