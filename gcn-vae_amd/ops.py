@@ -115,6 +115,52 @@ def join(*ids):
             cur.wait_stream(_side(i))
 
 
+# Parameter gradients BESIDE the backward pass.  A launch whose only consumer is the optimiser (a weight gradient written straight
+# into the gradient arena) need not hold up the kernels that feed autograd: it goes to one side stream -- a parallel branch of a
+# captured graph -- and that stream is joined once, when the engine has run the whole backward pass (the optimiser step comes after).
+# What such launches read is kept from the allocator until the join (autograd frees a node's saved tensors as soon as the node ran).
+# Off with several ranks: there the gradients feed all-reduces that are started inside the backward pass.
+# Used by the MADE backward (weight-gradient products that need one workgroup per CU, beside backward chains whose second round
+# of workgroups leaves half of the CUs idle: -0.13 ms at WN18RR size).  NOT by the R-GCN layers' or the decoder's weight
+# gradients: beside kernels that fill the chip on their own they cost more than they hide (FB15k-237: 1.047 -> 1.089 ms per step,
+# the mini-batch step 0.98 -> 1.11).
+BWD_SIDE = _os.environ.get('GV_BWD_SIDE', '1') == '1'
+_bwd_side_held = []
+
+
+def _several_ranks():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+@contextlib.contextmanager
+def backward_side(enabled, *held):
+    """Inside an autograd backward: run the enclosed launches on the side stream (after everything already enqueued); ``held``:
+    the tensors they touch.  Yields whether the side stream is in use."""
+    if not (enabled and BWD_SIDE) or lib.TIMER is not None or _several_ranks():      # (timed launches run alone: bench.py's per-kernel lines)
+        yield False
+        return
+    side, main = _side('bwd'), torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        yield True
+    first = not _bwd_side_held
+    _bwd_side_held.append(held)
+    if first:
+        def _join():
+            main.wait_stream(side)
+            _bwd_side_held.clear()
+        torch.autograd.Variable._execution_engine.queue_callback(_join)
+
+
+def backward_side_finish():
+    """Join the side stream if a backward pass left work on it without reaching its end (an exception inside the pass): called
+    by the optimiser before it reads or clears the gradient arena."""
+    if _bwd_side_held:
+        torch.cuda.current_stream().wait_stream(_side('bwd'))
+        _bwd_side_held.clear()
+
+
 class StayOnDevice:
     """Mixin of the HIP modules: once their parameters live on a ROCm device, ``module.cpu()`` / ``.to('cpu')`` leaves them
     there.  The reference moves its model to the host for validation (kgvae/link_predict.py:239-242, "full graph is too
@@ -3103,8 +3149,8 @@ class _MADEForwardBF16(torch.autograd.Function):
             tbufs, T, tt = _empty_t_tiles([d] + widths[:L - 1], S, n, bf)
         else:
             tbufs, tt = _empty_t_padded([d] + widths[:L - 1], max(S, 1), n, npad, bf)[:-1], 0
-        t_of = (lambda buf, q: dict(out_bf16_t=buf[q * T:], t_tile=tt)) if tiled else \
-               (lambda buf, q: dict(out_bf16_t=buf[:, q * npad:q * npad + n]))
+        t_of = (lambda buf, q, r0=0: dict(out_bf16_t=buf[q * T + r0 // 64:], t_tile=tt)) if tiled else \
+               (lambda buf, q, r0=0: dict(out_bf16_t=buf[:, q * npad:q * npad + n]))
         xin_t = tbufs[0]
         # fused (the IAF update inside the chain): row-major activations never leave the chain (the backward chain stages its ReLU
         # masks from the transposed copies), and of [mu | alpha] only exp(alpha + mu) is kept (+ alpha of the last pass)
@@ -3142,24 +3188,30 @@ class _MADEForwardBF16(torch.autograd.Function):
             else:
                 lib.call('gv_iaf_update_fwd', ptr(z), ptr(net), ld_net, ptr(x_old), ptr(cc), ptr(x_out), n, d, st)
         update(acts0[L - 1], 0, z, colcount[0], 0)
-        for p in range(1, P):
+
+        def fused_passes(r0, r1):
+            """Passes 1 .. P-1 for the rows [r0, r1) (r0 a multiple of 64): every launch of a pass is row-local."""
+            for p in range(1, P):
+                a, b, na, nb_ = (p - 1) * n + r0, (p - 1) * n + r1, p * n + r0, p * n + r1
+                # the pass's IAF update in the last layer's epilogue: x_new and its operand copies leave the chain
+                head = dict(w_packed=wbf[L - 1], n=widths[L - 1], k=ws[L - 1].shape[1], bias=bs[L - 1],
+                            iaf=dict(z=z[r0:r1], x_old=xin[a:b], colcount=colcount[p], ex=net_out[a:b]))
+                if p < S:   # fp32 x_new only where the next pass hands a column through; its operands in bf16
+                    head['iaf'].update(x_new=xin[na:nb_], keep=colcount[p + 1])
+                    head.update(out_bf16=xin_b[na:nb_], **t_of(xin_t, p, r0))
+                else:
+                    head['iaf'].update(x_new=x_out[r0:r1], alpha=alpha_last[r0:r1])
+                made_chain(xin_b[a:b], r1 - r0, [dict(w_packed=wbf[l], n=widths[l], k=ws[l].shape[1], bias=bs[l], relu=True,
+                                                      out_bits=sign[l][a:b], **t_of(acts_t[l], p - 1, r0)) for l in range(L - 1)] + [head],
+                           tag='madechain_fwd')
+        if fused:
+            _by_row_blocks(fused_passes, n, tiled)
+        for p in range(1, P) if not fused else ():
             sl = slice((p - 1) * n, p * n)
             tsl = slice((p - 1) * npad, (p - 1) * npad + n)
             inp = xin_b[sl]
             if chain:
                 head = dict(w_packed=wbf[L - 1], n=widths[L - 1], k=ws[L - 1].shape[1], bias=bs[L - 1])
-                if fused:       # the pass's IAF update in the last layer's epilogue: x_new and its operand copies leave the chain
-                    nsl = slice(p * n, (p + 1) * n)
-                    head['iaf'] = dict(z=z, x_old=xin[sl], colcount=colcount[p], ex=net_out[sl])
-                    if p < S:   # fp32 x_new only where the next pass hands a column through; its operands in bf16
-                        head['iaf'].update(x_new=xin[nsl], keep=colcount[p + 1])
-                        head.update(out_bf16=xin_b[nsl], **t_of(xin_t, p))
-                    else:
-                        head['iaf'].update(x_new=x_out, alpha=alpha_last)
-                    made_chain(inp, n, [dict(w_packed=wbf[l], n=widths[l], k=ws[l].shape[1], bias=bs[l], relu=True,
-                                             out_bits=sign[l][sl], **t_of(acts_t[l], p - 1)) for l in range(L - 1)] + [head],
-                               tag='madechain_fwd')
-                    continue
                 head['out_f32'] = net_out[sl]
                 made_chain(inp, n, [dict(w_packed=wbf[l], n=widths[l], k=ws[l].shape[1], bias=bs[l], relu=True,
                                          out_bf16=acts_b[l][sl], out_bf16_t=acts_t[l][:, tsl]) for l in range(L - 1)] + [head],
@@ -3219,35 +3271,46 @@ class _MADEForwardBF16(torch.autograd.Function):
         if tiled:
             gm_t, _, tb = _empty_t_tiles(widths, S, n, bf)
             gm_t_all = None
-            t_of = lambda buf, q: dict(out_bf16_t=buf[q * T:], t_tile=tb)
+            t_of = lambda buf, q, r0=0: dict(out_bf16_t=buf[q * T + r0 // 64:], t_tile=tb)
         else:
             *gm_t, gm_t_all = _empty_t_padded(widths, max(S, 1), n, npad, bf)
-            t_of = lambda buf, q: dict(out_bf16_t=buf[:, q * npad:q * npad + n])
+            t_of = lambda buf, q, r0=0: dict(out_bf16_t=buf[:, q * npad:q * npad + n])
         g_z = torch.empty(n, d, **f32) if (ctx.fused and P > 1) else torch.zeros(n, d, **f32)      # fused: the first pass writes it
         gz_p = torch.empty(n, d, **f32)
         g_cur = gx
-        for p in reversed(range(1, P)):
-            sl = slice((p - 1) * n, p * n)
-            tsl = slice((p - 1) * npad, (p - 1) * npad + n)
-            g_old = torch.empty(n, d, **f32)
-            if ctx.fused:
+        g_olds = {p: torch.empty(n, d, **f32) for p in range(1, P)} if ctx.fused else None      # dL/dx_old of every pass (allocated before any fork)
+
+        def fused_passes(r0, r1):
+            """The backward of passes P-1 .. 1 for the rows [r0, r1) (r0 a multiple of 64): every launch of a pass is row-local."""
+            g_in = gx
+            for p in reversed(range(1, P)):
+                a, b, t0 = (p - 1) * n + r0, (p - 1) * n + r1, r0 // 64
                 # from exp(alpha + mu); the gradient handed through to x_old (columns of count 0) is added by the chain's last layer
                 # without a log-det gradient (every pass but the last) g_alpha == g_mu: the chain's row-major input holds the g_mu half
                 # alone and the chain stages it twice (x_dup_half)
                 half = (gld is None or p != P - 1) and widths[L - 1] % 16 == 0 and L > 1
-                lib.call('gv_iaf_update_bwd_bf16_ex', ptr(z), ptr(net_out[sl]), d, ptr(colcount[p]), ptr(g_cur),
-                         ptr(gld) if p == P - 1 else None, ptr(g_z), ptr(gm_in), gm_in.stride(0),
-                         ptr(gm_t[L - 1][(p - 1) * T:] if tiled else gm_t[L - 1][:, tsl]), tb if tiled else gm_t[L - 1].stride(0), None,
-                         (1 if p == P - 1 else 0) | (2 if half else 0) | (4 if tiled else 0), n, d, st)
-                first = dict(w_packed=wbt[L - 1], n=widths[L - 2], k=widths[L - 1], mask_bits=acts_b[L - 2][sl],
-                             x_dup_half=half, **t_of(gm_t[L - 2], p - 1)) if L > 1 else None
-                made_chain(gm_in, n,
+                lib.call('gv_iaf_update_bwd_bf16_ex', ptr(z[r0:r1]), ptr(net_out[a:b]), d, ptr(colcount[p]), ptr(g_in[r0:r1]),
+                         ptr(gld[r0:r1]) if (p == P - 1 and gld is not None) else None, ptr(g_z[r0:r1]), ptr(gm_in[r0:r1]), gm_in.stride(0),
+                         ptr(gm_t[L - 1][(p - 1) * T + t0:] if tiled else gm_t[L - 1][:, (p - 1) * npad:]),
+                         tb if tiled else gm_t[L - 1].stride(0), None,
+                         (1 if p == P - 1 else 0) | (2 if half else 0) | (4 if tiled else 0), r1 - r0, d, lib.stream())
+                first = dict(w_packed=wbt[L - 1], n=widths[L - 2], k=widths[L - 1], mask_bits=acts_b[L - 2][a:b],
+                             x_dup_half=half, **t_of(gm_t[L - 2], p - 1, r0)) if L > 1 else None
+                made_chain(gm_in[r0:r1], r1 - r0,
                            ([first] if first is not None else []) +
-                           [dict(w_packed=wbt[l], n=widths[l - 1], k=widths[l], mask_bits=acts_b[l - 1][sl],
-                                 **t_of(gm_t[l - 1], p - 1)) for l in reversed(range(1, L - 1))] +
-                           [dict(w_packed=wbt[0], n=d, k=widths[0], out_f32=g_old, add=(g_cur, colcount[p]))], tag='madechain_bwd')
-                g_cur = g_old
-                continue
+                           [dict(w_packed=wbt[l], n=widths[l - 1], k=widths[l], mask_bits=acts_b[l - 1][a:b],
+                                 **t_of(gm_t[l - 1], p - 1, r0)) for l in reversed(range(1, L - 1))] +
+                           [dict(w_packed=wbt[0], n=d, k=widths[0], out_f32=g_olds[p][r0:r1], add=(g_in[r0:r1], colcount[p]))],
+                           tag='madechain_bwd')
+                g_in = g_olds[p]
+        if ctx.fused:
+            _by_row_blocks(fused_passes, n, tiled)
+            if P > 1:
+                g_cur = g_olds[1]
+        for p in reversed(range(1, P)) if not ctx.fused else ():
+            sl = slice((p - 1) * n, p * n)
+            tsl = slice((p - 1) * npad, (p - 1) * npad + n)
+            g_old = torch.empty(n, d, **f32)
             # the update's backward: g_z accumulated in place, [g_mu | g_alpha] straight into the bf16 operands of the products
             lib.call('gv_iaf_update_bwd_bf16', ptr(z), ptr(net_out[sl]), 2 * d, ptr(colcount[p]), ptr(g_cur),
                      ptr(gld) if p == P - 1 else None, ptr(g_z), ptr(gm_b[L - 1][sl]), gm_b[L - 1].stride(0),
@@ -3293,28 +3356,19 @@ class _MADEForwardBF16(torch.autograd.Function):
         # nothing later in the backward pass, and the next MADE's backward chains leave half of the CUs idle in their second
         # round of workgroups.  Only when every result goes straight into the optimiser's gradient arena (nothing is handed
         # back to autograd on this stream); the side stream is joined when the whole backward pass has run.
-        side = None
-        if MADE_GRADW_SIDE and tiled and ctx.row and ctx.masks is not None and S > 0 and not _several_ranks():
+        beside = False
+        if tiled and ctx.row and ctx.masks is not None and S > 0:
             _verify_direct(ctx)
-            if (all(ctx.direct_w[l] is not None and ctx.direct_w[l].data_ptr() in GRAD_FRESH and ctx.direct_w[l].is_contiguous()
-                    for l in range(L) if ctx.needs_input_grad[3 + l])
-                    and all(direct_b[l] is not None for l in range(L) if wants_gb[l])):
-                side, main = _side('made_gradw'), torch.cuda.current_stream()
-                side.wait_stream(main)
-        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            beside = (all(ctx.direct_w[l] is not None and ctx.direct_w[l].data_ptr() in GRAD_FRESH and ctx.direct_w[l].is_contiguous()
+                          for l in range(L) if ctx.needs_input_grad[3 + l])
+                      and all(direct_b[l] is not None for l in range(L) if wants_gb[l]))
+        with backward_side(beside, gm_t, xin_t, acts_t, row_gw, row_gb, g_row, acts0, ws):
             if ctx.row:
                 made_row_bwd(g_row, [dict(w=ws[l], act=acts0[l] if l < L - 1 else None, inp=acts0[l - 1] if l > 0 else None,
                                           gw=row_gw[l], gb=row_gb[l]) for l in range(L)])
             g_ws, g_bs = _MADEForwardBF16._weight_gradients(ctx, L, S, T, tiled, mtot, widths, ws, acts0, rows0, zero_row, row_gw, row_gb,
                                                             direct_b if ctx.row else None, wants_gb, gb_target, fused_gb, gm_t, gm_t_all,
-                                                            tb if tiled else 0, xin_t, acts_t, f32, st if side is None else lib.stream())
-        if side is not None:
-            held = [gm_t, xin_t, acts_t, row_gw, row_gb, g_row, acts0, ws]      # what the side launches read, kept from the allocator until the join
-
-            def _join():
-                main.wait_stream(side)
-                held.clear()
-            torch.autograd.Variable._execution_engine.queue_callback(_join)
+                                                            tb if tiled else 0, xin_t, acts_t, f32, lib.stream())
         return (g_z, None, None, *g_ws, *g_bs)
 
     @staticmethod
@@ -3379,12 +3433,53 @@ MADE_BF16_STORAGE = _os.environ.get('GV_MADE_BF16', '1') == '1'
 GRADW_SPLIT_MAX = int(_os.environ.get('GV_GRADW_SPLIT_MAX', '256'))      # most K slices of a MADE weight-gradient product
 MADE_CHAIN_IAF = _os.environ.get('GV_MADE_CHAIN_IAF', '1') == '1'      # the IAF update inside the chain's last layer
 MADE_T_TILES = _os.environ.get('GV_MADE_T_TILES', '1') == '1'          # ... and the transposed copies in tiles of 64 rows
-MADE_GRADW_SIDE = _os.environ.get('GV_MADE_GRADW_SIDE', '1') == '1'    # a MADE's weight-gradient products beside the rest of the backward pass
 
 
-def _several_ranks():
-    import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+MADE_ROW_BLOCKS = int(_os.environ.get('GV_MADE_ROW_BLOCKS', '2'))       # independent row blocks of a MADE's passes (1: off)
+MADE_ROW_BLOCKS_MIN_TILES = int(_os.environ.get('GV_MADE_ROW_BLOCKS_MIN_TILES', '0'))     # 0: more row tiles than chain workgroups fit the chip
+_chain_slots = {}
+
+
+def _made_row_blocks(n):
+    """Row ranges a MADE's passes are run over, as independent launch sequences on their own streams.  Every launch of a pass is
+    row-local (a chain workgroup owns 64 rows through all layers, the update and its backward are element-wise), so the passes of
+    one row block depend on nothing in another block -- but as ONE sequence of launches every pass waits for the last workgroup
+    of the one before it.  That is expensive here: two chain workgroups fit a CU, so the 640 workgroups of a WN18RR pass run a
+    second round on a quarter of the chip (forward chain: 60 us at 512 row tiles, 88 us at 576), and the chain (latency-bound,
+    ~2 TB/s) alternates with the update's backward (bandwidth-bound) instead of running beside it.  Two blocks of 320 row tiles
+    on two streams: 6.32 -> 5.72 ms per step (blocks cut at the last full round of workgroups, 512 + 128 tiles: 6.01; three
+    blocks 6.08, four 6.46).  Only where a pass has more row tiles than the chip holds chain workgroups: at FB15k-237 size (228
+    tiles, one partial round) two blocks cost 3.36 -> 3.42 ms."""
+    tiles = (n + 63) // 64
+    least = MADE_ROW_BLOCKS_MIN_TILES
+    if least <= 0:
+        dev = torch.cuda.current_device()
+        if dev not in _chain_slots:
+            _chain_slots[dev] = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+        least = _chain_slots[dev] + 1
+    k = MADE_ROW_BLOCKS if tiles >= least else 1
+    k = max(1, min(k, tiles))
+    cuts = [(tiles * i // k) * 64 for i in range(k)] + [n]
+    return [(cuts[i], cuts[i + 1]) for i in range(k)]
+
+
+def _by_row_blocks(run, n, tiled):
+    """run(r0, r1) over the row blocks of _made_row_blocks: the first on the current stream, the others on side streams that are
+    joined before returning (under hipGraph capture: parallel branches)."""
+    blocks = _made_row_blocks(n) if (tiled and lib.TIMER is None) else [(0, n)]      # (timed launches are whole launches: bench.py's K4 line)
+    if len(blocks) == 1:
+        run(0, n)
+        return
+    main = torch.cuda.current_stream()
+    sides = [_side(('made_rows', i)) for i in range(1, len(blocks))]
+    for sd in sides:
+        sd.wait_stream(main)
+    run(*blocks[0])
+    for sd, blk in zip(sides, blocks[1:]):
+        with torch.cuda.stream(sd):
+            run(*blk)
+    for sd in sides:
+        main.wait_stream(sd)
 
 
 def made_forward(z, colcount, weights, biases, masks=None):

@@ -78,6 +78,7 @@ class FlatAdam:
             ops.GRAD_FRESH.add(p.grad.data_ptr())
 
     def zero_grad(self):
+        ops.backward_side_finish()
         # the clip+Adam kernel clears the arena as it consumes it: right after step() there is nothing to do
         if self._clean:
             self._clean = False
@@ -91,6 +92,7 @@ class FlatAdam:
         return self.sumsq.sqrt()
 
     def step(self):
+        ops.backward_side_finish()        # (a no-op after a backward pass that ran to its end)
         if self.max_grad_norm is not None:
             lib.call('gv_clip_adam_step', ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
                      self.total, ptr(self._ws), ptr(self.sumsq), float(self.max_grad_norm), float(self.lr),

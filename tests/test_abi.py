@@ -127,3 +127,7 @@ def test_round3_entry_points_validate_their_arguments_on_the_host():
     layers = (ops._ChainLayer * 1)()
     layers[0].n, layers[0].k = 200, 200
     assert l.gv_made_chain(None, 200, 64, 1, ctypes.addressof(layers), None) != 0
+    # the 64-row-tile forms: tile distances are checked against the row counts before anything is launched
+    assert l.gv_gemm_bf16_gradw_tiles(None, 64 * 200, None, 64 * 200, 200, 200, 4096, None, 1, None, 8, None, 0, None) != 0 and 'NULL' in lib.last_error()
+    assert l.gv_iaf_update_fwd_bf16_tiles(None, None, 400, None, None, None, None, 200, None, 64 * 200, 0, 200, None) == 0    # n == 0
+    assert l.gv_iaf_update_fwd_bf16_tiles(None, None, 400, None, None, None, None, 200, None, 0, 10, 200, None) != 0 and 't_tile' in lib.last_error()

@@ -712,6 +712,42 @@ def test_train_driver_with_graph_step(tmp_path, capsys, bf16):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('blocks', [2, 3])
+def test_made_passes_over_row_blocks_on_their_own_streams_give_the_same_bits(monkeypatch, blocks):
+    """ops._by_row_blocks: the bf16 MADE node runs its passes over independent row blocks on side streams (every launch of a pass
+    is row-local) -- outputs and every gradient equal the one-block run bit for bit, also when the block boundary is not the end
+    of the rows' last 64-row tile and with the weight gradients going through the optimiser arena (the side-stream products)."""
+    from gcn_vae_amd import ops
+    from gcn_vae_amd.flows import MADE
+    from gcn_vae_amd.optim import FlatAdam
+    n, d = 1000, 40                       # 16 row tiles, the last one partial
+    z = torch.randn(n, d, generator=torch.Generator().manual_seed(5)).cuda()
+    res, seen = [], []
+    inner = ops._by_row_blocks
+    monkeypatch.setattr(ops, '_by_row_blocks', lambda run, rows, tiled: (seen.append((rows, tiled)), inner(run, rows, tiled))[1])
+    for k in (1, blocks):
+        monkeypatch.setattr(ops, 'MADE_ROW_BLOCKS', k)
+        monkeypatch.setattr(ops, 'MADE_ROW_BLOCKS_MIN_TILES', 1)
+        torch.manual_seed(3)
+        m = MADE(d, 56, 2).cuda()
+        opt = FlatAdam(list(m.parameters()), lr=1e-3, max_grad_norm=1.0)
+        opt.zero_grad()
+        with ops.gemm_precision('bf16'):
+            zz = z.clone().requires_grad_(True)
+            x, ld = m(zz)
+            (x.sin().sum() + (ld * ld).sum()).backward()
+        torch.cuda.synchronize()
+        res.append((x.detach().clone(), ld.detach().clone(), zz.grad.clone(), [p.grad.detach().clone() for p in m.parameters()]))
+        opt.close()
+    assert len(ops._made_row_blocks(n)) == blocks and ops._made_row_blocks(n)[1][0] % 64 == 0
+    assert seen and all(t for _, t in seen)            # the node took the path with the tiled copies (the one that is split)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert float(res[0][2].abs().max()) > 0
+    for a, b in zip(res[0][3], res[1][3]):
+        assert torch.equal(a, b) and float(a.abs().max()) > 0
+
+
+@pytest.mark.gpu
 def test_made_gradients_written_straight_into_the_optimiser_arena_equal_autograd():
     """With FlatAdam registered, MaskedLinear's masked weight gradient and the bf16 MADE node's bias gradients are stored
     straight into the (all-zero) arena slices instead of going through AccumulateGrad: same numbers as plain autograd, and a
