@@ -2767,15 +2767,18 @@ class _MADEForward(torch.autograd.Function):
         first_out = xin[0:n] if P > 1 else x_out
         # (columns outside the first index set would keep x_old = 0: flows.MADE checks at construction that there are none)
         lib.call('gv_iaf_update_fwd', ptr(z), ptr(acts0[L - 1]), 0, ptr(z), ptr(colcount[0]), ptr(first_out), n, d, st)
-        for p in range(1, P):
-            sl = slice((p - 1) * n, p * n)
-            inp = xin[sl]
-            for l in range(L):
-                out = acts[l][sl]
-                gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE, out=out)
-                inp = out
-            nxt = xin[p * n:(p + 1) * n] if p + 1 < P else x_out
-            lib.call('gv_iaf_update_fwd', ptr(z), ptr(inp), 2 * d, ptr(xin[sl]), ptr(colcount[p]), ptr(nxt), n, d, st)
+        def passes(r0, r1):      # passes 1 .. P-1 for the rows [r0, r1): every launch of a pass is row-local
+            for p in range(1, P):
+                a, b = (p - 1) * n + r0, (p - 1) * n + r1
+                inp = xin[a:b]
+                for l in range(L):
+                    out = acts[l][a:b]
+                    gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE, out=out)
+                    inp = out
+                nxt = xin[p * n + r0:p * n + r1] if p + 1 < P else x_out[r0:r1]
+                lib.call('gv_iaf_update_fwd', ptr(z[r0:r1]), ptr(inp), 2 * d, ptr(xin[a:b]), ptr(colcount[p]), ptr(nxt), r1 - r0, d,
+                         lib.stream())
+        _by_row_blocks(passes, n, MADE_F32_ROW_BLOCKS, MADE_F32_ROW_BLOCKS_MIN_TILES)
         log_det = torch.empty(n, **f32)
         if P > 1:
             lib.call('gv_rowsum', ptr(acts[L - 1][(S - 1) * n:]), 2 * d, d, d, ptr(log_det), n, st)
@@ -2802,20 +2805,26 @@ class _MADEForward(torch.autograd.Function):
         grads = [torch.empty(max(S, 1) * n, ws[l].shape[0], **f32) for l in range(L)]   # grad w.r.t. each layer's OUTPUT
         g_z = torch.zeros(n, d, **f32)
         gz_p = torch.empty(n, d, **f32)
-        g_cur = gx
-        for p in reversed(range(1, P)):
-            sl = slice((p - 1) * n, p * n)
-            g_old = torch.empty(n, d, **f32)
-            lib.call('gv_iaf_update_bwd', ptr(z), ptr(acts[L - 1][sl]), 2 * d, ptr(colcount[p]), ptr(g_cur),
-                     ptr(gld) if p == P - 1 else None, ptr(gz_p), ptr(grads[L - 1][sl]), ptr(g_old), n, d, st)
-            lib.call('gv_axpby', n * d, None, 1.0, ptr(gz_p), 1.0, ptr(g_z), st)
-            for l in reversed(range(L)):
-                mask = acts[l][sl] if l < L - 1 else None
-                if l > 0:
-                    gemm(grads[l][sl], ws[l], out=grads[l - 1][sl], a_relu_mask=mask)
-                else:       # gradient w.r.t. the pass's input x_p joins the update's pass-through gradient
-                    gemm(grads[0][sl], ws[0], out=g_old, accumulate=True, a_relu_mask=mask)
-            g_cur = g_old
+        g_olds = {p: torch.empty(n, d, **f32) for p in range(1, P)}      # dL/dx_old of every pass (allocated before any fork)
+
+        def passes(r0, r1):      # the backward of passes P-1 .. 1 for the rows [r0, r1): every launch is row-local
+            g_in, m = gx, r1 - r0
+            for p in reversed(range(1, P)):
+                a, b = (p - 1) * n + r0, (p - 1) * n + r1
+                g_old = g_olds[p][r0:r1]
+                lib.call('gv_iaf_update_bwd', ptr(z[r0:r1]), ptr(acts[L - 1][a:b]), 2 * d, ptr(colcount[p]), ptr(g_in[r0:r1]),
+                         ptr(gld[r0:r1]) if (p == P - 1 and gld is not None) else None, ptr(gz_p[r0:r1]), ptr(grads[L - 1][a:b]),
+                         ptr(g_old), m, d, lib.stream())
+                lib.call('gv_axpby', m * d, None, 1.0, ptr(gz_p[r0:r1]), 1.0, ptr(g_z[r0:r1]), lib.stream())
+                for l in reversed(range(L)):
+                    mask = acts[l][a:b] if l < L - 1 else None
+                    if l > 0:
+                        gemm(grads[l][a:b], ws[l], out=grads[l - 1][a:b], a_relu_mask=mask)
+                    else:       # gradient w.r.t. the pass's input x_p joins the update's pass-through gradient
+                        gemm(grads[0][a:b], ws[0], out=g_old, accumulate=True, a_relu_mask=mask)
+                g_in = g_olds[p]
+        _by_row_blocks(passes, n, MADE_F32_ROW_BLOCKS, MADE_F32_ROW_BLOCKS_MIN_TILES)
+        g_cur = g_olds[1] if P > 1 else gx
         # pass 0: the update's gradient w.r.t. the broadcast net row is its column sum; x_old was the zero matrix
         g_row = iaf_bwd_row0(z, acts0[L - 1], colcount[0], g_cur, gld if P == 1 else None, g_z)      # (1, 2D)
         rows0 = [None] * L                                        # masked single-row gradients per layer output
@@ -3205,7 +3214,7 @@ class _MADEForwardBF16(torch.autograd.Function):
                                                       out_bits=sign[l][a:b], **t_of(acts_t[l], p - 1, r0)) for l in range(L - 1)] + [head],
                            tag='madechain_fwd')
         if fused:
-            _by_row_blocks(fused_passes, n, tiled)
+            _by_row_blocks(fused_passes, n, None if tiled else 1)
         for p in range(1, P) if not fused else ():
             sl = slice((p - 1) * n, p * n)
             tsl = slice((p - 1) * npad, (p - 1) * npad + n)
@@ -3304,7 +3313,7 @@ class _MADEForwardBF16(torch.autograd.Function):
                            tag='madechain_bwd')
                 g_in = g_olds[p]
         if ctx.fused:
-            _by_row_blocks(fused_passes, n, tiled)
+            _by_row_blocks(fused_passes, n, None if tiled else 1)
             if P > 1:
                 g_cur = g_olds[1]
         for p in reversed(range(1, P)) if not ctx.fused else ():
@@ -3436,11 +3445,15 @@ MADE_T_TILES = _os.environ.get('GV_MADE_T_TILES', '1') == '1'          # ... and
 
 
 MADE_ROW_BLOCKS = int(_os.environ.get('GV_MADE_ROW_BLOCKS', '2'))       # independent row blocks of a MADE's passes (1: off)
+# ... of the fp32 node (a launch per product: 9.47 -> 9.33 ms for the mini-batch step with 3 IAF blocks, 9.52 -> 9.32 on the full
+# FB15k-237-sized graph; three blocks 10.4), from 128 row tiles on
+MADE_F32_ROW_BLOCKS = int(_os.environ.get('GV_MADE_F32_ROW_BLOCKS', '2'))
+MADE_F32_ROW_BLOCKS_MIN_TILES = int(_os.environ.get('GV_MADE_F32_ROW_BLOCKS_MIN_TILES', '128'))
 MADE_ROW_BLOCKS_MIN_TILES = int(_os.environ.get('GV_MADE_ROW_BLOCKS_MIN_TILES', '0'))     # 0: more row tiles than chain workgroups fit the chip
 _chain_slots = {}
 
 
-def _made_row_blocks(n):
+def _made_row_blocks(n, want=None, min_tiles=None):
     """Row ranges a MADE's passes are run over, as independent launch sequences on their own streams.  Every launch of a pass is
     row-local (a chain workgroup owns 64 rows through all layers, the update and its backward are element-wise), so the passes of
     one row block depend on nothing in another block -- but as ONE sequence of launches every pass waits for the last workgroup
@@ -3450,23 +3463,27 @@ def _made_row_blocks(n):
     on two streams: 6.32 -> 5.72 ms per step (blocks cut at the last full round of workgroups, 512 + 128 tiles: 6.01; three
     blocks 6.08, four 6.46).  Only where a pass has more row tiles than the chip holds chain workgroups: at FB15k-237 size (228
     tiles, one partial round) two blocks cost 3.36 -> 3.42 ms."""
+    want = MADE_ROW_BLOCKS if want is None else want
+    if want <= 1:
+        return [(0, n)]
     tiles = (n + 63) // 64
-    least = MADE_ROW_BLOCKS_MIN_TILES
+    least = MADE_ROW_BLOCKS_MIN_TILES if min_tiles is None else min_tiles
     if least <= 0:
         dev = torch.cuda.current_device()
         if dev not in _chain_slots:
             _chain_slots[dev] = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
         least = _chain_slots[dev] + 1
-    k = MADE_ROW_BLOCKS if tiles >= least else 1
+    k = want if tiles >= least else 1
     k = max(1, min(k, tiles))
     cuts = [(tiles * i // k) * 64 for i in range(k)] + [n]
     return [(cuts[i], cuts[i + 1]) for i in range(k)]
 
 
-def _by_row_blocks(run, n, tiled):
-    """run(r0, r1) over the row blocks of _made_row_blocks: the first on the current stream, the others on side streams that are
-    joined before returning (under hipGraph capture: parallel branches)."""
-    blocks = _made_row_blocks(n) if (tiled and lib.TIMER is None) else [(0, n)]      # (timed launches are whole launches: bench.py's K4 line)
+def _by_row_blocks(run, n, want, min_tiles=None):
+    """run(r0, r1) over the row blocks of _made_row_blocks (want: how many, None: MADE_ROW_BLOCKS; <= 1: all rows at once): the
+    first on the current stream, the others on side streams that are joined before returning (under hipGraph capture: parallel
+    branches)."""
+    blocks = _made_row_blocks(n, want, min_tiles) if lib.TIMER is None else [(0, n)]      # (timed launches are whole launches: bench.py's K4 line)
     if len(blocks) == 1:
         run(0, n)
         return

@@ -724,7 +724,7 @@ def test_made_passes_over_row_blocks_on_their_own_streams_give_the_same_bits(mon
     z = torch.randn(n, d, generator=torch.Generator().manual_seed(5)).cuda()
     res, seen = [], []
     inner = ops._by_row_blocks
-    monkeypatch.setattr(ops, '_by_row_blocks', lambda run, rows, tiled: (seen.append((rows, tiled)), inner(run, rows, tiled))[1])
+    monkeypatch.setattr(ops, '_by_row_blocks', lambda run, rows, want, *a: (seen.append((rows, want is None)), inner(run, rows, want, *a))[1])
     for k in (1, blocks):
         monkeypatch.setattr(ops, 'MADE_ROW_BLOCKS', k)
         monkeypatch.setattr(ops, 'MADE_ROW_BLOCKS_MIN_TILES', 1)
