@@ -214,6 +214,8 @@ class KGVAE(ops.StayOnDevice, nn.Module):
         self.node_id = h.squeeze()
         if self.row_part is not None:
             return self._forward_rows(g, h, r, norm)
+        if self.n_flows > 0:      # the flows' parameter-only work (mask folds, packed weights, pass 0's row) beside the encoder's layers
+            ops.made_prepare([f.call_arguments() for f in self.nf if isinstance(f, MADE)])
         h = self.input_layer(g, h, r, norm)
         eps = self._draw_noise(h.shape[0], h.device)
         h = self.rconv_layer_1(g, h, r, norm)
@@ -227,6 +229,7 @@ class KGVAE(ops.StayOnDevice, nn.Module):
         self._z_pri_flowed = None
         if self.n_flows > 0:
             z, log_det_sum = self._apply_flows(z)
+            ops.made_prepare_finish()
             if self.rows_dev is None:
                 self.flow_log_prob = torch.mean(log_det_sum.view(-1, 1))
             else:       # static-shape batch: the mean runs over the rows that exist (device count), padding rows masked out

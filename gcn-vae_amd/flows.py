@@ -71,10 +71,16 @@ class MADE(ops.StayOnDevice, nn.Module):
             x = layer(x, ops.ACT_RELU if i + 1 < len(lin) else ops.ACT_NONE, w)
         return x
 
-    def forward(self, z):
+    def call_arguments(self):
+        """(colcount, weights, biases, masks) of the node forward() runs: what ops.made_prepare needs to do the parameter-only part
+        of the call ahead of time."""
         lin = self._linears()
+        return self._colcount, [l.weight for l in lin], [l.bias for l in lin], [l.mask for l in lin]
+
+    def forward(self, z):
+        colcount, weights, biases, masks = self.call_arguments()
         # masks folded once per call, not per pass (the bf16 node folds all layers in one launch, forward and backward)
-        return ops.made_forward(z, self._colcount, [l.weight for l in lin], [l.bias for l in lin], masks=[l.mask for l in lin])
+        return ops.made_forward(z, colcount, weights, biases, masks=masks)
 
     def forward_unfused(self, z):
         """The same computation as a chain of per-op autograd nodes (kept for cross-checking the fused node)."""

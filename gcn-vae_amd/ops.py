@@ -3107,6 +3107,77 @@ def gemm_bf16_gradw_tiles(a, a_tile, b, b_tile, m, n, k, c_f32, accumulate=True,
              ptr(a_rowsum), split_k, ptr(ws), ws_bytes, lib.stream())
 
 
+def _made_params_work(masks, ws, bs, d, S):
+    """The part of a bf16 MADE forward that depends on the parameters alone: the mask fold (one launch for all layers), the
+    weights as bf16 -- fragment-packed for the chain kernel, forward and transposed form -- and pass 0 on its single zero row."""
+    if masks is not None:
+        ws = mul_multi(masks, ws)
+    L = len(ws)
+    dev = ws[0].device
+    f32 = dict(dtype=torch.float32, device=dev)
+    bf = dict(dtype=torch.bfloat16, device=dev)
+    widths = [w.shape[0] for w in ws]
+    chain = (MADE_CHAIN and S > 0 and L <= 8 and made_chain_fits(widths, [w.shape[1] for w in ws], False)
+             and made_chain_fits([w.shape[1] for w in reversed(ws)], [w.shape[0] for w in reversed(ws)], True))
+    fused = chain and MADE_CHAIN_IAF and d % 8 == 0 and widths[L - 1] == 2 * d
+    if chain:       # one launch per pass: fragment-packed weights (forward and transposed form from one launch per layer)
+        packed = made_pack_weights(ws, iaf_last=fused)
+        wbf, wbt = [pk[0] for pk in packed], [pk[1] for pk in packed]
+    else:
+        wbf = [torch.empty(w.shape[0], _pad8(w.shape[1]), **bf) for w in ws]
+        wbt = [torch.empty(w.shape[1], _pad8(w.shape[0]), **bf) for w in ws]
+        for w, a_, t_ in zip(ws, wbf, wbt):
+            cast_bf16(w, a_, t_)
+    # pass 0 on a single zero row (tiny: the generic GEMM with bf16-rounded operands)
+    zero_row = torch.zeros(1, d, **f32)
+    row = MADE_ROW and L <= 8 and d <= 512 and max(widths) <= 512 and all(w.shape[1] % 4 == 0 for w in ws)
+    if row:         # one single-workgroup launch for the whole row
+        acts0 = [torch.empty(1, widths[l], **f32) for l in range(L)]
+        made_row_fwd(None, [dict(w=ws[l], bias=bs[l], relu=l < L - 1, out=acts0[l]) for l in range(L)])
+    else:
+        acts0, inp = [], zero_row
+        for l in range(L):
+            inp = gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE, precision='bf16')
+            acts0.append(inp)
+    return dict(ws=ws, chain=chain, fused=fused, wbf=wbf, wbt=wbt, row=row, acts0=acts0, zero_row=zero_row)
+
+
+# A model that knows its MADE calls ahead of time (the IAF stack behind the R-GCN encoder) announces them at the start of its
+# forward: made_prepare runs _made_params_work of every announced call on ONE side stream -- beside the encoder's layers; under
+# capture a parallel branch -- and the node picks the result up behind an event.  Per flow that is a mask fold, a packing launch,
+# two fills and the single-workgroup row kernel: ~70 us that used to sit in front of every flow's first pass.
+MADE_PREPARE = _os.environ.get('GV_MADE_PREPARE', '1') == '1'
+_made_prep = {}
+
+
+def _made_prep_key(ws, d, S):
+    return (tuple(w.data_ptr() for w in ws), int(d), int(S))
+
+
+def made_prepare(calls):
+    """calls: [(colcount, weights, biases, masks)] of the bf16 MADE nodes the caller is about to run (made_forward's arguments)."""
+    if not MADE_PREPARE or not calls or GEMM_PRECISION != 'bf16' or not MADE_BF16_STORAGE or lib.TIMER is not None:
+        return
+    main, side = torch.cuda.current_stream(), _side('made_prep')
+    side.wait_stream(main)
+    with torch.cuda.stream(side), torch.no_grad():
+        for colcount, weights, biases, masks in calls:
+            d, S = weights[0].shape[1], colcount.shape[0] - 1
+            if masks is None or len(weights) > 8 or d % 8 or any(w.shape[0] % 8 or w.shape[1] % 8 for w in weights):
+                continue        # (not the call made_forward hands to the bf16 node with these very tensors)
+            prep = _made_params_work(tuple(masks), tuple(weights), tuple(biases), d, S)
+            prep['done'] = torch.cuda.Event()
+            prep['done'].record(side)
+            _made_prep[_made_prep_key(weights, d, S)] = prep
+
+
+def made_prepare_finish():
+    """Drop what was prepared and not picked up (and join the side stream: nothing may stay unjoined in a captured step)."""
+    if _made_prep:
+        torch.cuda.current_stream().wait_stream(_side('made_prep'))
+        _made_prep.clear()
+
+
 class _MADEForwardBF16(torch.autograd.Function):
     """MADE.forward (kgvae/flow_network.py:85-98) with bf16 operands in MEMORY (BASELINE configs[2]; semantics as the
     tests' CPU emulation pins them: operands rounded to bf16, fp32 products and sums).  Same structure as _MADEForward -- pass 0 on one
@@ -3123,7 +3194,6 @@ class _MADEForwardBF16(torch.autograd.Function):
         ctx.masks = masks
         if masks is not None:          # raw weights + their masks: folded here, all layers in one launch (and in backward likewise)
             ctx.direct_w = [_direct(w) for w in ws]
-            ws = mul_multi(masks, ws)
         z = _chk(z.contiguous(), name='z')
         n, d = z.shape
         P = colcount.shape[0]
@@ -3133,19 +3203,15 @@ class _MADEForwardBF16(torch.autograd.Function):
         bf = dict(dtype=torch.bfloat16, device=dev)
         st = lib.stream()
         npad = _pad8(n)
-        widths = [w.shape[0] for w in ws]                       # layer output widths; inputs: d, then widths[:-1]
-        # weights: bf16 (out, in) and bf16 transposed (in, out), once per call
-        chain = (MADE_CHAIN and S > 0 and L <= 8 and made_chain_fits(widths, [w.shape[1] for w in ws], False)
-                 and made_chain_fits([w.shape[1] for w in reversed(ws)], [w.shape[0] for w in reversed(ws)], True))
-        fused = chain and MADE_CHAIN_IAF and d % 8 == 0 and widths[L - 1] == 2 * d
-        if chain:       # one launch per pass: fragment-packed weights (forward and transposed form from one launch per layer)
-            packed = made_pack_weights(ws, iaf_last=fused)
-            wbf, wbt = [pk[0] for pk in packed], [pk[1] for pk in packed]
+        # what depends on the parameters alone (mask fold, bf16 / fragment-packed weights, pass 0's row): done ahead on a side stream
+        # where the model announced this call (made_prepare), here otherwise
+        prep = _made_prep.pop(_made_prep_key(ws, d, S), None)
+        if prep is not None:
+            torch.cuda.current_stream().wait_event(prep['done'])
         else:
-            wbf = [torch.empty(w.shape[0], _pad8(w.shape[1]), **bf) for w in ws]
-            wbt = [torch.empty(w.shape[1], _pad8(w.shape[0]), **bf) for w in ws]
-            for w, a_, t_ in zip(ws, wbf, wbt):
-                cast_bf16(w, a_, t_)
+            prep = _made_params_work(masks, ws, bs, d, S)
+        ws, chain, fused, wbf, wbt, row, acts0, zero_row = (prep[k_] for k_ in ('ws', 'chain', 'fused', 'wbf', 'wbt', 'row', 'acts0', 'zero_row'))
+        widths = [w.shape[0] for w in ws]                       # layer output widths; inputs: d, then widths[:-1]
         xin = torch.empty(max(S, 1) * n, d, **f32)               # fp32 pass inputs (update pass-through, backward)
         xin_b = torch.empty(max(S, 1) * n, _pad8(d), **bf)
         # fused: the transposed copies (read by the weight-gradient products alone) in tiles of 64 rows, when every product fits
@@ -3173,17 +3239,6 @@ class _MADEForwardBF16(torch.autograd.Function):
         else:
             net_out = torch.empty(max(S, 1) * n, widths[L - 1], **f32)   # [mu | alpha] of every stacked pass
         x_out = torch.empty(n, d, **f32)
-        # pass 0 on a single zero row (tiny: the generic GEMM with bf16-rounded operands)
-        zero_row = torch.zeros(1, d, **f32)
-        row = MADE_ROW and L <= 8 and d <= 512 and max(widths) <= 512 and all(w.shape[1] % 4 == 0 for w in ws)
-        if row:         # one single-workgroup launch for the whole row
-            acts0 = [torch.empty(1, widths[l], **f32) for l in range(L)]
-            made_row_fwd(None, [dict(w=ws[l], bias=bs[l], relu=l < L - 1, out=acts0[l]) for l in range(L)])
-        else:
-            acts0, inp = [], zero_row
-            for l in range(L):
-                inp = gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE, precision='bf16')
-                acts0.append(inp)
         def update(net, ld_net, x_old, cc, q):
             """The IAF update of one pass.  Its result is pass q + 1's input (slice q of the stacked buffers: fp32 + the bf16
             row-major and transposed copies the products read, written by the same launch) or, after the last pass, x_out."""

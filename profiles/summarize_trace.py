@@ -32,6 +32,14 @@ def main(path, steps=10):
     busy = sum(v[1] for v in agg.values())
     print(f'window: {len(win)} launches over {(t_last - t_first) / 1e3 / steps:.1f} us/step wall, '
           f'{busy / 1e3 / steps:.1f} us/step kernel-busy, {len(win) / steps:.0f} launches/step')
+    # how much of the window has 0 / 1 / 2 / >= 3 kernels in flight (streams side by side: parallel branches of the replayed graph)
+    ev = sorted([(int(r['Start_Timestamp']), 1) for r in win] + [(int(r['End_Timestamp']), -1) for r in win])
+    depth, last, hist = 0, ev[0][0], [0, 0, 0, 0]
+    for t, dlt in ev:
+        hist[min(depth, 3)] += t - last
+        last, depth = t, depth + dlt
+    tot = max(1, sum(hist))
+    print('kernels in flight: ' + ', '.join(f'{lbl} {100 * h / tot:.1f} %' for lbl, h in zip(('none', 'one', 'two', 'three or more'), hist)))
     print(f'{"kernel":112s} {"n/step":>7s} {"avg_us":>9s} {"us/step":>9s} {"%busy":>6s}')
     for k, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f'{k:112s} {n / steps:7.1f} {tot / n / 1e3:9.2f} {tot / 1e3 / steps:9.1f} {100 * tot / busy:6.1f}')
