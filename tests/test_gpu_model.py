@@ -748,6 +748,51 @@ def test_made_passes_over_row_blocks_on_their_own_streams_give_the_same_bits(mon
 
 
 @pytest.mark.gpu
+def test_flow_parameter_work_prepared_beside_the_encoder_gives_the_same_bits(monkeypatch):
+    """ops.made_prepare (KGVAE.forward announces its MADE calls: mask folds, packed weights and pass 0's row run on a side stream
+    beside the R-GCN layers and are picked up behind an event) against the node doing that work itself: same embedding, same loss,
+    same gradients, bit for bit; nothing prepared is left over."""
+    from gcn_vae_amd import ops, sampling
+    from gcn_vae_amd.data import synthetic_kg
+    from gcn_vae_amd.encoders import KGVAE
+    from gcn_vae_amd.train import LinkPredict
+    n, n_rel, h = 600, 8, 16
+    data = synthetic_kg(n, n_rel, 4000, seed=1)
+    g, rel, node_norm = sampling.build_test_graph(n, n_rel, data.train)
+    _, dst = g.edges()
+    node_id = torch.arange(n, device='cuda').view(-1, 1)
+    et = torch.from_numpy(rel).cuda()
+    enorm = torch.from_numpy(node_norm).cuda()[dst.cuda()].view(-1, 1).contiguous()
+    np.random.seed(0)
+    samples, labels = sampling.negative_sampling(data.train[:500], n, 3)
+    trip, lab = torch.from_numpy(samples).cuda(), torch.from_numpy(labels).cuda()
+    eps = torch.randn(n, h, generator=torch.Generator().manual_seed(1)).cuda()
+    res, used = [], []
+    inner = ops._made_params_work
+    monkeypatch.setattr(ops, '_made_params_work', lambda *a: (used.append(torch.cuda.current_stream().cuda_stream), inner(*a))[1])
+    for on in (False, True):
+        monkeypatch.setattr(ops, 'MADE_PREPARE', on)
+        torch.manual_seed(0)
+        net = LinkPredict(KGVAE, n, h, n_rel, num_bases=4, num_hidden_layers=2, dropout=0.0, use_cuda=True, reg_param=0.01,
+                          kl_param=1e-3, mmd_param=0.0, k=4, n_flows=2).cuda().train()
+        net.encoder.eps_override = eps
+        main = torch.cuda.current_stream().cuda_stream
+        del used[:]
+        with ops.gemm_precision('bf16'):
+            embed = net(g, node_id, et, enorm)
+            loss = net.get_loss(g, embed, trip, lab)[0]
+            loss.backward()
+        torch.cuda.synchronize()
+        assert len(used) == 2 and all((st != main) == on for st in used), (on, used, main)       # one call per flow, on the side stream when prepared
+        assert not ops._made_prep
+        res.append((embed.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert res[0][2].keys() == res[1][2].keys() and any('nf' in k for k in res[0][2])
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
+
+
+@pytest.mark.gpu
 def test_made_gradients_written_straight_into_the_optimiser_arena_equal_autograd():
     """With FlatAdam registered, MaskedLinear's masked weight gradient and the bf16 MADE node's bias gradients are stored
     straight into the (all-zero) arena slices instead of going through AccumulateGrad: same numbers as plain autograd, and a
