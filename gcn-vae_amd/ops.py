@@ -119,7 +119,8 @@ def join(*ids):
 # into the gradient arena) need not hold up the kernels that feed autograd: it goes to one side stream -- a parallel branch of a
 # captured graph -- and that stream is joined once, when the engine has run the whole backward pass (the optimiser step comes after).
 # What such launches read is kept from the allocator until the join (autograd frees a node's saved tensors as soon as the node ran).
-# Off with several ranks: there the gradients feed all-reduces that are started inside the backward pass.
+# Off when a process group exists: the gradients then feed all-reduces started inside the backward pass, and a captured step is a
+# chain of graph segments cut at the collectives (a stream forked in one segment cannot be joined in another).
 # Used by the MADE backward (weight-gradient products that need one workgroup per CU, beside backward chains whose second round
 # of workgroups leaves half of the CUs idle: -0.13 ms at WN18RR size).  NOT by the R-GCN layers' or the decoder's weight
 # gradients: beside kernels that fill the chip on their own they cost more than they hide (FB15k-237: 1.047 -> 1.089 ms per step,
@@ -128,16 +129,18 @@ BWD_SIDE = _os.environ.get('GV_BWD_SIDE', '1') == '1'
 _bwd_side_held = []
 
 
-def _several_ranks():
+def _process_group():
+    """A torch.distributed process group exists (even of one rank): the step then carries collectives, a captured step is a chain
+    of graph SEGMENTS cut at them, and a stream forked in one segment may not be joined in another -- no deferred side streams."""
     import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized()
 
 
 @contextlib.contextmanager
 def backward_side(enabled, *held):
     """Inside an autograd backward: run the enclosed launches on the side stream (after everything already enqueued); ``held``:
     the tensors they touch.  Yields whether the side stream is in use."""
-    if not (enabled and BWD_SIDE) or lib.TIMER is not None or _several_ranks():      # (timed launches run alone: bench.py's per-kernel lines)
+    if not (enabled and BWD_SIDE) or lib.TIMER is not None or _process_group():      # (timed launches run alone: bench.py's per-kernel lines)
         yield False
         return
     side, main = _side('bwd'), torch.cuda.current_stream()
@@ -2745,10 +2748,19 @@ class _MADEForward(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, z, colcount, *wb):
+    def forward(ctx, z, colcount, masks, *wb):
         ctx.set_materialize_grads(False)
         L = len(wb) // 2
         ws, bs = wb[:L], wb[L:]
+        # masks: the autoregressive masks when the weights are the RAW parameters -- folded here in one launch, and in the backward
+        # pass the masked weight gradients go straight into the optimiser's arena where that is registered (then, with the bias
+        # gradients, on the side stream: ops.backward_side); None: the weights are masked already
+        ctx.masks = masks
+        ctx.direct_w = [_direct(w) for w in ws] if masks is not None else [None] * L
+        ctx.direct_b = [_direct(b) if b is not None else None for b in bs]
+        _stamp_direct(ctx)
+        if masks is not None:
+            ws = mul_multi(masks, ws)
         z = _chk(z.contiguous(), name='z')
         n, d = z.shape
         P = colcount.shape[0]
@@ -2833,26 +2845,52 @@ class _MADEForward(torch.autograd.Function):
             if l > 0:
                 mask = acts0[l] if l < L - 1 else None
                 g_row = gemm(g_row, ws[l], a_relu_mask=mask)
+        # dL/dW_l, dL/db_l.  Nothing later in the backward pass needs them: with every one of them going straight into the optimiser's
+        # arena they run on the side stream, beside the next flow's (launch-bound) passes
+        _verify_direct(ctx)
+        wants_w = [ctx.needs_input_grad[3 + l] for l in range(L)]
+        wants_b = [ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l] for l in range(L)]
+        tgt_w = [ctx.direct_w[l] if (wants_w[l] and ctx.direct_w[l] is not None and ctx.direct_w[l].data_ptr() in GRAD_FRESH
+                                     and ctx.direct_w[l].is_contiguous()) else None for l in range(L)]
+        tgt_b = [ctx.direct_b[l] if (wants_b[l] and ctx.direct_b[l] is not None and ctx.direct_b[l].is_contiguous()) else None
+                 for l in range(L)]
+        beside = (ctx.masks is not None and L <= 8 and all(tgt_w[l] is not None for l in range(L) if wants_w[l])
+                  and all(tgt_b[l] is not None for l in range(L) if wants_b[l]))
         g_ws, g_bs = [], []
-        for l in range(L):
-            mask = acts[l] if l < L - 1 else None
-            mask0 = acts0[l] if l < L - 1 else None
-            inp0 = zero_row if l == 0 else acts0[l - 1]
-            gw = gb = None
-            if ctx.needs_input_grad[2 + l]:
-                gw = gemm(rows0[l], inp0, trans_a=True, a_relu_mask=mask0)           # pass 0: outer product of two rows
-                if S > 0:
-                    inp = xin if l == 0 else acts[l - 1]
-                    part = gemm(grads[l], inp, trans_a=True, a_relu_mask=mask,
-                                split_k=pick_split_k(ws[l].shape[0], ws[l].shape[1], S * n))
-                    lib.call('gv_axpby', gw.numel(), None, 1.0, ptr(part), 1.0, ptr(gw), st)
-            if ctx.has_bias[l] and ctx.needs_input_grad[2 + L + l]:
-                gb = colsum(rows0[l], relu_mask=mask0)
-                if S > 0:
-                    colsum(grads[l], relu_mask=mask, out=gb, accumulate=True)
-            g_ws.append(gw)
-            g_bs.append(gb)
-        return (g_z, None, *g_ws, *g_bs)
+        with backward_side(beside, grads, xin, acts, acts0, rows0, zero_row):
+            for l in range(L):
+                mask = acts[l] if l < L - 1 else None
+                mask0 = acts0[l] if l < L - 1 else None
+                inp0 = zero_row if l == 0 else acts0[l - 1]
+                gw = gb = None
+                if wants_w[l]:
+                    gw = gemm(rows0[l], inp0, trans_a=True, a_relu_mask=mask0)           # pass 0: outer product of two rows
+                    if S > 0:
+                        inp = xin if l == 0 else acts[l - 1]
+                        part = gemm(grads[l], inp, trans_a=True, a_relu_mask=mask,
+                                    split_k=pick_split_k(ws[l].shape[0], ws[l].shape[1], S * n))
+                        lib.call('gv_axpby', gw.numel(), None, 1.0, ptr(part), 1.0, ptr(gw), lib.stream())
+                if wants_b[l]:      # (a bias with a slice of the arena: ADDED there, whatever the slice holds)
+                    gb = colsum(rows0[l], relu_mask=mask0, out=tgt_b[l], accumulate=tgt_b[l] is not None)
+                    if S > 0:
+                        colsum(grads[l], relu_mask=mask, out=gb, accumulate=True)
+                    if tgt_b[l] is not None:
+                        GRAD_FRESH.discard(gb.data_ptr())
+                        gb = None
+                g_ws.append(gw)
+                g_bs.append(gb)
+            if ctx.masks is not None:       # dL/dW = mask * dL/d(mask * W): one launch for all layers, straight into the arena where fresh
+                idx = [l for l in range(L) if g_ws[l] is not None]
+                for i0 in range(0, len(idx), 8):
+                    part_idx = idx[i0:i0 + 8]
+                    res = mul_multi([ctx.masks[l] for l in part_idx], [g_ws[l] for l in part_idx], outs=[tgt_w[l] for l in part_idx])
+                    for l, r in zip(part_idx, res):
+                        if tgt_w[l] is not None:
+                            GRAD_FRESH.discard(tgt_w[l].data_ptr())
+                            g_ws[l] = None
+                        else:
+                            g_ws[l] = r
+        return (g_z, None, None, *g_ws, *g_bs)
 
 
 # ---- K4 in bf16 (csrc/k_made.hip): bf16 storage of weights and activations, every product the same NT kernel ----------------
@@ -3156,7 +3194,8 @@ def _made_prep_key(ws, d, S):
 
 def made_prepare(calls):
     """calls: [(colcount, weights, biases, masks)] of the bf16 MADE nodes the caller is about to run (made_forward's arguments)."""
-    if not MADE_PREPARE or not calls or GEMM_PRECISION != 'bf16' or not MADE_BF16_STORAGE or lib.TIMER is not None:
+    if (not MADE_PREPARE or not calls or GEMM_PRECISION != 'bf16' or not MADE_BF16_STORAGE or lib.TIMER is not None
+            or _process_group()):
         return
     main, side = torch.cuda.current_stream(), _side('made_prep')
     side.wait_stream(main)
@@ -3563,6 +3602,6 @@ def made_forward(z, colcount, weights, biases, masks=None):
         if masks is not None and len(weights) > 8:           # gv_mul_multi's table holds 8 entries
             weights, masks = [masked_weight(m, w) for m, w in zip(masks, weights)], None
         return _MADEForwardBF16.apply(z, colcount, tuple(masks) if masks is not None else None, *weights, *biases)
-    if masks is not None:
-        weights = [masked_weight(m, w) for m, w in zip(masks, weights)]
-    return _MADEForward.apply(z, colcount, *weights, *biases)
+    if masks is not None and len(weights) > 8:               # gv_mul_multi's table holds 8 entries
+        weights, masks = [masked_weight(m, w) for m, w in zip(masks, weights)], None
+    return _MADEForward.apply(z, colcount, tuple(masks) if masks is not None else None, *weights, *biases)
