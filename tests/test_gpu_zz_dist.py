@@ -36,7 +36,8 @@ def free_port():
 @pytest.mark.parametrize('extra', [['--partition', 'edge'], ['--no-graph', '--partition', 'edge'],
                                    ['--no-graph', '--partition', 'row'], ['--partition', 'row'], [],
                                    ['--partition', 'row', '--n-flows', '1'], ['--partition', 'edge', '--n-flows', '1'],
-                                   ['--graph-collectives', '--partition', 'edge']])
+                                   ['--graph-collectives', '--partition', 'edge'],
+                                   ['--partition', 'edge', '--n-flows', '1', '--gemm-precision', 'bf16']])
 def test_bench_single_rank_rccl(extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
