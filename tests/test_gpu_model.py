@@ -793,10 +793,12 @@ def test_flow_parameter_work_prepared_beside_the_encoder_gives_the_same_bits(mon
 
 
 @pytest.mark.gpu
-def test_made_gradients_written_straight_into_the_optimiser_arena_equal_autograd():
-    """With FlatAdam registered, MaskedLinear's masked weight gradient and the bf16 MADE node's bias gradients are stored
-    straight into the (all-zero) arena slices instead of going through AccumulateGrad: same numbers as plain autograd, and a
-    second backward() without zero_grad() in between doubles them (the slices are then no longer 'fresh': accumulate)."""
+@pytest.mark.parametrize('precision', ['bf16', 'f32'])
+def test_made_gradients_written_straight_into_the_optimiser_arena_equal_autograd(precision):
+    """With FlatAdam registered, the MADE nodes' (bf16 and fp32) masked weight gradients and bias gradients are stored straight into
+    the (all-zero) arena slices -- on the side stream that is joined when the backward pass has run -- instead of going through
+    AccumulateGrad: same numbers as plain autograd, and a second backward() without zero_grad() in between doubles them (the
+    slices are then no longer 'fresh': accumulate)."""
     from gcn_vae_amd import ops, sampling
     from gcn_vae_amd.data import synthetic_kg
     from gcn_vae_amd.encoders import KGVAE
@@ -825,7 +827,7 @@ def test_made_gradients_written_straight_into_the_optimiser_arena_equal_autograd
         embed = net(g, node_id, et, enorm)
         net.get_loss(g, embed, trip, lab)[0].backward()
 
-    with ops.gemm_precision('bf16'):
+    with ops.gemm_precision(precision):
         ref = build()
         backward_once(ref)
         want = {k: p.grad.detach().clone() for k, p in ref.named_parameters() if p.grad is not None}
