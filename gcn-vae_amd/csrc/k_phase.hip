@@ -345,13 +345,13 @@ bool phase_plan(int nb, int p, int q, bool trans, int k_req, PhasePlan* out) {
     int bpl = 0, u = 8, k = 0, qmajor = 0;
     if (!trans) {
         if (p == 2 && q == 2) { bpl = 2; k = 8; }
-        else if (p == 2 && q == 4) { bpl = 2; u = 6; k = 8; }   // two blocks per lane (one column part): 8 rows x 8 accumulators, 6 rows in flight
-        else if (p == 5 && q == 5) { bpl = 1; u = 4; k = 8; }     // one block per lane, two column parts: 8 rows x 5 accumulators; 228 tile-parts = one round of workgroups at FB15k-237 size
+        else if (p == 2 && q == 4) { bpl = 2; u = 8; k = 8; }   // two blocks per lane (one column part): 8 rows x 8 accumulators, 8 rows in flight (6 until the LDS-DMA source became a scalar base: 128 registers, no scratch; configs[4] scale 11.2 -> 11.0 ms)
+        else if (p == 5 && q == 5) { bpl = 1; u = 6; k = 8; }     // one block per lane, two column parts: 8 rows x 5 accumulators, 6 rows in flight (4 until round 3: 272 -> 257 us at h = 500); 228 tile-parts = one round of workgroups at FB15k-237 size
         else if (p == 5 && q == 10) { bpl = 1; u = 2; k = 4; qmajor = 1; }     // lean kernel on a q-major packed block (5, 6 rows: spills)     // lean kernel on a q-major packed block
     } else {
         if (p == 2 && q == 2) { bpl = 2; k = 8; }
         else if (p == 4 && q == 2) { bpl = 2; u = 4; k = 8; }
-        else if (p == 5 && q == 5) { bpl = 1; u = 4; k = 8; }
+        else if (p == 5 && q == 5) { bpl = 1; u = 6; k = 8; }
         else if (p == 10 && q == 5) { bpl = 1; u = 2; k = 8; }      // lean kernel: 8 rows x 5 accumulators, weights in two halves
     }
     if (!bpl || nb % bpl) return false;
@@ -474,12 +474,12 @@ extern "C" int gv_rgcn_bdd_aggregate_phases(const int32_t* off, const int32_t* n
         rc = launch_status("gv_rgcn_bdd_aggregate_phases");                                                         \
     }
     GV_PHASE_CASE(2, 2, false, 2, 8, 8) GV_PHASE_CASE(2, 2, false, 2, 4, 8)
-    GV_PHASE_CASE(2, 4, false, 2, 8, 6) GV_PHASE_CASE(2, 4, false, 2, 4, 6)
+    GV_PHASE_CASE(2, 4, false, 2, 8, 8) GV_PHASE_CASE(2, 4, false, 2, 4, 6)
     GV_PHASE_CASE(2, 2, true, 2, 8, 8) GV_PHASE_CASE(2, 2, true, 2, 4, 8)
     GV_PHASE_CASE(4, 2, true, 2, 8, 4) GV_PHASE_CASE(4, 2, true, 2, 4, 4)
-    GV_PHASE_CASE(5, 5, false, 1, 8, 4) GV_PHASE_CASE(5, 5, false, 1, 4, 6)
+    GV_PHASE_CASE(5, 5, false, 1, 8, 6) GV_PHASE_CASE(5, 5, false, 1, 4, 6)
     GV_PHASE_CASE_L(5, 10, false, 1, 4, 2, true)
-    GV_PHASE_CASE(5, 5, true, 1, 8, 4) GV_PHASE_CASE(5, 5, true, 1, 4, 6)
+    GV_PHASE_CASE(5, 5, true, 1, 8, 6) GV_PHASE_CASE(5, 5, true, 1, 4, 6)
     GV_PHASE_CASE_L(10, 5, true, 1, 8, 2, true) GV_PHASE_CASE_L(10, 5, true, 1, 4, 2, true) GV_PHASE_CASE(10, 5, true, 1, 3, 3)
 #undef GV_PHASE_CASE
 #undef GV_PHASE_CASE_L
