@@ -2730,878 +2730,8 @@ def loss_head(z, z_mean, z_sigma, w_rel, z_pre, flp, z_pri, pick, labels, tidx, 
                            float(mmd_w), bool(score_bias), embed_rows, rows_dev, getattr(z, '_gv_kl_link', None))
 
 
-class _MADEForward(torch.autograd.Function):
-    """MADE.forward (kgvae/flow_network.py:85-98) as ONE autograd node.
-
-    The reference runs ``len(self.m)`` (= n_hidden + 3) sequential passes of the masked MLP, each followed by
-    ``x[:, i] = z[:, i] * exp(alpha[:, i] + mu[:, i])``.  Here
-      * pass 0 -- whose input is the all-zero matrix, i.e. N identical rows -- evaluates the MLP on ONE row and
-        broadcasts it into the update (its backward sums the update's gradient over the rows and back-propagates
-        that single row);
-      * every later pass writes its layer activations into row slices of per-layer buffers stacked over the passes,
-        so the backward walks the passes in reverse with one NN GEMM per layer whose A operand is read through the
-        ReLU mask of the stored activation (no masking kernels, no materialised masked gradient), and forms each
-        layer's weight gradient ONCE as a single split-K product over all stacked rows (K = (passes-1) x N); the
-        reference's autograd does it per pass and sums.
-    Inputs: z (N, D); masked weights W_l (out_l, in_l) and biases, l = 0..L-1 (last layer: 2D outputs [mu | alpha]);
-    colcount int32 (passes, D).  Outputs: x (N, D), log_det (N,) = sum_d alpha of the last pass.
-    """
-
-    @staticmethod
-    def forward(ctx, z, colcount, masks, *wb):
-        ctx.set_materialize_grads(False)
-        L = len(wb) // 2
-        ws, bs = wb[:L], wb[L:]
-        # masks: the autoregressive masks when the weights are the RAW parameters -- folded here in one launch, and in the backward
-        # pass the masked weight gradients go straight into the optimiser's arena where that is registered (then, with the bias
-        # gradients, on the side stream: ops.backward_side); None: the weights are masked already
-        ctx.masks = masks
-        ctx.direct_w = [_direct(w) for w in ws] if masks is not None else [None] * L
-        ctx.direct_b = [_direct(b) if b is not None else None for b in bs]
-        _stamp_direct(ctx)
-        if masks is not None:
-            ws = mul_multi(masks, ws)
-        z = _chk(z.contiguous(), name='z')
-        n, d = z.shape
-        P = colcount.shape[0]
-        f32 = dict(dtype=torch.float32, device=z.device)
-        st = lib.stream()
-        S = P - 1                                                 # passes 1..P-1 are stacked; pass 0 is one row
-        xin = torch.empty(max(S, 1) * n, d, **f32)               # xin[s] = input of pass s+1 = output of pass s
-        acts = [torch.empty(max(S, 1) * n, ws[l].shape[0], **f32) for l in range(L)]   # acts[L-1] = [mu | alpha]
-        x_out = torch.empty(n, d, **f32)
-        # pass 0 on a single zero row
-        zero_row = torch.zeros(1, d, **f32)
-        acts0, inp = [], zero_row
-        for l in range(L):
-            inp = gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE)
-            acts0.append(inp)
-        first_out = xin[0:n] if P > 1 else x_out
-        # (columns outside the first index set would keep x_old = 0: flows.MADE checks at construction that there are none)
-        lib.call('gv_iaf_update_fwd', ptr(z), ptr(acts0[L - 1]), 0, ptr(z), ptr(colcount[0]), ptr(first_out), n, d, st)
-        def passes(r0, r1):      # passes 1 .. P-1 for the rows [r0, r1): every launch of a pass is row-local
-            for p in range(1, P):
-                a, b = (p - 1) * n + r0, (p - 1) * n + r1
-                inp = xin[a:b]
-                for l in range(L):
-                    out = acts[l][a:b]
-                    gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE, out=out)
-                    inp = out
-                nxt = xin[p * n + r0:p * n + r1] if p + 1 < P else x_out[r0:r1]
-                lib.call('gv_iaf_update_fwd', ptr(z[r0:r1]), ptr(inp), 2 * d, ptr(xin[a:b]), ptr(colcount[p]), ptr(nxt), r1 - r0, d,
-                         lib.stream())
-        _by_row_blocks(passes, n, MADE_F32_ROW_BLOCKS, MADE_F32_ROW_BLOCKS_MIN_TILES)
-        log_det = torch.empty(n, **f32)
-        if P > 1:
-            lib.call('gv_rowsum', ptr(acts[L - 1][(S - 1) * n:]), 2 * d, d, d, ptr(log_det), n, st)
-        else:
-            log_det = acts0[L - 1][:, d:].sum(dim=1).expand(n).contiguous()
-        ctx.save_for_backward(z, colcount, xin, zero_row, *acts, *acts0, *ws)
-        ctx.L = L
-        ctx.has_bias = [b is not None for b in bs]
-        return x_out, log_det
-
-    @staticmethod
-    def backward(ctx, gx, gld):
-        L = ctx.L
-        saved = ctx.saved_tensors
-        z, colcount, xin, zero_row = saved[:4]
-        acts, acts0, ws = saved[4:4 + L], saved[4 + L:4 + 2 * L], saved[4 + 2 * L:4 + 3 * L]
-        n, d = z.shape
-        P = colcount.shape[0]
-        S = P - 1
-        f32 = dict(dtype=torch.float32, device=z.device)
-        st = lib.stream()
-        gx = torch.zeros(n, d, **f32) if gx is None else _chk(gx.contiguous(), name='gx')
-        gld = None if gld is None else _chk(gld.contiguous(), name='gld')
-        grads = [torch.empty(max(S, 1) * n, ws[l].shape[0], **f32) for l in range(L)]   # grad w.r.t. each layer's OUTPUT
-        g_z = torch.zeros(n, d, **f32)
-        gz_p = torch.empty(n, d, **f32)
-        g_olds = {p: torch.empty(n, d, **f32) for p in range(1, P)}      # dL/dx_old of every pass (allocated before any fork)
-
-        def passes(r0, r1):      # the backward of passes P-1 .. 1 for the rows [r0, r1): every launch is row-local
-            g_in, m = gx, r1 - r0
-            for p in reversed(range(1, P)):
-                a, b = (p - 1) * n + r0, (p - 1) * n + r1
-                g_old = g_olds[p][r0:r1]
-                lib.call('gv_iaf_update_bwd', ptr(z[r0:r1]), ptr(acts[L - 1][a:b]), 2 * d, ptr(colcount[p]), ptr(g_in[r0:r1]),
-                         ptr(gld[r0:r1]) if (p == P - 1 and gld is not None) else None, ptr(gz_p[r0:r1]), ptr(grads[L - 1][a:b]),
-                         ptr(g_old), m, d, lib.stream())
-                lib.call('gv_axpby', m * d, None, 1.0, ptr(gz_p[r0:r1]), 1.0, ptr(g_z[r0:r1]), lib.stream())
-                for l in reversed(range(L)):
-                    mask = acts[l][a:b] if l < L - 1 else None
-                    if l > 0:
-                        gemm(grads[l][a:b], ws[l], out=grads[l - 1][a:b], a_relu_mask=mask)
-                    else:       # gradient w.r.t. the pass's input x_p joins the update's pass-through gradient
-                        gemm(grads[0][a:b], ws[0], out=g_old, accumulate=True, a_relu_mask=mask)
-                g_in = g_olds[p]
-        _by_row_blocks(passes, n, MADE_F32_ROW_BLOCKS, MADE_F32_ROW_BLOCKS_MIN_TILES)
-        g_cur = g_olds[1] if P > 1 else gx
-        # pass 0: the update's gradient w.r.t. the broadcast net row is its column sum; x_old was the zero matrix
-        g_row = iaf_bwd_row0(z, acts0[L - 1], colcount[0], g_cur, gld if P == 1 else None, g_z)      # (1, 2D)
-        rows0 = [None] * L                                        # masked single-row gradients per layer output
-        for l in reversed(range(L)):
-            rows0[l] = g_row
-            if l > 0:
-                mask = acts0[l] if l < L - 1 else None
-                g_row = gemm(g_row, ws[l], a_relu_mask=mask)
-        # dL/dW_l, dL/db_l.  Nothing later in the backward pass needs them: with every one of them going straight into the optimiser's
-        # arena they run on the side stream, beside the next flow's (launch-bound) passes
-        _verify_direct(ctx)
-        wants_w = [ctx.needs_input_grad[3 + l] for l in range(L)]
-        wants_b = [ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l] for l in range(L)]
-        tgt_w = [ctx.direct_w[l] if (wants_w[l] and ctx.direct_w[l] is not None and ctx.direct_w[l].data_ptr() in GRAD_FRESH
-                                     and ctx.direct_w[l].is_contiguous()) else None for l in range(L)]
-        tgt_b = [ctx.direct_b[l] if (wants_b[l] and ctx.direct_b[l] is not None and ctx.direct_b[l].is_contiguous()) else None
-                 for l in range(L)]
-        beside = (ctx.masks is not None and L <= 8 and all(tgt_w[l] is not None for l in range(L) if wants_w[l])
-                  and all(tgt_b[l] is not None for l in range(L) if wants_b[l]))
-        g_ws, g_bs = [], []
-        with backward_side(beside, grads, xin, acts, acts0, rows0, zero_row):
-            for l in range(L):
-                mask = acts[l] if l < L - 1 else None
-                mask0 = acts0[l] if l < L - 1 else None
-                inp0 = zero_row if l == 0 else acts0[l - 1]
-                gw = gb = None
-                if wants_w[l]:
-                    gw = gemm(rows0[l], inp0, trans_a=True, a_relu_mask=mask0)           # pass 0: outer product of two rows
-                    if S > 0:
-                        inp = xin if l == 0 else acts[l - 1]
-                        part = gemm(grads[l], inp, trans_a=True, a_relu_mask=mask,
-                                    split_k=pick_split_k(ws[l].shape[0], ws[l].shape[1], S * n))
-                        lib.call('gv_axpby', gw.numel(), None, 1.0, ptr(part), 1.0, ptr(gw), lib.stream())
-                if wants_b[l]:      # (a bias with a slice of the arena: ADDED there, whatever the slice holds)
-                    gb = colsum(rows0[l], relu_mask=mask0, out=tgt_b[l], accumulate=tgt_b[l] is not None)
-                    if S > 0:
-                        colsum(grads[l], relu_mask=mask, out=gb, accumulate=True)
-                    if tgt_b[l] is not None:
-                        GRAD_FRESH.discard(gb.data_ptr())
-                        gb = None
-                g_ws.append(gw)
-                g_bs.append(gb)
-            if ctx.masks is not None:       # dL/dW = mask * dL/d(mask * W): one launch for all layers, straight into the arena where fresh
-                idx = [l for l in range(L) if g_ws[l] is not None]
-                for i0 in range(0, len(idx), 8):
-                    part_idx = idx[i0:i0 + 8]
-                    res = mul_multi([ctx.masks[l] for l in part_idx], [g_ws[l] for l in part_idx], outs=[tgt_w[l] for l in part_idx])
-                    for l, r in zip(part_idx, res):
-                        if tgt_w[l] is not None:
-                            GRAD_FRESH.discard(tgt_w[l].data_ptr())
-                            g_ws[l] = None
-                        else:
-                            g_ws[l] = r
-        return (g_z, None, None, *g_ws, *g_bs)
-
-
-# ---- K4 in bf16 (csrc/k_made.hip): bf16 storage of weights and activations, every product the same NT kernel ----------------
-def _pad8(n):
-    return (int(n) + 7) // 8 * 8
-
-
-def _empty_t_padded(widths, passes, n, npad, kw):
-    """Transposed-copy buffers (width_i, passes*npad), carved out of ONE allocation so that one fill zeroes the pad columns
-    [n, npad) of every pass of every buffer (they take part in the weight-gradient reduction); the data columns are written
-    by the producing kernels."""
-    t = torch.empty(sum(widths), passes * npad, **kw)
-    if npad > n:
-        t.view(sum(widths), passes, npad)[:, :, n:].zero_()
-    out, o = [], 0
-    for w in widths:
-        out.append(t[o:o + w])
-        o += w
-    out.append(t)          # last: the whole allocation (one row-sum pass over all of it)
-    return out
-
-
-def _empty_t_tiles(widths, passes, n, kw):
-    """Transposed-copy buffers in tiles of 64 rows: ONE allocation [passes * T][sum(widths)][64] (T = ceil(n / 64) tiles per
-    pass), buffer i = the column range of width_i -- element (column c, stacked row r) at [r // 64][c][r % 64].  A workgroup of the
-    weight-gradient product (gv_gemm_bf16_gradw_tiles) then reads contiguous 128-B x width blocks, and a chain workgroup (64
-    rows) writes one.  The rows [n, 64 T) of every pass's last tile stay zero (they take part in the reduction).
-    Returns (buffers, tiles per pass, elements between two tiles)."""
-    T = (int(n) + 63) // 64
-    t = torch.empty(passes * T, sum(widths), 64, **kw)
-    if n % 64:
-        t.view(passes, T, sum(widths), 64)[:, T - 1, :, n % 64:].zero_()
-    out, o = [], 0
-    for w in widths:
-        out.append(t[:, o:o + w])
-        o += w
-    return out, T, sum(widths) * 64
-
-
-def cast_bf16(x, y=None, y_t=None):
-    """y = bf16(x) row-major and / or y_t[c, r] = bf16(x[r, c]); x fp32 (rows, cols) with unit inner stride."""
-    x, ldx = _row_major(x, 'x')
-    rows, cols = x.shape
-    lib.call('gv_cast_bf16', ptr(x), ldx, rows, cols, ptr(y), y.stride(0) if y is not None else 0, ptr(y_t),
-             y_t.stride(0) if y_t is not None else 0, lib.stream())
-
-
-def gemm_bf16_nt(a, b, m, n, k, bias=None, relu=False, mask=None, c_f32=None, accumulate=False, c_bf16=None, c_bf16_t=None,
-                 split_k=1):
-    """C[m, n] = epilogue(A[m, k] @ B[n, k]^T) on gv_gemm_bf16_nt; A bf16 or fp32 (rounded while staged), B bf16; row strides
-    are taken from the tensors (views of stacked / padded buffers)."""
-    ws, ws_bytes = None, 0
-    if split_k > 1:
-        ws_bytes = int(lib.load().gv_gemm_bf16_nt_workspace_bytes(m, n, split_k))
-        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=a.device)
-    lib.call('gv_gemm_bf16_nt', ptr(a), 1 if a.dtype == torch.float32 else 0, a.stride(0), ptr(b), b.stride(0), m, n, k,
-             ptr(bias), 1 if relu else 0, ptr(mask), mask.stride(0) if mask is not None else 0, ptr(c_f32),
-             c_f32.stride(0) if c_f32 is not None else 0, 1 if accumulate else 0, ptr(c_bf16),
-             c_bf16.stride(0) if c_bf16 is not None else 0, ptr(c_bf16_t), c_bf16_t.stride(0) if c_bf16_t is not None else 0,
-             split_k, ptr(ws), ws_bytes, lib.stream())
-
-
-DENSE_BF16_NT = _os.environ.get('GV_DENSE_BF16_NT', '1') == '1'
-
-
-def dense_bf16_forms(w):
-    """bf16 copies of a dense weight W (k_in, n_out) for the self-loop products on gv_gemm_bf16_nt (one launch): (W^T as (n_out,
-    pad8(k_in)), W as (k_in, pad8(n_out))); None when the bf16 dense path does not apply (fp32 precision, small or odd shapes)."""
-    if not (DENSE_BF16_NT and GEMM_PRECISION == 'bf16' and w.dim() == 2 and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0):
-        return None
-    kin, nout = w.shape
-    wt = torch.empty(nout, _pad8(kin), dtype=torch.bfloat16, device=w.device)
-    wb = torch.empty(kin, _pad8(nout), dtype=torch.bfloat16, device=w.device)
-    cast_bf16(w, wb, wt)
-    return wt, wb
-
-
-def dense_bf16(a, b_nt, n, k, bias=None):
-    """a (m, k) fp32 @ b_nt (n, k)^T bf16 -> (m, n) fp32: operands rounded to bf16, fp32 accumulation (gv_gemm_bf16_nt; the tiled
-    gv_gemm_bf16 takes 63 us for 40 943 x 200 x 200, this kernel 28)."""
-    a, _ = _row_major(a, 'a')
-    out = torch.empty(a.shape[0], n, dtype=torch.float32, device=a.device)
-    gemm_bf16_nt(a, b_nt, a.shape[0], n, k, bias=bias, c_f32=out)
-    return out
-
-
-def gemm_bf16_gradw_fits(m, n, k, split_k):
-    return bool(lib.load().gv_gemm_bf16_gradw_fits(int(m), int(n), int(k), int(split_k)))
-
-
-def gemm_bf16_gradw(a, b, m, n, k, c_f32, accumulate=True, a_rowsum=None, split_k=2):
-    """c_f32 (+)= A[m, k] @ B[n, k]^T over a long reduction on the whole-output kernel (gv_gemm_bf16_gradw), and, from the same
-    pass over A, a_rowsum[i] += sum_k A[i, k] (the bias gradient next to the weight gradient).  c_f32 dense (m, n)."""
-    if c_f32.stride(0) != n:
-        raise ValueError('gemm_bf16_gradw: the result must be dense')
-    ws_bytes = int(lib.load().gv_gemm_bf16_gradw_workspace_bytes(m, n, split_k))
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=a.device)
-    lib.call('gv_gemm_bf16_gradw', ptr(a), a.stride(0), ptr(b), b.stride(0), m, n, k, ptr(c_f32), 1 if accumulate else 0,
-             ptr(a_rowsum), split_k, ptr(ws), ws_bytes, lib.stream())
-
-
-class _ChainLayer(_ct.Structure):
-    """gv_chain_layer of include/gcnvae.h."""
-    _fields_ = [('w_packed', _ct.c_void_p), ('bias', _ct.c_void_p), ('mask', _ct.c_void_p), ('out_bf16', _ct.c_void_p),
-                ('out_bf16_t', _ct.c_void_p), ('out_f32', _ct.c_void_p), ('n', _ct.c_int32), ('k', _ct.c_int32),
-                ('relu', _ct.c_int32), ('accumulate', _ct.c_int32), ('ldmask', _ct.c_int32), ('ldb', _ct.c_int32),
-                ('ldt', _ct.c_int32), ('ldc', _ct.c_int32), ('iaf_z', _ct.c_void_p), ('iaf_x_old', _ct.c_void_p),
-                ('iaf_colcount', _ct.c_void_p), ('iaf_x_new', _ct.c_void_p), ('iaf_ex', _ct.c_void_p), ('iaf_alpha', _ct.c_void_p),
-                ('iaf_ld', _ct.c_int32), ('iaf_reserved', _ct.c_int32), ('iaf_keep_colcount', _ct.c_void_p), ('mask_t', _ct.c_void_p),
-                ('add_src', _ct.c_void_p), ('add_colcount', _ct.c_void_p), ('ldmask_t', _ct.c_int32), ('ldbits', _ct.c_int32),
-                ('out_bits', _ct.c_void_p), ('mask_bits', _ct.c_void_p), ('x_dup_half', _ct.c_int32), ('t_tile', _ct.c_int32)]
-
-
-class _RowLayer(_ct.Structure):
-    """gv_row_layer of include/gcnvae.h."""
-    _fields_ = [('w', _ct.c_void_p), ('bias', _ct.c_void_p), ('act', _ct.c_void_p), ('inp', _ct.c_void_p), ('out', _ct.c_void_p),
-                ('gw', _ct.c_void_p), ('gb', _ct.c_void_p), ('n', _ct.c_int32), ('k', _ct.c_int32), ('ld', _ct.c_int32),
-                ('relu', _ct.c_int32), ('ldgw', _ct.c_int32), ('reserved', _ct.c_int32)]
-
-
-def _row_layers(layers):
-    arr = (_RowLayer * len(layers))()
-    for c, d in zip(arr, layers):
-        w, ld = _row_major(d['w'], 'w')
-        gw = d.get('gw')
-        c.w, c.ld, c.n, c.k = ptr(w), ld, w.shape[0], w.shape[1]
-        c.bias, c.act, c.inp, c.out = ptr(d.get('bias')), ptr(d.get('act')), ptr(d.get('inp')), ptr(d.get('out'))
-        c.gw, c.gb = ptr(gw), ptr(d.get('gb'))
-        c.relu = 1 if d.get('relu') else 0
-        c.ldgw = gw.stride(0) if gw is not None else 0
-    return arr
-
-
-def made_row_fwd(x, layers):
-    """The masked MLP on ONE row (MADE's pass 0), one single-workgroup launch: layers = dicts with w (n, k) and optional bias,
-    relu, out (n,)."""
-    arr = _row_layers(layers)
-    lib.call('gv_made_row_fwd', ptr(x), len(layers), _ct.addressof(arr), lib.stream())
-
-
-def made_row_bwd(g_out, layers, g_x=None):
-    """Backward of made_row_fwd: layers = dicts with w and optional act (ReLU mask), inp (the layer's input row), gw, gb."""
-    arr = _row_layers(layers)
-    lib.call('gv_made_row_bwd', ptr(g_out), len(layers), _ct.addressof(arr), ptr(g_x), lib.stream())
-
-
-MADE_ROW = _os.environ.get('GV_MADE_ROW', '1') == '1'
-MADE_CHAIN = _os.environ.get('GV_MADE_CHAIN', '1') == '1'
-
-
-def made_pack_weight(w, fwd=True, bwd=True):
-    """Both fragment-packed bf16 copies of a fp32 weight W (n, k): for B = W (a forward layer) and B = W^T (backward-x)."""
-    w, ld = _row_major(w, 'w')
-    n, k = w.shape
-    l = lib.load()
-    pf = torch.empty(int(l.gv_made_pack_weight_elems(n, k)), dtype=torch.bfloat16, device=w.device) if fwd else None
-    pb = torch.empty(int(l.gv_made_pack_weight_elems(k, n)), dtype=torch.bfloat16, device=w.device) if bwd else None
-    lib.call('gv_made_pack_weight', ptr(w), ld, n, k, ptr(pf), ptr(pb), lib.stream())
-    return pf, pb
-
-
-def made_pack_weight_iaf(w):
-    """Forward packing of a [mu | alpha] layer whose chain carries the IAF update (gv_made_pack_weight_iaf)."""
-    w, ld = _row_major(w, 'w')
-    n, k = w.shape
-    pf = torch.empty(int(lib.load().gv_made_pack_weight_elems(n, k)), dtype=torch.bfloat16, device=w.device)
-    lib.call('gv_made_pack_weight_iaf', ptr(w), ld, n, k, ptr(pf), lib.stream())
-    return pf
-
-
-def made_pack_weights(ws, iaf_last=False):
-    """made_pack_weight for every layer of a MADE (at most 8) in one launch: [(packed W, packed W^T), ...]; iaf_last: the last
-    layer's forward copy in the tile order of a chain that carries the IAF update."""
-    ws = [_row_major(w, 'w') for w in ws]
-    l = lib.load()
-    dev = ws[0][0].device
-    pf = [torch.empty(int(l.gv_made_pack_weight_elems(w.shape[0], w.shape[1])), dtype=torch.bfloat16, device=dev) for w, _ in ws]
-    pb = [torch.empty(int(l.gv_made_pack_weight_elems(w.shape[1], w.shape[0])), dtype=torch.bfloat16, device=dev) for w, _ in ws]
-    k = len(ws)
-    tp = lambda ts: (_ct.c_void_p * k)(*[ptr(t) for t in ts])
-    ti = lambda vs: (_ct.c_int32 * k)(*[int(v) for v in vs])
-    tw, tf, tb = tp([w for w, _ in ws]), tp(pf), tp(pb)
-    tl, tn, tk = ti([ld for _, ld in ws]), ti([w.shape[0] for w, _ in ws]), ti([w.shape[1] for w, _ in ws])
-    lib.call('gv_made_pack_weight_multi_iaf' if iaf_last else 'gv_made_pack_weight_multi', k, _ct.addressof(tw), _ct.addressof(tl), _ct.addressof(tn), _ct.addressof(tk),
-             _ct.addressof(tf), _ct.addressof(tb), lib.stream())
-    return list(zip(pf, pb))
-
-
-def made_chain_fits(widths_n, widths_k, any_mask):
-    nl = len(widths_n)
-    arr_n = (_ct.c_int32 * nl)(*[int(v) for v in widths_n])
-    arr_k = (_ct.c_int32 * nl)(*[int(v) for v in widths_k])
-    return bool(lib.load().gv_made_chain_fits(nl, _ct.addressof(arr_n), _ct.addressof(arr_k), 1 if any_mask else 0))
-
-
-MADE_CHAIN_FLOPS = {}        # tag -> flops of one launch (filled while a KernelTimer is installed: bench.py's K4 roofline line)
-
-
-def made_chain(x, m, layers, tag=None):
-    """One launch for a chain of NT products (gv_made_chain): layers = dicts with w_packed, n, k and optional bias, relu, mask,
-    out_bf16, out_bf16_t (t_tile: in tiles of 64 rows, that many elements apart), out_f32, accumulate.  Row strides are taken
-    from the tensors."""
-    if tag is not None and lib.TIMER is not None:
-        MADE_CHAIN_FLOPS[tag] = 2.0 * int(m) * sum(int(d['n']) * int(d['k']) for d in layers)
-    arr = (_ChainLayer * len(layers))()
-    for c, d in zip(arr, layers):
-        mask, ob, ot, of = d.get('mask'), d.get('out_bf16'), d.get('out_bf16_t'), d.get('out_f32')
-        c.w_packed, c.bias, c.mask = ptr(d['w_packed']), ptr(d.get('bias')), ptr(mask)
-        c.out_bf16, c.out_bf16_t, c.out_f32 = ptr(ob), ptr(ot), ptr(of)
-        c.n, c.k, c.relu, c.accumulate = int(d['n']), int(d['k']), 1 if d.get('relu') else 0, 1 if d.get('accumulate') else 0
-        c.ldmask = mask.stride(0) if mask is not None else 0
-        c.ldb = ob.stride(0) if ob is not None else 0
-        c.ldt = ot.stride(0) if ot is not None else 0
-        if ot is not None and d.get('t_tile'):      # out_bf16_t in tiles of 64 rows (what gemm_bf16_gradw_tiles reads): ot starts at tile 0
-            c.ldt, c.t_tile = 64, int(d['t_tile'])
-        c.ldc = of.stride(0) if of is not None else 0
-        iaf = d.get('iaf')
-        if iaf is not None:      # dict(z, x_old, colcount, x_new=None, ex=None, alpha=None): fp32 [m][ld] with one common row stride
-            ts = [iaf[k_] for k_ in ('z', 'x_old', 'x_new', 'ex', 'alpha') if iaf.get(k_) is not None]
-            if len({t.stride(0) for t in ts}) != 1:
-                raise ValueError('made_chain: the IAF operands share one row stride')
-            c.iaf_z, c.iaf_x_old, c.iaf_colcount = ptr(iaf['z']), ptr(iaf['x_old']), ptr(iaf['colcount'])
-            c.iaf_x_new, c.iaf_ex, c.iaf_alpha = ptr(iaf.get('x_new')), ptr(iaf.get('ex')), ptr(iaf.get('alpha'))
-            c.iaf_ld = ts[0].stride(0)
-            c.iaf_reserved = int(iaf.get('debug', 0))
-            c.iaf_keep_colcount = ptr(iaf.get('keep'))
-        mt_, add = d.get('mask_t'), d.get('add')
-        if mt_ is not None:
-            c.mask_t, c.ldmask_t = ptr(mt_), mt_.stride(0)
-        c.x_dup_half = 1 if d.get('x_dup_half') else 0
-        obits, mbits = d.get('out_bits'), d.get('mask_bits')       # int32 (m, >= ceil(n / 32)) sign bits of a hidden activation
-        if obits is not None or mbits is not None:
-            bt = obits if obits is not None else mbits
-            if bt.dtype != torch.int32:
-                raise ValueError('made_chain: mask bits are int32 words')
-            c.out_bits, c.mask_bits, c.ldbits = ptr(obits), ptr(mbits), bt.stride(0)
-        if add is not None:      # (src fp32 [m][ldc], colcount): out_f32 += src where colcount == 0
-            if of is None or add[0].stride(0) != of.stride(0):
-                raise ValueError('made_chain: add_src shares the row stride of out_f32')
-            c.add_src, c.add_colcount = ptr(add[0]), ptr(add[1])
-    lib.call('gv_made_chain', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), lib.stream(), tag=tag)
-
-
-def gemm_bf16_gradw_tiles(a, a_tile, b, b_tile, m, n, k, c_f32, accumulate=True, a_rowsum=None, split_k=2):
-    """gemm_bf16_gradw with both operands in 64-deep K tiles (gv_gemm_bf16_gradw_tiles): element (row, kk) of A at
-    a.flatten()[(kk // 64) * a_tile + row * 64 + kk % 64]; a, b: bf16 tensors whose first element is tile 0 of row 0."""
-    if c_f32.stride(0) != n:
-        raise ValueError('gemm_bf16_gradw_tiles: the result must be dense')
-    ws_bytes = int(lib.load().gv_gemm_bf16_gradw_workspace_bytes(m, n, split_k))
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=c_f32.device)
-    lib.call('gv_gemm_bf16_gradw_tiles', ptr(a), int(a_tile), ptr(b), int(b_tile), m, n, k, ptr(c_f32), 1 if accumulate else 0,
-             ptr(a_rowsum), split_k, ptr(ws), ws_bytes, lib.stream())
-
-
-def _made_params_work(masks, ws, bs, d, S):
-    """The part of a bf16 MADE forward that depends on the parameters alone: the mask fold (one launch for all layers), the
-    weights as bf16 -- fragment-packed for the chain kernel, forward and transposed form -- and pass 0 on its single zero row."""
-    if masks is not None:
-        ws = mul_multi(masks, ws)
-    L = len(ws)
-    dev = ws[0].device
-    f32 = dict(dtype=torch.float32, device=dev)
-    bf = dict(dtype=torch.bfloat16, device=dev)
-    widths = [w.shape[0] for w in ws]
-    chain = (MADE_CHAIN and S > 0 and L <= 8 and made_chain_fits(widths, [w.shape[1] for w in ws], False)
-             and made_chain_fits([w.shape[1] for w in reversed(ws)], [w.shape[0] for w in reversed(ws)], True))
-    fused = chain and MADE_CHAIN_IAF and d % 8 == 0 and widths[L - 1] == 2 * d
-    if chain:       # one launch per pass: fragment-packed weights (forward and transposed form from one launch per layer)
-        packed = made_pack_weights(ws, iaf_last=fused)
-        wbf, wbt = [pk[0] for pk in packed], [pk[1] for pk in packed]
-    else:
-        wbf = [torch.empty(w.shape[0], _pad8(w.shape[1]), **bf) for w in ws]
-        wbt = [torch.empty(w.shape[1], _pad8(w.shape[0]), **bf) for w in ws]
-        for w, a_, t_ in zip(ws, wbf, wbt):
-            cast_bf16(w, a_, t_)
-    # pass 0 on a single zero row (tiny: the generic GEMM with bf16-rounded operands)
-    zero_row = torch.zeros(1, d, **f32)
-    row = MADE_ROW and L <= 8 and d <= 512 and max(widths) <= 512 and all(w.shape[1] % 4 == 0 for w in ws)
-    if row:         # one single-workgroup launch for the whole row
-        acts0 = [torch.empty(1, widths[l], **f32) for l in range(L)]
-        made_row_fwd(None, [dict(w=ws[l], bias=bs[l], relu=l < L - 1, out=acts0[l]) for l in range(L)])
-    else:
-        acts0, inp = [], zero_row
-        for l in range(L):
-            inp = gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE, precision='bf16')
-            acts0.append(inp)
-    return dict(ws=ws, chain=chain, fused=fused, wbf=wbf, wbt=wbt, row=row, acts0=acts0, zero_row=zero_row)
-
-
-# A model that knows its MADE calls ahead of time (the IAF stack behind the R-GCN encoder) announces them at the start of its
-# forward: made_prepare runs _made_params_work of every announced call on ONE side stream -- beside the encoder's layers; under
-# capture a parallel branch -- and the node picks the result up behind an event.  Per flow that is a mask fold, a packing launch,
-# two fills and the single-workgroup row kernel: ~70 us that used to sit in front of every flow's first pass.
-MADE_PREPARE = _os.environ.get('GV_MADE_PREPARE', '1') == '1'
-_made_prep = {}
-
-
-def _made_prep_key(ws, d, S):
-    return (tuple(w.data_ptr() for w in ws), int(d), int(S))
-
-
-def made_prepare(calls):
-    """calls: [(colcount, weights, biases, masks)] of the bf16 MADE nodes the caller is about to run (made_forward's arguments)."""
-    if (not MADE_PREPARE or not calls or GEMM_PRECISION != 'bf16' or not MADE_BF16_STORAGE or lib.TIMER is not None
-            or _process_group()):
-        return
-    main, side = torch.cuda.current_stream(), _side('made_prep')
-    side.wait_stream(main)
-    with torch.cuda.stream(side), torch.no_grad():
-        for colcount, weights, biases, masks in calls:
-            d, S = weights[0].shape[1], colcount.shape[0] - 1
-            if masks is None or len(weights) > 8 or d % 8 or any(w.shape[0] % 8 or w.shape[1] % 8 for w in weights):
-                continue        # (not the call made_forward hands to the bf16 node with these very tensors)
-            prep = _made_params_work(tuple(masks), tuple(weights), tuple(biases), d, S)
-            prep['done'] = torch.cuda.Event()
-            prep['done'].record(side)
-            _made_prep[_made_prep_key(weights, d, S)] = prep
-
-
-def made_prepare_finish():
-    """Drop what was prepared and not picked up (and join the side stream: nothing may stay unjoined in a captured step)."""
-    if _made_prep:
-        torch.cuda.current_stream().wait_stream(_side('made_prep'))
-        _made_prep.clear()
-
-
-class _MADEForwardBF16(torch.autograd.Function):
-    """MADE.forward (kgvae/flow_network.py:85-98) with bf16 operands in MEMORY (BASELINE configs[2]; semantics as the
-    tests' CPU emulation pins them: operands rounded to bf16, fp32 products and sums).  Same structure as _MADEForward -- pass 0 on one
-    broadcast row, the later passes stacked -- but the stacked activations are stored as bf16 row-major PLUS a bf16
-    transposed copy (written by the producing GEMM's epilogue), the backward keeps the ReLU-masked gradients of every layer the
-    same way, and all three product kinds (forward, backward-x, backward-W) run on gv_gemm_bf16_nt.  Per-pass column offset
-    in the transposed buffers is rounded up to 8 rows (8-B aligned stores); the pad columns stay zero."""
-
-    @staticmethod
-    def forward(ctx, z, colcount, masks, *wb):
-        ctx.set_materialize_grads(False)
-        L = len(wb) // 2
-        ws, bs = wb[:L], wb[L:]
-        ctx.masks = masks
-        if masks is not None:          # raw weights + their masks: folded here, all layers in one launch (and in backward likewise)
-            ctx.direct_w = [_direct(w) for w in ws]
-        z = _chk(z.contiguous(), name='z')
-        n, d = z.shape
-        P = colcount.shape[0]
-        S = P - 1
-        dev = z.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        bf = dict(dtype=torch.bfloat16, device=dev)
-        st = lib.stream()
-        npad = _pad8(n)
-        # what depends on the parameters alone (mask fold, bf16 / fragment-packed weights, pass 0's row): done ahead on a side stream
-        # where the model announced this call (made_prepare), here otherwise
-        prep = _made_prep.pop(_made_prep_key(ws, d, S), None)
-        if prep is not None:
-            torch.cuda.current_stream().wait_event(prep['done'])
-        else:
-            prep = _made_params_work(masks, ws, bs, d, S)
-        ws, chain, fused, wbf, wbt, row, acts0, zero_row = (prep[k_] for k_ in ('ws', 'chain', 'fused', 'wbf', 'wbt', 'row', 'acts0', 'zero_row'))
-        widths = [w.shape[0] for w in ws]                       # layer output widths; inputs: d, then widths[:-1]
-        xin = torch.empty(max(S, 1) * n, d, **f32)               # fp32 pass inputs (update pass-through, backward)
-        xin_b = torch.empty(max(S, 1) * n, _pad8(d), **bf)
-        # fused: the transposed copies (read by the weight-gradient products alone) in tiles of 64 rows, when every product fits
-        # the whole-output kernel; pass p then starts at tile p * T
-        T = (n + 63) // 64
-        split_t = max(2, min(GRADW_SPLIT_MAX, S * T * 64 // 512))
-        tiled = (fused and MADE_T_TILES and S > 0 and d % 4 == 0
-                 and all(gemm_bf16_gradw_fits(widths[l], ws[l].shape[1], S * T * 64, split_t) for l in range(L)))
-        if tiled:
-            tbufs, T, tt = _empty_t_tiles([d] + widths[:L - 1], S, n, bf)
-        else:
-            tbufs, tt = _empty_t_padded([d] + widths[:L - 1], max(S, 1), n, npad, bf)[:-1], 0
-        t_of = (lambda buf, q, r0=0: dict(out_bf16_t=buf[q * T + r0 // 64:], t_tile=tt)) if tiled else \
-               (lambda buf, q, r0=0: dict(out_bf16_t=buf[:, q * npad:q * npad + n]))
-        xin_t = tbufs[0]
-        # fused (the IAF update inside the chain): row-major activations never leave the chain (the backward chain stages its ReLU
-        # masks from the transposed copies), and of [mu | alpha] only exp(alpha + mu) is kept (+ alpha of the last pass)
-        acts_b = [] if fused else [torch.empty(max(S, 1) * n, _pad8(widths[l]), **bf) for l in range(L - 1)]
-        # ... as sign BITS, one int32 word per (row, 32 columns)
-        sign = [torch.empty(max(S, 1) * n, (widths[l] + 31) // 32, dtype=torch.int32, device=dev) for l in range(L - 1)] if fused else []
-        acts_t = tbufs[1:]
-        if fused:
-            net_out = torch.empty(max(S, 1) * n, d, **f32)           # exp(alpha + mu) of every stacked pass
-            alpha_last = torch.empty(n, d, **f32)
-        else:
-            net_out = torch.empty(max(S, 1) * n, widths[L - 1], **f32)   # [mu | alpha] of every stacked pass
-        x_out = torch.empty(n, d, **f32)
-        def update(net, ld_net, x_old, cc, q):
-            """The IAF update of one pass.  Its result is pass q + 1's input (slice q of the stacked buffers: fp32 + the bf16
-            row-major and transposed copies the products read, written by the same launch) or, after the last pass, x_out."""
-            if q < S and tiled:
-                lib.call('gv_iaf_update_fwd_bf16_tiles', ptr(z), ptr(net), ld_net, ptr(x_old), ptr(cc), ptr(xin[q * n:(q + 1) * n]),
-                         ptr(xin_b[q * n:(q + 1) * n]), xin_b.stride(0), ptr(xin_t[q * T:]), tt, n, d, st)
-            elif q < S:
-                lib.call('gv_iaf_update_fwd_bf16', ptr(z), ptr(net), ld_net, ptr(x_old), ptr(cc), ptr(xin[q * n:(q + 1) * n]),
-                         ptr(xin_b[q * n:(q + 1) * n]), xin_b.stride(0), ptr(xin_t[:, q * npad:q * npad + n]), xin_t.stride(0),
-                         n, d, st)
-            else:
-                lib.call('gv_iaf_update_fwd', ptr(z), ptr(net), ld_net, ptr(x_old), ptr(cc), ptr(x_out), n, d, st)
-        update(acts0[L - 1], 0, z, colcount[0], 0)
-
-        def fused_passes(r0, r1):
-            """Passes 1 .. P-1 for the rows [r0, r1) (r0 a multiple of 64): every launch of a pass is row-local."""
-            for p in range(1, P):
-                a, b, na, nb_ = (p - 1) * n + r0, (p - 1) * n + r1, p * n + r0, p * n + r1
-                # the pass's IAF update in the last layer's epilogue: x_new and its operand copies leave the chain
-                head = dict(w_packed=wbf[L - 1], n=widths[L - 1], k=ws[L - 1].shape[1], bias=bs[L - 1],
-                            iaf=dict(z=z[r0:r1], x_old=xin[a:b], colcount=colcount[p], ex=net_out[a:b]))
-                if p < S:   # fp32 x_new only where the next pass hands a column through; its operands in bf16
-                    head['iaf'].update(x_new=xin[na:nb_], keep=colcount[p + 1])
-                    head.update(out_bf16=xin_b[na:nb_], **t_of(xin_t, p, r0))
-                else:
-                    head['iaf'].update(x_new=x_out[r0:r1], alpha=alpha_last[r0:r1])
-                made_chain(xin_b[a:b], r1 - r0, [dict(w_packed=wbf[l], n=widths[l], k=ws[l].shape[1], bias=bs[l], relu=True,
-                                                      out_bits=sign[l][a:b], **t_of(acts_t[l], p - 1, r0)) for l in range(L - 1)] + [head],
-                           tag='madechain_fwd')
-        if fused:
-            _by_row_blocks(fused_passes, n, None if tiled else 1)
-        for p in range(1, P) if not fused else ():
-            sl = slice((p - 1) * n, p * n)
-            tsl = slice((p - 1) * npad, (p - 1) * npad + n)
-            inp = xin_b[sl]
-            if chain:
-                head = dict(w_packed=wbf[L - 1], n=widths[L - 1], k=ws[L - 1].shape[1], bias=bs[L - 1])
-                head['out_f32'] = net_out[sl]
-                made_chain(inp, n, [dict(w_packed=wbf[l], n=widths[l], k=ws[l].shape[1], bias=bs[l], relu=True,
-                                         out_bf16=acts_b[l][sl], out_bf16_t=acts_t[l][:, tsl]) for l in range(L - 1)] + [head],
-                           tag='madechain_fwd')
-            else:
-                for l in range(L - 1):
-                    gemm_bf16_nt(inp, wbf[l], n, widths[l], ws[l].shape[1], bias=bs[l], relu=True, c_bf16=acts_b[l][sl],
-                                 c_bf16_t=acts_t[l][:, tsl])
-                    inp = acts_b[l][sl]
-                gemm_bf16_nt(inp, wbf[L - 1], n, widths[L - 1], ws[L - 1].shape[1], bias=bs[L - 1], c_f32=net_out[sl])
-            update(net_out[sl], 2 * d, xin[sl], colcount[p], p)
-        log_det = torch.empty(n, **f32)
-        if P > 1 and fused:
-            lib.call('gv_rowsum', ptr(alpha_last), d, 0, d, ptr(log_det), n, st)
-        elif P > 1:
-            lib.call('gv_rowsum', ptr(net_out[(S - 1) * n:]), 2 * d, d, d, ptr(log_det), n, st)
-        else:
-            log_det = acts0[L - 1][:, d:].sum(dim=1).expand(n).contiguous()
-        ctx.save_for_backward(z, colcount, xin_t, zero_row, net_out, *(sign if fused else acts_b), *acts_t, *acts0, *wbt, *ws)
-        ctx.L = L
-        ctx.chain = chain
-        ctx.fused = fused
-        ctx.tiled, ctx.t_tile = tiled, tt
-        ctx.row = row
-        ctx.direct_b = [_direct(b) if b is not None else None for b in bs]
-        _stamp_direct(ctx)
-        ctx.has_bias = [b is not None for b in bs]
-        return x_out, log_det
-
-    @staticmethod
-    def backward(ctx, gx, gld):
-        L = ctx.L
-        saved = ctx.saved_tensors
-        z, colcount, xin_t, zero_row, net_out = saved[:5]
-        o = 5
-        acts_b, acts_t = saved[o:o + L - 1], saved[o + L - 1:o + 2 * (L - 1)]      # fused: acts_b holds the sign-bit words instead
-        o += 2 * (L - 1)
-        acts0, wbt, ws = saved[o:o + L], saved[o + L:o + 2 * L], saved[o + 2 * L:o + 3 * L]
-        n, d = z.shape
-        P = colcount.shape[0]
-        S = P - 1
-        dev = z.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        bf = dict(dtype=torch.bfloat16, device=dev)
-        st = lib.stream()
-        npad = _pad8(n)
-        widths = [w.shape[0] for w in ws]
-        gx = torch.zeros(n, d, **f32) if gx is None else _chk(gx.contiguous(), name='gx')
-        gld = None if gld is None else _chk(gld.contiguous(), name='gld')
-        # ReLU-masked gradients w.r.t. every layer's pre-activation: bf16 row-major (operand of backward-x) and transposed
-        # (operand of backward-W and of the bias sums)
-        if ctx.fused:   # only the chain's input [g_mu | g_alpha], one pass at a time; the hidden layers' stay inside the chain
-            gm_in = torch.empty(n, _pad8(widths[L - 1]), **bf)
-        else:
-            gm_b = [torch.empty(max(S, 1) * n, _pad8(widths[l]), **bf) for l in range(L)]
-        tiled, T = ctx.tiled, (n + 63) // 64
-        if tiled:
-            gm_t, _, tb = _empty_t_tiles(widths, S, n, bf)
-            gm_t_all = None
-            t_of = lambda buf, q, r0=0: dict(out_bf16_t=buf[q * T + r0 // 64:], t_tile=tb)
-        else:
-            *gm_t, gm_t_all = _empty_t_padded(widths, max(S, 1), n, npad, bf)
-            t_of = lambda buf, q, r0=0: dict(out_bf16_t=buf[:, q * npad:q * npad + n])
-        g_z = torch.empty(n, d, **f32) if (ctx.fused and P > 1) else torch.zeros(n, d, **f32)      # fused: the first pass writes it
-        gz_p = torch.empty(n, d, **f32)
-        g_cur = gx
-        g_olds = {p: torch.empty(n, d, **f32) for p in range(1, P)} if ctx.fused else None      # dL/dx_old of every pass (allocated before any fork)
-
-        def fused_passes(r0, r1):
-            """The backward of passes P-1 .. 1 for the rows [r0, r1) (r0 a multiple of 64): every launch of a pass is row-local."""
-            g_in = gx
-            for p in reversed(range(1, P)):
-                a, b, t0 = (p - 1) * n + r0, (p - 1) * n + r1, r0 // 64
-                # from exp(alpha + mu); the gradient handed through to x_old (columns of count 0) is added by the chain's last layer
-                # without a log-det gradient (every pass but the last) g_alpha == g_mu: the chain's row-major input holds the g_mu half
-                # alone and the chain stages it twice (x_dup_half)
-                half = (gld is None or p != P - 1) and widths[L - 1] % 16 == 0 and L > 1
-                lib.call('gv_iaf_update_bwd_bf16_ex', ptr(z[r0:r1]), ptr(net_out[a:b]), d, ptr(colcount[p]), ptr(g_in[r0:r1]),
-                         ptr(gld[r0:r1]) if (p == P - 1 and gld is not None) else None, ptr(g_z[r0:r1]), ptr(gm_in[r0:r1]), gm_in.stride(0),
-                         ptr(gm_t[L - 1][(p - 1) * T + t0:] if tiled else gm_t[L - 1][:, (p - 1) * npad:]),
-                         tb if tiled else gm_t[L - 1].stride(0), None,
-                         (1 if p == P - 1 else 0) | (2 if half else 0) | (4 if tiled else 0), r1 - r0, d, lib.stream())
-                first = dict(w_packed=wbt[L - 1], n=widths[L - 2], k=widths[L - 1], mask_bits=acts_b[L - 2][a:b],
-                             x_dup_half=half, **t_of(gm_t[L - 2], p - 1, r0)) if L > 1 else None
-                made_chain(gm_in[r0:r1], r1 - r0,
-                           ([first] if first is not None else []) +
-                           [dict(w_packed=wbt[l], n=widths[l - 1], k=widths[l], mask_bits=acts_b[l - 1][a:b],
-                                 **t_of(gm_t[l - 1], p - 1, r0)) for l in reversed(range(1, L - 1))] +
-                           [dict(w_packed=wbt[0], n=d, k=widths[0], out_f32=g_olds[p][r0:r1], add=(g_in[r0:r1], colcount[p]))],
-                           tag='madechain_bwd')
-                g_in = g_olds[p]
-        if ctx.fused:
-            _by_row_blocks(fused_passes, n, None if tiled else 1)
-            if P > 1:
-                g_cur = g_olds[1]
-        for p in reversed(range(1, P)) if not ctx.fused else ():
-            sl = slice((p - 1) * n, p * n)
-            tsl = slice((p - 1) * npad, (p - 1) * npad + n)
-            g_old = torch.empty(n, d, **f32)
-            # the update's backward: g_z accumulated in place, [g_mu | g_alpha] straight into the bf16 operands of the products
-            lib.call('gv_iaf_update_bwd_bf16', ptr(z), ptr(net_out[sl]), 2 * d, ptr(colcount[p]), ptr(g_cur),
-                     ptr(gld) if p == P - 1 else None, ptr(g_z), ptr(gm_b[L - 1][sl]), gm_b[L - 1].stride(0),
-                     ptr(gm_t[L - 1][:, tsl]), gm_t[L - 1].stride(0), ptr(g_old), n, d, st)
-            if ctx.chain:                        # g_{l-1} = (g_l W_l) * [a_{l-1} > 0] down to g_x, one launch
-                made_chain(gm_b[L - 1][sl], n,
-                           [dict(w_packed=wbt[l], n=widths[l - 1], k=widths[l], mask=acts_b[l - 1][sl], out_bf16=gm_b[l - 1][sl],
-                                 out_bf16_t=gm_t[l - 1][:, tsl]) for l in reversed(range(1, L))] +
-                           [dict(w_packed=wbt[0], n=d, k=widths[0], out_f32=g_old, accumulate=True)], tag='madechain_bwd')
-            else:
-                for l in reversed(range(1, L)):      # g_{l-1} = (g_l W_l) * [a_{l-1} > 0]
-                    gemm_bf16_nt(gm_b[l][sl], wbt[l], n, widths[l - 1], widths[l], mask=acts_b[l - 1][sl], c_bf16=gm_b[l - 1][sl],
-                                 c_bf16_t=gm_t[l - 1][:, tsl])
-                gemm_bf16_nt(gm_b[0][sl], wbt[0], n, d, widths[0], c_f32=g_old, accumulate=True)
-            g_cur = g_old
-        # pass 0: the update's gradient w.r.t. the broadcast net row is its column sum; x_old was the zero matrix
-        g_row = iaf_bwd_row0(z, acts0[L - 1], colcount[0], g_cur, gld if P == 1 else None, g_z)
-        rows0 = [None] * L
-        row_gw = row_gb = None
-        if ctx.row:     # the row's whole backward chain (masked row gradients, outer products, bias gradients): one launch
-            row_gw = [torch.empty(widths[l], ws[l].shape[1], **f32) if ctx.needs_input_grad[3 + l] else None for l in range(L)]
-            # a bias whose slice of the optimiser arena is still all-zero takes its gradient there directly
-            _verify_direct(ctx)
-            direct_b = [t if (t is not None and t.data_ptr() in GRAD_FRESH and t.is_contiguous()) else None for t in ctx.direct_b]
-            row_gb = [(direct_b[l] if direct_b[l] is not None else torch.empty(widths[l], **f32))
-                      if ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l] else None for l in range(L)]
-        else:
-            for l in reversed(range(L)):
-                rows0[l] = g_row
-                if l > 0:
-                    mask = acts0[l] if l < L - 1 else None
-                    g_row = gemm(g_row, ws[l], a_relu_mask=mask, precision='bf16')
-        mtot = S * T * 64 if tiled else max(S, 1) * npad
-        # where each layer's bias gradient accumulates, and whether the weight-gradient launch can take it along
-        wants_gb = [ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l] for l in range(L)]
-        gb_target = [(row_gb[l] if ctx.row else None) if wants_gb[l] else None for l in range(L)]
-        fused_gb = [S > 0 and ctx.row and gb_target[l] is not None and ctx.needs_input_grad[3 + l] and row_gw[l] is not None
-                    and row_gw[l].stride(0) == ws[l].shape[1]
-                    and gemm_bf16_gradw_fits(widths[l], ws[l].shape[1], mtot, max(2, min(GRADW_SPLIT_MAX, mtot // 512))) for l in range(L)]
-        if tiled:       # the tiled copies are read by the whole-output product alone: it takes every bias gradient along
-            fused_gb = [wants_gb[l] for l in range(L)]
-        # The weight-gradient products of this MADE on a SIDE stream (a parallel branch of a captured graph): they depend on
-        # nothing later in the backward pass, and the next MADE's backward chains leave half of the CUs idle in their second
-        # round of workgroups.  Only when every result goes straight into the optimiser's gradient arena (nothing is handed
-        # back to autograd on this stream); the side stream is joined when the whole backward pass has run.
-        beside = False
-        if tiled and ctx.row and ctx.masks is not None and S > 0:
-            _verify_direct(ctx)
-            beside = (all(ctx.direct_w[l] is not None and ctx.direct_w[l].data_ptr() in GRAD_FRESH and ctx.direct_w[l].is_contiguous()
-                          for l in range(L) if ctx.needs_input_grad[3 + l])
-                      and all(direct_b[l] is not None for l in range(L) if wants_gb[l]))
-        with backward_side(beside, gm_t, xin_t, acts_t, row_gw, row_gb, g_row, acts0, ws):
-            if ctx.row:
-                made_row_bwd(g_row, [dict(w=ws[l], act=acts0[l] if l < L - 1 else None, inp=acts0[l - 1] if l > 0 else None,
-                                          gw=row_gw[l], gb=row_gb[l]) for l in range(L)])
-            g_ws, g_bs = _MADEForwardBF16._weight_gradients(ctx, L, S, T, tiled, mtot, widths, ws, acts0, rows0, zero_row, row_gw, row_gb,
-                                                            direct_b if ctx.row else None, wants_gb, gb_target, fused_gb, gm_t, gm_t_all,
-                                                            tb if tiled else 0, xin_t, acts_t, f32, lib.stream())
-        return (g_z, None, None, *g_ws, *g_bs)
-
-    @staticmethod
-    def _weight_gradients(ctx, L, S, T, tiled, mtot, widths, ws, acts0, rows0, zero_row, row_gw, row_gb, direct_b, wants_gb, gb_target,
-                          fused_gb, gm_t, gm_t_all, tb, xin_t, acts_t, f32, st):
-        """dL/dW_l, dL/db_l of every layer from the stacked passes (+ pass 0's share, already in row_gw / row_gb), the mask fold."""
-        g_ws, g_bs, g_bs_acc = [], [], []
-        for l in range(L):
-            mask0 = acts0[l] if l < L - 1 else None
-            inp0 = zero_row if l == 0 else acts0[l - 1]
-            gw = gb = None
-            if ctx.needs_input_grad[3 + l]:
-                gw = row_gw[l] if ctx.row else gemm(rows0[l], inp0, trans_a=True, a_relu_mask=mask0, precision='bf16')
-                if S > 0 and not tiled:       # dW_l = g_l^T a_{l-1}: the NT kernel on the transposed copies, reduction over all stacked rows
-                    in_t = xin_t if l == 0 else acts_t[l - 1]
-                    split = max(2, min(GRADW_SPLIT_MAX, mtot // 512))
-                    if fused_gb[l]:      # ... and the stacked passes' share of the bias gradient from the same pass over g_l^T
-                        gemm_bf16_gradw(gm_t[l], in_t, widths[l], ws[l].shape[1], mtot, gw, accumulate=True,
-                                        a_rowsum=gb_target[l], split_k=split)
-                    else:
-                        gemm_bf16_nt(gm_t[l], in_t, widths[l], ws[l].shape[1], mtot, c_f32=gw, accumulate=True, split_k=split)
-            if ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l]:
-                gb = row_gb[l] if ctx.row else colsum(rows0[l], relu_mask=mask0)
-            if tiled and (gw is not None or gb is not None):
-                # dW_l = g_l^T a_{l-1} over all stacked rows, both operands in 64-row tiles, db_l from the same pass over g_l^T
-                gemm_bf16_gradw_tiles(gm_t[l], tb, xin_t if l == 0 else acts_t[l - 1], ctx.t_tile, widths[l], ws[l].shape[1], mtot,
-                                      gw if gw is not None else torch.empty(widths[l], ws[l].shape[1], **f32), accumulate=gw is not None,
-                                      a_rowsum=gb, split_k=max(2, min(GRADW_SPLIT_MAX, mtot // 512)))
-            if ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l]:
-                if S > 0 and L > 8:
-                    rws = torch.empty(int(lib.load().gv_rowsum_bf16_workspace_floats(widths[l], mtot)), **f32)
-                    lib.call('gv_rowsum_bf16', ptr(gm_t[l]), gm_t[l].stride(0), widths[l], mtot, ptr(gb), 1, ptr(rws), st)
-            g_bs_acc.append(None if fused_gb[l] else gb)      # where the row-sum pass still has to add this layer's share
-            if ctx.row and gb is not None and direct_b[l] is not None:
-                GRAD_FRESH.discard(gb.data_ptr())
-                gb = None
-            g_ws.append(gw)
-            g_bs.append(gb)
-        if S > 0 and L <= 8 and any(b is not None for b in g_bs_acc):
-            # the stacked passes' share of every bias gradient: ONE pass over the transposed gradient buffers of all layers
-            rws = torch.empty(int(lib.load().gv_rowsum_bf16_workspace_floats(sum(widths), mtot)), **f32)
-            outs = (_ct.c_void_p * L)(*[ptr(b) for b in g_bs_acc])
-            segs = (_ct.c_int32 * L)(*widths)
-            lib.call('gv_rowsum_bf16_segments', ptr(gm_t_all), gm_t_all.stride(0), sum(widths), mtot, L, _ct.addressof(outs),
-                     _ct.addressof(segs), 1, ptr(rws), st)
-        if ctx.masks is not None:       # dL/dW = mask * dL/d(mask * W): one launch for all layers, straight into the arena where fresh
-            _verify_direct(ctx)
-            idx = [l for l in range(L) if g_ws[l] is not None]
-            tgt = [ctx.direct_w[l] if (ctx.direct_w[l] is not None and ctx.direct_w[l].data_ptr() in GRAD_FRESH
-                                       and ctx.direct_w[l].is_contiguous()) else None for l in idx]
-            res = mul_multi([ctx.masks[l] for l in idx], [g_ws[l] for l in idx], outs=tgt) if idx else []
-            for l, t, r in zip(idx, tgt, res):
-                if t is not None:
-                    GRAD_FRESH.discard(t.data_ptr())
-                    g_ws[l] = None
-                else:
-                    g_ws[l] = r
-        return g_ws, g_bs
-
-
-MADE_BF16_STORAGE = _os.environ.get('GV_MADE_BF16', '1') == '1'
-GRADW_SPLIT_MAX = int(_os.environ.get('GV_GRADW_SPLIT_MAX', '256'))      # most K slices of a MADE weight-gradient product
-MADE_CHAIN_IAF = _os.environ.get('GV_MADE_CHAIN_IAF', '1') == '1'      # the IAF update inside the chain's last layer
-MADE_T_TILES = _os.environ.get('GV_MADE_T_TILES', '1') == '1'          # ... and the transposed copies in tiles of 64 rows
-
-
-MADE_ROW_BLOCKS = int(_os.environ.get('GV_MADE_ROW_BLOCKS', '2'))       # independent row blocks of a MADE's passes (1: off)
-# ... of the fp32 node (a launch per product: 9.47 -> 9.33 ms for the mini-batch step with 3 IAF blocks, 9.52 -> 9.32 on the full
-# FB15k-237-sized graph; three blocks 10.4), from 128 row tiles on
-MADE_F32_ROW_BLOCKS = int(_os.environ.get('GV_MADE_F32_ROW_BLOCKS', '2'))
-MADE_F32_ROW_BLOCKS_MIN_TILES = int(_os.environ.get('GV_MADE_F32_ROW_BLOCKS_MIN_TILES', '128'))
-MADE_ROW_BLOCKS_MIN_TILES = int(_os.environ.get('GV_MADE_ROW_BLOCKS_MIN_TILES', '0'))     # 0: more row tiles than chain workgroups fit the chip
-_chain_slots = {}
-
-
-def _made_row_blocks(n, want=None, min_tiles=None):
-    """Row ranges a MADE's passes are run over, as independent launch sequences on their own streams.  Every launch of a pass is
-    row-local (a chain workgroup owns 64 rows through all layers, the update and its backward are element-wise), so the passes of
-    one row block depend on nothing in another block -- but as ONE sequence of launches every pass waits for the last workgroup
-    of the one before it.  That is expensive here: two chain workgroups fit a CU, so the 640 workgroups of a WN18RR pass run a
-    second round on a quarter of the chip (forward chain: 60 us at 512 row tiles, 88 us at 576), and the chain (latency-bound,
-    ~2 TB/s) alternates with the update's backward (bandwidth-bound) instead of running beside it.  Two blocks of 320 row tiles
-    on two streams: 6.32 -> 5.72 ms per step (blocks cut at the last full round of workgroups, 512 + 128 tiles: 6.01; three
-    blocks 6.08, four 6.46).  Only where a pass has more row tiles than the chip holds chain workgroups: at FB15k-237 size (228
-    tiles, one partial round) two blocks cost 3.36 -> 3.42 ms."""
-    want = MADE_ROW_BLOCKS if want is None else want
-    if want <= 1:
-        return [(0, n)]
-    tiles = (n + 63) // 64
-    least = MADE_ROW_BLOCKS_MIN_TILES if min_tiles is None else min_tiles
-    if least <= 0:
-        dev = torch.cuda.current_device()
-        if dev not in _chain_slots:
-            _chain_slots[dev] = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
-        least = _chain_slots[dev] + 1
-    k = want if tiles >= least else 1
-    k = max(1, min(k, tiles))
-    cuts = [(tiles * i // k) * 64 for i in range(k)] + [n]
-    return [(cuts[i], cuts[i + 1]) for i in range(k)]
-
-
-def _by_row_blocks(run, n, want, min_tiles=None):
-    """run(r0, r1) over the row blocks of _made_row_blocks (want: how many, None: MADE_ROW_BLOCKS; <= 1: all rows at once): the
-    first on the current stream, the others on side streams that are joined before returning (under hipGraph capture: parallel
-    branches)."""
-    blocks = _made_row_blocks(n, want, min_tiles) if lib.TIMER is None else [(0, n)]      # (timed launches are whole launches: bench.py's K4 line)
-    if len(blocks) == 1:
-        run(0, n)
-        return
-    main = torch.cuda.current_stream()
-    sides = [_side(('made_rows', i)) for i in range(1, len(blocks))]
-    for sd in sides:
-        sd.wait_stream(main)
-    run(*blocks[0])
-    for sd, blk in zip(sides, blocks[1:]):
-        with torch.cuda.stream(sd):
-            run(*blk)
-    for sd in sides:
-        main.wait_stream(sd)
-
-
-def made_forward(z, colcount, weights, biases, masks=None):
-    """MADE.forward as one autograd node; with bf16 dense products (set_gemm_precision('bf16'), BASELINE configs[2]) and
-    layer widths that are multiples of 8 the bf16-storage pipeline of csrc/k_made.hip runs.  ``masks``: the autoregressive
-    masks when ``weights`` are the RAW parameters (MaskedLinear.weight); None when the masks are folded in already."""
-    if (GEMM_PRECISION == 'bf16' and MADE_BF16_STORAGE and z.shape[1] % 8 == 0 and all(w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0
-                                                                                       for w in weights)):
-        if masks is not None and len(weights) > 8:           # gv_mul_multi's table holds 8 entries
-            weights, masks = [masked_weight(m, w) for m, w in zip(masks, weights)], None
-        return _MADEForwardBF16.apply(z, colcount, tuple(masks) if masks is not None else None, *weights, *biases)
-    if masks is not None and len(weights) > 8:               # gv_mul_multi's table holds 8 entries
-        weights, masks = [masked_weight(m, w) for m, w in zip(masks, weights)], None
-    return _MADEForward.apply(z, colcount, tuple(masks) if masks is not None else None, *weights, *biases)
+# ------------------------------------------------------------------------------------------------
+# K4, the masked MLP of the IAF blocks (MADE): made.py -- same namespace for the callers (ops.made_forward, ops.made_chain, ...)
+# ------------------------------------------------------------------------------------------------
+from .made import *                                              # noqa: E402,F401,F403
+from .made import _ChainLayer, _RowLayer, _MADEForward, _MADEForwardBF16      # noqa: E402,F401

@@ -714,20 +714,20 @@ def test_train_driver_with_graph_step(tmp_path, capsys, bf16):
 @pytest.mark.gpu
 @pytest.mark.parametrize('blocks', [2, 3])
 def test_made_passes_over_row_blocks_on_their_own_streams_give_the_same_bits(monkeypatch, blocks):
-    """ops._by_row_blocks: the bf16 MADE node runs its passes over independent row blocks on side streams (every launch of a pass
+    """made._by_row_blocks: the bf16 MADE node runs its passes over independent row blocks on side streams (every launch of a pass
     is row-local) -- outputs and every gradient equal the one-block run bit for bit, also when the block boundary is not the end
     of the rows' last 64-row tile and with the weight gradients going through the optimiser arena (the side-stream products)."""
-    from gcn_vae_amd import ops
+    from gcn_vae_amd import made, ops
     from gcn_vae_amd.flows import MADE
     from gcn_vae_amd.optim import FlatAdam
     n, d = 1000, 40                       # 16 row tiles, the last one partial
     z = torch.randn(n, d, generator=torch.Generator().manual_seed(5)).cuda()
     res, seen = [], []
-    inner = ops._by_row_blocks
-    monkeypatch.setattr(ops, '_by_row_blocks', lambda run, rows, want, *a: (seen.append((rows, want is None)), inner(run, rows, want, *a))[1])
+    inner = made._by_row_blocks
+    monkeypatch.setattr(made, '_by_row_blocks', lambda run, rows, want, *a: (seen.append((rows, want is None)), inner(run, rows, want, *a))[1])
     for k in (1, blocks):
-        monkeypatch.setattr(ops, 'MADE_ROW_BLOCKS', k)
-        monkeypatch.setattr(ops, 'MADE_ROW_BLOCKS_MIN_TILES', 1)
+        monkeypatch.setattr(made, 'MADE_ROW_BLOCKS', k)
+        monkeypatch.setattr(made, 'MADE_ROW_BLOCKS_MIN_TILES', 1)
         torch.manual_seed(3)
         m = MADE(d, 56, 2).cuda()
         opt = FlatAdam(list(m.parameters()), lr=1e-3, max_grad_norm=1.0)
@@ -739,7 +739,7 @@ def test_made_passes_over_row_blocks_on_their_own_streams_give_the_same_bits(mon
         torch.cuda.synchronize()
         res.append((x.detach().clone(), ld.detach().clone(), zz.grad.clone(), [p.grad.detach().clone() for p in m.parameters()]))
         opt.close()
-    assert len(ops._made_row_blocks(n)) == blocks and ops._made_row_blocks(n)[1][0] % 64 == 0
+    assert len(made._made_row_blocks(n)) == blocks and made._made_row_blocks(n)[1][0] % 64 == 0
     assert seen and all(t for _, t in seen)            # the node took the path with the tiled copies (the one that is split)
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
     assert float(res[0][2].abs().max()) > 0
@@ -752,7 +752,7 @@ def test_flow_parameter_work_prepared_beside_the_encoder_gives_the_same_bits(mon
     """ops.made_prepare (KGVAE.forward announces its MADE calls: mask folds, packed weights and pass 0's row run on a side stream
     beside the R-GCN layers and are picked up behind an event) against the node doing that work itself: same embedding, same loss,
     same gradients, bit for bit; nothing prepared is left over."""
-    from gcn_vae_amd import ops, sampling
+    from gcn_vae_amd import made, ops, sampling
     from gcn_vae_amd.data import synthetic_kg
     from gcn_vae_amd.encoders import KGVAE
     from gcn_vae_amd.train import LinkPredict
@@ -768,10 +768,10 @@ def test_flow_parameter_work_prepared_beside_the_encoder_gives_the_same_bits(mon
     trip, lab = torch.from_numpy(samples).cuda(), torch.from_numpy(labels).cuda()
     eps = torch.randn(n, h, generator=torch.Generator().manual_seed(1)).cuda()
     res, used = [], []
-    inner = ops._made_params_work
-    monkeypatch.setattr(ops, '_made_params_work', lambda *a: (used.append(torch.cuda.current_stream().cuda_stream), inner(*a))[1])
+    inner = made._made_params_work
+    monkeypatch.setattr(made, '_made_params_work', lambda *a: (used.append(torch.cuda.current_stream().cuda_stream), inner(*a))[1])
     for on in (False, True):
-        monkeypatch.setattr(ops, 'MADE_PREPARE', on)
+        monkeypatch.setattr(made, 'MADE_PREPARE', on)
         torch.manual_seed(0)
         net = LinkPredict(KGVAE, n, h, n_rel, num_bases=4, num_hidden_layers=2, dropout=0.0, use_cuda=True, reg_param=0.01,
                           kl_param=1e-3, mmd_param=0.0, k=4, n_flows=2).cuda().train()
@@ -784,7 +784,7 @@ def test_flow_parameter_work_prepared_beside_the_encoder_gives_the_same_bits(mon
             loss.backward()
         torch.cuda.synchronize()
         assert len(used) == 2 and all((st != main) == on for st in used), (on, used, main)       # one call per flow, on the side stream when prepared
-        assert not ops._made_prep
+        assert not made._made_prep
         res.append((embed.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert res[0][2].keys() == res[1][2].keys() and any('nf' in k for k in res[0][2])
