@@ -164,7 +164,7 @@ def test_c5_scale_properties_and_sampled_rows(monkeypatch, phases, so):
     kernels, 'auto': the relation-phase kernel (the 800 MB feature table is HBM scale); so = 4 runs layer 2's block shapes."""
     from gcn_vae_amd import ops
     from oracle import rgcn as orgcn
-    monkeypatch.setattr(ops, 'K1_PHASES', phases)
+    monkeypatch.setattr(ops.indices, 'K1_PHASES', phases)
     n, e, r, nb, si = 1_000_000, 50_000_000, 2000, 100, 2          # so = 4: layer 2's 2x4 blocks (forward) / 4x2 (adjoint)
     dev = torch.device('cuda', 0)
     gen = torch.Generator(device=dev).manual_seed(0)

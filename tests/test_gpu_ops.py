@@ -107,11 +107,11 @@ def test_rel_graph_conv_relation_phases(ops, monkeypatch, fin, fout, nb, lds, th
     si, so = fin // nb, fout // nb
     if rows == 4 and not (si == 2 and so == 2):
         rows = 0
-    monkeypatch.setattr(ops, 'K1_PHASES', '1')
-    monkeypatch.setattr(ops, 'PHASE_LDS_BYTES', lds)
-    monkeypatch.setattr(ops, 'PHASE_THREADS', threads)
-    monkeypatch.setattr(ops, 'PHASE_ROWS', rows)
-    monkeypatch.setattr(ops, 'PHASE_BUFFERS', nbuf)
+    monkeypatch.setattr(ops.indices, 'K1_PHASES', '1')
+    monkeypatch.setattr(ops.indices, 'PHASE_LDS_BYTES', lds)
+    monkeypatch.setattr(ops.indices, 'PHASE_THREADS', threads)
+    monkeypatch.setattr(ops.indices, 'PHASE_ROWS', rows)
+    monkeypatch.setattr(ops.indices, 'PHASE_BUFFERS', nbuf)
     n, e, r = 300, 4000, 120
     src, dst, et, norm = zipf_graph(n, e, r, seed=fin + fout + nb)
     gen = torch.Generator().manual_seed(fin * 7 + nb)
@@ -145,8 +145,8 @@ def test_rel_graph_conv_relation_phases(ops, monkeypatch, fin, fout, nb, lds, th
 def test_relation_phase_lists_cover_every_edge_once(ops, monkeypatch):
     """Index property: the (tile, phase, wave) lists partition the edges; every edge sits in the list of its relation's
     phase and of the wave that owns its row's item, and carries that item's slot; every item has exactly one slot."""
-    monkeypatch.setattr(ops, 'PHASE_LDS_BYTES', 16384)
-    monkeypatch.setattr(ops, 'PHASE_THREADS', 256)
+    monkeypatch.setattr(ops.indices, 'PHASE_LDS_BYTES', 16384)
+    monkeypatch.setattr(ops.indices, 'PHASE_THREADS', 256)
     n, e, r, nb = 500, 3000, 37, 10
     src, dst, et, _ = zipf_graph(n, e, r, seed=3)
     gidx = ops.GraphIndex(src.cuda(), dst.cuda(), n, chunk=16)
@@ -1067,14 +1067,14 @@ def test_native_index_build_equals_torch_formulation(ops, monkeypatch, n, e, r, 
         src, dst, et = src[order], dst[order], et[order]
     src_t, dst_t, et_t = (torch.from_numpy(a).cuda() for a in (src, dst, et))
     built = {}
-    old = ops.NATIVE_INDEX
+    old = ops.indices.NATIVE_INDEX
     try:
         for native in (True, False):
-            ops.NATIVE_INDEX = native
+            ops.indices.NATIVE_INDEX = native
             g = ops.GraphIndex(src_t, dst_t, n, chunk=64, dst_sorted=sorted_dst, sync_free=True, num_src_nodes=n_src)
             built[native] = (g, ops.RelationIndex(g, et_t, r, chunk=32))
     finally:
-        ops.NATIVE_INDEX = old
+        ops.indices.NATIVE_INDEX = old
     (gn, rn), (gt, rt) = built[True], built[False]
     assert (gn.by_dst.perm is None) == (gt.by_dst.perm is None) == sorted_dst
     if not sorted_dst:
@@ -1097,13 +1097,13 @@ def test_native_triplet_index_equals_torch_formulation(ops, monkeypatch, T, n_en
     trip = np.stack([rs.choice(n_ent, size=T, p=p / p.sum()), rs.randint(0, n_rel, size=T), rs.randint(0, n_ent, size=T)], 1)
     trip_t = torch.from_numpy(trip.astype(np.int64)).cuda().reshape(T, 3)
     built = {}
-    old = ops.NATIVE_INDEX
+    old = ops.indices.NATIVE_INDEX
     try:
         for native in (True, False):
-            ops.NATIVE_INDEX = native
+            ops.indices.NATIVE_INDEX = native
             built[native] = ops.TripletIndex(trip_t, n_ent, n_rel, sync_free=True, locality=False)
     finally:
-        ops.NATIVE_INDEX = old
+        ops.indices.NATIVE_INDEX = old
     a, b = built[True], built[False]
     for name in ('trip32', 'inc_other', 'inc_rel', 'inc_tid', 'rel_s', 'rel_o', 'rel_tid'):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
