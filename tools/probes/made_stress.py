@@ -10,12 +10,14 @@ from gcn_vae_amd.flows import MADE
 from gcn_vae_amd.optim import FlatAdam
 
 n, d, steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40943, 200, int(sys.argv[2]) if len(sys.argv) > 2 else 6
+precision = sys.argv[3] if len(sys.argv) > 3 else 'bf16'          # 'f32': the fp32 node (a launch per product)
 torch.manual_seed(0)
 zs = [torch.randn(n, d, device='cuda') for _ in range(steps)]
 
 
 def run(multi, graph):
-    made.MADE_ROW_BLOCKS = 2 if multi else 1
+    made.MADE_ROW_BLOCKS = made.MADE_F32_ROW_BLOCKS = 2 if multi else 1
+    made.MADE_F32_ROW_BLOCKS_MIN_TILES = 1
     ops.BWD_SIDE = multi
     made.MADE_PREPARE = multi
     torch.manual_seed(1)
@@ -26,7 +28,7 @@ def run(multi, graph):
 
     def step():
         opt.zero_grad()
-        with ops.gemm_precision('bf16'):
+        with ops.gemm_precision(precision):
             ops.made_prepare([m.call_arguments() for m in ms])
             x = zin.clone().requires_grad_(True)
             y = x
@@ -63,6 +65,6 @@ def run(multi, graph):
 for graph in (False, True):
     ref, got = run(False, graph), run(True, graph)
     bad = [(i, j) for i, (a, b) in enumerate(zip(ref, got)) for j, (u, v) in enumerate(zip(a, b)) if not torch.equal(u, v)]
-    print(f'n={n} {"captured step" if graph else "eager steps"}: {steps} steps x {len(ref[0])} tensors, mismatches: {bad[:8] if bad else "none"}', flush=True)
+    print(f'n={n} {precision} {"captured step" if graph else "eager steps"}: {steps} steps x {len(ref[0])} tensors, mismatches: {bad[:8] if bad else "none"}', flush=True)
     assert not bad
 print('ok')
