@@ -748,6 +748,22 @@ def test_made_passes_over_row_blocks_on_their_own_streams_give_the_same_bits(mon
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('precision,n', [('bf16', 9000), ('f32', 5000)])
+def test_multi_stream_flow_stack_equals_the_plain_one_eagerly_and_in_a_captured_step(precision, n):
+    """tools/probes/made_stress.py: two MADE blocks in a row with FlatAdam -- two row blocks on their own streams, weight gradients
+    on the side stream (the first block's products beside the second block's backward), prepared parameters -- against the same
+    stack with all of that off: every output and gradient of several eager steps and of several replays of ONE captured step,
+    bit for bit."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('made_stress', os.path.join(root, 'tools', 'probes', 'made_stress.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.check(n=n, steps=3, precision=precision, d=64)
+
+
+@pytest.mark.gpu
 def test_flow_parameter_work_prepared_beside_the_encoder_gives_the_same_bits(monkeypatch):
     """ops.made_prepare (KGVAE.forward announces its MADE calls: mask folds, packed weights and pass 0's row run on a side stream
     beside the R-GCN layers and are picked up behind an event) against the node doing that work itself: same embedding, same loss,

@@ -9,15 +9,11 @@ from gcn_vae_amd import made, ops
 from gcn_vae_amd.flows import MADE
 from gcn_vae_amd.optim import FlatAdam
 
-n, d, steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40943, 200, int(sys.argv[2]) if len(sys.argv) > 2 else 6
-precision = sys.argv[3] if len(sys.argv) > 3 else 'bf16'          # 'f32': the fp32 node (a launch per product)
-torch.manual_seed(0)
-zs = [torch.randn(n, d, device='cuda') for _ in range(steps)]
 
 
-def run(multi, graph):
+def run(multi, graph, n, d, steps, precision, zs):
     made.MADE_ROW_BLOCKS = made.MADE_F32_ROW_BLOCKS = 2 if multi else 1
-    made.MADE_F32_ROW_BLOCKS_MIN_TILES = 1
+    made.MADE_F32_ROW_BLOCKS_MIN_TILES = made.MADE_ROW_BLOCKS_MIN_TILES = 1
     ops.BWD_SIDE = multi
     made.MADE_PREPARE = multi
     torch.manual_seed(1)
@@ -62,9 +58,27 @@ def run(multi, graph):
     return out
 
 
-for graph in (False, True):
-    ref, got = run(False, graph), run(True, graph)
-    bad = [(i, j) for i, (a, b) in enumerate(zip(ref, got)) for j, (u, v) in enumerate(zip(a, b)) if not torch.equal(u, v)]
-    print(f'n={n} {precision} {"captured step" if graph else "eager steps"}: {steps} steps x {len(ref[0])} tensors, mismatches: {bad[:8] if bad else "none"}', flush=True)
-    assert not bad
-print('ok')
+def check(n=40943, steps=6, precision='bf16', d=200, verbose=False):
+    """Raises AssertionError when any output or gradient of any step differs between the multi-stream and the plain form."""
+    keep = (made.MADE_ROW_BLOCKS, made.MADE_F32_ROW_BLOCKS, made.MADE_F32_ROW_BLOCKS_MIN_TILES, made.MADE_ROW_BLOCKS_MIN_TILES,
+            ops.BWD_SIDE, made.MADE_PREPARE)
+    torch.manual_seed(0)
+    zs = [torch.randn(n, d, device='cuda') for _ in range(steps)]
+    try:
+        for graph in (False, True):
+            ref, got = run(False, graph, n, d, steps, precision, zs), run(True, graph, n, d, steps, precision, zs)
+            bad = [(i, j) for i, (a, b) in enumerate(zip(ref, got)) for j, (u, v) in enumerate(zip(a, b)) if not torch.equal(u, v)]
+            if verbose:
+                print(f'n={n} {precision} {"captured step" if graph else "eager steps"}: {steps} steps x {len(ref[0])} tensors, '
+                      f'mismatches: {bad[:8] if bad else "none"}', flush=True)
+            assert not bad, (graph, bad[:8])
+            assert all(float(t.abs().max()) > 0 for t in ref[-1][3:])          # the gradients are there
+    finally:
+        (made.MADE_ROW_BLOCKS, made.MADE_F32_ROW_BLOCKS, made.MADE_F32_ROW_BLOCKS_MIN_TILES, made.MADE_ROW_BLOCKS_MIN_TILES,
+         ops.BWD_SIDE, made.MADE_PREPARE) = keep
+
+
+if __name__ == '__main__':
+    check(int(sys.argv[1]) if len(sys.argv) > 1 else 40943, int(sys.argv[2]) if len(sys.argv) > 2 else 6,
+          sys.argv[3] if len(sys.argv) > 3 else 'bf16', verbose=True)       # precision 'f32': the fp32 node (a launch per product)
+    print('ok')
