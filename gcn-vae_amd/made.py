@@ -758,7 +758,8 @@ class _MADEForwardBF16(torch.autograd.Function):
             beside = (all(ctx.direct_w[l] is not None and ctx.direct_w[l].data_ptr() in GRAD_FRESH and ctx.direct_w[l].is_contiguous()
                           for l in range(L) if ctx.needs_input_grad[3 + l])
                       and all(direct_b[l] is not None for l in range(L) if wants_gb[l]))
-        with backward_side(beside, gm_t, xin_t, acts_t, row_gw, row_gb, g_row, acts0, ws):
+        with backward_side(beside, gm_t, xin_t, acts_t, row_gw, row_gb, g_row, acts0, ws) as on_side:
+            ctx.gradw_cap = GRADW_SPLIT_MAX_SIDE if on_side else GRADW_SPLIT_MAX
             if ctx.row:
                 made_row_bwd(g_row, [dict(w=ws[l], act=acts0[l] if l < L - 1 else None, inp=acts0[l - 1] if l > 0 else None,
                                           gw=row_gw[l], gb=row_gb[l]) for l in range(L)])
@@ -792,7 +793,7 @@ class _MADEForwardBF16(torch.autograd.Function):
                 # dW_l = g_l^T a_{l-1} over all stacked rows, both operands in 64-row tiles, db_l from the same pass over g_l^T
                 gemm_bf16_gradw_tiles(gm_t[l], tb, xin_t if l == 0 else acts_t[l - 1], ctx.t_tile, widths[l], ws[l].shape[1], mtot,
                                       gw if gw is not None else torch.empty(widths[l], ws[l].shape[1], **f32), accumulate=gw is not None,
-                                      a_rowsum=gb, split_k=max(2, min(GRADW_SPLIT_MAX, mtot // 512)))
+                                      a_rowsum=gb, split_k=max(2, min(ctx.gradw_cap, mtot // 512)))
             if ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l]:
                 if S > 0 and L > 8:
                     rws = torch.empty(int(lib.load().gv_rowsum_bf16_workspace_floats(widths[l], mtot)), **f32)
@@ -827,6 +828,10 @@ class _MADEForwardBF16(torch.autograd.Function):
 
 MADE_BF16_STORAGE = _os.environ.get('GV_MADE_BF16', '1') == '1'
 GRADW_SPLIT_MAX = int(_os.environ.get('GV_GRADW_SPLIT_MAX', '256'))      # most K slices of a MADE weight-gradient product
+# ... when the products run on the side stream, beside the next flow's backward chains: a slice is a workgroup that takes a whole
+# CU's LDS, so fewer of them leave the chains more of the chip, and the partial sums are fewer (alone 256 slices are fastest: 58 us
+# against 73 at 128; in the c3 step 5.79 ms at 256, 5.72-5.77 at 128, 5.67-5.69 at 96, 5.72 at 64)
+GRADW_SPLIT_MAX_SIDE = int(_os.environ.get('GV_GRADW_SPLIT_MAX_SIDE', '96'))
 MADE_CHAIN_IAF = _os.environ.get('GV_MADE_CHAIN_IAF', '1') == '1'      # the IAF update inside the chain's last layer
 MADE_T_TILES = _os.environ.get('GV_MADE_T_TILES', '1') == '1'          # ... and the transposed copies in tiles of 64 rows
 

@@ -61,7 +61,8 @@ def run(multi, graph, n, d, steps, precision, zs):
 def check(n=40943, steps=6, precision='bf16', d=200, verbose=False):
     """Raises AssertionError when any output or gradient of any step differs between the multi-stream and the plain form."""
     keep = (made.MADE_ROW_BLOCKS, made.MADE_F32_ROW_BLOCKS, made.MADE_F32_ROW_BLOCKS_MIN_TILES, made.MADE_ROW_BLOCKS_MIN_TILES,
-            ops.BWD_SIDE, made.MADE_PREPARE)
+            ops.BWD_SIDE, made.MADE_PREPARE, made.GRADW_SPLIT_MAX_SIDE)
+    made.GRADW_SPLIT_MAX_SIDE = made.GRADW_SPLIT_MAX      # the same K slices on the side stream as on the main one: same sums, same bits
     torch.manual_seed(0)
     zs = [torch.randn(n, d, device='cuda') for _ in range(steps)]
     try:
@@ -75,7 +76,7 @@ def check(n=40943, steps=6, precision='bf16', d=200, verbose=False):
             assert all(float(t.abs().max()) > 0 for t in ref[-1][3:])          # the gradients are there
     finally:
         (made.MADE_ROW_BLOCKS, made.MADE_F32_ROW_BLOCKS, made.MADE_F32_ROW_BLOCKS_MIN_TILES, made.MADE_ROW_BLOCKS_MIN_TILES,
-         ops.BWD_SIDE, made.MADE_PREPARE) = keep
+         ops.BWD_SIDE, made.MADE_PREPARE, made.GRADW_SPLIT_MAX_SIDE) = keep
 
 
 if __name__ == '__main__':
