@@ -493,14 +493,17 @@ def made_prepare(calls):
     main, side = torch.cuda.current_stream(), _side('made_prep')
     side.wait_stream(main)
     with torch.cuda.stream(side), torch.no_grad():
+        done, joined, mine = torch.cuda.Event(), [False], []
         for colcount, weights, biases, masks in calls:
             d, S = weights[0].shape[1], colcount.shape[0] - 1
             if masks is None or len(weights) > 8 or d % 8 or any(w.shape[0] % 8 or w.shape[1] % 8 for w in weights):
                 continue        # (not the call made_forward hands to the bf16 node with these very tensors)
             prep = _made_params_work(tuple(masks), tuple(weights), tuple(biases), d, S)
-            prep['done'] = torch.cuda.Event()
-            prep['done'].record(side)
+            prep['done'], prep['joined'] = done, joined
             _made_prep[_made_prep_key(weights, d, S)] = prep
+            mine.append(prep)
+        if mine:
+            done.record(side)         # one event behind all of it: the first node that picks its part up waits, the others need not
 
 
 def made_prepare_finish():
@@ -539,7 +542,9 @@ class _MADEForwardBF16(torch.autograd.Function):
         # where the model announced this call (made_prepare), here otherwise
         prep = _made_prep.pop(_made_prep_key(ws, d, S), None)
         if prep is not None:
-            torch.cuda.current_stream().wait_event(prep['done'])
+            if not prep['joined'][0]:       # ONE join for everything that was prepared (a cross-stream edge costs a replayed graph 20-40 us)
+                torch.cuda.current_stream().wait_event(prep['done'])
+                prep['joined'][0] = True
         else:
             prep = _made_params_work(masks, ws, bs, d, S)
         ws, chain, fused, wbf, wbt, row, acts0, zero_row = (prep[k_] for k_ in ('ws', 'chain', 'fused', 'wbf', 'wbt', 'row', 'acts0', 'zero_row'))
