@@ -141,6 +141,12 @@ def backward_side(enabled, *held):
     """Inside an autograd backward: run the enclosed launches on the side stream (after everything already enqueued); ``held``:
     the tensors they touch.  Yields whether the side stream is in use."""
     if not (enabled and BWD_SIDE) or lib.TIMER is not None or _process_group():      # (timed launches run alone: bench.py's per-kernel lines)
+        # A node that stays on the main stream while an EARLIER node of this backward pass left work on the side stream: the two
+        # may write the same slices of the gradient arena (one MADE's parameters behind two nodes -- the posterior pass and a
+        # separate MMD prior pass; the first stores on the side stream, the second accumulates, or hands its gradient to
+        # AccumulateGrad, on this one).  Order them: this stream waits for the side stream first.
+        if _bwd_side_held:
+            torch.cuda.current_stream().wait_stream(_side('bwd'))
         yield False
         return
     side, main = _side('bwd'), torch.cuda.current_stream()
@@ -151,7 +157,12 @@ def backward_side(enabled, *held):
     _bwd_side_held.append(held)
     if first:
         def _join():
+            # the stream the pass was started under AND the one current now (backward() may be called under another stream than
+            # the node's launches ran on; the optimiser reads the arena on the caller's)
             main.wait_stream(side)
+            cur = torch.cuda.current_stream()
+            if cur != main:
+                cur.wait_stream(side)
             _bwd_side_held.clear()
         torch.autograd.Variable._execution_engine.queue_callback(_join)
 

@@ -87,6 +87,17 @@ class FlatAdam:
         self.flat_g.zero_()
         self._mark_fresh()
 
+    def snapshot(self):
+        """Copies of the parameter arena, both moment arenas and the step counter (device tensors): what ``restore`` puts back."""
+        return tuple(t.clone() for t in (self.flat_p, self.exp_avg, self.exp_avg_sq, self.step_t))
+
+    def restore(self, snap):
+        """Put a ``snapshot`` back IN PLACE (every address stays what a captured step recorded) and clear the gradient arena."""
+        for t, s in zip((self.flat_p, self.exp_avg, self.exp_avg_sq, self.step_t), snap):
+            t.copy_(s)
+        self.flat_g.zero_()
+        self._clean = True
+
     def grad_norm(self):
         """Total gradient norm of the last ``step`` (device scalar)."""
         return self.sumsq.sqrt()

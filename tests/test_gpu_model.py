@@ -863,6 +863,49 @@ def test_made_gradients_written_straight_into_the_optimiser_arena_equal_autograd
         del opt
 
 
+@pytest.mark.parametrize('precision,n', [('bf16', 3000), ('f32', 3000)])
+def test_two_made_nodes_on_shared_weights_order_their_arena_writes(monkeypatch, precision, n):
+    """ONE MADE's parameters behind TWO autograd nodes of the same backward pass (KGVAE's posterior pass and a
+    separate MMD prior pass).  The node that runs first stores its weight gradients into the fresh arena slices on the 'bwd' side
+    stream; the second one sees the slices no longer fresh and accumulates on the main stream -- ops.backward_side makes that
+    stream wait for the side stream first.  Held to the same pass with the side stream off, bit for bit (both orders of writes are
+    then the same sequence of stores and adds), also when backward() is called under another stream than the forward ran on."""
+    from gcn_vae_amd import ops
+    from gcn_vae_amd.flows import MADE
+    from gcn_vae_amd.optim import FlatAdam
+    d = 64
+    gen = torch.Generator().manual_seed(11)
+    z1, z2 = torch.randn(n, d, generator=gen).cuda(), torch.randn(200, d, generator=gen).cuda()
+    res = []
+    other = torch.cuda.Stream()
+    for side_on, other_stream in ((False, False), (True, False), (True, True)):
+        monkeypatch.setattr(ops, 'BWD_SIDE', side_on)
+        torch.manual_seed(3)
+        m = MADE(d, d, 2).cuda()
+        opt = FlatAdam(list(m.parameters()), lr=1e-3, max_grad_norm=1.0)
+        opt.zero_grad()
+        with ops.gemm_precision(precision):
+            x1, ld1 = m(z1)
+            x2, ld2 = m(z2)
+            loss = x1.sin().sum() + (ld1 * ld1).sum() + x2.cos().sum() + ld2.sum()
+            if other_stream:
+                other.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(other):
+                    loss.backward()
+                    opt.step()          # reads the arena on the caller's stream: the join has to cover it
+                torch.cuda.current_stream().wait_stream(other)
+            else:
+                loss.backward()
+                opt.step()
+        torch.cuda.synchronize()
+        assert not ops._bwd_side_held
+        res.append([p.detach().clone() for p in m.parameters()])
+        opt.close()
+    for a, b, c in zip(*res):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b) and torch.equal(a, c)
+
+
 @pytest.mark.parametrize('n_flows', [0, 2])
 def test_reference_validation_block_runs_unchanged_through_compat(tmp_path, n_flows):
     """kgvae/link_predict.py:239-261 replayed line for line on the aliases compat.install() registers: the reference moves its

@@ -175,3 +175,26 @@ def test_neighborhood_sampler_with_injected_draws_has_the_reference_distribution
     u = rs.randint(0, 2 ** 32, size=(len(trip) + 2, 4200), dtype=np.uint64)
     full = sampling.sample_edge_neighborhood_draws(*csr, len(trip), len(trip) + 2, lambda i, a: int(u[i, a]))
     assert sorted(full[:len(trip)].tolist()) == list(range(len(trip))) and (full[len(trip):] == -1).all()
+
+
+def test_bench_exits_nonzero_on_a_nonfinite_loss_and_headlines_the_dominant_kernel():
+    """bench.py: a result line whose last timed step ended on a NaN / inf loss is not a training measurement -- the program's
+    exit status says so; and the line's ``roofline`` names the kernel that is dominant by time (K4 when IAF blocks are on)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.result_exit_code({'loss_is_finite': True}) == 0
+    assert bench.result_exit_code({'loss_is_finite': False}) == bench.EXIT_NONFINITE_LOSS != 0
+    k1 = {'kernel': 'agg_N_10x20_nb20', 'frac': 0.4}
+    detail = {'agg_N_10x20_nb20': {'avg_us': 50.0, 'launches': 2}, 'gradw_10x20_nb20': {'avg_us': 60.0, 'launches': 2}}
+    assert bench.dominant_roofline(k1, detail, {}) == (k1, None)
+    k4 = {'madechain_fwd': {'avg_us': 80.0, 'launches': 30, 'achieved_TFLOPs': 240.0, 'peak_TFLOPs': 2500.0, 'frac': 0.096,
+                            'GFLOP': 19.7, 'operands': 'bf16'},
+          'madechain_bwd': {'avg_us': 90.0, 'launches': 30, 'achieved_TFLOPs': 210.0, 'peak_TFLOPs': 2500.0, 'frac': 0.084,
+                            'GFLOP': 19.7, 'operands': 'bf16'}}
+    roof, roof_k1 = bench.dominant_roofline(k1, detail, k4)
+    assert roof['kernel'] == 'madechain_bwd' and roof['bound'] == 'mfma' and roof['unit'] == 'TFLOP/s' and roof_k1 == k1
+    assert abs(roof['frac'] - 0.084) < 1e-9 and roof['peak'] == 2500.0
