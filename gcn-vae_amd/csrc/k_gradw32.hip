@@ -1,0 +1,277 @@
+// K4, fp32: the weight gradient of one masked-MLP layer over ALL stacked passes of a MADE (kgvae/flow_network.py:13-14, 85-98 under
+// autograd):   dW[j][i] (+)= wmask[j][i] * ( sum_k G[k][j] A[k][i] + g0[j] a0[i] ),   db[j] (+)= sum_k G[k][j] + g0[j]
+// with G [K][ldg] the (ReLU-masked) gradient w.r.t. the layer's output, A [K][lda] the layer's input, K = passes x nodes (50-200 k),
+// (g0, a0) pass 0's single broadcast row, wmask the layer's 0/1 autoregressive mask.
+//
+// As launches of the generic GEMM this was, per layer: a 64 x 64-tile split-K product at 0.27 of the fp32 MFMA peak (L2-bound: 16
+// flop per byte staged) + its split sum + a rank-1 product + an add + two column-sum launches + a share of the mask multiply:
+// ~190 us, 2.9 ms of the 7.9 ms mini-batch step with 3 IAF blocks.  Here ONE workgroup owns the WHOLE (up to 224 x 224) output for
+// its slice of K -- every operand element is staged once (36 flop per byte) -- and only the 32 x 32 output tiles in which the mask
+// holds a non-zero are computed (create_masks: lower-triangular => 28-34 of 49); the bias gradient comes from the staged G chunk;
+// a second launch sums the slices in a fixed order, adds pass 0's rank-1 term, applies the mask and stores or accumulates.
+#include "common.h"
+
+namespace gv {
+
+typedef float f32x16g __attribute__((ext_vector_type(16)));
+
+constexpr int GW_THREADS = 512, GW_WAVES = 8;
+constexpr int GW_KC = 32;            // rows of K per staged chunk
+constexpr int GW_BT = 7;             // 32-wide tiles per block side (224 columns)
+constexpr int GW_LD = GW_BT * 32;    // LDS row pitch (floats): a half-wave reads 32 consecutive floats of one row
+constexpr int GW_TPW = 7;            // tile slots per wave (49 tiles / 8 waves)
+constexpr int GW_PIECES = GW_KC * GW_LD / 4 / GW_THREADS;      // 16-B pieces per thread and operand = 3.5 -> 4
+static_assert(GW_KC * GW_LD / 4 <= 4 * GW_THREADS, "staging: four pieces per thread and operand");
+
+struct GradW32Args {
+    const float* g; const float* a;
+    const int32_t* plan;         // [ceil(m / 32)][ceil(n / 32)] 1 = the tile holds a non-zero of the mask
+    float* part;                 // [slices][mp][np]
+    float* dbpart;               // [slices][mp] or NULL
+    int ldg, lda, m, n, mp, np;
+    long long k, k_per_slice;
+};
+
+__global__ __launch_bounds__(GW_THREADS) void k_gradw32(const GradW32Args p) {
+    extern __shared__ __attribute__((aligned(16))) float gw_lds[];
+    float* const Gs = gw_lds;                               // [2][KC][LD]
+    float* const As = gw_lds + 2 * GW_KC * GW_LD;           // [2][KC][LD]
+    __shared__ int tiles[GW_BT * GW_BT];
+    __shared__ int ntiles;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int jt0 = blockIdx.y * GW_BT, it0 = blockIdx.z * GW_BT;           // first row / column tile of this block
+    const int mt_all = (p.m + 31) >> 5, nt_all = (p.n + 31) >> 5;
+    const int jts = min(GW_BT, mt_all - jt0), its = min(GW_BT, nt_all - it0);
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int j = 0; j < jts; ++j)
+            for (int i = 0; i < its; ++i)
+                if (p.plan[(jt0 + j) * nt_all + it0 + i]) tiles[c++] = (j << 8) | i;
+        ntiles = c;
+    }
+    __syncthreads();
+    const int cnt = ntiles;
+    // the block's active tiles dealt to the eight waves as evenly as they go (waves w and w + 4 share a SIMD)
+    const int base = cnt / GW_WAVES, extra = cnt % GW_WAVES;
+    const int first = wave * base + min(wave, extra), mine = base + (wave < extra ? 1 : 0);
+    int tj[GW_TPW], ti[GW_TPW];
+#pragma unroll
+    for (int t = 0; t < GW_TPW; ++t) {
+        const int e = tiles[min(first + min(t, max(mine - 1, 0)), max(cnt - 1, 0))];       // slots past the wave's last repeat it (computed, not stored)
+        tj[t] = __builtin_amdgcn_readfirstlane(cnt ? (e >> 8) * 32 : 0);
+        ti[t] = __builtin_amdgcn_readfirstlane(cnt ? (e & 0xff) * 32 : 0);
+    }
+    f32x16g acc[GW_TPW];
+#pragma unroll
+    for (int t = 0; t < GW_TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const long long k0 = (long long)blockIdx.x * p.k_per_slice, k1 = min(p.k, k0 + p.k_per_slice);
+    const int j0 = jt0 * 32, i0 = it0 * 32;
+    // ---- staging: chunk rows [kc, kc + KC) x the block's columns, 16-B pieces along the rows, zero outside the operands ----
+    float4 rg[4], ra[4];
+    auto load_chunk = [&](long long kc) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pc = (int)threadIdx.x + q * GW_THREADS;           // piece = (row, 4 columns)
+            const int row = pc / (GW_LD / 4), c4 = (pc - row * (GW_LD / 4)) * 4;
+            rg[q] = ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < GW_KC && kc + row < k1) {
+                if (j0 + c4 < p.m) rg[q] = *reinterpret_cast<const float4*>(p.g + (size_t)(kc + row) * p.ldg + j0 + c4);      // (m, n % 4 == 0)
+                if (i0 + c4 < p.n) ra[q] = *reinterpret_cast<const float4*>(p.a + (size_t)(kc + row) * p.lda + i0 + c4);
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pc = (int)threadIdx.x + q * GW_THREADS;
+            if (pc < GW_KC * GW_LD / 4) {
+                *reinterpret_cast<float4*>(Gs + buf * GW_KC * GW_LD + pc * 4) = rg[q];
+                *reinterpret_cast<float4*>(As + buf * GW_KC * GW_LD + pc * 4) = ra[q];
+            }
+        }
+    };
+    float dbsum = 0.f;          // threads 0 .. 223 of the blocks with blockIdx.z == 0: column j0 + threadIdx.x of G
+    const bool do_db = p.dbpart && blockIdx.z == 0 && (int)threadIdx.x < GW_LD;
+    load_chunk(k0);
+    int buf = 0;
+    for (long long kc = k0; kc < k1; kc += GW_KC) {
+        store_chunk(buf);
+        __syncthreads();
+        if (kc + GW_KC < k1) load_chunk(kc + GW_KC);           // the next chunk's loads fly under this chunk's MFMAs
+        const float* G = Gs + buf * GW_KC * GW_LD + lhi * GW_LD + l31;
+        const float* A = As + buf * GW_KC * GW_LD + lhi * GW_LD + l31;
+        // two slots at a time: two independent accumulator chains per wave (and two waves per SIMD)
+#define GW_PAIR(T0, T1)                                                                                         \
+        if (T0 < mine) {                                                                                        \
+            _Pragma("unroll") for (int s = 0; s < GW_KC / 2; ++s) {                                             \
+                const float g0_ = G[2 * s * GW_LD + tj[T0]], a0_ = A[2 * s * GW_LD + ti[T0]];                   \
+                acc[T0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0_, a0_, acc[T0], 0, 0, 0);                     \
+                if (T1 < GW_TPW) {                                                                              \
+                    const float g1_ = G[2 * s * GW_LD + tj[T1 < GW_TPW ? T1 : T0]], a1_ = A[2 * s * GW_LD + ti[T1 < GW_TPW ? T1 : T0]]; \
+                    acc[T1 < GW_TPW ? T1 : T0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1_, a1_, acc[T1 < GW_TPW ? T1 : T0], 0, 0, 0); \
+                }                                                                                               \
+            }                                                                                                   \
+        }
+        GW_PAIR(0, 1)
+        GW_PAIR(2, 3)
+        GW_PAIR(4, 5)
+        GW_PAIR(6, 7)
+#undef GW_PAIR
+        if (do_db) {           // the bias gradient's share of this chunk: rows in order, one column per thread
+            const float* col = Gs + buf * GW_KC * GW_LD + threadIdx.x;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < GW_KC; r += 2) { s0 += col[r * GW_LD]; s1 += col[(r + 1) * GW_LD]; }
+            dbsum += s0 + s1;
+        }
+        buf ^= 1;
+    }
+    // ---- the slice's partial tiles (only the wave's own slots), the bias partial ----
+    float* const part = p.part + (size_t)blockIdx.x * p.mp * p.np;
+#pragma unroll
+    for (int t = 0; t < GW_TPW; ++t)
+        if (t < mine) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = j0 + tj[t] + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                part[(size_t)row * p.np + i0 + ti[t] + l31] = acc[t][r];
+            }
+        }
+    if (do_db && j0 + (int)threadIdx.x < p.mp) p.dbpart[(size_t)blockIdx.x * p.mp + j0 + threadIdx.x] = dbsum;
+}
+
+struct GradW32Reduce {
+    const float* part; const float* dbpart; const int32_t* plan;
+    const float* wmask; const float* g0; const float* g0_act; const float* a0;
+    float* out; float* db;
+    int m, n, mp, np, ldw, ldo, slices, accumulate, db_accumulate;
+};
+
+// out[j][i] (+)= wmask * (ordered sum of the slices' partials + g0m[j] a0[i]); db[j] (+)= ordered sum + g0m[j];
+// g0m[j] = g0_act == NULL || g0_act[j] > 0 ? g0[j] : 0 (pass 0's row gradient behind its ReLU mask)
+__global__ __launch_bounds__(256) void k_gradw32_reduce(const GradW32Reduce p) {
+    const int nt_all = (p.n + 31) >> 5;
+    const size_t total = (size_t)p.m * p.n, slice = (size_t)p.mp * p.np;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total + (size_t)(p.db ? p.m : 0); e += (size_t)gridDim.x * 256) {
+        if (e >= total) {          // a bias entry
+            const int j = (int)(e - total);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int z = 0;
+            for (; z + 4 <= p.slices; z += 4) {
+                a0 += p.dbpart[(size_t)z * p.mp + j]; a1 += p.dbpart[(size_t)(z + 1) * p.mp + j];
+                a2 += p.dbpart[(size_t)(z + 2) * p.mp + j]; a3 += p.dbpart[(size_t)(z + 3) * p.mp + j];
+            }
+            for (; z < p.slices; ++z) a0 += p.dbpart[(size_t)z * p.mp + j];
+            float v = (a0 + a1) + (a2 + a3);
+            if (p.g0) v += (!p.g0_act || p.g0_act[j] > 0.f) ? p.g0[j] : 0.f;
+            p.db[j] = p.db_accumulate ? p.db[j] + v : v;
+            continue;
+        }
+        const int j = (int)(e / p.n), i = (int)(e - (size_t)j * p.n);
+        float v = 0.f;
+        if (p.plan[(j >> 5) * nt_all + (i >> 5)]) {
+            // 8 partials in flight (4 chains, fixed combine: the order does not depend on the launch geometry)
+            const float* src = p.part + (size_t)j * p.np + i;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int z = 0;
+            for (; z + 8 <= p.slices; z += 8) {
+                float t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[q] = src[(size_t)(z + q) * slice];
+                a0 += t[0]; a1 += t[1]; a2 += t[2]; a3 += t[3];
+                a0 += t[4]; a1 += t[5]; a2 += t[6]; a3 += t[7];
+            }
+            for (; z < p.slices; ++z) a0 += src[(size_t)z * slice];
+            v = (a0 + a1) + (a2 + a3);
+        }
+        if (p.g0) v += ((!p.g0_act || p.g0_act[j] > 0.f) ? p.g0[j] : 0.f) * p.a0[i];
+        if (p.wmask) v *= p.wmask[(size_t)j * p.ldw + i];
+        float* dst = p.out + (size_t)j * p.ldo + i;
+        *dst = p.accumulate ? *dst + v : v;
+    }
+}
+
+// plan[jt][it] = 1 when the 32 x 32 tile of the mask holds a non-zero (or there is no mask)
+__global__ __launch_bounds__(256) void k_gradw32_plan(const float* wmask, int ldw, int m, int n, int32_t* plan) {
+    const int nt_all = (n + 31) >> 5, mt_all = (m + 31) >> 5;
+    for (int t = blockIdx.x; t < mt_all * nt_all; t += gridDim.x) {
+        const int jt = t / nt_all, it = t - jt * nt_all;
+        bool any = wmask == nullptr;
+        if (wmask)
+            for (int e = threadIdx.x; e < 1024; e += 256) {
+                const int j = jt * 32 + (e >> 5), i = it * 32 + (e & 31);
+                if (j < m && i < n && wmask[(size_t)j * ldw + i] != 0.f) any = true;
+            }
+        const int flag = __syncthreads_or(any ? 1 : 0);
+        if (threadIdx.x == 0) plan[t] = flag ? 1 : 0;
+    }
+}
+
+static int gw_slices(int m, int n, long long k) {
+    const int blocks = ((m + 32 * GW_BT - 1) / (32 * GW_BT)) * ((n + 32 * GW_BT - 1) / (32 * GW_BT));
+    long long s = max(1, 256 / blocks);
+    s = min(s, max(1LL, k / (2 * GW_KC)));          // at least two chunks per slice
+    return (int)s;
+}
+
+}  // namespace gv
+
+using namespace gv;
+
+extern "C" int64_t gv_made_gradw_f32_plan_words(int m, int n) { return (int64_t)((m + 31) / 32) * ((n + 31) / 32); }
+
+extern "C" int gv_made_gradw_f32_plan(const float* wmask, int ldw, int m, int n, int32_t* plan, void* stream) {
+    GV_REQUIRE(m > 0 && n > 0 && plan && (!wmask || ldw >= n), GV_ERR_SHAPE, "gv_made_gradw_f32_plan: m=%d n=%d ldw=%d", m, n, ldw);
+    hipLaunchKernelGGL(k_gradw32_plan, dim3((unsigned)min((int64_t)256, gv_made_gradw_f32_plan_words(m, n))), dim3(256), 0, (hipStream_t)stream,
+                       wmask, ldw, m, n, plan);
+    return launch_status("gv_made_gradw_f32_plan");
+}
+
+extern "C" int64_t gv_made_gradw_f32_workspace_floats(int m, int n, int64_t k) {
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    const int64_t mp = (m + 31) / 32 * 32, np = (n + 31) / 32 * 32;
+    return (int64_t)gw_slices(m, n, k) * (mp * np + mp);
+}
+
+extern "C" int gv_made_gradw_f32(const float* g, int ldg, const float* a, int lda, int m, int n, int64_t k, const int32_t* plan,
+                                 const float* wmask, int ldw, const float* g0, const float* g0_act, const float* a0, float* out, int ldo,
+                                 int accumulate, float* db, int db_accumulate, float* workspace, int64_t workspace_floats, void* stream) {
+    GV_REQUIRE(m > 0 && n > 0 && k > 0 && m % 4 == 0 && n % 4 == 0 && ldg >= m && lda >= n && ldg % 4 == 0 && lda % 4 == 0 && ldo >= n,
+               GV_ERR_SHAPE, "gv_made_gradw_f32: m=%d n=%d k=%lld ldg=%d lda=%d ldo=%d (widths and pitches are multiples of 4)", m, n,
+               (long long)k, ldg, lda, ldo);
+    GV_REQUIRE(g && a && plan && out && workspace && aligned16(g) && aligned16(a), GV_ERR_NULL, "gv_made_gradw_f32: NULL / unaligned pointer");
+    GV_REQUIRE((!wmask || ldw >= n) && (!g0 || a0), GV_ERR_SHAPE, "gv_made_gradw_f32: mask pitch / pass 0's row needs both vectors");
+    GV_REQUIRE(workspace_floats >= gv_made_gradw_f32_workspace_floats(m, n, k), GV_ERR_SHAPE, "gv_made_gradw_f32: workspace of %lld floats, %lld needed",
+               (long long)workspace_floats, (long long)gv_made_gradw_f32_workspace_floats(m, n, k));
+    GradW32Args p;
+    p.g = g; p.a = a; p.plan = plan; p.ldg = ldg; p.lda = lda; p.m = m; p.n = n; p.k = k;
+    p.mp = (m + 31) / 32 * 32; p.np = (n + 31) / 32 * 32;
+    const int slices = gw_slices(m, n, k);
+    p.k_per_slice = ((k + slices - 1) / slices + GW_KC - 1) / GW_KC * GW_KC;
+    p.part = workspace;
+    p.dbpart = db ? workspace + (size_t)slices * p.mp * p.np : nullptr;
+    const size_t lds = (size_t)4 * GW_KC * GW_LD * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_gradw32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("gv_made_gradw_f32: cannot raise the dynamic LDS limit");
+            return GV_ERR_SHAPE;
+        }
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)slices, (unsigned)((m + 32 * GW_BT - 1) / (32 * GW_BT)), (unsigned)((n + 32 * GW_BT - 1) / (32 * GW_BT)));
+    hipLaunchKernelGGL(k_gradw32, grid, dim3(GW_THREADS), lds, (hipStream_t)stream, p);
+    int rc = launch_status("gv_made_gradw_f32");
+    if (rc != GV_OK) return rc;
+    GradW32Reduce r;
+    r.part = p.part; r.dbpart = p.dbpart; r.plan = plan; r.wmask = wmask; r.g0 = g0; r.g0_act = g0_act; r.a0 = a0; r.out = out; r.db = db;
+    r.m = m; r.n = n; r.mp = p.mp; r.np = p.np; r.ldw = ldw; r.ldo = ldo; r.slices = slices; r.accumulate = accumulate; r.db_accumulate = db_accumulate;
+    const size_t total = (size_t)m * n + (db ? m : 0);
+    hipLaunchKernelGGL(k_gradw32_reduce, dim3((unsigned)min((size_t)1024, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, r);
+    return launch_status("gv_made_gradw_f32(reduce)");
+}

@@ -72,25 +72,42 @@ class _MADEForward(torch.autograd.Function):
         first_out = xin[0:n] if P > 1 else x_out
         # (columns outside the first index set would keep x_old = 0: flows.MADE checks at construction that there are none)
         lib.call('gv_iaf_update_fwd', ptr(z), ptr(acts0[L - 1]), 0, ptr(z), ptr(colcount[0]), ptr(first_out), n, d, st)
+        # one launch per pass (gv_made_chain_f32: activations stay in LDS between the layers, the zero groups of the masked
+        # weights are not multiplied) where the widths fit; otherwise -- and with GV_MADE_CHAIN_F32=0 -- a launch per product
+        widths, kin = [w.shape[0] for w in ws], [w.shape[1] for w in ws]
+        chain = (MADE_CHAIN_F32 and S > 0 and L <= 8 and d % 8 == 0 and made_chain_f32_fits(widths, kin)
+                 and made_chain_f32_fits(list(reversed(kin)), list(reversed(widths))))
+        packed = plan_f = None
+        if chain:
+            packed = made_pack_weights_f32(ws)
+            plan_f = made_chain_f32_plan(widths, kin, masks)
         def passes(r0, r1):      # passes 1 .. P-1 for the rows [r0, r1): every launch of a pass is row-local
             for p in range(1, P):
                 a, b = (p - 1) * n + r0, (p - 1) * n + r1
                 inp = xin[a:b]
-                for l in range(L):
+                if chain:
+                    made_chain_f32(inp, r1 - r0, [dict(w_packed=packed[l][0], n=widths[l], k=kin[l], bias=bs[l], relu=l < L - 1,
+                                                       out_f32=acts[l][a:b]) for l in range(L)], plan_f, tag='madechain_fwd_f32')
+                    inp = acts[L - 1][a:b]
+                for l in range(L) if not chain else ():
                     out = acts[l][a:b]
                     gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE, out=out)
                     inp = out
                 nxt = xin[p * n + r0:p * n + r1] if p + 1 < P else x_out[r0:r1]
                 lib.call('gv_iaf_update_fwd', ptr(z[r0:r1]), ptr(inp), 2 * d, ptr(xin[a:b]), ptr(colcount[p]), ptr(nxt), r1 - r0, d,
                          lib.stream())
-        _by_row_blocks(passes, n, MADE_F32_ROW_BLOCKS, MADE_F32_ROW_BLOCKS_MIN_TILES)
+        if chain:       # MFMA-bound launches that fill the chip: one sequence over all rows (and the padding rows are skipped per workgroup)
+            passes(0, n)
+        else:
+            _by_row_blocks(passes, n, MADE_F32_ROW_BLOCKS, MADE_F32_ROW_BLOCKS_MIN_TILES)
         log_det = torch.empty(n, **f32)
         if P > 1:
             lib.call('gv_rowsum', ptr(acts[L - 1][(S - 1) * n:]), 2 * d, d, d, ptr(log_det), n, st)
         else:
             log_det = acts0[L - 1][:, d:].sum(dim=1).expand(n).contiguous()
-        ctx.save_for_backward(z, colcount, xin, zero_row, *acts, *acts0, *ws)
+        ctx.save_for_backward(z, colcount, xin, zero_row, *acts, *acts0, *ws, *([pk[1] for pk in packed] if chain else []))
         ctx.L = L
+        ctx.chain = chain
         ctx.has_bias = [b is not None for b in bs]
         return x_out, log_det
 
@@ -100,11 +117,15 @@ class _MADEForward(torch.autograd.Function):
         saved = ctx.saved_tensors
         z, colcount, xin, zero_row = saved[:4]
         acts, acts0, ws = saved[4:4 + L], saved[4 + L:4 + 2 * L], saved[4 + 2 * L:4 + 3 * L]
+        chain, wpb = ctx.chain, saved[4 + 3 * L:4 + 4 * L]          # fragment-packed B = W of every layer (backward-x chain)
         n, d = z.shape
         P = colcount.shape[0]
         S = P - 1
         f32 = dict(dtype=torch.float32, device=z.device)
         st = lib.stream()
+        widths, kin = [w.shape[0] for w in ws], [w.shape[1] for w in ws]
+        plan_b = made_chain_f32_plan(list(reversed(kin)), list(reversed(widths)),
+                                     list(reversed(ctx.masks)) if ctx.masks is not None else None, transposed=True) if chain else None
         gx = torch.zeros(n, d, **f32) if gx is None else _chk(gx.contiguous(), name='gx')
         gld = None if gld is None else _chk(gld.contiguous(), name='gld')
         grads = [torch.empty(max(S, 1) * n, ws[l].shape[0], **f32) for l in range(L)]   # grad w.r.t. each layer's OUTPUT
@@ -121,14 +142,23 @@ class _MADEForward(torch.autograd.Function):
                          ptr(gld[r0:r1]) if (p == P - 1 and gld is not None) else None, ptr(gz_p[r0:r1]), ptr(grads[L - 1][a:b]),
                          ptr(g_old), m, d, lib.stream())
                 lib.call('gv_axpby', m * d, None, 1.0, ptr(gz_p[r0:r1]), 1.0, ptr(g_z[r0:r1]), lib.stream())
-                for l in reversed(range(L)):
+                if chain:       # g_{l-1} = (g_l W_l) * [a_{l-1} > 0] down to g_x, one launch; the hidden gradients are STORED masked
+                    made_chain_f32(grads[L - 1][a:b], m,
+                                   [dict(w_packed=wpb[l], n=kin[l], k=widths[l], mask=acts[l - 1][a:b], out_f32=grads[l - 1][a:b])
+                                    for l in reversed(range(1, L))] +
+                                   [dict(w_packed=wpb[0], n=d, k=widths[0], out_f32=g_old, accumulate=True)], plan_b,
+                                   tag='madechain_bwd_f32')
+                for l in reversed(range(L)) if not chain else ():
                     mask = acts[l][a:b] if l < L - 1 else None
                     if l > 0:
                         gemm(grads[l][a:b], ws[l], out=grads[l - 1][a:b], a_relu_mask=mask)
                     else:       # gradient w.r.t. the pass's input x_p joins the update's pass-through gradient
                         gemm(grads[0][a:b], ws[0], out=g_old, accumulate=True, a_relu_mask=mask)
                 g_in = g_olds[p]
-        _by_row_blocks(passes, n, MADE_F32_ROW_BLOCKS, MADE_F32_ROW_BLOCKS_MIN_TILES)
+        if chain:
+            passes(0, n)
+        else:
+            _by_row_blocks(passes, n, MADE_F32_ROW_BLOCKS, MADE_F32_ROW_BLOCKS_MIN_TILES)
         g_cur = g_olds[1] if P > 1 else gx
         # pass 0: the update's gradient w.r.t. the broadcast net row is its column sum; x_old was the zero matrix
         g_row = iaf_bwd_row0(z, acts0[L - 1], colcount[0], g_cur, gld if P == 1 else None, g_z)      # (1, 2D)
@@ -150,8 +180,25 @@ class _MADEForward(torch.autograd.Function):
         beside = (ctx.masks is not None and L <= 8 and all(tgt_w[l] is not None for l in range(L) if wants_w[l])
                   and all(tgt_b[l] is not None for l in range(L) if wants_b[l]))
         g_ws, g_bs = [], []
+        # chain path: the hidden gradients are stored ReLU-masked, so each layer's weight AND bias gradient over all stacked passes,
+        # pass 0's rank-1 term, the mask fold and the store / add into the arena are ONE product on gv_made_gradw_f32 (+ its split sum)
+        fused_gradw = (chain and MADE_GRADW_F32 and S > 0 and all(w_ % 4 == 0 for w_ in widths + kin)
+                       and all(wants_w[l] for l in range(L)) and all(wants_b[l] or not ctx.has_bias[l] for l in range(L)))
         with backward_side(beside, grads, xin, acts, acts0, rows0, zero_row):
-            for l in range(L):
+            for l in range(L) if fused_gradw else ():
+                gw, gb = made_gradw_f32(grads[l], xin if l == 0 else acts[l - 1], wmask=ctx.masks[l] if ctx.masks is not None else None,
+                                        g0=rows0[l], g0_act=acts0[l] if l < L - 1 else None, a0=zero_row if l == 0 else acts0[l - 1],
+                                        out=tgt_w[l], accumulate=False, db=tgt_b[l], db_accumulate=tgt_b[l] is not None,
+                                        want_db=wants_b[l])
+                if tgt_w[l] is not None:
+                    GRAD_FRESH.discard(tgt_w[l].data_ptr())
+                    gw = None
+                if tgt_b[l] is not None:
+                    GRAD_FRESH.discard(tgt_b[l].data_ptr())
+                    gb = None
+                g_ws.append(gw)
+                g_bs.append(gb)
+            for l in range(L) if not fused_gradw else ():
                 mask = acts[l] if l < L - 1 else None
                 mask0 = acts0[l] if l < L - 1 else None
                 inp0 = zero_row if l == 0 else acts0[l - 1]
@@ -172,7 +219,7 @@ class _MADEForward(torch.autograd.Function):
                         gb = None
                 g_ws.append(gw)
                 g_bs.append(gb)
-            if ctx.masks is not None:       # dL/dW = mask * dL/d(mask * W): one launch for all layers, straight into the arena where fresh
+            if ctx.masks is not None and not fused_gradw:       # dL/dW = mask * dL/d(mask * W): one launch for all layers, straight into the arena where fresh
                 idx = [l for l in range(L) if g_ws[l] is not None]
                 for i0 in range(0, len(idx), 8):
                     part_idx = idx[i0:i0 + 8]
@@ -436,6 +483,146 @@ def gemm_bf16_gradw_tiles(a, a_tile, b, b_tile, m, n, k, c_f32, accumulate=True,
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=c_f32.device)
     lib.call('gv_gemm_bf16_gradw_tiles', ptr(a), int(a_tile), ptr(b), int(b_tile), m, n, k, ptr(c_f32), 1 if accumulate else 0,
              ptr(a_rowsum), split_k, ptr(ws), ws_bytes, lib.stream())
+
+
+# ---- K4 fused in fp32 (csrc/k_chain32.hip): one launch per MADE pass on the fp32 MFMA, zero groups of the masked weights skipped ----
+class _Chain32Layer(_ct.Structure):
+    """gv_chain32_layer of include/gcnvae.h."""
+    _fields_ = [('w_packed', _ct.c_void_p), ('bias', _ct.c_void_p), ('mask', _ct.c_void_p), ('out_f32', _ct.c_void_p),
+                ('n', _ct.c_int32), ('k', _ct.c_int32), ('relu', _ct.c_int32), ('accumulate', _ct.c_int32),
+                ('ldmask', _ct.c_int32), ('ldc', _ct.c_int32)]
+
+
+MADE_CHAIN_F32 = _os.environ.get('GV_MADE_CHAIN_F32', '1') == '1'      # the fp32 node's passes as one launch each
+MADE_CHAIN_F32_SKIP = _os.environ.get('GV_MADE_CHAIN_F32_SKIP', '1') == '1'      # ... walking only the non-zero groups of the masks
+PLAN_WORDS = 4 + 4 * 8 * 16 + 2 * 8 * 16          # GV_CHAIN32_PLAN_WORDS
+_chain32_plans = {}
+
+
+def made_chain_f32_fits(widths_n, widths_k):
+    nl = len(widths_n)
+    arr_n = (_ct.c_int32 * nl)(*[int(v) for v in widths_n])
+    arr_k = (_ct.c_int32 * nl)(*[int(v) for v in widths_k])
+    return bool(lib.load().gv_made_chain_f32_fits(nl, _ct.addressof(arr_n), _ct.addressof(arr_k)))
+
+
+def made_pack_weights_f32(ws, fwd=True, bwd=True):
+    """Fragment-packed fp32 copies of every layer's weight W (n, k) in one launch: [(B = W^T for the forward layer, B = W for the
+    backward-x layer), ...] (gv_made_pack_weight_f32_multi)."""
+    ws = [_row_major(w, 'w') for w in ws]
+    l = lib.load()
+    dev = ws[0][0].device
+    f32 = dict(dtype=torch.float32, device=dev)
+    pf = [torch.empty(int(l.gv_made_pack_weight_f32_elems(w.shape[0], w.shape[1])), **f32) if fwd else None for w, _ in ws]
+    pb = [torch.empty(int(l.gv_made_pack_weight_f32_elems(w.shape[1], w.shape[0])), **f32) if bwd else None for w, _ in ws]
+    k = len(ws)
+    tp = lambda ts: (_ct.c_void_p * k)(*[ptr(t) for t in ts])
+    ti = lambda vs: (_ct.c_int32 * k)(*[int(v) for v in vs])
+    tw, tf, tb = tp([w for w, _ in ws]), tp(pf), tp(pb)
+    tl, tn, tk = ti([ld for _, ld in ws]), ti([w.shape[0] for w, _ in ws]), ti([w.shape[1] for w, _ in ws])
+    lib.call('gv_made_pack_weight_f32_multi', k, _ct.addressof(tw), _ct.addressof(tl), _ct.addressof(tn), _ct.addressof(tk),
+             _ct.addressof(tf), _ct.addressof(tb), lib.stream())
+    return list(zip(pf, pb))
+
+
+def made_chain_f32_plan(widths_n, widths_k, masks=None, transposed=False):
+    """The plan of a chain (gv_made_chain_f32_plan): which 8-deep groups of every 32-column tile hold a non-zero of the layer's 0/1
+    mask, and the tiles dealt to the four waves.  One small launch per (mask set, widths, direction), then cached -- the entry
+    keeps the mask tensors it was computed from.  masks: per layer the mask of W (n_out, n_in) or None (dense); transposed: the
+    layers are backward-x layers (B = W: the layer's k runs over W's rows)."""
+    nl = len(widths_n)
+    if not MADE_CHAIN_F32_SKIP:
+        masks = None
+    key = (torch.cuda.current_device(), tuple(int(v) for v in widths_n), tuple(int(v) for v in widths_k), bool(transposed),
+           tuple((m.data_ptr(), m._version) if m is not None else None for m in masks) if masks is not None else None)
+    hit = _chain32_plans.get(key)
+    if hit is not None:
+        return hit[0]
+    dev = torch.device('cuda', torch.cuda.current_device())
+    plan = torch.empty(PLAN_WORDS, dtype=torch.int32, device=dev)
+    arr_n = (_ct.c_int32 * nl)(*[int(v) for v in widths_n])
+    arr_k = (_ct.c_int32 * nl)(*[int(v) for v in widths_k])
+    held, tm, tl = [], None, None
+    if masks is not None:
+        held = [_row_major(m, 'mask')[0] if m is not None else None for m in masks]
+        for m, n_, k_ in zip(held, widths_n, widths_k):
+            if m is not None and tuple(m.shape) != ((k_, n_) if transposed else (n_, k_)):
+                raise ValueError(f'made_chain_f32_plan: mask {tuple(m.shape)} does not belong to a layer of n={n_}, k={k_}')
+        tm = (_ct.c_void_p * nl)(*[ptr(m) for m in held])
+        tl = (_ct.c_int32 * nl)(*[m.stride(0) if m is not None else 0 for m in held])
+    tt = (_ct.c_int32 * nl)(*[1 if transposed else 0] * nl)
+    lib.call('gv_made_chain_f32_plan', nl, _ct.addressof(arr_n), _ct.addressof(arr_k), _ct.addressof(tm) if tm is not None else None,
+             _ct.addressof(tl) if tl is not None else None, _ct.addressof(tt), ptr(plan), lib.stream())
+    _chain32_plans[key] = (plan, held, masks)
+    return plan
+
+
+def made_chain_f32(x, m, layers, plan, tag=None):
+    """One launch for a chain of fp32 products (gv_made_chain_f32): layers = dicts with w_packed, n, k and optional bias, relu,
+    mask (fp32, kept where > 0), out_f32, accumulate; row strides are taken from the tensors.  Inside ops.live_rows a chain over
+    a node array of exactly ``cap`` rows skips the workgroups that hold only padding rows."""
+    if tag is not None and lib.TIMER is not None:
+        MADE_CHAIN_FLOPS[tag] = 2.0 * int(m) * sum(int(d['n']) * int(d['k']) for d in layers)
+    arr = (_Chain32Layer * len(layers))()
+    for c, d in zip(arr, layers):
+        mask, of = d.get('mask'), d.get('out_f32')
+        c.w_packed, c.bias, c.mask, c.out_f32 = ptr(d['w_packed']), ptr(d.get('bias')), ptr(mask), ptr(of)
+        c.n, c.k, c.relu, c.accumulate = int(d['n']), int(d['k']), 1 if d.get('relu') else 0, 1 if d.get('accumulate') else 0
+        c.ldmask = mask.stride(0) if mask is not None else 0
+        c.ldc = of.stride(0) if of is not None else 0
+    live = _ops.LIVE_ROWS
+    rows_dev = live[0] if (live is not None and int(m) == live[1] and x.device == live[0].device) else None
+    lib.call('gv_made_chain_f32', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), ptr(plan), ptr(rows_dev), lib.stream(),
+             tag=tag)
+
+
+MADE_GRADW_F32 = _os.environ.get('GV_MADE_GRADW_F32', '1') == '1'      # the fp32 node's weight / bias gradients on gv_made_gradw_f32
+_gradw32_plans = {}
+
+
+def made_gradw_f32_plan(m, n, wmask=None):
+    """Which 32 x 32 tiles of an (m, n) weight gradient can be non-zero under the layer's 0/1 mask (gv_made_gradw_f32_plan); one
+    small launch per mask, cached with the mask it was computed from."""
+    key = (torch.cuda.current_device(), int(m), int(n), (wmask.data_ptr(), wmask._version) if wmask is not None else None)
+    hit = _gradw32_plans.get(key)
+    if hit is not None:
+        return hit[0]
+    if wmask is not None:
+        wmask, ldw = _row_major(wmask, 'wmask')
+        if tuple(wmask.shape) != (m, n):
+            raise ValueError(f'made_gradw_f32_plan: mask {tuple(wmask.shape)} for an ({m}, {n}) weight')
+    plan = torch.empty(int(lib.load().gv_made_gradw_f32_plan_words(m, n)), dtype=torch.int32, device=torch.device('cuda', torch.cuda.current_device()))
+    lib.call('gv_made_gradw_f32_plan', ptr(wmask), ldw if wmask is not None else 0, int(m), int(n), ptr(plan), lib.stream())
+    _gradw32_plans[key] = (plan, wmask)
+    return plan
+
+
+def made_gradw_f32(g, a, wmask=None, g0=None, g0_act=None, a0=None, out=None, accumulate=False, db=None, db_accumulate=False, want_db=True):
+    """(dW, db) of one masked layer over all stacked rows (gv_made_gradw_f32): dW = wmask * (g^T a + g0m^T a0), db = column sums of g
+    + g0m, with g0m = pass 0's row gradient g0 (1, m) behind its ReLU mask g0_act (1, m) or None.  g (k, m) and a (k, n) fp32 with
+    unit inner stride; ``out`` / ``db``: where to store (or, with accumulate / db_accumulate, add) -- new tensors when None."""
+    g, ldg = _row_major(g, 'g')
+    a, lda = _row_major(a, 'a')
+    k, m = g.shape
+    n = a.shape[1]
+    if a.shape[0] != k:
+        raise ValueError('made_gradw_f32: g and a have different row counts')
+    f32 = dict(dtype=torch.float32, device=g.device)
+    if out is None:
+        out, accumulate = torch.empty(m, n, **f32), False
+    if db is None and want_db:
+        db, db_accumulate = torch.empty(m, **f32), False
+    if out.stride(1) != 1 or (db is not None and not db.is_contiguous()):
+        raise ValueError('made_gradw_f32: outputs with unit inner stride')
+    plan = made_gradw_f32_plan(m, n, wmask)
+    ldw = 0
+    if wmask is not None:
+        wmask, ldw = _row_major(wmask, 'wmask')
+    nws = int(lib.load().gv_made_gradw_f32_workspace_floats(m, n, k))
+    ws = torch.empty(nws, **f32)
+    lib.call('gv_made_gradw_f32', ptr(g), ldg, ptr(a), lda, int(m), int(n), int(k), ptr(plan), ptr(wmask), ldw, ptr(g0), ptr(g0_act), ptr(a0),
+             ptr(out), out.stride(0), 1 if accumulate else 0, ptr(db), 1 if db_accumulate else 0, ptr(ws), nws, lib.stream())
+    return out, db
 
 
 def _made_params_work(masks, ws, bs, d, S):

@@ -324,6 +324,56 @@ int gv_made_pack_weight_multi_iaf(int count, const float* const* w, const int32_
 int gv_made_chain_fits(int n_layers, const int32_t* n_of_layer, const int32_t* k_of_layer, int any_mask);
 int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, void* stream);
 /* ---------------------------------------------------------------------------------------------
+ * K4 fused in fp32 (the reference's own precision, kgvae/README.md:4-7): the same chain on v_mfma_f32_32x32x2_f32, fp32
+ * activations in LDS, walking only the parts of the masked weights (kgvae/flow_network.py:65-83: lower-triangular blocks) that
+ * hold a non-zero.  Layer i computes y_i = epilogue_i(y_{i-1} @ B_i) with B_i [k][n] FRAGMENT-PACKED (gv_made_pack_weight_f32_multi:
+ * packed_fwd of a weight W [n][k] is B = W^T, a forward layer; packed_bwd is B = W, the backward-x layer, whose n is W's k);
+ * epilogue: + bias, ReLU, zero where mask <= 0 (the ReLU mask of a backward layer: the forward activation, fp32 [m][ldmask]),
+ * then out_f32 [m][ldc] (accumulate != 0: +=).  Every output element is the k-ordered fp32 fma chain of gv_gemm_f32 without the
+ * terms the plan skips -- terms that are exactly zero -- so the results are bit-identical to the launch-per-product path on finite
+ * inputs.  Widths are multiples of 8, n <= 32 GV_CHAIN32_MAX_TILES, k <= 512, layers[i].k == layers[i-1].n, two LDS tiles of
+ * 64 x (widest input + 4) floats <= 160 KB (gv_made_chain_f32_fits tells).
+ * gv_made_chain_f32_plan (one small launch, once per mask set): from the 0/1 masks of the layers' weights (masks[i] fp32, pitch
+ * ldmask[i]; transposed[i] = 0: mask of W [n][k] for a forward layer, 1: mask of W [k-rows = the layer's k][n] for a backward-x
+ * layer; masks == NULL or masks[i] == NULL: dense) it writes GV_CHAIN32_PLAN_WORDS int32: per (layer, 32-column tile) the set of
+ * 8-deep reduction groups that hold a non-zero, and the layer's tiles dealt to the workgroup's four waves, longest first to the
+ * least loaded.  The plan depends on the masks and widths alone, not on m.
+ * rows_dev (optional device scalar): rows [*rows_dev, m) are padding -- a 64-row workgroup that holds only padding stores zeros
+ * to its non-accumulating outputs, as gv_gemm_f32_live_rows. */
+#define GV_CHAIN32_MAX_TILES 16
+#define GV_CHAIN32_PLAN_WORDS (4 + 4 * GV_CHAIN_MAX_LAYERS * GV_CHAIN32_MAX_TILES + 2 * GV_CHAIN_MAX_LAYERS * GV_CHAIN32_MAX_TILES)
+typedef struct gv_chain32_layer {
+    const float* w_packed;    /* B of this layer, fragment-packed: [tile of 32 columns][group of 8 k][lane 0..63] float4 =
+                               * B[8 g + 2 i + (lane >> 5)][32 t + (lane & 31)], i = 0..3; zero outside B */
+    const float* bias;        /* [n] or NULL */
+    const float* mask;        /* [m][ldmask] or NULL: the result is kept where mask > 0 */
+    float* out_f32;           /* [m][ldc] or NULL (not on the last layer) */
+    int32_t n, k, relu, accumulate, ldmask, ldc;
+} gv_chain32_layer;
+int64_t gv_made_pack_weight_f32_elems(int n, int k);
+int gv_made_pack_weight_f32_multi(int count, const float* const* w, const int32_t* ld, const int32_t* n, const int32_t* k,
+                                  float* const* packed_fwd, float* const* packed_bwd, void* stream);
+int gv_made_chain_f32_fits(int n_layers, const int32_t* n_of_layer, const int32_t* k_of_layer);
+int gv_made_chain_f32_plan(int n_layers, const int32_t* n_of_layer, const int32_t* k_of_layer, const float* const* masks,
+                           const int32_t* ldmask, const int32_t* transposed, int32_t* plan, void* stream);
+int gv_made_chain_f32(const float* x, int ldx, int m, int n_layers, const gv_chain32_layer* layers, const int32_t* plan,
+                      const int32_t* rows_dev, void* stream);
+/* The weight gradient of one masked-MLP layer over all stacked passes, fp32 (autograd of kgvae/flow_network.py:13-14 under the
+ * six-pass forward :85-98):   out[j][i] (+)= wmask[j][i] * ( sum_k g[k][j] a[k][i] + g0m[j] a0[i] ),   db[j] (+)= sum_k g[k][j] + g0m[j]
+ * g [k][ldg] the gradient w.r.t. the layer's output (ReLU-masked already where the layer has a ReLU), a [k][lda] the layer's input,
+ * (g0, a0) pass 0's single row (g0m[j] = g0[j] where g0_act == NULL or g0_act[j] > 0, else 0; g0 == NULL: no such term), wmask
+ * [m][ldw] the layer's 0/1 mask or NULL.  One workgroup owns the whole output (blocks of 224 x 224) for its slice of k and computes
+ * only the 32 x 32 tiles flagged in `plan` (gv_made_gradw_f32_plan: the tiles in which wmask holds a non-zero; all of them
+ * without a mask; gv_made_gradw_f32_plan_words int32) -- the others are stored as zero / left as they are when accumulating; the
+ * slices are summed in a fixed order by a second launch.  m, n, ldg, lda multiples of 4; db may be NULL; workspace of
+ * gv_made_gradw_f32_workspace_floats(m, n, k) floats. */
+int64_t gv_made_gradw_f32_plan_words(int m, int n);
+int gv_made_gradw_f32_plan(const float* wmask, int ldw, int m, int n, int32_t* plan, void* stream);
+int64_t gv_made_gradw_f32_workspace_floats(int m, int n, int64_t k);
+int gv_made_gradw_f32(const float* g, int ldg, const float* a, int lda, int m, int n, int64_t k, const int32_t* plan,
+                      const float* wmask, int ldw, const float* g0, const float* g0_act, const float* a0, float* out, int ldo,
+                      int accumulate, float* db, int db_accumulate, float* workspace, int64_t workspace_floats, void* stream);
+/* ---------------------------------------------------------------------------------------------
  * K4, pass 0 of MADE (kgvae/flow_network.py:85-98): the first pass feeds the masked MLP an all-zero input, so every node sees
  * the same ROW; the whole chain of 1 x k by k x n products is one single-workgroup launch.  Operands rounded to bf16, fp32
  * products and sums (the precision of BASELINE configs[2]).

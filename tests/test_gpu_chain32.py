@@ -1,0 +1,223 @@
+"""K4 fused in fp32 (csrc/k_chain32.hip, gv_made_chain_f32): one launch per MADE pass on the fp32 MFMA that walks only the non-zero
+groups of the masked weights (kgvae/flow_network.py:65-98).  Held to the launch-per-product path (gv_gemm_f32) BIT FOR BIT -- the
+skipped terms are exact zeros -- and, through the whole MADE node, to the golden vectors generated from the reference
+(tests/golden/made.npz, in test_gpu_model.py).   pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _made(d, h, n_hidden, seed=3):
+    from gcn_vae_amd.flows import MADE
+    torch.manual_seed(seed)
+    m = MADE(d, h, n_hidden).cuda()
+    with torch.no_grad():          # biases away from zero so that ReLU patterns are not trivial
+        for lin in m._linears():
+            lin.bias.uniform_(-0.3, 0.3)
+    return m
+
+
+def _plan_words(plan):
+    from gcn_vae_amd import made
+    w = plan.cpu().numpy().astype(np.int64)
+    assert w.size == made.PLAN_WORDS
+    counts, lists = w[:4], w[4:4 + 4 * 128].reshape(4, 128)
+    sets = w[4 + 4 * 128:].reshape(8, 16, 2)
+    sets = (sets[..., 0] & 0xffffffff) | ((sets[..., 1] & 0xffffffff) << 32)
+    return counts, lists, sets
+
+
+@pytest.mark.parametrize('d,h,n_hidden', [(200, 200, 3), (40, 56, 2), (16, 16, 3)])
+def test_plan_lists_every_tile_once_and_its_group_sets_are_the_masks_nonzero_groups(d, h, n_hidden):
+    """gv_made_chain_f32_plan against a numpy reading of the same 0/1 masks: the group set of every (layer, 32-column tile), forward
+    (B = W^T) and backward-x (B = W); every tile of every layer in exactly one wave's list, layers in ascending order; and the
+    lower-triangular masks of create_masks really do leave groups out (that is the point)."""
+    from gcn_vae_amd import made
+    m = _made(d, h, n_hidden)
+    masks = [l.mask for l in m._linears()]
+    widths, kin = [k.shape[0] for k in masks], [k.shape[1] for k in masks]
+    for transposed in (False, True):
+        if transposed:
+            ns, ks, ms = list(reversed(kin)), list(reversed(widths)), list(reversed(masks))
+        else:
+            ns, ks, ms = widths, kin, masks
+        plan = made.made_chain_f32_plan(ns, ks, ms, transposed=transposed)
+        torch.cuda.synchronize()
+        counts, lists, sets = _plan_words(plan)
+        seen = set()
+        for w in range(4):
+            units = [(int(e) >> 8, int(e) & 0xff) for e in lists[w, :counts[w]]]
+            assert units == sorted(units, key=lambda u: u[0]) or all(units[i][0] <= units[i + 1][0] for i in range(len(units) - 1))
+            for u in units:
+                assert u not in seen
+                seen.add(u)
+        assert seen == {(l, t) for l in range(len(ns)) for t in range((ns[l] + 31) // 32)}
+        skipped = total = 0
+        for l, (n_, k_, mk) in enumerate(zip(ns, ks, ms)):
+            b = mk.cpu().numpy().T if not transposed else mk.cpu().numpy()          # B [k][n]
+            assert b.shape == (k_, n_)
+            for t in range((n_ + 31) // 32):
+                want = 0
+                for g in range((k_ + 7) // 8):
+                    if b[8 * g:8 * g + 8, 32 * t:32 * t + 32].any():
+                        want |= 1 << g
+                total += (k_ + 7) // 8
+                skipped += (k_ + 7) // 8 - bin(want).count('1')
+                assert int(sets[l, t]) == (want or 1), (transposed, l, t, hex(int(sets[l, t])), hex(want))
+        if d >= 200:          # (narrow layers: a 32-column tile spans most of the degrees)
+            assert skipped > 0.2 * total, (skipped, total)
+    dense = made.made_chain_f32_plan(widths, kin, None)
+    _, _, sets = _plan_words(dense)
+    assert all(int(sets[l, t]) == (1 << ((kin[l] + 7) // 8)) - 1 for l in range(len(widths)) for t in range((widths[l] + 31) // 32))
+
+
+@pytest.mark.parametrize('d,h,n_hidden,rows', [(200, 200, 3, 1000), (200, 200, 3, 65), (40, 56, 2, 300), (16, 16, 3, 1), (64, 128, 1, 129)])
+def test_forward_and_backward_chains_equal_the_gemm_products_bit_for_bit(d, h, n_hidden, rows):
+    """One gv_made_chain_f32 launch against the same products as gv_gemm_f32 launches (bias, ReLU; backward: ReLU mask on the
+    operand, accumulating last product): every stored activation and gradient identical in every bit, with the masks' plan
+    (zero groups skipped) and with the dense plan."""
+    from gcn_vae_amd import made, ops
+    m = _made(d, h, n_hidden)
+    lin = m._linears()
+    L = len(lin)
+    ws = [ops.masked_weight(l.mask, l.weight).detach() for l in lin]
+    bs = [l.bias.detach() for l in lin]
+    masks = [l.mask for l in lin]
+    widths, kin = [w.shape[0] for w in ws], [w.shape[1] for w in ws]
+    assert made.made_chain_f32_fits(widths, kin) and made.made_chain_f32_fits(list(reversed(kin)), list(reversed(widths)))
+    gen = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, d, generator=gen).cuda()
+    # reference: a launch per product
+    want, inp = [], x
+    for l in range(L):
+        inp = ops.gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ops.ACT_RELU if l < L - 1 else ops.ACT_NONE)
+        want.append(inp)
+    g_top = torch.randn(rows, widths[-1], generator=gen).cuda()
+    g_old0 = torch.randn(rows, d, generator=gen).cuda()
+    want_g, g = [None] * L, g_top
+    for l in reversed(range(1, L)):
+        g = ops.gemm(g, ws[l], a_relu_mask=want[l] if l < L - 1 else None)
+        want_g[l - 1] = torch.where(want[l - 1] > 0, g, torch.zeros_like(g))          # what the chain stores: the MASKED gradient
+    want_gx = g_old0.clone()
+    ops.gemm(g, ws[0], out=want_gx, accumulate=True, a_relu_mask=want[0])
+    packed = made.made_pack_weights_f32(ws)
+    for use_masks in (True, False):
+        plan_f = made.made_chain_f32_plan(widths, kin, masks if use_masks else None)
+        plan_b = made.made_chain_f32_plan(list(reversed(kin)), list(reversed(widths)), list(reversed(masks)) if use_masks else None,
+                                          transposed=True)
+        acts = [torch.full((rows, widths[l]), float('nan'), device='cuda') for l in range(L)]
+        made.made_chain_f32(x, rows, [dict(w_packed=packed[l][0], n=widths[l], k=kin[l], bias=bs[l], relu=l < L - 1, out_f32=acts[l])
+                                      for l in range(L)], plan_f)
+        for l in range(L):
+            assert torch.equal(acts[l], want[l]), (use_masks, 'forward layer', l, float((acts[l] - want[l]).abs().max()))
+        grads = [torch.full((rows, widths[l]), float('nan'), device='cuda') for l in range(L - 1)]
+        gx = g_old0.clone()
+        made.made_chain_f32(g_top, rows,
+                            [dict(w_packed=packed[l][1], n=kin[l], k=widths[l], mask=acts[l - 1], out_f32=grads[l - 1])
+                             for l in reversed(range(1, L))] +
+                            [dict(w_packed=packed[0][1], n=d, k=widths[0], out_f32=gx, accumulate=True)], plan_b)
+        for l in range(L - 1):
+            assert torch.equal(grads[l], want_g[l]), (use_masks, 'backward layer', l, float((grads[l] - want_g[l]).abs().max()))
+        assert torch.equal(gx, want_gx), (use_masks, float((gx - want_gx).abs().max()))
+    assert float(want_gx.abs().max()) > 0 and all(float(w_.abs().max()) > 0 for w_ in want)
+
+
+@pytest.mark.parametrize('d,h,n_hidden,rows', [(200, 200, 3, 700), (40, 56, 2, 300)])
+def test_made_node_with_chains_equals_the_node_with_a_launch_per_product(monkeypatch, d, h, n_hidden, rows):
+    """The fp32 MADE node (made._MADEForward) with one chain launch per pass against GV_MADE_CHAIN_F32=0: x, log-det, dL/dz and every
+    parameter gradient bit for bit -- through plain autograd and with the gradients going straight into FlatAdam's arena."""
+    from gcn_vae_amd import made
+    from gcn_vae_amd.optim import FlatAdam
+    z = torch.randn(rows, d, generator=torch.Generator().manual_seed(5)).cuda()
+    tags, inner = [], made.made_chain_f32
+    monkeypatch.setattr(made, 'made_chain_f32', lambda *a, **k: (tags.append(k.get('tag')), inner(*a, **k))[1])
+    for with_opt in (False, True):
+        res = []
+        for on, gradw in ((False, False), (True, False), (True, True)):
+            monkeypatch.setattr(made, 'MADE_CHAIN_F32', on)
+            monkeypatch.setattr(made, 'MADE_GRADW_F32', gradw)       # (its own summation order: held to the others within fp32 rounding)
+            m = _made(d, h, n_hidden)
+            opt = FlatAdam(list(m.parameters()), lr=1e-3, max_grad_norm=1.0) if with_opt else None
+            if opt is not None:
+                opt.zero_grad()
+            zz = z.clone().requires_grad_(True)
+            del tags[:]
+            x, ld = m(zz)
+            (x.sin().sum() + (ld * ld).sum()).backward()
+            torch.cuda.synchronize()
+            assert (len(tags) == 2 * (len(m.m) - 1)) == on, (on, tags)
+            res.append((x.detach().clone(), ld.detach().clone(), zz.grad.clone(), [p.grad.detach().clone() for p in m.parameters()]))
+            if opt is not None:
+                opt.close()
+        for other in res[1:]:
+            assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1]) and torch.equal(res[0][2], other[2])
+        assert torch.isfinite(res[0][2]).all() and float(res[0][2].abs().max()) > 0
+        for a, b, c in zip(res[0][3], res[1][3], res[2][3]):
+            assert torch.equal(a, b) and float(a.abs().max()) > 0
+            torch.testing.assert_close(c, a, rtol=2e-5, atol=2e-6 * float(a.abs().max()))
+            assert bool(((a == 0) == (c == 0)).all()) or a.dim() == 1          # the masked-out entries are exact zeros in both
+
+
+def test_chain_skips_the_workgroups_that_hold_only_padding_rows():
+    """ops.live_rows: a chain over a node array of exactly ``cap`` rows stores zeros for the 64-row workgroups past the device row
+    count (nothing where it would accumulate) and computes the others in full."""
+    from gcn_vae_amd import made, ops
+    d, h, rows, live = 40, 56, 400, 150
+    m = _made(d, h, 2)
+    lin = m._linears()
+    L = len(lin)
+    ws = [ops.masked_weight(l.mask, l.weight).detach() for l in lin]
+    bs = [l.bias.detach() for l in lin]
+    widths, kin = [w.shape[0] for w in ws], [w.shape[1] for w in ws]
+    x = torch.randn(rows, d, generator=torch.Generator().manual_seed(1)).cuda()
+    packed = made.made_pack_weights_f32(ws)
+    plan = made.made_chain_f32_plan(widths, kin, [l.mask for l in lin])
+    full = [torch.empty(rows, widths[l], device='cuda') for l in range(L)]
+    made.made_chain_f32(x, rows, [dict(w_packed=packed[l][0], n=widths[l], k=kin[l], bias=bs[l], relu=l < L - 1, out_f32=full[l])
+                                  for l in range(L)], plan)
+    part = [torch.full((rows, widths[l]), 7.0, device='cuda') for l in range(L)]
+    rows_dev = torch.tensor([live], dtype=torch.int32, device='cuda')
+    with ops.live_rows(rows_dev, rows):
+        made.made_chain_f32(x, rows, [dict(w_packed=packed[l][0], n=widths[l], k=kin[l], bias=bs[l], relu=l < L - 1, out_f32=part[l],
+                                           accumulate=(l == L - 1)) for l in range(L)], plan)
+    edge = (live + 63) // 64 * 64
+    for l in range(L - 1):
+        assert torch.equal(part[l][:edge], full[l][:edge]) and float(part[l][edge:].abs().max()) == 0.0
+    assert torch.equal(part[L - 1][:edge], full[L - 1][:edge] + 7.0) and bool((part[L - 1][edge:] == 7.0).all())
+
+
+@pytest.mark.parametrize('m,n,k,masked', [(200, 200, 5000, True), (400, 200, 3000, True), (56, 40, 777, True), (200, 200, 64, False), (448, 256, 2100, False)])
+def test_gradw_f32_against_a_double_precision_product(m, n, k, masked):
+    """gv_made_gradw_f32: dW = wmask * (g^T a + g0m^T a0), db = column sums of g + g0m, against torch in fp64 -- storing and
+    accumulating, with and without pass 0's row, under a MADE mask (tiles without a non-zero are skipped: exact zeros) and dense."""
+    from gcn_vae_amd import made
+    gen = torch.Generator().manual_seed(m + n + k)
+    g = torch.randn(k, m, generator=gen).cuda()
+    a = torch.randn(k, n, generator=gen).cuda()
+    g0, act0, a0 = torch.randn(1, m, generator=gen).cuda(), torch.randn(1, m, generator=gen).cuda(), torch.randn(1, n, generator=gen).cuda()
+    wmask = None
+    if masked:
+        deg_out, deg_in = torch.arange(m) % max(n - 1, 1), torch.arange(n) % max(n - 1, 1)
+        wmask = (deg_out.unsqueeze(-1) >= deg_in.unsqueeze(0)).float().cuda()
+    g0m = torch.where(act0 > 0, g0, torch.zeros_like(g0)).double()
+    want = g.double().t() @ a.double() + g0m.t() @ a0.double()
+    want_db = g.double().sum(0) + g0m.view(-1)
+    if wmask is not None:
+        want = want * wmask.double()
+    scale = float(want.abs().max())
+    out, db = made.made_gradw_f32(g, a, wmask=wmask, g0=g0, g0_act=act0, a0=a0)
+    torch.testing.assert_close(out.double(), want, rtol=1e-5, atol=2e-6 * scale)
+    torch.testing.assert_close(db.double(), want_db, rtol=1e-5, atol=2e-6 * float(want_db.abs().max()))
+    if wmask is not None:
+        assert bool((out[wmask == 0] == 0).all())
+    # accumulate into existing contents, no pass-0 row, no bias
+    base = torch.randn(m, n, generator=gen).cuda()
+    out2 = base.clone()
+    made.made_gradw_f32(g, a, wmask=wmask, out=out2, accumulate=True, want_db=False)
+    want2 = base.double() + (g.double().t() @ a.double()) * (wmask.double() if wmask is not None else 1.0)
+    torch.testing.assert_close(out2.double(), want2, rtol=1e-5, atol=2e-6 * scale)
+    db3 = torch.full((m,), 3.0, device='cuda')
+    made.made_gradw_f32(g, a, wmask=wmask, db=db3, db_accumulate=True)
+    torch.testing.assert_close(db3.double(), 3.0 + g.double().sum(0), rtol=1e-5, atol=2e-6 * float(want_db.abs().max()))
