@@ -13,12 +13,13 @@ constexpr int ROW_THREADS = 1024, ROW_MAXW = 512;
 struct RowArgs {
     const float* x;          // forward: input row [k_0] or NULL (zeros); backward: gradient of the last layer's output [n_last]
     float* gx;               // backward: gradient w.r.t. the input row [k_0] or NULL
-    int n_layers;
+    int n_layers, exact;
     gv_row_layer L[GV_CHAIN_MAX_LAYERS];
 };
 
-__device__ __forceinline__ float rbf(float v) { return (float)(__bf16)v; }
-__device__ __forceinline__ float4 rbf4(float4 v) { return make_float4(rbf(v.x), rbf(v.y), rbf(v.z), rbf(v.w)); }
+// ex != 0: exact fp32 operands (the fp32 MADE node: layers[0].reserved = 1) instead of the bf16 rounding
+__device__ __forceinline__ float rbf(float v, int ex) { return ex ? v : (float)(__bf16)v; }
+__device__ __forceinline__ float4 rbf4(float4 v, int ex) { return make_float4(rbf(v.x, ex), rbf(v.y, ex), rbf(v.z, ex), rbf(v.w, ex)); }
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
 
 constexpr int ROW_WAVES = ROW_THREADS / 64;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row_fwd(const RowArgs p) {
     __shared__ __attribute__((aligned(16))) float xs[2][ROW_MAXW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < ROW_MAXW; i += ROW_THREADS) {
-        xs[0][i] = (p.x && i < p.L[0].k) ? rbf(p.x[i]) : 0.f;
+        xs[0][i] = (p.x && i < p.L[0].k) ? rbf(p.x[i], p.exact) : 0.f;
         xs[1][i] = 0.f;
     }
     __syncthreads();
@@ -76,13 +77,13 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row_fwd(const RowArgs p) {
 #pragma unroll
             for (int jb = 0; jb < ROW_JB; ++jb) {
                 const int j = j0 + jb * ROW_WAVES;
-                const float s = wave_sum(dot4(xa, rbf4(wa[jb])) + dot4(xb, rbf4(wb[jb])));
+                const float s = wave_sum(dot4(xa, rbf4(wa[jb], p.exact)) + dot4(xb, rbf4(wb[jb], p.exact)));
                 const float bj = rl_bcast_f(bvec, jb);
                 if (lane == 0 && j < n) {
                     float y = s + bj;
                     if (relu) y = fmaxf(y, 0.f);
                     if (outp) outp[j] = y;
-                    xout[j] = rbf(y);
+                    xout[j] = rbf(y, p.exact);
                 }
             }
         }
@@ -115,9 +116,9 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row_bwd(const RowArgs p) {
             float v = gl[j];
             if (act && !(act[j] > 0.f)) v = 0.f;
             if (gb) gb[j] = v;
-            gm[j] = rbf(v);
+            gm[j] = rbf(v, p.exact);
         }
-        for (int c = threadIdx.x; c < ROW_MAXW; c += ROW_THREADS) rin[c] = (inp && c < k) ? rbf(inp[c]) : 0.f;
+        for (int c = threadIdx.x; c < ROW_MAXW; c += ROW_THREADS) rin[c] = (inp && c < k) ? rbf(inp[c], p.exact) : 0.f;
         __syncthreads();
         const bool need_g = l > 0 || p.gx;
         const float4 ra = *reinterpret_cast<const float4*>(rin + 4 * lane), rb = *reinterpret_cast<const float4*>(rin + 256 + 4 * lane);
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row_bwd(const RowArgs p) {
                         *reinterpret_cast<float4*>(o + 256 + 4 * lane) = make_float4(gj * rb.x, gj * rb.y, gj * rb.z, gj * rb.w);
                 }
                 if (need_g) {       // g_{l-1} += gm[j] W[j][:]: this wave's rows in order
-                    const float4 a = rbf4(wa[jb]), b = rbf4(wb[jb]);
+                    const float4 a = rbf4(wa[jb], p.exact), b = rbf4(wb[jb], p.exact);
                     sa.x += gj * a.x; sa.y += gj * a.y; sa.z += gj * a.z; sa.w += gj * a.w;
                     sb.x += gj * b.x; sb.y += gj * b.y; sb.z += gj * b.z; sb.w += gj * b.w;
                 }
@@ -184,7 +185,7 @@ extern "C" int gv_made_row_fwd(const float* x, int n_layers, const gv_row_layer*
     int rc = row_check("gv_made_row_fwd", n_layers, layers, false);
     if (rc != GV_OK) return rc;
     RowArgs p;
-    p.x = x; p.gx = nullptr; p.n_layers = n_layers;
+    p.x = x; p.gx = nullptr; p.n_layers = n_layers; p.exact = layers[0].reserved ? 1 : 0;
     for (int i = 0; i < n_layers; ++i) p.L[i] = layers[i];
     bool wide = false;
     for (int i = 0; i < n_layers; ++i) wide = wide || layers[i].k > 256;
@@ -198,7 +199,7 @@ extern "C" int gv_made_row_bwd(const float* g_out, int n_layers, const gv_row_la
     if (rc != GV_OK) return rc;
     GV_REQUIRE(g_out, GV_ERR_NULL, "gv_made_row_bwd: NULL gradient");
     RowArgs p;
-    p.x = g_out; p.gx = g_x; p.n_layers = n_layers;
+    p.x = g_out; p.gx = g_x; p.n_layers = n_layers; p.exact = layers[0].reserved ? 1 : 0;
     for (int i = 0; i < n_layers; ++i) p.L[i] = layers[i];
     bool wide = false;
     for (int i = 0; i < n_layers; ++i) wide = wide || layers[i].k > 256;

@@ -63,12 +63,17 @@ class _MADEForward(torch.autograd.Function):
         xin = torch.empty(max(S, 1) * n, d, **f32)               # xin[s] = input of pass s+1 = output of pass s
         acts = [torch.empty(max(S, 1) * n, ws[l].shape[0], **f32) for l in range(L)]   # acts[L-1] = [mu | alpha]
         x_out = torch.empty(n, d, **f32)
-        # pass 0 on a single zero row
+        # pass 0 on a single zero row: one single-workgroup launch (exact fp32 operands) where the widths allow, else a launch per product
         zero_row = torch.zeros(1, d, **f32)
-        acts0, inp = [], zero_row
-        for l in range(L):
-            inp = gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE)
-            acts0.append(inp)
+        row = (MADE_ROW_F32 and L <= 8 and d <= 512 and max(w.shape[0] for w in ws) <= 512 and all(w.shape[1] % 4 == 0 for w in ws))
+        if row:
+            acts0 = [torch.empty(1, w.shape[0], **f32) for w in ws]
+            made_row_fwd(None, [dict(w=ws[l], bias=bs[l], relu=l < L - 1, out=acts0[l]) for l in range(L)], exact=True)
+        else:
+            acts0, inp = [], zero_row
+            for l in range(L):
+                inp = gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE)
+                acts0.append(inp)
         first_out = xin[0:n] if P > 1 else x_out
         # (columns outside the first index set would keep x_old = 0: flows.MADE checks at construction that there are none)
         lib.call('gv_iaf_update_fwd', ptr(z), ptr(acts0[L - 1]), 0, ptr(z), ptr(colcount[0]), ptr(first_out), n, d, st)
@@ -108,6 +113,7 @@ class _MADEForward(torch.autograd.Function):
         ctx.save_for_backward(z, colcount, xin, zero_row, *acts, *acts0, *ws, *([pk[1] for pk in packed] if chain else []))
         ctx.L = L
         ctx.chain = chain
+        ctx.row = row
         ctx.has_bias = [b is not None for b in bs]
         return x_out, log_det
 
@@ -138,10 +144,15 @@ class _MADEForward(torch.autograd.Function):
             for p in reversed(range(1, P)):
                 a, b = (p - 1) * n + r0, (p - 1) * n + r1
                 g_old = g_olds[p][r0:r1]
-                lib.call('gv_iaf_update_bwd', ptr(z[r0:r1]), ptr(acts[L - 1][a:b]), 2 * d, ptr(colcount[p]), ptr(g_in[r0:r1]),
-                         ptr(gld[r0:r1]) if (p == P - 1 and gld is not None) else None, ptr(gz_p[r0:r1]), ptr(grads[L - 1][a:b]),
-                         ptr(g_old), m, d, lib.stream())
-                lib.call('gv_axpby', m * d, None, 1.0, ptr(gz_p[r0:r1]), 1.0, ptr(g_z[r0:r1]), lib.stream())
+                if d % 4 == 0:       # dL/dz of the pass added to the running sum by the same launch
+                    lib.call('gv_iaf_update_bwd_acc', ptr(z[r0:r1]), ptr(acts[L - 1][a:b]), 2 * d, ptr(colcount[p]), ptr(g_in[r0:r1]),
+                             ptr(gld[r0:r1]) if (p == P - 1 and gld is not None) else None, ptr(g_z[r0:r1]), 1, ptr(grads[L - 1][a:b]),
+                             ptr(g_old), m, d, lib.stream())
+                else:
+                    lib.call('gv_iaf_update_bwd', ptr(z[r0:r1]), ptr(acts[L - 1][a:b]), 2 * d, ptr(colcount[p]), ptr(g_in[r0:r1]),
+                             ptr(gld[r0:r1]) if (p == P - 1 and gld is not None) else None, ptr(gz_p[r0:r1]), ptr(grads[L - 1][a:b]),
+                             ptr(g_old), m, d, lib.stream())
+                    lib.call('gv_axpby', m * d, None, 1.0, ptr(gz_p[r0:r1]), 1.0, ptr(g_z[r0:r1]), lib.stream())
                 if chain:       # g_{l-1} = (g_l W_l) * [a_{l-1} > 0] down to g_x, one launch; the hidden gradients are STORED masked
                     made_chain_f32(grads[L - 1][a:b], m,
                                    [dict(w_packed=wpb[l], n=kin[l], k=widths[l], mask=acts[l - 1][a:b], out_f32=grads[l - 1][a:b])
@@ -162,8 +173,17 @@ class _MADEForward(torch.autograd.Function):
         g_cur = g_olds[1] if P > 1 else gx
         # pass 0: the update's gradient w.r.t. the broadcast net row is its column sum; x_old was the zero matrix
         g_row = iaf_bwd_row0(z, acts0[L - 1], colcount[0], g_cur, gld if P == 1 else None, g_z)      # (1, 2D)
-        rows0 = [None] * L                                        # masked single-row gradients per layer output
-        for l in reversed(range(L)):
+        rows0 = [None] * L                                        # single-row gradients per layer output (masked where it is used)
+        # chain path: the hidden gradients are stored ReLU-masked, so each layer's weight AND bias gradient over all stacked passes,
+        # pass 0's rank-1 term, the mask fold and the store / add into the arena are ONE product on gv_made_gradw_f32 (+ its split sum)
+        fused_gradw = (ctx.chain and MADE_GRADW_F32 and S > 0 and all(w_ % 4 == 0 for w_ in widths + kin)
+                       and all(ctx.needs_input_grad[3 + l] for l in range(L))
+                       and all(ctx.needs_input_grad[3 + L + l] or not ctx.has_bias[l] for l in range(L)))
+        row_bwd = fused_gradw and ctx.row           # pass 0's backward chain as one single-workgroup launch: gm_l = its masked row gradients
+        if row_bwd:
+            rows0 = [torch.empty(1, widths[l], **f32) for l in range(L)]
+            made_row_bwd(g_row, [dict(w=ws[l], act=acts0[l] if l < L - 1 else None, gb=rows0[l]) for l in range(L)], exact=True)
+        for l in reversed(range(L)) if not row_bwd else ():
             rows0[l] = g_row
             if l > 0:
                 mask = acts0[l] if l < L - 1 else None
@@ -180,14 +200,11 @@ class _MADEForward(torch.autograd.Function):
         beside = (ctx.masks is not None and L <= 8 and all(tgt_w[l] is not None for l in range(L) if wants_w[l])
                   and all(tgt_b[l] is not None for l in range(L) if wants_b[l]))
         g_ws, g_bs = [], []
-        # chain path: the hidden gradients are stored ReLU-masked, so each layer's weight AND bias gradient over all stacked passes,
-        # pass 0's rank-1 term, the mask fold and the store / add into the arena are ONE product on gv_made_gradw_f32 (+ its split sum)
-        fused_gradw = (chain and MADE_GRADW_F32 and S > 0 and all(w_ % 4 == 0 for w_ in widths + kin)
-                       and all(wants_w[l] for l in range(L)) and all(wants_b[l] or not ctx.has_bias[l] for l in range(L)))
         with backward_side(beside, grads, xin, acts, acts0, rows0, zero_row):
             for l in range(L) if fused_gradw else ():
                 gw, gb = made_gradw_f32(grads[l], xin if l == 0 else acts[l - 1], wmask=ctx.masks[l] if ctx.masks is not None else None,
-                                        g0=rows0[l], g0_act=acts0[l] if l < L - 1 else None, a0=zero_row if l == 0 else acts0[l - 1],
+                                        g0=rows0[l], g0_act=acts0[l] if (l < L - 1 and not row_bwd) else None,
+                                        a0=zero_row if l == 0 else acts0[l - 1],
                                         out=tgt_w[l], accumulate=False, db=tgt_b[l], db_accumulate=tgt_b[l] is not None,
                                         want_db=wants_b[l])
                 if tgt_w[l] is not None:
@@ -351,8 +368,9 @@ class _RowLayer(_ct.Structure):
                 ('relu', _ct.c_int32), ('ldgw', _ct.c_int32), ('reserved', _ct.c_int32)]
 
 
-def _row_layers(layers):
+def _row_layers(layers, exact=False):
     arr = (_RowLayer * len(layers))()
+    arr[0].reserved = 1 if exact else 0          # exact fp32 operands instead of the bf16 rounding (the fp32 node)
     for c, d in zip(arr, layers):
         w, ld = _row_major(d['w'], 'w')
         gw = d.get('gw')
@@ -364,16 +382,16 @@ def _row_layers(layers):
     return arr
 
 
-def made_row_fwd(x, layers):
+def made_row_fwd(x, layers, exact=False):
     """The masked MLP on ONE row (MADE's pass 0), one single-workgroup launch: layers = dicts with w (n, k) and optional bias,
-    relu, out (n,)."""
-    arr = _row_layers(layers)
+    relu, out (n,).  exact: fp32 operands (default: rounded to bf16, configs[2])."""
+    arr = _row_layers(layers, exact)
     lib.call('gv_made_row_fwd', ptr(x), len(layers), _ct.addressof(arr), lib.stream())
 
 
-def made_row_bwd(g_out, layers, g_x=None):
+def made_row_bwd(g_out, layers, g_x=None, exact=False):
     """Backward of made_row_fwd: layers = dicts with w and optional act (ReLU mask), inp (the layer's input row), gw, gb."""
-    arr = _row_layers(layers)
+    arr = _row_layers(layers, exact)
     lib.call('gv_made_row_bwd', ptr(g_out), len(layers), _ct.addressof(arr), ptr(g_x), lib.stream())
 
 
@@ -577,6 +595,7 @@ def made_chain_f32(x, m, layers, plan, tag=None):
 
 
 MADE_GRADW_F32 = _os.environ.get('GV_MADE_GRADW_F32', '1') == '1'      # the fp32 node's weight / bias gradients on gv_made_gradw_f32
+MADE_ROW_F32 = _os.environ.get('GV_MADE_ROW_F32', '1') == '1'          # ... and its pass 0 (one broadcast row) as single-workgroup launches
 _gradw32_plans = {}
 
 

@@ -376,7 +376,7 @@ int gv_made_gradw_f32(const float* g, int ldg, const float* a, int lda, int m, i
 /* ---------------------------------------------------------------------------------------------
  * K4, pass 0 of MADE (kgvae/flow_network.py:85-98): the first pass feeds the masked MLP an all-zero input, so every node sees
  * the same ROW; the whole chain of 1 x k by k x n products is one single-workgroup launch.  Operands rounded to bf16, fp32
- * products and sums (the precision of BASELINE configs[2]).
+ * products and sums (the precision of BASELINE configs[2]); with layers[0].reserved != 0 the operands stay exact fp32 (the fp32 node).
  *   gv_made_row_fwd: y_l = act(y_{l-1} W_l^T + b_l); x = y_{-1} [k_0] (NULL: zeros); layer.out [n] receives y_l (fp32).
  *   gv_made_row_bwd: g_out = dL/dy_last [n_last]; per layer gm = g * [act > 0] (act NULL: no mask), gb [n] = gm,
  *     gw [n][ldgw] = gm^T inp (inp [k] = the layer's input row, NULL: zeros; gw is WRITTEN, not accumulated),
@@ -576,6 +576,11 @@ int gv_iaf_update_fwd(const float* z, const float* net, int ld_net, const float*
 int gv_iaf_update_bwd(const float* z, const float* net, int ld_net, const int32_t* colcount, const float* g_xnew,
                       const float* g_logdet /*[n] or NULL*/, float* g_z, float* g_net, float* g_xold, int64_t n, int d,
                       void* stream);
+/* ... with dL/dz ADDED in place where gz_accumulate != 0 (the caller sums it over a MADE's passes: no separate add), four columns
+ * per thread: d and ld_net multiples of 4, 16-B aligned operands; g_net is [n][2 d]. */
+int gv_iaf_update_bwd_acc(const float* z, const float* net, int ld_net, const int32_t* colcount, const float* g_xnew,
+                          const float* g_logdet, float* g_z, int gz_accumulate, float* g_net, float* g_xold, int64_t n, int d,
+                          void* stream);
 int gv_rowsum(const float* x, int ld, int col0, int ncols, float* out, int64_t n, void* stream);
 int gv_reverse_cols(const float* x, float* out, int64_t n, int d, void* stream);
 

@@ -138,6 +138,7 @@ def test_made_node_with_chains_equals_the_node_with_a_launch_per_product(monkeyp
         for on, gradw in ((False, False), (True, False), (True, True)):
             monkeypatch.setattr(made, 'MADE_CHAIN_F32', on)
             monkeypatch.setattr(made, 'MADE_GRADW_F32', gradw)       # (its own summation order: held to the others within fp32 rounding)
+            monkeypatch.setattr(made, 'MADE_ROW_F32', False)         # (pass 0 as one launch sums in another order too: its own test below)
             m = _made(d, h, n_hidden)
             opt = FlatAdam(list(m.parameters()), lr=1e-3, max_grad_norm=1.0) if with_opt else None
             if opt is not None:
@@ -221,3 +222,24 @@ def test_gradw_f32_against_a_double_precision_product(m, n, k, masked):
     db3 = torch.full((m,), 3.0, device='cuda')
     made.made_gradw_f32(g, a, wmask=wmask, db=db3, db_accumulate=True)
     torch.testing.assert_close(db3.double(), 3.0 + g.double().sum(0), rtol=1e-5, atol=2e-6 * float(want_db.abs().max()))
+
+
+@pytest.mark.parametrize('d,h,n_hidden,rows', [(200, 200, 3, 500), (40, 56, 2, 300)])
+def test_made_node_with_pass_0_as_single_workgroup_launches(monkeypatch, d, h, n_hidden, rows):
+    """GV_MADE_ROW_F32: pass 0 of the fp32 node (one broadcast row) on gv_made_row_fwd / _bwd with exact fp32 operands instead of
+    one-row products on the GEMM: same node within fp32 rounding (the row kernels sum along k in another order)."""
+    from gcn_vae_amd import made
+    z = torch.randn(rows, d, generator=torch.Generator().manual_seed(9)).cuda()
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(made, 'MADE_ROW_F32', on)
+        m = _made(d, h, n_hidden)
+        zz = z.clone().requires_grad_(True)
+        x, ld = m(zz)
+        (x.sin().sum() + (ld * ld).sum()).backward()
+        torch.cuda.synchronize()
+        res.append((x.detach().clone(), ld.detach().clone(), zz.grad.clone(), [p.grad.detach().clone() for p in m.parameters()]))
+    for a, b in zip(res[0][:3], res[1][:3]):
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6 * float(a.abs().max()))
+    for a, b in zip(res[0][3], res[1][3]):
+        torch.testing.assert_close(b, a, rtol=5e-5, atol=5e-6 * float(a.abs().max()))
