@@ -198,3 +198,24 @@ def test_bench_exits_nonzero_on_a_nonfinite_loss_and_headlines_the_dominant_kern
     roof, roof_k1 = bench.dominant_roofline(k1, detail, k4)
     assert roof['kernel'] == 'madechain_bwd' and roof['bound'] == 'mfma' and roof['unit'] == 'TFLOP/s' and roof_k1 == k1
     assert abs(roof['frac'] - 0.084) < 1e-9 and roof['peak'] == 2500.0
+
+
+def test_every_environment_knob_is_in_designs_table_and_the_other_way_round():
+    """DESIGN.md's knob table against the code: every GV_* environment variable the package, the kernels' host code or bench.py read
+    is a row of the table, and every variable the table names is read somewhere."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = (glob.glob(os.path.join(root, 'gcn-vae_amd', '*.py')) + glob.glob(os.path.join(root, 'gcn-vae_amd', 'csrc', '*.hip')) +
+             glob.glob(os.path.join(root, 'gcn-vae_amd', 'csrc', '*.h')) + [os.path.join(root, 'bench.py')])
+    pat = re.compile(r"""(?:environ(?:\.get|\.setdefault)?[\(\[]\s*['"]|getenv\(")(GV_[A-Z0-9_]+)""")
+    in_code = set()
+    for f in files:
+        in_code |= set(pat.findall(open(f).read()))
+    text = open(os.path.join(root, 'DESIGN.md')).read()
+    table = text[text.index('## Knobs'):text.index('## Out of scope')]
+    in_doc = set(re.findall(r'`(GV_[A-Z0-9_]+)`', table))
+    assert in_code, 'no knobs found: the pattern is out of date'
+    assert in_code - in_doc == set(), f'read by the code but missing from DESIGN.md: {sorted(in_code - in_doc)}'
+    assert in_doc - in_code == set(), f'in DESIGN.md but read nowhere: {sorted(in_doc - in_code)}'

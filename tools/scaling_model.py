@@ -64,5 +64,54 @@ def main():
                       f'{c["t1_ms"] * 1e-3 / step_r:9.2f}')
 
 
+# ---- STRONG scaling (bench.py's default with more than one rank: ONE graph, BASELINE configs[3..4]) ------------------------------
+STRONG = {
+    # measured 1-GPU steps (profiles/round3-4); node_share = the part of the step that is row-wise over nodes / triplets / parameters
+    # (self-loop products, epilogues, reparameterisation, KL, MMD, decoder, clip + Adam): replicated under edge sharding, divided
+    # under the row partition; the rest is K1 (aggregations + grad-W), divided by both
+    'c2 (FB15k-237, h=200)': dict(N=14541, h=200, other_mb=2.9, t1_ms=1.06, node_share=0.45),
+    'c4 (FB15k-237, h=500)': dict(N=14541, h=500, other_mb=14.6, t1_ms=3.44, node_share=0.35),
+    'c5 (1 M entities, 50 M edges, h=200)': dict(N=1_000_000, h=200, other_mb=3.0, t1_ms=82.0, node_share=0.22),
+}
+
+
+def strong(bw, alpha):
+    """Predicted STRONG-scaling step time and speed-up t(1) / t(p).  edge = edge blocks by relation + all-reduce of node rows
+    (north_star); edge+shard = the same with the optimiser sharded (reduce-scatter of the gradient arena, clip + Adam on 1/p of it,
+    all-gather of the updated parameters: the replicated Adam and half of the arena exchange go away); rows = destination-row
+    partition (all-gather forward, reduce-scatter backward, node-level work divided).  Collectives 'direct' (every peer on its own
+    link) / 'ring' (one link); half of each layer exchange is taken as hidden under the neighbouring kernels, as measured for
+    the 2-rank shared-GPU runs -- a guess until a SCALE run exists."""
+    for name, c in STRONG.items():
+        S1, S2 = c['N'] * c['h'] * 4, c['N'] * 2 * c['h'] * 4
+        arena = S1 + c['other_mb'] * 1e6
+        t1 = c['t1_ms'] * 1e-3
+        adam = min(0.3 * t1 * c['node_share'], 4 * arena * 2 / 4.0e12)      # clip + Adam: ~8 arena passes at ~4 TB/s
+        print(f'\n{name}: 1-GPU step {c["t1_ms"]} ms, node-level share {c["node_share"]}, S1 {S1 / 1e6:.1f} MB, S2 {S2 / 1e6:.1f} MB, '
+              f'arena {arena / 1e6:.1f} MB (STRONG scaling: one graph)')
+        print(f'{"ranks":>5} {"scheme":>26} {"compute ms":>11} {"exposed collectives ms":>23} {"step ms":>8} {"speed-up":>9}')
+        for p in (2, 4, 8):
+            for direct in (True, False):
+                tag = 'direct' if direct else 'ring'
+                k1, node = t1 * (1 - c['node_share']), t1 * c['node_share']
+                ar = 2 * (t_allreduce(S1, p, bw, alpha, direct) + t_allreduce(S2, p, bw, alpha, direct))
+                rows = [('edge / ' + tag, k1 / p + node, 0.5 * ar + t_allreduce(arena, p, bw, alpha, direct)),
+                        ('edge+sharded Adam / ' + tag, k1 / p + node - adam * (1 - 1 / p), 0.5 * ar + 2 * t_gather(arena, p, bw, alpha, direct)),
+                        ('rows / ' + tag, (k1 + node) / p,
+                         0.5 * 2 * (t_gather(S1, p, bw, alpha, direct) + t_gather(S2, p, bw, alpha, direct)) + t_allreduce(arena, p, bw, alpha, direct)),
+                        ('rows+sharded Adam / ' + tag, (k1 + node) / p,
+                         0.5 * 2 * (t_gather(S1, p, bw, alpha, direct) + t_gather(S2, p, bw, alpha, direct)) + 2 * t_gather(arena, p, bw, alpha, direct))]
+                for label, comp, coll in rows:
+                    step = comp + coll
+                    print(f'{p:5d} {label:>26} {comp * 1e3:11.3f} {coll * 1e3:23.3f} {step * 1e3:8.3f} {t1 / step:9.2f}')
+
+
 if __name__ == '__main__':
     main()
+    import sys
+    _a = argparse.ArgumentParser()
+    _a.add_argument('--eff', type=float, default=0.8)
+    _a.add_argument('--alpha-us', type=float, default=12.0)
+    _o = _a.parse_args()
+    print('\n================ STRONG scaling ================')
+    strong(153e9 * _o.eff, _o.alpha_us * 1e-6)
