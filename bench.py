@@ -103,6 +103,9 @@ def parse():
                    help='world size > 1: "edge" = edge-block sharding + all-reduce of node embeddings (north_star), "row" = '
                         'destination-row partition + all-gather / reduce-scatter (SURVEY 8e alternative), "auto" = time '
                         '--probe-steps steps of each during warm-up and run the faster one')
+    p.add_argument('--sharded-adam', action='store_true',
+                   help='world size > 1: distributed.ShardedFlatAdam -- reduce-scatter of the gradient arena, clip + Adam on 1/N of '
+                        'it per rank, all-gather of the updated parameters -- instead of the all-reduce + replicated update')
     p.add_argument('--probe-steps', type=int, default=10)
     p.add_argument('--profile-steps', type=int, default=3, help='instrumented eager steps for the roofline figure')
     args = p.parse_args()
@@ -718,8 +721,12 @@ def main():
     use_graph = not args.no_graph and ((world == 1 and not args.force_dist) or args.graph_collectives)
     use_segments = dist_on and not use_graph and not args.no_graph and not args.no_segments
     from gcn_vae_amd.optim import FlatAdam
-    opt = FlatAdam(params, lr=1e-3, max_grad_norm=1.0)      # clip_grad_norm_(1.0) + Adam over one flat arena
-    reducer = gdist.BucketedArenaReduce(opt.flat_g, opt.offsets) if dist_on else None
+    sharded = dist_on and args.sharded_adam
+    if sharded:     # the gradient exchange IS the optimiser step: no arena all-reduce under backward
+        opt = gdist.ShardedFlatAdam(params, lr=1e-3, max_grad_norm=1.0)
+    else:
+        opt = FlatAdam(params, lr=1e-3, max_grad_norm=1.0)      # clip_grad_norm_(1.0) + Adam over one flat arena
+    reducer = gdist.BucketedArenaReduce(opt.flat_g, opt.offsets) if (dist_on and not sharded) else None
     pick_rng = random.Random(rank)
     post_idx = torch.zeros(200, dtype=torch.long, device=dev)
     model.encoder.mmd_index_override = post_idx          # static buffer: contents refreshed per step on the host
@@ -757,6 +764,8 @@ def main():
         enc.grad_reducer = reducer if (dist_on and name == 'edge') else None      # row scheme: one piece, at the end
         if reducer is not None:
             reducer.average = name != 'row'       # row partition: every gradient is a partial sum over the ranks' rows
+        if sharded:
+            opt.sharded.average = name != 'row'
         # edge-block sharding replicates the node-level work: all ranks must draw the SAME dropout masks / noise;
         # the row partition draws per-rank noise for its own rows
         torch.manual_seed(m['seed'])
@@ -781,7 +790,7 @@ def main():
         embed = model(cur['g'], cur['node_id'], cur['etype'], cur['enorm'])
         loss, pred, kl, mmd = model.get_loss(cur['g'], embed, cur['samples'], cur['labels'])
         loss.backward(gradient=one)
-        if dist_on:
+        if reducer is not None:
             reducer.finish()               # what backward could not start early, the waits, the 1/world scale
         opt.step()
         return loss
@@ -1056,6 +1065,7 @@ def main():
                                        'destination-row partition x%d of %s, RCCL all-gather / reduce-scatter of node rows'
                                        % (world, 'the one graph' if w['strong'] else 'the union of the ranks\' edge blocks')),
                        'partition': cur['name'] if dist_on else None,
+                       'optimizer': 'sharded clip + Adam (reduce-scatter / all-gather of the arena)' if sharded else 'replicated clip + Adam',
                        'partition_probe_ms_per_step': {k: round(v, 4) for k, v in probe.items()} or None,
                        'row_partition_edges_per_rank': edge_counts},
             'final_loss': final_loss,

@@ -406,3 +406,101 @@ def sum_flat(flat_grads, group=None):
     all-reduce(sum) of the FlatAdam gradient arena, no division."""
     if dist.is_initialized():
         start_collective(lambda: dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group, async_op=True)).wait()
+
+
+# ---- the optimiser sharded over the ranks (round 4; SURVEY 8(e): "replicated params' grads all-reduced once per step" is what this
+# replaces) -----------------------------------------------------------------------------------------------------------------
+# With replicated parameters every rank all-reduces the whole gradient arena and runs clip + Adam on all of it.  Sharded: the
+# arena is cut into `world` equal pieces;   reduce-scatter(sum) of the gradients  ->  the global gradient norm from ONE all-reduce
+# of the pieces' sums of squares  ->  clip + Adam on the rank's piece (moments exist for that piece only)  ->  all-gather of the
+# updated parameters.  Same bytes on the links as the all-reduce (which is a reduce-scatter + all-gather), but the second half
+# now carries PARAMETERS, so the update itself is done once instead of `world` times and the moments take 1/world of the memory.
+class ShardedArenaStep:
+    """The communication + update pattern over flat tensors of any device.  ``sumsq(g) -> 0-d tensor`` and
+    ``adam(p, g, m, v, sumsq, step_t)`` are the local kernels (HIP: gv_mean_sq / gv_adam_step; the CPU tests pass torch
+    restatements)."""
+
+    def __init__(self, flat_p, flat_g, sumsq, adam, group=None, average=True, native=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        if flat_p.numel() != flat_g.numel() or flat_p.numel() % self.world:
+            raise ValueError(f'ShardedArenaStep: arenas of {flat_p.numel()} / {flat_g.numel()} entries, not a multiple of {self.world} ranks')
+        self.flat_p, self.flat_g = flat_p, flat_g
+        self.n = flat_p.numel() // self.world
+        self.lo = self.rank * self.n
+        self.m = torch.zeros(self.n, dtype=flat_p.dtype, device=flat_p.device)
+        self.v = torch.zeros(self.n, dtype=flat_p.dtype, device=flat_p.device)
+        self.g_piece = torch.zeros(self.n, dtype=flat_p.dtype, device=flat_p.device)
+        self.step_t = torch.zeros((), dtype=torch.float32, device=flat_p.device)
+        self.total_sumsq = torch.zeros((), dtype=torch.float32, device=flat_p.device)
+        self._sumsq, self._adam, self.average = sumsq, adam, bool(average)
+        self._gather = None
+        if native is None:
+            native = self.world > 1 and dist.get_backend(group) == 'nccl'
+        self.native = bool(native)
+
+    def step(self):
+        p_piece = self.flat_p[self.lo:self.lo + self.n]
+        if self.world == 1:
+            self.g_piece.copy_(self.flat_g)
+        elif self.native:
+            start_collective(lambda: dist.reduce_scatter_tensor(self.g_piece, self.flat_g, op=dist.ReduceOp.SUM, group=self.group,
+                                                                async_op=True)).wait()
+        else:           # functional fallback (gloo has no reduce-scatter): all-reduce, keep the rank's piece
+            start_collective(lambda: dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)).wait()
+            self.g_piece.copy_(self.flat_g[self.lo:self.lo + self.n])
+        if self.average and self.world > 1:
+            self.g_piece.mul_(1.0 / self.world)
+        self.total_sumsq.copy_(self._sumsq(self.g_piece))
+        if self.world > 1:          # the norm clip_grad_norm_ takes over ALL parameters: the pieces' sums of squares, summed
+            start_collective(lambda: dist.all_reduce(self.total_sumsq, op=dist.ReduceOp.SUM, group=self.group, async_op=True)).wait()
+        self.step_t += 1
+        self._adam(p_piece, self.g_piece, self.m, self.v, self.total_sumsq, self.step_t)
+        if self.world > 1:
+            if self.native:
+                self.g_piece.copy_(p_piece)          # (the gathered buffer must not overlap the piece it is gathered from; g_piece is free now)
+                start_collective(lambda: dist.all_gather_into_tensor(self.flat_p, self.g_piece, group=self.group, async_op=True)).wait()
+            else:       # functional fallback (gloo): a sum of disjoint pieces -- in a buffer of its own, never in the parameter arena
+                # itself: while a SegmentedGraph records the step the kernels around an (eagerly issued) collective are captured, not
+                # run, and a collective that sums the UN-zeroed arenas in place would double the parameters once, at capture time
+                if self._gather is None:
+                    self._gather = torch.zeros_like(self.flat_p)
+                self._gather.zero_()
+                self._gather[self.lo:self.lo + self.n].copy_(p_piece)
+                start_collective(lambda: dist.all_reduce(self._gather, op=dist.ReduceOp.SUM, group=self.group, async_op=True)).wait()
+                self.flat_p.copy_(self._gather)
+        self.flat_g.zero_()
+
+
+def ShardedFlatAdam(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, group=None, average=True):
+    """optim.FlatAdam whose step is sharded over the ranks (ShardedArenaStep on the HIP kernels): same arenas for parameters and
+    gradients (backward kernels still add straight into the gradient arena), moments for the rank's piece only.  Returns the
+    FlatAdam with ``step`` / ``snapshot`` / ``restore`` rebound; ``max_grad_norm`` is required (the clip is part of the update)."""
+    from . import lib
+    from .lib import ptr
+    from .optim import FlatAdam
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    opt = FlatAdam(params, lr=lr, betas=betas, eps=eps, max_grad_norm=max_grad_norm, total_multiple=world * FlatAdam.ALIGN, moments=False)
+    ws = torch.empty(1024, dtype=torch.float32, device=opt.flat_p.device)
+
+    def sumsq(g):
+        out = torch.empty((), dtype=torch.float32, device=g.device)
+        lib.call('gv_mean_sq', ptr(g), g.numel(), 1.0, ptr(out), ptr(ws), 0, lib.stream())
+        return out
+
+    def adam(p, g, m, v, total, step_t):
+        lib.call('gv_adam_step', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(total), float(max_grad_norm or 0.0), float(lr),
+                 float(betas[0]), float(betas[1]), float(eps), ptr(step_t), lib.stream())
+
+    sh = ShardedArenaStep(opt.flat_p, opt.flat_g, sumsq, adam, group=group, average=average)
+    opt.sharded = sh
+    opt.exp_avg, opt.exp_avg_sq, opt.step_t, opt.sumsq = sh.m, sh.v, sh.step_t, sh.total_sumsq
+
+    def step():
+        from . import ops
+        ops.backward_side_finish()
+        sh.step()
+        opt._clean = True
+    opt.step = step
+    return opt

@@ -17,7 +17,9 @@ from .lib import ptr
 class FlatAdam:
     ALIGN = 64   # floats: keeps every parameter 256-B aligned for the 16-B vector paths of the kernels
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None, total_multiple=1, moments=True):
+        """total_multiple: the arena length is rounded up to a multiple of it (a sharded optimiser cuts the arena into equal pieces);
+        moments=False: the caller keeps its own (smaller) moment arenas."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('FlatAdam: no trainable parameters')
@@ -29,11 +31,12 @@ class FlatAdam:
         for p in self.params:
             offs.append(total)
             total += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        total = (total + int(total_multiple) - 1) // int(total_multiple) * int(total_multiple)
         self.total = total
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total if moments else 0, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total if moments else 0, dtype=torch.float32, device=dev)
         self.step_t = torch.zeros((), dtype=torch.float32, device=dev)
         self.sumsq = torch.zeros((), dtype=torch.float32, device=dev)
         self._ws = torch.empty(1024, dtype=torch.float32, device=dev)

@@ -308,6 +308,76 @@ def test_row_partitioned_training_step_equals_single_process():
     np.testing.assert_array_equal(results[0][1], results[1][1])
 
 
+# ---- the sharded optimiser (distributed.ShardedArenaStep): reduce-scatter -> norm -> clip + Adam on a piece -> all-gather -----
+def _torch_sumsq(g):
+    return (g.double() * g.double()).sum().float()
+
+
+def _torch_adam(lr=1e-2, b1=0.9, b2=0.999, eps=1e-8, max_norm=1.0):
+    """torch restatement of gv_adam_step (csrc/k_elem.hip k_adam): clip coefficient from the TOTAL sum of squares, torch.optim.Adam's update."""
+    def adam(p, g, m, v, total, step_t):
+        clip = torch.clamp(max_norm / (total.sqrt() + 1e-6), max=1.0)
+        gi = g * clip
+        m.mul_(b1).add_(gi, alpha=1 - b1)
+        v.mul_(b2).addcmul_(gi, gi, value=1 - b2)
+        t = float(step_t)
+        bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+        p.sub_((lr / bc1) * m / (v.sqrt() / (bc2 ** 0.5) + eps))
+    return adam
+
+
+def sharded_worker(rank, world, port, out_q, steps):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import gcn_vae_amd  # noqa: F401
+        from gcn_vae_amd import distributed as gdist
+        n = 64 * world * 3
+        gen = torch.Generator().manual_seed(0)
+        p0 = torch.randn(n, generator=gen)
+        flat_p, flat_g = p0.clone(), torch.zeros(n)
+        sh = gdist.ShardedArenaStep(flat_p, flat_g, _torch_sumsq, _torch_adam(), average=True)
+        assert sh.n == n // world and sh.m.numel() == n // world          # moments for the rank's piece only
+        for s in range(steps):
+            flat_g.copy_(torch.randn(n, generator=torch.Generator().manual_seed(100 * s + rank)) * (3.0 if s == 0 else 0.01))
+            sh.step()
+            assert float(flat_g.abs().max()) == 0.0                          # the step consumes the gradient arena
+        out_q.put((rank, flat_p.numpy().copy(), float(sh.total_sumsq)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_optimiser_equals_the_single_process_update():
+    """Two gloo ranks, each with its own gradient arena: after ShardedArenaStep.step() every rank holds the SAME parameters, and
+    they are the parameters one process gets from the averaged gradient with clip_grad_norm_ over the whole arena + Adam --
+    bit for bit (the pieces' updates are element-wise; the norm is a sum of two piece sums in both runs), with the clip active
+    (step 0: large gradients) and inactive (later steps)."""
+    world, steps = 2, 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=sharded_worker, args=(r, world, port, q, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process: the same arithmetic on the whole arena, the norm summed piece by piece as the ranks do
+    n = 64 * world * 3
+    p_ref = torch.randn(n, generator=torch.Generator().manual_seed(0))
+    m, v, adam = torch.zeros(n), torch.zeros(n), _torch_adam()
+    for s in range(steps):
+        gs = [torch.randn(n, generator=torch.Generator().manual_seed(100 * s + r)) * (3.0 if s == 0 else 0.01) for r in range(world)]
+        g = (gs[0] + gs[1]) * (1.0 / world)
+        total = _torch_sumsq(g[:n // 2]) + _torch_sumsq(g[n // 2:])
+        if s == 0:
+            assert float(total.sqrt()) > 1.0          # the clip is active in the first step
+        adam(p_ref, g, m, v, total, torch.tensor(float(s + 1)))
+    np.testing.assert_array_equal(results[0][1], results[1][1])
+    np.testing.assert_array_equal(results[0][1], p_ref.numpy())
+
+
 def _bench_env():
     env = dict(os.environ)
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'GV_DIST_BACKEND'):

@@ -906,6 +906,44 @@ def test_two_made_nodes_on_shared_weights_order_their_arena_writes(monkeypatch, 
         assert torch.equal(a, b) and torch.equal(a, c)
 
 
+def test_sharded_flat_adam_on_one_rank_equals_flat_adam():
+    """distributed.ShardedFlatAdam without a process group (one piece = the whole arena) against optim.FlatAdam on the same
+    gradients: identical bits while the clip is inactive (the update is element-wise), 1e-6 when it is active (the two sum the
+    squares in different orders); the gradient arena is consumed; snapshot / restore go through the piece's moments."""
+    from gcn_vae_amd import distributed as gdist
+    from gcn_vae_amd.optim import FlatAdam
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(37, 16), (16,), (200, 8), (5,)]
+    res = []
+    for make in (lambda ps: FlatAdam(ps, lr=1e-2, max_grad_norm=1.0), lambda ps: gdist.ShardedFlatAdam(ps, lr=1e-2, max_grad_norm=1.0)):
+        g2 = torch.Generator().manual_seed(4)
+        params = [torch.nn.Parameter(torch.randn(*sh, generator=g2).cuda()) for sh in shapes]
+        opt = make(params)
+        snap, outs = None, []
+        for step, scale in enumerate((1e-3, 1e-3, 5.0)):          # two steps under the clip threshold, one far above it
+            gs = torch.Generator().manual_seed(10 + step)
+            opt.zero_grad()
+            for p_ in params:
+                p_.grad.copy_(torch.randn(*p_.shape, generator=gs).cuda() * scale)
+            opt.step()
+            torch.cuda.synchronize()
+            assert float(opt.flat_g.abs().max()) == 0.0
+            outs.append([p_.detach().clone() for p_ in params])
+            if step == 0:
+                snap = opt.snapshot()
+        opt.restore(snap)
+        outs.append([p_.detach().clone() for p_ in params])
+        res.append(outs)
+        opt.close()
+    for step in (0, 1):
+        for a, b in zip(res[0][step], res[1][step]):
+            assert torch.equal(a, b)
+    for a, b in zip(res[0][2], res[1][2]):
+        torch.testing.assert_close(b, a, rtol=1e-6, atol=1e-7)
+    for a, b, c in zip(res[1][3], res[1][0], res[0][3]):
+        assert torch.equal(a, b) and torch.equal(a, c)
+
+
 @pytest.mark.parametrize('n_flows', [0, 2])
 def test_reference_validation_block_runs_unchanged_through_compat(tmp_path, n_flows):
     """kgvae/link_predict.py:239-261 replayed line for line on the aliases compat.install() registers: the reference moves its

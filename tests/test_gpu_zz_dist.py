@@ -37,7 +37,8 @@ def free_port():
                                    ['--no-graph', '--partition', 'row'], ['--partition', 'row'], [],
                                    ['--partition', 'row', '--n-flows', '1'], ['--partition', 'edge', '--n-flows', '1'],
                                    ['--graph-collectives', '--partition', 'edge'],
-                                   ['--partition', 'edge', '--n-flows', '1', '--gemm-precision', 'bf16']])
+                                   ['--partition', 'edge', '--n-flows', '1', '--gemm-precision', 'bf16'],
+                                   ['--partition', 'edge', '--sharded-adam'], ['--partition', 'row', '--sharded-adam']])
 def test_bench_single_rank_rccl(extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
@@ -56,6 +57,8 @@ def test_bench_single_rank_rccl(extra):
         assert d['config']['launch'].startswith('hipgraph segments'), d['config']['launch']
     if 'row' in extra:       # RCCL's all_gather_into_tensor / reduce_scatter_tensor on a 1-rank group
         assert d['config']['partition'] == 'row'
+    if '--sharded-adam' in extra:       # reduce-scatter of the gradient arena, update of the rank's piece, all-gather of the parameters
+        assert d['config']['optimizer'].startswith('sharded') and 0.3 < d['final_loss'] < 3.0
     assert d['final_loss'] == d['final_loss']          # not NaN
 
 
@@ -94,7 +97,9 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
 
 
 @pytest.mark.parametrize('extra', [['--scaling', 'strong', '--partition', 'edge'], ['--scaling', 'strong', '--partition', 'row'],
-                                   ['--config', 'c4', '--scaling', 'strong', '--partition', 'edge']])
+                                   ['--config', 'c4', '--scaling', 'strong', '--partition', 'edge'],
+                                   ['--scaling', 'strong', '--partition', 'edge', '--sharded-adam'],
+                                   ['--scaling', 'strong', '--partition', 'row', '--sharded-adam']])
 def test_bench_two_ranks_strong_scaling_one_graph(extra):
     """bench.py --scaling strong on two ranks sharing one GPU (gloo): ONE FB15k-237-shaped graph, its directed edges cut by
     relation range (or by destination row), its triplets dealt round-robin; value counts the one graph's edges once."""
