@@ -17,6 +17,8 @@
 //
 // Same arithmetic as gv_gemm_bf16_nt per product (operands rounded to bf16, k accumulated in 16-deep steps in order, fp32
 // accumulators, epilogue order bias -> ReLU -> mask -> stores): results are bit-identical to the launch-per-product path.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gv {
@@ -24,6 +26,15 @@ namespace gv {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
+#ifndef GV_CHAIN_ABL
+#define GV_CHAIN_ABL 0          /* compile-time ablation bits (probes): 256 no transposed stores, 512 no LDS tile, 1024 no sign words, 2048 no fragment loads */
+#endif
+#ifndef GV_CHAIN_FAST_EPILOGUE
+#define GV_CHAIN_FAST_EPILOGUE 1
+#endif
+#ifndef GV_CHAIN_LDS_BARRIER
+#define GV_CHAIN_LDS_BARRIER 0      /* measured: no gain at WN18RR size (5.57 vs 5.59 ms), the stand-alone fused chain 115 -> 123 us */
+#endif
 constexpr int CH_BM = 64;        // rows per workgroup
 constexpr int CH_KS = 13;        // 16-deep steps per register set of B fragments (208 of k)
 constexpr int CH_MMA_WAVES = 7, CH_STORE_WAVES = 1;      // 8 waves: two per SIMD, 256 VGPRs each
@@ -34,12 +45,28 @@ constexpr int CH_L = GV_CHAIN_MAX_LAYERS;
 struct ChainArgs {
     const uint16_t* x;           // [m][ldx] bf16: input of layer 0
     int ldx, m, n_layers, ldk, has_mask;
+    int32_t* stamps;             // gv_made_chain_debug_stamps: s_memtime stamps of workgroup 0 (probes only), NULL otherwise
     gv_chain_layer L[CH_L];
 };
 
 __device__ __forceinline__ uint16_t bf_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
 
 struct ChainUnit { int l, tile, ch; };
+
+// a kernel-argument field as an opaque SGPR value: read once where it is pinned, not re-read at every later use
+__device__ __forceinline__ int chain_pin(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T* chain_pin_ptr(T* q) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    typedef __attribute__((address_space(1))) T GT;         // (a pointer rebuilt from integers is generic: FLAT accesses otherwise)
+    return (T*)(GT*)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ void chain_barrier() {
+    if (GV_CHAIN_LDS_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+}
 
 // column tiles of a layer: 32 output columns each; an IAF layer's tile is 16 mu columns + their 16 alpha columns
 __device__ __forceinline__ int chain_tiles(const gv_chain_layer& L) { return L.iaf_z ? ((L.n >> 1) + 15) >> 4 : (L.n + 31) >> 5; }
@@ -289,6 +316,74 @@ __device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const g
     }
 }
 
+// The epilogue of a HIDDEN layer of the fused MADE chains, in its common case: every row of the workgroup exists, the
+// transposed copy goes out in 64-row tiles (t_tile), no fp32 output.  In-kernel stamps (tools/probes/chain_stamps.py) showed the
+// general epilogue above at 5 000-7 000 cycles per unit against 1 600 for the unit's MFMAs -- ~900 instructions, most of them
+// 64-bit address arithmetic, per-store predicates with a branch each and kernel-argument reloads between the stores.  Here the
+// lane's address into the tile is ONE 32-bit offset computed once per kernel (voff = 4 h * 64 + r), every one of the 32
+// transposed stores is base (scalar) + voff + an immediate, nothing is predicated per lane, and the layer's fields arrive as
+// values.  bits_row: this lane's row of ReLU mask words (backward layers), or nullptr.
+__device__ __forceinline__ void chain_epilogue_fast(const f32x16_t (&acc)[2], int n, int tile, int relu, uint16_t* An, int ldk, int kp_next,
+                                                    const float* bias_l, const uint32_t* bits_l, int nt_bits, uint16_t* tbase,
+                                                    uint32_t* obits, int ldbits, int r, int h) {
+    asm volatile("" : "+v"(r), "+v"(h));
+    uint32_t sb[2] = {0u, 0u};          // the signs of the lane's 16 columns of rows r / 32 + r, at their bit positions in the tile's word
+    const unsigned voff = (unsigned)(4 * h * 64 + r);
+    uint16_t* const tb = tbase + tile * 32 * 64;                 // column 32 tile of this workgroup's 64-row tile
+    uint32_t w0 = 0xffffffffu, w1 = 0xffffffffu;
+    if (bits_l) {
+        w0 = bits_l[r * nt_bits + tile] >> (4 * h);
+        w1 = bits_l[(32 + r) * nt_bits + tile] >> (4 * h);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c0u = tile * 32 + 8 * g;                       // widths are multiples of 8: both halves of a group are inside or outside
+        if (c0u >= n) {
+            if (c0u < kp_next) {                                  // the padding columns of the next layer's tile
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<uint2*>(An + (mt * 32 + r) * ldk + c0u + 4 * h) = make_uint2(0, 0);
+            }
+            continue;
+        }
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias_l) bv = *reinterpret_cast<const float4*>(bias_l + c0u + 4 * h);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float v[4] = {acc[mt][4 * g] + bv.x, acc[mt][4 * g + 1] + bv.y, acc[mt][4 * g + 2] + bv.z, acc[mt][4 * g + 3] + bv.w};
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            const uint32_t wb = (mt ? w1 : w0) >> (8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (!(wb & (1u << e))) v[e] = 0.f;
+            const uint16_t b0 = bf_bits(v[0]), b1 = bf_bits(v[1]), b2 = bf_bits(v[2]), b3 = bf_bits(v[3]);
+            if (!(GV_CHAIN_ABL & 512)) *reinterpret_cast<uint2*>(An + (mt * 32 + r) * ldk + c0u + 4 * h) = make_uint2(b0 | ((uint32_t)b1 << 16), b2 | ((uint32_t)b3 << 16));
+            uint16_t* o = tb + voff + g * 8 * 64 + mt * 32;
+            if (!(GV_CHAIN_ABL & 256)) {
+                o[0] = b0;
+                o[64] = b1;
+                o[128] = b2;
+                o[192] = b3;
+            }
+            sb[mt] |= (((int16_t)b0 > 0 ? 1u : 0u) | ((int16_t)b1 > 0 ? 2u : 0u) | ((int16_t)b2 > 0 ? 4u : 0u) | ((int16_t)b3 > 0 ? 8u : 0u)) << (8 * g + 4 * h);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (obits && !(GV_CHAIN_ABL & 1024)) {
+        // ReLU sign words (gv_chain_layer.out_bits) straight from the registers: a row's word is the OR of its two lanes (h = 0, 1);
+        // the store wave -- which used to rebuild the words from the LDS tile, 7 000 cycles per layer once the epilogues above had
+        // shrunk to 4 000 -- skips the layer
+        const int partner = (int)(((threadIdx.x & 63) ^ 32) << 2);
+        const uint32_t o0 = (uint32_t)__builtin_amdgcn_ds_bpermute(partner, (int)sb[0]), o1 = (uint32_t)__builtin_amdgcn_ds_bpermute(partner, (int)sb[1]);
+        if (h == 0) {
+            obits[(size_t)r * ldbits + tile] = sb[0] | o0;
+            obits[(size_t)(32 + r) * ldbits + tile] = sb[1] | o1;
+        }
+    }
+}
+
 // The IAF update in the last layer's epilogue (kgvae/flow_network.py:92-96): the layer's weight is packed so that a tile holds
 // 16 mu columns (accumulator groups 0, 1) and the SAME columns' alpha (groups 2, 3), so a lane has both halves of
 //   x_new[r][c] = colcount[c] > 0 ? z[r][c] * expf(alpha + mu) : x_old[r][c]
@@ -382,11 +477,102 @@ __device__ __forceinline__ void chain_epilogue_iaf(const f32x16_t (&acc)[2], con
     }
 }
 
+// The same update in its common case (every row of the workgroup exists, no [mu | alpha] output, transposed copy in 64-row tiles
+// or none): as chain_epilogue_fast, the lane's place in the [m][ld] fp32 operands is two 32-bit offsets computed once per unit
+// (rows r and 32 + r), every access is a pinned scalar base + that offset + an immediate, nothing is predicated per lane and the
+// layer's fields arrive as values.  Stamps: 12 000-18 000 cycles per unit with the general form above.  Same arithmetic, element
+// by element.
+struct ChainIafPins {
+    const float* z; const float* x_old; float* x_new; float* ex; float* alpha; const int* keep; uint16_t* tbase;
+    int ld, d, has_bias, identity;
+};
+__device__ __forceinline__ void chain_epilogue_iaf_fast(const f32x16_t (&acc)[2], const ChainIafPins& P, int tile, uint16_t* An, int ldk,
+                                                        int kp_next, const float* bias_l, const int* cnt_lds, int r, int h) {
+    asm volatile("" : "+v"(r), "+v"(h));
+    const int d = P.d, cu = tile * 16;                       // first mu column of the tile
+    const unsigned vo[2] = {(unsigned)(r * P.ld + 4 * h), (unsigned)((32 + r) * P.ld + 4 * h)};
+    const unsigned voff_t = (unsigned)(4 * h * 64 + r);
+    // z of the lane's four (group, row) pairs first, then x_old where a column is handed through: loads and stores share one
+    // in-order counter, a load issued behind the epilogue's stores waits for every one of them
+    float4 zp[4], xo[4];
+    int4 cn[2];
+    bool keep[2], pass[2], gv[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        gv[g] = cu + 8 * g < d;                              // (d % 8 == 0: both halves of a group are inside or outside)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            zp[2 * g + mt] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (gv[g] && !P.identity) zp[2 * g + mt] = *reinterpret_cast<const float4*>(P.z + cu + 8 * g + vo[mt]);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        cn[g] = gv[g] ? *reinterpret_cast<const int4*>(cnt_lds + cu + 8 * g + 4 * h) : make_int4(1, 1, 1, 1);
+        keep[g] = true;
+        if (P.keep && gv[g]) {
+            const int4 kc = *reinterpret_cast<const int4*>(P.keep + cu + 8 * g + 4 * h);
+            keep[g] = kc.x <= 0 || kc.y <= 0 || kc.z <= 0 || kc.w <= 0;
+        }
+        pass[g] = cn[g].x <= 0 || cn[g].y <= 0 || cn[g].z <= 0 || cn[g].w <= 0;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            xo[2 * g + mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pass[g]) xo[2 * g + mt] = *reinterpret_cast<const float4*>(P.x_old + cu + 8 * g + vo[mt]);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (!gv[g]) {
+            if (cu + 8 * g < kp_next) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<uint2*>(An + (mt * 32 + r) * ldk + cu + 8 * g + 4 * h) = make_uint2(0, 0);
+            }
+            continue;
+        }
+        float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bm = ba;
+        if (P.has_bias) {
+            ba = *reinterpret_cast<const float4*>(bias_l + d + cu + 8 * g + 4 * h);
+            bm = *reinterpret_cast<const float4*>(bias_l + cu + 8 * g + 4 * h);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float4 v = make_float4(acc[mt][4 * g + 8], acc[mt][4 * g + 9], acc[mt][4 * g + 10], acc[mt][4 * g + 11]);      // alpha
+            float4 s = make_float4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);            // mu
+            v.x += ba.x; v.y += ba.y; v.z += ba.z; v.w += ba.w;
+            s.x += bm.x; s.y += bm.y; s.z += bm.z; s.w += bm.w;
+            const unsigned e = vo[mt] + (unsigned)(cu + 8 * g);
+            if (P.alpha) *reinterpret_cast<float4*>(P.alpha + e) = v;
+            v.x = expf(v.x + s.x); v.y = expf(v.y + s.y); v.z = expf(v.z + s.z); v.w = expf(v.w + s.w);
+            if (P.ex) *reinterpret_cast<float4*>(P.ex + e) = v;
+            s = zp[2 * g + mt];
+            v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+            s = xo[2 * g + mt];
+            if (cn[g].x <= 0) v.x = s.x;
+            if (cn[g].y <= 0) v.y = s.y;
+            if (cn[g].z <= 0) v.z = s.z;
+            if (cn[g].w <= 0) v.w = s.w;
+            if (P.x_new && keep[g]) *reinterpret_cast<float4*>(P.x_new + e) = v;
+            const uint16_t b0 = bf_bits(v.x), b1 = bf_bits(v.y), b2 = bf_bits(v.z), b3 = bf_bits(v.w);
+            if (cu + 8 * g < kp_next)
+                *reinterpret_cast<uint2*>(An + (mt * 32 + r) * ldk + cu + 8 * g + 4 * h) = make_uint2(b0 | ((uint32_t)b1 << 16), b2 | ((uint32_t)b3 << 16));
+            if (P.tbase) {
+                uint16_t* o = P.tbase + (cu + 8 * g) * 64 + voff_t + mt * 32;
+                o[0] = b0;
+                o[64] = b1;
+                o[128] = b2;
+                o[192] = b3;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // store wave: the row-major bf16 copy of a layer's result out of its LDS tile, 16-B pieces, reads issued in batches of 8.
 // (row, piece) advance incrementally: an integer division per piece would cost this single wave more than the copy itself
 template <bool FULL>
-__device__ __forceinline__ void chain_store(const gv_chain_layer& Ly, const uint16_t* An, int ldk, int m0, int m, int ts) {
-    if (!FULL && Ly.out_bits) {       // sign bits of the layer's (bf16-rounded) result, word [row][tile of 32 columns], out of the finished tile
+__device__ __forceinline__ void chain_store(const gv_chain_layer& Ly, const uint16_t* An, int ldk, int m0, int m, int ts, bool bits_done) {
+    if (!FULL && Ly.out_bits && !bits_done) {       // sign bits of the layer's (bf16-rounded) result, word [row][tile of 32 columns], out of the finished tile
         const int nt = (Ly.n + 31) >> 5;
         for (int i = ts; i < CH_BM * nt; i += CH_STORE_THREADS) {
             const int row = i / nt, t = i - row * nt;
@@ -447,6 +633,15 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
     const bool mma_wave = wave < CH_MMA_WAVES;
+    int ts_n = 0;
+    auto stamp = [&]() {
+        if (p.stamps && blockIdx.x == 0 && ts_n < 64) {
+            const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
+            if (lane == 0) p.stamps[wave * 64 + ts_n] = (int32_t)t;
+            ++ts_n;
+        }
+    };
+    stamp();
 
     // the first B fragments of an MMA wave are requested before anything else
     uint4 qa[CH_KS];
@@ -524,16 +719,20 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     f32x16_t acc[2];
     int layer = 0, bias_off = 0, bits_off = 0;
 
-    // cross layer boundaries until this wave stands in layer `target` (nl: past the last layer)
+    // cross layer boundaries until this wave stands in layer `target` (nl: past the last layer).  The boundary orders LDS traffic
+    // only (chain_barrier): __syncthreads() also drains the vector-memory counter -- every transposed 2-B store, sign-bit word and
+    // fp32 output of the epilogue acknowledged, the next unit's 13 weight fragments landed -- a microsecond per layer and tile
 #define CHAIN_CROSS(target)                                                                                              \
     while (layer < (target)) {                                                                                          \
-        __syncthreads();                                                                                                \
+        chain_barrier();                                                                                                \
         if (FULL && layer + 1 < nl && (p.L[layer + 1].mask || p.L[layer + 1].mask_t)) {                                 \
             chain_stage_mask(mbuf, ldk, p.L[layer + 1], m0, p.m);                                                       \
             __syncthreads();                                                                                            \
         }                                                                                                               \
         if (!mma_wave && (layer + 1 < nl || p.L[layer].iaf_z))                                                          \
-            chain_store<FULL>(p.L[layer], chain_lds + ((layer + 1) & 1) * CH_BM * ldk, ldk, m0, p.m, (int)threadIdx.x - CH_MMA_THREADS); \
+            chain_store<FULL>(p.L[layer], chain_lds + ((layer + 1) & 1) * CH_BM * ldk, ldk, m0, p.m, (int)threadIdx.x - CH_MMA_THREADS, \
+                              !FULL && GV_CHAIN_FAST_EPILOGUE && layer + 1 < nl && m0 + CH_BM <= p.m && p.L[layer].out_bf16_t && \
+                              p.L[layer].t_tile > 0 && !p.L[layer].out_f32 && !p.L[layer].add_src && !p.L[layer].iaf_z);  \
         bias_off += p.L[layer].n;                                                                                       \
         bits_off += p.L[layer].mask_bits ? CH_BM * ((p.L[layer].n + 31) >> 5) : 0;                                      \
         ++layer;                                                                                                        \
@@ -549,7 +748,9 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         unsigned noff = lane;                                                                                           \
         int nksc = 1;                                                                                                   \
         if (nu.l < nl) chain_unit_b(p, nu, lane, nb0, noff, nksc);                                                      \
+        stamp();                                                                                                        \
         chain_landed(Q, noff);                                                                                          \
+        stamp();                                                                                                        \
         if (u.ch == 0) {                                                                                                \
             _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;                                 \
         }                                                                                                               \
@@ -557,25 +758,57 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         int ra = r, ha = h;        /* opaque: a hoisted fragment address is one more register held across the whole loop */ \
         asm volatile("" : "+v"(ra), "+v"(ha));                                                                          \
         chain_mma(acc, Q, A + ra * ldk + 8 * ha + u.ch * CH_KS * 16, 32 * ldk, min(CH_KS, ks - u.ch * CH_KS));          \
+        stamp();                                                                                                        \
         const bool iaf_unit = Ly.iaf_z && u.ch + 1 == nch;                                                              \
-        if (iaf_unit)                                                                                                   \
+        if (iaf_unit) {                                                                                                 \
+            const bool fast_iaf = GV_CHAIN_FAST_EPILOGUE && m0 + CH_BM <= p.m && !Ly.out_f32 && !(Ly.iaf_reserved & ~1) &&  \
+                                  (!Ly.out_bf16_t || Ly.t_tile > 0);                                                    \
+            if (fast_iaf) {                                                                                             \
+                ChainIafPins P;                                                                                         \
+                P.ld = chain_pin(Ly.iaf_ld); P.d = chain_pin(Ly.n) >> 1; P.has_bias = Ly.bias ? 1 : 0; P.identity = chain_pin(Ly.iaf_reserved) & 1; \
+                const size_t row0 = (size_t)m0 * P.ld;                                                                  \
+                P.z = chain_pin_ptr(Ly.iaf_z) + row0; P.x_old = chain_pin_ptr(Ly.iaf_x_old) + row0;                     \
+                P.x_new = Ly.iaf_x_new ? chain_pin_ptr(Ly.iaf_x_new) + row0 : nullptr;                                  \
+                P.ex = Ly.iaf_ex ? chain_pin_ptr(Ly.iaf_ex) + row0 : nullptr;                                           \
+                P.alpha = Ly.iaf_alpha ? chain_pin_ptr(Ly.iaf_alpha) + row0 : nullptr;                                  \
+                P.keep = Ly.iaf_keep_colcount ? chain_pin_ptr(Ly.iaf_keep_colcount) : nullptr;                          \
+                P.tbase = Ly.out_bf16_t ? chain_pin_ptr(Ly.out_bf16_t) + (size_t)blockIdx.x * chain_pin(Ly.t_tile) : nullptr; \
+                chain_epilogue_iaf_fast(acc, P, u.tile, chain_lds + ((u.l + 1) & 1) * CH_BM * ldk, ldk,                 \
+                                        Ly.out_bf16 ? (P.d + 15) & ~15 : 0, bias_lds + bias_off,                        \
+                                        reinterpret_cast<const int*>(bias_lds + bias_total), r, h);                     \
+            } else                                                                                                      \
             chain_epilogue_iaf(acc, Ly, u.tile, m0, p.m, chain_lds + ((u.l + 1) & 1) * CH_BM * ldk, ldk,                \
                                Ly.out_bf16 ? ((Ly.n >> 1) + 15) & ~15 : 0, bias_lds + bias_off,                         \
                                reinterpret_cast<const int*>(bias_lds + bias_total), r, h);                              \
-        chain_issue(Q, nb0, noff, nksc);                                                                                \
-        if (u.ch + 1 == nch && !iaf_unit)                                                                               \
+        }                                                                                                               \
+        if (!(GV_CHAIN_ABL & 2048)) chain_issue(Q, nb0, noff, nksc);                                                    \
+        if (u.ch + 1 == nch && !iaf_unit) {                                                                             \
+            /* the common hidden layer of the fused chains (FULL == false): every row exists, transposed copy in 64-row tiles */ \
+            const bool fast = !FULL && GV_CHAIN_FAST_EPILOGUE && u.l + 1 < nl && m0 + CH_BM <= p.m && Ly.out_bf16_t && Ly.t_tile > 0 && \
+                              !Ly.out_f32 && !Ly.add_src;                                                               \
+            if (fast)                                                                                                   \
+                chain_epilogue_fast(acc, chain_pin(Ly.n), u.tile, chain_pin(Ly.relu), chain_lds + ((u.l + 1) & 1) * CH_BM * ldk, ldk, \
+                                    (chain_pin(Ly.n) + 15) & ~15, Ly.bias ? bias_lds + bias_off : nullptr,              \
+                                    Ly.mask_bits ? reinterpret_cast<const uint32_t*>(bias_lds + bits_base) + bits_off : nullptr, \
+                                    (chain_pin(Ly.n) + 31) >> 5, chain_pin_ptr(Ly.out_bf16_t) + (size_t)blockIdx.x * chain_pin(Ly.t_tile), \
+                                    Ly.out_bits ? chain_pin_ptr(Ly.out_bits) + (size_t)m0 * chain_pin(Ly.ldbits) : nullptr, chain_pin(Ly.ldbits), r, h); \
+            else                                                                                                        \
             chain_epilogue<FULL>(acc, Ly, u.tile, m0, p.m, chain_lds + ((u.l + 1) & 1) * CH_BM * ldk, ldk,              \
                            u.l + 1 < nl ? (Ly.n + 15) & ~15 : 0, mbuf, bias_lds + bias_off,                             \
                            reinterpret_cast<const int*>(bias_lds + bias_total),                                         \
                            reinterpret_cast<const uint32_t*>(bias_lds + bits_base) + bits_off, r, h);                   \
+        }                                                                                                               \
+        stamp();                                                                                                        \
         u = nu;                                                                                                         \
     }
 
+    stamp();
     for (;;) {
         CHAIN_CROSS(u.l)
         if (u.l >= nl) break;
         CHAIN_UNIT1(qa)
     }
+    stamp();
 #undef CHAIN_CROSS
 #undef CHAIN_UNIT1
 }
@@ -705,6 +938,14 @@ static int chain_ldk(int n_layers, const gv_chain_layer* layers, bool* has_mask)
     return ldk;
 }
 
+static int32_t* g_chain_stamps = nullptr;
+/* probes only: 8 x 64 int32 that workgroup 0's waves fill with s_memtime stamps (start; per unit: before / after the fragment
+ * fence, after the MFMAs, after the epilogue; end); NULL switches it off */
+extern "C" int gv_made_chain_debug_stamps(int32_t* buffer) {
+    g_chain_stamps = buffer;
+    return GV_OK;
+}
+
 extern "C" int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, void* stream) {
     GV_REQUIRE(m >= 0 && n_layers >= 1 && n_layers <= GV_CHAIN_MAX_LAYERS, GV_ERR_SHAPE, "gv_made_chain: m=%d n_layers=%d", m, n_layers);
     if (m == 0) return GV_OK;
@@ -753,7 +994,7 @@ extern "C" int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, co
         if (layers[i].mask_bits) bias_floats += (size_t)CH_BM * ((layers[i].n + 31) / 32);      // its bit tile
     const size_t lds = (size_t)(has_mask ? 3 : 2) * CH_BM * ldk * sizeof(uint16_t) + bias_floats * sizeof(float);
     GV_REQUIRE(lds <= 160 * 1024, GV_ERR_SHAPE, "gv_made_chain: layers this wide need %zu B of LDS (160 KB per CU)", lds);
-    p.x = x; p.ldx = ldx; p.m = m; p.n_layers = n_layers; p.ldk = ldk; p.has_mask = has_mask ? 1 : 0;
+    p.x = x; p.ldx = ldx; p.m = m; p.n_layers = n_layers; p.ldk = ldk; p.has_mask = has_mask ? 1 : 0; p.stamps = g_chain_stamps;
     bool full = false, bits = false;
     for (int i = 0; i < n_layers; ++i) {
         full = full || layers[i].mask || layers[i].mask_t || layers[i].accumulate;

@@ -323,6 +323,9 @@ int gv_made_pack_weight_multi_iaf(int count, const float* const* w, const int32_
                                   uint16_t* const* packed_fwd, uint16_t* const* packed_bwd, void* stream);
 int gv_made_chain_fits(int n_layers, const int32_t* n_of_layer, const int32_t* k_of_layer, int any_mask);
 int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, void* stream);
+/* probes only: a device buffer of 8 x 64 int32 that workgroup 0's waves of the following gv_made_chain launches fill with
+ * s_memtime stamps (tools/probes/chain_stamps.py); NULL (the default) switches it off */
+int gv_made_chain_debug_stamps(int32_t* buffer);
 /* ---------------------------------------------------------------------------------------------
  * K4 fused in fp32 (the reference's own precision, kgvae/README.md:4-7): the same chain on v_mfma_f32_32x32x2_f32, fp32
  * activations in LDS, walking only the parts of the masked weights (kgvae/flow_network.py:65-83: lower-triangular blocks) that
