@@ -253,6 +253,35 @@ __global__ __launch_bounds__(256) void k_rowsum(const float* x, int ld, int col0
     }
 }
 
+// flow_log_prob = mean over the rows that exist of the sum of the IAF blocks' per-row log-determinants (kgvae/model.py:116-123:
+// log_det_sum = sum_flows log_det; flow_log_prob = mean(log_det_sum)).  ONE 1 024-thread workgroup, ordered: thread t adds its rows
+// r = t, t + 1024, ... (per row the blocks in order), the 1 024 partials are added in a fixed tree.  rows_dev (optional): only
+// the first *rows_dev of the n rows exist (static-shape batch); the mean divides by that count.
+struct MeanRowsArgs { const float* x[8]; int count; };
+__global__ __launch_bounds__(1024) void k_mean_rows_multi(const MeanRowsArgs a, int64_t n, const int* rows_dev, float* out) {
+    __shared__ float sm[1024];
+    const int64_t live = rows_dev ? min((int64_t)*rows_dev, n) : n;
+    float acc = 0.f;
+    for (int64_t r = threadIdx.x; r < live; r += 1024) {
+        float s = 0.f;
+        for (int i = 0; i < a.count; ++i) s += a.x[i][r];
+        acc += s;
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sm[0] / (float)live;
+}
+// its backward: every block's per-row gradient is the same vector  g / rows  on the rows that exist, 0 on the padding rows
+__global__ __launch_bounds__(256) void k_mean_rows_bwd(const float* g, int64_t len, int64_t n, const int* rows_dev, float* out) {
+    const int64_t live = rows_dev ? min((int64_t)*rows_dev, n) : n;
+    const float v = *g / (float)live;
+    GV_GRID_STRIDE(i, len) out[i] = i < live ? v : 0.f;
+}
+
 __global__ __launch_bounds__(256) void k_reverse_cols(const float* x, float* out, int64_t n, int d) {
     const int64_t total = n * d;
     GV_GRID_STRIDE(i, total) {
@@ -556,6 +585,22 @@ extern "C" int gv_rowsum(const float* x, int ld, int col0, int ncols, float* out
     if (n <= 0) return GV_OK;
     hipLaunchKernelGGL(k_rowsum, dim3(grid_for(n, 4)), dim3(256), 0, GV_ST, x, ld, col0, ncols, out, n);
     return launch_status("gv_rowsum");
+}
+
+extern "C" int gv_mean_rows_multi(int count, const float* const* x, int64_t n, const int32_t* rows_dev, float* out, void* stream) {
+    GV_REQUIRE(count >= 1 && count <= 8 && x && out && n > 0, GV_ERR_SHAPE, "gv_mean_rows_multi: count=%d n=%lld", count, (long long)n);
+    MeanRowsArgs a;
+    a.count = count;
+    for (int i = 0; i < 8; ++i) a.x[i] = i < count ? x[i] : nullptr;
+    for (int i = 0; i < count; ++i) GV_REQUIRE(x[i], GV_ERR_NULL, "gv_mean_rows_multi: NULL vector %d", i);
+    hipLaunchKernelGGL(k_mean_rows_multi, dim3(1), dim3(1024), 0, GV_ST, a, n, rows_dev, out);
+    return launch_status("gv_mean_rows_multi");
+}
+
+extern "C" int gv_mean_rows_bwd(const float* g, int64_t len, int64_t n, const int32_t* rows_dev, float* out, void* stream) {
+    GV_REQUIRE(g && out && n > 0 && len >= n, GV_ERR_NULL, "gv_mean_rows_bwd: NULL pointer / len < n");
+    hipLaunchKernelGGL(k_mean_rows_bwd, dim3(grid_for(len, 1024)), dim3(256), 0, GV_ST, g, len, n, rows_dev, out);
+    return launch_status("gv_mean_rows_bwd");
 }
 
 extern "C" int gv_reverse_cols(const float* x, float* out, int64_t n, int d, void* stream) {

@@ -192,20 +192,26 @@ class KGVAE(ops.StayOnDevice, nn.Module):
         self.z_own = z
         return AllGatherRows.apply(ops.pad_rows(z, part.slot_rows), part)
 
-    def _apply_flows(self, z):
+    def _apply_flows(self, z, want_mean=False):
         """The IAF stack on the rows of z (kgvae/model.py:116-123); get_mmd's prior rows ride along when announced.
         Returns (z after the flows, per-row sum of the MADE log-determinants)."""
         n = z.shape[0]
         ride_along = self.batch_mmd_prior_with_forward and self.training
         if ride_along:
             z = ops.cat_rows(z, self._prior_draw(z.device, z.dtype))      # (kernel copies: no memcpy node in a captured step)
-        log_det_sum = None
+        log_dets = []
         for flow in self.nf:
             z, log_det = flow.forward(z)
             if isinstance(flow, MADE):            # PermuteLayer contributes zeros
-                log_det_sum = log_det if log_det_sum is None else log_det_sum + log_det
+                log_dets.append(log_det)
         if ride_along:      # (ops.split_rows: the slices' backward without a memcpy node in a captured step)
             z, self._z_pri_flowed = ops.split_rows(z, n)
+        if want_mean and 1 <= len(log_dets) <= 8:     # flow_log_prob in ONE launch (and one in backward) instead of adds + mask + sum + divide
+            return z, ops.mean_rows_multi(log_dets, n=n, rows_dev=self.rows_dev)
+        log_det_sum = None
+        for log_det in log_dets:
+            log_det_sum = log_det if log_det_sum is None else log_det_sum + log_det
+        if ride_along:
             log_det_sum = ops.split_rows(log_det_sum, n)[0]
         return z, log_det_sum
 
@@ -228,14 +234,17 @@ class KGVAE(ops.StayOnDevice, nn.Module):
         z, self.z_mean, self.z_sigma = ops.reparam(h, eps, self.z_pre.squeeze(0) if fuse_kl else None)
         self._z_pri_flowed = None
         if self.n_flows > 0:
-            z, log_det_sum = self._apply_flows(z)
+            # flow_log_prob = mean over the rows that exist (a static-shape batch: the device count) of the blocks' summed log-dets
+            z, self.flow_log_prob = self._apply_flows(z, want_mean=True)
             ops.made_prepare_finish()
-            if self.rows_dev is None:
-                self.flow_log_prob = torch.mean(log_det_sum.view(-1, 1))
-            else:       # static-shape batch: the mean runs over the rows that exist (device count), padding rows masked out
-                rows = self.rows_dev.reshape(()).to(log_det_sum.dtype)
-                live = torch.arange(log_det_sum.numel(), device=log_det_sum.device) < self.rows_dev.reshape(())
-                self.flow_log_prob = (log_det_sum.reshape(-1) * live).sum() / rows
+            if self.flow_log_prob.dim() != 0:       # (more than 8 blocks: the per-row sum came back)
+                log_det_sum = self.flow_log_prob
+                if self.rows_dev is None:
+                    self.flow_log_prob = torch.mean(log_det_sum.view(-1, 1))
+                else:
+                    rows = self.rows_dev.reshape(()).to(log_det_sum.dtype)
+                    live = torch.arange(log_det_sum.numel(), device=log_det_sum.device) < self.rows_dev.reshape(())
+                    self.flow_log_prob = (log_det_sum.reshape(-1) * live).sum() / rows
         return z
 
 

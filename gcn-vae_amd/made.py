@@ -23,6 +23,17 @@ from .ops import (ACT_NONE, ACT_RELU, GRAD_FRESH, _chk, _direct, _process_group,
                   backward_side, colsum, gemm, iaf_bwd_row0, masked_weight, mul_multi, pick_split_k)
 
 
+_zero_rows = {}
+
+
+def _zero_row(d, device):
+    """One read-only all-zero row (1, d) per device and width: pass 0's input (not a fill per call)."""
+    key = (device, int(d))
+    if key not in _zero_rows:
+        _zero_rows[key] = torch.zeros(1, int(d), dtype=torch.float32, device=device)
+    return _zero_rows[key]
+
+
 class _MADEForward(torch.autograd.Function):
     """MADE.forward (kgvae/flow_network.py:85-98) as ONE autograd node.
 
@@ -64,7 +75,7 @@ class _MADEForward(torch.autograd.Function):
         acts = [torch.empty(max(S, 1) * n, ws[l].shape[0], **f32) for l in range(L)]   # acts[L-1] = [mu | alpha]
         x_out = torch.empty(n, d, **f32)
         # pass 0 on a single zero row: one single-workgroup launch (exact fp32 operands) where the widths allow, else a launch per product
-        zero_row = torch.zeros(1, d, **f32)
+        zero_row = _zero_row(d, z.device)
         row = (MADE_ROW_F32 and L <= 8 and d <= 512 and max(w.shape[0] for w in ws) <= 512 and all(w.shape[1] % 4 == 0 for w in ws))
         if row:
             acts0 = [torch.empty(1, w.shape[0], **f32) for w in ws]
@@ -135,8 +146,9 @@ class _MADEForward(torch.autograd.Function):
         gx = torch.zeros(n, d, **f32) if gx is None else _chk(gx.contiguous(), name='gx')
         gld = None if gld is None else _chk(gld.contiguous(), name='gld')
         grads = [torch.empty(max(S, 1) * n, ws[l].shape[0], **f32) for l in range(L)]   # grad w.r.t. each layer's OUTPUT
-        g_z = torch.zeros(n, d, **f32)
-        gz_p = torch.empty(n, d, **f32)
+        acc_gz = d % 4 == 0 and P > 1                             # the update's backward adds dL/dz in place; the first pass run WRITES it
+        g_z = torch.empty(n, d, **f32) if acc_gz else torch.zeros(n, d, **f32)
+        gz_p = None if acc_gz else torch.empty(n, d, **f32)
         g_olds = {p: torch.empty(n, d, **f32) for p in range(1, P)}      # dL/dx_old of every pass (allocated before any fork)
 
         def passes(r0, r1):      # the backward of passes P-1 .. 1 for the rows [r0, r1): every launch is row-local
@@ -146,7 +158,8 @@ class _MADEForward(torch.autograd.Function):
                 g_old = g_olds[p][r0:r1]
                 if d % 4 == 0:       # dL/dz of the pass added to the running sum by the same launch
                     lib.call('gv_iaf_update_bwd_acc', ptr(z[r0:r1]), ptr(acts[L - 1][a:b]), 2 * d, ptr(colcount[p]), ptr(g_in[r0:r1]),
-                             ptr(gld[r0:r1]) if (p == P - 1 and gld is not None) else None, ptr(g_z[r0:r1]), 1, ptr(grads[L - 1][a:b]),
+                             ptr(gld[r0:r1]) if (p == P - 1 and gld is not None) else None, ptr(g_z[r0:r1]), 0 if p == P - 1 else 1,
+                             ptr(grads[L - 1][a:b]),
                              ptr(g_old), m, d, lib.stream())
                 else:
                     lib.call('gv_iaf_update_bwd', ptr(z[r0:r1]), ptr(acts[L - 1][a:b]), 2 * d, ptr(colcount[p]), ptr(g_in[r0:r1]),
@@ -666,7 +679,7 @@ def _made_params_work(masks, ws, bs, d, S):
         for w, a_, t_ in zip(ws, wbf, wbt):
             cast_bf16(w, a_, t_)
     # pass 0 on a single zero row (tiny: the generic GEMM with bf16-rounded operands)
-    zero_row = torch.zeros(1, d, **f32)
+    zero_row = _zero_row(d, dev)
     row = MADE_ROW and L <= 8 and d <= 512 and max(widths) <= 512 and all(w.shape[1] % 4 == 0 for w in ws)
     if row:         # one single-workgroup launch for the whole row
         acts0 = [torch.empty(1, widths[l], **f32) for l in range(L)]

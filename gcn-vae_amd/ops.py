@@ -1675,6 +1675,39 @@ def rowsum_cols(x, col0, ncols):
     return _RowSumCols.apply(x, col0, ncols)
 
 
+class _MeanRowsMulti(torch.autograd.Function):
+    """mean over the rows that exist of the sum of up to 8 per-row vectors: KGVAE.flow_log_prob (kgvae/model.py:116-123) in one
+    launch instead of adds + mask + sum + divide through torch; backward: one launch, the same gradient vector for every input.
+    Only the first ``n`` entries of the vectors take part (rows riding along behind them -- get_mmd's prior rows -- get zero)."""
+
+    @staticmethod
+    def forward(ctx, rows_dev, n, *xs):
+        xs = [_chk(x.contiguous().reshape(-1), name='log_det') for x in xs]
+        length = xs[0].numel()
+        if any(x.numel() != length for x in xs) or not 0 < n <= length:
+            raise ValueError('mean_rows_multi: vectors of one length >= n')
+        out = torch.empty((), dtype=torch.float32, device=xs[0].device)
+        tab = (_ct.c_void_p * len(xs))(*[ptr(x) for x in xs])
+        lib.call('gv_mean_rows_multi', len(xs), _ct.addressof(tab), n, ptr(rows_dev), ptr(out), lib.stream())
+        ctx.rows_dev, ctx.n, ctx.len, ctx.k = rows_dev, n, length, len(xs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _chk(g.contiguous().reshape(()), name='g')
+        gx = torch.empty(ctx.len, dtype=torch.float32, device=g.device)
+        lib.call('gv_mean_rows_bwd', ptr(g), ctx.len, ctx.n, ptr(ctx.rows_dev), ptr(gx), lib.stream())
+        return (None, None) + (gx,) * ctx.k
+
+
+def mean_rows_multi(xs, n=None, rows_dev=None):
+    """mean_r sum_i xs[i][r] over the first n rows (None: all) that exist (rows_dev: device int32 count, None = all n)."""
+    xs = list(xs)
+    if not 1 <= len(xs) <= 8:
+        raise ValueError('mean_rows_multi: 1..8 vectors')
+    return _MeanRowsMulti.apply(rows_dev, int(xs[0].numel() if n is None else n), *xs)
+
+
 class _ReverseCols(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
