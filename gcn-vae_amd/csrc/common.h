@@ -31,6 +31,44 @@ inline int launch_status(const char* what) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: a process that drives several devices has to raise it on
+// each one.  `done` is the call site's own bit mask (bit d = raised on device d); returns false -- with the library's error text
+// set -- when the attribute cannot be raised (the launch that follows would fail with a less telling message).
+inline bool raise_dynamic_lds(const void* kernel, int bytes, unsigned long long& done, const char* who) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) {
+        (void)hipGetLastError();
+        dev = 0;
+    }
+    if (done >> dev & 1ull) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("%s: cannot raise the dynamic LDS limit to %d B on device %d", who, bytes, dev);
+        return false;
+    }
+    done |= 1ull << dev;
+    return true;
+}
+
+// multiprocessor count of the CURRENT device (cached per device)
+inline int current_device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    if (!cus[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus[dev] = v;
+        else {
+            (void)hipGetLastError();
+            cus[dev] = 256;
+        }
+    }
+    return cus[dev];
+}
+
 // ---- device helpers -------------------------------------------------------------------------
 // Cross-lane reductions on the VALU's DPP path (no LDS-crossbar ds_bpermute round trips): two quad permutes, then
 // row_half_mirror and row_mirror leave every lane with the sum of its row of 16; the four row sums are read with

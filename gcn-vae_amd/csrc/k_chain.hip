@@ -1001,16 +1001,10 @@ extern "C" int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, co
         bits = bits || layers[i].mask_bits || layers[i].out_bits;
     }
     GV_REQUIRE(!(full && bits), GV_ERR_SHAPE, "gv_made_chain: mask bits do not combine with tile masks or an accumulating output in one chain");
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_made_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_made_chain<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("gv_made_chain: cannot raise the dynamic LDS limit");
-            return GV_ERR_SHAPE;
-        }
-        attr_set = true;
-    }
+    static unsigned long long lds_full = 0, lds_lean = 0;
+    if (!raise_dynamic_lds((const void*)k_made_chain<true>, 160 * 1024, lds_full, "gv_made_chain") ||
+        !raise_dynamic_lds((const void*)k_made_chain<false>, 160 * 1024, lds_lean, "gv_made_chain"))
+        return GV_ERR_SHAPE;
     const dim3 grid((unsigned)((m + CH_BM - 1) / CH_BM));
     if (full) hipLaunchKernelGGL(k_made_chain<true>, grid, dim3(CH_THREADS), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(k_made_chain<false>, grid, dim3(CH_THREADS), lds, (hipStream_t)stream, p);

@@ -41,6 +41,12 @@ constexpr int C32_THREADS = C32_WAVES * 64;
 constexpr int C32_L = GV_CHAIN_MAX_LAYERS;
 constexpr int C32_MAXT = GV_CHAIN32_MAX_TILES;            // column tiles per layer (n <= 512)
 constexpr int C32_MAXU = C32_L * C32_MAXT;                // units per list
+#ifndef GV_C32_SPLIT
+#define GV_C32_SPLIT 0          /* 1: the two waves of a SIMD share every unit -- rows 0..31 / 32..63 -- instead of alternating units.
+                                 * Measured WORSE (76 -> 92 us per pass): one accumulator per wave = two dependent MFMA chains per
+                                 * SIMD, ~780 cycles per pair of groups instead of 512; the alternating form has four chains in
+                                 * flight while both waves compute and two (620-670 cycles per group) while one runs alone. */
+#endif
 constexpr int C32_CHG = 25;         // groups per register set of weight fragments (200 of k: a 200-wide layer's unit is ONE chunk)
 // plan words: [0, 4) units per list; then 4 lists of C32_MAXU (layer << 8 | tile); then [layer][tile] group sets (lo, hi)
 constexpr int C32_PLAN_LISTS = 4, C32_PLAN_SETS = C32_PLAN_LISTS + C32_LISTS * C32_MAXU;
@@ -129,13 +135,13 @@ __device__ __forceinline__ unsigned long long c32_mma(f32x16c& acc0, f32x16c& ac
                 n1 = *reinterpret_cast<const float4*>(a_hi + 8 * g);
             }
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, q[i].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, q[i].x, acc1, 0, 0, 0);
+            if (!GV_C32_SPLIT) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, q[i].x, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, q[i].y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, q[i].y, acc1, 0, 0, 0);
+            if (!GV_C32_SPLIT) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, q[i].y, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, q[i].z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, q[i].z, acc1, 0, 0, 0);
+            if (!GV_C32_SPLIT) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, q[i].z, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, q[i].w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, q[i].w, acc1, 0, 0, 0);
+            if (!GV_C32_SPLIT) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, q[i].w, acc1, 0, 0, 0);
             a0 = n0;
             a1 = n1;
             __builtin_amdgcn_sched_barrier(0);
@@ -176,7 +182,7 @@ __device__ __forceinline__ C32Layer c32_layer(const gv_chain32_layer& L) {
 // stores in flight it costs a store round trip per batch of eight rows (measured: 10 000 cycles per epilogue instead of ~1 000).
 template <bool LOADS>
 __device__ __forceinline__ void c32_epilogue(const f32x16c& acc0, const f32x16c& acc1, const C32Layer& Ly, int tile, int m0, int m,
-                                             float* An, int ldn, const float* bias_l, int l31, int lhi, int debug) {
+                                             float* An, int ldn, const float* bias_l, int l31, int lhi, int debug, int half) {
     // opaque copies: without them the compiler hoists the per-row 64-bit offsets out of the unit loop and spills them
     int le = l31, he = lhi;
     asm volatile("" : "+v"(le), "+v"(he));
@@ -197,8 +203,9 @@ __device__ __forceinline__ void c32_epilogue(const f32x16c& acc0, const f32x16c&
     const bool full = m0 + C32_BM <= m && tile * 32 + 32 <= Ly.n;         // (wave-uniform) every element of the unit exists
     // eight rows at a time: the next unit's fragments (100 registers) may be in flight through all of this
 #pragma unroll
-    for (int mh = 0; mh < 4; ++mh) {
-        const int mt = mh >> 1, r0 = (mh & 1) * 8;
+    for (int mh = 0; mh < (GV_C32_SPLIT ? 2 : 4); ++mh) {
+        // (split: this wave's accumulator holds rows 32 half .. 32 half + 31 of the tile)
+        const int mt = GV_C32_SPLIT ? half : mh >> 1, r0 = (mh & 1) * 8;
         float mk[8], old[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) mk[j] = 1.f, old[j] = 0.f;
@@ -235,7 +242,7 @@ __device__ __forceinline__ void c32_epilogue(const f32x16c& acc0, const f32x16c&
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float t = (mt ? acc1[r0 + j] : acc0[r0 + j]) + bv;
+            float t = ((!GV_C32_SPLIT && mt) ? acc1[r0 + j] : acc0[r0 + j]) + bv;
             if (Ly.relu) t = fmaxf(t, 0.f);
             if (masked) t = mk[j] > 0.f ? t : 0.f;
             v[j] = t;
@@ -353,7 +360,8 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
         }
     };
 
-    C32Unit cu = {wave >> 2, 0, 0, 0ull};
+    const int half = wave >> 2;
+    C32Unit cu = {GV_C32_SPLIT ? 0 : half, 0, 0, 0ull};
     c32_open(plan, nl, list, nu, cu);
     float4 q[C32_CHG];
     {
@@ -387,14 +395,14 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
         for (;;) {
             c32_landed(q, off);
             if (p.debug & 4) left = 0ull;
-            else left = c32_mma(acc0, acc1, q, A + ra * lda + 4 * ha, A + (32 + ra) * lda + 4 * ha, left);
+            else left = c32_mma(acc0, acc1, q, A + ((GV_C32_SPLIT ? 32 * half : 0) + ra) * lda + 4 * ha, A + (32 + ra) * lda + 4 * ha, left);
             if (left == 0ull) break;
             c32_issue(q, b0, off, left);          // a unit of more than C32_CHG groups: its next chunk
         }
         // the wave's next unit: its fragments are requested now and land during the epilogue, the barrier and -- mostly -- the
         // OTHER wave of this SIMD's unit
         stamp();
-        C32Unit nx = {cu.ui + 2, 0, 0, 0ull};
+        C32Unit nx = {cu.ui + (GV_C32_SPLIT ? 1 : 2), 0, 0, 0ull};
         c32_open(plan, nl, list, nu, nx);
         const float4* nb0;
         unsigned noff;
@@ -408,8 +416,8 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
         {
             float* const An = ((cu.layer + 1) & 1) ? buf1 : buf0;
             const int ldn = ((cu.layer + 1) & 1) ? p.ld1 : p.ld0;
-            if (loads_in_epilogue) c32_epilogue<true>(acc0, acc1, Ly, cu.tile, m0, p.m, cu.layer + 1 < nl ? An : nullptr, ldn, bias_lds + bias_at, l31, lhi, p.debug);
-            else c32_epilogue<false>(acc0, acc1, Ly, cu.tile, m0, p.m, cu.layer + 1 < nl ? An : nullptr, ldn, bias_lds + bias_at, l31, lhi, p.debug);
+            if (loads_in_epilogue) c32_epilogue<true>(acc0, acc1, Ly, cu.tile, m0, p.m, cu.layer + 1 < nl ? An : nullptr, ldn, bias_lds + bias_at, l31, lhi, p.debug, half);
+            else c32_epilogue<false>(acc0, acc1, Ly, cu.tile, m0, p.m, cu.layer + 1 < nl ? An : nullptr, ldn, bias_lds + bias_at, l31, lhi, p.debug, half);
         }
         if (loads_in_epilogue && !(p.debug & 8)) c32_issue(q, nb0, noff, nx.set);
         stamp();
@@ -607,15 +615,8 @@ extern "C" int gv_made_chain_f32(const float* x, int ldx, int m, int n_layers, c
     size_t widths = 0;
     for (int i = 0; i < n_layers; ++i) widths += (size_t)ns[i];
     const size_t lds = (size_t)C32_BM * (p.ld0 + p.ld1) * sizeof(float) + C32_PLAN_WORDS * sizeof(int32_t) + widths * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_made_chain_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("gv_made_chain_f32: cannot raise the dynamic LDS limit");
-            return GV_ERR_SHAPE;
-        }
-        attr_set = true;
-    }
+    static unsigned long long lds_done = 0;
+    if (!raise_dynamic_lds((const void*)k_made_chain_f32, 160 * 1024, lds_done, "gv_made_chain_f32")) return GV_ERR_SHAPE;
     hipLaunchKernelGGL(k_made_chain_f32, dim3((unsigned)((m + C32_BM - 1) / C32_BM)), dim3(C32_THREADS), lds, (hipStream_t)stream, p);
     return launch_status("gv_made_chain_f32");
 }

@@ -271,15 +271,8 @@ extern "C" int gv_made_gradw_f32(const float* g, int ldg, const float* a, int ld
     p.part = workspace;
     p.dbpart = db ? workspace + (size_t)slices * p.mp * p.np : nullptr;
     const size_t lds = (size_t)4 * GW_KC * GW_LD * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_gradw32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("gv_made_gradw_f32: cannot raise the dynamic LDS limit");
-            return GV_ERR_SHAPE;
-        }
-        attr_set = true;
-    }
+    static unsigned long long lds_done = 0;
+    if (!raise_dynamic_lds((const void*)k_gradw32, (int)lds, lds_done, "gv_made_gradw_f32")) return GV_ERR_SHAPE;
     const dim3 grid((unsigned)slices, (unsigned)((m + 32 * GW_BT - 1) / (32 * GW_BT)), (unsigned)((n + 32 * GW_BT - 1) / (32 * GW_BT)));
     hipLaunchKernelGGL(k_gradw32, grid, dim3(GW_THREADS), lds, (hipStream_t)stream, p);
     int rc = launch_status("gv_made_gradw_f32");

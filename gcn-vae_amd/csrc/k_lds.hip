@@ -516,15 +516,7 @@ extern "C" int gv_rgcn_bdd_aggregate_lds(const int32_t* sitems, int n_sitems, co
     const size_t tq = (size_t)num_rels * pl.nq * pl.cl;
     const size_t lds = ((tq + 63) & ~(size_t)63) * 16 + (size_t)LDS_WAVES * pl.kb * pl.po * 4 + 16;
     // one workgroup per CU over all column parts (its waves share a counter that deals out the workgroup's super-items)
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            n_cu = v;
-        else
-            n_cu = 256;
-        (void)hipGetLastError();
-    }
+    const int n_cu = current_device_cus();
     int wgs = (max_workgroups > 0 ? max_workgroups : n_cu) / pl.parts;
     const int longest = n_sitems > n_empty ? n_sitems : n_empty;
     const int need = (longest + LDS_WAVES - 1) / LDS_WAVES;
@@ -536,12 +528,8 @@ extern "C" int gv_rgcn_bdd_aggregate_lds(const int32_t* sitems, int n_sitems, co
     if (rc == -1000 && blk_in == P_ && blk_out == Q_ && bf == BF_ && pl.ipl == IPL_ && pl.oh == OH_ && pl.bpp == BPP_ && \
         pl.u == U_ && pl.kb == KB_) {                                                                                   \
         auto kern = k_agg_lds<P_, Q_, IPL_, OH_, BPP_, U_, KB_, BF_>;                                                   \
-        static bool attr_done = false;                                                                                  \
-        if (!attr_done) {                                                                                               \
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET) != hipSuccess) \
-                (void)hipGetLastError();                                                                                \
-            attr_done = true;                                                                                           \
-        }                                                                                                               \
+        static unsigned long long lds_done = 0;                                                                         \
+        if (!raise_dynamic_lds((const void*)kern, LDS_BUDGET, lds_done, "gv_rgcn_bdd_aggregate_lds")) return GV_ERR_SHAPE; \
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                              \
         rc = launch_status("gv_rgcn_bdd_aggregate_lds");                                                               \
     }

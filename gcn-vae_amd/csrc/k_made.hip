@@ -795,15 +795,8 @@ extern "C" int gv_gemm_bf16_nt(const void* a, int a_is_f32, int lda, const uint1
         p.partial = (float*)workspace; p.k_per_split = per;
     }
     if (tall) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)k_gemm_bf16_tallk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TK_LDS_BYTES) != hipSuccess) {
-                (void)hipGetLastError();
-                set_error("gv_gemm_bf16_nt: cannot raise the dynamic LDS limit");
-                return GV_ERR_SHAPE;
-            }
-            attr_set = true;
-        }
+        static unsigned long long lds_done = 0;
+        if (!raise_dynamic_lds((const void*)k_gemm_bf16_tallk<false>, (int)TK_LDS_BYTES, lds_done, "gv_gemm_bf16_nt")) return GV_ERR_SHAPE;
         hipLaunchKernelGGL(k_gemm_bf16_tallk<false>, dim3((n + TK_T - 1) / TK_T, (m + TK_T - 1) / TK_T, splits), dim3(TK_THREADS), TK_LDS_BYTES,
                            st, p);
     } else {
@@ -853,15 +846,8 @@ static int gemm_bf16_gradw(const char* who, const uint16_t* a, int lda, unsigned
     p.rowsum_partial = a_rowsum ? (float*)workspace + (size_t)m * n : nullptr;
     p.a_tile = a_tile; p.b_tile = b_tile;
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_gemm_bf16_tallk<TILES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TK_LDS_BYTES) != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("%s: cannot raise the dynamic LDS limit", who);
-            return GV_ERR_SHAPE;
-        }
-        attr_set = true;
-    }
+    static unsigned long long lds_done = 0;
+    if (!raise_dynamic_lds((const void*)k_gemm_bf16_tallk<TILES>, (int)TK_LDS_BYTES, lds_done, "gv_gemm_bf16_gradw")) return GV_ERR_SHAPE;
     hipLaunchKernelGGL(k_gemm_bf16_tallk<TILES>, dim3((n + TK_T - 1) / TK_T, (m + TK_T - 1) / TK_T, splits), dim3(TK_THREADS), TK_LDS_BYTES, st, p);
     const size_t mn = (size_t)m * n;
     launch_splitk_sum(st, (const float*)workspace, splits, mn, p.partial_stride, c_f32, accumulate, (size_t)m, a_rowsum);

@@ -464,12 +464,8 @@ extern "C" int gv_rgcn_bdd_aggregate_phases(const int32_t* off, const int32_t* n
 #define GV_PHASE_CASE_L(P_, Q_, T_, B_, K_, U_, LEAN_)  /* U_ = M: feature rows in flight */                                                                        \
     if (rc == -1000 && blk_in == P_ && blk_out == Q_ && (transpose_w != 0) == T_ && pl.bpl == B_ && pl.k == K_) {    \
         auto kern = k_agg_phase<P_, Q_, T_, B_, K_, U_, LEAN_>;                                                             \
-        static bool attr_done = false;                                                                               \
-        if (!attr_done) {                                                                                            \
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
-                (void)hipGetLastError();                                                                             \
-            attr_done = true;                                                                                        \
-        }                                                                                                            \
+        static unsigned long long lds_done = 0;                                                                      \
+        if (!raise_dynamic_lds((const void*)kern, 160 * 1024, lds_done, "gv_rgcn_bdd_aggregate_phases")) return GV_ERR_SHAPE; \
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                           \
         rc = launch_status("gv_rgcn_bdd_aggregate_phases");                                                         \
     }

@@ -55,6 +55,10 @@ RECORDER = None
 def start_collective(start_fn):
     """``start_fn()`` issues a collective and returns an object with wait() (or None when it blocks).  Returns a handle
     with wait().  The tensors ``start_fn`` closes over must be the step's own (static under segmented capture)."""
+    # work a backward pass left on the 'bwd' side stream (a MADE's weight-gradient products) is joined here: the collective may
+    # read what it writes (the gradient arena), and under segmented capture a fork must be joined inside its own graph segment
+    from . import ops as _ops
+    _ops.backward_side_finish()
     if RECORDER is not None:
         return RECORDER.collective(start_fn)
     work = start_fn()

@@ -680,12 +680,22 @@ K1_LDS = _os.environ.get('GV_K1_LDS', 'auto')               # LDS-resident relat
 K1_LDS_WORKGROUPS = int(_os.environ.get('GV_K1_LDS_WGS', '0'))      # 0: one workgroup per CU
 K1_LDS_G = int(_os.environ.get('GV_K1_LDS_G', '64'))                # most edges of a super-item (the kernel takes up to 64)
 _LDS_PLANS = {}
-LDS_MIN_EDGES = 100_000     # its work lists are built with one host read-back: graphs that are rebuilt every step (mini-batches,
-#                             indexed sync-free) stay on the per-row kernels below this size
+
+
+LDS_MIN_EDGES = 100_000     # graphs indexed sync-free (rebuilt per step: mini-batches) stay on the per-row kernels below this size
 
 
 def lds_graph(gidx):
-    return (not gidx.sync_free) or gidx.num_edges >= LDS_MIN_EDGES
+    """Does the LDS-resident kernel take this graph?  Its super-item lists are built with host read-backs (LdsOrder.build:
+    data-dependent sizes) -- once per graph, cached on the index.  A graph indexed sync-free takes the path from LDS_MIN_EDGES
+    edges on (a large static graph whose lists are built during the eager warm-up steps); while the current stream is being
+    CAPTURED a graph whose lists do not exist yet stays on the per-row kernels instead of aborting the capture with a
+    synchronisation (a per-batch graph of that size inside graph_step.GraphedMiniBatchStep)."""
+    if gidx.sync_free and gidx.num_edges < LDS_MIN_EDGES:
+        return False
+    if not gidx._lds_seg_cache and torch.cuda.is_current_stream_capturing():
+        return False
+    return True
 
 
 def k1_bf16_applies(gidx, num_rels, num_bases, in_feat, out_feat):

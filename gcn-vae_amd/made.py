@@ -706,8 +706,7 @@ def _made_prep_key(ws, d, S):
 
 def made_prepare(calls):
     """calls: [(colcount, weights, biases, masks)] of the bf16 MADE nodes the caller is about to run (made_forward's arguments)."""
-    if (not MADE_PREPARE or not calls or _ops.GEMM_PRECISION != 'bf16' or not MADE_BF16_STORAGE or lib.TIMER is not None
-            or _process_group()):
+    if not calls or _ops.GEMM_PRECISION != 'bf16' or not MADE_BF16_STORAGE or not _ops.launch_layout().made_prepare:
         return
     main, side = torch.cuda.current_stream(), _side('made_prep')
     side.wait_stream(main)
@@ -1099,7 +1098,7 @@ def _by_row_blocks(run, n, want, min_tiles=None):
     """run(r0, r1) over the row blocks of _made_row_blocks (want: how many, None: MADE_ROW_BLOCKS; <= 1: all rows at once): the
     first on the current stream, the others on side streams that are joined before returning (under hipGraph capture: parallel
     branches)."""
-    blocks = _made_row_blocks(n, want, min_tiles) if lib.TIMER is None else [(0, n)]      # (timed launches are whole launches: bench.py's K4 line)
+    blocks = _made_row_blocks(n, want, min_tiles) if _ops.launch_layout().row_blocks else [(0, n)]      # (timed launches are whole launches: bench.py's K4 line)
     if len(blocks) == 1:
         run(0, n)
         return

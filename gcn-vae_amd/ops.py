@@ -129,6 +129,32 @@ BWD_SIDE = _os.environ.get('GV_BWD_SIDE', '1') == '1'
 _bwd_side_held = []
 
 
+@dataclass(frozen=True)
+class LaunchLayout:
+    """How a step may spread its launches over streams -- decided in ONE place (``launch_layout()``) from the process state, read by
+    ``backward_side``, ``made.made_prepare`` and ``made._by_row_blocks``."""
+    timed: bool             # a lib.KernelTimer is installed (bench.py's per-kernel figures): every launch runs alone, in order
+    process_group: bool     # a torch.distributed group exists: the step carries collectives, a captured step is a chain of segments
+    bwd_side: bool          # a MADE's weight-gradient products beside the rest of the backward pass (side stream 'bwd')
+    bwd_side_join_at_collective: bool   # ... joined in front of the next collective (a fork must not outlive its graph segment)
+    made_prepare: bool      # the flows' parameter-only work beside the encoder's layers (side stream 'made_prep')
+    row_blocks: bool        # a MADE's passes over independent row blocks on their own streams (forked and joined inside the node)
+
+
+def launch_layout():
+    from . import made as _made          # (made imports ops: resolved at call time)
+    timed, pg = lib.TIMER is not None, _process_group()
+    return LaunchLayout(
+        timed=timed, process_group=pg,
+        # the side stream is joined when the backward pass has run -- or, with collectives on the step, in front of the first
+        # collective after the fork (distributed.start_collective -> backward_side_finish): the products then still run beside the
+        # remaining backward chains of the flow stack, which is where they were hidden anyway
+        bwd_side=BWD_SIDE and not timed, bwd_side_join_at_collective=pg,
+        # forked at the START of the forward pass, in front of the encoder's collectives: not under a process group
+        made_prepare=_made.MADE_PREPARE and not timed and not pg,
+        row_blocks=not timed)
+
+
 def _process_group():
     """A torch.distributed process group exists (even of one rank): the step then carries collectives, a captured step is a chain
     of graph SEGMENTS cut at them, and a stream forked in one segment may not be joined in another -- no deferred side streams."""
@@ -140,7 +166,7 @@ def _process_group():
 def backward_side(enabled, *held):
     """Inside an autograd backward: run the enclosed launches on the side stream (after everything already enqueued); ``held``:
     the tensors they touch.  Yields whether the side stream is in use."""
-    if not (enabled and BWD_SIDE) or lib.TIMER is not None or _process_group():      # (timed launches run alone: bench.py's per-kernel lines)
+    if not (enabled and launch_layout().bwd_side):      # (timed launches run alone: bench.py's per-kernel lines)
         # A node that stays on the main stream while an EARLIER node of this backward pass left work on the side stream: the two
         # may write the same slices of the gradient arena (one MADE's parameters behind two nodes -- the posterior pass and a
         # separate MMD prior pass; the first stores on the side stream, the second accumulates, or hands its gradient to
@@ -157,6 +183,8 @@ def backward_side(enabled, *held):
     _bwd_side_held.append(held)
     if first:
         def _join():
+            if not _bwd_side_held:      # joined already (in front of a collective: backward_side_finish)
+                return
             # the stream the pass was started under AND the one current now (backward() may be called under another stream than
             # the node's launches ran on; the optimiser reads the arena on the caller's)
             main.wait_stream(side)
@@ -348,8 +376,14 @@ LIVE_ROWS = None        # (device int32 (1,), cap): inside a static-shape batch 
 
 class live_rows:
     """``with ops.live_rows(rows_dev, cap):`` -- the fp32 products over node arrays of exactly ``cap`` rows skip the padding rows
-    (gv_gemm_f32_live_rows: zero rows out, a shorter reduction for the weight gradients).  graph_step.GraphedMiniBatchStep wraps
-    the step in it: ~30 % of a sampled batch's 14 541 padded rows are padding."""
+    (gv_gemm_f32_live_rows: zero rows out, a shorter reduction for the weight gradients; gv_made_chain_f32: workgroups that hold
+    only padding rows).  graph_step.GraphedMiniBatchStep wraps the step in it: ~30 % of a sampled batch's 14 541 padded rows are
+    padding.
+    CONTRACT: inside the context EVERY fp32 operand of exactly ``cap`` rows is taken for a padded node array -- the match is by
+    row count, nothing marks the arrays.  The caller must not run products over other (cap, k) operands inside it (the captured
+    mini-batch step does not: its only other row counts are cap + 200 and 200).  The VALUES of padding rows behind the first
+    ``*rows_dev`` are unspecified (zeros from skipped tiles / workgroups, act(bias) from tiles that straddle the boundary); they
+    take no part in any sum, mean or gradient."""
 
     def __init__(self, rows_dev, cap):
         self.val = (rows_dev, int(cap)) if rows_dev is not None else None

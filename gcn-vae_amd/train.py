@@ -113,6 +113,13 @@ def _get_loss_rows(self, part, embed, tidx, flp, kl_w, mmd_w, z_pri, pick, label
 LinkPredict._get_loss_rows = _get_loss_rows
 
 
+def host_state_dict(model):
+    """The model's state_dict with every tensor on the HOST: the reference moves the model to the CPU before it saves
+    (kgvae/link_predict.py:242-246), so its checkpoints load with a plain ``torch.load`` on a box without a GPU.  HIP modules stay
+    on the device under ``.cpu()`` (ops.StayOnDevice), hence the explicit copy here."""
+    return {k: v.detach().cpu() for k, v in model.state_dict().items()}
+
+
 def _sync():
     torch.cuda.synchronize()
 
@@ -232,16 +239,16 @@ def main(args):
         if epoch % args.evaluate_every == 0:
             model.eval()
             print("start eval")
-            torch.save({'state_dict': model.state_dict(), 'epoch': epoch}, args.model_state_file)
+            torch.save({'state_dict': host_state_dict(model), 'epoch': epoch}, args.model_state_file)
             with torch.no_grad():
                 embed = model(val_graph, val_node_id, val_rel, val_norm)
             mrr = ranking.calc_mrr(embed, model.w_relation, valid_t, hits=[1, 3, 10], eval_bz=args.eval_batch_size,
                                    all_batches=False, flow_log_prob=model.encoder.get_flow_log_prob())
             if mrr < best_mrr:
-                torch.save({'state_dict': model.state_dict(), 'epoch': epoch}, args.model_state_file + "_latest")
+                torch.save({'state_dict': host_state_dict(model), 'epoch': epoch}, args.model_state_file + "_latest")
             else:
                 best_mrr = mrr
-                torch.save({'state_dict': model.state_dict(), 'epoch': epoch}, args.model_state_file)
+                torch.save({'state_dict': host_state_dict(model), 'epoch': epoch}, args.model_state_file)
         if epoch >= args.n_epochs:
             break
 

@@ -31,7 +31,7 @@ ts = big[made.PLAN_WORDS:].cpu().numpy().astype('int64').reshape(8, 64) & 0xffff
 plan = big[:made.PLAN_WORDS].cpu().numpy()
 t0 = ts[:, 0].min()
 for w in range(8):
-    lst = plan[4 + (w & 3) * 128: 4 + (w & 3) * 128 + plan[w & 3]][(w >> 2)::2]
+    lst = plan[4 + (w & 3) * 128: 4 + (w & 3) * 128 + plan[w & 3]][(w >> 2)::2]          # (GV_C32_SPLIT=1 builds: both waves walk the whole list)
     row = ts[w]
     n = int((row != 0).sum())
     rel = [(int(v) - int(t0)) & 0xffffffff for v in row[:n]]
