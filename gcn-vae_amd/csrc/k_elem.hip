@@ -258,22 +258,35 @@ __global__ __launch_bounds__(256) void k_rowsum(const float* x, int ld, int col0
 // r = t, t + 1024, ... (per row the blocks in order), the 1 024 partials are added in a fixed tree.  rows_dev (optional): only
 // the first *rows_dev of the n rows exist (static-shape batch); the mean divides by that count.
 struct MeanRowsArgs { const float* x[8]; int count; };
-__global__ __launch_bounds__(1024) void k_mean_rows_multi(const MeanRowsArgs a, int64_t n, const int* rows_dev, float* out) {
-    __shared__ float sm[1024];
+constexpr int MEAN_ROWS_BLOCKS = 64;
+// stage 1: block b sums rows [b * per, (b + 1) * per) (thread t its rows in order, the 256 thread sums in a fixed tree) -> part[b];
+// stage 2 (one block): the 64 partials in order, divided by the row count.  Same result whatever the launch geometry.
+__global__ __launch_bounds__(256) void k_mean_rows_part(const MeanRowsArgs a, int64_t n, const int* rows_dev, float* part) {
+    __shared__ float sm[256];
     const int64_t live = rows_dev ? min((int64_t)*rows_dev, n) : n;
+    const int64_t per = (n + MEAN_ROWS_BLOCKS - 1) / MEAN_ROWS_BLOCKS;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(live, r0 + per);
     float acc = 0.f;
-    for (int64_t r = threadIdx.x; r < live; r += 1024) {
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
         float s = 0.f;
         for (int i = 0; i < a.count; ++i) s += a.x[i][r];
         acc += s;
     }
     sm[threadIdx.x] = acc;
     __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
+    for (int w = 128; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = sm[0] / (float)live;
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+__global__ __launch_bounds__(64) void k_mean_rows_final(const float* part, int64_t n, const int* rows_dev, float* out) {
+    const int64_t live = rows_dev ? min((int64_t)*rows_dev, n) : n;
+    if (threadIdx.x == 0) {
+        float acc = 0.f;
+        for (int b = 0; b < MEAN_ROWS_BLOCKS; ++b) acc += part[b];
+        *out = acc / (float)live;
+    }
 }
 // its backward: every block's per-row gradient is the same vector  g / rows  on the rows that exist, 0 on the padding rows
 __global__ __launch_bounds__(256) void k_mean_rows_bwd(const float* g, int64_t len, int64_t n, const int* rows_dev, float* out) {
@@ -587,13 +600,15 @@ extern "C" int gv_rowsum(const float* x, int ld, int col0, int ncols, float* out
     return launch_status("gv_rowsum");
 }
 
-extern "C" int gv_mean_rows_multi(int count, const float* const* x, int64_t n, const int32_t* rows_dev, float* out, void* stream) {
-    GV_REQUIRE(count >= 1 && count <= 8 && x && out && n > 0, GV_ERR_SHAPE, "gv_mean_rows_multi: count=%d n=%lld", count, (long long)n);
+extern "C" int gv_mean_rows_multi(int count, const float* const* x, int64_t n, const int32_t* rows_dev, float* out, float* workspace,
+                                  void* stream) {
+    GV_REQUIRE(count >= 1 && count <= 8 && x && out && workspace && n > 0, GV_ERR_SHAPE, "gv_mean_rows_multi: count=%d n=%lld", count, (long long)n);
     MeanRowsArgs a;
     a.count = count;
     for (int i = 0; i < 8; ++i) a.x[i] = i < count ? x[i] : nullptr;
     for (int i = 0; i < count; ++i) GV_REQUIRE(x[i], GV_ERR_NULL, "gv_mean_rows_multi: NULL vector %d", i);
-    hipLaunchKernelGGL(k_mean_rows_multi, dim3(1), dim3(1024), 0, GV_ST, a, n, rows_dev, out);
+    hipLaunchKernelGGL(k_mean_rows_part, dim3(MEAN_ROWS_BLOCKS), dim3(256), 0, GV_ST, a, n, rows_dev, workspace);
+    hipLaunchKernelGGL(k_mean_rows_final, dim3(1), dim3(64), 0, GV_ST, workspace, n, rows_dev, out);
     return launch_status("gv_mean_rows_multi");
 }
 

@@ -125,7 +125,7 @@ SIGNATURES = {
     'gv_iaf_update_bwd_acc': (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _L, _I, _P]),
     'gv_rowsum': (_I, [_P, _I, _I, _I, _P, _L, _P]),
     'gv_reverse_cols': (_I, [_P, _P, _L, _I, _P]),
-    'gv_mean_rows_multi': (_I, [_I, _P, _L, _P, _P, _P]),
+    'gv_mean_rows_multi': (_I, [_I, _P, _L, _P, _P, _P, _P]),
     'gv_mean_rows_bwd': (_I, [_P, _L, _L, _P, _P, _P]),
     'gv_adam_step': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P, _P]),
     'gv_clip_adam_step': (_I, [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _P, _I, _P]),

@@ -1722,7 +1722,8 @@ class _MeanRowsMulti(torch.autograd.Function):
             raise ValueError('mean_rows_multi: vectors of one length >= n')
         out = torch.empty((), dtype=torch.float32, device=xs[0].device)
         tab = (_ct.c_void_p * len(xs))(*[ptr(x) for x in xs])
-        lib.call('gv_mean_rows_multi', len(xs), _ct.addressof(tab), n, ptr(rows_dev), ptr(out), lib.stream())
+        ws = torch.empty(64, dtype=torch.float32, device=xs[0].device)
+        lib.call('gv_mean_rows_multi', len(xs), _ct.addressof(tab), n, ptr(rows_dev), ptr(out), ptr(ws), lib.stream())
         ctx.rows_dev, ctx.n, ctx.len, ctx.k = rows_dev, n, length, len(xs)
         return out
 

@@ -588,9 +588,10 @@ int gv_rowsum(const float* x, int ld, int col0, int ncols, float* out, int64_t n
 int gv_reverse_cols(const float* x, float* out, int64_t n, int d, void* stream);
 /* flow_log_prob (kgvae/model.py:116-123): *out = mean over the rows that exist of sum_i x[i][r], x = the `count` (<= 8) IAF blocks'
  * per-row log-determinants [n] (host table of device pointers, read during the call); rows_dev (optional device int32): only the
- * first *rows_dev rows exist.  One workgroup, fixed summation order.  _bwd: out [len >= n] = *g / rows on the rows that exist, 0
+ * first *rows_dev rows exist.  64 blocks of rows + one finishing launch, fixed summation order; workspace: 64 floats.  _bwd: out [len >= n] = *g / rows on the rows that exist, 0
  * on the padding rows and on [n, len) (rows that ride along without taking part in the mean) -- the gradient of every vector. */
-int gv_mean_rows_multi(int count, const float* const* x, int64_t n, const int32_t* rows_dev, float* out, void* stream);
+int gv_mean_rows_multi(int count, const float* const* x, int64_t n, const int32_t* rows_dev, float* out, float* workspace,
+                       void* stream);
 int gv_mean_rows_bwd(const float* g, int64_t len, int64_t n, const int32_t* rows_dev, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
