@@ -54,10 +54,11 @@ constexpr int C32_PLAN_WORDS = C32_PLAN_SETS + 2 * C32_L * C32_MAXT;
 static_assert(C32_PLAN_WORDS == GV_CHAIN32_PLAN_WORDS, "include/gcnvae.h states the plan size");
 
 struct Chain32Args {
-    const float* x;              // [m][ldx]: input of layer 0
+    float* x;                    // [m][ldx]: input of layer 0 (passes: the first pass's slice of the stacked inputs)
     const int32_t* plan;         // gv_made_chain_f32_plan
     const int32_t* rows_dev;     // optional device scalar: rows [*rows_dev, m) are padding
     int ldx, m, n_layers, ld0, ld1, debug;
+    gv_chain32_iaf iaf;          // mode 0: one pass, no update (gv_made_chain_f32)
     gv_chain32_layer L[C32_L];
 };
 
@@ -274,6 +275,71 @@ __device__ __forceinline__ void c32_epilogue(const f32x16c& acc0, const f32x16c&
     }
 }
 
+// ---- the IAF update around the chain (gv_made_passes_f32), on the workgroup's own 64 rows, four columns per thread ----------
+// forward: x_new = count > 0 ? z * expf(alpha + mu) : x_old   (k_iaf_fwd's arithmetic)
+__device__ __forceinline__ void c32_update_fwd(const float* z, const float* net, int ld_net, const float* x_old, int ldx, const int* cnt,
+                                               float* x_new, int ld_new, int m0, int m, int d) {
+    const int q = d >> 2;
+    for (int i = threadIdx.x; i < C32_BM * q; i += C32_THREADS) {
+        const int row = m0 + i / q, c = (i % q) << 2;
+        if (row >= m) continue;
+        const int4 cn = *reinterpret_cast<const int4*>(cnt + c);
+        const bool any = cn.x > 0 || cn.y > 0 || cn.z > 0 || cn.w > 0, all = cn.x > 0 && cn.y > 0 && cn.z > 0 && cn.w > 0;
+        float4 zz = make_float4(0.f, 0.f, 0.f, 0.f), mu = zz, al = zz, xo = zz;
+        if (any) {
+            zz = *reinterpret_cast<const float4*>(z + (size_t)row * d + c);
+            mu = *reinterpret_cast<const float4*>(net + (size_t)row * ld_net + c);
+            al = *reinterpret_cast<const float4*>(net + (size_t)row * ld_net + d + c);
+        }
+        if (!all) xo = *reinterpret_cast<const float4*>(x_old + (size_t)row * ldx + c);
+        float4 o;
+        o.x = cn.x > 0 ? zz.x * expf(al.x + mu.x) : xo.x;
+        o.y = cn.y > 0 ? zz.y * expf(al.y + mu.y) : xo.y;
+        o.z = cn.z > 0 ? zz.z * expf(al.z + mu.z) : xo.z;
+        o.w = cn.w > 0 ? zz.w * expf(al.w + mu.w) : xo.w;
+        *reinterpret_cast<float4*>(x_new + (size_t)row * ld_new + c) = o;
+    }
+}
+
+// backward (k_iaf_bwd_v4's arithmetic): g_z (+)= g count e, g_mu = g count z e, g_alpha = g_logdet + g_mu, e = expf(alpha + mu);
+// the handed-through gradient (count == 0: g, else 0) goes to g_old, where the chain's last layer adds its own
+__device__ __forceinline__ void c32_update_bwd(const float* z, const float* net, int ld_net, const int* cnt, const float* g_in, int ld_gin,
+                                               const float* gld, float* g_z, bool gz_write, float* g_net, int ld_gnet, float* g_old,
+                                               int ld_gold, int m0, int m, int d) {
+    const int q = d >> 2;
+    for (int i = threadIdx.x; i < C32_BM * q; i += C32_THREADS) {
+        const int row = m0 + i / q, c = (i % q) << 2;
+        if (row >= m) continue;
+        const int4 cnt4 = *reinterpret_cast<const int4*>(cnt + c);
+        const float4 g = *reinterpret_cast<const float4*>(g_in + (size_t)row * ld_gin + c);
+        const float4 zz = *reinterpret_cast<const float4*>(z + (size_t)row * d + c);
+        const float4 mu = *reinterpret_cast<const float4*>(net + (size_t)row * ld_net + c), al = *reinterpret_cast<const float4*>(net + (size_t)row * ld_net + d + c);
+        float4 old = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!gz_write) old = *reinterpret_cast<const float4*>(g_z + (size_t)row * d + c);
+        const float gl = gld ? gld[row] : 0.f;
+        const int cn[4] = {cnt4.x, cnt4.y, cnt4.z, cnt4.w};
+        const float gv[4] = {g.x, g.y, g.z, g.w}, zv[4] = {zz.x, zz.y, zz.z, zz.w}, mv[4] = {mu.x, mu.y, mu.z, mu.w}, av[4] = {al.x, al.y, al.z, al.w};
+        float o_z[4], o_mu[4], o_al[4], o_old[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float g_mu = 0.f, g_al = gl, gz = 0.f, go = gv[e];
+            if (cn[e] > 0) {
+                const float ex = expf(av[e] + mv[e]);
+                const float gc = gv[e] * (float)cn[e];
+                gz = gc * ex;
+                g_mu = gc * zv[e] * ex;
+                g_al += g_mu;
+                go = 0.f;
+            }
+            o_z[e] = gz; o_mu[e] = g_mu; o_al[e] = g_al; o_old[e] = go;
+        }
+        *reinterpret_cast<float4*>(g_z + (size_t)row * d + c) = make_float4(old.x + o_z[0], old.y + o_z[1], old.z + o_z[2], old.w + o_z[3]);
+        *reinterpret_cast<float4*>(g_net + (size_t)row * ld_gnet + c) = make_float4(o_mu[0], o_mu[1], o_mu[2], o_mu[3]);
+        *reinterpret_cast<float4*>(g_net + (size_t)row * ld_gnet + d + c) = make_float4(o_al[0], o_al[1], o_al[2], o_al[3]);
+        *reinterpret_cast<float4*>(g_old + (size_t)row * ld_gold + c) = make_float4(o_old[0], o_old[1], o_old[2], o_old[3]);
+    }
+}
+
 __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Args p) {
     extern __shared__ __attribute__((aligned(16))) float c32_lds[];
     const int nl = p.n_layers, m0 = blockIdx.x * C32_BM;
@@ -282,23 +348,12 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
     float* const buf0 = c32_lds;
     float* const buf1 = c32_lds + C32_BM * p.ld0;
 
-    if (p.rows_dev) {
-        // a static-shape batch pads its node arrays: a workgroup whose rows are all padding stores zeros (nothing where it would
-        // accumulate), as gv_gemm_f32_live_rows does for its padding tiles
-        const int live = *p.rows_dev;
-        if (m0 >= live) {
-            for (int l = 0; l < nl; ++l) {
-                const gv_chain32_layer& Ly = p.L[l];
-                if (!Ly.out_f32 || Ly.accumulate) continue;
-                const int q = Ly.n >> 2;
-                for (int i = threadIdx.x; i < C32_BM * q; i += C32_THREADS) {
-                    const int row = m0 + i / q, c = (i % q) << 2;
-                    if (row < p.m) *reinterpret_cast<float4*>(Ly.out_f32 + (size_t)row * Ly.ldc + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-            return;
-        }
-    }
+    // a static-shape batch pads its node arrays: a workgroup whose rows are all padding stores zeros (nothing where it would
+    // accumulate) instead of running the layers, as gv_gemm_f32_live_rows does for its padding tiles
+    const bool padding = p.rows_dev && m0 >= *p.rows_dev;
+    const int n_pass = p.iaf.mode ? p.iaf.passes : 1;
+    const long long step = p.iaf.mode ? (long long)p.iaf.step : 0ll;
+    const gv_chain32_layer& Llast = p.L[nl - 1];
 
     // The layer descriptors are kernel arguments, indexed by a run-time layer number below: scalar loads from the kernarg buffer, one
     // cold miss (a microsecond) per 64-B line at the FIRST use -- i.e. in every layer's first unit, in series.  Touch every line
@@ -320,19 +375,6 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
             if (p.L[l].bias)
                 for (int i = threadIdx.x; i < p.L[l].n; i += C32_THREADS) bias_lds[at + i] = p.L[l].bias[i];
             at += p.L[l].n;
-        }
-    }
-    // ---- stage x: 64 rows x k0 floats, 16-B pieces along the rows, zero outside [0, m) --------------------------------------
-    {
-        const int k0 = p.L[0].k, q = k0 >> 2;       // k0 % 8 == 0
-        for (int i = threadIdx.x; i < C32_BM * q; i += C32_THREADS) {
-            const int row = i / q, c = (i - row * q) << 2;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + row < p.m) v = *reinterpret_cast<const float4*>(p.x + (size_t)(m0 + row) * p.ldx + c);
-            // columns c .. c + 3 of a group of 8: (c, c + 2) are neighbours in the even-k half, (c + 1, c + 3) in the odd-k half
-            float* o = buf0 + row * p.ld0 + (c & ~7) + ((c & 4) >> 1);
-            *reinterpret_cast<float2*>(o) = make_float2(v.x, v.z);
-            *reinterpret_cast<float2*>(o + 4) = make_float2(v.y, v.w);
         }
     }
     __syncthreads();
@@ -361,15 +403,53 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
     };
 
     const int half = wave >> 2;
-    C32Unit cu = {GV_C32_SPLIT ? 0 : half, 0, 0, 0ull};
-    c32_open(plan, nl, list, nu, cu);
     float4 q[C32_CHG];
+  for (int s = 0; s < n_pass; ++s) {
+    const long long so = (long long)s * step;            // rows from the first pass's slices to this pass's
+    float* const xs = p.x + so * p.ldx;
+    // the first unit's weight fragments are requested before the pass's element-wise front
+    C32Unit cu = {GV_C32_SPLIT ? 0 : half, 0, 0, 0ull};
+    c32_open(plan, nl, list, padding ? 0 : nu, cu);
     {
         const float4* b0;
         unsigned off;
         b_of(cu, b0, off);
         c32_issue(q, b0, off, cu.set);
     }
+    if (p.iaf.mode == 2) {
+        // the update's backward for this pass: [g_mu | g_alpha] into the chain's input slice, dL/dz, the handed-through gradient
+        const int d = p.iaf.d;
+        const float* g_in = s == 0 ? p.iaf.g_in : Llast.out_f32 + (so - step) * Llast.ldc;
+        c32_update_bwd(p.iaf.z, p.iaf.net + so * p.iaf.ld_net, p.iaf.ld_net, p.iaf.colcount + (step > 0 ? s : -s) * d, g_in,
+                       s == 0 ? d : Llast.ldc, (s == 0 && (p.iaf.flags & 1)) ? p.iaf.g_logdet : nullptr, p.iaf.g_z,
+                       s == 0 && (p.iaf.flags & 2), xs, p.ldx, Llast.out_f32 + so * Llast.ldc, Llast.ldc, m0, p.m, d);
+        __syncthreads();         // (drains the stores: the staging below and the last layer's epilogue read them back)
+    }
+    if (padding) {
+        for (int l = 0; l < nl; ++l) {
+            const gv_chain32_layer& Lz = p.L[l];
+            if (!Lz.out_f32 || Lz.accumulate) continue;
+            const int q4 = Lz.n >> 2;
+            float* o = Lz.out_f32 + so * Lz.ldc;
+            for (int i = threadIdx.x; i < C32_BM * q4; i += C32_THREADS) {
+                const int row = m0 + i / q4, c = (i % q4) << 2;
+                if (row < p.m) *reinterpret_cast<float4*>(o + (size_t)row * Lz.ldc + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    } else {
+        // ---- stage x: 64 rows x k0 floats, 16-B pieces along the rows, zero outside [0, m) ----------------------------------
+        const int k0 = p.L[0].k, q4 = k0 >> 2;       // k0 % 8 == 0
+        for (int i = threadIdx.x; i < C32_BM * q4; i += C32_THREADS) {
+            const int row = i / q4, c = (i - row * q4) << 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + row < p.m) v = *reinterpret_cast<const float4*>(xs + (size_t)(m0 + row) * p.ldx + c);
+            // columns c .. c + 3 of a group of 8: (c, c + 2) are neighbours in the even-k half, (c + 1, c + 3) in the odd-k half
+            float* o = buf0 + row * p.ld0 + (c & ~7) + ((c & 4) >> 1);
+            *reinterpret_cast<float2*>(o) = make_float2(v.x, v.z);
+            *reinterpret_cast<float2*>(o + 4) = make_float2(v.y, v.w);
+        }
+    }
+    __syncthreads();
     int layer = 0, bias_at = 0, bias_layer = 0;
 
     while (cu.layer < nl) {
@@ -378,7 +458,9 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
             ++layer;
         }
         stamp();
-        const C32Layer Ly = c32_layer(p.L[cu.layer]);
+        C32Layer Ly = c32_layer(p.L[cu.layer]);
+        if (Ly.out_f32) Ly.out_f32 += so * Ly.ldc;
+        if (Ly.mask) Ly.mask += so * Ly.ldmask;
         while (bias_layer < cu.layer) bias_at += p.L[bias_layer++].n;
         const float* A = (cu.layer & 1) ? buf1 : buf0;
         const int lda = (cu.layer & 1) ? p.ld1 : p.ld0;
@@ -427,6 +509,17 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
         c32_barrier();
         ++layer;
     }
+    if (p.iaf.mode == 1) {
+        // the IAF update behind the pass: the workgroup's [mu | alpha] rows are read back (drained stores), x_new is the next pass's
+        // input slice -- or x_out behind the launch's last pass
+        __syncthreads();
+        const int d = p.iaf.d;
+        const bool to_out = s + 1 == n_pass && (p.iaf.flags & 1);
+        c32_update_fwd(p.iaf.z, Llast.out_f32 + so * Llast.ldc, Llast.ldc, xs, p.ldx, p.iaf.colcount + (step > 0 ? s : -s) * d,
+                       to_out ? p.iaf.x_out : xs + step * p.ldx, to_out ? d : p.ldx, m0, p.m, d);
+    }
+    if (s + 1 < n_pass) __syncthreads();          // the next pass reads what this one stored, and reuses the LDS tiles
+  }
     stamp();
 }
 
@@ -589,8 +682,37 @@ extern "C" int gv_made_chain_f32_plan(int n_layers, const int32_t* n_of_layer, c
     return launch_status("gv_made_chain_f32_plan");
 }
 
+static int made_chain_f32(float* x, int ldx, int m, int n_layers, const gv_chain32_layer* layers, const int32_t* plan,
+                          const int32_t* rows_dev, const gv_chain32_iaf* iaf, void* stream);
+
 extern "C" int gv_made_chain_f32(const float* x, int ldx, int m, int n_layers, const gv_chain32_layer* layers, const int32_t* plan,
                                  const int32_t* rows_dev, void* stream) {
+    return made_chain_f32(const_cast<float*>(x), ldx, m, n_layers, layers, plan, rows_dev, nullptr, stream);
+}
+
+extern "C" int gv_made_passes_f32(float* x, int ldx, int m, int n_layers, const gv_chain32_layer* layers, const int32_t* plan,
+                                  const int32_t* rows_dev, const gv_chain32_iaf* iaf, void* stream) {
+    GV_REQUIRE(iaf && (iaf->mode == 1 || iaf->mode == 2) && iaf->passes >= 1 && iaf->d > 0 && iaf->d % 4 == 0, GV_ERR_SHAPE,
+               "gv_made_passes_f32: mode 1 / 2, passes >= 1, d %% 4 == 0");
+    GV_REQUIRE(iaf->z && iaf->colcount && aligned16(iaf->z) && aligned16(iaf->colcount), GV_ERR_NULL, "gv_made_passes_f32: z / colcount");
+    GV_REQUIRE(n_layers >= 1 && n_layers <= C32_L && layers, GV_ERR_SHAPE, "gv_made_passes_f32: n_layers=%d", n_layers);
+    const gv_chain32_layer& last = layers[n_layers - 1];
+    if (iaf->mode == 1) {
+        GV_REQUIRE(layers[0].k == iaf->d && last.n == 2 * iaf->d && last.out_f32 && !last.accumulate && ldx >= iaf->d, GV_ERR_SHAPE,
+                   "gv_made_passes_f32 (forward): the chain maps d -> [mu | alpha] (2 d, stored), ldx >= d");
+        GV_REQUIRE(!(iaf->flags & 1) || (iaf->x_out && aligned16(iaf->x_out)), GV_ERR_NULL, "gv_made_passes_f32 (forward): x_out");
+    } else {
+        GV_REQUIRE(layers[0].k == 2 * iaf->d && last.n == iaf->d && last.out_f32 && last.accumulate && ldx >= 2 * iaf->d, GV_ERR_SHAPE,
+                   "gv_made_passes_f32 (backward): the chain maps [g_mu | g_alpha] (2 d) -> d, the last layer accumulates, ldx >= 2 d");
+        GV_REQUIRE(iaf->net && iaf->g_in && iaf->g_z && iaf->ld_net >= 2 * iaf->d && iaf->ld_net % 4 == 0 && aligned16(iaf->net) &&
+                   aligned16(iaf->g_in) && aligned16(iaf->g_z) && (!(iaf->flags & 1) || iaf->g_logdet), GV_ERR_NULL,
+                   "gv_made_passes_f32 (backward): net / g_in / g_z / g_logdet");
+    }
+    return made_chain_f32(x, ldx, m, n_layers, layers, plan, rows_dev, iaf, stream);
+}
+
+static int made_chain_f32(float* x, int ldx, int m, int n_layers, const gv_chain32_layer* layers, const int32_t* plan,
+                          const int32_t* rows_dev, const gv_chain32_iaf* iaf, void* stream) {
     GV_REQUIRE(m >= 0 && n_layers >= 1 && n_layers <= C32_L, GV_ERR_SHAPE, "gv_made_chain_f32: m=%d n_layers=%d", m, n_layers);
     if (m == 0) return GV_OK;
     GV_REQUIRE(x && layers && plan, GV_ERR_NULL, "gv_made_chain_f32: NULL pointer");
@@ -611,6 +733,8 @@ extern "C" int gv_made_chain_f32(const float* x, int ldx, int m, int n_layers, c
                "gv_made_chain_f32: widths are multiples of 8 (n <= %d, k <= 512), k = the previous layer's n, two LDS tiles <= 160 KB",
                32 * C32_MAXT);
     p.x = x; p.ldx = ldx; p.m = m; p.n_layers = n_layers; p.plan = plan; p.rows_dev = rows_dev;
+    if (iaf) p.iaf = *iaf;
+    else { p.iaf = gv_chain32_iaf(); p.iaf.mode = 0; p.iaf.passes = 1; }
     { const char* e = getenv("GV_C32_DEBUG"); p.debug = e ? atoi(e) : 0; }
     size_t widths = 0;
     for (int i = 0; i < n_layers; ++i) widths += (size_t)ns[i];

@@ -85,6 +85,7 @@ SIGNATURES = {
     'gv_made_chain_f32_fits': (_I, [_I, _P, _P]),
     'gv_made_chain_f32_plan': (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),
     'gv_made_chain_f32': (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    'gv_made_passes_f32': (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P]),
     'gv_made_gradw_f32_plan_words': (_L, [_I, _I]),
     'gv_made_gradw_f32_plan': (_I, [_P, _I, _I, _I, _P, _P]),
     'gv_made_gradw_f32_workspace_floats': (_L, [_I, _I, _L]),

@@ -112,7 +112,14 @@ class _MADEForward(torch.autograd.Function):
                 nxt = xin[p * n + r0:p * n + r1] if p + 1 < P else x_out[r0:r1]
                 lib.call('gv_iaf_update_fwd', ptr(z[r0:r1]), ptr(inp), 2 * d, ptr(xin[a:b]), ptr(colcount[p]), ptr(nxt), r1 - r0, d,
                          lib.stream())
-        if chain:       # MFMA-bound launches that fill the chip: one sequence over all rows (and the padding rows are skipped per workgroup)
+        fused_passes = chain and MADE_PASSES_F32 and d % 4 == 0 and lib.TIMER is None
+        if fused_passes:
+            # ONE launch for passes 1 .. P-1 and their IAF updates: everything a pass does is local to a workgroup's 64 rows, so the
+            # workgroup walks the passes itself (stacked buffers: n rows per pass); 12 launches per MADE become 2
+            made_passes_f32(xin, n, [dict(w_packed=packed[l][0], n=widths[l], k=kin[l], bias=bs[l], relu=l < L - 1, out_f32=acts[l][0:n])
+                                     for l in range(L)], plan_f,
+                            dict(mode=1, passes=S, step=n, d=d, z=z, colcount=colcount[1], x_out=x_out, flags=1), tag='madechain_fwd_f32')
+        elif chain:       # MFMA-bound launches that fill the chip: one sequence over all rows (and the padding rows are skipped per workgroup)
             passes(0, n)
         else:
             _by_row_blocks(passes, n, MADE_F32_ROW_BLOCKS, MADE_F32_ROW_BLOCKS_MIN_TILES)
@@ -149,7 +156,9 @@ class _MADEForward(torch.autograd.Function):
         acc_gz = d % 4 == 0 and P > 1                             # the update's backward adds dL/dz in place; the first pass run WRITES it
         g_z = torch.empty(n, d, **f32) if acc_gz else torch.zeros(n, d, **f32)
         gz_p = None if acc_gz else torch.empty(n, d, **f32)
-        g_olds = {p: torch.empty(n, d, **f32) for p in range(1, P)}      # dL/dx_old of every pass (allocated before any fork)
+        fused_passes = chain and MADE_PASSES_F32 and d % 4 == 0 and P > 1 and lib.TIMER is None
+        gold_stack = torch.empty(max(S, 1) * n, d, **f32)                 # dL/dx_old of every pass, stacked like the activations
+        g_olds = {p: gold_stack[(p - 1) * n:p * n] for p in range(1, P)}
 
         def passes(r0, r1):      # the backward of passes P-1 .. 1 for the rows [r0, r1): every launch is row-local
             g_in, m = gx, r1 - r0
@@ -179,7 +188,17 @@ class _MADEForward(torch.autograd.Function):
                     else:       # gradient w.r.t. the pass's input x_p joins the update's pass-through gradient
                         gemm(grads[0][a:b], ws[0], out=g_old, accumulate=True, a_relu_mask=mask)
                 g_in = g_olds[p]
-        if chain:
+        if fused_passes:
+            # passes P-1 .. 1, each = the update's backward + the backward-x chain, in ONE launch (the buffers of consecutive passes
+            # are n rows apart, walked downwards)
+            a0 = (S - 1) * n
+            made_passes_f32(grads[L - 1][a0:a0 + n], n,
+                            [dict(w_packed=wpb[l], n=kin[l], k=widths[l], mask=acts[l - 1][a0:a0 + n], out_f32=grads[l - 1][a0:a0 + n])
+                             for l in reversed(range(1, L))] +
+                            [dict(w_packed=wpb[0], n=d, k=widths[0], out_f32=gold_stack[a0:a0 + n], accumulate=True)], plan_b,
+                            dict(mode=2, passes=S, step=-n, d=d, z=z, colcount=colcount[P - 1], net=acts[L - 1][a0:a0 + n], g_in=gx,
+                                 g_logdet=gld, g_z=g_z, flags=(1 if gld is not None else 0) | 2), tag='madechain_bwd_f32')
+        elif chain:
             passes(0, n)
         else:
             _by_row_blocks(passes, n, MADE_F32_ROW_BLOCKS, MADE_F32_ROW_BLOCKS_MIN_TILES)
@@ -655,6 +674,41 @@ def made_gradw_f32(g, a, wmask=None, g0=None, g0_act=None, a0=None, out=None, ac
     lib.call('gv_made_gradw_f32', ptr(g), ldg, ptr(a), lda, int(m), int(n), int(k), ptr(plan), ptr(wmask), ldw, ptr(g0), ptr(g0_act), ptr(a0),
              ptr(out), out.stride(0), 1 if accumulate else 0, ptr(db), 1 if db_accumulate else 0, ptr(ws), nws, lib.stream())
     return out, db
+
+
+class _Chain32Iaf(_ct.Structure):
+    """gv_chain32_iaf of include/gcnvae.h."""
+    _fields_ = [('mode', _ct.c_int32), ('passes', _ct.c_int32), ('d', _ct.c_int32), ('flags', _ct.c_int32), ('step', _ct.c_int64),
+                ('z', _ct.c_void_p), ('colcount', _ct.c_void_p), ('x_out', _ct.c_void_p), ('net', _ct.c_void_p), ('g_in', _ct.c_void_p),
+                ('g_logdet', _ct.c_void_p), ('g_z', _ct.c_void_p), ('ld_net', _ct.c_int32), ('reserved', _ct.c_int32)]
+
+
+MADE_PASSES_F32 = _os.environ.get('GV_MADE_PASSES_F32', '1') == '1'      # all stacked passes of a MADE + the IAF updates in ONE launch per direction
+
+
+def made_passes_f32(x, m, layers, plan, iaf, tag=None):
+    """Several passes of a MADE in one launch with the IAF update fused in (gv_made_passes_f32): ``layers`` as made_chain_f32, for the
+    launch's FIRST pass; ``iaf``: dict(mode=1 forward / 2 backward, passes, step (rows between passes in the stacked buffers, signed),
+    d, z, colcount (the first pass's counts), flags, and x_out (forward) / net, g_in, g_logdet, g_z (backward))."""
+    if tag is not None and lib.TIMER is not None:
+        MADE_CHAIN_FLOPS[tag] = 2.0 * int(m) * int(iaf['passes']) * sum(int(d_['n']) * int(d_['k']) for d_ in layers)
+    arr = (_Chain32Layer * len(layers))()
+    for c, d_ in zip(arr, layers):
+        mask, of = d_.get('mask'), d_.get('out_f32')
+        c.w_packed, c.bias, c.mask, c.out_f32 = ptr(d_['w_packed']), ptr(d_.get('bias')), ptr(mask), ptr(of)
+        c.n, c.k, c.relu, c.accumulate = int(d_['n']), int(d_['k']), 1 if d_.get('relu') else 0, 1 if d_.get('accumulate') else 0
+        c.ldmask = mask.stride(0) if mask is not None else 0
+        c.ldc = of.stride(0) if of is not None else 0
+    ia = _Chain32Iaf()
+    ia.mode, ia.passes, ia.d, ia.flags, ia.step = int(iaf['mode']), int(iaf['passes']), int(iaf['d']), int(iaf.get('flags', 0)), int(iaf['step'])
+    ia.z, ia.colcount, ia.x_out = ptr(iaf['z']), ptr(iaf['colcount']), ptr(iaf.get('x_out'))
+    net = iaf.get('net')
+    ia.net, ia.ld_net = ptr(net), net.stride(0) if net is not None else 0
+    ia.g_in, ia.g_logdet, ia.g_z = ptr(iaf.get('g_in')), ptr(iaf.get('g_logdet')), ptr(iaf.get('g_z'))
+    live = _ops.LIVE_ROWS
+    rows_dev = live[0] if (live is not None and int(m) == live[1] and x.device == live[0].device) else None
+    lib.call('gv_made_passes_f32', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), ptr(plan), ptr(rows_dev), _ct.addressof(ia),
+             lib.stream(), tag=tag)
 
 
 def _made_params_work(masks, ws, bs, d, S):

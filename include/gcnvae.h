@@ -361,6 +361,35 @@ int gv_made_chain_f32_plan(int n_layers, const int32_t* n_of_layer, const int32_
                            const int32_t* ldmask, const int32_t* transposed, int32_t* plan, void* stream);
 int gv_made_chain_f32(const float* x, int ldx, int m, int n_layers, const gv_chain32_layer* layers, const int32_t* plan,
                       const int32_t* rows_dev, void* stream);
+/* Several PASSES of a MADE in one launch, with the IAF update (kgvae/flow_network.py:92-97) fused in: everything a pass does is
+ * local to a workgroup's 64 rows -- the chain, the update x_new = count > 0 ? z * expf(alpha + mu) : x_old behind it (forward),
+ * the update's backward in front of it (backward) -- so the workgroup loops over the passes itself; the buffers of consecutive
+ * passes are `step` rows apart (stacked over the passes: forward step = +n, backward step = -n, n = rows of one pass).
+ * Pass s of the launch uses every layer's out_f32 / mask advanced by s * step rows.
+ *   mode 1 (forward): x = the first pass's input slice [m][ldx >= d]; the last layer is [mu | alpha] (n = 2 d, out_f32 required);
+ *     after pass s:  x_new -> x + (s + 1) * step rows  (the next pass's input), or, for the launch's last pass with flags bit 0,
+ *     -> x_out [m][d].  colcount = the counts [d] of the first pass, the next pass's d entries further.
+ *   mode 2 (backward): x = the first pass's slice of the buffer that receives [g_mu | g_alpha] [m][ldx >= 2 d] (written by the
+ *     update's backward, then the chain's input; the weight gradient of the last layer reads it afterwards); net / ld_net = the
+ *     forward [mu | alpha] of the first pass; the last layer is the accumulating one (out_f32 = dL/dx_old of the pass, d wide):
+ *     the update's backward stores the handed-through gradient there, the chain adds to it; g_in = dL/dx_new of the first pass,
+ *     later passes take the previous pass's out_f32 slice; g_logdet (flags bit 0: [m], first pass only); g_z [m][d] += the
+ *     passes' shares (flags bit 1: the first pass WRITES it); colcount as above, the next pass's counts d entries BACK.
+ * Same arithmetic, element by element, as gv_iaf_update_fwd / gv_iaf_update_bwd_acc around gv_made_chain_f32 launches.  d % 4 == 0. */
+typedef struct gv_chain32_iaf {
+    int32_t mode, passes, d, flags;
+    int64_t step;
+    const float* z;
+    const int32_t* colcount;
+    float* x_out;
+    const float* net;
+    const float* g_in;
+    const float* g_logdet;
+    float* g_z;
+    int32_t ld_net, reserved;
+} gv_chain32_iaf;
+int gv_made_passes_f32(float* x, int ldx, int m, int n_layers, const gv_chain32_layer* layers, const int32_t* plan,
+                       const int32_t* rows_dev, const gv_chain32_iaf* iaf, void* stream);
 /* The weight gradient of one masked-MLP layer over all stacked passes, fp32 (autograd of kgvae/flow_network.py:13-14 under the
  * six-pass forward :85-98):   out[j][i] (+)= wmask[j][i] * ( sum_k g[k][j] a[k][i] + g0m[j] a0[i] ),   db[j] (+)= sum_k g[k][j] + g0m[j]
  * g [k][ldg] the gradient w.r.t. the layer's output (ReLU-masked already where the layer has a ReLU), a [k][lda] the layer's input,

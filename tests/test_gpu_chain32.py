@@ -126,8 +126,9 @@ def test_forward_and_backward_chains_equal_the_gemm_products_bit_for_bit(d, h, n
 
 @pytest.mark.parametrize('d,h,n_hidden,rows', [(200, 200, 3, 700), (40, 56, 2, 300)])
 def test_made_node_with_chains_equals_the_node_with_a_launch_per_product(monkeypatch, d, h, n_hidden, rows):
-    """The fp32 MADE node (made._MADEForward) with one chain launch per pass against GV_MADE_CHAIN_F32=0: x, log-det, dL/dz and every
-    parameter gradient bit for bit -- through plain autograd and with the gradients going straight into FlatAdam's arena."""
+    """The fp32 MADE node (made._MADEForward) with one chain launch per pass, and with ALL passes + their IAF updates in one launch
+    per direction (gv_made_passes_f32), against GV_MADE_CHAIN_F32=0: x, log-det, dL/dz and every parameter gradient bit for bit --
+    through plain autograd and with the gradients going straight into FlatAdam's arena."""
     from gcn_vae_amd import made
     from gcn_vae_amd.optim import FlatAdam
     z = torch.randn(rows, d, generator=torch.Generator().manual_seed(5)).cuda()
@@ -135,8 +136,9 @@ def test_made_node_with_chains_equals_the_node_with_a_launch_per_product(monkeyp
     monkeypatch.setattr(made, 'made_chain_f32', lambda *a, **k: (tags.append(k.get('tag')), inner(*a, **k))[1])
     for with_opt in (False, True):
         res = []
-        for on, gradw in ((False, False), (True, False), (True, True)):
+        for on, passes, gradw in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
             monkeypatch.setattr(made, 'MADE_CHAIN_F32', on)
+            monkeypatch.setattr(made, 'MADE_PASSES_F32', passes)     # all passes + the IAF updates in one launch per direction
             monkeypatch.setattr(made, 'MADE_GRADW_F32', gradw)       # (its own summation order: held to the others within fp32 rounding)
             monkeypatch.setattr(made, 'MADE_ROW_F32', False)         # (pass 0 as one launch sums in another order too: its own test below)
             m = _made(d, h, n_hidden)
@@ -148,15 +150,15 @@ def test_made_node_with_chains_equals_the_node_with_a_launch_per_product(monkeyp
             x, ld = m(zz)
             (x.sin().sum() + (ld * ld).sum()).backward()
             torch.cuda.synchronize()
-            assert (len(tags) == 2 * (len(m.m) - 1)) == on, (on, tags)
+            assert len(tags) == (2 * (len(m.m) - 1) if (on and not passes) else 0), (on, passes, tags)
             res.append((x.detach().clone(), ld.detach().clone(), zz.grad.clone(), [p.grad.detach().clone() for p in m.parameters()]))
             if opt is not None:
                 opt.close()
         for other in res[1:]:
             assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1]) and torch.equal(res[0][2], other[2])
         assert torch.isfinite(res[0][2]).all() and float(res[0][2].abs().max()) > 0
-        for a, b, c in zip(res[0][3], res[1][3], res[2][3]):
-            assert torch.equal(a, b) and float(a.abs().max()) > 0
+        for a, b, b2, c in zip(res[0][3], res[1][3], res[2][3], res[3][3]):
+            assert torch.equal(a, b) and torch.equal(a, b2) and float(a.abs().max()) > 0
             torch.testing.assert_close(c, a, rtol=2e-5, atol=2e-6 * float(a.abs().max()))
             assert bool(((a == 0) == (c == 0)).all()) or a.dim() == 1          # the masked-out entries are exact zeros in both
 
@@ -243,3 +245,29 @@ def test_made_node_with_pass_0_as_single_workgroup_launches(monkeypatch, d, h, n
         torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6 * float(a.abs().max()))
     for a, b in zip(res[0][3], res[1][3]):
         torch.testing.assert_close(b, a, rtol=5e-5, atol=5e-6 * float(a.abs().max()))
+
+
+def test_fused_passes_on_a_padded_batch_equal_the_launch_per_pass_path(monkeypatch):
+    """ops.live_rows with the fused passes: workgroups that hold only padding rows skip the layers (zeros out) but still run the
+    IAF updates of their rows, exactly as the per-pass launches + update kernels do -- whole node, bit for bit, forward and backward."""
+    from gcn_vae_amd import made, ops
+    d, h, rows, live = 40, 56, 400, 150
+    z = torch.randn(rows, d, generator=torch.Generator().manual_seed(2)).cuda()
+    rows_dev = torch.tensor([live], dtype=torch.int32, device='cuda')
+    res = []
+    for passes in (False, True):
+        monkeypatch.setattr(made, 'MADE_PASSES_F32', passes)
+        monkeypatch.setattr(made, 'MADE_GRADW_F32', False)
+        monkeypatch.setattr(made, 'MADE_ROW_F32', False)
+        m = _made(d, h, 2)
+        zz = z.clone().requires_grad_(True)
+        with ops.live_rows(rows_dev, rows):
+            x, ld = m(zz)
+            w = torch.zeros(rows, 1, device='cuda')
+            w[:live] = 1.0                      # the padding rows take no part in the loss
+            ((x * w).sin().sum() + ((ld * w.view(-1)) ** 2).sum()).backward()
+        torch.cuda.synchronize()
+        res.append((x.detach().clone(), ld.detach().clone(), zz.grad.clone(), [p.grad.detach().clone() for p in m.parameters()]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    for a, b in zip(res[0][3], res[1][3]):
+        assert torch.equal(a, b) and float(a.abs().max()) > 0
