@@ -35,23 +35,31 @@ typedef float f32x16c __attribute__((ext_vector_type(16)));
 
 constexpr int C32_BM = 64;          // rows per workgroup
 constexpr int C32_LISTS = 4;        // unit lists of a plan: one per SIMD
-constexpr int C32_WAVES = 8;        // two per SIMD: waves w and w + 4 take the even / odd entries of list w & 3 and hide each
-                                    // other's fragment loads and epilogues (a workgroup's waves go to the SIMDs cyclically)
+#ifndef GV_C32_FINE
+#define GV_C32_FINE 0           /* 0 (default): units of 64 rows x 32 columns (two accumulators sharing the weight fragment), 8 waves =
+                                 * 2 per SIMD, 25-group fragment sets.  1: units of 32 x 32 (ONE accumulator, the unit carries its row
+                                 * half), 16 waves = 4 per SIMD, 13-group sets -- finer balance and shorter epilogues, but every
+                                 * weight fragment is fetched twice and a unit is two chunks: measured 85 / 85 us per pass against
+                                 * 76 / 83 (forward / backward-x), the step 5.31 vs 5.34 ms: not worth its 40 B of scratch.
+                                 * (A third form -- the two waves of a SIMD sharing every 64 x 32 unit by row half, i.e. two
+                                 * single-accumulator chains per SIMD -- ran 92 us: ~780 cycles per pair of groups instead of 512.) */
+#endif
+constexpr bool C32_SINGLE = GV_C32_FINE != 0;             // one accumulator per unit: the unit carries its row half
+constexpr int C32_WAVES = GV_C32_FINE ? 16 : 8;           // waves w, w + 4, ... share a SIMD (a workgroup's waves go to the SIMDs
+                                                          // cyclically) and take every (WAVES / 4)-th entry of list w & 3
+constexpr int C32_SLOTS = C32_WAVES / 4;
 constexpr int C32_THREADS = C32_WAVES * 64;
 constexpr int C32_L = GV_CHAIN_MAX_LAYERS;
 constexpr int C32_MAXT = GV_CHAIN32_MAX_TILES;            // column tiles per layer (n <= 512)
-constexpr int C32_MAXU = C32_L * C32_MAXT;                // units per list
-#ifndef GV_C32_SPLIT
-#define GV_C32_SPLIT 0          /* 1: the two waves of a SIMD share every unit -- rows 0..31 / 32..63 -- instead of alternating units.
-                                 * Measured WORSE (76 -> 92 us per pass): one accumulator per wave = two dependent MFMA chains per
-                                 * SIMD, ~780 cycles per pair of groups instead of 512; the alternating form has four chains in
-                                 * flight while both waves compute and two (620-670 cycles per group) while one runs alone. */
-#endif
-constexpr int C32_CHG = 25;         // groups per register set of weight fragments (200 of k: a 200-wide layer's unit is ONE chunk)
-// plan words: [0, 4) units per list; then 4 lists of C32_MAXU (layer << 8 | tile); then [layer][tile] group sets (lo, hi)
+constexpr int C32_MAXU = 2 * C32_L * C32_MAXT;            // units per list in the plan buffer (global memory)
+constexpr int C32_MAXU_LDS = 96;                          // ... of a chain that is launched (checked on the host): the LDS copy
+constexpr int C32_CHG = GV_C32_FINE ? 13 : 25;            // groups per register set of weight fragments
+// plan words: [0, 4) units per list; then 4 lists of C32_MAXU (layer << 8 | half << 7 | tile); then [layer][tile] group sets (lo, hi)
 constexpr int C32_PLAN_LISTS = 4, C32_PLAN_SETS = C32_PLAN_LISTS + C32_LISTS * C32_MAXU;
 constexpr int C32_PLAN_WORDS = C32_PLAN_SETS + 2 * C32_L * C32_MAXT;
 static_assert(C32_PLAN_WORDS == GV_CHAIN32_PLAN_WORDS, "include/gcnvae.h states the plan size");
+// the LDS copy is compact: counts, 4 lists of C32_MAXU_LDS, the group sets
+constexpr int C32_LPLAN_SETS = C32_PLAN_LISTS + C32_LISTS * C32_MAXU_LDS, C32_LPLAN_WORDS = C32_LPLAN_SETS + 2 * C32_L * C32_MAXT;
 
 struct Chain32Args {
     float* x;                    // [m][ldx]: input of layer 0 (passes: the first pass's slice of the stacked inputs)
@@ -78,21 +86,23 @@ __device__ __forceinline__ void c32_barrier() {
 
 struct C32Unit {
     int ui;                      // index into the list
-    int layer, tile;
+    int layer, tile, half;       // half: rows 32 half .. 32 half + 31 of the tile (single-accumulator units)
     unsigned long long set;      // groups of the unit
 };
 
-// load entry `ui` of a list (layer = n_layers when the list is exhausted)
+// load entry `ui` of a list (layer = n_layers when the list is exhausted); plan = the compact LDS copy
 __device__ __forceinline__ void c32_open(const int32_t* plan, int n_layers, const int32_t* list, int nu, C32Unit& c) {
     if (c.ui < nu) {
         const int e = sload(list + c.ui);
         c.layer = e >> 8;
-        c.tile = e & 0xff;
-        const int32_t* s = plan + C32_PLAN_SETS + 2 * (c.layer * C32_MAXT + c.tile);
+        c.tile = e & 0x7f;
+        c.half = (e >> 7) & 1;
+        const int32_t* s = plan + C32_LPLAN_SETS + 2 * (c.layer * C32_MAXT + c.tile);
         c.set = (unsigned long long)(unsigned)sload(s) | ((unsigned long long)(unsigned)sload(s + 1) << 32);
     } else {
         c.layer = n_layers;
         c.tile = 0;
+        c.half = 0;
         c.set = 0ull;
     }
 }
@@ -124,7 +134,8 @@ __device__ __forceinline__ void c32_issue(float4 (&q)[C32_CHG], const float4* ba
 __device__ __forceinline__ unsigned long long c32_mma(f32x16c& acc0, f32x16c& acc1, const float4 (&q)[C32_CHG], const float* a_lo,
                                                       const float* a_hi, unsigned long long left) {
     int g = __builtin_ctzll(left);
-    float4 a0 = *reinterpret_cast<const float4*>(a_lo + 8 * g), a1 = *reinterpret_cast<const float4*>(a_hi + 8 * g);
+    float4 a0 = *reinterpret_cast<const float4*>(a_lo + 8 * g), a1 = a0;
+    if (!C32_SINGLE) a1 = *reinterpret_cast<const float4*>(a_hi + 8 * g);
 #pragma unroll
     for (int i = 0; i < C32_CHG; ++i)
         if (left != 0ull) {
@@ -133,16 +144,16 @@ __device__ __forceinline__ unsigned long long c32_mma(f32x16c& acc0, f32x16c& ac
             if (i + 1 < C32_CHG && left != 0ull) {
                 g = __builtin_ctzll(left);
                 n0 = *reinterpret_cast<const float4*>(a_lo + 8 * g);
-                n1 = *reinterpret_cast<const float4*>(a_hi + 8 * g);
+                if (!C32_SINGLE) n1 = *reinterpret_cast<const float4*>(a_hi + 8 * g);
             }
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, q[i].x, acc0, 0, 0, 0);
-            if (!GV_C32_SPLIT) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, q[i].x, acc1, 0, 0, 0);
+            if (!C32_SINGLE) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, q[i].x, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, q[i].y, acc0, 0, 0, 0);
-            if (!GV_C32_SPLIT) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, q[i].y, acc1, 0, 0, 0);
+            if (!C32_SINGLE) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, q[i].y, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, q[i].z, acc0, 0, 0, 0);
-            if (!GV_C32_SPLIT) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, q[i].z, acc1, 0, 0, 0);
+            if (!C32_SINGLE) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, q[i].z, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, q[i].w, acc0, 0, 0, 0);
-            if (!GV_C32_SPLIT) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, q[i].w, acc1, 0, 0, 0);
+            if (!C32_SINGLE) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, q[i].w, acc1, 0, 0, 0);
             a0 = n0;
             a1 = n1;
             __builtin_amdgcn_sched_barrier(0);
@@ -204,9 +215,9 @@ __device__ __forceinline__ void c32_epilogue(const f32x16c& acc0, const f32x16c&
     const bool full = m0 + C32_BM <= m && tile * 32 + 32 <= Ly.n;         // (wave-uniform) every element of the unit exists
     // eight rows at a time: the next unit's fragments (100 registers) may be in flight through all of this
 #pragma unroll
-    for (int mh = 0; mh < (GV_C32_SPLIT ? 2 : 4); ++mh) {
-        // (split: this wave's accumulator holds rows 32 half .. 32 half + 31 of the tile)
-        const int mt = GV_C32_SPLIT ? half : mh >> 1, r0 = (mh & 1) * 8;
+    for (int mh = 0; mh < (C32_SINGLE ? 2 : 4); ++mh) {
+        // (single-accumulator units: the accumulator holds rows 32 half .. 32 half + 31 of the tile)
+        const int mt = C32_SINGLE ? half : mh >> 1, r0 = (mh & 1) * 8;
         float mk[8], old[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) mk[j] = 1.f, old[j] = 0.f;
@@ -243,7 +254,7 @@ __device__ __forceinline__ void c32_epilogue(const f32x16c& acc0, const f32x16c&
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float t = ((!GV_C32_SPLIT && mt) ? acc1[r0 + j] : acc0[r0 + j]) + bv;
+            float t = ((!C32_SINGLE && mt) ? acc1[r0 + j] : acc0[r0 + j]) + bv;
             if (Ly.relu) t = fmaxf(t, 0.f);
             if (masked) t = mk[j] > 0.f ? t : 0.f;
             v[j] = t;
@@ -366,9 +377,14 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
         asm volatile("" ::"s"(touch));
     }
     int32_t* const plan = reinterpret_cast<int32_t*>(c32_lds + C32_BM * (p.ld0 + p.ld1));
-    for (int i = threadIdx.x; i < C32_PLAN_WORDS; i += C32_THREADS) plan[i] = p.plan[i];
+    for (int i = threadIdx.x; i < C32_LPLAN_WORDS; i += C32_THREADS) {         // counts, the used head of every list, the group sets
+        int src = i;
+        if (i >= C32_LPLAN_SETS) src = C32_PLAN_SETS + (i - C32_LPLAN_SETS);
+        else if (i >= C32_PLAN_LISTS) src = C32_PLAN_LISTS + ((i - C32_PLAN_LISTS) / C32_MAXU_LDS) * C32_MAXU + (i - C32_PLAN_LISTS) % C32_MAXU_LDS;
+        plan[i] = p.plan[src];
+    }
     // every layer's bias behind it (no global round trip in an epilogue); bias_at[l] = where layer l's starts
-    float* const bias_lds = reinterpret_cast<float*>(plan + C32_PLAN_WORDS);
+    float* const bias_lds = reinterpret_cast<float*>(plan + C32_LPLAN_WORDS);
     {
         int at = 0;
         for (int l = 0; l < nl; ++l) {
@@ -389,7 +405,7 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
     };
     stamp();
     const int nu = sload(plan + (wave & 3));
-    const int32_t* const list = plan + C32_PLAN_LISTS + (wave & 3) * C32_MAXU;
+    const int32_t* const list = plan + C32_PLAN_LISTS + (wave & 3) * C32_MAXU_LDS;
     const float4* const any_b = reinterpret_cast<const float4*>(p.L[0].w_packed);      // a readable address for idle loads
 
     // where a unit's fragments start (its tile's group 0, this lane's slot)
@@ -402,13 +418,13 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
         }
     };
 
-    const int half = wave >> 2;
+    const int slot = wave >> 2;          // this wave takes entries slot, slot + C32_SLOTS, ... of its SIMD's list
     float4 q[C32_CHG];
   for (int s = 0; s < n_pass; ++s) {
     const long long so = (long long)s * step;            // rows from the first pass's slices to this pass's
     float* const xs = p.x + so * p.ldx;
     // the first unit's weight fragments are requested before the pass's element-wise front
-    C32Unit cu = {GV_C32_SPLIT ? 0 : half, 0, 0, 0ull};
+    C32Unit cu = {slot, 0, 0, 0, 0ull};
     c32_open(plan, nl, list, padding ? 0 : nu, cu);
     {
         const float4* b0;
@@ -477,14 +493,14 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
         for (;;) {
             c32_landed(q, off);
             if (p.debug & 4) left = 0ull;
-            else left = c32_mma(acc0, acc1, q, A + ((GV_C32_SPLIT ? 32 * half : 0) + ra) * lda + 4 * ha, A + (32 + ra) * lda + 4 * ha, left);
+            else left = c32_mma(acc0, acc1, q, A + ((C32_SINGLE ? 32 * cu.half : 0) + ra) * lda + 4 * ha, A + (32 + ra) * lda + 4 * ha, left);
             if (left == 0ull) break;
             c32_issue(q, b0, off, left);          // a unit of more than C32_CHG groups: its next chunk
         }
         // the wave's next unit: its fragments are requested now and land during the epilogue, the barrier and -- mostly -- the
         // OTHER wave of this SIMD's unit
         stamp();
-        C32Unit nx = {cu.ui + (GV_C32_SPLIT ? 1 : 2), 0, 0, 0ull};
+        C32Unit nx = {cu.ui + C32_SLOTS, 0, 0, 0, 0ull};
         c32_open(plan, nl, list, nu, nx);
         const float4* nb0;
         unsigned noff;
@@ -498,8 +514,8 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
         {
             float* const An = ((cu.layer + 1) & 1) ? buf1 : buf0;
             const int ldn = ((cu.layer + 1) & 1) ? p.ld1 : p.ld0;
-            if (loads_in_epilogue) c32_epilogue<true>(acc0, acc1, Ly, cu.tile, m0, p.m, cu.layer + 1 < nl ? An : nullptr, ldn, bias_lds + bias_at, l31, lhi, p.debug, half);
-            else c32_epilogue<false>(acc0, acc1, Ly, cu.tile, m0, p.m, cu.layer + 1 < nl ? An : nullptr, ldn, bias_lds + bias_at, l31, lhi, p.debug, half);
+            if (loads_in_epilogue) c32_epilogue<true>(acc0, acc1, Ly, cu.tile, m0, p.m, cu.layer + 1 < nl ? An : nullptr, ldn, bias_lds + bias_at, l31, lhi, p.debug, cu.half);
+            else c32_epilogue<false>(acc0, acc1, Ly, cu.tile, m0, p.m, cu.layer + 1 < nl ? An : nullptr, ldn, bias_lds + bias_at, l31, lhi, p.debug, cu.half);
         }
         if (loads_in_epilogue && !(p.debug & 8)) c32_issue(q, nb0, noff, nx.set);
         stamp();
@@ -600,6 +616,12 @@ __global__ __launch_bounds__(256) void k_chain32_plan(const Plan32Args p) {
                 for (int c = 1; c < C32_LISTS; ++c) if (load[c] < load[w]) w = c;
                 load[w] += cost[order[i]] + 1;          // (+ 1: a unit's epilogue is worth about a group)
                 lists[w * C32_MAXU + cnt[w]++] = (l << 8) | order[i];
+                if (C32_SINGLE) {                       // the tile's second row half: its own unit, to the list that is least loaded now
+                    int w2 = 0;
+                    for (int c = 1; c < C32_LISTS; ++c) if (load[c] < load[w2]) w2 = c;
+                    load[w2] += cost[order[i]] + 1;
+                    lists[w2 * C32_MAXU + cnt[w2]++] = (l << 8) | 0x80 | order[i];
+                }
             }
         }
         for (int w = 0; w < C32_LISTS; ++w) p.plan[w] = cnt[w];
@@ -651,7 +673,10 @@ static bool c32_pitches(int n_layers, const int32_t* n_of_layer, const int32_t* 
     *ld1 = w1 ? w1 + 4 : 0;
     size_t widths = 0;
     for (int i = 0; i < n_layers; ++i) widths += (size_t)n_of_layer[i];       // the biases
-    return (size_t)C32_BM * (*ld0 + *ld1) * sizeof(float) + C32_PLAN_WORDS * sizeof(int32_t) + widths * sizeof(float) <= 160 * 1024;
+    size_t units = 0;
+    for (int i = 0; i < n_layers; ++i) units += (size_t)((n_of_layer[i] + 31) / 32) * (C32_SINGLE ? 2 : 1);
+    if (units > (size_t)C32_MAXU_LDS) return false;          // (every list of the plan then fits its LDS copy)
+    return (size_t)C32_BM * (*ld0 + *ld1) * sizeof(float) + C32_LPLAN_WORDS * sizeof(int32_t) + widths * sizeof(float) <= 160 * 1024;
 }
 
 /* 1 when gv_made_chain_f32 can run this chain (widths are multiples of 8, n <= 32 GV_CHAIN32_MAX_TILES, k <= 512; both LDS tiles fit) */
@@ -738,7 +763,7 @@ static int made_chain_f32(float* x, int ldx, int m, int n_layers, const gv_chain
     { const char* e = getenv("GV_C32_DEBUG"); p.debug = e ? atoi(e) : 0; }
     size_t widths = 0;
     for (int i = 0; i < n_layers; ++i) widths += (size_t)ns[i];
-    const size_t lds = (size_t)C32_BM * (p.ld0 + p.ld1) * sizeof(float) + C32_PLAN_WORDS * sizeof(int32_t) + widths * sizeof(float);
+    const size_t lds = (size_t)C32_BM * (p.ld0 + p.ld1) * sizeof(float) + C32_LPLAN_WORDS * sizeof(int32_t) + widths * sizeof(float);
     static unsigned long long lds_done = 0;
     if (!raise_dynamic_lds((const void*)k_made_chain_f32, 160 * 1024, lds_done, "gv_made_chain_f32")) return GV_ERR_SHAPE;
     hipLaunchKernelGGL(k_made_chain_f32, dim3((unsigned)((m + C32_BM - 1) / C32_BM)), dim3(C32_THREADS), lds, (hipStream_t)stream, p);

@@ -545,7 +545,7 @@ class _Chain32Layer(_ct.Structure):
 
 MADE_CHAIN_F32 = _os.environ.get('GV_MADE_CHAIN_F32', '1') == '1'      # the fp32 node's passes as one launch each
 MADE_CHAIN_F32_SKIP = _os.environ.get('GV_MADE_CHAIN_F32_SKIP', '1') == '1'      # ... walking only the non-zero groups of the masks
-PLAN_WORDS = 4 + 4 * 8 * 16 + 2 * 8 * 16          # GV_CHAIN32_PLAN_WORDS
+PLAN_WORDS = 4 + 4 * 2 * 8 * 16 + 2 * 8 * 16          # GV_CHAIN32_PLAN_WORDS
 _chain32_plans = {}
 
 

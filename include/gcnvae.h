@@ -344,7 +344,7 @@ int gv_made_chain_debug_stamps(int32_t* buffer);
  * rows_dev (optional device scalar): rows [*rows_dev, m) are padding -- a 64-row workgroup that holds only padding stores zeros
  * to its non-accumulating outputs, as gv_gemm_f32_live_rows. */
 #define GV_CHAIN32_MAX_TILES 16
-#define GV_CHAIN32_PLAN_WORDS (4 + 4 * GV_CHAIN_MAX_LAYERS * GV_CHAIN32_MAX_TILES + 2 * GV_CHAIN_MAX_LAYERS * GV_CHAIN32_MAX_TILES)
+#define GV_CHAIN32_PLAN_WORDS (4 + 4 * 2 * GV_CHAIN_MAX_LAYERS * GV_CHAIN32_MAX_TILES + 2 * GV_CHAIN_MAX_LAYERS * GV_CHAIN32_MAX_TILES)
 typedef struct gv_chain32_layer {
     const float* w_packed;    /* B of this layer, fragment-packed: [tile of 32 columns][group of 8 k][lane 0..63] float4 =
                                * B[8 g + 2 i + (lane >> 5)][32 t + (lane & 31)], i = 0..3; zero outside B */

@@ -23,8 +23,8 @@ def _plan_words(plan):
     from gcn_vae_amd import made
     w = plan.cpu().numpy().astype(np.int64)
     assert w.size == made.PLAN_WORDS
-    counts, lists = w[:4], w[4:4 + 4 * 128].reshape(4, 128)
-    sets = w[4 + 4 * 128:].reshape(8, 16, 2)
+    counts, lists = w[:4], w[4:4 + 4 * 256].reshape(4, 256)
+    sets = w[4 + 4 * 256:].reshape(8, 16, 2)
     sets = (sets[..., 0] & 0xffffffff) | ((sets[..., 1] & 0xffffffff) << 32)
     return counts, lists, sets
 
@@ -48,7 +48,8 @@ def test_plan_lists_every_tile_once_and_its_group_sets_are_the_masks_nonzero_gro
         counts, lists, sets = _plan_words(plan)
         seen = set()
         for w in range(4):
-            units = [(int(e) >> 8, int(e) & 0xff) for e in lists[w, :counts[w]]]
+            units = [(int(e) >> 8, int(e) & 0x7f) for e in lists[w, :counts[w]]]          # (bit 7: the row half of a GV_C32_FINE build's units)
+            assert all(not (int(e) & 0x80) for e in lists[w, :counts[w]])
             assert units == sorted(units, key=lambda u: u[0]) or all(units[i][0] <= units[i + 1][0] for i in range(len(units) - 1))
             for u in units:
                 assert u not in seen

@@ -31,7 +31,7 @@ ts = big[made.PLAN_WORDS:].cpu().numpy().astype('int64').reshape(8, 64) & 0xffff
 plan = big[:made.PLAN_WORDS].cpu().numpy()
 t0 = ts[:, 0].min()
 for w in range(8):
-    lst = plan[4 + (w & 3) * 128: 4 + (w & 3) * 128 + plan[w & 3]][(w >> 2)::2]          # (GV_C32_SPLIT=1 builds: both waves walk the whole list)
+    lst = plan[4 + (w & 3) * 256: 4 + (w & 3) * 256 + plan[w & 3]][(w >> 2)::2]          # (GV_C32_SPLIT=1 builds: both waves walk the whole list)
     row = ts[w]
     n = int((row != 0).sum())
     rel = [(int(v) - int(t0)) & 0xffffffff for v in row[:n]]
@@ -39,7 +39,7 @@ for w in range(8):
     for i, e in enumerate(lst):
         b = 1 + 5 * i
         if b + 4 < n:
-            sets = plan[4 + 4 * 128 + 2 * ((e >> 8) * 16 + (e & 0xff))]
+            sets = plan[4 + 4 * 256 + 2 * ((e >> 8) * 16 + (e & 0x7f))]
             out.append(f'L{e >> 8}t{e & 0xff}: enter {rel[b]} mma {rel[b + 2] - rel[b + 1]} open+issue {rel[b + 3] - rel[b + 2]} epi {rel[b + 4] - rel[b + 3]} end {rel[b + 4]}')
     out.append(f'exit {rel[n - 1]}')
     print(f'wave {w}: ' + ' | '.join(out))
