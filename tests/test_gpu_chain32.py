@@ -272,3 +272,79 @@ def test_fused_passes_on_a_padded_batch_equal_the_launch_per_pass_path(monkeypat
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
     for a, b in zip(res[0][3], res[1][3]):
         assert torch.equal(a, b) and float(a.abs().max()) > 0
+
+
+def test_mean_rows_multi_is_flow_log_prob_and_its_gradient():
+    """ops.mean_rows_multi (gv_mean_rows_multi / _bwd) = mean over the rows that exist of the summed per-row log-determinants
+    (kgvae/model.py:116-123), against torch: all rows, a row limit (rows riding along behind the first n), a device row count."""
+    from gcn_vae_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    n, extra, live = 5000, 200, 3777
+    xs = [torch.randn(n + extra, generator=gen).cuda().requires_grad_(True) for _ in range(3)]
+    rows_dev = torch.tensor([live], dtype=torch.int32, device='cuda')
+    for limit, rd, count in ((None, None, n + extra), (n, None, n), (n, rows_dev, live)):
+        for x in xs:
+            x.grad = None
+        out = ops.mean_rows_multi(xs, n=limit, rows_dev=rd)
+        want = sum(x.detach().double()[:count] for x in xs).sum() / count
+        torch.testing.assert_close(out.double(), want, rtol=1e-5, atol=1e-6)
+        (out * 3.0).backward()
+        g = torch.zeros(n + extra, dtype=torch.float64, device='cuda')
+        g[:count] = 3.0 / count
+        for x in xs:
+            torch.testing.assert_close(x.grad.double(), g, rtol=1e-6, atol=0.0)
+
+
+def test_accumulating_update_backward_equals_the_two_launch_form():
+    """gv_iaf_update_bwd_acc (four columns per thread, dL/dz added in place or written) against gv_iaf_update_bwd + an add: every
+    output bit for bit, with and without a log-det gradient, with columns that are handed through (count 0) and counted twice."""
+    from gcn_vae_amd import lib
+    from gcn_vae_amd.lib import ptr
+    gen = torch.Generator().manual_seed(8)
+    n, d = 1000, 40
+    z, net, gx = (torch.randn(n, w, generator=gen).cuda() for w in (d, 2 * d, d))
+    net = net * 0.3
+    gld = torch.randn(n, generator=gen).cuda()
+    cnt = torch.ones(d, dtype=torch.int32, device='cuda')
+    cnt[-1], cnt[0] = 0, 2
+    for use_gld in (True, False):
+        gz_ref, gnet_ref, gold_ref = (torch.empty(n, w, device='cuda') for w in (d, 2 * d, d))
+        lib.call('gv_iaf_update_bwd', ptr(z), ptr(net), 2 * d, ptr(cnt), ptr(gx), ptr(gld) if use_gld else None, ptr(gz_ref), ptr(gnet_ref),
+                 ptr(gold_ref), n, d, lib.stream())
+        base = torch.randn(n, d, generator=gen).cuda()
+        for accumulate in (0, 1):
+            gz = base.clone()
+            gnet, gold = torch.empty(n, 2 * d, device='cuda'), torch.empty(n, d, device='cuda')
+            lib.call('gv_iaf_update_bwd_acc', ptr(z), ptr(net), 2 * d, ptr(cnt), ptr(gx), ptr(gld) if use_gld else None, ptr(gz), accumulate,
+                     ptr(gnet), ptr(gold), n, d, lib.stream())
+            assert torch.equal(gz, base + gz_ref if accumulate else gz_ref)
+            assert torch.equal(gnet, gnet_ref) and torch.equal(gold, gold_ref)
+    assert float(gold_ref[:, -1].abs().max()) > 0 and float(gold_ref[:, :-1].abs().max()) == 0
+
+
+def test_row_kernels_with_exact_fp32_operands_equal_one_row_products():
+    """gv_made_row_fwd / _bwd with layers[0].reserved = 1 (the fp32 node's pass 0): the masked MLP on ONE row and its backward with
+    exact fp32 operands, against the same chain as one-row products on gv_gemm_f32 (another summation order along k: fp32 rounding)."""
+    from gcn_vae_amd import made, ops
+    m = _made(200, 200, 3)
+    lin = m._linears()
+    L = len(lin)
+    ws = [ops.masked_weight(l.mask, l.weight).detach() for l in lin]
+    bs = [l.bias.detach() for l in lin]
+    acts = [torch.empty(1, w.shape[0], device='cuda') for w in ws]
+    made.made_row_fwd(None, [dict(w=ws[l], bias=bs[l], relu=l < L - 1, out=acts[l]) for l in range(L)], exact=True)
+    want, inp = [], torch.zeros(1, 200, device='cuda')
+    for l in range(L):
+        inp = ops.gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ops.ACT_RELU if l < L - 1 else ops.ACT_NONE)
+        want.append(inp)
+    for a, b in zip(acts, want):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    g_top = torch.randn(1, ws[-1].shape[0], generator=torch.Generator().manual_seed(1)).cuda()
+    gms = [torch.empty(1, w.shape[0], device='cuda') for w in ws]
+    made.made_row_bwd(g_top, [dict(w=ws[l], act=acts[l] if l < L - 1 else None, gb=gms[l]) for l in range(L)], exact=True)
+    g = g_top
+    for l in reversed(range(L)):
+        gm = g if l == L - 1 else torch.where(want[l] > 0, g, torch.zeros_like(g))
+        torch.testing.assert_close(gms[l], gm, rtol=1e-5, atol=1e-6 * float(gm.abs().max() + 1e-30))
+        if l > 0:
+            g = ops.gemm(gm, ws[l])
