@@ -1,8 +1,12 @@
 """K4: the masked MLP of the IAF blocks (kgvae/flow_network.py:62-98, MADE / MaskedLinear) as autograd nodes over the HIP entry
-points of csrc/k_made.hip, k_chain.hip, k_row.hip and k_gemm.hip.
+points of csrc/k_made.hip, k_chain.hip, k_chain32.hip, k_gradw32.hip, k_row.hip and k_gemm.hip.
 
   made_forward            MADE.forward as ONE node: _MADEForwardBF16 (bf16-stored operands, one gv_made_chain launch per pass, the
-                          IAF update in the chain's last layer; BASELINE configs[2]) or _MADEForward (fp32, a launch per product)
+                          IAF update in the chain's last layer; BASELINE configs[2]) or _MADEForward (fp32, the reference's own
+                          precision: all stacked passes + their IAF updates in one gv_made_passes_f32 launch per direction, weight
+                          and bias gradients on gv_made_gradw_f32, pass 0 on the row kernels; launch-per-product fallback)
+  made_chain_f32 / made_passes_f32 / made_gradw_f32 / made_pack_weights_f32 / made_*_plan   the fp32 K4 entry points (csrc/k_chain32.hip,
+                          k_gradw32.hip): zero groups / tiles of the masked weights are not multiplied
   made_prepare            the parameter-only part of the announced calls (mask folds, packed weights, pass 0's row) on a side stream
   made_chain / made_row_* / made_pack_weight* / gemm_bf16_* / cast_bf16 / dense_bf16*   thin wrappers of the C-ABI entry points
   _by_row_blocks          a node's passes over independent row blocks on their own streams
@@ -10,7 +14,6 @@ points of csrc/k_made.hip, k_chain.hip, k_row.hip and k_gemm.hip.
 Part of the ``ops`` namespace (ops re-exports everything here: callers keep writing ops.made_forward); the knobs of this file
 (MADE_*, GRADW_SPLIT_MAX, ...) are THIS module's globals.
 """
-import contextlib
 import ctypes as _ct
 import os as _os
 
@@ -19,7 +22,7 @@ import torch
 from . import lib
 from . import ops as _ops
 from .lib import ptr
-from .ops import (ACT_NONE, ACT_RELU, GRAD_FRESH, _chk, _direct, _process_group, _row_major, _side, _stamp_direct, _verify_direct,
+from .ops import (ACT_NONE, ACT_RELU, GRAD_FRESH, _chk, _direct, _row_major, _side, _stamp_direct, _verify_direct,
                   backward_side, colsum, gemm, iaf_bwd_row0, masked_weight, mul_multi, pick_split_k)
 
 
