@@ -29,10 +29,23 @@ struct GradW32Args {
     float* part;                 // [slices][mp][np]
     float* dbpart;               // [slices][mp] or NULL
     int ldg, lda, m, n, mp, np;
+    int slices, gy, gz, reserved;   // the product's share of the launch: slices x gy x gz workgroups (slice fastest)
     long long k, k_per_slice;
 };
 
-__global__ __launch_bounds__(GW_THREADS) void k_gradw32(const GradW32Args p) {
+// up to GW_MAXI products in ONE launch (the layers of a MADE): workgroups [first[q], first[q + 1]) belong to product q
+constexpr int GW_MAXI = 8;
+struct GradW32Multi {
+    int count, first[GW_MAXI + 1];
+    GradW32Args it[GW_MAXI];
+};
+
+__global__ __launch_bounds__(GW_THREADS) void k_gradw32(const GradW32Multi P) {
+    int q_ = 0;
+    while (q_ + 1 < P.count && (int)blockIdx.x >= P.first[q_ + 1]) ++q_;
+    const GradW32Args& p = P.it[q_];
+    const int local_ = (int)blockIdx.x - P.first[q_];
+    const int bx = local_ % p.slices, by = (local_ / p.slices) % p.gy, bz = local_ / (p.slices * p.gy);
     extern __shared__ __attribute__((aligned(16))) float gw_lds[];
     float* const Gs = gw_lds;                               // [2][KC][LD]
     float* const As = gw_lds + 2 * GW_KC * GW_LD;           // [2][KC][LD]
@@ -40,15 +53,16 @@ __global__ __launch_bounds__(GW_THREADS) void k_gradw32(const GradW32Args p) {
     __shared__ int ntiles;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int jt0 = blockIdx.y * GW_BT, it0 = blockIdx.z * GW_BT;           // first row / column tile of this block
+    const int jt0 = by * GW_BT, it0 = bz * GW_BT;           // first row / column tile of this block
     const int mt_all = (p.m + 31) >> 5, nt_all = (p.n + 31) >> 5;
     const int jts = min(GW_BT, mt_all - jt0), its = min(GW_BT, nt_all - it0);
-    if (threadIdx.x == 0) {
-        int c = 0;
-        for (int j = 0; j < jts; ++j)
-            for (int i = 0; i < its; ++i)
-                if (p.plan[(jt0 + j) * nt_all + it0 + i]) tiles[c++] = (j << 8) | i;
-        ntiles = c;
+    if (threadIdx.x < 64) {        // the block's active tiles, compacted in (j, i) order: one plan word per lane, ONE round trip
+        const int t = threadIdx.x, j = t / GW_BT, i = t - j * GW_BT;
+        const bool in = t < GW_BT * GW_BT && j < jts && i < its;
+        const bool on = in && p.plan[in ? (jt0 + j) * nt_all + it0 + i : 0] != 0;
+        const unsigned long long live = __ballot(on);
+        if (on) tiles[__popcll(live & ((1ull << t) - 1ull))] = (j << 8) | i;
+        if (t == 0) ntiles = __popcll(live);
     }
     __syncthreads();
     const int cnt = ntiles;
@@ -68,7 +82,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_gradw32(const GradW32Args p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const long long k0 = (long long)blockIdx.x * p.k_per_slice, k1 = min(p.k, k0 + p.k_per_slice);
+    const long long k0 = (long long)bx * p.k_per_slice, k1 = min(p.k, k0 + p.k_per_slice);
     const int j0 = jt0 * 32, i0 = it0 * 32;
     // ---- staging: chunk rows [kc, kc + KC) x the block's columns, 16-B pieces along the rows, zero outside the operands ----
     float4 rg[4], ra[4];
@@ -94,8 +108,8 @@ __global__ __launch_bounds__(GW_THREADS) void k_gradw32(const GradW32Args p) {
             }
         }
     };
-    float dbsum = 0.f;          // threads 0 .. 223 of the blocks with blockIdx.z == 0: column j0 + threadIdx.x of G
-    const bool do_db = p.dbpart && blockIdx.z == 0 && (int)threadIdx.x < GW_LD;
+    float dbsum = 0.f;          // threads 0 .. 223 of the blocks with bz == 0: column j0 + threadIdx.x of G
+    const bool do_db = p.dbpart && bz == 0 && (int)threadIdx.x < GW_LD;
     load_chunk(k0);
     int buf = 0;
     for (long long kc = k0; kc < k1; kc += GW_KC) {
@@ -104,16 +118,20 @@ __global__ __launch_bounds__(GW_THREADS) void k_gradw32(const GradW32Args p) {
         if (kc + GW_KC < k1) load_chunk(kc + GW_KC);           // the next chunk's loads fly under this chunk's MFMAs
         const float* G = Gs + buf * GW_KC * GW_LD + lhi * GW_LD + l31;
         const float* A = As + buf * GW_KC * GW_LD + lhi * GW_LD + l31;
-        // two slots at a time: two independent accumulator chains per wave (and two waves per SIMD)
+        // two slots at a time: two independent accumulator chains per wave (and two waves per SIMD); a wave's odd last slot runs
+        // as ONE chain (the SIMD's other wave fills the pipe) -- not as a repeated second tile that another MFMA per step pays for
 #define GW_PAIR(T0, T1)                                                                                         \
-        if (T0 < mine) {                                                                                        \
+        if (T1 < GW_TPW && T1 < mine) {                                                                         \
+            _Pragma("unroll") for (int s = 0; s < GW_KC / 2; ++s) {                                             \
+                const float g0_ = G[2 * s * GW_LD + tj[T0]], a0_ = A[2 * s * GW_LD + ti[T0]];                   \
+                const float g1_ = G[2 * s * GW_LD + tj[T1 < GW_TPW ? T1 : T0]], a1_ = A[2 * s * GW_LD + ti[T1 < GW_TPW ? T1 : T0]]; \
+                acc[T0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0_, a0_, acc[T0], 0, 0, 0);                     \
+                acc[T1 < GW_TPW ? T1 : T0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1_, a1_, acc[T1 < GW_TPW ? T1 : T0], 0, 0, 0); \
+            }                                                                                                   \
+        } else if (T0 < mine) {                                                                                 \
             _Pragma("unroll") for (int s = 0; s < GW_KC / 2; ++s) {                                             \
                 const float g0_ = G[2 * s * GW_LD + tj[T0]], a0_ = A[2 * s * GW_LD + ti[T0]];                   \
                 acc[T0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0_, a0_, acc[T0], 0, 0, 0);                     \
-                if (T1 < GW_TPW) {                                                                              \
-                    const float g1_ = G[2 * s * GW_LD + tj[T1 < GW_TPW ? T1 : T0]], a1_ = A[2 * s * GW_LD + ti[T1 < GW_TPW ? T1 : T0]]; \
-                    acc[T1 < GW_TPW ? T1 : T0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1_, a1_, acc[T1 < GW_TPW ? T1 : T0], 0, 0, 0); \
-                }                                                                                               \
             }                                                                                                   \
         }
         GW_PAIR(0, 1)
@@ -131,7 +149,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_gradw32(const GradW32Args p) {
         buf ^= 1;
     }
     // ---- the slice's partial tiles (only the wave's own slots), the bias partial ----
-    float* const part = p.part + (size_t)blockIdx.x * p.mp * p.np;
+    float* const part = p.part + (size_t)bx * p.mp * p.np;
 #pragma unroll
     for (int t = 0; t < GW_TPW; ++t)
         if (t < mine) {
@@ -141,14 +159,18 @@ __global__ __launch_bounds__(GW_THREADS) void k_gradw32(const GradW32Args p) {
                 part[(size_t)row * p.np + i0 + ti[t] + l31] = acc[t][r];
             }
         }
-    if (do_db && j0 + (int)threadIdx.x < p.mp) p.dbpart[(size_t)blockIdx.x * p.mp + j0 + threadIdx.x] = dbsum;
+    if (do_db && j0 + (int)threadIdx.x < p.mp) p.dbpart[(size_t)bx * p.mp + j0 + threadIdx.x] = dbsum;
 }
 
 struct GradW32Reduce {
     const float* part; const float* dbpart; const int32_t* plan;
     const float* wmask; const float* g0; const float* g0_act; const float* a0;
     float* out; float* db;
-    int m, n, mp, np, ldw, ldo, slices, accumulate, db_accumulate;
+    int m, n, mp, np, ldw, ldo, slices, accumulate, db_accumulate, blocks;     // blocks: the product's workgroups in the launch
+};
+struct GradW32ReduceMulti {
+    int count, first[GW_MAXI + 1];
+    GradW32Reduce it[GW_MAXI];
 };
 
 // out[j][i] (+)= wmask * (ordered sum of the slices' partials + g0m[j] a0[i]); db[j] (+)= ordered sum + g0m[j];
@@ -156,14 +178,18 @@ struct GradW32Reduce {
 // A workgroup owns 64 consecutive entries (of the m x n outputs, then of the m bias entries); its four waves each sum a quarter of
 // the slices in order (8 partials in flight, 4 chains, fixed combine), the quarters are added in order through LDS: 35 MB of
 // partials per 200 x 200 product are read by ~630 workgroups instead of 157 threads-in-series (27 -> ~9 us).
-__global__ __launch_bounds__(256) void k_gradw32_reduce(const GradW32Reduce p) {
+__global__ __launch_bounds__(256) void k_gradw32_reduce(const GradW32ReduceMulti P) {
+    int q_ = 0;
+    while (q_ + 1 < P.count && (int)blockIdx.x >= P.first[q_ + 1]) ++q_;
+    const GradW32Reduce& p = P.it[q_];
+    const int bx = (int)blockIdx.x - P.first[q_];
     __shared__ float sm[4][64];
     const int nt_all = (p.n + 31) >> 5;
     const size_t total = (size_t)p.m * p.n, slice = (size_t)p.mp * p.np;
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int per = (p.slices + 3) >> 2, z0 = q * per, z1 = min(p.slices, z0 + per);
     const size_t nblk_w = (total + 63) / 64;
-    for (size_t blk = blockIdx.x; blk < nblk_w + (size_t)(p.db ? (p.m + 63) / 64 : 0); blk += gridDim.x) {
+    for (size_t blk = bx; blk < nblk_w + (size_t)(p.db ? (p.m + 63) / 64 : 0); blk += p.blocks) {
         const bool is_b = blk >= nblk_w;
         const size_t e = (is_b ? blk - nblk_w : blk) * 64 + lane;
         const bool in = is_b ? e < (size_t)p.m : e < total;
@@ -250,37 +276,84 @@ extern "C" int gv_made_gradw_f32_plan(const float* wmask, int ldw, int m, int n,
 extern "C" int64_t gv_made_gradw_f32_workspace_floats(int m, int n, int64_t k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
     const int64_t mp = (m + 31) / 32 * 32, np = (n + 31) / 32 * 32;
-    return (int64_t)gw_slices(m, n, k) * (mp * np + mp);
+    return ((int64_t)gw_slices(m, n, k) * (mp * np + mp) + 63) / 64 * 64;
+}
+
+namespace gv {
+static int64_t gw_item_floats(const gv_gradw32_item& it) {
+    if (it.m <= 0 || it.n <= 0 || it.k <= 0) return 0;
+    const int64_t mp = (it.m + 31) / 32 * 32, np = (it.n + 31) / 32 * 32;
+    return ((int64_t)gw_slices(it.m, it.n, it.k) * (mp * np + mp) + 63) / 64 * 64;
+}
+}  // namespace gv
+
+extern "C" int64_t gv_made_gradw_f32_multi_workspace_floats(int count, const gv_gradw32_item* items) {
+    int64_t total = 0;
+    for (int q = 0; items && q < count; ++q) total += gw_item_floats(items[q]);
+    return total;
+}
+
+extern "C" int gv_made_gradw_f32_multi(int count, const gv_gradw32_item* items, float* workspace, int64_t workspace_floats, void* stream) {
+    GV_REQUIRE(count >= 1 && count <= GW_MAXI && items, GV_ERR_SHAPE, "gv_made_gradw_f32_multi: %d products (1 .. %d)", count, GW_MAXI);
+    GV_REQUIRE(workspace && workspace_floats >= gv_made_gradw_f32_multi_workspace_floats(count, items), GV_ERR_SHAPE,
+               "gv_made_gradw_f32_multi: workspace of %lld floats, %lld needed", (long long)workspace_floats,
+               (long long)gv_made_gradw_f32_multi_workspace_floats(count, items));
+    GradW32Multi P;
+    GradW32ReduceMulti R;
+    P.count = R.count = count;
+    P.first[0] = R.first[0] = 0;
+    float* ws = workspace;
+    for (int q = 0; q < count; ++q) {
+        const gv_gradw32_item& it = items[q];
+        GV_REQUIRE(it.m > 0 && it.n > 0 && it.k > 0 && it.m % 4 == 0 && it.n % 4 == 0 && it.ldg >= it.m && it.lda >= it.n && it.ldg % 4 == 0 &&
+                       it.lda % 4 == 0 && it.ldo >= it.n,
+                   GV_ERR_SHAPE, "gv_made_gradw_f32: product %d: m=%d n=%d k=%lld ldg=%d lda=%d ldo=%d (widths and pitches are multiples of 4)", q,
+                   it.m, it.n, (long long)it.k, it.ldg, it.lda, it.ldo);
+        GV_REQUIRE(it.g && it.a && it.plan && it.out && aligned16(it.g) && aligned16(it.a), GV_ERR_NULL,
+                   "gv_made_gradw_f32: product %d: NULL / unaligned pointer", q);
+        GV_REQUIRE((!it.wmask || it.ldw >= it.n) && (!it.g0 || it.a0), GV_ERR_SHAPE,
+                   "gv_made_gradw_f32: product %d: mask pitch / pass 0's row needs both vectors", q);
+        GradW32Args& p = P.it[q];
+        p.g = it.g; p.a = it.a; p.plan = it.plan; p.ldg = it.ldg; p.lda = it.lda; p.m = it.m; p.n = it.n; p.k = it.k;
+        p.mp = (it.m + 31) / 32 * 32; p.np = (it.n + 31) / 32 * 32;
+        p.slices = gw_slices(it.m, it.n, it.k);
+        p.gy = (it.m + 32 * GW_BT - 1) / (32 * GW_BT);
+        p.gz = (it.n + 32 * GW_BT - 1) / (32 * GW_BT);
+        p.reserved = 0;
+        p.k_per_slice = ((it.k + p.slices - 1) / p.slices + GW_KC - 1) / GW_KC * GW_KC;
+        p.part = ws;
+        p.dbpart = it.db ? ws + (size_t)p.slices * p.mp * p.np : nullptr;
+        ws += gw_item_floats(it);
+        P.first[q + 1] = P.first[q] + p.slices * p.gy * p.gz;
+        GradW32Reduce& r = R.it[q];
+        r.part = p.part; r.dbpart = p.dbpart; r.plan = it.plan; r.wmask = it.wmask; r.g0 = it.g0; r.g0_act = it.g0_act; r.a0 = it.a0;
+        r.out = it.out; r.db = it.db;
+        r.m = it.m; r.n = it.n; r.mp = p.mp; r.np = p.np; r.ldw = it.ldw; r.ldo = it.ldo; r.slices = p.slices;
+        r.accumulate = it.accumulate; r.db_accumulate = it.db_accumulate;
+        const size_t blocks = ((size_t)it.m * it.n + 63) / 64 + (it.db ? (it.m + 63) / 64 : 0);
+        r.blocks = (int)min((size_t)4096, blocks);
+        R.first[q + 1] = R.first[q] + r.blocks;
+    }
+    for (int q = count; q < GW_MAXI; ++q) {
+        P.first[q + 1] = P.first[count]; R.first[q + 1] = R.first[count];
+        P.it[q] = P.it[0]; R.it[q] = R.it[0];
+    }
+    const size_t lds = (size_t)4 * GW_KC * GW_LD * sizeof(float);
+    static unsigned long long lds_done = 0;
+    if (!raise_dynamic_lds((const void*)k_gradw32, (int)lds, lds_done, "gv_made_gradw_f32")) return GV_ERR_SHAPE;
+    hipLaunchKernelGGL(k_gradw32, dim3((unsigned)P.first[count]), dim3(GW_THREADS), lds, (hipStream_t)stream, P);
+    int rc = launch_status("gv_made_gradw_f32");
+    if (rc != GV_OK) return rc;
+    hipLaunchKernelGGL(k_gradw32_reduce, dim3((unsigned)R.first[count]), dim3(256), 0, (hipStream_t)stream, R);
+    return launch_status("gv_made_gradw_f32(reduce)");
 }
 
 extern "C" int gv_made_gradw_f32(const float* g, int ldg, const float* a, int lda, int m, int n, int64_t k, const int32_t* plan,
                                  const float* wmask, int ldw, const float* g0, const float* g0_act, const float* a0, float* out, int ldo,
                                  int accumulate, float* db, int db_accumulate, float* workspace, int64_t workspace_floats, void* stream) {
-    GV_REQUIRE(m > 0 && n > 0 && k > 0 && m % 4 == 0 && n % 4 == 0 && ldg >= m && lda >= n && ldg % 4 == 0 && lda % 4 == 0 && ldo >= n,
-               GV_ERR_SHAPE, "gv_made_gradw_f32: m=%d n=%d k=%lld ldg=%d lda=%d ldo=%d (widths and pitches are multiples of 4)", m, n,
-               (long long)k, ldg, lda, ldo);
-    GV_REQUIRE(g && a && plan && out && workspace && aligned16(g) && aligned16(a), GV_ERR_NULL, "gv_made_gradw_f32: NULL / unaligned pointer");
-    GV_REQUIRE((!wmask || ldw >= n) && (!g0 || a0), GV_ERR_SHAPE, "gv_made_gradw_f32: mask pitch / pass 0's row needs both vectors");
-    GV_REQUIRE(workspace_floats >= gv_made_gradw_f32_workspace_floats(m, n, k), GV_ERR_SHAPE, "gv_made_gradw_f32: workspace of %lld floats, %lld needed",
-               (long long)workspace_floats, (long long)gv_made_gradw_f32_workspace_floats(m, n, k));
-    GradW32Args p;
-    p.g = g; p.a = a; p.plan = plan; p.ldg = ldg; p.lda = lda; p.m = m; p.n = n; p.k = k;
-    p.mp = (m + 31) / 32 * 32; p.np = (n + 31) / 32 * 32;
-    const int slices = gw_slices(m, n, k);
-    p.k_per_slice = ((k + slices - 1) / slices + GW_KC - 1) / GW_KC * GW_KC;
-    p.part = workspace;
-    p.dbpart = db ? workspace + (size_t)slices * p.mp * p.np : nullptr;
-    const size_t lds = (size_t)4 * GW_KC * GW_LD * sizeof(float);
-    static unsigned long long lds_done = 0;
-    if (!raise_dynamic_lds((const void*)k_gradw32, (int)lds, lds_done, "gv_made_gradw_f32")) return GV_ERR_SHAPE;
-    const dim3 grid((unsigned)slices, (unsigned)((m + 32 * GW_BT - 1) / (32 * GW_BT)), (unsigned)((n + 32 * GW_BT - 1) / (32 * GW_BT)));
-    hipLaunchKernelGGL(k_gradw32, grid, dim3(GW_THREADS), lds, (hipStream_t)stream, p);
-    int rc = launch_status("gv_made_gradw_f32");
-    if (rc != GV_OK) return rc;
-    GradW32Reduce r;
-    r.part = p.part; r.dbpart = p.dbpart; r.plan = plan; r.wmask = wmask; r.g0 = g0; r.g0_act = g0_act; r.a0 = a0; r.out = out; r.db = db;
-    r.m = m; r.n = n; r.mp = p.mp; r.np = p.np; r.ldw = ldw; r.ldo = ldo; r.slices = slices; r.accumulate = accumulate; r.db_accumulate = db_accumulate;
-    const size_t blocks = ((size_t)m * n + 63) / 64 + (db ? (m + 63) / 64 : 0);
-    hipLaunchKernelGGL(k_gradw32_reduce, dim3((unsigned)min((size_t)4096, blocks)), dim3(256), 0, (hipStream_t)stream, r);
-    return launch_status("gv_made_gradw_f32(reduce)");
+    gv_gradw32_item it;
+    it.g = g; it.a = a; it.plan = plan; it.wmask = wmask; it.g0 = g0; it.g0_act = g0_act; it.a0 = a0; it.out = out; it.db = db;
+    it.ldg = ldg; it.lda = lda; it.m = m; it.n = n; it.ldw = ldw; it.ldo = ldo; it.accumulate = accumulate; it.db_accumulate = db_accumulate;
+    it.k = k;
+    return gv_made_gradw_f32_multi(1, &it, workspace, workspace_floats, stream);
 }

@@ -90,6 +90,8 @@ SIGNATURES = {
     'gv_made_gradw_f32_plan': (_I, [_P, _I, _I, _I, _P, _P]),
     'gv_made_gradw_f32_workspace_floats': (_L, [_I, _I, _L]),
     'gv_made_gradw_f32': (_I, [_P, _I, _P, _I, _I, _I, _L, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _I, _P, _L, _P]),
+    'gv_made_gradw_f32_multi_workspace_floats': (_L, [_I, _P]),
+    'gv_made_gradw_f32_multi': (_I, [_I, _P, _P, _L, _P]),
     'gv_made_row_fwd': (_I, [_P, _I, _P, _P]),
     'gv_made_row_bwd': (_I, [_P, _I, _P, _P, _P]),
     'gv_rel_rows_gemm': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),

@@ -37,6 +37,36 @@ def _zero_row(d, device):
     return _zero_rows[key]
 
 
+def _made_params_work_f32(masks, ws, bs, d, S):
+    """The part of _MADEForward.forward that depends on the parameters alone: the mask fold (one launch), pass 0 on its single zero
+    row -- one single-workgroup launch with exact fp32 operands where the widths allow, else a launch per product --, and for the
+    chain kernel (gv_made_chain_f32: activations stay in LDS between the layers, the zero groups of the masked weights are not
+    multiplied; otherwise -- and with GV_MADE_CHAIN_F32=0 -- a launch per product) the fragment-packed weights and the unit plan."""
+    L = len(ws)
+    if masks is not None:
+        ws = mul_multi(masks, ws)
+    dev = ws[0].device
+    f32 = dict(dtype=torch.float32, device=dev)
+    zero_row = _zero_row(d, dev)
+    row = (MADE_ROW_F32 and L <= 8 and d <= 512 and max(w.shape[0] for w in ws) <= 512 and all(w.shape[1] % 4 == 0 for w in ws))
+    if row:
+        acts0 = [torch.empty(1, w.shape[0], **f32) for w in ws]
+        made_row_fwd(None, [dict(w=ws[l], bias=bs[l], relu=l < L - 1, out=acts0[l]) for l in range(L)], exact=True)
+    else:
+        acts0, inp = [], zero_row
+        for l in range(L):
+            inp = gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE)
+            acts0.append(inp)
+    widths, kin = [w.shape[0] for w in ws], [w.shape[1] for w in ws]
+    chain = (MADE_CHAIN_F32 and S > 0 and L <= 8 and d % 8 == 0 and made_chain_f32_fits(widths, kin)
+             and made_chain_f32_fits(list(reversed(kin)), list(reversed(widths))))
+    packed = plan_f = None
+    if chain:
+        packed = made_pack_weights_f32(ws)
+        plan_f = made_chain_f32_plan(widths, kin, masks)
+    return dict(f32=True, ws=ws, row=row, acts0=acts0, zero_row=zero_row, chain=chain, packed=packed, plan_f=plan_f)
+
+
 class _MADEForward(torch.autograd.Function):
     """MADE.forward (kgvae/flow_network.py:85-98) as ONE autograd node.
 
@@ -66,40 +96,29 @@ class _MADEForward(torch.autograd.Function):
         ctx.direct_w = [_direct(w) for w in ws] if masks is not None else [None] * L
         ctx.direct_b = [_direct(b) if b is not None else None for b in bs]
         _stamp_direct(ctx)
-        if masks is not None:
-            ws = mul_multi(masks, ws)
         z = _chk(z.contiguous(), name='z')
         n, d = z.shape
         P = colcount.shape[0]
         f32 = dict(dtype=torch.float32, device=z.device)
         st = lib.stream()
         S = P - 1                                                 # passes 1..P-1 are stacked; pass 0 is one row
+        # what depends on the parameters alone (mask fold, fragment-packed weights, pass 0's row): done ahead on a side stream where
+        # the model announced this call (made_prepare), here otherwise
+        prep = _made_prep.pop(_made_prep_key(ws, d, S), None)
+        if prep is not None and prep.get('f32'):
+            if not prep['joined'][0]:       # ONE join for everything that was prepared
+                torch.cuda.current_stream().wait_event(prep['done'])
+                prep['joined'][0] = True
+        else:
+            prep = _made_params_work_f32(masks, ws, bs, d, S)
+        ws, row, acts0, zero_row, chain, packed, plan_f = (prep[k_] for k_ in ('ws', 'row', 'acts0', 'zero_row', 'chain', 'packed', 'plan_f'))
+        widths, kin = [w.shape[0] for w in ws], [w.shape[1] for w in ws]
         xin = torch.empty(max(S, 1) * n, d, **f32)               # xin[s] = input of pass s+1 = output of pass s
         acts = [torch.empty(max(S, 1) * n, ws[l].shape[0], **f32) for l in range(L)]   # acts[L-1] = [mu | alpha]
         x_out = torch.empty(n, d, **f32)
-        # pass 0 on a single zero row: one single-workgroup launch (exact fp32 operands) where the widths allow, else a launch per product
-        zero_row = _zero_row(d, z.device)
-        row = (MADE_ROW_F32 and L <= 8 and d <= 512 and max(w.shape[0] for w in ws) <= 512 and all(w.shape[1] % 4 == 0 for w in ws))
-        if row:
-            acts0 = [torch.empty(1, w.shape[0], **f32) for w in ws]
-            made_row_fwd(None, [dict(w=ws[l], bias=bs[l], relu=l < L - 1, out=acts0[l]) for l in range(L)], exact=True)
-        else:
-            acts0, inp = [], zero_row
-            for l in range(L):
-                inp = gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE)
-                acts0.append(inp)
         first_out = xin[0:n] if P > 1 else x_out
         # (columns outside the first index set would keep x_old = 0: flows.MADE checks at construction that there are none)
         lib.call('gv_iaf_update_fwd', ptr(z), ptr(acts0[L - 1]), 0, ptr(z), ptr(colcount[0]), ptr(first_out), n, d, st)
-        # one launch per pass (gv_made_chain_f32: activations stay in LDS between the layers, the zero groups of the masked
-        # weights are not multiplied) where the widths fit; otherwise -- and with GV_MADE_CHAIN_F32=0 -- a launch per product
-        widths, kin = [w.shape[0] for w in ws], [w.shape[1] for w in ws]
-        chain = (MADE_CHAIN_F32 and S > 0 and L <= 8 and d % 8 == 0 and made_chain_f32_fits(widths, kin)
-                 and made_chain_f32_fits(list(reversed(kin)), list(reversed(widths))))
-        packed = plan_f = None
-        if chain:
-            packed = made_pack_weights_f32(ws)
-            plan_f = made_chain_f32_plan(widths, kin, masks)
         def passes(r0, r1):      # passes 1 .. P-1 for the rows [r0, r1): every launch of a pass is row-local
             for p in range(1, P):
                 a, b = (p - 1) * n + r0, (p - 1) * n + r1
@@ -215,9 +234,8 @@ class _MADEForward(torch.autograd.Function):
                        and all(ctx.needs_input_grad[3 + l] for l in range(L))
                        and all(ctx.needs_input_grad[3 + L + l] or not ctx.has_bias[l] for l in range(L)))
         row_bwd = fused_gradw and ctx.row           # pass 0's backward chain as one single-workgroup launch: gm_l = its masked row gradients
-        if row_bwd:
+        if row_bwd:     # (launched below, with the products that consume it: nothing on the path to dL/dz reads these rows)
             rows0 = [torch.empty(1, widths[l], **f32) for l in range(L)]
-            made_row_bwd(g_row, [dict(w=ws[l], act=acts0[l] if l < L - 1 else None, gb=rows0[l]) for l in range(L)], exact=True)
         for l in reversed(range(L)) if not row_bwd else ():
             rows0[l] = g_row
             if l > 0:
@@ -235,13 +253,17 @@ class _MADEForward(torch.autograd.Function):
         beside = (ctx.masks is not None and L <= 8 and all(tgt_w[l] is not None for l in range(L) if wants_w[l])
                   and all(tgt_b[l] is not None for l in range(L) if wants_b[l]))
         g_ws, g_bs = [], []
-        with backward_side(beside, grads, xin, acts, acts0, rows0, zero_row):
+        with backward_side(beside, grads, xin, acts, acts0, rows0, zero_row, g_row, ws):
+            if row_bwd:
+                made_row_bwd(g_row, [dict(w=ws[l], act=acts0[l] if l < L - 1 else None, gb=rows0[l]) for l in range(L)], exact=True)
+            if fused_gradw:     # all layers' products in one launch pair
+                both = made_gradw_f32_multi([dict(g=grads[l], a=xin if l == 0 else acts[l - 1],
+                                                  wmask=ctx.masks[l] if ctx.masks is not None else None, g0=rows0[l],
+                                                  g0_act=acts0[l] if (l < L - 1 and not row_bwd) else None,
+                                                  a0=zero_row if l == 0 else acts0[l - 1], out=tgt_w[l], accumulate=False, db=tgt_b[l],
+                                                  db_accumulate=tgt_b[l] is not None, want_db=wants_b[l]) for l in range(L)])
             for l in range(L) if fused_gradw else ():
-                gw, gb = made_gradw_f32(grads[l], xin if l == 0 else acts[l - 1], wmask=ctx.masks[l] if ctx.masks is not None else None,
-                                        g0=rows0[l], g0_act=acts0[l] if (l < L - 1 and not row_bwd) else None,
-                                        a0=zero_row if l == 0 else acts0[l - 1],
-                                        out=tgt_w[l], accumulate=False, db=tgt_b[l], db_accumulate=tgt_b[l] is not None,
-                                        want_db=wants_b[l])
+                gw, gb = both[l]
                 if tgt_w[l] is not None:
                     GRAD_FRESH.discard(tgt_w[l].data_ptr())
                     gw = None
@@ -679,6 +701,50 @@ def made_gradw_f32(g, a, wmask=None, g0=None, g0_act=None, a0=None, out=None, ac
     return out, db
 
 
+class _GradW32Item(_ct.Structure):
+    """gv_gradw32_item of include/gcnvae.h."""
+    _fields_ = [(f, _ct.c_void_p) for f in ('g', 'a', 'plan', 'wmask', 'g0', 'g0_act', 'a0', 'out', 'db')] + \
+               [(f, _ct.c_int32) for f in ('ldg', 'lda', 'm', 'n', 'ldw', 'ldo', 'accumulate', 'db_accumulate')] + [('k', _ct.c_int64)]
+
+
+def made_gradw_f32_multi(items):
+    """made_gradw_f32 for up to 8 layers in ONE launch pair (gv_made_gradw_f32_multi): ``items`` = dicts with made_gradw_f32's
+    arguments; returns [(dW, db), ...]."""
+    if not 1 <= len(items) <= 8:
+        raise ValueError('made_gradw_f32_multi: 1 .. 8 products')
+    arr, keep, res = (_GradW32Item * len(items))(), [], []
+    for c, d_ in zip(arr, items):
+        g, ldg = _row_major(d_['g'], 'g')
+        a, lda = _row_major(d_['a'], 'a')
+        k, m = g.shape
+        n = a.shape[1]
+        if a.shape[0] != k:
+            raise ValueError('made_gradw_f32: g and a have different row counts')
+        f32 = dict(dtype=torch.float32, device=g.device)
+        out, accumulate = d_.get('out'), bool(d_.get('accumulate'))
+        db, db_accumulate = d_.get('db'), bool(d_.get('db_accumulate'))
+        if out is None:
+            out, accumulate = torch.empty(m, n, **f32), False
+        if db is None and d_.get('want_db', True):
+            db, db_accumulate = torch.empty(m, **f32), False
+        if out.stride(1) != 1 or (db is not None and not db.is_contiguous()):
+            raise ValueError('made_gradw_f32: outputs with unit inner stride')
+        wmask, ldw = d_.get('wmask'), 0
+        plan = made_gradw_f32_plan(m, n, wmask)
+        if wmask is not None:
+            wmask, ldw = _row_major(wmask, 'wmask')
+        c.g, c.a, c.plan, c.wmask, c.out, c.db = ptr(g), ptr(a), ptr(plan), ptr(wmask), ptr(out), ptr(db)
+        c.g0, c.g0_act, c.a0 = ptr(d_.get('g0')), ptr(d_.get('g0_act')), ptr(d_.get('a0'))
+        c.ldg, c.lda, c.m, c.n, c.ldw, c.ldo, c.k = ldg, lda, int(m), int(n), ldw, out.stride(0), int(k)
+        c.accumulate, c.db_accumulate = 1 if accumulate else 0, 1 if db_accumulate else 0
+        keep.append((g, a, wmask))
+        res.append((out, db))
+    nws = int(lib.load().gv_made_gradw_f32_multi_workspace_floats(len(items), _ct.addressof(arr)))
+    ws = torch.empty(nws, dtype=torch.float32, device=res[0][0].device)
+    lib.call('gv_made_gradw_f32_multi', len(items), _ct.addressof(arr), ptr(ws), nws, lib.stream())
+    return res
+
+
 class _Chain32Iaf(_ct.Structure):
     """gv_chain32_iaf of include/gcnvae.h."""
     _fields_ = [('mode', _ct.c_int32), ('passes', _ct.c_int32), ('d', _ct.c_int32), ('flags', _ct.c_int32), ('step', _ct.c_int64),
@@ -762,18 +828,22 @@ def _made_prep_key(ws, d, S):
 
 
 def made_prepare(calls):
-    """calls: [(colcount, weights, biases, masks)] of the bf16 MADE nodes the caller is about to run (made_forward's arguments)."""
-    if not calls or _ops.GEMM_PRECISION != 'bf16' or not MADE_BF16_STORAGE or not _ops.launch_layout().made_prepare:
+    """calls: [(colcount, weights, biases, masks)] of the MADE nodes the caller is about to run (made_forward's arguments)."""
+    if not calls or not calls[0][1][0].is_cuda or not _ops.launch_layout().made_prepare:      # (host tensors: the node itself refuses them)
         return
+    bf16 = _ops.GEMM_PRECISION == 'bf16' and MADE_BF16_STORAGE
     main, side = torch.cuda.current_stream(), _side('made_prep')
     side.wait_stream(main)
     with torch.cuda.stream(side), torch.no_grad():
         done, joined, mine = torch.cuda.Event(), [False], []
         for colcount, weights, biases, masks in calls:
             d, S = weights[0].shape[1], colcount.shape[0] - 1
-            if masks is None or len(weights) > 8 or d % 8 or any(w.shape[0] % 8 or w.shape[1] % 8 for w in weights):
-                continue        # (not the call made_forward hands to the bf16 node with these very tensors)
-            prep = _made_params_work(tuple(masks), tuple(weights), tuple(biases), d, S)
+            if masks is None or len(weights) > 8:
+                continue        # (not the call made_forward hands to a node with these very tensors)
+            if bf16 and not (d % 8 or any(w.shape[0] % 8 or w.shape[1] % 8 for w in weights)):
+                prep = _made_params_work(tuple(masks), tuple(weights), tuple(biases), d, S)
+            else:               # the fp32 node
+                prep = _made_params_work_f32(tuple(masks), tuple(weights), tuple(biases), d, S)
             prep['done'], prep['joined'] = done, joined
             _made_prep[_made_prep_key(weights, d, S)] = prep
             mine.append(prep)

@@ -405,6 +405,23 @@ int64_t gv_made_gradw_f32_workspace_floats(int m, int n, int64_t k);
 int gv_made_gradw_f32(const float* g, int ldg, const float* a, int lda, int m, int n, int64_t k, const int32_t* plan,
                       const float* wmask, int ldw, const float* g0, const float* g0_act, const float* a0, float* out, int ldo,
                       int accumulate, float* db, int db_accumulate, float* workspace, int64_t workspace_floats, void* stream);
+/* The same for up to 8 products (the layers of one MADE) in ONE launch pair: a product's fields as the arguments above; workspace of
+ * gv_made_gradw_f32_multi_workspace_floats(count, items) floats. */
+typedef struct gv_gradw32_item {
+    const float* g;
+    const float* a;
+    const int32_t* plan;
+    const float* wmask;
+    const float* g0;
+    const float* g0_act;
+    const float* a0;
+    float* out;
+    float* db;
+    int32_t ldg, lda, m, n, ldw, ldo, accumulate, db_accumulate;
+    int64_t k;
+} gv_gradw32_item;
+int64_t gv_made_gradw_f32_multi_workspace_floats(int count, const gv_gradw32_item* items);
+int gv_made_gradw_f32_multi(int count, const gv_gradw32_item* items, float* workspace, int64_t workspace_floats, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * K4, pass 0 of MADE (kgvae/flow_network.py:85-98): the first pass feeds the masked MLP an all-zero input, so every node sees
  * the same ROW; the whole chain of 1 x k by k x n products is one single-workgroup launch.  Operands rounded to bf16, fp32

@@ -227,6 +227,29 @@ def test_gradw_f32_against_a_double_precision_product(m, n, k, masked):
     torch.testing.assert_close(db3.double(), 3.0 + g.double().sum(0), rtol=1e-5, atol=2e-6 * float(want_db.abs().max()))
 
 
+def test_gradw_f32_of_several_layers_in_one_launch_pair_is_the_single_products_bit_for_bit():
+    """gv_made_gradw_f32_multi: the products of a MADE's layers (different shapes, masks, row terms, store / accumulate targets) in one
+    launch pair = each of them through gv_made_gradw_f32."""
+    from gcn_vae_amd import made
+    gen = torch.Generator().manual_seed(77)
+    k = 2900
+    shapes = [(200, 40), (200, 200), (56, 200), (400, 200), (80, 56)]
+    items, singles = [], []
+    for q, (m, n) in enumerate(shapes):
+        g, a = torch.randn(k, m, generator=gen).cuda(), torch.randn(k, n, generator=gen).cuda()
+        wmask = None if q == 2 else ((torch.arange(m) % max(n - 1, 1)).unsqueeze(-1) >= (torch.arange(n) % max(n - 1, 1)).unsqueeze(0)).float().cuda()
+        g0, act0, a0 = (torch.randn(1, m, generator=gen).cuda(), torch.randn(1, m, generator=gen).cuda(), torch.randn(1, n, generator=gen).cuda())
+        base, bias = torch.randn(m, n, generator=gen).cuda(), torch.randn(m, generator=gen).cuda()
+        kw = dict(wmask=wmask, g0=g0 if q != 1 else None, g0_act=act0 if q % 2 == 0 else None, a0=a0 if q != 1 else None,
+                  accumulate=q == 3, db_accumulate=q in (0, 3), want_db=q != 4)
+        singles.append(made.made_gradw_f32(g, a, out=base.clone(), db=bias.clone() if q != 4 else None, **kw))
+        items.append(dict(g=g, a=a, out=base.clone(), db=bias.clone() if q != 4 else None, **kw))
+    both = made.made_gradw_f32_multi(items)
+    for (o1, b1), (o2, b2) in zip(singles, both):
+        assert torch.equal(o1, o2)
+        assert (b1 is None and b2 is None) or torch.equal(b1, b2)
+
+
 @pytest.mark.parametrize('d,h,n_hidden,rows', [(200, 200, 3, 500), (40, 56, 2, 300)])
 def test_made_node_with_pass_0_as_single_workgroup_launches(monkeypatch, d, h, n_hidden, rows):
     """GV_MADE_ROW_F32: pass 0 of the fp32 node (one broadcast row) on gv_made_row_fwd / _bwd with exact fp32 operands instead of
