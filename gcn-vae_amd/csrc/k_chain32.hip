@@ -33,7 +33,6 @@ namespace gv {
 
 typedef float f32x16c __attribute__((ext_vector_type(16)));
 
-constexpr int C32_BM = 64;          // rows per workgroup
 constexpr int C32_LISTS = 4;        // unit lists of a plan: one per SIMD
 #ifndef GV_C32_FINE
 #define GV_C32_FINE 0           /* 0 (default): units of 64 rows x 32 columns (two accumulators sharing the weight fragment), 8 waves =
@@ -44,16 +43,18 @@ constexpr int C32_LISTS = 4;        // unit lists of a plan: one per SIMD
                                  * (A third form -- the two waves of a SIMD sharing every 64 x 32 unit by row half, i.e. two
                                  * single-accumulator chains per SIMD -- ran 92 us: ~780 cycles per pair of groups instead of 512.) */
 #endif
-constexpr bool C32_SINGLE = GV_C32_FINE != 0;             // one accumulator per unit: the unit carries its row half
-constexpr int C32_WAVES = GV_C32_FINE ? 16 : 8;           // waves w, w + 4, ... share a SIMD (a workgroup's waves go to the SIMDs
-                                                          // cyclically) and take every (WAVES / 4)-th entry of list w & 3
+constexpr int C32_BM = GV_C32_FINE == 2 ? 32 : 64;        // rows per workgroup
+constexpr bool C32_SINGLE = GV_C32_FINE != 0;             // one accumulator per unit
+constexpr bool C32_HALVES = GV_C32_FINE == 1;             // ... the unit carries its row half (two units per tile)
+constexpr int C32_WAVES = GV_C32_FINE == 1 ? 16 : GV_C32_FINE == 2 ? 4 : 8;   // waves w, w + 4, ... share a SIMD (a workgroup's waves go
+                                                          // to the SIMDs cyclically) and take every (WAVES / 4)-th entry of list w & 3
 constexpr int C32_SLOTS = C32_WAVES / 4;
 constexpr int C32_THREADS = C32_WAVES * 64;
 constexpr int C32_L = GV_CHAIN_MAX_LAYERS;
 constexpr int C32_MAXT = GV_CHAIN32_MAX_TILES;            // column tiles per layer (n <= 512)
 constexpr int C32_MAXU = 2 * C32_L * C32_MAXT;            // units per list in the plan buffer (global memory)
 constexpr int C32_MAXU_LDS = 96;                          // ... of a chain that is launched (checked on the host): the LDS copy
-constexpr int C32_CHG = GV_C32_FINE ? 13 : 25;            // groups per register set of weight fragments
+constexpr int C32_CHG = GV_C32_FINE == 1 ? 13 : 25;            // groups per register set of weight fragments
 // plan words: [0, 4) units per list; then 4 lists of C32_MAXU (layer << 8 | half << 7 | tile); then [layer][tile] group sets (lo, hi)
 constexpr int C32_PLAN_LISTS = 4, C32_PLAN_SETS = C32_PLAN_LISTS + C32_LISTS * C32_MAXU;
 constexpr int C32_PLAN_WORDS = C32_PLAN_SETS + 2 * C32_L * C32_MAXT;
@@ -289,7 +290,7 @@ __device__ __forceinline__ void c32_epilogue(const f32x16c& acc0, const f32x16c&
 // ---- the IAF update around the chain (gv_made_passes_f32), on the workgroup's own 64 rows, four columns per thread ----------
 // forward: x_new = count > 0 ? z * expf(alpha + mu) : x_old   (k_iaf_fwd's arithmetic)
 __device__ __forceinline__ void c32_update_fwd(const float* z, const float* net, int ld_net, const float* x_old, int ldx, const int* cnt,
-                                               float* x_new, int ld_new, int m0, int m, int d) {
+                                               float* x_new, int ld_new, int m0, int m, int d, bool reversed = false) {
     const int q = d >> 2;
     for (int i = threadIdx.x; i < C32_BM * q; i += C32_THREADS) {
         const int row = m0 + i / q, c = (i % q) << 2;
@@ -308,7 +309,21 @@ __device__ __forceinline__ void c32_update_fwd(const float* z, const float* net,
         o.y = cn.y > 0 ? zz.y * expf(al.y + mu.y) : xo.y;
         o.z = cn.z > 0 ? zz.z * expf(al.z + mu.z) : xo.z;
         o.w = cn.w > 0 ? zz.w * expf(al.w + mu.w) : xo.w;
-        *reinterpret_cast<float4*>(x_new + (size_t)row * ld_new + c) = o;
+        if (reversed) *reinterpret_cast<float4*>(x_new + (size_t)row * ld_new + (d - 4 - c)) = make_float4(o.w, o.z, o.y, o.x);
+        else *reinterpret_cast<float4*>(x_new + (size_t)row * ld_new + c) = o;
+    }
+}
+
+// log_det[row] = sum of the row's alpha columns (k_rowsum's order: lane l adds columns l, l + 64, ...; the wave's lanes by wave_sum)
+__device__ __forceinline__ void c32_logdet(const float* net, int ld_net, float* log_det, int m0, int m, int d, int wave, int lane) {
+    for (int r = wave; r < C32_BM; r += C32_WAVES) {
+        const int row = m0 + r;
+        if (row >= m) break;
+        const float* src = net + (size_t)row * ld_net + d;
+        float acc = 0.f;
+        for (int c = lane; c < d; c += 64) acc += src[c];
+        acc = wave_sum(acc);
+        if (lane == 0) log_det[row] = acc;
     }
 }
 
@@ -316,13 +331,14 @@ __device__ __forceinline__ void c32_update_fwd(const float* z, const float* net,
 // the handed-through gradient (count == 0: g, else 0) goes to g_old, where the chain's last layer adds its own
 __device__ __forceinline__ void c32_update_bwd(const float* z, const float* net, int ld_net, const int* cnt, const float* g_in, int ld_gin,
                                                const float* gld, float* g_z, bool gz_write, float* g_net, int ld_gnet, float* g_old,
-                                               int ld_gold, int m0, int m, int d) {
+                                               int ld_gold, int m0, int m, int d, bool reversed = false) {
     const int q = d >> 2;
     for (int i = threadIdx.x; i < C32_BM * q; i += C32_THREADS) {
         const int row = m0 + i / q, c = (i % q) << 2;
         if (row >= m) continue;
         const int4 cnt4 = *reinterpret_cast<const int4*>(cnt + c);
-        const float4 g = *reinterpret_cast<const float4*>(g_in + (size_t)row * ld_gin + c);
+        float4 g = *reinterpret_cast<const float4*>(g_in + (size_t)row * ld_gin + (reversed ? d - 4 - c : c));
+        if (reversed) g = make_float4(g.w, g.z, g.y, g.x);
         const float4 zz = *reinterpret_cast<const float4*>(z + (size_t)row * d + c);
         const float4 mu = *reinterpret_cast<const float4*>(net + (size_t)row * ld_net + c), al = *reinterpret_cast<const float4*>(net + (size_t)row * ld_net + d + c);
         float4 old = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
         for (int l = 0; l < nl; ++l) {
             if (p.L[l].bias)
                 for (int i = threadIdx.x; i < p.L[l].n; i += C32_THREADS) bias_lds[at + i] = p.L[l].bias[i];
-            at += p.L[l].n;
+            if (p.L[l].bias) at += p.L[l].n;          // (a layer without a bias takes no room: the backward chains have none)
         }
     }
     __syncthreads();
@@ -438,8 +454,14 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
         const float* g_in = s == 0 ? p.iaf.g_in : Llast.out_f32 + (so - step) * Llast.ldc;
         c32_update_bwd(p.iaf.z, p.iaf.net + so * p.iaf.ld_net, p.iaf.ld_net, p.iaf.colcount + (step > 0 ? s : -s) * d, g_in,
                        s == 0 ? d : Llast.ldc, (s == 0 && (p.iaf.flags & 1)) ? p.iaf.g_logdet : nullptr, p.iaf.g_z,
-                       s == 0 && (p.iaf.flags & 2), xs, p.ldx, Llast.out_f32 + so * Llast.ldc, Llast.ldc, m0, p.m, d);
+                       s == 0 && (p.iaf.flags & 2), xs, p.ldx, Llast.out_f32 + so * Llast.ldc, Llast.ldc, m0, p.m, d,
+                       s == 0 && (p.iaf.flags & 4));
         __syncthreads();         // (drains the stores: the staging below and the last layer's epilogue read them back)
+    }
+    if (p.iaf.mode == 1 && s == 0 && (p.iaf.flags & 4)) {
+        // the block's pass 0 fed the MLP an all-zero input: its [mu | alpha] is one row; its update gives the first stacked pass's input
+        c32_update_fwd(p.iaf.z, p.iaf.net0, 0, p.iaf.z, p.iaf.d, p.iaf.cnt0, xs, p.ldx, m0, p.m, p.iaf.d);
+        __syncthreads();         // (drains the stores: the staging below reads them back)
     }
     if (padding) {
         for (int l = 0; l < nl; ++l) {
@@ -477,7 +499,7 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
         C32Layer Ly = c32_layer(p.L[cu.layer]);
         if (Ly.out_f32) Ly.out_f32 += so * Ly.ldc;
         if (Ly.mask) Ly.mask += so * Ly.ldmask;
-        while (bias_layer < cu.layer) bias_at += p.L[bias_layer++].n;
+        while (bias_layer < cu.layer) { if (p.L[bias_layer].bias) bias_at += p.L[bias_layer].n; ++bias_layer; }
         const float* A = (cu.layer & 1) ? buf1 : buf0;
         const int lda = (cu.layer & 1) ? p.ld1 : p.ld0;
         const float4* b0;
@@ -532,7 +554,8 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
         const int d = p.iaf.d;
         const bool to_out = s + 1 == n_pass && (p.iaf.flags & 1);
         c32_update_fwd(p.iaf.z, Llast.out_f32 + so * Llast.ldc, Llast.ldc, xs, p.ldx, p.iaf.colcount + (step > 0 ? s : -s) * d,
-                       to_out ? p.iaf.x_out : xs + step * p.ldx, to_out ? d : p.ldx, m0, p.m, d);
+                       to_out ? p.iaf.x_out : xs + step * p.ldx, to_out ? d : p.ldx, m0, p.m, d, to_out && (p.iaf.flags & 16));
+        if (s + 1 == n_pass && (p.iaf.flags & 8)) c32_logdet(Llast.out_f32 + so * Llast.ldc, Llast.ldc, p.iaf.log_det, m0, p.m, d, wave, lane);
     }
     if (s + 1 < n_pass) __syncthreads();          // the next pass reads what this one stored, and reuses the LDS tiles
   }
@@ -616,7 +639,7 @@ __global__ __launch_bounds__(256) void k_chain32_plan(const Plan32Args p) {
                 for (int c = 1; c < C32_LISTS; ++c) if (load[c] < load[w]) w = c;
                 load[w] += cost[order[i]] + 1;          // (+ 1: a unit's epilogue is worth about a group)
                 lists[w * C32_MAXU + cnt[w]++] = (l << 8) | order[i];
-                if (C32_SINGLE) {                       // the tile's second row half: its own unit, to the list that is least loaded now
+                if (C32_HALVES) {                       // the tile's second row half: its own unit, to the list that is least loaded now
                     int w2 = 0;
                     for (int c = 1; c < C32_LISTS; ++c) if (load[c] < load[w2]) w2 = c;
                     load[w2] += cost[order[i]] + 1;
@@ -674,7 +697,7 @@ static bool c32_pitches(int n_layers, const int32_t* n_of_layer, const int32_t* 
     size_t widths = 0;
     for (int i = 0; i < n_layers; ++i) widths += (size_t)n_of_layer[i];       // the biases
     size_t units = 0;
-    for (int i = 0; i < n_layers; ++i) units += (size_t)((n_of_layer[i] + 31) / 32) * (C32_SINGLE ? 2 : 1);
+    for (int i = 0; i < n_layers; ++i) units += (size_t)((n_of_layer[i] + 31) / 32) * (C32_HALVES ? 2 : 1);
     if (units > (size_t)C32_MAXU_LDS) return false;          // (every list of the plan then fits its LDS copy)
     return (size_t)C32_BM * (*ld0 + *ld1) * sizeof(float) + C32_LPLAN_WORDS * sizeof(int32_t) + widths * sizeof(float) <= 160 * 1024;
 }
@@ -726,6 +749,9 @@ extern "C" int gv_made_passes_f32(float* x, int ldx, int m, int n_layers, const 
         GV_REQUIRE(layers[0].k == iaf->d && last.n == 2 * iaf->d && last.out_f32 && !last.accumulate && ldx >= iaf->d, GV_ERR_SHAPE,
                    "gv_made_passes_f32 (forward): the chain maps d -> [mu | alpha] (2 d, stored), ldx >= d");
         GV_REQUIRE(!(iaf->flags & 1) || (iaf->x_out && aligned16(iaf->x_out)), GV_ERR_NULL, "gv_made_passes_f32 (forward): x_out");
+        GV_REQUIRE(!(iaf->flags & 4) || (iaf->net0 && iaf->cnt0 && aligned16(iaf->net0) && aligned16(iaf->cnt0)), GV_ERR_NULL,
+                   "gv_made_passes_f32 (forward): pass 0's row / counts");
+        GV_REQUIRE(!(iaf->flags & 8) || iaf->log_det, GV_ERR_NULL, "gv_made_passes_f32 (forward): log_det");
     } else {
         GV_REQUIRE(layers[0].k == 2 * iaf->d && last.n == iaf->d && last.out_f32 && last.accumulate && ldx >= 2 * iaf->d, GV_ERR_SHAPE,
                    "gv_made_passes_f32 (backward): the chain maps [g_mu | g_alpha] (2 d) -> d, the last layer accumulates, ldx >= 2 d");
@@ -762,7 +788,7 @@ static int made_chain_f32(float* x, int ldx, int m, int n_layers, const gv_chain
     else { p.iaf = gv_chain32_iaf(); p.iaf.mode = 0; p.iaf.passes = 1; }
     { const char* e = getenv("GV_C32_DEBUG"); p.debug = e ? atoi(e) : 0; }
     size_t widths = 0;
-    for (int i = 0; i < n_layers; ++i) widths += (size_t)ns[i];
+    for (int i = 0; i < n_layers; ++i) widths += layers[i].bias ? (size_t)ns[i] : 0;
     const size_t lds = (size_t)C32_BM * (p.ld0 + p.ld1) * sizeof(float) + C32_LPLAN_WORDS * sizeof(int32_t) + widths * sizeof(float);
     static unsigned long long lds_done = 0;
     if (!raise_dynamic_lds((const void*)k_made_chain_f32, 160 * 1024, lds_done, "gv_made_chain_f32")) return GV_ERR_SHAPE;

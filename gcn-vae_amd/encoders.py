@@ -199,11 +199,18 @@ class KGVAE(ops.StayOnDevice, nn.Module):
         ride_along = self.batch_mmd_prior_with_forward and self.training
         if ride_along:
             z = ops.cat_rows(z, self._prior_draw(z.device, z.dtype))      # (kernel copies: no memcpy node in a captured step)
-        log_dets = []
-        for flow in self.nf:
-            z, log_det = flow.forward(z)
+        log_dets, flows, i = [], list(self.nf), 0
+        while i < len(flows):
+            flow = flows[i]
             if isinstance(flow, MADE):            # PermuteLayer contributes zeros
+                # (a PermuteLayer behind the block rides in the block's last launch: the columns come out reversed)
+                fold = i + 1 < len(flows) and type(flows[i + 1]) is PermuteLayer
+                z, log_det = flow.forward(z, reverse_out=fold)
                 log_dets.append(log_det)
+                i += 2 if fold else 1
+            else:
+                z, log_det = flow.forward(z)
+                i += 1
         if ride_along:      # (ops.split_rows: the slices' backward without a memcpy node in a captured step)
             z, self._z_pri_flowed = ops.split_rows(z, n)
         if want_mean and 1 <= len(log_dets) <= 8:     # flow_log_prob in ONE launch (and one in backward) instead of adds + mask + sum + divide

@@ -77,10 +77,12 @@ class MADE(ops.StayOnDevice, nn.Module):
         lin = self._linears()
         return self._colcount, [l.weight for l in lin], [l.bias for l in lin], [l.mask for l in lin]
 
-    def forward(self, z):
+    def forward(self, z, reverse_out=False):
+        """``reverse_out``: x comes back with its columns reversed -- the PermuteLayer that follows the block in an IAF stack
+        (kgvae/model.py:60-66) folded into the node's last launch (the caller then skips that layer)."""
         colcount, weights, biases, masks = self.call_arguments()
         # masks folded once per call, not per pass (the bf16 node folds all layers in one launch, forward and backward)
-        return ops.made_forward(z, colcount, weights, biases, masks=masks)
+        return ops.made_forward(z, colcount, weights, biases, masks=masks, reverse_out=reverse_out)
 
     def forward_unfused(self, z):
         """The same computation as a chain of per-op autograd nodes (kept for cross-checking the fused node)."""

@@ -85,10 +85,11 @@ class _MADEForward(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, z, colcount, masks, *wb):
+    def forward(ctx, z, colcount, masks, reverse_out, *wb):
         ctx.set_materialize_grads(False)
         L = len(wb) // 2
         ws, bs = wb[:L], wb[L:]
+        ctx.reverse_out = bool(reverse_out)      # x comes out with its columns reversed (the PermuteLayer behind the block rides along)
         # masks: the autoregressive masks when the weights are the RAW parameters -- folded here in one launch, and in the backward
         # pass the masked weight gradients go straight into the optimiser's arena where that is registered (then, with the bias
         # gradients, on the side stream: ops.backward_side); None: the weights are masked already
@@ -117,8 +118,13 @@ class _MADEForward(torch.autograd.Function):
         acts = [torch.empty(max(S, 1) * n, ws[l].shape[0], **f32) for l in range(L)]   # acts[L-1] = [mu | alpha]
         x_out = torch.empty(n, d, **f32)
         first_out = xin[0:n] if P > 1 else x_out
+        # ONE launch for passes 1 .. P-1 and their IAF updates (below); pass 0's update, the log-determinant and the column reversal
+        # of a PermuteLayer behind the block ride in it
+        fused_passes = chain and MADE_PASSES_F32 and d % 4 == 0 and lib.TIMER is None
+        log_det = torch.empty(n, **f32)
         # (columns outside the first index set would keep x_old = 0: flows.MADE checks at construction that there are none)
-        lib.call('gv_iaf_update_fwd', ptr(z), ptr(acts0[L - 1]), 0, ptr(z), ptr(colcount[0]), ptr(first_out), n, d, st)
+        if not fused_passes:
+            lib.call('gv_iaf_update_fwd', ptr(z), ptr(acts0[L - 1]), 0, ptr(z), ptr(colcount[0]), ptr(first_out), n, d, st)
         def passes(r0, r1):      # passes 1 .. P-1 for the rows [r0, r1): every launch of a pass is row-local
             for p in range(1, P):
                 a, b = (p - 1) * n + r0, (p - 1) * n + r1
@@ -134,22 +140,27 @@ class _MADEForward(torch.autograd.Function):
                 nxt = xin[p * n + r0:p * n + r1] if p + 1 < P else x_out[r0:r1]
                 lib.call('gv_iaf_update_fwd', ptr(z[r0:r1]), ptr(inp), 2 * d, ptr(xin[a:b]), ptr(colcount[p]), ptr(nxt), r1 - r0, d,
                          lib.stream())
-        fused_passes = chain and MADE_PASSES_F32 and d % 4 == 0 and lib.TIMER is None
         if fused_passes:
-            # ONE launch for passes 1 .. P-1 and their IAF updates: everything a pass does is local to a workgroup's 64 rows, so the
-            # workgroup walks the passes itself (stacked buffers: n rows per pass); 12 launches per MADE become 2
+            # everything a pass does is local to a workgroup's 64 rows, so the workgroup walks the passes itself (stacked buffers: n
+            # rows per pass); 12 launches per MADE become 1
             made_passes_f32(xin, n, [dict(w_packed=packed[l][0], n=widths[l], k=kin[l], bias=bs[l], relu=l < L - 1, out_f32=acts[l][0:n])
                                      for l in range(L)], plan_f,
-                            dict(mode=1, passes=S, step=n, d=d, z=z, colcount=colcount[1], x_out=x_out, flags=1), tag='madechain_fwd_f32')
+                            dict(mode=1, passes=S, step=n, d=d, z=z, colcount=colcount[1], x_out=x_out, net0=acts0[L - 1], cnt0=colcount[0],
+                                 log_det=log_det, flags=1 | 4 | 8 | (16 if ctx.reverse_out else 0)), tag='madechain_fwd_f32')
         elif chain:       # MFMA-bound launches that fill the chip: one sequence over all rows (and the padding rows are skipped per workgroup)
             passes(0, n)
         else:
             _by_row_blocks(passes, n, MADE_F32_ROW_BLOCKS, MADE_F32_ROW_BLOCKS_MIN_TILES)
-        log_det = torch.empty(n, **f32)
-        if P > 1:
+        if fused_passes:
+            pass
+        elif P > 1:
             lib.call('gv_rowsum', ptr(acts[L - 1][(S - 1) * n:]), 2 * d, d, d, ptr(log_det), n, st)
         else:
             log_det = acts0[L - 1][:, d:].sum(dim=1).expand(n).contiguous()
+        if ctx.reverse_out and not fused_passes:
+            rev = torch.empty_like(x_out)
+            lib.call('gv_reverse_cols', ptr(x_out), ptr(rev), n, d, st)
+            x_out = rev
         ctx.save_for_backward(z, colcount, xin, zero_row, *acts, *acts0, *ws, *([pk[1] for pk in packed] if chain else []))
         ctx.L = L
         ctx.chain = chain
@@ -174,11 +185,15 @@ class _MADEForward(torch.autograd.Function):
                                      list(reversed(ctx.masks)) if ctx.masks is not None else None, transposed=True) if chain else None
         gx = torch.zeros(n, d, **f32) if gx is None else _chk(gx.contiguous(), name='gx')
         gld = None if gld is None else _chk(gld.contiguous(), name='gld')
+        fused_passes = chain and MADE_PASSES_F32 and d % 4 == 0 and P > 1 and lib.TIMER is None
+        if ctx.reverse_out and not fused_passes:          # (the fused launch reads dL/dx with its columns reversed)
+            rev = torch.empty_like(gx)
+            lib.call('gv_reverse_cols', ptr(gx), ptr(rev), n, d, st)
+            gx = rev
         grads = [torch.empty(max(S, 1) * n, ws[l].shape[0], **f32) for l in range(L)]   # grad w.r.t. each layer's OUTPUT
         acc_gz = d % 4 == 0 and P > 1                             # the update's backward adds dL/dz in place; the first pass run WRITES it
         g_z = torch.empty(n, d, **f32) if acc_gz else torch.zeros(n, d, **f32)
         gz_p = None if acc_gz else torch.empty(n, d, **f32)
-        fused_passes = chain and MADE_PASSES_F32 and d % 4 == 0 and P > 1 and lib.TIMER is None
         gold_stack = torch.empty(max(S, 1) * n, d, **f32)                 # dL/dx_old of every pass, stacked like the activations
         g_olds = {p: gold_stack[(p - 1) * n:p * n] for p in range(1, P)}
 
@@ -219,7 +234,8 @@ class _MADEForward(torch.autograd.Function):
                              for l in reversed(range(1, L))] +
                             [dict(w_packed=wpb[0], n=d, k=widths[0], out_f32=gold_stack[a0:a0 + n], accumulate=True)], plan_b,
                             dict(mode=2, passes=S, step=-n, d=d, z=z, colcount=colcount[P - 1], net=acts[L - 1][a0:a0 + n], g_in=gx,
-                                 g_logdet=gld, g_z=g_z, flags=(1 if gld is not None else 0) | 2), tag='madechain_bwd_f32')
+                                 g_logdet=gld, g_z=g_z, flags=(1 if gld is not None else 0) | 2 | (4 if ctx.reverse_out else 0)),
+                            tag='madechain_bwd_f32')
         elif chain:
             passes(0, n)
         else:
@@ -231,8 +247,8 @@ class _MADEForward(torch.autograd.Function):
         # chain path: the hidden gradients are stored ReLU-masked, so each layer's weight AND bias gradient over all stacked passes,
         # pass 0's rank-1 term, the mask fold and the store / add into the arena are ONE product on gv_made_gradw_f32 (+ its split sum)
         fused_gradw = (ctx.chain and MADE_GRADW_F32 and S > 0 and all(w_ % 4 == 0 for w_ in widths + kin)
-                       and all(ctx.needs_input_grad[3 + l] for l in range(L))
-                       and all(ctx.needs_input_grad[3 + L + l] or not ctx.has_bias[l] for l in range(L)))
+                       and all(ctx.needs_input_grad[4 + l] for l in range(L))
+                       and all(ctx.needs_input_grad[4 + L + l] or not ctx.has_bias[l] for l in range(L)))
         row_bwd = fused_gradw and ctx.row           # pass 0's backward chain as one single-workgroup launch: gm_l = its masked row gradients
         if row_bwd:     # (launched below, with the products that consume it: nothing on the path to dL/dz reads these rows)
             rows0 = [torch.empty(1, widths[l], **f32) for l in range(L)]
@@ -244,8 +260,8 @@ class _MADEForward(torch.autograd.Function):
         # dL/dW_l, dL/db_l.  Nothing later in the backward pass needs them: with every one of them going straight into the optimiser's
         # arena they run on the side stream, beside the next flow's (launch-bound) passes
         _verify_direct(ctx)
-        wants_w = [ctx.needs_input_grad[3 + l] for l in range(L)]
-        wants_b = [ctx.has_bias[l] and ctx.needs_input_grad[3 + L + l] for l in range(L)]
+        wants_w = [ctx.needs_input_grad[4 + l] for l in range(L)]
+        wants_b = [ctx.has_bias[l] and ctx.needs_input_grad[4 + L + l] for l in range(L)]
         tgt_w = [ctx.direct_w[l] if (wants_w[l] and ctx.direct_w[l] is not None and ctx.direct_w[l].data_ptr() in GRAD_FRESH
                                      and ctx.direct_w[l].is_contiguous()) else None for l in range(L)]
         tgt_b = [ctx.direct_b[l] if (wants_b[l] and ctx.direct_b[l] is not None and ctx.direct_b[l].is_contiguous()) else None
@@ -304,7 +320,7 @@ class _MADEForward(torch.autograd.Function):
                             g_ws[l] = None
                         else:
                             g_ws[l] = r
-        return (g_z, None, None, *g_ws, *g_bs)
+        return (g_z, None, None, None, *g_ws, *g_bs)
 
 
 # ---- K4 in bf16 (csrc/k_made.hip): bf16 storage of weights and activations, every product the same NT kernel ----------------
@@ -749,7 +765,8 @@ class _Chain32Iaf(_ct.Structure):
     """gv_chain32_iaf of include/gcnvae.h."""
     _fields_ = [('mode', _ct.c_int32), ('passes', _ct.c_int32), ('d', _ct.c_int32), ('flags', _ct.c_int32), ('step', _ct.c_int64),
                 ('z', _ct.c_void_p), ('colcount', _ct.c_void_p), ('x_out', _ct.c_void_p), ('net', _ct.c_void_p), ('g_in', _ct.c_void_p),
-                ('g_logdet', _ct.c_void_p), ('g_z', _ct.c_void_p), ('ld_net', _ct.c_int32), ('reserved', _ct.c_int32)]
+                ('g_logdet', _ct.c_void_p), ('g_z', _ct.c_void_p), ('ld_net', _ct.c_int32), ('reserved', _ct.c_int32),
+                ('net0', _ct.c_void_p), ('cnt0', _ct.c_void_p), ('log_det', _ct.c_void_p)]
 
 
 MADE_PASSES_F32 = _os.environ.get('GV_MADE_PASSES_F32', '1') == '1'      # all stacked passes of a MADE + the IAF updates in ONE launch per direction
@@ -774,6 +791,7 @@ def made_passes_f32(x, m, layers, plan, iaf, tag=None):
     net = iaf.get('net')
     ia.net, ia.ld_net = ptr(net), net.stride(0) if net is not None else 0
     ia.g_in, ia.g_logdet, ia.g_z = ptr(iaf.get('g_in')), ptr(iaf.get('g_logdet')), ptr(iaf.get('g_z'))
+    ia.net0, ia.cnt0, ia.log_det = ptr(iaf.get('net0')), ptr(iaf.get('cnt0')), ptr(iaf.get('log_det'))
     live = _ops.LIVE_ROWS
     rows_dev = live[0] if (live is not None and int(m) == live[1] and x.device == live[0].device) else None
     lib.call('gv_made_passes_f32', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), ptr(plan), ptr(rows_dev), _ct.addressof(ia),
@@ -1241,7 +1259,7 @@ def _by_row_blocks(run, n, want, min_tiles=None):
         main.wait_stream(sd)
 
 
-def made_forward(z, colcount, weights, biases, masks=None):
+def made_forward(z, colcount, weights, biases, masks=None, reverse_out=False):
     """MADE.forward as one autograd node; with bf16 dense products (set_gemm_precision('bf16'), BASELINE configs[2]) and
     layer widths that are multiples of 8 the bf16-storage pipeline of csrc/k_made.hip runs.  ``masks``: the autoregressive
     masks when ``weights`` are the RAW parameters (MaskedLinear.weight); None when the masks are folded in already."""
@@ -1249,7 +1267,8 @@ def made_forward(z, colcount, weights, biases, masks=None):
                                                                                        for w in weights)):
         if masks is not None and len(weights) > 8:           # gv_mul_multi's table holds 8 entries
             weights, masks = [masked_weight(m, w) for m, w in zip(masks, weights)], None
-        return _MADEForwardBF16.apply(z, colcount, tuple(masks) if masks is not None else None, *weights, *biases)
+        x, log_det = _MADEForwardBF16.apply(z, colcount, tuple(masks) if masks is not None else None, *weights, *biases)
+        return (_ops.reverse_cols(x) if reverse_out else x), log_det
     if masks is not None and len(weights) > 8:               # gv_mul_multi's table holds 8 entries
         weights, masks = [masked_weight(m, w) for m, w in zip(masks, weights)], None
-    return _MADEForward.apply(z, colcount, tuple(masks) if masks is not None else None, *weights, *biases)
+    return _MADEForward.apply(z, colcount, tuple(masks) if masks is not None else None, bool(reverse_out), *weights, *biases)

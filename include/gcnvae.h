@@ -375,6 +375,12 @@ int gv_made_chain_f32(const float* x, int ldx, int m, int n_layers, const gv_cha
  *     the update's backward stores the handed-through gradient there, the chain adds to it; g_in = dL/dx_new of the first pass,
  *     later passes take the previous pass's out_f32 slice; g_logdet (flags bit 0: [m], first pass only); g_z [m][d] += the
  *     passes' shares (flags bit 1: the first pass WRITES it); colcount as above, the next pass's counts d entries BACK.
+ *   What sits around the passes of a MADE block rides along (flags, all optional):
+ *     forward  bit 2: the first pass's input is itself an update -- of pass 0, whose [mu | alpha] is ONE row net0 [2 d] with the
+ *                     counts cnt0 [d] (x_old = 0) -- computed here and stored to x before it is staged;
+ *              bit 3: log_det [m] = the row sums of alpha of the launch's last pass (gv_rowsum's order);
+ *              bit 4: x_out is stored with its columns REVERSED (the PermuteLayer behind the block, kgvae/flow_network.py:18-35);
+ *     backward bit 2: g_in (the first pass's dL/dx_new) is read with its columns reversed (that PermuteLayer's backward).
  * Same arithmetic, element by element, as gv_iaf_update_fwd / gv_iaf_update_bwd_acc around gv_made_chain_f32 launches.  d % 4 == 0. */
 typedef struct gv_chain32_iaf {
     int32_t mode, passes, d, flags;
@@ -387,6 +393,9 @@ typedef struct gv_chain32_iaf {
     const float* g_logdet;
     float* g_z;
     int32_t ld_net, reserved;
+    const float* net0;
+    const int32_t* cnt0;
+    float* log_det;
 } gv_chain32_iaf;
 int gv_made_passes_f32(float* x, int ldx, int m, int n_layers, const gv_chain32_layer* layers, const int32_t* plan,
                        const int32_t* rows_dev, const gv_chain32_iaf* iaf, void* stream);

@@ -297,6 +297,34 @@ def test_fused_passes_on_a_padded_batch_equal_the_launch_per_pass_path(monkeypat
         assert torch.equal(a, b) and float(a.abs().max()) > 0
 
 
+@pytest.mark.parametrize('passes', [True, False])
+def test_made_block_with_the_permute_layer_folded_in_equals_block_then_permute(monkeypatch, passes):
+    """MADE.forward(z, reverse_out=True) -- the PermuteLayer behind an IAF block as reversed column stores of the block's last
+    launch, reversed reads of dL/dx in its backward launch -- against the block followed by the layer: bit for bit, values and
+    gradients; with the launch-per-pass path (explicit gv_reverse_cols around the node) as well."""
+    from gcn_vae_amd import flows, made
+    monkeypatch.setattr(made, 'MADE_PASSES_F32', passes)
+    d, h, rows = 200, 200, 777
+    z = torch.randn(rows, d, generator=torch.Generator().manual_seed(12)).cuda()
+    probe = torch.randn(rows, d, generator=torch.Generator().manual_seed(13)).cuda()
+    perm = flows.PermuteLayer(d)
+    res = []
+    for fold in (False, True):
+        m = _made(d, h, 3)
+        zz = z.clone().requires_grad_(True)
+        if fold:
+            x, ld = m(zz, reverse_out=True)
+        else:
+            x, ld = m(zz)
+            x = perm(x)[0]
+        ((x * probe).sum() + (ld ** 2).sum()).backward()
+        torch.cuda.synchronize()
+        res.append((x.detach().clone(), ld.detach().clone(), zz.grad.clone(), [p.grad.detach().clone() for p in m.parameters()]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    for a, b in zip(res[0][3], res[1][3]):
+        assert torch.equal(a, b) and float(a.abs().max()) > 0
+
+
 def test_mean_rows_multi_is_flow_log_prob_and_its_gradient():
     """ops.mean_rows_multi (gv_mean_rows_multi / _bwd) = mean over the rows that exist of the summed per-row log-determinants
     (kgvae/model.py:116-123), against torch: all rows, a row limit (rows riding along behind the first n), a device row count."""
