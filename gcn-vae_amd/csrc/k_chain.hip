@@ -304,12 +304,15 @@ __device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const g
             if (c0 < kp_next)
                 *reinterpret_cast<uint2*>(An + row * ldk + c0) =
                     cv ? make_uint2(b0 | ((uint32_t)b1 << 16), b2 | ((uint32_t)b3 << 16)) : make_uint2(0, 0);
-            if (Ly.out_bf16_t && cv && m0 + row < m) {
+            // (tiled copies: the rows of the last tile past m are written as zeros -- they take part in the weight-gradient reduction,
+            // and the caller's buffer then needs no fill)
+            if (Ly.out_bf16_t && cv && (m0 + row < m || (!FULL && Ly.t_tile))) {      // (the lean instance: every MADE pass)
+                const bool real = m0 + row < m;
                 uint16_t* o = Ly.out_bf16_t + (size_t)c0 * Ly.ldt + (Ly.t_tile ? (int)blockIdx.x * Ly.t_tile : m0) + row;
-                o[0] = b0;
-                o[Ly.ldt] = b1;
-                o[2 * (size_t)Ly.ldt] = b2;
-                o[3 * (size_t)Ly.ldt] = b3;
+                o[0] = real ? b0 : (uint16_t)0;
+                o[Ly.ldt] = real ? b1 : (uint16_t)0;
+                o[2 * (size_t)Ly.ldt] = real ? b2 : (uint16_t)0;
+                o[3 * (size_t)Ly.ldt] = real ? b3 : (uint16_t)0;
             }
         }
         __builtin_amdgcn_sched_barrier(0);      // one group at a time keeps the address registers few
@@ -465,12 +468,12 @@ __device__ __forceinline__ void chain_epilogue_iaf(const f32x16_t (&acc)[2], con
             if (c0 < kp_next && !(dbg & 8))
                 *reinterpret_cast<uint2*>(An + row * ldk + c0) =
                     cv ? make_uint2(b0 | ((uint32_t)b1 << 16), b2 | ((uint32_t)b3 << 16)) : make_uint2(0, 0);
-            if (Ly.out_bf16_t && live && !(dbg & 4)) {
+            if (Ly.out_bf16_t && cv && (live || Ly.t_tile) && !(dbg & 4)) {      // (tiled copies: zeros in the rows past m, as above)
                 uint16_t* o = Ly.out_bf16_t + (size_t)c0 * Ly.ldt + (Ly.t_tile ? (int)blockIdx.x * Ly.t_tile : m0) + row;
-                o[0] = b0;
-                o[Ly.ldt] = b1;
-                o[2 * (size_t)Ly.ldt] = b2;
-                o[3 * (size_t)Ly.ldt] = b3;
+                o[0] = live ? b0 : (uint16_t)0;
+                o[Ly.ldt] = live ? b1 : (uint16_t)0;
+                o[2 * (size_t)Ly.ldt] = live ? b2 : (uint16_t)0;
+                o[3 * (size_t)Ly.ldt] = live ? b3 : (uint16_t)0;
             }
             __builtin_amdgcn_sched_barrier(0);
         }

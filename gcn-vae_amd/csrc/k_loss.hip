@@ -370,6 +370,124 @@ __global__ __launch_bounds__(256) void k_kl_fwd_v4(const float* z, const float* 
     if (threadIdx.x == 0) part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
+// FOUR NODES PER WAVE (h <= 256, h % 4 == 0, k <= 16): a row of 16 lanes owns one node, lane l of the row the float4 columns
+// l, l + 16, l + 32, l + 48.  The form above spends most of its ~850 VALU instructions per node on k + 2 whole-wave reductions
+// (four DPP steps, four v_readlane and three adds each, serialised by the loop over the components); a row's reduction is the
+// four DPP steps alone, the four nodes of a wave share every instruction, and the component loop's LDS reads serve four nodes.
+// (Measured at FB15k-237 size: 34.4 -> 32.4 us.  The kernel is bound by its per-element arithmetic -- ablations, NOTES.md round 4:
+// softplus + sqrt 13 us, the component loop 5, the own-density term 4, the three row stores 4 of 37 -- and fewer, longer workgroups
+// with the next rows in flight are SLOWER: 256 / 512 / 768 workgroups 54 / 40 / 34 us.)  Per element the same expressions as k_kl_fwd / k_kl_fwd_v4; the sums over a node's columns and over the nodes run in another
+// (fixed) order.
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<DPP_QUAD_1032>(v));
+    v = fmaxf(v, dpp_f<DPP_QUAD_2301>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_kl_fwd_v5(const float* z, const float* m, int ld_m, const float* v,
+                                                   const float* mix, const float* flp, float* resp, float* part,
+                                                   int64_t n, int h, int k, const int* rows_dev, const float* h2,
+                                                   const float* eps, float* z_out, float* v_out, float* m_out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float wsum[4];
+    __shared__ float lconst[KL_KMAX];
+    if (rows_dev) n = *rows_dev;
+    const int kh = k * h;
+    for (int i = threadIdx.x; i < 2 * kh / 4; i += 256) reinterpret_cast<float4*>(sm)[i] = reinterpret_cast<const float4*>(mix)[i];
+    for (int j = threadIdx.x >> 6; j < k; j += 4) {
+        float t = 0.f;
+        for (int c = threadIdx.x & 63; c < h; c += 64) t += mix[2 * kh + j * h + c];
+        t = wave_sum(t);
+        if ((threadIdx.x & 63) == 0) lconst[j] = t;
+    }
+    __syncthreads();
+    const float* mu = sm;
+    const float* i2v = sm + kh;
+    const int lane = threadIdx.x & 63, l16 = lane & 15, rw = lane >> 4, wv = threadIdx.x >> 6;
+    const float fl = flp ? *flp : 0.f;
+    const float logk = logf((float)k);
+    constexpr int G = 4;
+    bool on[G];
+    int col[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        col[g] = 4 * (l16 + 16 * g);
+        on[g] = col[g] < h;
+    }
+    float my_terms = 0.f;                       // every lane of a row: the sum of the row's nodes' terms, in node order
+    for (int64_t base = (int64_t)blockIdx.x * 16 + wv * 4; base < n; base += (int64_t)gridDim.x * 16) {      // (wave-uniform)
+        const bool live = base + rw < n;
+        const int64_t r = live ? base + rw : n - 1;      // rows past the end shadow the last node: uniform control flow, no effects
+        float zz[G][4];
+        float a = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) zz[g][i] = 0.f;
+            if (!on[g]) continue;
+            float mm[4], vv[4];
+            if (h2) {      // fused reparameterisation (K3)
+                const float4 m4 = *reinterpret_cast<const float4*>(h2 + r * 2 * h + col[g]);
+                const float4 r4 = *reinterpret_cast<const float4*>(h2 + r * 2 * h + h + col[g]);
+                const float4 e4 = *reinterpret_cast<const float4*>(eps + r * h + col[g]);
+                const float raw[4] = {r4.x, r4.y, r4.z, r4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
+                mm[0] = m4.x; mm[1] = m4.y; mm[2] = m4.z; mm[3] = m4.w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    vv[i] = softplus_t(raw[i]) + 1e-8f;
+                    zz[g][i] = mm[i] + ee[i] * sqrtf(vv[i]);
+                }
+                if (live) {
+                    *reinterpret_cast<float4*>(z_out + r * h + col[g]) = make_float4(zz[g][0], zz[g][1], zz[g][2], zz[g][3]);
+                    *reinterpret_cast<float4*>(v_out + r * h + col[g]) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    if (m_out) *reinterpret_cast<float4*>(m_out + r * h + col[g]) = m4;
+                }
+            } else {
+                const float4 z4 = *reinterpret_cast<const float4*>(z + r * h + col[g]);
+                const float4 m4 = *reinterpret_cast<const float4*>(m + r * ld_m + col[g]);
+                const float4 v4 = *reinterpret_cast<const float4*>(v + r * h + col[g]);
+                zz[g][0] = z4.x; zz[g][1] = z4.y; zz[g][2] = z4.z; zz[g][3] = z4.w;
+                mm[0] = m4.x; mm[1] = m4.y; mm[2] = m4.z; mm[3] = m4.w;
+                vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = zz[g][i] - mm[i];
+                a += -(d * d) / (2.f * vv[i]) - logf(sqrtf(vv[i])) - LOG_SQRT_2PI;
+            }
+        }
+        a = row16_sum(a);
+        float my_l = -INFINITY;
+        for (int j = 0; j < k; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (!on[g]) continue;
+                const float4 mu4 = *reinterpret_cast<const float4*>(mu + j * h + col[g]);
+                const float4 iv4 = *reinterpret_cast<const float4*>(i2v + j * h + col[g]);
+                const float d0 = zz[g][0] - mu4.x, d1 = zz[g][1] - mu4.y, d2 = zz[g][2] - mu4.z, d3 = zz[g][3] - mu4.w;
+                acc = fmaf(-(d0 * d0), iv4.x, acc);
+                acc = fmaf(-(d1 * d1), iv4.y, acc);
+                acc = fmaf(-(d2 * d2), iv4.z, acc);
+                acc = fmaf(-(d3 * d3), iv4.w, acc);
+            }
+            acc = row16_sum(acc) - lconst[j];
+            if (l16 == j) my_l = acc;
+        }
+        const float mx = row16_max(my_l);
+        const float e = l16 < k ? expf(my_l - mx) : 0.f;
+        const float se = row16_sum(e);
+        if (live && l16 < k) resp[r * k + l16] = e / se;
+        if (live) my_terms += a + fl - (mx + logf(se) - logk);
+    }
+    const float t = (rl_bcast_f(my_terms, 0) + rl_bcast_f(my_terms, 16)) + (rl_bcast_f(my_terms, 32) + rl_bcast_f(my_terms, 48));
+    if (lane == 0) wsum[wv] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
 // per-node gradients gz, gm, gv (scaled by *gkl / n)
 __global__ __launch_bounds__(256) void k_kl_bwd_nodes(const float* z, const float* m, int ld_m, const float* v,
                                                       const float* mix, const float* resp, const float* gkl, float gscale,
@@ -507,6 +625,165 @@ __global__ __launch_bounds__(256) void k_kl_bwd_fused(const float* z, const floa
             const float gvv = (sm[KT + j][0][lane] + sm[KT + j][1][lane]) + (sm[KT + j][2][lane] + sm[KT + j][3][lane]);
             part[((size_t)blockIdx.y * 2 * k + j) * h + c] = -gmu * 2.f * i2[j];       // same terms as k_kl_bwd_mix_part
             part[((size_t)blockIdx.y * 2 * k + k + j) * h + c] = -gvv;
+        }
+    }
+}
+
+// The fused backward with a lane on FOUR CONSECUTIVE COLUMNS (h <= 256, h % 4 == 0, k <= KT): one wave covers a whole row, so the
+// node rows move in 16-B accesses (the lane-per-column form above reads and writes 256 B per wave-instruction, and its fourth
+// 64-column tile of a 200-wide row keeps 8 of 64 lanes busy), the row's responsibilities are read once instead of once per tile,
+// and the mixture table comes from LDS.  Grid = KL_SLICES workgroups of 8 waves that interleave the slice's rows, two rows in
+// flight per wave; the waves' 2 k partial sums are combined through LDS two components at a time, in wave order.  Per element the
+// same expressions; a slice's rows are summed in another (fixed) order.
+constexpr int KLB_WAVES = 8, KLB_KR = 2;
+template <int KT>
+__global__ __launch_bounds__(64 * KLB_WAVES) void k_kl_bwd_cols4(const float* z, const float* m, int ld_m, const float* v, const float* mix,
+                                                                  const float* resp, const float* gkl, float gscale, float z_extra,
+                                                                  float* gz, float* gm, float* gv, float* part, int64_t n, int h, int k,
+                                                                  const int* rows_dev, const float* h2, const float* eps,
+                                                                  const float* gz_up, float* gh2) {
+    extern __shared__ __attribute__((aligned(16))) float4 sm4[];      // [2][k * h / 4] (mu_j, 1/(2 v_j)), then red[2 KR][waves][64]
+    const int64_t n_real = rows_dev ? (int64_t)*rows_dev : n;
+    const float refit = (float)n / (float)n_real;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int h4 = h >> 2, kh4 = k * h4;
+    const bool ok = lane < h4;
+    const int col = 4 * lane;
+    for (int i = threadIdx.x; i < 2 * kh4; i += 64 * KLB_WAVES) sm4[i] = reinterpret_cast<const float4*>(mix)[i];
+    const float4* smu = sm4 + (ok ? lane : 0);
+    const float4* si2 = smu + kh4;
+    float4* red = sm4 + 2 * kh4;
+    const int nsl = gridDim.x;
+    const int64_t per = (n + nsl - 1) / nsl;
+    const int64_t r0 = blockIdx.x * per, r1 = min(n, r0 + per);
+    const float cg = gscale * (gkl ? *gkl : 1.f) / (float)n * refit;
+    const float cz = z_extra * (gkl ? *gkl : 1.f) * refit;
+    float amu[KT][4], av[KT][4];
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { amu[j][i] = 0.f; av[j][i] = 0.f; }
+    __syncthreads();
+    constexpr int RU = 2;
+    for (int64_t rb = r0 + w; rb < r1; rb += KLB_WAVES * RU) {
+        // the rows' responsibilities: lanes 16u .. 16u + k - 1 load row u's k values, read back by v_readlane
+        float rv = 0.f;
+        {
+            const int64_t rr = rb + KLB_WAVES * (lane >> 4);
+            if ((lane & 15) < k && (lane >> 4) < RU && rr < r1 && rr < n_real) rv = resp[rr * k + (lane & 15)];
+        }
+        float zz[RU][4], mm[RU][4], vv[RU][4], rawv[RU][4], ee[RU][4], gu[RU][4];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int64_t r = rb + KLB_WAVES * u;
+            float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f), m4 = z4, v4 = make_float4(1.f, 1.f, 1.f, 1.f), r4 = z4, e4 = z4, g4 = z4;
+            if (ok && r < r1) {
+                z4 = *reinterpret_cast<const float4*>(z + r * h + col);
+                m4 = *reinterpret_cast<const float4*>(m + r * ld_m + col);
+                v4 = *reinterpret_cast<const float4*>(v + r * h + col);
+                if (gh2) {
+                    r4 = *reinterpret_cast<const float4*>(h2 + r * 2 * h + h + col);
+                    e4 = *reinterpret_cast<const float4*>(eps + r * h + col);
+                    if (gz_up) g4 = *reinterpret_cast<const float4*>(gz_up + r * h + col);
+                }
+            }
+            zz[u][0] = z4.x; zz[u][1] = z4.y; zz[u][2] = z4.z; zz[u][3] = z4.w;
+            mm[u][0] = m4.x; mm[u][1] = m4.y; mm[u][2] = m4.z; mm[u][3] = m4.w;
+            vv[u][0] = v4.x; vv[u][1] = v4.y; vv[u][2] = v4.z; vv[u][3] = v4.w;
+            rawv[u][0] = r4.x; rawv[u][1] = r4.y; rawv[u][2] = r4.z; rawv[u][3] = r4.w;
+            ee[u][0] = e4.x; ee[u][1] = e4.y; ee[u][2] = e4.z; ee[u][3] = e4.w;
+            gu[u][0] = g4.x; gu[u][1] = g4.y; gu[u][2] = g4.z; gu[u][3] = g4.w;
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int64_t r = rb + KLB_WAVES * u;
+            if (r >= r1) break;                            // wave-uniform
+            if (r >= n_real) {                             // padding row (wave-uniform): zero gradients, no share in the sums
+                if (ok) {
+                    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gh2) {
+                        *reinterpret_cast<float4*>(gh2 + r * 2 * h + col) = zero;
+                        *reinterpret_cast<float4*>(gh2 + r * 2 * h + h + col) = zero;
+                    } else {
+                        *reinterpret_cast<float4*>(gz + r * h + col) = zero;
+                        *reinterpret_cast<float4*>(gm + r * h + col) = zero;
+                        *reinterpret_cast<float4*>(gv + r * h + col) = zero;
+                    }
+                }
+                continue;
+            }
+            float mixg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                if (j < k) {
+                    const float ra = rl_bcast_f(rv, 16 * u + j);
+                    const float4 mu4 = smu[j * h4], i24 = si2[j * h4];
+                    const float mu_[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, i2_[4] = {i24.x, i24.y, i24.z, i24.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float dj = zz[u][i] - mu_[i];
+                        mixg[i] = fmaf(ra * dj, 2.f * i2_[i], mixg[i]);
+                        amu[j][i] = fmaf(ra, dj, amu[j][i]);
+                        av[j][i] = fmaf(ra, dj * dj * 2.f * i2_[i] * i2_[i] - i2_[i], av[j][i]);
+                    }
+                }
+            }
+            if (ok) {
+                float o0[4], o1[4], o2[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d = zz[u][i] - mm[u][i];
+                    const float gzk = fmaf(cz, zz[u][i], cg * (-d / vv[u][i] + mixg[i]));
+                    const float gmk = cg * (d / vv[u][i]);
+                    const float gvk = cg * (d * d / (2.f * vv[u][i] * vv[u][i]) - 0.5f / vv[u][i]);
+                    if (gh2) {     // fused reparameterisation backward (K3)
+                        const float g = gzk + gu[u][i];
+                        const float dv = g * ee[u][i] * 0.5f / sqrtf(vv[u][i]) + gvk;
+                        o0[i] = g + gmk;
+                        o1[i] = rawv[u][i] > 20.f ? dv : dv / (1.f + expf(-rawv[u][i]));
+                    } else {
+                        o0[i] = gzk; o1[i] = gmk; o2[i] = gvk;
+                    }
+                }
+                if (gh2) {
+                    *reinterpret_cast<float4*>(gh2 + r * 2 * h + col) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+                    *reinterpret_cast<float4*>(gh2 + r * 2 * h + h + col) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+                } else {
+                    *reinterpret_cast<float4*>(gz + r * h + col) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+                    *reinterpret_cast<float4*>(gm + r * h + col) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+                    *reinterpret_cast<float4*>(gv + r * h + col) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                }
+            }
+        }
+    }
+    // the waves' sums, KR components per round: red[(2 c + kind)][wave][lane]; wave q < 2 KR adds entry q's 8 partials in wave order
+    for (int j0 = 0; j0 < k; j0 += KLB_KR) {
+        __syncthreads();                                   // (the previous round's readers are done; round 0: the row loop's LDS reads)
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            if (j >= j0 && j < j0 + KLB_KR && j < k) {
+                red[((2 * (j - j0)) * KLB_WAVES + w) * 64 + lane] = make_float4(amu[j][0], amu[j][1], amu[j][2], amu[j][3]);
+                red[((2 * (j - j0) + 1) * KLB_WAVES + w) * 64 + lane] = make_float4(av[j][0], av[j][1], av[j][2], av[j][3]);
+            }
+        }
+        __syncthreads();
+        const int j = j0 + (w >> 1), kind = w & 1;
+        if (w < 2 * KLB_KR && j < k && ok) {
+            float4 t = red[((2 * (j - j0) + kind) * KLB_WAVES) * 64 + lane];
+#pragma unroll
+            for (int q = 1; q < KLB_WAVES; ++q) {
+                const float4 x = red[((2 * (j - j0) + kind) * KLB_WAVES + q) * 64 + lane];
+                t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
+            }
+            float4 o;
+            if (kind == 0) {       // same terms as k_kl_bwd_mix_part
+                const float4 i24 = si2[j * h4];
+                o = make_float4(-t.x * 2.f * i24.x, -t.y * 2.f * i24.y, -t.z * 2.f * i24.z, -t.w * 2.f * i24.w);
+            } else {
+                o = make_float4(-t.x, -t.y, -t.z, -t.w);
+            }
+            *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 2 * k + (kind ? k : 0) + j) * h + col) = o;
         }
     }
 }
@@ -816,6 +1093,12 @@ static bool kl_fwd_v4(int nb, size_t lds, hipStream_t st, const float* z, const 
                     (!h2 || aligned16(h2)) && (!eps || aligned16(eps)) && (!z_out || aligned16(z_out)) && (!v_out || aligned16(v_out)) &&
                     (!m_out || aligned16(m_out));
     if (!env || h % 4 != 0 || h > 1024 || !al) return false;
+    static const int v5 = getenv("GV_KL_V5") ? atoi(getenv("GV_KL_V5")) : 1;
+    if (v5 && h <= 256 && k <= 16) {      // four nodes per wave
+        hipLaunchKernelGGL(k_kl_fwd_v5, dim3(nb), dim3(256), lds, st, z, m, ld_m, v, mix, flp, resp, part, n, h, k, rows_dev, h2, eps,
+                           z_out, v_out, m_out);
+        return true;
+    }
 #define GV_KL_V4(G_) hipLaunchKernelGGL(k_kl_fwd_v4<G_>, dim3(nb), dim3(256), lds, st, z, m, ld_m, v, mix, flp, resp, part, n, h, k, rows_dev, h2, eps, z_out, v_out, m_out)
     if (h <= 256) GV_KL_V4(1);
     else if (h <= 512) GV_KL_V4(2);
@@ -851,6 +1134,24 @@ extern "C" int gv_kl_fwd(const float* z, const float* m, int ld_m, const float* 
     return launch_status("gv_kl_fwd");
 }
 
+// the float4-column backward where rows are 16-B aligned (GV_KL_BWD_V4=0 keeps the lane-per-column form)
+static bool kl_bwd_cols4(hipStream_t st, const float* z, const float* m, int ld_m, const float* v, const float* mix, const float* resp,
+                         const float* gkl, float gscale, float z_extra, float* gz, float* gm, float* gv, float* part, int64_t n, int h,
+                         int k, const int* rows_dev, const float* h2, const float* eps, const float* gz_up, float* gh2) {
+    static const int env = getenv("GV_KL_BWD_V4") ? atoi(getenv("GV_KL_BWD_V4")) : 1;
+    const bool al = aligned16(z) && aligned16(m) && ld_m % 4 == 0 && aligned16(v) && aligned16(mix) && aligned16(part) &&
+                    (!gz || aligned16(gz)) && (!gm || aligned16(gm)) && (!gv || aligned16(gv)) && (!h2 || aligned16(h2)) &&
+                    (!eps || aligned16(eps)) && (!gz_up || aligned16(gz_up)) && (!gh2 || aligned16(gh2));
+    if (!env || h % 4 != 0 || h > 256 || k > 10 || !al) return false;      // (a 16-component instance spills: k > 10 keeps the other form)
+    const size_t lds = ((size_t)2 * k * h / 4 + (size_t)2 * KLB_KR * KLB_WAVES * 64) * sizeof(float4);
+    if (lds > 64 * 1024) return false;
+#define GV_KLB(KT_) hipLaunchKernelGGL(k_kl_bwd_cols4<KT_>, dim3(KL_SLICES), dim3(64 * KLB_WAVES), lds, st, z, m, ld_m, v, mix, resp, gkl, \
+                                       gscale, z_extra, gz, gm, gv, part, n, h, k, rows_dev, h2, eps, gz_up, gh2)
+    GV_KLB(10);
+#undef GV_KLB
+    return true;
+}
+
 extern "C" int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* v, const float* z_pre,
                          const float* resp, const float* gkl, float gscale, float z_extra, float* gz, float* gm,
                          float* gv, float* g_zpre, int accumulate_zpre, float* workspace, int mix_ready, int64_t n, int h,
@@ -861,7 +1162,9 @@ extern "C" int gv_kl_bwd(const float* z, const float* m, int ld_m, const float* 
     float* mix = workspace;  // mix_ready: the caller hands back the workspace gv_kl_fwd filled for the same z_pre
     if (!mix_ready) hipLaunchKernelGGL(k_kl_mix, dim3((k * h + 255) / 256), dim3(256), 0, GV_ST, z_pre, k, h, mix);
     float* part = workspace + 3 * (size_t)k * h + RED_BLOCKS;
-    if (k <= KL_FUSED_KT) {
+    if (kl_bwd_cols4(GV_ST, z, m, ld_m, v, mix, resp, gkl, gscale, z_extra, gz, gm, gv, part, n, h, k, rows_dev, nullptr, nullptr,
+                     nullptr, nullptr)) {
+    } else if (k <= KL_FUSED_KT) {
         hipLaunchKernelGGL(k_kl_bwd_fused<KL_FUSED_KT>, dim3((h + 63) / 64, KL_SLICES), dim3(256), 0, GV_ST, z, m, ld_m, v, mix,
                            resp, gkl, gscale, z_extra, gz, gm, gv, part, n, h, k, rows_dev);
     } else {
@@ -919,8 +1222,10 @@ extern "C" int gv_reparam_kl_bwd(const float* z, const float* h2, const float* v
     float* part = workspace + 3 * (size_t)k * h + RED_BLOCKS;
     float* none = nullptr;
     const int* no_rows = nullptr;
-    hipLaunchKernelGGL(k_kl_bwd_fused<KL_FUSED_KT>, dim3((h + 63) / 64, KL_SLICES), dim3(256), 0, GV_ST, z, h2, 2 * h, v,
-                       (const float*)mix, resp, gkl, gscale, z_extra, none, none, none, part, n, h, k, no_rows, h2, eps, gz_up, gh2);
+    if (!kl_bwd_cols4(GV_ST, z, h2, 2 * h, v, mix, resp, gkl, gscale, z_extra, none, none, none, part, n, h, k, no_rows, h2, eps, gz_up,
+                      gh2))
+        hipLaunchKernelGGL(k_kl_bwd_fused<KL_FUSED_KT>, dim3((h + 63) / 64, KL_SLICES), dim3(256), 0, GV_ST, z, h2, 2 * h, v,
+                           (const float*)mix, resp, gkl, gscale, z_extra, none, none, none, part, n, h, k, no_rows, h2, eps, gz_up, gh2);
     hipLaunchKernelGGL(k_kl_bwd_mix_final, dim3((2 * k * h + 15) / 16), dim3(1024), 0, GV_ST, (const float*)part, z_pre, gkl, gscale,
                        g_zpre, accumulate_zpre, n, h, k, KL_SLICES, no_rows);
     return launch_status("gv_reparam_kl_bwd");

@@ -432,10 +432,12 @@ __device__ __forceinline__ void iaf_tile_out(const uint16_t (*t)[68], uint16_t* 
     if (t_tile > 0) ldt = 64;
     for (int i = threadIdx.x; i < 64 * 16; i += 256) {
         const int cc = i >> 4, rq = (i & 15) << 2;
-        if (c0 + cc >= d || r0 + rq >= rows) continue;
+        // (tiled destination: the whole 64-row tile is written -- the LDS tile holds zeros in the rows past `rows`, which take part in
+        // the weight-gradient reduction, so the caller's buffer needs no fill)
+        if (c0 + cc >= d || (t_tile <= 0 && r0 + rq >= rows)) continue;
         uint16_t* o = dst_t + (size_t)(c0 + cc) * ldt + roff + rq;
         const uint2 v = *reinterpret_cast<const uint2*>(&t[cc][rq]);
-        if (r0 + rq + 3 < rows) {
+        if (t_tile > 0 || r0 + rq + 3 < rows) {
             *reinterpret_cast<uint2*>(o) = v;
         } else {
             o[0] = (uint16_t)(v.x & 0xffff);

@@ -347,12 +347,14 @@ def _empty_t_tiles(widths, passes, n, kw):
     """Transposed-copy buffers in tiles of 64 rows: ONE allocation [passes * T][sum(widths)][64] (T = ceil(n / 64) tiles per
     pass), buffer i = the column range of width_i -- element (column c, stacked row r) at [r // 64][c][r % 64].  A workgroup of the
     weight-gradient product (gv_gemm_bf16_gradw_tiles) then reads contiguous 128-B x width blocks, and a chain workgroup (64
-    rows) writes one.  The rows [n, 64 T) of every pass's last tile stay zero (they take part in the reduction).
+    rows) writes one.  The rows [n, 64 T) of every pass's last tile are zero (they take part in the reduction): written so by the producers.
     Returns (buffers, tiles per pass, elements between two tiles)."""
     T = (int(n) + 63) // 64
     t = torch.empty(passes * T, sum(widths), 64, **kw)
-    if n % 64:
-        t.view(passes, T, sum(widths), 64)[:, T - 1, :, n % 64:].zero_()
+    # (no fill: every producer of a tile -- the chains' epilogues, the IAF update kernels -- writes zeros into the rows past n;
+    # GV_MADE_POISON=1 starts the buffer as NaNs so that a producer that does not shows up in the tests)
+    if _os.environ.get('GV_MADE_POISON') == '1':
+        t.fill_(float('nan'))
     out, o = [], 0
     for w in widths:
         out.append(t[:, o:o + w])

@@ -214,7 +214,8 @@ int gv_rel_gradw_gemm(const float* x, int ld_x, const int32_t* x_rows, const flo
 int gv_iaf_update_fwd_bf16(const float* z, const float* net, int ld_net, const float* x_old, const int32_t* colcount, float* x_new,
                            uint16_t* x_b, int ldb, uint16_t* x_t, int ldt, int64_t n, int d, void* stream);
 /* ... x_t in tiles of 64 rows: element (column c, row r) at x_t[(r / 64) * t_tile + c * 64 + r % 64], t_tile >= 64 d elements
- * between tiles -- the operand form of gv_gemm_bf16_gradw_tiles; rows [n, 64 ceil(n / 64)) of the last tile are not written. */
+ * between tiles -- the operand form of gv_gemm_bf16_gradw_tiles; rows [n, 64 ceil(n / 64)) of the last tile are written as
+ * zeros (they take part in that product's reduction: the caller's buffer needs no fill); gv_iaf_update_bwd_bf16_ex likewise. */
 int gv_iaf_update_fwd_bf16_tiles(const float* z, const float* net, int ld_net, const float* x_old, const int32_t* colcount,
                                  float* x_new, uint16_t* x_b, int ldb, uint16_t* x_t, int64_t t_tile, int64_t n, int d, void* stream);
 int gv_iaf_update_bwd_bf16(const float* z, const float* net, int ld_net, const int32_t* colcount, const float* gx, const float* gld,
@@ -323,7 +324,8 @@ typedef struct gv_chain_layer {
     int32_t x_dup_half;           /* layer 0 only: x holds columns [0, k / 2) alone and columns [k / 2, k) repeat them (k % 16 == 0) */
     int32_t t_tile;               /* > 0: out_bf16_t in tiles of 64 ROWS -- element (column c, row r) at [(r / 64) * t_tile + c * 64 + r % 64]
                                    * (ldt == 64, t_tile >= 64 n elements between tiles): what gv_gemm_bf16_gradw_tiles reads; rows
-                                   * [m, 64 ceil(m / 64)) of the last tile are not written.  0: [n][ldt] */
+                                   * [m, 64 ceil(m / 64)) of the last tile are written as zeros by chains without tile masks / an
+                                   * accumulating output (every MADE pass), left alone by the others.  0: [n][ldt] */
 } gv_chain_layer;
 int64_t gv_made_pack_weight_elems(int n, int k);
 int gv_made_pack_weight(const float* w, int ld, int n, int k, uint16_t* packed_fwd, uint16_t* packed_bwd, void* stream);

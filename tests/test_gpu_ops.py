@@ -585,6 +585,28 @@ def test_mean_sq_and_kl(ops):
           okg.kl_term(z, m, v, z_pre, None))
 
 
+@pytest.mark.parametrize('n,h,k', [(5, 16, 3), (1000, 256, 10), (77, 200, 16), (64, 8, 4), (2049, 200, 10), (300, 260, 10), (40, 30, 5)])
+def test_kl_kernel_forms_over_shapes(ops, n, h, k):
+    """gv_kl_fwd / gv_kl_bwd over the shapes that select their kernel forms -- four nodes per wave (h <= 256, k <= 16; node counts
+    that leave rows of a wave without a node), a lane on four columns (wider rows, or k > 10 in the backward), a lane per column
+    (h % 4 != 0) -- against the oracle: the KL term and every gradient."""
+    gen = torch.Generator().manual_seed(n + h + k)
+    z = torch.randn(n, h, generator=gen)
+    m = torch.randn(n, h, generator=gen) * 0.5
+    v = torch.rand(n, h, generator=gen) + 0.2
+    z_pre = torch.randn(1, 2 * k, h, generator=gen) / np.sqrt(k * h) * 30
+    flp = torch.tensor(-0.4)
+    to = [t.clone().requires_grad_(True) for t in (z, m, v, z_pre, flp)]
+    klo = okg.kl_term(*to)
+    (klo * 1.5).backward()
+    tg = [t.cuda().requires_grad_(True) for t in (z, m, v, z_pre, flp)]
+    klg = ops.kl_to_mixture(tg[0], tg[1], tg[2], tg[3].squeeze(0), tg[4])
+    (klg * 1.5).backward()
+    close(klg, klo)
+    for a, b, nm in zip(tg, to, ('z', 'm', 'v', 'z_pre', 'flp')):
+        close(a.grad, b.grad, msg=nm)
+
+
 def test_product_rejects_cpu_tensors(ops):
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         ops.gemm(torch.randn(4, 4), torch.randn(4, 4))
@@ -1761,7 +1783,9 @@ def _untile(t, rows):
 @pytest.mark.parametrize('m,d', [(300, 200), (64, 24), (1000, 72)])
 def test_transposed_copies_in_tiles_of_64_rows_hold_the_same_values_and_the_product_reads_them(ops, m, d):
     """The 64-row-tile form of the transposed bf16 copies (gv_chain_layer.t_tile, gv_iaf_update_fwd_bf16_tiles,
-    gv_iaf_update_bwd_bf16_ex flag 4) against the [column][row] form of the same launches, bit for bit, rows behind m untouched;
+    gv_iaf_update_bwd_bf16_ex flag 4) against the [column][row] form of the same launches, bit for bit; the rows behind m of the
+    last tile are written as ZEROS (they take part in the weight-gradient reduction: the caller's buffer needs no fill), columns
+    outside the destination stay untouched;
     gv_gemm_bf16_gradw_tiles on tiled operands against gv_gemm_bf16_gradw on the same operands as [row][k], bit for bit."""
     from gcn_vae_amd import lib
     from gcn_vae_amd.lib import ptr
@@ -1783,7 +1807,7 @@ def test_transposed_copies_in_tiles_of_64_rows_hold_the_same_values_and_the_prod
              (d + extra) * 64, m, d, lib.stream())
     assert torch.equal(xn, xn2) and torch.equal(i16(xb), i16(xb2))
     assert torch.equal(i16(_untile(big[:, extra:], m)), i16(xt[:, :m]))
-    assert bool((big[:, :extra] == 7.0).all()) and (m % 64 == 0 or bool((big[T - 1, :, m % 64:] == 7.0).all()))
+    assert bool((big[:, :extra] == 7.0).all()) and (m % 64 == 0 or bool((big[T - 1, extra:, m % 64:] == 0.0).all()))
     # backward update
     ex, gx = torch.randn(m, d, generator=g).to(dev).exp(), torch.randn(m, d, generator=g).to(dev)
     gld = torch.randn(m, generator=g).to(dev)
@@ -1796,7 +1820,7 @@ def test_transposed_copies_in_tiles_of_64_rows_hold_the_same_values_and_the_prod
         res.append((gz, gb, gt))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(i16(res[0][1]), i16(res[1][1]))
     assert torch.equal(i16(_untile(res[1][2][:, extra:], m)), i16(res[0][2][:, :m]))
-    assert bool((res[1][2][:, :extra] == 7.0).all()) and (m % 64 == 0 or bool((res[1][2][T - 1, :, m % 64:] == 7.0).all()))
+    assert bool((res[1][2][:, :extra] == 7.0).all()) and (m % 64 == 0 or bool((res[1][2][T - 1, extra:, m % 64:] == 0.0).all()))
     # a chain: hidden layer and a last layer that carries the update, both with a transposed copy
     k0 = 40
     ws = [(torch.randn(d, k0, generator=g) / k0 ** 0.5).to(dev), (torch.randn(2 * d, d, generator=g) / d ** 0.5).to(dev)]
@@ -1818,7 +1842,7 @@ def test_transposed_copies_in_tiles_of_64_rows_hold_the_same_values_and_the_prod
         outs.append((x1, x1b, buf))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(i16(outs[0][1]), i16(outs[1][1]))
     assert torch.equal(i16(_untile(outs[1][2][:, extra:], m)), i16(outs[0][2][:, :m]))
-    assert bool((outs[1][2][:, :extra] == 7.0).all()) and (m % 64 == 0 or bool((outs[1][2][T - 1, :, m % 64:] == 7.0).all()))
+    assert bool((outs[1][2][:, :extra] == 7.0).all()) and (m % 64 == 0 or bool((outs[1][2][T - 1, extra:, m % 64:] == 0.0).all()))
     # the weight-gradient product on the tiled copies of two passes == on the same operands as [row][k]
     S = 2
     tl = torch.zeros(S * T, 3 * d + extra, 64, **bf)
