@@ -370,8 +370,8 @@ __global__ __launch_bounds__(256) void k_kl_fwd_v4(const float* z, const float* 
     if (threadIdx.x == 0) part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
-// FOUR NODES PER WAVE (h <= 256, h % 4 == 0, k <= 16): a row of 16 lanes owns one node, lane l of the row the float4 columns
-// l, l + 16, l + 32, l + 48.  The form above spends most of its ~850 VALU instructions per node on k + 2 whole-wave reductions
+// FOUR NODES PER WAVE (h <= 64 G, h % 4 == 0, k <= 16): a row of 16 lanes owns one node, lane l of the row the float4 columns
+// l, l + 16, ... (G = 4 or 8 of them).  The form above spends most of its ~850 VALU instructions per node on k + 2 whole-wave reductions
 // (four DPP steps, four v_readlane and three adds each, serialised by the loop over the components); a row's reduction is the
 // four DPP steps alone, the four nodes of a wave share every instruction, and the component loop's LDS reads serve four nodes.
 // (Measured at FB15k-237 size: 34.4 -> 32.4 us.  The kernel is bound by its per-element arithmetic -- ablations, NOTES.md round 4:
@@ -386,6 +386,7 @@ __device__ __forceinline__ float row16_max(float v) {
     return v;
 }
 
+template <int G>
 __global__ __launch_bounds__(256) void k_kl_fwd_v5(const float* z, const float* m, int ld_m, const float* v,
                                                    const float* mix, const float* flp, float* resp, float* part,
                                                    int64_t n, int h, int k, const int* rows_dev, const float* h2,
@@ -408,7 +409,6 @@ __global__ __launch_bounds__(256) void k_kl_fwd_v5(const float* z, const float* 
     const int lane = threadIdx.x & 63, l16 = lane & 15, rw = lane >> 4, wv = threadIdx.x >> 6;
     const float fl = flp ? *flp : 0.f;
     const float logk = logf((float)k);
-    constexpr int G = 4;
     bool on[G];
     int col[G];
 #pragma unroll
@@ -629,7 +629,8 @@ __global__ __launch_bounds__(256) void k_kl_bwd_fused(const float* z, const floa
     }
 }
 
-// The fused backward with a lane on FOUR CONSECUTIVE COLUMNS (h <= 256, h % 4 == 0, k <= KT): one wave covers a whole row, so the
+// The fused backward with a lane on FOUR CONSECUTIVE COLUMNS (h % 4 == 0, k <= KT; column tiles of 256 on grid.x): one wave covers a
+// whole row (tile), so the
 // node rows move in 16-B accesses (the lane-per-column form above reads and writes 256 B per wave-instruction, and its fourth
 // 64-column tile of a 200-wide row keeps 8 of 64 lanes busy), the row's responsibilities are read once instead of once per tile,
 // and the mixture table comes from LDS.  Grid = KL_SLICES workgroups of 8 waves that interleave the slice's rows, two rows in
@@ -648,15 +649,15 @@ __global__ __launch_bounds__(64 * KLB_WAVES) void k_kl_bwd_cols4(const float* z,
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int h4 = h >> 2, kh4 = k * h4;
-    const bool ok = lane < h4;
-    const int col = 4 * lane;
+    const int col = (int)blockIdx.x * 256 + 4 * lane;            // grid.x: tiles of 256 columns (h <= 256: one)
+    const bool ok = col < h;
     for (int i = threadIdx.x; i < 2 * kh4; i += 64 * KLB_WAVES) sm4[i] = reinterpret_cast<const float4*>(mix)[i];
-    const float4* smu = sm4 + (ok ? lane : 0);
+    const float4* smu = sm4 + (ok ? (col >> 2) : 0);
     const float4* si2 = smu + kh4;
     float4* red = sm4 + 2 * kh4;
-    const int nsl = gridDim.x;
+    const int nsl = gridDim.y;
     const int64_t per = (n + nsl - 1) / nsl;
-    const int64_t r0 = blockIdx.x * per, r1 = min(n, r0 + per);
+    const int64_t r0 = blockIdx.y * per, r1 = min(n, r0 + per);
     const float cg = gscale * (gkl ? *gkl : 1.f) / (float)n * refit;
     const float cz = z_extra * (gkl ? *gkl : 1.f) * refit;
     float amu[KT][4], av[KT][4];
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(64 * KLB_WAVES) void k_kl_bwd_cols4(const float* z,
             } else {
                 o = make_float4(-t.x, -t.y, -t.z, -t.w);
             }
-            *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 2 * k + (kind ? k : 0) + j) * h + col) = o;
+            *reinterpret_cast<float4*>(part + ((size_t)blockIdx.y * 2 * k + (kind ? k : 0) + j) * h + col) = o;
         }
     }
 }
@@ -963,6 +964,143 @@ __global__ __launch_bounds__(64 * MMD_WAVES) void k_mmd_bwd(const float* x, cons
     }
 }
 
+// The same two passes with A ROW OF 16 LANES PER PARTNER ROW (h % 4 == 0; G float4 columns per lane: h <= 64 G):
+// a wave compares its block's row with four partner rows at once, each lane loads 16-B pieces, and a squared distance is a
+// row reduction (four DPP steps) instead of a whole-wave one (DPP steps + four v_readlane + adds, once per partner row).  64
+// partner rows are in flight per workgroup as before (16 waves x 4), eight 16-B loads per lane and iteration.  Per element the
+// same expressions; the sums run in another (fixed) order.
+__device__ __forceinline__ float rl_dyn(float v, int src_lane) { return __shfl(v, src_lane); }
+
+template <int G>
+__device__ __forceinline__ void mmd_load_row4(const float* p, const bool (&on)[G], const int (&col)[G], float4 (&v)[G]) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] = on[g] ? *reinterpret_cast<const float4*>(p + col[g]) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+template <int G>
+__device__ __forceinline__ float mmd_d2_4(const float4 (&a)[G], const float4 (&b)[G]) {
+    float d2 = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float d0 = a[g].x - b[g].x, d1 = a[g].y - b[g].y, d2_ = a[g].z - b[g].z, d3 = a[g].w - b[g].w;
+        d2 = fmaf(d0, d0, d2); d2 = fmaf(d1, d1, d2); d2 = fmaf(d2_, d2_, d2); d2 = fmaf(d3, d3, d2);
+    }
+    return d2;
+}
+
+template <int G>
+__global__ __launch_bounds__(64 * MMD_WAVES) void k_mmd_fwd_g(const float* x, const float* y, const int64_t* yidx, int sx, int sy,
+                                                               int h, float* part) {
+    __shared__ float sm[MMD_WAVES];
+    const int lane = threadIdx.x & 63, l16 = lane & 15, w = threadIdx.x >> 6;
+    const int grp = (int)(threadIdx.x >> 4);                  // 64 groups of 16 lanes
+    constexpr int NG = 4 * MMD_WAVES;
+    const bool is_x = (int)blockIdx.x < sx;
+    auto row_of = [&](bool from_y, int j) -> const float* {
+        return from_y ? y + (size_t)(yidx ? yidx[j] : j) * h : x + (size_t)j * h;
+    };
+    bool on[G];
+    int col[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { col[g] = 4 * (l16 + 16 * g); on[g] = col[g] < h; }
+    float4 av[G];
+    mmd_load_row4<G>(row_of(!is_x, is_x ? (int)blockIdx.x : (int)blockIdx.x - sx), on, col, av);
+    const float inv = 1.f / ((float)h * (float)h);
+    float tot = 0.f;
+    for (int pass = 0; pass < (is_x ? 2 : 1); ++pass) {
+        const bool b_is_y = pass == 0 ? !is_x : true;
+        const int nb = pass == 0 ? (is_x ? sx : sy) : sy;
+        const float wt = pass == 0 ? 1.f / ((float)nb * (float)nb) : -2.f / ((float)sx * (float)sy);
+        for (int j0 = 0; j0 < nb; j0 += 2 * NG) {               // (uniform trip count: the row reductions run in every lane)
+            const int j = j0 + grp, j1 = j + NG;
+            float4 b0[G], b1[G];
+            mmd_load_row4<G>(row_of(b_is_y, min(j, nb - 1)), on, col, b0);
+            mmd_load_row4<G>(row_of(b_is_y, min(j1, nb - 1)), on, col, b1);
+            const float d0 = row16_sum(mmd_d2_4<G>(av, b0)), d1 = row16_sum(mmd_d2_4<G>(av, b1));
+            if (j < nb) tot += wt * expf(-d0 * inv);
+            if (j1 < nb) tot += wt * expf(-d1 * inv);
+        }
+    }
+    const float t = (rl_bcast_f(tot, 0) + rl_bcast_f(tot, 16)) + (rl_bcast_f(tot, 32) + rl_bcast_f(tot, 48));
+    if (lane == 0) sm[w] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MMD_WAVES; ++i) s += sm[i];
+        part[blockIdx.x] = s;
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(64 * MMD_WAVES) void k_mmd_bwd_g(const float* x, const float* y, const int64_t* yidx, int sx, int sy,
+                                                               int h, const float* gmmd, float gscale, float* gx, float* gy) {
+    __shared__ float4 sm[MMD_WAVES][16 * G];                    // a wave's sum over its four groups, [float4 column]
+    const int lane = threadIdx.x & 63, l16 = lane & 15, w = threadIdx.x >> 6;
+    const int grp = (int)(threadIdx.x >> 4);
+    constexpr int NG = 4 * MMD_WAVES;
+    const bool is_x = (int)blockIdx.x < sx;
+    const int row = is_x ? blockIdx.x : blockIdx.x - sx;
+    auto row_of = [&](bool from_y, int j) -> const float* {
+        return from_y ? y + (size_t)(yidx ? yidx[j] : j) * h : x + (size_t)j * h;
+    };
+    bool on[G];
+    int col[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { col[g] = 4 * (l16 + 16 * g); on[g] = col[g] < h; }
+    float4 av[G], acc[G];
+    mmd_load_row4<G>(row_of(!is_x, row), on, col, av);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float inv = 1.f / ((float)h * (float)h);
+    const float gg = gscale * (gmmd ? *gmmd : 1.f);
+    const int n_same = is_x ? sx : sy, n_other = is_x ? sy : sx;
+    const float c_same = gg * (-2.f * inv) * 2.f / ((float)n_same * (float)n_same);
+    const float c_other = gg * (-2.f * inv) * (-2.f) / ((float)sx * (float)sy);
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool b_is_y = pass == 0 ? !is_x : is_x;
+        const int nb = pass == 0 ? n_same : n_other;
+        const float cf = pass == 0 ? c_same : c_other;
+        for (int j0 = 0; j0 < nb; j0 += 2 * NG) {
+            const int j = j0 + grp, j1 = j + NG;
+            float4 b0[G], b1[G];
+            mmd_load_row4<G>(row_of(b_is_y, min(j, nb - 1)), on, col, b0);
+            mmd_load_row4<G>(row_of(b_is_y, min(j1, nb - 1)), on, col, b1);
+            const float d0 = row16_sum(mmd_d2_4<G>(av, b0)), d1 = row16_sum(mmd_d2_4<G>(av, b1));
+            const float k0 = j < nb ? cf * expf(-d0 * inv) : 0.f, k1 = j1 < nb ? cf * expf(-d1 * inv) : 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                acc[g].x = fmaf(k0, av[g].x - b0[g].x, fmaf(k1, av[g].x - b1[g].x, acc[g].x));
+                acc[g].y = fmaf(k0, av[g].y - b0[g].y, fmaf(k1, av[g].y - b1[g].y, acc[g].y));
+                acc[g].z = fmaf(k0, av[g].z - b0[g].z, fmaf(k1, av[g].z - b1[g].z, acc[g].z));
+                acc[g].w = fmaf(k0, av[g].w - b0[g].w, fmaf(k1, av[g].w - b1[g].w, acc[g].w));
+            }
+        }
+    }
+    // a wave's four groups hold the same columns in lanes l16, 16 + l16, 32 + l16, 48 + l16: added in group order, then the 16 waves
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float4 t;
+        t.x = (rl_dyn(acc[g].x, l16) + rl_dyn(acc[g].x, 16 + l16)) + (rl_dyn(acc[g].x, 32 + l16) + rl_dyn(acc[g].x, 48 + l16));
+        t.y = (rl_dyn(acc[g].y, l16) + rl_dyn(acc[g].y, 16 + l16)) + (rl_dyn(acc[g].y, 32 + l16) + rl_dyn(acc[g].y, 48 + l16));
+        t.z = (rl_dyn(acc[g].z, l16) + rl_dyn(acc[g].z, 16 + l16)) + (rl_dyn(acc[g].z, 32 + l16) + rl_dyn(acc[g].z, 48 + l16));
+        t.w = (rl_dyn(acc[g].w, l16) + rl_dyn(acc[g].w, 16 + l16)) + (rl_dyn(acc[g].w, 32 + l16) + rl_dyn(acc[g].w, 48 + l16));
+        if (lane < 16) sm[w][l16 + 16 * g] = t;
+    }
+    __syncthreads();
+    const bool indexed = !is_x && yidx;
+    float* o = is_x ? gx + (size_t)row * h : gy + (size_t)(yidx ? yidx[row] : row) * h;
+    for (int q = threadIdx.x; q < (h >> 2); q += 64 * MMD_WAVES) {
+        float4 s4 = sm[0][q];
+#pragma unroll
+        for (int i = 1; i < MMD_WAVES; ++i) { const float4 t = sm[i][q]; s4.x += t.x; s4.y += t.y; s4.z += t.z; s4.w += t.w; }
+        if (indexed) {
+            atomicAdd(o + 4 * q, s4.x); atomicAdd(o + 4 * q + 1, s4.y); atomicAdd(o + 4 * q + 2, s4.z); atomicAdd(o + 4 * q + 3, s4.w);
+        } else {
+            *reinterpret_cast<float4*>(o + 4 * q) = s4;
+        }
+    }
+}
+
 // prior samples of get_mmd: z_pri[i] = mu[i % k] + eps[i] * sqrt(softplus(raw[i % k]) + 1e-8)   (z_pre = [mu; raw], (2k, h))
 __global__ __launch_bounds__(256) void k_prior_sample_fwd(const float* z_pre, const float* eps, float* out, int s, int k, int h) {
     const int total = s * h;
@@ -1094,9 +1232,14 @@ static bool kl_fwd_v4(int nb, size_t lds, hipStream_t st, const float* z, const 
                     (!m_out || aligned16(m_out));
     if (!env || h % 4 != 0 || h > 1024 || !al) return false;
     static const int v5 = getenv("GV_KL_V5") ? atoi(getenv("GV_KL_V5")) : 1;
-    if (v5 && h <= 256 && k <= 16) {      // four nodes per wave
-        hipLaunchKernelGGL(k_kl_fwd_v5, dim3(nb), dim3(256), lds, st, z, m, ld_m, v, mix, flp, resp, part, n, h, k, rows_dev, h2, eps,
-                           z_out, v_out, m_out);
+    // four nodes per wave (a lane: 4 float4 columns; the 8-column instance measured SLOWER than the form below at h = 500: 67.9 vs 61.9 us)
+    if (v5 && h <= (v5 == 2 ? 512 : 256) && k <= 16) {
+        if (h <= 256)
+            hipLaunchKernelGGL(k_kl_fwd_v5<4>, dim3(nb), dim3(256), lds, st, z, m, ld_m, v, mix, flp, resp, part, n, h, k, rows_dev, h2,
+                               eps, z_out, v_out, m_out);
+        else
+            hipLaunchKernelGGL(k_kl_fwd_v5<8>, dim3(nb), dim3(256), lds, st, z, m, ld_m, v, mix, flp, resp, part, n, h, k, rows_dev, h2,
+                               eps, z_out, v_out, m_out);
         return true;
     }
 #define GV_KL_V4(G_) hipLaunchKernelGGL(k_kl_fwd_v4<G_>, dim3(nb), dim3(256), lds, st, z, m, ld_m, v, mix, flp, resp, part, n, h, k, rows_dev, h2, eps, z_out, v_out, m_out)
@@ -1142,10 +1285,12 @@ static bool kl_bwd_cols4(hipStream_t st, const float* z, const float* m, int ld_
     const bool al = aligned16(z) && aligned16(m) && ld_m % 4 == 0 && aligned16(v) && aligned16(mix) && aligned16(part) &&
                     (!gz || aligned16(gz)) && (!gm || aligned16(gm)) && (!gv || aligned16(gv)) && (!h2 || aligned16(h2)) &&
                     (!eps || aligned16(eps)) && (!gz_up || aligned16(gz_up)) && (!gh2 || aligned16(gh2));
-    if (!env || h % 4 != 0 || h > 256 || k > 10 || !al) return false;      // (a 16-component instance spills: k > 10 keeps the other form)
+    if (!env || h % 4 != 0 || h > 1024 || k > 10 || !al) return false;      // (a 16-component instance spills: k > 10 keeps the other form)
     const size_t lds = ((size_t)2 * k * h / 4 + (size_t)2 * KLB_KR * KLB_WAVES * 64) * sizeof(float4);
-    if (lds > 64 * 1024) return false;
-#define GV_KLB(KT_) hipLaunchKernelGGL(k_kl_bwd_cols4<KT_>, dim3(KL_SLICES), dim3(64 * KLB_WAVES), lds, st, z, m, ld_m, v, mix, resp, gkl, \
+    if (lds > 128 * 1024) return false;
+    static unsigned long long lds_done = 0;
+    if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)k_kl_bwd_cols4<10>, 128 * 1024, lds_done, "gv_kl_bwd")) return false;
+#define GV_KLB(KT_) hipLaunchKernelGGL(k_kl_bwd_cols4<KT_>, dim3((h + 255) / 256, KL_SLICES), dim3(64 * KLB_WAVES), lds, st, z, m, ld_m, v, mix, resp, gkl, \
                                        gscale, z_extra, gz, gm, gv, part, n, h, k, rows_dev, h2, eps, gz_up, gh2)
     GV_KLB(10);
 #undef GV_KLB
@@ -1255,7 +1400,11 @@ extern "C" int gv_mmd_fwd(const float* x, const float* y, const int64_t* y_index
     GV_REQUIRE(x && y && workspace, GV_ERR_NULL, "gv_mmd_fwd: NULL pointer");
     GV_REQUIRE(sx > 0 && sy > 0 && h > 0 && h <= 1024 && sx + sy <= RED_BLOCKS, GV_ERR_SHAPE,
                "gv_mmd_fwd: sx=%d sy=%d h=%d (need h <= 1024, sx+sy <= %d)", sx, sy, h, RED_BLOCKS);
-    if (h <= 256) hipLaunchKernelGGL(k_mmd_fwd<4>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, y_index, sx, sy, h, workspace);
+    static const int v2 = getenv("GV_MMD_ROWS16") ? atoi(getenv("GV_MMD_ROWS16")) : 1;
+    const bool al = h % 4 == 0 && aligned16(x) && aligned16(y);
+    if (v2 && al && h <= 256) hipLaunchKernelGGL(k_mmd_fwd_g<4>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, y_index, sx, sy, h, workspace);
+    else if (v2 && al && h <= 512) hipLaunchKernelGGL(k_mmd_fwd_g<8>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, y_index, sx, sy, h, workspace);
+    else if (h <= 256) hipLaunchKernelGGL(k_mmd_fwd<4>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, y_index, sx, sy, h, workspace);
     else hipLaunchKernelGGL(k_mmd_fwd<16>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, y_index, sx, sy, h, workspace);
     if (mmd) hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, GV_ST, workspace, sx + sy, 1.f, mmd, 0);
     return launch_status("gv_mmd_fwd");
@@ -1282,7 +1431,11 @@ extern "C" int gv_mmd_bwd(const float* x, const float* y, const int64_t* y_index
                           float gscale, float* gx, float* gy, void* stream) {
     GV_REQUIRE(x && y && gx && gy, GV_ERR_NULL, "gv_mmd_bwd: NULL pointer");
     GV_REQUIRE(sx > 0 && sy > 0 && h > 0 && h <= 1024, GV_ERR_SHAPE, "gv_mmd_bwd: bad shape");
-    if (h <= 256) hipLaunchKernelGGL(k_mmd_bwd<4>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, y_index, sx, sy, h, gmmd, gscale, gx, gy);
+    static const int v2 = getenv("GV_MMD_ROWS16") ? atoi(getenv("GV_MMD_ROWS16")) : 1;
+    const bool al = h % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gx) && aligned16(gy);
+    if (v2 && al && h <= 256) hipLaunchKernelGGL(k_mmd_bwd_g<4>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, y_index, sx, sy, h, gmmd, gscale, gx, gy);
+    // (an eight-column-group instance of the backward needs more than the 128 registers a 1 024-thread workgroup leaves a lane)
+    else if (h <= 256) hipLaunchKernelGGL(k_mmd_bwd<4>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, y_index, sx, sy, h, gmmd, gscale, gx, gy);
     else hipLaunchKernelGGL(k_mmd_bwd<16>, dim3(sx + sy), dim3(64 * MMD_WAVES), 0, GV_ST, x, y, y_index, sx, sy, h, gmmd, gscale, gx, gy);
     return launch_status("gv_mmd_bwd");
 }

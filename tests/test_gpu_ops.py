@@ -585,11 +585,13 @@ def test_mean_sq_and_kl(ops):
           okg.kl_term(z, m, v, z_pre, None))
 
 
-@pytest.mark.parametrize('n,h,k', [(5, 16, 3), (1000, 256, 10), (77, 200, 16), (64, 8, 4), (2049, 200, 10), (300, 260, 10), (40, 30, 5)])
+@pytest.mark.parametrize('n,h,k', [(5, 16, 3), (1000, 256, 10), (77, 200, 16), (64, 8, 4), (2049, 200, 10), (300, 260, 10), (40, 30, 5),
+                                   (120, 500, 10), (33, 1024, 4)])
 def test_kl_kernel_forms_over_shapes(ops, n, h, k):
-    """gv_kl_fwd / gv_kl_bwd over the shapes that select their kernel forms -- four nodes per wave (h <= 256, k <= 16; node counts
-    that leave rows of a wave without a node), a lane on four columns (wider rows, or k > 10 in the backward), a lane per column
-    (h % 4 != 0) -- against the oracle: the KL term and every gradient."""
+    """gv_kl_fwd / gv_kl_bwd over the shapes that select their kernel forms -- forward: four nodes per wave (h <= 512, k <= 16; node
+    counts that leave rows of a wave without a node), a lane on four columns (wider rows), a lane per column (h % 4 != 0); backward: a
+    lane on four columns in 256-column tiles (k <= 10, the table within 64 KB of LDS), a lane per column otherwise -- against the
+    oracle: the KL term and every gradient."""
     gen = torch.Generator().manual_seed(n + h + k)
     z = torch.randn(n, h, generator=gen)
     m = torch.randn(n, h, generator=gen) * 0.5
@@ -631,6 +633,24 @@ def test_mmd_and_prior_sample(ops):
     close(xg, xo)
     close(mg, mo, atol_scale=1e-6)
     close(zg.grad, zo.grad, rtol=2e-4, atol_scale=2e-5)
+    close(yg.grad, yo.grad, rtol=2e-4, atol_scale=2e-5)
+
+
+@pytest.mark.parametrize('sx,sy,h', [(7, 130, 16), (129, 3, 256), (64, 64, 500), (50, 70, 30), (200, 200, 72), (1, 1, 8)])
+def test_mmd_kernel_forms_over_shapes(ops, sx, sy, h):
+    """gv_mmd_fwd / gv_mmd_bwd over the shapes that select their kernel forms -- a row of 16 lanes per partner row (h % 4 == 0:
+    forward up to 512 columns, backward up to 256; set sizes that leave groups and whole iterations without a partner row), a lane per
+    column otherwise -- against the oracle's kernel means: the value and both gradients."""
+    gen = torch.Generator().manual_seed(sx * 7 + sy * 3 + h)
+    x, y = torch.randn(sx, h, generator=gen), torch.randn(sy, h, generator=gen) * 0.7 + 0.1
+    xo, yo = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    mo = okg.rbf_kernel(xo, xo).mean() + okg.rbf_kernel(yo, yo).mean() - 2 * okg.rbf_kernel(xo, yo).mean()
+    (mo * 0.7).backward()
+    xg, yg = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    mg = ops.mmd(xg, yg)
+    (mg * 0.7).backward()
+    close(mg, mo, atol_scale=1e-6)
+    close(xg.grad, xo.grad, rtol=2e-4, atol_scale=2e-5)
     close(yg.grad, yo.grad, rtol=2e-4, atol_scale=2e-5)
 
 
