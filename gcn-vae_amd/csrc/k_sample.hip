@@ -76,6 +76,54 @@ __global__ void k_map_pairs(const int* a, const int* b, long long k, const int* 
     b_local[i] = rank[b[i]];
 }
 
+// gv_relabel_pairs as ONE launch when the id range fits a CU's LDS (num_ids + 1 ints: up to ~38 000 ids): one 1 024-thread
+// workgroup keeps the flags, then their exclusive ranks, in LDS -- clear, mark, block scan, compact, map, with barriers where the
+// six-launch form (fill, mark, rocPRIM's two scan kernels, compact, map) has launch boundaries.  A sampled batch is ~20 000 pairs
+// over 14 541 ids: every one of those launches is at the ~5 us floor of a graph node.  Same results (integer work).
+__global__ __launch_bounds__(1024) void k_relabel_one(const int* __restrict__ a, const int* __restrict__ b, long long k, int num_ids,
+                                                      int* __restrict__ uniq, int cap, int* __restrict__ a_local,
+                                                      int* __restrict__ b_local, int* __restrict__ count) {
+    extern __shared__ int lds_rank[];              // [num_ids + 1]: flags, then exclusive ranks (rank[num_ids] = how many ids occur)
+    __shared__ int wtot[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int n = num_ids + 1;
+    for (int i = t; i < n; i += 1024) lds_rank[i] = 0;
+    __syncthreads();
+    for (long long i = t; i < k; i += 1024) {
+        lds_rank[a[i]] = 1;
+        lds_rank[b[i]] = 1;
+    }
+    __syncthreads();
+    const int per = (n + 1023) / 1024, lo = min(n, t * per), hi = min(n, lo + per);      // thread t: a contiguous block of ids
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += lds_rank[i];
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    int run = inc - sum;
+    for (int ww = 0; ww < w; ++ww) run += wtot[ww];
+    for (int i = lo; i < hi; ++i) {
+        const int f = lds_rank[i];
+        lds_rank[i] = run;
+        run += f;
+    }
+    __syncthreads();
+    if (t == 0) *count = lds_rank[num_ids];
+    for (int id = t; id < num_ids; id += 1024) {
+        const int r = lds_rank[id];
+        if (lds_rank[id + 1] != r && r < cap) uniq[r] = id;
+    }
+    for (long long i = t; i < k; i += 1024) {
+        a_local[i] = lds_rank[a[i]];
+        b_local[i] = lds_rank[b[i]];
+    }
+}
+
 // samples (k * (neg_rate + 1), 3) int64: rows [0, k) = positives, row k + j*k + p = positive p with its subject
 // (hit_subject) or object replaced by values[j*k + p]  (np.tile(pos, (neg_rate, 1)) order); labels 1 / 0
 __global__ void k_negative_sampling(const int* s, const int* r, const int* o, long long k, int neg_rate, const int* n_ent_dev,
@@ -197,6 +245,17 @@ extern "C" int gv_relabel_pairs(const int32_t* a, const int32_t* b, int64_t k, i
     GV_REQUIRE(count && workspace && ((a && b && a_local && b_local && uniq) || k == 0), GV_ERR_NULL, "gv_relabel_pairs: NULL pointer");
     GV_REQUIRE(workspace_bytes >= gv_relabel_workspace_bytes(num_ids), GV_ERR_WORKSPACE, "gv_relabel_pairs: workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    {   // the one-launch form while the id range fits LDS (GV_SAMPLER_ONE_LAUNCH=0: the six-launch form, as beyond that range)
+        static const int one = getenv("GV_SAMPLER_ONE_LAUNCH") ? atoi(getenv("GV_SAMPLER_ONE_LAUNCH")) : 1;
+        const size_t lds = (size_t)(num_ids + 1) * sizeof(int);
+        static unsigned long long lds_done = 0;
+        if (one && lds <= 150 * 1024 &&
+            (lds <= 48 * 1024 || raise_dynamic_lds((const void*)k_relabel_one, 150 * 1024, lds_done, "gv_relabel_pairs"))) {
+            hipLaunchKernelGGL(k_relabel_one, dim3(1), dim3(1024), lds, st, a, b, (long long)k, num_ids, uniq, uniq_cap, a_local, b_local,
+                               count);
+            return launch_status("gv_relabel_pairs");
+        }
+    }
     char* p = (char*)workspace;
     int* flags = (int*)p; p += al256((size_t)(num_ids + 1) * sizeof(int));
     int* rank = (int*)p; p += al256((size_t)(num_ids + 1) * sizeof(int));

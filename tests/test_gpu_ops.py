@@ -1327,6 +1327,48 @@ def test_native_sampler_stages_equal_host_pipeline(ops):
     assert np.array_equal(norm.cpu().numpy(), norm_h[ed.numpy()].astype(np.float32))       # 1 / in-degree, bit for bit
 
 
+@pytest.mark.parametrize('num_nodes,n_rel,k,m', [(14541, 237, 20000, 10000), (50, 3, 1, 1), (700, 9, 333, 77), (32000, 400, 30000, 30000),
+                                                 (40000, 11, 9000, 4000), (5000, 5, 40000, 33000)])
+def test_native_sampler_relabel_and_graph_build_over_sizes(ops, num_nodes, n_rel, k, m):
+    """gv_relabel_pairs and gv_graph_from_triplets against numpy (np.unique / np.lexsort / bincount): the relabelling as one
+    single-workgroup launch (ids within LDS) and as the six-launch form beyond; batch sizes of the reference's regime, odd sizes, a
+    single triplet.  Integer arrays equal; the norm bit for bit."""
+    from gcn_vae_amd import lib
+    from gcn_vae_amd.lib import ptr
+    rs = np.random.RandomState(num_nodes + k)
+    hub = (rs.zipf(1.6, size=2 * k) - 1) % num_nodes                         # a few hub entities, as in a sampled batch
+    a, b = hub[:k].astype(np.int32), rs.randint(0, num_nodes, size=k).astype(np.int32)
+    rel = rs.randint(0, n_rel, size=k).astype(np.int32)
+    st = lib.stream()
+    cap = min(2 * k, num_nodes)
+    uniq, src, dst, count = (torch.empty(cap, dtype=torch.int32, device='cuda'), torch.empty(k, dtype=torch.int32, device='cuda'),
+                             torch.empty(k, dtype=torch.int32, device='cuda'), torch.empty(1, dtype=torch.int32, device='cuda'))
+    wb = int(lib.load().gv_relabel_workspace_bytes(num_nodes))
+    ws = torch.empty(wb, dtype=torch.uint8, device='cuda')
+    a_g, b_g, rel_d = _i32(a), _i32(b), _i32(rel)
+    lib.call('gv_relabel_pairs', ptr(a_g), ptr(b_g), k, num_nodes, ptr(uniq), cap, ptr(src), ptr(dst), ptr(count), ptr(ws), wb, st)
+    uniq_v, inv = np.unique((a, b), return_inverse=True)
+    src_h, dst_h = np.reshape(inv, (2, -1))
+    n = int(count.item())
+    assert n == len(uniq_v) and np.array_equal(uniq[:n].cpu().numpy(), uniq_v)
+    assert np.array_equal(src.cpu().numpy(), src_h) and np.array_equal(dst.cpu().numpy(), dst_h)
+    keep = rs.choice(k, size=m, replace=False).astype(np.int32)
+    s_k, r_k, o_k = src_h[keep], rel[keep], dst_h[keep]
+    es, ed, er = np.concatenate((s_k, o_k)), np.concatenate((o_k, s_k)), np.concatenate((r_k, r_k + n_rel))
+    order = np.lexsort((er, es, ed))                                         # sorted(zip(dst, src, rel)), kgvae/utils.py:146-147
+    es, ed, er = es[order], ed[order], er[order]
+    indeg = np.bincount(ed, minlength=cap)
+    src2, dst2, rel2 = (torch.empty(2 * m, dtype=torch.int32, device='cuda') for _ in range(3))
+    norm = torch.empty(2 * m, dtype=torch.float32, device='cuda')
+    gb = int(lib.load().gv_graph_from_triplets_workspace_bytes(m, cap, n_rel))
+    gws = torch.empty(gb, dtype=torch.uint8, device='cuda')
+    keep_d = _i32(keep)
+    lib.call('gv_graph_from_triplets', ptr(src), ptr(rel_d), ptr(dst), ptr(keep_d), m, cap, n_rel, ptr(src2), ptr(dst2), ptr(rel2),
+             ptr(norm), ptr(gws), gb, st)
+    assert np.array_equal(src2.cpu().numpy(), es) and np.array_equal(dst2.cpu().numpy(), ed) and np.array_equal(rel2.cpu().numpy(), er)
+    assert np.array_equal(norm.cpu().numpy(), (1.0 / indeg[ed].astype(np.float32)).astype(np.float32))
+
+
 def test_native_sampler_negative_draws_match_numpy_restatement(ops):
     from gcn_vae_amd import lib
     from gcn_vae_amd.lib import ptr
