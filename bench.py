@@ -890,6 +890,10 @@ def main():
     # remove the per-kernel host cost but add a graph launch per segment; "auto" measures instead of guessing.
     programs, probe = {}, {}
     auto = dist_on and args.partition == 'auto'
+    # Every scheme / launch variant is warmed, captured and probed from the SAME initial weights and moments, and so are the timed
+    # regions afterwards: the probes of `--partition auto` are dozens of updates, enough with IAF blocks to leave exp(alpha + mu) at
+    # overflow (a two-rank configs[2] run then timed a NaN model and exited with status 4; an explicit --partition was fine)
+    snap0 = opt.snapshot()
     def agreed(ok):
         """True only if EVERY rank got through the stage: all ranks keep or drop a scheme together."""
         if world > 1:
@@ -915,6 +919,7 @@ def main():
         if auto and use_segments and name == 'edge':
             variants.append((True, 1))        # one all-reduce per layer instead of two overlapped halves: 2 collectives fewer
         for sgm, chunks in variants:
+            opt.restore(snap0)
             _ops.DIST_FWD_CHUNKS = chunks
             if chunks != 2:
                 warm(1)        # the row-block cut of this variant is built (one host synchronisation) outside the capture
@@ -931,6 +936,7 @@ def main():
     mode_name, launch, replay, static_loss, _ops.DIST_FWD_CHUNKS = programs[chosen]
     if cur.get('name') != mode_name:
         configure(mode_name)
+    opt.restore(snap0)
     T = int(cur['samples'].shape[0])
 
     def run_step():

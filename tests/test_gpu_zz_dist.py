@@ -96,6 +96,22 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert d['config']['partition'] in ('edge', 'row')
 
 
+def test_bench_two_ranks_auto_partition_with_iaf_blocks_ends_finite():
+    """`--partition auto` warms, captures and probes five programs before the timed steps: dozens of updates.  With IAF blocks
+    (BASELINE configs[2]: WN18RR shape, 3 blocks, bf16 products) that used to leave exp(alpha + mu) at overflow -- the timed regions
+    then started from NaN weights and bench.py exited with status 4.  Every probed program and every timed region now starts from
+    the initial weights and moments."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GV_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--config', 'c3', '--steps', '3',
+           '--warmup', '2', '--no-cpu-baseline', '--profile-steps', '0']
+    out = run_ranks(cmd, env, 900)
+    assert out.returncode == 0, (out.stdout[-1500:] + '\n' + out.stderr[-2500:])
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['loss_is_finite'] is True and d['final_loss'] == d['final_loss']
+    assert len(d['config']['partition_probe_ms_per_step']) == 5
+
+
 @pytest.mark.parametrize('extra', [['--scaling', 'strong', '--partition', 'edge'], ['--scaling', 'strong', '--partition', 'row'],
                                    ['--config', 'c4', '--scaling', 'strong', '--partition', 'edge'],
                                    ['--scaling', 'strong', '--partition', 'edge', '--sharded-adam'],
