@@ -586,7 +586,7 @@ def test_mean_sq_and_kl(ops):
 
 
 @pytest.mark.parametrize('n,h,k', [(5, 16, 3), (1000, 256, 10), (77, 200, 16), (64, 8, 4), (2049, 200, 10), (300, 260, 10), (40, 30, 5),
-                                   (120, 500, 10), (33, 1024, 4)])
+                                   (120, 500, 10), (33, 1024, 4), (40001, 200, 10)])      # (> 16 384 nodes: a wave's second iteration)
 def test_kl_kernel_forms_over_shapes(ops, n, h, k):
     """gv_kl_fwd / gv_kl_bwd over the shapes that select their kernel forms -- forward: four nodes per wave (h <= 512, k <= 16; node
     counts that leave rows of a wave without a node), a lane on four columns (wider rows), a lane per column (h % 4 != 0); backward: a
