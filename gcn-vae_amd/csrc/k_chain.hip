@@ -46,6 +46,8 @@ struct ChainArgs {
     const uint16_t* x;           // [m][ldx] bf16: input of layer 0
     int ldx, m, n_layers, ldk, has_mask;
     int32_t* stamps;             // gv_made_chain_debug_stamps: s_memtime stamps of workgroup 0 (probes only), NULL otherwise
+    gv_chain_iafb ib;            // ib.gx != NULL: layer 0's input is made in the prologue (the IAF update's backward), x unused
+    int ib_lds_off;              // floats from the bias block to the stage's 2 x 64 x IB_LD transposition block
     gv_chain_layer L[CH_L];
 };
 
@@ -617,6 +619,111 @@ __device__ __forceinline__ void chain_store(const gv_chain_layer& Ly, const uint
     }
 }
 
+// The IAF update's BACKWARD as the first stage of a backward chain (gv_made_chain_iafb; kgvae/flow_network.py:92-96 differentiated):
+// per element, from dL/dx_new (gx), ex = exp(alpha + mu) (what the forward chain kept), z and the pass's column counts,
+//   count > 0:  g_z = gx count ex,  g_mu = gx count z ex,  g_alpha = g_logdet + g_mu;   count == 0:  g_mu = 0, g_alpha = g_logdet
+// -- the arithmetic of gv_iaf_update_bwd_bf16_ex, element by element.  [g_mu | g_alpha] goes as bf16 straight into layer 0's LDS
+// tile (the separate launch wrote it row-major to memory and the chain read it back), its transposed copy (the operand of the last
+// layer's weight gradient) leaves through a [column][row] LDS block of 64 columns at a time, g_z is added in place.  Four column
+// blocks per 200-wide row; the next block's operands are requested before the current one leaves.
+constexpr int IB_LD = 68;      // rows of the transposition block, padded (8-B reads of four rows, conflict-free 2-B writes)
+__device__ __forceinline__ void chain_stage_iafb(uint16_t* tile, int ldk, uint16_t* tmx, const gv_chain_iafb& ib, int m0, int m) {
+    const int d = ib.d, nblk = (d + 63) >> 6;
+    const int t = threadIdx.x;
+    uint16_t (*tm)[IB_LD] = reinterpret_cast<uint16_t (*)[IB_LD]>(tmx);                 // [64 columns][rows]: g_mu
+    uint16_t (*ta)[IB_LD] = reinterpret_cast<uint16_t (*)[IB_LD]>(tmx + 64 * IB_LD);    // g_alpha
+    // a block is 64 rows x 16 pieces of four columns = 1 024 pieces: two per thread (piece j of thread t: rows t / 16 and 32 + t / 16)
+    const int cq = (t & 15) << 2, rr0 = t >> 4;
+    struct Ops { float4 g[2], e[2], z[2], a[2]; int4 cn; };
+    // pinned (scalar) bases + ONE 32-bit byte offset per row: 64-bit per-lane addresses of four arrays x two rows were what spilled
+    const float* const gx_p = chain_pin_ptr(ib.gx);
+    const float* const ex_p = chain_pin_ptr(ib.ex);
+    const float* const z_p = chain_pin_ptr(ib.z);
+    float* const gz_p = chain_pin_ptr(ib.gz);
+    const int ld = chain_pin(ib.ld), fl = chain_pin(ib.flags);
+    const unsigned off0 = (unsigned)((m0 + rr0) * ld + cq) * 4u, off1 = (unsigned)((m0 + rr0 + 32) * ld + cq) * 4u;
+    auto at = [](const float* base, unsigned byte_off) { return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off); };
+    auto request = [&](int blk, Ops& o) {
+        const int c = blk * 64 + cq;
+        o.cn = make_int4(0, 0, 0, 0);
+        if (c < d) o.cn = *reinterpret_cast<const int4*>(ib.colcount + c);
+        const bool any = o.cn.x > 0 || o.cn.y > 0 || o.cn.z > 0 || o.cn.w > 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = m0 + rr0 + 32 * j;
+            const unsigned e = (j ? off1 : off0) + (unsigned)blk * 256u;
+            o.g[j] = o.e[j] = o.z[j] = o.a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < m && c < d) {
+                o.g[j] = *at(gx_p, e);
+                if (!(fl & 1)) o.a[j] = *at(gz_p, e);
+                if (any) {
+                    o.z[j] = *at(z_p, e);
+                    o.e[j] = *at(ex_p, e);
+                }
+            }
+        }
+    };
+    Ops cur;
+    request(0, cur);
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int c = blk * 64 + cq;
+        const int cn[4] = {cur.cn.x, cur.cn.y, cur.cn.z, cur.cn.w};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rr = rr0 + 32 * j, r = m0 + rr;
+            const float gv[4] = {cur.g[j].x, cur.g[j].y, cur.g[j].z, cur.g[j].w}, zv[4] = {cur.z[j].x, cur.z[j].y, cur.z[j].z, cur.z[j].w},
+                        ev[4] = {cur.e[j].x, cur.e[j].y, cur.e[j].z, cur.e[j].w};
+            uint16_t bm[4] = {0, 0, 0, 0}, ba[4] = {0, 0, 0, 0};
+            if (r < m && c < d) {
+                const float gl = ib.gld ? ib.gld[r] : 0.f;
+                float gz[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float g_mu = 0.f, g_al = gl, g_z = 0.f;
+                    if (cn[q] > 0) {
+                        const float gc = gv[q] * (float)cn[q];
+                        g_z = gc * ev[q];
+                        g_mu = gc * zv[q] * ev[q];
+                        g_al += g_mu;
+                    }
+                    gz[q] = g_z;
+                    bm[q] = bf_bits(g_mu);
+                    ba[q] = bf_bits(g_al);
+                }
+                float4 acc4 = cur.a[j];
+                acc4.x += gz[0]; acc4.y += gz[1]; acc4.z += gz[2]; acc4.w += gz[3];
+                *reinterpret_cast<float4*>(reinterpret_cast<char*>(gz_p) + (j ? off1 : off0) + (unsigned)blk * 256u) = acc4;
+            }
+            if (c < d) {      // layer 0's input row: [g_mu | g_alpha] (rows past m: zeros)
+                *reinterpret_cast<uint2*>(tile + rr * ldk + c) = make_uint2(bm[0] | ((uint32_t)bm[1] << 16), bm[2] | ((uint32_t)bm[3] << 16));
+                *reinterpret_cast<uint2*>(tile + rr * ldk + d + c) = make_uint2(ba[0] | ((uint32_t)ba[1] << 16), ba[2] | ((uint32_t)ba[3] << 16));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                tm[cq + q][rr] = bm[q];
+                ta[cq + q][rr] = ba[q];
+            }
+        }
+        if (blk + 1 < nblk) request(blk + 1, cur);      // in flight under the block's way out (one register set: the kernel has 128)
+        __syncthreads();
+        // the block's transposed copies: four consecutive rows of a column per 8-B store (16 lanes = 128 contiguous bytes); the whole
+        // 64-row tile is written (zeros in the rows past m: they take part in the weight-gradient reduction)
+        uint16_t* const gt = ib.gnt + (size_t)blockIdx.x * ib.t_tile;
+        for (int i = t; i < 2 * 64 * 16; i += CH_THREADS) {
+            const int half = i >> 10, cc = (i >> 4) & 63, rq = (i & 15) << 2;
+            if (blk * 64 + cc >= d) continue;
+            const uint2 v = *reinterpret_cast<const uint2*>(half ? &ta[cc][rq] : &tm[cc][rq]);
+            *reinterpret_cast<uint2*>(gt + (size_t)(half * d + blk * 64 + cc) * 64 + rq) = v;
+        }
+        __syncthreads();
+    }
+    // the padding columns [2 d, ldk) of the tile: zeros (the last 16-deep step of layer 0 may reach into them)
+    for (int i = t; i < CH_BM * (((2 * d + 15) & ~15) - 2 * d); i += CH_THREADS) {
+        const int pw = ((2 * d + 15) & ~15) - 2 * d;
+        tile[(i / pw) * ldk + 2 * d + i % pw] = 0;
+    }
+}
+
 // Every wave walks its own list of units (layer, column tile, 13-step chunk) in ONE flat loop.  Between units a wave crosses layer
 // boundaries; crossing layer l -> l + 1 is the same for every wave of the workgroup:
 //   barrier (layer l's tile complete)  ->  [mask of layer l + 1 staged by everyone, barrier]  ->  store wave: layer l's copies.
@@ -709,7 +816,9 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 bl += CH_BM * nt;
             }
     }
-    if (p.L[0].x_dup_half) {      // x holds one half of the columns, the other half repeats it ([g_mu | g_alpha] with g_alpha == g_mu)
+    if (!FULL && p.ib.gx) {       // the IAF update's backward makes layer 0's input here (its block buffer sits behind the bit tiles)
+        chain_stage_iafb(chain_lds, ldk, reinterpret_cast<uint16_t*>(bias_lds + p.ib_lds_off), p.ib, m0, p.m);
+    } else if (p.L[0].x_dup_half) {      // x holds one half of the columns, the other half repeats it ([g_mu | g_alpha] with g_alpha == g_mu)
         const int half = p.L[0].k >> 1;
         chain_stage(chain_lds, ldk, p.x, p.ldx, m0, p.m, half, half);
         chain_stage(chain_lds + half, ldk, p.x, p.ldx, m0, p.m, half, half);
@@ -949,13 +1058,40 @@ extern "C" int gv_made_chain_debug_stamps(int32_t* buffer) {
     return GV_OK;
 }
 
+static int made_chain_launch(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, const gv_chain_iafb* stage,
+                             void* stream);
+
 extern "C" int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, void* stream) {
+    return made_chain_launch(x, ldx, m, n_layers, layers, nullptr, stream);
+}
+
+extern "C" int gv_made_chain_iafb(const gv_chain_iafb* stage, int m, int n_layers, const gv_chain_layer* layers, void* stream) {
+    GV_REQUIRE(stage, GV_ERR_NULL, "gv_made_chain_iafb: NULL stage");
+    return made_chain_launch(nullptr, 0, m, n_layers, layers, stage, stream);
+}
+
+static int made_chain_launch(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, const gv_chain_iafb* stage,
+                             void* stream) {
     GV_REQUIRE(m >= 0 && n_layers >= 1 && n_layers <= GV_CHAIN_MAX_LAYERS, GV_ERR_SHAPE, "gv_made_chain: m=%d n_layers=%d", m, n_layers);
     if (m == 0) return GV_OK;
-    GV_REQUIRE(x && layers, GV_ERR_NULL, "gv_made_chain: NULL pointer");
-    GV_REQUIRE(ldx % 8 == 0 && aligned16(x) && ldx >= (layers[0].x_dup_half ? layers[0].k / 2 : layers[0].k), GV_ERR_ALIGN,
-               "gv_made_chain: x rows must be 16-B aligned pieces (ldx=%d)", ldx);
-    GV_REQUIRE(!layers[0].x_dup_half || layers[0].k % 16 == 0, GV_ERR_SHAPE, "gv_made_chain: x_dup_half needs k %% 16 == 0");
+    GV_REQUIRE((x || stage) && layers, GV_ERR_NULL, "gv_made_chain: NULL pointer");
+    if (stage) {
+        const gv_chain_iafb& ib = *stage;
+        GV_REQUIRE(ib.z && ib.ex && ib.gx && ib.gz && ib.colcount && ib.gnt, GV_ERR_NULL, "gv_made_chain_iafb: NULL operand");
+        GV_REQUIRE(ib.d > 0 && ib.d % 4 == 0 && layers[0].k == 2 * ib.d && ib.ld >= ib.d && ib.ld % 4 == 0 && ib.t_tile >= 128 * ib.d &&
+                       ib.t_tile % 4 == 0 && (int64_t)ib.t_tile * ((m + CH_BM - 1) / CH_BM) <= INT32_MAX,
+                   GV_ERR_SHAPE, "gv_made_chain_iafb: d=%d (d %% 4 == 0, layer 0 takes 2 d = %d columns), ld=%d, t_tile=%d", ib.d,
+                   layers[0].k, ib.ld, ib.t_tile);
+        GV_REQUIRE(aligned16(ib.z) && aligned16(ib.ex) && aligned16(ib.gx) && aligned16(ib.gz) && aligned16(ib.colcount) &&
+                       (reinterpret_cast<uintptr_t>(ib.gnt) & 7u) == 0, GV_ERR_ALIGN, "gv_made_chain_iafb: fp32 rows must be 16-B aligned");
+        GV_REQUIRE(!layers[0].x_dup_half, GV_ERR_SHAPE, "gv_made_chain_iafb: the stage fills both halves of layer 0's input itself");
+        GV_REQUIRE((int64_t)m * ib.ld * 4 < (1ll << 32), GV_ERR_SHAPE, "gv_made_chain_iafb: m * ld = %lld elements exceed the stage's 32-bit byte offsets",
+                   (long long)m * ib.ld);
+    } else {
+        GV_REQUIRE(ldx % 8 == 0 && aligned16(x) && ldx >= (layers[0].x_dup_half ? layers[0].k / 2 : layers[0].k), GV_ERR_ALIGN,
+                   "gv_made_chain: x rows must be 16-B aligned pieces (ldx=%d)", ldx);
+        GV_REQUIRE(!layers[0].x_dup_half || layers[0].k % 16 == 0, GV_ERR_SHAPE, "gv_made_chain: x_dup_half needs k %% 16 == 0");
+    }
     ChainArgs p;
     for (int i = 0; i < n_layers; ++i) {
         const gv_chain_layer& L = layers[i];
@@ -995,15 +1131,21 @@ extern "C" int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, co
     else if (layers[n_layers - 1].add_src) bias_floats += (size_t)layers[n_layers - 1].n;
     for (int i = 0; i < n_layers; ++i)
         if (layers[i].mask_bits) bias_floats += (size_t)CH_BM * ((layers[i].n + 31) / 32);      // its bit tile
-    const size_t lds = (size_t)(has_mask ? 3 : 2) * CH_BM * ldk * sizeof(uint16_t) + bias_floats * sizeof(float);
+    bias_floats = (bias_floats + 1) & ~(size_t)1;      // (the stage's block is read in 8-B pieces)
+    const size_t lds = (size_t)(has_mask ? 3 : 2) * CH_BM * ldk * sizeof(uint16_t) + bias_floats * sizeof(float) +
+                       (stage ? (size_t)2 * 64 * IB_LD * sizeof(uint16_t) : 0);
     GV_REQUIRE(lds <= 160 * 1024, GV_ERR_SHAPE, "gv_made_chain: layers this wide need %zu B of LDS (160 KB per CU)", lds);
     p.x = x; p.ldx = ldx; p.m = m; p.n_layers = n_layers; p.ldk = ldk; p.has_mask = has_mask ? 1 : 0; p.stamps = g_chain_stamps;
+    p.ib_lds_off = (int)bias_floats;
+    if (stage) p.ib = *stage;
+    else { p.ib = gv_chain_iafb{}; }
     bool full = false, bits = false;
     for (int i = 0; i < n_layers; ++i) {
         full = full || layers[i].mask || layers[i].mask_t || layers[i].accumulate;
         bits = bits || layers[i].mask_bits || layers[i].out_bits;
     }
     GV_REQUIRE(!(full && bits), GV_ERR_SHAPE, "gv_made_chain: mask bits do not combine with tile masks or an accumulating output in one chain");
+    GV_REQUIRE(!(full && stage), GV_ERR_SHAPE, "gv_made_chain_iafb: not with tile masks or an accumulating output");
     static unsigned long long lds_full = 0, lds_lean = 0;
     if (!raise_dynamic_lds((const void*)k_made_chain<true>, 160 * 1024, lds_full, "gv_made_chain") ||
         !raise_dynamic_lds((const void*)k_made_chain<false>, 160 * 1024, lds_lean, "gv_made_chain"))

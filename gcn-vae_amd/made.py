@@ -436,6 +436,13 @@ class _ChainLayer(_ct.Structure):
                 ('out_bits', _ct.c_void_p), ('mask_bits', _ct.c_void_p), ('x_dup_half', _ct.c_int32), ('t_tile', _ct.c_int32)]
 
 
+class _ChainIafb(_ct.Structure):
+    """gv_chain_iafb of include/gcnvae.h."""
+    _fields_ = [('z', _ct.c_void_p), ('ex', _ct.c_void_p), ('gx', _ct.c_void_p), ('gld', _ct.c_void_p), ('gz', _ct.c_void_p),
+                ('colcount', _ct.c_void_p), ('gnt', _ct.c_void_p), ('ld', _ct.c_int32), ('d', _ct.c_int32), ('t_tile', _ct.c_int32),
+                ('flags', _ct.c_int32)]
+
+
 class _RowLayer(_ct.Structure):
     """gv_row_layer of include/gcnvae.h."""
     _fields_ = [('w', _ct.c_void_p), ('bias', _ct.c_void_p), ('act', _ct.c_void_p), ('inp', _ct.c_void_p), ('out', _ct.c_void_p),
@@ -522,10 +529,11 @@ def made_chain_fits(widths_n, widths_k, any_mask):
 MADE_CHAIN_FLOPS = {}        # tag -> flops of one launch (filled while a KernelTimer is installed: bench.py's K4 roofline line)
 
 
-def made_chain(x, m, layers, tag=None):
+def made_chain(x, m, layers, tag=None, stage=None):
     """One launch for a chain of NT products (gv_made_chain): layers = dicts with w_packed, n, k and optional bias, relu, mask,
     out_bf16, out_bf16_t (t_tile: in tiles of 64 rows, that many elements apart), out_f32, accumulate.  Row strides are taken
-    from the tensors."""
+    from the tensors.  stage (x = None then): the IAF update's backward as the chain's first stage (gv_made_chain_iafb) --
+    dict(z, ex, gx, gz, colcount, gnt, t_tile, gld=None, overwrite_gz=False), fp32 (m, d) operands of one row stride."""
     if tag is not None and lib.TIMER is not None:
         MADE_CHAIN_FLOPS[tag] = 2.0 * int(m) * sum(int(d['n']) * int(d['k']) for d in layers)
     arr = (_ChainLayer * len(layers))()
@@ -564,6 +572,17 @@ def made_chain(x, m, layers, tag=None):
             if of is None or add[0].stride(0) != of.stride(0):
                 raise ValueError('made_chain: add_src shares the row stride of out_f32')
             c.add_src, c.add_colcount = ptr(add[0]), ptr(add[1])
+    if stage is not None:
+        ts = [stage[k_] for k_ in ('z', 'ex', 'gx', 'gz')]
+        if len({t.stride(0) for t in ts}) != 1:
+            raise ValueError('made_chain: the stage operands share one row stride')
+        sb = _ChainIafb()
+        sb.z, sb.ex, sb.gx, sb.gz = (ptr(t) for t in ts)
+        sb.gld, sb.colcount, sb.gnt = ptr(stage.get('gld')), ptr(stage['colcount']), ptr(stage['gnt'])
+        sb.ld, sb.d, sb.t_tile = ts[0].stride(0), int(ts[0].shape[1]), int(stage['t_tile'])
+        sb.flags = 1 if stage.get('overwrite_gz') else 0
+        lib.call('gv_made_chain_iafb', _ct.addressof(sb), int(m), len(layers), _ct.addressof(arr), lib.stream(), tag=tag)
+        return
     lib.call('gv_made_chain', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), lib.stream(), tag=tag)
 
 
@@ -1055,6 +1074,20 @@ class _MADEForwardBF16(torch.autograd.Function):
                 # without a log-det gradient (every pass but the last) g_alpha == g_mu: the chain's row-major input holds the g_mu half
                 # alone and the chain stages it twice (x_dup_half)
                 half = (gld is None or p != P - 1) and widths[L - 1] % 16 == 0 and L > 1
+                if MADE_CHAIN_IAFB and tiled and L > 1 and d % 4 == 0 and (r1 - r0) * d * 4 < (1 << 32):
+                    # ... as the backward chain's FIRST STAGE: [g_mu | g_alpha] goes straight into layer 0's LDS tile
+                    made_chain(None, r1 - r0,
+                               [dict(w_packed=wbt[L - 1], n=widths[L - 2], k=widths[L - 1], mask_bits=acts_b[L - 2][a:b],
+                                     **t_of(gm_t[L - 2], p - 1, r0))] +
+                               [dict(w_packed=wbt[l], n=widths[l - 1], k=widths[l], mask_bits=acts_b[l - 1][a:b],
+                                     **t_of(gm_t[l - 1], p - 1, r0)) for l in reversed(range(1, L - 1))] +
+                               [dict(w_packed=wbt[0], n=d, k=widths[0], out_f32=g_olds[p][r0:r1], add=(g_in[r0:r1], colcount[p]))],
+                               tag='madechain_bwd',
+                               stage=dict(z=z[r0:r1], ex=net_out[a:b], gx=g_in[r0:r1], gz=g_z[r0:r1], colcount=colcount[p],
+                                          gnt=gm_t[L - 1][(p - 1) * T + t0:], t_tile=tb,
+                                          gld=gld[r0:r1] if (p == P - 1 and gld is not None) else None, overwrite_gz=p == P - 1))
+                    g_in = g_olds[p]
+                    continue
                 lib.call('gv_iaf_update_bwd_bf16_ex', ptr(z[r0:r1]), ptr(net_out[a:b]), d, ptr(colcount[p]), ptr(g_in[r0:r1]),
                          ptr(gld[r0:r1]) if (p == P - 1 and gld is not None) else None, ptr(g_z[r0:r1]), ptr(gm_in[r0:r1]), gm_in.stride(0),
                          ptr(gm_t[L - 1][(p - 1) * T + t0:] if tiled else gm_t[L - 1][:, (p - 1) * npad:]),
@@ -1203,6 +1236,7 @@ GRADW_SPLIT_MAX = int(_os.environ.get('GV_GRADW_SPLIT_MAX', '256'))      # most 
 # against 73 at 128; in the c3 step 5.79 ms at 256, 5.72-5.77 at 128, 5.67-5.69 at 96, 5.72 at 64)
 GRADW_SPLIT_MAX_SIDE = int(_os.environ.get('GV_GRADW_SPLIT_MAX_SIDE', '96'))
 MADE_CHAIN_IAF = _os.environ.get('GV_MADE_CHAIN_IAF', '1') == '1'      # the IAF update inside the chain's last layer
+MADE_CHAIN_IAFB = _os.environ.get('GV_MADE_CHAIN_IAFB', '1') == '1'    # ... and its backward as the backward chain's first stage
 MADE_T_TILES = _os.environ.get('GV_MADE_T_TILES', '1') == '1'          # ... and the transposed copies in tiles of 64 rows
 
 

@@ -340,6 +340,18 @@ int gv_made_pack_weight_multi_iaf(int count, const float* const* w, const int32_
                                   uint16_t* const* packed_fwd, uint16_t* const* packed_bwd, void* stream);
 int gv_made_chain_fits(int n_layers, const int32_t* n_of_layer, const int32_t* k_of_layer, int any_mask);
 int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, void* stream);
+/* A backward chain whose FIRST STAGE is the IAF update's backward (gv_iaf_update_bwd_bf16_ex with flags bit 2, then gv_made_chain on
+ * its result, as one launch): per 64-row workgroup, g_net = [g_mu | g_alpha] is computed from dL/dx_new (gx), ex = exp(alpha + mu),
+ * z and the pass's column counts -- the arithmetic of gv_iaf_update_bwd_bf16_ex element by element -- and goes as bf16 straight
+ * into layer 0's LDS tile (layers[0].k == 2 d; never to memory), its transposed copy into gnt in tiles of 64 rows (element (column c
+ * of 2 d, row r) at gnt[(r / 64) * t_tile + c * 64 + r % 64]; whole tiles are written, zeros past m), g_z is added into gz (flags
+ * bit 0: written).  gld (per-row dL/dlogdet) may be NULL.  All fp32 operands [m][ld], 16-B aligned rows, d % 4 == 0.  Only chains
+ * without tile masks / accumulating outputs (every MADE pass of the fused path). */
+typedef struct gv_chain_iafb {
+    const float* z; const float* ex; const float* gx; const float* gld; float* gz; const int32_t* colcount; uint16_t* gnt;
+    int32_t ld, d, t_tile, flags;
+} gv_chain_iafb;
+int gv_made_chain_iafb(const gv_chain_iafb* stage, int m, int n_layers, const gv_chain_layer* layers, void* stream);
 /* probes only: a device buffer of 8 x 64 int32 that workgroup 0's waves of the following gv_made_chain launches fill with
  * s_memtime stamps (tools/probes/chain_stamps.py); NULL (the default) switches it off */
 int gv_made_chain_debug_stamps(int32_t* buffer);

@@ -748,6 +748,40 @@ def test_made_passes_over_row_blocks_on_their_own_streams_give_the_same_bits(mon
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n,d,hidden,n_hidden', [(1000, 40, 56, 2), (64, 200, 200, 3), (4300, 200, 200, 3), (130, 8, 16, 1)])
+def test_iaf_update_backward_as_the_first_stage_of_the_backward_chain_gives_the_same_bits(monkeypatch, n, d, hidden, n_hidden):
+    """gv_made_chain_iafb: the bf16 MADE node's backward with the IAF update's backward made in the prologue of the backward chain
+    ([g_mu | g_alpha] straight into layer 0's LDS tile, the transposed copy through a 64-column LDS block, g_z added in place)
+    against the two-launch form (gv_iaf_update_bwd_bf16_ex, then gv_made_chain): x, log-det, dL/dz and every parameter gradient
+    bit for bit -- with and without a log-det gradient, row counts that end inside a 64-row tile, one tile, d = 8 (one column
+    block, partly filled) and d = 200 (four blocks, the last one 8 columns)."""
+    from gcn_vae_amd import made, ops
+    from gcn_vae_amd.flows import MADE
+    z = torch.randn(n, d, generator=torch.Generator().manual_seed(n + d)).cuda()
+    calls = []
+    inner = made.made_chain
+    monkeypatch.setattr(made, 'made_chain', lambda x, *a, **k: (calls.append(k.get('stage') is not None), inner(x, *a, **k))[1])
+    for with_ld in (True, False):
+        res = []
+        for on in (False, True):
+            calls.clear()
+            monkeypatch.setattr(made, 'MADE_CHAIN_IAFB', on)
+            torch.manual_seed(3)
+            m = MADE(d, hidden, n_hidden).cuda()
+            with ops.gemm_precision('bf16'):
+                zz = z.clone().requires_grad_(True)
+                x, ld = m(zz)
+                (x.sin().sum() + ((ld * ld).sum() if with_ld else 0.0)).backward()
+            torch.cuda.synchronize()
+            assert any(calls) == on, 'the node did not take the expected backward form'
+            res.append((x.detach().clone(), ld.detach().clone(), zz.grad.clone(), [p.grad.detach().clone() for p in m.parameters()]))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+        assert float(res[0][2].abs().max()) > 0
+        for a, b in zip(res[0][3], res[1][3]):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('precision,n', [('bf16', 9000), ('f32', 5000)])
 def test_multi_stream_flow_stack_equals_the_plain_one_eagerly_and_in_a_captured_step(precision, n):
     """tools/probes/made_stress.py: two MADE blocks in a row with FlatAdam -- two row blocks on their own streams, weight gradients
