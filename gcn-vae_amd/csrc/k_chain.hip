@@ -663,9 +663,10 @@ __device__ __forceinline__ void chain_stage_iafb(uint16_t* tile, int ldk, uint16
             }
         }
     };
-    Ops cur;
+    Ops cur, nxt;
     request(0, cur);
     for (int blk = 0; blk < nblk; ++blk) {
+        if (blk + 1 < nblk) request(blk + 1, nxt);      // the next block's operands fly under this block's arithmetic and way out
         const int c = blk * 64 + cq;
         const int cn[4] = {cur.cn.x, cur.cn.y, cur.cn.z, cur.cn.w};
 #pragma unroll
@@ -704,7 +705,6 @@ __device__ __forceinline__ void chain_stage_iafb(uint16_t* tile, int ldk, uint16
                 ta[cq + q][rr] = ba[q];
             }
         }
-        if (blk + 1 < nblk) request(blk + 1, cur);      // in flight under the block's way out (one register set: the kernel has 128)
         __syncthreads();
         // the block's transposed copies: four consecutive rows of a column per 8-B store (16 lanes = 128 contiguous bytes); the whole
         // 64-row tile is written (zeros in the rows past m: they take part in the weight-gradient reduction)
@@ -716,6 +716,7 @@ __device__ __forceinline__ void chain_stage_iafb(uint16_t* tile, int ldk, uint16
             *reinterpret_cast<uint2*>(gt + (size_t)(half * d + blk * 64 + cc) * 64 + rq) = v;
         }
         __syncthreads();
+        if (blk + 1 < nblk) cur = nxt;
     }
     // the padding columns [2 d, ldk) of the tile: zeros (the last 16-deep step of layer 0 may reach into them)
     for (int i = t; i < CH_BM * (((2 * d + 15) & ~15) - 2 * d); i += CH_THREADS) {
@@ -734,7 +735,7 @@ __device__ __forceinline__ void chain_stage_iafb(uint16_t* tile, int ldk, uint16
 // two unit bodies with fixed set roles) measured the same at 228 tiles and cost 52 registers.
 // FULL = false: the instance for chains without tile masks (mask / mask_t) and without an accumulating fp32 output -- every
 // MADE pass of the fused path; without that code it keeps clear of the 128-register limit (the full instance spills ~30 B)
-template <bool FULL>
+template <bool FULL, bool IB = false>
 __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_made_chain(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t chain_lds[];
     const int ldk = p.ldk, nl = p.n_layers, m0 = blockIdx.x * CH_BM;
@@ -757,6 +758,9 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     uint4 qa[CH_KS];
     ChainUnit u = {nl, wave, 0};
     const uint4* const any_b = reinterpret_cast<const uint4*>(p.L[0].w_packed);      // a readable address for idle loads
+    const uint4* first_b = any_b;
+    unsigned first_off = 0;
+    int first_ksc = 1;
     {
         const uint4* b0 = any_b;
         unsigned off = lane;
@@ -767,7 +771,9 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             if (u.l < nl) u.tile = chain_first_tile(p.L[u.l], wave);
             if (u.l < nl) chain_unit_b(p, u, lane, b0, off, ksc);
         }
-        chain_issue(qa, b0, off, ksc);
+        first_b = b0; first_off = off; first_ksc = ksc;
+        // (the IAF-backward instance requests them behind its stage: the stage's two operand sets need the registers)
+        if constexpr (!IB) chain_issue(qa, b0, off, ksc);
     }
     int bias_total = 0, bits_base = 0;
     {       // every layer's bias into LDS (all loads in flight together): no global round trip in an epilogue
@@ -816,8 +822,9 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 bl += CH_BM * nt;
             }
     }
-    if (!FULL && p.ib.gx) {       // the IAF update's backward makes layer 0's input here (its block buffer sits behind the bit tiles)
+    if constexpr (IB) {           // the IAF update's backward makes layer 0's input here (its block buffer sits behind the bit tiles)
         chain_stage_iafb(chain_lds, ldk, reinterpret_cast<uint16_t*>(bias_lds + p.ib_lds_off), p.ib, m0, p.m);
+        chain_issue(qa, first_b, first_off, first_ksc);
     } else if (p.L[0].x_dup_half) {      // x holds one half of the columns, the other half repeats it ([g_mu | g_alpha] with g_alpha == g_mu)
         const int half = p.L[0].k >> 1;
         chain_stage(chain_lds, ldk, p.x, p.ldx, m0, p.m, half, half);
@@ -1151,7 +1158,10 @@ static int made_chain_launch(const uint16_t* x, int ldx, int m, int n_layers, co
         !raise_dynamic_lds((const void*)k_made_chain<false>, 160 * 1024, lds_lean, "gv_made_chain"))
         return GV_ERR_SHAPE;
     const dim3 grid((unsigned)((m + CH_BM - 1) / CH_BM));
-    if (full) hipLaunchKernelGGL(k_made_chain<true>, grid, dim3(CH_THREADS), lds, (hipStream_t)stream, p);
+    static unsigned long long lds_ib = 0;
+    if (stage && !raise_dynamic_lds((const void*)k_made_chain<false, true>, 160 * 1024, lds_ib, "gv_made_chain_iafb")) return GV_ERR_SHAPE;
+    if (stage) hipLaunchKernelGGL((k_made_chain<false, true>), grid, dim3(CH_THREADS), lds, (hipStream_t)stream, p);
+    else if (full) hipLaunchKernelGGL(k_made_chain<true>, grid, dim3(CH_THREADS), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(k_made_chain<false>, grid, dim3(CH_THREADS), lds, (hipStream_t)stream, p);
     return launch_status("gv_made_chain");
 }
