@@ -1967,7 +1967,7 @@ class _LossHead(torch.autograd.Function):
         g = _chk(g.reshape(1).contiguous(), name='gloss')
         # every buffer a side branch writes is allocated here, before the forks
         dscore = torch.empty(T, **f32)
-        dbias = torch.zeros((), **f32) if has_bias else None
+        dbias = torch.empty((), **f32) if has_bias else None      # (written by gv_bce_grad's ordered final sum: no fill)
         ws = torch.empty(1024, **f32)
         link = ctx.kl_link
         gz = torch.empty_like(z) if link is None else None
