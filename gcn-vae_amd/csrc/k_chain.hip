@@ -41,6 +41,7 @@ constexpr int CH_MMA_WAVES = 7, CH_STORE_WAVES = 1;      // 8 waves: two per SIM
 constexpr int CH_MMA_THREADS = CH_MMA_WAVES * 64, CH_STORE_THREADS = CH_STORE_WAVES * 64;
 constexpr int CH_THREADS = CH_MMA_THREADS + CH_STORE_THREADS;
 constexpr int CH_L = GV_CHAIN_MAX_LAYERS;
+constexpr int CH_MAX_PASSES = 6;       // passes of one launch of the IAF-backward instance (the reference's MADE makes six; the first is a row kernel)
 
 struct ChainArgs {
     const uint16_t* x;           // [m][ldx] bf16: input of layer 0
@@ -48,7 +49,14 @@ struct ChainArgs {
     int32_t* stamps;             // gv_made_chain_debug_stamps: s_memtime stamps of workgroup 0 (probes only), NULL otherwise
     gv_chain_iafb ib;            // ib.gx != NULL: layer 0's input is made in the prologue (the IAF update's backward), x unused
     int ib_lds_off;              // floats from the bias block to the stage's 2 x 64 x IB_LD transposition block
+    int n_passes;                // IB: passes of a MADE's backward in this launch (pass[q]: what differs from pass to pass)
     gv_chain_layer L[CH_L];
+    struct Pass {
+        const float* ex; const float* gx; const float* gld; const int32_t* cc; uint16_t* gnt; float* of; const float* add;
+        int32_t flags, pad;
+        const uint32_t* bits[CH_L];
+        uint16_t* out_t[CH_L];
+    } pass[CH_MAX_PASSES];
 };
 
 __device__ __forceinline__ uint16_t bf_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
@@ -63,6 +71,18 @@ __device__ __forceinline__ T* chain_pin_ptr(T* q) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
     typedef __attribute__((address_space(1))) T GT;         // (a pointer rebuilt from integers is generic: FLAT accesses otherwise)
     return (T*)(GT*)(((unsigned long long)hi << 32) | lo);
+}
+
+// the same as an opaque scalar made HERE (volatile: not hoisted out of an enclosing loop, where it would be held -- or spilled -- across it)
+template <typename T>
+__device__ __forceinline__ T* chain_pin_here(T* q) {
+    asm volatile("" : "+s"(q));
+    typedef __attribute__((address_space(1))) T GT;
+    return (T*)(GT*)q;
+}
+__device__ __forceinline__ int chain_pin_here(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
 }
 
 __device__ __forceinline__ void chain_barrier() {
@@ -318,6 +338,38 @@ __device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const g
             }
         }
         __builtin_amdgcn_sched_barrier(0);      // one group at a time keeps the address registers few
+    }
+}
+
+// The LAST layer of a backward chain with the IAF-backward stage: fp32 output (dL/dx_old of the pass) + the gradient the update
+// hands through where a column's count is 0 (counts in LDS) -- what chain_epilogue does for such a layer, with the pass's pointers
+// given explicitly (the pass loop: pass q's output is pass q + 1's dL/dx_new).  Same arithmetic, element by element.
+__device__ __forceinline__ void chain_epilogue_last(const f32x16_t (&acc)[2], int n, int tile, int m0, int m, const float* bias_l,
+                                                    float* of, int ldc, const float* add, const int* cnt_lds, int r, int h) {
+    asm volatile("" : "+v"(r), "+v"(h));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c0 = tile * 32 + 8 * g + 4 * h;
+        if (c0 >= n) continue;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias_l) bv = *reinterpret_cast<const float4*>(bias_l + c0);
+        const int4 ac = *reinterpret_cast<const int4*>(cnt_lds + c0);
+        const bool any0 = add && (ac.x <= 0 || ac.y <= 0 || ac.z <= 0 || ac.w <= 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int row = mt * 32 + r;
+            if (m0 + row >= m) continue;
+            float4 o = make_float4(acc[mt][4 * g] + bv.x, acc[mt][4 * g + 1] + bv.y, acc[mt][4 * g + 2] + bv.z, acc[mt][4 * g + 3] + bv.w);
+            if (any0) {
+                const float4 av = *reinterpret_cast<const float4*>(add + (size_t)(m0 + row) * ldc + c0);
+                if (ac.x <= 0) o.x += av.x;
+                if (ac.y <= 0) o.y += av.y;
+                if (ac.z <= 0) o.z += av.z;
+                if (ac.w <= 0) o.w += av.w;
+            }
+            *reinterpret_cast<float4*>(of + (size_t)(m0 + row) * ldc + c0) = o;
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -627,26 +679,29 @@ __device__ __forceinline__ void chain_store(const gv_chain_layer& Ly, const uint
 // layer's weight gradient) leaves through a [column][row] LDS block of 64 columns at a time, g_z is added in place.  Four column
 // blocks per 200-wide row; the next block's operands are requested before the current one leaves.
 constexpr int IB_LD = 68;      // rows of the transposition block, padded (8-B reads of four rows, conflict-free 2-B writes)
-__device__ __forceinline__ void chain_stage_iafb(uint16_t* tile, int ldk, uint16_t* tmx, const gv_chain_iafb& ib, int m0, int m) {
+__device__ __forceinline__ void chain_stage_iafb(uint16_t* tile, int ldk, uint16_t* tmx, const gv_chain_iafb& ib, int m0, int m,
+                                                 const float* ex_q, const float* gx_q, const float* gld_q, const int32_t* cc_q,
+                                                 uint16_t* gnt_q, int flags_q) {
     const int d = ib.d, nblk = (d + 63) >> 6;
-    const int t = threadIdx.x;
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));      // opaque: inside the pass loop everything derived from it would be hoisted and held across the unit loop
     uint16_t (*tm)[IB_LD] = reinterpret_cast<uint16_t (*)[IB_LD]>(tmx);                 // [64 columns][rows]: g_mu
     uint16_t (*ta)[IB_LD] = reinterpret_cast<uint16_t (*)[IB_LD]>(tmx + 64 * IB_LD);    // g_alpha
     // a block is 64 rows x 16 pieces of four columns = 1 024 pieces: two per thread (piece j of thread t: rows t / 16 and 32 + t / 16)
     const int cq = (t & 15) << 2, rr0 = t >> 4;
     struct Ops { float4 g[2], e[2], z[2], a[2]; int4 cn; };
     // pinned (scalar) bases + ONE 32-bit byte offset per row: 64-bit per-lane addresses of four arrays x two rows were what spilled
-    const float* const gx_p = chain_pin_ptr(ib.gx);
-    const float* const ex_p = chain_pin_ptr(ib.ex);
-    const float* const z_p = chain_pin_ptr(ib.z);
-    float* const gz_p = chain_pin_ptr(ib.gz);
-    const int ld = chain_pin(ib.ld), fl = chain_pin(ib.flags);
+    const float* const gx_p = chain_pin_here(gx_q);
+    const float* const ex_p = chain_pin_here(ex_q);
+    const float* const z_p = chain_pin_here(ib.z);
+    float* const gz_p = chain_pin_here(ib.gz);
+    const int ld = chain_pin_here(ib.ld), fl = chain_pin_here(flags_q);
     const unsigned off0 = (unsigned)((m0 + rr0) * ld + cq) * 4u, off1 = (unsigned)((m0 + rr0 + 32) * ld + cq) * 4u;
     auto at = [](const float* base, unsigned byte_off) { return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off); };
     auto request = [&](int blk, Ops& o) {
         const int c = blk * 64 + cq;
         o.cn = make_int4(0, 0, 0, 0);
-        if (c < d) o.cn = *reinterpret_cast<const int4*>(ib.colcount + c);
+        if (c < d) o.cn = *reinterpret_cast<const int4*>(cc_q + c);
         const bool any = o.cn.x > 0 || o.cn.y > 0 || o.cn.z > 0 || o.cn.w > 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -676,7 +731,7 @@ __device__ __forceinline__ void chain_stage_iafb(uint16_t* tile, int ldk, uint16
                         ev[4] = {cur.e[j].x, cur.e[j].y, cur.e[j].z, cur.e[j].w};
             uint16_t bm[4] = {0, 0, 0, 0}, ba[4] = {0, 0, 0, 0};
             if (r < m && c < d) {
-                const float gl = ib.gld ? ib.gld[r] : 0.f;
+                const float gl = gld_q ? gld_q[r] : 0.f;
                 float gz[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -708,7 +763,7 @@ __device__ __forceinline__ void chain_stage_iafb(uint16_t* tile, int ldk, uint16
         __syncthreads();
         // the block's transposed copies: four consecutive rows of a column per 8-B store (16 lanes = 128 contiguous bytes); the whole
         // 64-row tile is written (zeros in the rows past m: they take part in the weight-gradient reduction)
-        uint16_t* const gt = ib.gnt + (size_t)blockIdx.x * ib.t_tile;
+        uint16_t* const gt = gnt_q + (size_t)blockIdx.x * ib.t_tile;
         for (int i = t; i < 2 * 64 * 16; i += CH_THREADS) {
             const int half = i >> 10, cc = (i >> 4) & 63, rq = (i & 15) << 2;
             if (blk * 64 + cc >= d) continue;
@@ -741,8 +796,9 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     const int ldk = p.ldk, nl = p.n_layers, m0 = blockIdx.x * CH_BM;
     uint16_t* mbuf = chain_lds + 2 * CH_BM * ldk;
     float* bias_lds = reinterpret_cast<float*>(chain_lds + (p.has_mask ? 3 : 2) * CH_BM * ldk);
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int r = lane & 31, h = lane >> 5;
+    int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    int r = lane & 31, h = lane >> 5, tid = threadIdx.x;
     const bool mma_wave = wave < CH_MMA_WAVES;
     int ts_n = 0;
     auto stamp = [&]() {
@@ -822,8 +878,30 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 bl += CH_BM * nt;
             }
     }
+    // IB: ALL passes of a MADE's backward in this launch (p.n_passes; p.pass[q] holds what differs from pass to pass: pass q's
+    // dL/dx_new is pass q - 1's fp32 output).  A workgroup keeps its 64 rows through the passes: every step of a pass is row-local.
+    int q = 0;
+  next_pass:
     if constexpr (IB) {           // the IAF update's backward makes layer 0's input here (its block buffer sits behind the bit tiles)
-        chain_stage_iafb(chain_lds, ldk, reinterpret_cast<uint16_t*>(bias_lds + p.ib_lds_off), p.ib, m0, p.m);
+        {
+            // per pass again, from an opaque copy: what derives from the thread index is otherwise computed once in front of the
+            // pass loop and held across it, on top of what the unit loop holds
+            asm volatile("" : "+v"(lane));
+            tid = lane | (wave << 6); r = lane & 31; h = lane >> 5;
+            const ChainArgs::Pass& pq = p.pass[q];
+            chain_stage_iafb(chain_lds, ldk, reinterpret_cast<uint16_t*>(bias_lds + p.ib_lds_off), p.ib, m0, p.m, pq.ex, pq.gx, pq.gld, pq.cc,
+                             pq.gnt, pq.flags);
+        }
+        if (q > 0) {              // this wave's first unit again
+            u = {nl, wave, 0};
+            first_b = any_b; first_off = lane; first_ksc = 1;
+            if (mma_wave) {
+                u.l = 0;
+                while (u.l < nl && chain_first_tile(p.L[u.l], wave) >= chain_tiles(p.L[u.l])) ++u.l;
+                if (u.l < nl) u.tile = chain_first_tile(p.L[u.l], wave);
+                if (u.l < nl) chain_unit_b(p, u, lane, first_b, first_off, first_ksc);
+            }
+        }
         chain_issue(qa, first_b, first_off, first_ksc);
     } else if (p.L[0].x_dup_half) {      // x holds one half of the columns, the other half repeats it ([g_mu | g_alpha] with g_alpha == g_mu)
         const int half = p.L[0].k >> 1;
@@ -837,6 +915,10 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 
     f32x16_t acc[2];
     int layer = 0, bias_off = 0, bits_off = 0;
+    if (IB) {       // defined here: nothing of the previous pass's accumulators is carried around the pass loop and through the stage
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+    }
 
     // cross layer boundaries until this wave stands in layer `target` (nl: past the last layer).  The boundary orders LDS traffic
     // only (chain_barrier): __syncthreads() also drains the vector-memory counter -- every transposed 2-B store, sign-bit word and
@@ -849,12 +931,15 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             __syncthreads();                                                                                            \
         }                                                                                                               \
         if (!mma_wave && (layer + 1 < nl || p.L[layer].iaf_z))                                                          \
-            chain_store<FULL>(p.L[layer], chain_lds + ((layer + 1) & 1) * CH_BM * ldk, ldk, m0, p.m, (int)threadIdx.x - CH_MMA_THREADS, \
+            chain_store<FULL>(p.L[layer], chain_lds + ((layer + 1) & 1) * CH_BM * ldk, ldk, m0, p.m, tid - CH_MMA_THREADS, \
                               !FULL && GV_CHAIN_FAST_EPILOGUE && layer + 1 < nl && m0 + CH_BM <= p.m && p.L[layer].out_bf16_t && \
                               p.L[layer].t_tile > 0 && !p.L[layer].out_f32 && !p.L[layer].add_src && !p.L[layer].iaf_z);  \
         bias_off += p.L[layer].n;                                                                                       \
         bits_off += p.L[layer].mask_bits ? CH_BM * ((p.L[layer].n + 31) >> 5) : 0;                                      \
         ++layer;                                                                                                        \
+        if (IB) { /* a unit behind a boundary starts at chunk 0: said here, the accumulators are dead across the boundary */ \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;                                 \
+        }                                                                                                               \
     }
 
     // one unit: fence (its fragments were requested during the previous unit's epilogue), MFMAs, reload for the next unit, epilogue
@@ -901,6 +986,20 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                                reinterpret_cast<const int*>(bias_lds + bias_total), r, h);                              \
         }                                                                                                               \
         if (!(GV_CHAIN_ABL & 2048)) chain_issue(Q, nb0, noff, nksc);                                                    \
+        if (IB && u.ch + 1 == nch) {                                                                                    \
+            /* backward chain behind the IAF-backward stage: hidden layers on the fast epilogue also in the last, partial tile (its  \
+               rows past m hold zeros from the stage on: no bias, the mask bits of such rows are 0 -- zeros go into the tile's pad    \
+               rows, which is what they must hold); the last layer's fp32 output with this pass's pointers */           \
+            if (u.l + 1 < nl)                                                                                           \
+                chain_epilogue_fast(acc, chain_pin(Ly.n), u.tile, chain_pin(Ly.relu), chain_lds + ((u.l + 1) & 1) * CH_BM * ldk, ldk, \
+                                    (chain_pin(Ly.n) + 15) & ~15, Ly.bias ? bias_lds + bias_off : nullptr,              \
+                                    Ly.mask_bits ? reinterpret_cast<const uint32_t*>(bias_lds + bits_base) + bits_off : nullptr, \
+                                    (chain_pin(Ly.n) + 31) >> 5, chain_pin_ptr(p.pass[q].out_t[u.l]) + (size_t)blockIdx.x * chain_pin(Ly.t_tile), \
+                                    nullptr, 0, r, h);                                                                  \
+            else                                                                                                        \
+                chain_epilogue_last(acc, Ly.n, u.tile, m0, p.m, Ly.bias ? bias_lds + bias_off : nullptr, p.pass[q].of, Ly.ldc, \
+                                    p.pass[q].add, reinterpret_cast<const int*>(bias_lds + bias_total), r, h);         \
+        } else                                                                                                          \
         if (u.ch + 1 == nch && !iaf_unit) {                                                                             \
             /* the common hidden layer of the fused chains (FULL == false): every row exists, transposed copy in 64-row tiles */ \
             const bool fast = !FULL && GV_CHAIN_FAST_EPILOGUE && u.l + 1 < nl && m0 + CH_BM <= p.m && Ly.out_bf16_t && Ly.t_tile > 0 && \
@@ -928,6 +1027,30 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         CHAIN_UNIT1(qa)
     }
     stamp();
+    if constexpr (IB) {
+        if (++q < p.n_passes) {
+            // every wave is behind the last layer's barrier: the next pass's column counts and mask bits replace this pass's in LDS (the
+            // stage's barriers order them in front of their first readers)
+            const ChainArgs::Pass& pq = p.pass[q];
+            const gv_chain_layer& Ll = p.L[nl - 1];
+            __syncthreads();      // (with the vector-memory counter drained: this pass's fp32 output, every wave's part of it, is the next stage's gx)
+            const int tx = tid;
+            if (tx < Ll.n) reinterpret_cast<int*>(bias_lds + bias_total)[tx] = pq.cc[tx];
+            uint32_t* bl = reinterpret_cast<uint32_t*>(bias_lds + bits_base);
+            for (int l = 0; l < nl; ++l)
+                if (p.L[l].mask_bits) {
+                    const int nt = (p.L[l].n + 31) >> 5;
+                    const uint32_t* src = pq.bits[l];
+                    for (int i = tx; i < CH_BM * nt; i += CH_THREADS) {
+                        const int row = i / nt, t = i - row * nt;
+                        bl[i] = m0 + row < p.m ? src[(size_t)(m0 + row) * p.L[l].ldbits + t] : 0u;
+                    }
+                    bl += CH_BM * nt;
+                }
+            layer = 0; bias_off = 0; bits_off = 0;
+            goto next_pass;
+        }
+    }
 #undef CHAIN_CROSS
 #undef CHAIN_UNIT1
 }
@@ -1092,6 +1215,20 @@ static int made_chain_launch(const uint16_t* x, int ldx, int m, int n_layers, co
         GV_REQUIRE(aligned16(ib.z) && aligned16(ib.ex) && aligned16(ib.gx) && aligned16(ib.gz) && aligned16(ib.colcount) &&
                        (reinterpret_cast<uintptr_t>(ib.gnt) & 7u) == 0, GV_ERR_ALIGN, "gv_made_chain_iafb: fp32 rows must be 16-B aligned");
         GV_REQUIRE(!layers[0].x_dup_half, GV_ERR_SHAPE, "gv_made_chain_iafb: the stage fills both halves of layer 0's input itself");
+        GV_REQUIRE(ib.n_passes >= 0 && ib.n_passes <= CH_MAX_PASSES, GV_ERR_SHAPE, "gv_made_chain_iafb: n_passes=%d (at most %d)", ib.n_passes,
+                   CH_MAX_PASSES);
+        {   // what the instance's epilogues assume (every MADE backward chain of the fused path is of this form)
+            const gv_chain_layer& last = layers[n_layers - 1];
+            bool ok = n_layers >= 2 && last.out_f32 && !last.out_bf16_t && !last.relu && !last.mask_bits && !last.out_bits && !last.iaf_z &&
+                      (!last.add_src || last.add_colcount);
+            for (int l = 0; l + 1 < n_layers; ++l)
+                ok = ok && layers[l].out_bf16_t && layers[l].t_tile > 0 && !layers[l].out_f32 && !layers[l].add_src && !layers[l].out_bits &&
+                     !layers[l].bias && !layers[l].out_bf16 && !layers[l].iaf_z;
+            GV_REQUIRE(ok, GV_ERR_SHAPE, "gv_made_chain_iafb: hidden layers write tiled transposed copies alone (no bias), the last layer an fp32 output");
+        }
+        GV_REQUIRE(ib.n_passes <= 1 || layers[n_layers - 1].ldc == ib.ld, GV_ERR_SHAPE,
+                   "gv_made_chain_iafb: with n_passes > 1 the last layer's fp32 output is the next pass's gx: ldc=%d must equal ld=%d",
+                   layers[n_layers - 1].ldc, ib.ld);
         GV_REQUIRE((int64_t)m * ib.ld * 4 < (1ll << 32), GV_ERR_SHAPE, "gv_made_chain_iafb: m * ld = %lld elements exceed the stage's 32-bit byte offsets",
                    (long long)m * ib.ld);
     } else {
@@ -1144,8 +1281,31 @@ static int made_chain_launch(const uint16_t* x, int ldx, int m, int n_layers, co
     GV_REQUIRE(lds <= 160 * 1024, GV_ERR_SHAPE, "gv_made_chain: layers this wide need %zu B of LDS (160 KB per CU)", lds);
     p.x = x; p.ldx = ldx; p.m = m; p.n_layers = n_layers; p.ldk = ldk; p.has_mask = has_mask ? 1 : 0; p.stamps = g_chain_stamps;
     p.ib_lds_off = (int)bias_floats;
-    if (stage) p.ib = *stage;
-    else { p.ib = gv_chain_iafb{}; }
+    p.n_passes = 1;
+    for (int q = 0; q < CH_MAX_PASSES; ++q) p.pass[q] = ChainArgs::Pass{};
+    if (stage) {
+        p.ib = *stage;
+        const gv_chain_layer& last = layers[n_layers - 1];
+        p.n_passes = stage->n_passes > 1 ? stage->n_passes : 1;
+        for (int q = 0; q < p.n_passes; ++q) {
+            ChainArgs::Pass& pq = p.pass[q];
+            float* const of_prev = q ? last.out_f32 + (int64_t)(q - 1) * stage->of_step : nullptr;
+            pq.ex = stage->ex + (int64_t)q * stage->rows_step * stage->ld;
+            pq.gx = q ? of_prev : stage->gx;                 // pass q's dL/dx_new is pass q - 1's dL/dx_old
+            pq.gld = q ? nullptr : stage->gld;
+            pq.cc = stage->colcount + (int64_t)q * stage->cc_step;
+            pq.gnt = stage->gnt + (int64_t)q * stage->tiles_step * stage->t_tile;
+            pq.flags = q ? (stage->flags & ~1) : stage->flags;
+            pq.of = last.out_f32 ? last.out_f32 + (int64_t)q * stage->of_step : nullptr;
+            pq.add = q ? (last.add_src ? of_prev : nullptr) : last.add_src;
+            for (int l = 0; l < n_layers; ++l) {
+                pq.bits[l] = layers[l].mask_bits ? layers[l].mask_bits + (int64_t)q * stage->rows_step * layers[l].ldbits : nullptr;
+                pq.out_t[l] = layers[l].out_bf16_t ? layers[l].out_bf16_t + (int64_t)q * stage->tiles_step * layers[l].t_tile : nullptr;
+            }
+        }
+    } else {
+        p.ib = gv_chain_iafb{};
+    }
     bool full = false, bits = false;
     for (int i = 0; i < n_layers; ++i) {
         full = full || layers[i].mask || layers[i].mask_t || layers[i].accumulate;

@@ -440,7 +440,8 @@ class _ChainIafb(_ct.Structure):
     """gv_chain_iafb of include/gcnvae.h."""
     _fields_ = [('z', _ct.c_void_p), ('ex', _ct.c_void_p), ('gx', _ct.c_void_p), ('gld', _ct.c_void_p), ('gz', _ct.c_void_p),
                 ('colcount', _ct.c_void_p), ('gnt', _ct.c_void_p), ('ld', _ct.c_int32), ('d', _ct.c_int32), ('t_tile', _ct.c_int32),
-                ('flags', _ct.c_int32)]
+                ('flags', _ct.c_int32), ('n_passes', _ct.c_int32), ('rows_step', _ct.c_int32), ('tiles_step', _ct.c_int32),
+                ('cc_step', _ct.c_int32), ('of_step', _ct.c_int64)]
 
 
 class _RowLayer(_ct.Structure):
@@ -533,7 +534,8 @@ def made_chain(x, m, layers, tag=None, stage=None):
     """One launch for a chain of NT products (gv_made_chain): layers = dicts with w_packed, n, k and optional bias, relu, mask,
     out_bf16, out_bf16_t (t_tile: in tiles of 64 rows, that many elements apart), out_f32, accumulate.  Row strides are taken
     from the tensors.  stage (x = None then): the IAF update's backward as the chain's first stage (gv_made_chain_iafb) --
-    dict(z, ex, gx, gz, colcount, gnt, t_tile, gld=None, overwrite_gz=False), fp32 (m, d) operands of one row stride."""
+    dict(z, ex, gx, gz, colcount, gnt, t_tile, gld=None, overwrite_gz=False), fp32 (m, d) operands of one row stride; with
+    passes=dict(n, rows_step, tiles_step, cc_step, of_step) the launch walks n passes whose operands lie those steps apart."""
     if tag is not None and lib.TIMER is not None:
         MADE_CHAIN_FLOPS[tag] = 2.0 * int(m) * sum(int(d['n']) * int(d['k']) for d in layers)
     arr = (_ChainLayer * len(layers))()
@@ -581,6 +583,10 @@ def made_chain(x, m, layers, tag=None, stage=None):
         sb.gld, sb.colcount, sb.gnt = ptr(stage.get('gld')), ptr(stage['colcount']), ptr(stage['gnt'])
         sb.ld, sb.d, sb.t_tile = ts[0].stride(0), int(ts[0].shape[1]), int(stage['t_tile'])
         sb.flags = 1 if stage.get('overwrite_gz') else 0
+        ps = stage.get('passes')
+        if ps is not None:
+            sb.n_passes, sb.rows_step, sb.tiles_step = int(ps['n']), int(ps['rows_step']), int(ps['tiles_step'])
+            sb.cc_step, sb.of_step = int(ps['cc_step']), int(ps['of_step'])
         lib.call('gv_made_chain_iafb', _ct.addressof(sb), int(m), len(layers), _ct.addressof(arr), lib.stream(), tag=tag)
         return
     lib.call('gv_made_chain', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), lib.stream(), tag=tag)
@@ -1063,19 +1069,26 @@ class _MADEForwardBF16(torch.autograd.Function):
         g_z = torch.empty(n, d, **f32) if (ctx.fused and P > 1) else torch.zeros(n, d, **f32)      # fused: the first pass writes it
         gz_p = torch.empty(n, d, **f32)
         g_cur = gx
-        g_olds = {p: torch.empty(n, d, **f32) for p in range(1, P)} if ctx.fused else None      # dL/dx_old of every pass (allocated before any fork)
+        # dL/dx_old of every pass, stacked (allocated before any fork)
+        gold_stack = torch.empty(max(P - 1, 1) * n, d, **f32) if ctx.fused else None
+        g_olds = {p: gold_stack[(p - 1) * n:p * n] for p in range(1, P)} if ctx.fused else None
 
         def fused_passes(r0, r1):
             """The backward of passes P-1 .. 1 for the rows [r0, r1) (r0 a multiple of 64): every launch of a pass is row-local."""
             g_in = gx
-            for p in reversed(range(1, P)):
+            todo = list(reversed(range(1, P)))
+            while todo:
+                p = todo.pop(0)
                 a, b, t0 = (p - 1) * n + r0, (p - 1) * n + r1, r0 // 64
                 # from exp(alpha + mu); the gradient handed through to x_old (columns of count 0) is added by the chain's last layer
                 # without a log-det gradient (every pass but the last) g_alpha == g_mu: the chain's row-major input holds the g_mu half
                 # alone and the chain stages it twice (x_dup_half)
                 half = (gld is None or p != P - 1) and widths[L - 1] % 16 == 0 and L > 1
                 if MADE_CHAIN_IAFB and tiled and L > 1 and d % 4 == 0 and (r1 - r0) * d * 4 < (1 << 32):
-                    # ... as the backward chain's FIRST STAGE: [g_mu | g_alpha] goes straight into layer 0's LDS tile
+                    # ... as the backward chain's FIRST STAGE: [g_mu | g_alpha] goes straight into layer 0's LDS tile; up to six passes
+                    # (this one and the ones below it: their operands lie one pass apart in the stacked buffers) per launch
+                    more = min(len(todo), MADE_CHAIN_PASSES - 1) if g_in.stride(0) == gold_stack.stride(0) else 0
+                    passes = dict(n=more + 1, rows_step=-n, tiles_step=-T, cc_step=-colcount.stride(0), of_step=-n * gold_stack.stride(0))
                     made_chain(None, r1 - r0,
                                [dict(w_packed=wbt[L - 1], n=widths[L - 2], k=widths[L - 1], mask_bits=acts_b[L - 2][a:b],
                                      **t_of(gm_t[L - 2], p - 1, r0))] +
@@ -1085,8 +1098,10 @@ class _MADEForwardBF16(torch.autograd.Function):
                                tag='madechain_bwd',
                                stage=dict(z=z[r0:r1], ex=net_out[a:b], gx=g_in[r0:r1], gz=g_z[r0:r1], colcount=colcount[p],
                                           gnt=gm_t[L - 1][(p - 1) * T + t0:], t_tile=tb,
-                                          gld=gld[r0:r1] if (p == P - 1 and gld is not None) else None, overwrite_gz=p == P - 1))
-                    g_in = g_olds[p]
+                                          gld=gld[r0:r1] if (p == P - 1 and gld is not None) else None, overwrite_gz=p == P - 1,
+                                          passes=passes if more else None))
+                    del todo[:more]
+                    g_in = g_olds[p - more]
                     continue
                 lib.call('gv_iaf_update_bwd_bf16_ex', ptr(z[r0:r1]), ptr(net_out[a:b]), d, ptr(colcount[p]), ptr(g_in[r0:r1]),
                          ptr(gld[r0:r1]) if (p == P - 1 and gld is not None) else None, ptr(g_z[r0:r1]), ptr(gm_in[r0:r1]), gm_in.stride(0),
@@ -1236,6 +1251,12 @@ GRADW_SPLIT_MAX = int(_os.environ.get('GV_GRADW_SPLIT_MAX', '256'))      # most 
 # against 73 at 128; in the c3 step 5.79 ms at 256, 5.72-5.77 at 128, 5.67-5.69 at 96, 5.72 at 64)
 GRADW_SPLIT_MAX_SIDE = int(_os.environ.get('GV_GRADW_SPLIT_MAX_SIDE', '96'))
 MADE_CHAIN_IAF = _os.environ.get('GV_MADE_CHAIN_IAF', '1') == '1'      # the IAF update inside the chain's last layer
+# ... and that many passes of the backward per launch (gv_chain_iafb.n_passes).  The looped launch needs 28 % less kernel time per
+# pass (FB15k-237 size, 3 IAF blocks: 3 x 203 us against 15 x 56 us) and LOSES as a step (2.96 -> 3.12 ms; WN18RR 5.24 -> 5.44): its
+# workgroups hold their CU's LDS (134 KB) through all passes, and the weight-gradient products of the block before, which run beside
+# it on the side stream and are the longer of the two, only get the CUs the chain leaves free (k_gemm_bf16_tallk: 50 -> 63 us).
+# tools/probes/passes_grid.sh: no split / row-block setting turns that around.  1 = a launch per pass.
+MADE_CHAIN_PASSES = max(1, min(6, int(_os.environ.get('GV_MADE_CHAIN_PASSES', '1'))))
 MADE_CHAIN_IAFB = _os.environ.get('GV_MADE_CHAIN_IAFB', '1') == '1'    # ... and its backward as the backward chain's first stage
 MADE_T_TILES = _os.environ.get('GV_MADE_T_TILES', '1') == '1'          # ... and the transposed copies in tiles of 64 rows
 

@@ -350,6 +350,13 @@ int gv_made_chain(const uint16_t* x, int ldx, int m, int n_layers, const gv_chai
 typedef struct gv_chain_iafb {
     const float* z; const float* ex; const float* gx; const float* gld; float* gz; const int32_t* colcount; uint16_t* gnt;
     int32_t ld, d, t_tile, flags;
+    /* n_passes > 1 (at most 6): ALL passes of a MADE's backward in the one launch -- a workgroup keeps its 64 rows through them
+     * (every step of a pass is row-local).  The pointers above and in `layers` describe the pass processed first; pass q's operands
+     * lie q steps further in the stacked buffers (steps may be negative): ex and every mask_bits by rows_step rows, gnt and every
+     * out_bf16_t by tiles_step tiles, colcount by cc_step ints, the last layer's out_f32 by of_step floats; pass q's gx and add_src
+     * are pass q - 1's out_f32; gld and flags bit 0 belong to the first pass alone.  Hidden layers: tiled out_bf16_t alone, no bias. */
+    int32_t n_passes, rows_step, tiles_step, cc_step;
+    int64_t of_step;
 } gv_chain_iafb;
 int gv_made_chain_iafb(const gv_chain_iafb* stage, int m, int n_layers, const gv_chain_layer* layers, void* stream);
 /* probes only: a device buffer of 8 x 64 int32 that workgroup 0's waves of the following gv_made_chain launches fill with

@@ -754,7 +754,9 @@ def test_iaf_update_backward_as_the_first_stage_of_the_backward_chain_gives_the_
     ([g_mu | g_alpha] straight into layer 0's LDS tile, the transposed copy through a 64-column LDS block, g_z added in place)
     against the two-launch form (gv_iaf_update_bwd_bf16_ex, then gv_made_chain): x, log-det, dL/dz and every parameter gradient
     bit for bit -- with and without a log-det gradient, row counts that end inside a 64-row tile, one tile, d = 8 (one column
-    block, partly filled) and d = 200 (four blocks, the last one 8 columns)."""
+    block, partly filled) and d = 200 (four blocks, the last one 8 columns).  The one-launch form with ONE launch per pass, with
+    groups of two passes (n_passes = 2: the last group may hold one) and with all passes of the node in one launch (n_passes up to
+    6: a pass reads the fp32 output its workgroup wrote in the pass before)."""
     from gcn_vae_amd import made, ops
     from gcn_vae_amd.flows import MADE
     z = torch.randn(n, d, generator=torch.Generator().manual_seed(n + d)).cuda()
@@ -763,9 +765,10 @@ def test_iaf_update_backward_as_the_first_stage_of_the_backward_chain_gives_the_
     monkeypatch.setattr(made, 'made_chain', lambda x, *a, **k: (calls.append(k.get('stage') is not None), inner(x, *a, **k))[1])
     for with_ld in (True, False):
         res = []
-        for on in (False, True):
+        for on, per_launch in ((False, 1), (True, 1), (True, 2), (True, 6)):
             calls.clear()
             monkeypatch.setattr(made, 'MADE_CHAIN_IAFB', on)
+            monkeypatch.setattr(made, 'MADE_CHAIN_PASSES', per_launch)
             torch.manual_seed(3)
             m = MADE(d, hidden, n_hidden).cuda()
             with ops.gemm_precision('bf16'):
@@ -774,11 +777,15 @@ def test_iaf_update_backward_as_the_first_stage_of_the_backward_chain_gives_the_
                 (x.sin().sum() + ((ld * ld).sum() if with_ld else 0.0)).backward()
             torch.cuda.synchronize()
             assert any(calls) == on, 'the node did not take the expected backward form'
+            if on:      # P = n_hidden + 3 index sets: P - 1 passes in groups of per_launch, per row block
+                groups = -(-(n_hidden + 2) // per_launch)
+                assert sum(calls) == groups * len(made._made_row_blocks(n)), (sum(calls), groups)
             res.append((x.detach().clone(), ld.detach().clone(), zz.grad.clone(), [p.grad.detach().clone() for p in m.parameters()]))
-        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
         assert float(res[0][2].abs().max()) > 0
-        for a, b in zip(res[0][3], res[1][3]):
-            assert torch.equal(a, b)
+        for other in res[1:]:
+            assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1]) and torch.equal(res[0][2], other[2])
+            for a, b in zip(res[0][3], other[3]):
+                assert torch.equal(a, b)
 
 
 @pytest.mark.gpu
