@@ -48,7 +48,8 @@ struct ChainArgs {
     int ldx, m, n_layers, ldk, has_mask;
     int32_t* stamps;             // gv_made_chain_debug_stamps: s_memtime stamps of workgroup 0 (probes only), NULL otherwise
     gv_chain_iafb ib;            // ib.gx != NULL: layer 0's input is made in the prologue (the IAF update's backward), x unused
-    int ib_lds_off;              // floats from the bias block to the stage's 2 x 64 x IB_LD transposition block
+    int ib_lds_off;              // floats from the bias block to the stage's 2 x IB_COLS x IB_LD transposition block
+    int ld0;                     // IB: row stride of layer 0's input tile (== ldk, or wider: the tile then spans both activation buffers)
     int n_passes;                // IB: passes of a MADE's backward in this launch (pass[q]: what differs from pass to pass)
     gv_chain_layer L[CH_L];
     struct Pass {
@@ -679,42 +680,40 @@ __device__ __forceinline__ void chain_store(const gv_chain_layer& Ly, const uint
 // layer's weight gradient) leaves through a [column][row] LDS block of 64 columns at a time, g_z is added in place.  Four column
 // blocks per 200-wide row; the next block's operands are requested before the current one leaves.
 constexpr int IB_LD = 68;      // rows of the transposition block, padded (8-B reads of four rows, conflict-free 2-B writes)
+constexpr int IB_COLS = 32;    // its columns (g_mu and g_alpha each: 2 x 32 x 68 x 2 B = 8.5 KB -- with 64 the backward chain of a 200-wide MADE
+                               // would not fit twice into a CU's LDS)
 __device__ __forceinline__ void chain_stage_iafb(uint16_t* tile, int ldk, uint16_t* tmx, const gv_chain_iafb& ib, int m0, int m,
                                                  const float* ex_q, const float* gx_q, const float* gld_q, const int32_t* cc_q,
                                                  uint16_t* gnt_q, int flags_q) {
-    const int d = ib.d, nblk = (d + 63) >> 6;
+    const int d = ib.d, nblk = (d + IB_COLS - 1) / IB_COLS;
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));      // opaque: inside the pass loop everything derived from it would be hoisted and held across the unit loop
-    uint16_t (*tm)[IB_LD] = reinterpret_cast<uint16_t (*)[IB_LD]>(tmx);                 // [64 columns][rows]: g_mu
-    uint16_t (*ta)[IB_LD] = reinterpret_cast<uint16_t (*)[IB_LD]>(tmx + 64 * IB_LD);    // g_alpha
-    // a block is 64 rows x 16 pieces of four columns = 1 024 pieces: two per thread (piece j of thread t: rows t / 16 and 32 + t / 16)
-    const int cq = (t & 15) << 2, rr0 = t >> 4;
-    struct Ops { float4 g[2], e[2], z[2], a[2]; int4 cn; };
-    // pinned (scalar) bases + ONE 32-bit byte offset per row: 64-bit per-lane addresses of four arrays x two rows were what spilled
+    uint16_t (*tm)[IB_LD] = reinterpret_cast<uint16_t (*)[IB_LD]>(tmx);                      // [32 columns][rows]: g_mu
+    uint16_t (*ta)[IB_LD] = reinterpret_cast<uint16_t (*)[IB_LD]>(tmx + IB_COLS * IB_LD);    // g_alpha
+    // a block is 64 rows x 8 pieces of four columns = 512 pieces: one per thread
+    const int cq = (t & 7) << 2, rr = t >> 3, r = m0 + rr;
+    struct Ops { float4 g, e, z, a; int4 cn; };
+    // pinned (scalar) bases + ONE 32-bit byte offset: 64-bit per-lane addresses of four arrays were what spilled
     const float* const gx_p = chain_pin_here(gx_q);
     const float* const ex_p = chain_pin_here(ex_q);
     const float* const z_p = chain_pin_here(ib.z);
     float* const gz_p = chain_pin_here(ib.gz);
     const int ld = chain_pin_here(ib.ld), fl = chain_pin_here(flags_q);
-    const unsigned off0 = (unsigned)((m0 + rr0) * ld + cq) * 4u, off1 = (unsigned)((m0 + rr0 + 32) * ld + cq) * 4u;
+    const unsigned off0 = (unsigned)(r * ld + cq) * 4u;
     auto at = [](const float* base, unsigned byte_off) { return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off); };
     auto request = [&](int blk, Ops& o) {
-        const int c = blk * 64 + cq;
+        const int c = blk * IB_COLS + cq;
         o.cn = make_int4(0, 0, 0, 0);
         if (c < d) o.cn = *reinterpret_cast<const int4*>(cc_q + c);
         const bool any = o.cn.x > 0 || o.cn.y > 0 || o.cn.z > 0 || o.cn.w > 0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = m0 + rr0 + 32 * j;
-            const unsigned e = (j ? off1 : off0) + (unsigned)blk * 256u;
-            o.g[j] = o.e[j] = o.z[j] = o.a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < m && c < d) {
-                o.g[j] = *at(gx_p, e);
-                if (!(fl & 1)) o.a[j] = *at(gz_p, e);
-                if (any) {
-                    o.z[j] = *at(z_p, e);
-                    o.e[j] = *at(ex_p, e);
-                }
+        const unsigned e = off0 + (unsigned)blk * (IB_COLS * 4u);
+        o.g = o.e = o.z = o.a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < m && c < d) {
+            o.g = *at(gx_p, e);
+            if (!(fl & 1)) o.a = *at(gz_p, e);
+            if (any) {
+                o.z = *at(z_p, e);
+                o.e = *at(ex_p, e);
             }
         }
     };
@@ -722,13 +721,11 @@ __device__ __forceinline__ void chain_stage_iafb(uint16_t* tile, int ldk, uint16
     request(0, cur);
     for (int blk = 0; blk < nblk; ++blk) {
         if (blk + 1 < nblk) request(blk + 1, nxt);      // the next block's operands fly under this block's arithmetic and way out
-        const int c = blk * 64 + cq;
+        const int c = blk * IB_COLS + cq;
         const int cn[4] = {cur.cn.x, cur.cn.y, cur.cn.z, cur.cn.w};
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int rr = rr0 + 32 * j, r = m0 + rr;
-            const float gv[4] = {cur.g[j].x, cur.g[j].y, cur.g[j].z, cur.g[j].w}, zv[4] = {cur.z[j].x, cur.z[j].y, cur.z[j].z, cur.z[j].w},
-                        ev[4] = {cur.e[j].x, cur.e[j].y, cur.e[j].z, cur.e[j].w};
+        {
+            const float gv[4] = {cur.g.x, cur.g.y, cur.g.z, cur.g.w}, zv[4] = {cur.z.x, cur.z.y, cur.z.z, cur.z.w},
+                        ev[4] = {cur.e.x, cur.e.y, cur.e.z, cur.e.w};
             uint16_t bm[4] = {0, 0, 0, 0}, ba[4] = {0, 0, 0, 0};
             if (r < m && c < d) {
                 const float gl = gld_q ? gld_q[r] : 0.f;
@@ -746,9 +743,9 @@ __device__ __forceinline__ void chain_stage_iafb(uint16_t* tile, int ldk, uint16
                     bm[q] = bf_bits(g_mu);
                     ba[q] = bf_bits(g_al);
                 }
-                float4 acc4 = cur.a[j];
+                float4 acc4 = cur.a;
                 acc4.x += gz[0]; acc4.y += gz[1]; acc4.z += gz[2]; acc4.w += gz[3];
-                *reinterpret_cast<float4*>(reinterpret_cast<char*>(gz_p) + (j ? off1 : off0) + (unsigned)blk * 256u) = acc4;
+                *reinterpret_cast<float4*>(reinterpret_cast<char*>(gz_p) + off0 + (unsigned)blk * (IB_COLS * 4u)) = acc4;
             }
             if (c < d) {      // layer 0's input row: [g_mu | g_alpha] (rows past m: zeros)
                 *reinterpret_cast<uint2*>(tile + rr * ldk + c) = make_uint2(bm[0] | ((uint32_t)bm[1] << 16), bm[2] | ((uint32_t)bm[3] << 16));
@@ -764,11 +761,11 @@ __device__ __forceinline__ void chain_stage_iafb(uint16_t* tile, int ldk, uint16
         // the block's transposed copies: four consecutive rows of a column per 8-B store (16 lanes = 128 contiguous bytes); the whole
         // 64-row tile is written (zeros in the rows past m: they take part in the weight-gradient reduction)
         uint16_t* const gt = gnt_q + (size_t)blockIdx.x * ib.t_tile;
-        for (int i = t; i < 2 * 64 * 16; i += CH_THREADS) {
-            const int half = i >> 10, cc = (i >> 4) & 63, rq = (i & 15) << 2;
-            if (blk * 64 + cc >= d) continue;
+        for (int i = t; i < 2 * IB_COLS * 16; i += CH_THREADS) {
+            const int half = i / (IB_COLS * 16), cc = (i >> 4) & (IB_COLS - 1), rq = (i & 15) << 2;
+            if (blk * IB_COLS + cc >= d) continue;
             const uint2 v = *reinterpret_cast<const uint2*>(half ? &ta[cc][rq] : &tm[cc][rq]);
-            *reinterpret_cast<uint2*>(gt + (size_t)(half * d + blk * 64 + cc) * 64 + rq) = v;
+            *reinterpret_cast<uint2*>(gt + (size_t)(half * d + blk * IB_COLS + cc) * 64 + rq) = v;
         }
         __syncthreads();
         if (blk + 1 < nblk) cur = nxt;
@@ -800,6 +797,13 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     int r = lane & 31, h = lane >> 5, tid = threadIdx.x;
     const bool mma_wave = wave < CH_MMA_WAVES;
+    // IB, layer 0's 2 d-wide input tile at its own row stride, laid over BOTH activation buffers (the others are sized for the
+    // hidden widths: 134 -> 76 KB of LDS for a 200-wide MADE, two workgroups per CU): layer 0's output then lands on columns its
+    // input still holds -- one more barrier, between the layer's last MFMA and its epilogues (every wave has at most one tile of
+    // it: host-checked)
+    const int ld0 = IB ? p.ld0 : ldk;
+    const bool wide0 = IB && p.ld0 != p.ldk;
+    const bool l0_unit = mma_wave && wave < chain_tiles(p.L[0]);
     int ts_n = 0;
     auto stamp = [&]() {
         if (p.stamps && blockIdx.x == 0 && ts_n < 64) {
@@ -889,7 +893,7 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             asm volatile("" : "+v"(lane));
             tid = lane | (wave << 6); r = lane & 31; h = lane >> 5;
             const ChainArgs::Pass& pq = p.pass[q];
-            chain_stage_iafb(chain_lds, ldk, reinterpret_cast<uint16_t*>(bias_lds + p.ib_lds_off), p.ib, m0, p.m, pq.ex, pq.gx, pq.gld, pq.cc,
+            chain_stage_iafb(chain_lds, ld0, reinterpret_cast<uint16_t*>(bias_lds + p.ib_lds_off), p.ib, m0, p.m, pq.ex, pq.gx, pq.gld, pq.cc,
                              pq.gnt, pq.flags);
         }
         if (q > 0) {              // this wave's first unit again
@@ -925,6 +929,7 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     // fp32 output of the epilogue acknowledged, the next unit's 13 weight fragments landed -- a microsecond per layer and tile
 #define CHAIN_CROSS(target)                                                                                              \
     while (layer < (target)) {                                                                                          \
+        if (IB && wide0 && layer == 0 && !l0_unit) chain_barrier();      /* (the barrier in front of layer 0's epilogues) */ \
         chain_barrier();                                                                                                \
         if (FULL && layer + 1 < nl && (p.L[layer + 1].mask || p.L[layer + 1].mask_t)) {                                 \
             chain_stage_mask(mbuf, ldk, p.L[layer + 1], m0, p.m);                                                       \
@@ -961,7 +966,8 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         const uint16_t* A = chain_lds + (u.l & 1) * CH_BM * ldk;                                                        \
         int ra = r, ha = h;        /* opaque: a hoisted fragment address is one more register held across the whole loop */ \
         asm volatile("" : "+v"(ra), "+v"(ha));                                                                          \
-        chain_mma(acc, Q, A + ra * ldk + 8 * ha + u.ch * CH_KS * 16, 32 * ldk, min(CH_KS, ks - u.ch * CH_KS));          \
+        const int lda = (IB && u.l == 0) ? ld0 : ldk;                                                                   \
+        chain_mma(acc, Q, A + ra * lda + 8 * ha + u.ch * CH_KS * 16, 32 * lda, min(CH_KS, ks - u.ch * CH_KS));          \
         stamp();                                                                                                        \
         const bool iaf_unit = Ly.iaf_z && u.ch + 1 == nch;                                                              \
         if (iaf_unit) {                                                                                                 \
@@ -986,6 +992,7 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                                reinterpret_cast<const int*>(bias_lds + bias_total), r, h);                              \
         }                                                                                                               \
         if (!(GV_CHAIN_ABL & 2048)) chain_issue(Q, nb0, noff, nksc);                                                    \
+        if (IB && wide0 && u.l == 0 && u.ch + 1 == nch) chain_barrier();                                                \
         if (IB && u.ch + 1 == nch) {                                                                                    \
             /* backward chain behind the IAF-backward stage: hidden layers on the fast epilogue also in the last, partial tile (its  \
                rows past m hold zeros from the stage on: no bias, the mask bits of such rows are 0 -- zeros go into the tile's pad    \
@@ -1268,7 +1275,14 @@ static int made_chain_launch(const uint16_t* x, int ldx, int m, int n_layers, co
         p.L[i] = L;
     }
     bool has_mask;
-    const int ldk = chain_ldk(n_layers, layers, &has_mask);
+    int ldk = chain_ldk(n_layers, layers, &has_mask), ld0 = ldk;
+    if (stage && n_layers >= 2) {
+        // the stage's 2 d-wide tile over both activation buffers when the layers behind it are narrower (GV_CHAIN_WIDE0=0: off)
+        static const bool wide_on = !(getenv("GV_CHAIN_WIDE0") && getenv("GV_CHAIN_WIDE0")[0] == '0');
+        bool hm;
+        const int ldn = chain_ldk(n_layers - 1, layers + 1, &hm);
+        if (wide_on && ldn < ldk && CH_BM * ldk <= 2 * CH_BM * ldn && (layers[0].n + 31) / 32 <= CH_MMA_WAVES) ldk = ldn;
+    }
     size_t bias_floats = 0;
     for (int i = 0; i < n_layers; ++i) bias_floats += (size_t)layers[i].n;
     if (layers[n_layers - 1].iaf_z) bias_floats += (size_t)layers[n_layers - 1].n / 2;      // its column counts
@@ -1277,10 +1291,11 @@ static int made_chain_launch(const uint16_t* x, int ldx, int m, int n_layers, co
         if (layers[i].mask_bits) bias_floats += (size_t)CH_BM * ((layers[i].n + 31) / 32);      // its bit tile
     bias_floats = (bias_floats + 1) & ~(size_t)1;      // (the stage's block is read in 8-B pieces)
     const size_t lds = (size_t)(has_mask ? 3 : 2) * CH_BM * ldk * sizeof(uint16_t) + bias_floats * sizeof(float) +
-                       (stage ? (size_t)2 * 64 * IB_LD * sizeof(uint16_t) : 0);
+                       (stage ? (size_t)2 * IB_COLS * IB_LD * sizeof(uint16_t) : 0);
     GV_REQUIRE(lds <= 160 * 1024, GV_ERR_SHAPE, "gv_made_chain: layers this wide need %zu B of LDS (160 KB per CU)", lds);
     p.x = x; p.ldx = ldx; p.m = m; p.n_layers = n_layers; p.ldk = ldk; p.has_mask = has_mask ? 1 : 0; p.stamps = g_chain_stamps;
     p.ib_lds_off = (int)bias_floats;
+    p.ld0 = ld0;
     p.n_passes = 1;
     for (int q = 0; q < CH_MAX_PASSES; ++q) p.pass[q] = ChainArgs::Pass{};
     if (stage) {
