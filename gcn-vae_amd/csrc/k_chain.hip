@@ -57,6 +57,10 @@ struct ChainArgs {
         int32_t flags, pad;
         const uint32_t* bits[CH_L];
         uint16_t* out_t[CH_L];
+        // the FORWARD passes launch (gv_made_chain_fwd) reads the same table: gx = x_old, of = x_new, add = alpha, cc = the pass's column
+        // counts, gnt = x_new's tiled transposed copy, bits / out_t = the hidden layers' sign words and tiled copies (outputs), and
+        const int32_t* keep;     // ... the next pass's column counts (x_new is stored where one of them is 0)
+        uint16_t* ob;            // ... x_new as row-major bf16 in memory (NULL: it only stays in LDS, as the next pass's input)
     } pass[CH_MAX_PASSES];
 };
 
@@ -381,9 +385,12 @@ __device__ __forceinline__ void chain_epilogue_last(const f32x16_t (&acc)[2], in
 // lane's address into the tile is ONE 32-bit offset computed once per kernel (voff = 4 h * 64 + r), every one of the 32
 // transposed stores is base (scalar) + voff + an immediate, nothing is predicated per lane, and the layer's fields arrive as
 // values.  bits_row: this lane's row of ReLU mask words (backward layers), or nullptr.
+// PRED (the forward passes launch, whose last workgroup may hold fewer than 64 rows): rows past m leave as zeros -- LDS tile, tiled
+// copy, sign bits -- and their sign words are not stored
+template <bool PRED = false>
 __device__ __forceinline__ void chain_epilogue_fast(const f32x16_t (&acc)[2], int n, int tile, int relu, uint16_t* An, int ldk, int kp_next,
                                                     const float* bias_l, const uint32_t* bits_l, int nt_bits, uint16_t* tbase,
-                                                    uint32_t* obits, int ldbits, int r, int h) {
+                                                    uint32_t* obits, int ldbits, int r, int h, int last_row = CH_BM - 1) {
     asm volatile("" : "+v"(r), "+v"(h));
     uint32_t sb[2] = {0u, 0u};          // the signs of the lane's 16 columns of rows r / 32 + r, at their bit positions in the tile's word
     const unsigned voff = (unsigned)(4 * h * 64 + r);
@@ -392,6 +399,10 @@ __device__ __forceinline__ void chain_epilogue_fast(const f32x16_t (&acc)[2], in
     if (bits_l) {
         w0 = bits_l[r * nt_bits + tile] >> (4 * h);
         w1 = bits_l[(32 + r) * nt_bits + tile] >> (4 * h);
+    }
+    if (PRED) {
+        if (r > last_row) w0 = 0u;
+        if (32 + r > last_row) w1 = 0u;
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -436,8 +447,8 @@ __device__ __forceinline__ void chain_epilogue_fast(const f32x16_t (&acc)[2], in
         const int partner = (int)(((threadIdx.x & 63) ^ 32) << 2);
         const uint32_t o0 = (uint32_t)__builtin_amdgcn_ds_bpermute(partner, (int)sb[0]), o1 = (uint32_t)__builtin_amdgcn_ds_bpermute(partner, (int)sb[1]);
         if (h == 0) {
-            obits[(size_t)r * ldbits + tile] = sb[0] | o0;
-            obits[(size_t)(32 + r) * ldbits + tile] = sb[1] | o1;
+            if (!PRED || r <= last_row) obits[(size_t)r * ldbits + tile] = sb[0] | o0;
+            if (!PRED || 32 + r <= last_row) obits[(size_t)(32 + r) * ldbits + tile] = sb[1] | o1;
         }
     }
 }
@@ -544,11 +555,16 @@ struct ChainIafPins {
     const float* z; const float* x_old; float* x_new; float* ex; float* alpha; const int* keep; uint16_t* tbase;
     int ld, d, has_bias, identity;
 };
+// PRED: the workgroup may hold fewer than 64 rows (last_row = its last one): loads of the rows past it read row last_row, their
+// stores are skipped, their bf16 copies (LDS tile, tiled transposed copy) are zeros
+template <bool PRED = false>
 __device__ __forceinline__ void chain_epilogue_iaf_fast(const f32x16_t (&acc)[2], const ChainIafPins& P, int tile, uint16_t* An, int ldk,
-                                                        int kp_next, const float* bias_l, const int* cnt_lds, int r, int h) {
+                                                        int kp_next, const float* bias_l, const int* cnt_lds, int r, int h, int last_row = CH_BM - 1) {
     asm volatile("" : "+v"(r), "+v"(h));
     const int d = P.d, cu = tile * 16;                       // first mu column of the tile
-    const unsigned vo[2] = {(unsigned)(r * P.ld + 4 * h), (unsigned)((32 + r) * P.ld + 4 * h)};
+    const bool live[2] = {!PRED || r <= last_row, !PRED || 32 + r <= last_row};
+    const unsigned vo[2] = {(unsigned)((PRED ? min(r, last_row) : r) * P.ld + 4 * h),
+                            (unsigned)((PRED ? min(32 + r, last_row) : 32 + r) * P.ld + 4 * h)};
     const unsigned voff_t = (unsigned)(4 * h * 64 + r);
     // z of the lane's four (group, row) pairs first, then x_old where a column is handed through: loads and stores share one
     // in-order counter, a load issued behind the epilogue's stores waits for every one of them
@@ -600,9 +616,9 @@ __device__ __forceinline__ void chain_epilogue_iaf_fast(const f32x16_t (&acc)[2]
             v.x += ba.x; v.y += ba.y; v.z += ba.z; v.w += ba.w;
             s.x += bm.x; s.y += bm.y; s.z += bm.z; s.w += bm.w;
             const unsigned e = vo[mt] + (unsigned)(cu + 8 * g);
-            if (P.alpha) *reinterpret_cast<float4*>(P.alpha + e) = v;
+            if (P.alpha && live[mt]) *reinterpret_cast<float4*>(P.alpha + e) = v;
             v.x = expf(v.x + s.x); v.y = expf(v.y + s.y); v.z = expf(v.z + s.z); v.w = expf(v.w + s.w);
-            if (P.ex) *reinterpret_cast<float4*>(P.ex + e) = v;
+            if (P.ex && live[mt]) *reinterpret_cast<float4*>(P.ex + e) = v;
             s = zp[2 * g + mt];
             v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
             s = xo[2 * g + mt];
@@ -610,8 +626,9 @@ __device__ __forceinline__ void chain_epilogue_iaf_fast(const f32x16_t (&acc)[2]
             if (cn[g].y <= 0) v.y = s.y;
             if (cn[g].z <= 0) v.z = s.z;
             if (cn[g].w <= 0) v.w = s.w;
-            if (P.x_new && keep[g]) *reinterpret_cast<float4*>(P.x_new + e) = v;
-            const uint16_t b0 = bf_bits(v.x), b1 = bf_bits(v.y), b2 = bf_bits(v.z), b3 = bf_bits(v.w);
+            if (P.x_new && keep[g] && live[mt]) *reinterpret_cast<float4*>(P.x_new + e) = v;
+            uint16_t b0 = bf_bits(v.x), b1 = bf_bits(v.y), b2 = bf_bits(v.z), b3 = bf_bits(v.w);
+            if (PRED && !live[mt]) b0 = b1 = b2 = b3 = 0;
             if (cu + 8 * g < kp_next)
                 *reinterpret_cast<uint2*>(An + (mt * 32 + r) * ldk + cu + 8 * g + 4 * h) = make_uint2(b0 | ((uint32_t)b1 << 16), b2 | ((uint32_t)b3 << 16));
             if (P.tbase) {
@@ -628,6 +645,7 @@ __device__ __forceinline__ void chain_epilogue_iaf_fast(const f32x16_t (&acc)[2]
 
 // store wave: the row-major bf16 copy of a layer's result out of its LDS tile, 16-B pieces, reads issued in batches of 8.
 // (row, piece) advance incrementally: an integer division per piece would cost this single wave more than the copy itself
+__device__ __forceinline__ void chain_store_rows(uint16_t* out, int ldb, int ppr, const uint16_t* An, int ldk, int m0, int m, int ts);
 template <bool FULL>
 __device__ __forceinline__ void chain_store(const gv_chain_layer& Ly, const uint16_t* An, int ldk, int m0, int m, int ts, bool bits_done) {
     if (!FULL && Ly.out_bits && !bits_done) {       // sign bits of the layer's (bf16-rounded) result, word [row][tile of 32 columns], out of the finished tile
@@ -650,7 +668,10 @@ __device__ __forceinline__ void chain_store(const gv_chain_layer& Ly, const uint
         }
     }
     if (!Ly.out_bf16) return;
-    const int ppr = (Ly.iaf_z ? Ly.n >> 1 : Ly.n) >> 3, total = CH_BM * ppr;      // an IAF layer's tile holds x_new: d columns
+    chain_store_rows(Ly.out_bf16, Ly.ldb, (Ly.iaf_z ? Ly.n >> 1 : Ly.n) >> 3, An, ldk, m0, m, ts);      // an IAF layer's tile holds x_new: d columns
+}
+__device__ __forceinline__ void chain_store_rows(uint16_t* out, int ldb, int ppr, const uint16_t* An, int ldk, int m0, int m, int ts) {
+    const int total = CH_BM * ppr;
     const int drow = CH_STORE_THREADS / ppr, dpc = CH_STORE_THREADS - drow * ppr;      // one step of 64 pieces
     int row = ts / ppr, pc = ts - row * ppr;
     for (int base = 0; base < total; base += CH_STORE_THREADS * 8) {
@@ -668,7 +689,7 @@ __device__ __forceinline__ void chain_store(const gv_chain_layer& Ly, const uint
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (rw[j] < CH_BM && m0 + rw[j] < m) *reinterpret_cast<uint4*>(Ly.out_bf16 + (size_t)(m0 + rw[j]) * Ly.ldb + kk[j]) = v[j];
+            if (rw[j] < CH_BM && m0 + rw[j] < m) *reinterpret_cast<uint4*>(out + (size_t)(m0 + rw[j]) * ldb + kk[j]) = v[j];
     }
 }
 
@@ -787,8 +808,10 @@ __device__ __forceinline__ void chain_stage_iafb(uint16_t* tile, int ldk, uint16
 // two unit bodies with fixed set roles) measured the same at 228 tiles and cost 52 registers.
 // FULL = false: the instance for chains without tile masks (mask / mask_t) and without an accumulating fp32 output -- every
 // MADE pass of the fused path; without that code it keeps clear of the 128-register limit (the full instance spills ~30 B)
-template <bool FULL, bool IB = false>
-__global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_made_chain(const ChainArgs p) {
+// FW: the forward passes launch (gv_made_chain_fwd): ALL passes of a MADE's forward; p.pass[q] holds pass q's outputs and IAF operands,
+// pass q's x_new stays in LDS as pass q + 1's input (the buffer roles swap from pass to pass when the layer count is odd)
+template <bool FULL, bool IB, bool FW>
+__device__ __forceinline__ void chain_body(const ChainArgs& p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t chain_lds[];
     const int ldk = p.ldk, nl = p.n_layers, m0 = blockIdx.x * CH_BM;
     uint16_t* mbuf = chain_lds + 2 * CH_BM * ldk;
@@ -833,7 +856,8 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         }
         first_b = b0; first_off = off; first_ksc = ksc;
         // (the IAF-backward instance requests them behind its stage: the stage's two operand sets need the registers)
-        if constexpr (!IB) chain_issue(qa, b0, off, ksc);
+        // (... and the forward passes launch at the head of every pass)
+        if constexpr (!IB && !FW) chain_issue(qa, b0, off, ksc);
     }
     int bias_total = 0, bits_base = 0;
     {       // every layer's bias into LDS (all loads in flight together): no global round trip in an epilogue
@@ -853,7 +877,7 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         bias_total = off;
         const gv_chain_layer& Ll = p.L[nl - 1];      // an IAF layer's column counts behind the biases
         if (Ll.iaf_z && (int)threadIdx.x < (Ll.n >> 1))
-            reinterpret_cast<int*>(bias_lds + off)[threadIdx.x] = Ll.iaf_colcount[threadIdx.x];
+            reinterpret_cast<int*>(bias_lds + off)[threadIdx.x] = (FW ? p.pass[0].cc : Ll.iaf_colcount)[threadIdx.x];
         else if (Ll.add_src && (int)threadIdx.x < Ll.n)
             reinterpret_cast<int*>(bias_lds + off)[threadIdx.x] = Ll.add_colcount[threadIdx.x];
         off += Ll.iaf_z ? Ll.n >> 1 : (Ll.add_src ? Ll.n : 0);
@@ -884,9 +908,26 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     }
     // IB: ALL passes of a MADE's backward in this launch (p.n_passes; p.pass[q] holds what differs from pass to pass: pass q's
     // dL/dx_new is pass q - 1's fp32 output).  A workgroup keeps its 64 rows through the passes: every step of a pass is row-local.
-    int q = 0;
+    int q = 0, par = 0;          // par (FW): the buffer that holds layer 0's input of this pass
+    const int last_row = min(CH_BM, p.m - m0) - 1;
   next_pass:
-    if constexpr (IB) {           // the IAF update's backward makes layer 0's input here (its block buffer sits behind the bit tiles)
+    if constexpr (FW) {
+        asm volatile("" : "+v"(lane));      // (per pass from an opaque copy, as below)
+        tid = lane | (wave << 6); r = lane & 31; h = lane >> 5;
+        if (q > 0) {              // x_new of the pass before is in LDS already; this wave's first unit again
+            u = {nl, wave, 0};
+            first_b = any_b; first_off = lane; first_ksc = 1;
+            if (mma_wave) {
+                u.l = 0;
+                while (u.l < nl && chain_first_tile(p.L[u.l], wave) >= chain_tiles(p.L[u.l])) ++u.l;
+                if (u.l < nl) u.tile = chain_first_tile(p.L[u.l], wave);
+                if (u.l < nl) chain_unit_b(p, u, lane, first_b, first_off, first_ksc);
+            }
+        } else {
+            chain_stage(chain_lds, ldk, p.x, p.ldx, m0, p.m, p.L[0].k, (p.L[0].k + 15) & ~15);
+        }
+        chain_issue(qa, first_b, first_off, first_ksc);
+    } else if constexpr (IB) {           // the IAF update's backward makes layer 0's input here (its block buffer sits behind the bit tiles)
         {
             // per pass again, from an opaque copy: what derives from the thread index is otherwise computed once in front of the
             // pass loop and held across it, on top of what the unit loop holds
@@ -919,7 +960,7 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 
     f32x16_t acc[2];
     int layer = 0, bias_off = 0, bits_off = 0;
-    if (IB) {       // defined here: nothing of the previous pass's accumulators is carried around the pass loop and through the stage
+    if (IB || FW) { // defined here: nothing of the previous pass's accumulators is carried around the pass loop and through the stage
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
     }
@@ -935,6 +976,11 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             chain_stage_mask(mbuf, ldk, p.L[layer + 1], m0, p.m);                                                       \
             __syncthreads();                                                                                            \
         }                                                                                                               \
+        if (FW) {        /* hidden layers leave through their epilogues alone; x_new's row-major copy where the pass wants one */ \
+            if (!mma_wave && layer + 1 == nl && p.pass[q].ob)                                                            \
+                chain_store_rows(p.pass[q].ob, p.L[layer].ldb, p.L[layer].n >> 4, chain_lds + ((layer + 1 + par) & 1) * CH_BM * ldk, ldk, \
+                                 m0, p.m, tid - CH_MMA_THREADS);                                                        \
+        } else                                                                                                          \
         if (!mma_wave && (layer + 1 < nl || p.L[layer].iaf_z))                                                          \
             chain_store<FULL>(p.L[layer], chain_lds + ((layer + 1) & 1) * CH_BM * ldk, ldk, m0, p.m, tid - CH_MMA_THREADS, \
                               !FULL && GV_CHAIN_FAST_EPILOGUE && layer + 1 < nl && m0 + CH_BM <= p.m && p.L[layer].out_bf16_t && \
@@ -942,7 +988,7 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         bias_off += p.L[layer].n;                                                                                       \
         bits_off += p.L[layer].mask_bits ? CH_BM * ((p.L[layer].n + 31) >> 5) : 0;                                      \
         ++layer;                                                                                                        \
-        if (IB) { /* a unit behind a boundary starts at chunk 0: said here, the accumulators are dead across the boundary */ \
+        if (IB || FW) { /* a unit behind a boundary starts at chunk 0: said here, the accumulators are dead across the boundary */ \
             _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;                                 \
         }                                                                                                               \
     }
@@ -963,13 +1009,28 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         if (u.ch == 0) {                                                                                                \
             _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;                                 \
         }                                                                                                               \
-        const uint16_t* A = chain_lds + (u.l & 1) * CH_BM * ldk;                                                        \
+        const uint16_t* A = chain_lds + ((u.l + (FW ? par : 0)) & 1) * CH_BM * ldk;                                     \
+        uint16_t* const An = chain_lds + ((u.l + 1 + (FW ? par : 0)) & 1) * CH_BM * ldk;                                \
         int ra = r, ha = h;        /* opaque: a hoisted fragment address is one more register held across the whole loop */ \
         asm volatile("" : "+v"(ra), "+v"(ha));                                                                          \
         const int lda = (IB && u.l == 0) ? ld0 : ldk;                                                                   \
         chain_mma(acc, Q, A + ra * lda + 8 * ha + u.ch * CH_KS * 16, 32 * lda, min(CH_KS, ks - u.ch * CH_KS));          \
         stamp();                                                                                                        \
-        const bool iaf_unit = Ly.iaf_z && u.ch + 1 == nch;                                                              \
+        const bool iaf_unit = !FW && Ly.iaf_z && u.ch + 1 == nch;                                                       \
+        if (FW && u.ch + 1 == nch && u.l + 1 == nl) {      /* the IAF update with this pass's operands */               \
+            const ChainArgs::Pass& pq = p.pass[q];                                                                      \
+            ChainIafPins P;                                                                                             \
+            P.ld = chain_pin(Ly.iaf_ld); P.d = chain_pin(Ly.n) >> 1; P.has_bias = Ly.bias ? 1 : 0; P.identity = 0;      \
+            const size_t row0 = (size_t)m0 * P.ld;                                                                      \
+            P.z = chain_pin_ptr(Ly.iaf_z) + row0; P.x_old = chain_pin_ptr(pq.gx) + row0;                                \
+            P.x_new = pq.of ? chain_pin_ptr(pq.of) + row0 : nullptr;                                                    \
+            P.ex = pq.ex ? chain_pin_ptr(const_cast<float*>(pq.ex)) + row0 : nullptr;                                   \
+            P.alpha = pq.add ? chain_pin_ptr(const_cast<float*>(pq.add)) + row0 : nullptr;                              \
+            P.keep = pq.keep ? chain_pin_ptr(pq.keep) : nullptr;                                                        \
+            P.tbase = pq.gnt ? chain_pin_ptr(pq.gnt) + (size_t)blockIdx.x * chain_pin(Ly.t_tile) : nullptr;            \
+            chain_epilogue_iaf_fast<true>(acc, P, u.tile, An, ldk, (pq.flags & 1) ? (P.d + 15) & ~15 : 0, bias_lds + bias_off, \
+                                          reinterpret_cast<const int*>(bias_lds + bias_total), r, h, last_row);         \
+        }                                                                                                               \
         if (iaf_unit) {                                                                                                 \
             const bool fast_iaf = GV_CHAIN_FAST_EPILOGUE && m0 + CH_BM <= p.m && !Ly.out_f32 && !(Ly.iaf_reserved & ~1) &&  \
                                   (!Ly.out_bf16_t || Ly.t_tile > 0);                                                    \
@@ -993,6 +1054,14 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         }                                                                                                               \
         if (!(GV_CHAIN_ABL & 2048)) chain_issue(Q, nb0, noff, nksc);                                                    \
         if (IB && wide0 && u.l == 0 && u.ch + 1 == nch) chain_barrier();                                                \
+        if (FW) {                                                                                                       \
+            if (u.ch + 1 == nch && u.l + 1 < nl)                                                                        \
+                chain_epilogue_fast<true>(acc, chain_pin(Ly.n), u.tile, chain_pin(Ly.relu), An, ldk, (chain_pin(Ly.n) + 15) & ~15, \
+                                          Ly.bias ? bias_lds + bias_off : nullptr, nullptr, 0,                          \
+                                          chain_pin_ptr(p.pass[q].out_t[u.l]) + (size_t)blockIdx.x * chain_pin(Ly.t_tile), \
+                                          chain_pin_ptr(const_cast<uint32_t*>(p.pass[q].bits[u.l])) + (size_t)m0 * chain_pin(Ly.ldbits), \
+                                          chain_pin(Ly.ldbits), r, h, last_row);                                        \
+        } else                                                                                                          \
         if (IB && u.ch + 1 == nch) {                                                                                    \
             /* backward chain behind the IAF-backward stage: hidden layers on the fast epilogue also in the last, partial tile (its  \
                rows past m hold zeros from the stage on: no bias, the mask bits of such rows are 0 -- zeros go into the tile's pad    \
@@ -1034,6 +1103,16 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         CHAIN_UNIT1(qa)
     }
     stamp();
+    if constexpr (FW) {
+        if (++q < p.n_passes) {
+            __syncthreads();      // (x_new of this pass is the next one's x_old: with the vector-memory counter drained)
+            const gv_chain_layer& Ll = p.L[nl - 1];
+            if (tid < (Ll.n >> 1)) reinterpret_cast<int*>(bias_lds + bias_total)[tid] = p.pass[q].cc[tid];
+            par ^= nl & 1;
+            layer = 0; bias_off = 0; bits_off = 0;
+            goto next_pass;
+        }
+    }
     if constexpr (IB) {
         if (++q < p.n_passes) {
             // every wave is behind the last layer's barrier: the next pass's column counts and mask bits replace this pass's in LDS (the
@@ -1060,6 +1139,14 @@ __global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     }
 #undef CHAIN_CROSS
 #undef CHAIN_UNIT1
+}
+
+template <bool FULL, bool IB = false>
+__global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_made_chain(const ChainArgs p) {
+    chain_body<FULL, IB, false>(p);
+}
+__global__ __launch_bounds__(CH_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_made_chain_fwd(const ChainArgs p) {
+    chain_body<false, false, true>(p);
 }
 
 // packed[(t * ks + s) * 64 + lane][e] = bf16(B[32 t + (lane & 31)][16 s + 8 (lane >> 5) + e]), zero outside B;
@@ -1339,6 +1426,67 @@ static int made_chain_launch(const uint16_t* x, int ldx, int m, int n_layers, co
     else if (full) hipLaunchKernelGGL(k_made_chain<true>, grid, dim3(CH_THREADS), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(k_made_chain<false>, grid, dim3(CH_THREADS), lds, (hipStream_t)stream, p);
     return launch_status("gv_made_chain");
+}
+
+/* ALL passes of a MADE's forward (kgvae/flow_network.py:85-98, the loop over the index sets) in one launch: see include/gcnvae.h */
+extern "C" int gv_made_chain_fwd(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, int n_passes,
+                                 const gv_chain_fwd_pass* passes, void* stream) {
+    GV_REQUIRE(m >= 0 && n_layers >= 2 && n_layers <= GV_CHAIN_MAX_LAYERS && n_passes >= 1 && n_passes <= CH_MAX_PASSES, GV_ERR_SHAPE,
+               "gv_made_chain_fwd: m=%d n_layers=%d n_passes=%d (2-%d layers, 1-%d passes)", m, n_layers, n_passes, GV_CHAIN_MAX_LAYERS, CH_MAX_PASSES);
+    if (m == 0) return GV_OK;
+    GV_REQUIRE(x && layers && passes, GV_ERR_NULL, "gv_made_chain_fwd: NULL pointer");
+    GV_REQUIRE(ldx % 8 == 0 && aligned16(x) && ldx >= layers[0].k, GV_ERR_ALIGN, "gv_made_chain_fwd: x rows must be 16-B aligned pieces (ldx=%d)", ldx);
+    const gv_chain_layer& last = layers[n_layers - 1];
+    const int d = last.n / 2, tiles = (m + CH_BM - 1) / CH_BM;
+    ChainArgs p;
+    for (int i = 0; i < n_layers; ++i) {
+        const gv_chain_layer& L = layers[i];
+        GV_REQUIRE(L.n > 0 && L.k > 0 && L.n % 8 == 0 && L.k % 8 == 0 && L.n <= CH_THREADS && (i == 0 || L.k == layers[i - 1].n), GV_ERR_SHAPE,
+                   "gv_made_chain_fwd: layer %d is %d x %d (widths are multiples of 8, k = the previous layer's n)", i, L.n, L.k);
+        GV_REQUIRE(L.w_packed && aligned16(L.w_packed), GV_ERR_NULL, "gv_made_chain_fwd: layer %d has no packed weight", i);
+        GV_REQUIRE(!L.mask && !L.mask_t && !L.mask_bits && !L.out_f32 && !L.accumulate && !L.add_src && !L.x_dup_half, GV_ERR_SHAPE,
+                   "gv_made_chain_fwd: layer %d: no masks, fp32 outputs or add sources in this launch", i);
+        if (i + 1 < n_layers)
+            GV_REQUIRE(L.relu && !L.iaf_z && L.t_tile >= CH_BM * L.n && (int64_t)L.t_tile * tiles <= INT32_MAX && L.ldbits >= (L.n + 31) / 32,
+                       GV_ERR_SHAPE, "gv_made_chain_fwd: hidden layer %d: ReLU, tiled copies (t_tile=%d >= 64 n), sign words (ldbits=%d)", i,
+                       L.t_tile, L.ldbits);
+        p.L[i] = L;
+    }
+    GV_REQUIRE(last.iaf_z && aligned16(last.iaf_z) && last.n % 16 == 0 && !last.relu && last.iaf_ld >= d && last.iaf_ld % 4 == 0 &&
+                   (int64_t)CH_BM * last.iaf_ld * 4 < (1ll << 31),
+               GV_ERR_SHAPE, "gv_made_chain_fwd: the last layer carries the IAF update: n = 2 d with d %% 8 == 0, z [m][iaf_ld]");
+    GV_REQUIRE(last.iaf_reserved == 0, GV_ERR_SHAPE, "gv_made_chain_fwd: no probe switches");
+    bool has_mask;
+    const int ldk = chain_ldk(n_layers, layers, &has_mask);
+    size_t bias_floats = (size_t)d;
+    for (int i = 0; i < n_layers; ++i) bias_floats += (size_t)layers[i].n;
+    const size_t lds = (size_t)2 * CH_BM * ldk * sizeof(uint16_t) + bias_floats * sizeof(float);
+    GV_REQUIRE(lds <= 160 * 1024, GV_ERR_SHAPE, "gv_made_chain_fwd: layers this wide need %zu B of LDS (160 KB per CU)", lds);
+    p.x = x; p.ldx = ldx; p.m = m; p.n_layers = n_layers; p.ldk = ldk; p.has_mask = 0; p.stamps = g_chain_stamps;
+    p.ib = gv_chain_iafb{}; p.ib_lds_off = (int)bias_floats; p.ld0 = ldk; p.n_passes = n_passes;
+    for (int q = 0; q < CH_MAX_PASSES; ++q) p.pass[q] = ChainArgs::Pass{};
+    for (int q = 0; q < n_passes; ++q) {
+        const gv_chain_fwd_pass& f = passes[q];
+        ChainArgs::Pass& pq = p.pass[q];
+        GV_REQUIRE(f.x_old && f.colcount && f.ex && aligned16(f.x_old) && aligned16(f.colcount) && aligned16(f.ex) &&
+                       (!f.x_new || aligned16(f.x_new)) && (!f.alpha || aligned16(f.alpha)) && (!f.keep_colcount || aligned16(f.keep_colcount)),
+                   GV_ERR_NULL, "gv_made_chain_fwd: pass %d: x_old, colcount, ex (16-B aligned fp32 rows)", q);
+        GV_REQUIRE((!f.out_bf16 || (last.ldb >= d && last.ldb % 8 == 0 && aligned16(f.out_bf16))) &&
+                       (!f.out_bf16_t || (last.t_tile >= CH_BM * d && (int64_t)last.t_tile * tiles <= INT32_MAX)),
+                   GV_ERR_ALIGN, "gv_made_chain_fwd: pass %d: x_new's bf16 copies (ldb=%d, t_tile=%d)", q, last.ldb, last.t_tile);
+        pq.ex = f.ex; pq.gx = f.x_old; pq.cc = f.colcount; pq.gnt = f.out_bf16_t; pq.of = f.x_new; pq.add = f.alpha;
+        pq.keep = f.keep_colcount; pq.ob = f.out_bf16;
+        pq.flags = (q + 1 < n_passes || f.out_bf16) ? 1 : 0;          // x_new into the LDS tile
+        for (int l = 0; l + 1 < n_layers; ++l) {
+            GV_REQUIRE(f.act_t[l] && f.act_bits[l], GV_ERR_NULL, "gv_made_chain_fwd: pass %d: hidden layer %d has no tiled copy / sign words", q, l);
+            pq.out_t[l] = f.act_t[l];
+            pq.bits[l] = reinterpret_cast<const uint32_t*>(f.act_bits[l]);
+        }
+    }
+    static unsigned long long lds_fw = 0;
+    if (!raise_dynamic_lds((const void*)k_made_chain_fwd, 160 * 1024, lds_fw, "gv_made_chain_fwd")) return GV_ERR_SHAPE;
+    hipLaunchKernelGGL(k_made_chain_fwd, dim3((unsigned)tiles), dim3(CH_THREADS), lds, (hipStream_t)stream, p);
+    return launch_status("gv_made_chain_fwd");
 }
 
 /* 1 when gv_made_chain can run this chain (widths; LDS), 0 otherwise -- callers then launch product by product */

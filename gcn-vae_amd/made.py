@@ -444,6 +444,13 @@ class _ChainIafb(_ct.Structure):
                 ('cc_step', _ct.c_int32), ('of_step', _ct.c_int64)]
 
 
+class _ChainFwdPass(_ct.Structure):
+    """gv_chain_fwd_pass of include/gcnvae.h."""
+    _fields_ = [('x_old', _ct.c_void_p), ('x_new', _ct.c_void_p), ('ex', _ct.c_void_p), ('alpha', _ct.c_void_p),
+                ('colcount', _ct.c_void_p), ('keep_colcount', _ct.c_void_p), ('out_bf16', _ct.c_void_p), ('out_bf16_t', _ct.c_void_p),
+                ('act_t', _ct.c_void_p * 8), ('act_bits', _ct.c_void_p * 8)]
+
+
 class _RowLayer(_ct.Structure):
     """gv_row_layer of include/gcnvae.h."""
     _fields_ = [('w', _ct.c_void_p), ('bias', _ct.c_void_p), ('act', _ct.c_void_p), ('inp', _ct.c_void_p), ('out', _ct.c_void_p),
@@ -538,6 +545,45 @@ def made_chain(x, m, layers, tag=None, stage=None):
     passes=dict(n, rows_step, tiles_step, cc_step, of_step) the launch walks n passes whose operands lie those steps apart."""
     if tag is not None and lib.TIMER is not None:
         MADE_CHAIN_FLOPS[tag] = 2.0 * int(m) * sum(int(d['n']) * int(d['k']) for d in layers)
+    arr = _chain_layers(layers)
+    if stage is not None:
+        ts = [stage[k_] for k_ in ('z', 'ex', 'gx', 'gz')]
+        if len({t.stride(0) for t in ts}) != 1:
+            raise ValueError('made_chain: the stage operands share one row stride')
+        sb = _ChainIafb()
+        sb.z, sb.ex, sb.gx, sb.gz = (ptr(t) for t in ts)
+        sb.gld, sb.colcount, sb.gnt = ptr(stage.get('gld')), ptr(stage['colcount']), ptr(stage['gnt'])
+        sb.ld, sb.d, sb.t_tile = ts[0].stride(0), int(ts[0].shape[1]), int(stage['t_tile'])
+        sb.flags = 1 if stage.get('overwrite_gz') else 0
+        ps = stage.get('passes')
+        if ps is not None:
+            sb.n_passes, sb.rows_step, sb.tiles_step = int(ps['n']), int(ps['rows_step']), int(ps['tiles_step'])
+            sb.cc_step, sb.of_step = int(ps['cc_step']), int(ps['of_step'])
+        lib.call('gv_made_chain_iafb', _ct.addressof(sb), int(m), len(layers), _ct.addressof(arr), lib.stream(), tag=tag)
+        return
+    lib.call('gv_made_chain', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), lib.stream(), tag=tag)
+
+
+def made_chain_fwd(x, m, layers, passes, tag=None):
+    """ALL passes of a MADE's forward in one launch (gv_made_chain_fwd).  layers: what made_chain takes for ONE pass (the first
+    pass's dicts: strides and shared fields are read from them); passes: per pass dict(x_old, colcount, ex, x_new=None, alpha=None,
+    keep=None, out_bf16=None, out_bf16_t=None, act_t=[...], act_bits=[...]) -- the pointers that differ from pass to pass."""
+    if tag is not None and lib.TIMER is not None:
+        MADE_CHAIN_FLOPS[tag] = 2.0 * int(m) * len(passes) * sum(int(d['n']) * int(d['k']) for d in layers)
+    arr = _chain_layers(layers)
+    tab = (_ChainFwdPass * len(passes))()
+    for c, d in zip(tab, passes):
+        c.x_old, c.x_new, c.ex, c.alpha = ptr(d['x_old']), ptr(d.get('x_new')), ptr(d['ex']), ptr(d.get('alpha'))
+        c.colcount, c.keep_colcount = ptr(d['colcount']), ptr(d.get('keep'))
+        c.out_bf16, c.out_bf16_t = ptr(d.get('out_bf16')), ptr(d.get('out_bf16_t'))
+        for l, (t, b) in enumerate(zip(d['act_t'], d['act_bits'])):
+            c.act_t[l], c.act_bits[l] = ptr(t), ptr(b)
+    lib.call('gv_made_chain_fwd', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), len(passes), _ct.addressof(tab), lib.stream(),
+             tag=tag)
+
+
+def _chain_layers(layers):
+    """The gv_chain_layer array of made_chain's layer dicts."""
     arr = (_ChainLayer * len(layers))()
     for c, d in zip(arr, layers):
         mask, ob, ot, of = d.get('mask'), d.get('out_bf16'), d.get('out_bf16_t'), d.get('out_f32')
@@ -574,22 +620,7 @@ def made_chain(x, m, layers, tag=None, stage=None):
             if of is None or add[0].stride(0) != of.stride(0):
                 raise ValueError('made_chain: add_src shares the row stride of out_f32')
             c.add_src, c.add_colcount = ptr(add[0]), ptr(add[1])
-    if stage is not None:
-        ts = [stage[k_] for k_ in ('z', 'ex', 'gx', 'gz')]
-        if len({t.stride(0) for t in ts}) != 1:
-            raise ValueError('made_chain: the stage operands share one row stride')
-        sb = _ChainIafb()
-        sb.z, sb.ex, sb.gx, sb.gz = (ptr(t) for t in ts)
-        sb.gld, sb.colcount, sb.gnt = ptr(stage.get('gld')), ptr(stage['colcount']), ptr(stage['gnt'])
-        sb.ld, sb.d, sb.t_tile = ts[0].stride(0), int(ts[0].shape[1]), int(stage['t_tile'])
-        sb.flags = 1 if stage.get('overwrite_gz') else 0
-        ps = stage.get('passes')
-        if ps is not None:
-            sb.n_passes, sb.rows_step, sb.tiles_step = int(ps['n']), int(ps['rows_step']), int(ps['tiles_step'])
-            sb.cc_step, sb.of_step = int(ps['cc_step']), int(ps['of_step'])
-        lib.call('gv_made_chain_iafb', _ct.addressof(sb), int(m), len(layers), _ct.addressof(arr), lib.stream(), tag=tag)
-        return
-    lib.call('gv_made_chain', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), lib.stream(), tag=tag)
+    return arr
 
 
 def gemm_bf16_gradw_tiles(a, a_tile, b, b_tile, m, n, k, c_f32, accumulate=True, a_rowsum=None, split_k=2):
@@ -982,11 +1013,36 @@ class _MADEForwardBF16(torch.autograd.Function):
 
         def fused_passes(r0, r1):
             """Passes 1 .. P-1 for the rows [r0, r1) (r0 a multiple of 64): every launch of a pass is row-local."""
-            for p in range(1, P):
+            todo = list(range(1, P))
+            while todo:
+                p = todo.pop(0)
                 a, b, na, nb_ = (p - 1) * n + r0, (p - 1) * n + r1, p * n + r0, p * n + r1
                 # the pass's IAF update in the last layer's epilogue: x_new and its operand copies leave the chain
                 head = dict(w_packed=wbf[L - 1], n=widths[L - 1], k=ws[L - 1].shape[1], bias=bs[L - 1],
                             iaf=dict(z=z[r0:r1], x_old=xin[a:b], colcount=colcount[p], ex=net_out[a:b]))
+                per_launch = MADE_FWD_PASSES or (6 if len(_made_row_blocks(n)) == 1 else 3)
+                if per_launch > 1 and tiled and L > 1 and d % 8 == 0:
+                    # ... for up to six passes in ONE launch (gv_made_chain_fwd): a workgroup keeps its 64 rows, x_new stays in LDS
+                    # as the next pass's input; its row-major bf16 copy goes to memory only behind the last pass of a launch
+                    grp = [p] + todo[:per_launch - 1]
+                    del todo[:len(grp) - 1]
+                    tab = []
+                    for g in grp:
+                        ga, gb, gna, gnb = (g - 1) * n + r0, (g - 1) * n + r1, g * n + r0, g * n + r1
+                        e = dict(x_old=xin[ga:gb], colcount=colcount[g], ex=net_out[ga:gb],
+                                 act_t=[acts_t[l][(g - 1) * T + r0 // 64:] for l in range(L - 1)],
+                                 act_bits=[sign[l][ga:gb] for l in range(L - 1)])
+                        if g < S:
+                            e.update(x_new=xin[gna:gnb], keep=colcount[g + 1], out_bf16_t=xin_t[g * T + r0 // 64:],
+                                     out_bf16=xin_b[gna:gnb] if g == grp[-1] else None)
+                        else:
+                            e.update(x_new=x_out[r0:r1], alpha=alpha_last[r0:r1])
+                        tab.append(e)
+                    head.update(out_bf16=xin_b[a:b], **t_of(xin_t, p, r0))          # (strides / tile size of x_new's copies)
+                    made_chain_fwd(xin_b[a:b], r1 - r0,
+                                   [dict(w_packed=wbf[l], n=widths[l], k=ws[l].shape[1], bias=bs[l], relu=True, out_bits=sign[l][a:b],
+                                         **t_of(acts_t[l], p - 1, r0)) for l in range(L - 1)] + [head], tab, tag='madechain_fwd')
+                    continue
                 if p < S:   # fp32 x_new only where the next pass hands a column through; its operands in bf16
                     head['iaf'].update(x_new=xin[na:nb_], keep=colcount[p + 1])
                     head.update(out_bf16=xin_b[na:nb_], **t_of(xin_t, p, r0))
@@ -1257,6 +1313,11 @@ MADE_CHAIN_IAF = _os.environ.get('GV_MADE_CHAIN_IAF', '1') == '1'      # the IAF
 # it on the side stream and are the longer of the two, only get the CUs the chain leaves free (k_gemm_bf16_tallk: 50 -> 63 us).
 # tools/probes/passes_grid.sh: no split / row-block setting turns that around.  1 = a launch per pass.
 MADE_CHAIN_PASSES = max(1, min(6, int(_os.environ.get('GV_MADE_CHAIN_PASSES', '1'))))
+# passes of the forward per gv_made_chain_fwd launch (1: a gv_made_chain launch per pass).  0 = by size: all of them (up to six) where
+# a pass's row tiles fit the chip's workgroup slots (FB15k-237 size + 3 IAF blocks: 2.96 -> 2.80 ms), three where they do not and the
+# passes run over two row blocks (WN18RR, 640 tiles on 512 slots: the second round of workgroups lasts as long as a launch does --
+# 5.18 ms per pass-launch, 5.05 / 4.99 / 5.11 with two / three / all passes per launch)
+MADE_FWD_PASSES = max(0, min(6, int(_os.environ.get('GV_MADE_FWD_PASSES', '0'))))
 MADE_CHAIN_IAFB = _os.environ.get('GV_MADE_CHAIN_IAFB', '1') == '1'    # ... and its backward as the backward chain's first stage
 MADE_T_TILES = _os.environ.get('GV_MADE_T_TILES', '1') == '1'          # ... and the transposed copies in tiles of 64 rows
 

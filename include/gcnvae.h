@@ -359,6 +359,23 @@ typedef struct gv_chain_iafb {
     int64_t of_step;
 } gv_chain_iafb;
 int gv_made_chain_iafb(const gv_chain_iafb* stage, int m, int n_layers, const gv_chain_layer* layers, void* stream);
+/* ALL passes of a MADE's forward in one launch (kgvae/flow_network.py:85-98: the loop over the index sets, pass 1 on -- pass 0 runs
+ * on one broadcast row): n_passes (1-6) times the chain gv_made_chain runs for one pass -- hidden layers with ReLU, the IAF update
+ * in the last layer's epilogue -- with a workgroup keeping its 64 rows through the passes: pass q's x_new stays in LDS (bf16) as
+ * pass q + 1's input, x is read for pass 0 alone.  `layers` gives what the passes share (packed weights, biases, n, k, relu,
+ * ldbits, t_tile of the tiled copies; in the last layer iaf_z, iaf_ld, ldb, t_tile); passes[q] what differs: the IAF operands
+ * (x_old / x_new / ex / alpha [m][iaf_ld] fp32; x_new is stored where keep_colcount has a 0 or keep_colcount is NULL), x_new's bf16
+ * copies (out_bf16 [m][ldb] row-major, may be NULL; out_bf16_t in tiles of 64 rows, may be NULL) and per hidden layer l the tiled
+ * transposed copy act_t[l] and the sign words act_bits[l] [m][ldbits].  A caller that chains passes hands pass q + 1 the x_new of
+ * pass q as x_old.  Same arithmetic, element by element, as n_passes calls of gv_made_chain; rows past m of the last 64-row tile
+ * leave as zeros in the tiled copies.  Hidden widths <= 512, d % 8 == 0. */
+typedef struct gv_chain_fwd_pass {
+    const float* x_old; float* x_new; float* ex; float* alpha; const int32_t* colcount; const int32_t* keep_colcount;
+    uint16_t* out_bf16; uint16_t* out_bf16_t;
+    uint16_t* act_t[GV_CHAIN_MAX_LAYERS]; int32_t* act_bits[GV_CHAIN_MAX_LAYERS];
+} gv_chain_fwd_pass;
+int gv_made_chain_fwd(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, int n_passes,
+                      const gv_chain_fwd_pass* passes, void* stream);
 /* probes only: a device buffer of 8 x 64 int32 that workgroup 0's waves of the following gv_made_chain launches fill with
  * s_memtime stamps (tools/probes/chain_stamps.py); NULL (the default) switches it off */
 int gv_made_chain_debug_stamps(int32_t* buffer);

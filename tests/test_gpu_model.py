@@ -789,6 +789,45 @@ def test_iaf_update_backward_as_the_first_stage_of_the_backward_chain_gives_the_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n,d,hidden,n_hidden', [(1000, 40, 56, 2), (64, 200, 200, 3), (4300, 200, 200, 3), (130, 8, 16, 1), (700, 64, 96, 4)])
+def test_all_forward_passes_of_a_made_in_one_launch_give_the_same_bits(monkeypatch, n, d, hidden, n_hidden):
+    """gv_made_chain_fwd: the bf16 MADE node's forward passes 1 .. P-1 in ONE launch (a workgroup keeps its 64 rows, x_new stays
+    in LDS as the next pass's input; the buffer roles swap from pass to pass when the layer count is odd: n_hidden + 2 layers)
+    against one gv_made_chain launch per pass: x, log-det, dL/dz and every parameter gradient -- i.e. everything the forward
+    stores for the backward: exp(alpha + mu), the sign words and the tiled transposed copies of every pass -- bit for bit; in
+    groups of two passes and with all passes in one launch; row counts that end inside a 64-row tile (the last workgroup's rows
+    past m leave as zeros in the tiled copies and store nothing else)."""
+    from gcn_vae_amd import made, ops
+    from gcn_vae_amd.flows import MADE
+    z = torch.randn(n, d, generator=torch.Generator().manual_seed(n + d)).cuda()
+    calls = []
+    inner = made.made_chain_fwd
+    monkeypatch.setattr(made, 'made_chain_fwd', lambda x, m, layers, passes, **k: (calls.append(len(passes)), inner(x, m, layers, passes, **k))[1])
+    res = []
+    for per_launch in (1, 2, 6, 0):         # (0: chosen by size -- all passes where the rows run as one block, three otherwise)
+        calls.clear()
+        monkeypatch.setattr(made, 'MADE_FWD_PASSES', per_launch)
+        per_launch = per_launch or (6 if len(made._made_row_blocks(n)) == 1 else 3)
+        torch.manual_seed(3)
+        m = MADE(d, hidden, n_hidden).cuda()
+        with ops.gemm_precision('bf16'):
+            zz = z.clone().requires_grad_(True)
+            x, ld = m(zz)
+            (x.sin().sum() + (ld * ld).sum()).backward()
+        torch.cuda.synchronize()
+        if per_launch == 1:
+            assert not calls
+        else:       # P - 1 = n_hidden + 2 passes in groups of per_launch, per row block
+            assert sum(calls) == (n_hidden + 2) * len(made._made_row_blocks(n)) and max(calls) == min(per_launch, n_hidden + 2), calls
+        res.append((x.detach().clone(), ld.detach().clone(), zz.grad.clone(), [p.grad.detach().clone() for p in m.parameters()]))
+    assert float(res[0][2].abs().max()) > 0 and bool(torch.isfinite(res[0][0]).all())
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1]) and torch.equal(res[0][2], other[2])
+        for a, b in zip(res[0][3], other[3]):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('precision,n', [('bf16', 9000), ('f32', 5000)])
 def test_multi_stream_flow_stack_equals_the_plain_one_eagerly_and_in_a_captured_step(precision, n):
     """tools/probes/made_stress.py: two MADE blocks in a row with FlatAdam -- two row blocks on their own streams, weight gradients
