@@ -1233,7 +1233,7 @@ class _MADEForwardBF16(torch.autograd.Function):
                           for l in range(L) if ctx.needs_input_grad[3 + l])
                       and all(direct_b[l] is not None for l in range(L) if wants_gb[l]))
         with backward_side(beside, gm_t, xin_t, acts_t, row_gw, row_gb, g_row, acts0, ws) as on_side:
-            ctx.gradw_cap = GRADW_SPLIT_MAX_SIDE if on_side else GRADW_SPLIT_MAX
+            ctx.gradw_cap = (GRADW_SPLIT_MAX_SIDE or (128 if len(_made_row_blocks(n)) > 1 else 96)) if on_side else GRADW_SPLIT_MAX
             if ctx.row:
                 made_row_bwd(g_row, [dict(w=ws[l], act=acts0[l] if l < L - 1 else None, inp=acts0[l - 1] if l > 0 else None,
                                           gw=row_gw[l], gb=row_gb[l]) for l in range(L)])
@@ -1304,8 +1304,10 @@ MADE_BF16_STORAGE = _os.environ.get('GV_MADE_BF16', '1') == '1'
 GRADW_SPLIT_MAX = int(_os.environ.get('GV_GRADW_SPLIT_MAX', '256'))      # most K slices of a MADE weight-gradient product
 # ... when the products run on the side stream, beside the next flow's backward chains: a slice is a workgroup that takes a whole
 # CU's LDS, so fewer of them leave the chains more of the chip, and the partial sums are fewer (alone 256 slices are fastest: 58 us
-# against 73 at 128; in the c3 step 5.79 ms at 256, 5.72-5.77 at 128, 5.67-5.69 at 96, 5.72 at 64)
-GRADW_SPLIT_MAX_SIDE = int(_os.environ.get('GV_GRADW_SPLIT_MAX_SIDE', '96'))
+# against 73 at 128; in the c3 step 5.79 ms at 256, 5.72-5.77 at 128, 5.67-5.69 at 96, 5.72 at 64).  0 = by size: 96, and 128 where
+# the passes run over two row blocks -- since the backward chains run two workgroups per CU (GV_CHAIN_WIDE0) the c3 step is 4.98-5.01 ms
+# at 128 against 5.06-5.08 at 96; FB15k-237 size + 3 IAF blocks stays best at 96 (2.83 against 2.86)
+GRADW_SPLIT_MAX_SIDE = int(_os.environ.get('GV_GRADW_SPLIT_MAX_SIDE', '0'))
 MADE_CHAIN_IAF = _os.environ.get('GV_MADE_CHAIN_IAF', '1') == '1'      # the IAF update inside the chain's last layer
 # ... and that many passes of the backward per launch (gv_chain_iafb.n_passes).  The looped launch needs 28 % less kernel time per
 # pass (FB15k-237 size, 3 IAF blocks: 3 x 203 us against 15 x 56 us) and LOSES as a step (2.96 -> 3.12 ms; WN18RR 5.24 -> 5.44): its
