@@ -450,7 +450,15 @@ def k4_records(ms, _ops):
                    'operands': 'f32' if f32 else 'bf16',
                    'achieved_TFLOPs': round(flops / 1e12 / (avg_ms * 1e-3), 1) if avg_ms > 0 else None, 'peak_TFLOPs': peak}
         if k4[tag]['achieved_TFLOPs']:
-            k4[tag]['frac'] = round(k4[tag]['achieved_TFLOPs'] / peak, 4)
+            k4[tag]['frac_mfma'] = k4[tag]['frac'] = round(k4[tag]['achieved_TFLOPs'] / peak, 4)
+        # the bf16 chains also against HBM: the ALGORITHMIC bytes of a launch (every operand and result of a pass once: DESIGN.md §4)
+        # over the same time; the launch is graded by the bound it is closer to
+        nbytes = getattr(_ops, 'MADE_CHAIN_BYTES', {}).get(tag)
+        if nbytes and avg_ms > 0:
+            gbs = nbytes / 1e9 / (avg_ms * 1e-3)
+            k4[tag].update(algorithmic_MB=round(nbytes / 1e6, 1), achieved_GBs=round(gbs, 1), frac_hbm=round(gbs / HBM_PEAK_GBS, 4))
+            if k4[tag]['frac_hbm'] > k4[tag].get('frac', 0.0):
+                k4[tag].update(bound='hbm', frac=k4[tag]['frac_hbm'])
     return k4
 
 
@@ -480,7 +488,31 @@ def result_exit_code(rec):
     return 0 if rec.get('loss_is_finite', True) else EXIT_NONFINITE_LOSS
 
 
-def dominant_roofline(k1_roofline, detail, k4):
+K4_KERNEL = {'madechain_bwd': 'k_made_chain<false,true>', 'madechain_fwd': 'k_made_chain_fwd'}
+
+
+def pmc_traffic_k4(tag, config, n_rows):
+    """(HBM-side bytes of one TIMED launch of a bf16 chain tag, provenance) from the newest committed PMC passes of this
+    configuration (as pmc_traffic_for).  The PMC passes ran the production layout -- a launch per row block -- while the timed
+    launch covers all rows: the counter figure is scaled by the number of row blocks."""
+    import glob
+    name = K4_KERNEL.get(tag)
+    if name is None or config is None:
+        return None, None
+    from gcn_vae_amd import made as _made
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*', f'pmc_traffic_{config}.json')))):
+        try:
+            data = json.load(open(path))
+        except Exception:
+            continue
+        if name in data:
+            blocks = len(_made._made_row_blocks(n_rows))
+            return data[name]['traffic_bytes'] * blocks, dict(data.get('_meta') or {}, file=os.path.relpath(path, ROOT), kernel=name,
+                                                             scaled_by_row_blocks=blocks)
+    return None, None
+
+
+def dominant_roofline(k1_roofline, detail, k4, config=None, n_rows=None):
     """The line's ``roofline`` object: the kernel that is dominant BY TIME among the instrumented launches of one step (HIP-event
     averages x launches).  With IAF blocks that is the fused MADE pass (K4, flops against the MFMA peak of its operand type);
     without, the K1 aggregations, graded by their WORST instance.  Returns (roofline, roofline_k1): roofline_k1 is the worst K1
@@ -491,8 +523,14 @@ def dominant_roofline(k1_roofline, detail, k4):
         return k1_roofline, None
     dom = max((t for t in k4 if k4[t].get('frac')), key=lambda t: k4[t]['avg_us'] * k4[t]['launches'])
     d = k4[dom]
-    roof = {'kernel': dom, 'bound': 'mfma', 'achieved': d['achieved_TFLOPs'], 'peak': d['peak_TFLOPs'], 'unit': 'TFLOP/s',
-            'frac': d['frac'], 'traffic': None, 'avg_us': d['avg_us'], 'GFLOP': d['GFLOP'], 'operands': d.get('operands'),
+    hbm = d.get('bound') == 'hbm'
+    traffic, traffic_src = pmc_traffic_k4(dom, config, n_rows) if n_rows else (None, None)
+    roof = {'kernel': dom, 'bound': d.get('bound', 'mfma'), 'achieved': d['achieved_GBs'] if hbm else d['achieved_TFLOPs'],
+            'peak': HBM_PEAK_GBS if hbm else d['peak_TFLOPs'], 'unit': 'GB/s' if hbm else 'TFLOP/s',
+            'frac': d['frac'], 'frac_mfma': d.get('frac_mfma'), 'frac_hbm': d.get('frac_hbm'), 'algorithmic_MB': d.get('algorithmic_MB'),
+            'traffic': traffic, 'traffic_source': traffic_src,
+            'traffic_over_algorithmic': round(traffic / (d['algorithmic_MB'] * 1e6), 3) if (traffic and d.get('algorithmic_MB')) else None,
+            'avg_us': d['avg_us'], 'GFLOP': d['GFLOP'], 'operands': d.get('operands'),
             'share_of_instrumented_time': round(t_k4 / max(t_k1 + t_k4, 1e-9), 3),
             'instances': {t: v.get('frac') for t, v in sorted(k4.items())}}
     return roof, k1_roofline
@@ -1098,7 +1136,8 @@ def main():
             'final_loss': final_loss,
             'roofline': roofline, 'roofline_detail': detail, 'roofline_k4': k4 or None, 'k1_GBs_per_rank': per_rank_k1,
         }
-        out['roofline'], out['roofline_k1'] = dominant_roofline(roofline, detail, k4)
+        std_shape = args.hidden == CONFIGS[args.config].get('hidden', args.hidden) and args.n_flows == CONFIGS[args.config].get('flows', args.n_flows)
+        out['roofline'], out['roofline_k1'] = dominant_roofline(roofline, detail, k4, args.config if std_shape else None, n_nodes)
         out['cpu_baseline'], out['parity_check'] = cpu_rec, parity_rec
         out['config']['k1_operands'] = 'bf16 (fp32 accumulate, fp32 rows in memory)' if k1_bf else 'f32'
         out['loss_is_finite'] = bool(np.isfinite(final_loss))

@@ -534,7 +534,38 @@ def made_chain_fits(widths_n, widths_k, any_mask):
     return bool(lib.load().gv_made_chain_fits(nl, _ct.addressof(arr_n), _ct.addressof(arr_k), 1 if any_mask else 0))
 
 
-MADE_CHAIN_FLOPS = {}        # tag -> flops of one launch (filled while a KernelTimer is installed: bench.py's K4 roofline line)
+MADE_CHAIN_FLOPS = {}        # tag -> MEAN flops of a launch (filled while a KernelTimer is installed: bench.py's K4 roofline line)
+_chain_flops_acc = {}        # tag -> [sum, launches]: the launches of one tag differ in size where the passes go in groups (3 + 2)
+
+
+MADE_CHAIN_BYTES = {}        # tag -> MEAN algorithmic HBM bytes of a launch (bf16 chains: what a pass must read and write once)
+
+
+def _note_chain_flops(tag, flops, nbytes=None):
+    acc = _chain_flops_acc.setdefault(tag, [0.0, 0, 0.0])
+    acc[0] += flops
+    acc[1] += 1
+    MADE_CHAIN_FLOPS[tag] = acc[0] / acc[1]
+    if nbytes is not None:
+        acc[2] += nbytes
+        MADE_CHAIN_BYTES[tag] = acc[2] / acc[1]
+
+
+def _chain_layer_bytes(m, d):
+    """Algorithmic bytes one layer dict of made_chain moves for m rows: its outputs and masks once (weights, biases and column
+    counts stay in cache; an add source / x_old is read for the columns of count 0 alone: not counted)."""
+    n = int(d['n'])
+    iaf = d.get('iaf')
+    wide = n // 2 if iaf is not None else n               # an IAF layer's bf16 outputs hold x_new: d columns
+    b = 0
+    b += 2 * wide * m if d.get('out_bf16') is not None else 0
+    b += 2 * wide * m if d.get('out_bf16_t') is not None else 0
+    b += 4 * n * m if d.get('out_f32') is not None else 0
+    b += 2 * n * m if (d.get('mask') is not None or d.get('mask_t') is not None) else 0
+    b += 4 * ((n + 31) // 32) * m if (d.get('out_bits') is not None or d.get('mask_bits') is not None) else 0
+    if iaf is not None:                                    # z read; ex / alpha written (x_new / x_old: handed-through columns alone)
+        b += 4 * wide * m * (1 + (iaf.get('ex') is not None) + (iaf.get('alpha') is not None))
+    return b
 
 
 def made_chain(x, m, layers, tag=None, stage=None):
@@ -544,7 +575,14 @@ def made_chain(x, m, layers, tag=None, stage=None):
     dict(z, ex, gx, gz, colcount, gnt, t_tile, gld=None, overwrite_gz=False), fp32 (m, d) operands of one row stride; with
     passes=dict(n, rows_step, tiles_step, cc_step, of_step) the launch walks n passes whose operands lie those steps apart."""
     if tag is not None and lib.TIMER is not None:
-        MADE_CHAIN_FLOPS[tag] = 2.0 * int(m) * sum(int(d['n']) * int(d['k']) for d in layers)
+        nb = sum(_chain_layer_bytes(int(m), d) for d in layers)
+        if stage is not None:      # gx, ex, z read, g_z written (and read unless it starts here), [g_mu | g_alpha]'s tiled copy written
+            dd = int(stage['z'].shape[1])
+            nb += int(m) * dd * (4 * (4 if stage.get('overwrite_gz') else 5) + 2 * 2) * int((stage.get('passes') or {}).get('n', 1))
+            nb += (int((stage.get('passes') or {}).get('n', 1)) - 1) * sum(_chain_layer_bytes(int(m), d) for d in layers)
+        else:
+            nb += 2 * int(layers[0]['k']) * int(m) // (2 if layers[0].get('x_dup_half') else 1)
+        _note_chain_flops(tag, 2.0 * int(m) * sum(int(d['n']) * int(d['k']) for d in layers) * int(((stage or {}).get('passes') or {}).get('n', 1)), nb)
     arr = _chain_layers(layers)
     if stage is not None:
         ts = [stage[k_] for k_ in ('z', 'ex', 'gx', 'gz')]
@@ -569,7 +607,12 @@ def made_chain_fwd(x, m, layers, passes, tag=None):
     pass's dicts: strides and shared fields are read from them); passes: per pass dict(x_old, colcount, ex, x_new=None, alpha=None,
     keep=None, out_bf16=None, out_bf16_t=None, act_t=[...], act_bits=[...]) -- the pointers that differ from pass to pass."""
     if tag is not None and lib.TIMER is not None:
-        MADE_CHAIN_FLOPS[tag] = 2.0 * int(m) * len(passes) * sum(int(d['n']) * int(d['k']) for d in layers)
+        dd, nb = int(layers[-1]['n']) // 2, 2 * int(layers[0]['k']) * int(m)        # x: read for the first pass alone
+        for e in passes:
+            nb += sum(2 * int(d['n']) * int(m) + 4 * ((int(d['n']) + 31) // 32) * int(m) for d in layers[:-1])      # tiled copies + sign words
+            nb += 4 * dd * int(m) * (1 + 1 + (e.get('alpha') is not None))                                         # z read, ex (alpha) written
+            nb += 2 * dd * int(m) * ((e.get('out_bf16') is not None) + (e.get('out_bf16_t') is not None))
+        _note_chain_flops(tag, 2.0 * int(m) * len(passes) * sum(int(d['n']) * int(d['k']) for d in layers), nb)
     arr = _chain_layers(layers)
     tab = (_ChainFwdPass * len(passes))()
     for c, d in zip(tab, passes):
@@ -711,7 +754,7 @@ def made_chain_f32(x, m, layers, plan, tag=None):
     mask (fp32, kept where > 0), out_f32, accumulate; row strides are taken from the tensors.  Inside ops.live_rows a chain over
     a node array of exactly ``cap`` rows skips the workgroups that hold only padding rows."""
     if tag is not None and lib.TIMER is not None:
-        MADE_CHAIN_FLOPS[tag] = 2.0 * int(m) * sum(int(d['n']) * int(d['k']) for d in layers)
+        _note_chain_flops(tag, 2.0 * int(m) * sum(int(d['n']) * int(d['k']) for d in layers))
     arr = (_Chain32Layer * len(layers))()
     for c, d in zip(arr, layers):
         mask, of = d.get('mask'), d.get('out_f32')
@@ -835,7 +878,7 @@ def made_passes_f32(x, m, layers, plan, iaf, tag=None):
     launch's FIRST pass; ``iaf``: dict(mode=1 forward / 2 backward, passes, step (rows between passes in the stacked buffers, signed),
     d, z, colcount (the first pass's counts), flags, and x_out (forward) / net, g_in, g_logdet, g_z (backward))."""
     if tag is not None and lib.TIMER is not None:
-        MADE_CHAIN_FLOPS[tag] = 2.0 * int(m) * int(iaf['passes']) * sum(int(d_['n']) * int(d_['k']) for d_ in layers)
+        _note_chain_flops(tag, 2.0 * int(m) * int(iaf['passes']) * sum(int(d_['n']) * int(d_['k']) for d_ in layers))
     arr = (_Chain32Layer * len(layers))()
     for c, d_ in zip(arr, layers):
         mask, of = d_.get('mask'), d_.get('out_f32')
