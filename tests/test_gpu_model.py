@@ -828,6 +828,53 @@ def test_all_forward_passes_of_a_made_in_one_launch_give_the_same_bits(monkeypat
 
 
 @pytest.mark.gpu
+def test_forward_passes_launch_refuses_what_it_cannot_run():
+    """gv_made_chain_fwd's argument checks (include/gcnvae.h): more than six passes, a hidden layer without ReLU / without its tiled
+    copy, a pass without its sign words or IAF operands -- a status and a message, no launch; the well-formed call runs."""
+    from gcn_vae_amd import made
+    m, d, h = 100, 16, 32
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(0)
+    ws = [torch.randn(h, d, generator=g).cuda() * 0.1, torch.randn(2 * d, h, generator=g).cuda() * 0.1]
+    (pf0, _), (pf1, _) = made.made_pack_weights(ws, iaf_last=True)
+    x = torch.randn(m, d, generator=g).cuda().to(torch.bfloat16)
+    z, xo = torch.randn(m, d, generator=g).cuda(), torch.randn(m, d, generator=g).cuda()
+    cc = torch.ones(d, dtype=torch.int32, device=dev)
+    T, tt = (m + 63) // 64, 64 * max(d, h)
+    f32, bf = dict(dtype=torch.float32, device=dev), dict(dtype=torch.bfloat16, device=dev)
+
+    def pass_():
+        return dict(x_old=xo, colcount=cc, ex=torch.empty(m, d, **f32), x_new=torch.empty(m, d, **f32),
+                    out_bf16_t=torch.zeros(T * tt, **bf), act_t=[torch.zeros(T * tt, **bf)],
+                    act_bits=[torch.zeros(m, 1, dtype=torch.int32, device=dev)])
+
+    def layers(relu=True, tiled=True):
+        first = dict(w_packed=pf0, n=h, k=d, relu=relu, out_bits=torch.zeros(m, 1, dtype=torch.int32, device=dev))
+        if tiled:
+            first.update(out_bf16_t=torch.zeros(T * tt, **bf), t_tile=tt)
+        return [first, dict(w_packed=pf1, n=2 * d, k=h, iaf=dict(z=z, x_old=xo, colcount=cc, ex=torch.empty(m, d, **f32)),
+                            out_bf16=torch.empty(m, d, **bf), out_bf16_t=torch.zeros(T * tt, **bf), t_tile=tt)]
+
+    made.made_chain_fwd(x, m, layers(), [pass_(), pass_()])
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='n_passes'):
+        made.made_chain_fwd(x, m, layers(), [pass_() for _ in range(7)])
+    with pytest.raises(RuntimeError, match='hidden layer 0'):
+        made.made_chain_fwd(x, m, layers(relu=False), [pass_()])
+    with pytest.raises(RuntimeError, match='hidden layer 0'):
+        made.made_chain_fwd(x, m, layers(tiled=False), [pass_()])
+    bad = pass_()
+    bad['act_bits'] = [None]
+    with pytest.raises(RuntimeError, match='sign words'):
+        made.made_chain_fwd(x, m, layers(), [bad])
+    bad = pass_()
+    bad['ex'] = None
+    with pytest.raises((RuntimeError, KeyError), match='pass 0|ex'):
+        made.made_chain_fwd(x, m, layers(), [bad])
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('precision,n', [('bf16', 9000), ('f32', 5000)])
 def test_multi_stream_flow_stack_equals_the_plain_one_eagerly_and_in_a_captured_step(precision, n):
     """tools/probes/made_stress.py: two MADE blocks in a row with FlatAdam -- two row blocks on their own streams, weight gradients
