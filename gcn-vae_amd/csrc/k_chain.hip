@@ -350,7 +350,7 @@ __device__ __forceinline__ void chain_epilogue(const f32x16_t (&acc)[2], const g
 // hands through where a column's count is 0 (counts in LDS) -- what chain_epilogue does for such a layer, with the pass's pointers
 // given explicitly (the pass loop: pass q's output is pass q + 1's dL/dx_new).  Same arithmetic, element by element.
 __device__ __forceinline__ void chain_epilogue_last(const f32x16_t (&acc)[2], int n, int tile, int m0, int m, const float* bias_l,
-                                                    float* of, int ldc, const float* add, const int* cnt_lds, int r, int h) {
+                                                    float* of, int ldc, const float* add, const int* cnt_lds, int r, int h, int add_rev = 0) {
     asm volatile("" : "+v"(r), "+v"(h));
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -366,7 +366,13 @@ __device__ __forceinline__ void chain_epilogue_last(const f32x16_t (&acc)[2], in
             if (m0 + row >= m) continue;
             float4 o = make_float4(acc[mt][4 * g] + bv.x, acc[mt][4 * g + 1] + bv.y, acc[mt][4 * g + 2] + bv.z, acc[mt][4 * g + 3] + bv.w);
             if (any0) {
-                const float4 av = *reinterpret_cast<const float4*>(add + (size_t)(m0 + row) * ldc + c0);
+                float4 av;
+                if (add_rev) {      // (the handed-through gradient is dL/dx_new: reversed columns as in the stage)
+                    const float4 t4 = *reinterpret_cast<const float4*>(add + (size_t)(m0 + row) * ldc + (n - 4 - c0));
+                    av = make_float4(t4.w, t4.z, t4.y, t4.x);
+                } else {
+                    av = *reinterpret_cast<const float4*>(add + (size_t)(m0 + row) * ldc + c0);
+                }
                 if (ac.x <= 0) o.x += av.x;
                 if (ac.y <= 0) o.y += av.y;
                 if (ac.z <= 0) o.z += av.z;
@@ -554,6 +560,7 @@ __device__ __forceinline__ void chain_epilogue_iaf(const f32x16_t (&acc)[2], con
 struct ChainIafPins {
     const float* z; const float* x_old; float* x_new; float* ex; float* alpha; const int* keep; uint16_t* tbase;
     int ld, d, has_bias, identity;
+    int rev;      // x_new leaves with its columns reversed (the PermuteLayer behind an IAF block, kgvae/model.py:60-66, folded in)
 };
 // PRED: the workgroup may hold fewer than 64 rows (last_row = its last one): loads of the rows past it read row last_row, their
 // stores are skipped, their bf16 copies (LDS tile, tiled transposed copy) are zeros
@@ -626,7 +633,10 @@ __device__ __forceinline__ void chain_epilogue_iaf_fast(const f32x16_t (&acc)[2]
             if (cn[g].y <= 0) v.y = s.y;
             if (cn[g].z <= 0) v.z = s.z;
             if (cn[g].w <= 0) v.w = s.w;
-            if (P.x_new && keep[g] && live[mt]) *reinterpret_cast<float4*>(P.x_new + e) = v;
+            if (P.x_new && keep[g] && live[mt]) {
+                if (P.rev) *reinterpret_cast<float4*>(P.x_new + (vo[mt] + (unsigned)(d - 4 - cu - 8 * g - 8 * h))) = make_float4(v.w, v.z, v.y, v.x);
+                else *reinterpret_cast<float4*>(P.x_new + e) = v;
+            }
             uint16_t b0 = bf_bits(v.x), b1 = bf_bits(v.y), b2 = bf_bits(v.z), b3 = bf_bits(v.w);
             if (PRED && !live[mt]) b0 = b1 = b2 = b3 = 0;
             if (cu + 8 * g < kp_next)
@@ -730,7 +740,12 @@ __device__ __forceinline__ void chain_stage_iafb(uint16_t* tile, int ldk, uint16
         const unsigned e = off0 + (unsigned)blk * (IB_COLS * 4u);
         o.g = o.e = o.z = o.a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < m && c < d) {
-            o.g = *at(gx_p, e);
+            if (fl & 2) {       // dL/dx_new arrives with its columns reversed (the PermuteLayer behind the block, folded in)
+                const float4 t4 = *at(gx_p, off0 - (unsigned)cq * 4u + (unsigned)(d - 4 - c) * 4u);
+                o.g = make_float4(t4.w, t4.z, t4.y, t4.x);
+            } else {
+                o.g = *at(gx_p, e);
+            }
             if (!(fl & 1)) o.a = *at(gz_p, e);
             if (any) {
                 o.z = *at(z_p, e);
@@ -1021,6 +1036,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p) {
             const ChainArgs::Pass& pq = p.pass[q];                                                                      \
             ChainIafPins P;                                                                                             \
             P.ld = chain_pin(Ly.iaf_ld); P.d = chain_pin(Ly.n) >> 1; P.has_bias = Ly.bias ? 1 : 0; P.identity = 0;      \
+            P.rev = (chain_pin(pq.flags) >> 1) & 1;                                                                     \
             const size_t row0 = (size_t)m0 * P.ld;                                                                      \
             P.z = chain_pin_ptr(Ly.iaf_z) + row0; P.x_old = chain_pin_ptr(pq.gx) + row0;                                \
             P.x_new = pq.of ? chain_pin_ptr(pq.of) + row0 : nullptr;                                                    \
@@ -1037,6 +1053,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p) {
             if (fast_iaf) {                                                                                             \
                 ChainIafPins P;                                                                                         \
                 P.ld = chain_pin(Ly.iaf_ld); P.d = chain_pin(Ly.n) >> 1; P.has_bias = Ly.bias ? 1 : 0; P.identity = chain_pin(Ly.iaf_reserved) & 1; \
+                P.rev = 0;                                                                                              \
                 const size_t row0 = (size_t)m0 * P.ld;                                                                  \
                 P.z = chain_pin_ptr(Ly.iaf_z) + row0; P.x_old = chain_pin_ptr(Ly.iaf_x_old) + row0;                     \
                 P.x_new = Ly.iaf_x_new ? chain_pin_ptr(Ly.iaf_x_new) + row0 : nullptr;                                  \
@@ -1074,7 +1091,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p) {
                                     nullptr, 0, r, h);                                                                  \
             else                                                                                                        \
                 chain_epilogue_last(acc, Ly.n, u.tile, m0, p.m, Ly.bias ? bias_lds + bias_off : nullptr, p.pass[q].of, Ly.ldc, \
-                                    p.pass[q].add, reinterpret_cast<const int*>(bias_lds + bias_total), r, h);         \
+                                    p.pass[q].add, reinterpret_cast<const int*>(bias_lds + bias_total), r, h, p.pass[q].flags & 2); \
         } else                                                                                                          \
         if (u.ch + 1 == nch && !iaf_unit) {                                                                             \
             /* the common hidden layer of the fused chains (FULL == false): every row exists, transposed copy in 64-row tiles */ \
@@ -1397,7 +1414,7 @@ static int made_chain_launch(const uint16_t* x, int ldx, int m, int n_layers, co
             pq.gld = q ? nullptr : stage->gld;
             pq.cc = stage->colcount + (int64_t)q * stage->cc_step;
             pq.gnt = stage->gnt + (int64_t)q * stage->tiles_step * stage->t_tile;
-            pq.flags = q ? (stage->flags & ~1) : stage->flags;
+            pq.flags = q ? (stage->flags & ~3) : stage->flags;       // (bit 0: g_z starts here, bit 1: reversed gx -- the first pass alone)
             pq.of = last.out_f32 ? last.out_f32 + (int64_t)q * stage->of_step : nullptr;
             pq.add = q ? (last.add_src ? of_prev : nullptr) : last.add_src;
             for (int l = 0; l < n_layers; ++l) {
@@ -1476,7 +1493,7 @@ extern "C" int gv_made_chain_fwd(const uint16_t* x, int ldx, int m, int n_layers
                    GV_ERR_ALIGN, "gv_made_chain_fwd: pass %d: x_new's bf16 copies (ldb=%d, t_tile=%d)", q, last.ldb, last.t_tile);
         pq.ex = f.ex; pq.gx = f.x_old; pq.cc = f.colcount; pq.gnt = f.out_bf16_t; pq.of = f.x_new; pq.add = f.alpha;
         pq.keep = f.keep_colcount; pq.ob = f.out_bf16;
-        pq.flags = (q + 1 < n_passes || f.out_bf16) ? 1 : 0;          // x_new into the LDS tile
+        pq.flags = ((q + 1 < n_passes || f.out_bf16) ? 1 : 0) | ((f.flags & 1) ? 2 : 0);          // x_new into the LDS tile; reversed x_new
         for (int l = 0; l + 1 < n_layers; ++l) {
             GV_REQUIRE(f.act_t[l] && f.act_bits[l], GV_ERR_NULL, "gv_made_chain_fwd: pass %d: hidden layer %d has no tiled copy / sign words", q, l);
             pq.out_t[l] = f.act_t[l];

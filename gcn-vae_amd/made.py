@@ -448,7 +448,7 @@ class _ChainFwdPass(_ct.Structure):
     """gv_chain_fwd_pass of include/gcnvae.h."""
     _fields_ = [('x_old', _ct.c_void_p), ('x_new', _ct.c_void_p), ('ex', _ct.c_void_p), ('alpha', _ct.c_void_p),
                 ('colcount', _ct.c_void_p), ('keep_colcount', _ct.c_void_p), ('out_bf16', _ct.c_void_p), ('out_bf16_t', _ct.c_void_p),
-                ('act_t', _ct.c_void_p * 8), ('act_bits', _ct.c_void_p * 8)]
+                ('act_t', _ct.c_void_p * 8), ('act_bits', _ct.c_void_p * 8), ('flags', _ct.c_int32), ('reserved', _ct.c_int32)]
 
 
 class _RowLayer(_ct.Structure):
@@ -592,7 +592,7 @@ def made_chain(x, m, layers, tag=None, stage=None):
         sb.z, sb.ex, sb.gx, sb.gz = (ptr(t) for t in ts)
         sb.gld, sb.colcount, sb.gnt = ptr(stage.get('gld')), ptr(stage['colcount']), ptr(stage['gnt'])
         sb.ld, sb.d, sb.t_tile = ts[0].stride(0), int(ts[0].shape[1]), int(stage['t_tile'])
-        sb.flags = 1 if stage.get('overwrite_gz') else 0
+        sb.flags = (1 if stage.get('overwrite_gz') else 0) | (2 if stage.get('gx_reversed') else 0)
         ps = stage.get('passes')
         if ps is not None:
             sb.n_passes, sb.rows_step, sb.tiles_step = int(ps['n']), int(ps['rows_step']), int(ps['tiles_step'])
@@ -621,6 +621,7 @@ def made_chain_fwd(x, m, layers, passes, tag=None):
         c.out_bf16, c.out_bf16_t = ptr(d.get('out_bf16')), ptr(d.get('out_bf16_t'))
         for l, (t, b) in enumerate(zip(d['act_t'], d['act_bits'])):
             c.act_t[l], c.act_bits[l] = ptr(t), ptr(b)
+        c.flags = 1 if d.get('reverse_x_new') else 0
     lib.call('gv_made_chain_fwd', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), len(passes), _ct.addressof(tab), lib.stream(),
              tag=tag)
 
@@ -988,6 +989,7 @@ class _MADEForwardBF16(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, colcount, masks, *wb):
         ctx.set_materialize_grads(False)
+        reverse_out, wb = bool(wb[-1]), wb[:-1]      # x comes out with its columns reversed (the PermuteLayer behind the block rides along)
         L = len(wb) // 2
         ws, bs = wb[:L], wb[L:]
         ctx.masks = masks
@@ -1054,6 +1056,8 @@ class _MADEForwardBF16(torch.autograd.Function):
                 lib.call('gv_iaf_update_fwd', ptr(z), ptr(net), ld_net, ptr(x_old), ptr(cc), ptr(x_out), n, d, st)
         update(acts0[L - 1], 0, z, colcount[0], 0)
 
+        folded = [False]           # the last pass stored x_out reversed already
+
         def fused_passes(r0, r1):
             """Passes 1 .. P-1 for the rows [r0, r1) (r0 a multiple of 64): every launch of a pass is row-local."""
             todo = list(range(1, P))
@@ -1079,7 +1083,8 @@ class _MADEForwardBF16(torch.autograd.Function):
                             e.update(x_new=xin[gna:gnb], keep=colcount[g + 1], out_bf16_t=xin_t[g * T + r0 // 64:],
                                      out_bf16=xin_b[gna:gnb] if g == grp[-1] else None)
                         else:
-                            e.update(x_new=x_out[r0:r1], alpha=alpha_last[r0:r1])
+                            e.update(x_new=x_out[r0:r1], alpha=alpha_last[r0:r1], reverse_x_new=reverse_out)
+                            folded[0] = reverse_out
                         tab.append(e)
                     head.update(out_bf16=xin_b[a:b], **t_of(xin_t, p, r0))          # (strides / tile size of x_new's copies)
                     made_chain_fwd(xin_b[a:b], r1 - r0,
@@ -1120,6 +1125,11 @@ class _MADEForwardBF16(torch.autograd.Function):
             lib.call('gv_rowsum', ptr(net_out[(S - 1) * n:]), 2 * d, d, d, ptr(log_det), n, st)
         else:
             log_det = acts0[L - 1][:, d:].sum(dim=1).expand(n).contiguous()
+        if reverse_out and not folded[0]:
+            rev = torch.empty_like(x_out)
+            lib.call('gv_reverse_cols', ptr(x_out), ptr(rev), n, d, st)
+            x_out = rev
+        ctx.reverse_out = reverse_out
         ctx.save_for_backward(z, colcount, xin_t, zero_row, net_out, *(sign if fused else acts_b), *acts_t, *acts0, *wbt, *ws)
         ctx.L = L
         ctx.chain = chain
@@ -1151,6 +1161,14 @@ class _MADEForwardBF16(torch.autograd.Function):
         widths = [w.shape[0] for w in ws]
         gx = torch.zeros(n, d, **f32) if gx is None else _chk(gx.contiguous(), name='gx')
         gld = None if gld is None else _chk(gld.contiguous(), name='gld')
+        # dL/dx arrives with reversed columns where the forward folded the PermuteLayer in: the first backward launch reads it that
+        # way when it is the chain with the update's backward as its first stage; otherwise it is reversed here
+        gx_rev = ctx.reverse_out and (ctx.fused and P > 1 and MADE_CHAIN_IAFB and ctx.tiled and L > 1 and d % 4 == 0
+                                      and n * d * 4 < (1 << 32))
+        if ctx.reverse_out and not gx_rev:
+            rev = torch.empty_like(gx)
+            lib.call('gv_reverse_cols', ptr(gx), ptr(rev), n, d, st)
+            gx = rev
         # ReLU-masked gradients w.r.t. every layer's pre-activation: bf16 row-major (operand of backward-x) and transposed
         # (operand of backward-W and of the bias sums)
         if ctx.fused:   # only the chain's input [g_mu | g_alpha], one pass at a time; the hidden layers' stay inside the chain
@@ -1198,7 +1216,7 @@ class _MADEForwardBF16(torch.autograd.Function):
                                stage=dict(z=z[r0:r1], ex=net_out[a:b], gx=g_in[r0:r1], gz=g_z[r0:r1], colcount=colcount[p],
                                           gnt=gm_t[L - 1][(p - 1) * T + t0:], t_tile=tb,
                                           gld=gld[r0:r1] if (p == P - 1 and gld is not None) else None, overwrite_gz=p == P - 1,
-                                          passes=passes if more else None))
+                                          gx_reversed=gx_rev and p == P - 1, passes=passes if more else None))
                     del todo[:more]
                     g_in = g_olds[p - more]
                     continue
@@ -1283,7 +1301,7 @@ class _MADEForwardBF16(torch.autograd.Function):
             g_ws, g_bs = _MADEForwardBF16._weight_gradients(ctx, L, S, T, tiled, mtot, widths, ws, acts0, rows0, zero_row, row_gw, row_gb,
                                                             direct_b if ctx.row else None, wants_gb, gb_target, fused_gb, gm_t, gm_t_all,
                                                             tb if tiled else 0, xin_t, acts_t, f32, lib.stream())
-        return (g_z, None, None, *g_ws, *g_bs)
+        return (g_z, None, None, *g_ws, *g_bs, None)
 
     @staticmethod
     def _weight_gradients(ctx, L, S, T, tiled, mtot, widths, ws, acts0, rows0, zero_row, row_gw, row_gb, direct_b, wants_gb, gb_target,
@@ -1430,8 +1448,7 @@ def made_forward(z, colcount, weights, biases, masks=None, reverse_out=False):
                                                                                        for w in weights)):
         if masks is not None and len(weights) > 8:           # gv_mul_multi's table holds 8 entries
             weights, masks = [masked_weight(m, w) for m, w in zip(masks, weights)], None
-        x, log_det = _MADEForwardBF16.apply(z, colcount, tuple(masks) if masks is not None else None, *weights, *biases)
-        return (_ops.reverse_cols(x) if reverse_out else x), log_det
+        return _MADEForwardBF16.apply(z, colcount, tuple(masks) if masks is not None else None, *weights, *biases, bool(reverse_out))
     if masks is not None and len(weights) > 8:               # gv_mul_multi's table holds 8 entries
         weights, masks = [masked_weight(m, w) for m, w in zip(masks, weights)], None
     return _MADEForward.apply(z, colcount, tuple(masks) if masks is not None else None, bool(reverse_out), *weights, *biases)

@@ -354,7 +354,9 @@ typedef struct gv_chain_iafb {
      * (every step of a pass is row-local).  The pointers above and in `layers` describe the pass processed first; pass q's operands
      * lie q steps further in the stacked buffers (steps may be negative): ex and every mask_bits by rows_step rows, gnt and every
      * out_bf16_t by tiles_step tiles, colcount by cc_step ints, the last layer's out_f32 by of_step floats; pass q's gx and add_src
-     * are pass q - 1's out_f32; gld and flags bit 0 belong to the first pass alone.  Hidden layers: tiled out_bf16_t alone, no bias. */
+     * are pass q - 1's out_f32; gld and flags bits 0 / 1 belong to the first pass alone.  Hidden layers: tiled out_bf16_t alone, no bias.
+     * flags bit 1: gx -- and the last layer's add_src, the same gradient -- hold their columns REVERSED (the backward of a PermuteLayer
+     * behind the block, folded in). */
     int32_t n_passes, rows_step, tiles_step, cc_step;
     int64_t of_step;
 } gv_chain_iafb;
@@ -373,6 +375,8 @@ typedef struct gv_chain_fwd_pass {
     const float* x_old; float* x_new; float* ex; float* alpha; const int32_t* colcount; const int32_t* keep_colcount;
     uint16_t* out_bf16; uint16_t* out_bf16_t;
     uint16_t* act_t[GV_CHAIN_MAX_LAYERS]; int32_t* act_bits[GV_CHAIN_MAX_LAYERS];
+    int32_t flags, reserved;      /* flags bit 0: x_new (fp32) is stored with its columns REVERSED -- the PermuteLayer behind an IAF block
+                                   * (kgvae/model.py:60-66) folded into the block's last pass; the bf16 copies keep the natural order */
 } gv_chain_fwd_pass;
 int gv_made_chain_fwd(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, int n_passes,
                       const gv_chain_fwd_pass* passes, void* stream);

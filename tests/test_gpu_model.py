@@ -828,6 +828,45 @@ def test_all_forward_passes_of_a_made_in_one_launch_give_the_same_bits(monkeypat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n,d,hidden,n_hidden', [(1000, 40, 56, 2), (4300, 200, 200, 3), (130, 8, 16, 1)])
+def test_permute_layer_folded_into_the_bf16_made_node_gives_the_same_bits(monkeypatch, n, d, hidden, n_hidden):
+    """MADE.forward(reverse_out=True) on the bf16 node -- the PermuteLayer behind an IAF block (kgvae/model.py:60-66): the last
+    forward pass stores x with its columns reversed (gv_chain_fwd_pass.flags), the first backward launch reads dL/dx and the
+    handed-through gradient that way (gv_chain_iafb.flags bit 1) -- against the node followed by ops.reverse_cols: x, log-det,
+    dL/dz, every parameter gradient bit for bit; also where the passes go one launch each (the reversal then stays a launch)."""
+    from gcn_vae_amd import made, ops
+    from gcn_vae_amd.flows import MADE
+    z = torch.randn(n, d, generator=torch.Generator().manual_seed(n + d)).cuda()
+    wgt = torch.randn(n, d, generator=torch.Generator().manual_seed(1)).cuda()       # (a loss that tells the columns apart)
+    rev_calls = []
+    inner = made.lib.call
+    monkeypatch.setattr(made.lib, 'call', lambda name, *a, **k: (rev_calls.append(name) if name == 'gv_reverse_cols' else None, inner(name, *a, **k))[1])
+    res = []
+    for fold, per_launch in ((False, 0), (True, 0), (True, 1)):
+        rev_calls.clear()
+        monkeypatch.setattr(made, 'MADE_FWD_PASSES', per_launch)
+        torch.manual_seed(3)
+        m = MADE(d, hidden, n_hidden).cuda()
+        with ops.gemm_precision('bf16'):
+            zz = z.clone().requires_grad_(True)
+            if fold:
+                x, ld = m(zz, reverse_out=True)
+            else:
+                x, ld = m(zz)
+                x = ops.reverse_cols(x)
+            ((x * wgt).sin().sum() + (ld * ld).sum()).backward()
+        torch.cuda.synchronize()
+        if fold and per_launch == 0:
+            assert not rev_calls, 'the reversal was expected to ride along'
+        res.append((x.detach().clone(), ld.detach().clone(), zz.grad.clone(), [p.grad.detach().clone() for p in m.parameters()]))
+    assert float(res[0][2].abs().max()) > 0
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1]) and torch.equal(res[0][2], other[2])
+        for a, b in zip(res[0][3], other[3]):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 def test_forward_passes_launch_refuses_what_it_cannot_run():
     """gv_made_chain_fwd's argument checks (include/gcnvae.h): more than six passes, a hidden layer without ReLU / without its tiled
     copy, a pass without its sign words or IAF operands -- a status and a message, no launch; the well-formed call runs."""
