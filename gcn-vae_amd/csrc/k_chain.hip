@@ -50,6 +50,7 @@ struct ChainArgs {
     gv_chain_iafb ib;            // ib.gx != NULL: layer 0's input is made in the prologue (the IAF update's backward), x unused
     int ib_lds_off;              // floats from the bias block to the stage's 2 x IB_COLS x IB_LD transposition block
     int ld0;                     // IB: row stride of layer 0's input tile (== ldk, or wider: the tile then spans both activation buffers)
+    gv_chain_fwd_row0 row0;      // FW, row0.net_row != NULL: pass 0's update makes layer 0's input of the first pass (x unused)
     int n_passes;                // IB: passes of a MADE's backward in this launch (pass[q]: what differs from pass to pass)
     gv_chain_layer L[CH_L];
     struct Pass {
@@ -813,6 +814,55 @@ __device__ __forceinline__ void chain_stage_iafb(uint16_t* tile, int ldk, uint16
     }
 }
 
+// Pass 0's IAF update as the first stage of the forward passes launch (gv_made_chain_fwd_row0): the net's output of pass 0 is ONE row
+// ([mu | alpha], the MADE of a zero input: kgvae/flow_network.py:88-97 with x = 0), every column's count is positive, so
+//   x[r][c] = z[r][c] * expf(alpha[c] + mu[c])
+// -- the arithmetic of gv_iaf_update_fwd_bf16_tiles on a broadcast row.  x leaves as fp32 (the passes' x_old), as bf16 into layer 0's
+// LDS tile and, through a [column][row] block of 32 columns, as the tiled transposed copy; rows past m: zeros in both bf16 forms.
+__device__ __forceinline__ void chain_stage_row0(uint16_t* tile, int ldk, uint16_t* tmx, const gv_chain_fwd_row0& f, const float* z, int ld,
+                                                 int d, int t_tile, int m0, int m) {
+    const int nblk = (d + IB_COLS - 1) / IB_COLS;
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    uint16_t (*tm)[IB_LD] = reinterpret_cast<uint16_t (*)[IB_LD]>(tmx);
+    const int cq = (t & 7) << 2, rr = t >> 3, r = m0 + rr;      // a block is 64 rows x 8 pieces of four columns: one per thread
+    const float* const z_p = chain_pin_here(z);
+    float* const x_p = chain_pin_here(f.x_f32);
+    const float* const n_p = chain_pin_here(f.net_row);
+    const unsigned off0 = (unsigned)(r * ld + cq) * 4u;
+    uint16_t* const gt = f.x_t + (size_t)blockIdx.x * t_tile;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int c = blk * IB_COLS + cq;
+        uint16_t b[4] = {0, 0, 0, 0};
+        if (r < m && c < d) {
+            const unsigned e = off0 + (unsigned)blk * (IB_COLS * 4u);
+            const float4 zv = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(z_p) + e);
+            const float4 mu = *reinterpret_cast<const float4*>(n_p + c), al = *reinterpret_cast<const float4*>(n_p + d + c);
+            float4 x;
+            x.x = zv.x * expf(al.x + mu.x);
+            x.y = zv.y * expf(al.y + mu.y);
+            x.z = zv.z * expf(al.z + mu.z);
+            x.w = zv.w * expf(al.w + mu.w);
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(x_p) + e) = x;
+            b[0] = bf_bits(x.x); b[1] = bf_bits(x.y); b[2] = bf_bits(x.z); b[3] = bf_bits(x.w);
+        }
+        if (c < d) *reinterpret_cast<uint2*>(tile + rr * ldk + c) = make_uint2(b[0] | ((uint32_t)b[1] << 16), b[2] | ((uint32_t)b[3] << 16));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tm[cq + q][rr] = b[q];
+        __syncthreads();
+        {       // the block's transposed copy: four consecutive rows of a column per 8-B store; 32 x 16 pieces = one per thread
+            const int cc = (t >> 4) & (IB_COLS - 1), rq = (t & 15) << 2;
+            if (blk * IB_COLS + cc < d)
+                *reinterpret_cast<uint2*>(gt + (size_t)(blk * IB_COLS + cc) * 64 + rq) = *reinterpret_cast<const uint2*>(&tm[cc][rq]);
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < CH_BM * (((d + 15) & ~15) - d); i += CH_THREADS) {      // the tile's padding columns [d, 16 ceil(d / 16))
+        const int pw = ((d + 15) & ~15) - d;
+        tile[(i / pw) * ldk + d + i % pw] = 0;
+    }
+}
+
 // Every wave walks its own list of units (layer, column tile, 13-step chunk) in ONE flat loop.  Between units a wave crosses layer
 // boundaries; crossing layer l -> l + 1 is the same for every wave of the workgroup:
 //   barrier (layer l's tile complete)  ->  [mask of layer l + 1 staged by everyone, barrier]  ->  store wave: layer l's copies.
@@ -938,6 +988,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p) {
                 if (u.l < nl) u.tile = chain_first_tile(p.L[u.l], wave);
                 if (u.l < nl) chain_unit_b(p, u, lane, first_b, first_off, first_ksc);
             }
+        } else if (p.row0.net_row) {
+            const gv_chain_layer& Ll = p.L[nl - 1];
+            chain_stage_row0(chain_lds, ldk, reinterpret_cast<uint16_t*>(bias_lds + p.ib_lds_off), p.row0, Ll.iaf_z, Ll.iaf_ld, Ll.n >> 1, Ll.t_tile,
+                             m0, p.m);
         } else {
             chain_stage(chain_lds, ldk, p.x, p.ldx, m0, p.m, p.L[0].k, (p.L[0].k + 15) & ~15);
         }
@@ -1446,13 +1500,33 @@ static int made_chain_launch(const uint16_t* x, int ldx, int m, int n_layers, co
 }
 
 /* ALL passes of a MADE's forward (kgvae/flow_network.py:85-98, the loop over the index sets) in one launch: see include/gcnvae.h */
+static int made_chain_fwd_launch(const uint16_t* x, int ldx, const gv_chain_fwd_row0* first, int m, int n_layers, const gv_chain_layer* layers,
+                                 int n_passes, const gv_chain_fwd_pass* passes, void* stream);
 extern "C" int gv_made_chain_fwd(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, int n_passes,
                                  const gv_chain_fwd_pass* passes, void* stream) {
+    return made_chain_fwd_launch(x, ldx, nullptr, m, n_layers, layers, n_passes, passes, stream);
+}
+extern "C" int gv_made_chain_fwd_row0(const gv_chain_fwd_row0* first, int m, int n_layers, const gv_chain_layer* layers, int n_passes,
+                                      const gv_chain_fwd_pass* passes, void* stream) {
+    GV_REQUIRE(first, GV_ERR_NULL, "gv_made_chain_fwd_row0: NULL pointer");
+    return made_chain_fwd_launch(nullptr, 0, first, m, n_layers, layers, n_passes, passes, stream);
+}
+static int made_chain_fwd_launch(const uint16_t* x, int ldx, const gv_chain_fwd_row0* first, int m, int n_layers, const gv_chain_layer* layers,
+                                 int n_passes, const gv_chain_fwd_pass* passes, void* stream) {
     GV_REQUIRE(m >= 0 && n_layers >= 2 && n_layers <= GV_CHAIN_MAX_LAYERS && n_passes >= 1 && n_passes <= CH_MAX_PASSES, GV_ERR_SHAPE,
                "gv_made_chain_fwd: m=%d n_layers=%d n_passes=%d (2-%d layers, 1-%d passes)", m, n_layers, n_passes, GV_CHAIN_MAX_LAYERS, CH_MAX_PASSES);
     if (m == 0) return GV_OK;
-    GV_REQUIRE(x && layers && passes, GV_ERR_NULL, "gv_made_chain_fwd: NULL pointer");
-    GV_REQUIRE(ldx % 8 == 0 && aligned16(x) && ldx >= layers[0].k, GV_ERR_ALIGN, "gv_made_chain_fwd: x rows must be 16-B aligned pieces (ldx=%d)", ldx);
+    GV_REQUIRE((x || first) && layers && passes, GV_ERR_NULL, "gv_made_chain_fwd: NULL pointer");
+    if (first) {
+        const gv_chain_layer& lastL = layers[n_layers - 1];
+        GV_REQUIRE(first->net_row && first->x_f32 && first->x_t && aligned16(first->net_row) && aligned16(first->x_f32) &&
+                       (reinterpret_cast<uintptr_t>(first->x_t) & 7u) == 0, GV_ERR_NULL, "gv_made_chain_fwd_row0: net_row, x_f32, x_t (aligned)");
+        GV_REQUIRE(layers[0].k == lastL.n / 2 && lastL.n % 8 == 0 && lastL.t_tile >= CH_BM * (lastL.n / 2) && (int64_t)m * lastL.iaf_ld * 4 < (1ll << 32),
+                   GV_ERR_SHAPE, "gv_made_chain_fwd_row0: layer 0 reads the d = %d columns of x (k = %d), tiled copy t_tile = %d", lastL.n / 2,
+                   layers[0].k, lastL.t_tile);
+    } else {
+        GV_REQUIRE(ldx % 8 == 0 && aligned16(x) && ldx >= layers[0].k, GV_ERR_ALIGN, "gv_made_chain_fwd: x rows must be 16-B aligned pieces (ldx=%d)", ldx);
+    }
     const gv_chain_layer& last = layers[n_layers - 1];
     const int d = last.n / 2, tiles = (m + CH_BM - 1) / CH_BM;
     ChainArgs p;
@@ -1477,10 +1551,12 @@ extern "C" int gv_made_chain_fwd(const uint16_t* x, int ldx, int m, int n_layers
     const int ldk = chain_ldk(n_layers, layers, &has_mask);
     size_t bias_floats = (size_t)d;
     for (int i = 0; i < n_layers; ++i) bias_floats += (size_t)layers[i].n;
-    const size_t lds = (size_t)2 * CH_BM * ldk * sizeof(uint16_t) + bias_floats * sizeof(float);
+    bias_floats = (bias_floats + 1) & ~(size_t)1;      // (the row-0 stage's block is read in 8-B pieces)
+    const size_t lds = (size_t)2 * CH_BM * ldk * sizeof(uint16_t) + bias_floats * sizeof(float) + (first ? (size_t)IB_COLS * IB_LD * sizeof(uint16_t) : 0);
     GV_REQUIRE(lds <= 160 * 1024, GV_ERR_SHAPE, "gv_made_chain_fwd: layers this wide need %zu B of LDS (160 KB per CU)", lds);
     p.x = x; p.ldx = ldx; p.m = m; p.n_layers = n_layers; p.ldk = ldk; p.has_mask = 0; p.stamps = g_chain_stamps;
     p.ib = gv_chain_iafb{}; p.ib_lds_off = (int)bias_floats; p.ld0 = ldk; p.n_passes = n_passes;
+    p.row0 = first ? *first : gv_chain_fwd_row0{};
     for (int q = 0; q < CH_MAX_PASSES; ++q) p.pass[q] = ChainArgs::Pass{};
     for (int q = 0; q < n_passes; ++q) {
         const gv_chain_fwd_pass& f = passes[q];

@@ -83,6 +83,7 @@ SIGNATURES = {
     'gv_made_chain': (_I, [_P, _I, _I, _I, _P, _P]),
     'gv_made_chain_iafb': (_I, [_P, _I, _I, _P, _P]),
     'gv_made_chain_fwd': (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
+    'gv_made_chain_fwd_row0': (_I, [_P, _I, _I, _P, _I, _P, _P]),
     'gv_made_chain_debug_stamps': (_I, [_P]),
     'gv_made_pack_weight_f32_elems': (_L, [_I, _I]),
     'gv_made_pack_weight_f32_multi': (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),

@@ -451,6 +451,11 @@ class _ChainFwdPass(_ct.Structure):
                 ('act_t', _ct.c_void_p * 8), ('act_bits', _ct.c_void_p * 8), ('flags', _ct.c_int32), ('reserved', _ct.c_int32)]
 
 
+class _ChainFwdRow0(_ct.Structure):
+    """gv_chain_fwd_row0 of include/gcnvae.h."""
+    _fields_ = [('net_row', _ct.c_void_p), ('x_f32', _ct.c_void_p), ('x_t', _ct.c_void_p)]
+
+
 class _RowLayer(_ct.Structure):
     """gv_row_layer of include/gcnvae.h."""
     _fields_ = [('w', _ct.c_void_p), ('bias', _ct.c_void_p), ('act', _ct.c_void_p), ('inp', _ct.c_void_p), ('out', _ct.c_void_p),
@@ -602,12 +607,15 @@ def made_chain(x, m, layers, tag=None, stage=None):
     lib.call('gv_made_chain', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), lib.stream(), tag=tag)
 
 
-def made_chain_fwd(x, m, layers, passes, tag=None):
+def made_chain_fwd(x, m, layers, passes, tag=None, row0=None):
     """ALL passes of a MADE's forward in one launch (gv_made_chain_fwd).  layers: what made_chain takes for ONE pass (the first
     pass's dicts: strides and shared fields are read from them); passes: per pass dict(x_old, colcount, ex, x_new=None, alpha=None,
-    keep=None, out_bf16=None, out_bf16_t=None, act_t=[...], act_bits=[...]) -- the pointers that differ from pass to pass."""
+    keep=None, out_bf16=None, out_bf16_t=None, act_t=[...], act_bits=[...]) -- the pointers that differ from pass to pass.
+    row0 (x = None then): dict(net_row, x_f32, x_t) -- pass 0's update as the launch's first stage (gv_made_chain_fwd_row0)."""
     if tag is not None and lib.TIMER is not None:
-        dd, nb = int(layers[-1]['n']) // 2, 2 * int(layers[0]['k']) * int(m)        # x: read for the first pass alone
+        dd = int(layers[-1]['n']) // 2
+        # x: read for the first pass alone -- or made from z by the row-0 stage (z read, x written as fp32 and as its tiled copy)
+        nb = (2 * int(layers[0]['k']) if row0 is None else (4 + 4 + 2) * dd) * int(m)
         for e in passes:
             nb += sum(2 * int(d['n']) * int(m) + 4 * ((int(d['n']) + 31) // 32) * int(m) for d in layers[:-1])      # tiled copies + sign words
             nb += 4 * dd * int(m) * (1 + 1 + (e.get('alpha') is not None))                                         # z read, ex (alpha) written
@@ -622,6 +630,12 @@ def made_chain_fwd(x, m, layers, passes, tag=None):
         for l, (t, b) in enumerate(zip(d['act_t'], d['act_bits'])):
             c.act_t[l], c.act_bits[l] = ptr(t), ptr(b)
         c.flags = 1 if d.get('reverse_x_new') else 0
+    if row0 is not None:
+        f = _ChainFwdRow0()
+        f.net_row, f.x_f32, f.x_t = ptr(row0['net_row']), ptr(row0['x_f32']), ptr(row0['x_t'])
+        lib.call('gv_made_chain_fwd_row0', _ct.addressof(f), int(m), len(layers), _ct.addressof(arr), len(passes), _ct.addressof(tab),
+                 lib.stream(), tag=tag)
+        return
     lib.call('gv_made_chain_fwd', ptr(x), x.stride(0), int(m), len(layers), _ct.addressof(arr), len(passes), _ct.addressof(tab), lib.stream(),
              tag=tag)
 
@@ -1054,7 +1068,12 @@ class _MADEForwardBF16(torch.autograd.Function):
                          n, d, st)
             else:
                 lib.call('gv_iaf_update_fwd', ptr(z), ptr(net), ld_net, ptr(x_old), ptr(cc), ptr(x_out), n, d, st)
-        update(acts0[L - 1], 0, z, colcount[0], 0)
+        # pass 0's update: the first stage of the forward passes launch where that launch runs (gv_made_chain_fwd_row0), else its own launch
+        per_launch = MADE_FWD_PASSES or (6 if len(_made_row_blocks(n)) == 1 else 3)
+        fwd_loop = fused and tiled and L > 1 and d % 8 == 0 and per_launch > 1 and S > 0
+        row0_in_launch = fwd_loop and MADE_FWD_ROW0 and n * xin.stride(0) * 4 < (1 << 32) and acts0[L - 1].is_contiguous()
+        if not row0_in_launch:
+            update(acts0[L - 1], 0, z, colcount[0], 0)
 
         folded = [False]           # the last pass stored x_out reversed already
 
@@ -1067,8 +1086,7 @@ class _MADEForwardBF16(torch.autograd.Function):
                 # the pass's IAF update in the last layer's epilogue: x_new and its operand copies leave the chain
                 head = dict(w_packed=wbf[L - 1], n=widths[L - 1], k=ws[L - 1].shape[1], bias=bs[L - 1],
                             iaf=dict(z=z[r0:r1], x_old=xin[a:b], colcount=colcount[p], ex=net_out[a:b]))
-                per_launch = MADE_FWD_PASSES or (6 if len(_made_row_blocks(n)) == 1 else 3)
-                if per_launch > 1 and tiled and L > 1 and d % 8 == 0:
+                if fwd_loop:
                     # ... for up to six passes in ONE launch (gv_made_chain_fwd): a workgroup keeps its 64 rows, x_new stays in LDS
                     # as the next pass's input; its row-major bf16 copy goes to memory only behind the last pass of a launch
                     grp = [p] + todo[:per_launch - 1]
@@ -1087,9 +1105,10 @@ class _MADEForwardBF16(torch.autograd.Function):
                             folded[0] = reverse_out
                         tab.append(e)
                     head.update(out_bf16=xin_b[a:b], **t_of(xin_t, p, r0))          # (strides / tile size of x_new's copies)
-                    made_chain_fwd(xin_b[a:b], r1 - r0,
+                    first = dict(net_row=acts0[L - 1], x_f32=xin[r0:r1], x_t=xin_t[r0 // 64:]) if (row0_in_launch and p == 1) else None
+                    made_chain_fwd(xin_b[a:b] if first is None else None, r1 - r0,
                                    [dict(w_packed=wbf[l], n=widths[l], k=ws[l].shape[1], bias=bs[l], relu=True, out_bits=sign[l][a:b],
-                                         **t_of(acts_t[l], p - 1, r0)) for l in range(L - 1)] + [head], tab, tag='madechain_fwd')
+                                         **t_of(acts_t[l], p - 1, r0)) for l in range(L - 1)] + [head], tab, tag='madechain_fwd', row0=first)
                     continue
                 if p < S:   # fp32 x_new only where the next pass hands a column through; its operands in bf16
                     head['iaf'].update(x_new=xin[na:nb_], keep=colcount[p + 1])
@@ -1381,6 +1400,7 @@ MADE_CHAIN_PASSES = max(1, min(6, int(_os.environ.get('GV_MADE_CHAIN_PASSES', '1
 # passes run over two row blocks (WN18RR, 640 tiles on 512 slots: the second round of workgroups lasts as long as a launch does --
 # 5.18 ms per pass-launch, 5.05 / 4.99 / 5.11 with two / three / all passes per launch)
 MADE_FWD_PASSES = max(0, min(6, int(_os.environ.get('GV_MADE_FWD_PASSES', '0'))))
+MADE_FWD_ROW0 = _os.environ.get('GV_MADE_FWD_ROW0', '1') == '1'      # ... with pass 0's update as that launch's first stage
 MADE_CHAIN_IAFB = _os.environ.get('GV_MADE_CHAIN_IAFB', '1') == '1'    # ... and its backward as the backward chain's first stage
 MADE_T_TILES = _os.environ.get('GV_MADE_T_TILES', '1') == '1'          # ... and the transposed copies in tiles of 64 rows
 

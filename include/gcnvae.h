@@ -380,6 +380,14 @@ typedef struct gv_chain_fwd_pass {
 } gv_chain_fwd_pass;
 int gv_made_chain_fwd(const uint16_t* x, int ldx, int m, int n_layers, const gv_chain_layer* layers, int n_passes,
                       const gv_chain_fwd_pass* passes, void* stream);
+/* ... with PASS 0's update as the launch's first stage instead of an input x: the net's output of pass 0 is one row (the MADE of a zero
+ * input), net_row = [mu | alpha] (2 d fp32), every column's count is positive: x = z * expf(alpha + mu) -- the arithmetic of
+ * gv_iaf_update_fwd_bf16_tiles on a broadcast row -- goes as bf16 straight into layer 0's LDS tile, as fp32 to x_f32 ([m][iaf_ld]:
+ * what passes[0].x_old points at) and as the tiled transposed bf16 copy to x_t (the last layer's t_tile; rows past m: zeros).
+ * z, iaf_ld and t_tile are the last layer's; layers[0].k == d. */
+typedef struct gv_chain_fwd_row0 { const float* net_row; float* x_f32; uint16_t* x_t; } gv_chain_fwd_row0;
+int gv_made_chain_fwd_row0(const gv_chain_fwd_row0* first, int m, int n_layers, const gv_chain_layer* layers, int n_passes,
+                           const gv_chain_fwd_pass* passes, void* stream);
 /* probes only: a device buffer of 8 x 64 int32 that workgroup 0's waves of the following gv_made_chain launches fill with
  * s_memtime stamps (tools/probes/chain_stamps.py); NULL (the default) switches it off */
 int gv_made_chain_debug_stamps(int32_t* buffer);
