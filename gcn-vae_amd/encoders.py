@@ -200,17 +200,20 @@ class KGVAE(ops.StayOnDevice, nn.Module):
         if ride_along:
             z = ops.cat_rows(z, self._prior_draw(z.device, z.dtype))      # (kernel copies: no memcpy node in a captured step)
         log_dets, flows, i = [], list(self.nf), 0
-        while i < len(flows):
-            flow = flows[i]
-            if isinstance(flow, MADE):            # PermuteLayer contributes zeros
-                # (a PermuteLayer behind the block rides in the block's last launch: the columns come out reversed)
-                fold = i + 1 < len(flows) and type(flows[i + 1]) is PermuteLayer
-                z, log_det = flow.forward(z, reverse_out=fold)
-                log_dets.append(log_det)
-                i += 2 if fold else 1
-            else:
-                z, log_det = flow.forward(z)
-                i += 1
+        # (the bf16 MADE nodes' row blocks stay forked from the first block to the last: ops.made.keep_row_blocks_forked)
+        with ops.made.keep_row_blocks_forked(z.shape[0]):
+            while i < len(flows):
+                flow = flows[i]
+                if isinstance(flow, MADE):            # PermuteLayer contributes zeros
+                    # (a PermuteLayer behind the block rides in the block's last launch: the columns come out reversed)
+                    fold = i + 1 < len(flows) and type(flows[i + 1]) is PermuteLayer
+                    z, log_det = flow.forward(z, reverse_out=fold)
+                    log_dets.append(log_det)
+                    i += 2 if fold else 1
+                else:
+                    ops.made.fork_sync()
+                    z, log_det = flow.forward(z)
+                    i += 1
         if ride_along:      # (ops.split_rows: the slices' backward without a memcpy node in a captured step)
             z, self._z_pri_flowed = ops.split_rows(z, n)
         if want_mean and 1 <= len(log_dets) <= 8:     # flow_log_prob in ONE launch (and one in backward) instead of adds + mask + sum + divide

@@ -14,6 +14,7 @@ points of csrc/k_made.hip, k_chain.hip, k_chain32.hip, k_gradw32.hip, k_row.hip 
 Part of the ``ops`` namespace (ops re-exports everything here: callers keep writing ops.made_forward); the knobs of this file
 (MADE_*, GRADW_SPLIT_MAX, ...) are THIS module's globals.
 """
+import contextlib
 import ctypes as _ct
 import os as _os
 
@@ -1021,11 +1022,14 @@ class _MADEForwardBF16(torch.autograd.Function):
         # what depends on the parameters alone (mask fold, bf16 / fragment-packed weights, pass 0's row): done ahead on a side stream
         # where the model announced this call (made_prepare), here otherwise
         prep = _made_prep.pop(_made_prep_key(ws, d, S), None)
+        prep_was_ready = prep is not None and prep['joined'][0]
         if prep is not None:
             if not prep['joined'][0]:       # ONE join for everything that was prepared (a cross-stream edge costs a replayed graph 20-40 us)
+                fork_sync()
                 torch.cuda.current_stream().wait_event(prep['done'])
                 prep['joined'][0] = True
         else:
+            fork_sync()
             prep = _made_params_work(masks, ws, bs, d, S)
         ws, chain, fused, wbf, wbt, row, acts0, zero_row = (prep[k_] for k_ in ('ws', 'chain', 'fused', 'wbf', 'wbt', 'row', 'acts0', 'zero_row'))
         widths = [w.shape[0] for w in ws]                       # layer output widths; inputs: d, then widths[:-1]
@@ -1072,6 +1076,10 @@ class _MADEForwardBF16(torch.autograd.Function):
         per_launch = MADE_FWD_PASSES or (6 if len(_made_row_blocks(n)) == 1 else 3)
         fwd_loop = fused and tiled and L > 1 and d % 8 == 0 and per_launch > 1 and S > 0
         row0_in_launch = fwd_loop and MADE_FWD_ROW0 and n * xin.stride(0) * 4 < (1 << 32) and acts0[L - 1].is_contiguous()
+        # the row blocks stay forked over the whole flow stack where nothing of this node runs over all rows but the log-det row sums
+        kept = _FORK is not None and _FORK['n'] == n and row0_in_launch and prep_was_ready
+        if not kept:
+            fork_sync()
         if not row0_in_launch:
             update(acts0[L - 1], 0, z, colcount[0], 0)
 
@@ -1119,7 +1127,7 @@ class _MADEForwardBF16(torch.autograd.Function):
                                                       out_bits=sign[l][a:b], **t_of(acts_t[l], p - 1, r0)) for l in range(L - 1)] + [head],
                            tag='madechain_fwd')
         if fused:
-            _by_row_blocks(fused_passes, n, None if tiled else 1)
+            _by_row_blocks(fused_passes, n, None if tiled else 1, keep_forked=kept)
         for p in range(1, P) if not fused else ():
             sl = slice((p - 1) * n, p * n)
             tsl = slice((p - 1) * npad, (p - 1) * npad + n)
@@ -1138,16 +1146,21 @@ class _MADEForwardBF16(torch.autograd.Function):
                 gemm_bf16_nt(inp, wbf[L - 1], n, widths[L - 1], ws[L - 1].shape[1], bias=bs[L - 1], c_f32=net_out[sl])
             update(net_out[sl], 2 * d, xin[sl], colcount[p], p)
         log_det = torch.empty(n, **f32)
-        if P > 1 and fused:
+        if kept:        # (over all rows: behind the stack's one join)
+            _FORK['deferred'].append(lambda: lib.call('gv_rowsum', ptr(alpha_last), d, 0, d, ptr(log_det), n, lib.stream()))
+        elif P > 1 and fused:
             lib.call('gv_rowsum', ptr(alpha_last), d, 0, d, ptr(log_det), n, st)
         elif P > 1:
             lib.call('gv_rowsum', ptr(net_out[(S - 1) * n:]), 2 * d, d, d, ptr(log_det), n, st)
         else:
             log_det = acts0[L - 1][:, d:].sum(dim=1).expand(n).contiguous()
         if reverse_out and not folded[0]:
+            fork_sync()
             rev = torch.empty_like(x_out)
             lib.call('gv_reverse_cols', ptr(x_out), ptr(rev), n, d, st)
             x_out = rev
+        if kept:
+            _FORK['hold'].append(dict(locals()))       # nothing of this node is handed back to the allocator before the join
         ctx.reverse_out = reverse_out
         ctx.save_for_backward(z, colcount, xin_t, zero_row, net_out, *(sign if fused else acts_b), *acts_t, *acts0, *wbt, *ws)
         ctx.L = L
@@ -1440,10 +1453,81 @@ def _made_row_blocks(n, want=None, min_tiles=None):
     return [(cuts[i], cuts[i + 1]) for i in range(k)]
 
 
-def _by_row_blocks(run, n, want, min_tiles=None):
+# ONE fork and ONE join of the row blocks per flow STACK (forward): everything between two bf16 MADE nodes of an IAF stack is row-local
+# once the PermuteLayer and pass 0's update ride in the nodes' launches, so a block's launches of node k + 1 depend on the same block's
+# launches of node k alone -- the side streams stay forked from the first node to the last, the log-det row sums (the only launches
+# over all rows) run behind the one join.  A cross-stream edge costs a replayed graph 20-40 us; three IAF blocks had six per direction.
+# Temporaries of the nodes are kept until the join (a freed buffer could otherwise be handed to another block's stream).
+_FORK = None
+MADE_KEEP_FORKED = _os.environ.get('GV_MADE_KEEP_FORKED', '1') == '1'
+
+
+@contextlib.contextmanager
+def keep_row_blocks_forked(n):
+    """Around the MADE forward calls of one flow stack on n rows (encoders.KGVAE._apply_flows)."""
+    global _FORK
+    layout = _ops.launch_layout()
+    blocks = _made_row_blocks(n) if layout.row_blocks else [(0, n)]
+    if len(blocks) == 1 or layout.process_group or not MADE_KEEP_FORKED or _FORK is not None or _ops.GEMM_PRECISION != 'bf16':
+        yield
+        return
+    join_prepared()                           # (parameter-only work of every node: joined once, in front of the fork)
+    main = torch.cuda.current_stream()
+    sides = [_side(('made_rows', i)) for i in range(1, len(blocks))]
+    for sd in sides:
+        sd.wait_stream(main)
+    _FORK = dict(n=n, blocks=blocks, sides=sides, hold=[], deferred=[], main=main, open=True)
+    try:
+        yield
+    finally:
+        st, _FORK = _FORK, None
+        _fork_join(st)
+        for fn in st['deferred']:
+            fn()
+        st['hold'].clear()
+
+
+def _fork_join(st):
+    if st['open']:
+        for sd in st['sides']:
+            st['main'].wait_stream(sd)
+        st['open'] = False
+
+
+def fork_sync():
+    """Something that is not row-blocked is about to read what the blocks wrote: join now (and fork again behind it)."""
+    if _FORK is not None and _FORK['open']:
+        _fork_join(_FORK)
+
+
+def _fork_reopen():
+    if _FORK is not None and not _FORK['open']:
+        for sd in _FORK['sides']:
+            sd.wait_stream(_FORK['main'])
+        _FORK['open'] = True
+
+
+def join_prepared():
+    """Wait (once) for the parameter-only work made_prepare left on its side stream."""
+    for prep in _made_prep.values():
+        if not prep['joined'][0]:
+            torch.cuda.current_stream().wait_event(prep['done'])
+            prep['joined'][0] = True
+        break
+
+
+def _by_row_blocks(run, n, want, min_tiles=None, keep_forked=False):
     """run(r0, r1) over the row blocks of _made_row_blocks (want: how many, None: MADE_ROW_BLOCKS; <= 1: all rows at once): the
     first on the current stream, the others on side streams that are joined before returning (under hipGraph capture: parallel
     branches)."""
+    if keep_forked and _FORK is not None and _FORK['n'] == n and want is None and min_tiles is None:
+        _fork_reopen()
+        run(*_FORK['blocks'][0])
+        for sd, blk in zip(_FORK['sides'], _FORK['blocks'][1:]):
+            with torch.cuda.stream(sd):
+                run(*blk)
+        return
+    fork_sync()
     blocks = _made_row_blocks(n, want, min_tiles) if _ops.launch_layout().row_blocks else [(0, n)]      # (timed launches are whole launches: bench.py's K4 line)
     if len(blocks) == 1:
         run(0, n)

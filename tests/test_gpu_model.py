@@ -724,7 +724,7 @@ def test_made_passes_over_row_blocks_on_their_own_streams_give_the_same_bits(mon
     z = torch.randn(n, d, generator=torch.Generator().manual_seed(5)).cuda()
     res, seen = [], []
     inner = made._by_row_blocks
-    monkeypatch.setattr(made, '_by_row_blocks', lambda run, rows, want, *a: (seen.append((rows, want is None)), inner(run, rows, want, *a))[1])
+    monkeypatch.setattr(made, '_by_row_blocks', lambda run, rows, want, *a, **k: (seen.append((rows, want is None)), inner(run, rows, want, *a, **k))[1])
     for k in (1, blocks):
         monkeypatch.setattr(made, 'MADE_ROW_BLOCKS', k)
         monkeypatch.setattr(made, 'MADE_ROW_BLOCKS_MIN_TILES', 1)
@@ -972,6 +972,59 @@ def test_flow_parameter_work_prepared_beside_the_encoder_gives_the_same_bits(mon
     assert res[0][2].keys() == res[1][2].keys() and any('nf' in k for k in res[0][2])
     for k in res[0][2]:
         assert torch.equal(res[0][2][k], res[1][2][k]), k
+
+
+@pytest.mark.gpu
+def test_row_blocks_kept_forked_over_the_flow_stack_give_the_same_bits(monkeypatch):
+    """made.keep_row_blocks_forked (KGVAE._apply_flows): the bf16 MADE nodes of a three-block IAF stack run their row blocks on side
+    streams that stay forked from the first node to the last -- one fork, one join, the log-det row sums behind it, every node's
+    temporaries held until then -- against a fork and a join per node: embedding, loss and every gradient of two
+    consecutive steps bit for bit (the captured step: bench.py --config c3, whose parity leg runs it against the oracle)."""
+    from gcn_vae_amd import made, ops, sampling
+    from gcn_vae_amd.data import synthetic_kg
+    from gcn_vae_amd.encoders import KGVAE
+    from gcn_vae_amd.train import LinkPredict
+    n, n_rel, h = 1000, 8, 16
+    data = synthetic_kg(n, n_rel, 6000, seed=1)
+    g, rel, node_norm = sampling.build_test_graph(n, n_rel, data.train)
+    _, dst = g.edges()
+    node_id = torch.arange(n, device='cuda').view(-1, 1)
+    et = torch.from_numpy(rel).cuda()
+    enorm = torch.from_numpy(node_norm).cuda()[dst.cuda()].view(-1, 1).contiguous()
+    np.random.seed(0)
+    samples, labels = sampling.negative_sampling(data.train[:500], n, 3)
+    trip, lab = torch.from_numpy(samples).cuda(), torch.from_numpy(labels).cuda()
+    eps = torch.randn(n, h, generator=torch.Generator().manual_seed(1)).cuda()
+    monkeypatch.setattr(made, 'MADE_ROW_BLOCKS', 2)
+    monkeypatch.setattr(made, 'MADE_ROW_BLOCKS_MIN_TILES', 1)
+    joins = []
+    inner = made._fork_join
+    monkeypatch.setattr(made, '_fork_join', lambda st: (joins.append(st['open']), inner(st))[1])
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(made, 'MADE_KEEP_FORKED', on)
+        torch.manual_seed(0)
+        net = LinkPredict(KGVAE, n, h, n_rel, num_bases=4, num_hidden_layers=2, dropout=0.0, use_cuda=True, reg_param=0.01,
+                          kl_param=1e-3, mmd_param=0.0, k=4, n_flows=3).cuda().train()
+        net.encoder.eps_override = eps
+        del joins[:]
+        outs = []
+        with ops.gemm_precision('bf16'):
+            for _ in range(2):
+                net.zero_grad(set_to_none=True)
+                embed = net(g, node_id, et, enorm)
+                loss = net.get_loss(g, embed, trip, lab)[0]
+                loss.backward()
+                torch.cuda.synchronize()
+                outs.append((embed.detach().clone(), loss.detach().clone(),
+                             {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+        assert (joins == [True, True]) if on else not joins, joins          # one join of the kept fork per forward pass
+        assert made._FORK is None and not made._made_prep
+        res.append(outs)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2].keys() == b[2].keys() and any('nf' in k for k in a[2])
+        for k in a[2]:
+            assert torch.equal(a[2][k], b[2][k]), k
 
 
 @pytest.mark.gpu
