@@ -652,10 +652,51 @@ __global__ __launch_bounds__(1024) void k_splitk_sum(const float* __restrict__ p
     else out2[i - mn] += s;
 }
 
+// ... four consecutive outputs per lane (16-B loads: a wave reads 1 KB of a partial at a time instead of 256 B; the same splits per
+// wave and the same order of additions per output as above: bit-identical).  mn, stride, m2 multiples of 4, 16-B aligned operands.
+__global__ __launch_bounds__(1024) void k_splitk_sum4(const float* __restrict__ partial, int splits, size_t mn, size_t stride, float* out,
+                                                      int accumulate, size_t m2, float* out2) {
+    __shared__ float4 share[16][64];
+    const size_t total = mn + (out2 ? m2 : 0);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int per = (splits + nw - 1) / nw, z0 = w * per, z1 = min(splits, z0 + per);
+    const size_t i = ((size_t)blockIdx.x * 64 + lane) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < total) {
+        int z = z0;
+        for (; z + 8 <= z1; z += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(partial + (size_t)(z + j) * stride + i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+        }
+        for (; z < z1; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)z * stride + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    if (nw > 1) {
+        share[w][lane] = s;
+        __syncthreads();
+        if (w != 0) return;
+        for (int j = 1; j < nw; ++j) { const float4 v = share[j][lane]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    }
+    if (i >= total) return;
+    float4* o = reinterpret_cast<float4*>(i < mn ? out + i : out2 + (i - mn));
+    if (i < mn ? accumulate != 0 : true) { const float4 v = *o; s.x = v.x + s.x; s.y = v.y + s.y; s.z = v.z + s.z; s.w = v.w + s.w; }
+    *o = s;
+}
 static void launch_splitk_sum(hipStream_t st, const float* partial, int splits, size_t mn, size_t stride, float* out, int accumulate,
                               size_t m2, float* out2) {
     const size_t total = mn + (out2 ? m2 : 0);
     const int nw = splits >= 64 ? 16 : splits >= 16 ? 4 : 1;      // ~>= 4 partials per wave
+    static const bool wide = !(getenv("GV_SPLITK_SUM4") && getenv("GV_SPLITK_SUM4")[0] == '0');
+    if (wide && mn % 4 == 0 && stride % 4 == 0 && (!out2 || m2 % 4 == 0) && aligned16(partial) && aligned16(out) && (!out2 || aligned16(out2))) {
+        hipLaunchKernelGGL(k_splitk_sum4, dim3((unsigned)((total / 4 + 63) / 64)), dim3(64 * nw), 0, st, partial, splits, mn, stride, out, accumulate,
+                           m2, out2);
+        return;
+    }
     hipLaunchKernelGGL(k_splitk_sum, dim3((unsigned)((total + 63) / 64)), dim3(64 * nw), 0, st, partial, splits, mn, stride, out, accumulate,
                        m2, out2);
 }
