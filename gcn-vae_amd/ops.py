@@ -127,6 +127,24 @@ def join(*ids):
 # the mini-batch step 0.98 -> 1.11).
 BWD_SIDE = _os.environ.get('GV_BWD_SIDE', '1') == '1'
 _bwd_side_held = []
+# ... the R-GCN layers' weight gradients too (round 4, with the arena targets): 'auto' = where the layer is large and the side stream
+# carries nothing else in this backward pass -- measured per step: h = 500 3.41 -> 3.28 ms, 1 M nodes / 50 M edges 81.4 -> 78.9,
+# FB15k-237 size 1.026 -> 1.020; NOT the mini-batch graph (20 000 edges: 0.967 -> 1.006) and not behind IAF blocks, whose weight-gradient
+# products already run there (WN18RR + 3 IAF 4.98 -> 5.19, mini-batch + 3 IAF fp32 5.03 -> 5.15).  '0' / '1': never / wherever possible.
+RGCN_BWD_SIDE = _os.environ.get('GV_RGCN_BWD_SIDE', 'auto')
+RGCN_BWD_SIDE_MIN_WORK = 10 ** 8       # edges x widest side of the layer
+
+
+_bwd_side_others = [False]     # something other than an R-GCN layer put work on the side stream in this backward pass
+
+
+def rgcn_bwd_side(num_edges, width):
+    layout = launch_layout()
+    if not layout.bwd_side or layout.process_group:      # (under a process group the arena feeds collectives started inside the pass)
+        return False
+    if RGCN_BWD_SIDE == 'auto':
+        return not _bwd_side_others[0] and num_edges * width >= RGCN_BWD_SIDE_MIN_WORK
+    return RGCN_BWD_SIDE == '1'
 
 
 @dataclass(frozen=True)
@@ -163,7 +181,7 @@ def _process_group():
 
 
 @contextlib.contextmanager
-def backward_side(enabled, *held):
+def backward_side(enabled, *held, rgcn=False):
     """Inside an autograd backward: run the enclosed launches on the side stream (after everything already enqueued); ``held``:
     the tensors they touch.  Yields whether the side stream is in use."""
     if not (enabled and launch_layout().bwd_side):      # (timed launches run alone: bench.py's per-kernel lines)
@@ -181,6 +199,8 @@ def backward_side(enabled, *held):
         yield True
     first = not _bwd_side_held
     _bwd_side_held.append(held)
+    if not rgcn:
+        _bwd_side_others[0] = True
     if first:
         def _join():
             if not _bwd_side_held:      # joined already (in front of a collective: backward_side_finish)
@@ -192,6 +212,7 @@ def backward_side(enabled, *held):
             if cur != main:
                 cur.wait_stream(side)
             _bwd_side_held.clear()
+            _bwd_side_others[0] = False
         torch.autograd.Variable._execution_engine.queue_callback(_join)
 
 
@@ -201,6 +222,7 @@ def backward_side_finish():
     if _bwd_side_held:
         torch.cuda.current_stream().wait_stream(_side('bwd'))
         _bwd_side_held.clear()
+        _bwd_side_others[0] = False
 
 
 class StayOnDevice:
@@ -920,8 +942,18 @@ class _RelGraphConvBdd(torch.autograd.Function):
             g_agg = copy_of(g)
             pending = reduce_hook(g_agg)
         grad_loop = gx_loop = None
+        # the layer's two weight gradients (stored straight into the optimiser's arena: nothing in this backward pass reads them)
+        # on the side stream, beside the dL/dx path -- where that pays (RGCN_BWD_SIDE)
+        side_w = reduce_hook is None and d_l is not None and d_w is not None and loop_weight is not None \
+            and ctx.needs_input_grad[3] and ctx.needs_input_grad[1] and rgcn_bwd_side(gidx.num_edges, max(x.shape[1], g.shape[1]))
+        if side_w:
+            with backward_side(True, x, g, g_agg, weight, coef, rgcn=True):
+                gemm(x, g, trans_a=True, split_k=pick_split_k(x.shape[1], g.shape[1], x.shape[0]), out=d_l, accumulate=True)
+                static = not gidx.sync_free and coef is not None
+                coef_r, idx_r = (ridx.coef_in_rel_order(coef), None) if static else (coef, ridx.by_rel.perm)
+                bdd_grad_weight(ridx.by_rel.seg, ridx.src_by_rel, ridx.dst_by_rel, coef_r, idx_r, x, g_agg, nb, si, so, out=d_w, accumulate=True)
         if loop_weight is not None:
-            if ctx.needs_input_grad[3]:
+            if ctx.needs_input_grad[3] and not side_w:
                 grad_loop = gemm(x, g, trans_a=True, split_k=pick_split_k(x.shape[1], g.shape[1], x.shape[0]),
                                  out=d_l, accumulate=d_l is not None)
                 if d_l is not None:
@@ -985,7 +1017,7 @@ class _RelGraphConvBdd(torch.autograd.Function):
             lib.call('gv_axpby', grad_x.numel(), None, 1.0, ptr(grad_x), 1.0, ptr(x_add), lib.stream())
             grad_x = None
         grad_w = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not side_w:
             static = not gidx.sync_free and coef is not None
             coef_r, idx_r = (ridx.coef_in_rel_order(coef), None) if static else (coef, ridx.by_rel.perm)
             grad_w = bdd_grad_weight(ridx.by_rel.seg, ridx.src_by_rel, ridx.dst_by_rel, coef_r, idx_r, x,

@@ -1028,6 +1028,65 @@ def test_row_blocks_kept_forked_over_the_flow_stack_give_the_same_bits(monkeypat
 
 
 @pytest.mark.gpu
+def test_rgcn_weight_gradients_on_the_backward_side_stream_give_the_same_bits(monkeypatch):
+    """ops.rgcn_bwd_side: with FlatAdam registered the R-GCN layers' block-weight and self-loop-weight gradients are stored into the
+    arena on the backward side stream, beside the dL/dx path (joined when the backward pass has run): every gradient and the
+    weights after a clipped Adam step bit for bit as with everything on one stream; 'auto' takes the side stream for a large layer
+    alone and not behind IAF blocks (their weight-gradient products run there)."""
+    from gcn_vae_amd import ops, sampling
+    from gcn_vae_amd.data import synthetic_kg
+    from gcn_vae_amd.encoders import KGVAE
+    from gcn_vae_amd.optim import FlatAdam
+    from gcn_vae_amd.train import LinkPredict
+    n, n_rel, h = 500, 8, 16
+    data = synthetic_kg(n, n_rel, 4000, seed=0)
+    g, rel, node_norm = sampling.build_test_graph(n, n_rel, data.train)
+    _, dst = g.edges()
+    node_id = torch.arange(n, device='cuda').view(-1, 1)
+    et = torch.from_numpy(rel).cuda()
+    enorm = torch.from_numpy(node_norm).cuda()[dst.cuda()].view(-1, 1).contiguous()
+    np.random.seed(0)
+    samples, labels = sampling.negative_sampling(data.train[:500], n, 3)
+    trip, lab = torch.from_numpy(samples).cuda(), torch.from_numpy(labels).cuda()
+    eps = torch.randn(n, h, generator=torch.Generator().manual_seed(1)).cuda()
+    taken = []
+    inner = ops.backward_side
+
+    def spy(enabled, *held, **kw):
+        if kw.get('rgcn'):
+            taken.append(True)
+        return inner(enabled, *held, **kw)
+    monkeypatch.setattr(ops, 'backward_side', spy)
+    res = []
+    for mode, flows, work, expect in (('0', 0, 1, 0), ('1', 0, 1, 2), ('auto', 0, 1, 2), ('auto', 0, 10 ** 12, 0), ('auto', 2, 1, 0), ('0', 2, 1, 0)):
+        monkeypatch.setattr(ops, 'RGCN_BWD_SIDE', mode)
+        monkeypatch.setattr(ops, 'RGCN_BWD_SIDE_MIN_WORK', work)
+        del taken[:]
+        torch.manual_seed(0)
+        net = LinkPredict(KGVAE, n, h, n_rel, num_bases=4, num_hidden_layers=2, dropout=0.0, use_cuda=True, reg_param=0.01,
+                          kl_param=1e-3, mmd_param=0.0, k=4, n_flows=flows).cuda().train()
+        net.encoder.eps_override = eps
+        opt = FlatAdam([p for p in net.parameters() if p.requires_grad], lr=1e-2, max_grad_norm=1.0)
+        opt.zero_grad()
+        embed = net(g, node_id, et, enorm)
+        net.get_loss(g, embed, trip, lab)[0].backward()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+        opt.step()
+        torch.cuda.synchronize()
+        assert len(taken) == expect, (mode, flows, work, taken)        # both R-GCN layers, or neither
+        res.append((flows, grads, {k: p.detach().clone() for k, p in net.named_parameters()}))
+        opt.close()
+    for flows, grads, weights in res[1:]:
+        ref = res[0] if flows == 0 else res[-1]
+        assert grads.keys() == ref[1].keys() and any('loop_weight' in k for k in grads)
+        for k in grads:
+            assert torch.equal(grads[k], ref[1][k]), k
+        for k in weights:
+            assert torch.equal(weights[k], ref[2][k]), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('precision', ['bf16', 'f32'])
 def test_made_gradients_written_straight_into_the_optimiser_arena_equal_autograd(precision):
     """With FlatAdam registered, the MADE nodes' (bf16 and fp32) masked weight gradients and bias gradients are stored straight into
