@@ -2044,9 +2044,12 @@ class _LossHead(torch.autograd.Function):
         lib.call('gv_bce_grad', ptr(score), ptr(labels), ptr(g), ptr(dscore), ptr(tidx.pos3),
                  ptr(d_inc) if tidx.pos3 is not None else None, ptr(d_rel) if tidx.pos3 is not None else None,
                  ptr(dbias), ptr(ws), T, st)
-        bdd_grad_weight(tidx.rel, tidx.rel_s, tidx.rel_o, d_rel, idx_rel, z, z, h, 1, 1, out=g_w,
-                        accumulate=d_w is not None)
-        lib.call('gv_axpby', w_rel.numel(), ptr(g), 2.0 * reg_w / w_rel.numel(), ptr(w_rel), 1.0, ptr(g_w), st)
+        # the relation-side gradient (an arena target: nothing in this backward pass reads it) beside the node-side one
+        side_rel = d_w is not None and _os.environ.get('GV_TMP_DEC_SIDE', '0') == '1' and rgcn_bwd_side(10 ** 9, 1)
+        with backward_side(side_rel, z, d_rel, idx_rel, w_rel, g, g_w, rgcn=True) if side_rel else contextlib.nullcontext():
+            bdd_grad_weight(tidx.rel, tidx.rel_s, tidx.rel_o, d_rel, idx_rel, z, z, h, 1, 1, out=g_w,
+                            accumulate=d_w is not None)
+            lib.call('gv_axpby', w_rel.numel(), ptr(g), 2.0 * reg_w / w_rel.numel(), ptr(w_rel), 1.0, ptr(g_w), lib.stream())
         join(1)
         g_z = bdd_aggregate(tidx.inc, tidx.inc_other, tidx.inc_rel, d_inc, idx_inc, z, w_rel, h, 1, 1,
                             addend=gz)
