@@ -131,6 +131,7 @@ _bwd_side_held = []
 # carries nothing else in this backward pass -- measured per step: h = 500 3.41 -> 3.28 ms, 1 M nodes / 50 M edges 81.4 -> 78.9,
 # FB15k-237 size 1.026 -> 1.020; NOT the mini-batch graph (20 000 edges: 0.967 -> 1.006) and not behind IAF blocks, whose weight-gradient
 # products already run there (WN18RR + 3 IAF 4.98 -> 5.19, mini-batch + 3 IAF fp32 5.03 -> 5.15).  '0' / '1': never / wherever possible.
+# (The decoder's relation-side gradient the same way: 1.020 -> 1.048 ms -- a 24-us launch does not carry its fork and join.)
 RGCN_BWD_SIDE = _os.environ.get('GV_RGCN_BWD_SIDE', 'auto')
 RGCN_BWD_SIDE_MIN_WORK = 10 ** 8       # edges x widest side of the layer
 
@@ -2044,12 +2045,9 @@ class _LossHead(torch.autograd.Function):
         lib.call('gv_bce_grad', ptr(score), ptr(labels), ptr(g), ptr(dscore), ptr(tidx.pos3),
                  ptr(d_inc) if tidx.pos3 is not None else None, ptr(d_rel) if tidx.pos3 is not None else None,
                  ptr(dbias), ptr(ws), T, st)
-        # the relation-side gradient (an arena target: nothing in this backward pass reads it) beside the node-side one
-        side_rel = d_w is not None and _os.environ.get('GV_TMP_DEC_SIDE', '0') == '1' and rgcn_bwd_side(10 ** 9, 1)
-        with backward_side(side_rel, z, d_rel, idx_rel, w_rel, g, g_w, rgcn=True) if side_rel else contextlib.nullcontext():
-            bdd_grad_weight(tidx.rel, tidx.rel_s, tidx.rel_o, d_rel, idx_rel, z, z, h, 1, 1, out=g_w,
-                            accumulate=d_w is not None)
-            lib.call('gv_axpby', w_rel.numel(), ptr(g), 2.0 * reg_w / w_rel.numel(), ptr(w_rel), 1.0, ptr(g_w), lib.stream())
+        bdd_grad_weight(tidx.rel, tidx.rel_s, tidx.rel_o, d_rel, idx_rel, z, z, h, 1, 1, out=g_w,
+                        accumulate=d_w is not None)
+        lib.call('gv_axpby', w_rel.numel(), ptr(g), 2.0 * reg_w / w_rel.numel(), ptr(w_rel), 1.0, ptr(g_w), st)
         join(1)
         g_z = bdd_aggregate(tidx.inc, tidx.inc_other, tidx.inc_rel, d_inc, idx_inc, z, w_rel, h, 1, 1,
                             addend=gz)
