@@ -122,9 +122,9 @@ def join(*ids):
 # Off when a process group exists: the gradients then feed all-reduces started inside the backward pass, and a captured step is a
 # chain of graph segments cut at the collectives (a stream forked in one segment cannot be joined in another).
 # Used by the MADE backward (weight-gradient products that need one workgroup per CU, beside backward chains whose second round
-# of workgroups leaves half of the CUs idle: -0.13 ms at WN18RR size).  NOT by the R-GCN layers' or the decoder's weight
-# gradients: beside kernels that fill the chip on their own they cost more than they hide (FB15k-237: 1.047 -> 1.089 ms per step,
-# the mini-batch step 0.98 -> 1.11).
+# of workgroups leaves half of the CUs idle: -0.13 ms at WN18RR size) and, since round 4, by the R-GCN layers' weight gradients
+# where the layer is large (RGCN_BWD_SIDE below; in round 3, with the gradients going through AccumulateGrad and other kernels,
+# the same cost more than it hid: FB15k-237 1.047 -> 1.089 ms per step, the mini-batch step 0.98 -> 1.11).  Not by the decoder's.
 BWD_SIDE = _os.environ.get('GV_BWD_SIDE', '1') == '1'
 _bwd_side_held = []
 # ... the R-GCN layers' weight gradients too (round 4, with the arena targets): 'auto' = where the layer is large and the side stream
