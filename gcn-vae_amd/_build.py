@@ -16,6 +16,9 @@ OBJ = os.path.join(HERE, 'csrc', '_obj')
 LIB = os.path.join(HERE, 'libgcnvae_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+# per-file additions (k_stream.hip: hipcc's SLP pass pairs the scalar multiply-adds into v_pk_fma_f32 and pays ~30 registers of
+# pair copies for it -- scratch at the 128-register budget of a 1 024-thread workgroup)
+FILE_FLAGS = {'k_stream.hip': ['-fno-slp-vectorize']}
 
 
 def _newer(src, dst):
@@ -35,7 +38,7 @@ def build(force=False, verbose=False):
 
     def compile_one(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed on {src}:\n{r.stderr}')

@@ -13,58 +13,9 @@
 // No atomics: every row is summed by one wave in (phase, original edge) order -> bitwise reproducible.
 #include <stdlib.h>
 
-#include "common.h"
+#include "k_phase.h"
 
 namespace gv {
-
-struct PhaseParams {
-    const int* off;          // [(n_tiles * nw * n_phases) + 1] first edge position of every (tile, wave, phase) list
-    const int* nbr;          // [E] gathered row of each edge, in (tile, wave, phase, slot) order
-    const int* meta;         // [E] ((etype - phase*G) << 4) | item slot k
-    const float* coef;       // [E] or NULL
-    const int4* titems;      // [n_tiles][nw*K] {row (-1: none), slot (-1: final row), 0, 0}
-    const float4* wpk;       // lane-packed weights [parts][R][NQ][L] float4 (+ 64 float4 of slack)
-    int n_phases, G, R;
-    const float* feat;
-    int ld_feat;
-    const float* addend;
-    int ld_add;
-    int act;
-    const uint8_t* keep;
-    float keep_scale;
-    float* out;
-    int ld_out;
-    float* partial;
-    int out_dim;
-    int nbp;                 // diagonal blocks per column part
-    int L;                   // active lanes per part = nbp / BPL
-    int slab;                // float4 per LDS buffer (>= G*NQ*L rounded up to 64)
-    int nbuf;                // LDS weight buffers: 2 (phase p+1 lands while p is computed) or 1 (twice the relations per phase)
-};
-
-__device__ __forceinline__ int prl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ float prl_f(float v, int lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-// One LDS-DMA wave-instruction: 64 x 16 B from per-lane global addresses to lds_byte_addr + lane*16.  Issued from inline
-// asm on purpose: hipcc does not count it, so its waits for the feature gathers stay COUNTED (vmcnt(U-1)) instead of
-// draining to vmcnt(0) as they do beside a builtin LDS-DMA; the gathers are younger than the phase's DMAs, so every such
-// wait still covers them, and the phase ends with an explicit vmcnt(0) before the barrier (cdna_hip_programming.md 5.7).
-__device__ __forceinline__ void glds16(const float4* gbase, unsigned byte_off, unsigned lds_byte_addr) {
-    // scalar base + 32-bit per-lane byte offset: no 64-bit per-lane pointer stays live across the launch (it was the one
-    // value the 128-register kernels spilled)
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(byte_off), "s"(gbase), "s"(lds_byte_addr)
-                 : "memory");
-}
-
-// A register vector that may be indexed by a wave-uniform run-time position: hipcc lowers that to M0-relative register
-// addressing (s_set_gpr_idx), so the vector stays in VGPRs (a K-way branch tree over static arrays instead makes the
-// structurizer copy registers around and spill).
-template <int N> struct AccVec { typedef float type __attribute__((ext_vector_type(N))); };
 
 // LEAN (wide blocks, where registers decide how many rows a wave can own): one block per lane whose weights are q-major in the
 // lane's list (the transposed product's natural order); the weights are fetched and used in two halves of the output columns,
@@ -267,35 +218,7 @@ __global__ __launch_bounds__(1024) void k_agg_phase(const PhaseParams a) {
         }
     }
 
-    if (!active) return;
-    const int col0 = (part * a.nbp + lane * BPL) * Q;
-    const int4* __restrict__ ti = a.titems + ((size_t)tile * nw + wv) * K;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int4 it = ti[k];
-        if (it.x < 0) continue;
-        float o[PV];
-#pragma unroll
-        for (int i = 0; i < PV; ++i) o[i] = acc[k][i];
-        if (it.y >= 0) {
-            if (a.partial) store_vec<PV>(a.partial + (size_t)it.y * a.out_dim + col0, o);
-            continue;
-        }
-        if (a.addend) {
-            float ad[PV];
-            load_vec<PV>(a.addend + (size_t)it.x * a.ld_add + col0, ad);
-#pragma unroll
-            for (int i = 0; i < PV; ++i) o[i] += ad[i];
-        }
-#pragma unroll
-        for (int i = 0; i < PV; ++i) o[i] = apply_act(o[i], a.act);
-        if (a.keep) {
-            const uint8_t* kp = a.keep + (size_t)it.x * a.out_dim + col0;
-#pragma unroll
-            for (int i = 0; i < PV; ++i) o[i] = kp[i] ? o[i] * a.keep_scale : 0.f;
-        }
-        store_vec<PV>(a.out + (size_t)it.x * a.ld_out + col0, o);
-    }
+    phase_epilogue<PV, K>(a, acc, tile, nw, wv, part, lane, active);
 }
 
 // row layout [R][nb*P*Q] -> [parts][R][NQ][L] float4: quad jq of the WV = BPL*P*Q weights of lane l of a column part
@@ -335,12 +258,9 @@ __global__ __launch_bounds__(256) void k_pack_weight_phase(const float* __restri
     }
 }
 
-namespace {
-struct PhasePlan { int bpl, parts, lanes, nq, k, u, qmajor; };
-
 // instantiated shapes: blocks per lane as in k_agg_fast where the lane's gather then is 16 B (2-wide blocks: two per lane),
 // one 5- or 10-wide block per lane otherwise; the fewest column parts that fit a part's lanes into one wave
-bool phase_plan(int nb, int p, int q, bool trans, int k_req, PhasePlan* out) {
+bool phase_plan(int nb, int p, int q, bool trans, int k_req, int threads_req, PhasePlan* out) {
     // k = rows per wave (K * PV accumulator registers); M feature rows in flight (<= 32 registers), per instantiation below
     int bpl = 0, u = 8, k = 0, qmajor = 0;
     if (!trans) {
@@ -355,6 +275,11 @@ bool phase_plan(int nb, int p, int q, bool trans, int k_req, PhasePlan* out) {
         else if (p == 10 && q == 5) { bpl = 1; u = 2; k = 8; }      // lean kernel: 8 rows x 5 accumulators, weights in two halves
     }
     if (!bpl || nb % bpl) return false;
+    // workgroup size: 1 024 threads (16 waves of 128 registers) unless the caller names one.  (Measured and not kept for the 5x10
+    // blocks, whose 10 accumulators per row leave such a wave 4 rows: 12 waves of 168 registers owning 11 rows each -- one round of
+    // workgroups instead of two, 13 instead of 5 edges per wave and phase -- 493 us against 401: three waves per SIMD hide less
+    // than four; 8 waves of 16 rows 641 us.)
+    const int threads = threads_req > 0 ? threads_req : 1024;
     if (k_req && k_req != k) {
         if (trans && p == 10 && q == 5 && k_req == 3) { k = 3; u = 3; }      // the plain kernel, 3 rows per wave
         else if (k_req != 4 || k < 4) return false;       // the 8-row shapes also come with 4 rows per wave
@@ -369,21 +294,21 @@ bool phase_plan(int nb, int p, int q, bool trans, int k_req, PhasePlan* out) {
         if (slots % c == 0 && slots / c <= 64) parts = c;
     if (!parts) return false;
     out->bpl = bpl; out->parts = parts; out->lanes = slots / parts; out->nq = (bpl * p * q + 3) / 4; out->k = k; out->u = u;
-    out->qmajor = qmajor;
+    out->qmajor = qmajor; out->threads = threads;
     return true;
 }
-}  // namespace
 
 }  // namespace gv
 
 using namespace gv;
 
 extern "C" int gv_rgcn_bdd_phase_plan(int num_bases, int blk_in, int blk_out, int transpose_w, int num_rels, int lds_bytes,
-                                      int num_buffers, int rows_per_wave, int32_t* plan_host /*[6]*/) {
+                                      int num_buffers, int rows_per_wave, int block_threads, int32_t* plan_host /*[7]*/) {
     PhasePlan pl;
     if (num_bases <= 0 || blk_in <= 0 || blk_out <= 0 || num_rels <= 0 || !plan_host) return 0;
     if (num_buffers != 1 && num_buffers != 2) return 0;
-    if (!phase_plan(num_bases, blk_in, blk_out, transpose_w != 0, rows_per_wave, &pl)) return 0;
+    if (block_threads < 0 || block_threads > 1024 || block_threads % 64) return 0;
+    if (!phase_plan(num_bases, blk_in, blk_out, transpose_w != 0, rows_per_wave, block_threads, &pl)) return 0;
     const int rel_bytes = pl.nq * pl.lanes * 16;
     int g = (lds_bytes / num_buffers - 1024) / rel_bytes;
     if (g > num_rels) g = num_rels;
@@ -392,6 +317,7 @@ extern "C" int gv_rgcn_bdd_phase_plan(int num_bases, int blk_in, int blk_out, in
     plan_host[0] = pl.bpl; plan_host[1] = pl.parts; plan_host[2] = pl.k; plan_host[3] = g;
     plan_host[4] = (num_rels + g - 1) / g;                       /* phases */
     plan_host[5] = pl.parts * num_rels * pl.nq * pl.lanes * 4 + 64 * 4;      /* floats of the packed weight buffer */
+    plan_host[6] = pl.threads;
     return 1;
 }
 
@@ -399,7 +325,7 @@ extern "C" int gv_rgcn_bdd_pack_weight_phase(const float* weight, int num_rels, 
                                              int transpose_w, float* packed, void* stream) {
     GV_REQUIRE(weight && packed, GV_ERR_NULL, "gv_rgcn_bdd_pack_weight_phase: NULL pointer");
     PhasePlan pl;
-    GV_REQUIRE(phase_plan(num_bases, blk_in, blk_out, transpose_w != 0, 0, &pl), GV_ERR_SHAPE,
+    GV_REQUIRE(phase_plan(num_bases, blk_in, blk_out, transpose_w != 0, 0, 0, &pl), GV_ERR_SHAPE,
                "gv_rgcn_bdd_pack_weight_phase: no phase kernel for num_bases=%d blocks %dx%d trans=%d", num_bases, blk_in,
                blk_out, transpose_w);
     GV_REQUIRE(aligned16(packed), GV_ERR_ALIGN, "gv_rgcn_bdd_pack_weight_phase: 16-B alignment required");
@@ -431,7 +357,7 @@ extern "C" int gv_rgcn_bdd_aggregate_phases(const int32_t* off, const int32_t* n
     GV_REQUIRE(block_threads >= 64 && block_threads <= 1024 && block_threads % 64 == 0, GV_ERR_SHAPE,
                "gv_rgcn_bdd_aggregate_phases: block_threads=%d", block_threads);
     PhasePlan pl;
-    GV_REQUIRE(phase_plan(num_bases, blk_in, blk_out, transpose_w != 0, rows_per_wave, &pl), GV_ERR_SHAPE,
+    GV_REQUIRE(phase_plan(num_bases, blk_in, blk_out, transpose_w != 0, rows_per_wave, block_threads, &pl), GV_ERR_SHAPE,
                "gv_rgcn_bdd_aggregate_phases: no phase kernel for blocks %dx%d trans=%d num_bases=%d with %d rows per wave",
                blk_in, blk_out, transpose_w, num_bases, rows_per_wave);
     GV_REQUIRE(rels_per_phase >= 1 && rels_per_phase <= 4096, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate_phases: rels_per_phase=%d",
@@ -439,7 +365,7 @@ extern "C" int gv_rgcn_bdd_aggregate_phases(const int32_t* off, const int32_t* n
     const int rel_quads = pl.nq * pl.lanes;
     const int slab = ((rels_per_phase * rel_quads + 63) / 64) * 64;
     GV_REQUIRE(num_buffers == 1 || num_buffers == 2, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate_phases: num_buffers=%d", num_buffers);
-    const size_t lds = (size_t)num_buffers * slab * 16;
+    const size_t lds = (size_t)num_buffers * slab * 16 + 256;      // + the quads lanes past the part's last slot read (and ignore)
     GV_REQUIRE(lds <= 160 * 1024, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate_phases: %d relations per phase need %zu B of LDS",
                rels_per_phase, lds);
     // 16-B accesses where a lane's gathered / stored vector is a multiple of 4 floats, 8-B where it is even, 4-B otherwise
@@ -457,9 +383,15 @@ extern "C" int gv_rgcn_bdd_aggregate_phases(const int32_t* off, const int32_t* n
     a.feat = feat; a.ld_feat = ld_feat; a.addend = addend; a.ld_add = ld_addend; a.act = act; a.keep = keep;
     a.keep_scale = keep_scale; a.out = out; a.ld_out = ld_out; a.partial = partial; a.out_dim = num_bases * blk_out;
     a.nbp = num_bases / pl.parts; a.L = pl.lanes; a.slab = slab; a.nbuf = num_buffers;
+    { const char* e = getenv("GV_PHASE_DEBUG"); a.debug = e ? atoi(e) : 0; }
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(n_tiles, pl.parts), block(block_threads);
     int rc = -1000;
+    // the streamed form (k_stream.hip; GV_PHASE_STREAM=0 keeps the batch-per-list kernel below): same lists, bit-identical sums
+    {
+        const char* e = getenv("GV_PHASE_STREAM");
+        if (!(e && e[0] == '0')) rc = launch_phase_stream(a, pl, blk_in, blk_out, transpose_w != 0, grid, block, lds, st);
+    }
 #define GV_PHASE_CASE(P_, Q_, T_, B_, K_, U_) GV_PHASE_CASE_L(P_, Q_, T_, B_, K_, U_, false)
 #define GV_PHASE_CASE_L(P_, Q_, T_, B_, K_, U_, LEAN_)  /* U_ = M: feature rows in flight */                                                                        \
     if (rc == -1000 && blk_in == P_ && blk_out == Q_ && (transpose_w != 0) == T_ && pl.bpl == B_ && pl.k == K_) {    \

@@ -365,7 +365,7 @@ class RelationIndex:
         """Tiles x relation phases x waves edge lists for the K1 phase kernel (csrc/k_phase.hip), built once per static
         graph, side ('dst': forward, 'src': backward w.r.t. x) and block shape; None when no phase kernel covers the shape."""
         cache = self.__dict__.setdefault('_phases', {})
-        key = (side, int(num_bases), int(blk_in), int(blk_out), PHASE_LDS_BYTES, PHASE_ROWS, PHASE_THREADS, PHASE_BUFFERS)
+        key = (side, int(num_bases), int(blk_in), int(blk_out), PHASE_LDS_BYTES, PHASE_ROWS, PHASE_THREADS, PHASE_BUFFERS, phase_stream_on())
         if key not in cache:
             cache[key] = PhaseOrder.build(self, g, side, num_bases, blk_in, blk_out)
         return cache[key]
@@ -464,8 +464,13 @@ PHASE_MIN_EDGES = 100_000
 PHASE_MIN_TABLE_BYTES = 192 << 20
 PHASE_LDS_BYTES = int(_os.environ.get('GV_PHASE_LDS', str(160 * 1024)))    # weight buffer(s) of one workgroup
 PHASE_ROWS = int(_os.environ.get('GV_PHASE_ROWS', '0'))                     # rows per wave (0: the shape's default)
-PHASE_THREADS = int(_os.environ.get('GV_PHASE_THREADS', '1024'))
+PHASE_THREADS = int(_os.environ.get('GV_PHASE_THREADS', '0'))                # workgroup threads (0: the shape's default -- 1 024, or 768 for the 5x10 blocks)
 PHASE_BUFFERS = int(_os.environ.get('GV_PHASE_BUFFERS', '1'))               # 1: twice the relations per phase (measured faster); 2: staging overlaps compute
+
+
+def phase_stream_on():
+    """GV_PHASE_STREAM as the library reads it (per call: tests and probes flip it in os.environ)."""
+    return _os.environ.get('GV_PHASE_STREAM', '1') != '0'
 
 
 def use_phases(gidx, blk_in, blk_out, transpose_w, table_rows, table_cols):
@@ -504,11 +509,13 @@ class PhaseOrder:
     @staticmethod
     def build(ridx: 'RelationIndex', g: 'GraphIndex', side: str, num_bases: int, blk_in: int, blk_out: int):
         trans = side == 'src'
-        plan = (_ct.c_int32 * 6)()
+        plan = (_ct.c_int32 * 7)()
+        # the geometries of more than 8 rows per wave exist in the streamed kernel only: with it switched off ask for 1 024 threads
+        threads_req = PHASE_THREADS if (PHASE_THREADS or phase_stream_on()) else 1024
         if not lib.load().gv_rgcn_bdd_phase_plan(int(num_bases), int(blk_in), int(blk_out), 1 if trans else 0, ridx.num_rels,
-                                                 PHASE_LDS_BYTES, PHASE_BUFFERS, PHASE_ROWS, _ct.addressof(plan)):
+                                                 PHASE_LDS_BYTES, PHASE_BUFFERS, PHASE_ROWS, threads_req, _ct.addressof(plan)):
             return None
-        _bpl, _parts, K, G, n_phases, packed_floats = (int(v) for v in plan)
+        _bpl, _parts, K, G, n_phases, packed_floats, threads = (int(v) for v in plan)
         order = g.by_dst if side == 'dst' else g.by_src
         nbr_sorted = g.nbr_by_dst if side == 'dst' else g.nbr_by_src
         et_sorted = (ridx.et_by_dst if side == 'dst' else ridx.et_by_src).long()
@@ -518,7 +525,7 @@ class PhaseOrder:
         items = seg.items[:seg.n_items]
         items = items[items[:, 0] >= 0].long()                   # drop the -1 padding of upper-bound-sized lists
         n_items = int(items.shape[0])
-        nw = PHASE_THREADS // 64
+        nw = threads // 64
         T = nw * K
         n_tiles = max(1, -(-n_items // T))
         # deal the items to (tile, wave, slot) heaviest first, snake order: similar edge totals per tile and per wave
@@ -557,7 +564,7 @@ class PhaseOrder:
         perm = perm_pos if order.perm is None else order.perm.long()[perm_pos]
         n_fix = int((seg.fix[:seg.n_fix, 0] >= 0).sum()) if seg.n_fix > 0 else 0
         return PhaseOrder(off, nbr, meta, perm, tile_items.contiguous(), n_tiles, seg.fix, n_fix, seg.n_slots, n_rows, K, G,
-                          n_phases, PHASE_THREADS, PHASE_BUFFERS, packed_floats, trans)
+                          n_phases, threads, PHASE_BUFFERS, packed_floats, trans)
 
     def coef(self, coef: torch.Tensor) -> torch.Tensor:
         """Per-edge coefficients (caller's edge order) in list order; cached on the tensor (kept alive) and its version."""

@@ -123,11 +123,16 @@ int gv_rgcn_bdd_pack_weight_pair(const float* weight, int num_rels, int num_base
  *   weight_packed  gv_rgcn_bdd_pack_weight_phase(weight): [parts][R][NQ][L] float4, plan[5] floats
  * Every row is summed by one wave in (phase, list) order: no atomics, bitwise reproducible.
  * gv_rgcn_bdd_phase_plan returns 1 when a phase kernel exists for the block shape and writes (HOST pointer)
- *   plan[6] = {blocks per lane, column parts, K, rels_per_phase for lds_bytes of LDS, n_phases, floats of weight_packed};
+ *   plan[7] = {blocks per lane, column parts, K, rels_per_phase for lds_bytes of LDS, n_phases, floats of weight_packed,
+ *              workgroup threads};
  * num_buffers = 2: phase p+1's weights land while phase p is computed; 1: one buffer with twice the relations per phase,
- * refilled between two barriers.  rows_per_wave = 0: the shape's default K, 4: small tiles (the 8-row shapes). */
+ * refilled between two barriers.  rows_per_wave = 0: the shape's default K, 4: small tiles (the 8-row shapes).
+ * block_threads = 0: the shape's default workgroup (1 024 threads; 768 = 12 waves of 11 rows for the 5x10 blocks), else
+ * the caller's (a multiple of 64); plan[6] is what gv_rgcn_bdd_aggregate_phases must be launched with.
+ * GV_PHASE_STREAM=0 selects the round-2 kernel (one batch of rows per list) instead of the streamed one (a ring of rows in
+ * flight across phase boundaries; the only one with the 11-row geometry): same lists, bit-identical results. */
 int gv_rgcn_bdd_phase_plan(int num_bases, int blk_in, int blk_out, int transpose_w, int num_rels, int lds_bytes,
-                           int num_buffers, int rows_per_wave, int32_t* plan_host);
+                           int num_buffers, int rows_per_wave, int block_threads, int32_t* plan_host);
 int gv_rgcn_bdd_pack_weight_phase(const float* weight, int num_rels, int num_bases, int blk_in, int blk_out, int transpose_w,
                                   float* packed, void* stream);
 int gv_rgcn_bdd_aggregate_phases(const int32_t* off, const int32_t* nbr, const int32_t* meta, const float* coef,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """K1 by relation phases (csrc/k_phase.hip) beside the per-row kernels on the FB15k-237-shaped graph:
-    python tools/tile_bench.py [hidden ...]          (default 200 500)
+    python tools/phase_bench.py [hidden ...]          (default 200 500)
 prints us per launch, algorithmic GB/s (SURVEY 8(d) bytes) and the largest difference between the two paths."""
 import os
 import sys
@@ -43,7 +43,9 @@ def main():
                 ref = ops.bdd_aggregate(order.seg, nbr, ety, coef_o, None, feat, wk, nb, p, q, tr, add, 1 if add is not None else 0, packed=pk)
                 t_row = timeit(lambda: ops.bdd_aggregate(order.seg, nbr, ety, coef_o, None, feat, wk, nb, p, q, tr, add,
                                                          1 if add is not None else 0, packed=pk))
-                tl = ridx.phase_order(gidx, side, nb, p, q)
+                stream_only = os.environ.get('PHASE_BENCH_STREAM_ONLY') == '1'      # geometries only the streamed kernel has
+                os.environ['GV_PHASE_STREAM'] = '1' if stream_only else '0'
+                tl = ridx.phase_order(gidx, side, nb, p, q)                        # the batch-per-list kernel's geometry
                 if tl is None:
                     print(f'h={h} {side} {p}x{q}: per-row {t_row:7.1f} us; no phase kernel')
                     continue
@@ -57,7 +59,22 @@ def main():
                       f'({by / t_tile / 1e3:6.0f} GB/s = {by / t_tile / 1e3 / 8000:.2f} of 8 TB/s) + pack {t_pack:5.1f} us   '
                       f'rel.diff {err:.1e}   [tiles {tl.n_tiles}, phases {tl.n_phases} x {tl.rels_per_phase} relations, '
                       f'{tl.rows_per_wave} rows/wave, threads {tl.threads}]', flush=True)
+                # the streamed form (csrc/k_stream.hip) in ITS geometry: the same per-row order, so bit-identical sums; ring depths GV_PHASE_STREAM_D
+                os.environ['GV_PHASE_STREAM'] = '1'
+                ts = ridx.phase_order(gidx, side, nb, p, q)
+                cs = ts.coef(norm)
+                for d in DEPTHS:
+                    os.environ['GV_PHASE_STREAM_D'] = str(d)
+                    got_s = ops.bdd_aggregate_phases(ts, cs, feat, wp, R, nb, p, q, add, 1 if add is not None else 0)
+                    same = bool(torch.equal(got_s, got))
+                    t_s = timeit(lambda: ops.bdd_aggregate_phases(ts, cs, feat, wp, R, nb, p, q, add, 1 if add is not None else 0))
+                    print(f'    streamed, depth {d or "default"}: {t_s:7.1f} us ({by / t_s / 1e3:6.0f} GB/s = {by / t_s / 1e3 / 8000:.2f} '
+                          f'of 8 TB/s)   bit-identical: {same}   [tiles {ts.n_tiles}, {ts.rows_per_wave} rows/wave, threads {ts.threads}]',
+                          flush=True)
+                os.environ.pop('GV_PHASE_STREAM_D', None)
 
+
+DEPTHS = [int(d) for d in os.environ.get('PHASE_BENCH_DEPTHS', '0,4,6,8').split(',')]
 
 if __name__ == '__main__':
     main()
