@@ -28,6 +28,7 @@ struct PhaseParams {
     int L;                   // active lanes per part = nbp / BPL
     int slab;                // float4 per LDS buffer (>= G*NQ*L rounded up to 64)
     int nbuf;                // LDS weight buffers: 2 (phase p+1 lands while p is computed) or 1 (twice the relations per phase)
+    int parts, n_tiles, xcd_parts;      // column parts; tiles; 1: the streamed kernel's 1-D grid with part = (id % 8) / 4 (two parts)
     int debug;               // GV_PHASE_DEBUG (probes only; results are wrong): 1 no barriers, 2 no weight staging
 };
 
@@ -60,7 +61,7 @@ template <int PV, int K>
 __device__ __forceinline__ void phase_epilogue(const PhaseParams& a, float (&acc)[K][PV], int tile, int nw, int wv, int part, int lane,
                                                bool active) {
     if (!active) return;
-    const int col0 = part * (a.out_dim / (int)gridDim.y) + lane * PV;
+    const int col0 = part * (a.out_dim / a.parts) + lane * PV;
     const int4* __restrict__ ti = a.titems + ((size_t)tile * nw + wv) * K;
 #pragma unroll
     for (int k = 0; k < K; ++k) {

@@ -384,6 +384,7 @@ extern "C" int gv_rgcn_bdd_aggregate_phases(const int32_t* off, const int32_t* n
     a.keep_scale = keep_scale; a.out = out; a.ld_out = ld_out; a.partial = partial; a.out_dim = num_bases * blk_out;
     a.nbp = num_bases / pl.parts; a.L = pl.lanes; a.slab = slab; a.nbuf = num_buffers;
     { const char* e = getenv("GV_PHASE_DEBUG"); a.debug = e ? atoi(e) : 0; }
+    a.parts = pl.parts; a.n_tiles = n_tiles; a.xcd_parts = 0;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(n_tiles, pl.parts), block(block_threads);
     int rc = -1000;
