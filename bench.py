@@ -242,33 +242,40 @@ def algorithmic_bytes(tag, E, N, R, T):
 
 
 def pmc_traffic_for(tag, config='c2'):
-    """(HBM-side bytes per launch, provenance) of the kernel behind a K1 tag IN THIS CONFIGURATION, from the newest committed
-    rocprofv3 PMC passes of this command (profiles/round*/pmc_traffic_<config>.json, or the round-1 pmc_traffic.json for c2:
-    (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc runs, gfx950 correction per MI355X_MICROARCH.md; the file's "_meta" names
-    the commit and date it was measured at).  (None, None) when no profile of that kernel and configuration is committed."""
+    """(HBM-side bytes per launch, provenance) of the kernel INSTANCE behind a K1 tag in this configuration, from the newest
+    committed rocprofv3 PMC passes of this command (profiles/round*/pmc_traffic_<config>.json: (2*FETCH_SIZE + WRITE_SIZE) KiB,
+    separate --pmc runs, gfx950 correction per MI355X_MICROARCH.md).  A figure is attached only when (a) the file's
+    "_meta.k1_source_sha" equals the hash of the K1 sources of THIS tree (profiles/summarize_pmc.py: the instance the tag runs is
+    then the instance that was measured) and (b) exactly one kernel of the file matches the tag's family, block shape and
+    orientation; the provenance names that kernel in full.  Otherwise (None, {"stale": reason})."""
     import glob
     import re
+    import importlib.util
     kind, rest = tag.split('_', 1)
     if kind != 'agg':
         return None, None
     tr, blk, _ = rest.split('_')
     p, q = blk.split('x')
     # (the LDS-resident kernel's name carries no orientation -- its packing does: both directions of a square block share it)
-    pat = re.compile(r'k_agg_(fast|packed|phase|split)<%s, ?%s, ?%s,|k_agg_lds<%s, ?%s,' % (p, q, 'true' if tr == 'T' else 'false', p, q))
-    best, src = None, None
+    pat = re.compile(r'k_agg_(fast|packed|phase|stream|split)<%s, ?%s, ?%s,|k_agg_lds<%s, ?%s,' % (p, q, 'true' if tr == 'T' else 'false', p, q))
     paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*', f'pmc_traffic_{config}.json')))
-    if config == 'c2':
-        paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*', 'pmc_traffic.json'))) + paths
-    for path in paths:
-        try:
-            data = json.load(open(path))
-        except Exception:
-            continue
-        for k, v in data.items():
-            if k != '_meta' and pat.search(k):
-                best = v['traffic_bytes']
-                src = dict(data.get('_meta', {}), file=os.path.relpath(path, ROOT))
-    return best, src
+    if not paths:
+        return None, None
+    path = paths[-1]
+    try:
+        data = json.load(open(path))
+    except Exception:
+        return None, None
+    meta = dict(data.get('_meta', {}), file=os.path.relpath(path, ROOT))
+    spec = importlib.util.spec_from_file_location('_gv_summarize_pmc', os.path.join(ROOT, 'profiles', 'summarize_pmc.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if meta.get('k1_source_sha') != mod.k1_source_sha(ROOT):
+        return None, {'stale': 'the K1 sources changed since this PMC pass (or it predates the source hash)', 'file': meta['file']}
+    hits = [k for k in data if k != '_meta' and pat.search(k)]
+    if len(hits) != 1:
+        return None, {'stale': f'{len(hits)} kernels of the file match {tag}', 'file': meta['file']}
+    return data[hits[0]]['traffic_bytes'], dict(meta, kernel=hits[0])
 
 
 def k1_bf16_mode(w, args, dev):
@@ -529,6 +536,8 @@ def dominant_roofline(k1_roofline, detail, k4, config=None, n_rows=None):
             'peak': HBM_PEAK_GBS if hbm else d['peak_TFLOPs'], 'unit': 'GB/s' if hbm else 'TFLOP/s',
             'frac': d['frac'], 'frac_mfma': d.get('frac_mfma'), 'frac_hbm': d.get('frac_hbm'), 'algorithmic_MB': d.get('algorithmic_MB'),
             'traffic': traffic, 'traffic_source': traffic_src,
+            # (an ESTIMATE where the PMC pass ran one launch per row block and the timed launch covers all rows: counter bytes x blocks)
+            'traffic_is_scaled_estimate': bool(traffic_src and traffic_src.get('scaled_by_row_blocks', 1) > 1),
             'traffic_over_algorithmic': round(traffic / (d['algorithmic_MB'] * 1e6), 3) if (traffic and d.get('algorithmic_MB')) else None,
             'avg_us': d['avg_us'], 'GFLOP': d['GFLOP'], 'operands': d.get('operands'),
             'share_of_instrumented_time': round(t_k4 / max(t_k1 + t_k4, 1e-9), 3),

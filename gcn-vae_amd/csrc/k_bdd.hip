@@ -996,6 +996,44 @@ __global__ __launch_bounds__(256) void k_gradw_fixup(const int4* fix, int n_fix,
     *o = accumulate ? *o + acc : acc;
 }
 
+// the same sums with a lane on FOUR consecutive columns (w_row % 4 == 0: 16-B loads, a quarter of the waves; at h = 500 a
+// relation's row is 10-20 kB and its ~9 slices were summed by 40-80 waves of 256-B loads: 85 us per launch, three per step).
+// Element by element ordered_slot_sum's four chains and combine: bit-identical.
+__global__ __launch_bounds__(256) void k_gradw_fixup4(const int4* fix, int n_fix, const float* partial, int w_row,
+                                                      float* grad_w, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int quads = w_row >> 2, tiles = (quads + 63) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (wave >= n_fix * tiles) return;
+    const int4 f = fix[wave / tiles];
+    if (f.x < 0) return;
+    const int c4 = (wave % tiles) * 64 + lane;
+    if (c4 >= quads) return;
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(partial + (size_t)f.y * w_row) + c4;
+    const size_t stride = (size_t)quads;
+    const int n = f.z;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    auto add = [](float4& a, const float4& v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+    int k = 0;
+    for (; k + 8 <= n; k += 8) {
+        const float4 v0 = p[(size_t)(k + 0) * stride], v1 = p[(size_t)(k + 1) * stride];
+        const float4 v2 = p[(size_t)(k + 2) * stride], v3 = p[(size_t)(k + 3) * stride];
+        const float4 v4 = p[(size_t)(k + 4) * stride], v5 = p[(size_t)(k + 5) * stride];
+        const float4 v6 = p[(size_t)(k + 6) * stride], v7 = p[(size_t)(k + 7) * stride];
+        add(a0, v0); add(a1, v1); add(a2, v2); add(a3, v3);
+        add(a0, v4); add(a1, v5); add(a2, v6); add(a3, v7);
+    }
+    for (; k < n; ++k) add(a0, p[(size_t)k * stride]);
+    float4 acc = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                             (a0.w + a1.w) + (a2.w + a3.w));
+    float4* o = reinterpret_cast<float4*>(grad_w + (size_t)f.x * w_row) + c4;
+    if (accumulate) {
+        const float4 t = *o;
+        acc.x = t.x + acc.x; acc.y = t.y + acc.y; acc.z = t.z + acc.z; acc.w = t.w + acc.w;
+    }
+    *o = acc;
+}
+
 // ---------------------------------------------------------------------------------------------
 __global__ void k_items_count(const int* rowptr, int n_seg, int chunk, int* n_chunks, int* n_slots, int* is_split) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1362,9 +1400,15 @@ extern "C" int gv_rgcn_bdd_grad_weight(const int32_t* items, int n_items, const 
     if (rc == -1000) rc = launch_items(k_gradw_generic, a, n_items, st, "gv_rgcn_bdd_grad_weight(generic)");
     if (rc != GV_OK) return rc;
     if (n_fix > 0) {
-        const int waves = n_fix * ((a.w_row + 63) / 64);
-        hipLaunchKernelGGL(k_gradw_fixup, dim3((waves + 3) / 4), dim3(256), 0, st, (const int4*)fix, n_fix, partial,
-                           a.w_row, grad_w, accumulate);
+        if (a.w_row % 4 == 0 && aligned16(partial) && aligned16(grad_w)) {
+            const int waves = n_fix * ((a.w_row / 4 + 63) / 64);
+            hipLaunchKernelGGL(k_gradw_fixup4, dim3((waves + 3) / 4), dim3(256), 0, st, (const int4*)fix, n_fix, partial,
+                               a.w_row, grad_w, accumulate);
+        } else {
+            const int waves = n_fix * ((a.w_row + 63) / 64);
+            hipLaunchKernelGGL(k_gradw_fixup, dim3((waves + 3) / 4), dim3(256), 0, st, (const int4*)fix, n_fix, partial,
+                               a.w_row, grad_w, accumulate);
+        }
         return launch_status("gv_rgcn_bdd_grad_weight(fixup)");
     }
     return GV_OK;

@@ -480,7 +480,8 @@ class ShardedArenaStep:
 def ShardedFlatAdam(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, group=None, average=True):
     """optim.FlatAdam whose step is sharded over the ranks (ShardedArenaStep on the HIP kernels): same arenas for parameters and
     gradients (backward kernels still add straight into the gradient arena), moments for the rank's piece only.  Returns the
-    FlatAdam with ``step`` / ``snapshot`` / ``restore`` rebound; ``max_grad_norm`` is required (the clip is part of the update)."""
+    FlatAdam with ``step`` rebound; ``snapshot`` / ``restore`` are FlatAdam's own and work on the rank's piece through the aliased
+    ``exp_avg`` / ``exp_avg_sq`` / ``step_t`` attributes.  ``max_grad_norm`` is required (the clip is part of the update)."""
     from . import lib
     from .lib import ptr
     from .optim import FlatAdam

@@ -18,7 +18,7 @@ for c in $cfgs; do
     rm -rf /tmp/pp_$ctr
     rocprofv3 --pmc $ctr --output-format csv -d /tmp/pp_$ctr -o p -- python3 bench.py --config $c --steps 3 --warmup 2 --no-graph $common > /dev/null 2>> "$out/stderr_$c.log"
   done
-  python3 profiles/summarize_pmc.py "$(find /tmp/pp_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find /tmp/pp_WRITE_SIZE -name '*counter_collection.csv' | head -1)" "$out/pmc_traffic_$c.json" > "$out/pmc_traffic_summary_$c.txt"
+  python3 profiles/summarize_pmc.py "$(find /tmp/pp_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find /tmp/pp_WRITE_SIZE -name '*counter_collection.csv' | head -1)" "$out/pmc_traffic_$c.json" "tools/collect_profiles.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of python3 bench.py --config $c --steps 3 --warmup 2 --no-graph $common; traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB" > "$out/pmc_traffic_summary_$c.txt"
   echo "== $c: pmc TCC hit/miss"; date +%T
   rm -rf /tmp/pp_l2
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d /tmp/pp_l2 -o p -- python3 bench.py --config $c --steps 3 --warmup 2 --no-graph $common > /dev/null 2>> "$out/stderr_$c.log"
