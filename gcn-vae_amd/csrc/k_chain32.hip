@@ -331,11 +331,21 @@ __device__ __forceinline__ void c32_logdet(const float* net, int ld_net, float* 
 // the handed-through gradient (count == 0: g, else 0) goes to g_old, where the chain's last layer adds its own
 __device__ __forceinline__ void c32_update_bwd(const float* z, const float* net, int ld_net, const int* cnt, const float* g_in, int ld_gin,
                                                const float* gld, float* g_z, bool gz_write, float* g_net, int ld_gnet, float* g_old,
-                                               int ld_gold, int m0, int m, int d, bool reversed = false) {
+                                               int ld_gold, int m0, int m, int d, bool reversed = false, int live = 0x7fffffff) {
     const int q = d >> 2;
     for (int i = threadIdx.x; i < C32_BM * q; i += C32_THREADS) {
         const int row = m0 + i / q, c = (i % q) << 2;
         if (row >= m) continue;
+        if (row >= live) {
+            // a padding row of a static-shape batch (rows [*rows_dev, m)): whatever the caller left in its dL/dx and dL/dlogdet, its
+            // [g_mu | g_alpha] is ZERO -- the weight / bias gradient products reduce over all m stacked rows, padding included
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gz_write) *reinterpret_cast<float4*>(g_z + (size_t)row * d + c) = zero;
+            *reinterpret_cast<float4*>(g_net + (size_t)row * ld_gnet + c) = zero;
+            *reinterpret_cast<float4*>(g_net + (size_t)row * ld_gnet + d + c) = zero;
+            *reinterpret_cast<float4*>(g_old + (size_t)row * ld_gold + c) = zero;
+            continue;
+        }
         const int4 cnt4 = *reinterpret_cast<const int4*>(cnt + c);
         float4 g = *reinterpret_cast<const float4*>(g_in + (size_t)row * ld_gin + (reversed ? d - 4 - c : c));
         if (reversed) g = make_float4(g.w, g.z, g.y, g.x);
@@ -455,7 +465,7 @@ __global__ __launch_bounds__(C32_THREADS) void k_made_chain_f32(const Chain32Arg
         c32_update_bwd(p.iaf.z, p.iaf.net + so * p.iaf.ld_net, p.iaf.ld_net, p.iaf.colcount + (step > 0 ? s : -s) * d, g_in,
                        s == 0 ? d : Llast.ldc, (s == 0 && (p.iaf.flags & 1)) ? p.iaf.g_logdet : nullptr, p.iaf.g_z,
                        s == 0 && (p.iaf.flags & 2), xs, p.ldx, Llast.out_f32 + so * Llast.ldc, Llast.ldc, m0, p.m, d,
-                       s == 0 && (p.iaf.flags & 4));
+                       s == 0 && (p.iaf.flags & 4), p.rows_dev ? *p.rows_dev : 0x7fffffff);
         __syncthreads();         // (drains the stores: the staging below and the last layer's epilogue read them back)
     }
     if (p.iaf.mode == 1 && s == 0 && (p.iaf.flags & 4)) {

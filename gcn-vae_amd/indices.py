@@ -700,16 +700,25 @@ _LDS_PLANS = {}
 LDS_MIN_EDGES = 100_000     # graphs indexed sync-free (rebuilt per step: mini-batches) stay on the per-row kernels below this size
 
 
-def lds_graph(gidx):
+def lds_graph(gidx, side=None, max_edges=None):
     """Does the LDS-resident kernel take this graph?  Its super-item lists are built with host read-backs (LdsOrder.build:
-    data-dependent sizes) -- once per graph, cached on the index.  A graph indexed sync-free takes the path from LDS_MIN_EDGES
-    edges on (a large static graph whose lists are built during the eager warm-up steps); while the current stream is being
-    CAPTURED a graph whose lists do not exist yet stays on the per-row kernels instead of aborting the capture with a
-    synchronisation (a per-batch graph of that size inside graph_step.GraphedMiniBatchStep)."""
+    data-dependent sizes) -- once per graph, ordering and list size, cached on the index.  A graph indexed sync-free takes the path
+    from LDS_MIN_EDGES edges on (a large static graph whose lists are built during the eager warm-up steps); while the current
+    stream is being CAPTURED a launch whose list (``side``, ``max_edges``) does not exist yet stays on the per-row kernels instead
+    of aborting the capture with a synchronisation (a per-batch graph of that size inside graph_step.GraphedMiniBatchStep; a
+    backward pass captured after an eager no-grad forward built only the 'dst' list) -- with a warning, once per graph, because
+    the captured program then keeps the per-row kernels for good."""
     if gidx.sync_free and gidx.num_edges < LDS_MIN_EDGES:
         return False
-    if not gidx._lds_seg_cache and torch.cuda.is_current_stream_capturing():
-        return False
+    if torch.cuda.is_current_stream_capturing():
+        have = bool(gidx._lds_seg_cache) if side is None else (side, int(max_edges)) in gidx._lds_seg_cache
+        if not have:
+            if not getattr(gidx, '_lds_capture_warned', False):
+                gidx._lds_capture_warned = True
+                import warnings
+                warnings.warn('K1: the LDS-resident kernel\'s work list of this graph does not exist yet and cannot be built under '
+                              'stream capture; the captured step keeps the per-row kernels (run one eager step first)')
+            return False
     return True
 
 

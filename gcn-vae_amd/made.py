@@ -34,8 +34,18 @@ def _zero_row(d, device):
     """One read-only all-zero row (1, d) per device and width: pass 0's input (not a fill per call)."""
     key = (device, int(d))
     if key not in _zero_rows:
-        _zero_rows[key] = torch.zeros(1, int(d), dtype=torch.float32, device=device)
+        row = torch.zeros(1, int(d), dtype=torch.float32, device=device)
+        if _capturing():
+            return row      # a tensor filled by a RECORDED launch lives in the graph's pool and is uninitialised until a replay: not cached
+        _zero_rows[key] = row
     return _zero_rows[key]
+
+
+def _capturing():
+    """Is the current stream being captured?  The process-wide caches of this module (the zero row, the chain and weight-gradient
+    plans) are filled by a launch on the current stream: under capture that launch is only recorded, so the tensor is built for
+    that call alone and not cached -- an eager use before the first replay would read uninitialised memory."""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
 def _made_params_work_f32(masks, ws, bs, d, S):
@@ -761,7 +771,8 @@ def made_chain_f32_plan(widths_n, widths_k, masks=None, transposed=False):
     tt = (_ct.c_int32 * nl)(*[1 if transposed else 0] * nl)
     lib.call('gv_made_chain_f32_plan', nl, _ct.addressof(arr_n), _ct.addressof(arr_k), _ct.addressof(tm) if tm is not None else None,
              _ct.addressof(tl) if tl is not None else None, _ct.addressof(tt), ptr(plan), lib.stream())
-    _chain32_plans[key] = (plan, held, masks)
+    if not _capturing():
+        _chain32_plans[key] = (plan, held, masks)
     return plan
 
 
@@ -802,7 +813,8 @@ def made_gradw_f32_plan(m, n, wmask=None):
             raise ValueError(f'made_gradw_f32_plan: mask {tuple(wmask.shape)} for an ({m}, {n}) weight')
     plan = torch.empty(int(lib.load().gv_made_gradw_f32_plan_words(m, n)), dtype=torch.int32, device=torch.device('cuda', torch.cuda.current_device()))
     lib.call('gv_made_gradw_f32_plan', ptr(wmask), ldw if wmask is not None else 0, int(m), int(n), ptr(plan), lib.stream())
-    _gradw32_plans[key] = (plan, wmask)
+    if not _capturing():
+        _gradw32_plans[key] = (plan, wmask)
     return plan
 
 

@@ -223,7 +223,9 @@ def backward_side_finish():
     if _bwd_side_held:
         torch.cuda.current_stream().wait_stream(_side('bwd'))
         _bwd_side_held.clear()
-        _bwd_side_others[0] = False
+    # unconditionally: a pass that raised (or ran without the engine's end-of-pass callback) after a MADE node had set the flag would
+    # otherwise keep rgcn_bwd_side('auto') off for the rest of the process
+    _bwd_side_others[0] = False
 
 
 class StayOnDevice:
@@ -877,8 +879,16 @@ class _RelGraphConvBdd(torch.autograd.Function):
             return None
 
         ctx.grouped = not ctx.tiles and reduce_hook is None and use_relation_groups(weight, gidx)
-        lp = lds_plan(weight.shape[0], num_bases, si, so) if (not ctx.tiles and not ctx.grouped and reduce_hook is None and lds_graph(gidx)) else None
+        lp = lds_plan(weight.shape[0], num_bases, si, so) if (not ctx.tiles and not ctx.grouped and reduce_hook is None) else None
+        if lp is not None and not lds_graph(gidx, 'dst', lp[2]):
+            lp = None
         ctx.k1_bf = bool(lp[3]) if lp is not None else False
+        if lp is not None and not torch.cuda.is_current_stream_capturing():
+            # the backward-x launch's list too, while a host read-back is still allowed: a step captured after this eager forward
+            # (a no-grad evaluation pass in front of the training capture) must not find it missing
+            lp_b = lds_plan(weight.shape[0], num_bases, so, si, bf=ctx.k1_bf)
+            if lp_b is not None:
+                gidx.lds_order('src', lp_b[2])
         if lp is not None:       # few relation types: the whole table resident in LDS (csrc/k_lds.hip)
             out = bdd_aggregate_lds(gidx.lds_order('dst', lp[2]), gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x,
                                     pack_weight_lds(weight, num_bases, si, so, False, lp), weight.shape[0], num_bases, si, so,
@@ -955,8 +965,9 @@ class _RelGraphConvBdd(torch.autograd.Function):
                 bdd_grad_weight(ridx.by_rel.seg, ridx.src_by_rel, ridx.dst_by_rel, coef_r, idx_r, x, g_agg, nb, si, so, out=d_w, accumulate=True)
         if loop_weight is not None:
             if ctx.needs_input_grad[3] and not side_w:
-                grad_loop = gemm(x, g, trans_a=True, split_k=pick_split_k(x.shape[1], g.shape[1], x.shape[0]),
-                                 out=d_l, accumulate=d_l is not None)
+                with backward_side(False):      # (arena target on this stream: ordered behind whatever an earlier node left on the side stream)
+                    grad_loop = gemm(x, g, trans_a=True, split_k=pick_split_k(x.shape[1], g.shape[1], x.shape[0]),
+                                     out=d_l, accumulate=d_l is not None)
                 if d_l is not None:
                     grad_loop = None
             if ctx.needs_input_grad[0]:
@@ -984,8 +995,9 @@ class _RelGraphConvBdd(torch.autograd.Function):
             grad_x = bdd_aggregate_phases(tl, None if coef is None else tl.coef(coef), g_agg,
                                           pack_weight_phase(tl, weight, nb, so, si), weight.shape[0], nb, so, si, gx_loop,
                                           out=x_tgt)
-        elif ctx.needs_input_grad[0] and not ctx.grouped and reduce_hook is None and lds_graph(gidx) and \
-                lds_plan(weight.shape[0], nb, so, si, bf=ctx.k1_bf) is not None:
+        elif ctx.needs_input_grad[0] and not ctx.grouped and reduce_hook is None and \
+                lds_plan(weight.shape[0], nb, so, si, bf=ctx.k1_bf) is not None and \
+                lds_graph(gidx, 'src', lds_plan(weight.shape[0], nb, so, si, bf=ctx.k1_bf)[2]):
             lp = lds_plan(weight.shape[0], nb, so, si, bf=ctx.k1_bf)
             static = not gidx.sync_free and coef is not None
             coef_s, idx_s = (gidx.coef_in_src_order(coef), None) if static else (coef, gidx.by_src.perm)
@@ -1021,8 +1033,9 @@ class _RelGraphConvBdd(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not side_w:
             static = not gidx.sync_free and coef is not None
             coef_r, idx_r = (ridx.coef_in_rel_order(coef), None) if static else (coef, ridx.by_rel.perm)
-            grad_w = bdd_grad_weight(ridx.by_rel.seg, ridx.src_by_rel, ridx.dst_by_rel, coef_r, idx_r, x,
-                                     g_agg, nb, si, so, out=d_w, accumulate=d_w is not None)
+            with backward_side(False):
+                grad_w = bdd_grad_weight(ridx.by_rel.seg, ridx.src_by_rel, ridx.dst_by_rel, coef_r, idx_r, x,
+                                         g_agg, nb, si, so, out=d_w, accumulate=d_w is not None)
             if d_w is not None:
                 grad_w = None
         return grad_x, grad_w, grad_bias, grad_loop, None, None, None, None, None, None, None, None

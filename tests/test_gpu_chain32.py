@@ -297,6 +297,35 @@ def test_fused_passes_on_a_padded_batch_equal_the_launch_per_pass_path(monkeypat
         assert torch.equal(a, b) and float(a.abs().max()) > 0
 
 
+def test_padding_rows_with_poisoned_gradients_do_not_reach_the_parameter_gradients():
+    """ops.live_rows + the fused passes + gv_made_gradw_f32: the weight / bias gradient products reduce over all stacked rows, padding
+    included, so the update's backward stores ZEROS as [g_mu | g_alpha] of padding rows whatever dL/dx and dL/dlogdet hold there (a
+    loss that does not mask them: here NaN-poisoned).  Parameter gradients = the node on the live rows alone; dL/dz of the live rows too."""
+    from gcn_vae_amd import ops
+    d, h, rows, live = 40, 56, 400, 150
+    z = torch.randn(rows, d, generator=torch.Generator().manual_seed(4)).cuda()
+    rows_dev = torch.tensor([live], dtype=torch.int32, device='cuda')
+    probe = torch.randn(rows, d, generator=torch.Generator().manual_seed(5)).cuda()
+    ref_m = _made(d, h, 2)
+    zr = z[:live].clone().requires_grad_(True)
+    x, ld = ref_m(zr)
+    ((x * probe[:live]).sum() + (ld ** 2).sum()).backward()
+    m = _made(d, h, 2)
+    zz = z.clone().requires_grad_(True)
+    with ops.live_rows(rows_dev, rows):
+        x2, ld2 = m(zz)
+        gx = probe.clone()
+        gx[live:] = float('nan')
+        gl = 2 * ld2.detach().clone()
+        gl[live:] = float('nan')
+        torch.autograd.backward([x2, ld2], [gx, gl])
+    torch.cuda.synchronize()
+    torch.testing.assert_close(zz.grad[:live], zr.grad, rtol=2e-5, atol=2e-6 * float(zr.grad.abs().max()))
+    for a, b in zip(ref_m.parameters(), m.parameters()):
+        assert torch.isfinite(b.grad).all()
+        torch.testing.assert_close(b.grad, a.grad, rtol=5e-5, atol=5e-6 * float(a.grad.abs().max()))
+
+
 @pytest.mark.parametrize('passes', [True, False])
 def test_made_block_with_the_permute_layer_folded_in_equals_block_then_permute(monkeypatch, passes):
     """MADE.forward(z, reverse_out=True) -- the PermuteLayer behind an IAF block as reversed column stores of the block's last
