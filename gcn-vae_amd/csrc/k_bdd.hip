@@ -38,11 +38,6 @@ struct AggParams {
     int nb;
     int p, q;  // runtime block sizes (generic kernel)
     int nbp;   // blocks per column part (fast kernels: grid.y parts of nbp blocks each, nbp/BPL <= 64 lanes)
-    // split rows finished INSIDE the launch (fix_ctr != NULL): see "the slice that arrives last sums its row" below
-    const int4* fix;
-    int n_fix;
-    int* fix_ctr;  // [n_fix][gridDim.y] arrival counters, zero before and after every launch
-    int fix_nw;    // waves of the stand-alone fix-up's workgroup (its summation order is reproduced bit for bit)
 };
 
 __device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -50,123 +45,6 @@ __device__ __forceinline__ float rl_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-
-// ---- split rows finished inside the aggregation launch: the slice that arrives last sums its row ------------------------------
-// A hub row is cut into <= chunk-edge slices, each summed by its own wave into a partial slot; the stand-alone fix-up launch
-// (k_agg_fixup) then adds a row's slots in slot order and applies the epilogue.  That launch is 5-6 us of a 1 ms step four or
-// five times over, so with AggParams.fix_ctr the LAST slice of a row to finish does its work instead:
-//   every slice:  partial slot stored with agent-scope (write-through, sc1) stores -> s_waitcnt vmcnt(0) -> ONE agent-scope
-//                 atomic add on the row's counter (per column part);
-//   the slice whose add returned slices - 1:  counter back to 0 (the next launch finds it clear), agent-scope acquire
-//                 (this CU's L1 may hold lines of the partial buffer from an earlier launch), the row's slots read back with
-//                 agent-scope loads and added IN THE FIX-UP'S ORDER (shares of fix_nw waves, four interleaved chains each),
-//                 then the ordinary epilogue and store of a whole row.
-// Per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by another CU's stores (MI355X guide,
-// "inter-workgroup visibility"): hence write-through stores, the drained vector-memory counter in front of the add, and the
-// acquire + L1-bypassing loads on the reading side.  Which slice sums is timing; WHAT it sums, and in which order, is not:
-// results are bit-identical to the two-launch form (tests/test_gpu_ops.py::test_fused_fixup_*).
-__device__ __forceinline__ int find_fix(const int4* __restrict__ fix, int n_fix, int slot) {
-    // entries are in row order, first slots ascending; an upper-bound-sized list ends in {-1, -1, -1, -1} entries.  A 64-ary
-    // search with the wave's lanes (ALL 64 must be alive): each round is one load + one ballot, two rounds for 4 096 entries --
-    // a binary search is a dozen dependent loads, 5 us at the end of a wave whose whole slice took 3
-    const int lane = threadIdx.x & 63;
-    int base = 0, span = n_fix;           // the answer lies in [base, base + span)
-    while (span > 1) {
-        const int step = (span + 63) >> 6;
-        const int i = base + lane * step;
-        int y = -1;
-        if (lane * step < span) y = fix[i].y;
-        const unsigned long long hit = __ballot(y >= 0 && y <= slot);      // a prefix of the lanes (slot >= the first entry's)
-        const int c = max(1, __popcll(hit));
-        base += (c - 1) * step;
-        span = min(step, span - (c - 1) * step);
-    }
-    return base;
-}
-
-template <int W>
-__device__ __forceinline__ void st_agent(float* p, const float (&v)[W]) {
-#pragma unroll
-    for (int i = 0; i < W; ++i) __hip_atomic_store(p + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <int W>
-__device__ __forceinline__ void ld_agent(const float* p, float (&v)[W]) {
-#pragma unroll
-    for (int i = 0; i < W; ++i) v[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// ordered_slot_sum (below) for W consecutive columns of a lane: the same four chains over the same elements in the same order
-template <int W>
-__device__ __forceinline__ void ordered_slot_sum_agent(const float* p, int n, size_t stride, float (&out)[W]) {
-    float a[4][W];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int i = 0; i < W; ++i) a[c][i] = 0.f;
-    int k = 0;
-    for (; k + 8 <= n; k += 8) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float v[4][W];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) ld_agent<W>(p + (size_t)(k + 4 * half + c) * stride, v[c]);
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int i = 0; i < W; ++i) a[c][i] += v[c][i];
-        }
-    }
-    for (; k < n; ++k) {
-        float v[W];
-        ld_agent<W>(p + (size_t)k * stride, v);
-#pragma unroll
-        for (int i = 0; i < W; ++i) a[0][i] += v[i];
-    }
-#pragma unroll
-    for (int i = 0; i < W; ++i) out[i] = (a[0][i] + a[1][i]) + (a[2][i] + a[3][i]);
-}
-
-// Called by every lane that stored a piece of the slice's slot (lane 0 among them), after those stores; fi = find_fix(slot), found
-// while all 64 lanes were still alive.  True for the wave that arrived
-// last: `f` is the row's fix entry {row, first slot, slices, 0} and the wave goes on to sum the row (split_row_sum) and finish it.
-__device__ __forceinline__ bool split_arrive(const AggParams& a, int fi, int4& f) {
-    f = a.fix[fi];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partial stores have left
-    int* ctr = a.fix_ctr + (size_t)fi * gridDim.y + blockIdx.y;
-    int prev = 0;
-    if ((threadIdx.x & 63) == 0) prev = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    prev = __builtin_amdgcn_readfirstlane(prev);
-    if (prev + 1 < f.z) return false;
-    if ((threadIdx.x & 63) == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return true;
-}
-
-// the sum of row f's slots for W consecutive columns from `col`, in k_agg_fixup's order (fix_nw shares added in wave order)
-template <int W>
-__device__ __forceinline__ void split_row_sum(const AggParams& a, const int4& f, int col, float (&acc)[W]) {
-    if constexpr (W > 4 && W % 4 == 0) {      // four columns at a time: the tail must not set the kernel's register count
-#pragma unroll 1
-        for (int h = 0; h < W / 4; ++h) {
-            float t[4];
-            split_row_sum<4>(a, f, col + 4 * h, t);
-#pragma unroll
-            for (int q = 0; q < W / 4; ++q)
-                if (q == h) { acc[4 * q] = t[0]; acc[4 * q + 1] = t[1]; acc[4 * q + 2] = t[2]; acc[4 * q + 3] = t[3]; }
-        }
-        return;
-    }
-    const int nw = a.fix_nw, per = (f.z + nw - 1) / nw;
-    for (int w = 0; w < nw; ++w) {
-        const int k0 = min(f.z, w * per), k1 = min(f.z, k0 + per);
-        float s[W];
-#pragma unroll
-        for (int i = 0; i < W; ++i) s[i] = 0.f;
-        if (k1 > k0) ordered_slot_sum_agent<W>(a.partial + (size_t)(f.y + k0) * a.out_dim + col, k1 - k0, (size_t)a.out_dim, s);
-#pragma unroll
-        for (int i = 0; i < W; ++i) acc[i] = w == 0 ? s[i] : acc[i] + s[i];
-    }
-}
 
 template <int P, int Q, bool TRANS, int BPL>
 __device__ __forceinline__ void block_fma(const float (&x)[BPL * P], const float (&w)[BPL * P * Q], float c,
@@ -313,20 +191,12 @@ __global__ __launch_bounds__(256) void k_agg_fast(const AggParams a) {
     
         }
     }
-    const int fix_i = (it.w >= 0 && a.fix_ctr) ? find_fix(a.fix, a.n_fix, it.w) : 0;      // (all 64 lanes search)
     if (!active) return;
     const int col0 = blk0 * Q;
-    int row = it.x;
-    if (it.w >= 0) {
-        if (!a.fix_ctr) {
-            store_vec<PV>(a.partial + (size_t)it.w * a.out_dim + col0, acc);
-            return;
-        }
-        st_agent<PV>(a.partial + (size_t)it.w * a.out_dim + col0, acc);
-        int4 f;
-        if (!split_arrive(a, fix_i, f)) return;
-        split_row_sum<PV>(a, f, col0, acc);      // the last slice of the row to arrive: the row's sum, then its epilogue
-        row = f.x;
+    const int row = it.x;
+    if (it.w >= 0) {                             // a slice of a split (hub) row: its partial slot, summed in order by k_agg_fixup
+        store_vec<PV>(a.partial + (size_t)it.w * a.out_dim + col0, acc);
+        return;
     }
     if (a.addend) {
         float ad[PV];
@@ -432,20 +302,12 @@ __global__ __launch_bounds__(256) void k_agg_split(const AggParams a) {
             }
         }
     }
-    const int fix_i = (it.w >= 0 && a.fix_ctr) ? find_fix(a.fix, a.n_fix, it.w) : 0;      // (all 64 lanes search)
     if (!active) return;
     const int col0 = blk * QO + sub * QS;
-    int row = it.x;
+    const int row = it.x;
     if (it.w >= 0) {
-        if (!a.fix_ctr) {
-            store_vec<QS>(a.partial + (size_t)it.w * a.out_dim + col0, acc);
-            return;
-        }
-        st_agent<QS>(a.partial + (size_t)it.w * a.out_dim + col0, acc);
-        int4 f;
-        if (!split_arrive(a, fix_i, f)) return;
-        split_row_sum<QS>(a, f, col0, acc);
-        row = f.x;
+        store_vec<QS>(a.partial + (size_t)it.w * a.out_dim + col0, acc);
+        return;
     }
     if (a.addend) {
         float ad[QS];
@@ -583,9 +445,8 @@ __global__ __launch_bounds__(256) void k_agg_packed(const AggParams a) {
             r_keep = r;
         }
     }
-    const int fix_i = (it.w >= 0 && a.fix_ctr) ? find_fix(a.fix, a.n_fix, it.w) : 0;      // (all 64 lanes search)
     if (!active) return;
-    int row = it.x;
+    const int row = it.x;
     if (it.w >= 0) {
 #pragma unroll
         for (int sb = 0; sb < BPL; ++sb) {
@@ -593,20 +454,9 @@ __global__ __launch_bounds__(256) void k_agg_packed(const AggParams a) {
             float o[Q];
 #pragma unroll
             for (int i = 0; i < Q; ++i) o[i] = acc[sb * Q + i];
-            if (a.fix_ctr) st_agent<Q>(a.partial + (size_t)it.w * a.out_dim + col, o);
-            else store_vec<Q>(a.partial + (size_t)it.w * a.out_dim + col, o);
+            store_vec<Q>(a.partial + (size_t)it.w * a.out_dim + col, o);
         }
-        if (!a.fix_ctr) return;
-        int4 f;
-        if (!split_arrive(a, fix_i, f)) return;
-#pragma unroll
-        for (int sb = 0; sb < BPL; ++sb) {       // the last slice of the row to arrive: the row's sum, then its epilogue
-            float o[Q];
-            split_row_sum<Q>(a, f, owned_block<BPL, ADJ>(lane, sb, L) * Q, o);
-#pragma unroll
-            for (int i = 0; i < Q; ++i) acc[sb * Q + i] = o[i];
-        }
-        row = f.x;
+        return;
     }
 #pragma unroll
     for (int sb = 0; sb < BPL; ++sb) {
@@ -1198,18 +1048,6 @@ extern "C" int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const in
                                      int weight_packed, const float* addend, int ld_addend, int act,
                                      const uint8_t* keep, float keep_scale, float* out, int ld_out, float* partial,
                                      void* stream) {
-    return gv_rgcn_bdd_aggregate_arrive(items, n_items, fix, n_fix, nbr, etype, coef, coef_idx, feat, ld_feat, weight, num_rels,
-                                        num_bases, blk_in, blk_out, transpose_w, weight_packed, addend, ld_addend, act, keep,
-                                        keep_scale, out, ld_out, partial, nullptr, 0, stream);
-}
-
-extern "C" int gv_rgcn_bdd_aggregate_arrive(const int32_t* items, int n_items, const int32_t* fix, int n_fix,
-                                            const int32_t* nbr, const int32_t* etype, const float* coef,
-                                            const int32_t* coef_idx, const float* feat, int ld_feat, const float* weight,
-                                            int num_rels, int num_bases, int blk_in, int blk_out, int transpose_w,
-                                            int weight_packed, const float* addend, int ld_addend, int act,
-                                            const uint8_t* keep, float keep_scale, float* out, int ld_out, float* partial,
-                                            int32_t* fix_counters, int64_t n_fix_counters, void* stream) {
     GV_REQUIRE(n_items >= 0 && n_fix >= 0, GV_ERR_SHAPE, "gv_rgcn_bdd_aggregate: negative item count");
     if (n_items == 0) return GV_OK;
     // nbr / etype may be NULL for an edge-less graph (every item then has begin == end and never reads them)
@@ -1227,11 +1065,6 @@ extern "C" int gv_rgcn_bdd_aggregate_arrive(const int32_t* items, int n_items, c
     a.w_row = num_bases * blk_in * blk_out; a.addend = addend; a.ld_add = ld_addend; a.act = act; a.keep = keep;
     a.keep_scale = keep_scale; a.out = out; a.ld_out = ld_out; a.partial = partial;
     a.out_dim = num_bases * blk_out; a.nb = num_bases; a.p = blk_in; a.q = blk_out;
-    // split rows finished by their last slice inside the launch (k_agg_fast / _split / _packed) when the caller lends counters:
-    // GV_K1_FIX_PARTS per fix entry (one per column part), all zero -- the launch leaves them zero
-    const int fix_nw = (long long)n_fix * ((a.out_dim + 63) / 64) >= 65536 ? 16 : 4;      // the stand-alone fix-up's workgroup
-    const bool lend = fix_counters && n_fix > 0 && n_fix_counters >= (int64_t)n_fix * GV_K1_FIX_PARTS;
-    a.fix = (const int4*)fix; a.n_fix = n_fix; a.fix_ctr = lend ? fix_counters : nullptr; a.fix_nw = fix_nw;
     hipStream_t st = (hipStream_t)stream;
     // vector paths: 16-B accesses need every row base 16-B aligned (ld % 4); the odd block sizes (5, 10) only
     // issue 8-B accesses, for which ld % 2 suffices -- h = 500, 1000 satisfy both
@@ -1280,7 +1113,6 @@ extern "C" int gv_rgcn_bdd_aggregate_arrive(const int32_t* items, int n_items, c
     const bool has_plan = lane_plan(num_bases, blk_in, &lp, true);
     const int bpl = has_plan ? lp.bpl : 0;
     if (rc == -1000) a.nbp = has_plan ? num_bases / lp.parts : num_bases;
-    if (rc == -1000 && lp.parts > GV_K1_FIX_PARTS) a.fix_ctr = nullptr;
 #define GV_AGG_CASE(P_, Q_, T_, B_, U_)                                                               \
     if (rc == -1000 && vec_ok && blk_in == P_ && blk_out == Q_ && (transpose_w != 0) == T_ && bpl == B_) \
         rc = launch_items(k_agg_fast<P_, Q_, T_, B_, U_>, a, n_items, st, "gv_rgcn_bdd_aggregate", lp.parts);
@@ -1319,14 +1151,13 @@ extern "C" int gv_rgcn_bdd_aggregate_arrive(const int32_t* items, int n_items, c
     GV_AGG_CASE(10, 10, true, 1, 1)
 #undef GV_AGG_CASE
     if (rc == -1000) {
-        a.fix_ctr = nullptr;      // (the generic kernel sweeps the row 64 columns at a time: its split rows keep the second launch)
         if (transpose_w)
             rc = launch_items(k_agg_generic<true>, a, n_items, st, "gv_rgcn_bdd_aggregate(generic)");
         else
             rc = launch_items(k_agg_generic<false>, a, n_items, st, "gv_rgcn_bdd_aggregate(generic)");
     }
     if (rc != GV_OK) return rc;
-    if (n_fix > 0 && !a.fix_ctr) {
+    if (n_fix > 0) {         // split (hub) rows: their slots summed in order, then the epilogue
         const int pairs = n_fix * ((a.out_dim + 63) / 64);
         hipLaunchKernelGGL(k_agg_fixup, dim3(pairs), dim3(pairs >= 65536 ? 1024 : 256), 0, st, (const int4*)fix, n_fix, partial,
                            a.out_dim, addend, ld_addend, act, keep, keep_scale, out, ld_out);

@@ -32,10 +32,6 @@ class SegmentItems:
     n_slots: int
     rowptr: torch.Tensor     # int32 [n_seg + 1]
     chunk: int
-    # the same items with the slices of split (hub) rows FIRST (static graphs only): the order of the launches that finish split
-    # rows themselves (ops.bdd_aggregate / gv_rgcn_bdd_aggregate_arrive) -- the slices are the longest items and the wave that
-    # arrives last still has the row to sum, so they start first and that tail runs under the rest of the grid
-    hub_first: Optional[torch.Tensor] = None
 
 
 def build_segment_items(rowptr: torch.Tensor, chunk: int, n_edges: Optional[int] = None) -> SegmentItems:
@@ -64,11 +60,7 @@ def build_segment_items(rowptr: torch.Tensor, chunk: int, n_edges: Optional[int]
         fix = torch.full((max(n_fix, 1), 4), -1, dtype=torch.int32, device=dev)
     lib.call('gv_segment_items_fill', ptr(rowptr), n_seg, chunk, ptr(offs[0]), ptr(offs[1]), ptr(offs[2]),
              ptr(items), ptr(fix), lib.stream())
-    hub_first = None
-    # exact lists (an index built once per graph): the hub-first order for the fused fix-up (opt-in: ops.FUSE_FIXUP)
-    if n_edges is None and n_fix > 0 and _os.environ.get('GV_K1_FUSE_FIXUP', '0') == '1':
-        hub_first = items[torch.argsort((items[:n_items, 3] < 0).to(torch.int8), stable=True)].contiguous()
-    return SegmentItems(items, fix, n_items, n_fix, n_slot_total, rowptr, chunk, hub_first)
+    return SegmentItems(items, fix, n_items, n_fix, n_slot_total, rowptr, chunk)
 
 
 def _rowptr_from_sorted(keys_sorted: torch.Tensor, n_seg: int) -> torch.Tensor:

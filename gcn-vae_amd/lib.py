@@ -35,8 +35,6 @@ SIGNATURES = {
     'gv_segment_items_fill': (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P]),
     'gv_rgcn_bdd_aggregate': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I,
                                    _P, _I, _I, _P, _F, _P, _I, _P, _P]),
-    'gv_rgcn_bdd_aggregate_arrive': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I,
-                                          _P, _I, _I, _P, _F, _P, _I, _P, _P, _L, _P]),
     'gv_rgcn_bdd_phase_plan': (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'gv_rgcn_bdd_pack_weight_phase': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'gv_rgcn_bdd_aggregate_phases': (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I,

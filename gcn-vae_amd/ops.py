@@ -314,30 +314,6 @@ def _check_items(seg: SegmentItems):
         raise ValueError('work-item list has no storage')
 
 
-# Split (hub) rows finished inside the aggregation launch by the slice that arrives last (csrc/k_bdd.hip, "the slice that arrives
-# last sums its row") instead of by a second launch: the launches borrow arrival counters that are zero before and after every
-# launch -- one pool per (device, stream), since two launches that may run concurrently must not share counters.
-# OFF by default -- measured on the FB15k-237 step (profiles/round4/fused_fixup_ab.txt): bit-identical results, 5 launches fewer,
-# but every K1 launch 5-17 us LONGER (1.054 -> 1.069 ms per step; the mini-batch step 0.989 -> 1.011): the row's sum is one wave's
-# dependent chain (store, drain, agent-scope add, acquire, 8 slots per round trip read back from memory) behind its last 128-edge
-# slice, i.e. it lengthens the critical path of the launch by more than the 5.4 us launch it saves, hub slices first or not.
-FUSE_FIXUP = _os.environ.get('GV_K1_FUSE_FIXUP', '0') == '1'
-FIX_PARTS = 8                      # = GV_K1_FIX_PARTS (include/gcnvae.h): counters per fix entry
-FIX_POOL_ENTRIES = 1 << 20         # 4 MB per stream that ever launches K1: fix lists of up to 131 072 hub rows
-_fix_pools = {}
-
-
-def fix_counters(n_fix):
-    """(pointer source, entries) of the current stream's counter pool, or (None, 0) when the list does not fit it."""
-    if n_fix <= 0 or n_fix * FIX_PARTS > FIX_POOL_ENTRIES:
-        return None, 0
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
-    pool = _fix_pools.get(key)
-    if pool is None:
-        pool = _fix_pools[key] = torch.zeros(FIX_POOL_ENTRIES, dtype=torch.int32, device='cuda')
-    return pool, FIX_POOL_ENTRIES
-
-
 def bdd_aggregate(seg: SegmentItems, nbr, etype, coef, coef_idx, feat, weight, num_bases, blk_in, blk_out,
                   transpose_w=False, addend=None, act=ACT_NONE, keep=None, keep_scale=1.0, out=None, packed=False):
     feat, ld_feat = _row_major(feat, 'feat')
@@ -368,16 +344,12 @@ def bdd_aggregate(seg: SegmentItems, nbr, etype, coef, coef_idx, feat, weight, n
         partial = torch.empty(seg.n_slots, out_dim, dtype=torch.float32, device=feat.device)
     ld_out = out.stride(0) if n_seg > 1 else out_dim
     tag = f'agg_{"T" if transpose_w else "N"}_{blk_in}x{blk_out}_nb{num_bases}'
-    # split rows finished inside the launch (opt-in, see FUSE_FIXUP): static graphs, whose lists come with the hub rows' slices first
-    fused = FUSE_FIXUP and seg.hub_first is not None
-    ctr, n_ctr = fix_counters(seg.n_fix) if fused else (None, 0)
-    items = seg.hub_first if ctr is not None else seg.items
-    # (per-kernel timing, bench.py: the two-launch form times the aggregation kernel alone; the fused form is one kernel anyway)
-    timed = lib.TIMER is not None and ctr is None
-    lib.call('gv_rgcn_bdd_aggregate_arrive', ptr(items), seg.n_items, ptr(seg.fix), 0 if timed else seg.n_fix, ptr(nbr),
+    # (per-kernel timing, bench.py: the aggregation kernel is timed alone, the split rows' fix-up launched behind it)
+    timed = lib.TIMER is not None
+    lib.call('gv_rgcn_bdd_aggregate', ptr(seg.items), seg.n_items, ptr(seg.fix), 0 if timed else seg.n_fix, ptr(nbr),
              ptr(etype), ptr(coef), ptr(coef_idx), ptr(feat), ld_feat, ptr(weight), num_rels, num_bases, blk_in,
              blk_out, 1 if transpose_w else 0, 1 if packed else 0, ptr(addend), ld_add, act, ptr(keep),
-             float(keep_scale), ptr(out), ld_out, ptr(partial), ptr(ctr), n_ctr, lib.stream(), tag=tag)
+             float(keep_scale), ptr(out), ld_out, ptr(partial), lib.stream(), tag=tag)
     if timed and seg.n_fix > 0:      # the aggregation kernel was timed alone; finish the split rows
         lib.call('gv_rgcn_bdd_fixup', ptr(seg.fix), seg.n_fix, ptr(partial), out_dim, ptr(addend), ld_add, act,
                  ptr(keep), float(keep_scale), ptr(out), ld_out, lib.stream())

@@ -81,21 +81,6 @@ int gv_rgcn_bdd_aggregate(const int32_t* items, int n_items, const int32_t* fix,
                           const float* addend, int ld_addend, int act, const uint8_t* keep, float keep_scale,
                           float* out, int ld_out, float* partial, void* stream);
 
-/* The same launch with the split (hub) rows FINISHED INSIDE IT: each slice stores its partial slot write-through, drains its
- * stores and adds 1 to the row's arrival counter; the slice whose add came last reads the row's slots back and adds them in the
- * fix-up pass's order (bit-identical results), then applies the epilogue -- no second launch.  fix_counters: int32
- * [n_fix_counters >= n_fix * GV_K1_FIX_PARTS], ALL ZERO at the call; the launch leaves them zero, so one buffer serves every
- * launch of a stream (not two launches that may run concurrently).  NULL / too small, or a block shape served by the generic
- * kernel: the two-launch form above. */
-#define GV_K1_FIX_PARTS 8
-int gv_rgcn_bdd_aggregate_arrive(const int32_t* items, int n_items, const int32_t* fix, int n_fix,
-                                 const int32_t* nbr, const int32_t* etype, const float* coef, const int32_t* coef_idx,
-                                 const float* feat, int ld_feat, const float* weight, int num_rels, int num_bases,
-                                 int blk_in, int blk_out, int transpose_w, int weight_packed,
-                                 const float* addend, int ld_addend, int act, const uint8_t* keep, float keep_scale,
-                                 float* out, int ld_out, float* partial, int32_t* fix_counters, int64_t n_fix_counters,
-                                 void* stream);
-
 /* Lane-packed relation weights for K1 (weight_packed = 1 above): the per-edge weight read becomes one
  * contiguous burst per load instruction (it dominates K1's cache traffic).  The layout depends on the launch
  * kind, so pack once per (layer, transpose_w) per step; packed has the size of weight.

@@ -297,6 +297,38 @@ def test_fused_passes_on_a_padded_batch_equal_the_launch_per_pass_path(monkeypat
         assert torch.equal(a, b) and float(a.abs().max()) > 0
 
 
+def test_non_finite_input_in_a_masked_out_group_is_skipped_here_and_poisons_the_reference(monkeypatch):
+    """Documented difference.  The reference forms mask * weight and multiplies EVERYTHING
+    (kgvae/flow_network.py:14-15): an infinite activation times a masked (zero) weight is NaN, torch.relu hands the NaN on, and the
+    whole row of the node's output is NaN.  Here (a) the fp32 chain multiplies only the 8-deep groups in which the mask holds a
+    non-zero, so a unit whose mask excludes the whole group of the infinite input never sees it, and (b) the kernels' ReLU is
+    fmaxf(x, 0), which returns 0 for a NaN: what a dense plan (GV_MADE_CHAIN_F32_SKIP=0) does produce is scrubbed at the next
+    activation.  The row stays finite except for the infinite column itself; its NaNs are a subset of the reference's; the other
+    rows are untouched.  On finite inputs the node is bit-identical to the launch-per-product path (the tests above)."""
+    from gcn_vae_amd import made
+    from oracle import flows as oflows
+    d, h, rows = 200, 200, 64
+    z = torch.randn(rows, d, generator=torch.Generator().manual_seed(21))
+    z[0, d - 2] = float('inf')          # degree d - 2: masked out of every hidden unit but one
+    outs = {}
+    for skip in (True, False):
+        monkeypatch.setattr(made, 'MADE_CHAIN_F32_SKIP', skip)
+        made._chain32_plans.clear()
+        m = _made(d, h, 3)
+        with torch.no_grad():
+            x, ld = m(z.cuda())
+        torch.cuda.synchronize()
+        outs[skip] = x.cpu()
+        state = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    made._chain32_plans.clear()
+    xo, _ = oflows.made_forward(z, oflows.made_layers_from_state(state, '', 3), d, h, 3)
+    assert bool(torch.isnan(xo[0]).all()), 'the reference poisons the whole row'
+    for skip, x in outs.items():
+        assert not torch.isnan(x[0]).any(), skip                    # (a subset of the reference's NaNs: here the empty one)
+        assert int(torch.isinf(x[0]).sum()) == 1 and bool(torch.isinf(x[0, d - 2])), skip
+        torch.testing.assert_close(x[1:], xo[1:], rtol=1e-4, atol=1e-5)          # the other rows: the reference's values
+
+
 def test_padding_rows_with_poisoned_gradients_do_not_reach_the_parameter_gradients():
     """ops.live_rows + the fused passes + gv_made_gradw_f32: the weight / bias gradient products reduce over all stacked rows, padding
     included, so the update's backward stores ZEROS as [g_mu | g_alpha] of padding rows whatever dL/dx and dL/dlogdet hold there (a

@@ -218,61 +218,6 @@ def test_rel_graph_conv_fwd_bwd(ops, fin, fout, nb, chunk):
         close(pg['loop_weight'].grad, po['loop_weight'].grad, msg='grad_loop')
 
 
-@pytest.mark.parametrize('fin,fout,nb', [(200, 200, 100), (200, 400, 100), (40, 40, 40), (200, 200, 20), (200, 400, 20),
-                                         (500, 500, 100), (500, 1000, 100), (16, 32, 4)])
-@pytest.mark.parametrize('chunk,sync_free', [(8, False), (64, False), (16, True)])
-def test_fused_fixup_equals_the_two_launch_form(ops, monkeypatch, fin, fout, nb, chunk, sync_free):
-    """Split (hub) rows finished inside the aggregation launch by the slice that arrives last (gv_rgcn_bdd_aggregate_arrive:
-    write-through partial stores, an arrival counter per row and column part, the slots read back and added in the fix-up pass's
-    order; opt-in, GV_K1_FUSE_FIXUP=1: it measured slower than the launch it saves) against the two-launch form, BIT FOR BIT: forward (2x2 / 2x4 / 1x1 / 10x10 / 10x20 / 5x5 / 5x10 / 4x8 blocks: the
-    per-row, lane-packed and column-split kernels, one and two column parts) and backward-x (the transposed launches).  Zipf 1.1:
-    a quarter of the edges end in one row -- hundreds of slices at 8 edges per item; sync-free lists end in -1 entries.  The
-    counters are left zero: the launches of the second pass run on the same pool."""
-    n, e, r = 300, 12000, 120                                             # (DGL clamps num_bases to num_rels)
-    src, dst, et, norm = zipf_graph(n, e, r, seed=fin + fout + nb + chunk)
-    order = np.lexsort((et.numpy(), src.numpy(), dst.numpy()))
-    src, dst, et, norm = src[order], dst[order], et[order], norm[order]
-    gen = torch.Generator().manual_seed(fin + 11 * nb)
-    x = torch.randn(n, fin, generator=gen)
-    p = orgcn.init_params(fin, fout, r, 'bdd', nb, True, True, gen)
-    p['h_bias'] = torch.randn(fout, generator=gen) * 0.1
-    keep = (torch.rand(n, fout, generator=gen) > 0.2).to(torch.uint8)
-    gout = torch.randn(n, fout, generator=gen)
-    monkeypatch.setattr(ops, 'lds_plan', lambda *a, **k: None)            # per-row kernels (the LDS / phase kernels keep their fix-up)
-    monkeypatch.setattr(ops, 'use_phases', lambda *a, **k: False)
-    gidx = ops.GraphIndex(src.cuda(), dst.cuda(), n, chunk=chunk, dst_sorted=True, sync_free=sync_free)
-    ridx = ops.RelationIndex(gidx, et.cuda(), r, chunk=max(4, chunk // 2))
-    assert gidx.by_dst.seg.n_fix > 0 and gidx.by_src.seg.n_fix > 0
-    for seg in (gidx.by_dst.seg, gidx.by_src.seg):
-        if seg.hub_first is None:      # (built by the index only with GV_K1_FUSE_FIXUP=1, and never for per-batch lists)
-            seg.hub_first = seg.items[torch.argsort((seg.items[:seg.n_items, 3] < 0).to(torch.int8), stable=True)].contiguous()
-        first = seg.hub_first[:, 3] >= 0
-        assert int(first.sum()) > 0 and bool(first[:int(first.sum())].all())          # every slice in front of every whole row
-    lent = []
-    real_counters = ops.fix_counters
-    monkeypatch.setattr(ops, 'fix_counters', lambda n: (lent.append(n), real_counters(n))[1])
-
-    def run(fused):
-        monkeypatch.setattr(ops, 'FUSE_FIXUP', fused)
-        xg = x.cuda().requires_grad_(True)
-        pg = {k: v.cuda().requires_grad_(True) for k, v in p.items()}
-        hg = ops.rel_graph_conv_bdd(xg, pg['weight'], pg['h_bias'], pg['loop_weight'], norm.cuda(), gidx, ridx, nb, 1, keep.cuda(),
-                                    1.0 / 0.8)
-        hg.backward(gout.cuda())
-        return hg.detach(), xg.grad
-
-    h0, gx0 = run(False)
-    pool = None
-    for _ in range(2):
-        h1, gx1 = run(True)
-        assert torch.equal(h1, h0) and torch.equal(gx1, gx0)
-        pool = real_counters(1)[0]
-        assert pool is not None and int(pool.abs().max()) == 0            # every counter is back at zero
-    assert len(lent) == 4                                                  # forward and backward-x of both fused runs borrowed counters
-    ho = orgcn.rel_graph_conv(x, src, dst, et, norm, p, 'bdd', nb, torch.relu, dropout_keep=keep, dropout_p=0.2)
-    close(h1, ho, msg='forward vs the oracle')
-
-
 @pytest.mark.parametrize('fin,fout,nb,r', [(200, 200, 20, 22), (200, 400, 20, 22), (200, 400, 20, 20), (100, 100, 10, 13)])
 @pytest.mark.parametrize('max_edges,shuffle', [(64, False), (8, False), (64, True)])
 def test_rel_graph_conv_lds_resident_weights(ops, monkeypatch, fin, fout, nb, r, max_edges, shuffle):
