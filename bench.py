@@ -487,6 +487,24 @@ def rewarm(step_fn, seconds):
 
 
 EXIT_NONFINITE_LOSS = 4
+EXIT_RANK_FAILED = 5           # a rank raised outside the recoverable places: it names itself and its phase on stderr, then leaves
+
+_PHASE = ['start']
+
+
+def phase(name):
+    """Name the part of the run this rank is in (printed when it fails) -- and, for tests, fail here: GV_BENCH_FAIL=<rank>/<phase prefix>[/exit]
+    raises in that rank when it enters a phase whose name starts with the prefix ('/exit': the process dies without a word, as a
+    rank killed from outside would)."""
+    _PHASE[0] = name
+    spec = os.environ.get('GV_BENCH_FAIL')
+    if spec:
+        parts = spec.split('/')
+        if len(parts) >= 2 and parts[0] == os.environ.get('RANK', '0') and name.startswith(parts[1]):
+            if len(parts) > 2 and parts[2] == 'exit':
+                os._exit(9)
+            raise RuntimeError(f'injected failure (GV_BENCH_FAIL={spec})')
+
 
 
 def result_exit_code(rec):
@@ -728,6 +746,26 @@ def run_minibatch(args):
 
 
 def main():
+    """Every failure of a rank outside the recoverable places (a refused capture falls back to eager launches on all ranks) ends the
+    rank with EXIT_RANK_FAILED after ONE stderr line naming rank and phase; the launcher (torch.distributed.run) then stops the other
+    ranks, and a rank blocked in a collective with a dead peer leaves the same way once the collective times out
+    (distributed.collective_timeout)."""
+    try:
+        return _main()
+    except SystemExit:
+        raise
+    except BaseException as exc:      # noqa: BLE001 -- the point is to leave, loudly, whatever it was
+        rank = os.environ.get('RANK', '0')
+        print(f'[bench] rank {rank} failed in phase "{_PHASE[0]}": {type(exc).__name__}: {str(exc).splitlines()[0] if str(exc) else ""}',
+              file=sys.stderr, flush=True)
+        if os.environ.get('GV_BENCH_TRACEBACK'):
+            import traceback
+            traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(EXIT_RANK_FAILED)      # (no interpreter teardown: a half-built process group can hang in its destructors)
+
+
+def _main():
     args = parse()
     if args.config == 'mb':
         return run_minibatch(args)
@@ -756,7 +794,7 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29511')
         import torch.distributed as _d
         torch.cuda.set_device(local_rank)
-        _d.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', local_rank))
+        _d.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', local_rank), timeout=gdist.collective_timeout())
     # GV_DIST_BACKEND=gloo: functional check of the multi-rank path on a box with fewer GPUs than ranks (ranks then share
     # devices; gloo moves CUDA tensors through the host).  Never a performance configuration.
     backend = os.environ.get('GV_DIST_BACKEND', 'nccl')
@@ -768,7 +806,7 @@ def main():
         torch.cuda.set_device(dev_index)
         import torch.distributed as _dg
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        _dg.init_process_group(backend)
+        _dg.init_process_group(backend, timeout=gdist.collective_timeout())
     else:
         gdist.init_process_group('nccl' if world > 1 else None)
     torch.cuda.set_device(dev_index)
@@ -776,6 +814,7 @@ def main():
     lib.load()
     import torch.distributed as dist
 
+    phase('setup: workload + model')
     w = make_workload(rank, world, args, dev)
     model = build_model(w, args).to(dev).train()
     n_nodes, E = w['data'].num_nodes, int(w['src'].numel())
@@ -885,6 +924,7 @@ def main():
             sg, out = SegmentedGraph(), None
             try:
                 refresh_host_inputs()
+                phase('capture: hipGraph segments')
                 out = sg.capture(step_body, stream=side)
             except Exception as exc:
                 print(f'[bench] segmented capture failed on rank {rank}: {type(exc).__name__}: {exc}; running eagerly',
@@ -894,6 +934,7 @@ def main():
                     traceback.print_exc()
                 sg = None
                 torch.cuda.synchronize()
+            phase('capture: agreeing on the program')
             if world > 1:      # all ranks must run the same program: one failed capture sends everybody to eager launches
                 ok = torch.tensor([1 if sg is not None else 0], device=dev)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -936,6 +977,7 @@ def main():
 
     # candidates = scheme x launch mode.  With collectives on the step the launch mode is part of the question: segments
     # remove the per-kernel host cost but add a graph launch per segment; "auto" measures instead of guessing.
+    phase('warm-up, capture and probe of the partition schemes')
     programs, probe = {}, {}
     auto = dist_on and args.partition == 'auto'
     # Every scheme / launch variant is warmed, captured and probed from the SAME initial weights and moments, and so are the timed
@@ -1017,6 +1059,7 @@ def main():
     # from the same weights): `value` is the median region, the first region's figure is reported beside it
     regions = []
     for _rep in range(max(1, args.repeats)):
+        phase(f'timed region {_rep + 1}')
         opt.restore(snap)
         torch.cuda.synchronize()
         if world > 1:
@@ -1048,6 +1091,7 @@ def main():
         dist.all_reduce(ec)
         edge_counts = [int(v) for v in ec.tolist()]
 
+    phase('roofline leg (instrumented eager steps)')
     # ---- roofline leg: the same step, eager, with HIP events around the K1 launches --------------
     roofline, detail, k4 = None, {}, {}
     per_rank_k1 = None

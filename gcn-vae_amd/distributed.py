@@ -26,6 +26,14 @@ def env_world():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
 
 
+def collective_timeout():
+    """Seconds a collective may take before the process group gives up on it (GV_DIST_TIMEOUT, default 300 -- torch's own default
+    is 10 / 30 minutes): a rank that died or never arrived then costs every other rank that long at most, after which RCCL's
+    watchdog (or gloo's wait) raises and the rank exits non-zero naming the phase it was in (bench.py, train.py)."""
+    import datetime
+    return datetime.timedelta(seconds=float(os.environ.get('GV_DIST_TIMEOUT', '300')))
+
+
 def init_process_group(backend=None):
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
@@ -36,9 +44,9 @@ def init_process_group(backend=None):
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend, device_id=torch.device('cuda', local_rank))
+            dist.init_process_group(backend, device_id=torch.device('cuda', local_rank), timeout=collective_timeout())
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=collective_timeout())
     return rank, local_rank, world
 
 

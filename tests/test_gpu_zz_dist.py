@@ -153,8 +153,29 @@ def test_bench_starts_its_own_ranks_strong_scaling_by_default():
     assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['scaling'] == 'strong'
     assert d['config']['trained_graph_edges'] == 544230
     assert len(d['ms_per_step_repeats']) == 3 and d['ms_per_step_median'] > 0
-    assert abs(d['ms_per_step'] - d['ms_per_step_repeats'][0]) < 1e-3
+    assert abs(d['ms_per_step'] - d['ms_per_step_median']) < 1e-9 and abs(d['ms_per_step_first_region'] - d['ms_per_step_repeats'][0]) < 1e-3
     assert len(d['k1_GBs_per_rank']) == 2 and all(v and min(v.values()) > 0 for v in d['k1_GBs_per_rank'])
+
+
+@pytest.mark.parametrize('fail,expect', [('1/capture: agreeing', 'rank 1 failed in phase "capture: agreeing on the program"'),
+                                         ('1/capture: agreeing/exit', 'rank 0 failed in phase "capture: agreeing on the program"'),
+                                         ('0/timed region 2', 'rank 0 failed in phase "timed region 2"')])
+def test_a_failing_rank_ends_the_whole_job_with_a_status_and_a_named_phase(fail, expect):
+    """First-contact robustness of the multi-rank bench: a rank that raises outside the recoverable places -- or dies without a word
+    ('/exit': the peer then fails in the collective it was waiting in) -- ends with EXIT_RANK_FAILED after one stderr line naming
+    rank and phase; the launcher stops the other rank; `bench.py --gpus 2` returns non-zero instead of hanging until the driver's
+    limit.  (GV_BENCH_FAIL injects the failure; GV_DIST_TIMEOUT bounds what a collective may wait for a dead peer.)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GV_DIST_BACKEND='gloo', GV_BENCH_FAIL=fail, GV_DIST_TIMEOUT='60')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+           '--profile-steps', '0', '--positives', '2000', '--partition', 'edge', '--probe-steps', '2']
+    t0 = time.time()
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0, out.stderr[-2000:]
+    assert expect in out.stderr, out.stderr[-3000:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{')], 'no result line from a failed job'
+    assert time.time() - t0 < 400
 
 
 @pytest.mark.parametrize('partition', ['edge', 'row'])

@@ -66,22 +66,31 @@ def main():
 
 # ---- STRONG scaling (bench.py's default with more than one rank: ONE graph, BASELINE configs[3..4]) ------------------------------
 STRONG = {
-    # measured 1-GPU steps (profiles/round3-4); node_share = the part of the step that is row-wise over nodes / triplets / parameters
+    # measured 1-GPU steps (profiles/round5); node_share = the part of the step that is row-wise over nodes / triplets / parameters
     # (self-loop products, epilogues, reparameterisation, KL, MMD, decoder, clip + Adam): replicated under edge sharding, divided
-    # under the row partition; the rest is K1 (aggregations + grad-W), divided by both
-    'c2 (FB15k-237, h=200)': dict(N=14541, h=200, other_mb=2.9, t1_ms=1.06, node_share=0.45),
-    'c4 (FB15k-237, h=500)': dict(N=14541, h=500, other_mb=14.6, t1_ms=3.44, node_share=0.35),
-    'c5 (1 M entities, 50 M edges, h=200)': dict(N=1_000_000, h=200, other_mb=3.0, t1_ms=82.0, node_share=0.22),
+    # under the row partition; the rest is K1 (aggregations + grad-W), divided by both.  k1_rel_gain: what a relation shard buys K1
+    # itself -- a rank then touches R/p relation types, so the phase kernels stage 1/p of the table per tile (FB15k-237 at h = 500:
+    # 4 phases instead of 32 -> the measured no-barrier / no-staging bound, profiles/round5/phase_ablation.txt; 1 M nodes: the
+    # 1.3x weight re-fetch traffic goes) -- applied to the K1 share only
+    'c2 (FB15k-237, h=200)': dict(N=14541, h=200, other_mb=2.9, t1_ms=1.02, node_share=0.45, k1_rel_gain=1.0),
+    'c4 (FB15k-237, h=500)': dict(N=14541, h=500, other_mb=14.6, t1_ms=3.09, node_share=0.38, k1_rel_gain=1.35),
+    'c5 (1 M entities, 50 M edges, h=200)': dict(N=1_000_000, h=200, other_mb=3.0, t1_ms=76.6, node_share=0.22, k1_rel_gain=1.15),
 }
 
 
 def strong(bw, alpha):
-    """Predicted STRONG-scaling step time and speed-up t(1) / t(p).  edge = edge blocks by relation + all-reduce of node rows
-    (north_star); edge+shard = the same with the optimiser sharded (reduce-scatter of the gradient arena, clip + Adam on 1/p of it,
-    all-gather of the updated parameters: the replicated Adam and half of the arena exchange go away); rows = destination-row
-    partition (all-gather forward, reduce-scatter backward, node-level work divided).  Collectives 'direct' (every peer on its own
-    link) / 'ring' (one link); half of each layer exchange is taken as hidden under the neighbouring kernels, as measured for
-    the 2-rank shared-GPU runs -- a guess until a SCALE run exists."""
+    """Predicted STRONG-scaling step time and speed-up t(1) / t(p).
+      edge          edge blocks by relation + all-reduce of node rows (north_star as written): node-level work replicated
+      edge+shard    ... with the optimiser sharded (reduce-scatter of the gradient arena, clip + Adam on 1/p of it, all-gather of
+                    the updated parameters)
+      rel+rows      north_star's relation shard WITHOUT the replicated node-level work: K1 over the rank's relations produces partial
+                    rows of the whole table, REDUCE-SCATTER gives every rank the rows it owns, the node-level work runs on N/p rows,
+                    ALL-GATHER rebuilds the table for the next layer (backward: all-gather of dL/dh, K1^T, reduce-scatter) -- twice
+                    the bytes of the row partition per layer, K1 itself faster (k1_rel_gain).  Modelled, not built: see the table
+      rows          destination-row partition (all-gather forward, reduce-scatter backward, node-level work divided): what is built
+    Collectives 'direct' (every peer on its own link) / 'ring' (one link).  `hidden` = the fraction of every layer exchange that
+    runs under kernels: 0.5 is what the 2-rank shared-GPU runs showed; 1.0 is the bound no schedule can beat (the arena exchange
+    of the optimiser is never hidden: it sits between backward and the update)."""
     for name, c in STRONG.items():
         S1, S2 = c['N'] * c['h'] * 4, c['N'] * 2 * c['h'] * 4
         arena = S1 + c['other_mb'] * 1e6
@@ -89,21 +98,28 @@ def strong(bw, alpha):
         adam = min(0.3 * t1 * c['node_share'], 4 * arena * 2 / 4.0e12)      # clip + Adam: ~8 arena passes at ~4 TB/s
         print(f'\n{name}: 1-GPU step {c["t1_ms"]} ms, node-level share {c["node_share"]}, S1 {S1 / 1e6:.1f} MB, S2 {S2 / 1e6:.1f} MB, '
               f'arena {arena / 1e6:.1f} MB (STRONG scaling: one graph)')
-        print(f'{"ranks":>5} {"scheme":>26} {"compute ms":>11} {"exposed collectives ms":>23} {"step ms":>8} {"speed-up":>9}')
+        print(f'{"ranks":>5} {"scheme":>28} {"compute ms":>11} {"layer exchanges ms":>19} {"arena ms":>9} {"step ms (half hidden)":>22} '
+              f'{"speed-up":>9} {"all hidden":>11}')
         for p in (2, 4, 8):
             for direct in (True, False):
                 tag = 'direct' if direct else 'ring'
                 k1, node = t1 * (1 - c['node_share']), t1 * c['node_share']
                 ar = 2 * (t_allreduce(S1, p, bw, alpha, direct) + t_allreduce(S2, p, bw, alpha, direct))
-                rows = [('edge / ' + tag, k1 / p + node, 0.5 * ar + t_allreduce(arena, p, bw, alpha, direct)),
-                        ('edge+sharded Adam / ' + tag, k1 / p + node - adam * (1 - 1 / p), 0.5 * ar + 2 * t_gather(arena, p, bw, alpha, direct)),
-                        ('rows / ' + tag, (k1 + node) / p,
-                         0.5 * 2 * (t_gather(S1, p, bw, alpha, direct) + t_gather(S2, p, bw, alpha, direct)) + t_allreduce(arena, p, bw, alpha, direct)),
-                        ('rows+sharded Adam / ' + tag, (k1 + node) / p,
-                         0.5 * 2 * (t_gather(S1, p, bw, alpha, direct) + t_gather(S2, p, bw, alpha, direct)) + 2 * t_gather(arena, p, bw, alpha, direct))]
-                for label, comp, coll in rows:
-                    step = comp + coll
-                    print(f'{p:5d} {label:>26} {comp * 1e3:11.3f} {coll * 1e3:23.3f} {step * 1e3:8.3f} {t1 / step:9.2f}')
+                ag = 2 * (t_gather(S1, p, bw, alpha, direct) + t_gather(S2, p, bw, alpha, direct))
+                # rel+rows: layer 1 forward RS(S1) [its input is the replicated table], layer 2 forward AG(S1) + RS(S2); backward
+                # AG(S2) + RS(S1), AG(S1) + [layer 1's dL/dx is a parameter gradient]: three exchanges of S1 and one of S2 each way
+                relrows = 2 * (2 * t_gather(S1, p, bw, alpha, direct) + t_gather(S2, p, bw, alpha, direct)) + \
+                    2 * t_gather(S1, p, bw, alpha, direct)
+                rows = [('edge / ' + tag, k1 / p + node, ar, t_allreduce(arena, p, bw, alpha, direct)),
+                        ('edge+sharded Adam / ' + tag, k1 / p + node - adam * (1 - 1 / p), ar, 2 * t_gather(arena, p, bw, alpha, direct)),
+                        ('rel+rows, sharded Adam / ' + tag, k1 / p / c['k1_rel_gain'] + node / p, relrows, 2 * t_gather(arena, p, bw, alpha, direct)),
+                        ('rows / ' + tag, (k1 + node) / p, ag, t_allreduce(arena, p, bw, alpha, direct)),
+                        ('rows+sharded Adam / ' + tag, (k1 + node) / p, ag, 2 * t_gather(arena, p, bw, alpha, direct))]
+                for label, comp, layer, ar_t in rows:
+                    step = comp + 0.5 * layer + ar_t
+                    best = comp + ar_t                       # every layer exchange hidden
+                    print(f'{p:5d} {label:>28} {comp * 1e3:11.3f} {layer * 1e3:19.3f} {ar_t * 1e3:9.3f} {step * 1e3:22.3f} '
+                          f'{t1 / step:9.2f} {t1 / best:11.2f}')
 
 
 if __name__ == '__main__':
