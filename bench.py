@@ -1005,17 +1005,27 @@ def _main():
             del modes[name]
             continue
         # (segments?, destination-row blocks of the edge scheme's chunked forward all-reduce)
-        variants = [(use_segments, 2)] if not (auto and use_segments) else [(True, 2), (False, 2)]
+        # (segments?, destination-row blocks of the edge scheme's chunked forward all-reduce, blocks of the row scheme's PIPELINED
+        #  layer exchange -- 1: one all-gather / reduce-scatter between the layers, not overlapped with their aggregations)
+        row_env = max(1, int(os.environ.get('GV_DIST_ROW_CHUNKS', '1')))
+        variants = [(use_segments, 2, row_env)] if not (auto and use_segments) else [(True, 2, row_env), (False, 2, row_env)]
         if auto and use_segments and name == 'edge':
-            variants.append((True, 1))        # one all-reduce per layer instead of two overlapped halves: 2 collectives fewer
-        for sgm, chunks in variants:
+            variants.append((True, 1, row_env))        # one all-reduce per layer instead of two overlapped halves: 2 collectives fewer
+        if auto and name == 'row' and world > 1:
+            variants += [(use_segments, 2, rc) for rc in (2, 4) if rc != row_env]      # the pipelined exchange, 2 and 4 blocks
+        for sgm, chunks, row_chunks in variants:
             opt.restore(snap0)
             _ops.DIST_FWD_CHUNKS = chunks
+            rp = getattr(model.encoder, 'row_part', None)
+            if rp is not None and rp.chunks != row_chunks:
+                rp.chunks = row_chunks
+                warm(1)        # the row blocks of this variant are cut (one host synchronisation) outside the capture
             if chunks != 2:
                 warm(1)        # the row-block cut of this variant is built (one host synchronisation) outside the capture
-            key = name if (len(variants) == 1 and not auto) else '%s/%s%s' % (name, 'segments' if sgm else 'eager',
-                                                                               '' if chunks == 2 else '/1-block')
-            programs[key] = (name,) + capture_current(sgm) + (chunks,)
+            key = name if (len(variants) == 1 and not auto) else '%s/%s%s%s' % (name, 'segments' if sgm else 'eager',
+                                                                                 '' if chunks == 2 else '/1-block',
+                                                                                 '' if row_chunks == row_env else '/pipelined-%d' % row_chunks)
+            programs[key] = (name,) + capture_current(sgm) + (chunks, row_chunks)
             if auto or len(modes) * len(variants) > 1:
                 k = max(1, args.probe_steps)
                 timed_run(1, programs[key][2])
@@ -1023,9 +1033,11 @@ def _main():
     if not programs:
         raise RuntimeError('bench.py: no multi-GPU scheme could run a step (see the messages above)')
     chosen = min(probe, key=probe.get) if probe else next(iter(programs))   # identical on all ranks (max-reduced times)
-    mode_name, launch, replay, static_loss, _ops.DIST_FWD_CHUNKS = programs[chosen]
+    mode_name, launch, replay, static_loss, _ops.DIST_FWD_CHUNKS, row_chunks = programs[chosen]
     if cur.get('name') != mode_name:
         configure(mode_name)
+    if getattr(model.encoder, 'row_part', None) is not None:
+        model.encoder.row_part.chunks = row_chunks
     opt.restore(snap0)
     T = int(cur['samples'].shape[0])
 

@@ -264,6 +264,50 @@ class RowPartition:
         if native is None:      # all_gather_into_tensor / reduce_scatter_tensor: RCCL yes, gloo no
             native = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == 'nccl'
         self.native = bool(native)
+        # PIPELINED exchanges (GV_DIST_ROW_CHUNKS = C > 1): a layer's output rows leave in C blocks of slot rows -- block k is
+        # gathered while block k + 1 is still being aggregated -- and the backward's partial gradient of the table is
+        # reduce-scattered the same way, block by block under the next block's K1^T (gather_rows / reduce_scatter_rows)
+        self.chunks = max(1, int(os.environ.get('GV_DIST_ROW_CHUNKS', '1')))
+
+    def chunk_bounds(self, chunks=None):
+        """[(a, b)] slot-row ranges of the pipelined exchanges: the same on every rank (collectives need equal sizes)."""
+        c = max(1, min(int(chunks or self.chunks), self.slot_rows))
+        cuts = sorted(set([0] + [(self.slot_rows * k) // c for k in range(1, c)] + [self.slot_rows]))
+        return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
+
+    def _views(self, full, a, b):
+        return [full[r * self.slot_rows + a:r * self.slot_rows + b] for r in range(self.world)]
+
+    def gather_rows(self, out_full, x_slot, a, b):
+        """Rows [a, b) of EVERY rank's slot into their places of the full table (out_full[r * slot + a : r * slot + b] <- rank r's
+        x_slot[a:b]).  Returns a handle with wait()."""
+        if self.world == 1:
+            out_full[a:b].copy_(x_slot[a:b])
+            return _Done()
+        mine = x_slot[a:b].contiguous()
+        if self.native:      # RCCL: the list form (the outputs are row ranges of one buffer, a stride apart)
+            views = self._views(out_full, a, b)
+            return start_collective(lambda: dist.all_gather(views, mine, group=self.group, async_op=True))
+        tmp = torch.zeros(self.world, b - a, x_slot.shape[1], dtype=x_slot.dtype, device=x_slot.device)      # functional fallback (gloo)
+        tmp[self.rank].copy_(mine)
+        start_collective(lambda: dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)).wait()
+        for r, v in enumerate(self._views(out_full, a, b)):
+            v.copy_(tmp[r])
+        return _Done()
+
+    def reduce_scatter_rows(self, out_slot, g_full, a, b):
+        """out_slot[a:b] <- sum over ranks of THIS rank's rows [a, b) of g_full (g_full[rank * slot + a : rank * slot + b])."""
+        if self.world == 1:
+            out_slot[a:b].copy_(g_full[a:b])
+            return _Done()
+        if self.native:
+            ins = [v.contiguous() for v in self._views(g_full, a, b)]
+            out = out_slot[a:b]
+            return start_collective(lambda: dist.reduce_scatter(out, ins, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        tmp = torch.stack([v for v in self._views(g_full, a, b)], 0).contiguous()                              # functional fallback (gloo)
+        start_collective(lambda: dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)).wait()
+        out_slot[a:b].copy_(tmp[self.rank])
+        return _Done()
 
     def all_gather(self, out_full, x_slot):
         """out_full (world*slot, h) <- every rank's slot (slot, h).  Returns a handle with wait()."""

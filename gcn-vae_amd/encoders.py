@@ -180,8 +180,14 @@ class KGVAE(ops.StayOnDevice, nn.Module):
         eps = self._draw_noise(c, x0.device)
         if eps.shape[0] != c:          # parity overrides are given for all positions: take the rank's rows
             eps = eps[part.row0:part.row0 + c].contiguous()
-        h1 = self.rconv_layer_1.forward_rows(g, x0, r, norm, part, gather_input=False, pad_output=True)
-        h2 = self.rconv_layer_2.forward_rows(g, h1, r, norm, part, gather_input=True, pad_output=False)
+        if getattr(part, 'chunks', 1) > 1:
+            # pipelined exchange (GV_DIST_ROW_CHUNKS): layer 1 gathers its rows block by block under its own aggregation; layer 2's
+            # backward reduce-scatters dL/dh1 block by block under its own K1^T
+            h1 = self.rconv_layer_1.forward_rows(g, x0, r, norm, part, gather_input=False, pad_output=True, gather_output=True)
+            h2 = self.rconv_layer_2.forward_rows(g, h1, r, norm, part, gather_input=False, pad_output=False, x_gathered=True)
+        else:
+            h1 = self.rconv_layer_1.forward_rows(g, x0, r, norm, part, gather_input=False, pad_output=True)
+            h2 = self.rconv_layer_2.forward_rows(g, h1, r, norm, part, gather_input=True, pad_output=False)
         z, self.z_mean, self.z_sigma = ops.reparam(h2, eps)
         self.flow_log_prob = None
         self._z_pri_flowed = None

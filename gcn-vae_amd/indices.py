@@ -213,6 +213,48 @@ class GraphIndex:
         self._chunk_cache[n_chunks] = out
         return out
 
+    def row_blocks(self, side: str, blocks):
+        """Work items of the ``side`` ('dst' / 'src') ordering restricted to BLOCKS of rows: ``blocks`` = one list of (row0, row1)
+        ranges per block (a block of the pipelined multi-GPU exchanges is the same slot-row range of every rank: ``world`` ranges of
+        the table).  Returns one SegmentItems per block (item / fix-up lists = the concatenated slices of the ordering's lists;
+        partial slots keep their numbers).  Cached per (side, blocks); synchronises once when built."""
+        key = (side, tuple(tuple((int(a), int(b)) for a, b in blk) for blk in blocks))
+        hit = self._chunk_cache.get(key)
+        if hit is not None:
+            return hit
+        seg = (self.by_dst if side == 'dst' else self.by_src).seg
+        n_items = int((seg.items[:seg.n_items, 0] >= 0).sum())
+        n_fix = int((seg.fix[:seg.n_fix, 0] >= 0).sum()) if seg.n_fix > 0 else 0
+        item_seg = seg.items[:n_items, 0].contiguous().to(torch.int64)
+        fix_seg = seg.fix[:n_fix, 0].contiguous().to(torch.int64)
+        flat = [r for blk in key[1] for ab in blk for r in ab]
+        bounds = torch.tensor(flat, device=seg.items.device, dtype=torch.int64)
+        ib = torch.searchsorted(item_seg, bounds).tolist()
+        fb = torch.searchsorted(fix_seg, bounds).tolist() if n_fix > 0 else [0] * len(flat)
+        out, q = [], 0
+        for blk in key[1]:
+            it, fx = [], []
+            for _ in blk:
+                it.append(seg.items[ib[q]:ib[q + 1]])
+                if n_fix > 0:
+                    fx.append(seg.fix[fb[q]:fb[q + 1]])
+                q += 2
+            items = torch.cat(it, 0).contiguous() if it else seg.items[:0]
+            fix = torch.cat(fx, 0).contiguous() if fx else seg.fix[:0]
+            if fix.shape[0] == 0:
+                fix = seg.fix[:1] if seg.fix.shape[0] else torch.full((1, 4), -1, dtype=torch.int32, device=seg.items.device)
+                nf = 0
+            else:
+                nf = int(fix.shape[0])
+            if items.shape[0] == 0:
+                items = torch.full((1, 4), -1, dtype=torch.int32, device=seg.items.device)
+                ni = 0
+            else:
+                ni = int(items.shape[0])
+            out.append(SegmentItems(items, fix, ni, nf, seg.n_slots, seg.rowptr, seg.chunk))
+        self._chunk_cache[key] = out
+        return out
+
     def relation_index(self, etypes: torch.Tensor, num_rels: int) -> 'RelationIndex':
         key = (etypes.data_ptr(), etypes._version, int(num_rels))
         hit = self._rel_cache.get(key)

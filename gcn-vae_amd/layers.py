@@ -88,9 +88,11 @@ class RelGraphConv(ops.StayOnDevice, nn.Module):
         """The RNG job that fills ``keep`` (uint8, (N, out_feat)) with this layer's Bernoulli(1 - p) decisions."""
         return (keep, ops.RNG_KEEP_MASK, float(self.dropout.p), self.rng_stream)
 
-    def forward_rows(self, g, x, etypes, norm, part, gather_input, pad_output):
+    def forward_rows(self, g, x, etypes, norm, part, gather_input, pad_output, gather_output=False, x_gathered=False):
         """The layer on ONE rank's row block of the multi-GPU destination-row partition (ops.rel_graph_conv_rows):
-        ``g`` is the rank's distributed.RowBlockGraph, ``x`` the full table (gather_input False) or the rank's slot."""
+        ``g`` is the rank's distributed.RowBlockGraph, ``x`` the full table (gather_input False) or the rank's slot.
+        gather_output / x_gathered: the pipelined exchange between two layers (the producer gathers its rows block by block
+        under its own aggregation and returns the full table; the consumer reduce-scatters its backward the same way)."""
         if self.regularizer != 'bdd':
             raise NotImplementedError('the row partition covers the bdd regulariser (the reference encoders use only it)')
         gidx = graph_index_of(g, x.device)
@@ -104,7 +106,8 @@ class RelGraphConv(ops.StayOnDevice, nn.Module):
             keep = keep[part.row0:part.row0 + c].contiguous()
         return ops.rel_graph_conv_rows(x, self.weight, self.h_bias if self.bias else None,
                                        self.loop_weight if self.self_loop else None, norm, gidx, ridx, self.num_bases,
-                                       part, act_id, keep, scale if keep is not None else 1.0, gather_input, pad_output)
+                                       part, act_id, keep, scale if keep is not None else 1.0, gather_input, pad_output,
+                                       gather_output, x_gathered)
 
     def forward(self, g, x, etypes, norm=None):
         x, etypes, norm = ops.to_module_device(self.weight, x, etypes, norm)

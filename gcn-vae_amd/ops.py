@@ -1221,11 +1221,18 @@ class _RelGraphConvRows(torch.autograd.Function):
       otherwise      x already is the full table (replicated embedding lookup); backward returns this rank's partial
                      gradient of all its rows (summed later by the parameter-gradient all-reduce)
       pad_output     return a (slot_rows, out) tensor with a zero tail, ready to be gathered by the next layer
+      gather_output  PIPELINED exchange (part.chunks > 1): the layer itself gathers its output -- its rows are aggregated in
+                     part.chunks blocks of slot rows and block k's all-gather runs under block k + 1's aggregation -- and returns
+                     the FULL table (total_rows, out).  The gradient that comes back for it is the consumer's reduce-scattered
+                     partial sums, valid in this rank's slot rows only (see x_gathered)
+      x_gathered     x is such a gathered table: no gather here; backward computes K1^T block by block (the same slot-row range
+                     of every rank per block), reduce-scatters block k under block k + 1 and returns a full-size tensor whose
+                     rows of THIS rank's slot hold the summed gradient (the others are never read)
     """
 
     @staticmethod
     def forward(ctx, x, weight, h_bias, loop_weight, norm, gidx, ridx, num_bases, act, keep, keep_scale, part,
-                gather_input, pad_output):
+                gather_input, pad_output, gather_output=False, x_gathered=False):
         x, _ = _row_major(x, 'x')
         c, slot, row0, total = part.own_rows, part.slot_rows, part.row0, part.total_rows
         in_feat = x.shape[1]
@@ -1234,6 +1241,8 @@ class _RelGraphConvRows(torch.autograd.Function):
         out_feat = num_bases * so
         if gidx.num_nodes != c or gidx.num_src_nodes != total:
             raise ValueError(f'row-partition graph index is {gidx.num_nodes} x {gidx.num_src_nodes}, expected {c} x {total}')
+        if x_gathered and gather_input:
+            raise ValueError('x_gathered: the table arrives gathered, gather_input must be False')
         if x.shape[0] != (slot if gather_input else total):
             raise ValueError(f'x has {x.shape[0]} rows, expected {slot if gather_input else total}')
         coef = None if norm is None else norm.reshape(-1)
@@ -1259,40 +1268,63 @@ class _RelGraphConvRows(torch.autograd.Function):
                 addend = gemm(x_own, loop_weight, bias=h_bias)
             elif h_bias is not None:
                 addend = h_bias.unsqueeze(0).expand(c, out_feat).contiguous()
+        pad_output = pad_output or gather_output
         buf = torch.empty(slot if pad_output else c, out_feat, dtype=torch.float32, device=x.device)
         if pad_output and c < slot:
             buf[c:].zero_()
         if pending is not None:
             pending.wait()
         out = buf[:c]
-        if c > 0:
+        result = buf
+        if gather_output:
+            # block k of the rank's rows is final (aggregate + epilogue in one launch) -> its gather starts; block k + 1 follows
+            result = torch.empty(total, out_feat, dtype=torch.float32, device=x.device)
+            bounds = part.chunk_bounds()
+            subs = gidx.row_blocks('dst', [[(min(a, c), min(b, c))] for a, b in bounds])
+            waits = []
+            for (a, b), sub in zip(bounds, subs):
+                if c > 0 and sub.n_items > 0:
+                    bdd_aggregate(sub, gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x_full, w_fwd, num_bases,
+                                  si, so, False, addend, act, keep, keep_scale, out=out, packed=pk)
+                waits.append(part.gather_rows(result, buf, a, b))
+            for wt in waits:
+                wt.wait()
+        elif c > 0:
             bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x_full, w_fwd, num_bases,
                           si, so, False, addend, act, keep, keep_scale, out=out, packed=pk)
         ctx.save_for_backward(x_full, weight, loop_weight, coef, out if act == ACT_RELU else None, keep)
         ctx.meta = (gidx, ridx, num_bases, si, so, act, keep_scale, h_bias is not None, part, gather_input)
+        ctx.pipe = (bool(gather_output), bool(x_gathered))
         ctx.w_version = weight._version
         ctx.direct = (_direct(weight), _direct(h_bias), _direct(loop_weight))
         _stamp_direct(ctx)
-        return buf
+        return result
 
     @staticmethod
     def backward(ctx, grad_out):
         x_full, weight, loop_weight, coef, out, keep = ctx.saved_tensors
         gidx, ridx, nb, si, so, act, keep_scale, has_bias, part, gather_input = ctx.meta
+        gather_output, x_gathered = ctx.pipe
         c, slot, row0, total = part.own_rows, part.slot_rows, part.row0, part.total_rows
         _verify_direct(ctx)
         d_w, d_b, d_l = ctx.direct
         dev, in_feat = x_full.device, x_full.shape[1]
-        grad_out = grad_out[:c]
+        # (a gathered output's gradient is the consumer's reduce-scattered sums, valid in this rank's slot rows)
+        grad_out = grad_out[row0:row0 + c] if gather_output else grad_out[:c]
         x_own = x_full[row0:row0 + c]
         grad_bias = grad_loop = grad_w = None
         if c == 0:           # a rank without rows: contributes zeros to the exchange
             gfull = torch.zeros(total, in_feat, dtype=torch.float32, device=dev)
-            if gather_input:
+            if gather_input or x_gathered:
                 own = torch.empty(slot, in_feat, dtype=torch.float32, device=dev)
+                if x_gathered:
+                    for a, b in part.chunk_bounds():
+                        part.reduce_scatter_rows(own, gfull, a, b).wait()
+                    gfull[row0:row0 + slot].copy_(own)
+                    return (gfull,) + (None,) * 15
                 part.reduce_scatter(own, gfull).wait()
-                return (own,) + (None,) * 13
-            return (gfull,) + (None,) * 13
+                return (own,) + (None,) * 15
+            return (gfull,) + (None,) * 15
         if has_bias and ctx.needs_input_grad[2]:
             grad_bias = d_b if d_b is not None else torch.empty(grad_out.shape[1], dtype=torch.float32, device=dev)
             g = epilogue_bwd(out, grad_out, act, keep, keep_scale, colsum_out=grad_bias, colsum_accumulate=d_b is not None)
@@ -1310,8 +1342,22 @@ class _RelGraphConvRows(torch.autograd.Function):
                 w_bwd = pack_weight(weight, nb, so, si, True) if pk else weight
             static = not gidx.sync_free and coef is not None
             coef_s, idx_s = (gidx.coef_in_src_order(coef), None) if static else (coef, gidx.by_src.perm)
-            gfull = bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, coef_s, idx_s, g, w_bwd, nb, so, si,
-                                  True, None, packed=pk)                      # (total, in): this rank's partial sums
+            own_sum = waits = None
+            if x_gathered:
+                # block k = the same slot-row range of EVERY rank's slot: its partial sums are complete after its own launch and
+                # leave (reduce-scatter) while block k + 1 is computed
+                bounds = part.chunk_bounds()
+                subs = gidx.row_blocks('src', [[(r * slot + a, r * slot + b) for r in range(part.world)] for a, b in bounds])
+                gfull = torch.empty(total, in_feat, dtype=torch.float32, device=dev)
+                own_sum = torch.empty(slot, in_feat, dtype=torch.float32, device=dev)
+                waits = []
+                for (a, b), sub in zip(bounds, subs):
+                    bdd_aggregate(sub, gidx.nbr_by_src, ridx.et_by_src, coef_s, idx_s, g, w_bwd, nb, so, si, True, None,
+                                  packed=pk, out=gfull)
+                    waits.append(part.reduce_scatter_rows(own_sum, gfull, a, b))
+            else:
+                gfull = bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, coef_s, idx_s, g, w_bwd, nb, so, si,
+                                      True, None, packed=pk)                      # (total, in): this rank's partial sums
             if gather_input:
                 grad_x = torch.empty(slot, in_feat, dtype=torch.float32, device=dev)
                 pending = part.reduce_scatter(grad_x, gfull)
@@ -1335,16 +1381,21 @@ class _RelGraphConvRows(torch.autograd.Function):
                 grad_w = None
         if pending is not None:
             pending.wait()
+        if x_gathered and ctx.needs_input_grad[0]:
+            for wt in waits:
+                wt.wait()
+            grad_x[row0:row0 + slot].copy_(own_sum)      # the summed gradient in this rank's slot rows; the other rows are never read
         if gx_loop is not None:       # the self-loop term only touches the rank's own rows
             own = grad_x[:c] if gather_input else grad_x[row0:row0 + c]
             lib.call('gv_axpby', own.numel(), None, 1.0, ptr(gx_loop), 1.0, ptr(own), lib.stream())
-        return (grad_x, grad_w, grad_bias, grad_loop) + (None,) * 10
+        return (grad_x, grad_w, grad_bias, grad_loop) + (None,) * 12
 
 
 def rel_graph_conv_rows(x, weight, h_bias, loop_weight, norm, gidx, ridx, num_bases, part, act=ACT_NONE, keep=None,
-                        keep_scale=1.0, gather_input=True, pad_output=False):
+                        keep_scale=1.0, gather_input=True, pad_output=False, gather_output=False, x_gathered=False):
     return _RelGraphConvRows.apply(x, weight, h_bias, loop_weight, norm, gidx, ridx, num_bases, act, keep,
-                                   float(keep_scale), part, bool(gather_input), bool(pad_output))
+                                   float(keep_scale), part, bool(gather_input), bool(pad_output), bool(gather_output),
+                                   bool(x_gathered))
 
 
 class _PadRows(torch.autograd.Function):

@@ -251,6 +251,21 @@ def rows_worker(rank, world, port, out_q):
         own = torch.empty(slot, 2)
         part.reduce_scatter(own, full * (rank + 1)).wait()
         assert torch.equal(own, torch.full((slot, 2), float((rank + 1) * 3)))
+        # the pipelined exchanges' block forms: rows [a, b) of every slot gathered into their places / reduce-scattered from them
+        bounds = part.chunk_bounds(3)
+        assert bounds[0][0] == 0 and bounds[-1][1] == slot and all(bounds[i][1] == bounds[i + 1][0] for i in range(len(bounds) - 1))
+        mine = torch.arange(slot * 2, dtype=torch.float32).view(slot, 2) + 100.0 * rank
+        full2 = torch.full((world * slot, 2), -1.0)
+        for a, b in bounds:
+            part.gather_rows(full2, mine, a, b).wait()
+        for r in range(world):
+            assert torch.equal(full2[r * slot:(r + 1) * slot], torch.arange(slot * 2, dtype=torch.float32).view(slot, 2) + 100.0 * r)
+        own2 = torch.full((slot, 2), -1.0)
+        gsrc = (torch.arange(world * slot * 2, dtype=torch.float32).view(world * slot, 2)) * (rank + 1)
+        for a, b in bounds:
+            part.reduce_scatter_rows(own2, gsrc, a, b).wait()
+        want = torch.arange(world * slot * 2, dtype=torch.float32).view(world * slot, 2)[rank * slot:(rank + 1) * slot] * sum(range(1, world + 1))
+        assert torch.equal(own2, want)
         # this rank's edges: destination in its row block; sources are positions in the full table
         ps, pd = pos[torch.from_numpy(src)], pos[torch.from_numpy(dst)]
         sel = (pd >= row0) & (pd < row0 + slot)

@@ -92,7 +92,8 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert d['value'] > 0 and d['final_loss'] == d['final_loss']
     # "auto" probes both multi-GPU schemes during warm-up and runs the faster one
     assert set(d['config']['partition_probe_ms_per_step']) == {'edge/segments', 'edge/eager', 'edge/segments/1-block',
-                                                               'row/segments', 'row/eager'}
+                                                               'row/segments', 'row/eager', 'row/segments/pipelined-2',
+                                                               'row/segments/pipelined-4'}
     assert d['config']['partition'] in ('edge', 'row')
 
 
@@ -109,7 +110,7 @@ def test_bench_two_ranks_auto_partition_with_iaf_blocks_ends_finite():
     assert out.returncode == 0, (out.stdout[-1500:] + '\n' + out.stderr[-2500:])
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert d['n_gpus'] == 2 and d['loss_is_finite'] is True and d['final_loss'] == d['final_loss']
-    assert len(d['config']['partition_probe_ms_per_step']) == 5
+    assert len(d['config']['partition_probe_ms_per_step']) == 7
 
 
 @pytest.mark.parametrize('extra', [['--scaling', 'strong', '--partition', 'edge'], ['--scaling', 'strong', '--partition', 'row'],
@@ -194,23 +195,25 @@ def test_bench_two_ranks_each_partition(partition):
         assert sum(ec) == 2 * d['config']['edges_per_gpu'] and max(ec) < 1.2 * min(ec)
 
 
-@pytest.mark.parametrize('flows', ['0', '2'])
-def test_row_partition_single_rank_equals_whole_graph_run(flows):
+@pytest.mark.parametrize('flows,chunks', [('0', '1'), ('2', '1'), ('0', '4')])
+def test_row_partition_single_rank_equals_whole_graph_run(flows, chunks):
     """world 1: the destination-row path (rectangular index, ops.rel_graph_conv_rows, the loss shares) with local copies
     in place of the collectives equals the ordinary single-GPU path (flows = IAF blocks on the rank's rows)."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'workers', 'dist_rows_worker.py')], cwd=ROOT,
-                         env=dict(os.environ, WORLD_SIZE='1', GV_WORKER_FLOWS=flows), capture_output=True, text=True,
+                         env=dict(os.environ, WORLD_SIZE='1', GV_WORKER_FLOWS=flows, GV_DIST_ROW_CHUNKS=chunks), capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:] + '\n' + out.stderr[-2500:])
     assert out.stdout.count('worst rel err') == 1, out.stdout[-1500:]
 
 
-@pytest.mark.parametrize('flows', ['0', '2'])
-def test_two_ranks_row_partition_equals_single_process(flows):
+@pytest.mark.parametrize('flows,chunks', [('0', '1'), ('2', '1'), ('0', '3'), ('2', '2')])
+def test_two_ranks_row_partition_equals_single_process(flows, chunks):
     """world_size 2 on ONE GPU (gloo): every rank owns a block of node rows and the edges ending in them; all-gather of
     layer-1 rows and of z, reduce-scatter of their gradients, summed parameter gradients == the single-process run.
-    flows = 2: the IAF stack runs on the rank's rows, flow_log_prob is the all-reduced mean of the row sums."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GV_WORKER_FLOWS=flows)
+    flows = 2: the IAF stack runs on the rank's rows, flow_log_prob is the all-reduced mean of the row sums.
+    chunks > 1 (GV_DIST_ROW_CHUNKS): the PIPELINED exchange between the two layers -- layer 1 gathers its rows block by block under
+    its own aggregation, layer 2's backward reduce-scatters dL/dh1 block by block under its own K1^T -- same results."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GV_WORKER_FLOWS=flows, GV_DIST_ROW_CHUNKS=chunks)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(free_port()), os.path.join(ROOT, 'tests', 'workers', 'dist_rows_worker.py')]
     out = run_ranks(cmd, env, 600)
