@@ -98,27 +98,39 @@ def strong(bw, alpha):
         adam = min(0.3 * t1 * c['node_share'], 4 * arena * 2 / 4.0e12)      # clip + Adam: ~8 arena passes at ~4 TB/s
         print(f'\n{name}: 1-GPU step {c["t1_ms"]} ms, node-level share {c["node_share"]}, S1 {S1 / 1e6:.1f} MB, S2 {S2 / 1e6:.1f} MB, '
               f'arena {arena / 1e6:.1f} MB (STRONG scaling: one graph)')
-        print(f'{"ranks":>5} {"scheme":>28} {"compute ms":>11} {"layer exchanges ms":>19} {"arena ms":>9} {"step ms (half hidden)":>22} '
+        print(f'{"ranks":>5} {"scheme":>34} {"compute ms":>11} {"layer exchanges ms":>19} {"arena ms":>9} {"step ms":>22} '
               f'{"speed-up":>9} {"all hidden":>11}')
         for p in (2, 4, 8):
             for direct in (True, False):
                 tag = 'direct' if direct else 'ring'
                 k1, node = t1 * (1 - c['node_share']), t1 * c['node_share']
                 ar = 2 * (t_allreduce(S1, p, bw, alpha, direct) + t_allreduce(S2, p, bw, alpha, direct))
-                ag = 2 * (t_gather(S1, p, bw, alpha, direct) + t_gather(S2, p, bw, alpha, direct))
-                # rel+rows: layer 1 forward RS(S1) [its input is the replicated table], layer 2 forward AG(S1) + RS(S2); backward
-                # AG(S2) + RS(S1), AG(S1) + [layer 1's dL/dx is a parameter gradient]: three exchanges of S1 and one of S2 each way
-                relrows = 2 * (2 * t_gather(S1, p, bw, alpha, direct) + t_gather(S2, p, bw, alpha, direct)) + \
-                    2 * t_gather(S1, p, bw, alpha, direct)
+                # rows: four exchanges of S1 per step -- all-gather of h1 (layer 1 -> 2) and of z (-> decoder) forward, reduce-scatter of
+                # dL/dz and dL/dh1 backward (h2 = [mean | pre-variance] stays on its owner: the reparameterisation is row-wise)
+                ag = 4 * t_gather(S1, p, bw, alpha, direct)
+                # ... pipelined (GV_DIST_ROW_CHUNKS = C, built): the h1 pair leaves in C blocks under the layers' own aggregations, 1/C
+                # of it stays exposed; the z pair has only the rank's KL pass beside it
+                C = 4
+                one = t_gather(S1, p, bw, alpha, direct)
+                # what stays exposed of the pipelined h1 pair: the last block's transfer + one latency per block; the z pair whole
+                pipe_exposed = 2 * one + 2 * ((one - alpha) / C + C * alpha)
+                # rel+rows: layer 1 forward RS(S1) [its input is the replicated table], layer 2 forward AG(S1) + RS(S2), AG(S1) of z; backward
+                # RS(S1) of dL/dz, AG(S2) + RS(S1), AG(S1): six exchanges of S1 and two of S2 per step
+                relrows = 6 * t_gather(S1, p, bw, alpha, direct) + 2 * t_gather(S2, p, bw, alpha, direct)
                 rows = [('edge / ' + tag, k1 / p + node, ar, t_allreduce(arena, p, bw, alpha, direct)),
                         ('edge+sharded Adam / ' + tag, k1 / p + node - adam * (1 - 1 / p), ar, 2 * t_gather(arena, p, bw, alpha, direct)),
                         ('rel+rows, sharded Adam / ' + tag, k1 / p / c['k1_rel_gain'] + node / p, relrows, 2 * t_gather(arena, p, bw, alpha, direct)),
                         ('rows / ' + tag, (k1 + node) / p, ag, t_allreduce(arena, p, bw, alpha, direct)),
+                        ('rows, h1 pair in 4 blocks / ' + tag, (k1 + node) / p, pipe_exposed, t_allreduce(arena, p, bw, alpha, direct)),
                         ('rows+sharded Adam / ' + tag, (k1 + node) / p, ag, 2 * t_gather(arena, p, bw, alpha, direct))]
                 for label, comp, layer, ar_t in rows:
-                    step = comp + 0.5 * layer + ar_t
+                    # exposed share of the layer exchanges: the edge scheme's all-reduces run in two destination-row blocks under the next block's
+                    # aggregation and the self-loop product (half, as the 2-rank shared-GPU runs showed); the row scheme's single
+                    # all-gather / reduce-scatter per pair has only the rank's self-loop product beside it (counted whole); 'in 4 blocks':
+                    # `layer` already is what stays exposed
+                    step = comp + (0.5 if label.startswith('edge') or label.startswith('rel') else 1.0) * layer + ar_t
                     best = comp + ar_t                       # every layer exchange hidden
-                    print(f'{p:5d} {label:>28} {comp * 1e3:11.3f} {layer * 1e3:19.3f} {ar_t * 1e3:9.3f} {step * 1e3:22.3f} '
+                    print(f'{p:5d} {label:>34} {comp * 1e3:11.3f} {layer * 1e3:19.3f} {ar_t * 1e3:9.3f} {step * 1e3:22.3f} '
                           f'{t1 / step:9.2f} {t1 / best:11.2f}')
 
 
