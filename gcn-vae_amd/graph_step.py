@@ -14,10 +14,18 @@ R-GCN layers, reparameterisation, the loss head, backward, clip + Adam.  What ma
 Eager launching costs ~2.3 ms per step here against ~0.8 ms of kernel time (the step is ~130 launches of 3-40 us); the replay
 removes the host from the loop.  tests/test_gpu_model.py holds the replayed steps equal to eager ones.
 """
+import os as _os
+
 import torch
 
 from . import ops
 from .optim import FlatAdam
+
+
+class _Rows:
+    """What LinkPredict.triplet_index reads of the embedding it is handed: the row count and the device."""
+    def __init__(self, n, device):
+        self.shape, self.device = (int(n),), device
 
 
 class GraphedMiniBatchStep:
@@ -37,6 +45,9 @@ class GraphedMiniBatchStep:
         self.graph = None
         self.out = None
         self.side = torch.cuda.Stream(device=dev)
+        # the triplet index (DistMult backward: ~12 launches of ~5 us, needed by the loss head) is built on its own stream beside
+        # the encoder's forward instead of between the encoder and the loss head
+        self.idx_side = torch.cuda.Stream(device=dev) if _os.environ.get('GV_MB_INDEX_SIDE', '1') == '1' else None
 
     def body(self):
         """The step, launched eagerly (also what the capture records).  The model's static-batch settings (device row count,
@@ -55,8 +66,16 @@ class GraphedMiniBatchStep:
             enc.fuse_kl_with_reparam = False               # the KL pass needs the device row count: it stays in the loss head here
         try:
             self.opt.zero_grad()
+            if self.idx_side is not None and hasattr(m, 'triplet_index'):
+                # (the graph's own index the same way, on a second stream, waited for behind layer 1's self-loop product: 1.07 ms
+                # against 0.94 -- the builders' small launches then compete with the forward pass's for the dispatcher)
+                self.idx_side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.idx_side):
+                    m.triplet_index(_Rows(b.node_id.shape[0], b.samples.device), b.samples)      # cached: get_loss finds it built
             with ops.live_rows(b.rows_dev, b.node_id.shape[0]):      # the dense products skip the padding rows
                 embed = m(b.g, b.node_id, b.edge_type, b.edge_norm)
+                if self.idx_side is not None:
+                    torch.cuda.current_stream().wait_stream(self.idx_side)
                 loss, pred, kl, mmd = m.get_loss(b.g, embed, b.samples, b.labels)
                 loss.backward(gradient=self.one.expand_as(loss))
             self.opt.step()
