@@ -36,8 +36,7 @@ __global__ void k_iota_copy(int* x, const int* keys, int* copy, int64_t n) {
 
 // rowptr[s] = number of sorted keys < s  (s = 0 .. n_seg)
 template <typename KeyT>
-__global__ void k_lower_bounds(const KeyT* keys_sorted, int64_t n, int n_seg, int* rowptr) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void lower_bound_of(const KeyT* keys_sorted, int64_t n, int n_seg, int* rowptr, int s) {
     if (s > n_seg) return;
     int64_t lo = 0, hi = n;
     while (lo < hi) {
@@ -45,6 +44,11 @@ __global__ void k_lower_bounds(const KeyT* keys_sorted, int64_t n, int n_seg, in
         if ((int)keys_sorted[mid] < s) lo = mid + 1; else hi = mid;
     }
     rowptr[s] = (int)lo;
+}
+
+template <typename KeyT>
+__global__ void k_lower_bounds(const KeyT* keys_sorted, int64_t n, int n_seg, int* rowptr) {
+    lower_bound_of<KeyT>(keys_sorted, n, n_seg, rowptr, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 __global__ void k_item_counts(const int* rowptr, int n_seg, int chunk, Tri* counts) {
@@ -79,17 +83,22 @@ __global__ void k_items_fill_packed(const int* rowptr, int n_seg, int chunk, con
 // input order and the sort is stable.
 constexpr int RS_T = 1024, RS_W = 16, RS_MAXB = 512;
 
+// (the bodies take the block's number b among the B blocks of ITS ordering: the batched launches below run several orderings in one grid)
 template <typename KIn>
-__global__ __launch_bounds__(1024) void k_rs_hist(const KIn* keys, int n, int tile, int shift, int nbits, int* hist) {
+__device__ __forceinline__ void rs_hist_body(const KIn* keys, int n, int tile, int shift, int nbits, int* hist, const int b, const int B) {
     __shared__ int bins[RS_MAXB];
     const int nbins = 1 << nbits;
     for (int d = threadIdx.x; d < nbins; d += RS_T) bins[d] = 0;
     __syncthreads();
-    const int b = blockIdx.x, B = gridDim.x;
     const int beg = b * tile, end = min(n, beg + tile);
     for (int i = beg + threadIdx.x; i < end; i += RS_T) atomicAdd(&bins[((int)keys[i] >> shift) & (nbins - 1)], 1);
     __syncthreads();
     for (int d = threadIdx.x; d < nbins; d += RS_T) hist[d * B + b] = bins[d];      // [digit][block]: the scan order
+}
+
+template <typename KIn>
+__global__ __launch_bounds__(1024) void k_rs_hist(const KIn* keys, int n, int tile, int shift, int nbits, int* hist) {
+    rs_hist_body<KIn>(keys, n, tile, shift, nbits, hist, blockIdx.x, gridDim.x);
 }
 
 // one more array carried through the final pass's permutation (the gathers the builders need anyway)
@@ -103,8 +112,9 @@ struct RsCarry {
 // with MAXR = 4 (tiles of <= 4096 entries: everything up to 0.5 M entries) the block first puts its tile in digit order in LDS
 // and then writes it out with consecutive threads on consecutive addresses (runs of tile / nbins entries per digit).
 template <typename KIn, bool IOTA, int MAXR>
-__global__ __launch_bounds__(1024) void k_rs_scatter(const KIn* keys, const int* vals, int n, int tile, int shift, int nbits,
-                                                     const int* hist, unsigned short* keys_out, int* vals_out, RsCarry carry) {
+__device__ __forceinline__ void rs_scatter_body(const KIn* keys, const int* vals, int n, int tile, int shift, int nbits,
+                                                const int* hist, unsigned short* keys_out, int* vals_out, const RsCarry& carry,
+                                                const int b, const int B) {
     constexpr bool STAGE = MAXR <= 4;
     constexpr int STAGED = STAGE ? MAXR * RS_T : 1;
     __shared__ int wh[RS_W][RS_MAXB];      // per (wave, digit): count, then the wave's first position for the digit
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(1024) void k_rs_scatter(const KIn* keys, const int*
     __shared__ int sval[STAGED];
     __shared__ unsigned short skey[STAGED];
     const int nbins = 1 << nbits, mask = nbins - 1;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, b = blockIdx.x, B = gridDim.x;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int beg = b * tile, end = min(n, beg + tile);
     const int rounds = tile / RS_T;
     const int wbeg = beg + w * rounds * 64 + lane;
@@ -263,6 +273,12 @@ __global__ __launch_bounds__(1024) void k_rs_scatter(const KIn* keys, const int*
     }
 }
 
+template <typename KIn, bool IOTA, int MAXR>
+__global__ __launch_bounds__(1024) void k_rs_scatter(const KIn* keys, const int* vals, int n, int tile, int shift, int nbits,
+                                                     const int* hist, unsigned short* keys_out, int* vals_out, RsCarry carry) {
+    rs_scatter_body<KIn, IOTA, MAXR>(keys, vals, n, tile, shift, nbits, hist, keys_out, vals_out, carry, blockIdx.x, gridDim.x);
+}
+
 // work-item counts, their exclusive scan, the item / fix-up lists and the -1 padding behind them in ONE launch (n_seg <=
 // 65 536): a block owns 1024 consecutive segments and adds up the counts of all segments before its own itself (the rowptr is
 // <= 256 KB and L2-resident: cheaper than a scan kernel in between).  Same lists as k_item_counts + scan + k_items_fill_packed.
@@ -274,12 +290,12 @@ __device__ inline Tri item_count(int deg, int chunk, int chunk_shift) {
 __device__ inline Tri tri_shfl_up(const Tri& v, int o) { return Tri{__shfl_up(v.a, o), __shfl_up(v.b, o), __shfl_up(v.c, o)}; }
 __device__ inline Tri tri_shfl_xor(const Tri& v, int o) { return Tri{__shfl_xor(v.a, o), __shfl_xor(v.b, o), __shfl_xor(v.c, o)}; }
 
-__global__ __launch_bounds__(1024) void k_items_blocks(const int* rowptr, int n_seg, int chunk, int chunk_shift, int4* items,
-                                                       int items_cap, int4* fix, int fix_cap) {
+__device__ __forceinline__ void items_blocks_body(const int* rowptr, int n_seg, int chunk, int chunk_shift, int4* items,
+                                                  int items_cap, int4* fix, int fix_cap, const int b, const int B) {
     __shared__ Tri red[3][RS_W];
     __shared__ int s_oa[RS_T + 1], s_ob[RS_T], s_beg[RS_T], s_end[RS_T];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int base = blockIdx.x * RS_T;
+    const int base = b * RS_T;
     Tri before{0, 0, 0}, total{0, 0, 0};
     const int s = base + t;
     int beg = 0, end = 0;
@@ -343,9 +359,14 @@ __global__ __launch_bounds__(1024) void k_items_blocks(const int* rowptr, int n_
             items[first.a + i] = make_int4(base + seg, bb, min(s_end[seg], bb + chunk), n_it > 1 ? s_ob[seg] + k : -1);
     }
     const int4 none = make_int4(-1, -1, -1, -1);
-    const int stride = gridDim.x * RS_T;
+    const int stride = B * RS_T;
     for (int i = tot.a + base + t; i < items_cap; i += stride) items[i] = none;
     for (int i = tot.c + base + t; i < fix_cap; i += stride) fix[i] = none;
+}
+
+__global__ __launch_bounds__(1024) void k_items_blocks(const int* rowptr, int n_seg, int chunk, int chunk_shift, int4* items,
+                                                       int items_cap, int4* fix, int fix_cap) {
+    items_blocks_body(rowptr, n_seg, chunk, chunk_shift, items, items_cap, fix, fix_cap, blockIdx.x, gridDim.x);
 }
 
 __global__ void k_gather3_i32(const int* s1, int* o1, const int* s2, int* o2, const int* s3, int* o3, const int* idx, int64_t n) {
@@ -390,6 +411,131 @@ __global__ void k_triplet_columns(const int* trip, int64_t T, int* s, int* r, in
     s[i] = trip[3 * i];
     r[i] = trip[3 * i + 1];
     o[i] = trip[3 * i + 2];
+}
+
+// ---- several orderings in the SAME launches (gv_build_csr_batch) -----------------------------------------------------------------
+// A sampled batch needs five orderings (graph by destination / source / relation, triplets by entity / relation) of 20-60 k entries:
+// every pass of every ordering is one short launch, ~30 dependent launches of ~4 us each.  The orderings do not depend on each
+// other, so pass p of all of them runs as ONE grid: a block finds its ordering from the block ranges below and runs the same body
+// as the single-ordering kernel.  Six launches for any number of orderings (histogram + scatter per pass, row pointers, items).
+constexpr int IDX_MAX_JOBS = 8;
+
+struct IdxJob {
+    const int* keys;
+    int n, n_seg, chunk, chunk_shift;
+    int tile, blocks, passes, bits0, bits1;      // passes 0 = the keys are sorted already (perm NULL: identity)
+    int* perm;
+    unsigned short* k16_a;
+    unsigned short* k16_b;
+    int* iota;
+    int* hist;
+    RsCarry carry;
+    int* rowptr;
+    int4* items;
+    int4* fix;
+    int items_cap, fix_cap;
+    int lb_blocks, copy_blocks, it_blocks;       // blocks of this ordering in the row-pointer (+ identity carry) and items launches
+};
+
+struct IdxBatch {
+    IdxJob j[IDX_MAX_JOBS];
+    int n;
+};
+
+template <int PASS>
+__global__ __launch_bounds__(1024) void k_rs_hist_batch(const IdxBatch bt) {
+    int b = blockIdx.x;
+    for (int q = 0; q < bt.n; ++q) {
+        const IdxJob& J = bt.j[q];
+        const int nb = J.passes > PASS ? J.blocks : 0;
+        if (b < nb) {
+            if (PASS == 0) rs_hist_body<int>(J.keys, J.n, J.tile, 0, J.bits0, J.hist, b, nb);
+            else rs_hist_body<unsigned short>(J.k16_a, J.n, J.tile, J.bits0, J.bits1, J.hist, b, nb);
+            return;
+        }
+        b -= nb;
+    }
+}
+
+template <int PASS>
+__global__ __launch_bounds__(1024) void k_rs_scatter_batch(const IdxBatch bt) {
+    int b = blockIdx.x;
+    for (int q = 0; q < bt.n; ++q) {
+        const IdxJob& J = bt.j[q];
+        const int nb = J.passes > PASS ? J.blocks : 0;
+        if (b < nb) {
+            RsCarry none;
+            for (int a = 0; a < 3; ++a) { none.src[a] = nullptr; none.out[a] = nullptr; }
+            if (PASS == 0) {
+                const bool last = J.passes == 1;
+                rs_scatter_body<int, true, 4>(J.keys, nullptr, J.n, J.tile, 0, J.bits0, J.hist, J.k16_a, last ? J.perm : J.iota,
+                                              last ? J.carry : none, b, nb);
+            } else {
+                rs_scatter_body<unsigned short, false, 4>(J.k16_a, J.iota, J.n, J.tile, J.bits0, J.bits1, J.hist, J.k16_b, J.perm,
+                                                          J.carry, b, nb);
+            }
+            return;
+        }
+        b -= nb;
+    }
+}
+
+// row pointers of every ordering; an ordering whose keys came sorted (no permutation) copies its carried arrays here
+__global__ __launch_bounds__(256) void k_lower_bounds_batch(const IdxBatch bt) {
+    int b = blockIdx.x;
+    for (int q = 0; q < bt.n; ++q) {
+        const IdxJob& J = bt.j[q];
+        if (b < J.lb_blocks) {
+            const int s = b * 256 + threadIdx.x;
+            if (J.passes == 0) lower_bound_of<int>(J.keys, J.n, J.n_seg, J.rowptr, s);
+            else lower_bound_of<unsigned short>(J.passes == 1 ? J.k16_a : J.k16_b, J.n, J.n_seg, J.rowptr, s);
+            return;
+        }
+        b -= J.lb_blocks;
+        if (b < J.copy_blocks) {
+            const int i = b * 256 + threadIdx.x;
+            if (i < J.n)
+                for (int a = 0; a < 3; ++a)
+                    if (J.carry.src[a]) J.carry.out[a][i] = J.carry.src[a][i];
+            return;
+        }
+        b -= J.copy_blocks;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_items_blocks_batch(const IdxBatch bt) {
+    int b = blockIdx.x;
+    for (int q = 0; q < bt.n; ++q) {
+        const IdxJob& J = bt.j[q];
+        if (b < J.it_blocks) {
+            items_blocks_body(J.rowptr, J.n_seg, J.chunk, J.chunk_shift, J.items, J.items_cap, J.fix, J.fix_cap, b, J.it_blocks);
+            return;
+        }
+        b -= J.it_blocks;
+    }
+}
+
+// the incidence list and the columns of a triplet batch in one launch (the inputs of its two orderings)
+template <typename TripT>
+__global__ void k_triplet_lists(const TripT* trip, int64_t T, int* ent, int* other, int* rel2, int* tid, int* cs, int* cr, int* co,
+                                int* trip32) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * T) return;
+    const int64_t t = i < T ? i : i - T;
+    const int s = (int)trip[3 * t], r = (int)trip[3 * t + 1], o = (int)trip[3 * t + 2];
+    if (trip32 && i < T) { trip32[3 * t] = s; trip32[3 * t + 1] = r; trip32[3 * t + 2] = o; }
+    ent[i] = i < T ? s : o;
+    other[i] = i < T ? o : s;
+    rel2[i] = r;
+    tid[i] = (int)t;
+    if (i < T) { cs[i] = s; cr[i] = r; co[i] = o; }
+}
+
+// two int32 arrays to int64 in one launch (node ids / row picks that the reference's interfaces carry as int64)
+__global__ void k_widen2_i32(const int* a, long long* a_out, int64_t na, const int* b, long long* b_out, int64_t nb) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) a_out[i] = a[i];
+    else if (i < na + nb) b_out[i - na] = b[i - na];
 }
 
 }  // namespace gv
@@ -733,4 +879,119 @@ extern "C" int gv_triplet_index_build(const int32_t* trip, int64_t T, int n_ent,
     if (rc != GV_OK) return rc;
     (void)col;
     return launch_status("gv_triplet_index_build");
+}
+
+// ---- gv_build_csr_batch: see the batched kernels above ----------------------------------------------------------------------------
+namespace {
+
+bool batch_job_fits(const gv_csr_job& j, RsPlan& pl) {
+    if (j.n <= 0 || j.n >= (1ll << 31) || j.n_seg <= 0 || j.n_seg > 65536 || j.chunk <= 0) return false;
+    if (!j.perm) { pl.tile = RS_T; pl.blocks = 0; pl.passes = 0; pl.bits[0] = pl.bits[1] = 0; return true; }
+    return rs_plan(j.n, j.n_seg, pl) && pl.tile <= 4 * RS_T;
+}
+
+}  // namespace
+
+extern "C" int64_t gv_build_csr_batch_workspace_bytes(const gv_csr_job* jobs, int n_jobs) {
+    if (!jobs || n_jobs <= 0) return 0;
+    size_t total = 0;
+    for (int q = 0; q < n_jobs; ++q) total += Scratch::bytes(jobs[q].n > 0 ? jobs[q].n : 0, jobs[q].n_seg > 0 ? jobs[q].n_seg : 0);
+    return (int64_t)total;
+}
+
+extern "C" int gv_build_csr_batch(const gv_csr_job* jobs, int n_jobs, void* workspace, int64_t workspace_bytes, void* stream) {
+    GV_REQUIRE(n_jobs >= 0 && n_jobs <= IDX_MAX_JOBS, GV_ERR_SHAPE, "gv_build_csr_batch: %d orderings (at most %d)", n_jobs, IDX_MAX_JOBS);
+    if (n_jobs == 0) return GV_OK;
+    GV_REQUIRE(jobs && workspace, GV_ERR_NULL, "gv_build_csr_batch: NULL pointer");
+    GV_REQUIRE(workspace_bytes >= gv_build_csr_batch_workspace_bytes(jobs, n_jobs), GV_ERR_WORKSPACE, "gv_build_csr_batch: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    bool batched = getenv("GV_INDEX_SORT") == nullptr && !(getenv("GV_INDEX_BATCH") && atoi(getenv("GV_INDEX_BATCH")) == 0);
+    RsPlan plans[IDX_MAX_JOBS];
+    for (int q = 0; q < n_jobs; ++q) {
+        const gv_csr_job& j = jobs[q];
+        GV_REQUIRE(j.n >= 0 && j.n < (1ll << 31) && j.n_seg >= 0 && j.chunk > 0, GV_ERR_SHAPE, "gv_build_csr_batch: ordering %d: n=%lld n_seg=%d chunk=%d",
+                   q, (long long)j.n, j.n_seg, j.chunk);
+        GV_REQUIRE((j.keys || j.n == 0) && j.rowptr && j.items && j.fix, GV_ERR_NULL, "gv_build_csr_batch: ordering %d: NULL pointer", q);
+        GV_REQUIRE(j.items_cap >= 1 && j.fix_cap >= 1, GV_ERR_SHAPE, "gv_build_csr_batch: ordering %d: empty item buffers", q);
+        for (int a = 0; a < 3; ++a)
+            GV_REQUIRE(!j.carry_src[a] || j.carry_out[a], GV_ERR_NULL, "gv_build_csr_batch: ordering %d: carried array %d has no output", q, a);
+        batched = batched && batch_job_fits(j, plans[q]);
+    }
+    char* base = (char*)workspace;
+    if (!batched) {      // some ordering is outside the batched kernels (empty, > 65 536 segments, > 0.5 M entries): one after the other
+        for (int q = 0; q < n_jobs; ++q) {
+            const gv_csr_job& j = jobs[q];
+            Scratch sc(base, j.n, j.n_seg);
+            base += Scratch::bytes(j.n, j.n_seg);
+            const RsCarry carry = carry_of(j.carry_src[0], j.carry_out[0], j.carry_src[1], j.carry_out[1], j.carry_src[2], j.carry_out[2]);
+            const int rc = order_and_items(j.keys, j.n, j.n_seg, j.chunk, j.perm, j.rowptr, j.items, j.items_cap, j.fix, j.fix_cap, sc, st,
+                                           j.carry_src[0] ? &carry : nullptr);
+            if (rc != GV_OK) return rc;
+        }
+        return launch_status("gv_build_csr_batch");
+    }
+    IdxBatch bt;
+    bt.n = n_jobs;
+    int sort_blocks[2] = {0, 0}, lb_total = 0, it_total = 0;
+    for (int q = 0; q < n_jobs; ++q) {
+        const gv_csr_job& j = jobs[q];
+        const RsPlan& pl = plans[q];
+        Scratch sc(base, j.n, j.n_seg);
+        base += Scratch::bytes(j.n, j.n_seg);
+        IdxJob& J = bt.j[q];
+        J.keys = j.keys; J.n = (int)j.n; J.n_seg = j.n_seg; J.chunk = j.chunk;
+        J.chunk_shift = -1;
+        for (int k = 0; k < 31; ++k)
+            if (j.chunk == (1 << k)) J.chunk_shift = k;
+        J.tile = pl.tile; J.blocks = pl.blocks; J.passes = pl.passes; J.bits0 = pl.bits[0]; J.bits1 = pl.bits[1];
+        J.perm = j.perm;
+        J.k16_a = (unsigned short*)sc.keys_sorted;
+        J.k16_b = J.k16_a + ((j.n + 7) & ~(int64_t)7);
+        J.iota = sc.iota;
+        J.hist = (int*)sc.cub;
+        J.carry = carry_of(j.carry_src[0], j.carry_out[0], j.carry_src[1], j.carry_out[1], j.carry_src[2], j.carry_out[2]);
+        J.rowptr = j.rowptr; J.items = (int4*)j.items; J.fix = (int4*)j.fix; J.items_cap = j.items_cap; J.fix_cap = j.fix_cap;
+        J.lb_blocks = (j.n_seg + 1 + 255) / 256;
+        J.copy_blocks = (pl.passes == 0 && j.carry_src[0]) ? (int)((j.n + 255) / 256) : 0;
+        J.it_blocks = (j.n_seg + RS_T - 1) / RS_T;
+        if (pl.passes >= 1) sort_blocks[0] += pl.blocks;
+        if (pl.passes >= 2) sort_blocks[1] += pl.blocks;
+        lb_total += J.lb_blocks + J.copy_blocks;
+        it_total += J.it_blocks;
+    }
+    if (sort_blocks[0] > 0) {
+        hipLaunchKernelGGL(k_rs_hist_batch<0>, dim3(sort_blocks[0]), dim3(RS_T), 0, st, bt);
+        hipLaunchKernelGGL(k_rs_scatter_batch<0>, dim3(sort_blocks[0]), dim3(RS_T), 0, st, bt);
+    }
+    if (sort_blocks[1] > 0) {
+        hipLaunchKernelGGL(k_rs_hist_batch<1>, dim3(sort_blocks[1]), dim3(RS_T), 0, st, bt);
+        hipLaunchKernelGGL(k_rs_scatter_batch<1>, dim3(sort_blocks[1]), dim3(RS_T), 0, st, bt);
+    }
+    hipLaunchKernelGGL(k_lower_bounds_batch, dim3(lb_total), dim3(256), 0, st, bt);
+    hipLaunchKernelGGL(k_items_blocks_batch, dim3(it_total), dim3(RS_T), 0, st, bt);
+    return launch_status("gv_build_csr_batch");
+}
+
+extern "C" int gv_triplet_lists(const void* trip, int trip_is_int64, int64_t T, int32_t* ent, int32_t* other, int32_t* rel2, int32_t* tid,
+                                int32_t* col_s, int32_t* col_r, int32_t* col_o, int32_t* trip32, void* stream) {
+    GV_REQUIRE(T >= 0 && 2 * T < (1ll << 31), GV_ERR_SHAPE, "gv_triplet_lists: T=%lld", (long long)T);
+    if (T == 0) return GV_OK;
+    GV_REQUIRE(trip && ent && other && rel2 && tid && col_s && col_r && col_o, GV_ERR_NULL, "gv_triplet_lists: NULL pointer");
+    const dim3 grid((unsigned)((2 * T + 255) / 256)), block(256);
+    if (trip_is_int64)
+        hipLaunchKernelGGL(k_triplet_lists<long long>, grid, block, 0, (hipStream_t)stream, (const long long*)trip, T, ent, other, rel2, tid,
+                           col_s, col_r, col_o, trip32);
+    else
+        hipLaunchKernelGGL(k_triplet_lists<int>, grid, block, 0, (hipStream_t)stream, (const int*)trip, T, ent, other, rel2, tid, col_s, col_r,
+                           col_o, trip32);
+    return launch_status("gv_triplet_lists");
+}
+
+extern "C" int gv_widen2_i32(const int32_t* a, int64_t* a_out, int64_t na, const int32_t* b, int64_t* b_out, int64_t nb, void* stream) {
+    GV_REQUIRE(na >= 0 && nb >= 0, GV_ERR_SHAPE, "gv_widen2_i32: na=%lld nb=%lld", (long long)na, (long long)nb);
+    if (na + nb == 0) return GV_OK;
+    GV_REQUIRE((na == 0 || (a && a_out)) && (nb == 0 || (b && b_out)), GV_ERR_NULL, "gv_widen2_i32: NULL pointer");
+    hipLaunchKernelGGL(k_widen2_i32, dim3((unsigned)((na + nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, (long long*)a_out, na, b,
+                       (long long*)b_out, nb);
+    return launch_status("gv_widen2_i32");
 }

@@ -131,13 +131,16 @@ class DeviceSampler:
         lib.call('gv_graph_from_triplets', ptr(src), ptr(rel), ptr(dst), ptr(keep), m, cap, self.num_rels, ptr(src2), ptr(dst2),
                  ptr(rel2), ptr(norm), ptr(gws), gb, st)
         if static:
+            pick32 = None
             if mmd_pick is not None:       # KGVAE.get_mmd's posterior rows: distinct rows of the ones that exist (kgvae/model.py:96)
                 pick32 = torch.empty(mmd_pick.numel(), **i32)
                 lib.call('gv_perm_sample', cap, mmd_pick.numel(), self.seed, tick, tick_dev, ptr(count), STREAM_PICK, ptr(pick32), st)
-                mmd_pick.copy_(pick32)
+            # node ids and row picks as the int64 tensors the modules take: one launch for both (two torch conversion kernels before)
+            uniq64 = torch.empty(cap, dtype=torch.int64, device=dev)
+            lib.call('gv_widen2_i32', ptr(uniq), ptr(uniq64), cap, ptr(pick32), ptr(mmd_pick), 0 if mmd_pick is None else mmd_pick.numel(), st)
             g = KGraph.from_device_edges(cap, src2, dst2, dst_sorted=True)       # rows [count, cap): isolated padding nodes
             # (relation ids stay int32 here: the index builders take them as they are -- one conversion kernel less per step)
-            return DeviceBatch(g, uniq.long().view(-1, 1), rel2, norm, samples, labels, rows_dev=count)
+            return DeviceBatch(g, uniq64.view(-1, 1), rel2, norm, samples, labels, rows_dev=count)
         n = int(count.item())                                                    # the one host sync per batch
         g = KGraph.from_device_edges(n, src2, dst2, dst_sorted=True)
         return DeviceBatch(g, uniq[:n].long().view(-1, 1), rel2.long(), norm, samples, labels)

@@ -66,7 +66,8 @@ class GraphedMiniBatchStep:
             enc.fuse_kl_with_reparam = False               # the KL pass needs the device row count: it stays in the loss head here
         try:
             self.opt.zero_grad()
-            if self.idx_side is not None and hasattr(m, 'triplet_index'):
+            batched = self._batch_indices(b)
+            if not batched and self.idx_side is not None and hasattr(m, 'triplet_index'):
                 # (the graph's own index the same way, on a second stream, waited for behind layer 1's self-loop product: 1.07 ms
                 # against 0.94 -- the builders' small launches then compete with the forward pass's for the dispatcher)
                 self.idx_side.wait_stream(torch.cuda.current_stream())
@@ -74,7 +75,7 @@ class GraphedMiniBatchStep:
                     m.triplet_index(_Rows(b.node_id.shape[0], b.samples.device), b.samples)      # cached: get_loss finds it built
             with ops.live_rows(b.rows_dev, b.node_id.shape[0]):      # the dense products skip the padding rows
                 embed = m(b.g, b.node_id, b.edge_type, b.edge_norm)
-                if self.idx_side is not None:
+                if not batched and self.idx_side is not None:
                     torch.cuda.current_stream().wait_stream(self.idx_side)
                 loss, pred, kl, mmd = m.get_loss(b.g, embed, b.samples, b.labels)
                 loss.backward(gradient=self.one.expand_as(loss))
@@ -89,6 +90,30 @@ class GraphedMiniBatchStep:
                 enc.fuse_kl_with_reparam = saved[3]
         self.batch = b
         return loss, pred, kl, mmd
+
+    def _batch_indices(self, b):
+        """All of the batch's orderings (graph by destination / source, relation, triplet incidences, triplets by relation) in
+        shared launches (ops.build_batch_indices: 7 launches instead of ~30 dependent ones of ~4 us), handed to the places the
+        modules look their indices up: the graph's per-device cache, the graph index's relation cache, the model's triplet cache.
+        False = not applicable (GV_INDEX_BATCH=0, a model without those caches): the modules build their indices as they go."""
+        m = self.model
+        layers = [l for l in m.modules() if hasattr(l, 'num_rels') and hasattr(l, 'num_bases')]
+        dev_edges = getattr(b.g, '_dev_edges', None)
+        if not (ops.indices.BATCH_INDEX and ops.indices.NATIVE_INDEX and layers and dev_edges is not None and hasattr(m, 'w_relation')
+                and hasattr(m, '_tidx_key') and b.edge_type.dtype == torch.int32):
+            return False
+        num_rels = {int(l.num_rels) for l in layers}
+        if len(num_rels) != 1:
+            return False
+        src, dst = dev_edges
+        dev = src.device
+        n = b.node_id.shape[0]
+        gidx, _, tidx = ops.build_batch_indices(src, dst, b.edge_type, n, num_rels.pop(), b.samples, n, m.w_relation.shape[0],
+                                                dst_sorted=bool(getattr(b.g, '_dst_sorted', False)))
+        b.g._index[(dev.type, dev.index if dev.index is not None else torch.cuda.current_device())] = gidx
+        m._tidx, m._tidx_keepalive = tidx, b.samples
+        m._tidx_key = (b.samples.data_ptr(), b.samples._version, tuple(b.samples.shape), n)
+        return True
 
     def capture(self, warmup=3):
         """Eager warm-up steps (they are real training steps) on the capture stream, then the recording."""

@@ -19,6 +19,10 @@ SIGNATURES = {
     'gv_index_caps': (None, [_L, _I, _I, _P, _P, _P]),
     'gv_index_workspace_bytes': (_L, [_L, _I]),
     'gv_build_csr': (_I, [_P, _L, _I, _I, _P, _P, _P, _I, _P, _I, _P, _L, _P]),
+    'gv_build_csr_batch_workspace_bytes': (_L, [_P, _I]),
+    'gv_build_csr_batch': (_I, [_P, _I, _P, _L, _P]),
+    'gv_triplet_lists': (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'gv_widen2_i32': (_I, [_P, _P, _L, _P, _P, _L, _P]),
     'gv_graph_index_build': (_I, [_P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _L, _P]),
     'gv_relation_index_build': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _L, _P]),
     'gv_triplet_index_build': (_I, [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I,

@@ -751,6 +751,36 @@ int gv_triplet_index_build(const int32_t* trip, int64_t T, int n_ent, int n_rel,
                            int32_t* rowptr_rel, int32_t* items_rel, int items_rel_cap, int32_t* fix_rel, int fix_rel_cap,
                            void* workspace, int64_t workspace_bytes, void* stream);
 
+/* SEVERAL orderings in the same launches: a sampled batch (kgvae/link_predict.py:200-236) rebuilds five of them per step (edges by
+ * destination / source / relation, triplets by entity / relation), each 20-60 k entries -- every pass of every ordering is one short
+ * launch, and a step is bound by the number of DEPENDENT launches.  The orderings are independent, so pass p of all of them runs as one
+ * grid: six launches (two histogram + scatter passes, row pointers, work items) for up to 8 orderings, bit-identical to gv_build_csr
+ * ordering by ordering.  carry_src[k] (optional, up to three arrays) come out permuted with the ordering: carry_out[k][i] =
+ * carry_src[k][perm[i]] (perm NULL: copied) -- the neighbour / relation columns the index builders above gather.  Orderings outside
+ * the batched kernels (n = 0, n_seg > 65 536, n > 524 288, GV_INDEX_SORT set) make the call run them one after the other. */
+typedef struct gv_csr_job {
+    const int32_t* keys;            /* n segment ids in [0, n_seg) */
+    int64_t n;
+    int32_t n_seg, chunk;
+    int32_t* perm;                  /* out, n entries; NULL: keys are already sorted */
+    int32_t* rowptr;                /* out, n_seg + 1 */
+    int32_t* items;                 /* out, 4 * items_cap (gv_index_caps) */
+    int32_t* fix;                   /* out, 4 * fix_cap */
+    int32_t items_cap, fix_cap;
+    const int32_t* carry_src[3];
+    int32_t* carry_out[3];
+} gv_csr_job;
+int64_t gv_build_csr_batch_workspace_bytes(const gv_csr_job* jobs, int n_jobs);
+int gv_build_csr_batch(const gv_csr_job* jobs, int n_jobs, void* workspace, int64_t workspace_bytes, void* stream);
+/* the inputs of a triplet batch's two orderings in one launch: the 2T incidences (ent = subject | object, other = object | subject,
+ * rel2, tid = triplet number) and the three columns of the (T, 3) list */
+int gv_triplet_lists(const void* trip /* (T, 3) int32, or int64 as utils.negative_sampling returns it */, int trip_is_int64, int64_t T,
+                     int32_t* ent, int32_t* other, int32_t* rel2, int32_t* tid, int32_t* col_s, int32_t* col_r, int32_t* col_o,
+                     int32_t* trip32 /* optional: the (T, 3) list as int32 */, void* stream);
+/* a_out[i] = a[i], b_out[i] = b[i]: the sampler's int32 node ids and row picks as the int64 tensors the reference's interfaces carry
+ * (g.ndata['id'], random.sample rows), one launch for both */
+int gv_widen2_i32(const int32_t* a, int64_t* a_out, int64_t na, const int32_t* b, int64_t* b_out, int64_t nb, void* stream);
+
 /* ---- mini-batch preparation on the device (kgvae/utils.py:79-171) -------------------------------------------
  * Random draws are Philox4x32-10 outputs keyed by (seed, tick, stream_id): a batch is a pure function of those three. */
 /* out[i] = i-th output of a keyed permutation of [0, n), i < k <= n: k DISTINCT indices (np.random.choice(n, k, replace=False),

@@ -66,14 +66,14 @@ def test_product_never_imports_the_oracle():
 
 def test_header_is_plain_c_and_struct_layouts_match_the_ctypes_mirrors(tmp_path):
     """include/gcnvae.h compiles as C99 on its own (no C++, no HIP, no torch types), and the two descriptor structs the MADE
-    entry points take (gv_chain_layer, gv_row_layer) have the size and field offsets of their ctypes mirrors in ops.py."""
+    entry points take (gv_chain_layer, gv_row_layer) and the batched index builder's gv_csr_job have the size and field offsets of their ctypes mirrors in ops.py."""
     import shutil
     import subprocess
     import pytest
     if shutil.which('gcc') is None:
         pytest.skip('no gcc')
     from gcn_vae_amd import ops
-    fields = {'gv_chain_layer': ops._ChainLayer, 'gv_row_layer': ops._RowLayer}
+    fields = {'gv_chain_layer': ops._ChainLayer, 'gv_row_layer': ops._RowLayer, 'gv_csr_job': ops.indices._CsrJob}
     lines = []
     for name, cls in fields.items():
         lines.append(f'printf("{name} %zu", sizeof({name}));')

@@ -1153,6 +1153,59 @@ def test_native_triplet_index_equals_torch_formulation(ops, monkeypatch, T, n_en
     assert a.fwd_order is None and a.pos3 is None and b.fwd_order is None and b.pos3 is None
 
 
+@pytest.mark.parametrize('n,e,r,sorted_dst,T', [(300, 5000, 12, True, 2000), (300, 5000, 12, False, 0), (14541, 30000, 474, True, 330000),
+                                                 (2000, 60000, 474, True, 5000), (1, 7, 1, True, 3), (120, 0, 5, True, 40),
+                                                 (3000, 600000, 60, False, 1000)])      # the last two: outside the batched kernels
+def test_batched_index_build_equals_the_builders_one_by_one(ops, monkeypatch, n, e, r, sorted_dst, T):
+    """ops.build_batch_indices (gv_triplet_lists + gv_build_csr_batch: every pass of the five orderings in one launch) against
+    GraphIndex / RelationIndex / TripletIndex built one after the other: every array equal."""
+    monkeypatch.delenv('GV_INDEX_SORT', raising=False)
+    rs = np.random.RandomState(n + e + T)
+    p = (np.arange(n) + 1.0) ** -1.2
+    dst = rs.choice(n, size=e, p=p / p.sum())
+    src = rs.randint(0, n, size=e)
+    et = rs.randint(0, r, size=e)
+    if sorted_dst:
+        order = np.lexsort((et, src, dst))
+        src, dst, et = src[order], dst[order], et[order]
+    src_t, dst_t, et_t = (torch.from_numpy(a.astype(np.int32)).cuda() for a in (src, dst, et))
+    n_trel = max(1, r // 2)
+    trip = np.stack([rs.randint(0, n, size=T), rs.randint(0, n_trel, size=T), rs.randint(0, n, size=T)], 1).astype(np.int64)
+    trip_t = torch.from_numpy(trip).cuda().reshape(T, 3)
+    gb, rb, tb = ops.build_batch_indices(src_t, dst_t, et_t, n, r, trip_t if T else None, n, n_trel, dst_sorted=sorted_dst)
+    g = ops.GraphIndex(src_t, dst_t, n, dst_sorted=sorted_dst, sync_free=True)
+    ri = ops.RelationIndex(g, et_t, r)
+    assert (gb.by_dst.perm is None) == sorted_dst
+    if not sorted_dst:
+        assert torch.equal(gb.by_dst.perm, g.by_dst.perm)
+    assert torch.equal(gb.by_src.perm, g.by_src.perm)
+    assert torch.equal(gb.nbr_by_dst, g.nbr_by_dst) and torch.equal(gb.nbr_by_src, g.nbr_by_src)
+    assert _same_items(gb.by_dst.seg, g.by_dst.seg) and _same_items(gb.by_src.seg, g.by_src.seg)
+    for name in ('et_by_dst', 'et_by_src', 'src_by_rel', 'dst_by_rel'):
+        assert torch.equal(getattr(rb, name), getattr(ri, name)), name
+    assert torch.equal(rb.by_rel.perm, ri.by_rel.perm) and _same_items(rb.by_rel.seg, ri.by_rel.seg)
+    assert gb.relation_index(et_t, r) is rb                      # found by the layers' lookup
+    if T:
+        t1 = ops.TripletIndex(trip_t, n, n_trel, sync_free=True)
+        for name in ('trip32', 'inc_other', 'inc_rel', 'inc_tid', 'rel_s', 'rel_o', 'rel_tid'):
+            assert torch.equal(getattr(tb, name), getattr(t1, name)), name
+        assert _same_items(tb.inc, t1.inc) and _same_items(tb.rel, t1.rel)
+    else:
+        assert tb is None
+
+
+def test_gv_build_csr_batch_reports_bad_arguments(ops):
+    from gcn_vae_amd import lib
+    import ctypes
+    jobs = (ops.indices._CsrJob * 9)()
+    assert lib.load().gv_build_csr_batch(ctypes.addressof(jobs), 9, None, 0, None) != 0          # more orderings than a batch holds
+    assert lib.load().gv_build_csr_batch(ctypes.addressof(jobs), 0, None, 0, None) == 0
+    jobs[0].n, jobs[0].n_seg, jobs[0].chunk = 5, 3, 16
+    assert lib.load().gv_build_csr_batch(ctypes.addressof(jobs), 1, None, 0, None) != 0 and 'NULL' in lib.last_error()
+    assert lib.load().gv_triplet_lists(None, 0, 4, None, None, None, None, None, None, None, None, None) != 0
+    assert lib.load().gv_widen2_i32(None, None, 3, None, None, 0, None) != 0 and lib.load().gv_widen2_i32(None, None, 0, None, None, 0, None) == 0
+
+
 @pytest.mark.parametrize('n,n_seg', [(10000, 37),
                                      # the 16-bit-key path (n >= 100 000) in ONE scatter pass (n_seg <= 256) at the lengths where the
                                      # sorted-key half once ran past its area into the sort's own value input: n % 128 in [1, 64]
