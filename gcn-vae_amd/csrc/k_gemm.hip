@@ -31,6 +31,13 @@ struct GemmParams {
     int act, accumulate, split_k, k_chunk;
     int vec_a, vec_b;
     const int* rows_dev;   // optional device scalar: only the first *rows_dev rows of the stored A exist (padding of a static-shape batch)
+    // B known to be zero in whole blocks (an autoregressive mask folded into the weights): per 64-column tile of C one word, bit c set =
+    // B holds non-zero entries in k-chunk c (16 wide); chunks with a clear bit are not loaded and not multiplied (BK = 16, no split-K)
+    const unsigned long long* kmask;
+    // C known to be zero in whole 64 x 64 tiles (the weight gradient of such a layer): bit (i * tmask_ld + j) set = tile (i, j) is wanted;
+    // other tiles are stored as zeros (nothing when accumulating) without reading A or B
+    const unsigned long long* tmask;
+    int tmask_ld;
 };
 
 // guarded load of VPT consecutive floats (VPT % 4 == 0) along the contiguous dimension; `lim` bounds that
@@ -141,8 +148,14 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmParams p) {
         const int full = (gridDim.y / 8) * 8 * ntn;
         if (lin < full) {
             const int xcd = lin & 7, j = lin >> 3;
-            nt_i = j % ntn;
+            // (rotated by the m-tile group: an XCD deals its slots to its 32 CUs in turn, so with 8 column tiles a CU would receive the
+            // SAME column tile every time -- and under k-chunk words the column tiles differ in length: 72 us instead of ~55 on the 500 x 500
+            // MADE layer, the CUs holding the unmasked tiles finishing last)
+            nt_i = (j + j / ntn) % ntn;
             mt_i = (j / ntn) * 8 + xcd;
+            // wanted-tile words (a block-triangular weight gradient): XCD x would hold row-tile x of every column tile, i.e. 1 .. 8 wanted
+            // tiles -- along the anti-diagonals every XCD holds the same number
+            if (p.tmask) mt_i = (j / ntn) * 8 + ((xcd + nt_i) & 7);
         }
     }
     const int m0 = mt_i * BM, n0 = nt_i * BN;
@@ -175,16 +188,51 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmParams p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
 
+    bool wanted = true;
+    if (p.tmask) {      // a tile of C that the caller knows to be zero: every 64 x 64 part of it is unwanted
+        wanted = false;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const int bit = (mt_i * MT + t) * p.tmask_ld + nt_i * NT + u;
+                if ((mt_i * MT + t) * 64 < p.m && (nt_i * NT + u) * 64 < p.n) wanted = wanted || ((p.tmask[bit >> 6] >> (bit & 63)) & 1ull);
+            }
+    }
+    // the k-chunks to walk: all of [kbeg, kend), or the ones whose bit is set in this column tile's word (NT == 1, BK == 16)
+    unsigned long long todo = ~0ull;
+    const bool sparse = p.kmask != nullptr;
+    if (sparse) {
+        todo = p.kmask[nt_i];                                  // bits count 16-wide chunks
+        if (BK == 32) {                                        // a 32-deep step is walked when either of its halves is marked
+            unsigned long long t = (todo | (todo >> 1)) & 0x5555555555555555ull, packed = 0ull;
+            for (int i = 0; i < 32; ++i) packed |= ((t >> (2 * i)) & 1ull) << i;
+            todo = packed;
+        }
+    }
+    if (!wanted) todo = 0ull;
+    auto next_chunk = [&](int from) -> int {      // first chunk >= from inside the k range that is to be walked, or kend
+        if (!sparse && wanted) return from;
+        const int c = from / BK;
+        const unsigned long long rest = c < 64 ? (todo >> c) : 0ull;
+        if (!rest) return kend;
+        return (c + __builtin_ctzll(rest)) * BK;
+    };
+
     float ra[BM * BK / 256], rb[BN * BK / 256];
-    load_a<TA, BM, BK>(p, m0, kbeg, kend, ra);
-    load_b<TB, BN, BK>(p, n0, kbeg, kend, rb);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    int k0 = min(next_chunk(kbeg), kend);
+    if (k0 < kend) {
+        load_a<TA, BM, BK>(p, m0, k0, kend, ra);
+        load_b<TB, BN, BK>(p, n0, k0, kend, rb);
+    }
+    while (k0 < kend) {
         stage_a<TA, BM, BK>(As, ra);
         stage_b<TB, BN, BK>(Bs, rb);
         __syncthreads();
-        if (k0 + BK < kend) {  // next tile's loads fly under this tile's MFMAs
-            load_a<TA, BM, BK>(p, m0, k0 + BK, kend, ra);
-            load_b<TB, BN, BK>(p, n0, k0 + BK, kend, rb);
+        const int k1 = min(next_chunk(k0 + BK), kend);
+        if (k1 < kend) {  // next tile's loads fly under this tile's MFMAs
+            load_a<TA, BM, BK>(p, m0, k1, kend, ra);
+            load_b<TB, BN, BK>(p, n0, k1, kend, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
@@ -200,6 +248,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmParams p) {
                     acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], bf[u], acc[t][u], 0, 0, 0);
         }
         __syncthreads();
+        k0 = k1;
     }
     // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -635,7 +684,8 @@ extern "C" int64_t gv_gemm_workspace_bytes(int m, int n, int k, int split_k) {
 
 static int gemm_any(bool bf16, int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b,
                     int ldb, float* c, int ldc, const float* bias, int act, int accumulate, int split_k,
-                    const float* a_relu_mask, void* workspace, int64_t workspace_bytes, void* stream, const int32_t* rows_dev = nullptr) {
+                    const float* a_relu_mask, void* workspace, int64_t workspace_bytes, void* stream, const int32_t* rows_dev = nullptr,
+                    const uint64_t* kmask = nullptr, const uint64_t* tmask = nullptr) {
     GV_REQUIRE(m >= 0 && n >= 0 && k >= 0, GV_ERR_SHAPE, "gv_gemm_f32: negative size");
     if (m == 0 || n == 0) return GV_OK;
     GV_REQUIRE(a && b && c, GV_ERR_NULL, "gv_gemm_f32: NULL matrix");
@@ -654,6 +704,12 @@ static int gemm_any(bool bf16, int trans_a, int trans_b, int m, int n, int k, co
     p.vec_a = aligned16(a) && (lda % 4 == 0) && (!a_relu_mask || aligned16(a_relu_mask));
     p.vec_b = aligned16(b) && (ldb % 4 == 0);
     p.rows_dev = bf16 ? nullptr : rows_dev;
+    GV_REQUIRE(!kmask || (!bf16 && split_k == 1 && k <= 64 * 16), GV_ERR_SHAPE,
+               "gv_gemm_f32_sparse: k-chunk words cover fp32 products of k <= 1024 without split-K (k=%d split_k=%d)", k, split_k);
+    GV_REQUIRE(!tmask || !bf16, GV_ERR_SHAPE, "gv_gemm_f32_sparse: fp32 only");
+    p.kmask = (const unsigned long long*)kmask;
+    p.tmask = (const unsigned long long*)tmask;
+    p.tmask_ld = (n + 63) / 64;
     if (split_k > 1) {
         GV_REQUIRE(workspace, GV_ERR_NULL, "gv_gemm_f32: split_k needs a workspace");
         GV_REQUIRE(workspace_bytes >= gv_gemm_workspace_bytes(m, n, k, split_k), GV_ERR_WORKSPACE,
@@ -683,11 +739,14 @@ static int gemm_any(bool bf16, int trans_a, int trans_b, int m, int n, int k, co
     static const int mt_env = getenv("GV_GEMM_MT") ? atoi(getenv("GV_GEMM_MT")) : 0;   // tuning knobs
     static const int nt_env = getenv("GV_GEMM_NT") ? atoi(getenv("GV_GEMM_NT")) : 0;
     static const int bk_env = getenv("GV_GEMM_BK") ? atoi(getenv("GV_GEMM_BK")) : 0;
-    const int nt = nt_env == 2 ? 2 : 1;        // 128-column tiles measured 8-12 % slower on every C2 shape: opt-in only
+    const int nt = (nt_env == 2 && !kmask) ? 2 : 1;        // 128-column tiles measured 8-12 % slower on every C2 shape: opt-in only
     const int bn = 64 * nt;
     const long blocks128 = (long)((n + bn - 1) / bn) * ((m + 127) / 128) * split_k;
     const int mt = mt_env ? mt_env : (blocks128 >= 1024 ? 2 : 1);
-    const int bk = bk_env ? (bk_env == 16 ? 16 : 32) : (trans_a ? 32 : 16);
+    // with k-chunk words: 16-deep steps = exactly the marked chunks (GV_GEMM_SPARSE_BK=32: 32-deep steps walked when either half is
+    // marked -- measured the same, 66 us on the 500 x 500 MADE layer against 92 dense)
+    static const int sparse_bk = getenv("GV_GEMM_SPARSE_BK") ? atoi(getenv("GV_GEMM_SPARSE_BK")) : 16;
+    const int bk = kmask ? (sparse_bk == 32 ? 32 : 16) : (bk_env ? (bk_env == 16 ? 16 : 32) : (trans_a ? 32 : 16));
     dim3 grid((n + bn - 1) / bn, (m + 64 * mt - 1) / (64 * mt), split_k), block(256);
 #define GV_GEMM_CFG(TA_, TB_, MT_, NT_, BK_) \
     if (mt == MT_ && nt == NT_ && bk == BK_) hipLaunchKernelGGL((k_gemm_f32<TA_, TB_, MT_, NT_, BK_>), grid, block, 0, st, p);
@@ -729,6 +788,14 @@ extern "C" int gv_gemm_f32_live_rows(int trans_a, int trans_b, int m, int n, int
                     workspace, workspace_bytes, stream, rows_dev);
 }
 
+extern "C" int gv_gemm_f32_sparse(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b, int ldb,
+                                  float* c, int ldc, const float* bias, int act, int accumulate, int split_k, const float* a_relu_mask,
+                                  void* workspace, int64_t workspace_bytes, const int32_t* rows_dev, const uint64_t* b_k_chunks,
+                                  const uint64_t* c_tiles, void* stream) {
+    return gemm_any(false, trans_a, trans_b, m, n, k, a, lda, b, ldb, c, ldc, bias, act, accumulate, split_k, a_relu_mask,
+                    workspace, workspace_bytes, stream, rows_dev, b_k_chunks, c_tiles);
+}
+
 extern "C" int gv_gemm_bf16(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b,
                             int ldb, float* c, int ldc, const float* bias, int act, int accumulate, int split_k,
                             const float* a_relu_mask, void* workspace, int64_t workspace_bytes, void* stream) {
@@ -749,7 +816,7 @@ extern "C" int gv_rank_scores(const float* q, int ld_q, const float* e, int ld_e
     p.act = GV_ACT_NONE; p.accumulate = 0; p.split_k = 1; p.k_chunk = h;
     p.vec_a = aligned16(q) && (ld_q % 4 == 0);
     p.vec_b = aligned16(e) && (ld_e % 4 == 0);
-    p.rows_dev = nullptr;
+    p.rows_dev = nullptr; p.kmask = nullptr; p.tmask = nullptr; p.tmask_ld = 0;
     rp.target = target; rp.bias = bias; rp.tgt = tgt; rp.count = count;
     hipStream_t st = (hipStream_t)stream;
     if (fill_words(count, 0u, (size_t)m * sizeof(int), st) != hipSuccess) return launch_status("gv_rank_scores(fill)");

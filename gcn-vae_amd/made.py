@@ -48,6 +48,28 @@ def _capturing():
     return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
+MADE_SPARSE_F32 = _os.environ.get('GV_MADE_SPARSE_F32', '1') == '1'      # per-layer products (widths outside the chain kernel) skip the masks' zero blocks
+_sparse_words = {}
+
+
+def _mask_words(masks):
+    """Per layer the block words of its autoregressive mask for the three products of the per-layer path (ops.block_words: forward,
+    backward-x, weight-gradient tiles); None where they do not apply.  Built once per mask set (a host read-back of static masks:
+    never under capture -- a step captured before any eager use runs dense)."""
+    if masks is None or not MADE_SPARSE_F32:
+        return None
+    key = tuple((m.data_ptr(), tuple(m.shape)) for m in masks)
+    hit = _sparse_words.get(key)
+    if hit is None:
+        if _capturing():
+            return None
+        if len(_sparse_words) > 64:
+            _sparse_words.clear()
+        hit = _sparse_words[key] = ([dict(fwd=_ops.block_words(m, 'fwd'), bwd=_ops.block_words(m, 'bwd'), tiles=_ops.block_words(m, 'tiles'))
+                                     for m in masks], masks)       # (holds the masks: the key is their addresses)
+    return hit[0]
+
+
 def _made_params_work_f32(masks, ws, bs, d, S):
     """The part of _MADEForward.forward that depends on the parameters alone: the mask fold (one launch), pass 0 on its single zero
     row -- one single-workgroup launch with exact fp32 operands where the widths allow, else a launch per product --, and for the
@@ -136,6 +158,9 @@ class _MADEForward(torch.autograd.Function):
         # (columns outside the first index set would keep x_old = 0: flows.MADE checks at construction that there are none)
         if not fused_passes:
             lib.call('gv_iaf_update_fwd', ptr(z), ptr(acts0[L - 1]), 0, ptr(z), ptr(colcount[0]), ptr(first_out), n, d, st)
+        words = None if chain else _mask_words(masks)       # zero blocks of the masked weights: skipped by the per-layer products
+        ctx.words = words
+
         def passes(r0, r1):      # passes 1 .. P-1 for the rows [r0, r1): every launch of a pass is row-local
             for p in range(1, P):
                 a, b = (p - 1) * n + r0, (p - 1) * n + r1
@@ -146,7 +171,8 @@ class _MADEForward(torch.autograd.Function):
                     inp = acts[L - 1][a:b]
                 for l in range(L) if not chain else ():
                     out = acts[l][a:b]
-                    gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE, out=out)
+                    gemm(inp, ws[l], trans_b=True, bias=bs[l], act=ACT_RELU if l < L - 1 else ACT_NONE, out=out,
+                         b_k_chunks=None if words is None else words[l]['fwd'])
                     inp = out
                 nxt = xin[p * n + r0:p * n + r1] if p + 1 < P else x_out[r0:r1]
                 lib.call('gv_iaf_update_fwd', ptr(z[r0:r1]), ptr(inp), 2 * d, ptr(xin[a:b]), ptr(colcount[p]), ptr(nxt), r1 - r0, d,
@@ -208,6 +234,8 @@ class _MADEForward(torch.autograd.Function):
         gold_stack = torch.empty(max(S, 1) * n, d, **f32)                 # dL/dx_old of every pass, stacked like the activations
         g_olds = {p: gold_stack[(p - 1) * n:p * n] for p in range(1, P)}
 
+        words = getattr(ctx, 'words', None)
+
         def passes(r0, r1):      # the backward of passes P-1 .. 1 for the rows [r0, r1): every launch is row-local
             g_in, m = gx, r1 - r0
             for p in reversed(range(1, P)):
@@ -231,10 +259,11 @@ class _MADEForward(torch.autograd.Function):
                                    tag='madechain_bwd_f32')
                 for l in reversed(range(L)) if not chain else ():
                     mask = acts[l][a:b] if l < L - 1 else None
+                    kw = None if words is None else words[l]['bwd']
                     if l > 0:
-                        gemm(grads[l][a:b], ws[l], out=grads[l - 1][a:b], a_relu_mask=mask)
+                        gemm(grads[l][a:b], ws[l], out=grads[l - 1][a:b], a_relu_mask=mask, b_k_chunks=kw)
                     else:       # gradient w.r.t. the pass's input x_p joins the update's pass-through gradient
-                        gemm(grads[0][a:b], ws[0], out=g_old, accumulate=True, a_relu_mask=mask)
+                        gemm(grads[0][a:b], ws[0], out=g_old, accumulate=True, a_relu_mask=mask, b_k_chunks=kw)
                 g_in = g_olds[p]
         if fused_passes:
             # passes P-1 .. 1, each = the update's backward + the backward-x chain, in ONE launch (the buffers of consecutive passes
@@ -309,7 +338,8 @@ class _MADEForward(torch.autograd.Function):
                     if S > 0:
                         inp = xin if l == 0 else acts[l - 1]
                         part = gemm(grads[l], inp, trans_a=True, a_relu_mask=mask,
-                                    split_k=pick_split_k(ws[l].shape[0], ws[l].shape[1], S * n))
+                                    split_k=pick_split_k(ws[l].shape[0], ws[l].shape[1], S * n),
+                                    c_tiles=None if (words is None or ctx.masks is None) else words[l]['tiles'])
                         lib.call('gv_axpby', gw.numel(), None, 1.0, ptr(part), 1.0, ptr(gw), lib.stream())
                 if wants_b[l]:      # (a bias with a slice of the arena: ADDED there, whatever the slice holds)
                     gb = colsum(rows0[l], relu_mask=mask0, out=tgt_b[l], accumulate=tgt_b[l] is not None)

@@ -426,9 +426,10 @@ class live_rows:
 
 
 def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, accumulate=False, split_k=1,
-         a_relu_mask=None, precision=None):
+         a_relu_mask=None, precision=None, b_k_chunks=None, c_tiles=None):
     """out = act(op(a') @ op(b) + bias) (+ out);  a' = a * [a_relu_mask > 0] when a mask (same layout as a) is given.
-    precision None = the global GEMM_PRECISION."""
+    precision None = the global GEMM_PRECISION.  b_k_chunks / c_tiles (int64 device words, ops.block_words): blocks of op(b) / tiles
+    of the result known to be zero are skipped (gv_gemm_f32_sparse; fp32 only)."""
     a, lda = _row_major(a, 'a')
     b, ldb = _row_major(b, 'b')
     m, k = (a.shape[1], a.shape[0]) if trans_a else a.shape
@@ -450,6 +451,16 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, 
             raise ValueError('a_relu_mask must have the shape and leading dimension of a')
     entry = 'gv_gemm_bf16' if (precision or GEMM_PRECISION) == 'bf16' else 'gv_gemm_f32'
     live = LIVE_ROWS
+    if (b_k_chunks is not None or c_tiles is not None) and entry == 'gv_gemm_f32':
+        if b_k_chunks is not None and (b_k_chunks.dtype != torch.int64 or b_k_chunks.numel() < (n + 63) // 64 or k > 1024 or split_k != 1):
+            raise ValueError('b_k_chunks: one int64 word per 64-column tile, k <= 1024, no split-K')
+        if c_tiles is not None and (c_tiles.dtype != torch.int64 or c_tiles.numel() * 64 < ((m + 63) // 64) * ((n + 63) // 64)):
+            raise ValueError('c_tiles: one bit per 64 x 64 tile of the result')
+        rows = live[0] if (live is not None and a.shape[0] == live[1] and a.device == live[0].device) else None
+        lib.call('gv_gemm_f32_sparse', 1 if trans_a else 0, 1 if trans_b else 0, m, n, k, ptr(a), lda, ptr(b), ldb, ptr(out),
+                 out.stride(0) if m > 1 else n, ptr(bias), act, 1 if accumulate else 0, split_k, ptr(a_relu_mask), ptr(ws),
+                 ws_bytes, ptr(rows), ptr(b_k_chunks), ptr(c_tiles), lib.stream())
+        return out
     if live is not None and entry == 'gv_gemm_f32' and a.shape[0] == live[1] and a.device == live[0].device:
         lib.call('gv_gemm_f32_live_rows', 1 if trans_a else 0, 1 if trans_b else 0, m, n, k, ptr(a), lda, ptr(b), ldb, ptr(out),
                  out.stride(0) if m > 1 else n, ptr(bias), act, 1 if accumulate else 0, split_k, ptr(a_relu_mask), ptr(ws),
@@ -459,6 +470,40 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, 
              out.stride(0) if m > 1 else n, ptr(bias), act, 1 if accumulate else 0, split_k, ptr(a_relu_mask), ptr(ws),
              ws_bytes, lib.stream())
     return out
+
+
+def block_words(mask, kind):
+    """Which blocks of a 0/1 matrix hold a non-zero entry, as the int64 words gv_gemm_f32_sparse takes (host-side: one read-back of the
+    mask -- build them once per static mask).  ``mask`` (out, in), as a MaskedLinear stores it.
+      'fwd'   y = x @ (W * mask)^T : per 64 outputs one word, bit c = inputs 16 c .. 16 c + 15 reach any of them
+      'bwd'   g_x = g @ (W * mask) : per 64 inputs one word, bit c = outputs 16 c .. 16 c + 15 depend on any of them
+      'tiles' dW = g^T @ x         : bit (i * ceil(in / 64) + j) = the 64 x 64 tile (i, j) of the (out, in) gradient is wanted"""
+    import numpy as np
+    m = (mask.detach().to('cpu').numpy() != 0)
+    o, i = m.shape
+
+    def pad(x, r, c):
+        y = np.zeros((-(-x.shape[0] // r) * r, -(-x.shape[1] // c) * c), dtype=bool)
+        y[:x.shape[0], :x.shape[1]] = x
+        return y
+    if kind in ('fwd', 'bwd'):
+        mm = m if kind == 'fwd' else m.T                       # rows = the product's columns n, columns = its k
+        if mm.shape[1] > 1024:
+            return None
+        y = pad(mm, 64, 16)
+        blk = y.reshape(y.shape[0] // 64, 64, y.shape[1] // 16, 16).any(axis=(1, 3))       # (n tiles, k chunks)
+        words = np.zeros(blk.shape[0], dtype=np.uint64)
+        for c in range(blk.shape[1]):
+            words |= blk[:, c].astype(np.uint64) << np.uint64(c)
+    elif kind == 'tiles':
+        y = pad(m, 64, 64)
+        blk = y.reshape(y.shape[0] // 64, 64, y.shape[1] // 64, 64).any(axis=(1, 3)).reshape(-1)
+        words = np.zeros((blk.size + 63) // 64, dtype=np.uint64)
+        for b in np.nonzero(blk)[0]:
+            words[b >> 6] |= np.uint64(1) << np.uint64(b & 63)
+    else:
+        raise ValueError(kind)
+    return torch.from_numpy(words.view(np.int64).copy()).to(mask.device)
 
 
 def rank_scores(q, entities, target, bias=None):

@@ -164,6 +164,76 @@ def test_made_node_with_chains_equals_the_node_with_a_launch_per_product(monkeyp
             assert bool(((a == 0) == (c == 0)).all()) or a.dim() == 1          # the masked-out entries are exact zeros in both
 
 
+@pytest.mark.parametrize('out_f,in_f,rows', [(500, 500, 700), (1000, 500, 300), (72, 136, 129), (64, 16, 64)])
+def test_products_that_skip_the_zero_blocks_of_a_mask_equal_the_dense_ones(out_f, in_f, rows):
+    """gv_gemm_f32_sparse (ops.gemm(b_k_chunks= / c_tiles=)) with the block words of an autoregressive mask (ops.block_words) against
+    the dense products of the masked weights: forward, backward-x and the weight gradient bit for bit (a skipped block only ever
+    added exact zeros); with a device row count the padding tiles are skipped as in the dense entry."""
+    from gcn_vae_amd import ops
+    gen = torch.Generator().manual_seed(out_f + in_f)
+    deg_out, deg_in = torch.arange(out_f) % max(in_f - 1, 1), torch.arange(in_f) % max(in_f - 1, 1)
+    mask = (deg_out[:, None] >= deg_in[None, :]).float().cuda()
+    w = (torch.randn(out_f, in_f, generator=gen).cuda() * mask).contiguous()
+    x = torch.randn(rows, in_f, generator=gen).cuda()
+    g = torch.randn(rows, out_f, generator=gen).cuda()
+    bias = torch.randn(out_f, generator=gen).cuda()
+    fwd, bwd, tiles = (ops.block_words(mask, k) for k in ('fwd', 'bwd', 'tiles'))
+    zero_share = 1.0 - float(sum(bin(int(v) & (2 ** 64 - 1)).count('1') for v in fwd.tolist())) / (fwd.numel() * ((in_f + 15) // 16))
+    assert zero_share > 0.2 or out_f < 128
+    y0 = ops.gemm(x, w, trans_b=True, bias=bias, act=ops.ACT_RELU)
+    y1 = ops.gemm(x, w, trans_b=True, bias=bias, act=ops.ACT_RELU, b_k_chunks=fwd)
+    assert torch.equal(y0, y1) and float(y0.abs().max()) > 0
+    gx0 = ops.gemm(g, w, a_relu_mask=y0)
+    gx1 = ops.gemm(g, w, a_relu_mask=y0, b_k_chunks=bwd)
+    assert torch.equal(gx0, gx1)
+    acc0, acc1 = gx0.clone(), gx0.clone()
+    ops.gemm(g, w, out=acc0, accumulate=True)
+    ops.gemm(g, w, out=acc1, accumulate=True, b_k_chunks=bwd)
+    assert torch.equal(acc0, acc1)
+    for split in (1, 4):
+        gw0 = ops.gemm(g, x, trans_a=True, split_k=split) * mask
+        gw1 = ops.gemm(g, x, trans_a=True, split_k=split, c_tiles=tiles)
+        assert torch.equal(gw0, gw1 * mask)
+        assert bool((gw1[mask == 0].abs() < 3.4e38).all())                  # unwanted tiles hold zeros, not garbage
+        t = mask.new_zeros(((out_f + 63) // 64) * 64, ((in_f + 63) // 64) * 64)
+        t[:out_f, :in_f] = mask
+        dead = ~(t.reshape(t.shape[0] // 64, 64, t.shape[1] // 64, 64).amax(dim=(1, 3)) > 0)
+        full = dead.repeat_interleave(64, 0).repeat_interleave(64, 1)[:out_f, :in_f]
+        assert float(gw1[full].abs().max() if bool(full.any()) else 0.0) == 0.0
+    live = torch.tensor([rows // 2], dtype=torch.int32, device='cuda')
+    with ops.live_rows(live, rows):
+        a = ops.gemm(x, w, trans_b=True, bias=bias)
+        b = ops.gemm(x, w, trans_b=True, bias=bias, b_k_chunks=fwd)
+    assert torch.equal(a, b)
+
+
+def test_made_node_per_layer_products_skip_the_masks_zero_blocks(monkeypatch):
+    """A MADE too wide for the one-launch chain (per-layer products): with GV_MADE_SPARSE_F32 the products walk only the non-zero blocks
+    of the masked weights -- x, log-det, dL/dz and every parameter gradient equal the dense run bit for bit."""
+    from gcn_vae_amd import made
+    d, h, rows = 72, 136, 333
+    z = torch.randn(rows, d, generator=torch.Generator().manual_seed(9)).cuda()
+    res, calls = [], []
+    inner = made.gemm
+    monkeypatch.setattr(made, 'gemm', lambda *a, **k: (calls.append(k.get('b_k_chunks') is not None or k.get('c_tiles') is not None), inner(*a, **k))[1])
+    for sparse in (False, True):
+        monkeypatch.setattr(made, 'MADE_CHAIN_F32', False)
+        monkeypatch.setattr(made, 'MADE_SPARSE_F32', sparse)
+        monkeypatch.setattr(made, 'MADE_ROW_F32', False)
+        made._sparse_words.clear()
+        m = _made(d, h, 2)
+        zz = z.clone().requires_grad_(True)
+        del calls[:]
+        x, ld = m(zz)
+        (x.sin().sum() + (ld * ld).sum()).backward()
+        torch.cuda.synchronize()
+        assert any(calls) == sparse
+        res.append((x.detach().clone(), ld.detach().clone(), zz.grad.clone(), [p.grad.detach().clone() for p in m.parameters()]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    for a, b in zip(res[0][3], res[1][3]):
+        assert torch.equal(a, b) and float(a.abs().max()) > 0
+
+
 def test_chain_skips_the_workgroups_that_hold_only_padding_rows():
     """ops.live_rows: a chain over a node array of exactly ``cap`` rows stores zeros for the 64-row workgroups past the device row
     count (nothing where it would accumulate) and computes the others in full."""
