@@ -154,8 +154,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmParams p) {
             nt_i = (j + j / ntn) % ntn;
             mt_i = (j / ntn) * 8 + xcd;
             // wanted-tile words (a block-triangular weight gradient): XCD x would hold row-tile x of every column tile, i.e. 1 .. 8 wanted
-            // tiles -- along the anti-diagonals every XCD holds the same number
-            if (p.tmask) mt_i = (j / ntn) * 8 + ((xcd + nt_i) & 7);
+            // tiles, and a CU -- dealt every 32nd slot of its XCD -- the SAME tile of every k-split.  Tiles with (row + column) % 8 = x
+            // go to XCD x (4-5 wanted ones each under a triangular mask), the column rotated with the split so that a CU's blocks differ
+            if (p.tmask) {
+                const int z = blockIdx.z;
+                nt_i = (nt_i + z + (z >> 2)) % ntn;
+                mt_i = (j / ntn) * 8 + ((xcd - nt_i) & 7);
+            }
         }
     }
     const int m0 = mt_i * BM, n0 = nt_i * BN;
