@@ -99,7 +99,7 @@ class GraphedMiniBatchStep:
         m = self.model
         layers = [l for l in m.modules() if hasattr(l, 'num_rels') and hasattr(l, 'num_bases')]
         dev_edges = getattr(b.g, '_dev_edges', None)
-        if not (ops.indices.BATCH_INDEX and ops.indices.NATIVE_INDEX and layers and dev_edges is not None and hasattr(m, 'w_relation')
+        if not (ops.batch_index.BATCH_INDEX and ops.indices.NATIVE_INDEX and layers and dev_edges is not None and hasattr(m, 'w_relation')
                 and hasattr(m, '_tidx_key') and b.edge_type.dtype == torch.int32):
             return False
         num_rels = {int(l.num_rels) for l in layers}

@@ -288,6 +288,8 @@ def _row_major(t, name='matrix'):
 from .indices import *                                           # noqa: E402,F401,F403
 from .indices import _carve_i32, _index_caps, _index_workspace, _rowptr_from_sorted      # noqa: E402,F401
 from . import indices                                            # noqa: E402,F401  (ops.indices.<KNOB>: where that file's knobs live)
+from . import batch_index                                        # noqa: E402,F401
+from .batch_index import build_batch_indices                      # noqa: E402,F401
 
 
 # ------------------------------------------------------------------------------------------------

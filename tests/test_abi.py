@@ -73,7 +73,7 @@ def test_header_is_plain_c_and_struct_layouts_match_the_ctypes_mirrors(tmp_path)
     if shutil.which('gcc') is None:
         pytest.skip('no gcc')
     from gcn_vae_amd import ops
-    fields = {'gv_chain_layer': ops._ChainLayer, 'gv_row_layer': ops._RowLayer, 'gv_csr_job': ops.indices._CsrJob}
+    fields = {'gv_chain_layer': ops._ChainLayer, 'gv_row_layer': ops._RowLayer, 'gv_csr_job': ops.batch_index._CsrJob}
     lines = []
     for name, cls in fields.items():
         lines.append(f'printf("{name} %zu", sizeof({name}));')

@@ -1197,7 +1197,7 @@ def test_batched_index_build_equals_the_builders_one_by_one(ops, monkeypatch, n,
 def test_gv_build_csr_batch_reports_bad_arguments(ops):
     from gcn_vae_amd import lib
     import ctypes
-    jobs = (ops.indices._CsrJob * 9)()
+    jobs = (ops.batch_index._CsrJob * 9)()
     assert lib.load().gv_build_csr_batch(ctypes.addressof(jobs), 9, None, 0, None) != 0          # more orderings than a batch holds
     assert lib.load().gv_build_csr_batch(ctypes.addressof(jobs), 0, None, 0, None) == 0
     jobs[0].n, jobs[0].n_seg, jobs[0].chunk = 5, 3, 16
