@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 evidence on one MI355X for ONE configuration: bench line, in-step kernel trace, SERIALISED kernel trace (side streams
 # off: every kernel alone -- the "alone" fractions of DESIGN.md), PMC traffic (FETCH / WRITE, separate passes) and L2 hit rates.
-#   GV_HEAD=<commit> tools/collect_round5.sh <config> [bench flags for the bench line]
+#   GV_HEAD=<commit> [SKIP_PMC=1] tools/collect_round5.sh <config> [bench flags for the bench line]
 set -e -o pipefail
 c=$1; shift
 out=$PWD/gpurun_out/r5
@@ -23,6 +23,7 @@ for mode in instep serial; do
   if [ $mode = instep ]; then head -40 "$(find /tmp/pp -name '*kernel_stats.csv' | head -1)" > "$out/kernel_stats_top_$c.csv"; fi
   unset GV_BWD_SIDE GV_RGCN_BWD_SIDE GV_MADE_PREPARE
 done
+if [ "${SKIP_PMC:-0}" = 1 ]; then echo "== done (no counter passes: SKIP_PMC=1)"; rm -rf /tmp/pp; exit 0; fi
 for ctr in FETCH_SIZE WRITE_SIZE; do
   echo "== $c: pmc $ctr"; date +%T
   rm -rf /tmp/pp_$ctr
