@@ -38,6 +38,7 @@ struct GemmParams {
     // other tiles are stored as zeros (nothing when accumulating) without reading A or B
     const unsigned long long* tmask;
     int tmask_ld;
+    int tmask_wanted;      // > 0 (split-K only): the launch holds ONE block row per wanted tile -- block x is the x-th set bit of tmask
 };
 
 // guarded load of VPT consecutive floats (VPT % 4 == 0) along the contiguous dimension; `lim` bounds that
@@ -143,7 +144,20 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmParams p) {
     // the SAME XCD, so that a tall A (configs[4]: 800 MB, far beyond the Infinity Cache) crosses the fabric once instead of once
     // per n-tile.  (Whole groups of 8 m-tiles only; the ragged end keeps the plain order.)
     int mt_i = blockIdx.y, nt_i = blockIdx.x;
-    {
+    if (p.tmask_wanted > 0) {
+        // the x-th wanted 64 x 64 tile (MT = NT = 1): no block exists for the others -- with one block per tile, wanted or not, the CUs
+        // that were dealt 4 wanted blocks set the launch's time whatever the others hold (2-4 per CU under a triangular mask)
+        int rank = blockIdx.x, bit = -1;
+        for (int w = 0; bit < 0; ++w) {
+            unsigned long long word = p.tmask[w];
+            const int pc = __popcll(word);
+            if (rank >= pc) { rank -= pc; continue; }
+            for (int i = 0; i < rank; ++i) word &= word - 1;
+            bit = 64 * w + __builtin_ctzll(word);
+        }
+        mt_i = bit / p.tmask_ld;
+        nt_i = bit - mt_i * p.tmask_ld;
+    } else {
         const int ntn = gridDim.x, lin = blockIdx.y * ntn + blockIdx.x;
         const int full = (gridDim.y / 8) * 8 * ntn;
         if (lin < full) {
@@ -610,6 +624,10 @@ __global__ __launch_bounds__(256) void k_gemm_splitk_reduce(const GemmParams p) 
         for (; z < p.split_k; ++z) a0 += p.ws[(size_t)z * total + i];
         float v = (a0 + a1) + (a2 + a3);
         const int row = (int)(i / p.n), col = (int)(i - (size_t)row * p.n);
+        if (p.tmask_wanted > 0) {      // no block wrote the partial tiles of an unwanted tile
+            const int bit = (row >> 6) * p.tmask_ld + (col >> 6);
+            if (!((p.tmask[bit >> 6] >> (bit & 63)) & 1ull)) v = 0.f;
+        }
         if (p.bias) v += p.bias[col];
         v = apply_act(v, p.act);
         float* dst = p.c + (size_t)row * p.ldc + col;
@@ -690,7 +708,7 @@ extern "C" int64_t gv_gemm_workspace_bytes(int m, int n, int k, int split_k) {
 static int gemm_any(bool bf16, int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b,
                     int ldb, float* c, int ldc, const float* bias, int act, int accumulate, int split_k,
                     const float* a_relu_mask, void* workspace, int64_t workspace_bytes, void* stream, const int32_t* rows_dev = nullptr,
-                    const uint64_t* kmask = nullptr, const uint64_t* tmask = nullptr) {
+                    const uint64_t* kmask = nullptr, const uint64_t* tmask = nullptr, int tiles_wanted = 0) {
     GV_REQUIRE(m >= 0 && n >= 0 && k >= 0, GV_ERR_SHAPE, "gv_gemm_f32: negative size");
     if (m == 0 || n == 0) return GV_OK;
     GV_REQUIRE(a && b && c, GV_ERR_NULL, "gv_gemm_f32: NULL matrix");
@@ -715,6 +733,9 @@ static int gemm_any(bool bf16, int trans_a, int trans_b, int m, int n, int k, co
     p.kmask = (const unsigned long long*)kmask;
     p.tmask = (const unsigned long long*)tmask;
     p.tmask_ld = (n + 63) / 64;
+    GV_REQUIRE(tiles_wanted >= 0 && tiles_wanted <= ((m + 63) / 64) * ((n + 63) / 64), GV_ERR_SHAPE, "gv_gemm_f32_sparse: c_tiles_wanted=%d", tiles_wanted);
+    // one block row per WANTED tile (and nothing for the others) where the partial tiles go through the split-K sum, which knows the words too
+    p.tmask_wanted = (tmask && tiles_wanted > 0 && split_k > 1) ? tiles_wanted : 0;
     if (split_k > 1) {
         GV_REQUIRE(workspace, GV_ERR_NULL, "gv_gemm_f32: split_k needs a workspace");
         GV_REQUIRE(workspace_bytes >= gv_gemm_workspace_bytes(m, n, k, split_k), GV_ERR_WORKSPACE,
@@ -744,15 +765,16 @@ static int gemm_any(bool bf16, int trans_a, int trans_b, int m, int n, int k, co
     static const int mt_env = getenv("GV_GEMM_MT") ? atoi(getenv("GV_GEMM_MT")) : 0;   // tuning knobs
     static const int nt_env = getenv("GV_GEMM_NT") ? atoi(getenv("GV_GEMM_NT")) : 0;
     static const int bk_env = getenv("GV_GEMM_BK") ? atoi(getenv("GV_GEMM_BK")) : 0;
-    const int nt = (nt_env == 2 && !kmask) ? 2 : 1;        // 128-column tiles measured 8-12 % slower on every C2 shape: opt-in only
+    const int nt = (nt_env == 2 && !kmask && !(tmask && tiles_wanted > 0 && split_k > 1)) ? 2 : 1;        // 128-column tiles measured 8-12 % slower on every C2 shape: opt-in only
     const int bn = 64 * nt;
     const long blocks128 = (long)((n + bn - 1) / bn) * ((m + 127) / 128) * split_k;
-    const int mt = mt_env ? mt_env : (blocks128 >= 1024 ? 2 : 1);
+    const int mt = p.tmask_wanted ? 1 : (mt_env ? mt_env : (blocks128 >= 1024 ? 2 : 1));
     // with k-chunk words: 16-deep steps = exactly the marked chunks (GV_GEMM_SPARSE_BK=32: 32-deep steps walked when either half is
     // marked -- measured the same, 66 us on the 500 x 500 MADE layer against 92 dense)
     static const int sparse_bk = getenv("GV_GEMM_SPARSE_BK") ? atoi(getenv("GV_GEMM_SPARSE_BK")) : 16;
     const int bk = kmask ? (sparse_bk == 32 ? 32 : 16) : (bk_env ? (bk_env == 16 ? 16 : 32) : (trans_a ? 32 : 16));
     dim3 grid((n + bn - 1) / bn, (m + 64 * mt - 1) / (64 * mt), split_k), block(256);
+    if (p.tmask_wanted) { grid.x = p.tmask_wanted; grid.y = 1; }
 #define GV_GEMM_CFG(TA_, TB_, MT_, NT_, BK_) \
     if (mt == MT_ && nt == NT_ && bk == BK_) hipLaunchKernelGGL((k_gemm_f32<TA_, TB_, MT_, NT_, BK_>), grid, block, 0, st, p);
 #define GV_GEMM_LAUNCH(TA_, TB_)                                                                       \
@@ -796,9 +818,9 @@ extern "C" int gv_gemm_f32_live_rows(int trans_a, int trans_b, int m, int n, int
 extern "C" int gv_gemm_f32_sparse(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b, int ldb,
                                   float* c, int ldc, const float* bias, int act, int accumulate, int split_k, const float* a_relu_mask,
                                   void* workspace, int64_t workspace_bytes, const int32_t* rows_dev, const uint64_t* b_k_chunks,
-                                  const uint64_t* c_tiles, void* stream) {
+                                  const uint64_t* c_tiles, int c_tiles_wanted, void* stream) {
     return gemm_any(false, trans_a, trans_b, m, n, k, a, lda, b, ldb, c, ldc, bias, act, accumulate, split_k, a_relu_mask,
-                    workspace, workspace_bytes, stream, rows_dev, b_k_chunks, c_tiles);
+                    workspace, workspace_bytes, stream, rows_dev, b_k_chunks, c_tiles, c_tiles_wanted);
 }
 
 extern "C" int gv_gemm_bf16(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b,
@@ -821,7 +843,7 @@ extern "C" int gv_rank_scores(const float* q, int ld_q, const float* e, int ld_e
     p.act = GV_ACT_NONE; p.accumulate = 0; p.split_k = 1; p.k_chunk = h;
     p.vec_a = aligned16(q) && (ld_q % 4 == 0);
     p.vec_b = aligned16(e) && (ld_e % 4 == 0);
-    p.rows_dev = nullptr; p.kmask = nullptr; p.tmask = nullptr; p.tmask_ld = 0;
+    p.rows_dev = nullptr; p.kmask = nullptr; p.tmask = nullptr; p.tmask_ld = 0; p.tmask_wanted = 0;
     rp.target = target; rp.bias = bias; rp.tgt = tgt; rp.count = count;
     hipStream_t st = (hipStream_t)stream;
     if (fill_words(count, 0u, (size_t)m * sizeof(int), st) != hipSuccess) return launch_status("gv_rank_scores(fill)");

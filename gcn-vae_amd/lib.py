@@ -58,7 +58,7 @@ SIGNATURES = {
     'gv_gemm_workspace_bytes': (_L, [_I, _I, _I, _I]),
     'gv_gemm_f32': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P]),
     'gv_gemm_f32_live_rows': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P, _P]),
-    'gv_gemm_f32_sparse': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P]),
+    'gv_gemm_f32_sparse': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P, _I, _P]),
     'gv_gemm_bf16': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P]),
     'gv_gemm_bf16_nt_workspace_bytes': (_L, [_I, _I, _I]),
     'gv_gemm_bf16_gradw_fits': (_I, [_I, _I, _I, _I]),

@@ -337,9 +337,9 @@ class _MADEForward(torch.autograd.Function):
                     gw = gemm(rows0[l], inp0, trans_a=True, a_relu_mask=mask0)           # pass 0: outer product of two rows
                     if S > 0:
                         inp = xin if l == 0 else acts[l - 1]
+                        tiles = None if (words is None or ctx.masks is None) else words[l]['tiles']
                         part = gemm(grads[l], inp, trans_a=True, a_relu_mask=mask,
-                                    split_k=pick_split_k(ws[l].shape[0], ws[l].shape[1], S * n),
-                                    c_tiles=None if (words is None or ctx.masks is None) else words[l]['tiles'])
+                                    split_k=pick_split_k(ws[l].shape[0], ws[l].shape[1], S * n), c_tiles=tiles)
                         lib.call('gv_axpby', gw.numel(), None, 1.0, ptr(part), 1.0, ptr(gw), lib.stream())
                 if wants_b[l]:      # (a bias with a slice of the arena: ADDED there, whatever the slice holds)
                     gb = colsum(rows0[l], relu_mask=mask0, out=tgt_b[l], accumulate=tgt_b[l] is not None)

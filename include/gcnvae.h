@@ -541,13 +541,14 @@ int gv_gemm_f32_live_rows(int trans_a, int trans_b, int m, int n, int k, const f
  *   b_k_chunks (optional): one 64-bit word per 64-column tile of C; bit c set = op(B)[16 c .. 16 c + 15][that tile's columns] holds
  *     non-zero entries.  Chunks with a clear bit are neither loaded nor multiplied (k <= 1024, split_k == 1);
  *   c_tiles (optional): bit (i * ceil(n / 64) + j) of the word array set = the 64 x 64 tile (i, j) of C is wanted; other tiles are
- *     stored as act(bias) (zeros for the weight-gradient products this is for) without reading A or B.
+ *     stored as act(bias) (zeros for the weight-gradient products this is for) without reading A or B.  c_tiles_wanted = the number
+ *     of set bits if the caller knows it (0: unknown): with split_k > 1 the launch then holds blocks for the wanted tiles only.
  * Equal to the dense product wherever the skipped blocks are zero and the other operand is finite there (0 * inf is never formed:
  * the same statement as for gv_made_chain_f32's mask walk). */
 int gv_gemm_f32_sparse(int trans_a, int trans_b, int m, int n, int k, const float* a, int lda, const float* b, int ldb, float* c,
                        int ldc, const float* bias, int act, int accumulate, int split_k, const float* a_relu_mask, void* workspace,
                        int64_t workspace_bytes, const int32_t* rows_dev /* optional */, const uint64_t* b_k_chunks,
-                       const uint64_t* c_tiles, void* stream);
+                       const uint64_t* c_tiles, int c_tiles_wanted, void* stream);
 /* The same product with bf16 OPERANDS and fp32 accumulation (BASELINE configs[2]: "bf16"): A and B are fp32 in memory,
  * rounded to bf16 (round-to-nearest-even) as they are staged, multiplied on v_mfma_f32_32x32x16_bf16; bias, act,
  * accumulate, split-K and the result stay fp32.  Equals an fp32 GEMM of the rounded operands up to summation order. */
