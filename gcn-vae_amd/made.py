@@ -58,7 +58,7 @@ def _mask_words(masks):
     never under capture -- a step captured before any eager use runs dense)."""
     if masks is None or not MADE_SPARSE_F32:
         return None
-    key = tuple((m.data_ptr(), tuple(m.shape)) for m in masks)
+    key = tuple((m.data_ptr(), tuple(m.shape), m._version) for m in masks)
     hit = _sparse_words.get(key)
     if hit is None:
         if _capturing():
