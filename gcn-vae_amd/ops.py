@@ -294,6 +294,13 @@ from .batch_index import build_batch_indices                      # noqa: E402,F
 
 # ------------------------------------------------------------------------------------------------
 # raw ops
+def _k1_items(gidx, seg):
+    """The work-item list a single-GPU K1 launch over a static graph walks: long items first where that is switched on."""
+    if indices.K1_ITEMS_LARGEST_FIRST and not gidx.sync_free:
+        return indices.largest_first(seg)
+    return seg
+
+
 def pack_supported(num_bases, blk_in, blk_out, transpose_w=False):
     return bool(lib.load().gv_rgcn_bdd_pack_supported(num_bases, blk_in, blk_out, 1 if transpose_w else 0))
 
@@ -929,10 +936,10 @@ class _RelGraphConvBdd(torch.autograd.Function):
                                 keep_scale, packed=pk)
         elif reduce_hook is None and K1_REL_RUNS and not gidx.sync_free:
             nbr_r, et_r, eid_r, coef_r = ridx.rel_sorted(gidx, 'dst', coef)      # rows sorted by relation: weight reuse along runs
-            out = bdd_aggregate(gidx.by_dst.seg, nbr_r, et_r, coef_r, None, x, w_fwd,
+            out = bdd_aggregate(_k1_items(gidx, gidx.by_dst.seg), nbr_r, et_r, coef_r, None, x, w_fwd,
                                 num_bases, si, so, False, self_loop_term(), act, keep, keep_scale, packed=pk)
         elif reduce_hook is None:
-            out = bdd_aggregate(gidx.by_dst.seg, gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x, w_fwd,
+            out = bdd_aggregate(_k1_items(gidx, gidx.by_dst.seg), gidx.nbr_by_dst, ridx.et_by_dst, coef, gidx.by_dst.perm, x, w_fwd,
                                 num_bases, si, so, False, self_loop_term(), act, keep, keep_scale, packed=pk)
         else:
             # edge-sharded: aggregate the destination rows in DIST_FWD_CHUNKS blocks; the all-reduce of block c runs
@@ -1045,11 +1052,11 @@ class _RelGraphConvBdd(torch.autograd.Function):
                 grad_x = bdd_aggregate(seg, nbr, ety, coef_g, None, g_agg, w_bwd, nb, so, si, True, gx_loop, out=x_tgt, packed=pk)
             elif K1_REL_RUNS and not gidx.sync_free and reduce_hook is None:
                 nbr_r, et_r, eid_r, coef_r = ridx.rel_sorted(gidx, 'src', coef)
-                grad_x = bdd_aggregate(gidx.by_src.seg, nbr_r, et_r, coef_r, None, g_agg,
+                grad_x = bdd_aggregate(_k1_items(gidx, gidx.by_src.seg), nbr_r, et_r, coef_r, None, g_agg,
                                        w_bwd, nb, so, si, True, gx_loop, out=x_tgt, packed=pk)
             else:
                 coef_s, idx_s = (gidx.coef_in_src_order(coef), None) if static else (coef, gidx.by_src.perm)
-                grad_x = bdd_aggregate(gidx.by_src.seg, gidx.nbr_by_src, ridx.et_by_src, coef_s, idx_s, g_agg,
+                grad_x = bdd_aggregate(_k1_items(gidx, gidx.by_src.seg), gidx.nbr_by_src, ridx.et_by_src, coef_s, idx_s, g_agg,
                                        w_bwd, nb, so, si, True, gx_loop, out=x_tgt, packed=pk)
         if grad_x is not None and x_tgt is not None:
             grad_x = None                                  # written in place
@@ -2139,8 +2146,8 @@ class _LossHead(torch.autograd.Function):
                         accumulate=d_w is not None)
         lib.call('gv_axpby', w_rel.numel(), ptr(g), 2.0 * reg_w / w_rel.numel(), ptr(w_rel), 1.0, ptr(g_w), st)
         join(1)
-        g_z = bdd_aggregate(tidx.inc, tidx.inc_other, tidx.inc_rel, d_inc, idx_inc, z, w_rel, h, 1, 1,
-                            addend=gz)
+        g_z = bdd_aggregate(indices.largest_first(tidx.inc) if indices.K1_ITEMS_LARGEST_FIRST else tidx.inc, tidx.inc_other, tidx.inc_rel,
+                            d_inc, idx_inc, z, w_rel, h, 1, 1, addend=gz)
         if link is not None and mmd_w > 0:       # no KL buffer to ride on: the MMD rows are added to the decoder's gradient
             lib.call('gv_mmd_bwd', ptr(z_pri), ptr(z), ptr(pick), z_pri.shape[0], pick.numel(), h, ptr(g), mmd_w,
                      ptr(g_pri), ptr(g_z), st)

@@ -1083,6 +1083,32 @@ def test_rank_scores_full_fb15k237_eval_properties(ops):
 
 
 # ------------------------------------------------------------------------------------------------
+def test_work_items_longest_first_is_a_permutation_with_the_same_results(ops):
+    """indices.largest_first: the same items in another order (long ones first, a per-batch -1-padded list untouched); an aggregation
+    over the reordered list equals the one over the built list bit for bit."""
+    rs = np.random.RandomState(3)
+    n, e, r = 3000, 90000, 12
+    p = (np.arange(n) + 1.0) ** -1.1
+    dst = np.sort(rs.choice(n, size=e, p=p / p.sum()))
+    src, et = rs.randint(0, n, size=e), rs.randint(0, r, size=e)
+    g = ops.GraphIndex(torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda(), n, chunk=64, dst_sorted=True)
+    ridx = ops.RelationIndex(g, torch.from_numpy(et).cuda(), r)
+    seg = g.by_dst.seg
+    lf = ops.indices.largest_first(seg)
+    assert lf is not seg and ops.indices.largest_first(seg) is lf and ops.indices.largest_first(lf) is lf
+    a, b = seg.items[:seg.n_items].cpu().numpy(), lf.items[:lf.n_items].cpu().numpy()
+    assert sorted(map(tuple, a)) == sorted(map(tuple, b))
+    size = b[:, 2] - b[:, 1]
+    assert (size[:-1] >= size[1:]).all() and size[0] == 64 and size[-1] <= 1
+    x = torch.randn(n, 8, generator=torch.Generator().manual_seed(0)).cuda()
+    w = torch.randn(r, 4 * 2 * 2, generator=torch.Generator().manual_seed(1)).cuda()
+    out0 = ops.bdd_aggregate(seg, g.nbr_by_dst, ridx.et_by_dst, None, None, x, w, 4, 2, 2)
+    out1 = ops.bdd_aggregate(lf, g.nbr_by_dst, ridx.et_by_dst, None, None, x, w, 4, 2, 2)
+    assert torch.equal(out0, out1) and float(out0.abs().max()) > 0
+    gb = ops.GraphIndex(torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda(), n, dst_sorted=True, sync_free=True)
+    assert ops.indices.largest_first(gb.by_dst.seg) is gb.by_dst.seg          # upper-bound-sized, -1 padded: as built
+
+
 # SURVEY 8(f-1) / 8(b) gv_build_csr: native, synchronisation-free index construction == the torch formulation
 def _same_items(a, b):
     return (a.n_items == b.n_items and a.n_fix == b.n_fix and a.n_slots == b.n_slots and a.chunk == b.chunk
