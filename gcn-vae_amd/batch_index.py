@@ -81,19 +81,19 @@ def build_batch_indices(src, dst, etypes, num_nodes, num_rels, triplets=None, nu
     g.num_nodes, g.num_edges, g.num_src_nodes, g.device, g.sync_free = nd, E, ns, dev, True
     g._rel_cache, g._chunk_cache, g._lds_seg_cache = {}, {}, {}
     g.src32, g.dst32, g.nbr_by_dst, g.nbr_by_src = src32, dst32, nbr_d, nbr_s
-    g.by_dst = EdgeOrder(None if dst_sorted else perm_d, SegmentItems(it_d.view(-1, 4), fx_d.view(-1, 4), ci_d, cf_d, slots_d, rp_d, chunk))
-    g.by_src = EdgeOrder(perm_s, SegmentItems(it_s.view(-1, 4), fx_s.view(-1, 4), ci_s, cf_s, slots_s, rp_s, chunk))
+    g.by_dst = EdgeOrder(None if dst_sorted else perm_d, SegmentItems(it_d.view(-1, 4), fx_d.view(-1, 4), ci_d, cf_d, slots_d, rp_d, chunk, exact=False))
+    g.by_src = EdgeOrder(perm_s, SegmentItems(it_s.view(-1, 4), fx_s.view(-1, 4), ci_s, cf_s, slots_s, rp_s, chunk, exact=False))
     g._batch_keepalive = (keep, ws)
     r = RelationIndex.__new__(RelationIndex)
     r.num_rels, r.keepalive, r._rel_sorted = int(num_rels), etypes, {}
     r.et_by_dst, r.et_by_src, r.src_by_rel, r.dst_by_rel = et_d, et_s, src_r, dst_r
-    r.by_rel = EdgeOrder(perm_r, SegmentItems(it_r.view(-1, 4), fx_r.view(-1, 4), ci_r, cf_r, slots_r, rp_r, chunk_r))
+    r.by_rel = EdgeOrder(perm_r, SegmentItems(it_r.view(-1, 4), fx_r.view(-1, 4), ci_r, cf_r, slots_r, rp_r, chunk_r, exact=False))
     g._rel_cache[(etypes.data_ptr(), etypes._version, int(num_rels))] = r
     if triplets is not None:
         tidx = TripletIndex.__new__(TripletIndex)
         tidx.T, tidx.num_entities, tidx.num_rels, tidx.trip32 = T, ne, nr, trip32
         tidx.inc_other, tidx.inc_rel, tidx.inc_tid, tidx.rel_s, tidx.rel_o, tidx.rel_tid = inc_other, inc_rel, inc_tid, rel_s, rel_o, rel_tid
-        tidx.inc = SegmentItems(it_i.view(-1, 4), fx_i.view(-1, 4), ci_i, cf_i, slots_i, rp_i, chunk_t)
-        tidx.rel = SegmentItems(it_q.view(-1, 4), fx_q.view(-1, 4), ci_q, cf_q, slots_q, rp_q, chunk_tr)
+        tidx.inc = SegmentItems(it_i.view(-1, 4), fx_i.view(-1, 4), ci_i, cf_i, slots_i, rp_i, chunk_t, exact=False)
+        tidx.rel = SegmentItems(it_q.view(-1, 4), fx_q.view(-1, 4), ci_q, cf_q, slots_q, rp_q, chunk_tr, exact=False)
         tidx.fwd_order = tidx.pos3 = None
     return g, r, tidx

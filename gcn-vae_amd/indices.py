@@ -32,6 +32,7 @@ class SegmentItems:
     n_slots: int
     rowptr: torch.Tensor     # int32 [n_seg + 1]
     chunk: int
+    exact: bool = True       # False: sized by upper bounds and -1 padded (the synchronisation-free builders of per-batch indices)
 
 
 def build_segment_items(rowptr: torch.Tensor, chunk: int, n_edges: Optional[int] = None) -> SegmentItems:
@@ -60,7 +61,7 @@ def build_segment_items(rowptr: torch.Tensor, chunk: int, n_edges: Optional[int]
         fix = torch.full((max(n_fix, 1), 4), -1, dtype=torch.int32, device=dev)
     lib.call('gv_segment_items_fill', ptr(rowptr), n_seg, chunk, ptr(offs[0]), ptr(offs[1]), ptr(offs[2]),
              ptr(items), ptr(fix), lib.stream())
-    return SegmentItems(items, fix, n_items, n_fix, n_slot_total, rowptr, chunk)
+    return SegmentItems(items, fix, n_items, n_fix, n_slot_total, rowptr, chunk, exact=n_edges is None)
 
 
 # Work items of a static graph's K1 launches in order of their length (longest first).  A workgroup is four waves = four consecutive
@@ -80,7 +81,7 @@ def largest_first(seg: SegmentItems) -> SegmentItems:
     if hit is not None:
         return hit
     n = seg.n_items
-    if n < 1024 or bool((seg.items[:n, 0] < 0).any()):
+    if n < 1024 or not seg.exact:
         seg._largest_first = seg
         return seg
     it = seg.items[:n]
@@ -193,8 +194,8 @@ class GraphIndex:
                  ptr(nbr_s), ptr(rp_s), ptr(it_s), ci_s, ptr(fx_s), cf_s, ptr(ws), ws_bytes, lib.stream())
         self.nbr_by_dst, self.nbr_by_src = nbr_d, nbr_s
         self.by_dst = EdgeOrder(None if dst_sorted else perm_d,
-                                SegmentItems(it_d.view(-1, 4), fx_d.view(-1, 4), ci_d, cf_d, slots_d, rp_d, chunk))
-        self.by_src = EdgeOrder(perm_s, SegmentItems(it_s.view(-1, 4), fx_s.view(-1, 4), ci_s, cf_s, slots_s, rp_s, chunk))
+                                SegmentItems(it_d.view(-1, 4), fx_d.view(-1, 4), ci_d, cf_d, slots_d, rp_d, chunk, exact=False))
+        self.by_src = EdgeOrder(perm_s, SegmentItems(it_s.view(-1, 4), fx_s.view(-1, 4), ci_s, cf_s, slots_s, rp_s, chunk, exact=False))
 
     def lds_order(self, side: str, max_edges: int) -> 'LdsOrder':
         """Super-items of one ordering for the LDS-resident K1 kernel (csrc/k_lds.hip); built once per graph, cached."""
@@ -345,7 +346,7 @@ class RelationIndex:
             lib.call('gv_relation_index_build', ptr(g.src32), ptr(g.dst32), ptr(et32), ptr(g.by_dst.perm), ptr(g.by_src.perm),
                      E, self.num_rels, chunk, ptr(self.et_by_dst), ptr(self.et_by_src), ptr(perm_r), ptr(self.src_by_rel),
                      ptr(self.dst_by_rel), ptr(rp), ptr(it), ci, ptr(fx), cf, ptr(ws), ws_bytes, lib.stream())
-            self.by_rel = EdgeOrder(perm_r, SegmentItems(it.view(-1, 4), fx.view(-1, 4), ci, cf, slots, rp, chunk))
+            self.by_rel = EdgeOrder(perm_r, SegmentItems(it.view(-1, 4), fx.view(-1, 4), ci, cf, slots, rp, chunk, exact=False))
             return
         self.et_by_dst = (et if g.by_dst.perm is None else et[g.by_dst.perm.long()]).to(torch.int32).contiguous()
         self.et_by_src = et[g.by_src.perm.long()].to(torch.int32).contiguous()
@@ -897,8 +898,8 @@ class TripletIndex:
                      ptr(self.inc_rel), ptr(self.inc_tid), ptr(rp_i), ptr(it_i), ci_i, ptr(fx_i), cf_i, ptr(self.rel_s),
                      ptr(self.rel_o), ptr(self.rel_tid), ptr(rp_r), ptr(it_r), ci_r, ptr(fx_r), cf_r, ptr(ws), ws_bytes,
                      lib.stream())
-            self.inc = SegmentItems(it_i.view(-1, 4), fx_i.view(-1, 4), ci_i, cf_i, slots_i, rp_i, chunk)
-            self.rel = SegmentItems(it_r.view(-1, 4), fx_r.view(-1, 4), ci_r, cf_r, slots_r, rp_r, chunk_rel)
+            self.inc = SegmentItems(it_i.view(-1, 4), fx_i.view(-1, 4), ci_i, cf_i, slots_i, rp_i, chunk, exact=False)
+            self.rel = SegmentItems(it_r.view(-1, 4), fx_r.view(-1, 4), ci_r, cf_r, slots_r, rp_r, chunk_rel, exact=False)
             self.fwd_order = self.pos3 = None
             return
         t = t.to(torch.int64)
