@@ -1083,6 +1083,33 @@ def test_rank_scores_full_fb15k237_eval_properties(ops):
 
 
 # ------------------------------------------------------------------------------------------------
+def test_phase_lists_with_waves_chosen_per_item_give_the_same_rows(ops, monkeypatch):
+    """PhaseOrder.build: the greedy choice of an item's wave inside its tile (GV_PHASE_GREEDY) against the snake deal -- the same tiles,
+    other (wave, slot) places, shorter per-phase maxima, and an aggregation that is bit-identical (a row keeps its summation order)."""
+    rs = np.random.RandomState(11)
+    n, e, r = 5000, 200000, 60
+    p = (np.arange(n) + 1.0) ** -1.1
+    dst = np.sort(rs.choice(n, size=e, p=p / p.sum()))
+    src, et = rs.randint(0, n, size=e), rs.randint(0, r, size=e)
+    g = ops.GraphIndex(torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda(), n, dst_sorted=True)
+    ridx = ops.RelationIndex(g, torch.from_numpy(et).cuda(), r)
+    nb, si, so = 100, 5, 5
+    x = torch.randn(n, nb * si, generator=torch.Generator().manual_seed(0)).cuda()
+    w = torch.randn(r, nb * si * so, generator=torch.Generator().manual_seed(1)).cuda()
+    outs, longest = [], []
+    for greedy in (False, True):
+        monkeypatch.setattr(ops.indices, 'PHASE_GREEDY', greedy)
+        ph = ops.indices.PhaseOrder.build(ridx, g, 'dst', nb, si, so)
+        assert ph is not None
+        nw = ph.threads // 64
+        lens = (ph.off[1:] - ph.off[:-1]).view(ph.n_tiles, nw, ph.n_phases)
+        assert int(lens.sum()) == e
+        longest.append(int(lens.max(1).values.sum()))
+        outs.append(ops.bdd_aggregate_phases(ph, None, x, ops.pack_weight_phase(ph, w, nb, si, so), r, nb, si, so))
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().max()) > 0
+    assert longest[1] < 0.95 * longest[0], longest
+
+
 def test_work_items_longest_first_is_a_permutation_with_the_same_results(ops):
     """indices.largest_first: the same items in another order (long ones first, a per-batch -1-padded list untouched); an aggregation
     over the reordered list equals the one over the built list bit for bit."""
