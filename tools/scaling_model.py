@@ -72,9 +72,9 @@ STRONG = {
     # itself -- a rank then touches R/p relation types, so the phase kernels stage 1/p of the table per tile (FB15k-237 at h = 500:
     # 4 phases instead of 32 -> the measured no-barrier / no-staging bound, profiles/round5/phase_ablation.txt; 1 M nodes: the
     # 1.3x weight re-fetch traffic goes) -- applied to the K1 share only
-    'c2 (FB15k-237, h=200)': dict(N=14541, h=200, other_mb=2.9, t1_ms=1.02, node_share=0.45, k1_rel_gain=1.0),
-    'c4 (FB15k-237, h=500)': dict(N=14541, h=500, other_mb=14.6, t1_ms=3.09, node_share=0.38, k1_rel_gain=1.35),
-    'c5 (1 M entities, 50 M edges, h=200)': dict(N=1_000_000, h=200, other_mb=3.0, t1_ms=76.6, node_share=0.22, k1_rel_gain=1.15),
+    'c2 (FB15k-237, h=200)': dict(N=14541, h=200, other_mb=2.9, t1_ms=1.005, node_share=0.45, k1_rel_gain=1.0),
+    'c4 (FB15k-237, h=500)': dict(N=14541, h=500, other_mb=14.6, t1_ms=3.00, node_share=0.38, k1_rel_gain=1.35),
+    'c5 (1 M entities, 50 M edges, h=200)': dict(N=1_000_000, h=200, other_mb=3.0, t1_ms=74.9, node_share=0.22, k1_rel_gain=1.15),
 }
 
 
