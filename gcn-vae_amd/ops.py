@@ -294,6 +294,20 @@ from .batch_index import build_batch_indices                      # noqa: E402,F
 
 # ------------------------------------------------------------------------------------------------
 # raw ops
+RGCN_SIDE_GRADW_FIRST = _os.environ.get('GV_RGCN_SIDE_GRADW_FIRST', 'auto')
+
+
+def rgcn_side_gradw_first(num_edges, width):
+    """Order of the layer's two weight gradients on the backward side stream.  The main stream runs the self-loop's dL/dx product
+    (MFMA-bound) and then the K1^T aggregation (cache-bandwidth-bound); with the relation-weight gradient (cache-bandwidth-bound)
+    FIRST on the side stream and the self-loop's weight-gradient product (MFMA-bound) behind it, the launches that run beside each
+    other want different things.  Measured: FB15k-237 size, h = 200: 1.005 -> 0.986 ms; h = 500: 2.993 -> 2.999; 1 M nodes / 50 M
+    edges: 75.0 -> 75.2; WN18RR + 3 IAF: the same.  'auto': cache-resident graphs at input widths up to 256; '0' / '1' force."""
+    if RGCN_SIDE_GRADW_FIRST in ('0', '1'):
+        return RGCN_SIDE_GRADW_FIRST == '1'
+    return num_edges <= 4_000_000 and width <= 256
+
+
 def _k1_items(gidx, seg):
     """The work-item list a single-GPU K1 launch over a static graph walks: long items first where that is switched on."""
     if indices.K1_ITEMS_LARGEST_FIRST and not gidx.sync_free:
@@ -991,10 +1005,14 @@ class _RelGraphConvBdd(torch.autograd.Function):
             and ctx.needs_input_grad[3] and ctx.needs_input_grad[1] and rgcn_bwd_side(gidx.num_edges, max(x.shape[1], g.shape[1]))
         if side_w:
             with backward_side(True, x, g, g_agg, weight, coef, rgcn=True):
-                gemm(x, g, trans_a=True, split_k=pick_split_k(x.shape[1], g.shape[1], x.shape[0]), out=d_l, accumulate=True)
+                gw_first = rgcn_side_gradw_first(gidx.num_edges, x.shape[1])
+                if not gw_first:
+                    gemm(x, g, trans_a=True, split_k=pick_split_k(x.shape[1], g.shape[1], x.shape[0]), out=d_l, accumulate=True)
                 static = not gidx.sync_free and coef is not None
                 coef_r, idx_r = (ridx.coef_in_rel_order(coef), None) if static else (coef, ridx.by_rel.perm)
                 bdd_grad_weight(ridx.by_rel.seg, ridx.src_by_rel, ridx.dst_by_rel, coef_r, idx_r, x, g_agg, nb, si, so, out=d_w, accumulate=True)
+                if gw_first:
+                    gemm(x, g, trans_a=True, split_k=pick_split_k(x.shape[1], g.shape[1], x.shape[0]), out=d_l, accumulate=True)
         if loop_weight is not None:
             if ctx.needs_input_grad[3] and not side_w:
                 # (on this stream, NOT ordered behind the side stream: d_l / d_w are this layer's own arena slices, which no
